@@ -1,0 +1,174 @@
+"""ctypes mirror of include/grut_amd.h and the loader of the HIP shared library.
+
+The library is the product: there is no CPU fallback.  `load_library()` raises if
+`libgrut_amd.so` has not been built (run `python -c "import __graft_entry__ as g; g.build()"`
+or `python -m 3dgrut_amd.build` equivalent, see build.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+ABI_VERSION = 1
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgrut_amd.so")
+
+# ---- enums (include/grut_amd.h) -------------------------------------------------
+SHUTTER_ROLLING_TOP_TO_BOTTOM, SHUTTER_ROLLING_LEFT_TO_RIGHT, SHUTTER_ROLLING_BOTTOM_TO_TOP, \
+    SHUTTER_ROLLING_RIGHT_TO_LEFT, SHUTTER_GLOBAL = range(5)
+CAMERA_OPENCV_PINHOLE, CAMERA_OPENCV_FISHEYE, CAMERA_FTHETA = range(3)
+FTHETA_PIXELDIST_TO_ANGLE, FTHETA_ANGLE_TO_PIXELDIST = range(2)
+
+GRUT_OK = 0
+STATUS_NAMES = {0: "OK", -1: "BAD_INPUT", -2: "RUNTIME", -3: "NOT_READY", -4: "UNSUPPORTED"}
+
+
+class GrutCamera(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("shutter", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+        ("principal_point", C.c_float * 2), ("focal_length", C.c_float * 2),
+        ("radial", C.c_float * 6), ("tangential", C.c_float * 2), ("thin_prism", C.c_float * 4),
+        ("max_angle", C.c_float), ("ftheta_reference_poly", C.c_int32),
+        ("ftheta_pixeldist_to_angle", C.c_float * 6), ("ftheta_angle_to_pixeldist", C.c_float * 6),
+        ("ftheta_linear_cde", C.c_float * 3),
+    ]
+
+
+class GutConfig(C.Structure):
+    _fields_ = [
+        ("particle_kernel_degree", C.c_int32), ("particle_kernel_min_response", C.c_float),
+        ("particle_kernel_min_alpha", C.c_float), ("particle_kernel_max_alpha", C.c_float),
+        ("min_transmittance", C.c_float), ("particle_radiance_sph_degree", C.c_int32),
+        ("enable_hitcounts", C.c_int32), ("enable_kernel_timings", C.c_int32),
+        ("ut_alpha", C.c_float), ("ut_beta", C.c_float), ("ut_kappa", C.c_float),
+        ("ut_in_image_margin_factor", C.c_float), ("ut_require_all_sigma_points_valid", C.c_int32),
+        ("n_rolling_shutter_iterations", C.c_int32), ("k_buffer_size", C.c_int32),
+        ("global_z_order", C.c_int32), ("rect_bounding", C.c_int32),
+        ("tight_opacity_bounding", C.c_int32), ("tile_based_culling", C.c_int32),
+    ]
+
+
+class GutFrame(C.Structure):
+    _fields_ = [
+        ("frame_id", C.c_uint32), ("n_active_features", C.c_int32), ("num_particles", C.c_uint32),
+        ("width", C.c_int32), ("height", C.c_int32), ("camera", GrutCamera),
+        ("pose_start", C.c_float * 7), ("pose_end", C.c_float * 7),
+    ]
+
+
+class GutStats(C.Structure):
+    _fields_ = [
+        ("num_particles", C.c_uint32), ("num_visible", C.c_uint32), ("num_intersections", C.c_uint64),
+        ("num_tiles", C.c_uint32), ("key_bits", C.c_uint32),
+    ]
+
+
+class GrtConfig(C.Structure):
+    _fields_ = [
+        ("particle_kernel_degree", C.c_int32), ("particle_kernel_min_response", C.c_float),
+        ("particle_kernel_min_alpha", C.c_float), ("particle_kernel_max_alpha", C.c_float),
+        ("particle_kernel_density_clamping", C.c_int32), ("particle_radiance_sph_degree", C.c_int32),
+        ("enable_normals", C.c_int32), ("enable_hitcounts", C.c_int32), ("enable_kernel_timings", C.c_int32),
+        ("max_hits_per_trace", C.c_int32),
+    ]
+
+
+class GrtFrame(C.Structure):
+    _fields_ = [
+        ("frame_id", C.c_uint32), ("sph_degree", C.c_int32), ("min_transmittance", C.c_float),
+        ("num_particles", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
+        ("ray_to_world", C.c_float * 12),
+    ]
+
+
+class GrtStats(C.Structure):
+    _fields_ = [
+        ("num_particles", C.c_uint32), ("num_nodes", C.c_uint32), ("nodes_visited", C.c_uint64),
+        ("candidates", C.c_uint64), ("processed_hits", C.c_uint64), ("scene_aabb", C.c_float * 6),
+    ]
+
+
+# every symbol include/grut_amd.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = [
+    "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_timings", "gut_stats",
+    "gut_debug_fetch", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
+    "grut_scan_scratch_bytes",
+    "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats",
+    "grut_last_error", "grut_abi_version",
+]
+
+_lib = None
+
+
+def _declare(lib):
+    vp, fp, ip, up = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p  # device pointers travel as integers
+    lib.gut_create.argtypes = [C.POINTER(GutConfig), C.POINTER(C.c_void_p)]
+    lib.gut_create.restype = C.c_int
+    lib.gut_destroy.argtypes = [C.c_void_p]
+    lib.gut_destroy.restype = None
+    lib.gut_forward.argtypes = [C.c_void_p, vp, C.POINTER(GutFrame), fp, fp, fp, fp, fp, fp, fp, ip]
+    lib.gut_forward.restype = C.c_int
+    lib.gut_backward.argtypes = [C.c_void_p, vp, C.POINTER(GutFrame)] + [fp] * 10
+    lib.gut_backward.restype = C.c_int
+    lib.gut_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.gut_timings.restype = C.c_int
+    lib.gut_stats.argtypes = [C.c_void_p, C.POINTER(GutStats)]
+    lib.gut_stats.restype = C.c_int
+    lib.gut_debug_fetch.argtypes = [C.c_void_p, vp] + [up] * 8
+    lib.gut_debug_fetch.restype = C.c_int
+    lib.grut_sort_pairs_u32.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, up, up, up, up, vp, C.c_uint64,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.grut_sort_pairs_u32.restype = C.c_int
+    lib.grut_sort_scratch_bytes.argtypes = [C.c_uint32]
+    lib.grut_sort_scratch_bytes.restype = C.c_uint64
+    lib.grut_inclusive_scan_u32.argtypes = [vp, C.c_uint32, up, up, vp, C.c_uint64]
+    lib.grut_inclusive_scan_u32.restype = C.c_int
+    lib.grut_scan_scratch_bytes.argtypes = [C.c_uint32]
+    lib.grut_scan_scratch_bytes.restype = C.c_uint64
+    lib.grt_create.argtypes = [C.POINTER(GrtConfig), C.POINTER(C.c_void_p)]
+    lib.grt_create.restype = C.c_int
+    lib.grt_destroy.argtypes = [C.c_void_p]
+    lib.grt_destroy.restype = None
+    lib.grt_build_bvh.argtypes = [C.c_void_p, vp, C.c_uint32, fp, fp, fp, fp, C.c_int, C.c_int]
+    lib.grt_build_bvh.restype = C.c_int
+    lib.grt_forward.argtypes = [C.c_void_p, vp, C.POINTER(GrtFrame)] + [fp] * 9 + [ip]
+    lib.grt_forward.restype = C.c_int
+    lib.grt_backward.argtypes = [C.c_void_p, vp, C.POINTER(GrtFrame)] + [fp] * 14
+    lib.grt_backward.restype = C.c_int
+    lib.grt_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.grt_timings.restype = C.c_int
+    lib.grt_stats.argtypes = [C.c_void_p, C.POINTER(GrtStats)]
+    lib.grt_stats.restype = C.c_int
+    lib.grut_last_error.argtypes = []
+    lib.grut_last_error.restype = C.c_char_p
+    lib.grut_abi_version.argtypes = []
+    lib.grut_abi_version.restype = C.c_int
+
+
+def load_library(path: str | None = None):
+    """Load libgrut_amd.so (built in-tree by build.py).  Fails loudly if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or os.environ.get("GRUT_AMD_LIB", LIB_PATH)
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"3dgrut_amd: HIP library not found at {p}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, --offload-arch=gfx950). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(p)
+    _declare(lib)
+    ver = lib.grut_abi_version()
+    if ver != ABI_VERSION:
+        raise RuntimeError(f"3dgrut_amd: ABI mismatch, library {ver} vs python {ABI_VERSION}; rebuild")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != GRUT_OK:
+        lib = load_library()
+        msg = lib.grut_last_error()
+        raise RuntimeError(f"3dgrut_amd: {what} failed with {STATUS_NAMES.get(status, status)}: "
+                           f"{msg.decode() if msg else ''}")

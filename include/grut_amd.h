@@ -1,0 +1,239 @@
+/*
+ * grut_amd.h — C-ABI of the MI355X-native 3DGUT / 3DGRT renderer plugin.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no
+ * torch types.  Every entry point replaces one method of the reference's
+ * pybind11 classes (citations are into /root/reference):
+ *
+ *   gut_create / gut_destroy   <- SplatRaster(json)            threedgut_tracer/bindings.cpp:103-109,
+ *                                                              src/splatRaster.cpp:163-181
+ *   gut_forward                <- SplatRaster::trace            include/3dgut/splatRaster.h:47-63,
+ *                                                              src/splatRaster.cpp:184-261
+ *   gut_backward               <- SplatRaster::trace_bwd        include/3dgut/splatRaster.h:65-86,
+ *                                                              src/splatRaster.cpp:264-350
+ *   gut_timings                <- SplatRaster::collect_times    src/splatRaster.cpp:352-382
+ *   grt_create / grt_destroy   <- OptixTracer(...)              threedgrt_tracer/include/3dgrt/optixTracer.h:128-147
+ *   grt_build_bvh              <- OptixTracer::build_bvh        optixTracer.h:149-155, src/optixTracer.cpp:616-890
+ *   grt_forward                <- OptixTracer::trace            optixTracer.h:157-166, src/optixTracer.cpp:893-960
+ *   grt_backward               <- OptixTracer::trace_bwd        optixTracer.h:168-177, src/optixTracer.cpp:962-1031
+ *
+ * Ownership: every I/O buffer is allocated by the caller (PyTorch) on the GPU
+ * the handle was created on; a handle owns only grow-only scratch (and, for
+ * 3DGRT, the BVH).  All work is enqueued on the hipStream_t passed in; the
+ * backward of a frame must be enqueued on the same stream as its forward
+ * (same rule as gutRenderer.cu:436-440).  Functions return 0 on success and a
+ * negative GrutStatus otherwise; nothing throws across this boundary.
+ */
+#ifndef GRUT_AMD_H
+#define GRUT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (mirrors ErrorCode, 3dgut/utils/status.h:22-29) -------- */
+typedef enum GrutStatus {
+    GRUT_OK              = 0,
+    GRUT_ERR_BAD_INPUT   = -1,
+    GRUT_ERR_RUNTIME     = -2, /* a HIP call failed; see grut_last_error() */
+    GRUT_ERR_NOT_READY   = -3, /* backward without a matching forward / BVH not built */
+    GRUT_ERR_UNSUPPORTED = -4
+} GrutStatus;
+
+/* ---- camera model (sensors/cameraModels.h:22-72) ------------------------- */
+enum { GRUT_SHUTTER_ROLLING_TOP_TO_BOTTOM = 0,
+       GRUT_SHUTTER_ROLLING_LEFT_TO_RIGHT = 1,
+       GRUT_SHUTTER_ROLLING_BOTTOM_TO_TOP = 2,
+       GRUT_SHUTTER_ROLLING_RIGHT_TO_LEFT = 3,
+       GRUT_SHUTTER_GLOBAL                = 4 };
+
+enum { GRUT_CAMERA_OPENCV_PINHOLE = 0,
+       GRUT_CAMERA_OPENCV_FISHEYE = 1,
+       GRUT_CAMERA_FTHETA         = 2 };
+
+enum { GRUT_FTHETA_PIXELDIST_TO_ANGLE = 0,
+       GRUT_FTHETA_ANGLE_TO_PIXELDIST = 1 };
+
+typedef struct GrutCamera {
+    int32_t model;              /* GRUT_CAMERA_*  */
+    int32_t shutter;            /* GRUT_SHUTTER_* */
+    int32_t width, height;      /* resolution of the ray image */
+    float principal_point[2];
+    float focal_length[2];      /* pinhole + fisheye */
+    float radial[6];            /* pinhole: k1..k6; fisheye: k1..k4 */
+    float tangential[2];        /* pinhole */
+    float thin_prism[4];        /* pinhole */
+    float max_angle;            /* fisheye + ftheta */
+    int32_t ftheta_reference_poly;
+    float ftheta_pixeldist_to_angle[6];
+    float ftheta_angle_to_pixeldist[6];
+    float ftheta_linear_cde[3];
+} GrutCamera;
+
+/* ---- 3DGUT ---------------------------------------------------------------- */
+/* Mirrors the conf.render.* keys setup_3dgut.py:41-95 turns into -D macros.   */
+typedef struct GutConfig {
+    int32_t particle_kernel_degree;      /* 2 (default 3dgut.yaml) | 4 | 3 | 5 | 8 | 1 | 0 */
+    float   particle_kernel_min_response;/* 0.0113 */
+    float   particle_kernel_min_alpha;   /* 1/255  */
+    float   particle_kernel_max_alpha;   /* 0.99   */
+    float   min_transmittance;           /* 1e-4   */
+    int32_t particle_radiance_sph_degree;/* max degree of the SH buffer: 3 -> 16 coeffs */
+    int32_t enable_hitcounts;
+    int32_t enable_kernel_timings;
+    /* render.splat.* */
+    float   ut_alpha, ut_beta, ut_kappa; /* 1, 2, 0 */
+    float   ut_in_image_margin_factor;   /* 0.1 */
+    int32_t ut_require_all_sigma_points_valid; /* must be 0 (threedgut.cuh:78) */
+    int32_t n_rolling_shutter_iterations;/* 5 */
+    int32_t k_buffer_size;               /* 0 = unsorted compositing */
+    int32_t global_z_order;              /* 1 */
+    int32_t rect_bounding;               /* 1 */
+    int32_t tight_opacity_bounding;      /* 1 */
+    int32_t tile_based_culling;          /* 1 */
+} GutConfig;
+
+/* Per-call frame description: SplatRaster::trace's non-tensor arguments. */
+typedef struct GutFrame {
+    uint32_t   frame_id;
+    int32_t    n_active_features;  /* active SH degree (model.n_active_features) */
+    uint32_t   num_particles;
+    int32_t    width, height;      /* rays are [height, width, 3] */
+    GrutCamera camera;
+    float      pose_start[7];      /* world->sensor, [t(3), q(x,y,z,w)] (tracer.py:359-380) */
+    float      pose_end[7];
+} GutFrame;
+
+/* Measured work of the last forward (for the roofline byte model). */
+typedef struct GutStats {
+    uint32_t num_particles;      /* N  */
+    uint32_t num_visible;        /* Nv: particles with >=1 tile */
+    uint64_t num_intersections;  /* I  */
+    uint32_t num_tiles;
+    uint32_t key_bits;           /* bits of the tile part of the sort key */
+} GutStats;
+
+typedef struct GutHandle GutHandle;
+
+int  gut_create(const GutConfig* config, GutHandle** handle);
+void gut_destroy(GutHandle* handle);
+
+/*  particle_density : [N,12] f32  {pos.xyz, density, quat.wxyz, scale.xyz, pad}
+ *  particle_sph     : [N, 3*(deg+1)^2] f32, coefficient-major float3
+ *  ray_origin/dir   : [H,W,3] f32, in sensor space (transformed by the inverse mid-exposure pose)
+ *  out_feat_density : [H,W,4] f32  (rgb, 1-T)          must arrive zero-filled
+ *  out_hit_distance : [H,W,1] f32                      must arrive filled with 1e6 (splatRaster.cpp:213)
+ *  out_hit_count    : [H,W,1] f32                      must arrive zero-filled
+ *  out_visibility   : [N]     i32 (bit pattern read by the caller as float, splatRaster.cpp:215)  */
+int gut_forward(GutHandle* handle, void* stream, const GutFrame* frame,
+                const float* particle_density, const float* particle_sph,
+                const float* ray_origin, const float* ray_direction,
+                float* out_feat_density, float* out_hit_distance,
+                float* out_hit_count, int32_t* out_visibility);
+
+/*  grad_particle_density : [N,12] f32, must arrive zero-filled (accumulated with atomics)
+ *  grad_particle_sph     : [N, 3*(deg+1)^2] f32, fully overwritten (no zero-fill needed) */
+int gut_backward(GutHandle* handle, void* stream, const GutFrame* frame,
+                 const float* particle_density, const float* particle_sph,
+                 const float* ray_origin, const float* ray_direction,
+                 const float* feat_density, const float* grad_feat_density,
+                 const float* hit_distance, const float* grad_hit_distance,
+                 float* grad_particle_density, float* grad_particle_sph);
+
+/* average ms of the forward / backward launches since the last call (-1 if none). Synchronises. */
+int gut_timings(GutHandle* handle, float* forward_ms, float* backward_ms);
+int gut_stats(GutHandle* handle, GutStats* stats);
+
+/* ---- stage-level entry points (parity tests drive each stage alone) ------ */
+/* Stable LSD radix sort of (key,value) pairs on key bits [begin_bit,end_bit). tmp buffers sized n. */
+int grut_sort_pairs_u32(void* stream, uint32_t n, int begin_bit, int end_bit,
+                        uint32_t* keys, uint32_t* values,
+                        uint32_t* keys_tmp, uint32_t* values_tmp,
+                        void* scratch, uint64_t scratch_bytes,
+                        uint32_t** sorted_keys, uint32_t** sorted_values);
+uint64_t grut_sort_scratch_bytes(uint32_t n);
+/* inclusive prefix sum of n u32 (cub::DeviceScan::InclusiveSum, gutRenderer.cu:302-310) */
+int grut_inclusive_scan_u32(void* stream, uint32_t n, const uint32_t* in, uint32_t* out,
+                            void* scratch, uint64_t scratch_bytes);
+uint64_t grut_scan_scratch_bytes(uint32_t n);
+
+/* Copies the binning products of the last gut_forward to caller DEVICE buffers (any may be NULL):
+ * tiles_count[N] u32, proj_pos[N,2], conic_opacity[N,4], extent[N,2], depth[N], rgb[N,3],
+ * sorted_particle_idx[I] u32, tile_ranges[tiles,2] u32. */
+int gut_debug_fetch(GutHandle* handle, void* stream,
+                    uint32_t* tiles_count, float* proj_pos, float* conic_opacity, float* extent,
+                    float* depth, float* rgb, uint32_t* sorted_particle_idx, uint32_t* tile_ranges);
+
+/* ---- 3DGRT ----------------------------------------------------------------- */
+typedef struct GrtConfig {
+    int32_t particle_kernel_degree;        /* 4 (3dgrt.yaml) */
+    float   particle_kernel_min_response;  /* 0.0113 */
+    float   particle_kernel_min_alpha;     /* 1/255 */
+    float   particle_kernel_max_alpha;     /* 0.99 */
+    int32_t particle_kernel_density_clamping; /* 1 */
+    int32_t particle_radiance_sph_degree;  /* 3 */
+    int32_t enable_normals;
+    int32_t enable_hitcounts;
+    int32_t enable_kernel_timings;
+    int32_t max_hits_per_trace;            /* 16 (pipelineParameters.h:83) */
+} GrtConfig;
+
+typedef struct GrtFrame {
+    uint32_t frame_id;
+    int32_t  sph_degree;          /* active SH degree */
+    float    min_transmittance;
+    uint32_t num_particles;
+    int32_t  width, height;
+    float    ray_to_world[12];    /* row-major 3x4 */
+} GrtFrame;
+
+typedef struct GrtStats {
+    uint32_t num_particles;
+    uint32_t num_nodes;
+    uint64_t nodes_visited;     /* only in instrumented launches */
+    uint64_t candidates;
+    uint64_t processed_hits;
+    float    scene_aabb[6];
+} GrtStats;
+
+typedef struct GrtHandle GrtHandle;
+
+int  grt_create(const GrtConfig* config, GrtHandle** handle);
+void grt_destroy(GrtHandle* handle);
+
+/* positions[N,3], rotations[N,4] wxyz normalised, scales[N,3], densities[N] — activated values */
+int grt_build_bvh(GrtHandle* handle, void* stream, uint32_t num_particles,
+                  const float* positions, const float* rotations,
+                  const float* scales, const float* densities,
+                  int rebuild, int allow_update);
+
+/*  out_features [H,W,3], out_density [H,W,1], out_hit_distance [H,W,2] (integrated depth, last hit t),
+ *  out_normals [H,W,3], out_hits_count [H,W,1], out_visibility [N] i32 — all must arrive zero-filled */
+int grt_forward(GrtHandle* handle, void* stream, const GrtFrame* frame,
+                const float* particle_density, const float* particle_sph,
+                const float* ray_origin, const float* ray_direction,
+                float* out_features, float* out_density, float* out_hit_distance,
+                float* out_normals, float* out_hits_count, int32_t* out_visibility);
+
+int grt_backward(GrtHandle* handle, void* stream, const GrtFrame* frame,
+                 const float* particle_density, const float* particle_sph,
+                 const float* ray_origin, const float* ray_direction,
+                 const float* features, const float* density, const float* hit_distance, const float* normals,
+                 const float* grad_features, const float* grad_density,
+                 const float* grad_hit_distance, const float* grad_normals,
+                 float* grad_particle_density, float* grad_particle_sph);
+
+int grt_timings(GrtHandle* handle, float* forward_ms, float* backward_ms, float* build_ms);
+int grt_stats(GrtHandle* handle, GrtStats* stats);
+
+/* human-readable text of the last error raised on the calling thread */
+const char* grut_last_error(void);
+/* ABI version; bumped whenever a struct above changes */
+int grut_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRUT_AMD_H */

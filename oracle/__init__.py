@@ -1,0 +1,153 @@
+"""CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+numpy-facing wrapper of oracle/gut_oracle.c and oracle/grt_oracle.c, the CPU restatement of the
+reference's 3DGUT / 3DGRT algorithms.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this package — the product package (3dgrut_amd) never does, and has
+no CPU fallback.
+
+Two flavours are built by `make -C oracle`: liboracle32.so (float, mirrors the arithmetic type of
+the reference) and liboracle64.so (double, for finite-difference gradient checks).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import importlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_abi = importlib.import_module("3dgrut_amd._abi")  # struct mirrors of include/grut_amd.h only
+GutConfig, GrutCamera, GrtConfig = _abi.GutConfig, _abi.GrutCamera, _abi.GrtConfig
+
+_libs = {}
+
+
+def build(force: bool = False):
+    """Compile the oracle with gcc (seconds)."""
+    out = os.path.join(_HERE, "_build", "liboracle32.so")
+    if force or not os.path.exists(out) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(out)
+            for f in ("gut_oracle.c", "grt_oracle.c", "orc_math.h")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"] if force else ["make", "-C", _HERE, "-s"])
+
+
+def lib(dtype=np.float32):
+    key = np.dtype(dtype).itemsize
+    if key not in _libs:
+        build()
+        name = "liboracle32.so" if key == 4 else "liboracle64.so"
+        l = C.CDLL(os.path.join(_HERE, "_build", name))
+        assert l.orc_sizeof_real() == key
+        l.orc_gut_bin.restype = C.c_uint64
+        l.orc_higher_msb.restype = C.c_uint32
+        _libs[key] = l
+    return _libs[key]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def default_gut_config(**kw) -> GutConfig:
+    """configs/render/3dgut.yaml + configs/render/3dgrt.yaml defaults (reference)."""
+    cfg = GutConfig(
+        particle_kernel_degree=2, particle_kernel_min_response=0.0113, particle_kernel_min_alpha=1.0 / 255.0,
+        particle_kernel_max_alpha=0.99, min_transmittance=0.0001, particle_radiance_sph_degree=3,
+        enable_hitcounts=1, enable_kernel_timings=0, ut_alpha=1.0, ut_beta=2.0, ut_kappa=0.0,
+        ut_in_image_margin_factor=0.1, ut_require_all_sigma_points_valid=0, n_rolling_shutter_iterations=5,
+        k_buffer_size=0, global_z_order=1, rect_bounding=1, tight_opacity_bounding=1, tile_based_culling=1)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def default_grt_config(**kw) -> GrtConfig:
+    cfg = GrtConfig(
+        particle_kernel_degree=4, particle_kernel_min_response=0.0113, particle_kernel_min_alpha=1.0 / 255.0,
+        particle_kernel_max_alpha=0.99, particle_kernel_density_clamping=1, particle_radiance_sph_degree=3,
+        enable_normals=0, enable_hitcounts=1, enable_kernel_timings=0, max_hits_per_trace=16)
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+# ------------------------------------------------------------------------------------------
+# 3DGUT
+# ------------------------------------------------------------------------------------------
+def gut_project(cfg, cam, pose_start, pose_end, n_active, density12, sph, dtype=np.float32):
+    l = lib(dtype)
+    d12, s = _c(density12, dtype), _c(sph, dtype)
+    N = d12.shape[0]
+    ps, pe = _c(pose_start, dtype), _c(pose_end, dtype)
+    out = dict(
+        tiles_count=np.zeros(N, np.uint32), proj_pos=np.zeros((N, 2), dtype), conic_opacity=np.zeros((N, 4), dtype),
+        extent=np.zeros((N, 2), dtype), depth=np.zeros(N, dtype), rgb=np.zeros((N, 3), dtype),
+        visibility=np.zeros(N, np.int32))
+    l.orc_gut_project(C.byref(cfg), C.byref(cam), _p(ps), _p(pe), C.c_uint32(N), C.c_int(n_active), _p(d12), _p(s),
+                      _p(out["tiles_count"]), _p(out["proj_pos"]), _p(out["conic_opacity"]), _p(out["extent"]),
+                      _p(out["depth"]), _p(out["rgb"]), _p(out["visibility"]))
+    return out
+
+
+def gut_bin(cfg, width, height, proj, dtype=np.float32):
+    l = lib(dtype)
+    N = proj["tiles_count"].shape[0]
+    args = (C.byref(cfg), C.c_int(width), C.c_int(height), C.c_uint32(N), _p(proj["tiles_count"]),
+            _p(proj["proj_pos"]), _p(proj["conic_opacity"]), _p(proj["extent"]), _p(proj["depth"]))
+    total = int(l.orc_gut_bin(*args, None, None, None))
+    tiles = ((width + 15) // 16) * ((height + 15) // 16)
+    keys = np.zeros(max(total, 1), np.uint64)
+    idx = np.zeros(max(total, 1), np.uint32)
+    ranges = np.zeros((tiles, 2), np.uint32)
+    if total:
+        l.orc_gut_bin(*args, _p(keys), _p(idx), _p(ranges))
+    return dict(num_intersections=total, sorted_keys=keys[:total], sorted_idx=idx[:total], tile_ranges=ranges)
+
+
+def gut_forward(cfg, cam, pose_start, pose_end, n_active, density12, sph, ray_o, ray_d, dtype=np.float32):
+    """Full reference forward (SplatRaster::trace semantics incl. output initial values)."""
+    l = lib(dtype)
+    H, W = cam.height, cam.width
+    proj = gut_project(cfg, cam, pose_start, pose_end, n_active, density12, sph, dtype)
+    bins = gut_bin(cfg, W, H, proj, dtype)
+    fd = np.zeros((H, W, 4), dtype)
+    dist = np.full((H, W, 1), 1e6, dtype)
+    cnt = np.zeros((H, W, 1), dtype)
+    ro, rd = _c(ray_o, dtype).reshape(H, W, 3), _c(ray_d, dtype).reshape(H, W, 3)
+    d12 = _c(density12, dtype)
+    ps, pe = _c(pose_start, dtype), _c(pose_end, dtype)
+    if bins["num_intersections"] > 0:  # gutRenderer.cu:323-325 early return
+        r = l.orc_gut_render_fwd(C.byref(cfg), C.c_int(W), C.c_int(H), _p(ps), _p(pe), _p(d12), _p(proj["rgb"]),
+                                 _p(bins["sorted_idx"]), _p(bins["tile_ranges"]), _p(ro), _p(rd),
+                                 _p(fd), _p(dist), _p(cnt))
+        assert r == 0
+    return dict(feat_density=fd, hit_distance=dist, hit_count=cnt, visibility=proj["visibility"],
+                proj=proj, bins=bins, rays=(ro, rd), density12=d12, sph=_c(sph, dtype), poses=(ps, pe))
+
+
+def gut_backward(cfg, cam, n_active, fwd, g_feat_density, g_hit_distance, dtype=np.float32):
+    """Reference backward (SplatRaster::trace_bwd): returns (grad_density12 [N,12], grad_sph [N,3*ncoef])."""
+    l = lib(dtype)
+    H, W = cam.height, cam.width
+    d12, sph = fwd["density12"], fwd["sph"]
+    N = d12.shape[0]
+    ps, pe = fwd["poses"]
+    ro, rd = fwd["rays"]
+    gd = np.zeros((N, 12), dtype)
+    grgb = np.zeros((N, 3), dtype)
+    gsph = np.zeros_like(sph)
+    gfd, gdist = _c(g_feat_density, dtype), _c(g_hit_distance, dtype)
+    if fwd["bins"]["num_intersections"] > 0:
+        r = l.orc_gut_render_bwd(C.byref(cfg), C.c_int(W), C.c_int(H), _p(ps), _p(pe), _p(d12), _p(fwd["proj"]["rgb"]),
+                                 _p(fwd["bins"]["sorted_idx"]), _p(fwd["bins"]["tile_ranges"]), _p(ro), _p(rd),
+                                 _p(fwd["feat_density"]), _p(gfd), _p(fwd["hit_distance"]), _p(gdist), _p(gd), _p(grgb))
+        assert r == 0
+    l.orc_gut_project_bwd(C.byref(cfg), _p(ps), _p(pe), C.c_uint32(N), C.c_int(n_active),
+                          _p(fwd["proj"]["tiles_count"]), _p(d12), _p(sph), _p(grgb), _p(gd), _p(gsph))
+    return gd, gsph, grgb
