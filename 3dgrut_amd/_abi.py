@@ -19,6 +19,8 @@ SHUTTER_ROLLING_TOP_TO_BOTTOM, SHUTTER_ROLLING_LEFT_TO_RIGHT, SHUTTER_ROLLING_BO
 CAMERA_OPENCV_PINHOLE, CAMERA_OPENCV_FISHEYE, CAMERA_FTHETA = range(3)
 FTHETA_PIXELDIST_TO_ANGLE, FTHETA_ANGLE_TO_PIXELDIST = range(2)
 
+GUT_STAGES = ["project", "depth_sort", "scan", "expand", "tile_sort", "tile_ranges", "render_fwd", "render_bwd", "project_bwd"]
+
 GRUT_OK = 0
 STATUS_NAMES = {0: "OK", -1: "BAD_INPUT", -2: "RUNTIME", -3: "NOT_READY", -4: "UNSUPPORTED"}
 
@@ -91,6 +93,7 @@ class GrtStats(C.Structure):
 # every symbol include/grut_amd.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
     "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_timings", "gut_stats",
+    "gut_profile_enable", "gut_profile_read",
     "gut_debug_fetch", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats",
@@ -114,6 +117,10 @@ def _declare(lib):
     lib.gut_timings.restype = C.c_int
     lib.gut_stats.argtypes = [C.c_void_p, C.POINTER(GutStats)]
     lib.gut_stats.restype = C.c_int
+    lib.gut_profile_enable.argtypes = [C.c_void_p, C.c_int]
+    lib.gut_profile_enable.restype = C.c_int
+    lib.gut_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.gut_profile_read.restype = C.c_int
     lib.gut_debug_fetch.argtypes = [C.c_void_p, vp] + [up] * 8
     lib.gut_debug_fetch.restype = C.c_int
     lib.grut_sort_pairs_u32.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, up, up, up, up, vp, C.c_uint64,

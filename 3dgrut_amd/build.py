@@ -1,0 +1,73 @@
+"""In-tree build of libgrut_amd.so with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python 3dgrut_amd/build.py [--force] [--verbose]
+
+One object per .hip file, rebuilt only when its sources are newer; linked into csrc/libgrut_amd.so,
+which travels to the GPU box with the repository snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(CSRC, "libgrut_amd.so")
+SOURCES = ["scan_sort.hip", "gut_kernels.hip", "gut_api.hip", "grt_api.hip"]
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + \
+           [os.path.join(HERE, "..", "include", "grut_amd.h")]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    hipcc = _hipcc()
+    deps = _deps()
+    objs, jobs = [], []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        op = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or _stale(op, [sp] + deps):
+            jobs.append([hipcc, "-x", "hip", *FLAGS, *extra_flags, "-c", sp, "-o", op])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr:
+            print(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if force or jobs or _stale(OUT, objs):
+        run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", OUT])
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv))

@@ -1,0 +1,214 @@
+// common.hpp — shared host/device utilities of libgrut_amd (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/grut_amd.h"
+
+#define GRUT_ABI_VERSION 1
+#define GRUT_WAVE 64
+
+namespace grut {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_last_error(const char* fmt, ...);
+
+#define GRUT_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            grut::set_last_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return GRUT_ERR_RUNTIME;                                                            \
+        }                                                                                       \
+    } while (0)
+
+#define GRUT_CHECK(expr)                       \
+    do {                                       \
+        int _s = (expr);                       \
+        if (_s != GRUT_OK) return _s;          \
+    } while (0)
+
+#define GRUT_REQUIRE(cond, ...)                \
+    do {                                       \
+        if (!(cond)) {                         \
+            grut::set_last_error(__VA_ARGS__); \
+            return GRUT_ERR_BAD_INPUT;         \
+        }                                      \
+    } while (0)
+
+// ---- grow-only device scratch (the role of CudaBuffer::enlarge, src/cudaBuffer.cpp:44-60) ---
+struct DeviceBuffer {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need, float growth = 1.0f) {
+        if (need <= bytes) return GRUT_OK;
+        size_t n = (size_t)((double)need * growth);
+        n = (n + 255) & ~(size_t)255;
+        if (ptr) GRUT_HIP(hipFree(ptr));
+        ptr = nullptr;
+        bytes = 0;
+        GRUT_HIP(hipMalloc(&ptr, n));
+        bytes = n;
+        return GRUT_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+
+inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// ---- hipEvent ring for Tracer.timings (splatRaster.cpp:118-161) -----------------------------
+struct EventTimer {
+    static constexpr int kRing = 256;
+    hipEvent_t start[kRing], stop[kRing];
+    int count = 0, created = 0;
+    int begin(hipStream_t s) {
+        int i = count % kRing;
+        if (i >= created) {
+            GRUT_HIP(hipEventCreate(&start[i]));
+            GRUT_HIP(hipEventCreate(&stop[i]));
+            created = i + 1;
+        }
+        GRUT_HIP(hipEventRecord(start[i], s));
+        return GRUT_OK;
+    }
+    int end(hipStream_t s) {
+        int i = count % kRing;
+        GRUT_HIP(hipEventRecord(stop[i], s));
+        count++;
+        return GRUT_OK;
+    }
+    // average ms since the last collect (-1 if none); synchronises on the last event
+    float collect() {
+        int n = count < kRing ? count : kRing;
+        if (n == 0) return -1.f;
+        double sum = 0;
+        for (int i = 0; i < n; ++i) {
+            float ms = 0;
+            (void)hipEventSynchronize(stop[i]);
+            (void)hipEventElapsedTime(&ms, start[i], stop[i]);
+            sum += ms;
+        }
+        count = 0;
+        return (float)(sum / n);
+    }
+    void destroy() {
+        for (int i = 0; i < created; ++i) {
+            (void)hipEventDestroy(start[i]);
+            (void)hipEventDestroy(stop[i]);
+        }
+        created = 0;
+    }
+};
+
+// ---- scan / sort primitives (scan_sort.hip) -------------------------------------------------
+// inclusive scan of n u32; if gather != nullptr the input element i is in[gather[i]].
+size_t scan_scratch_bytes(uint32_t n);
+int inclusive_scan_u32(hipStream_t s, uint32_t n, const uint32_t* in, const uint32_t* gather, uint32_t* out,
+                       void* scratch, size_t scratch_bytes);
+// stable LSD radix sort on key bits [begin_bit, end_bit); ping-pongs between (keys,vals) and (keys_tmp,vals_tmp),
+// *out_keys/*out_vals receive the buffers holding the sorted result.  `n_dev` (optional) points to the element
+// count in device memory (<= n); blocks beyond it exit early, so `n` may be a capacity bound.
+size_t sort_scratch_bytes(uint32_t n);
+int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_bit, int end_bit,
+                   uint32_t* keys, uint32_t* vals, uint32_t* keys_tmp, uint32_t* vals_tmp,
+                   void* scratch, size_t scratch_bytes, uint32_t** out_keys, uint32_t** out_vals);
+
+}  // namespace grut
+
+// ---- device math ----------------------------------------------------------------------------
+#ifdef __HIPCC__
+namespace grut {
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+    return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+// rows of a 3x3
+struct m3 {
+    f3 r0, r1, r2;
+};
+__device__ __forceinline__ f3 mul_rows(const m3& m, f3 p) { return f3{dot(m.r0, p), dot(m.r1, p), dot(m.r2, p)}; }
+// m^T * g (matmul_bw_vec, mathUtils.cuh:451-456)
+__device__ __forceinline__ f3 mul_cols(const m3& m, f3 g) {
+    return f3{g.x * m.r0.x + g.y * m.r1.x + g.z * m.r2.x, g.x * m.r0.y + g.y * m.r1.y + g.z * m.r2.y,
+              g.x * m.r0.z + g.y * m.r1.z + g.z * m.r2.z};
+}
+// rows of R^T from a (w,x,y,z) quaternion (models/gaussianParticles.cuh:39-59)
+__device__ __forceinline__ m3 quat_wxyz_to_rotT(float r, float x, float y, float z) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+    const float rx = r * x, ry = r * y, rz = r * z;
+    m3 m;
+    m.r0 = f3{1.f - 2.f * (yy + zz), 2.f * (xy + rz), 2.f * (xz - ry)};
+    m.r1 = f3{2.f * (xy - rz), 1.f - 2.f * (xx + zz), 2.f * (yz + rx)};
+    m.r2 = f3{2.f * (xz + ry), 2.f * (yz - rx), 1.f - 2.f * (xx + yy)};
+    return m;
+}
+
+// generalized Gaussian response (models/gaussianParticles.cuh:267-308); DEG is a compile-time constant
+template <int DEG>
+__device__ __forceinline__ float particle_response(float g) {
+    if constexpr (DEG == 8) { const float g2 = g * g; return __expf(-0.000685871056241f * g2 * g2); }
+    else if constexpr (DEG == 5) return __expf(-0.0185185185185f * g * g * sqrtf(g));
+    else if constexpr (DEG == 4) return __expf(-0.0555555555556f * g * g);
+    else if constexpr (DEG == 3) return __expf(-0.166666666667f * g * sqrtf(g));
+    else if constexpr (DEG == 1) return __expf(-1.5f * sqrtf(g));
+    else if constexpr (DEG == 0) return fmaxf(1.f - 0.329630334487f * sqrtf(g), 0.f);
+    else return __expf(-0.5f * g);
+}
+// d response / d grayDist * upstream (models/gaussianParticles.cuh:223-265)
+template <int DEG>
+__device__ __forceinline__ float particle_response_grd(float g, float gres, float gresGrd) {
+    if constexpr (DEG == 8) return (-0.000685871056241f * 4.f) * g * g * g * gres * gresGrd;
+    else if constexpr (DEG == 5) return (-0.0185185185185f * 2.5f) * g * sqrtf(g) * gres * gresGrd;
+    else if constexpr (DEG == 4) return (-0.0555555555556f * 2.f) * g * gres * gresGrd;
+    else if constexpr (DEG == 3) return (-0.166666666667f * 1.5f) * sqrtf(g) * gres * gresGrd;
+    else if constexpr (DEG == 1) return (-1.5f * 0.5f) * sqrtf(g) * gres * gresGrd;
+    else if constexpr (DEG == 0) return gres > 0.f ? (0.5f * -0.329630334487f * rsqrtf(g)) * gresGrd : 0.f;
+    else return -0.5f * gres * gresGrd;
+}
+
+// ---- wave64 helpers -------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+    // v + dpp(v); lanes with no source (bound_ctrl) add 0
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true);
+    return v + __int_as_float(moved);
+}
+// full-wave sum; the total lands in lane 63 (LLVM AtomicOptimizer's DPP sequence for gfx9)
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v = dpp_add<0x111>(v);        // row_shr:1
+    v = dpp_add<0x112>(v);        // row_shr:2
+    v = dpp_add<0x114>(v);        // row_shr:4
+    v = dpp_add<0x118>(v);        // row_shr:8
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 -> rows 1,3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = wave_sum_to_lane63(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+}  // namespace grut
+#endif  // __HIPCC__

@@ -1,0 +1,412 @@
+// gut_api.hip — host orchestration of the 3DGUT path behind the C-ABI (include/grut_amd.h).
+// Plays the role of SplatRaster + GUTRenderer (threedgut_tracer/src/splatRaster.cpp:184-350,
+// src/gutRenderer.cu:241-520) without libtorch: all I/O buffers belong to the caller.
+#include <vector>
+
+#include "gut_internal.hpp"
+
+namespace grut {
+
+static thread_local char g_last_error[512] = "";
+void set_last_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+}
+
+static uint32_t bits_for(uint32_t n) {  // smallest b with (1<<b) > n  -> the all-ones pad key never aliases a tile
+    uint32_t b = 1;
+    while ((1ull << b) <= n) ++b;
+    return b;
+}
+
+}  // namespace grut
+
+using namespace grut;
+
+struct GutHandle {
+    GutConfig cfg;
+    int device = -1;
+    // per-particle scratch
+    DeviceBuffer tiles_count, proj_pos, conic_opacity, extent, depth, rgb, depth_key, particle_idx;
+    DeviceBuffer depth_key_tmp, particle_idx_tmp, offsets, sort_scratch, scan_scratch, counters;
+    DeviceBuffer g_rgb;
+    // per-intersection scratch
+    DeviceBuffer tile_keys, tile_vals, tile_keys_tmp, tile_vals_tmp, tile_sort_scratch, ranges;
+    uint32_t* host_counters = nullptr;  // pinned: [0] = I (last offset), [1] = Nv
+    hipEvent_t count_event = nullptr;
+    // forward context consumed by backward (role of GutRenderForwardContext)
+    bool have_forward = false;
+    hipStream_t fwd_stream = nullptr;
+    GutParams params;
+    uint32_t num_intersections = 0;
+    uint32_t* sorted_particle_idx = nullptr;  // points into tile_vals or tile_vals_tmp
+    uint32_t* sorted_tile_keys = nullptr;
+    uint32_t* rank_to_particle = nullptr;
+    GutStats stats;
+    EventTimer fwd_timer, bwd_timer;
+    // per-stage profiling (gut_profile_enable)
+    bool profile = false;
+    static constexpr int kProfRing = 64;
+    hipEvent_t prof_ev[kProfRing][GUT_NUM_STAGES][2];
+    bool prof_used[kProfRing][GUT_NUM_STAGES];
+    int prof_slot = 0, prof_created = 0;
+    int prof_fwd_slot = 0;
+
+    int stage_begin(int stage, hipStream_t s, int slot) {
+        if (!profile) return GRUT_OK;
+        GRUT_HIP(hipEventRecord(prof_ev[slot][stage][0], s));
+        return GRUT_OK;
+    }
+    int stage_end(int stage, hipStream_t s, int slot) {
+        if (!profile) return GRUT_OK;
+        GRUT_HIP(hipEventRecord(prof_ev[slot][stage][1], s));
+        prof_used[slot][stage] = true;
+        return GRUT_OK;
+    }
+};
+
+static int validate_config(const GutConfig& c) {
+    GRUT_REQUIRE(c.ut_require_all_sigma_points_valid == 0, "ut_require_all_sigma_points_valid must be false (threedgut.cuh:78)");
+    GRUT_REQUIRE(c.particle_radiance_sph_degree >= 0 && c.particle_radiance_sph_degree <= 3, "sph degree must be in [0,3]");
+    if (c.k_buffer_size != 0) {
+        set_last_error("k_buffer_size=%d: only the unsorted renderer (k_buffer_size=0) is implemented", c.k_buffer_size);
+        return GRUT_ERR_UNSUPPORTED;
+    }
+    const int d = c.particle_kernel_degree;
+    GRUT_REQUIRE(d == 0 || d == 1 || d == 2 || d == 3 || d == 4 || d == 5 || d == 8, "unsupported particle_kernel_degree %d", d);
+    return GRUT_OK;
+}
+
+static GutParams make_params(const GutConfig& c, const GutFrame& f) {
+    GutParams P;
+    memset(&P, 0, sizeof(P));
+    P.degree = c.particle_kernel_degree;
+    P.min_response = c.particle_kernel_min_response;
+    P.min_alpha = c.particle_kernel_min_alpha;
+    P.max_alpha = c.particle_kernel_max_alpha;
+    P.min_transmittance = c.min_transmittance;
+    P.n_active = f.n_active_features < c.particle_radiance_sph_degree ? f.n_active_features : c.particle_radiance_sph_degree;
+    if (P.n_active < 0) P.n_active = 0;
+    P.ncoef = (c.particle_radiance_sph_degree + 1) * (c.particle_radiance_sph_degree + 1);
+    P.hitcounts = c.enable_hitcounts;
+    const float D = 3.f;
+    const float lambda = c.ut_alpha * c.ut_alpha * (D + c.ut_kappa) - D;  // gutProjector.cuh:150
+    P.ut_w0m = lambda / (D + lambda);
+    P.ut_wi = 1.f / (2.f * (D + lambda));
+    P.ut_w0c = lambda / (D + lambda) + (1.f - c.ut_alpha * c.ut_alpha + c.ut_beta);
+    P.ut_delta = sqrtf(c.ut_alpha * c.ut_alpha * (D + c.ut_kappa));  // setup_3dgut.py:44
+    P.ut_margin = c.ut_in_image_margin_factor;
+    P.ut_require_all = c.ut_require_all_sigma_points_valid;
+    P.n_rs_iter = c.n_rolling_shutter_iterations;
+    P.k_buffer = c.k_buffer_size;
+    P.global_z = c.global_z_order;
+    P.rect_bounding = c.rect_bounding;
+    P.tight_opacity = c.tight_opacity_bounding;
+    P.tile_culling = c.tile_based_culling;
+    P.W = f.width;
+    P.H = f.height;
+    P.gx = (f.width + 15) / 16;
+    P.gy = (f.height + 15) / 16;
+    P.N = f.num_particles;
+    P.cam = f.camera;
+    P.poses = make_frame_poses(f.pose_start, f.pose_end);
+    return P;
+}
+
+static int ensure_particle_scratch(GutHandle* h, uint32_t N) {
+    const size_t n = N ? N : 1;
+    GRUT_CHECK(h->tiles_count.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->proj_pos.ensure(n * 8, 1.25f));
+    GRUT_CHECK(h->conic_opacity.ensure(n * 16, 1.25f));
+    GRUT_CHECK(h->extent.ensure(n * 8, 1.25f));
+    GRUT_CHECK(h->depth.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->rgb.ensure(n * 12, 1.25f));
+    GRUT_CHECK(h->depth_key.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->particle_idx.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->depth_key_tmp.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->particle_idx_tmp.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->offsets.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
+    GRUT_CHECK(h->scan_scratch.ensure(scan_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
+    GRUT_CHECK(h->counters.ensure(64));
+    return GRUT_OK;
+}
+
+static int ensure_intersection_scratch(GutHandle* h, uint32_t I, uint32_t tiles) {
+    const size_t n = I ? I : 1;
+    GRUT_CHECK(h->tile_keys.ensure(n * 4, 1.3f));
+    GRUT_CHECK(h->tile_vals.ensure(n * 4, 1.3f));
+    GRUT_CHECK(h->tile_keys_tmp.ensure(n * 4, 1.3f));
+    GRUT_CHECK(h->tile_vals_tmp.ensure(n * 4, 1.3f));
+    GRUT_CHECK(h->tile_sort_scratch.ensure(sort_scratch_bytes((uint32_t)n), 1.3f));
+    GRUT_CHECK(h->ranges.ensure((size_t)tiles * 8 + 8));
+    return GRUT_OK;
+}
+
+static GutProjected projected_view(GutHandle* h) {
+    GutProjected p;
+    p.tiles_count = h->tiles_count.as<uint32_t>();
+    p.proj_pos = h->proj_pos.as<float2>();
+    p.conic_opacity = h->conic_opacity.as<float4>();
+    p.extent = h->extent.as<float2>();
+    p.depth = h->depth.as<float>();
+    p.rgb = h->rgb.as<float>();
+    p.depth_key = h->depth_key.as<uint32_t>();
+    p.particle_idx = h->particle_idx.as<uint32_t>();
+    return p;
+}
+
+extern "C" {
+
+int grut_abi_version(void) { return GRUT_ABI_VERSION; }
+const char* grut_last_error(void) { return grut::g_last_error; }
+
+int gut_create(const GutConfig* config, GutHandle** handle) {
+    GRUT_REQUIRE(config && handle, "gut_create: null argument");
+    GRUT_CHECK(validate_config(*config));
+    GutHandle* h = new GutHandle();
+    h->cfg = *config;
+    memset(&h->stats, 0, sizeof(h->stats));
+    if (hipGetDevice(&h->device) != hipSuccess) {
+        set_last_error("gut_create: no HIP device");
+        delete h;
+        return GRUT_ERR_RUNTIME;
+    }
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->host_counters), 64, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->count_event, hipEventDisableTiming) != hipSuccess) {
+        set_last_error("gut_create: pinned counter / event allocation failed");
+        delete h;
+        return GRUT_ERR_RUNTIME;
+    }
+    *handle = h;
+    return GRUT_OK;
+}
+
+void gut_destroy(GutHandle* h) {
+    if (!h) return;
+    DeviceBuffer* bufs[] = {&h->tiles_count, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->rgb, &h->depth_key,
+                            &h->particle_idx, &h->depth_key_tmp, &h->particle_idx_tmp, &h->offsets, &h->sort_scratch,
+                            &h->scan_scratch, &h->counters, &h->g_rgb, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
+                            &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges};
+    for (DeviceBuffer* b : bufs) b->release();
+    if (h->host_counters) (void)hipHostFree(h->host_counters);
+    if (h->count_event) (void)hipEventDestroy(h->count_event);
+    h->fwd_timer.destroy();
+    h->bwd_timer.destroy();
+    if (h->prof_created)
+        for (int r = 0; r < GutHandle::kProfRing; ++r)
+            for (int st = 0; st < GUT_NUM_STAGES; ++st) {
+                (void)hipEventDestroy(h->prof_ev[r][st][0]);
+                (void)hipEventDestroy(h->prof_ev[r][st][1]);
+            }
+    delete h;
+}
+
+int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const float* particle_sph,
+                const float* ray_origin, const float* ray_direction, float* out_feat_density, float* out_hit_distance,
+                float* out_hit_count, int32_t* out_visibility) {
+    GRUT_REQUIRE(h && frame, "gut_forward: null handle/frame");
+    GRUT_REQUIRE(frame->width > 0 && frame->height > 0, "gut_forward: empty image");
+    GRUT_REQUIRE(ray_origin && ray_direction && out_feat_density && out_hit_distance && out_hit_count, "gut_forward: null ray/output buffer");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    h->have_forward = false;
+    const uint32_t N = frame->num_particles;
+    h->params = make_params(h->cfg, *frame);
+    const GutParams& P = h->params;
+    const uint32_t tiles = (uint32_t)(P.gx * P.gy);
+    h->stats.num_particles = N;
+    h->stats.num_tiles = tiles;
+    h->stats.num_visible = 0;
+    h->stats.num_intersections = 0;
+    h->stats.key_bits = bits_for(tiles);
+    h->num_intersections = 0;
+    h->fwd_stream = s;
+    if (N == 0) {  // nothing to render: outputs keep their initial values
+        h->have_forward = true;
+        return GRUT_OK;
+    }
+    GRUT_REQUIRE(particle_density && particle_sph && out_visibility, "gut_forward: null particle buffer");
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
+
+    GRUT_CHECK(ensure_particle_scratch(h, N));
+    const GutProjected proj = projected_view(h);
+    uint32_t* d_counters = h->counters.as<uint32_t>();
+    GRUT_HIP(hipMemsetAsync(d_counters, 0, 64, s));
+
+    const int slot = h->prof_slot % GutHandle::kProfRing;
+    if (h->profile) {
+        for (int st = 0; st < GUT_NUM_STAGES; ++st) h->prof_used[slot][st] = false;
+        h->prof_fwd_slot = slot;
+        h->prof_slot++;
+    }
+    // K1 projection
+    GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT, s, slot));
+    launch_project(s, P, particle_density, particle_sph, proj, out_visibility, d_counters + 1);
+    GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT, s, slot));
+    GRUT_CHECK(h->stage_begin(GUT_STAGE_DEPTH_SORT, s, slot));
+    // K2 depth sort of the particles (N keys): rank order = (depth bits, particle index)
+    uint32_t *sorted_depth = nullptr, *rank_to_particle = nullptr;
+    GRUT_CHECK(sort_pairs_u32(s, N, nullptr, 0, 32, proj.depth_key, proj.particle_idx, h->depth_key_tmp.as<uint32_t>(),
+                              h->particle_idx_tmp.as<uint32_t>(), h->sort_scratch.ptr, h->sort_scratch.bytes, &sorted_depth,
+                              &rank_to_particle));
+    h->rank_to_particle = rank_to_particle;
+    GRUT_CHECK(h->stage_end(GUT_STAGE_DEPTH_SORT, s, slot));
+    GRUT_CHECK(h->stage_begin(GUT_STAGE_SCAN, s, slot));
+    // K3 offsets[r] = sum_{r' <= r} tiles_count[rank_to_particle[r']]
+    GRUT_CHECK(inclusive_scan_u32(s, N, proj.tiles_count, rank_to_particle, h->offsets.as<uint32_t>(), h->scan_scratch.ptr,
+                                  h->scan_scratch.bytes));
+    GRUT_CHECK(h->stage_end(GUT_STAGE_SCAN, s, slot));
+    // I and Nv to the host; the host waits for the scan only, the GPU keeps going
+    GRUT_HIP(hipMemcpyAsync(&h->host_counters[0], h->offsets.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+    GRUT_HIP(hipMemcpyAsync(&h->host_counters[1], d_counters + 1, 4, hipMemcpyDeviceToHost, s));
+    GRUT_HIP(hipEventRecord(h->count_event, s));
+    GRUT_HIP(hipEventSynchronize(h->count_event));
+    const uint32_t I = h->host_counters[0];
+    h->stats.num_visible = h->host_counters[1];
+    h->stats.num_intersections = I;
+    h->num_intersections = I;
+    if (I == 0) {  // gutRenderer.cu:323-325
+        if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
+        h->have_forward = true;
+        return GRUT_OK;
+    }
+    GRUT_CHECK(ensure_intersection_scratch(h, I, tiles));
+    // K4 expansion in rank order
+    GRUT_CHECK(h->stage_begin(GUT_STAGE_EXPAND, s, slot));
+    launch_expand(s, P, proj, rank_to_particle, h->offsets.as<uint32_t>(), I, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>());
+    GRUT_CHECK(h->stage_end(GUT_STAGE_EXPAND, s, slot));
+    GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_SORT, s, slot));
+    // K5 stable radix passes over the tile bits only
+    uint32_t *sorted_tiles = nullptr, *sorted_idx = nullptr;
+    GRUT_CHECK(sort_pairs_u32(s, I, nullptr, 0, (int)h->stats.key_bits, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>(),
+                              h->tile_keys_tmp.as<uint32_t>(), h->tile_vals_tmp.as<uint32_t>(), h->tile_sort_scratch.ptr,
+                              h->tile_sort_scratch.bytes, &sorted_tiles, &sorted_idx));
+    h->sorted_tile_keys = sorted_tiles;
+    h->sorted_particle_idx = sorted_idx;
+    GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_SORT, s, slot));
+    GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_RANGES, s, slot));
+    // K6 tile ranges
+    GRUT_HIP(hipMemsetAsync(h->ranges.ptr, 0, (size_t)tiles * 8, s));
+    const uint32_t tile_mask = (h->stats.key_bits >= 32) ? 0xFFFFFFFFu : ((1u << h->stats.key_bits) - 1u);
+    launch_tile_ranges(s, I, tile_mask, tiles, sorted_tiles, h->ranges.as<uint32_t>());
+    GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_RANGES, s, slot));
+    // K7 compositing
+    GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_FWD, s, slot));
+    launch_render_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, particle_density, proj.rgb, ray_origin, ray_direction,
+                      out_feat_density, out_hit_distance, out_hit_count);
+    GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_FWD, s, slot));
+    GRUT_HIP(hipGetLastError());
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
+    h->have_forward = true;
+    return GRUT_OK;
+}
+
+int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const float* particle_sph,
+                 const float* ray_origin, const float* ray_direction, const float* feat_density, const float* grad_feat_density,
+                 const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_particle_sph) {
+    GRUT_REQUIRE(h && frame, "gut_backward: null handle/frame");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (!h->have_forward || h->fwd_stream != s) {  // gutRenderer.cu:436-440
+        set_last_error("gut_backward: no forward context on this stream");
+        return GRUT_ERR_NOT_READY;
+    }
+    const GutParams& P = h->params;
+    GRUT_REQUIRE(frame->num_particles == P.N && frame->width == P.W && frame->height == P.H, "gut_backward: frame differs from the forward frame");
+    if (P.N == 0) return GRUT_OK;
+    GRUT_REQUIRE(particle_density && particle_sph && feat_density && grad_feat_density && hit_distance && grad_hit_distance &&
+                     grad_particle_density && grad_particle_sph, "gut_backward: null buffer");
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
+    const GutProjected proj = projected_view(h);
+    GRUT_CHECK(h->g_rgb.ensure((size_t)P.N * 12, 1.25f));
+    GRUT_HIP(hipMemsetAsync(h->g_rgb.ptr, 0, (size_t)P.N * 12, s));
+    const int slot = h->prof_fwd_slot;
+    if (h->num_intersections > 0) {
+        GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_BWD, s, slot));
+        launch_render_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_particle_idx, particle_density, proj.rgb, ray_origin, ray_direction,
+                          feat_density, grad_feat_density, hit_distance, grad_hit_distance, grad_particle_density, h->g_rgb.as<float>());
+        GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_BWD, s, slot));
+    }
+    GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));
+    launch_project_bwd(s, P, proj.tiles_count, particle_density, particle_sph, proj.rgb, h->g_rgb.as<float>(), grad_particle_density,
+                       grad_particle_sph);
+    GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT_BWD, s, slot));
+    GRUT_HIP(hipGetLastError());
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
+    return GRUT_OK;
+}
+
+int gut_timings(GutHandle* h, float* forward_ms, float* backward_ms) {
+    GRUT_REQUIRE(h, "gut_timings: null handle");
+    if (forward_ms) *forward_ms = h->fwd_timer.collect();
+    if (backward_ms) *backward_ms = h->bwd_timer.collect();
+    return GRUT_OK;
+}
+
+int gut_profile_enable(GutHandle* h, int enable) {
+    GRUT_REQUIRE(h, "gut_profile_enable: null handle");
+    if (enable && h->prof_created == 0) {
+        for (int r = 0; r < GutHandle::kProfRing; ++r)
+            for (int st = 0; st < GUT_NUM_STAGES; ++st) {
+                GRUT_HIP(hipEventCreate(&h->prof_ev[r][st][0]));
+                GRUT_HIP(hipEventCreate(&h->prof_ev[r][st][1]));
+                h->prof_used[r][st] = false;
+            }
+        h->prof_created = 1;
+    }
+    h->profile = enable != 0;
+    return GRUT_OK;
+}
+
+int gut_profile_read(GutHandle* h, float* stage_ms) {
+    GRUT_REQUIRE(h && stage_ms, "gut_profile_read: null argument");
+    GRUT_REQUIRE(h->prof_created, "gut_profile_read: profiling was never enabled");
+    for (int st = 0; st < GUT_NUM_STAGES; ++st) {
+        double sum = 0;
+        int n = 0;
+        for (int r = 0; r < GutHandle::kProfRing; ++r) {
+            if (!h->prof_used[r][st]) continue;
+            float ms = 0.f;
+            GRUT_HIP(hipEventSynchronize(h->prof_ev[r][st][1]));
+            GRUT_HIP(hipEventElapsedTime(&ms, h->prof_ev[r][st][0], h->prof_ev[r][st][1]));
+            sum += ms;
+            n++;
+            h->prof_used[r][st] = false;
+        }
+        stage_ms[st] = n ? (float)(sum / n) : -1.f;
+    }
+    h->prof_slot = 0;
+    return GRUT_OK;
+}
+
+int gut_stats(GutHandle* h, GutStats* stats) {
+    GRUT_REQUIRE(h && stats, "gut_stats: null argument");
+    *stats = h->stats;
+    return GRUT_OK;
+}
+
+int gut_debug_fetch(GutHandle* h, void* stream_, uint32_t* tiles_count, float* proj_pos, float* conic_opacity, float* extent,
+                    float* depth, float* rgb, uint32_t* sorted_particle_idx, uint32_t* tile_ranges) {
+    GRUT_REQUIRE(h && h->have_forward, "gut_debug_fetch: no forward context");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    const size_t N = h->params.N;
+    const size_t I = h->num_intersections;
+    const size_t tiles = (size_t)h->params.gx * h->params.gy;
+    const hipMemcpyKind k = hipMemcpyDeviceToDevice;
+    if (N) {
+        if (tiles_count) GRUT_HIP(hipMemcpyAsync(tiles_count, h->tiles_count.ptr, N * 4, k, s));
+        if (proj_pos) GRUT_HIP(hipMemcpyAsync(proj_pos, h->proj_pos.ptr, N * 8, k, s));
+        if (conic_opacity) GRUT_HIP(hipMemcpyAsync(conic_opacity, h->conic_opacity.ptr, N * 16, k, s));
+        if (extent) GRUT_HIP(hipMemcpyAsync(extent, h->extent.ptr, N * 8, k, s));
+        if (depth) GRUT_HIP(hipMemcpyAsync(depth, h->depth.ptr, N * 4, k, s));
+        if (rgb) GRUT_HIP(hipMemcpyAsync(rgb, h->rgb.ptr, N * 12, k, s));
+    }
+    if (I) {
+        if (sorted_particle_idx) GRUT_HIP(hipMemcpyAsync(sorted_particle_idx, h->sorted_particle_idx, I * 4, k, s));
+        if (tile_ranges) GRUT_HIP(hipMemcpyAsync(tile_ranges, h->ranges.ptr, tiles * 8, k, s));
+    }
+    return GRUT_OK;
+}
+
+}  // extern "C"

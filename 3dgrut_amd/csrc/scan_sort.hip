@@ -1,0 +1,327 @@
+// scan_sort.hip — device-wide prefix sum and stable LSD radix sort for gfx950 (wave64).
+//
+// These replace the two CUB primitives on the reference's 3DGUT path
+// (cub::DeviceScan::InclusiveSum gutRenderer.cu:302-310, cub::DeviceRadixSort::SortPairs :356-365).
+// Both are three-kernel, fully deterministic formulations (no inter-workgroup hand-off inside a
+// launch, so no dependence on dispatch order — cdna_hip_programming.md §6 G16):
+//   scan : per-block reduce -> single-block scan of block sums -> per-block scan + offset
+//   sort : per pass { per-block digit histogram -> scan of the digit-major histogram matrix ->
+//                     per-block stable ranking (wave64 ballot match) + scatter }
+// HBM-bound integer work: 16 B/lane vector loads where the layout allows, 8-bit digits.
+#include "common.hpp"
+
+namespace grut {
+
+namespace {
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems   = 8;
+constexpr int kScanTile    = kScanThreads * kScanItems;  // 2048
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t n = __shfl_up(v, off, 64);
+        if (lane >= off) v += n;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread (256 threads); returns exclusive prefix, *total = block sum
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t* total, uint32_t* s_wave /*[4]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t incl = wave_incl_scan_u32(v, lane);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint32_t s = s_wave[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    *total = tot;
+    __syncthreads();
+    return base + incl - v;
+}
+
+__device__ __forceinline__ void load_items(const uint32_t* __restrict__ in, const uint32_t* __restrict__ gather,
+                                           uint32_t base, uint32_t n, uint32_t (&x)[kScanItems]) {
+    const uint32_t i0 = base + threadIdx.x * kScanItems;
+    if (!gather && i0 + kScanItems <= n) {
+        const uint4 a = *reinterpret_cast<const uint4*>(in + i0);
+        const uint4 b = *reinterpret_cast<const uint4*>(in + i0 + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k) {
+            const uint32_t i = i0 + k;
+            x[k] = i < n ? (gather ? in[gather[i]] : in[i]) : 0u;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(const uint32_t* __restrict__ in,
+                                                                   const uint32_t* __restrict__ gather, uint32_t n,
+                                                                   uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t x[kScanItems];
+    load_items(in, gather, blockIdx.x * kScanTile, n, x);
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) s += x[k];
+    uint32_t total;
+    (void)block_excl_scan_256(s, &total, s_wave);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// exclusive scan of nb block sums in place, one workgroup
+__global__ __launch_bounds__(kScanThreads) void scan_block_sums_kernel(uint32_t* __restrict__ block_sums, uint32_t nb) {
+    __shared__ uint32_t s_wave[4];
+    const uint32_t per = (nb + kScanThreads - 1) / kScanThreads;
+    const uint32_t b0 = threadIdx.x * per;
+    uint32_t s = 0;
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t i = b0 + k;
+        if (i < nb) s += block_sums[i];
+    }
+    uint32_t total;
+    uint32_t run = block_excl_scan_256(s, &total, s_wave);
+    for (uint32_t k = 0; k < per; ++k) {
+        const uint32_t i = b0 + k;
+        if (i < nb) {
+            const uint32_t v = block_sums[i];
+            block_sums[i] = run;
+            run += v;
+        }
+    }
+}
+
+template <bool EXCLUSIVE>
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(const uint32_t* __restrict__ in,
+                                                                  const uint32_t* __restrict__ gather, uint32_t n,
+                                                                  const uint32_t* __restrict__ block_sums,
+                                                                  uint32_t* __restrict__ out) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t x[kScanItems];
+    const uint32_t base = blockIdx.x * kScanTile;
+    load_items(in, gather, base, n, x);
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) s += x[k];
+    uint32_t total;
+    uint32_t run = block_excl_scan_256(s, &total, s_wave) + block_sums[blockIdx.x];
+    const uint32_t i0 = base + threadIdx.x * kScanItems;
+    uint32_t y[kScanItems];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (EXCLUSIVE) { y[k] = run; run += x[k]; }
+        else { run += x[k]; y[k] = run; }
+    }
+    if (i0 + kScanItems <= n) {
+        *reinterpret_cast<uint4*>(out + i0)     = make_uint4(y[0], y[1], y[2], y[3]);
+        *reinterpret_cast<uint4*>(out + i0 + 4) = make_uint4(y[4], y[5], y[6], y[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanItems; ++k)
+            if (i0 + k < n) out[i0 + k] = y[k];
+    }
+}
+
+int scan_impl(hipStream_t s, uint32_t n, const uint32_t* in, const uint32_t* gather, uint32_t* out, bool exclusive,
+              void* scratch, size_t scratch_bytes) {
+    if (n == 0) return GRUT_OK;
+    const uint32_t nb = div_up(n, kScanTile);
+    GRUT_REQUIRE(scratch_bytes >= (size_t)nb * sizeof(uint32_t), "scan scratch too small");
+    uint32_t* sums = reinterpret_cast<uint32_t*>(scratch);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kScanThreads), 0, s, sums, nb);
+    if (exclusive)
+        hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums, out);
+    else
+        hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums, out);
+    GRUT_HIP(hipGetLastError());
+    return GRUT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// radix sort
+// ---------------------------------------------------------------------------------------------
+constexpr int kSortThreads = 256;
+constexpr int kSortRounds  = 16;                         // keys per lane
+constexpr int kSortTile    = kSortThreads * kSortRounds;  // 4096 keys per workgroup
+constexpr int kSortWaveKeys = 64 * kSortRounds;           // 1024 contiguous keys per wave
+constexpr int kRadix       = 256;
+
+__device__ __forceinline__ uint32_t eff_count(uint32_t n, const uint32_t* n_dev) {
+    if (!n_dev) return n;
+    const uint32_t m = *n_dev;
+    return m < n ? m : n;
+}
+
+// histogram matrix is digit-major: hist[d * nb + b]
+__global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                  const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
+                                                                  uint32_t nb, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_hist[4][kRadix];
+    const int wave = threadIdx.x >> 6;
+    const uint32_t ne = eff_count(n, n_dev);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_hist[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * kSortTile;
+    if (base < ne) {
+        // 16 B per lane, 4 loads per thread
+#pragma unroll
+        for (int k = 0; k < kSortRounds / 4; ++k) {
+            const uint32_t i = base + (k * kSortThreads + threadIdx.x) * 4;
+            if (i + 4 <= ne) {
+                const uint4 v = *reinterpret_cast<const uint4*>(keys + i);
+                atomicAdd(&s_hist[wave][(v.x >> shift) & mask], 1u);
+                atomicAdd(&s_hist[wave][(v.y >> shift) & mask], 1u);
+                atomicAdd(&s_hist[wave][(v.z >> shift) & mask], 1u);
+                atomicAdd(&s_hist[wave][(v.w >> shift) & mask], 1u);
+            } else {
+                for (uint32_t j = i; j < ne && j < i + 4; ++j) atomicAdd(&s_hist[wave][(keys[j] >> shift) & mask], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t d = threadIdx.x;
+    hist[(size_t)d * nb + blockIdx.x] = s_hist[0][d] + s_hist[1][d] + s_hist[2][d] + s_hist[3][d];
+}
+
+__global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                                     const uint32_t* __restrict__ vals_in, uint32_t n,
+                                                                     const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
+                                                                     uint32_t nb, const uint32_t* __restrict__ hist_scanned,
+                                                                     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    // per-wave digit counters; after the ranking phase they are turned into global scatter bases
+    __shared__ uint32_t s_cnt[4][kRadix];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ne = eff_count(n, n_dev);
+    const uint32_t base = blockIdx.x * kSortTile;
+    if (base >= ne) return;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t key[kSortRounds], val[kSortRounds], rank[kSortRounds];
+    const uint32_t wbase = base + wave * kSortWaveKeys;
+    volatile uint32_t* cnt = s_cnt[wave];
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        const bool valid = i < ne;
+        key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[r] = valid ? vals_in[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        const bool valid = i < ne;
+        const uint32_t d = (key[r] >> shift) & mask;
+        // lanes holding the same digit (wave64 match via 8 ballots)
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t count  = (uint32_t)__popcll(m);
+        uint32_t old = 0;
+        if (valid) old = cnt[d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) cnt[d] = old + count;
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = old + before;
+    }
+    __syncthreads();
+    // thread d: exclusive prefix of digit d over the 4 waves + global base of (digit, block)
+    {
+        const uint32_t d = threadIdx.x;
+        uint32_t run = hist_scanned[(size_t)d * nb + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = s_cnt[w][d];
+            s_cnt[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        if (i < ne) {
+            const uint32_t d = (key[r] >> shift) & mask;
+            const uint32_t dst = s_cnt[wave][d] + rank[r];
+            keys_out[dst] = key[r];
+            vals_out[dst] = val[r];
+        }
+    }
+}
+
+}  // namespace
+
+size_t scan_scratch_bytes(uint32_t n) { return (size_t)(div_up(n, kScanTile) + 1) * sizeof(uint32_t); }
+
+int inclusive_scan_u32(hipStream_t s, uint32_t n, const uint32_t* in, const uint32_t* gather, uint32_t* out,
+                       void* scratch, size_t scratch_bytes) {
+    return scan_impl(s, n, in, gather, out, false, scratch, scratch_bytes);
+}
+
+size_t sort_scratch_bytes(uint32_t n) {
+    const uint32_t nb = div_up(n, kSortTile);
+    const size_t hist = (size_t)kRadix * nb * sizeof(uint32_t);
+    return hist + scan_scratch_bytes(kRadix * nb) + 256;
+}
+
+int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_bit, int end_bit,
+                   uint32_t* keys, uint32_t* vals, uint32_t* keys_tmp, uint32_t* vals_tmp,
+                   void* scratch, size_t scratch_bytes, uint32_t** out_keys, uint32_t** out_vals) {
+    *out_keys = keys;
+    *out_vals = vals;
+    if (n == 0 || end_bit <= begin_bit) return GRUT_OK;
+    GRUT_REQUIRE(scratch_bytes >= sort_scratch_bytes(n), "sort scratch too small");
+    const uint32_t nb = div_up(n, kSortTile);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(scratch);
+    void* scan_scratch = hist + (size_t)kRadix * nb;
+    const size_t scan_bytes = scan_scratch_bytes(kRadix * nb);
+    uint32_t *ki = keys, *vi = vals, *ko = keys_tmp, *vo = vals_tmp;
+    for (int bit = begin_bit; bit < end_bit; bit += 8) {
+        const int nbits = (end_bit - bit) < 8 ? (end_bit - bit) : 8;
+        const uint32_t mask = (1u << nbits) - 1u;
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(kSortThreads), 0, s, ki, n, n_dev, bit, mask, nb, hist);
+        GRUT_CHECK(scan_impl(s, kRadix * nb, hist, nullptr, hist, true, scan_scratch, scan_bytes));
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(kSortThreads), 0, s, ki, vi, n, n_dev, bit, mask, nb, hist, ko, vo);
+        uint32_t* t;
+        t = ki; ki = ko; ko = t;
+        t = vi; vi = vo; vo = t;
+    }
+    GRUT_HIP(hipGetLastError());
+    *out_keys = ki;
+    *out_vals = vi;
+    return GRUT_OK;
+}
+
+}  // namespace grut
+
+// ---- C-ABI stage wrappers -------------------------------------------------------------------
+extern "C" {
+
+uint64_t grut_sort_scratch_bytes(uint32_t n) { return grut::sort_scratch_bytes(n); }
+uint64_t grut_scan_scratch_bytes(uint32_t n) { return grut::scan_scratch_bytes(n); }
+
+int grut_sort_pairs_u32(void* stream, uint32_t n, int begin_bit, int end_bit, uint32_t* keys, uint32_t* values,
+                        uint32_t* keys_tmp, uint32_t* values_tmp, void* scratch, uint64_t scratch_bytes,
+                        uint32_t** sorted_keys, uint32_t** sorted_values) {
+    return grut::sort_pairs_u32(reinterpret_cast<hipStream_t>(stream), n, nullptr, begin_bit, end_bit, keys, values,
+                                keys_tmp, values_tmp, scratch, scratch_bytes, sorted_keys, sorted_values);
+}
+
+int grut_inclusive_scan_u32(void* stream, uint32_t n, const uint32_t* in, uint32_t* out, void* scratch, uint64_t scratch_bytes) {
+    return grut::inclusive_scan_u32(reinterpret_cast<hipStream_t>(stream), n, in, nullptr, out, scratch, scratch_bytes);
+}
+
+}  // extern "C"

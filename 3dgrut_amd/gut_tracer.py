@@ -1,0 +1,207 @@
+"""3DGUT renderer plugin: drop-in for `threedgut_tracer.Tracer` (threedgut_tracer/tracer.py:158-349).
+
+Same surface — `Tracer(conf)`, `.build_acc(gaussians, rebuild)`, `.render(gaussians, gpu_batch, train, frame_id)`,
+`.timings` — same autograd contract (differentiable inputs: positions / rotation / scale / density / features;
+outputs: feature+opacity image, hit distance, hit count, visibility), but the device work is the HIP library
+behind include/grut_amd.h.  PyTorch only owns tensors, the autograd graph and the current stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _abi
+from .camera import camera_from_batch
+
+_FALSE_DEFAULTS = dict(
+    particle_kernel_degree=2, particle_kernel_min_response=0.0113, particle_kernel_min_alpha=1.0 / 255.0,
+    particle_kernel_max_alpha=0.99, min_transmittance=0.0001, particle_radiance_sph_degree=3,
+    enable_hitcounts=True, enable_kernel_timings=False)
+_SPLAT_DEFAULTS = dict(
+    ut_alpha=1.0, ut_beta=2.0, ut_kappa=0.0, ut_in_image_margin_factor=0.1, ut_require_all_sigma_points_valid=False,
+    n_rolling_shutter_iterations=5, k_buffer_size=0, global_z_order=True, rect_bounding=True,
+    tight_opacity_bounding=True, tile_based_culling=True)
+
+
+def _conf_get(node, name, default=None):
+    """OmegaConf DictConfig, SimpleNamespace or plain dict — attribute or item access."""
+    if node is None:
+        return default
+    if isinstance(node, dict):
+        return node.get(name, default)
+    try:
+        v = getattr(node, name)
+        return default if v is None else v
+    except (AttributeError, KeyError):
+        try:
+            return node[name]
+        except Exception:
+            return default
+
+
+def gut_config_from_conf(conf) -> _abi.GutConfig:
+    """conf.render.* -> GutConfig (the keys setup_3dgut.py:41-95 turns into -D macros)."""
+    render = _conf_get(conf, "render")
+    splat = _conf_get(render, "splat")
+    cfg = _abi.GutConfig()
+    for k, d in _FALSE_DEFAULTS.items():
+        v = _conf_get(render, k, d)
+        setattr(cfg, k, type(d)(v) if not isinstance(d, bool) else int(bool(v)))
+    for k, d in _SPLAT_DEFAULTS.items():
+        v = _conf_get(splat, k, d)
+        setattr(cfg, k, type(d)(v) if not isinstance(d, bool) else int(bool(v)))
+    if _conf_get(render, "particle_feature_half", False) or _conf_get(render, "feature_output_half", False):
+        raise NotImplementedError("3dgrut_amd: fp16 particle features / outputs are not supported (fp32 only)")
+    if _conf_get(splat, "fine_grained_load_balancing", False):
+        # the CDNA4 renderer is already strip-granular; the flag selects no different result in the reference
+        pass
+    return cfg
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _GutNative:
+    """Owns the C handle (role of lib3dgut_cc.SplatRaster)."""
+
+    def __init__(self, cfg: _abi.GutConfig):
+        self.lib = _abi.load_library()
+        self.cfg = cfg
+        self.handle = C.c_void_p()
+        _abi.check(self.lib.gut_create(C.byref(cfg), C.byref(self.handle)), "gut_create")
+        self.ncoef = (cfg.particle_radiance_sph_degree + 1) ** 2
+        self._timings = {}  # last collected averages persist like SplatRaster::m_timings (splatRaster.cpp:352-382)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None) and self.handle.value:
+                self.lib.gut_destroy(self.handle)
+                self.handle = C.c_void_p()
+        except Exception:
+            pass
+
+    def make_frame(self, frame_id, n_active, n, height, width, cam, pose_start, pose_end) -> _abi.GutFrame:
+        f = _abi.GutFrame()
+        f.frame_id, f.n_active_features, f.num_particles = int(frame_id) & 0xFFFFFFFF, int(n_active), int(n)
+        f.width, f.height = int(width), int(height)
+        f.camera = cam
+        for i in range(7):
+            f.pose_start[i] = float(pose_start[i])
+            f.pose_end[i] = float(pose_end[i])
+        return f
+
+    def trace(self, frame, particle_density, particle_sph, ray_ori, ray_dir):
+        dev = ray_ori.device
+        H, W = frame.height, frame.width
+        N = frame.num_particles
+        opts = dict(dtype=torch.float32, device=dev)
+        out_fd = torch.zeros((H, W, 4), **opts)
+        out_dist = torch.full((H, W, 1), 1e6, **opts)  # splatRaster.cpp:213
+        out_cnt = torch.zeros((H, W, 1), **opts)
+        vis_i32 = torch.zeros((N, 1), dtype=torch.int32, device=dev)
+        _abi.check(self.lib.gut_forward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
+                                        _ptr(ray_ori), _ptr(ray_dir), _ptr(out_fd), _ptr(out_dist), _ptr(out_cnt), _ptr(vis_i32)),
+                   "gut_forward")
+        # the reference returns a float tensor holding the int bit pattern (splatRaster.cpp:215,249); consumers call .bool()
+        return out_fd, out_dist, out_cnt, vis_i32.view(torch.float32)
+
+    def trace_bwd(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_fd, dist, g_dist):
+        dev = ray_ori.device
+        g_density = torch.zeros_like(particle_density)
+        g_sph = torch.empty_like(particle_sph)  # fully overwritten by the projection-backward kernel
+        _abi.check(self.lib.gut_backward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
+                                         _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(g_fd), _ptr(dist), _ptr(g_dist),
+                                         _ptr(g_density), _ptr(g_sph)), "gut_backward")
+        return g_density, g_sph
+
+    def collect_times(self):
+        if not self.cfg.enable_kernel_timings:
+            return {}
+        f, b = C.c_float(-1), C.c_float(-1)
+        _abi.check(self.lib.gut_timings(self.handle, C.byref(f), C.byref(b)), "gut_timings")
+        if f.value >= 0:
+            self._timings["forward_render"] = f.value
+        if b.value >= 0:
+            self._timings["backward_render"] = b.value
+        return dict(self._timings)
+
+    def stats(self) -> _abi.GutStats:
+        s = _abi.GutStats()
+        _abi.check(self.lib.gut_stats(self.handle, C.byref(s)), "gut_stats")
+        return s
+
+
+class Tracer:
+    class _Autograd(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_sph):
+            particle_density = torch.cat([mog_pos, mog_dns, mog_rot, mog_scl, torch.zeros_like(mog_dns)], dim=1).contiguous()
+            particle_features = mog_sph.contiguous()
+            fd, dist, cnt, vis = native.trace(frame, particle_density, particle_features, ray_ori, ray_dir)
+            ctx.save_for_backward(ray_ori, ray_dir, fd, dist, particle_density, particle_features)
+            ctx.native, ctx.frame = native, frame
+            ctx.mark_non_differentiable(cnt, vis)
+            return fd, dist, cnt, vis
+
+        @staticmethod
+        def backward(ctx, g_fd, g_dist, _g_cnt, _g_vis):
+            ray_ori, ray_dir, fd, dist, particle_density, particle_features = ctx.saved_tensors
+            if g_fd is None:
+                g_fd = torch.zeros_like(fd)
+            if g_dist is None:
+                g_dist = torch.zeros_like(dist)
+            g_density, g_sph = ctx.native.trace_bwd(ctx.frame, particle_density, particle_features, ray_ori, ray_dir,
+                                                    fd, g_fd.contiguous(), dist, g_dist.contiguous())
+            g_pos, g_dns, g_rot, g_scl, _ = torch.split(g_density, [3, 1, 4, 3, 1], dim=1)
+            return (None, None, None, None, g_pos.contiguous(), g_rot.contiguous(), g_scl.contiguous(),
+                    g_dns.contiguous(), g_sph)
+
+    def __init__(self, conf):
+        self.device = "cuda"
+        self.conf = conf
+        if not torch.cuda.is_available():
+            raise RuntimeError("3dgrut_amd.Tracer needs a ROCm GPU (there is no CPU fallback)")
+        torch.zeros(1, device=self.device)  # force context creation (tracer.py:292)
+        self.tracer_wrapper = _GutNative(gut_config_from_conf(conf))
+
+    @property
+    def timings(self):
+        return self.tracer_wrapper.collect_times()
+
+    def build_acc(self, gaussians, rebuild=True):
+        pass  # no-op for 3DGUT (tracer.py:301-302)
+
+    def render(self, gaussians, gpu_batch, train=False, frame_id=0):
+        rays_o = gpu_batch.rays_ori if not isinstance(gpu_batch, dict) else gpu_batch["rays_ori"]
+        rays_d = gpu_batch.rays_dir if not isinstance(gpu_batch, dict) else gpu_batch["rays_dir"]
+        cam, pose_start, pose_end = camera_from_batch(gpu_batch)
+        H, W = int(rays_o.shape[1]), int(rays_o.shape[2])
+        native = self.tracer_wrapper
+        frame = native.make_frame(frame_id, gaussians.n_active_features, gaussians.num_gaussians, H, W, cam, pose_start, pose_end)
+        feats = gaussians.get_features()
+        if feats.shape[1] != 3 * native.ncoef:
+            raise ValueError(f"features have {feats.shape[1]} columns, expected {3 * native.ncoef} for SH degree "
+                             f"{native.cfg.particle_radiance_sph_degree}")
+        pred_features_alpha, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
+            native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(),
+            gaussians.positions.contiguous(), gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(),
+            gaussians.get_density().contiguous(), feats.contiguous())
+        d = getattr(gaussians, "ray_feature_dim", 3)
+        pred_features = pred_features_alpha[..., :d].unsqueeze(0).contiguous()
+        pred_opacity = pred_features_alpha[..., d:].unsqueeze(0).contiguous()
+        timings = native.collect_times()
+        return {
+            "pred_features": pred_features,
+            "pred_opacity": pred_opacity,
+            "pred_dist": pred_dist.unsqueeze(0).contiguous(),
+            "pred_normals": torch.nn.functional.normalize(torch.ones_like(pred_features), dim=3),
+            "hits_count": hits_count.unsqueeze(0).contiguous(),
+            "frame_time_ms": timings["forward_render"] if "forward_render" in timings else 0.0,
+            "mog_visibility": mog_visibility,
+        }

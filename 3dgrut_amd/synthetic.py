@@ -139,3 +139,51 @@ def upstream_grads(width: int, height: int, seed: int = 7):
     g_fd = (rng.normal(0.0, 1.0, (height, width, 4)) / p).astype(np.float32)
     g_dist = np.zeros((height, width, 1), np.float32)
     return g_fd, g_dist
+
+
+class SimpleGaussians:
+    """Minimal stand-in for MixtureOfGaussians' renderer-facing surface (threedgrut/model/model.py:50-118):
+    activated tensors are stored directly as leaf tensors so tests / bench can read `.grad` on them."""
+
+    def __init__(self, density12, sph, device="cuda", n_active_features=3, requires_grad=True):
+        import torch
+        d = torch.as_tensor(density12, dtype=torch.float32, device=device)
+        self.positions = d[:, 0:3].clone().requires_grad_(requires_grad)
+        self._density = d[:, 3:4].clone().requires_grad_(requires_grad)
+        self._rotation = d[:, 4:8].clone().requires_grad_(requires_grad)
+        self._scale = d[:, 8:11].clone().requires_grad_(requires_grad)
+        self._features = torch.as_tensor(sph, dtype=torch.float32, device=device).clone().requires_grad_(requires_grad)
+        self.n_active_features = n_active_features
+        self.ray_feature_dim = 3
+
+    @property
+    def num_gaussians(self):
+        return self.positions.shape[0]
+
+    def get_rotation(self):
+        return self._rotation
+
+    def get_scale(self):
+        return self._scale
+
+    def get_density(self):
+        return self._density
+
+    def get_features(self):
+        return self._features
+
+    def parameters(self):
+        return [self.positions, self._rotation, self._scale, self._density, self._features]
+
+    def zero_grad(self):
+        for p in self.parameters():
+            p.grad = None
+
+    def grads_packed(self):
+        """(grad [N,12] in the packed layout, grad_sph [N,3*ncoef]) as numpy."""
+        import torch
+        n = self.num_gaussians
+        z = torch.zeros((n, 1), device=self.positions.device)
+        g = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.parameters()]
+        packed = torch.cat([g[0], g[3], g[1], g[2], z], dim=1)
+        return packed.detach().cpu().numpy(), g[4].detach().cpu().numpy()

@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py — train rays/s of the 3DGUT hot path (forward + backward of one view per GPU per step).
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched
+under torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+
+Workload: BASELINE.json's metric config — 1M synthetic "trained-like" Gaussians (SURVEY §8d cloud B), pinhole
+camera with the Lego field of view on a radius-4 orbit, 1920x1080, SH degree 3, default 3dgut.yaml flags.
+Each rank renders its own view (weak scaling); for N>1 the packed Gaussian gradients are sum-all-reduced
+over RCCL every step (the path's one exchange step).
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+WORKLOADS = {
+    # name: (num_gaussians, width, height, median_scale)
+    "c4_1m_1080p": (1_000_000, 1920, 1080, 0.01),
+    "c2_1m_800": (1_000_000, 800, 800, 0.01),
+    "c1_100k_400": (100_000, 400, 400, 0.01),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+
+
+def byte_model(N, Nv, I, P, tile_bits, sph_coeffs=16):
+    """Algorithmic bytes per launch of each stage (with this design's key widths)."""
+    sh = sph_coeffs * 12
+    return {
+        "project": N * (48 + 4 + 56) + Nv * sh,
+        "depth_sort": N * 4 * (4 + 16),                      # 4 passes x (hist read 4 B + pairs in/out 16 B)
+        "scan": N * 8,
+        "expand": N * 44 + I * 8,
+        "tile_sort": I * ((tile_bits + 7) // 8) * (4 + 16),
+        "tile_ranges": I * 4,
+        "render_fwd": I * (4 + 48 + 12) + P * (24 + 24),
+        "render_bwd": I * (4 + 48 + 12) + I * 112 + P * (24 + 16 + 4 + 16 + 4),
+        "project_bwd": Nv * (12 + 48 + sh + sh + 12) + (N - Nv) * sh,
+    }
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """Oracle (CPU restatement of the reference) on a bounded sample: C1-sized frames, fwd+bwd."""
+    import oracle
+    from scenes import make_scene
+    syn = importlib.import_module("3dgrut_amd.synthetic")
+    n, w, h, ms = WORKLOADS["c1_100k_400"]
+    scene = make_scene(n=n, width=w, height=h, median_scale=ms)
+    cfg = oracle.default_gut_config()
+    g_fd, g_dist = syn.upstream_grads(w, h)
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    t0 = time.time()
+    frames = 0
+    while True:
+        fwd = oracle.gut_forward(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], 3, scene["density12"], scene["sph"], *scene["rays"])
+        oracle.gut_backward(cfg, scene["cam"], 3, fwd, g_fd, g_dist)
+        frames += 1
+        if time.time() - t0 > seconds_budget * 0.5 or frames >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": frames * w * h / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{frames} fwd+bwd frames of {n} Gaussians at {w}x{h} (config C1) through the C oracle, OpenMP over pixels"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c4_1m_1080p", choices=list(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    syn = importlib.import_module("3dgrut_amd.synthetic")
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    abi = importlib.import_module("3dgrut_amd._abi")
+    from scenes import torch_batch
+
+    n, W, H, ms = WORKLOADS[args.workload]
+    d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=ms)
+    K = syn.pinhole_intrinsics(W, H)
+    ro, rd = syn.pinhole_rays(W, H, K)
+    batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(rank, n_views=max(world, 8))[None], intrinsics=K), dev)
+    tracer = gt.Tracer({"render": {"splat": {}}})
+    nat = tracer.tracer_wrapper
+    g = syn.SimpleGaussians(d12, sph, device=dev)
+    g_fd_np, g_dist_np = syn.upstream_grads(W, H)
+    g_fd = torch.as_tensor(g_fd_np, device=dev)
+    g_dist = torch.as_tensor(g_dist_np, device=dev)
+    flat = None
+
+    def step():
+        nonlocal flat
+        g.zero_grad()
+        out = tracer.render(g, batch, train=True)
+        fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
+        torch.autograd.backward([fd, out["pred_dist"][0]], [g_fd, g_dist])
+        if world > 1:  # one fused all-reduce of all Gaussian gradients ([N,59] fp32)
+            grads = [p.grad for p in g.parameters()]
+            flat = torch.cat([x.reshape(-1) for x in grads])
+            dist.all_reduce(flat)
+
+    for _ in range(args.warmup):
+        step()
+    abi.check(nat.lib.gut_profile_enable(nat.handle, 1), "gut_profile_enable")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    stage_ms = (C.c_float * len(abi.GUT_STAGES))()
+    abi.check(nat.lib.gut_profile_read(nat.handle, stage_ms), "gut_profile_read")
+    st = nat.stats()
+    if rank == 0:
+        P = W * H
+        stages = {k: float(stage_ms[i]) for i, k in enumerate(abi.GUT_STAGES)}
+        model = byte_model(int(st.num_particles), int(st.num_visible), int(st.num_intersections), P, int(st.key_bits))
+        dom = max(stages, key=lambda k: stages[k])
+        achieved = model[dom] / (stages[dom] * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        total_bytes = sum(model.values())
+        result = {
+            "metric": "train rays/sec (3DGUT forward+backward, primary rays)",
+            "value": world * P * args.steps / dt,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"3DGUT fwd+bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "
+                                   f"SH degree 3, k_buffer 0", "name": args.workload,
+                       "parallelism": f"view-dp{world}" + (" + RCCL grad all-reduce" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": f"gut_{dom}", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes": model[dom], "kernel_ms": stages[dom]},
+            "stages_ms": stages,
+            "stage_bytes": model,
+            "frame_algorithmic_gb": total_bytes / 1e9,
+            "frame_hbm_frac": (total_bytes / (dt / args.steps)) / 1e9 / HBM_PEAK_GBS,
+            "work": {"N": int(st.num_particles), "Nv": int(st.num_visible), "I": int(st.num_intersections), "P": P,
+                     "tiles": int(st.num_tiles), "tile_key_bits": int(st.key_bits)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -146,6 +146,14 @@ int gut_backward(GutHandle* handle, void* stream, const GutFrame* frame,
 int gut_timings(GutHandle* handle, float* forward_ms, float* backward_ms);
 int gut_stats(GutHandle* handle, GutStats* stats);
 
+/* Per-stage device time (hipEvents on the launch stream), for the roofline report.  While enabled, every
+ * gut_forward / gut_backward brackets each stage with an event pair; gut_profile_read synchronises, returns the
+ * average ms per stage since the last read (-1 where a stage did not run) and resets the accumulators. */
+enum { GUT_STAGE_PROJECT = 0, GUT_STAGE_DEPTH_SORT, GUT_STAGE_SCAN, GUT_STAGE_EXPAND, GUT_STAGE_TILE_SORT,
+       GUT_STAGE_TILE_RANGES, GUT_STAGE_RENDER_FWD, GUT_STAGE_RENDER_BWD, GUT_STAGE_PROJECT_BWD, GUT_NUM_STAGES };
+int gut_profile_enable(GutHandle* handle, int enable);
+int gut_profile_read(GutHandle* handle, float* stage_ms /* [GUT_NUM_STAGES] */);
+
 /* ---- stage-level entry points (parity tests drive each stage alone) ------ */
 /* Stable LSD radix sort of (key,value) pairs on key bits [begin_bit,end_bit). tmp buffers sized n. */
 int grut_sort_pairs_u32(void* stream, uint32_t n, int begin_bit, int end_bit,
