@@ -158,6 +158,9 @@ def load_library(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     p = path or os.environ.get("GRUT_AMD_LIB", LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64; it must be resident first so that this library
+    # binds to the same HIP runtime (same device context, streams and allocations) instead of a second copy.
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise RuntimeError(
             f"3dgrut_amd: HIP library not found at {p}. Build it with "

