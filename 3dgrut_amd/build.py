@@ -18,6 +18,8 @@ OUT = os.path.join(CSRC, "libgrut_amd.so")
 SOURCES = ["scan_sort.hip", "gut_kernels.hip", "gut_api.hip", "grt_api.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast",
+         # SLP-packing scalar f32 math into v_pk_*_f32 costs register-pair shuffles (v_mov) and VGPRs on gfx950
+         "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 

@@ -205,6 +205,39 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 -> rows 2,3
     return v;
 }
+// ---- wave64 reduce-scatter of 16 values ------------------------------------------------------
+// In: every lane holds v[0..15].  Out: lane l returns the sum over ALL 64 lanes of v[l & 15].
+// Four DPP butterfly steps inside each 16-lane row (row_mirror, row_half_mirror, quad xor 2, quad xor 1;
+// each lane keeps the half of its values selected by one lane-id bit and adds its partner's copy of the
+// same half: 8+4+2+1 DPP adds instead of 16 x 6), then two cross-row exchanges of the single survivor.
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_reduce_scatter16(const float (&v)[16], int lane) {
+    const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
+    float w[8], x[4], y[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float keep = b3 ? v[8 + i] : v[i], send = b3 ? v[i] : v[8 + i];
+        w[i] = keep + dpp_perm<0x140>(send);  // row_mirror: partner = lane ^ 15
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float keep = b2 ? w[4 + i] : w[i], send = b2 ? w[i] : w[4 + i];
+        x[i] = keep + dpp_perm<0x141>(send);  // row_half_mirror: partner = lane ^ 7
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const float keep = b1 ? x[2 + i] : x[i], send = b1 ? x[i] : x[2 + i];
+        y[i] = keep + dpp_perm<0x4E>(send);   // quad_perm [2,3,0,1]: partner = lane ^ 2
+    }
+    float z = (b0 ? y[1] : y[0]) + dpp_perm<0xB1>(b0 ? y[0] : y[1]);  // quad_perm [1,0,3,2]: partner = lane ^ 1
+    z += __shfl_xor(z, 16, 64);
+    z += __shfl_xor(z, 32, 64);
+    return z;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v = wave_sum_to_lane63(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));

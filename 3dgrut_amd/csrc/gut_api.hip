@@ -34,6 +34,8 @@ struct GutHandle {
     DeviceBuffer g_rgb;
     // per-intersection scratch
     DeviceBuffer tile_keys, tile_vals, tile_keys_tmp, tile_vals_tmp, tile_sort_scratch, ranges;
+    DeviceBuffer ck_tc, ck_d, ck_reached, ck_boundary_tile;
+    GutCheckpoints checkpoints;
     uint32_t* host_counters = nullptr;  // pinned: [0] = I (last offset), [1] = Nv
     hipEvent_t count_event = nullptr;
     // forward context consumed by backward (role of GutRenderForwardContext)
@@ -142,6 +144,16 @@ static int ensure_intersection_scratch(GutHandle* h, uint32_t I, uint32_t tiles)
     GRUT_CHECK(h->tile_vals_tmp.ensure(n * 4, 1.3f));
     GRUT_CHECK(h->tile_sort_scratch.ensure(sort_scratch_bytes((uint32_t)n), 1.3f));
     GRUT_CHECK(h->ranges.ensure((size_t)tiles * 8 + 8));
+    const size_t nb = (size_t)I / kGutSegment + 1;
+    GRUT_CHECK(h->ck_tc.ensure(nb * 4 * 64 * 16, 1.3f));
+    GRUT_CHECK(h->ck_d.ensure(nb * 4 * 64 * 4, 1.3f));
+    GRUT_CHECK(h->ck_reached.ensure(nb * 4, 1.3f));
+    GRUT_CHECK(h->ck_boundary_tile.ensure(nb * 4, 1.3f));
+    h->checkpoints.tc = h->ck_tc.as<float4>();
+    h->checkpoints.d = h->ck_d.as<float>();
+    h->checkpoints.reached = h->ck_reached.as<uint8_t>();
+    h->checkpoints.boundary_tile = h->ck_boundary_tile.as<uint32_t>();
+    h->checkpoints.num_boundaries = (uint32_t)nb;
     return GRUT_OK;
 }
 
@@ -189,7 +201,8 @@ void gut_destroy(GutHandle* h) {
     DeviceBuffer* bufs[] = {&h->tiles_count, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->rgb, &h->depth_key,
                             &h->particle_idx, &h->depth_key_tmp, &h->particle_idx_tmp, &h->offsets, &h->sort_scratch,
                             &h->scan_scratch, &h->counters, &h->g_rgb, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
-                            &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges};
+                            &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges, &h->ck_tc, &h->ck_d, &h->ck_reached,
+                            &h->ck_boundary_tile};
     for (DeviceBuffer* b : bufs) b->release();
     if (h->host_counters) (void)hipHostFree(h->host_counters);
     if (h->count_event) (void)hipEventDestroy(h->count_event);
@@ -290,12 +303,13 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     // K6 tile ranges
     GRUT_HIP(hipMemsetAsync(h->ranges.ptr, 0, (size_t)tiles * 8, s));
     const uint32_t tile_mask = (h->stats.key_bits >= 32) ? 0xFFFFFFFFu : ((1u << h->stats.key_bits) - 1u);
-    launch_tile_ranges(s, I, tile_mask, tiles, sorted_tiles, h->ranges.as<uint32_t>());
+    GRUT_HIP(hipMemsetAsync(h->ck_reached.ptr, 0, (size_t)h->checkpoints.num_boundaries * 4, s));
+    launch_tile_ranges(s, I, tile_mask, tiles, sorted_tiles, h->ranges.as<uint32_t>(), h->checkpoints.boundary_tile);
     GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_RANGES, s, slot));
     // K7 compositing
     GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_FWD, s, slot));
     launch_render_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, particle_density, proj.rgb, ray_origin, ray_direction,
-                      out_feat_density, out_hit_distance, out_hit_count);
+                      out_feat_density, out_hit_distance, out_hit_count, h->checkpoints, true);
     GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_FWD, s, slot));
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
@@ -315,8 +329,8 @@ int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float
     const GutParams& P = h->params;
     GRUT_REQUIRE(frame->num_particles == P.N && frame->width == P.W && frame->height == P.H, "gut_backward: frame differs from the forward frame");
     if (P.N == 0) return GRUT_OK;
-    GRUT_REQUIRE(particle_density && particle_sph && feat_density && grad_feat_density && hit_distance && grad_hit_distance &&
-                     grad_particle_density && grad_particle_sph, "gut_backward: null buffer");
+    GRUT_REQUIRE(particle_density && particle_sph && feat_density && grad_feat_density && hit_distance && grad_particle_density &&
+                     grad_particle_sph, "gut_backward: null buffer");  // grad_hit_distance may be NULL (no depth gradient)
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
     const GutProjected proj = projected_view(h);
     GRUT_CHECK(h->g_rgb.ensure((size_t)P.N * 12, 1.25f));
@@ -325,7 +339,8 @@ int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float
     if (h->num_intersections > 0) {
         GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_BWD, s, slot));
         launch_render_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_particle_idx, particle_density, proj.rgb, ray_origin, ray_direction,
-                          feat_density, grad_feat_density, hit_distance, grad_hit_distance, grad_particle_density, h->g_rgb.as<float>());
+                          feat_density, grad_feat_density, hit_distance, grad_hit_distance, grad_particle_density, h->g_rgb.as<float>(),
+                          h->checkpoints);
         GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_BWD, s, slot));
     }
     GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));

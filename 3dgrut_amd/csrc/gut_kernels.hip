@@ -11,6 +11,8 @@
 //     waves), and terminates per wave by ballot;
 //   * the gradient sweep reduces each particle's 14 gradient terms over the wave with DPP adds and
 //     flushes one atomic set per (strip, particle-with-hit) from an LDS accumulator.
+#include <cstdlib>
+
 #include "gut_internal.hpp"
 
 namespace grut {
@@ -287,11 +289,14 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
 // K6: tile ranges — computeSortedTileRangeIndices (gutRenderer.cu:46-76)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gut_tile_ranges_kernel(uint32_t n, uint32_t tile_mask, uint32_t num_tiles,
-                                                              const uint32_t* __restrict__ sorted_tile_keys, uint2* __restrict__ ranges) {
+                                                              const uint32_t* __restrict__ sorted_tile_keys, uint2* __restrict__ ranges,
+                                                              uint32_t* __restrict__ boundary_tile) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t t = sorted_tile_keys[k] & tile_mask;
     const bool valid = t < num_tiles;
+    // segment boundary b sits at sorted index b * kGutSegment; remember which tile's list it cuts
+    if ((k % kGutSegment) == 0) boundary_tile[k / kGutSegment] = valid ? t : 0xFFFFFFFFu;
     if (k == 0) {
         if (valid) ranges[t].x = 0;
     } else {
@@ -355,19 +360,22 @@ __device__ __forceinline__ bool strip_mapping(uint32_t b, uint32_t num_tiles, ui
     return tile < num_tiles;
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // K7: compositing forward — GUTKBufferRenderer::evalKBuffer, K = 0 (gutKBufferRenderer.cuh:273-352)
 // one wave64 = 16x4 pixels; LDS record per staged tile entry: 5 x float4
 //   q0 = M.r0, pos.x | q1 = M.r1, pos.y | q2 = M.r2, pos.z | q3 = scale.xyz, density | q4 = rgb(clamped), -
 //   with M = diag(1/scale) * R^T  (canonical-space transform, gaussianParticles.slang:96-110)
+// Staging rounds are aligned to multiples of 64 in the global sorted list, so every segment boundary
+// (multiple of kGutSegment) is a round start, where the running state is checkpointed for the gradient sweep.
 // ---------------------------------------------------------------------------------------------
-template <int DEG>
+template <int DEG, bool CKPT>
 __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges,
                                                             const uint32_t* __restrict__ sorted_idx,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                             float4* __restrict__ out_fd, float* __restrict__ out_dist,
-                                                            float* __restrict__ out_cnt) {
+                                                            float* __restrict__ out_cnt, GutCheckpoints ck) {
     __shared__ float4 s_rec[64 * 5];
     uint32_t tile, strip;
     if (!strip_mapping(blockIdx.x, P.gx * P.gy, tile, strip)) return;
@@ -381,22 +389,30 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
     float T = 1.f, D = 0.f, Cr = 0.f, Cg = 0.f, Cb = 0.f;
     uint32_t cnt = 0;
 
-    for (uint32_t b = range.x; b < range.y; b += 64) {
+    uint32_t b = range.x;
+    while (b < range.y) {
         if (!__any(alive)) break;
-        {   // stage 64 entries
+        const uint32_t bend = min(range.y, (b & ~63u) + 64u);
+        if (CKPT && b > range.x && (b % kGutSegment) == 0) {
+            const size_t slot = ((size_t)(b / kGutSegment) * 4 + strip) * 64 + lane;
+            ck.tc[slot] = make_float4(alive ? T : 0.f, Cr, Cg, Cb);  // dead lanes restart dead (T = 0 < min_transmittance)
+            ck.d[slot] = D;
+            if (lane == 0) ck.reached[(size_t)(b / kGutSegment) * 4 + strip] = 1;
+        }
+        {   // stage up to 64 entries
             const uint32_t e = b + lane;
             float4 q0, q1, q2, q3, q4;
             q0 = q1 = q2 = make_float4(0.f, 0.f, 0.f, 0.f);
             q3 = make_float4(1.f, 1.f, 1.f, 0.f);
             q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < range.y) {
+            if (e < bend) {
                 const uint32_t idx = sorted_idx[e];
                 if (idx != 0xFFFFFFFFu) {
                     const float4 a = density12[3 * (size_t)idx + 0];
                     const float4 q = density12[3 * (size_t)idx + 1];
                     const float4 s = density12[3 * (size_t)idx + 2];
                     const m3 rt = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
-                    const float ix = 1.f / s.x, iy = 1.f / s.y, iz = 1.f / s.z;
+                    const float ix = __builtin_amdgcn_rcpf(s.x), iy = __builtin_amdgcn_rcpf(s.y), iz = __builtin_amdgcn_rcpf(s.z);
                     q0 = make_float4(rt.r0.x * ix, rt.r0.y * ix, rt.r0.z * ix, a.x);
                     q1 = make_float4(rt.r1.x * iy, rt.r1.y * iy, rt.r1.z * iy, a.y);
                     q2 = make_float4(rt.r2.x * iz, rt.r2.y * iz, rt.r2.z * iz, a.z);
@@ -409,7 +425,7 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
             s_rec[lane * 5 + 3] = q3; s_rec[lane * 5 + 4] = q4;
         }
         __syncthreads();  // single-wave workgroup: orders the LDS hand-off
-        const int n = (int)min(64u, range.y - b);
+        const int n = (int)(bend - b);
         for (int j = 0; j < n; ++j) {
             if (!alive) continue;
             const float4 q0 = s_rec[j * 5 + 0], q1 = s_rec[j * 5 + 1], q2 = s_rec[j * 5 + 2], q3 = s_rec[j * 5 + 3];
@@ -439,6 +455,7 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
             }
         }
         __syncthreads();
+        b = bend;
     }
     if (ray.valid) {
         const size_t pix = (size_t)py * P.W + px;
@@ -452,35 +469,75 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
 // K8: compositing backward — evalBackwardNoKBuffer SH branch (gutKBufferRenderer.cuh:642-716) with
 // processHitBwd (models/gaussianParticles.cuh:484-751).  LDS record: 7 x float4
 //   q0 = rotT.r0, pos.x | q1 = rotT.r1, pos.y | q2 = rotT.r2, pos.z | q3 = scale.xyz, density
-//   q4 = quat wxyz      | q5 = rgb(clamped), as_float(idx) | q6 = 1/scale.xyz, -
+//   q4 = 2 * quat wxyz  | q5 = rgb(clamped), as_float(idx) | q6 = 1/scale.xyz, -
+//
+// Per hit every lane produces 14 terms that are summed over the wave (wave_reduce_scatter16) and flushed with
+// one atomic set per (strip, particle-with-hit):
+//   B[3]   = d L / d (R^T (o - mu))            -> position gradient = -R B      (applied once, at flush)
+//   dn     = d L / d density
+//   dq[4]  = d L / d quaternion (w,x,y,z)
+//   S[3]   with scale gradient = -S / scale                                     (applied once, at flush)
+//   dc[3]  = d L / d (clamped particle radiance)
+//
+// With u = gro, v = grdu, n = v/|v|:  grayDist = |n x u|^2 = |u|^2 - (n.u)^2, hence
+//   d gray / d u = 2 a,   d gray / d v = 2 beta a,   a = u - (n.u) n,   beta = -(n.u)/|v|
+// i.e. every geometric gradient that flows through grayDist is a multiple of the single vector a.  The reference's
+// chain (two cross-product backward passes, safe_normalize_bw, two matmul_bw_quat) collapses to one rank-1
+// contraction  d rotT = (giscl*a) (x) (gposc + beta d)  — same mathematics, ~4x fewer instructions.  When a depth
+// gradient flows in (HAS_GDIST) the hit-distance terms are added in their generic form.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void quat_bw(f3 p, f3 g, float4 q, float& dr, float& dx, float& dy, float& dz) {
-    // matmul_bw_quat (mathUtils.cuh:458-521): accumulates into dr,dx,dy,dz
-    const f3 d0 = p * g.x, d1 = p * g.y, d2 = p * g.z;
-    const float r = q.x, x = q.y, y = q.z, z = q.w;
-    dy += -4.f * y * d0.x; dz += -4.f * z * d0.x;
-    dr += 2.f * z * d0.y; dx += 2.f * y * d0.y; dy += 2.f * x * d0.y; dz += 2.f * r * d0.y;
-    dr += -2.f * y * d0.z; dx += 2.f * z * d0.z; dy += -2.f * r * d0.z; dz += 2.f * x * d0.z;
-    dr += -2.f * z * d1.x; dx += 2.f * y * d1.x; dy += 2.f * x * d1.x; dz += -2.f * r * d1.x;
-    dx += -4.f * x * d1.y; dz += -4.f * z * d1.y;
-    dr += 2.f * x * d1.z; dx += 2.f * r * d1.z; dy += 2.f * z * d1.z; dz += 2.f * y * d1.z;
-    dr += 2.f * y * d2.x; dx += 2.f * z * d2.x; dy += 2.f * r * d2.x; dz += 2.f * x * d2.x;
-    dr += -2.f * x * d2.y; dx += -2.f * r * d2.y; dy += 2.f * z * d2.y; dz += 2.f * y * d2.y;
-    dx += -4.f * x * d2.z; dy += -4.f * y * d2.z;
+// gradient of sum_ij b_i e_j rotT_ij(q) w.r.t. q = (r,x,y,z); q2 = 2q (matmul_bw_quat, mathUtils.cuh:458-521)
+__device__ __forceinline__ void quat_contract(f3 b, f3 e, float4 q2, float& dr, float& dx, float& dy, float& dz) {
+    const float r = q2.x, x = q2.y, y = q2.z, z = q2.w;
+    const float m00 = b.x * e.x, m01 = b.x * e.y, m02 = b.x * e.z;
+    const float m10 = b.y * e.x, m11 = b.y * e.y, m12 = b.y * e.z;
+    const float m20 = b.z * e.x, m21 = b.z * e.y, m22 = b.z * e.z;
+    // rotT = [[1-2(yy+zz), 2(xy+rz), 2(xz-ry)], [2(xy-rz), 1-2(xx+zz), 2(yz+rx)], [2(xz+ry), 2(yz-rx), 1-2(xx+yy)]]
+    const float s01 = m01 + m10, s02 = m02 + m20, s12 = m12 + m21;   // symmetric parts
+    const float a01 = m01 - m10, a02 = m20 - m02, a12 = m12 - m21;   // antisymmetric parts (signs as in rotT)
+    dr += z * a01 + y * a02 + x * a12;
+    dx += y * s01 + z * s02 + r * a12 - 2.f * x * (m11 + m22);
+    dy += x * s01 + z * s12 + r * a02 - 2.f * y * (m00 + m22);
+    dz += x * s02 + y * s12 + r * a01 - 2.f * z * (m00 + m11);
 }
 
-template <int DEG>
+template <int DEG, bool HAS_GDIST, bool COUNT = false>
 __global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const uint2* __restrict__ ranges,
                                                             const uint32_t* __restrict__ sorted_idx,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                             const float4* __restrict__ fd, const float4* __restrict__ g_fd,
                                                             const float* __restrict__ dist, const float* __restrict__ g_dist,
-                                                            float* __restrict__ g_density12, float* __restrict__ g_rgb) {
-    __shared__ float4 s_rec[64 * 7];
-    __shared__ float4 s_acc[64 * 4];  // per staged entry: 14 reduced gradient terms (+2 pad)
-    uint32_t tile, strip;
-    if (!strip_mapping(blockIdx.x, P.gx * P.gy, tile, strip)) return;
+                                                            float* __restrict__ g_density12, float* __restrict__ g_rgb,
+                                                            GutCheckpoints ck, unsigned long long* __restrict__ counters = nullptr) {
+    // 32 staged entries per round: 5.5 KB of LDS per wave keeps ~7 waves per SIMD resident (the sweep is
+    // latency-bound at 3-4 waves per SIMD: rocprofv3 showed 45% SQ_WAIT_INST_ANY with 64-entry rounds)
+    constexpr uint32_t kBatch = 32;
+    __shared__ float4 s_rec[kBatch * 7];
+    __shared__ float s_acc[kBatch * 16];  // per staged entry: 14 wave-reduced terms (+2 pad)
+    // task = (virtual tile, strip): virtual tiles [0, tilesPad) are the first segment of each tile list, virtual tile
+    // tilesPad + b is the segment starting at segment boundary b (sorted index b * kGutSegment)
+    const uint32_t num_tiles = (uint32_t)(P.gx * P.gy), tiles_pad = (num_tiles + 7u) & ~7u;
+    uint32_t vtile, strip;
+    (void)strip_mapping(blockIdx.x, 0xFFFFFFFFu, vtile, strip);
+    uint32_t tile, seg_begin;
+    bool from_checkpoint = false;
+    uint32_t boundary = 0;
+    if (vtile < tiles_pad) {
+        tile = vtile;
+        if (tile >= num_tiles) return;
+        seg_begin = ranges[tile].x;
+    } else {
+        boundary = vtile - tiles_pad;
+        if (boundary == 0 || boundary >= ck.num_boundaries) return;
+        tile = ck.boundary_tile[boundary];
+        if (tile >= num_tiles) return;
+        seg_begin = boundary * kGutSegment;
+        if (seg_begin <= ranges[tile].x) return;                     // the boundary is this tile's own list start
+        if (!ck.reached[(size_t)boundary * 4 + strip]) return;       // the forward sweep never got here alive
+        from_checkpoint = true;
+    }
+    const uint32_t seg_end = min(ranges[tile].y, (seg_begin / kGutSegment + 1u) * kGutSegment);
     const int lane = threadIdx.x;
     const int px = (int)(tile % P.gx) * 16 + (lane & 15);
     const int py = (int)(tile / P.gx) * 16 + (int)strip * 4 + (lane >> 4);
@@ -495,20 +552,28 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const u
         const float4 f = fd[pix], g = g_fd[pix];
         C_fin = mk3(f.x, f.y, f.z); gC = mk3(g.x, g.y, g.z);
         T_fin = 1.f - f.w; gT = -g.w;
-        D_fin = dist[pix]; gD = g_dist[pix];
+        if (HAS_GDIST) { D_fin = dist[pix]; gD = g_dist[pix]; }
     }
-    const uint2 range = ranges[tile];
+    if (from_checkpoint) {
+        const size_t slot = ((size_t)boundary * 4 + strip) * 64 + lane;
+        const float4 c = ck.tc[slot];
+        T = c.x; Cr = c.y; Cg = c.z; Cb = c.w;
+        if (HAS_GDIST) D = ck.d[slot];
+        alive = alive && !(T < P.min_transmittance);
+    }
 
-    for (uint32_t b = range.x; b < range.y; b += 64) {
+    uint32_t b = seg_begin;
+    while (b < seg_end) {
         if (!__any(alive)) break;
-        {
+        const uint32_t bend = min(seg_end, (b & ~(kBatch - 1u)) + kBatch);
+        if (lane < (int)kBatch) {
             const uint32_t e = b + lane;
             float4 q0, q1, q2, q3, q4, q5, q6;
             q0 = q1 = q2 = q4 = make_float4(0.f, 0.f, 0.f, 0.f);
             q3 = make_float4(1.f, 1.f, 1.f, 0.f);
             q5 = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
             q6 = make_float4(1.f, 1.f, 1.f, 0.f);
-            if (e < range.y) {
+            if (e < bend) {
                 const uint32_t idx = sorted_idx[e];
                 if (idx != 0xFFFFFFFFu) {
                     const float4 a = density12[3 * (size_t)idx + 0];
@@ -519,22 +584,22 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const u
                     q1 = make_float4(rt.r1.x, rt.r1.y, rt.r1.z, a.y);
                     q2 = make_float4(rt.r2.x, rt.r2.y, rt.r2.z, a.z);
                     q3 = make_float4(s.x, s.y, s.z, a.w);
-                    q4 = q;
+                    q4 = make_float4(2.f * q.x, 2.f * q.y, 2.f * q.z, 2.f * q.w);
                     q5 = make_float4(fmaxf(rgb[3 * (size_t)idx], 0.f), fmaxf(rgb[3 * (size_t)idx + 1], 0.f),
                                      fmaxf(rgb[3 * (size_t)idx + 2], 0.f), __uint_as_float(idx));
-                    q6 = make_float4(1.f / s.x, 1.f / s.y, 1.f / s.z, 0.f);
+                    q6 = make_float4(__builtin_amdgcn_rcpf(s.x), __builtin_amdgcn_rcpf(s.y), __builtin_amdgcn_rcpf(s.z), 0.f);
                 }
             }
             float4* r = &s_rec[lane * 7];
             r[0] = q0; r[1] = q1; r[2] = q2; r[3] = q3; r[4] = q4; r[5] = q5; r[6] = q6;
         }
         __syncthreads();
-        const int n = (int)min(64u, range.y - b);
-        unsigned long long hit_entries = 0ull;  // wave-uniform: staged entries with >= 1 hit in this wave
+        const int n = (int)(bend - b);
+        uint32_t hit_entries = 0u;  // wave-uniform: staged entries with >= 1 hit in this wave
         for (int j = 0; j < n; ++j) {
             if (!__any(alive)) break;
-            float g_px = 0.f, g_py = 0.f, g_pz = 0.f, g_dn = 0.f, g_qr = 0.f, g_qx = 0.f, g_qy = 0.f, g_qz = 0.f;
-            float g_sx = 0.f, g_sy = 0.f, g_sz = 0.f, g_cr = 0.f, g_cg = 0.f, g_cb = 0.f;
+            float t_bx = 0.f, t_by = 0.f, t_bz = 0.f, t_dn = 0.f, t_qr = 0.f, t_qx = 0.f, t_qy = 0.f, t_qz = 0.f;
+            float t_sx = 0.f, t_sy = 0.f, t_sz = 0.f, t_cr = 0.f, t_cg = 0.f, t_cb = 0.f;
             bool hit = false;
             if (alive) {
                 const float4* rec = &s_rec[j * 7];
@@ -543,112 +608,109 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const u
                 const f3 gscl = mk3(q3.x, q3.y, q3.z), giscl = mk3(q6.x, q6.y, q6.z);
                 const float dens = q3.w;
                 const f3 gposc = ray.o - mk3(q0.w, q1.w, q2.w);
-                const f3 gposcr = mul_rows(rotT, gposc);
-                const f3 gro = giscl * gposcr;
-                const f3 rdr = mul_rows(rotT, ray.d);
-                const f3 grdu = giscl * rdr;
-                const float l2 = dot(grdu, grdu);
+                const f3 u = giscl * mul_rows(rotT, gposc);           // gro
+                const f3 v = giscl * mul_rows(rotT, ray.d);           // grdu
+                const float l2 = dot(v, v);
                 const float il = l2 > 0.f ? __builtin_amdgcn_rsqf(l2) : 1.f;  // safe_normalize
-                const f3 grd = grdu * il;
-                const f3 gcrod = cross(grd, gro);
-                const float gray = dot(gcrod, gcrod);
+                const f3 nrm = v * il;                                 // grd
+                const float nu = dot(nrm, u);
+                const f3 avec = u - nrm * nu;                          // component of u orthogonal to the ray
+                const float gray = dot(avec, avec);                    // == |grd x gro|^2
                 const float gres = particle_response<DEG>(gray);
                 const float galpha = fminf(P.max_alpha, gres * dens);
                 if ((gres > P.min_response) && (galpha > P.min_alpha)) {
                     hit = true;
                     const float4 q4 = rec[4], q5 = rec[5];
                     const f3 feat = mk3(q5.x, q5.y, q5.z);
-                    const float pdot = -dot(grd, gro);
-                    const f3 grdd = grd * pdot;
-                    const f3 grds = gscl * grdd;
-                    const float gsq = dot(grds, grds);
-                    const float gdist = __builtin_amdgcn_sqrtf(gsq);
                     const float weight = galpha * T;
                     const float nextT = (1.f - galpha) * T;
                     const float inextT = nextT <= P.min_transmittance ? 0.f : __builtin_amdgcn_rcpf(nextT);
-
-                    D = fmaf(weight, gdist, D);
-                    const float resHitT = fmaxf((D_fin - D) * inextT, 0.f);
-                    const float galphaRayHitGrd = (gdist - resHitT) * T * gD;
-                    const f3 grdsRayHitGrd = gsq > 0.f ? grds * (weight * __builtin_amdgcn_rcpf(gdist) * gD) : mk3(0.f, 0.f, 0.f);
-                    const f3 gsclRayHitGrd = grdd * grdsRayHitGrd;
-                    const float grdScaledDot = dot(grdsRayHitGrd * gscl, grd);
-                    const f3 grdRayHitGrd = (gscl * grdsRayHitGrd) * pdot - gro * grdScaledDot;
-                    const f3 groRayHitGrd = grd * (-grdScaledDot);
-
                     const float resTrm = galpha < 0.999999f ? T_fin * __builtin_amdgcn_rcpf(1.f - galpha) : T;
-                    const float galphaRayDnsGrd = resTrm * -gT;
-
-                    g_cr = gC.x * weight; g_cg = gC.y * weight; g_cb = gC.z * weight;
+                    float dalpha = resTrm * -gT;  // d L / d alpha
+                    t_cr = gC.x * weight; t_cg = gC.y * weight; t_cb = gC.z * weight;
                     Cr = fmaf(feat.x, weight, Cr); Cg = fmaf(feat.y, weight, Cg); Cb = fmaf(feat.z, weight, Cb);
                     const f3 resRad = mk3(fmaxf((C_fin.x - Cr) * inextT, 0.f), fmaxf((C_fin.y - Cg) * inextT, 0.f),
                                           fmaxf((C_fin.z - Cb) * inextT, 0.f));
-                    const float common = galphaRayHitGrd + galphaRayDnsGrd +
-                                         T * ((feat.x - resRad.x) * gC.x + (feat.y - resRad.y) * gC.y + (feat.z - resRad.z) * gC.z);
-                    g_dn = gres * common;
-                    const float gresGrd = dens * common;
-                    const float grayGrd = particle_response_grd<DEG>(gray, gres, gresGrd);
+                    dalpha += T * ((feat.x - resRad.x) * gC.x + (feat.y - resRad.y) * gC.y + (feat.z - resRad.z) * gC.z);
 
-                    const f3 gcrodGrd = gcrod * (2.f * grayGrd);
-                    const f3 grdGrd = mk3(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x,
-                                          gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
-                    const f3 groGrd = mk3(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z,
-                                          gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
-                    const f3 groTot = groGrd + groRayHitGrd;
-                    // d gro / d scale = -gposcr / scale^2 = -gro / scale
-                    const f3 gsclGrdGro = mk3(-gro.x * giscl.x, -gro.y * giscl.y, -gro.z * giscl.z) * groTot;
-                    const f3 gposcrGrd = giscl * groTot;
-                    const f3 gposcGrd = mul_cols(rotT, gposcrGrd);
-                    g_px = -gposcGrd.x; g_py = -gposcGrd.y; g_pz = -gposcGrd.z;
-                    quat_bw(gposc, gposcrGrd, q4, g_qr, g_qx, g_qy, g_qz);
-
-                    // safe_normalize_bw(grdu, grdGrd + grdRayHitGrd)
-                    const f3 gsum = grdGrd + grdRayHitGrd;
-                    f3 grduGrd = mk3(0.f, 0.f, 0.f);
-                    if (l2 > 0.f) {
-                        const float il3 = il * il * il;
-                        const float sdot = gsum.x * grdu.x + gsum.y * grdu.y + gsum.z * grdu.z;
-                        grduGrd = gsum * il - grdu * (il3 * sdot);
+                    // hit-distance terms (models/gaussianParticles.cuh:545-580), generic form
+                    f3 u_extra = mk3(0.f, 0.f, 0.f), v_extra = mk3(0.f, 0.f, 0.f), s_extra = mk3(0.f, 0.f, 0.f);
+                    if (HAS_GDIST) {
+                        const float pdot = -nu;
+                        const f3 grdd = nrm * pdot;
+                        const f3 grds = gscl * grdd;
+                        const float gsq = dot(grds, grds);
+                        const float gdist = __builtin_amdgcn_sqrtf(gsq);
+                        D = fmaf(weight, gdist, D);
+                        const float resHitT = fmaxf((D_fin - D) * inextT, 0.f);
+                        dalpha += (gdist - resHitT) * T * gD;
+                        const f3 grdsGrd = gsq > 0.f ? grds * (weight * __builtin_amdgcn_rcpf(gdist) * gD) : mk3(0.f, 0.f, 0.f);
+                        s_extra = grdd * grdsGrd;                              // direct d hitT / d scale
+                        const float sd = dot(grdsGrd * gscl, nrm);
+                        const f3 nGrd = (gscl * grdsGrd) * pdot - u * sd;       // d / d grd
+                        u_extra = nrm * (-sd);                                   // d / d gro
+                        // safe_normalize_bw: (g - n (n.g)) / |v|
+                        v_extra = l2 > 0.f ? (nGrd - nrm * dot(nrm, nGrd)) * il : mk3(0.f, 0.f, 0.f);
                     }
-                    const f3 sclFromDir = mk3(-grdu.x * giscl.x, -grdu.y * giscl.y, -grdu.z * giscl.z) * grduGrd;
-                    g_sx = gsclRayHitGrd.x + gsclGrdGro.x + sclFromDir.x;
-                    g_sy = gsclRayHitGrd.y + gsclGrdGro.y + sclFromDir.y;
-                    g_sz = gsclRayHitGrd.z + gsclGrdGro.z + sclFromDir.z;
-                    const f3 rdrGrd = giscl * grduGrd;
-                    quat_bw(ray.d, rdrGrd, q4, g_qr, g_qx, g_qy, g_qz);
 
+                    t_dn = gres * dalpha;
+                    const float w2 = 2.f * particle_response_grd<DEG>(gray, gres, dens * dalpha);  // 2 dL/dgray
+                    const float beta = l2 > 0.f ? -nu * il : 0.f;
+                    f3 uGrd = avec * w2;             // d L / d gro
+                    f3 vGrd = uGrd * beta;           // d L / d grdu
+                    if (HAS_GDIST) { uGrd = uGrd + u_extra; vGrd = vGrd + v_extra; }
+                    const f3 bu = giscl * uGrd, bv = giscl * vGrd;   // d L / d (R^T gposc), d L / d (R^T d)
+                    t_bx = bu.x; t_by = bu.y; t_bz = bu.z;
+                    // scale: gro_i, grdu_i ~ 1/s_i  ->  d/ds_i = -(gro_i uGrd_i + grdu_i vGrd_i)/s_i (+ direct hitT term)
+                    t_sx = fmaf(u.x, uGrd.x, v.x * vGrd.x); t_sy = fmaf(u.y, uGrd.y, v.y * vGrd.y); t_sz = fmaf(u.z, uGrd.z, v.z * vGrd.z);
+                    if (HAS_GDIST) { t_sx -= gscl.x * s_extra.x; t_sy -= gscl.y * s_extra.y; t_sz -= gscl.z * s_extra.z; }
+                    if (HAS_GDIST) {
+                        quat_contract(bu, gposc, q4, t_qr, t_qx, t_qy, t_qz);
+                        quat_contract(bv, ray.d, q4, t_qr, t_qx, t_qy, t_qz);
+                    } else {  // bv = beta * bu: rank-1
+                        quat_contract(bu, gposc + ray.d * beta, q4, t_qr, t_qx, t_qy, t_qz);
+                    }
                     T = nextT;
                     if (T < P.min_transmittance) alive = false;
                 }
             }
-            if (__any(hit)) {
-                hit_entries |= (1ull << j);
-                g_px = wave_sum_to_lane63(g_px); g_py = wave_sum_to_lane63(g_py); g_pz = wave_sum_to_lane63(g_pz);
-                g_dn = wave_sum_to_lane63(g_dn);
-                g_qr = wave_sum_to_lane63(g_qr); g_qx = wave_sum_to_lane63(g_qx); g_qy = wave_sum_to_lane63(g_qy); g_qz = wave_sum_to_lane63(g_qz);
-                g_sx = wave_sum_to_lane63(g_sx); g_sy = wave_sum_to_lane63(g_sy); g_sz = wave_sum_to_lane63(g_sz);
-                g_cr = wave_sum_to_lane63(g_cr); g_cg = wave_sum_to_lane63(g_cg); g_cb = wave_sum_to_lane63(g_cb);
-                if (lane == 63) {
-                    s_acc[j * 4 + 0] = make_float4(g_px, g_py, g_pz, g_dn);
-                    s_acc[j * 4 + 1] = make_float4(g_qr, g_qx, g_qy, g_qz);
-                    s_acc[j * 4 + 2] = make_float4(g_sx, g_sy, g_sz, 0.f);
-                    s_acc[j * 4 + 3] = make_float4(g_cr, g_cg, g_cb, 0.f);
+            if (COUNT) {
+                const unsigned long long hm = __ballot(hit), am = __ballot(alive);
+                if (lane == 0) {
+                    atomicAdd(&counters[0], 1ull);                              // (strip, entry) pairs processed
+                    if (hm) atomicAdd(&counters[1], 1ull);                      // ... with at least one hit
+                    atomicAdd(&counters[2], (unsigned long long)__popcll(hm));  // hits
+                    atomicAdd(&counters[3], (unsigned long long)__popcll(am));  // lanes still alive after the entry
                 }
+            }
+            if (__any(hit)) {
+                hit_entries |= (1u << j);
+                const float terms[16] = {t_bx, t_by, t_bz, t_dn, t_qr, t_qx, t_qy, t_qz, t_sx, t_sy, t_sz, 0.f, t_cr, t_cg, t_cb, 0.f};
+                const float tot = wave_reduce_scatter16(terms, lane);
+                if (lane < 16) s_acc[j * 16 + lane] = tot;
             }
         }
         __syncthreads();
         // flush: lane j owns staged entry j; one atomic set per (strip, particle with a hit)
-        if ((hit_entries >> lane) & 1ull) {
-            const uint32_t idx = __float_as_uint(s_rec[lane * 7 + 5].w);
-            const float4 a0 = s_acc[lane * 4 + 0], a1 = s_acc[lane * 4 + 1], a2 = s_acc[lane * 4 + 2], a3 = s_acc[lane * 4 + 3];
+        if (lane < (int)kBatch && ((hit_entries >> lane) & 1u)) {
+            const float4* rec = &s_rec[lane * 7];
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q6 = rec[6];
+            const uint32_t idx = __float_as_uint(rec[5].w);
+            const float4* acc = reinterpret_cast<const float4*>(&s_acc[lane * 16]);
+            const float4 a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+            // position = -R B  (matmul_bw_vec with rows of R^T), scale = -S / scale
+            const float gpx = -(a0.x * q0.x + a0.y * q1.x + a0.z * q2.x);
+            const float gpy = -(a0.x * q0.y + a0.y * q1.y + a0.z * q2.y);
+            const float gpz = -(a0.x * q0.z + a0.y * q1.z + a0.z * q2.z);
             float* gd = g_density12 + 12 * (size_t)idx;
-            atomicAdd(gd + 0, a0.x); atomicAdd(gd + 1, a0.y); atomicAdd(gd + 2, a0.z); atomicAdd(gd + 3, a0.w);
+            atomicAdd(gd + 0, gpx); atomicAdd(gd + 1, gpy); atomicAdd(gd + 2, gpz); atomicAdd(gd + 3, a0.w);
             atomicAdd(gd + 4, a1.x); atomicAdd(gd + 5, a1.y); atomicAdd(gd + 6, a1.z); atomicAdd(gd + 7, a1.w);
-            atomicAdd(gd + 8, a2.x); atomicAdd(gd + 9, a2.y); atomicAdd(gd + 10, a2.z);
+            atomicAdd(gd + 8, -a2.x * q6.x); atomicAdd(gd + 9, -a2.y * q6.y); atomicAdd(gd + 10, -a2.z * q6.z);
             float* gr = g_rgb + 3 * (size_t)idx;
             atomicAdd(gr + 0, a3.x); atomicAdd(gr + 1, a3.y); atomicAdd(gr + 2, a3.z);
         }
         __syncthreads();
+        b = bend;
     }
 }
 
@@ -717,14 +779,20 @@ void launch_expand(hipStream_t s, const GutParams& P, const GutProjected& proj, 
                        tile_keys, tile_vals);
 }
 void launch_tile_ranges(hipStream_t s, uint32_t n, uint32_t tile_mask, uint32_t num_tiles, const uint32_t* sorted_tile_keys,
-                        uint32_t* ranges) {
+                        uint32_t* ranges, uint32_t* boundary_tile) {
     hipLaunchKernelGGL(gut_tile_ranges_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, tile_mask, num_tiles, sorted_tile_keys,
-                       reinterpret_cast<uint2*>(ranges));
+                       reinterpret_cast<uint2*>(ranges), boundary_tile);
 }
 
 static uint32_t strip_grid(const GutParams& P) {
     const uint32_t tiles = (uint32_t)(P.gx * P.gy);
     return ((tiles + 7u) & ~7u) * 4u;
+}
+// tile-first segments + one task set per segment boundary, padded to the 8-XCD interleave
+static uint32_t segment_grid(const GutParams& P, uint32_t num_boundaries) {
+    const uint32_t tiles = (uint32_t)(P.gx * P.gy);
+    const uint32_t vtiles = ((tiles + 7u) & ~7u) + ((num_boundaries + 7u) & ~7u);
+    return vtiles * 4u;
 }
 
 #define GRUT_DISPATCH_DEGREE(DEG, ...)                         \
@@ -739,20 +807,52 @@ static uint32_t strip_grid(const GutParams& P) {
     }
 
 void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_idx, const float* density12,
-                       const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist, float* out_cnt) {
-    GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL(gut_render_fwd_kernel<D_>, dim3(strip_grid(P)), dim3(64), 0, s, P,
-                                                      reinterpret_cast<const uint2*>(ranges), sorted_idx,
-                                                      reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
-                                                      reinterpret_cast<float4*>(out_fd), out_dist, out_cnt));
+                       const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist, float* out_cnt,
+                       const GutCheckpoints& ck, bool write_checkpoints) {
+    if (write_checkpoints) {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_fwd_kernel<D_, true>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                          reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck));
+    } else {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_fwd_kernel<D_, false>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                          reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck));
+    }
 }
 void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_idx, const float* density12,
                        const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* dist,
-                       const float* g_dist, float* g_density12, float* g_rgb) {
-    GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL(gut_render_bwd_kernel<D_>, dim3(strip_grid(P)), dim3(64), 0, s, P,
-                                                      reinterpret_cast<const uint2*>(ranges), sorted_idx,
-                                                      reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
-                                                      reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
-                                                      g_dist, g_density12, g_rgb));
+                       const float* g_dist, float* g_density12, float* g_rgb, const GutCheckpoints& ck) {
+    const dim3 grid(segment_grid(P, ck.num_boundaries));
+    if (getenv("GRUT_COUNT_HITS") && P.degree == 2) {  // development aid: work statistics of the gradient sweep
+        unsigned long long* d = nullptr;
+        unsigned long long hcnt[4] = {0, 0, 0, 0};
+        (void)hipMalloc(&d, 32);
+        (void)hipMemsetAsync(d, 0, 32, s);
+        hipLaunchKernelGGL((gut_render_bwd_kernel<2, false, true>), grid, dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges),
+                           sorted_idx, reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d, reinterpret_cast<const float4*>(fd),
+                           reinterpret_cast<const float4*>(g_fd), dist, g_dist, g_density12, g_rgb, ck, d);
+        (void)hipMemcpyAsync(hcnt, d, 32, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(d);
+        fprintf(stderr, "[grut] bwd strip-entries processed %llu, with>=1 hit %llu, hits %llu, alive-lane-entries %llu\n", hcnt[0], hcnt[1],
+                hcnt[2], hcnt[3]);
+        return;
+    }
+    if (g_dist) {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_bwd_kernel<D_, true>), grid, dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                          reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
+                                                          g_dist, g_density12, g_rgb, ck, nullptr));
+    } else {  // no depth gradient flows in: the hit-distance terms vanish identically
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_bwd_kernel<D_, false>), grid, dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                          reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
+                                                          g_dist, g_density12, g_rgb, ck, nullptr));
+    }
 }
 void launch_project_bwd(hipStream_t s, const GutParams& P, const uint32_t* tiles_count, const float* density12, const float* sph,
                         const float* rgb, const float* g_rgb, float* g_density12, float* g_sph) {

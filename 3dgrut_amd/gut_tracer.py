@@ -147,6 +147,7 @@ class Tracer:
             ctx.save_for_backward(ray_ori, ray_dir, fd, dist, particle_density, particle_features)
             ctx.native, ctx.frame = native, frame
             ctx.mark_non_differentiable(cnt, vis)
+            ctx.set_materialize_grads(False)
             return fd, dist, cnt, vis
 
         @staticmethod
@@ -154,10 +155,10 @@ class Tracer:
             ray_ori, ray_dir, fd, dist, particle_density, particle_features = ctx.saved_tensors
             if g_fd is None:
                 g_fd = torch.zeros_like(fd)
-            if g_dist is None:
-                g_dist = torch.zeros_like(dist)
+            # g_dist is None when the loss never touched pred_dist: the library then runs the variant without
+            # hit-distance terms (autograd materialises zeros unless told otherwise, see set_materialize_grads)
             g_density, g_sph = ctx.native.trace_bwd(ctx.frame, particle_density, particle_features, ray_ori, ray_dir,
-                                                    fd, g_fd.contiguous(), dist, g_dist.contiguous())
+                                                    fd, g_fd.contiguous(), dist, None if g_dist is None else g_dist.contiguous())
             g_pos, g_dns, g_rot, g_scl, _ = torch.split(g_density, [3, 1, 4, 3, 1], dim=1)
             return (None, None, None, None, g_pos.contiguous(), g_rot.contiguous(), g_scl.contiguous(),
                     g_dns.contiguous(), g_sph)

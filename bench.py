@@ -118,7 +118,9 @@ def main():
         g.zero_grad()
         out = tracer.render(g, batch, train=True)
         fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
-        torch.autograd.backward([fd, out["pred_dist"][0]], [g_fd, g_dist])
+        # upstream gradients per SURVEY §8d: d_rgb, d_opacity ~ N(0,1)/P and no gradient into the hit distance
+        # (training never back-props depth: trainer.py:677-748)
+        torch.autograd.backward([fd], [g_fd])
         if world > 1:  # one fused all-reduce of all Gaussian gradients ([N,59] fp32)
             grads = [p.grad for p in g.parameters()]
             flat = torch.cat([x.reshape(-1) for x in grads])

@@ -133,7 +133,10 @@ int gut_forward(GutHandle* handle, void* stream, const GutFrame* frame,
                 float* out_feat_density, float* out_hit_distance,
                 float* out_hit_count, int32_t* out_visibility);
 
-/*  grad_particle_density : [N,12] f32, must arrive zero-filled (accumulated with atomics)
+/*  grad_hit_distance     : [H,W,1] f32 or NULL when no gradient flows into the hit distance (the usual
+ *                          training case: trainer.py:677-748 supervises colour/opacity only) — selects the
+ *                          kernel variant without the hit-distance terms
+ *  grad_particle_density : [N,12] f32, must arrive zero-filled (accumulated with atomics)
  *  grad_particle_sph     : [N, 3*(deg+1)^2] f32, fully overwritten (no zero-fill needed) */
 int gut_backward(GutHandle* handle, void* stream, const GutFrame* frame,
                  const float* particle_density, const float* particle_sph,

@@ -35,7 +35,9 @@ def _run_gpu(scene, g_fd=None, g_dist=None, n_active=3, **render_kw):
     res = dict(out=out, tracer=tr, gaussians=g)
     if g_fd is not None:
         fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
-        loss = (fd * torch.as_tensor(g_fd, device="cuda")).sum() + (out["pred_dist"][0] * torch.as_tensor(g_dist, device="cuda")).sum()
+        loss = (fd * torch.as_tensor(g_fd, device="cuda")).sum()
+        if g_dist is not None:  # otherwise no gradient reaches pred_dist: the library runs its no-depth-gradient variant
+            loss = loss + (out["pred_dist"][0] * torch.as_tensor(g_dist, device="cuda")).sum()
         loss.backward()
         res["grads"] = g.grads_packed()
     torch.cuda.synchronize()
@@ -75,12 +77,17 @@ def test_forward_matches_oracle(n, w, h, scale):
     assert (cnt != ora["fwd"]["hit_count"][..., 0]).mean() < 5e-3
 
 
-def test_backward_matches_oracle():
-    scene = make_scene(n=3000, width=96, height=64, median_scale=0.06)
-    g_fd, g_dist = syn.upstream_grads(96, 64)
-    g_fd *= 96 * 64
-    g_dist = (np.random.default_rng(5).normal(size=g_dist.shape) * 0.1).astype(np.float32)
-    gpu, ora = _run_gpu(scene, g_fd, g_dist), _run_oracle(scene, g_fd, g_dist)
+@pytest.mark.parametrize("n,w,h,scale,with_depth_grad", [(3000, 96, 64, 0.06, True), (3000, 96, 64, 0.06, False),
+                                                         (30000, 160, 96, 0.05, False), (30000, 160, 96, 0.05, True)])
+def test_backward_matches_oracle(n, w, h, scale, with_depth_grad):
+    """The larger scene has tile lists of several hundred entries, i.e. several checkpointed segments per tile."""
+    scene = make_scene(n=n, width=w, height=h, median_scale=scale)
+    g_fd, g_dist = syn.upstream_grads(w, h)
+    g_fd *= w * h
+    if with_depth_grad:
+        g_dist = (np.random.default_rng(5).normal(size=g_dist.shape) * 0.1).astype(np.float32)
+    gpu = _run_gpu(scene, g_fd, g_dist if with_depth_grad else None)
+    ora = _run_oracle(scene, g_fd, g_dist)
     _image_checks(gpu["out"], ora["fwd"])
     gd, gsph = gpu["grads"]
     rd, rsph, _ = ora["grads"]
