@@ -151,3 +151,38 @@ def gut_backward(cfg, cam, n_active, fwd, g_feat_density, g_hit_distance, dtype=
     l.orc_gut_project_bwd(C.byref(cfg), _p(ps), _p(pe), C.c_uint32(N), C.c_int(n_active),
                           _p(fwd["proj"]["tiles_count"]), _p(d12), _p(sph), _p(grgb), _p(gd), _p(gsph))
     return gd, gsph, grgb
+
+
+# ------------------------------------------------------------------------------------------
+# per-hit known-answer entry points (tests/test_oracle_cpu.py against tests/golden/*.npz)
+# ------------------------------------------------------------------------------------------
+def _real(dtype):
+    return C.c_float if np.dtype(dtype).itemsize == 4 else C.c_double
+
+
+def gut_process_hit_fwd(degree, min_response, min_alpha, max_alpha, ray_o, ray_d, density12, feat3, state5, dtype=np.float32):
+    """One 3DGUT hit on a running ray state {T, rgb[3], depth}; returns (accepted, new state)."""
+    l, R = lib(dtype), _real(dtype)
+    st = _c(state5, dtype).copy()
+    T, rgb, dep = st[0:1].copy(), st[1:4].copy(), st[4:5].copy()
+    acc = l.orc_gut_process_hit_fwd(C.c_int(degree), R(min_response), R(min_alpha), R(max_alpha), _p(_c(ray_o, dtype)), _p(_c(ray_d, dtype)),
+                                    _p(_c(density12, dtype)), _p(_c(feat3, dtype)), _p(T), _p(rgb), _p(dep))
+    return int(acc), np.concatenate([T, rgb, dep])
+
+
+def gut_process_hit_bwd(degree, min_response, min_alpha, max_alpha, min_transmittance, ray_o, ray_d, density12, feat3, state5, fin5,
+                        grads5, dtype=np.float32):
+    l, R = lib(dtype), _real(dtype)
+    st = _c(state5, dtype).copy()
+    gd, gf = np.zeros(12, dtype), np.zeros(3, dtype)
+    l.orc_gut_process_hit_bwd(C.c_int(degree), R(min_response), R(min_alpha), R(max_alpha), R(min_transmittance), _p(_c(ray_o, dtype)),
+                              _p(_c(ray_d, dtype)), _p(_c(density12, dtype)), _p(_c(feat3, dtype)), _p(st), _p(_c(fin5, dtype)),
+                              _p(_c(grads5, dtype)), _p(gd), _p(gf))
+    return st, gd, gf
+
+
+def sh_radiance(deg, coeffs48, dir3, clamped=True, dtype=np.float32):
+    l = lib(dtype)
+    out = np.zeros(3, dtype)
+    l.orc_sh_radiance(C.c_int(deg), C.c_int(3), _p(_c(coeffs48, dtype)), _p(_c(dir3, dtype)), C.c_int(int(clamped)), _p(out))
+    return out

@@ -1,0 +1,84 @@
+#!/usr/bin/env python
+"""Turn rocprofv3's rocpd sqlite outputs (gpurun_out/prof_*/…_results.db) into the text summaries kept under profiles/.
+
+    python scripts/rocprof_summary.py stats  <stats.db>  > profiles/rNN_kernel_stats.txt
+    python scripts/rocprof_summary.py pmc    <fetch.db> <write.db>  > profiles/rNN_pmc_hbm.txt
+    python scripts/rocprof_summary.py traffic <fetch.db> <write.db> <workload>   (writes profiles/pmc_traffic.json)
+
+FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE tallies 128-B read requests at 64 B
+(MI355X_MICROARCH.md, "HBM"): the corrected column doubles it.  WRITE_SIZE is taken as reported (uncalibrated there).
+"""
+import json
+import os
+import re
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name: str) -> str:
+    m = re.search(r"((?:gut|grt|radix|scan)_[a-z0-9_]+)(<[^>]*>)?", name)
+    if m:
+        return m.group(1) + (m.group(2) or "")
+    return name[:70]
+
+
+def stats(db):
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+    print(f"# rocprofv3 --kernel-trace --stats summary ({os.path.basename(os.path.dirname(db))}); durations in us")
+    print(f"{'kernel':60s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
+    for n, calls, tot, avg, pct in rows:
+        print(f"{short(n):60s} {calls:6d} {tot:12.1f} {avg:10.2f} {pct:6.2f}")
+
+
+def counter_avgs(db, counter):
+    c = sqlite3.connect(db)
+    out = {}
+    q = "select kernel_name, value, duration from counters_collection where counter_name = ?"
+    for name, value, dur in c.execute(q, (counter,)):
+        k = short(name)
+        e = out.setdefault(k, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += value
+        e[2] += dur
+    return {k: (n, v / n, d / n) for k, (n, v, d) in out.items()}
+
+
+def pmc(fetch_db, write_db):
+    f = counter_avgs(fetch_db, "FETCH_SIZE")
+    w = counter_avgs(write_db, "WRITE_SIZE")
+    print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), averages per dispatch")
+    print("# read_MB_corrected = 2 x FETCH_SIZE (gfx950 counts 128-B requests at 64 B); write as reported")
+    print(f"{'kernel':60s} {'calls':>6s} {'fetch_MB':>10s} {'read_MB_corr':>13s} {'write_MB':>10s} {'hbm_MB':>10s} {'avg_us':>9s}")
+    for k in sorted(f, key=lambda k: -f[k][1]):
+        n, fv, dur = f[k]
+        wv = w.get(k, (0, 0.0, 0.0))[1]
+        if not (k.startswith(("gut_", "grt_", "radix_", "scan_"))):
+            continue
+        print(f"{k:60s} {n:6d} {fv / 1024:10.2f} {2 * fv / 1024:13.2f} {wv / 1024:10.2f} {(2 * fv + wv) / 1024:10.2f} {dur / 1e3:9.1f}")
+
+
+STAGE_OF = {"gut_project_kernel": "project", "gut_expand_kernel": "expand", "gut_tile_ranges_kernel": "tile_ranges",
+            "gut_render_fwd_kernel": "render_fwd", "gut_render_bwd_kernel": "render_bwd", "gut_project_bwd_kernel": "project_bwd"}
+
+
+def traffic(fetch_db, write_db, workload):
+    f = counter_avgs(fetch_db, "FETCH_SIZE")
+    w = counter_avgs(write_db, "WRITE_SIZE")
+    res = {}
+    for k, (n, fv, _) in f.items():
+        base = re.sub(r"<.*", "", k)
+        if base in STAGE_OF:
+            res[STAGE_OF[base]] = int((2 * fv + w.get(k, (0, 0.0, 0.0))[1]) * 1024)
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    allw = json.load(open(path)) if os.path.exists(path) else {}
+    allw[workload] = res
+    json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    cmd = sys.argv[1]
+    {"stats": stats, "pmc": pmc, "traffic": traffic}[cmd](*sys.argv[2:])

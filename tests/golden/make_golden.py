@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""Generates tests/golden/per_hit_deg{2,4}.npz from the REFERENCE's own per-hit math.
+
+Run in the build container only (needs /root/reference):
+
+    make -C oracle ref && python tests/golden/make_golden.py
+
+oracle/ref/*.cpp compile threedgrt_tracer/include/3dgrt/kernels/cuda/gaussianParticles.cuh and
+threedgut_tracer/include/3dgut/kernels/cuda/models/gaussianParticles.cuh on the host (g++ + a CUDA shim) into
+oracle/_ref/*.so; this script feeds them seeded random rays / particles / ray states and stores inputs and outputs.
+The reference ships no golden vectors of its own for this path, so these known-answer vectors,
+produced by the reference's source, are what pins the oracle (tests/test_oracle_cpu.py).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.path.join(ROOT, "oracle", "_ref")
+
+F = np.float32
+MIN_RESPONSE, MIN_ALPHA, MIN_T_GUT, MIN_T_GRT = F(0.0113), F(1.0 / 255.0), F(1e-4), F(1e-3)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def cases(n, seed):
+    """Random particles with rays aimed near them so that most cases are accepted hits."""
+    r = np.random.default_rng(seed)
+    pos = r.uniform(-1, 1, (n, 3))
+    scl = np.exp(r.normal(np.log(0.1), 0.6, (n, 3)))
+    q = r.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    dens = r.uniform(0.02, 1.0, (n, 1))
+    d12 = np.concatenate([pos, dens, q, scl, np.zeros((n, 1))], 1).astype(F)
+    ro = r.uniform(-4, 4, (n, 3))
+    target = pos + r.normal(size=(n, 3)) * scl.mean(1, keepdims=True) * 1.2
+    rd = target - ro
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    sph = (r.normal(size=(n, 48)) * 0.3).astype(F)
+    feat = r.uniform(0, 1, (n, 3)).astype(F)
+    T = r.uniform(0.05, 1.0, (n, 1))
+    state5 = np.concatenate([T, r.uniform(0, 1, (n, 3)) * (1 - T), r.uniform(0, 3, (n, 1)) * (1 - T)], 1).astype(F)
+    fin5 = np.concatenate([T * r.uniform(0.0, 0.9, (n, 1)), state5[:, 1:4] + r.uniform(0, 0.5, (n, 3)),
+                           state5[:, 4:5] + r.uniform(0, 2, (n, 1))], 1).astype(F)
+    grads5 = r.normal(size=(n, 5)).astype(F)
+    return dict(ray_o=ro.astype(F), ray_d=rd.astype(F), density12=d12, sph48=sph, feat3=feat, state5=state5, fin5=fin5,
+                grads5=grads5)
+
+
+def run(degree, n=512, seed=1234):
+    grt = C.CDLL(os.path.join(REF, f"libref_hit_deg{degree}.so"))
+    gut = C.CDLL(os.path.join(REF, f"libref_gut_hit_deg{degree}.so"))
+    assert grt.ref_degree() == degree and gut.ref_gut_degree() == degree
+    for fn in (grt.ref_particle_response, grt.ref_particle_response_grd):
+        fn.restype = C.c_float
+    grt.ref_particle_response.argtypes = [C.c_float]
+    grt.ref_particle_response_grd.argtypes = [C.c_float] * 3
+    c = cases(n, seed + degree)
+    out = dict(c)
+    out["params"] = np.array([MIN_RESPONSE, MIN_ALPHA, MIN_T_GUT, MIN_T_GRT], F)
+    fl = C.c_float
+    # ---- 3DGUT per-hit (per-particle radiance) ----
+    gut_fwd_state = c["state5"].copy()
+    gut_fwd_acc = np.zeros(n, np.int32)
+    gut_bwd_state = c["state5"].copy()
+    gut_gd = np.zeros((n, 12), F)
+    gut_gf = np.zeros((n, 3), F)
+    # ---- 3DGRT per-hit (per-ray SH radiance, normals) ----
+    grt_state = np.concatenate([c["state5"], np.zeros((n, 3), F)], 1)
+    grt_acc = np.zeros(n, np.int32)
+    grt_bwd_state = c["state5"].copy()
+    grt_gd = np.zeros((n, 12), F)
+    grt_gs = np.zeros((n, 48), F)
+    sh_out = np.zeros((4, n, 3), F)
+    sh_bwd_out = np.zeros((n, 3), F)
+    sh_bwd_g = np.zeros((n, 48), F)
+    custom_t = np.zeros(n, F)
+    custom_ok = np.zeros(n, np.int32)
+    inst_t = np.zeros(n, F)
+    inst_ok = np.zeros(n, np.int32)
+    pray = np.zeros((n, 6), F)
+    for i in range(n):
+        a = {k: np.ascontiguousarray(v[i]) for k, v in c.items()}
+        gut_fwd_acc[i] = gut.ref_gut_process_hit_fwd(_p(a["ray_o"]), _p(a["ray_d"]), _p(a["density12"]), _p(a["feat3"]), fl(MIN_RESPONSE),
+                                                     fl(MIN_ALPHA), _p(gut_fwd_state[i]))
+        gut.ref_gut_process_hit_bwd(_p(a["ray_o"]), _p(a["ray_d"]), _p(a["density12"]), _p(a["feat3"]), fl(MIN_RESPONSE), fl(MIN_ALPHA),
+                                    fl(MIN_T_GUT), _p(gut_bwd_state[i]), _p(a["fin5"]), _p(a["grads5"]), _p(gut_gd[i]), _p(gut_gf[i]))
+        grt_acc[i] = grt.ref_process_hit(_p(a["ray_o"]), _p(a["ray_d"]), _p(a["density12"]), _p(a["sph48"]), fl(MIN_RESPONSE), fl(MIN_ALPHA),
+                                         3, 1, _p(grt_state[i]))
+        grt.ref_process_hit_bwd(_p(a["ray_o"]), _p(a["ray_d"]), _p(a["density12"]), _p(a["sph48"]), fl(MIN_RESPONSE), fl(MIN_ALPHA),
+                                fl(MIN_T_GRT), 3, _p(grt_bwd_state[i]), _p(a["fin5"]), _p(a["grads5"]), _p(grt_gd[i]), _p(grt_gs[i]))
+        for deg in range(4):
+            grt.ref_radiance_from_sph(deg, _p(a["sph48"]), _p(a["ray_d"]), _p(sh_out[deg, i]))
+        grt.ref_radiance_from_sph_bwd(3, _p(a["sph48"]), _p(a["ray_d"]), fl(0.37), _p(np.ascontiguousarray(a["grads5"][1:4])),
+                                      _p(sh_bwd_out[i]), _p(sh_bwd_g[i]))
+        t = fl(0)
+        custom_ok[i] = grt.ref_intersect_custom(_p(a["ray_o"]), _p(a["ray_d"]), _p(a["density12"]), fl(0.0), fl(1e6), fl(9.0), C.byref(t))
+        custom_t[i] = t.value
+        # instance-space ray: o' = (R^T (o - mu)) / (r s), d' = (R^T d) / (r s) with r = 3 (the proxy's kernel scale)
+        d12 = c["density12"][i].astype(np.float64)
+        w, x, y, z = d12[4:8]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                      [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        po = (R.T @ (c["ray_o"][i] - d12[0:3])) / (3.0 * d12[8:11])
+        pd = (R.T @ c["ray_d"][i].astype(np.float64)) / (3.0 * d12[8:11])
+        pray[i] = np.concatenate([po, pd]).astype(F)
+        inst_ok[i] = grt.ref_intersect_instance(_p(np.ascontiguousarray(pray[i, :3])), _p(np.ascontiguousarray(pray[i, 3:])), fl(0.0), fl(1e6),
+                                                fl(1.0), C.byref(t))
+        inst_t[i] = t.value
+    gray = np.linspace(0, 12, 64).astype(F)
+    resp = np.array([grt.ref_particle_response(fl(g)) for g in gray], F)
+    resp_grd = np.array([grt.ref_particle_response_grd(fl(g), fl(r), fl(0.7)) for g, r in zip(gray, resp)], F)
+    out.update(gut_fwd_state=gut_fwd_state, gut_fwd_accept=gut_fwd_acc, gut_bwd_state=gut_bwd_state, gut_g_density12=gut_gd,
+               gut_g_feat3=gut_gf, grt_fwd_state=grt_state, grt_fwd_accept=grt_acc, grt_bwd_state=grt_bwd_state,
+               grt_g_density12=grt_gd, grt_g_sph48=grt_gs, sh_radiance=sh_out, sh_bwd_radiance=sh_bwd_out, sh_bwd_g_sph48=sh_bwd_g,
+               custom_t=custom_t, custom_ok=custom_ok, instance_ray=pray, instance_t=inst_t, instance_ok=inst_ok,
+               gray=gray, response=resp, response_grd=resp_grd)
+    path = os.path.join(HERE, f"per_hit_deg{degree}.npz")
+    np.savez_compressed(path, **out)
+    print(path, f"accepted gut {gut_fwd_acc.mean():.2f} grt {grt_acc.mean():.2f} custom {custom_ok.mean():.2f} instance {inst_ok.mean():.2f}")
+
+
+if __name__ == "__main__":
+    for d in (2, 4):
+        run(d)

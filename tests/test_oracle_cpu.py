@@ -1,0 +1,159 @@
+"""CPU: pins the oracle (oracle/*.c, the CPU restatement used as checker) to the REFERENCE's own per-hit math.
+
+tests/golden/per_hit_deg{2,4}.npz were produced by the reference's source headers compiled on the host
+(tests/golden/make_golden.py, oracle/ref/).  Where oracle/_ref/ is present (build container), the same comparison is
+repeated live on fresh seeds.  Further CPU checks: analytic backward of the oracle against central finite differences
+of its own forward in float64, and basic invariants of the binning restatement.
+"""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from scenes import make_scene, rel_err
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+syn = importlib.import_module("3dgrut_amd.synthetic")
+
+
+def _golden(degree):
+    return np.load(os.path.join(HERE, "golden", f"per_hit_deg{degree}.npz"))
+
+
+def _close(a, b, rtol=2e-5, atol=2e-6):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) <= atol + rtol * np.maximum(np.abs(a), np.abs(b)))
+
+
+@pytest.mark.parametrize("degree", [2, 4])
+def test_gut_per_hit_forward_matches_reference_vectors(degree):
+    g = _golden(degree)
+    mr, ma = float(g["params"][0]), float(g["params"][1])
+    n = g["ray_o"].shape[0]
+    for i in range(n):
+        acc, st = oracle.gut_process_hit_fwd(degree, mr, ma, 0.99, g["ray_o"][i], g["ray_d"][i], g["density12"][i], g["feat3"][i],
+                                             g["state5"][i])
+        assert acc == int(g["gut_fwd_accept"][i]), i
+        assert _close(st, g["gut_fwd_state"][i]), (i, st, g["gut_fwd_state"][i])
+    assert g["gut_fwd_accept"].sum() > n // 2
+
+
+@pytest.mark.parametrize("degree", [2, 4])
+def test_gut_per_hit_backward_matches_reference_vectors(degree):
+    g = _golden(degree)
+    mr, ma, mt = float(g["params"][0]), float(g["params"][1]), float(g["params"][2])
+    worst = 0.0
+    for i in range(g["ray_o"].shape[0]):
+        st, gd, gf = oracle.gut_process_hit_bwd(degree, mr, ma, 0.99, mt, g["ray_o"][i], g["ray_d"][i], g["density12"][i], g["feat3"][i],
+                                                g["state5"][i], g["fin5"][i], g["grads5"][i])
+        assert _close(st, g["gut_bwd_state"][i]), i
+        ref = np.concatenate([g["gut_g_density12"][i], g["gut_g_feat3"][i]]).astype(np.float64)
+        got = np.concatenate([gd, gf]).astype(np.float64)
+        scale = np.abs(ref).max() + 1e-20
+        worst = max(worst, np.abs(got - ref).max() / scale)
+    # identical formulas in the same arithmetic type: agreement to float rounding of the largest component
+    assert worst < 2e-4, worst
+
+
+def test_sh_radiance_matches_reference_vectors():
+    g = _golden(2)
+    for i in range(0, g["ray_o"].shape[0], 4):
+        for deg in range(4):
+            got = oracle.sh_radiance(deg, g["sph48"][i], g["ray_d"][i], clamped=True)
+            assert _close(got, g["sh_radiance"][deg, i], rtol=1e-5, atol=1e-6), (i, deg)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libref_gut_hit_deg2.so")),
+                    reason="oracle/_ref is built only where /root/reference is mounted")
+def test_gut_per_hit_live_against_reference_library():
+    ref = C.CDLL(os.path.join(os.path.dirname(HERE), "oracle", "_ref", "libref_gut_hit_deg2.so"))
+    r = np.random.default_rng(77)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    fl = C.c_float
+    for _ in range(200):
+        pos = r.uniform(-1, 1, 3)
+        scl = np.exp(r.normal(np.log(0.1), 0.6, 3))
+        q = r.normal(size=4)
+        q /= np.linalg.norm(q)
+        d12 = np.concatenate([pos, [r.uniform(0.02, 1)], q, scl, [0]]).astype(np.float32)
+        ro = r.uniform(-4, 4, 3).astype(np.float32)
+        rd = pos + r.normal(size=3) * scl.mean() - ro
+        rd = (rd / np.linalg.norm(rd)).astype(np.float32)
+        feat = r.uniform(0, 1, 3).astype(np.float32)
+        st0 = np.array([r.uniform(0.1, 1), 0.1, 0.2, 0.3, 0.5], np.float32)
+        st_ref = st0.copy()
+        acc_ref = ref.ref_gut_process_hit_fwd(p(ro), p(rd), p(d12), p(feat), fl(0.0113), fl(1 / 255), p(st_ref))
+        acc, st = oracle.gut_process_hit_fwd(2, 0.0113, 1 / 255, 0.99, ro, rd, d12, feat, st0)
+        assert acc == acc_ref and _close(st, st_ref)
+
+
+def _fd_check(scene, n_probe=12, eps=1e-6):
+    """Oracle analytic gradient vs central differences of the oracle forward, float64, scalar loss <g, image>."""
+    cfg = oracle.default_gut_config()
+    W, H = scene["W"], scene["H"]
+    g_fd, g_dist = syn.upstream_grads(W, H)
+    g_fd = g_fd.astype(np.float64) * W * H
+    g_dist = (np.random.default_rng(9).normal(size=g_dist.shape) * 0.05).astype(np.float64)
+    d12 = scene["density12"].astype(np.float64)
+    sph = scene["sph"].astype(np.float64)
+
+    def loss(d, s):
+        f = oracle.gut_forward(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], 3, d, s, *scene["rays"], dtype=np.float64)
+        return float((f["feat_density"] * g_fd).sum() + (np.where(f["hit_distance"] < 1e5, f["hit_distance"], 0) * g_dist).sum()), f
+
+    _, fwd = loss(d12, sph)
+    gd, gsph, _ = oracle.gut_backward(cfg, scene["cam"], 3, fwd, g_fd, g_dist, dtype=np.float64)
+    rng = np.random.default_rng(2)
+    vis = np.nonzero(fwd["proj"]["tiles_count"] > 0)[0]
+    errs = []
+    for _ in range(n_probe):
+        i = int(rng.choice(vis))
+        for col in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):
+            dp, dm = d12.copy(), d12.copy()
+            h = eps * max(1.0, abs(d12[i, col]))
+            dp[i, col] += h
+            dm[i, col] -= h
+            fdiff = (loss(dp, sph)[0] - loss(dm, sph)[0]) / (2 * h)
+            errs.append((abs(fdiff - gd[i, col]), abs(gd[i, col]), i, col))
+    return errs, np.abs(gd).max(0)
+
+
+def test_oracle_backward_is_the_gradient_of_oracle_forward():
+    """No gradient flows through the 2-D projection in the reference (only via the per-particle radiance direction and
+    the 3-D per-ray response), and the binning is piecewise constant, so finite differences of the full forward must
+    reproduce the analytic backward wherever no accept/reject threshold is crossed."""
+    scene = make_scene(n=300, width=32, height=32, median_scale=0.12, max_density=0.6)
+    errs, colmax = _fd_check(scene)
+    bad = [e for e in errs if e[0] > 2e-4 * max(colmax[e[3]], 1e-12) + 1e-7]
+    # a probe may straddle a threshold (hit accepted on one side only): allow a small fraction of outliers
+    assert len(bad) <= max(2, len(errs) // 20), bad[:5]
+
+
+def test_binning_restatement_invariants():
+    scene = make_scene(n=3000, width=96, height=64, median_scale=0.06)
+    cfg = oracle.default_gut_config()
+    fwd = oracle.gut_forward(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], 3, scene["density12"], scene["sph"], *scene["rays"])
+    b, proj = fwd["bins"], fwd["proj"]
+    assert b["num_intersections"] == int(proj["tiles_count"].sum()) > 0
+    keys = b["sorted_keys"]
+    assert np.all(keys[1:] >= keys[:-1])
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    lens = (b["tile_ranges"][:, 1].astype(np.int64) - b["tile_ranges"][:, 0])
+    assert lens.sum() == b["num_intersections"]
+    assert np.array_equal(np.bincount(tiles, minlength=len(lens)), lens)
+    # depth bits of each entry equal the particle's view depth
+    dbits = proj["depth"].astype(np.float32).view(np.uint32)
+    assert np.array_equal((keys & np.uint64(0xFFFFFFFF)).astype(np.uint32), dbits[b["sorted_idx"]])
+    assert oracle.lib().orc_higher_msb(C.c_uint32(24)) == 5 and oracle.lib().orc_higher_msb(C.c_uint32(8160)) == 13
+
+
+def test_empty_scene_outputs_keep_initial_values():
+    scene = make_scene(n=16, width=16, height=16)
+    scene["density12"][:, 3] = 0.0
+    fwd = oracle.gut_forward(oracle.default_gut_config(), scene["cam"], scene["pose_start"], scene["pose_end"], 3, scene["density12"],
+                             scene["sph"], *scene["rays"])
+    assert fwd["bins"]["num_intersections"] == 0
+    assert np.all(fwd["feat_density"] == 0) and np.all(fwd["hit_distance"] == np.float32(1e6))
