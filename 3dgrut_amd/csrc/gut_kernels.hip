@@ -100,9 +100,11 @@ __device__ __forceinline__ TileBBox tile_space_bbox(int gx, int gy, float px, fl
 __device__ __forceinline__ float saturate(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 
 // tileMinParticlePowerResponse, gutProjector.cuh:49-78.  Evaluated by both the counting pass and the
-// expansion pass on identical stored inputs; kept out-of-line (noinline) so that both kernels run the
-// very same instruction sequence and their results agree bit for bit.
-__device__ __noinline__ float tile_min_power(float tx, float ty, float4 co, float mx, float my) {
+// expansion pass on identical stored inputs.  FP contraction is switched off inside so that both kernels
+// round identically whatever the surrounding code looks like after inlining (a disagreement would only
+// cost a padded or a dropped tile entry: the expansion bounds its writes by the counted range).
+__device__ __forceinline__ float tile_min_power(float tx, float ty, float4 co, float mx, float my) {
+#pragma clang fp contract(off)
     const float ts = 16.f;
     const float tminx = ts * tx, tminy = ts * ty, tmaxx = ts + tminx, tmaxy = ts + tminy;
     const float offx = tminx - mx, offy = tminy - my;
@@ -121,6 +123,25 @@ __device__ __noinline__ float tile_min_power(float tx, float ty, float4 co, floa
     return 0.f;
 }
 
+// Wave-cooperative walk over one particle's tile bounding box: the 64 lanes form an 8x8 block of tiles that
+// sweeps the box, so a particle covering thousands of tiles costs the wave ~area/64 steps instead of stalling one
+// lane for `area` steps (projected extents are heavy-tailed: kernel time used to be one giant particle's lane).
+// All arguments are wave-uniform.  `emit(keep, tile_index)` is called once per step by every lane.
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float bcast_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+template <typename Emit>
+__device__ __forceinline__ void coop_tile_walk(int lane, int gx, bool culling, TileBBox bb, float4 co, float cx, float cy, float pmax,
+                                               Emit&& emit) {
+    const int lx = lane & 7, ly = lane >> 3;
+    for (int by = bb.miny; by < bb.maxy; by += 8)
+        for (int bx = bb.minx; bx < bb.maxx; bx += 8) {
+            const int x = bx + lx, y = by + ly;
+            bool keep = (x < bb.maxx) && (y < bb.maxy);
+            if (keep && culling) keep = tile_min_power((float)x, (float)y, co, cx, cy) < pmax;
+            emit(keep, (uint32_t)(y * gx + x));
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: projection onto tiles — GUTProjector::eval (gutProjector.cuh:217-322)
 // ---------------------------------------------------------------------------------------------
@@ -128,19 +149,23 @@ __global__ __launch_bounds__(256) void gut_project_kernel(GutParams P, const flo
                                                           const float* __restrict__ sph, GutProjected out,
                                                           int32_t* __restrict__ visibility, uint32_t* __restrict__ num_visible) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     bool has_tiles = false;
+    uint32_t ntiles = 0;
+    int vis = 0;
+    float cx = 0.f, cy = 0.f, ex = 0.f, ey = 0.f, depth = 0.f, pmax_tile = 0.f, view_z_keep = 0.f;
+    float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+    TileBBox bb = {0, 0, 0, 0};
+    f3 pos = mk3(0.f, 0.f, 0.f);
     if (i < P.N) {
         const float4 a = density12[3 * (size_t)i + 0];  // pos.xyz, density
         const float4 b = density12[3 * (size_t)i + 1];  // quat wxyz
         const float4 c = density12[3 * (size_t)i + 2];  // scale.xyz, pad
-        const f3 pos = mk3(a.x, a.y, a.z);
+        pos = mk3(a.x, a.y, a.z);
         const float opacity = a.w;
 
-        uint32_t ntiles = 0;
-        int vis = 0;
-        float cx = 0.f, cy = 0.f, ex = 0.f, ey = 0.f, depth = 0.f;
-        float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
         const float view_z = fmaf(P.poses.view_R[6], pos.x, fmaf(P.poses.view_R[7], pos.y, fmaf(P.poses.view_R[8], pos.z, P.poses.view_t[2])));
+        view_z_keep = view_z;
         bool ok = (opacity >= P.min_alpha) && (view_z >= 0.2f);
         if (ok) {
             const m3 rotT = quat_wxyz_to_rotT(b.x, b.y, b.z, b.w);
@@ -189,20 +214,30 @@ __global__ __launch_bounds__(256) void gut_project_kernel(GutParams P, const flo
                         ok = radius > 0.f;
                         if (ok) {
                             vis = 1;
-                            const TileBBox bb = tile_space_bbox(P.gx, P.gy, cx, cy, ex, ey);
-                            if (P.tile_culling) {
-                                const float pmax2 = logf(co.w / P.min_alpha);  // same expression as the expansion pass
-                                for (int y = bb.miny; y < bb.maxy; ++y)
-                                    for (int x = bb.minx; x < bb.maxx; ++x)
-                                        if (tile_min_power((float)x, (float)y, co, cx, cy) < pmax2) ntiles++;
-                            } else {
-                                ntiles = (uint32_t)((bb.maxx - bb.minx) * (bb.maxy - bb.miny));
-                            }
+                            bb = tile_space_bbox(P.gx, P.gy, cx, cy, ex, ey);
+                            pmax_tile = logf(co.w / P.min_alpha);  // same expression as the expansion pass
+                            if (!P.tile_culling) ntiles = (uint32_t)((bb.maxx - bb.minx) * (bb.maxy - bb.miny));
                         }
                     }
                 }
             }
         }
+    }
+    // per-tile culling count (gutProjector.cuh:279-293), one particle at a time across the wave
+    if (P.tile_culling) {
+        unsigned long long todo = __ballot(vis != 0);
+        while (todo) {
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const TileBBox sb = {bcast_i(bb.minx, src), bcast_i(bb.miny, src), bcast_i(bb.maxx, src), bcast_i(bb.maxy, src)};
+            const float4 sco = make_float4(bcast_f(co.x, src), bcast_f(co.y, src), bcast_f(co.z, src), 0.f);
+            uint32_t cnt = 0;
+            coop_tile_walk(lane, P.gx, true, sb, sco, bcast_f(cx, src), bcast_f(cy, src), bcast_f(pmax_tile, src),
+                           [&](bool keep, uint32_t) { cnt += (uint32_t)__popcll(__ballot(keep)); });
+            if (lane == src) ntiles = cnt;
+        }
+    }
+    if (i < P.N) {
         visibility[i] = vis;
         out.tiles_count[i] = ntiles;
         has_tiles = ntiles > 0;
@@ -232,7 +267,7 @@ __global__ __launch_bounds__(256) void gut_project_kernel(GutParams P, const flo
             out.proj_pos[i] = make_float2(cx, cy);
             out.conic_opacity[i] = co;
             out.extent[i] = make_float2(ex, ey);
-            depth = P.global_z ? view_z : dist;
+            depth = P.global_z ? view_z_keep : dist;
             out.depth[i] = depth;
             out.depth_key[i] = __float_as_uint(depth);
         }
@@ -250,38 +285,52 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
                                                          const uint32_t* __restrict__ offsets, uint32_t capacity,
                                                          uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_vals) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= P.N) return;
-    uint32_t off = r == 0 ? 0u : offsets[r - 1];
-    uint32_t max_off = offsets[r];
-    if (max_off == off) return;
-    if (max_off > capacity) max_off = capacity;
-    const uint32_t p = rank_to_particle[r];
-    const float2 ext = proj.extent[p];
-    if (!(ext.x <= 1e-06f)) {
-        const float2 c = proj.proj_pos[p];
-        const TileBBox bb = tile_space_bbox(P.gx, P.gy, c.x, c.y, ext.x, ext.y);
-        if (P.tile_culling) {
-            const float4 co = proj.conic_opacity[p];
-            const float pmax = logf(co.w / P.min_alpha);
-            for (int y = bb.miny; (y < bb.maxy) && (off < max_off); ++y)
-                for (int x = bb.minx; (x < bb.maxx) && (off < max_off); ++x)
-                    if (tile_min_power((float)x, (float)y, co, c.x, c.y) < pmax) {
-                        tile_keys[off] = (uint32_t)(y * P.gx + x);
-                        tile_vals[off] = p;
-                        off++;
-                    }
-        } else {
-            for (int y = bb.miny; (y < bb.maxy) && (off < max_off); ++y)
-                for (int x = bb.minx; (x < bb.maxx) && (off < max_off); ++x) {
-                    tile_keys[off] = (uint32_t)(y * P.gx + x);
-                    tile_vals[off] = p;
-                    off++;
-                }
+    const int lane = threadIdx.x & 63;
+    uint32_t off = 0, max_off = 0, p = 0;
+    float cx = 0.f, cy = 0.f, pmax = 0.f;
+    float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
+    TileBBox bb = {0, 0, 0, 0};
+    if (r < P.N) {
+        off = r == 0 ? 0u : offsets[r - 1];
+        max_off = min(offsets[r], capacity);
+        if (max_off > off) {
+            p = rank_to_particle[r];
+            const float2 ext = proj.extent[p];
+            if (!(ext.x <= 1e-06f)) {
+                const float2 c = proj.proj_pos[p];
+                cx = c.x; cy = c.y;
+                bb = tile_space_bbox(P.gx, P.gy, cx, cy, ext.x, ext.y);
+                co = proj.conic_opacity[p];
+                pmax = logf(co.w / P.min_alpha);
+            }
         }
     }
-    for (; off < max_off; ++off) {  // gutProjector.cuh:372-376 padding
-        tile_keys[off] = 0xFFFFFFFFu;
-        tile_vals[off] = 0xFFFFFFFFu;
+    // one particle at a time across the wave: its entries land contiguously at [off, max_off) (coalesced stores);
+    // their order inside the range is irrelevant, the tile sort that follows is stable per (tile) and each
+    // (tile, particle) pair occurs once
+    unsigned long long todo = __ballot(max_off > off);
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const TileBBox sb = {bcast_i(bb.minx, src), bcast_i(bb.miny, src), bcast_i(bb.maxx, src), bcast_i(bb.maxy, src)};
+        const float4 sco = make_float4(bcast_f(co.x, src), bcast_f(co.y, src), bcast_f(co.z, src), 0.f);
+        const uint32_t sp = (uint32_t)bcast_i((int)p, src), send = (uint32_t)bcast_i((int)max_off, src);
+        uint32_t o = (uint32_t)bcast_i((int)off, src);
+        coop_tile_walk(lane, P.gx, P.tile_culling != 0, sb, sco, bcast_f(cx, src), bcast_f(cy, src), bcast_f(pmax, src),
+                       [&](bool keep, uint32_t tile) {
+                           const unsigned long long m = __ballot(keep);
+                           const uint32_t slot = o + (uint32_t)__popcll(m & lt_mask);
+                           if (keep && slot < send) {
+                               tile_keys[slot] = tile;
+                               tile_vals[slot] = sp;
+                           }
+                           o += (uint32_t)__popcll(m);
+                       });
+        for (uint32_t k = o + lane; k < send; k += 64) {  // gutProjector.cuh:372-376 padding
+            tile_keys[k] = 0xFFFFFFFFu;
+            tile_vals[k] = 0xFFFFFFFFu;
+        }
     }
 }
 
@@ -719,48 +768,68 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const u
 // dRGB -> dSH (clamp-masked) and d direction -> d position; every SH gradient row is written exactly once
 // (zeros for particles without tiles), so the caller does not need to zero-fill grad_sph.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gut_project_bwd_kernel(GutParams P, const uint32_t* __restrict__ tiles_count,
+// SH rows travel through LDS (row stride 49 floats: conflict-free both ways): a wave reads the coefficient rows of
+// its 64 particles and writes their gradient rows as contiguous 192-byte segments instead of 64 scattered rows.
+constexpr int kShStride = 49;
+__global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const uint32_t* __restrict__ tiles_count,
                                                               const float4* __restrict__ density12, const float* __restrict__ sph,
                                                               const float* __restrict__ rgb, const float* __restrict__ g_rgb,
                                                               float* __restrict__ g_density12, float* __restrict__ g_sph) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.N) return;
-    float* gs = g_sph + (size_t)i * 3 * P.ncoef;
+    __shared__ float s_rows[2][64 * kShStride];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t wave_base = blockIdx.x * 128u + (uint32_t)wave * 64u;
+    const uint32_t i = wave_base + lane;
+    const int rowlen = 3 * P.ncoef;
     const int nact = min((P.n_active + 1) * (P.n_active + 1), P.ncoef);
-    if (tiles_count[i] == 0) {
-        for (int k = 0; k < 3 * P.ncoef; ++k) gs[k] = 0.f;
-        return;
+    float* rows = s_rows[wave];
+    const bool has = (i < P.N) && (tiles_count[i] != 0);
+    const unsigned long long has_mask = __ballot(has);
+    // stage in: one row per step, lanes across the row
+    for (unsigned long long m = has_mask; m;) {
+        const int row = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if (lane < 3 * nact) rows[row * kShStride + lane] = sph[(size_t)(wave_base + row) * rowlen + lane];
     }
-    const float4 a = density12[3 * (size_t)i];
-    const f3 v = mk3(a.x, a.y, a.z) - mk3(P.poses.s2w_t[0], P.poses.s2w_t[1], P.poses.s2w_t[2]);
-    const float len = sqrtf(dot(v, v));
-    const float ilen = 1.f / len;
-    const f3 dir = v * ilen;
-    f3 g = mk3(g_rgb[3 * (size_t)i], g_rgb[3 * (size_t)i + 1], g_rgb[3 * (size_t)i + 2]);
-    // clamp mask on the unclamped radiance stored by the forward projection
-    if (!(rgb[3 * (size_t)i] > 0.f)) g.x = 0.f;
-    if (!(rgb[3 * (size_t)i + 1] > 0.f)) g.y = 0.f;
-    if (!(rgb[3 * (size_t)i + 2] > 0.f)) g.z = 0.f;
-    float basis[16];
-    f3 dbasis[16];
-    sh_basis(P.n_active, dir, basis);
-    sh_basis_grad(P.n_active, dir, dbasis);
-    const float* coef = sph + (size_t)i * 3 * P.ncoef;
-    f3 gdir = mk3(0.f, 0.f, 0.f);
-    for (int k = 0; k < P.ncoef; ++k) {
-        if (k < nact) {
-            gs[3 * k] = basis[k] * g.x; gs[3 * k + 1] = basis[k] * g.y; gs[3 * k + 2] = basis[k] * g.z;
-            const float s = g.x * coef[3 * k] + g.y * coef[3 * k + 1] + g.z * coef[3 * k + 2];
-            gdir = gdir + dbasis[k] * s;
-        } else {
-            gs[3 * k] = 0.f; gs[3 * k + 1] = 0.f; gs[3 * k + 2] = 0.f;
+    __syncthreads();
+    float* myrow = rows + lane * kShStride;
+    if (has) {
+        const float4 a = density12[3 * (size_t)i];
+        const f3 v = mk3(a.x, a.y, a.z) - mk3(P.poses.s2w_t[0], P.poses.s2w_t[1], P.poses.s2w_t[2]);
+        const float len = sqrtf(dot(v, v));
+        const float ilen = 1.f / len;
+        const f3 dir = v * ilen;
+        f3 g = mk3(g_rgb[3 * (size_t)i], g_rgb[3 * (size_t)i + 1], g_rgb[3 * (size_t)i + 2]);
+        // clamp mask on the unclamped radiance stored by the forward projection
+        if (!(rgb[3 * (size_t)i] > 0.f)) g.x = 0.f;
+        if (!(rgb[3 * (size_t)i + 1] > 0.f)) g.y = 0.f;
+        if (!(rgb[3 * (size_t)i + 2] > 0.f)) g.z = 0.f;
+        float basis[16];
+        f3 dbasis[16];
+        sh_basis(P.n_active, dir, basis);
+        sh_basis_grad(P.n_active, dir, dbasis);
+        f3 gdir = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < nact) {
+                const float s = g.x * myrow[3 * k] + g.y * myrow[3 * k + 1] + g.z * myrow[3 * k + 2];
+                gdir = gdir + dbasis[k] * s;
+                myrow[3 * k] = basis[k] * g.x; myrow[3 * k + 1] = basis[k] * g.y; myrow[3 * k + 2] = basis[k] * g.z;
+            }
         }
+        for (int k = 3 * nact; k < rowlen; ++k) myrow[k] = 0.f;
+        const float ng = dot(dir, gdir);
+        const f3 gpos = (gdir - dir * ng) * ilen;
+        g_density12[12 * (size_t)i + 0] += gpos.x;
+        g_density12[12 * (size_t)i + 1] += gpos.y;
+        g_density12[12 * (size_t)i + 2] += gpos.z;
+    } else {
+        for (int k = 0; k < rowlen; ++k) myrow[k] = 0.f;
     }
-    const float ng = dot(dir, gdir);
-    const f3 gpos = (gdir - dir * ng) * ilen;
-    g_density12[12 * (size_t)i + 0] += gpos.x;
-    g_density12[12 * (size_t)i + 1] += gpos.y;
-    g_density12[12 * (size_t)i + 2] += gpos.z;
+    __syncthreads();
+    // stage out: every row of the wave, zeros included (the caller does not pre-fill grad_sph)
+    const int nrows = (int)min(64u, P.N > wave_base ? P.N - wave_base : 0u);
+    for (int row = 0; row < nrows; ++row)
+        if (lane < rowlen) g_sph[(size_t)(wave_base + row) * rowlen + lane] = rows[row * kShStride + lane];
 }
 
 }  // namespace
@@ -856,7 +925,7 @@ void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
 }
 void launch_project_bwd(hipStream_t s, const GutParams& P, const uint32_t* tiles_count, const float* density12, const float* sph,
                         const float* rgb, const float* g_rgb, float* g_density12, float* g_sph) {
-    hipLaunchKernelGGL(gut_project_bwd_kernel, dim3(div_up(P.N, 256)), dim3(256), 0, s, P, tiles_count,
+    hipLaunchKernelGGL(gut_project_bwd_kernel, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, tiles_count,
                        reinterpret_cast<const float4*>(density12), sph, rgb, g_rgb, g_density12, g_sph);
 }
 

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: the N>1 path's exchange step (3dgrut_amd/dp.py) is correct by construction."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module("3dgrut_amd.dp")
+    torch.manual_seed(0)
+    n = 257
+    params = [torch.zeros(n, 3), torch.zeros(n, 4), torch.zeros(n, 3), torch.zeros(n, 1), torch.zeros(n, 48)]
+    g = torch.Generator().manual_seed(100 + rank)
+    for i, p in enumerate(params):
+        if not (rank == 1 and i == 3):  # rank 1 never produced a density gradient: counts as zero
+            p.grad = torch.randn(p.shape, generator=g)
+    local = [None if p.grad is None else p.grad.clone() for p in params]
+    cam = torch.tensor([0.0, 0.0, float(rank + 1)])
+    pos = torch.randn(n, 3, generator=torch.Generator().manual_seed(5))
+    stat, mask = dp.local_densify_stats(params[0].grad, pos, cam)
+    acc, den = stat.clone(), mask.clone()
+    dp.reduce_densify_accumulators(acc, den)
+    ex = dp.GradientExchange(params, average=True)
+    ex.reduce()
+    vis = torch.zeros(n, 1)
+    vis[rank::2] = 1.4e-45  # int bit pattern 1
+    red_vis = dp.reduce_visibility(vis)
+    out[rank] = dict(grads=[p.grad.numpy().copy() for p in params], local=[None if l is None else l.numpy() for l in local],
+                     stat=stat.numpy(), acc=acc.numpy(), den=den.numpy(), vis=red_vis.numpy(), views=dp.shard_views(5, rank, world))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    for i in range(5):
+        a = r0["local"][i]
+        b = r1["local"][i] if r1["local"][i] is not None else np.zeros_like(a)
+        np.testing.assert_allclose(r0["grads"][i], (a + b) / 2, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(r0["grads"][i], r1["grads"][i])  # identical on every rank
+    np.testing.assert_allclose(r0["acc"], r0["stat"] + r1["stat"], rtol=1e-6)
+    np.testing.assert_array_equal(r0["den"], np.full_like(r0["den"], 2.0))
+    assert r0["vis"].all() and r1["vis"].all()
+    assert r0["views"] == [0, 2, 4] and r1["views"] == [1, 3]
