@@ -238,6 +238,45 @@ __device__ __forceinline__ float wave_reduce_scatter16(const float (&v)[16], int
     return z;
 }
 
+// ---- packed fp32: two pixels per lane ---------------------------------------------------------
+// gfx950 issues one wave64 VALU instruction per 4 cycles per SIMD; v_pk_fma/mul/add_f32 do two floats per lane in
+// that slot.  The compositing kernels therefore keep a PAIR of pixels per lane in float2 registers; per-particle
+// (wave-uniform) operands are broadcast by the instruction's op_sel, so no shuffles are needed.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct p3 {
+    v2f x, y, z;
+};
+__device__ __forceinline__ v2f splat(float s) { v2f r = {s, s}; return r; }
+__device__ __forceinline__ v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pfma(float a, v2f b, v2f c) { return __builtin_elementwise_fma(splat(a), b, c); }
+__device__ __forceinline__ v2f pdot(p3 a, p3 b) { return pfma(a.x, b.x, pfma(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ v2f pdot(f3 a, p3 b) { return pfma(a.x, b.x, pfma(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ p3 pcross(p3 a, p3 b) {
+    return p3{pfma(a.y, b.z, -(a.z * b.y)), pfma(a.z, b.x, -(a.x * b.z)), pfma(a.x, b.y, -(a.y * b.x))};
+}
+__device__ __forceinline__ p3 pcross(p3 a, f3 b) {
+    return p3{pfma(b.z, a.y, -(b.y * a.z)), pfma(b.x, a.z, -(b.z * a.x)), pfma(b.y, a.x, -(b.x * a.y))};
+}
+__device__ __forceinline__ v2f psel(bool c0, bool c1, v2f t, v2f f) { v2f r = {c0 ? t.x : f.x, c1 ? t.y : f.y}; return r; }
+__device__ __forceinline__ v2f pmax0(v2f a) { v2f r = {fmaxf(a.x, 0.f), fmaxf(a.y, 0.f)}; return r; }
+__device__ __forceinline__ v2f prcp(v2f a) { v2f r = {__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; return r; }
+
+// largest grayDist g with particle_response<DEG>(g) > x  (x in (0,1); 0 when no g qualifies).  Lets the per-pixel
+// accept test run on grayDist itself, without a transcendental: response > min_response && response*density > min_alpha
+//   <=>  grayDist < response_gray_limit(max(min_response, min_alpha / density))
+template <int DEG>
+__device__ __forceinline__ float response_gray_limit(float x) {
+    if (!(x < 1.f) || !(x > 0.f)) return x > 0.f ? 0.f : 3.0e38f;
+    const float L = -logf(x);
+    if constexpr (DEG == 8) return sqrtf(sqrtf(L / 0.000685871056241f));
+    else if constexpr (DEG == 5) return powf(L / 0.0185185185185f, 0.4f);
+    else if constexpr (DEG == 4) return sqrtf(L / 0.0555555555556f);
+    else if constexpr (DEG == 3) return powf(L / 0.166666666667f, 2.f / 3.f);
+    else if constexpr (DEG == 1) { const float t = L / 1.5f; return t * t; }
+    else if constexpr (DEG == 0) { const float t = (1.f - x) / 0.329630334487f; return t * t; }
+    else return 2.f * L;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
     v = wave_sum_to_lane63(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));

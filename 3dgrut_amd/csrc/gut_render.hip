@@ -1,0 +1,663 @@
+// gut_render.hip — 3DGUT compositing for gfx950: front-to-back alpha compositing of the sorted tile lists and its
+// gradient sweep.
+//
+// Reference behaviour restated (not translated): gutKBufferRenderer.cuh:199-352 (render, K = 0), :642-716
+// (evalBackwardNoKBuffer, SH branch), common/rayPayload.cuh:75-193, rayPayloadBackward.cuh:30-73,
+// models/gaussianParticles.cuh:350-422 (processHitFwd), :484-751 (processHitBwd).
+//
+// CDNA4 design.  Both sweeps are bound by fp32 VALU issue (one wave64 VALU instruction per 4 cycles per SIMD), not by
+// HBM, so the kernels are organised around instruction count:
+//   * one wave64 owns a 16x8 half tile and every lane carries a PAIR of pixels (rows y and y+4) in float2 registers,
+//     so the multiply/add bulk of the per-(pixel, particle) math issues as v_pk_fma/mul/add_f32; per-particle operands
+//     are wave-uniform LDS broadcasts selected by the packed instructions' op_sel;
+//   * the accept test runs on the un-normalised quantities |v x u|^2 < g_max |v|^2 (u, v = ray origin / direction in
+//     the particle's canonical frame, g_max = per-particle limit on grayDist derived from min_response and
+//     min_alpha / density when the entry is staged): no transcendental on the reject path;
+//   * when every ray of the wave shares its origin (pinhole / fisheye batches: rays_ori = 0 in camera space) the
+//     canonical origin u is per particle and is staged with the record instead of being recomputed per pixel;
+//   * gradient sweep: with a = u - v (v.u)/|v|^2 every geometric gradient is a multiple of a, so per hit a lane
+//     produces  B = dL/d(R^T(o-mu))  (3),  M = B (x) (o - mu - t d)  (9, d rotT = M),  d density (1), d radiance (3)
+//     = 16 terms; the two pixels are folded in-lane, reduce-scattered over the wave with DPP (lane l ends up with
+//     the wave total of term l mod 16) and flushed with ONE atomic set per (half tile, particle-with-hit); quaternion,
+//     scale and position gradients are contracted from (B, M) once per flush, not per pixel.
+#include "gut_internal.hpp"
+
+namespace grut {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// rays (rayPayload.cuh:75-108, bounding_box.h:89-140)
+// ---------------------------------------------------------------------------------------------
+struct Ray {
+    f3 o, d;
+    float tmin, tmax;
+    bool valid;
+};
+__device__ __forceinline__ void swapf(float& a, float& b) { const float t = a; a = b; b = t; }
+__device__ __forceinline__ Ray init_ray(const GutParams& P, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                        int px, int py) {
+    Ray r;
+    r.valid = false;
+    r.o = mk3(0.f, 0.f, 0.f);
+    r.d = mk3(0.f, 0.f, 1.f);
+    r.tmin = r.tmax = 0.f;
+    if (px >= P.W || py >= P.H) return r;
+    const size_t pix = (size_t)py * P.W + px;
+    const f3 so = mk3(ray_o[3 * pix], ray_o[3 * pix + 1], ray_o[3 * pix + 2]);
+    const f3 sd = mk3(ray_d[3 * pix], ray_d[3 * pix + 1], ray_d[3 * pix + 2]);
+    const float* R = P.poses.s2w_R;
+    r.o = apply_rows(R, P.poses.s2w_t, so);
+    r.d = mk3(fmaf(R[0], sd.x, fmaf(R[1], sd.y, R[2] * sd.z)), fmaf(R[3], sd.x, fmaf(R[4], sd.y, R[5] * sd.z)),
+              fmaf(R[6], sd.x, fmaf(R[7], sd.y, R[8] * sd.z)));
+    const float lo = -1e6f, hi = 1e6f, big = 3.4028234663852886e+38f;
+    float tmin = (lo - r.o.x) / r.d.x, tmax = (hi - r.o.x) / r.d.x;
+    if (tmin > tmax) swapf(tmin, tmax);
+    float tymin = (lo - r.o.y) / r.d.y, tymax = (hi - r.o.y) / r.d.y;
+    if (tymin > tymax) swapf(tymin, tymax);
+    bool miss = (tmin > tymax) || (tymin > tmax);
+    if (tymin > tmin) tmin = tymin;
+    if (tymax < tmax) tmax = tymax;
+    float tzmin = (lo - r.o.z) / r.d.z, tzmax = (hi - r.o.z) / r.d.z;
+    if (tzmin > tzmax) swapf(tzmin, tzmax);
+    miss = miss || (tmin > tzmax) || (tzmin > tmax);
+    if (tzmin > tmin) tmin = tzmin;
+    if (tzmax < tmax) tmax = tzmax;
+    if (miss) { tmin = big; tmax = big; }
+    r.tmin = fmaxf(tmin, 0.f);
+    r.tmax = tmax;
+    r.valid = r.tmax > r.tmin;
+    return r;
+}
+
+// The pixel pair of a lane and the wave-level facts about its rays.
+struct RayPair {
+    p3 o, d;
+    v2f tmin, tmax;
+    bool valid0, valid1;
+    int px, py0, py1;
+    bool uniform_origin;  // every valid ray of the wave starts at `origin`
+    f3 origin;
+};
+__device__ __forceinline__ RayPair init_ray_pair(const GutParams& P, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                 uint32_t tile, uint32_t half, int lane) {
+    RayPair rp;
+    rp.px = (int)(tile % P.gx) * 16 + (lane & 15);
+    rp.py0 = (int)(tile / P.gx) * 16 + (int)half * 8 + (lane >> 4);
+    rp.py1 = rp.py0 + 4;
+    const Ray a = init_ray(P, ray_o, ray_d, rp.px, rp.py0), b = init_ray(P, ray_o, ray_d, rp.px, rp.py1);
+    rp.o = p3{v2f{a.o.x, b.o.x}, v2f{a.o.y, b.o.y}, v2f{a.o.z, b.o.z}};
+    rp.d = p3{v2f{a.d.x, b.d.x}, v2f{a.d.y, b.d.y}, v2f{a.d.z, b.d.z}};
+    rp.tmin = v2f{a.tmin, b.tmin};
+    rp.tmax = v2f{a.tmax, b.tmax};
+    rp.valid0 = a.valid;
+    rp.valid1 = b.valid;
+    // wave-uniform origin?  take the first valid ray as the candidate
+    const unsigned long long m0 = __ballot(a.valid), m1 = __ballot(b.valid);
+    f3 cand = mk3(0.f, 0.f, 0.f);
+    if (m0) {
+        const int src = __ffsll((long long)m0) - 1;
+        cand = mk3(__shfl(a.o.x, src, 64), __shfl(a.o.y, src, 64), __shfl(a.o.z, src, 64));
+    } else if (m1) {
+        const int src = __ffsll((long long)m1) - 1;
+        cand = mk3(__shfl(b.o.x, src, 64), __shfl(b.o.y, src, 64), __shfl(b.o.z, src, 64));
+    }
+    const bool same0 = !a.valid || (a.o.x == cand.x && a.o.y == cand.y && a.o.z == cand.z);
+    const bool same1 = !b.valid || (b.o.x == cand.x && b.o.y == cand.y && b.o.z == cand.z);
+    rp.uniform_origin = __all(same0 && same1);
+    rp.origin = cand;
+    return rp;
+}
+
+// block -> (virtual tile, half) with both halves of a tile on one XCD (block b runs on XCD b % 8)
+__device__ __forceinline__ void half_mapping(uint32_t b, uint32_t& vtile, uint32_t& half) {
+    const uint32_t xcd = b & 7u, slot = b >> 3;
+    vtile = ((slot >> 1) << 3) + xcd;
+    half = slot & 1u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// staged tile entry: 6 x float4 in LDS
+//   r0 = M.r0, pos.x | r1 = M.r1, pos.y | r2 = M.r2, pos.z      M = diag(1/scale) R^T  (gaussianParticles.slang:96-110)
+//   r3 = scale.xyz (fwd) or 1/scale.xyz (bwd), density
+//   r4 = clamped radiance rgb, g_max
+//   r5 = u0 = M (origin - pos) (uniform-origin waves), as_float(particle index)
+// Padding entries (index 0xFFFFFFFF) get M = I and g_max = 0: finite everywhere, never accepted.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRecQuads = 6;
+
+struct RawEntry {
+    uint32_t idx;
+    float4 a, q, s;
+    f3 rgb;
+};
+__device__ __forceinline__ RawEntry load_entry(uint32_t e, uint32_t end, const uint32_t* __restrict__ sorted_idx,
+                                               const float4* __restrict__ density12, const float* __restrict__ rgb) {
+    RawEntry r;
+    r.idx = 0xFFFFFFFFu;
+    r.a = r.q = r.s = make_float4(0.f, 0.f, 0.f, 0.f);
+    r.rgb = mk3(0.f, 0.f, 0.f);
+    if (e < end) {
+        r.idx = sorted_idx[e];
+        if (r.idx != 0xFFFFFFFFu) {
+            r.a = density12[3 * (size_t)r.idx + 0];
+            r.q = density12[3 * (size_t)r.idx + 1];
+            r.s = density12[3 * (size_t)r.idx + 2];
+            r.rgb = mk3(rgb[3 * (size_t)r.idx], rgb[3 * (size_t)r.idx + 1], rgb[3 * (size_t)r.idx + 2]);
+        }
+    }
+    return r;
+}
+template <int DEG, bool INVERSE_SCALE>
+__device__ __forceinline__ void stage_entry(const GutParams& P, const RawEntry& r, bool uniform_origin, f3 origin, float4* __restrict__ rec) {
+    float4 r0 = make_float4(1.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 1.f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
+    float4 r3 = make_float4(1.f, 1.f, 1.f, 0.f), r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 r5 = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
+    if (r.idx != 0xFFFFFFFFu) {
+        const m3 rt = quat_wxyz_to_rotT(r.q.x, r.q.y, r.q.z, r.q.w);
+        const float ix = __builtin_amdgcn_rcpf(r.s.x), iy = __builtin_amdgcn_rcpf(r.s.y), iz = __builtin_amdgcn_rcpf(r.s.z);
+        r0 = make_float4(rt.r0.x * ix, rt.r0.y * ix, rt.r0.z * ix, r.a.x);
+        r1 = make_float4(rt.r1.x * iy, rt.r1.y * iy, rt.r1.z * iy, r.a.y);
+        r2 = make_float4(rt.r2.x * iz, rt.r2.y * iz, rt.r2.z * iz, r.a.z);
+        r3 = INVERSE_SCALE ? make_float4(ix, iy, iz, r.a.w) : make_float4(r.s.x, r.s.y, r.s.z, r.a.w);
+        const float need = fmaxf(P.min_response, P.min_alpha / r.a.w);   // response must exceed this
+        const float gmax = (P.max_alpha > P.min_alpha && r.a.w > 0.f) ? response_gray_limit<DEG>(need) : 0.f;
+        r4 = make_float4(fmaxf(r.rgb.x, 0.f), fmaxf(r.rgb.y, 0.f), fmaxf(r.rgb.z, 0.f), gmax);
+        if (uniform_origin) {
+            const f3 dl = origin - mk3(r.a.x, r.a.y, r.a.z);
+            r5.x = dot(mk3(r0.x, r0.y, r0.z), dl);
+            r5.y = dot(mk3(r1.x, r1.y, r1.z), dl);
+            r5.z = dot(mk3(r2.x, r2.y, r2.z), dl);
+        }
+        r5.w = __uint_as_float(r.idx);
+    }
+    rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4; rec[5] = r5;
+}
+
+// canonical-frame ray of the pixel pair against one staged entry, and the accept test
+struct PairGeom {
+    p3 u, v;        // canonical origin, canonical (un-normalised) direction
+    v2f l2, cc;     // |v|^2, |v x u|^2  (grayDist = cc / l2)
+    bool acc0, acc1;
+};
+template <bool UNI>
+__device__ __forceinline__ PairGeom pair_geometry(const RayPair& rp, const float4* __restrict__ rec) {
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+    PairGeom g;
+    const f3 m0 = mk3(r0.x, r0.y, r0.z), m1 = mk3(r1.x, r1.y, r1.z), m2 = mk3(r2.x, r2.y, r2.z);
+    g.v = p3{pdot(m0, rp.d), pdot(m1, rp.d), pdot(m2, rp.d)};
+    if (UNI) {
+        const float4 r5 = rec[5];
+        g.u = p3{splat(r5.x), splat(r5.y), splat(r5.z)};
+    } else {
+        const p3 dl = p3{rp.o.x - r0.w, rp.o.y - r1.w, rp.o.z - r2.w};
+        g.u = p3{pdot(m0, dl), pdot(m1, dl), pdot(m2, dl)};
+    }
+    g.l2 = pdot(g.v, g.v);
+    const p3 c = pcross(g.v, g.u);
+    g.cc = pdot(c, c);
+    const v2f lim = rec[4].w * g.l2;
+    g.acc0 = g.cc.x < lim.x;
+    g.acc1 = g.cc.y < lim.y;
+    return g;
+}
+
+// particle_response<DEG> for a pixel pair (one v_exp_f32 per pixel, the polynomial part packed)
+template <int DEG>
+__device__ __forceinline__ v2f pair_response(v2f g) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    if constexpr (DEG == 2) {
+        const v2f e = g * (-0.5f * kLog2e);
+        return v2f{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    } else if constexpr (DEG == 4) {
+        const v2f e = (g * g) * (-0.0555555555556f * kLog2e);
+        return v2f{__builtin_amdgcn_exp2f(e.x), __builtin_amdgcn_exp2f(e.y)};
+    } else {
+        return v2f{particle_response<DEG>(g.x), particle_response<DEG>(g.y)};
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7: compositing forward — GUTKBufferRenderer::evalKBuffer, K = 0 (gutKBufferRenderer.cuh:273-352)
+// Rounds are aligned to multiples of 64 in the global sorted list, so every segment boundary (multiple of
+// kGutSegment) is a round start, where the running state is checkpointed for the gradient sweep.
+// ---------------------------------------------------------------------------------------------
+struct FwdState {
+    v2f T, D, Cr, Cg, Cb, cnt;
+};
+template <int DEG, bool CKPT, bool UNI>
+__device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPair& rp, uint2 range, uint32_t half, int lane,
+                                                 const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ density12,
+                                                 const float* __restrict__ rgb, const GutCheckpoints& ck, float4* __restrict__ s_rec,
+                                                 FwdState& st) {
+    bool alive0 = rp.valid0, alive1 = rp.valid1;
+    v2f T = splat(1.f), D = splat(0.f), Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f), cnt = splat(0.f);
+    uint32_t b = range.x;
+    RawEntry next = load_entry(b + lane, min(range.y, (b & ~63u) + 64u), sorted_idx, density12, rgb);
+    while (b < range.y) {
+        if (!__any(alive0 || alive1)) break;
+        const uint32_t bend = min(range.y, (b & ~63u) + 64u);
+        if (CKPT && b > range.x && (b % kGutSegment) == 0) {
+            const size_t slot = (((size_t)(b / kGutSegment) * 2 + half) * 64 + lane) * 2;
+            // dead pixels restart dead (T = 0 < min_transmittance)
+            ck.tc[slot] = make_float4(alive0 ? T.x : 0.f, Cr.x, Cg.x, Cb.x);
+            ck.tc[slot + 1] = make_float4(alive1 ? T.y : 0.f, Cr.y, Cg.y, Cb.y);
+            ck.d[slot] = D.x;
+            ck.d[slot + 1] = D.y;
+            if (lane == 0) ck.reached[(size_t)(b / kGutSegment) * 2 + half] = 1;
+        }
+        stage_entry<DEG, false>(P, next, UNI, rp.origin, &s_rec[lane * kRecQuads]);
+        __syncthreads();  // single-wave workgroup: orders the LDS hand-off
+        // fetch the following round while this one is being composited
+        next = load_entry(bend + lane, min(range.y, bend + 64u), sorted_idx, density12, rgb);
+        const int n = (int)(bend - b);
+        for (int j = 0; j < n; ++j) {
+            const float4* rec = &s_rec[j * kRecQuads];
+            const PairGeom g = pair_geometry<UNI>(rp, rec);
+            const bool c0 = g.acc0 && alive0, c1 = g.acc1 && alive1;
+            if (!__any(c0 || c1)) continue;
+            const float4 r3 = rec[3], r4 = rec[4];
+            const v2f il2 = prcp(g.l2);
+            const v2f gray = g.cc * il2;
+            const v2f resp = pair_response<DEG>(gray);
+            const v2f ad = resp * r3.w;
+            // hit distance |S n (n.-u)| = |v.u| |S v| / |v|^2   (gaussianParticles.slang:181-190)
+            const v2f vu = pdot(g.v, g.u);
+            const p3 sv = p3{r3.x * g.v.x, r3.y * g.v.y, r3.z * g.v.z};
+            const v2f ss = pdot(sv, sv) * (vu * vu);
+            const v2f hitT = v2f{__builtin_amdgcn_sqrtf(ss.x), __builtin_amdgcn_sqrtf(ss.y)} * il2;
+            const bool h0 = c0 && (hitT.x > rp.tmin.x) && (hitT.x < rp.tmax.x);
+            const bool h1 = c1 && (hitT.y > rp.tmin.y) && (hitT.y < rp.tmax.y);
+            const v2f alpha = psel(h0, h1, v2f{fminf(P.max_alpha, ad.x), fminf(P.max_alpha, ad.y)}, splat(0.f));
+            const v2f hT = psel(h0, h1, hitT, splat(0.f));
+            const v2f w = alpha * T;
+            D = pfma(hT, w, D);
+            T = T * (1.f - alpha);
+            Cr = pfma(r4.x, w, Cr);
+            Cg = pfma(r4.y, w, Cg);
+            Cb = pfma(r4.z, w, Cb);
+            cnt += psel(w.x > 0.f, w.y > 0.f, splat(1.f), splat(0.f));
+            alive0 = alive0 && !(T.x < P.min_transmittance);
+            alive1 = alive1 && !(T.y < P.min_transmittance);
+        }
+        __syncthreads();
+        b = bend;
+    }
+    st = FwdState{T, D, Cr, Cg, Cb, cnt};
+}
+
+template <int DEG, bool CKPT>
+__global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges,
+                                                            const uint32_t* __restrict__ sorted_idx,
+                                                            const float4* __restrict__ density12, const float* __restrict__ rgb,
+                                                            const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                            float4* __restrict__ out_fd, float* __restrict__ out_dist,
+                                                            float* __restrict__ out_cnt, GutCheckpoints ck) {
+    __shared__ float4 s_rec[64 * kRecQuads];
+    uint32_t tile, half;
+    half_mapping(blockIdx.x, tile, half);
+    if (tile >= (uint32_t)(P.gx * P.gy)) return;
+    const int lane = threadIdx.x;
+    const RayPair rp = init_ray_pair(P, ray_o, ray_d, tile, half, lane);
+    const uint2 range = ranges[tile];
+    FwdState st;
+    // two copies of the sweep: the shared-origin one keeps the canonical origin out of the per-pixel math
+    if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true>(P, rp, range, half, lane, sorted_idx, density12, rgb, ck, s_rec, st);
+    else render_fwd_sweep<DEG, CKPT, false>(P, rp, range, half, lane, sorted_idx, density12, rgb, ck, s_rec, st);
+    if (rp.valid0) {
+        const size_t pix = (size_t)rp.py0 * P.W + rp.px;
+        out_fd[pix] = make_float4(st.Cr.x, st.Cg.x, st.Cb.x, 1.f - st.T.x);
+        out_dist[pix] = st.D.x;
+        if (P.hitcounts) out_cnt[pix] = st.cnt.x;
+    }
+    if (rp.valid1) {
+        const size_t pix = (size_t)rp.py1 * P.W + rp.px;
+        out_fd[pix] = make_float4(st.Cr.y, st.Cg.y, st.Cb.y, 1.f - st.T.y);
+        out_dist[pix] = st.D.y;
+        if (P.hitcounts) out_cnt[pix] = st.cnt.y;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8: compositing backward — evalBackwardNoKBuffer SH branch (gutKBufferRenderer.cuh:642-716) with
+// processHitBwd (models/gaussianParticles.cuh:484-751).
+//
+// With u = gro, v = grdu (un-normalised), t = (v.u)/|v|^2, a = u - t v:  grayDist = |a|^2 and
+//   d gray / d u = 2 a,      d gray / d v = -2 t a
+// so with wg = dL/d gray:  uGrd = 2 wg a,  vGrd = -t uGrd,  B = uGrd / scale = dL/d(R^T (o - mu)),
+//   dL/d rotT = B (x) (o - mu) + (-t B) (x) d = B (x) e,   e = (o - mu) - t d
+//   dL/d position = -R B,     dL/d scale_i = -(1/s_i) sum_j rotT_ij M_ij,    M = sum over pixels of B (x) e
+// which is the reference's chain (two cross-product backward passes, safe_normalize_bw, matmul_bw_vec/quat) collapsed.
+// For uniform-origin waves  M = (sum B) (x) (o - mu) - sum (t B) (x) d  and only the second sum is reduced.
+// When a depth gradient flows in (HAS_GDIST) the hit-distance terms (gaussianParticles.cuh:545-580) are added in
+// their generic form: B (x) (o-mu) and Bv (x) d are accumulated separately and the direct scale term is reduced in a
+// second pass.
+// ---------------------------------------------------------------------------------------------
+// gradient of sum_ij m_ij rotT_ij(q) w.r.t. q = (r,x,y,z); q2 = 2q (matmul_bw_quat, mathUtils.cuh:458-521)
+__device__ __forceinline__ float4 quat_contract(const float m[9], float4 q2) {
+    const float r = q2.x, x = q2.y, y = q2.z, z = q2.w;
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+    // rotT = [[1-2(yy+zz), 2(xy+rz), 2(xz-ry)], [2(xy-rz), 1-2(xx+zz), 2(yz+rx)], [2(xz+ry), 2(yz-rx), 1-2(xx+yy)]]
+    const float s01 = m01 + m10, s02 = m02 + m20, s12 = m12 + m21;   // symmetric parts
+    const float a01 = m01 - m10, a02 = m20 - m02, a12 = m12 - m21;   // antisymmetric parts (signs as in rotT)
+    float4 d;
+    d.x = z * a01 + y * a02 + x * a12;
+    d.y = y * s01 + z * s02 + r * a12 - 2.f * x * (m11 + m22);
+    d.z = x * s01 + z * s12 + r * a02 - 2.f * y * (m00 + m22);
+    d.w = x * s02 + y * s12 + r * a01 - 2.f * z * (m00 + m11);
+    return d;
+}
+
+constexpr uint32_t kBwdBatch = 32;  // staged entries per round of the gradient sweep
+
+struct BwdPixels {
+    v2f T, D, Cr, Cg, Cb;           // running state
+    v2f T_fin, D_fin, gT, gD;       // forward results and upstream gradients
+    p3 C_fin, gC;
+    bool alive0, alive1;
+};
+template <int DEG, bool HAS_GDIST, bool UNI>
+__device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPair& rp, uint32_t seg_begin, uint32_t seg_end, int lane,
+                                                 const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ density12,
+                                                 const float* __restrict__ rgb, float* __restrict__ g_density12, float* __restrict__ g_rgb,
+                                                 float4* __restrict__ s_rec, float* __restrict__ s_acc, float* __restrict__ s_acc2,
+                                                 const BwdPixels& px) {
+    constexpr uint32_t kBatch = kBwdBatch;
+    v2f T = px.T, D = px.D, Cr = px.Cr, Cg = px.Cg, Cb = px.Cb;
+    const v2f T_fin = px.T_fin, D_fin = px.D_fin, gT = px.gT, gD = px.gD;
+    const p3 C_fin = px.C_fin, gC = px.gC;
+    bool alive0 = px.alive0, alive1 = px.alive1;
+    uint32_t b = seg_begin;
+    RawEntry next = load_entry(b + lane, min(seg_end, (b & ~(kBatch - 1u)) + kBatch), sorted_idx, density12, rgb);
+    while (b < seg_end) {
+        if (!__any(alive0 || alive1)) break;
+        const uint32_t bend = min(seg_end, (b & ~(kBatch - 1u)) + kBatch);
+        if (lane < (int)kBatch) stage_entry<DEG, true>(P, next, UNI, rp.origin, &s_rec[lane * kRecQuads]);
+        __syncthreads();
+        next = load_entry(bend + lane, min(seg_end, bend + kBatch), sorted_idx, density12, rgb);
+        const int n = (int)(bend - b);
+        uint32_t hit_entries = 0u;  // wave-uniform: staged entries with >= 1 hit in this wave
+        for (int j = 0; j < n; ++j) {
+            if (!__any(alive0 || alive1)) break;
+            const float4* rec = &s_rec[j * kRecQuads];
+            const PairGeom g = pair_geometry<UNI>(rp, rec);
+            const bool h0 = g.acc0 && alive0, h1 = g.acc1 && alive1;
+            if (!__any(h0 || h1)) continue;
+            hit_entries |= (1u << j);
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
+            const v2f il2 = prcp(g.l2);
+            const v2f gray = g.cc * il2;
+            const v2f resp = pair_response<DEG>(gray);
+            const v2f ad = resp * r3.w;
+            const v2f alpha = psel(h0, h1, v2f{fminf(P.max_alpha, ad.x), fminf(P.max_alpha, ad.y)}, splat(0.f));
+            const v2f weight = alpha * T;
+            const v2f oma = 1.f - alpha;
+            const v2f nextT = oma * T;
+            v2f inextT = prcp(nextT);
+            inextT = psel(nextT.x <= P.min_transmittance, nextT.y <= P.min_transmittance, splat(0.f), inextT);
+            const v2f resTrm = psel(alpha.x < 0.999999f, alpha.y < 0.999999f, T_fin * prcp(oma), T);
+            v2f dalpha = -(resTrm * gT);  // d L / d alpha
+            const p3 dc = p3{gC.x * weight, gC.y * weight, gC.z * weight};
+            Cr = pfma(r4.x, weight, Cr); Cg = pfma(r4.y, weight, Cg); Cb = pfma(r4.z, weight, Cb);
+            const v2f rr = pmax0((C_fin.x - Cr) * inextT), rg = pmax0((C_fin.y - Cg) * inextT), rb = pmax0((C_fin.z - Cb) * inextT);
+            dalpha = pfma(T, pfma(r4.x - rr, gC.x, pfma(r4.y - rg, gC.y, (r4.z - rb) * gC.z)), dalpha);
+
+            const v2f vu = pdot(g.v, g.u);
+            const v2f t = vu * il2;
+            const p3 a = p3{pfma(-t, g.v.x, g.u.x), pfma(-t, g.v.y, g.u.y), pfma(-t, g.v.z, g.u.z)};
+            // canonical-frame offsets of the ray origin, needed un-scaled for the rotation gradient
+            p3 dl;
+            if (UNI) dl = p3{splat(rp.origin.x - r0.w), splat(rp.origin.y - r1.w), splat(rp.origin.z - r2.w)};
+            else dl = p3{rp.o.x - r0.w, rp.o.y - r1.w, rp.o.z - r2.w};
+
+            p3 uX = p3{splat(0.f), splat(0.f), splat(0.f)}, vX = uX, sX = uX;   // hit-distance extras
+            if (HAS_GDIST) {
+                // n = v/|v|, pdot = -(n.u), grds = s * n * pdot, hitT = |grds|  (gaussianParticles.cuh:545-580)
+                const v2f il = v2f{__builtin_amdgcn_rsqf(g.l2.x), __builtin_amdgcn_rsqf(g.l2.y)};
+                const p3 nrm = p3{g.v.x * il, g.v.y * il, g.v.z * il};
+                const v2f nu = vu * il;
+                const v2f pdt = -nu;
+                const p3 gscl = p3{prcp(splat(r3.x)), prcp(splat(r3.y)), prcp(splat(r3.z))};
+                const p3 grdd = p3{nrm.x * pdt, nrm.y * pdt, nrm.z * pdt};
+                const p3 grds = p3{gscl.x * grdd.x, gscl.y * grdd.y, gscl.z * grdd.z};
+                const v2f gsq = pdot(grds, grds);
+                const v2f gdist = v2f{__builtin_amdgcn_sqrtf(gsq.x), __builtin_amdgcn_sqrtf(gsq.y)};
+                D = pfma(weight, gdist, D);
+                const v2f resHitT = pmax0((D_fin - D) * inextT);
+                dalpha = pfma((gdist - resHitT) * T, gD, dalpha);
+                const v2f k = psel(gsq.x > 0.f, gsq.y > 0.f, weight * prcp(gdist) * gD, splat(0.f));
+                const p3 grdsGrd = p3{grds.x * k, grds.y * k, grds.z * k};
+                sX = p3{grdd.x * grdsGrd.x, grdd.y * grdsGrd.y, grdd.z * grdsGrd.z};     // direct d hitT / d scale
+                const p3 sg = p3{gscl.x * grdsGrd.x, gscl.y * grdsGrd.y, gscl.z * grdsGrd.z};
+                const v2f sd = pdot(sg, nrm);
+                const p3 nGrd = p3{pfma(sg.x, pdt, -(g.u.x * sd)), pfma(sg.y, pdt, -(g.u.y * sd)), pfma(sg.z, pdt, -(g.u.z * sd))};
+                uX = p3{-(nrm.x * sd), -(nrm.y * sd), -(nrm.z * sd)};                    // d / d gro
+                const v2f ng = pdot(nrm, nGrd);                                          // safe_normalize_bw
+                vX = p3{(nGrd.x - nrm.x * ng) * il, (nGrd.y - nrm.y * ng) * il, (nGrd.z - nrm.z * ng) * il};
+            }
+
+            dalpha = psel(h0, h1, dalpha, splat(0.f));
+            const v2f dn = resp * dalpha;
+            const v2f dresp = r3.w * dalpha;
+            const v2f wg2 = psel(h0, h1, 2.f * v2f{particle_response_grd<DEG>(gray.x, resp.x, dresp.x),
+                                                    particle_response_grd<DEG>(gray.y, resp.y, dresp.y)}, splat(0.f));
+            p3 uGrd = p3{a.x * wg2, a.y * wg2, a.z * wg2};                 // d L / d gro
+            float terms[16], extra[16];
+            if (!HAS_GDIST) {
+                const p3 B = p3{r3.x * uGrd.x, r3.y * uGrd.y, r3.z * uGrd.z};   // d L / d (R^T (o - mu))
+                p3 e;   // second factor of the rank-1 rotation gradient
+                v2f s;  // ... and its scale on B
+                if (UNI) { e = rp.d; s = -t; }                    // (sum B) (x) (o - mu) is added at flush
+                else { e = p3{pfma(-t, rp.d.x, dl.x), pfma(-t, rp.d.y, dl.y), pfma(-t, rp.d.z, dl.z)}; s = splat(1.f); }
+                const p3 Bs = p3{B.x * s, B.y * s, B.z * s};
+                const v2f m[9] = {Bs.x * e.x, Bs.x * e.y, Bs.x * e.z, Bs.y * e.x, Bs.y * e.y, Bs.y * e.z, Bs.z * e.x, Bs.z * e.y, Bs.z * e.z};
+                terms[0] = B.x.x + B.x.y; terms[1] = B.y.x + B.y.y; terms[2] = B.z.x + B.z.y; terms[3] = dn.x + dn.y;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) terms[4 + k] = m[k].x + m[k].y;
+                terms[13] = dc.x.x + dc.x.y; terms[14] = dc.y.x + dc.y.y; terms[15] = dc.z.x + dc.z.y;
+            } else {
+                const v2f mt = psel(h0, h1, splat(1.f), splat(0.f));
+                uGrd = p3{pfma(uX.x, mt, uGrd.x), pfma(uX.y, mt, uGrd.y), pfma(uX.z, mt, uGrd.z)};
+                const p3 vGrd = p3{pfma(vX.x, mt, -(t * a.x * wg2)), pfma(vX.y, mt, -(t * a.y * wg2)), pfma(vX.z, mt, -(t * a.z * wg2))};
+                const p3 B = p3{r3.x * uGrd.x, r3.y * uGrd.y, r3.z * uGrd.z};
+                const p3 Bv = p3{r3.x * vGrd.x, r3.y * vGrd.y, r3.z * vGrd.z};
+                const v2f m[9] = {pfma(B.x, dl.x, Bv.x * rp.d.x), pfma(B.x, dl.y, Bv.x * rp.d.y), pfma(B.x, dl.z, Bv.x * rp.d.z),
+                                  pfma(B.y, dl.x, Bv.y * rp.d.x), pfma(B.y, dl.y, Bv.y * rp.d.y), pfma(B.y, dl.z, Bv.y * rp.d.z),
+                                  pfma(B.z, dl.x, Bv.z * rp.d.x), pfma(B.z, dl.y, Bv.z * rp.d.y), pfma(B.z, dl.z, Bv.z * rp.d.z)};
+                terms[0] = B.x.x + B.x.y; terms[1] = B.y.x + B.y.y; terms[2] = B.z.x + B.z.y; terms[3] = dn.x + dn.y;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) terms[4 + k] = m[k].x + m[k].y;
+                terms[13] = dc.x.x + dc.x.y; terms[14] = dc.y.x + dc.y.y; terms[15] = dc.z.x + dc.z.y;
+                const p3 sXm = p3{sX.x * mt, sX.y * mt, sX.z * mt};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) extra[k] = 0.f;
+                extra[0] = sXm.x.x + sXm.x.y; extra[1] = sXm.y.x + sXm.y.y; extra[2] = sXm.z.x + sXm.z.y;
+            }
+            const float tot = wave_reduce_scatter16(terms, lane);
+            if (lane < 16) s_acc[j * 16 + lane] = tot;
+            if (HAS_GDIST) {
+                const float tot2 = wave_reduce_scatter16(extra, lane);
+                if (lane < 16) s_acc2[j * 16 + lane] = tot2;
+            }
+            T = nextT;
+            alive0 = alive0 && !(T.x < P.min_transmittance);
+            alive1 = alive1 && !(T.y < P.min_transmittance);
+        }
+        __syncthreads();
+        // flush: lane j owns staged entry j; one atomic set per (half tile, particle with a hit)
+        if (lane < (int)kBatch && ((hit_entries >> lane) & 1u)) {
+            const float4* rec = &s_rec[lane * kRecQuads];
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];   // r3.xyz = 1/scale
+            const uint32_t idx = __float_as_uint(rec[5].w);
+            const float4* acc = reinterpret_cast<const float4*>(&s_acc[lane * 16]);
+            const float4 a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+            const f3 B = mk3(a0.x, a0.y, a0.z);
+            float m[9] = {a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x};
+            if (!HAS_GDIST && UNI) {
+                const f3 dl = rp.origin - mk3(r0.w, r1.w, r2.w);
+                m[0] += B.x * dl.x; m[1] += B.x * dl.y; m[2] += B.x * dl.z;
+                m[3] += B.y * dl.x; m[4] += B.y * dl.y; m[5] += B.y * dl.z;
+                m[6] += B.z * dl.x; m[7] += B.z * dl.y; m[8] += B.z * dl.z;
+            }
+            // rows of R^T from the staged M = diag(1/s) R^T
+            const f3 sc = mk3(__builtin_amdgcn_rcpf(r3.x), __builtin_amdgcn_rcpf(r3.y), __builtin_amdgcn_rcpf(r3.z));
+            const f3 t0 = mk3(r0.x, r0.y, r0.z) * sc.x, t1 = mk3(r1.x, r1.y, r1.z) * sc.y, t2 = mk3(r2.x, r2.y, r2.z) * sc.z;
+            // position = -R B  (matmul_bw_vec with rows of R^T)
+            const float gpx = -(B.x * t0.x + B.y * t1.x + B.z * t2.x);
+            const float gpy = -(B.x * t0.y + B.y * t1.y + B.z * t2.y);
+            const float gpz = -(B.x * t0.z + B.y * t1.z + B.z * t2.z);
+            // scale_i = -(1/s_i) sum_j rotT_ij m_ij (+ direct hit-distance term)
+            float gsx = -r3.x * (t0.x * m[0] + t0.y * m[1] + t0.z * m[2]);
+            float gsy = -r3.y * (t1.x * m[3] + t1.y * m[4] + t1.z * m[5]);
+            float gsz = -r3.z * (t2.x * m[6] + t2.y * m[7] + t2.z * m[8]);
+            if (HAS_GDIST) { gsx += s_acc2[lane * 16 + 0]; gsy += s_acc2[lane * 16 + 1]; gsz += s_acc2[lane * 16 + 2]; }
+            const float4 q = density12[3 * (size_t)idx + 1];
+            const float4 dq = quat_contract(m, make_float4(2.f * q.x, 2.f * q.y, 2.f * q.z, 2.f * q.w));
+            float* gd = g_density12 + 12 * (size_t)idx;
+            atomicAdd(gd + 0, gpx); atomicAdd(gd + 1, gpy); atomicAdd(gd + 2, gpz); atomicAdd(gd + 3, a0.w);
+            atomicAdd(gd + 4, dq.x); atomicAdd(gd + 5, dq.y); atomicAdd(gd + 6, dq.z); atomicAdd(gd + 7, dq.w);
+            atomicAdd(gd + 8, gsx); atomicAdd(gd + 9, gsy); atomicAdd(gd + 10, gsz);
+            float* gr = g_rgb + 3 * (size_t)idx;
+            atomicAdd(gr + 0, a3.y); atomicAdd(gr + 1, a3.z); atomicAdd(gr + 2, a3.w);
+        }
+        __syncthreads();
+        b = bend;
+    }
+}
+
+template <int DEG, bool HAS_GDIST>
+__global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const uint2* __restrict__ ranges,
+                                                            const uint32_t* __restrict__ sorted_idx,
+                                                            const float4* __restrict__ density12, const float* __restrict__ rgb,
+                                                            const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                            const float4* __restrict__ fd, const float4* __restrict__ g_fd,
+                                                            const float* __restrict__ dist, const float* __restrict__ g_dist,
+                                                            float* __restrict__ g_density12, float* __restrict__ g_rgb,
+                                                            GutCheckpoints ck) {
+    constexpr uint32_t kBatch = kBwdBatch;
+    __shared__ float4 s_rec[kBatch * kRecQuads];
+    __shared__ float s_acc[kBatch * 16];                       // per staged entry: 16 wave-reduced terms
+    __shared__ float s_acc2[HAS_GDIST ? kBatch * 16 : 1];      // depth-gradient extras (3 used)
+    // task = (virtual tile, half).  Virtual tiles [0, bndPad) are the segments that start at segment boundary b (sorted
+    // index b * kGutSegment): they are the long, dense tasks and are dispatched first so that the tail of the launch
+    // is made of the short first segments of each tile list, virtual tiles [bndPad, bndPad + tiles).
+    const uint32_t num_tiles = (uint32_t)(P.gx * P.gy), bnd_pad = (ck.num_boundaries + 7u) & ~7u;
+    uint32_t vtile, half;
+    half_mapping(blockIdx.x, vtile, half);
+    uint32_t tile, seg_begin;
+    bool from_checkpoint = false;
+    uint32_t boundary = 0;
+    if (vtile >= bnd_pad) {
+        tile = vtile - bnd_pad;
+        if (tile >= num_tiles) return;
+        seg_begin = ranges[tile].x;
+    } else {
+        boundary = vtile;
+        if (boundary == 0 || boundary >= ck.num_boundaries) return;
+        if (!ck.reached[(size_t)boundary * 2 + half]) return;        // the forward sweep never got here alive
+        tile = ck.boundary_tile[boundary];
+        if (tile >= num_tiles) return;
+        seg_begin = boundary * kGutSegment;
+        if (seg_begin <= ranges[tile].x) return;                     // the boundary is this tile's own list start
+        from_checkpoint = true;
+    }
+    const uint32_t seg_end = min(ranges[tile].y, (seg_begin / kGutSegment + 1u) * kGutSegment);
+    const int lane = threadIdx.x;
+    const RayPair rp = init_ray_pair(P, ray_o, ray_d, tile, half, lane);
+    bool alive0 = rp.valid0, alive1 = rp.valid1;
+
+    v2f T = splat(1.f), D = splat(0.f), Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f);
+    v2f T_fin = splat(0.f), D_fin = splat(0.f), gT = splat(0.f), gD = splat(0.f);
+    p3 C_fin = p3{splat(0.f), splat(0.f), splat(0.f)}, gC = C_fin;
+    if (alive0) {
+        const size_t pix = (size_t)rp.py0 * P.W + rp.px;
+        const float4 f = fd[pix], g = g_fd[pix];
+        C_fin.x.x = f.x; C_fin.y.x = f.y; C_fin.z.x = f.z; gC.x.x = g.x; gC.y.x = g.y; gC.z.x = g.z;
+        T_fin.x = 1.f - f.w; gT.x = -g.w;
+        if (HAS_GDIST) { D_fin.x = dist[pix]; gD.x = g_dist[pix]; }
+    }
+    if (alive1) {
+        const size_t pix = (size_t)rp.py1 * P.W + rp.px;
+        const float4 f = fd[pix], g = g_fd[pix];
+        C_fin.x.y = f.x; C_fin.y.y = f.y; C_fin.z.y = f.z; gC.x.y = g.x; gC.y.y = g.y; gC.z.y = g.z;
+        T_fin.y = 1.f - f.w; gT.y = -g.w;
+        if (HAS_GDIST) { D_fin.y = dist[pix]; gD.y = g_dist[pix]; }
+    }
+    if (from_checkpoint) {
+        const size_t slot = (((size_t)boundary * 2 + half) * 64 + lane) * 2;
+        const float4 c0 = ck.tc[slot], c1 = ck.tc[slot + 1];
+        T = v2f{c0.x, c1.x}; Cr = v2f{c0.y, c1.y}; Cg = v2f{c0.z, c1.z}; Cb = v2f{c0.w, c1.w};
+        if (HAS_GDIST) D = v2f{ck.d[slot], ck.d[slot + 1]};
+        alive0 = alive0 && !(T.x < P.min_transmittance);
+        alive1 = alive1 && !(T.y < P.min_transmittance);
+    }
+
+    BwdPixels px{T, D, Cr, Cg, Cb, T_fin, D_fin, gT, gD, C_fin, gC, alive0, alive1};
+    if (rp.uniform_origin)
+        render_bwd_sweep<DEG, HAS_GDIST, true>(P, rp, seg_begin, seg_end, lane, sorted_idx, density12, rgb, g_density12, g_rgb, s_rec, s_acc, s_acc2, px);
+    else
+        render_bwd_sweep<DEG, HAS_GDIST, false>(P, rp, seg_begin, seg_end, lane, sorted_idx, density12, rgb, g_density12, g_rgb, s_rec, s_acc, s_acc2, px);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static uint32_t half_grid(const GutParams& P) {
+    const uint32_t tiles = (uint32_t)(P.gx * P.gy);
+    return ((tiles + 7u) & ~7u) * 2u;
+}
+// tile-first segments + one task set per segment boundary, padded to the 8-XCD interleave
+static uint32_t segment_grid(const GutParams& P, uint32_t num_boundaries) {
+    const uint32_t tiles = (uint32_t)(P.gx * P.gy);
+    const uint32_t vtiles = ((tiles + 7u) & ~7u) + ((num_boundaries + 7u) & ~7u);
+    return vtiles * 2u;
+}
+
+#define GRUT_DISPATCH_DEGREE(DEG, ...)                         \
+    switch (DEG) {                                             \
+    case 0: { constexpr int D_ = 0; __VA_ARGS__; } break;      \
+    case 1: { constexpr int D_ = 1; __VA_ARGS__; } break;      \
+    case 3: { constexpr int D_ = 3; __VA_ARGS__; } break;      \
+    case 4: { constexpr int D_ = 4; __VA_ARGS__; } break;      \
+    case 5: { constexpr int D_ = 5; __VA_ARGS__; } break;      \
+    case 8: { constexpr int D_ = 8; __VA_ARGS__; } break;      \
+    default: { constexpr int D_ = 2; __VA_ARGS__; } break;     \
+    }
+
+void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_idx, const float* density12,
+                       const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist, float* out_cnt,
+                       const GutCheckpoints& ck, bool write_checkpoints) {
+    if (write_checkpoints) {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_fwd_kernel<D_, true>), dim3(half_grid(P)), dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                          reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck));
+    } else {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_fwd_kernel<D_, false>), dim3(half_grid(P)), dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                          reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck));
+    }
+}
+void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_idx, const float* density12,
+                       const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* dist,
+                       const float* g_dist, float* g_density12, float* g_rgb, const GutCheckpoints& ck) {
+    const dim3 grid(segment_grid(P, ck.num_boundaries));
+    if (g_dist) {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_bwd_kernel<D_, true>), grid, dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                          reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
+                                                          g_dist, g_density12, g_rgb, ck));
+    } else {  // no depth gradient flows in: the hit-distance terms vanish identically
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_bwd_kernel<D_, false>), grid, dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                          reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
+                                                          g_dist, g_density12, g_rgb, ck));
+    }
+}
+
+}  // namespace grut
