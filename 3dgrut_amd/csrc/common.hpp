@@ -214,7 +214,7 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_perm(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
-__device__ __forceinline__ float wave_reduce_scatter16(const float (&v)[16], int lane) {
+__device__ __forceinline__ float wave_reduce_scatter16_rows(const float (&v)[16], int lane) {
     const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
     float w[8], x[4], y[2];
 #pragma unroll
@@ -233,6 +233,13 @@ __device__ __forceinline__ float wave_reduce_scatter16(const float (&v)[16], int
         y[i] = keep + dpp_perm<0x4E>(send);   // quad_perm [2,3,0,1]: partner = lane ^ 2
     }
     float z = (b0 ? y[1] : y[0]) + dpp_perm<0xB1>(b0 ? y[0] : y[1]);  // quad_perm [1,0,3,2]: partner = lane ^ 1
+    return z;
+}
+// After the four in-row steps lane l holds the sum over its 16-lane ROW of v[l & 15]; the wave total of term t is the
+// sum of lanes t, t+16, t+32, t+48.  wave_reduce_scatter16 finishes with two cross-row exchanges; the *_rows variant
+// returns the per-row partials so that a consumer that goes through LDS anyway can add the four rows there.
+__device__ __forceinline__ float wave_reduce_scatter16(const float (&v)[16], int lane) {
+    float z = wave_reduce_scatter16_rows(v, lane);
     z += __shfl_xor(z, 16, 64);
     z += __shfl_xor(z, 32, 64);
     return z;
@@ -253,9 +260,6 @@ __device__ __forceinline__ v2f pdot(p3 a, p3 b) { return pfma(a.x, b.x, pfma(a.y
 __device__ __forceinline__ v2f pdot(f3 a, p3 b) { return pfma(a.x, b.x, pfma(a.y, b.y, a.z * b.z)); }
 __device__ __forceinline__ p3 pcross(p3 a, p3 b) {
     return p3{pfma(a.y, b.z, -(a.z * b.y)), pfma(a.z, b.x, -(a.x * b.z)), pfma(a.x, b.y, -(a.y * b.x))};
-}
-__device__ __forceinline__ p3 pcross(p3 a, f3 b) {
-    return p3{pfma(b.z, a.y, -(b.y * a.z)), pfma(b.x, a.z, -(b.z * a.x)), pfma(b.y, a.x, -(b.x * a.y))};
 }
 __device__ __forceinline__ v2f psel(bool c0, bool c1, v2f t, v2f f) { v2f r = {c0 ? t.x : f.x, c1 ? t.y : f.y}; return r; }
 __device__ __forceinline__ v2f pmax0(v2f a) { v2f r = {fmaxf(a.x, 0.f), fmaxf(a.y, 0.f)}; return r; }

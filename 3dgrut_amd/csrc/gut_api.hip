@@ -31,7 +31,7 @@ struct GutHandle {
     // per-particle scratch
     DeviceBuffer tiles_count, proj_pos, conic_opacity, extent, depth, rgb, depth_key, particle_idx;
     DeviceBuffer depth_key_tmp, particle_idx_tmp, offsets, sort_scratch, scan_scratch, counters;
-    DeviceBuffer g_rgb;
+    DeviceBuffer part_offset, pos_particle, grad_partial, grad_flag, g_rgb;
     // per-intersection scratch
     DeviceBuffer tile_keys, tile_vals, tile_keys_tmp, tile_vals_tmp, tile_sort_scratch, ranges;
     DeviceBuffer ck_tc, ck_d, ck_reached, ck_boundary_tile;
@@ -43,7 +43,7 @@ struct GutHandle {
     hipStream_t fwd_stream = nullptr;
     GutParams params;
     uint32_t num_intersections = 0;
-    uint32_t* sorted_particle_idx = nullptr;  // points into tile_vals or tile_vals_tmp
+    uint32_t* sorted_pos = nullptr;  // sorted expansion positions: points into tile_vals or tile_vals_tmp
     uint32_t* sorted_tile_keys = nullptr;
     uint32_t* rank_to_particle = nullptr;
     GutStats stats;
@@ -130,6 +130,7 @@ static int ensure_particle_scratch(GutHandle* h, uint32_t N) {
     GRUT_CHECK(h->depth_key_tmp.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->particle_idx_tmp.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->offsets.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->part_offset.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     GRUT_CHECK(h->scan_scratch.ensure(scan_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     GRUT_CHECK(h->counters.ensure(64));
@@ -142,6 +143,7 @@ static int ensure_intersection_scratch(GutHandle* h, uint32_t I, uint32_t tiles)
     GRUT_CHECK(h->tile_vals.ensure(n * 4, 1.3f));
     GRUT_CHECK(h->tile_keys_tmp.ensure(n * 4, 1.3f));
     GRUT_CHECK(h->tile_vals_tmp.ensure(n * 4, 1.3f));
+    GRUT_CHECK(h->pos_particle.ensure(n * 4, 1.3f));
     GRUT_CHECK(h->tile_sort_scratch.ensure(sort_scratch_bytes((uint32_t)n), 1.3f));
     GRUT_CHECK(h->ranges.ensure((size_t)tiles * 8 + 8));
     const size_t nb = (size_t)I / kGutSegment + 1;
@@ -167,6 +169,7 @@ static GutProjected projected_view(GutHandle* h) {
     p.rgb = h->rgb.as<float>();
     p.depth_key = h->depth_key.as<uint32_t>();
     p.particle_idx = h->particle_idx.as<uint32_t>();
+    p.part_offset = h->part_offset.as<uint32_t>();
     return p;
 }
 
@@ -200,7 +203,8 @@ void gut_destroy(GutHandle* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->tiles_count, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->rgb, &h->depth_key,
                             &h->particle_idx, &h->depth_key_tmp, &h->particle_idx_tmp, &h->offsets, &h->sort_scratch,
-                            &h->scan_scratch, &h->counters, &h->g_rgb, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
+                            &h->scan_scratch, &h->counters, &h->part_offset, &h->pos_particle, &h->grad_partial, &h->grad_flag,
+                            &h->g_rgb, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
                             &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges, &h->ck_tc, &h->ck_d, &h->ck_reached,
                             &h->ck_boundary_tile};
     for (DeviceBuffer* b : bufs) b->release();
@@ -288,7 +292,8 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     GRUT_CHECK(ensure_intersection_scratch(h, I, tiles));
     // K4 expansion in rank order
     GRUT_CHECK(h->stage_begin(GUT_STAGE_EXPAND, s, slot));
-    launch_expand(s, P, proj, rank_to_particle, h->offsets.as<uint32_t>(), I, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>());
+    launch_expand(s, P, proj, rank_to_particle, h->offsets.as<uint32_t>(), I, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>(),
+                  h->pos_particle.as<uint32_t>());
     GRUT_CHECK(h->stage_end(GUT_STAGE_EXPAND, s, slot));
     GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_SORT, s, slot));
     // K5 stable radix passes over the tile bits only
@@ -297,7 +302,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
                               h->tile_keys_tmp.as<uint32_t>(), h->tile_vals_tmp.as<uint32_t>(), h->tile_sort_scratch.ptr,
                               h->tile_sort_scratch.bytes, &sorted_tiles, &sorted_idx));
     h->sorted_tile_keys = sorted_tiles;
-    h->sorted_particle_idx = sorted_idx;
+    h->sorted_pos = sorted_idx;
     GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_SORT, s, slot));
     GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_RANGES, s, slot));
     // K6 tile ranges
@@ -308,7 +313,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_RANGES, s, slot));
     // K7 compositing
     GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_FWD, s, slot));
-    launch_render_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, particle_density, proj.rgb, ray_origin, ray_direction,
+    launch_render_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, proj.rgb, ray_origin, ray_direction,
                       out_feat_density, out_hit_distance, out_hit_count, h->checkpoints, true);
     GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_FWD, s, slot));
     GRUT_HIP(hipGetLastError());
@@ -333,19 +338,30 @@ int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float
                      grad_particle_sph, "gut_backward: null buffer");  // grad_hit_distance may be NULL (no depth gradient)
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
     const GutProjected proj = projected_view(h);
-    GRUT_CHECK(h->g_rgb.ensure((size_t)P.N * 12, 1.25f));
-    GRUT_HIP(hipMemsetAsync(h->g_rgb.ptr, 0, (size_t)P.N * 12, s));
     const int slot = h->prof_fwd_slot;
-    if (h->num_intersections > 0) {
+    const bool has_gdist = grad_hit_distance != nullptr;
+    GutGradSlots slots;
+    slots.stride = has_gdist ? 20 : 16;
+    slots.partial = nullptr;
+    slots.flag = nullptr;
+    slots.pos_particle = h->pos_particle.as<uint32_t>();
+    const size_t I = h->num_intersections;
+    if (I > 0) {
+        // one slot per (tile entry, half tile); only flagged slots are ever read, so only the flags are cleared
+        GRUT_CHECK(h->grad_partial.ensure(2 * I * (size_t)slots.stride * 4, 1.3f));
+        GRUT_CHECK(h->grad_flag.ensure(2 * I + 32, 1.3f));  // + slack: flags are scanned 16 at a time
+        slots.partial = h->grad_partial.as<float>();
+        slots.flag = h->grad_flag.as<uint8_t>();
+        GRUT_HIP(hipMemsetAsync(slots.flag, 0, 2 * I, s));
         GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_BWD, s, slot));
-        launch_render_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_particle_idx, particle_density, proj.rgb, ray_origin, ray_direction,
-                          feat_density, grad_feat_density, hit_distance, grad_hit_distance, grad_particle_density, h->g_rgb.as<float>(),
-                          h->checkpoints);
+        launch_render_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_pos, particle_density, proj.rgb, ray_origin, ray_direction, feat_density,
+                          grad_feat_density, hit_distance, grad_hit_distance, slots, h->checkpoints);
         GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_BWD, s, slot));
     }
     GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));
-    launch_project_bwd(s, P, proj.tiles_count, particle_density, particle_sph, proj.rgb, h->g_rgb.as<float>(), grad_particle_density,
-                       grad_particle_sph);
+    GRUT_CHECK(h->g_rgb.ensure((size_t)P.N * 12, 1.25f));  // per-particle radiance gradient between gather and SH backward
+    launch_grad_finalize(s, P, proj, particle_density, particle_sph, slots, has_gdist, I > 0, h->g_rgb.as<float>(), grad_particle_density,
+                         grad_particle_sph);
     GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT_BWD, s, slot));
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
@@ -418,7 +434,7 @@ int gut_debug_fetch(GutHandle* h, void* stream_, uint32_t* tiles_count, float* p
         if (rgb) GRUT_HIP(hipMemcpyAsync(rgb, h->rgb.ptr, N * 12, k, s));
     }
     if (I) {
-        if (sorted_particle_idx) GRUT_HIP(hipMemcpyAsync(sorted_particle_idx, h->sorted_particle_idx, I * 4, k, s));
+        if (sorted_particle_idx) launch_gather_particle_idx(s, (uint32_t)I, h->sorted_pos, h->pos_particle.as<uint32_t>(), sorted_particle_idx);
         if (tile_ranges) GRUT_HIP(hipMemcpyAsync(tile_ranges, h->ranges.ptr, tiles * 8, k, s));
     }
     return GRUT_OK;

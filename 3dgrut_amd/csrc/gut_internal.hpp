@@ -29,6 +29,18 @@ struct GutProjected {
     float* rgb;              // [N,3] unclamped radiance for the camera-centre direction
     uint32_t* depth_key;     // [N] float bits of depth, 0xFFFFFFFF when the particle touches no tile
     uint32_t* particle_idx;  // [N] identity, value array of the depth sort
+    uint32_t* part_offset;   // [N] start of the particle's tile entries in expansion order (valid where tiles_count > 0)
+};
+
+// Gradient partials of the compositing sweep.  Tile entries are identified by their position q in EXPANSION order
+// (particle-major: particle p owns [part_offset[p], part_offset[p] + tiles_count[p])).  Each (entry, half tile) task
+// that hit the particle writes its wave-reduced gradient terms to slot q*2 + half and raises the slot's flag, so
+// the per-particle gather (gut_grad_finalize) sums a contiguous range: no atomics, bitwise reproducible gradients.
+struct GutGradSlots {
+    float* partial;              // [2 I][stride]  {B(3), d density, M(9), d radiance(3)} (+ direct scale terms, pad)
+    uint8_t* flag;               // [2 I]          zeroed before every gradient sweep
+    const uint32_t* pos_particle;// [I]            particle of expansion position q (0xFFFFFFFF = padding)
+    int stride;                  // floats per slot: 16, or 20 when a depth gradient flows in
 };
 
 // the gradient sweep runs a long tile list as independent segments of this many sorted entries
@@ -49,16 +61,18 @@ struct GutCheckpoints {
 void launch_project(hipStream_t s, const GutParams& P, const float* density12, const float* sph, const GutProjected& out,
                     int32_t* visibility, uint32_t* num_visible);
 void launch_expand(hipStream_t s, const GutParams& P, const GutProjected& proj, const uint32_t* rank_to_particle,
-                   const uint32_t* offsets, uint32_t capacity, uint32_t* tile_keys, uint32_t* tile_vals);
+                   const uint32_t* offsets, uint32_t capacity, uint32_t* tile_keys, uint32_t* tile_vals, uint32_t* pos_particle);
+void launch_gather_particle_idx(hipStream_t s, uint32_t n, const uint32_t* sorted_pos, const uint32_t* pos_particle, uint32_t* out);
 void launch_tile_ranges(hipStream_t s, uint32_t n, uint32_t tile_mask, uint32_t num_tiles, const uint32_t* sorted_tile_keys,
                         uint32_t* ranges, uint32_t* boundary_tile);
-void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_idx, const float* density12,
+void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                       const float* density12,
                        const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist, float* out_cnt,
                        const GutCheckpoints& ck, bool write_checkpoints);
-void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_idx, const float* density12,
+void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const float* density12,
                        const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* dist,
-                       const float* g_dist, float* g_density12, float* g_rgb, const GutCheckpoints& ck);
-void launch_project_bwd(hipStream_t s, const GutParams& P, const uint32_t* tiles_count, const float* density12, const float* sph,
-                        const float* rgb, const float* g_rgb, float* g_density12, float* g_sph);
+                       const float* g_dist, const GutGradSlots& slots, const GutCheckpoints& ck);
+void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
+                          const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, float* g_density12, float* g_sph);
 
 }  // namespace grut

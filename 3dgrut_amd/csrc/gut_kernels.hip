@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void gut_project_kernel(GutParams P, const flo
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProjected proj, const uint32_t* __restrict__ rank_to_particle,
                                                          const uint32_t* __restrict__ offsets, uint32_t capacity,
-                                                         uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_vals) {
+                                                         uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_vals,
+                                                         uint32_t* __restrict__ pos_particle) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     uint32_t off = 0, max_off = 0, p = 0;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
         max_off = min(offsets[r], capacity);
         if (max_off > off) {
             p = rank_to_particle[r];
+            proj.part_offset[p] = off;
             const float2 ext = proj.extent[p];
             if (!(ext.x <= 1e-06f)) {
                 const float2 c = proj.proj_pos[p];
@@ -321,17 +323,25 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
                        [&](bool keep, uint32_t tile) {
                            const unsigned long long m = __ballot(keep);
                            const uint32_t slot = o + (uint32_t)__popcll(m & lt_mask);
-                           if (keep && slot < send) {
+                           if (keep && slot < send) {  // the sort carries the expansion position, not the particle
                                tile_keys[slot] = tile;
-                               tile_vals[slot] = sp;
+                               tile_vals[slot] = slot;
+                               pos_particle[slot] = sp;
                            }
                            o += (uint32_t)__popcll(m);
                        });
         for (uint32_t k = o + lane; k < send; k += 64) {  // gutProjector.cuh:372-376 padding
             tile_keys[k] = 0xFFFFFFFFu;
-            tile_vals[k] = 0xFFFFFFFFu;
+            tile_vals[k] = k;
+            pos_particle[k] = 0xFFFFFFFFu;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void gut_gather_particle_idx_kernel(uint32_t n, const uint32_t* __restrict__ sorted_pos,
+                                                                      const uint32_t* __restrict__ pos_particle, uint32_t* __restrict__ out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = pos_particle[sorted_pos[k]];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -359,12 +369,128 @@ __global__ __launch_bounds__(256) void gut_tile_ranges_kernel(uint32_t n, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-// K9: projection backward — GUTProjector::evalBackward (gutProjector.cuh:390-430): per visible particle
-// dRGB -> dSH (clamp-masked) and d direction -> d position; every SH gradient row is written exactly once
-// (zeros for particles without tiles), so the caller does not need to zero-fill grad_sph.
-// ---------------------------------------------------------------------------------------------
+// K9: gradient finalisation = per-particle gather of the compositing partials + projection backward
+// (GUTProjector::evalBackward, gutProjector.cuh:390-430).  One lane per particle:
+//   * sums the particle's slots [2 off, 2 (off + count)) that the gradient sweep flagged (particles covering many
+//     tiles are gathered by the whole wave instead, so that no lane becomes the critical path);
+//   * contracts (B, M) into the position / quaternion / scale gradients (matmul_bw_vec, matmul_bw_quat and the
+//     1/scale chain of models/gaussianParticles.cuh:624-751, applied once per particle instead of once per hit);
+//   * pushes the radiance gradient through the clamp and the SH basis (dRGB -> dSH, d direction -> d position);
+//   * writes the complete [N,12] and [N,3*ncoef] gradient rows (zeros for particles without tiles): nothing is
+//     accumulated in place, so the result does not depend on what the output buffers held.
 // SH rows travel through LDS (row stride 49 floats: conflict-free both ways): a wave reads the coefficient rows of
 // its 64 particles and writes their gradient rows as contiguous 192-byte segments instead of 64 scattered rows.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kGatherSmall = 128;  // tile counts up to this are gathered by the owning lane
+struct __attribute__((packed, aligned(2))) FlagChunk {
+    unsigned long long lo, hi;
+};
+
+// gradient of sum_ij m_ij rotT_ij(q) w.r.t. q = (r,x,y,z); q2 = 2q (matmul_bw_quat, mathUtils.cuh:458-521)
+__device__ __forceinline__ float4 quat_contract(const float m[9], float4 q2) {
+    const float r = q2.x, x = q2.y, y = q2.z, z = q2.w;
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
+    // rotT = [[1-2(yy+zz), 2(xy+rz), 2(xz-ry)], [2(xy-rz), 1-2(xx+zz), 2(yz+rx)], [2(xz+ry), 2(yz-rx), 1-2(xx+yy)]]
+    const float s01 = m01 + m10, s02 = m02 + m20, s12 = m12 + m21;   // symmetric parts
+    const float a01 = m01 - m10, a02 = m20 - m02, a12 = m12 - m21;   // antisymmetric parts (signs as in rotT)
+    float4 d;
+    d.x = z * a01 + y * a02 + x * a12;
+    d.y = y * s01 + z * s02 + r * a12 - 2.f * x * (m11 + m22);
+    d.z = x * s01 + z * s12 + r * a02 - 2.f * y * (m00 + m22);
+    d.w = x * s02 + y * s12 + r * a01 - 2.f * z * (m00 + m11);
+    return d;
+}
+
+template <int STRIDE>
+__device__ __forceinline__ void add_slot(const float* __restrict__ partial, size_t slot, float (&acc)[STRIDE]) {
+    const float4* pp = reinterpret_cast<const float4*>(partial + slot * STRIDE);
+#pragma unroll
+    for (int k = 0; k < STRIDE / 4; ++k) {
+        const float4 v = pp[k];
+        acc[4 * k] += v.x; acc[4 * k + 1] += v.y; acc[4 * k + 2] += v.z; acc[4 * k + 3] += v.w;
+    }
+}
+
+template <int STRIDE>
+__global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutProjected proj, const float4* __restrict__ density12,
+                                                              GutGradSlots slots, int have_partials, float* __restrict__ g_density12,
+                                                              float* __restrict__ g_rgb) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t count = (i < P.N) ? proj.tiles_count[i] : 0u;
+    const bool has = count != 0;
+    float acc[STRIDE];
+#pragma unroll
+    for (int k = 0; k < STRIDE; ++k) acc[k] = 0.f;
+    const uint32_t off = has ? proj.part_offset[i] : 0u;
+    if (have_partials) {
+        if (has && count <= kGatherSmall) {
+            // 16 flags per (unaligned) load; set flags are rare (most tile entries lie behind the rays' termination)
+            const size_t s0 = 2 * (size_t)off;
+            const uint32_t nb = 2 * count;
+            for (uint32_t c = 0; c < nb; c += 16) {
+                const FlagChunk w = *reinterpret_cast<const FlagChunk*>(slots.flag + s0 + c);  // buffer has 32 B of slack
+                const uint32_t rem = nb - c;
+                unsigned long long lo = w.lo, hi = w.hi;
+                if (rem < 8) { lo &= (1ull << (8 * rem)) - 1ull; hi = 0ull; }
+                else if (rem < 16) hi &= (rem == 8) ? 0ull : ((1ull << (8 * (rem - 8))) - 1ull);
+                while (lo) {
+                    const int b = (__ffsll((long long)lo) - 1) >> 3;
+                    lo &= ~(0xFFull << (8 * b));
+                    add_slot<STRIDE>(slots.partial, s0 + c + b, acc);
+                }
+                while (hi) {
+                    const int b = (__ffsll((long long)hi) - 1) >> 3;
+                    hi &= ~(0xFFull << (8 * b));
+                    add_slot<STRIDE>(slots.partial, s0 + c + 8 + b, acc);
+                }
+            }
+        }
+        unsigned long long big = __ballot(has && count > kGatherSmall);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const size_t s0 = 2 * (size_t)(uint32_t)__builtin_amdgcn_readlane((int)off, src);
+            const uint32_t n2 = 2u * (uint32_t)__builtin_amdgcn_readlane((int)count, src);
+            float part[STRIDE];
+#pragma unroll
+            for (int k = 0; k < STRIDE; ++k) part[k] = 0.f;
+            for (uint32_t k = lane; k < n2; k += 64)
+                if (slots.flag[s0 + k]) add_slot<STRIDE>(slots.partial, s0 + k, part);
+#pragma unroll
+            for (int k = 0; k < STRIDE; ++k) {
+                const float tot = wave_sum(part[k]);
+                if (lane == src) acc[k] = tot;
+            }
+        }
+    }
+    if (i >= P.N) return;
+    float4* gd = reinterpret_cast<float4*>(g_density12 + 12 * (size_t)i);
+    if (!has) {
+        gd[0] = gd[1] = gd[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float4 q = density12[3 * (size_t)i + 1], sc = density12[3 * (size_t)i + 2];
+    const m3 rt = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
+    const f3 B = mk3(acc[0], acc[1], acc[2]);
+    const float* m = &acc[4];
+    // position = -R B  (matmul_bw_vec with rows of R^T); the SH direction term is added by the projection backward
+    const f3 gpos = mk3(-(B.x * rt.r0.x + B.y * rt.r1.x + B.z * rt.r2.x), -(B.x * rt.r0.y + B.y * rt.r1.y + B.z * rt.r2.y),
+                        -(B.x * rt.r0.z + B.y * rt.r1.z + B.z * rt.r2.z));
+    // scale_i = -(1/s_i) sum_j rotT_ij m_ij (+ direct hit-distance term)
+    float gsx = -(rt.r0.x * m[0] + rt.r0.y * m[1] + rt.r0.z * m[2]) / sc.x;
+    float gsy = -(rt.r1.x * m[3] + rt.r1.y * m[4] + rt.r1.z * m[5]) / sc.y;
+    float gsz = -(rt.r2.x * m[6] + rt.r2.y * m[7] + rt.r2.z * m[8]) / sc.z;
+    if (STRIDE > 16) { gsx += acc[16]; gsy += acc[17]; gsz += acc[18]; }
+    const float4 dq = quat_contract(m, make_float4(2.f * q.x, 2.f * q.y, 2.f * q.z, 2.f * q.w));
+    gd[0] = make_float4(gpos.x, gpos.y, gpos.z, acc[3]);
+    gd[1] = dq;
+    gd[2] = make_float4(gsx, gsy, gsz, 0.f);
+    g_rgb[3 * (size_t)i] = acc[13];
+    g_rgb[3 * (size_t)i + 1] = acc[14];
+    g_rgb[3 * (size_t)i + 2] = acc[15];
+}
+
 constexpr int kShStride = 49;
 __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const uint32_t* __restrict__ tiles_count,
                                                               const float4* __restrict__ density12, const float* __restrict__ sph,
@@ -438,9 +564,12 @@ void launch_project(hipStream_t s, const GutParams& P, const float* density12, c
                        out, visibility, num_visible);
 }
 void launch_expand(hipStream_t s, const GutParams& P, const GutProjected& proj, const uint32_t* rank_to_particle,
-                   const uint32_t* offsets, uint32_t capacity, uint32_t* tile_keys, uint32_t* tile_vals) {
+                   const uint32_t* offsets, uint32_t capacity, uint32_t* tile_keys, uint32_t* tile_vals, uint32_t* pos_particle) {
     hipLaunchKernelGGL(gut_expand_kernel, dim3(div_up(P.N, 256)), dim3(256), 0, s, P, proj, rank_to_particle, offsets, capacity,
-                       tile_keys, tile_vals);
+                       tile_keys, tile_vals, pos_particle);
+}
+void launch_gather_particle_idx(hipStream_t s, uint32_t n, const uint32_t* sorted_pos, const uint32_t* pos_particle, uint32_t* out) {
+    if (n) hipLaunchKernelGGL(gut_gather_particle_idx_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, sorted_pos, pos_particle, out);
 }
 void launch_tile_ranges(hipStream_t s, uint32_t n, uint32_t tile_mask, uint32_t num_tiles, const uint32_t* sorted_tile_keys,
                         uint32_t* ranges, uint32_t* boundary_tile) {
@@ -448,10 +577,17 @@ void launch_tile_ranges(hipStream_t s, uint32_t n, uint32_t tile_mask, uint32_t 
                        reinterpret_cast<uint2*>(ranges), boundary_tile);
 }
 
-void launch_project_bwd(hipStream_t s, const GutParams& P, const uint32_t* tiles_count, const float* density12, const float* sph,
-                        const float* rgb, const float* g_rgb, float* g_density12, float* g_sph) {
-    hipLaunchKernelGGL(gut_project_bwd_kernel, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, tiles_count,
-                       reinterpret_cast<const float4*>(density12), sph, rgb, g_rgb, g_density12, g_sph);
+void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
+                          const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, float* g_density12, float* g_sph) {
+    const dim3 grid(div_up(P.N, 256)), block(256);
+    if (has_gdist)
+        hipLaunchKernelGGL(gut_grad_gather_kernel<20>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
+                           have_partials ? 1 : 0, g_density12, g_rgb);
+    else
+        hipLaunchKernelGGL(gut_grad_gather_kernel<16>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
+                           have_partials ? 1 : 0, g_density12, g_rgb);
+    hipLaunchKernelGGL(gut_project_bwd_kernel, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
+                       reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_density12, g_sph);
 }
 
 }  // namespace grut

@@ -121,24 +121,31 @@ __device__ __forceinline__ void half_mapping(uint32_t b, uint32_t& vtile, uint32
 //   r0 = M.r0, pos.x | r1 = M.r1, pos.y | r2 = M.r2, pos.z      M = diag(1/scale) R^T  (gaussianParticles.slang:96-110)
 //   r3 = scale.xyz (fwd) or 1/scale.xyz (bwd), density
 //   r4 = clamped radiance rgb, g_max
-//   r5 = u0 = M (origin - pos) (uniform-origin waves), as_float(particle index)
+//   r5 = u0 = M (origin - pos) (uniform-origin waves), as_float(expansion position of the entry)
 // Padding entries (index 0xFFFFFFFF) get M = I and g_max = 0: finite everywhere, never accepted.
 // ---------------------------------------------------------------------------------------------
 constexpr int kRecQuads = 6;
 
 struct RawEntry {
-    uint32_t idx;
+    uint32_t idx, pos;   // particle, expansion position of the entry (its gradient slot)
     float4 a, q, s;
     f3 rgb;
 };
-__device__ __forceinline__ RawEntry load_entry(uint32_t e, uint32_t end, const uint32_t* __restrict__ sorted_idx,
+// the sorted lists carry expansion positions; pos_particle maps them to particles (0xFFFFFFFF = padding)
+struct EntryLists {
+    const uint32_t* __restrict__ sorted_pos;
+    const uint32_t* __restrict__ pos_particle;
+};
+__device__ __forceinline__ RawEntry load_entry(uint32_t e, uint32_t end, const EntryLists& lists,
                                                const float4* __restrict__ density12, const float* __restrict__ rgb) {
     RawEntry r;
     r.idx = 0xFFFFFFFFu;
+    r.pos = 0u;
     r.a = r.q = r.s = make_float4(0.f, 0.f, 0.f, 0.f);
     r.rgb = mk3(0.f, 0.f, 0.f);
     if (e < end) {
-        r.idx = sorted_idx[e];
+        r.pos = lists.sorted_pos[e];
+        r.idx = lists.pos_particle[r.pos];
         if (r.idx != 0xFFFFFFFFu) {
             r.a = density12[3 * (size_t)r.idx + 0];
             r.q = density12[3 * (size_t)r.idx + 1];
@@ -169,7 +176,7 @@ __device__ __forceinline__ void stage_entry(const GutParams& P, const RawEntry& 
             r5.y = dot(mk3(r1.x, r1.y, r1.z), dl);
             r5.z = dot(mk3(r2.x, r2.y, r2.z), dl);
         }
-        r5.w = __uint_as_float(r.idx);
+        r5.w = __uint_as_float(r.pos);
     }
     rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4; rec[5] = r5;
 }
@@ -227,13 +234,13 @@ struct FwdState {
 };
 template <int DEG, bool CKPT, bool UNI>
 __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPair& rp, uint2 range, uint32_t half, int lane,
-                                                 const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ density12,
+                                                 const EntryLists& lists, const float4* __restrict__ density12,
                                                  const float* __restrict__ rgb, const GutCheckpoints& ck, float4* __restrict__ s_rec,
                                                  FwdState& st) {
     bool alive0 = rp.valid0, alive1 = rp.valid1;
     v2f T = splat(1.f), D = splat(0.f), Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f), cnt = splat(0.f);
     uint32_t b = range.x;
-    RawEntry next = load_entry(b + lane, min(range.y, (b & ~63u) + 64u), sorted_idx, density12, rgb);
+    RawEntry next = load_entry(b + lane, min(range.y, (b & ~63u) + 64u), lists, density12, rgb);
     while (b < range.y) {
         if (!__any(alive0 || alive1)) break;
         const uint32_t bend = min(range.y, (b & ~63u) + 64u);
@@ -249,7 +256,7 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         stage_entry<DEG, false>(P, next, UNI, rp.origin, &s_rec[lane * kRecQuads]);
         __syncthreads();  // single-wave workgroup: orders the LDS hand-off
         // fetch the following round while this one is being composited
-        next = load_entry(bend + lane, min(range.y, bend + 64u), sorted_idx, density12, rgb);
+        next = load_entry(bend + lane, min(range.y, bend + 64u), lists, density12, rgb);
         const int n = (int)(bend - b);
         for (int j = 0; j < n; ++j) {
             const float4* rec = &s_rec[j * kRecQuads];
@@ -287,8 +294,7 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
 }
 
 template <int DEG, bool CKPT>
-__global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges,
-                                                            const uint32_t* __restrict__ sorted_idx,
+__global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                             float4* __restrict__ out_fd, float* __restrict__ out_dist,
@@ -302,8 +308,8 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
     const uint2 range = ranges[tile];
     FwdState st;
     // two copies of the sweep: the shared-origin one keeps the canonical origin out of the per-pixel math
-    if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true>(P, rp, range, half, lane, sorted_idx, density12, rgb, ck, s_rec, st);
-    else render_fwd_sweep<DEG, CKPT, false>(P, rp, range, half, lane, sorted_idx, density12, rgb, ck, s_rec, st);
+    if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
+    else render_fwd_sweep<DEG, CKPT, false>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
     if (rp.valid0) {
         const size_t pix = (size_t)rp.py0 * P.W + rp.px;
         out_fd[pix] = make_float4(st.Cr.x, st.Cg.x, st.Cb.x, 1.f - st.T.x);
@@ -333,21 +339,6 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
 // their generic form: B (x) (o-mu) and Bv (x) d are accumulated separately and the direct scale term is reduced in a
 // second pass.
 // ---------------------------------------------------------------------------------------------
-// gradient of sum_ij m_ij rotT_ij(q) w.r.t. q = (r,x,y,z); q2 = 2q (matmul_bw_quat, mathUtils.cuh:458-521)
-__device__ __forceinline__ float4 quat_contract(const float m[9], float4 q2) {
-    const float r = q2.x, x = q2.y, y = q2.z, z = q2.w;
-    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5], m20 = m[6], m21 = m[7], m22 = m[8];
-    // rotT = [[1-2(yy+zz), 2(xy+rz), 2(xz-ry)], [2(xy-rz), 1-2(xx+zz), 2(yz+rx)], [2(xz+ry), 2(yz-rx), 1-2(xx+yy)]]
-    const float s01 = m01 + m10, s02 = m02 + m20, s12 = m12 + m21;   // symmetric parts
-    const float a01 = m01 - m10, a02 = m20 - m02, a12 = m12 - m21;   // antisymmetric parts (signs as in rotT)
-    float4 d;
-    d.x = z * a01 + y * a02 + x * a12;
-    d.y = y * s01 + z * s02 + r * a12 - 2.f * x * (m11 + m22);
-    d.z = x * s01 + z * s12 + r * a02 - 2.f * y * (m00 + m22);
-    d.w = x * s02 + y * s12 + r * a01 - 2.f * z * (m00 + m11);
-    return d;
-}
-
 constexpr uint32_t kBwdBatch = 32;  // staged entries per round of the gradient sweep
 
 struct BwdPixels {
@@ -358,8 +349,8 @@ struct BwdPixels {
 };
 template <int DEG, bool HAS_GDIST, bool UNI>
 __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPair& rp, uint32_t seg_begin, uint32_t seg_end, int lane,
-                                                 const uint32_t* __restrict__ sorted_idx, const float4* __restrict__ density12,
-                                                 const float* __restrict__ rgb, float* __restrict__ g_density12, float* __restrict__ g_rgb,
+                                                 uint32_t half, const EntryLists& lists, const float4* __restrict__ density12,
+                                                 const float* __restrict__ rgb, const GutGradSlots& slots,
                                                  float4* __restrict__ s_rec, float* __restrict__ s_acc, float* __restrict__ s_acc2,
                                                  const BwdPixels& px) {
     constexpr uint32_t kBatch = kBwdBatch;
@@ -368,13 +359,13 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
     const p3 C_fin = px.C_fin, gC = px.gC;
     bool alive0 = px.alive0, alive1 = px.alive1;
     uint32_t b = seg_begin;
-    RawEntry next = load_entry(b + lane, min(seg_end, (b & ~(kBatch - 1u)) + kBatch), sorted_idx, density12, rgb);
+    RawEntry next = load_entry(b + lane, min(seg_end, (b & ~(kBatch - 1u)) + kBatch), lists, density12, rgb);
     while (b < seg_end) {
         if (!__any(alive0 || alive1)) break;
         const uint32_t bend = min(seg_end, (b & ~(kBatch - 1u)) + kBatch);
         if (lane < (int)kBatch) stage_entry<DEG, true>(P, next, UNI, rp.origin, &s_rec[lane * kRecQuads]);
         __syncthreads();
-        next = load_entry(bend + lane, min(seg_end, bend + kBatch), sorted_idx, density12, rgb);
+        next = load_entry(bend + lane, min(seg_end, bend + kBatch), lists, density12, rgb);
         const int n = (int)(bend - b);
         uint32_t hit_entries = 0u;  // wave-uniform: staged entries with >= 1 hit in this wave
         for (int j = 0; j < n; ++j) {
@@ -473,52 +464,42 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
                 for (int k = 0; k < 16; ++k) extra[k] = 0.f;
                 extra[0] = sXm.x.x + sXm.x.y; extra[1] = sXm.y.x + sXm.y.y; extra[2] = sXm.z.x + sXm.z.y;
             }
-            const float tot = wave_reduce_scatter16(terms, lane);
-            if (lane < 16) s_acc[j * 16 + lane] = tot;
-            if (HAS_GDIST) {
-                const float tot2 = wave_reduce_scatter16(extra, lane);
-                if (lane < 16) s_acc2[j * 16 + lane] = tot2;
-            }
+            // lane l ends with the sum over its 16-lane row of term l & 15; the four rows are added by the flush
+            s_acc[j * 64 + lane] = wave_reduce_scatter16_rows(terms, lane);
+            if (HAS_GDIST) s_acc2[j * 64 + lane] = wave_reduce_scatter16_rows(extra, lane);
             T = nextT;
             alive0 = alive0 && !(T.x < P.min_transmittance);
             alive1 = alive1 && !(T.y < P.min_transmittance);
         }
         __syncthreads();
-        // flush: lane j owns staged entry j; one atomic set per (half tile, particle with a hit)
+        // flush: lane j owns staged entry j and stores the wave totals of its 16 (+3) terms to the entry's gradient slot
         if (lane < (int)kBatch && ((hit_entries >> lane) & 1u)) {
             const float4* rec = &s_rec[lane * kRecQuads];
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];   // r3.xyz = 1/scale
-            const uint32_t idx = __float_as_uint(rec[5].w);
-            const float4* acc = reinterpret_cast<const float4*>(&s_acc[lane * 16]);
-            const float4 a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
-            const f3 B = mk3(a0.x, a0.y, a0.z);
-            float m[9] = {a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w, a3.x};
-            if (!HAS_GDIST && UNI) {
-                const f3 dl = rp.origin - mk3(r0.w, r1.w, r2.w);
-                m[0] += B.x * dl.x; m[1] += B.x * dl.y; m[2] += B.x * dl.z;
-                m[3] += B.y * dl.x; m[4] += B.y * dl.y; m[5] += B.y * dl.z;
-                m[6] += B.z * dl.x; m[7] += B.z * dl.y; m[8] += B.z * dl.z;
+            const uint32_t pos = __float_as_uint(rec[5].w);
+            const float4* acc = reinterpret_cast<const float4*>(&s_acc[lane * 64]);
+            float4 a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+#pragma unroll
+            for (int r = 1; r < 4; ++r) {
+                const float4 b0 = acc[4 * r], b1 = acc[4 * r + 1], b2 = acc[4 * r + 2], b3 = acc[4 * r + 3];
+                a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w; a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+                a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w; a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
             }
-            // rows of R^T from the staged M = diag(1/s) R^T
-            const f3 sc = mk3(__builtin_amdgcn_rcpf(r3.x), __builtin_amdgcn_rcpf(r3.y), __builtin_amdgcn_rcpf(r3.z));
-            const f3 t0 = mk3(r0.x, r0.y, r0.z) * sc.x, t1 = mk3(r1.x, r1.y, r1.z) * sc.y, t2 = mk3(r2.x, r2.y, r2.z) * sc.z;
-            // position = -R B  (matmul_bw_vec with rows of R^T)
-            const float gpx = -(B.x * t0.x + B.y * t1.x + B.z * t2.x);
-            const float gpy = -(B.x * t0.y + B.y * t1.y + B.z * t2.y);
-            const float gpz = -(B.x * t0.z + B.y * t1.z + B.z * t2.z);
-            // scale_i = -(1/s_i) sum_j rotT_ij m_ij (+ direct hit-distance term)
-            float gsx = -r3.x * (t0.x * m[0] + t0.y * m[1] + t0.z * m[2]);
-            float gsy = -r3.y * (t1.x * m[3] + t1.y * m[4] + t1.z * m[5]);
-            float gsz = -r3.z * (t2.x * m[6] + t2.y * m[7] + t2.z * m[8]);
-            if (HAS_GDIST) { gsx += s_acc2[lane * 16 + 0]; gsy += s_acc2[lane * 16 + 1]; gsz += s_acc2[lane * 16 + 2]; }
-            const float4 q = density12[3 * (size_t)idx + 1];
-            const float4 dq = quat_contract(m, make_float4(2.f * q.x, 2.f * q.y, 2.f * q.z, 2.f * q.w));
-            float* gd = g_density12 + 12 * (size_t)idx;
-            atomicAdd(gd + 0, gpx); atomicAdd(gd + 1, gpy); atomicAdd(gd + 2, gpz); atomicAdd(gd + 3, a0.w);
-            atomicAdd(gd + 4, dq.x); atomicAdd(gd + 5, dq.y); atomicAdd(gd + 6, dq.z); atomicAdd(gd + 7, dq.w);
-            atomicAdd(gd + 8, gsx); atomicAdd(gd + 9, gsy); atomicAdd(gd + 10, gsz);
-            float* gr = g_rgb + 3 * (size_t)idx;
-            atomicAdd(gr + 0, a3.y); atomicAdd(gr + 1, a3.z); atomicAdd(gr + 2, a3.w);
+            if (!HAS_GDIST && UNI) {  // complete M = (sum B) (x) (o - mu) - sum (t B) (x) d
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                const f3 dl = rp.origin - mk3(r0.w, r1.w, r2.w);
+                a1.x += a0.x * dl.x; a1.y += a0.x * dl.y; a1.z += a0.x * dl.z;
+                a1.w += a0.y * dl.x; a2.x += a0.y * dl.y; a2.y += a0.y * dl.z;
+                a2.z += a0.z * dl.x; a2.w += a0.z * dl.y; a3.x += a0.z * dl.z;
+            }
+            const size_t slot = 2 * (size_t)pos + half;
+            float4* out = reinterpret_cast<float4*>(slots.partial + slot * (HAS_GDIST ? 20 : 16));
+            out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
+            if (HAS_GDIST) {
+                float ex = 0.f, ey = 0.f, ez = 0.f;
+                for (int r = 0; r < 4; ++r) { ex += s_acc2[lane * 64 + 16 * r]; ey += s_acc2[lane * 64 + 16 * r + 1]; ez += s_acc2[lane * 64 + 16 * r + 2]; }
+                out[4] = make_float4(ex, ey, ez, 0.f);
+            }
+            slots.flag[slot] = 1;
         }
         __syncthreads();
         b = bend;
@@ -526,18 +507,16 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
 }
 
 template <int DEG, bool HAS_GDIST>
-__global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const uint2* __restrict__ ranges,
-                                                            const uint32_t* __restrict__ sorted_idx,
+__global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                             const float4* __restrict__ fd, const float4* __restrict__ g_fd,
                                                             const float* __restrict__ dist, const float* __restrict__ g_dist,
-                                                            float* __restrict__ g_density12, float* __restrict__ g_rgb,
-                                                            GutCheckpoints ck) {
+                                                            GutGradSlots slots, GutCheckpoints ck) {
     constexpr uint32_t kBatch = kBwdBatch;
     __shared__ float4 s_rec[kBatch * kRecQuads];
-    __shared__ float s_acc[kBatch * 16];                       // per staged entry: 16 wave-reduced terms
-    __shared__ float s_acc2[HAS_GDIST ? kBatch * 16 : 1];      // depth-gradient extras (3 used)
+    __shared__ float s_acc[kBatch * 64];                       // per staged entry: 16 terms x 4 row partials
+    __shared__ float s_acc2[HAS_GDIST ? kBatch * 64 : 1];      // depth-gradient extras (3 terms used)
     // task = (virtual tile, half).  Virtual tiles [0, bndPad) are the segments that start at segment boundary b (sorted
     // index b * kGutSegment): they are the long, dense tasks and are dispatched first so that the tail of the launch
     // is made of the short first segments of each tile list, virtual tiles [bndPad, bndPad + tiles).
@@ -594,9 +573,9 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const u
 
     BwdPixels px{T, D, Cr, Cg, Cb, T_fin, D_fin, gT, gD, C_fin, gC, alive0, alive1};
     if (rp.uniform_origin)
-        render_bwd_sweep<DEG, HAS_GDIST, true>(P, rp, seg_begin, seg_end, lane, sorted_idx, density12, rgb, g_density12, g_rgb, s_rec, s_acc, s_acc2, px);
+        render_bwd_sweep<DEG, HAS_GDIST, true>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, px);
     else
-        render_bwd_sweep<DEG, HAS_GDIST, false>(P, rp, seg_begin, seg_end, lane, sorted_idx, density12, rgb, g_density12, g_rgb, s_rec, s_acc, s_acc2, px);
+        render_bwd_sweep<DEG, HAS_GDIST, false>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, px);
 }
 
 }  // namespace
@@ -626,37 +605,39 @@ static uint32_t segment_grid(const GutParams& P, uint32_t num_boundaries) {
     default: { constexpr int D_ = 2; __VA_ARGS__; } break;     \
     }
 
-void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_idx, const float* density12,
-                       const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist, float* out_cnt,
-                       const GutCheckpoints& ck, bool write_checkpoints) {
+void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                       const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
+                       float* out_cnt, const GutCheckpoints& ck, bool write_checkpoints) {
+    const EntryLists lists{sorted_pos, pos_particle};
     if (write_checkpoints) {
         GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_fwd_kernel<D_, true>), dim3(half_grid(P)), dim3(64), 0, s, P,
-                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const uint2*>(ranges), lists,
                                                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
                                                           reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck));
     } else {
         GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_fwd_kernel<D_, false>), dim3(half_grid(P)), dim3(64), 0, s, P,
-                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const uint2*>(ranges), lists,
                                                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
                                                           reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck));
     }
 }
-void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_idx, const float* density12,
+void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const float* density12,
                        const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* dist,
-                       const float* g_dist, float* g_density12, float* g_rgb, const GutCheckpoints& ck) {
+                       const float* g_dist, const GutGradSlots& slots, const GutCheckpoints& ck) {
     const dim3 grid(segment_grid(P, ck.num_boundaries));
+    const EntryLists lists{sorted_pos, slots.pos_particle};
     if (g_dist) {
         GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_bwd_kernel<D_, true>), grid, dim3(64), 0, s, P,
-                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const uint2*>(ranges), lists,
                                                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
                                                           reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
-                                                          g_dist, g_density12, g_rgb, ck));
+                                                          g_dist, slots, ck));
     } else {  // no depth gradient flows in: the hit-distance terms vanish identically
         GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_bwd_kernel<D_, false>), grid, dim3(64), 0, s, P,
-                                                          reinterpret_cast<const uint2*>(ranges), sorted_idx,
+                                                          reinterpret_cast<const uint2*>(ranges), lists,
                                                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
                                                           reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
-                                                          g_dist, g_density12, g_rgb, ck));
+                                                          g_dist, slots, ck));
     }
 }
 

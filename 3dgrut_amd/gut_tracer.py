@@ -113,8 +113,8 @@ class _GutNative:
 
     def trace_bwd(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_fd, dist, g_dist):
         dev = ray_ori.device
-        g_density = torch.zeros_like(particle_density)
-        g_sph = torch.empty_like(particle_sph)  # fully overwritten by the projection-backward kernel
+        g_density = torch.empty_like(particle_density)  # both fully overwritten by the gradient-finalisation kernel
+        g_sph = torch.empty_like(particle_sph)
         _abi.check(self.lib.gut_backward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
                                          _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(g_fd), _ptr(dist), _ptr(g_dist),
                                          _ptr(g_density), _ptr(g_sph)), "gut_backward")

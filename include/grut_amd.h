@@ -136,8 +136,9 @@ int gut_forward(GutHandle* handle, void* stream, const GutFrame* frame,
 /*  grad_hit_distance     : [H,W,1] f32 or NULL when no gradient flows into the hit distance (the usual
  *                          training case: trainer.py:677-748 supervises colour/opacity only) — selects the
  *                          kernel variant without the hit-distance terms
- *  grad_particle_density : [N,12] f32, must arrive zero-filled (accumulated with atomics)
- *  grad_particle_sph     : [N, 3*(deg+1)^2] f32, fully overwritten (no zero-fill needed) */
+ *  grad_particle_density : [N,12] f32 and grad_particle_sph [N, 3*(deg+1)^2] f32 are fully overwritten (no zero fill
+ *                          needed): gradients are gathered per particle from per-tile-entry partials, not accumulated
+ *                          with atomics, so they are bitwise reproducible from run to run */
 int gut_backward(GutHandle* handle, void* stream, const GutFrame* frame,
                  const float* particle_density, const float* particle_sph,
                  const float* ray_origin, const float* ray_direction,
