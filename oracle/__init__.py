@@ -186,3 +186,93 @@ def sh_radiance(deg, coeffs48, dir3, clamped=True, dtype=np.float32):
     out = np.zeros(3, dtype)
     l.orc_sh_radiance(C.c_int(deg), C.c_int(3), _p(_c(coeffs48, dtype)), _p(_c(dir3, dtype)), C.c_int(int(clamped)), _p(out))
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# 3DGRT
+# ------------------------------------------------------------------------------------------
+def grt_proxies(cfg, positions, rotations, scales, densities, dtype=np.float32):
+    """Instance records {W rows, mu} [N,12], world AABBs [N,6], pruning slack [N], scene AABB [6]."""
+    l = lib(dtype)
+    pos, rot, scl, dns = _c(positions, dtype), _c(rotations, dtype), _c(scales, dtype), _c(densities, dtype).reshape(-1)
+    N = pos.shape[0]
+    inst, aabb, slack, scene = np.zeros((N, 12), dtype), np.zeros((N, 6), dtype), np.zeros(N, dtype), np.zeros(6, dtype)
+    l.orc_grt_proxies(C.byref(cfg), C.c_uint32(N), _p(pos), _p(rot), _p(scl), _p(dns), _p(inst), _p(aabb), _p(slack), _p(scene))
+    return dict(inst=inst, aabb=aabb, slack=slack, scene=scene)
+
+
+def grt_forward(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, ray_o, ray_d, inst=None, scene=None, dbg_cap=0,
+                dtype=np.float32):
+    """OptixTracer::trace semantics.  ray_to_world: [3,4]; rays: [H,W,3] in ray space.  `inst` / `scene` may be supplied
+    (e.g. the proxies the GPU built) so that hit order can be compared bit-exactly."""
+    l, R = lib(dtype), _real(dtype)
+    d12, s = _c(density12, dtype), _c(sph, dtype)
+    N = d12.shape[0]
+    if inst is None:
+        pr = grt_proxies(cfg, d12[:, 0:3], d12[:, 4:8], d12[:, 8:11], d12[:, 3], dtype)
+        inst, scene = pr["inst"], pr["scene"]
+    inst, scene = _c(inst, dtype), _c(scene, dtype)
+    ro, rd = _c(ray_o, dtype), _c(ray_d, dtype)
+    H, W = ro.shape[-3], ro.shape[-2]
+    n = H * W
+    m = _c(np.asarray(ray_to_world)[:3, :4], dtype)
+    out = dict(features=np.zeros((H, W, 3), dtype), density=np.zeros((H, W, 1), dtype), hit_distance=np.zeros((H, W, 2), dtype),
+               normals=np.zeros((H, W, 3), dtype), hit_count=np.zeros((H, W, 1), dtype), visibility=np.zeros(N, np.int32))
+    dbg_ids = np.full((n, max(dbg_cap, 1)), 0xFFFFFFFF, np.uint32)
+    dbg_cnt = np.zeros(n, np.uint32)
+    r = l.orc_grt_trace_fwd(C.byref(cfg), C.c_uint32(N), _p(d12), _p(s), C.c_int(sph_deg), R(min_transmittance), _p(inst), _p(scene),
+                            _p(m), C.c_uint32(n), _p(ro), _p(rd), _p(out["features"]), _p(out["density"]), _p(out["hit_distance"]),
+                            _p(out["normals"]), _p(out["hit_count"]), _p(out["visibility"]),
+                            _p(dbg_ids) if dbg_cap else None, _p(dbg_cnt), C.c_uint32(dbg_cap))
+    assert r == 0
+    out.update(hit_ids=dbg_ids, hit_num=dbg_cnt, inst=inst, scene=scene, density12=d12, sph=s, rays=(ro, rd), ray_to_world=m)
+    return out
+
+
+def grt_backward(cfg, sph_deg, min_transmittance, fwd, g_features, g_density, g_hit_distance, dtype=np.float32):
+    """OptixTracer::trace_bwd: returns (grad_density12 [N,12], grad_sph [N,3*ncoef])."""
+    l, R = lib(dtype), _real(dtype)
+    d12, s = fwd["density12"], fwd["sph"]
+    N = d12.shape[0]
+    ro, rd = fwd["rays"]
+    n = ro.shape[-3] * ro.shape[-2]
+    gd, gs = np.zeros((N, 12), dtype), np.zeros_like(s)
+    r = l.orc_grt_trace_bwd(C.byref(cfg), C.c_uint32(N), _p(d12), _p(s), C.c_int(sph_deg), R(min_transmittance), _p(fwd["inst"]),
+                            _p(fwd["scene"]), _p(fwd["ray_to_world"]), C.c_uint32(n), _p(ro), _p(rd), _p(fwd["features"]),
+                            _p(fwd["density"]), _p(fwd["hit_distance"]), _p(_c(g_features, dtype)), _p(_c(g_density, dtype)),
+                            _p(_c(g_hit_distance, dtype)), _p(gd), _p(gs))
+    assert r == 0
+    return gd, gs
+
+
+def grt_process_hit_fwd(degree, min_response, min_alpha, max_alpha, ray_o, ray_d, density12, sph48, sph_deg, with_normal, state8,
+                        dtype=np.float32):
+    l, R = lib(dtype), _real(dtype)
+    st = _c(state8, dtype).copy()
+    acc = l.orc_grt_process_hit_fwd(C.c_int(degree), R(min_response), R(min_alpha), R(max_alpha), _p(_c(ray_o, dtype)), _p(_c(ray_d, dtype)),
+                                    _p(_c(density12, dtype)), _p(_c(sph48, dtype)), C.c_int(sph_deg), C.c_int(int(with_normal)), _p(st))
+    return int(acc), st
+
+
+def grt_process_hit_bwd(degree, min_response, min_alpha, max_alpha, min_transmittance, ray_o, ray_d, density12, sph48, sph_deg, state5,
+                        fin5, grads5, dtype=np.float32):
+    l, R = lib(dtype), _real(dtype)
+    st = _c(state5, dtype).copy()
+    gd, gs = np.zeros(12, dtype), np.zeros(48, dtype)
+    l.orc_grt_process_hit_bwd(C.c_int(degree), R(min_response), R(min_alpha), R(max_alpha), R(min_transmittance), _p(_c(ray_o, dtype)),
+                              _p(_c(ray_d, dtype)), _p(_c(density12, dtype)), _p(_c(sph48, dtype)), C.c_int(sph_deg), _p(st),
+                              _p(_c(fin5, dtype)), _p(_c(grads5, dtype)), _p(gd), _p(gs))
+    return st, gd, gs
+
+
+def grt_intersect_instance(pray_o, pray_d, tmin, tmax, max_sqdist, dtype=np.float32):
+    l, R = lib(dtype), _real(dtype)
+    t = np.zeros(1, dtype)
+    ok = l.orc_grt_intersect_instance(_p(_c(pray_o, dtype)), _p(_c(pray_d, dtype)), R(tmin), R(tmax), R(max_sqdist), _p(t))
+    return int(ok), float(t[0])
+
+
+def grt_kernel_scale(density, min_response, clamping, degree, dtype=np.float32):
+    l, R = lib(dtype), _real(dtype)
+    l.orc_grt_kernel_scale.restype = R
+    return float(l.orc_grt_kernel_scale(R(density), R(min_response), C.c_int(int(clamping)), R(degree)))

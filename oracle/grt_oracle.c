@@ -1,1 +1,434 @@
-/* grt_oracle.c placeholder, filled in below */
+/*
+ * grt_oracle.c — CPU restatement of the reference 3DGRT path (threedgrt_tracer).
+ * TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker;
+ * never imported by the product package.
+ *
+ * Parity pinning: the per-hit math (orc_grt_process_hit_fwd/bwd, candidate tests) is checked against the reference's own
+ * header (threedgrt_tracer/include/3dgrt/kernels/cuda/gaussianParticles.cuh) compiled on the host (oracle/_ref) through
+ * the golden vectors in tests/golden/.  OptiX (un-vendored, v7.5) is replaced by its documented semantics: the
+ * candidate set of a trace is every instance whose transformed unit box the ray interval touches and whose intersection
+ * program accepts; any-hit keeps the 16 smallest hit distances (referenceOptix.cu:210-248).  Where OptiX leaves the
+ * order undefined (equal distances) the oracle orders by (distance, particle index).
+ *
+ * Sequence restated: optixTracer.cpp:616-890 (proxies), referenceOptix.cu:103-186 (forward ray generation),
+ * referenceBwdOptix.cu:103-170 (backward), 3dgrt/kernels/cuda/gaussianParticles.cuh:337-731 (per-hit math).
+ */
+#include "orc_math.h"
+#include "../include/grut_amd.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#define GRT_INVALID 0xFFFFFFFFu
+#define GRT_MAX_K 64
+
+/* particlePrimitives.cu:27-51 kernelScale */
+real orc_grt_kernel_scale(real density, real min_response, int clamping, real degree) {
+    const real modulation = clamping ? density : 1;
+    const real mr = r_min(min_response / modulation, R_(0.97));
+    if (degree < 0) {
+        const real k = r_fabs(degree);
+        const real s = 1 / r_pow(3, k);
+        return r_pow((1 / (r_log(mr) - 1) + 1) / s, 1 / k);
+    }
+    if (degree == 0) return ((1 - mr) / 3) / R_(-0.329630334487);
+    const real a = R_(-4.5) / r_pow(3, degree);
+    return r_pow(r_log(mr) / a, 1 / degree);
+}
+
+/* computeGaussianEnclosingInstancesKernel, particlePrimitives.cu:543-610: instance transform [R diag(kscl) | mu] over a
+ * unit box.  Emitted here as the INVERSE map (what traversal needs): inst = {W rows (9), mu (3)}, W = diag(1/kscl) R^T,
+ * so that the object-space ray is o' = W (o - mu), d' = W d.  Also the world AABB of the box, the pruning slack
+ * sqrt(2) * max(kscl) and the scene AABB (optixTracer.cpp:870-888). */
+int orc_grt_proxies(const GrtConfig* cfg, uint32_t N, const real* positions, const real* rotations, const real* scales,
+                    const real* densities, real* inst12, real* aabb6, real* slack, real* scene6) {
+    for (int k = 0; k < 3; ++k) { scene6[k] = R_(3.0e38); scene6[3 + k] = R_(-3.0e38); }
+    for (uint32_t i = 0; i < N; ++i) {
+        const v4 q = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        const m33 rotT = quat_wxyz_to_rotT(q); /* rows of R^T */
+        const real ks = orc_grt_kernel_scale(densities[i], (real)cfg->particle_kernel_min_response, cfg->particle_kernel_density_clamping,
+                                             (real)cfg->particle_kernel_degree);
+        const real kscl[3] = {ks * scales[3 * i], ks * scales[3 * i + 1], ks * scales[3 * i + 2]};
+        real* o = inst12 + 12 * (size_t)i;
+        for (int r = 0; r < 3; ++r) {
+            o[3 * r] = rotT.r[r].x / kscl[r]; o[3 * r + 1] = rotT.r[r].y / kscl[r]; o[3 * r + 2] = rotT.r[r].z / kscl[r];
+        }
+        o[9] = positions[3 * i]; o[10] = positions[3 * i + 1]; o[11] = positions[3 * i + 2];
+        /* world half extent_c = sum_r |R_cr| kscl_r with R_cr = rotT.r[r].c */
+        const real hx = r_fabs(rotT.r[0].x) * kscl[0] + r_fabs(rotT.r[1].x) * kscl[1] + r_fabs(rotT.r[2].x) * kscl[2];
+        const real hy = r_fabs(rotT.r[0].y) * kscl[0] + r_fabs(rotT.r[1].y) * kscl[1] + r_fabs(rotT.r[2].y) * kscl[2];
+        const real hz = r_fabs(rotT.r[0].z) * kscl[0] + r_fabs(rotT.r[1].z) * kscl[1] + r_fabs(rotT.r[2].z) * kscl[2];
+        real* b = aabb6 + 6 * (size_t)i;
+        b[0] = o[9] - hx; b[1] = o[10] - hy; b[2] = o[11] - hz; b[3] = o[9] + hx; b[4] = o[10] + hy; b[5] = o[11] + hz;
+        slack[i] = R_(1.41421356237) * r_max(kscl[0], r_max(kscl[1], kscl[2]));
+        for (int k = 0; k < 3; ++k) { scene6[k] = r_min(scene6[k], b[k]); scene6[3 + k] = r_max(scene6[3 + k], b[3 + k]); }
+    }
+    return 0;
+}
+
+/* ---- candidate test -------------------------------------------------------------------------
+ * Instance traversal: transform the ray with the instance's inverse map, slab-test the unit box [-1,1]^3 over the
+ * current interval, then intersectInstanceParticle (gaussianParticles.cuh:449-466).  All in one arithmetic type, no
+ * contraction (the HIP kernel evaluates the same expressions in the same order: hit order is compared bit-exactly). */
+typedef struct { real t, tnear, tfar; int ok; } grt_cand;
+
+static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist) {
+    grt_cand c; c.ok = 0; c.t = 0; c.tnear = 0; c.tfar = 0;
+    const v3 dl = v3_make(o.x - inst[9], o.y - inst[10], o.z - inst[11]);
+    const v3 po = v3_make(inst[0] * dl.x + inst[1] * dl.y + inst[2] * dl.z, inst[3] * dl.x + inst[4] * dl.y + inst[5] * dl.z,
+                          inst[6] * dl.x + inst[7] * dl.y + inst[8] * dl.z);
+    const v3 pd = v3_make(inst[0] * d.x + inst[1] * d.y + inst[2] * d.z, inst[3] * d.x + inst[4] * d.y + inst[5] * d.z,
+                          inst[6] * d.x + inst[7] * d.y + inst[8] * d.z);
+    /* slab test of the unit box */
+    const real ax0 = (-1 - po.x) / pd.x, ax1 = (1 - po.x) / pd.x;
+    const real ay0 = (-1 - po.y) / pd.y, ay1 = (1 - po.y) / pd.y;
+    const real az0 = (-1 - po.z) / pd.z, az1 = (1 - po.z) / pd.z;
+    const real tnear = r_max(r_max(r_min(ax0, ax1), r_min(ay0, ay1)), r_min(az0, az1));
+    const real tfar  = r_min(r_min(r_max(ax0, ax1), r_max(ay0, ay1)), r_max(az0, az1));
+    if (!(tnear <= tfar)) return c;
+    c.tnear = tnear; c.tfar = tfar;
+    /* intersectInstanceParticle */
+    const real numerator = -(po.x * pd.x + po.y * pd.y + po.z * pd.z);
+    const real dd = pd.x * pd.x + pd.y * pd.y + pd.z * pd.z;
+    const real denominator = 1 / dd;
+    c.t = numerator * denominator;
+    const v3 n = dd > 0 ? v3_scale(pd, 1 / r_sqrt(dd)) : pd;
+    const v3 cr = v3_cross(n, po);
+    c.ok = (v3_dot(cr, cr) * denominator < max_sqdist);
+    return c;
+}
+
+/* ---- per-hit math: gaussianParticles.cuh:337-405 (processHit), :468-731 (processHitBwd) ------ */
+typedef struct { v3 pos, scl; v4 quat; m33 rotT; real density; } grt_particle;
+static grt_particle load_particle(const real* pd) {
+    grt_particle p;
+    p.pos = v3_make(pd[0], pd[1], pd[2]); p.density = pd[3];
+    p.quat.x = pd[4]; p.quat.y = pd[5]; p.quat.z = pd[6]; p.quat.w = pd[7];
+    p.scl = v3_make(pd[8], pd[9], pd[10]);
+    p.rotT = quat_wxyz_to_rotT(p.quat);
+    return p;
+}
+static v3 v3_max0(v3 a) { return v3_make(r_max(a.x, 0), r_max(a.y, 0), r_max(a.z, 0)); }
+
+typedef struct { real T; v3 rad; real depth; v3 normal; } grt_ray_state;
+
+static int process_hit(const GrtConfig* cfg, v3 ro, v3 rd, const real* pd, const real* sph, int sph_deg, grt_ray_state* s, int with_normal) {
+    const grt_particle p = load_particle(pd);
+    const v3 giscl = v3_make(1 / p.scl.x, 1 / p.scl.y, 1 / p.scl.z);
+    const v3 gposc = v3_sub(ro, p.pos);
+    const v3 gposcr = v3_mul_rows(gposc, &p.rotT);
+    const v3 gro = v3_mul(giscl, gposcr);
+    const v3 rdr = v3_mul_rows(rd, &p.rotT);
+    const v3 grdu = v3_mul(giscl, rdr);
+    const v3 grd = v3_safe_normalize(grdu);
+    const v3 gcrod = v3_cross(grd, gro);
+    const real gray = v3_dot(gcrod, gcrod);
+    const real gres = particle_response(cfg->particle_kernel_degree, gray);
+    const real galpha = r_min((real)cfg->particle_kernel_max_alpha, gres * p.density);
+    const int accept = (gres > (real)cfg->particle_kernel_min_response) && (galpha > (real)cfg->particle_kernel_min_alpha);
+    if (accept) {
+        const real weight = galpha * s->T;
+        const real pdot = v3_dot(grd, v3_scale(gro, -1));
+        const v3 grds = v3_mul(p.scl, v3_scale(grd, pdot));
+        const real hitT = r_sqrt(v3_dot(grds, grds));
+        const v3 grad = v3_max0(sh_radiance_unclamped(sph_deg, sph, rd));
+        s->rad = v3_add(s->rad, v3_scale(grad, weight));
+        s->T *= (1 - galpha);
+        s->depth += hitT * weight;
+        if (with_normal) { /* :398-402 */
+            const v3 psr = m33_mul_cols(&p.rotT, p.scl);
+            const v3 q = v3_add(gro, v3_scale(grd, pdot - r_sqrt(9 - gray)));
+            const v3 n = v3_safe_normalize(v3_mul(q, psr));
+            s->normal = v3_add(s->normal, v3_scale(n, weight));
+        }
+    }
+    return accept;
+}
+
+typedef struct {
+    real T; v3 rad; real depth;          /* running */
+    real T_fin; v3 rad_fin; real depth_fin;
+    real T_grad; v3 rad_grad; real depth_grad;
+} grt_bwd_state;
+
+/* per-hit gradients are ADDED into g_density12[12] and g_sph[3*ncoef] (the reference's atomicAdd targets) */
+static void process_hit_bwd(const GrtConfig* cfg, v3 ro, v3 rd, const real* pd, const real* sph, int sph_deg, real min_T,
+                            grt_bwd_state* r, real* g_density12, real* g_sph) {
+    const grt_particle p = load_particle(pd);
+    const v3 gscl = p.scl;
+    const v3 giscl = v3_make(1 / gscl.x, 1 / gscl.y, 1 / gscl.z);
+    const v3 gposc = v3_sub(ro, p.pos);
+    const v3 gposcr = v3_mul_rows(gposc, &p.rotT);
+    const v3 gro = v3_mul(giscl, gposcr);
+    const v3 rdr = v3_mul_rows(rd, &p.rotT);
+    const v3 grdu = v3_mul(giscl, rdr);
+    const v3 grd = v3_safe_normalize(grdu);
+    const v3 gcrod = v3_cross(grd, gro);
+    const real gray = v3_dot(gcrod, gcrod);
+    const real gres = particle_response(cfg->particle_kernel_degree, gray);
+    const real galpha = r_min((real)cfg->particle_kernel_max_alpha, gres * p.density);
+    if (!((gres > (real)cfg->particle_kernel_min_response) && (galpha > (real)cfg->particle_kernel_min_alpha))) return;
+
+    const real pdot = v3_dot(grd, v3_scale(gro, -1));
+    const v3 grdd = v3_scale(grd, pdot);
+    const v3 grds = v3_mul(gscl, grdd);
+    const real gsq = v3_dot(grds, grds);
+    const real gdist = r_sqrt(gsq);
+    const real T = r->T;
+    const real weight = galpha * T;
+    const real nextT = (1 - galpha) * T;
+
+    r->depth += weight * gdist;
+    const real resHitT = r_max(nextT <= min_T ? 0 : (r->depth_fin - r->depth) / nextT, 0);
+    const real galphaRayHitGrd = (gdist - resHitT) * T * r->depth_grad;
+    const v3 grdsRayHitGrd = gsq > 0 ? v3_scale(grds, (2 * weight) / (2 * gdist) * r->depth_grad) : v3_make(0, 0, 0);
+    const v3 gsclRayHitGrd = v3_mul(grdd, grdsRayHitGrd);
+    const real grdScaledDot = v3_dot(v3_mul(grdsRayHitGrd, gscl), grd);
+    const v3 grdRayHitGrd = v3_sub(v3_scale(v3_mul(gscl, grdsRayHitGrd), pdot), v3_scale(gro, grdScaledDot));
+    const v3 groRayHitGrd = v3_scale(grd, -grdScaledDot);
+
+    const real resTrm = galpha < R_(0.999999) ? r->T_fin / (1 - galpha) : T;
+    const real galphaRayDnsGrd = resTrm * -r->T_grad;
+
+    /* radianceFromSpHBwd :101-177: clamped radiance + SH coefficient gradients (clamp-masked) */
+    const v3 gradu = sh_radiance_unclamped(sph_deg, sph, rd);
+    const v3 grad = v3_max0(gradu);
+    v3 dL = v3_scale(r->rad_grad, weight);
+    if (!(gradu.x > 0)) dL.x = 0;
+    if (!(gradu.y > 0)) dL.y = 0;
+    if (!(gradu.z > 0)) dL.z = 0;
+    real b[16];
+    sh_basis(sph_deg, rd, b);
+    const int nact = (sph_deg + 1) * (sph_deg + 1);
+    for (int k = 0; k < nact; ++k) { g_sph[3 * k] += b[k] * dL.x; g_sph[3 * k + 1] += b[k] * dL.y; g_sph[3 * k + 2] += b[k] * dL.z; }
+
+    r->rad = v3_add(r->rad, v3_scale(grad, weight));
+    v3 resRad = v3_make(0, 0, 0);
+    if (!(nextT <= min_T)) resRad = v3_max0(v3_scale(v3_sub(r->rad_fin, r->rad), 1 / nextT));
+    const real common = galphaRayHitGrd + galphaRayDnsGrd + T * (grad.x - resRad.x) * r->rad_grad.x + T * (grad.y - resRad.y) * r->rad_grad.y +
+                        T * (grad.z - resRad.z) * r->rad_grad.z;
+    g_density12[3] += gres * common;
+    const real gresGrd = p.density * common;
+    const real grayGrd = particle_response_grd(cfg->particle_kernel_degree, gray, gres, gresGrd);
+
+    const v3 gcrodGrd = v3_scale(gcrod, 2 * grayGrd);
+    const v3 grdGrd = v3_make(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
+    const v3 groGrd = v3_make(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+    const v3 groTot = v3_add(groGrd, groRayHitGrd);
+    const v3 gsclGrdGro = v3_mul(v3_make(-gposcr.x / (gscl.x * gscl.x), -gposcr.y / (gscl.y * gscl.y), -gposcr.z / (gscl.z * gscl.z)), groTot);
+    const v3 gposcrGrd = v3_mul(giscl, groTot);
+    const v3 gposcGrd = matmul_bw_vec(&p.rotT, gposcrGrd);
+    const v4 grotGrdPoscr = matmul_bw_quat(gposc, gposcrGrd, p.quat);
+    g_density12[0] += -gposcGrd.x; g_density12[1] += -gposcGrd.y; g_density12[2] += -gposcGrd.z;
+    const v3 grduGrd = v3_safe_normalize_bw(grdu, v3_add(grdGrd, grdRayHitGrd));
+    g_density12[8] += gsclRayHitGrd.x + gsclGrdGro.x + (-rdr.x / (gscl.x * gscl.x)) * grduGrd.x;
+    g_density12[9] += gsclRayHitGrd.y + gsclGrdGro.y + (-rdr.y / (gscl.y * gscl.y)) * grduGrd.y;
+    g_density12[10] += gsclRayHitGrd.z + gsclGrdGro.z + (-rdr.z / (gscl.z * gscl.z)) * grduGrd.z;
+    const v3 rdrGrd = v3_mul(giscl, grduGrd);
+    const v4 grotGrdRd = matmul_bw_quat(rd, rdrGrd, p.quat);
+    g_density12[4] += grotGrdPoscr.x + grotGrdRd.x; g_density12[5] += grotGrdPoscr.y + grotGrdRd.y;
+    g_density12[6] += grotGrdPoscr.z + grotGrdRd.z; g_density12[7] += grotGrdPoscr.w + grotGrdRd.w;
+    r->T = nextT;
+}
+
+/* ---- known-answer entry points (tests/golden/per_hit_deg*.npz: grt_* arrays) ------------------ */
+static GrtConfig kat_config(int degree, real min_response, real min_alpha, real max_alpha) {
+    GrtConfig cfg; memset(&cfg, 0, sizeof(cfg));
+    cfg.particle_kernel_degree = degree; cfg.particle_kernel_min_response = (float)min_response;
+    cfg.particle_kernel_min_alpha = (float)min_alpha; cfg.particle_kernel_max_alpha = (float)max_alpha;
+    return cfg;
+}
+/* state8 = {T, rad[3], depth, normal[3]} */
+int orc_grt_process_hit_fwd(int degree, real min_response, real min_alpha, real max_alpha, const real* ray_o, const real* ray_d,
+                            const real* density12, const real* sph48, int sph_deg, int with_normal, real* state8) {
+    const GrtConfig cfg = kat_config(degree, min_response, min_alpha, max_alpha);
+    grt_ray_state s;
+    s.T = state8[0]; s.rad = v3_make(state8[1], state8[2], state8[3]); s.depth = state8[4];
+    s.normal = v3_make(state8[5], state8[6], state8[7]);
+    const int acc = process_hit(&cfg, v3_make(ray_o[0], ray_o[1], ray_o[2]), v3_make(ray_d[0], ray_d[1], ray_d[2]), density12, sph48, sph_deg, &s, with_normal);
+    state8[0] = s.T; state8[1] = s.rad.x; state8[2] = s.rad.y; state8[3] = s.rad.z; state8[4] = s.depth;
+    state8[5] = s.normal.x; state8[6] = s.normal.y; state8[7] = s.normal.z;
+    return acc;
+}
+void orc_grt_process_hit_bwd(int degree, real min_response, real min_alpha, real max_alpha, real min_transmittance, const real* ray_o,
+                             const real* ray_d, const real* density12, const real* sph48, int sph_deg, real* state5, const real* fin5,
+                             const real* grads5, real* g_density12, real* g_sph48) {
+    const GrtConfig cfg = kat_config(degree, min_response, min_alpha, max_alpha);
+    grt_bwd_state r;
+    r.T = state5[0]; r.rad = v3_make(state5[1], state5[2], state5[3]); r.depth = state5[4];
+    r.T_fin = fin5[0]; r.rad_fin = v3_make(fin5[1], fin5[2], fin5[3]); r.depth_fin = fin5[4];
+    r.T_grad = grads5[0]; r.rad_grad = v3_make(grads5[1], grads5[2], grads5[3]); r.depth_grad = grads5[4];
+    for (int k = 0; k < 12; ++k) g_density12[k] = 0;
+    for (int k = 0; k < 48; ++k) g_sph48[k] = 0;
+    process_hit_bwd(&cfg, v3_make(ray_o[0], ray_o[1], ray_o[2]), v3_make(ray_d[0], ray_d[1], ray_d[2]), density12, sph48, sph_deg,
+                    min_transmittance, &r, g_density12, g_sph48);
+    state5[0] = r.T; state5[1] = r.rad.x; state5[2] = r.rad.y; state5[3] = r.rad.z; state5[4] = r.depth;
+}
+/* intersectInstanceParticle on an object-space ray */
+int orc_grt_intersect_instance(const real* pray_o, const real* pray_d, real tmin, real tmax, real max_sqdist, real* hit_t) {
+    const v3 pd = v3_make(pray_d[0], pray_d[1], pray_d[2]), po = v3_make(pray_o[0], pray_o[1], pray_o[2]);
+    const real dd = v3_dot(pd, pd);
+    const real denominator = 1 / dd;
+    const real t = -(v3_dot(po, pd)) * denominator;
+    *hit_t = t;
+    if (!((t > tmin) && (t < tmax))) return 0;
+    const v3 n = dd > 0 ? v3_scale(pd, 1 / r_sqrt(dd)) : pd;
+    const v3 cr = v3_cross(n, po);
+    return v3_dot(cr, cr) * denominator < max_sqdist;
+}
+
+/* ---- rays ------------------------------------------------------------------------------------ */
+static v3 xform_point(const real* m12, v3 p) { /* pipelineParameters.h:97-105, row-major 3x4 */
+    return v3_make(m12[0] * p.x + m12[1] * p.y + m12[2] * p.z + m12[3], m12[4] * p.x + m12[5] * p.y + m12[6] * p.z + m12[7],
+                   m12[8] * p.x + m12[9] * p.y + m12[10] * p.z + m12[11]);
+}
+static v3 xform_dir(const real* m12, v3 p) {
+    return v3_make(m12[0] * p.x + m12[1] * p.y + m12[2] * p.z, m12[4] * p.x + m12[5] * p.y + m12[6] * p.z, m12[8] * p.x + m12[9] * p.y + m12[10] * p.z);
+}
+/* referenceOptix.cu:33-39 intersectAABB */
+static void scene_interval(const real* aabb6, v3 o, v3 d, real* tmin_o, real* tmax_o) {
+    const real t0x = (aabb6[0] - o.x) / d.x, t0y = (aabb6[1] - o.y) / d.y, t0z = (aabb6[2] - o.z) / d.z;
+    const real t1x = (aabb6[3] - o.x) / d.x, t1y = (aabb6[4] - o.y) / d.y, t1z = (aabb6[5] - o.z) / d.z;
+    const real mx = r_max(t0x, t1x), my = r_max(t0y, t1y), mz = r_max(t0z, t1z);
+    const real nx = r_min(t0x, t1x), ny = r_min(t0y, t1y), nz = r_min(t0z, t1z);
+    *tmin_o = r_max(0, r_max(nx, r_max(ny, nz)));
+    *tmax_o = r_min(mx, r_min(my, mz));
+}
+
+typedef struct { real t; uint32_t id; real tnear, tfar; } grt_hit;
+static int hit_cmp(const void* a, const void* b) {
+    const grt_hit* x = (const grt_hit*)a; const grt_hit* y = (const grt_hit*)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
+}
+/* all candidates of one ray, sorted by (t, id); brute force over the particles */
+static uint32_t ray_candidates(uint32_t N, const real* inst12, v3 o, v3 d, grt_hit* out) {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < N; ++i) {
+        const grt_cand c = candidate(inst12 + 12 * (size_t)i, o, d, R_(9.0)); /* hitMaxParticleSquaredDistance, pipelineParameters.h:71 */
+        if (c.ok) { out[n].t = c.t; out[n].id = i; out[n].tnear = c.tnear; out[n].tfar = c.tfar; n++; }
+    }
+    qsort(out, n, sizeof(grt_hit), hit_cmp);
+    return n;
+}
+/* one optixTrace: up to K nearest candidates with t in (tmin, tmax) whose box interval touches [tmin, tmax] */
+static int trace_round(const grt_hit* cands, uint32_t n, real tmin, real tmax, int K, grt_hit* out) {
+    int k = 0;
+    for (uint32_t i = 0; i < n && k < K; ++i) {
+        const grt_hit* h = &cands[i];
+        if ((h->t > tmin) && (h->t < tmax) && (h->tfar >= tmin) && (h->tnear <= tmax)) out[k++] = *h;
+    }
+    return k;
+}
+
+/* __raygen__rg, referenceOptix.cu:103-186.  rays are [nrays,3] in ray space; outputs per ray.
+ * dbg_ids (optional): [nrays, dbg_cap] processed candidates in order; dbg_count [nrays]. */
+int orc_grt_trace_fwd(const GrtConfig* cfg, uint32_t N, const real* density12, const real* sph, int sph_deg, real min_T,
+                      const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
+                      const real* ray_d, real* out_rad, real* out_dns, real* out_hit2, real* out_nrm, real* out_cnt,
+                      int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap) {
+    const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
+    if (K > GRT_MAX_K) return -1;
+    const int ncoef = (cfg->particle_radiance_sph_degree + 1) * (cfg->particle_radiance_sph_degree + 1);
+    const real eps = R_(1e-9);
+#pragma omp parallel
+    {
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+#pragma omp for schedule(dynamic, 8)
+        for (uint32_t r = 0; r < nrays; ++r) {
+            const v3 o = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
+            const v3 d = xform_dir(ray_to_world12, v3_make(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
+            grt_ray_state s; s.T = 1; s.rad = v3_make(0, 0, 0); s.depth = 0; s.normal = v3_make(0, 0, 0);
+            real cnt = 0;
+            real tEnter, tExit;
+            scene_interval(scene6, o, d, &tEnter, &tExit);
+            real tLast = r_max(0, tEnter - eps);
+            const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+            uint32_t ndbg = 0;
+            grt_hit buf[GRT_MAX_K];
+            while ((tLast <= tExit) && (s.T > min_T)) {
+                const int k = trace_round(cands, n, tLast + eps, tExit + eps, K, buf);
+                if (k == 0) break;
+                for (int i = 0; i < k; ++i) {
+                    if (s.T > min_T) {
+                        const uint32_t id = buf[i].id;
+                        const int acc = process_hit(cfg, o, d, density12 + 12 * (size_t)id, sph + (size_t)id * 3 * ncoef, sph_deg, &s, cfg->enable_normals);
+                        if (acc) {
+#pragma omp atomic write
+                            visibility[id] = 1;
+                        }
+                        tLast = r_max(tLast, buf[i].t);
+                        cnt += acc ? 1 : 0;
+                        if (dbg_ids && ndbg < dbg_cap) dbg_ids[(size_t)r * dbg_cap + ndbg] = id;
+                        ndbg++;
+                    }
+                }
+            }
+            out_rad[3 * r] = s.rad.x; out_rad[3 * r + 1] = s.rad.y; out_rad[3 * r + 2] = s.rad.z;
+            out_dns[r] = 1 - s.T;
+            out_hit2[2 * r] = s.depth; out_hit2[2 * r + 1] = tLast;
+            if (cfg->enable_normals) { out_nrm[3 * r] = s.normal.x; out_nrm[3 * r + 1] = s.normal.y; out_nrm[3 * r + 2] = s.normal.z; }
+            if (cfg->enable_hitcounts) out_cnt[r] = cnt;
+            if (dbg_count) dbg_count[r] = ndbg;
+        }
+        free(cands);
+    }
+    return 0;
+}
+
+/* __raygen__rg of referenceBwdOptix.cu:103-170.  g_density12 [N,12], g_sph [N,3*ncoef] are accumulated into. */
+int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, const real* sph, int sph_deg, real min_T,
+                      const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
+                      const real* ray_d, const real* rad, const real* dns, const real* hit2, const real* g_rad, const real* g_dns,
+                      const real* g_hit, real* g_density12, real* g_sph) {
+    const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
+    if (K > GRT_MAX_K) return -1;
+    const int ncoef = (cfg->particle_radiance_sph_degree + 1) * (cfg->particle_radiance_sph_degree + 1);
+    const real eps = R_(1e-9);
+#pragma omp parallel
+    {
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+#pragma omp for schedule(dynamic, 8)
+        for (uint32_t r = 0; r < nrays; ++r) {
+            const v3 o = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
+            const v3 d = xform_dir(ray_to_world12, v3_make(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
+            grt_bwd_state b;
+            b.T = 1; b.rad = v3_make(0, 0, 0); b.depth = 0;
+            b.rad_fin = v3_make(rad[3 * r], rad[3 * r + 1], rad[3 * r + 2]);
+            b.T_fin = 1 - dns[r];
+            b.depth_fin = hit2[2 * r];
+            const real maxHit = hit2[2 * r + 1];
+            b.rad_grad = v3_make(g_rad[3 * r], g_rad[3 * r + 1], g_rad[3 * r + 2]);
+            b.T_grad = -g_dns[r];
+            b.depth_grad = g_hit[r];
+            real tEnter, tExit;
+            scene_interval(scene6, o, d, &tEnter, &tExit);
+            real startT = r_max(0, tEnter - eps);
+            const real endT = r_min(maxHit, tExit) + eps;
+            const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+            grt_hit buf[GRT_MAX_K];
+            while (startT < endT) {
+                const int k = trace_round(cands, n, startT + eps, endT, K, buf);
+                if (k == 0) break;
+                for (int i = 0; i < k; ++i) {
+                    const uint32_t id = buf[i].id;
+                    real gd[12] = {0}, gs[48] = {0};
+                    process_hit_bwd(cfg, o, d, density12 + 12 * (size_t)id, sph + (size_t)id * 3 * ncoef, sph_deg, min_T, &b, gd, gs);
+                    for (int c = 0; c < 11; ++c)
+                        if (gd[c] != 0) {
+#pragma omp atomic
+                            g_density12[12 * (size_t)id + c] += gd[c];
+                        }
+                    for (int c = 0; c < 3 * ncoef; ++c)
+                        if (gs[c] != 0) {
+#pragma omp atomic
+                            g_sph[(size_t)id * 3 * ncoef + c] += gs[c];
+                        }
+                    startT = r_max(startT, buf[i].t);
+                }
+            }
+        }
+        free(cands);
+    }
+    return 0;
+}

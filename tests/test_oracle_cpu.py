@@ -157,3 +157,110 @@ def test_empty_scene_outputs_keep_initial_values():
                              scene["sph"], *scene["rays"])
     assert fwd["bins"]["num_intersections"] == 0
     assert np.all(fwd["feat_density"] == 0) and np.all(fwd["hit_distance"] == np.float32(1e6))
+
+
+# ------------------------------------------------------------------------------------------
+# 3DGRT oracle
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("degree", [2, 4])
+def test_grt_per_hit_matches_reference_vectors(degree):
+    g = _golden(degree)
+    mr, ma, mt = float(g["params"][0]), float(g["params"][1]), float(g["params"][3])
+    worst = 0.0
+    for i in range(g["ray_o"].shape[0]):
+        st0 = np.concatenate([g["state5"][i], np.zeros(3, np.float32)])
+        acc, st = oracle.grt_process_hit_fwd(degree, mr, ma, 0.99, g["ray_o"][i], g["ray_d"][i], g["density12"][i], g["sph48"][i], 3, True, st0)
+        assert acc == int(g["grt_fwd_accept"][i]), i
+        assert _close(st[:5], g["grt_fwd_state"][i][:5]), (i, st, g["grt_fwd_state"][i])
+        assert _close(st[5:], g["grt_fwd_state"][i][5:], rtol=2e-4, atol=1e-5), (i, st[5:], g["grt_fwd_state"][i][5:])
+        s5, gd, gs = oracle.grt_process_hit_bwd(degree, mr, ma, 0.99, mt, g["ray_o"][i], g["ray_d"][i], g["density12"][i], g["sph48"][i], 3,
+                                                g["state5"][i], g["fin5"][i], g["grads5"][i])
+        assert _close(s5, g["grt_bwd_state"][i]), i
+        ref = np.concatenate([g["grt_g_density12"][i], g["grt_g_sph48"][i]]).astype(np.float64)
+        got = np.concatenate([gd, gs]).astype(np.float64)
+        worst = max(worst, np.abs(got - ref).max() / (np.abs(ref).max() + 1e-20))
+    assert worst < 2e-4, worst
+
+
+def test_grt_instance_intersection_matches_reference_vectors():
+    g = _golden(4)
+    for i in range(g["ray_o"].shape[0]):
+        ok, t = oracle.grt_intersect_instance(g["instance_ray"][i, :3], g["instance_ray"][i, 3:], 0.0, 1e6, 1.0)
+        assert ok == int(g["instance_ok"][i]), i
+        assert _close(t, g["instance_t"][i], rtol=1e-6, atol=1e-7), (i, t, g["instance_t"][i])
+
+
+def test_grt_kernel_scale_known_values():
+    """particlePrimitives.cu:27-51: r with exp(a r^b) = min_response, a = -4.5/3^b (~3.0 deg 4 / 2.99 deg 2)."""
+    assert oracle.grt_kernel_scale(0.5, 0.0113, False, 4) == pytest.approx((np.log(0.0113) / (-4.5 / 81)) ** 0.25, rel=1e-6)
+    assert oracle.grt_kernel_scale(0.5, 0.0113, False, 2) == pytest.approx((np.log(0.0113) / (-0.5)) ** 0.5, rel=1e-6)
+    # density clamping: min response modulated by the density, capped at 0.97
+    assert oracle.grt_kernel_scale(0.5, 0.0113, True, 4) == pytest.approx((np.log(0.0226) / (-4.5 / 81)) ** 0.25, rel=1e-6)
+    assert oracle.grt_kernel_scale(0.005, 0.0113, True, 4) == pytest.approx((np.log(0.97) / (-4.5 / 81)) ** 0.25, rel=1e-5)
+
+
+def _grt_scene(n=400, w=24, h=16):
+    scene = make_scene(n=n, width=w, height=h, median_scale=0.12, max_density=0.7)
+    T = scene["batch"]["T_to_world"][0]
+    return scene, T
+
+
+def test_grt_forward_orders_hits_and_matches_brute_force_compositing():
+    scene, T = _grt_scene()
+    cfg = oracle.default_grt_config()
+    out = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, T, *scene["rays"], dbg_cap=256)
+    assert out["density"].max() > 0.3 and out["hit_count"].max() >= 2
+    # hit lists: every processed candidate appears once per ray (distances increase strictly round to round)
+    for r in range(0, out["hit_ids"].shape[0], 7):
+        ids = out["hit_ids"][r, : out["hit_num"][r]]
+        assert len(set(ids.tolist())) == len(ids)
+    # visibility = particles with at least one accepted hit
+    assert out["visibility"].sum() > 0
+    # two cameras' worth of sanity: opacity within [0,1], depth non-negative
+    assert np.all(out["density"] >= 0) and np.all(out["density"] <= 1) and np.all(out["hit_distance"][..., 0] >= 0)
+
+
+def test_grt_backward_is_the_gradient_of_forward_away_from_the_last_hit():
+    """Finite differences of the f64 oracle forward reproduce its analytic backward, except for the reference's own quirk
+    that the backward replay excludes the hit AT the saved last-hit distance (endT = tLast + 1e-9, strict compare,
+    referenceBwdOptix.cu:126-131); rays that do not saturate process every candidate, and for those the last candidate
+    is the one dropped, so the probe compares against a loss whose rays saturate early is avoided by low densities."""
+    scene, T = _grt_scene(n=150, w=12, h=8)
+    scene["density12"][:, 3] *= 0.5
+    cfg = oracle.default_grt_config()
+    d12, sph = scene["density12"].astype(np.float64), scene["sph"].astype(np.float64)
+    H, W = 8, 12
+    rng = np.random.default_rng(3)
+    g_rad, g_dns, g_hit = rng.normal(size=(H, W, 3)), rng.normal(size=(H, W, 1)), rng.normal(size=(H, W, 1)) * 0.1
+
+    def run(d):
+        return oracle.grt_forward(cfg, d, sph, 3, 1e-3, T, *scene["rays"], dbg_cap=512, dtype=np.float64)
+
+    f0 = run(d12)
+    gd, gs = oracle.grt_backward(cfg, 3, 1e-3, f0, g_rad, g_dns, g_hit, dtype=np.float64)
+    # the quirk: contributions of each ray's last processed candidate are missing from gd; measure FD on a loss that
+    # masks them out is impractical, so check only particles that are never the last candidate of any ray
+    last = set()
+    for r in range(H * W):
+        k = int(f0["hit_num"][r])
+        if k:
+            last.add(int(f0["hit_ids"][r, k - 1]))
+    probes = [i for i in np.nonzero(np.abs(gd).sum(1) > 0)[0] if i not in last][:6]
+    assert probes
+
+    def loss(d):
+        f = run(d)
+        return float((f["features"] * g_rad).sum() + (f["density"] * g_dns).sum() + (f["hit_distance"][..., :1] * g_hit).sum())
+
+    bad = 0
+    for i in probes:
+        for col in range(11):
+            h = 1e-6 * max(1.0, abs(d12[i, col]))
+            dp, dm = d12.copy(), d12.copy()
+            dp[i, col] += h
+            dm[i, col] -= h
+            fd = (loss(dp) - loss(dm)) / (2 * h)
+            if abs(fd - gd[i, col]) > 2e-4 * np.abs(gd[:, col]).max() + 1e-7:
+                bad += 1
+    # a probe particle still influences the (dropped) last hits of rays it precedes through their transmittance
+    assert bad <= len(probes) * 11 // 4, bad
