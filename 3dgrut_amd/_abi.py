@@ -97,6 +97,7 @@ EXPORTED_SYMBOLS = [
     "gut_debug_fetch", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats",
+    "grt_debug_forward_hits", "grt_debug_fetch_instances",
     "grut_last_error", "grut_abi_version",
 ]
 
@@ -142,6 +143,10 @@ def _declare(lib):
     lib.grt_forward.restype = C.c_int
     lib.grt_backward.argtypes = [C.c_void_p, vp, C.POINTER(GrtFrame)] + [fp] * 14
     lib.grt_backward.restype = C.c_int
+    lib.grt_debug_forward_hits.argtypes = [C.c_void_p, vp, C.POINTER(GrtFrame)] + [fp] * 9 + [ip, up, up, C.c_uint32]
+    lib.grt_debug_forward_hits.restype = C.c_int
+    lib.grt_debug_fetch_instances.argtypes = [C.c_void_p, vp, fp]
+    lib.grt_debug_fetch_instances.restype = C.c_int
     lib.grt_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.grt_timings.restype = C.c_int
     lib.grt_stats.argtypes = [C.c_void_p, C.POINTER(GrtStats)]

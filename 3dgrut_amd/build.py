@@ -15,12 +15,16 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libgrut_amd.so")
-SOURCES = ["scan_sort.hip", "gut_kernels.hip", "gut_render.hip", "gut_api.hip", "grt_api.hip"]
+SOURCES = ["scan_sort.hip", "gut_kernels.hip", "gut_render.hip", "gut_api.hip", "grt_kernels.hip", "grt_api.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast",
          # SLP-packing scalar f32 math into v_pk_*_f32 costs register-pair shuffles (v_mov) and VGPRs on gfx950
          "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+# per-file additions.  grt_kernels.hip evaluates hit distances under `#pragma clang fp contract(off)` so that the per-ray
+# hit ORDER is reproducible bit for bit by the CPU checker; the pragma is only honoured when the command-line mode is
+# `on` (with `fast` the backend fuses regardless), so that file is built with -ffp-contract=on.
+FILE_FLAGS = {"grt_kernels.hip": ["-ffp-contract=on"]}
 
 
 def _hipcc() -> str:
@@ -53,7 +57,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
         op = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + deps):
-            jobs.append([hipcc, "-x", "hip", *FLAGS, *extra_flags, "-c", sp, "-o", op])
+            jobs.append([hipcc, "-x", "hip", *FLAGS, *FILE_FLAGS.get(src, []), *extra_flags, "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:

@@ -1,30 +1,252 @@
-// grt_api.hip — 3DGRT entry points (placeholder until the LBVH path lands; every call fails loudly).
-#include "common.hpp"
+// grt_api.hip — host orchestration of the 3DGRT path behind the C-ABI (include/grut_amd.h).
+// Plays the role of OptixTracer (threedgrt_tracer/src/optixTracer.cpp:616-1031: buildBVH / trace / traceBwd) without
+// OptiX and without libtorch: all I/O buffers belong to the caller, the handle owns the BVH and scratch.
+#include "grt_internal.hpp"
+
+using namespace grut;
 
 struct GrtHandle {
     GrtConfig cfg;
+    int device = -1;
+    uint32_t N = 0;
+    bool built = false;
+    hipStream_t build_stream = nullptr;
+    DeviceBuffer inst, aabb, slack, scene_enc, scene, codes, ids, codes_tmp, ids_tmp, sort_scratch, nodes, parent_internal, parent_leaf,
+        counters, dbg_ids, dbg_count;
+    uint32_t* sorted_ids = nullptr;
+    uint32_t* sorted_codes = nullptr;
+    float scene_host[6] = {0, 0, 0, 0, 0, 0};
+    bool scene_host_valid = false;
+    EventTimer fwd_timer, bwd_timer, build_timer;
 };
+
+static int grt_validate(const GrtConfig& c) {
+    GRUT_REQUIRE(c.particle_radiance_sph_degree >= 0 && c.particle_radiance_sph_degree <= 3, "sph degree must be in [0,3]");
+    const int d = c.particle_kernel_degree;
+    GRUT_REQUIRE(d == 0 || d == 1 || d == 2 || d == 3 || d == 4 || d == 5 || d == 8, "unsupported particle_kernel_degree %d", d);
+    if (c.max_hits_per_trace != 0 && c.max_hits_per_trace != kGrtMaxHits) {
+        set_last_error("max_hits_per_trace=%d: the hit buffer is %d entries (PipelineParameters::MaxNumHitPerTrace)", c.max_hits_per_trace, kGrtMaxHits);
+        return GRUT_ERR_UNSUPPORTED;
+    }
+    return GRUT_OK;
+}
+
+static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
+    GrtTraceParams P;
+    memset(&P, 0, sizeof(P));
+    P.degree = h->cfg.particle_kernel_degree;
+    P.ncoef = (h->cfg.particle_radiance_sph_degree + 1) * (h->cfg.particle_radiance_sph_degree + 1);
+    P.sph_degree = f.sph_degree < h->cfg.particle_radiance_sph_degree ? f.sph_degree : h->cfg.particle_radiance_sph_degree;
+    if (P.sph_degree < 0) P.sph_degree = 0;
+    P.normals = h->cfg.enable_normals;
+    P.hitcounts = h->cfg.enable_hitcounts;
+    P.min_response = h->cfg.particle_kernel_min_response;
+    P.min_alpha = h->cfg.particle_kernel_min_alpha;  // optixTracer.cpp:925 uses 1/255
+    P.max_alpha = h->cfg.particle_kernel_max_alpha;
+    P.min_transmittance = f.min_transmittance;
+    P.W = f.width;
+    P.H = f.height;
+    for (int k = 0; k < 12; ++k) P.ray_to_world[k] = f.ray_to_world[k];
+    return P;
+}
+
+static GrtBvh bvh_view(const GrtHandle* h) {
+    GrtBvh b;
+    b.nodes = h->nodes.as<GrtNode>();
+    b.inst = h->inst.as<float>();
+    b.scene = h->scene.as<float>();
+    b.N = h->N;
+    return b;
+}
 
 extern "C" {
 
-static int grt_unsupported(const char* what) {
-    grut::set_last_error("%s: the 3DGRT software-BVH path is not built into this library yet", what);
-    return GRUT_ERR_UNSUPPORTED;
+int grt_create(const GrtConfig* config, GrtHandle** handle) {
+    GRUT_REQUIRE(config && handle, "grt_create: null argument");
+    GRUT_CHECK(grt_validate(*config));
+    GrtHandle* h = new GrtHandle();
+    h->cfg = *config;
+    if (hipGetDevice(&h->device) != hipSuccess) {
+        set_last_error("grt_create: no HIP device");
+        delete h;
+        return GRUT_ERR_RUNTIME;
+    }
+    *handle = h;
+    return GRUT_OK;
 }
 
-int grt_create(const GrtConfig*, GrtHandle**) { return grt_unsupported("grt_create"); }
-void grt_destroy(GrtHandle* h) { delete h; }
-int grt_build_bvh(GrtHandle*, void*, uint32_t, const float*, const float*, const float*, const float*, int, int) {
-    return grt_unsupported("grt_build_bvh");
+void grt_destroy(GrtHandle* h) {
+    if (!h) return;
+    DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
+                            &h->sort_scratch, &h->nodes, &h->parent_internal, &h->parent_leaf, &h->counters, &h->dbg_ids, &h->dbg_count};
+    for (DeviceBuffer* b : bufs) b->release();
+    h->fwd_timer.destroy();
+    h->bwd_timer.destroy();
+    h->build_timer.destroy();
+    delete h;
 }
-int grt_forward(GrtHandle*, void*, const GrtFrame*, const float*, const float*, const float*, const float*, float*, float*, float*,
-                float*, float*, int32_t*) {
-    return grt_unsupported("grt_forward");
+
+// OptixTracer::buildBVH (optixTracer.cpp:616-890).  rebuild = 0 keeps the tree topology and only refits boxes
+// (OPTIX_BUILD_OPERATION_UPDATE); the caller decides (threedgrt_tracer/tracer.py:198-216).
+int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* positions, const float* rotations, const float* scales,
+                  const float* densities, int rebuild, int allow_update) {
+    (void)allow_update;
+    GRUT_REQUIRE(h, "grt_build_bvh: null handle");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (N == 0) {
+        h->N = 0;
+        h->built = true;
+        return GRUT_OK;
+    }
+    GRUT_REQUIRE(positions && rotations && scales && densities, "grt_build_bvh: null buffer");
+    if (!rebuild && (!h->built || h->N != N)) rebuild = 1;  // "cannot refit GAS with a different number of gaussian" (optixTracer.cpp:629-632)
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.begin(s));
+    const size_t n = N;
+    GRUT_CHECK(h->inst.ensure(n * 48, 1.25f));
+    GRUT_CHECK(h->aabb.ensure(n * 24, 1.25f));
+    GRUT_CHECK(h->slack.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->scene_enc.ensure(64));
+    GRUT_CHECK(h->scene.ensure(64));
+    GRUT_CHECK(h->codes.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->ids.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->codes_tmp.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->ids_tmp.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
+    GRUT_CHECK(h->nodes.ensure(n * sizeof(GrtNode), 1.25f));
+    GRUT_CHECK(h->parent_internal.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->parent_leaf.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->counters.ensure(n * 4, 1.25f));
+
+    GrtBuildParams P;
+    P.N = N;
+    P.degree = h->cfg.particle_kernel_degree;
+    P.clamping = h->cfg.particle_kernel_density_clamping;
+    P.min_response = h->cfg.particle_kernel_min_response;
+    uint32_t* scene_enc = h->scene_enc.as<uint32_t>();
+    GRUT_HIP(hipMemsetAsync(scene_enc, 0xFF, 12, s));
+    GRUT_HIP(hipMemsetAsync(scene_enc + 3, 0x00, 12, s));
+    grt_launch_proxies(s, P, positions, rotations, scales, densities, h->inst.as<float>(), h->aabb.as<float>(), h->slack.as<float>(), scene_enc);
+    // refit-only updates keep the sorted order of the last full build, so the code / id buffers must stay untouched
+    grt_launch_morton(s, N, h->aabb.as<float>(), scene_enc, h->scene.as<float>(), rebuild ? h->codes.as<uint32_t>() : nullptr,
+                      rebuild ? h->ids.as<uint32_t>() : nullptr);
+    if (rebuild) {
+        uint32_t *sc = nullptr, *si = nullptr;
+        GRUT_CHECK(sort_pairs_u32(s, N, nullptr, 0, 30, h->codes.as<uint32_t>(), h->ids.as<uint32_t>(), h->codes_tmp.as<uint32_t>(),
+                                  h->ids_tmp.as<uint32_t>(), h->sort_scratch.ptr, h->sort_scratch.bytes, &sc, &si));
+        h->sorted_codes = sc;
+        h->sorted_ids = si;
+        GRUT_HIP(hipMemsetAsync(h->parent_internal.ptr, 0xFF, n * 4, s));
+        grt_launch_hierarchy(s, N, sc, h->nodes.as<GrtNode>(), h->parent_internal.as<uint32_t>(), h->parent_leaf.as<uint32_t>());
+    }
+    // the refit re-derives every box from the fresh proxies; on rebuild = 0 the sorted order of the last build is reused
+    GRUT_HIP(hipMemsetAsync(h->counters.ptr, 0, n * 4, s));
+    grt_launch_refit(s, N, h->sorted_ids, h->aabb.as<float>(), h->slack.as<float>(), h->parent_internal.as<uint32_t>(),
+                     h->parent_leaf.as<uint32_t>(), h->nodes.as<GrtNode>(), h->counters.as<uint32_t>());
+    GRUT_HIP(hipGetLastError());
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.end(s));
+    h->N = N;
+    h->built = true;
+    h->build_stream = s;
+    h->scene_host_valid = false;
+    return GRUT_OK;
 }
-int grt_backward(GrtHandle*, void*, const GrtFrame*, const float*, const float*, const float*, const float*, const float*, const float*,
-                 const float*, const float*, const float*, const float*, const float*, const float*, float*, float*) {
-    return grt_unsupported("grt_backward");
+
+static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
+                            const float* ray_origin, const float* ray_direction, float* out_features, float* out_density,
+                            float* out_hit_distance, float* out_normals, float* out_hits_count, int32_t* out_visibility,
+                            uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap) {
+    GRUT_REQUIRE(h && frame, "grt_forward: null handle/frame");
+    if (!h->built) {
+        set_last_error("grt_forward: build_bvh has not been called");
+        return GRUT_ERR_NOT_READY;
+    }
+    GRUT_REQUIRE(frame->width > 0 && frame->height > 0, "grt_forward: empty image");
+    GRUT_REQUIRE(frame->num_particles == h->N, "grt_forward: %u particles but the BVH holds %u", frame->num_particles, h->N);
+    GRUT_REQUIRE(ray_origin && ray_direction && out_features && out_density && out_hit_distance && out_hits_count, "grt_forward: null buffer");
+    if (h->N == 0) return GRUT_OK;  // outputs keep their (zero) initial values
+    GRUT_REQUIRE(particle_density && particle_sph && out_visibility, "grt_forward: null particle buffer");
+    GRUT_REQUIRE(!h->cfg.enable_normals || out_normals, "grt_forward: normals enabled but no buffer");
+    GrtTraceParams P = trace_params(h, *frame);
+    P.dbg_cap = dbg_cap;
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
+    grt_launch_trace_fwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
+                         out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count);
+    GRUT_HIP(hipGetLastError());
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
+    return GRUT_OK;
 }
-int grt_timings(GrtHandle*, float*, float*, float*) { return grt_unsupported("grt_timings"); }
-int grt_stats(GrtHandle*, GrtStats*) { return grt_unsupported("grt_stats"); }
+
+int grt_forward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
+                const float* ray_origin, const float* ray_direction, float* out_features, float* out_density, float* out_hit_distance,
+                float* out_normals, float* out_hits_count, int32_t* out_visibility) {
+    return grt_forward_impl(h, reinterpret_cast<hipStream_t>(stream_), frame, particle_density, particle_sph, ray_origin, ray_direction,
+                            out_features, out_density, out_hit_distance, out_normals, out_hits_count, out_visibility, nullptr, nullptr, 0);
 }
+
+int grt_debug_forward_hits(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
+                           const float* ray_origin, const float* ray_direction, float* out_features, float* out_density,
+                           float* out_hit_distance, float* out_normals, float* out_hits_count, int32_t* out_visibility,
+                           uint32_t* hit_ids, uint32_t* hit_counts, uint32_t capacity) {
+    GRUT_REQUIRE(hit_ids && hit_counts && capacity > 0, "grt_debug_forward_hits: null hit buffers");
+    return grt_forward_impl(h, reinterpret_cast<hipStream_t>(stream_), frame, particle_density, particle_sph, ray_origin, ray_direction,
+                            out_features, out_density, out_hit_distance, out_normals, out_hits_count, out_visibility, hit_ids, hit_counts,
+                            capacity);
+}
+
+int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
+                 const float* ray_origin, const float* ray_direction, const float* features, const float* density, const float* hit_distance,
+                 const float* normals, const float* grad_features, const float* grad_density, const float* grad_hit_distance,
+                 const float* grad_normals, float* grad_particle_density, float* grad_particle_sph) {
+    (void)normals;
+    (void)grad_normals;  // the reference's backward does not propagate the normal gradient either (referenceBwdOptix.cu:103-170)
+    GRUT_REQUIRE(h && frame, "grt_backward: null handle/frame");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (!h->built) {
+        set_last_error("grt_backward: build_bvh has not been called");
+        return GRUT_ERR_NOT_READY;
+    }
+    GRUT_REQUIRE(frame->num_particles == h->N, "grt_backward: %u particles but the BVH holds %u", frame->num_particles, h->N);
+    if (h->N == 0) return GRUT_OK;
+    GRUT_REQUIRE(particle_density && particle_sph && ray_origin && ray_direction && features && density && hit_distance && grad_features &&
+                     grad_density && grad_particle_density && grad_particle_sph, "grt_backward: null buffer");
+    const GrtTraceParams P = trace_params(h, *frame);
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
+    grt_launch_trace_bwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, features, density, hit_distance,
+                         grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph);
+    GRUT_HIP(hipGetLastError());
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
+    return GRUT_OK;
+}
+
+int grt_timings(GrtHandle* h, float* forward_ms, float* backward_ms, float* build_ms) {
+    GRUT_REQUIRE(h, "grt_timings: null handle");
+    if (forward_ms) *forward_ms = h->fwd_timer.collect();
+    if (backward_ms) *backward_ms = h->bwd_timer.collect();
+    if (build_ms) *build_ms = h->build_timer.collect();
+    return GRUT_OK;
+}
+
+int grt_stats(GrtHandle* h, GrtStats* stats) {
+    GRUT_REQUIRE(h && stats, "grt_stats: null argument");
+    memset(stats, 0, sizeof(*stats));
+    stats->num_particles = h->N;
+    stats->num_nodes = h->N > 1 ? h->N - 1 : (h->N ? 1 : 0);
+    if (h->built && h->N > 0) {
+        if (!h->scene_host_valid) {  // synchronises with the build stream
+            GRUT_HIP(hipMemcpyAsync(h->scene_host, h->scene.ptr, 24, hipMemcpyDeviceToHost, h->build_stream));
+            GRUT_HIP(hipStreamSynchronize(h->build_stream));
+            h->scene_host_valid = true;
+        }
+        for (int k = 0; k < 6; ++k) stats->scene_aabb[k] = h->scene_host[k];
+    }
+    return GRUT_OK;
+}
+
+// copies the proxy instance records (inverse maps {W rows, mu}, [N,12]) of the last build to a caller DEVICE buffer
+int grt_debug_fetch_instances(GrtHandle* h, void* stream_, float* instances) {
+    GRUT_REQUIRE(h && h->built && instances, "grt_debug_fetch_instances: no BVH / null buffer");
+    if (h->N) GRUT_HIP(hipMemcpyAsync(instances, h->inst.ptr, (size_t)h->N * 48, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream_)));
+    return GRUT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// grt_internal.hpp — types shared by grt_kernels.hip (device) and grt_api.hip (host orchestration) of the 3DGRT path.
+#pragma once
+
+#include "common.hpp"
+
+namespace grut {
+
+// Binary BVH node, 64 bytes: the boxes of BOTH children live in the parent, so one 64-byte fetch serves two box tests.
+// child code: bit 31 set -> leaf, low bits = particle index; kGrtNoChild = empty slot (only in a one-particle tree).
+// slack = sqrt(2) * (largest proxy half axis below the child): lower bound of a candidate's hit distance is
+// (box entry distance - slack), see DESIGN.md "3DGRT traversal".
+struct GrtNode {
+    float lo0[3]; uint32_t c0;
+    float hi0[3]; float slack0;
+    float lo1[3]; uint32_t c1;
+    float hi1[3]; float slack1;
+};
+static_assert(sizeof(GrtNode) == 64, "GrtNode must be 64 bytes");
+constexpr uint32_t kGrtLeafBit = 0x80000000u;
+constexpr uint32_t kGrtNoChild = 0xFFFFFFFFu;
+constexpr int kGrtMaxHits = 16;       // PipelineParameters::MaxNumHitPerTrace (pipelineParameters.h:83)
+constexpr int kGrtStackDepth = 64;    // a radix tree over 30+32-bit keys is at most 62 levels deep
+
+struct GrtBuildParams {
+    uint32_t N;
+    int degree, clamping;
+    float min_response;
+};
+
+struct GrtBvh {
+    const GrtNode* nodes;    // [max(N-1, 1)] internal nodes, root = 0
+    const float* inst;       // [N,12] inverse instance map {W rows, mu}: o' = W (o - mu), d' = W d
+    const float* scene;      // [6] scene AABB
+    uint32_t N;
+};
+
+struct GrtTraceParams {
+    int degree, sph_degree, ncoef, normals, hitcounts;
+    float min_response, min_alpha, max_alpha, min_transmittance;
+    int W, H;
+    float ray_to_world[12];
+    uint32_t dbg_cap;
+};
+
+// build stages
+void grt_launch_proxies(hipStream_t s, const GrtBuildParams& P, const float* pos, const float* rot, const float* scl, const float* dns,
+                        float* inst, float* aabb, float* slack, uint32_t* scene_enc);
+void grt_launch_morton(hipStream_t s, uint32_t N, const float* aabb, const uint32_t* scene_enc, float* scene, uint32_t* codes, uint32_t* ids);
+void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_codes, GrtNode* nodes, uint32_t* parent_internal,
+                          uint32_t* parent_leaf);
+void grt_launch_refit(hipStream_t s, uint32_t N, const uint32_t* sorted_ids, const float* aabb, const float* slack,
+                      const uint32_t* parent_internal, const uint32_t* parent_leaf, GrtNode* nodes, uint32_t* counters);
+// trace
+void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
+                          const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
+                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count);
+void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
+                          const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
+                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph);
+
+}  // namespace grut

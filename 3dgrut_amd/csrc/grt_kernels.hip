@@ -1,0 +1,706 @@
+// grt_kernels.hip — 3DGRT device code for gfx950: Gaussian proxy instances, LBVH build, and a software stack-based
+// BVH traversal that gathers per-ray ordered hit lists, composites them and differentiates them.
+//
+// Reference behaviour restated (not translated): threedgrt_tracer/src/particlePrimitives.cu:27-51, 543-610 (proxy
+// instances), src/optixTracer.cpp:616-890 (acceleration structure build; OptiX + RT cores there, an LBVH here),
+// src/kernels/cuda/referenceOptix.cu:45-248 (k = 16 nearest-hit rounds, any-hit insertion sort),
+// referenceBwdOptix.cu:103-170, include/3dgrt/kernels/cuda/gaussianParticles.cuh:337-731 (per-hit math).
+//
+// CDNA4 design (no RT cores):
+//   * LBVH: 30-bit Morton codes of the proxy centres, the stable radix sort shared with the 3DGUT path (ties broken by
+//     particle index), Karras' radix-tree construction, bottom-up refit with agent-scope acquire/release counters.
+//     Nodes are 64 B and carry BOTH children's boxes, so each dependent fetch serves two slab tests.
+//   * One lane per ray, one wave64 per 8x8 pixel block (coherent rays share node fetches through L1/L2); the per-lane
+//     traversal stack lives in LDS ([depth][lane], conflict-free); the 16-entry (distance, particle) buffer of a trace
+//     round lives in registers and is kept sorted by an unrolled compare-exchange chain, lexicographic in
+//     (distance, particle index) so that the hit order does not depend on traversal order.
+//   * A candidate's hit distance t (closest approach in the proxy's scaled frame) can precede the entry of the ray
+//     into the proxy's box by at most sqrt(2) * (largest proxy half axis); nodes store that slack, and a subtree is
+//     pruned only when (box entry - slack) exceeds the current 16th-nearest distance.
+#include "grt_internal.hpp"
+
+namespace grut {
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// proxies
+// ---------------------------------------------------------------------------------------------
+// particlePrimitives.cu:27-51 kernelScale
+__device__ __forceinline__ float kernel_scale(float density, float min_response, int clamping, float degree) {
+    const float modulation = clamping ? density : 1.0f;
+    const float mr = fminf(min_response / modulation, 0.97f);
+    if (degree < 0.f) {
+        const float k = fabsf(degree);
+        const float s = 1.0f / powf(3.0f, k);
+        return powf((1.f / (logf(mr) - 1.f) + 1.f) / s, 1.f / k);
+    }
+    if (degree == 0.f) return ((1.0f - mr) / 3.0f) / -0.329630334487f;
+    const float a = -4.5f / powf(3.0f, degree);
+    return powf(logf(mr) / a, 1.0f / degree);
+}
+
+__device__ __forceinline__ uint32_t enc_ordered(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_ordered(uint32_t e) {
+    return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e);
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// computeGaussianEnclosingInstancesKernel (particlePrimitives.cu:543-610), emitted as the inverse instance map
+__global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const float* __restrict__ pos, const float* __restrict__ rot,
+                                                        const float* __restrict__ scl, const float* __restrict__ dns,
+                                                        float* __restrict__ inst, float* __restrict__ aabb, float* __restrict__ slack,
+                                                        uint32_t* __restrict__ scene_enc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (i < P.N) {
+        const m3 rt = quat_wxyz_to_rotT(rot[4 * (size_t)i], rot[4 * (size_t)i + 1], rot[4 * (size_t)i + 2], rot[4 * (size_t)i + 3]);
+        const float ks = kernel_scale(dns[i], P.min_response, P.clamping, (float)P.degree);
+        const float k0 = ks * scl[3 * (size_t)i], k1 = ks * scl[3 * (size_t)i + 1], k2 = ks * scl[3 * (size_t)i + 2];
+        const float cx = pos[3 * (size_t)i], cy = pos[3 * (size_t)i + 1], cz = pos[3 * (size_t)i + 2];
+        float* o = inst + 12 * (size_t)i;
+        o[0] = rt.r0.x / k0; o[1] = rt.r0.y / k0; o[2] = rt.r0.z / k0;
+        o[3] = rt.r1.x / k1; o[4] = rt.r1.y / k1; o[5] = rt.r1.z / k1;
+        o[6] = rt.r2.x / k2; o[7] = rt.r2.y / k2; o[8] = rt.r2.z / k2;
+        o[9] = cx; o[10] = cy; o[11] = cz;
+        // world half extents of the oriented box, padded by a hair so that rounding can never make the ray miss the
+        // AABB of a box it touches (culling must stay conservative; candidates are decided in the proxy's own frame)
+        float hx = fabsf(rt.r0.x) * k0 + fabsf(rt.r1.x) * k1 + fabsf(rt.r2.x) * k2;
+        float hy = fabsf(rt.r0.y) * k0 + fabsf(rt.r1.y) * k1 + fabsf(rt.r2.y) * k2;
+        float hz = fabsf(rt.r0.z) * k0 + fabsf(rt.r1.z) * k1 + fabsf(rt.r2.z) * k2;
+        hx += 1e-4f * hx + 1e-6f * (fabsf(cx) + 1.f); hy += 1e-4f * hy + 1e-6f * (fabsf(cy) + 1.f); hz += 1e-4f * hz + 1e-6f * (fabsf(cz) + 1.f);
+        lo[0] = cx - hx; lo[1] = cy - hy; lo[2] = cz - hz; hi[0] = cx + hx; hi[1] = cy + hy; hi[2] = cz + hz;
+        float* b = aabb + 6 * (size_t)i;
+        b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+        slack[i] = 1.41421356237f * 1.0001f * fmaxf(k0, fmaxf(k1, k2));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float mn = wave_min(lo[k]), mx = wave_max(hi[k]);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&scene_enc[k], enc_ordered(mn));
+            atomicMax(&scene_enc[3 + k], enc_ordered(mx));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__global__ __launch_bounds__(256) void grt_morton_kernel(uint32_t N, const float* __restrict__ aabb, const uint32_t* __restrict__ scene_enc,
+                                                         float* __restrict__ scene, uint32_t* __restrict__ codes, uint32_t* __restrict__ ids) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float s[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] = dec_ordered(scene_enc[k]);
+    if (i == 0)
+        for (int k = 0; k < 6; ++k) scene[k] = s[k];
+    if (i >= N || !codes) return;  // codes == nullptr: refit-only update, just publish the scene box
+    const float* b = aabb + 6 * (size_t)i;
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float c = 0.5f * (b[k] + b[3 + k]);
+        const float ext = fmaxf(s[3 + k] - s[k], 1e-30f);
+        const float u = fminf(fmaxf((c - s[k]) / ext, 0.f), 1.f);
+        q[k] = min((uint32_t)(u * 1024.f), 1023u);
+    }
+    codes[i] = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+    ids[i] = i;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hierarchy: Karras 2012 radix tree over the sorted (code, position) keys
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int delta_fn(const uint32_t* __restrict__ codes, int N, int i, int j) {
+    if (j < 0 || j >= N) return -1;
+    const uint32_t a = codes[i], b = codes[j];
+    if (a == b) return 32 + __clz((uint32_t)(i ^ j));
+    return __clz(a ^ b);
+}
+__global__ __launch_bounds__(256) void grt_hierarchy_kernel(uint32_t Nu, const uint32_t* __restrict__ codes, GrtNode* __restrict__ nodes,
+                                                            uint32_t* __restrict__ parent_internal, uint32_t* __restrict__ parent_leaf) {
+    const int N = (int)Nu;
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= N - 1) return;
+    const int d = (delta_fn(codes, N, i, i + 1) - delta_fn(codes, N, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta_fn(codes, N, i, i - d);
+    int lmax = 2;
+    while (delta_fn(codes, N, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta_fn(codes, N, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta_fn(codes, N, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (delta_fn(codes, N, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const bool left_leaf = min(i, j) == gamma, right_leaf = max(i, j) == gamma + 1;
+    if (left_leaf) parent_leaf[gamma] = (uint32_t)i;
+    else { parent_internal[gamma] = (uint32_t)i; nodes[i].c0 = (uint32_t)gamma; }
+    if (right_leaf) parent_leaf[gamma + 1] = (uint32_t)i | 0x80000000u;
+    else { parent_internal[gamma + 1] = (uint32_t)i | 0x80000000u; nodes[i].c1 = (uint32_t)(gamma + 1); }
+}
+
+__device__ __forceinline__ void write_child(GrtNode* __restrict__ node, uint32_t side, const float lo[3], const float hi[3], float slack) {
+    float* base = reinterpret_cast<float*>(node) + (side ? 8 : 0);
+    base[0] = lo[0]; base[1] = lo[1]; base[2] = lo[2];
+    base[4] = hi[0]; base[5] = hi[1]; base[6] = hi[2]; base[7] = slack;
+}
+// bottom-up refit: the second thread to arrive at a node owns it (both child slots are then complete)
+__global__ __launch_bounds__(256) void grt_refit_kernel(uint32_t N, const uint32_t* __restrict__ sorted_ids, const float* __restrict__ aabb,
+                                                        const float* __restrict__ slack, const uint32_t* __restrict__ parent_internal,
+                                                        const uint32_t* __restrict__ parent_leaf, GrtNode* nodes, uint32_t* counters) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= N) return;
+    const uint32_t id = sorted_ids[j];
+    float lo[3], hi[3];
+    const float* b = aabb + 6 * (size_t)id;
+    lo[0] = b[0]; lo[1] = b[1]; lo[2] = b[2]; hi[0] = b[3]; hi[1] = b[4]; hi[2] = b[5];
+    float sl = slack[id];
+    if (N == 1) {  // single particle: the root has one leaf and one empty slot
+        write_child(&nodes[0], 0, lo, hi, sl);
+        nodes[0].c0 = kGrtLeafBit | id;
+        const float elo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ehi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        write_child(&nodes[0], 1, elo, ehi, 0.f);
+        nodes[0].c1 = kGrtNoChild;
+        return;
+    }
+    uint32_t p = parent_leaf[j];
+    uint32_t node = p & 0x7FFFFFFFu, side = p >> 31;
+    write_child(&nodes[node], side, lo, hi, sl);
+    if (side) nodes[node].c1 = kGrtLeafBit | id;
+    else nodes[node].c0 = kGrtLeafBit | id;
+    while (true) {
+        // release our child slot, acquire the sibling's (agent scope: the two threads may sit on different XCDs)
+        const uint32_t old = __hip_atomic_fetch_add(&counters[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 0) return;
+        float* other = reinterpret_cast<float*>(&nodes[node]) + (side ? 0 : 8);
+        const float o0 = __hip_atomic_load(other + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float o1 = __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float o2 = __hip_atomic_load(other + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float o4 = __hip_atomic_load(other + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float o5 = __hip_atomic_load(other + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float o6 = __hip_atomic_load(other + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float o7 = __hip_atomic_load(other + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lo[0] = fminf(lo[0], o0); lo[1] = fminf(lo[1], o1); lo[2] = fminf(lo[2], o2);
+        hi[0] = fmaxf(hi[0], o4); hi[1] = fmaxf(hi[1], o5); hi[2] = fmaxf(hi[2], o6);
+        sl = fmaxf(sl, o7);
+        p = parent_internal[node];
+        if (p == 0xFFFFFFFFu) return;  // root finished
+        node = p & 0x7FFFFFFFu;
+        side = p >> 31;
+        write_child(&nodes[node], side, lo, hi, sl);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-ray machinery
+// ---------------------------------------------------------------------------------------------
+struct RayW {
+    f3 o, d, inv;
+};
+__device__ __forceinline__ float safe_rcp(float v) {
+    return fabsf(v) > 1e-30f ? 1.0f / v : copysignf(1.0e30f, v);
+}
+__device__ __forceinline__ RayW make_ray(const GrtTraceParams& P, const float* __restrict__ ray_o, const float* __restrict__ ray_d, size_t pix) {
+    const f3 so = mk3(ray_o[3 * pix], ray_o[3 * pix + 1], ray_o[3 * pix + 2]);
+    const f3 sd = mk3(ray_d[3 * pix], ray_d[3 * pix + 1], ray_d[3 * pix + 2]);
+    const float* m = P.ray_to_world;
+    RayW r;
+    // pipelineParameters.h:97-117 (no contraction: the oracle's candidate test starts from the same world-space ray)
+    {
+#pragma clang fp contract(off)
+        r.o = mk3(m[0] * so.x + m[1] * so.y + m[2] * so.z + m[3], m[4] * so.x + m[5] * so.y + m[6] * so.z + m[7],
+                  m[8] * so.x + m[9] * so.y + m[10] * so.z + m[11]);
+        r.d = mk3(m[0] * sd.x + m[1] * sd.y + m[2] * sd.z, m[4] * sd.x + m[5] * sd.y + m[6] * sd.z, m[8] * sd.x + m[9] * sd.y + m[10] * sd.z);
+    }
+    r.inv = mk3(safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z));
+    return r;
+}
+// referenceOptix.cu:33-39 intersectAABB
+__device__ __forceinline__ void scene_interval(const float* __restrict__ s, const RayW& r, float& tmin, float& tmax) {
+#pragma clang fp contract(off)
+    const float t0x = (s[0] - r.o.x) / r.d.x, t0y = (s[1] - r.o.y) / r.d.y, t0z = (s[2] - r.o.z) / r.d.z;
+    const float t1x = (s[3] - r.o.x) / r.d.x, t1y = (s[4] - r.o.y) / r.d.y, t1z = (s[5] - r.o.z) / r.d.z;
+    tmin = fmaxf(0.f, fmaxf(fminf(t0x, t1x), fmaxf(fminf(t0y, t1y), fminf(t0z, t1z))));
+    tmax = fminf(fmaxf(t0x, t1x), fminf(fmaxf(t0y, t1y), fmaxf(t0z, t1z)));
+}
+
+// candidate test in the proxy's frame — written with explicit operation order and no FP contraction, so that the CPU
+// checker (tests) can evaluate bit-identical distances and the per-ray hit ORDER can be compared exactly
+struct Cand {
+    float t, tnear, tfar;
+    bool ok;
+};
+__device__ __forceinline__ Cand candidate(const float* __restrict__ inst, const RayW& r) {
+#pragma clang fp contract(off)
+    Cand c;
+    c.ok = false; c.t = 0.f; c.tnear = 0.f; c.tfar = 0.f;
+    const float4 a = reinterpret_cast<const float4*>(inst)[0], b = reinterpret_cast<const float4*>(inst)[1], e = reinterpret_cast<const float4*>(inst)[2];
+    // inst = {W00 W01 W02 W10 | W11 W12 W20 W21 | W22 mux muy muz}
+    const float dlx = r.o.x - e.y, dly = r.o.y - e.z, dlz = r.o.z - e.w;
+    const float pox = a.x * dlx + a.y * dly + a.z * dlz, poy = a.w * dlx + b.x * dly + b.y * dlz, poz = b.z * dlx + b.w * dly + e.x * dlz;
+    const float pdx = a.x * r.d.x + a.y * r.d.y + a.z * r.d.z, pdy = a.w * r.d.x + b.x * r.d.y + b.y * r.d.z,
+                pdz = b.z * r.d.x + b.w * r.d.y + e.x * r.d.z;
+    const float ax0 = (-1.f - pox) / pdx, ax1 = (1.f - pox) / pdx;
+    const float ay0 = (-1.f - poy) / pdy, ay1 = (1.f - poy) / pdy;
+    const float az0 = (-1.f - poz) / pdz, az1 = (1.f - poz) / pdz;
+    // r_min / r_max of the oracle are plain comparisons (a < b ? a : b), NaN-propagating in the same way
+    auto mn = [](float x, float y) { return x < y ? x : y; };
+    auto mx = [](float x, float y) { return x > y ? x : y; };
+    const float tnear = mx(mx(mn(ax0, ax1), mn(ay0, ay1)), mn(az0, az1));
+    const float tfar = mn(mn(mx(ax0, ax1), mx(ay0, ay1)), mx(az0, az1));
+    if (!(tnear <= tfar)) return c;
+    c.tnear = tnear; c.tfar = tfar;
+    const float numerator = -(pox * pdx + poy * pdy + poz * pdz);
+    const float dd = pdx * pdx + pdy * pdy + pdz * pdz;
+    const float denominator = 1.f / dd;
+    c.t = numerator * denominator;
+    const float il = dd > 0.f ? 1.f / sqrtf(dd) : 1.f;
+    const float nx = pdx * il, ny = pdy * il, nz = pdz * il;
+    const float crx = ny * poz - nz * poy, cry = nz * pox - nx * poz, crz = nx * poy - ny * pox;
+    c.ok = ((crx * crx + cry * cry + crz * crz) * denominator < 9.0f);  // hitMaxParticleSquaredDistance, pipelineParameters.h:71
+    return c;
+}
+
+__device__ __forceinline__ bool hit_less(float t, uint32_t id, float bt, uint32_t bi) { return (t < bt) || (t == bt && id < bi); }
+
+struct HitBuffer {
+    float t[kGrtMaxHits];
+    uint32_t id[kGrtMaxHits];
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int k = 0; k < kGrtMaxHits; ++k) { t[k] = 3.0e38f; id[k] = 0xFFFFFFFFu; }
+    }
+    // compare-exchange chain of __anyhit__ah (referenceOptix.cu:210-246), lexicographic in (distance, particle)
+    __device__ __forceinline__ void insert(float ht, uint32_t hid) {
+#pragma unroll
+        for (int k = 0; k < kGrtMaxHits; ++k) {
+            const bool lt = hit_less(ht, hid, t[k], id[k]);
+            const float tt = lt ? t[k] : ht;
+            const uint32_t ii = lt ? id[k] : hid;
+            t[k] = lt ? ht : t[k];
+            id[k] = lt ? hid : id[k];
+            ht = tt; hid = ii;
+        }
+    }
+};
+
+// slab test of a child's world box; returns entry/exit distances
+__device__ __forceinline__ bool box_hit(const float* __restrict__ lo, const float* __restrict__ hi, const RayW& r, float& tn, float& tf) {
+    const float x0 = (lo[0] - r.o.x) * r.inv.x, x1 = (hi[0] - r.o.x) * r.inv.x;
+    const float y0 = (lo[1] - r.o.y) * r.inv.y, y1 = (hi[1] - r.o.y) * r.inv.y;
+    const float z0 = (lo[2] - r.o.z) * r.inv.z, z1 = (hi[2] - r.o.z) * r.inv.z;
+    tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+    tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+    return tn <= tf * 1.0000004f + 1e-30f;
+}
+
+// one optixTrace: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in (t, particle)
+__device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, float tmin, float tmax, uint32_t* __restrict__ stack /* [depth*64 + lane] */,
+                                            HitBuffer& buf) {
+    buf.clear();
+    int sp = 0;
+    uint32_t cur = 0;  // root
+    bool have = true;
+    while (true) {
+        if (!have) {
+            if (sp == 0) break;
+            cur = stack[(--sp) * 64];
+        }
+        have = false;
+        const float4* nq = reinterpret_cast<const float4*>(&bvh.nodes[cur]);
+        const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+        const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q1.x, q1.y, q1.z}, lo1[3] = {q2.x, q2.y, q2.z}, hi1[3] = {q3.x, q3.y, q3.z};
+        const uint32_t c0 = __float_as_uint(q0.w), c1 = __float_as_uint(q2.w);
+        float tn0, tf0, tn1, tf1;
+        const float bound = fminf(tmax, buf.t[kGrtMaxHits - 1]);
+        bool h0 = (c0 != kGrtNoChild) && box_hit(lo0, hi0, r, tn0, tf0) && (tf0 >= tmin) && (tn0 <= tmax) && (tn0 - q1.w <= bound);
+        bool h1 = (c1 != kGrtNoChild) && box_hit(lo1, hi1, r, tn1, tf1) && (tf1 >= tmin) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
+        // leaves are tested on the spot
+        if (h0 && (c0 & kGrtLeafBit)) {
+            const uint32_t id = c0 & ~kGrtLeafBit;
+            const Cand c = candidate(bvh.inst + 12 * (size_t)id, r);
+            if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
+                hit_less(c.t, id, buf.t[kGrtMaxHits - 1], buf.id[kGrtMaxHits - 1]))
+                buf.insert(c.t, id);
+            h0 = false;
+        }
+        if (h1 && (c1 & kGrtLeafBit)) {
+            const uint32_t id = c1 & ~kGrtLeafBit;
+            const Cand c = candidate(bvh.inst + 12 * (size_t)id, r);
+            if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
+                hit_less(c.t, id, buf.t[kGrtMaxHits - 1], buf.id[kGrtMaxHits - 1]))
+                buf.insert(c.t, id);
+            h1 = false;
+        }
+        if (h0 && h1) {  // descend into the nearer child, keep the farther one
+            const bool first0 = tn0 <= tn1;
+            stack[(sp++) * 64] = first0 ? c1 : c0;
+            cur = first0 ? c0 : c1;
+            have = true;
+        } else if (h0 || h1) {
+            cur = h0 ? c0 : c1;
+            have = true;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-hit math (gaussianParticles.cuh:337-405, :468-731): scalar per ray, SH evaluated along the ray
+// ---------------------------------------------------------------------------------------------
+struct Particle {
+    f3 pos, scl;
+    float4 quat;
+    m3 rotT;
+    float density;
+};
+__device__ __forceinline__ Particle load_particle(const float4* __restrict__ density12, uint32_t id) {
+    const float4 a = density12[3 * (size_t)id], q = density12[3 * (size_t)id + 1], s = density12[3 * (size_t)id + 2];
+    Particle p;
+    p.pos = mk3(a.x, a.y, a.z); p.density = a.w; p.quat = q; p.scl = mk3(s.x, s.y, s.z);
+    p.rotT = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
+    return p;
+}
+__device__ __forceinline__ void sh_basis16(int deg, f3 d, float b[16]) {
+    const float x = d.x, y = d.y, z = d.z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = 0.f;
+    b[0] = 0.28209479177387814f;
+    if (deg > 0) {
+        const float c1 = 0.4886025119029199f;
+        b[1] = -c1 * y; b[2] = c1 * z; b[3] = -c1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = 1.0925484305920792f * xy; b[5] = -1.0925484305920792f * yz; b[6] = 0.31539156525252005f * (2.f * zz - xx - yy);
+            b[7] = -1.0925484305920792f * xz; b[8] = 0.5462742152960396f * (xx - yy);
+            if (deg > 2) {
+                b[9] = -0.5900435899266435f * y * (3.f * xx - yy);
+                b[10] = 2.890611442640554f * xy * z;
+                b[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
+                b[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                b[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
+                b[14] = 1.445305721320277f * z * (xx - yy);
+                b[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+// unclamped radiance along direction d
+__device__ __forceinline__ f3 sh_radiance(const GrtTraceParams& P, const float* __restrict__ sph, uint32_t id, const float b[16]) {
+    const float* c = sph + (size_t)id * 3 * P.ncoef;
+    const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
+    f3 rad = mk3(0.f, 0.f, 0.f);
+    for (int k = 0; k < nact; ++k) {
+        rad.x = fmaf(b[k], c[3 * k], rad.x); rad.y = fmaf(b[k], c[3 * k + 1], rad.y); rad.z = fmaf(b[k], c[3 * k + 2], rad.z);
+    }
+    return rad + mk3(0.5f, 0.5f, 0.5f);
+}
+
+struct HitGeom {
+    f3 gposc, gposcr, gro, rdr, grdu, grd, gcrod, giscl;
+    float gray, gres, galpha;
+    bool accept;
+};
+template <int DEG>
+__device__ __forceinline__ HitGeom hit_geometry(const GrtTraceParams& P, const Particle& p, const RayW& r) {
+    HitGeom g;
+    g.giscl = mk3(1.f / p.scl.x, 1.f / p.scl.y, 1.f / p.scl.z);
+    g.gposc = r.o - p.pos;
+    g.gposcr = mul_rows(p.rotT, g.gposc);
+    g.gro = g.giscl * g.gposcr;
+    g.rdr = mul_rows(p.rotT, r.d);
+    g.grdu = g.giscl * g.rdr;
+    const float l2 = dot(g.grdu, g.grdu);
+    g.grd = l2 > 0.f ? g.grdu * (1.f / sqrtf(l2)) : g.grdu;
+    g.gcrod = cross(g.grd, g.gro);
+    g.gray = dot(g.gcrod, g.gcrod);
+    g.gres = particle_response<DEG>(g.gray);
+    g.galpha = fminf(P.max_alpha, g.gres * p.density);
+    g.accept = (g.gres > P.min_response) && (g.galpha > P.min_alpha);
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: __raygen__rg of referenceOptix.cu:103-186
+// ---------------------------------------------------------------------------------------------
+template <int DEG>
+__global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
+                                                           const float* __restrict__ sph, const float* __restrict__ ray_o,
+                                                           const float* __restrict__ ray_d, float* __restrict__ out_rad,
+                                                           float* __restrict__ out_dns, float* __restrict__ out_hit2,
+                                                           float* __restrict__ out_nrm, float* __restrict__ out_cnt,
+                                                           int32_t* __restrict__ visibility, uint32_t* __restrict__ dbg_ids,
+                                                           uint32_t* __restrict__ dbg_count) {
+    __shared__ uint32_t s_stack[kGrtStackDepth * 64];
+    const int lane = threadIdx.x;
+    const int px = (int)blockIdx.x * 8 + (lane & 7), py = (int)blockIdx.y * 8 + (lane >> 3);
+    if (px >= P.W || py >= P.H) return;
+    const size_t pix = (size_t)py * P.W + px;
+    const RayW r = make_ray(P, ray_o, ray_d, pix);
+    float basis[16];
+    sh_basis16(P.sph_degree, r.d, basis);
+
+    f3 rad = mk3(0.f, 0.f, 0.f), nrm = mk3(0.f, 0.f, 0.f);
+    float T = 1.f, depth = 0.f, cnt = 0.f;
+    float tEnter, tExit;
+    scene_interval(bvh.scene, r, tEnter, tExit);
+    constexpr float eps = 1e-9f;
+    float tLast = fmaxf(0.f, tEnter - eps);
+    uint32_t ndbg = 0;
+    HitBuffer buf;
+    while ((tLast <= tExit) && (T > P.min_transmittance)) {
+        trace_round(bvh, r, tLast + eps, tExit + eps, s_stack + lane, buf);
+        if (buf.id[0] == 0xFFFFFFFFu) break;
+#pragma unroll
+        for (int i = 0; i < kGrtMaxHits; ++i) {
+            const uint32_t id = buf.id[i];
+            if ((id != 0xFFFFFFFFu) && (T > P.min_transmittance)) {
+                const Particle p = load_particle(density12, id);
+                const HitGeom g = hit_geometry<DEG>(P, p, r);
+                if (g.accept) {
+                    const float weight = g.galpha * T;
+                    const float pdot = -dot(g.grd, g.gro);
+                    const f3 grds = p.scl * g.grd * pdot;
+                    const float hitT = sqrtf(dot(grds, grds));
+                    const f3 u = sh_radiance(P, sph, id, basis);
+                    const f3 c = mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f));
+                    rad = rad + c * weight;
+                    T *= (1.f - g.galpha);
+                    depth = fmaf(hitT, weight, depth);
+                    if (P.normals) {  // gaussianParticles.cuh:398-402
+                        const f3 psr = mul_cols(p.rotT, p.scl);
+                        const f3 q = (g.gro + g.grd * (pdot - sqrtf(9.f - g.gray))) * psr;
+                        const float l2 = dot(q, q);
+                        const f3 n = l2 > 0.f ? q * (1.f / sqrtf(l2)) : q;
+                        nrm = nrm + n * weight;
+                    }
+                    visibility[id] = 1;  // benign race: every writer stores the same value (referenceOptix.cu:158-161)
+                    cnt += 1.f;
+                }
+                tLast = fmaxf(tLast, buf.t[i]);
+                if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = id;
+                ndbg++;
+            }
+        }
+    }
+    out_rad[3 * pix] = rad.x; out_rad[3 * pix + 1] = rad.y; out_rad[3 * pix + 2] = rad.z;
+    out_dns[pix] = 1.f - T;
+    out_hit2[2 * pix] = depth; out_hit2[2 * pix + 1] = tLast;
+    if (P.normals) { out_nrm[3 * pix] = nrm.x; out_nrm[3 * pix + 1] = nrm.y; out_nrm[3 * pix + 2] = nrm.z; }
+    if (P.hitcounts) out_cnt[pix] = cnt;
+    if (dbg_count) dbg_count[pix] = ndbg;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward: __raygen__rg of referenceBwdOptix.cu:103-170 + processHitBwd (gaussianParticles.cuh:468-731)
+// ---------------------------------------------------------------------------------------------
+// gradient of (p * rotT(q)) . g w.r.t. q (matmul_bw_quat, mathUtils.h)
+__device__ __forceinline__ float4 matmul_bw_quat(f3 p, f3 g, float4 q) {
+    const f3 d0 = p * g.x, d1 = p * g.y, d2 = p * g.z;
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    float dr = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+    dy += -4.f * y * d0.x; dz += -4.f * z * d0.x;
+    dr += 2.f * z * d0.y; dx += 2.f * y * d0.y; dy += 2.f * x * d0.y; dz += 2.f * r * d0.y;
+    dr += -2.f * y * d0.z; dx += 2.f * z * d0.z; dy += -2.f * r * d0.z; dz += 2.f * x * d0.z;
+    dr += -2.f * z * d1.x; dx += 2.f * y * d1.x; dy += 2.f * x * d1.x; dz += -2.f * r * d1.x;
+    dx += -4.f * x * d1.y; dz += -4.f * z * d1.y;
+    dr += 2.f * x * d1.z; dx += 2.f * r * d1.z; dy += 2.f * z * d1.z; dz += 2.f * y * d1.z;
+    dr += 2.f * y * d2.x; dx += 2.f * z * d2.x; dy += 2.f * r * d2.x; dz += 2.f * x * d2.x;
+    dr += -2.f * x * d2.y; dx += -2.f * r * d2.y; dy += 2.f * z * d2.y; dz += 2.f * y * d2.y;
+    dx += -4.f * x * d2.z; dy += -4.f * y * d2.z;
+    return make_float4(dr, dx, dy, dz);
+}
+
+template <int DEG>
+__global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
+                                                           const float* __restrict__ sph, const float* __restrict__ ray_o,
+                                                           const float* __restrict__ ray_d, const float* __restrict__ in_rad,
+                                                           const float* __restrict__ in_dns, const float* __restrict__ in_hit2,
+                                                           const float* __restrict__ g_rad, const float* __restrict__ g_dns,
+                                                           const float* __restrict__ g_hit, float* __restrict__ g_density12,
+                                                           float* __restrict__ g_sph) {
+    __shared__ uint32_t s_stack[kGrtStackDepth * 64];
+    const int lane = threadIdx.x;
+    const int px = (int)blockIdx.x * 8 + (lane & 7), py = (int)blockIdx.y * 8 + (lane >> 3);
+    if (px >= P.W || py >= P.H) return;
+    const size_t pix = (size_t)py * P.W + px;
+    const RayW r = make_ray(P, ray_o, ray_d, pix);
+    float basis[16];
+    sh_basis16(P.sph_degree, r.d, basis);
+    const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
+
+    const f3 rad_fin = mk3(in_rad[3 * pix], in_rad[3 * pix + 1], in_rad[3 * pix + 2]);
+    const float T_fin = 1.f - in_dns[pix], depth_fin = in_hit2[2 * pix], max_hit = in_hit2[2 * pix + 1];
+    const f3 rad_grad = mk3(g_rad[3 * pix], g_rad[3 * pix + 1], g_rad[3 * pix + 2]);
+    const float T_grad = -g_dns[pix], depth_grad = g_hit ? g_hit[pix] : 0.f;
+
+    f3 rad = mk3(0.f, 0.f, 0.f);
+    float T = 1.f, depth = 0.f;
+    float tEnter, tExit;
+    scene_interval(bvh.scene, r, tEnter, tExit);
+    constexpr float eps = 1e-9f;
+    float startT = fmaxf(0.f, tEnter - eps);
+    const float endT = fminf(max_hit, tExit) + eps;
+    HitBuffer buf;
+    while (startT < endT) {
+        trace_round(bvh, r, startT + eps, endT, s_stack + lane, buf);
+        if (buf.id[0] == 0xFFFFFFFFu) break;
+#pragma unroll
+        for (int i = 0; i < kGrtMaxHits; ++i) {
+            const uint32_t id = buf.id[i];
+            if (id == 0xFFFFFFFFu) continue;
+            const Particle p = load_particle(density12, id);
+            const HitGeom g = hit_geometry<DEG>(P, p, r);
+            if (g.accept) {
+                const f3 gscl = p.scl;
+                const float pdot = -dot(g.grd, g.gro);
+                const f3 grdd = g.grd * pdot;
+                const f3 grds = gscl * grdd;
+                const float gsq = dot(grds, grds);
+                const float gdist = sqrtf(gsq);
+                const float weight = g.galpha * T;
+                const float nextT = (1.f - g.galpha) * T;
+                depth = fmaf(weight, gdist, depth);
+                const float resHitT = fmaxf(nextT <= P.min_transmittance ? 0.f : (depth_fin - depth) / nextT, 0.f);
+                const float galphaRayHitGrd = (gdist - resHitT) * T * depth_grad;
+                const f3 grdsRayHitGrd = gsq > 0.f ? grds * ((2.f * weight) / (2.f * gdist) * depth_grad) : mk3(0.f, 0.f, 0.f);
+                const f3 gsclRayHitGrd = grdd * grdsRayHitGrd;
+                const float grdScaledDot = dot(grdsRayHitGrd * gscl, g.grd);
+                const f3 grdRayHitGrd = gscl * grdsRayHitGrd * pdot - g.gro * grdScaledDot;
+                const f3 groRayHitGrd = g.grd * (-grdScaledDot);
+                const float resTrm = g.galpha < 0.999999f ? T_fin / (1.f - g.galpha) : T;
+                const float galphaRayDnsGrd = resTrm * -T_grad;
+
+                // radianceFromSpHBwd (:101-177)
+                const f3 gradu = sh_radiance(P, sph, id, basis);
+                const f3 grad = mk3(fmaxf(gradu.x, 0.f), fmaxf(gradu.y, 0.f), fmaxf(gradu.z, 0.f));
+                f3 dL = rad_grad * weight;
+                if (!(gradu.x > 0.f)) dL.x = 0.f;
+                if (!(gradu.y > 0.f)) dL.y = 0.f;
+                if (!(gradu.z > 0.f)) dL.z = 0.f;
+                float* gs = g_sph + (size_t)id * 3 * P.ncoef;
+                for (int k = 0; k < nact; ++k) {
+                    atomicAdd(gs + 3 * k, basis[k] * dL.x);
+                    atomicAdd(gs + 3 * k + 1, basis[k] * dL.y);
+                    atomicAdd(gs + 3 * k + 2, basis[k] * dL.z);
+                }
+                rad = rad + grad * weight;
+                f3 resRad = mk3(0.f, 0.f, 0.f);
+                if (!(nextT <= P.min_transmittance)) {
+                    const float inT = 1.f / nextT;
+                    resRad = mk3(fmaxf((rad_fin.x - rad.x) * inT, 0.f), fmaxf((rad_fin.y - rad.y) * inT, 0.f), fmaxf((rad_fin.z - rad.z) * inT, 0.f));
+                }
+                const float common = galphaRayHitGrd + galphaRayDnsGrd + T * (grad.x - resRad.x) * rad_grad.x + T * (grad.y - resRad.y) * rad_grad.y +
+                                     T * (grad.z - resRad.z) * rad_grad.z;
+                float* gd = g_density12 + 12 * (size_t)id;
+                atomicAdd(gd + 3, g.gres * common);
+                const float gresGrd = p.density * common;
+                const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, gresGrd);
+                const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
+                const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x,
+                                      gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
+                const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z,
+                                      gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
+                const f3 groTot = groGrd + groRayHitGrd;
+                const f3 is2 = g.giscl * g.giscl;
+                const f3 gsclGrdGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;
+                const f3 gposcrGrd = g.giscl * groTot;
+                const f3 gposcGrd = mul_cols(p.rotT, gposcrGrd);
+                const float4 grotGrdPoscr = matmul_bw_quat(g.gposc, gposcrGrd, p.quat);
+                atomicAdd(gd + 0, -gposcGrd.x); atomicAdd(gd + 1, -gposcGrd.y); atomicAdd(gd + 2, -gposcGrd.z);
+                // safe_normalize_bw
+                const f3 dn = grdGrd + grdRayHitGrd;
+                const float l2 = dot(g.grdu, g.grdu);
+                f3 grduGrd = mk3(0.f, 0.f, 0.f);
+                if (l2 > 0.f) {
+                    const float il = 1.f / sqrtf(l2), il3 = il * il * il;
+                    const float sdot = dot(dn, g.grdu);
+                    grduGrd = dn * il - g.grdu * (il3 * sdot);
+                }
+                atomicAdd(gd + 8, gsclRayHitGrd.x + gsclGrdGro.x + (-g.rdr.x * is2.x) * grduGrd.x);
+                atomicAdd(gd + 9, gsclRayHitGrd.y + gsclGrdGro.y + (-g.rdr.y * is2.y) * grduGrd.y);
+                atomicAdd(gd + 10, gsclRayHitGrd.z + gsclGrdGro.z + (-g.rdr.z * is2.z) * grduGrd.z);
+                const f3 rdrGrd = g.giscl * grduGrd;
+                const float4 grotGrdRd = matmul_bw_quat(r.d, rdrGrd, p.quat);
+                atomicAdd(gd + 4, grotGrdPoscr.x + grotGrdRd.x); atomicAdd(gd + 5, grotGrdPoscr.y + grotGrdRd.y);
+                atomicAdd(gd + 6, grotGrdPoscr.z + grotGrdRd.z); atomicAdd(gd + 7, grotGrdPoscr.w + grotGrdRd.w);
+                T = nextT;
+            }
+            startT = fmaxf(startT, buf.t[i]);
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+void grt_launch_proxies(hipStream_t s, const GrtBuildParams& P, const float* pos, const float* rot, const float* scl, const float* dns,
+                        float* inst, float* aabb, float* slack, uint32_t* scene_enc) {
+    hipLaunchKernelGGL(grt_proxy_kernel, dim3(div_up(P.N, 256)), dim3(256), 0, s, P, pos, rot, scl, dns, inst, aabb, slack, scene_enc);
+}
+void grt_launch_morton(hipStream_t s, uint32_t N, const float* aabb, const uint32_t* scene_enc, float* scene, uint32_t* codes, uint32_t* ids) {
+    hipLaunchKernelGGL(grt_morton_kernel, dim3(div_up(N, 256)), dim3(256), 0, s, N, aabb, scene_enc, scene, codes, ids);
+}
+void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_codes, GrtNode* nodes, uint32_t* parent_internal,
+                          uint32_t* parent_leaf) {
+    if (N > 1)
+        hipLaunchKernelGGL(grt_hierarchy_kernel, dim3(div_up(N - 1, 256)), dim3(256), 0, s, N, sorted_codes, nodes, parent_internal, parent_leaf);
+}
+void grt_launch_refit(hipStream_t s, uint32_t N, const uint32_t* sorted_ids, const float* aabb, const float* slack,
+                      const uint32_t* parent_internal, const uint32_t* parent_leaf, GrtNode* nodes, uint32_t* counters) {
+    hipLaunchKernelGGL(grt_refit_kernel, dim3(div_up(N, 256)), dim3(256), 0, s, N, sorted_ids, aabb, slack, parent_internal, parent_leaf, nodes,
+                       counters);
+}
+
+#define GRT_DISPATCH_DEGREE(DEG, ...)                          \
+    switch (DEG) {                                             \
+    case 0: { constexpr int D_ = 0; __VA_ARGS__; } break;      \
+    case 1: { constexpr int D_ = 1; __VA_ARGS__; } break;      \
+    case 2: { constexpr int D_ = 2; __VA_ARGS__; } break;      \
+    case 3: { constexpr int D_ = 3; __VA_ARGS__; } break;      \
+    case 5: { constexpr int D_ = 5; __VA_ARGS__; } break;      \
+    case 8: { constexpr int D_ = 8; __VA_ARGS__; } break;      \
+    default: { constexpr int D_ = 4; __VA_ARGS__; } break;     \
+    }
+
+void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
+                          const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
+                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count) {
+    const dim3 grid(div_up((uint32_t)P.W, 8), div_up((uint32_t)P.H, 8));
+    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_>), grid, dim3(64), 0, s, P, bvh,
+                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns, out_hit2,
+                                                     out_nrm, out_cnt, visibility, dbg_ids, dbg_count));
+}
+void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
+                          const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
+                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph) {
+    const dim3 grid(div_up((uint32_t)P.W, 8), div_up((uint32_t)P.H, 8));
+    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_>), grid, dim3(64), 0, s, P, bvh,
+                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns,
+                                                     g_hit, g_density12, g_sph));
+}
+
+}  // namespace grut

@@ -237,6 +237,17 @@ int grt_backward(GrtHandle* handle, void* stream, const GrtFrame* frame,
                  const float* grad_hit_distance, const float* grad_normals,
                  float* grad_particle_density, float* grad_particle_sph);
 
+/* grt_forward that also records, per ray, the particles it processed in order (the BVH hit-order parity test):
+ * hit_ids [H*W, capacity] u32, hit_counts [H*W] u32 (counts may exceed capacity; only the first `capacity` are stored) */
+int grt_debug_forward_hits(GrtHandle* handle, void* stream, const GrtFrame* frame,
+                           const float* particle_density, const float* particle_sph,
+                           const float* ray_origin, const float* ray_direction,
+                           float* out_features, float* out_density, float* out_hit_distance,
+                           float* out_normals, float* out_hits_count, int32_t* out_visibility,
+                           uint32_t* hit_ids, uint32_t* hit_counts, uint32_t capacity);
+/* proxy instance records of the last build: [N,12] f32 = rows of W = diag(1/kscl) R^T, then mu (object ray: o' = W (o - mu)) */
+int grt_debug_fetch_instances(GrtHandle* handle, void* stream, float* instances);
+
 int grt_timings(GrtHandle* handle, float* forward_ms, float* backward_ms, float* build_ms);
 int grt_stats(GrtHandle* handle, GrtStats* stats);
 

@@ -1,0 +1,153 @@
+"""GPU parity: the HIP 3DGRT path (LBVH + software traversal, through the C-ABI and the Tracer plugin surface) against
+the CPU oracle.  The per-ray ORDER of processed particles is compared bit-exactly: both sides evaluate the candidate test
+and the hit distance with the same fp32 expressions on the same proxy instance records (fetched from the GPU build)."""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle
+from scenes import make_scene, rel_err, torch_batch
+
+pytestmark = pytest.mark.gpu
+syn = importlib.import_module("3dgrut_amd.synthetic")
+
+
+def _tracer(**render_kw):
+    gt = importlib.import_module("3dgrut_amd.grt_tracer")
+    return gt.Tracer({"render": render_kw})
+
+
+def _scene(n, w, h, scale, max_density=0.8, kind="trained"):
+    scene = make_scene(n=n, width=w, height=h, median_scale=scale, max_density=max_density, kind=kind)
+    scene["T"] = scene["batch"]["T_to_world"][0]
+    return scene
+
+
+def _gpu_hits(scene, cap=256, **kw):
+    import torch
+    tr = _tracer(**kw)
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+    tr.build_acc(g, rebuild=True)
+    nat = tr.tracer_wrapper
+    batch = torch_batch(scene["batch"], "cuda")
+    H, W = scene["H"], scene["W"]
+    frame = nat.make_frame(0, 3, tr._min_transmittance, g.num_gaussians, H, W, batch.T_to_world)
+    d12 = torch.as_tensor(scene["density12"], device="cuda").contiguous()
+    sph = torch.as_tensor(scene["sph"], device="cuda").contiguous()
+    res = nat.trace(frame, d12, sph, batch.rays_ori.contiguous(), batch.rays_dir.contiguous(), hit_capacity=cap)
+    inst = nat.instances(g.num_gaussians, "cuda").cpu().numpy()
+    scene_aabb = np.array(list(nat.stats().scene_aabb), np.float32)
+    torch.cuda.synchronize()
+    return tr, [t.cpu().numpy() for t in res], inst, scene_aabb
+
+
+@pytest.mark.parametrize("n,w,h,scale,kind", [(500, 40, 24, 0.12, "trained"), (4000, 64, 48, 0.06, "trained"), (1, 16, 16, 0.3, "trained"),
+                                              (2, 16, 16, 0.3, "trained"), (3000, 48, 32, 0.05, "random")])
+def test_hit_order_is_bit_exact(n, w, h, scale, kind):
+    scene = _scene(n, w, h, scale, kind=kind)
+    tr, (feat, dns, hit, nrm, cnt, vis, ids, num), inst, scene_aabb = _gpu_hits(scene)
+    cfg = oracle.default_grt_config()
+    ora = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=scene_aabb, dbg_cap=256)
+    num = num.astype(np.int64)
+    assert np.array_equal(num, ora["hit_num"].astype(np.int64)), f"{(num != ora['hit_num']).sum()} rays with a different number of processed hits"
+    k = np.minimum(num, 256)
+    got, ref = ids.view(np.uint32), ora["hit_ids"]
+    for r in range(h * w):
+        assert np.array_equal(got[r, :k[r]], ref[r, :k[r]]), f"ray {r}: order differs"
+    assert num.max() > 0 or n <= 2
+    # compositing of identical hit lists: images agree to rounding
+    assert np.abs(feat[0] - ora["features"]).max() < 1e-4 and np.abs(dns[0] - ora["density"]).max() < 1e-4
+    assert np.abs(hit[0] - ora["hit_distance"]).max() < 1e-4 * max(1.0, float(np.abs(ora["hit_distance"]).max()))
+    assert np.array_equal(cnt[0], ora["hit_count"])
+    assert np.array_equal(vis.view(np.int32).reshape(-1) != 0, ora["visibility"] != 0)
+
+
+def test_proxies_match_oracle():
+    scene = _scene(2000, 16, 16, 0.08)
+    tr, _, inst, scene_aabb = _gpu_hits(scene)
+    d12 = scene["density12"]
+    pr = oracle.grt_proxies(oracle.default_grt_config(), d12[:, 0:3], d12[:, 4:8], d12[:, 8:11], d12[:, 3])
+    assert rel_err(inst, pr["inst"]) < 2e-6
+    ext = pr["scene"][3:] - pr["scene"][:3]
+    assert np.all(scene_aabb[:3] <= pr["scene"][:3] + 1e-6) and np.all(scene_aabb[3:] >= pr["scene"][3:] - 1e-6)  # padded, never smaller
+    assert np.all(np.abs(scene_aabb - pr["scene"]) < 2e-3 * ext.max())
+
+
+def _render(scene, g_rad=None, g_dns=None, g_hit=None, **kw):
+    import torch
+    tr = _tracer(**kw)
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+    tr.build_acc(g, rebuild=True)
+    out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
+    res = dict(out=out, tracer=tr)
+    if g_rad is not None:
+        loss = (out["pred_features"][0] * torch.as_tensor(g_rad, device="cuda")).sum() + (out["pred_opacity"][0] * torch.as_tensor(g_dns, device="cuda")).sum()
+        if g_hit is not None:
+            loss = loss + (out["pred_dist"][0] * torch.as_tensor(g_hit, device="cuda")).sum()
+        loss.backward()
+        res["grads"] = g.grads_packed()
+    torch.cuda.synchronize()
+    return res
+
+
+@pytest.mark.parametrize("n,w,h,scale,with_depth_grad", [(800, 48, 32, 0.1, True), (800, 48, 32, 0.1, False), (6000, 64, 40, 0.05, False)])
+def test_render_and_gradients_match_oracle(n, w, h, scale, with_depth_grad):
+    scene = _scene(n, w, h, scale)
+    rng = np.random.default_rng(4)
+    g_rad = rng.normal(size=(h, w, 3)).astype(np.float32)
+    g_dns = rng.normal(size=(h, w, 1)).astype(np.float32)
+    g_hit = (rng.normal(size=(h, w, 1)) * 0.1).astype(np.float32)
+    gpu = _render(scene, g_rad, g_dns, g_hit if with_depth_grad else None)
+    cfg = oracle.default_grt_config()
+    ora = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"])
+    out = gpu["out"]
+    f = out["pred_features"][0].detach().cpu().numpy()
+    o = out["pred_opacity"][0].detach().cpu().numpy()
+    d = out["pred_dist"][0].detach().cpu().numpy()
+    bad = (np.abs(f - ora["features"]).max(-1) > 1e-4) | (np.abs(o - ora["density"])[..., 0] > 1e-4) | \
+          (np.abs(d - ora["hit_distance"][..., :1])[..., 0] > 1e-4 * np.maximum(1.0, ora["hit_distance"][..., 0]))
+    assert bad.mean() <= 5e-3, f"{bad.sum()} pixels beyond tolerance"
+    rd, rs = oracle.grt_backward(cfg, 3, 1e-3, ora, g_rad, g_dns, g_hit if with_depth_grad else np.zeros_like(g_hit))
+    f64 = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"], dtype=np.float64)
+    rd64, rs64 = oracle.grt_backward(cfg, 3, 1e-3, f64, g_rad, g_dns, g_hit if with_depth_grad else np.zeros_like(g_hit), dtype=np.float64)
+    gd, gs = gpu["grads"]
+    n_flip = int(bad.sum()) + int((out["hits_count"][0, ..., 0].detach().cpu().numpy() != ora["hit_count"][..., 0]).sum())
+
+    def trimmed(a, b, drop):
+        e = np.abs(np.asarray(a, np.float64) - b).reshape(a.shape[0], -1).max(1)
+        e = np.sort(e)[: max(1, len(e) - drop)]
+        return float(e.max() / (np.abs(b).max() + 1e-12))
+
+    for name, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
+        e = min(trimmed(gd[:, sl], rd[:, sl], 3 * n_flip), trimmed(gd[:, sl], rd64[:, sl], 3 * n_flip))
+        assert e < 1e-3, f"grad {name}: rel err {e:.3e}"
+    assert min(trimmed(gs, rs, 3 * n_flip), trimmed(gs, rs64, 3 * n_flip)) < 1e-3
+
+
+def test_refit_update_matches_full_rebuild():
+    """rebuild=False keeps the tree topology and refits the boxes (OPTIX_BUILD_OPERATION_UPDATE); results must not change."""
+    import torch
+    scene = _scene(3000, 48, 32, 0.06)
+    tr = _tracer(particle_kernel_density_clamping=False)
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+    batch = torch_batch(scene["batch"], "cuda")
+    tr.build_acc(g, rebuild=True)
+    with torch.no_grad():
+        g.positions += 0.01 * torch.randn_like(g.positions)
+    tr.build_acc(g, rebuild=False)
+    a = tr.render(g, batch)["pred_features"].detach().clone()
+    tr.build_acc(g, rebuild=True)
+    b = tr.render(g, batch)["pred_features"].detach()
+    assert torch.allclose(a, b, atol=1e-6)
+
+
+def test_errors_are_loud():
+    gt = importlib.import_module("3dgrut_amd.grt_tracer")
+    with pytest.raises(NotImplementedError):
+        gt.Tracer({"render": {"primitive_type": "icosahedron"}})
+    tr = _tracer()
+    scene = _scene(10, 8, 8, 0.2)
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+    with pytest.raises(RuntimeError, match="build_bvh"):
+        tr.render(g, torch_batch(scene["batch"], "cuda"))
