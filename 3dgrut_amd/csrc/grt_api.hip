@@ -1,6 +1,8 @@
 // grt_api.hip — host orchestration of the 3DGRT path behind the C-ABI (include/grut_amd.h).
 // Plays the role of OptixTracer (threedgrt_tracer/src/optixTracer.cpp:616-1031: buildBVH / trace / traceBwd) without
 // OptiX and without libtorch: all I/O buffers belong to the caller, the handle owns the BVH and scratch.
+#include <cstdlib>
+
 #include "grt_internal.hpp"
 
 using namespace grut;
@@ -18,6 +20,8 @@ struct GrtHandle {
     float scene_host[6] = {0, 0, 0, 0, 0, 0};
     bool scene_host_valid = false;
     EventTimer fwd_timer, bwd_timer, build_timer;
+    DeviceBuffer work_counters;  // instrumented launches (GRUT_GRT_COUNT=1): nodes, leaf tests, processed hits, rounds, inserts
+    unsigned long long work_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 static int grt_validate(const GrtConfig& c) {
@@ -78,7 +82,8 @@ int grt_create(const GrtConfig* config, GrtHandle** handle) {
 void grt_destroy(GrtHandle* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
-                            &h->sort_scratch, &h->nodes, &h->parent_internal, &h->parent_leaf, &h->counters, &h->dbg_ids, &h->dbg_count};
+                            &h->sort_scratch, &h->nodes, &h->parent_internal, &h->parent_leaf, &h->counters, &h->dbg_ids, &h->dbg_count,
+                            &h->work_counters};
     for (DeviceBuffer* b : bufs) b->release();
     h->fwd_timer.destroy();
     h->bwd_timer.destroy();
@@ -169,8 +174,20 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     GrtTraceParams P = trace_params(h, *frame);
     P.dbg_cap = dbg_cap;
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
+    unsigned long long* counters = nullptr;
+    if (getenv("GRUT_GRT_COUNT")) {  // development aid: work statistics of the traversal, read back by grt_stats
+        GRUT_CHECK(h->work_counters.ensure(64));
+        counters = h->work_counters.as<unsigned long long>();
+        GRUT_HIP(hipMemsetAsync(counters, 0, 64, s));
+    }
     grt_launch_trace_fwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
-                         out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count);
+                         out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters);
+    if (counters) {
+        GRUT_HIP(hipMemcpyAsync(h->work_host, counters, 64, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipStreamSynchronize(s));
+        fprintf(stderr, "[grut] grt fwd: nodes %llu, leaf tests %llu, processed %llu, rounds %llu, inserts %llu (rays %d)\n", h->work_host[0],
+                h->work_host[1], h->work_host[2], h->work_host[3], h->work_host[4], frame->width * frame->height);
+    }
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
     return GRUT_OK;
@@ -231,6 +248,9 @@ int grt_stats(GrtHandle* h, GrtStats* stats) {
     memset(stats, 0, sizeof(*stats));
     stats->num_particles = h->N;
     stats->num_nodes = h->N > 1 ? h->N - 1 : (h->N ? 1 : 0);
+    stats->nodes_visited = h->work_host[0];
+    stats->candidates = h->work_host[1];
+    stats->processed_hits = h->work_host[2];
     if (h->built && h->N > 0) {
         if (!h->scene_host_valid) {  // synchronises with the build stream
             GRUT_HIP(hipMemcpyAsync(h->scene_host, h->scene.ptr, 24, hipMemcpyDeviceToHost, h->build_stream));

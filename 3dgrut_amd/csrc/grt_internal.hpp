@@ -53,7 +53,7 @@ void grt_launch_refit(hipStream_t s, uint32_t N, const uint32_t* sorted_ids, con
 // trace
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
-                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count);
+                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters);
 void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
                           const float* g_dns, const float* g_hit, float* g_density12, float* g_sph);

@@ -7,8 +7,8 @@
 // referenceBwdOptix.cu:103-170, include/3dgrt/kernels/cuda/gaussianParticles.cuh:337-731 (per-hit math).
 //
 // CDNA4 design (no RT cores):
-//   * LBVH: 30-bit Morton codes of the proxy centres, the stable radix sort shared with the 3DGUT path (ties broken by
-//     particle index), Karras' radix-tree construction, bottom-up refit with agent-scope acquire/release counters.
+//   * LBVH: keys = (size octave, 27-bit Morton code of the proxy centre), the stable radix sort shared with the 3DGUT
+//     path (ties broken by particle index), Karras' radix-tree construction, bottom-up refit with agent-scope acquire/release counters.
 //     Nodes are 64 B and carry BOTH children's boxes, so each dependent fetch serves two slab tests.
 //   * One lane per ray, one wave64 per 8x8 pixel block (coherent rays share node fetches through L1/L2); the per-lane
 //     traversal stack lives in LDS ([depth][lane], conflict-free); the 16-entry (distance, particle) buffer of a trace
@@ -96,13 +96,18 @@ __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const 
     }
 }
 
-__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+__device__ __forceinline__ uint32_t expand_bits9(uint32_t v) {  // 9 bits -> every third bit of 27
+    v &= 0x1FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
+// Sort key = (size class : 3 bits) | (27-bit Morton code of the proxy centre).  The size class is the octave of the
+// proxy's largest half extent relative to the scene: a radix tree over these keys separates the octaves in its top
+// three levels, so a few scene-sized Gaussians bloat only the small subtree of their own class instead of the ancestors
+// of a million small ones (an LBVH on centres alone made every ray visit thousands of inflated nodes per trace round).
 __global__ __launch_bounds__(256) void grt_morton_kernel(uint32_t N, const float* __restrict__ aabb, const uint32_t* __restrict__ scene_enc,
                                                          float* __restrict__ scene, uint32_t* __restrict__ codes, uint32_t* __restrict__ ids) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,14 +119,19 @@ __global__ __launch_bounds__(256) void grt_morton_kernel(uint32_t N, const float
     if (i >= N || !codes) return;  // codes == nullptr: refit-only update, just publish the scene box
     const float* b = aabb + 6 * (size_t)i;
     uint32_t q[3];
+    float half_max = 0.f, scene_max = 0.f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float c = 0.5f * (b[k] + b[3 + k]);
         const float ext = fmaxf(s[3 + k] - s[k], 1e-30f);
         const float u = fminf(fmaxf((c - s[k]) / ext, 0.f), 1.f);
-        q[k] = min((uint32_t)(u * 1024.f), 1023u);
+        q[k] = min((uint32_t)(u * 512.f), 511u);
+        half_max = fmaxf(half_max, 0.5f * (b[3 + k] - b[k]));
+        scene_max = fmaxf(scene_max, ext);
     }
-    codes[i] = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+    const int octave = (int)floorf(log2f(scene_max / fmaxf(half_max, 1e-30f)));  // >= 0: the scene contains the proxy
+    const uint32_t cls = (uint32_t)min(max(octave - 1, 0), 7);
+    codes[i] = (cls << 27) | (expand_bits9(q[0]) << 2) | (expand_bits9(q[1]) << 1) | expand_bits9(q[2]);
     ids[i] = i;
 }
 
@@ -317,50 +327,79 @@ __device__ __forceinline__ bool box_hit(const float* __restrict__ lo, const floa
 }
 
 // one optixTrace: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in (t, particle)
-__device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, float tmin, float tmax, uint32_t* __restrict__ stack /* [depth*64 + lane] */,
-                                            HitBuffer& buf) {
+struct TraceCounters {
+    uint32_t nodes = 0, leaf_tests = 0, inserts = 0, rounds = 0, processed = 0;
+};
+
+// one optixTrace for every ray of the wave: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in
+// (t, particle), per lane.  PACKET traversal: the 64 rays of an 8x8 pixel block walk the tree TOGETHER — one wave-uniform
+// stack (LDS, 64 words per wave), node and proxy records fetched once per wave through the scalar path, every lane
+// tests its own ray against the two child boxes, and a child is entered when ANY lane needs it.  Primary rays of a
+// block are coherent, so the union of their paths is barely larger than one ray's path: the node fetches, the stack
+// traffic and the divergence of 64 independent walks collapse into one.  Pruning stays per lane (its own interval and
+// its own current 16th-nearest distance); lanes that are done (`active` false) just ride along.
+template <bool COUNT>
+__device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, float tmin, float tmax, bool active, int lane,
+                                            uint32_t* __restrict__ stack /* [64] per wave */, HitBuffer& buf, TraceCounters& tc) {
     buf.clear();
+    if (COUNT && active) tc.rounds++;
+    if (!__any(active)) return;
     int sp = 0;
     uint32_t cur = 0;  // root
     bool have = true;
     while (true) {
         if (!have) {
             if (sp == 0) break;
-            cur = stack[(--sp) * 64];
+            cur = stack[--sp];
         }
         have = false;
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+        if (COUNT && lane == 0) tc.nodes++;
         const float4* nq = reinterpret_cast<const float4*>(&bvh.nodes[cur]);
         const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
         const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q1.x, q1.y, q1.z}, lo1[3] = {q2.x, q2.y, q2.z}, hi1[3] = {q3.x, q3.y, q3.z};
         const uint32_t c0 = __float_as_uint(q0.w), c1 = __float_as_uint(q2.w);
         float tn0, tf0, tn1, tf1;
         const float bound = fminf(tmax, buf.t[kGrtMaxHits - 1]);
-        bool h0 = (c0 != kGrtNoChild) && box_hit(lo0, hi0, r, tn0, tf0) && (tf0 >= tmin) && (tn0 <= tmax) && (tn0 - q1.w <= bound);
-        bool h1 = (c1 != kGrtNoChild) && box_hit(lo1, hi1, r, tn1, tf1) && (tf1 >= tmin) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
-        // leaves are tested on the spot
-        if (h0 && (c0 & kGrtLeafBit)) {
+        const bool h0 = active && (c0 != kGrtNoChild) && box_hit(lo0, hi0, r, tn0, tf0) && (tf0 >= tmin) && (tn0 <= tmax) && (tn0 - q1.w <= bound);
+        const bool h1 = active && (c1 != kGrtNoChild) && box_hit(lo1, hi1, r, tn1, tf1) && (tf1 >= tmin) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
+        bool a0 = __any(h0), a1 = __any(h1);
+        // leaves are tested on the spot, by the lanes whose ray touches the leaf's box
+        if (a0 && (c0 & kGrtLeafBit)) {
             const uint32_t id = c0 & ~kGrtLeafBit;
-            const Cand c = candidate(bvh.inst + 12 * (size_t)id, r);
-            if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
-                hit_less(c.t, id, buf.t[kGrtMaxHits - 1], buf.id[kGrtMaxHits - 1]))
-                buf.insert(c.t, id);
-            h0 = false;
+            if (h0) {
+                const Cand c = candidate(bvh.inst + 12 * (size_t)id, r);
+                if (COUNT) tc.leaf_tests++;
+                if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
+                    hit_less(c.t, id, buf.t[kGrtMaxHits - 1], buf.id[kGrtMaxHits - 1])) {
+                    buf.insert(c.t, id);
+                    if (COUNT) tc.inserts++;
+                }
+            }
+            a0 = false;
         }
-        if (h1 && (c1 & kGrtLeafBit)) {
+        if (a1 && (c1 & kGrtLeafBit)) {
             const uint32_t id = c1 & ~kGrtLeafBit;
-            const Cand c = candidate(bvh.inst + 12 * (size_t)id, r);
-            if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
-                hit_less(c.t, id, buf.t[kGrtMaxHits - 1], buf.id[kGrtMaxHits - 1]))
-                buf.insert(c.t, id);
-            h1 = false;
+            if (h1) {
+                const Cand c = candidate(bvh.inst + 12 * (size_t)id, r);
+                if (COUNT) tc.leaf_tests++;
+                if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
+                    hit_less(c.t, id, buf.t[kGrtMaxHits - 1], buf.id[kGrtMaxHits - 1])) {
+                    buf.insert(c.t, id);
+                    if (COUNT) tc.inserts++;
+                }
+            }
+            a1 = false;
         }
-        if (h0 && h1) {  // descend into the nearer child, keep the farther one
-            const bool first0 = tn0 <= tn1;
-            stack[(sp++) * 64] = first0 ? c1 : c0;
+        if (a0 && a1) {  // enter the child most lanes reach first, keep the other
+            const int v0 = __popcll(__ballot(h0 && (!h1 || tn0 <= tn1))), v1 = __popcll(__ballot(h1 && (!h0 || tn1 < tn0)));
+            const bool first0 = v0 >= v1;
+            if (lane == 0) stack[sp] = first0 ? c1 : c0;
+            sp++;
             cur = first0 ? c0 : c1;
             have = true;
-        } else if (h0 || h1) {
-            cur = h0 ? c0 : c1;
+        } else if (a0 || a1) {
+            cur = a0 ? c0 : c1;
             have = true;
         }
     }
@@ -444,19 +483,20 @@ __device__ __forceinline__ HitGeom hit_geometry(const GrtTraceParams& P, const P
 // ---------------------------------------------------------------------------------------------
 // forward: __raygen__rg of referenceOptix.cu:103-186
 // ---------------------------------------------------------------------------------------------
-template <int DEG>
+template <int DEG, bool COUNT>
 __global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
                                                            const float* __restrict__ sph, const float* __restrict__ ray_o,
                                                            const float* __restrict__ ray_d, float* __restrict__ out_rad,
                                                            float* __restrict__ out_dns, float* __restrict__ out_hit2,
                                                            float* __restrict__ out_nrm, float* __restrict__ out_cnt,
                                                            int32_t* __restrict__ visibility, uint32_t* __restrict__ dbg_ids,
-                                                           uint32_t* __restrict__ dbg_count) {
-    __shared__ uint32_t s_stack[kGrtStackDepth * 64];
+                                                           uint32_t* __restrict__ dbg_count, unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t s_stack[kGrtStackDepth];
+    TraceCounters tc;
     const int lane = threadIdx.x;
     const int px = (int)blockIdx.x * 8 + (lane & 7), py = (int)blockIdx.y * 8 + (lane >> 3);
-    if (px >= P.W || py >= P.H) return;
-    const size_t pix = (size_t)py * P.W + px;
+    const bool in_image = (px < P.W) && (py < P.H);
+    const size_t pix = in_image ? (size_t)py * P.W + px : 0;  // out-of-image lanes shadow pixel 0 and never write
     const RayW r = make_ray(P, ray_o, ray_d, pix);
     float basis[16];
     sh_basis16(P.sph_degree, r.d, basis);
@@ -469,9 +509,13 @@ __global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, Grt
     float tLast = fmaxf(0.f, tEnter - eps);
     uint32_t ndbg = 0;
     HitBuffer buf;
-    while ((tLast <= tExit) && (T > P.min_transmittance)) {
-        trace_round(bvh, r, tLast + eps, tExit + eps, s_stack + lane, buf);
-        if (buf.id[0] == 0xFFFFFFFFu) break;
+    bool running = in_image;
+    while (true) {
+        running = running && (tLast <= tExit) && (T > P.min_transmittance);
+        if (!__any(running)) break;
+        trace_round<COUNT>(bvh, r, tLast + eps, tExit + eps, running, lane, s_stack, buf, tc);
+        if (buf.id[0] == 0xFFFFFFFFu) running = false;
+        if (!running) continue;
 #pragma unroll
         for (int i = 0; i < kGrtMaxHits; ++i) {
             const uint32_t id = buf.id[i];
@@ -499,17 +543,26 @@ __global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, Grt
                     cnt += 1.f;
                 }
                 tLast = fmaxf(tLast, buf.t[i]);
+                if (COUNT) tc.processed++;
                 if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = id;
                 ndbg++;
             }
         }
     }
+    if (!in_image) return;
     out_rad[3 * pix] = rad.x; out_rad[3 * pix + 1] = rad.y; out_rad[3 * pix + 2] = rad.z;
     out_dns[pix] = 1.f - T;
     out_hit2[2 * pix] = depth; out_hit2[2 * pix + 1] = tLast;
     if (P.normals) { out_nrm[3 * pix] = nrm.x; out_nrm[3 * pix + 1] = nrm.y; out_nrm[3 * pix + 2] = nrm.z; }
     if (P.hitcounts) out_cnt[pix] = cnt;
     if (dbg_count) dbg_count[pix] = ndbg;
+    if (COUNT) {  // work statistics for GrtStats (instrumented launches only)
+        atomicAdd(&counters[0], (unsigned long long)tc.nodes);
+        atomicAdd(&counters[1], (unsigned long long)tc.leaf_tests);
+        atomicAdd(&counters[2], (unsigned long long)tc.processed);
+        atomicAdd(&counters[3], (unsigned long long)tc.rounds);
+        atomicAdd(&counters[4], (unsigned long long)tc.inserts);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -540,11 +593,11 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
                                                            const float* __restrict__ g_rad, const float* __restrict__ g_dns,
                                                            const float* __restrict__ g_hit, float* __restrict__ g_density12,
                                                            float* __restrict__ g_sph) {
-    __shared__ uint32_t s_stack[kGrtStackDepth * 64];
+    __shared__ uint32_t s_stack[kGrtStackDepth];
     const int lane = threadIdx.x;
     const int px = (int)blockIdx.x * 8 + (lane & 7), py = (int)blockIdx.y * 8 + (lane >> 3);
-    if (px >= P.W || py >= P.H) return;
-    const size_t pix = (size_t)py * P.W + px;
+    const bool in_image = (px < P.W) && (py < P.H);
+    const size_t pix = in_image ? (size_t)py * P.W + px : 0;  // out-of-image lanes shadow pixel 0 and never write
     const RayW r = make_ray(P, ray_o, ray_d, pix);
     float basis[16];
     sh_basis16(P.sph_degree, r.d, basis);
@@ -563,9 +616,14 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
     float startT = fmaxf(0.f, tEnter - eps);
     const float endT = fminf(max_hit, tExit) + eps;
     HitBuffer buf;
-    while (startT < endT) {
-        trace_round(bvh, r, startT + eps, endT, s_stack + lane, buf);
-        if (buf.id[0] == 0xFFFFFFFFu) break;
+    bool running = in_image;
+    while (true) {
+        running = running && (startT < endT);
+        if (!__any(running)) break;
+        TraceCounters tc;
+        trace_round<false>(bvh, r, startT + eps, endT, running, lane, s_stack, buf, tc);
+        if (buf.id[0] == 0xFFFFFFFFu) running = false;
+        if (!running) continue;
 #pragma unroll
         for (int i = 0; i < kGrtMaxHits; ++i) {
             const uint32_t id = buf.id[i];
@@ -688,11 +746,17 @@ void grt_launch_refit(hipStream_t s, uint32_t N, const uint32_t* sorted_ids, con
 
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
-                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count) {
+                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters) {
     const dim3 grid(div_up((uint32_t)P.W, 8), div_up((uint32_t)P.H, 8));
-    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_>), grid, dim3(64), 0, s, P, bvh,
-                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns, out_hit2,
-                                                     out_nrm, out_cnt, visibility, dbg_ids, dbg_count));
+    if (counters) {
+        GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, true>), grid, dim3(64), 0, s, P, bvh,
+                                                         reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns,
+                                                         out_hit2, out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters));
+    } else {
+        GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, false>), grid, dim3(64), 0, s, P, bvh,
+                                                         reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns,
+                                                         out_hit2, out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters));
+    }
 }
 void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,

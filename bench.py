@@ -29,6 +29,9 @@ WORKLOADS = {
     "c4_1m_1080p": (1_000_000, 1920, 1080, 0.01),
     "c2_1m_800": (1_000_000, 800, 800, 0.01),
     "c1_100k_400": (100_000, 400, 400, 0.01),
+    # BASELINE config 3 (not the default bench line): 3DGRT software-BVH primary rays, forward + backward
+    "c3_grt_1m_800": (1_000_000, 800, 800, 0.01),
+    "c3_grt_100k_400": (100_000, 400, 400, 0.01),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -73,6 +76,64 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"{frames} fwd+bwd frames of {n} Gaussians at {w}x{h} (config C1) through the C oracle, OpenMP over pixels"}
 
 
+def bench_grt(args, world, rank, dev, dist, n, W, H, ms):
+    """3DGRT: BVH build + forward + backward of one view per GPU per step (the reference rebuilds the BVH every iteration,
+    trainer.py:1257-1263).  Traversal is latency / divergence bound; the line reports rays/s and per-stage ms."""
+    syn = importlib.import_module("3dgrut_amd.synthetic")
+    grt = importlib.import_module("3dgrut_amd.grt_tracer")
+    from scenes import torch_batch
+    d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=ms)
+    K = syn.pinhole_intrinsics(W, H)
+    ro, rd = syn.pinhole_rays(W, H, K)
+    batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(rank, n_views=max(world, 8))[None], intrinsics=K), dev)
+    tracer = grt.Tracer({"render": {"enable_kernel_timings": True}})
+    g = syn.SimpleGaussians(d12, sph, device=dev)
+    g_fd_np, _ = syn.upstream_grads(W, H)
+    g_fd = torch.as_tensor(g_fd_np, device=dev)
+
+    def step():
+        g.zero_grad()
+        tracer.build_acc(g, rebuild=True)
+        out = tracer.render(g, batch, train=True)
+        fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
+        torch.autograd.backward([fd], [g_fd])
+        if world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in g.parameters()])
+            dist.all_reduce(flat)
+
+    for _ in range(args.warmup):
+        step()
+    tracer.timings
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stages = tracer.timings
+    if rank == 0:
+        P = W * H
+        print(json.dumps({
+            "metric": "train rays/sec (3DGRT software-BVH forward+backward, primary rays)", "value": world * P * args.steps / dt,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"3DGRT BVH build + fwd + bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "
+                                   f"SH degree 3, k = 16 hits per trace", "name": args.workload, "parallelism": f"view-dp{world}"},
+            "stages_ms": stages}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +162,8 @@ def main():
     from scenes import torch_batch
 
     n, W, H, ms = WORKLOADS[args.workload]
+    if "grt" in args.workload:
+        return bench_grt(args, world, rank, dev, dist, n, W, H, ms)
     d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=ms)
     K = syn.pinhole_intrinsics(W, H)
     ro, rd = syn.pinhole_rays(W, H, K)
