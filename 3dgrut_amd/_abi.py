@@ -55,6 +55,7 @@ class GutFrame(C.Structure):
         ("frame_id", C.c_uint32), ("n_active_features", C.c_int32), ("num_particles", C.c_uint32),
         ("width", C.c_int32), ("height", C.c_int32), ("camera", GrutCamera),
         ("pose_start", C.c_float * 7), ("pose_end", C.c_float * 7),
+        ("device_T_to_world", C.c_void_p), ("device_T_to_world_end", C.c_void_p),
     ]
 
 

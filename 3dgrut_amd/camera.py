@@ -72,9 +72,13 @@ def _enum_name(v):
     return v if isinstance(v, str) else getattr(v, "name", str(v))
 
 
-def camera_from_batch(gpu_batch):
-    """-> (GrutCamera, pose_start[7], pose_end[7]); raises ValueError like tracer.py:486-488."""
-    if _get(gpu_batch, "rays_in_world_space", False):
+def camera_from_batch(gpu_batch, poses_on_device=False):
+    """-> (GrutCamera, pose_start[7], pose_end[7]); raises ValueError like tracer.py:486-488.
+
+    poses_on_device: the caller hands the camera-to-world matrices to the library as device pointers
+    (GutFrame.device_T_to_world); the host-side poses are then placeholders and the pose tensors are NOT read back
+    (a `.cpu()` here would wait for everything queued on the stream — the stall the reference has every iteration)."""
+    if _get(gpu_batch, "rays_in_world_space", False) or poses_on_device:
         ps = pe = np.array([0, 0, 0, 0, 0, 0, 1], np.float32)
     else:
         p0 = _to_numpy(_get(gpu_batch, "T_to_world")).squeeze()

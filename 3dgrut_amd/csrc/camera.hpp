@@ -43,7 +43,7 @@ __host__ __device__ inline void quat_slerp(const float a[4], const float b_in[4]
 }
 
 // tcnn::quat(mat3) == glm::quat_cast; R as rows
-inline void rows_to_quat_xyzw(const float R[9], float q[4]) {
+__host__ __device__ inline void rows_to_quat_xyzw(const float R[9], float q[4]) {
     const float m00 = R[0], m11 = R[4], m22 = R[8];
     const float fx = m00 - m11 - m22, fy = m11 - m00 - m22, fz = m22 - m00 - m11, fw = m00 + m11 + m22;
     int big = 0;
@@ -61,13 +61,13 @@ inline void rows_to_quat_xyzw(const float R[9], float q[4]) {
     }
 }
 
-inline Pose pose_interpolate(const Pose& a, const Pose& b, float t) {  // sensors.h:53-66
+__host__ __device__ inline Pose pose_interpolate(const Pose& a, const Pose& b, float t) {  // sensors.h:53-66
     Pose o;
     quat_slerp(a.q, b.q, t, o.q);
     for (int i = 0; i < 3; ++i) o.t[i] = a.t[i] * (1.f - t) + b.t[i] * t;
     return o;
 }
-inline Pose pose_inverse(const Pose& p) {  // sensors.h:44-51
+__host__ __device__ inline Pose pose_inverse(const Pose& p) {  // sensors.h:44-51
     float R[9], Rt[9];
     quat_xyzw_to_rows(p.q, R);
     for (int i = 0; i < 3; ++i)
@@ -86,7 +86,7 @@ struct FramePoses {
     float s2w_R[9], s2w_t[3];    // sensor->world of the mid-exposure pose (gutRenderer.cu:266-267, 407)
 };
 
-inline FramePoses make_frame_poses(const float ps7[7], const float pe7[7]) {
+__host__ __device__ inline FramePoses make_frame_poses(const float ps7[7], const float pe7[7]) {
     Pose s, e;
     for (int i = 0; i < 3; ++i) { s.t[i] = ps7[i]; e.t[i] = pe7[i]; }
     for (int i = 0; i < 4; ++i) { s.q[i] = ps7[3 + i]; e.q[i] = pe7[3 + i]; }
@@ -99,6 +99,36 @@ inline FramePoses make_frame_poses(const float ps7[7], const float pe7[7]) {
     quat_xyzw_to_rows(mid.q, f.view_R);
     quat_xyzw_to_rows(inv.q, f.s2w_R);
     return f;
+}
+
+// [t, q(x,y,z,w)] of the inverse of a rigid camera-to-world matrix (row-major 4x4): what the plugin's host code
+// derives with numpy (threedgut_tracer/tracer.py:88-136, 359-380, 414-423), here for poses that live in device memory.
+__host__ __device__ inline void c2w_to_world_to_sensor(const float* m, float out7[7]) {
+    // rigid inverse: R^T, -R^T t
+    float R[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = m[4 * j + i];
+    for (int i = 0; i < 3; ++i) out7[i] = -(R[3 * i] * m[3] + R[3 * i + 1] * m[7] + R[3 * i + 2] * m[11]);
+    // SensorPose3DModel.__so3_matrix_to_quat (tracer.py:88-136)
+    const float dm[4] = {R[0], R[4], R[8], R[0] + R[4] + R[8]};
+    int c = 0;
+    for (int k = 1; k < 4; ++k)
+        if (dm[k] > dm[c]) c = k;
+    float q[4];
+    if (c != 3) {
+        const int i = c, j = (c + 1) % 3, k = (c + 2) % 3;
+        q[i] = 1.f - dm[3] + 2.f * R[3 * i + i];
+        q[j] = R[3 * j + i] + R[3 * i + j];
+        q[k] = R[3 * k + i] + R[3 * i + k];
+        q[3] = R[3 * k + j] - R[3 * j + k];
+    } else {
+        q[0] = R[7] - R[5];
+        q[1] = R[2] - R[6];
+        q[2] = R[3] - R[1];
+        q[3] = 1.f + dm[3];
+    }
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int k = 0; k < 4; ++k) out7[3 + k] = q[k] / n;
 }
 
 #ifdef __HIPCC__

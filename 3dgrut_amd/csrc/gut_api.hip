@@ -31,7 +31,7 @@ struct GutHandle {
     // per-particle scratch
     DeviceBuffer tiles_count, proj_pos, conic_opacity, extent, depth, rgb, depth_key, particle_idx;
     DeviceBuffer depth_key_tmp, particle_idx_tmp, offsets, sort_scratch, scan_scratch, counters;
-    DeviceBuffer part_offset, pos_particle, grad_partial, grad_flag, g_rgb;
+    DeviceBuffer part_offset, pos_particle, grad_partial, grad_flag, g_rgb, poses_dev;
     // per-intersection scratch
     DeviceBuffer tile_keys, tile_vals, tile_keys_tmp, tile_vals_tmp, tile_sort_scratch, ranges;
     DeviceBuffer ck_tc, ck_d, ck_reached, ck_boundary_tile;
@@ -43,6 +43,8 @@ struct GutHandle {
     hipStream_t fwd_stream = nullptr;
     GutParams params;
     uint32_t num_intersections = 0;
+    uint32_t tile_capacity = 0;  // entries the per-intersection scratch can hold (0 until the first frame sized it)
+    uint32_t ck_boundaries_capacity = 0;
     uint32_t* sorted_pos = nullptr;  // sorted expansion positions: points into tile_vals or tile_vals_tmp
     uint32_t* sorted_tile_keys = nullptr;
     uint32_t* rank_to_particle = nullptr;
@@ -114,6 +116,7 @@ static GutParams make_params(const GutConfig& c, const GutFrame& f) {
     P.N = f.num_particles;
     P.cam = f.camera;
     P.poses = make_frame_poses(f.pose_start, f.pose_end);
+    P.poses_dev = nullptr;
     return P;
 }
 
@@ -139,6 +142,7 @@ static int ensure_particle_scratch(GutHandle* h, uint32_t N) {
 
 static int ensure_intersection_scratch(GutHandle* h, uint32_t I, uint32_t tiles) {
     const size_t n = I ? I : 1;
+    if (n > h->tile_capacity) h->tile_capacity = (uint32_t)n;
     GRUT_CHECK(h->tile_keys.ensure(n * 4, 1.3f));
     GRUT_CHECK(h->tile_vals.ensure(n * 4, 1.3f));
     GRUT_CHECK(h->tile_keys_tmp.ensure(n * 4, 1.3f));
@@ -156,6 +160,7 @@ static int ensure_intersection_scratch(GutHandle* h, uint32_t I, uint32_t tiles)
     h->checkpoints.reached = h->ck_reached.as<uint8_t>();
     h->checkpoints.boundary_tile = h->ck_boundary_tile.as<uint32_t>();
     h->checkpoints.num_boundaries = (uint32_t)nb;
+    h->ck_boundaries_capacity = (uint32_t)nb;
     return GRUT_OK;
 }
 
@@ -204,7 +209,7 @@ void gut_destroy(GutHandle* h) {
     DeviceBuffer* bufs[] = {&h->tiles_count, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->rgb, &h->depth_key,
                             &h->particle_idx, &h->depth_key_tmp, &h->particle_idx_tmp, &h->offsets, &h->sort_scratch,
                             &h->scan_scratch, &h->counters, &h->part_offset, &h->pos_particle, &h->grad_partial, &h->grad_flag,
-                            &h->g_rgb, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
+                            &h->g_rgb, &h->poses_dev, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
                             &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges, &h->ck_tc, &h->ck_d, &h->ck_reached,
                             &h->ck_boundary_tile};
     for (DeviceBuffer* b : bufs) b->release();
@@ -248,6 +253,11 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
 
     GRUT_CHECK(ensure_particle_scratch(h, N));
+    if (frame->device_T_to_world) {  // poses stay on the device
+        GRUT_CHECK(h->poses_dev.ensure(sizeof(FramePoses)));
+        launch_frame_poses(s, frame->device_T_to_world, frame->device_T_to_world_end, h->poses_dev.as<FramePoses>());
+        h->params.poses_dev = h->poses_dev.as<FramePoses>();
+    }
     const GutProjected proj = projected_view(h);
     uint32_t* d_counters = h->counters.as<uint32_t>();
     GRUT_HIP(hipMemsetAsync(d_counters, 0, 64, s));
@@ -275,47 +285,65 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     GRUT_CHECK(inclusive_scan_u32(s, N, proj.tiles_count, rank_to_particle, h->offsets.as<uint32_t>(), h->scan_scratch.ptr,
                                   h->scan_scratch.bytes));
     GRUT_CHECK(h->stage_end(GUT_STAGE_SCAN, s, slot));
-    // I and Nv to the host; the host waits for the scan only, the GPU keeps going
+    // I and Nv travel to the host asynchronously.  The rest of the frame (expansion, tile sort, ranges, compositing) is
+    // enqueued SPECULATIVELY against the current capacity of the per-intersection scratch, with the true count read on
+    // the device, so the GPU never waits for the host to wake up and launch a dozen small kernels (the reference blocks
+    // here, gutRenderer.cu:313-321).  Only if the count turns out to exceed the capacity is the tail redone.
     GRUT_HIP(hipMemcpyAsync(&h->host_counters[0], h->offsets.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
     GRUT_HIP(hipMemcpyAsync(&h->host_counters[1], d_counters + 1, 4, hipMemcpyDeviceToHost, s));
     GRUT_HIP(hipEventRecord(h->count_event, s));
+    const uint32_t tile_mask = (h->stats.key_bits >= 32) ? 0xFFFFFFFFu : ((1u << h->stats.key_bits) - 1u);
+    auto enqueue_tail = [&](uint32_t n, const uint32_t* n_dev) -> int {
+        // K4 expansion in rank order
+        GRUT_CHECK(h->stage_begin(GUT_STAGE_EXPAND, s, slot));
+        launch_expand(s, P, proj, rank_to_particle, h->offsets.as<uint32_t>(), n, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>(),
+                      h->pos_particle.as<uint32_t>());
+        GRUT_CHECK(h->stage_end(GUT_STAGE_EXPAND, s, slot));
+        // K5 stable radix passes over the tile bits only
+        GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_SORT, s, slot));
+        uint32_t *sorted_tiles = nullptr, *sorted_idx = nullptr;
+        GRUT_CHECK(sort_pairs_u32(s, n, n_dev, 0, (int)h->stats.key_bits, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>(),
+                                  h->tile_keys_tmp.as<uint32_t>(), h->tile_vals_tmp.as<uint32_t>(), h->tile_sort_scratch.ptr,
+                                  h->tile_sort_scratch.bytes, &sorted_tiles, &sorted_idx));
+        h->sorted_tile_keys = sorted_tiles;
+        h->sorted_pos = sorted_idx;
+        GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_SORT, s, slot));
+        // K6 tile ranges
+        GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_RANGES, s, slot));
+        GRUT_HIP(hipMemsetAsync(h->ranges.ptr, 0, (size_t)tiles * 8, s));
+        GRUT_HIP(hipMemsetAsync(h->ck_reached.ptr, 0, (size_t)h->ck_boundaries_capacity * 4, s));
+        launch_tile_ranges(s, n, n_dev, tile_mask, tiles, sorted_tiles, h->ranges.as<uint32_t>(), h->checkpoints.boundary_tile);
+        GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_RANGES, s, slot));
+        // K7 compositing
+        GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_FWD, s, slot));
+        launch_render_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, proj.rgb, ray_origin,
+                          ray_direction, out_feat_density, out_hit_distance, out_hit_count, h->checkpoints, true);
+        GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_FWD, s, slot));
+        return GRUT_OK;
+    };
+    const bool speculative = h->tile_capacity > 0;
+    if (speculative) GRUT_CHECK(enqueue_tail(h->tile_capacity, h->offsets.as<uint32_t>() + (N - 1)));
     GRUT_HIP(hipEventSynchronize(h->count_event));
     const uint32_t I = h->host_counters[0];
     h->stats.num_visible = h->host_counters[1];
     h->stats.num_intersections = I;
     h->num_intersections = I;
-    if (I == 0) {  // gutRenderer.cu:323-325
+    if (I == 0) {  // gutRenderer.cu:323-325: nothing is composited, the hit distance keeps its initial value
+        if (speculative) {
+            const float far = 1e6f;
+            uint32_t bits;
+            memcpy(&bits, &far, 4);
+            GRUT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_hit_distance), (int)bits, (size_t)P.W * P.H, s));
+        }
         if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
         h->have_forward = true;
         return GRUT_OK;
     }
-    GRUT_CHECK(ensure_intersection_scratch(h, I, tiles));
-    // K4 expansion in rank order
-    GRUT_CHECK(h->stage_begin(GUT_STAGE_EXPAND, s, slot));
-    launch_expand(s, P, proj, rank_to_particle, h->offsets.as<uint32_t>(), I, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>(),
-                  h->pos_particle.as<uint32_t>());
-    GRUT_CHECK(h->stage_end(GUT_STAGE_EXPAND, s, slot));
-    GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_SORT, s, slot));
-    // K5 stable radix passes over the tile bits only
-    uint32_t *sorted_tiles = nullptr, *sorted_idx = nullptr;
-    GRUT_CHECK(sort_pairs_u32(s, I, nullptr, 0, (int)h->stats.key_bits, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>(),
-                              h->tile_keys_tmp.as<uint32_t>(), h->tile_vals_tmp.as<uint32_t>(), h->tile_sort_scratch.ptr,
-                              h->tile_sort_scratch.bytes, &sorted_tiles, &sorted_idx));
-    h->sorted_tile_keys = sorted_tiles;
-    h->sorted_pos = sorted_idx;
-    GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_SORT, s, slot));
-    GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_RANGES, s, slot));
-    // K6 tile ranges
-    GRUT_HIP(hipMemsetAsync(h->ranges.ptr, 0, (size_t)tiles * 8, s));
-    const uint32_t tile_mask = (h->stats.key_bits >= 32) ? 0xFFFFFFFFu : ((1u << h->stats.key_bits) - 1u);
-    GRUT_HIP(hipMemsetAsync(h->ck_reached.ptr, 0, (size_t)h->checkpoints.num_boundaries * 4, s));
-    launch_tile_ranges(s, I, tile_mask, tiles, sorted_tiles, h->ranges.as<uint32_t>(), h->checkpoints.boundary_tile);
-    GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_RANGES, s, slot));
-    // K7 compositing
-    GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_FWD, s, slot));
-    launch_render_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, proj.rgb, ray_origin, ray_direction,
-                      out_feat_density, out_hit_distance, out_hit_count, h->checkpoints, true);
-    GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_FWD, s, slot));
+    if (!speculative || I > h->tile_capacity) {
+        GRUT_CHECK(ensure_intersection_scratch(h, I + I / 2, tiles));  // head-room: the next frames speculate against it
+        GRUT_CHECK(enqueue_tail(I, nullptr));
+    }
+    h->checkpoints.num_boundaries = I / kGutSegment + 1;  // what the gradient sweep iterates over
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
     h->have_forward = true;

@@ -16,8 +16,13 @@ struct GutParams {
     int W, H, gx, gy;
     uint32_t N;
     GrutCamera cam;
-    FramePoses poses;
+    FramePoses poses;             // derived on the host from GutFrame::pose_start / pose_end ...
+    const FramePoses* poses_dev;  // ... or on the device from GutFrame::device_T_to_world[_end] (then this is non-null)
 };
+#ifdef __HIPCC__
+__device__ __forceinline__ const FramePoses& frame_poses(const GutParams& P) { return P.poses_dev ? *P.poses_dev : P.poses; }
+#endif
+void launch_frame_poses(hipStream_t s, const float* T_start, const float* T_end, FramePoses* out);
 
 // per-particle products of the projection (role of GutRenderForwardContext's particle buffers, gutRenderer.cu:166-177)
 struct GutProjected {
@@ -63,8 +68,8 @@ void launch_project(hipStream_t s, const GutParams& P, const float* density12, c
 void launch_expand(hipStream_t s, const GutParams& P, const GutProjected& proj, const uint32_t* rank_to_particle,
                    const uint32_t* offsets, uint32_t capacity, uint32_t* tile_keys, uint32_t* tile_vals, uint32_t* pos_particle);
 void launch_gather_particle_idx(hipStream_t s, uint32_t n, const uint32_t* sorted_pos, const uint32_t* pos_particle, uint32_t* out);
-void launch_tile_ranges(hipStream_t s, uint32_t n, uint32_t tile_mask, uint32_t num_tiles, const uint32_t* sorted_tile_keys,
-                        uint32_t* ranges, uint32_t* boundary_tile);
+void launch_tile_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32_t tile_mask, uint32_t num_tiles,
+                        const uint32_t* sorted_tile_keys, uint32_t* ranges, uint32_t* boundary_tile);
 void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                        const float* density12,
                        const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist, float* out_cnt,

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void gut_project_kernel(GutParams P, const flo
                                                           int32_t* __restrict__ visibility, uint32_t* __restrict__ num_visible) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const FramePoses& FP = frame_poses(P);
     bool has_tiles = false;
     uint32_t ntiles = 0;
     int vis = 0;
@@ -164,21 +165,21 @@ __global__ __launch_bounds__(256) void gut_project_kernel(GutParams P, const flo
         pos = mk3(a.x, a.y, a.z);
         const float opacity = a.w;
 
-        const float view_z = fmaf(P.poses.view_R[6], pos.x, fmaf(P.poses.view_R[7], pos.y, fmaf(P.poses.view_R[8], pos.z, P.poses.view_t[2])));
+        const float view_z = fmaf(FP.view_R[6], pos.x, fmaf(FP.view_R[7], pos.y, fmaf(FP.view_R[8], pos.z, FP.view_t[2])));
         view_z_keep = view_z;
         bool ok = (opacity >= P.min_alpha) && (view_z >= 0.2f);
         if (ok) {
             const m3 rotT = quat_wxyz_to_rotT(b.x, b.y, b.z, b.w);
             float spx[7], spy[7];
             int nvalid = 0;
-            nvalid += project_point_with_shutter(P.cam, P.poses, P.n_rs_iter, pos, P.ut_margin, spx[0], spy[0]) ? 1 : 0;
+            nvalid += project_point_with_shutter(P.cam, FP, P.n_rs_iter, pos, P.ut_margin, spx[0], spy[0]) ? 1 : 0;
             cx = spx[0] * P.ut_w0m; cy = spy[0] * P.ut_w0m;
             const f3 axes[3] = {rotT.r0 * (P.ut_delta * c.x), rotT.r1 * (P.ut_delta * c.y), rotT.r2 * (P.ut_delta * c.z)};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                nvalid += project_point_with_shutter(P.cam, P.poses, P.n_rs_iter, pos + axes[k], P.ut_margin, spx[k + 1], spy[k + 1]) ? 1 : 0;
+                nvalid += project_point_with_shutter(P.cam, FP, P.n_rs_iter, pos + axes[k], P.ut_margin, spx[k + 1], spy[k + 1]) ? 1 : 0;
                 cx += P.ut_wi * spx[k + 1]; cy += P.ut_wi * spy[k + 1];
-                nvalid += project_point_with_shutter(P.cam, P.poses, P.n_rs_iter, pos - axes[k], P.ut_margin, spx[k + 4], spy[k + 4]) ? 1 : 0;
+                nvalid += project_point_with_shutter(P.cam, FP, P.n_rs_iter, pos - axes[k], P.ut_margin, spx[k + 4], spy[k + 4]) ? 1 : 0;
                 cx += P.ut_wi * spx[k + 4]; cy += P.ut_wi * spy[k + 4];
             }
             ok = P.ut_require_all ? (nvalid == 7) : (nvalid > 0);
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void gut_project_kernel(GutParams P, const flo
             out.depth[i] = 0.f;
             out.depth_key[i] = 0xFFFFFFFFu;  // sorts behind every visible particle
         } else {
-            const f3 ray = pos - mk3(P.poses.s2w_t[0], P.poses.s2w_t[1], P.poses.s2w_t[2]);
+            const f3 ray = pos - mk3(FP.s2w_t[0], FP.s2w_t[1], FP.s2w_t[2]);
             const float dist = sqrtf(dot(ray, ray));
             const f3 dir = ray * (1.f / dist);
             float basis[16];
@@ -347,10 +348,11 @@ __global__ __launch_bounds__(256) void gut_gather_particle_idx_kernel(uint32_t n
 // ---------------------------------------------------------------------------------------------
 // K6: tile ranges — computeSortedTileRangeIndices (gutRenderer.cu:46-76)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gut_tile_ranges_kernel(uint32_t n, uint32_t tile_mask, uint32_t num_tiles,
-                                                              const uint32_t* __restrict__ sorted_tile_keys, uint2* __restrict__ ranges,
-                                                              uint32_t* __restrict__ boundary_tile) {
+__global__ __launch_bounds__(256) void gut_tile_ranges_kernel(uint32_t n_cap, const uint32_t* __restrict__ n_dev, uint32_t tile_mask,
+                                                              uint32_t num_tiles, const uint32_t* __restrict__ sorted_tile_keys,
+                                                              uint2* __restrict__ ranges, uint32_t* __restrict__ boundary_tile) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = n_dev ? min(n_cap, *n_dev) : n_cap;  // n_cap may be a capacity bound (speculative launch)
     if (k >= n) return;
     const uint32_t t = sorted_tile_keys[k] & tile_mask;
     const bool valid = t < num_tiles;
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
     const int rowlen = 3 * P.ncoef;
     const int nact = min((P.n_active + 1) * (P.n_active + 1), P.ncoef);
     float* rows = s_rows[wave];
+    const FramePoses& FP = frame_poses(P);
     const bool has = (i < P.N) && (tiles_count[i] != 0);
     const unsigned long long has_mask = __ballot(has);
     // stage in: one row per step, lanes across the row
@@ -515,7 +518,7 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
     float* myrow = rows + lane * kShStride;
     if (has) {
         const float4 a = density12[3 * (size_t)i];
-        const f3 v = mk3(a.x, a.y, a.z) - mk3(P.poses.s2w_t[0], P.poses.s2w_t[1], P.poses.s2w_t[2]);
+        const f3 v = mk3(a.x, a.y, a.z) - mk3(FP.s2w_t[0], FP.s2w_t[1], FP.s2w_t[2]);
         const float len = sqrtf(dot(v, v));
         const float ilen = 1.f / len;
         const f3 dir = v * ilen;
@@ -553,7 +556,22 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
         if (lane < rowlen) g_sph[(size_t)(wave_base + row) * rowlen + lane] = rows[row * kShStride + lane];
 }
 
+// frame poses from camera-to-world matrices in device memory (no host round trip, no stream sync)
+__global__ void gut_frame_poses_kernel(const float* __restrict__ T_start, const float* __restrict__ T_end, FramePoses* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float ps[7], pe[7];
+    c2w_to_world_to_sensor(T_start, ps);
+    if (T_end) c2w_to_world_to_sensor(T_end, pe);
+    else
+        for (int k = 0; k < 7; ++k) pe[k] = ps[k];
+    *out = make_frame_poses(ps, pe);
+}
+
 }  // namespace
+
+void launch_frame_poses(hipStream_t s, const float* T_start, const float* T_end, FramePoses* out) {
+    hipLaunchKernelGGL(gut_frame_poses_kernel, dim3(1), dim3(64), 0, s, T_start, T_end, out);
+}
 
 // ---------------------------------------------------------------------------------------------
 // launchers
@@ -571,9 +589,9 @@ void launch_expand(hipStream_t s, const GutParams& P, const GutProjected& proj, 
 void launch_gather_particle_idx(hipStream_t s, uint32_t n, const uint32_t* sorted_pos, const uint32_t* pos_particle, uint32_t* out) {
     if (n) hipLaunchKernelGGL(gut_gather_particle_idx_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, sorted_pos, pos_particle, out);
 }
-void launch_tile_ranges(hipStream_t s, uint32_t n, uint32_t tile_mask, uint32_t num_tiles, const uint32_t* sorted_tile_keys,
-                        uint32_t* ranges, uint32_t* boundary_tile) {
-    hipLaunchKernelGGL(gut_tile_ranges_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, tile_mask, num_tiles, sorted_tile_keys,
+void launch_tile_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32_t tile_mask, uint32_t num_tiles,
+                        const uint32_t* sorted_tile_keys, uint32_t* ranges, uint32_t* boundary_tile) {
+    hipLaunchKernelGGL(gut_tile_ranges_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, n_dev, tile_mask, num_tiles, sorted_tile_keys,
                        reinterpret_cast<uint2*>(ranges), boundary_tile);
 }
 

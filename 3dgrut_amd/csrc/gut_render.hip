@@ -46,8 +46,9 @@ __device__ __forceinline__ Ray init_ray(const GutParams& P, const float* __restr
     const size_t pix = (size_t)py * P.W + px;
     const f3 so = mk3(ray_o[3 * pix], ray_o[3 * pix + 1], ray_o[3 * pix + 2]);
     const f3 sd = mk3(ray_d[3 * pix], ray_d[3 * pix + 1], ray_d[3 * pix + 2]);
-    const float* R = P.poses.s2w_R;
-    r.o = apply_rows(R, P.poses.s2w_t, so);
+    const FramePoses& FP = frame_poses(P);
+    const float* R = FP.s2w_R;
+    r.o = apply_rows(R, FP.s2w_t, so);
     r.d = mk3(fmaf(R[0], sd.x, fmaf(R[1], sd.y, R[2] * sd.z)), fmaf(R[3], sd.x, fmaf(R[4], sd.y, R[5] * sd.z)),
               fmaf(R[6], sd.x, fmaf(R[7], sd.y, R[8] * sd.z)));
     const float lo = -1e6f, hi = 1e6f, big = 3.4028234663852886e+38f;

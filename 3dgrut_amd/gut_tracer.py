@@ -146,22 +146,28 @@ class Tracer:
             fd, dist, cnt, vis = native.trace(frame, particle_density, particle_features, ray_ori, ray_dir)
             ctx.save_for_backward(ray_ori, ray_dir, fd, dist, particle_density, particle_features)
             ctx.native, ctx.frame = native, frame
+            # the op hands out features and opacity as separate tensors (what render() returns), so that autograd does not
+            # have to route their gradients back through slice / contiguous nodes
+            feat = fd[..., :3].unsqueeze(0).contiguous()
+            opa = fd[..., 3:].unsqueeze(0).contiguous()
             ctx.mark_non_differentiable(cnt, vis)
             ctx.set_materialize_grads(False)
-            return fd, dist, cnt, vis
+            return feat, opa, dist, cnt, vis
 
         @staticmethod
-        def backward(ctx, g_fd, g_dist, _g_cnt, _g_vis):
+        def backward(ctx, g_feat, g_opa, g_dist, _g_cnt, _g_vis):
             ray_ori, ray_dir, fd, dist, particle_density, particle_features = ctx.saved_tensors
-            if g_fd is None:
-                g_fd = torch.zeros_like(fd)
+            H, W = fd.shape[0], fd.shape[1]
+            g_feat = fd.new_zeros((H, W, 3)) if g_feat is None else g_feat.reshape(H, W, 3)
+            g_opa = fd.new_zeros((H, W, 1)) if g_opa is None else g_opa.reshape(H, W, 1)
+            g_fd = torch.cat([g_feat, g_opa], dim=-1)
             # g_dist is None when the loss never touched pred_dist: the library then runs the variant without
             # hit-distance terms (autograd materialises zeros unless told otherwise, see set_materialize_grads)
             g_density, g_sph = ctx.native.trace_bwd(ctx.frame, particle_density, particle_features, ray_ori, ray_dir,
-                                                    fd, g_fd.contiguous(), dist, None if g_dist is None else g_dist.contiguous())
+                                                    fd, g_fd, dist, None if g_dist is None else g_dist.contiguous())
+            # views into the packed gradient, as the reference returns them (tracer.py:268-285): no copies
             g_pos, g_dns, g_rot, g_scl, _ = torch.split(g_density, [3, 1, 4, 3, 1], dim=1)
-            return (None, None, None, None, g_pos.contiguous(), g_rot.contiguous(), g_scl.contiguous(),
-                    g_dns.contiguous(), g_sph)
+            return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph
 
     def __init__(self, conf):
         self.device = "cuda"
@@ -178,31 +184,48 @@ class Tracer:
     def build_acc(self, gaussians, rebuild=True):
         pass  # no-op for 3DGUT (tracer.py:301-302)
 
+    def _constant_normals(self, like):
+        """normalize(ones) (tracer.py:345): a constant per resolution — built once instead of four elementwise passes per frame."""
+        key = (tuple(like.shape), like.device, like.dtype)
+        if getattr(self, "_normals_key", None) != key:
+            self._normals = torch.nn.functional.normalize(torch.ones_like(like), dim=3)
+            self._normals_key = key
+        return self._normals
+
     def render(self, gaussians, gpu_batch, train=False, frame_id=0):
         rays_o = gpu_batch.rays_ori if not isinstance(gpu_batch, dict) else gpu_batch["rays_ori"]
         rays_d = gpu_batch.rays_dir if not isinstance(gpu_batch, dict) else gpu_batch["rays_dir"]
-        cam, pose_start, pose_end = camera_from_batch(gpu_batch)
+        T0 = gpu_batch["T_to_world"] if isinstance(gpu_batch, dict) else gpu_batch.T_to_world
+        T1 = (gpu_batch.get("T_to_world_end") if isinstance(gpu_batch, dict) else getattr(gpu_batch, "T_to_world_end", None))
+        in_world = bool(gpu_batch.get("rays_in_world_space", False) if isinstance(gpu_batch, dict) else getattr(gpu_batch, "rays_in_world_space", False))
+        dev_poses = torch.is_tensor(T0) and T0.is_cuda and not in_world and (T1 is None or (torch.is_tensor(T1) and T1.is_cuda))
+        cam, pose_start, pose_end = camera_from_batch(gpu_batch, poses_on_device=dev_poses)
         H, W = int(rays_o.shape[1]), int(rays_o.shape[2])
         native = self.tracer_wrapper
         frame = native.make_frame(frame_id, gaussians.n_active_features, gaussians.num_gaussians, H, W, cam, pose_start, pose_end)
+        if dev_poses:  # the library derives the sensor poses on the GPU: no host round trip, no stream drain
+            t0 = T0.detach().reshape(-1, 4, 4)[0].to(torch.float32).contiguous()
+            t1 = None if T1 is None else T1.detach().reshape(-1, 4, 4)[0].to(torch.float32).contiguous()
+            frame.device_T_to_world = t0.data_ptr()
+            frame.device_T_to_world_end = None if t1 is None else t1.data_ptr()
+            frame._keepalive = (t0, t1)
         feats = gaussians.get_features()
         if feats.shape[1] != 3 * native.ncoef:
             raise ValueError(f"features have {feats.shape[1]} columns, expected {3 * native.ncoef} for SH degree "
                              f"{native.cfg.particle_radiance_sph_degree}")
-        pred_features_alpha, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
+        pred_features, pred_opacity, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
             native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(),
             gaussians.positions.contiguous(), gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(),
             gaussians.get_density().contiguous(), feats.contiguous())
-        d = getattr(gaussians, "ray_feature_dim", 3)
-        pred_features = pred_features_alpha[..., :d].unsqueeze(0).contiguous()
-        pred_opacity = pred_features_alpha[..., d:].unsqueeze(0).contiguous()
+        if getattr(gaussians, "ray_feature_dim", 3) != 3:
+            raise NotImplementedError("3dgrut_amd: only SH radiance features (ray_feature_dim = 3) are supported")
         timings = native.collect_times()
         return {
             "pred_features": pred_features,
             "pred_opacity": pred_opacity,
-            "pred_dist": pred_dist.unsqueeze(0).contiguous(),
-            "pred_normals": torch.nn.functional.normalize(torch.ones_like(pred_features), dim=3),
-            "hits_count": hits_count.unsqueeze(0).contiguous(),
+            "pred_dist": pred_dist.unsqueeze(0),
+            "pred_normals": self._constant_normals(pred_features),
+            "hits_count": hits_count.unsqueeze(0),
             "frame_time_ms": timings["forward_render"] if "forward_render" in timings else 0.0,
             "mog_visibility": mog_visibility,
         }

@@ -173,17 +173,16 @@ def main():
     g = syn.SimpleGaussians(d12, sph, device=dev)
     g_fd_np, g_dist_np = syn.upstream_grads(W, H)
     g_fd = torch.as_tensor(g_fd_np, device=dev)
-    g_dist = torch.as_tensor(g_dist_np, device=dev)
+    g_rgb, g_opa = g_fd[None, ..., :3].contiguous(), g_fd[None, ..., 3:].contiguous()
     flat = None
 
     def step():
         nonlocal flat
         g.zero_grad()
         out = tracer.render(g, batch, train=True)
-        fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
         # upstream gradients per SURVEY §8d: d_rgb, d_opacity ~ N(0,1)/P and no gradient into the hit distance
         # (training never back-props depth: trainer.py:677-748)
-        torch.autograd.backward([fd], [g_fd])
+        torch.autograd.backward([out["pred_features"], out["pred_opacity"]], [g_rgb, g_opa])
         if world > 1:  # one fused all-reduce of all Gaussian gradients ([N,59] fp32)
             grads = [p.grad for p in g.parameters()]
             flat = torch.cat([x.reshape(-1) for x in grads])

@@ -104,6 +104,11 @@ typedef struct GutFrame {
     GrutCamera camera;
     float      pose_start[7];      /* world->sensor, [t(3), q(x,y,z,w)] (tracer.py:359-380) */
     float      pose_end[7];
+    /* Optional: camera-to-world matrices (row-major 4x4 f32) in DEVICE memory.  When device_T_to_world is non-NULL the
+     * library derives the sensor poses on the GPU (same math as tracer.py:359-423) and ignores pose_start / pose_end, so
+     * the caller never has to read the pose back to the host (the reference's `.cpu()` there drains the stream). */
+    const float* device_T_to_world;
+    const float* device_T_to_world_end; /* NULL: static sensor (end = start) */
 } GutFrame;
 
 /* Measured work of the last forward (for the roofline byte model). */
