@@ -20,6 +20,13 @@ struct GrtHandle {
     float scene_host[6] = {0, 0, 0, 0, 0, 0};
     bool scene_host_valid = false;
     EventTimer fwd_timer, bwd_timer, build_timer;
+    DeviceBuffer log_pool, log_table, log_nbwd, log_state;  // forward hit log (grt_internal.hpp: GrtHitLog)
+    GrtHitLog log = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+    bool log_valid = false;        // the last forward recorded a log for exactly this frame geometry
+    int log_W = 0, log_H = 0;
+    uint32_t* log_state_host = nullptr;  // pinned copy of {chunks used, overflow} of the last logged forward
+    hipEvent_t log_event = nullptr;
+    bool log_event_pending = false;
     DeviceBuffer work_counters;  // instrumented launches (GRUT_GRT_COUNT=1): nodes, leaf tests, processed hits, rounds, inserts
     unsigned long long work_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -75,6 +82,12 @@ int grt_create(const GrtConfig* config, GrtHandle** handle) {
         delete h;
         return GRUT_ERR_RUNTIME;
     }
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->log_state_host), 64, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->log_event, hipEventDisableTiming) != hipSuccess) {
+        set_last_error("grt_create: pinned buffer / event allocation failed");
+        delete h;
+        return GRUT_ERR_RUNTIME;
+    }
     *handle = h;
     return GRUT_OK;
 }
@@ -83,8 +96,10 @@ void grt_destroy(GrtHandle* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
                             &h->sort_scratch, &h->nodes, &h->parent_internal, &h->parent_leaf, &h->counters, &h->dbg_ids, &h->dbg_count,
-                            &h->work_counters};
+                            &h->work_counters, &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state};
     for (DeviceBuffer* b : bufs) b->release();
+    if (h->log_state_host) (void)hipHostFree(h->log_state_host);
+    if (h->log_event) (void)hipEventDestroy(h->log_event);
     h->fwd_timer.destroy();
     h->bwd_timer.destroy();
     h->build_timer.destroy();
@@ -174,6 +189,37 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     GrtTraceParams P = trace_params(h, *frame);
     P.dbg_cap = dbg_cap;
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
+    // hit log for the backward (only when the caller announces one: GrtFrame::keep_hits_for_backward)
+    GrtHitLog log = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+    h->log_valid = false;
+    if (frame->keep_hits_for_backward && !dbg_ids) {
+        const uint32_t blocks = div_up((uint32_t)P.W, 8) * div_up((uint32_t)P.H, 8);
+        constexpr uint32_t kMaxRounds = 48;
+        uint32_t want = blocks * 10u;  // first guess; grown from the measured use of earlier frames
+        if (h->log_event_pending && hipEventQuery(h->log_event) == hipSuccess) {
+            h->log_event_pending = false;
+            const uint32_t used = h->log_state_host[0];
+            if (used + used / 2 > want) want = used + used / 2;
+        }
+        if (h->log.capacity_chunks > want) want = h->log.capacity_chunks;
+        if (const char* e = getenv("GRUT_GRT_LOG_CHUNKS")) want = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 1u;  // tests: force the overflow fallback
+        GRUT_CHECK(h->log_pool.ensure((size_t)want * 2 * kGrtMaxHits * 64 * 4));  // ids + box entry distances
+        GRUT_CHECK(h->log_table.ensure((size_t)blocks * kMaxRounds * 4, 1.25f));
+        GRUT_CHECK(h->log_nbwd.ensure((size_t)P.W * P.H * 4, 1.25f));
+        GRUT_CHECK(h->log_state.ensure(64));
+        h->log.pool = h->log_pool.as<uint32_t>();
+        h->log.table = h->log_table.as<uint32_t>();
+        h->log.nbwd = h->log_nbwd.as<uint32_t>();
+        h->log.state = h->log_state.as<uint32_t>();
+        h->log.capacity_chunks = want;
+        h->log.max_rounds = kMaxRounds;
+        GRUT_HIP(hipMemsetAsync(h->log.table, 0xFF, (size_t)blocks * kMaxRounds * 4, s));
+        GRUT_HIP(hipMemsetAsync(h->log.state, 0, 64, s));
+        log = h->log;
+        h->log_valid = true;
+        h->log_W = P.W;
+        h->log_H = P.H;
+    }
     unsigned long long* counters = nullptr;
     if (getenv("GRUT_GRT_COUNT")) {  // development aid: work statistics of the traversal, read back by grt_stats
         GRUT_CHECK(h->work_counters.ensure(64));
@@ -181,7 +227,12 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
         GRUT_HIP(hipMemsetAsync(counters, 0, 64, s));
     }
     grt_launch_trace_fwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
-                         out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters);
+                         out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters, log);
+    if (log.pool && !h->log_event_pending) {  // how much of the pool the frame used, read lazily by a later forward
+        GRUT_HIP(hipMemcpyAsync(h->log_state_host, log.state, 8, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipEventRecord(h->log_event, s));
+        h->log_event_pending = true;
+    }
     if (counters) {
         GRUT_HIP(hipMemcpyAsync(h->work_host, counters, 64, hipMemcpyDeviceToHost, s));
         GRUT_HIP(hipStreamSynchronize(s));
@@ -228,8 +279,10 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
                      grad_density && grad_particle_density && grad_particle_sph, "grt_backward: null buffer");
     const GrtTraceParams P = trace_params(h, *frame);
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
+    GrtHitLog log = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (h->log_valid && h->log_W == P.W && h->log_H == P.H) log = h->log;  // replay the hits the forward of this frame processed
     grt_launch_trace_bwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, features, density, hit_distance,
-                         grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph);
+                         grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph, log);
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
     return GRUT_OK;

@@ -42,6 +42,19 @@ struct GrtTraceParams {
     uint32_t dbg_cap;
 };
 
+// Log of the forward's processed hits, so that the backward replays them instead of traversing again.  One chunk =
+// the 16 x 64 particle ids a wave processed in one trace round ([slot][lane], 0xFFFFFFFF = not processed); a wave's
+// chunks are listed in `table[block][round]`.  `nbwd[ray]` = how many of a ray's processed hits the backward visits
+// (those with t < endT, referenceBwdOptix.cu:126-131).  If the pool or the table overflows, `state[1]` is raised and
+// the backward falls back to traversal.
+struct GrtHitLog {
+    uint32_t* pool;      // [capacity_chunks][2][16][64]: particle ids, then the ray's entry distance into each proxy box
+    uint32_t* table;     // [num_blocks][max_rounds]
+    uint32_t* nbwd;      // [W*H]
+    uint32_t* state;     // [0] = chunks allocated, [1] = overflow flag
+    uint32_t capacity_chunks, max_rounds;
+};
+
 // build stages
 void grt_launch_proxies(hipStream_t s, const GrtBuildParams& P, const float* pos, const float* rot, const float* scl, const float* dns,
                         float* inst, float* aabb, float* slack, uint32_t* scene_enc);
@@ -53,9 +66,10 @@ void grt_launch_refit(hipStream_t s, uint32_t N, const uint32_t* sorted_ids, con
 // trace
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
-                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters);
+                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters,
+                          const GrtHitLog& log);
 void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
-                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph);
+                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log);
 
 }  // namespace grut

@@ -302,6 +302,11 @@ struct HitBuffer {
 #pragma unroll
         for (int k = 0; k < kGrtMaxHits; ++k) { t[k] = 3.0e38f; id[k] = 0xFFFFFFFFu; }
     }
+    // park the sorted list in LDS ([slot][lane]) so that the per-hit code can loop over it instead of being unrolled 16x
+    __device__ __forceinline__ void store(float* __restrict__ st, uint32_t* __restrict__ sid, int lane) const {
+#pragma unroll
+        for (int k = 0; k < kGrtMaxHits; ++k) { st[k * 64 + lane] = t[k]; sid[k * 64 + lane] = id[k]; }
+    }
     // compare-exchange chain of __anyhit__ah (referenceOptix.cu:210-246), lexicographic in (distance, particle)
     __device__ __forceinline__ void insert(float ht, uint32_t hid) {
 #pragma unroll
@@ -490,8 +495,11 @@ __global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, Grt
                                                            float* __restrict__ out_dns, float* __restrict__ out_hit2,
                                                            float* __restrict__ out_nrm, float* __restrict__ out_cnt,
                                                            int32_t* __restrict__ visibility, uint32_t* __restrict__ dbg_ids,
-                                                           uint32_t* __restrict__ dbg_count, unsigned long long* __restrict__ counters) {
+                                                           uint32_t* __restrict__ dbg_count, unsigned long long* __restrict__ counters,
+                                                           GrtHitLog log) {
     __shared__ uint32_t s_stack[kGrtStackDepth];
+    __shared__ float s_hit_t[kGrtMaxHits * 64];
+    __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
     TraceCounters tc;
     const int lane = threadIdx.x;
     const int px = (int)blockIdx.x * 8 + (lane & 7), py = (int)blockIdx.y * 8 + (lane >> 3);
@@ -510,16 +518,41 @@ __global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, Grt
     uint32_t ndbg = 0;
     HitBuffer buf;
     bool running = in_image;
+    const uint32_t block = blockIdx.y * gridDim.x + blockIdx.x;
+    uint32_t round = 0, nproc = 0, nties = 0;  // processed hits, and how many of the last ones share t == tLast
     while (true) {
         running = running && (tLast <= tExit) && (T > P.min_transmittance);
         if (!__any(running)) break;
         trace_round<COUNT>(bvh, r, tLast + eps, tExit + eps, running, lane, s_stack, buf, tc);
         if (buf.id[0] == 0xFFFFFFFFu) running = false;
-        if (!running) continue;
-#pragma unroll
+        // hit log: one chunk per (wave, round)
+        uint32_t* chunk = nullptr;
+        if (log.pool) {
+            uint32_t c = 0xFFFFFFFFu;
+            if (lane == 0) {
+                if (round < log.max_rounds) c = atomicAdd(&log.state[0], 1u);
+                if (c >= log.capacity_chunks) { c = 0xFFFFFFFFu; log.state[1] = 1u; }
+                if (round < log.max_rounds) log.table[(size_t)block * log.max_rounds + round] = c;
+            }
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c != 0xFFFFFFFFu) chunk = log.pool + (size_t)c * (2 * kGrtMaxHits * 64) + lane;
+            round++;
+        }
+        buf.store(s_hit_t, s_hit_id, lane);
+#pragma unroll 1
         for (int i = 0; i < kGrtMaxHits; ++i) {
-            const uint32_t id = buf.id[i];
-            if ((id != 0xFFFFFFFFu) && (T > P.min_transmittance)) {
+            const uint32_t id = s_hit_id[i * 64 + lane];
+            const float hit_t = s_hit_t[i * 64 + lane];
+            const bool process = running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
+            if (!__any(process) && !chunk) break;  // ascending list: nothing further for any lane
+            if (chunk) {
+                chunk[i * 64] = process ? id : 0xFFFFFFFFu;
+                // the backward's trace interval ends at endT: it does not see a proxy whose box the ray enters later
+                if (process) chunk[(kGrtMaxHits + i) * 64] = __float_as_uint(candidate(bvh.inst + 12 * (size_t)id, r).tnear);
+            }
+            if (process) {
+                nproc++;
+                nties = (hit_t > tLast) ? 1u : (nties + 1u);
                 const Particle p = load_particle(density12, id);
                 const HitGeom g = hit_geometry<DEG>(P, p, r);
                 if (g.accept) {
@@ -542,7 +575,7 @@ __global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, Grt
                     visibility[id] = 1;  // benign race: every writer stores the same value (referenceOptix.cu:158-161)
                     cnt += 1.f;
                 }
-                tLast = fmaxf(tLast, buf.t[i]);
+                tLast = fmaxf(tLast, hit_t);
                 if (COUNT) tc.processed++;
                 if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = id;
                 ndbg++;
@@ -556,6 +589,10 @@ __global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, Grt
     if (P.normals) { out_nrm[3 * pix] = nrm.x; out_nrm[3 * pix + 1] = nrm.y; out_nrm[3 * pix + 2] = nrm.z; }
     if (P.hitcounts) out_cnt[pix] = cnt;
     if (dbg_count) dbg_count[pix] = ndbg;
+    if (log.pool) {  // the backward visits hits with t < endT = tLast + 1e-9: in fp32 that usually excludes the hits AT tLast
+        const float endT = fminf(tLast, tExit) + eps;
+        log.nbwd[pix] = (tLast < endT) ? nproc : nproc - nties;
+    }
     if (COUNT) {  // work statistics for GrtStats (instrumented launches only)
         atomicAdd(&counters[0], (unsigned long long)tc.nodes);
         atomicAdd(&counters[1], (unsigned long long)tc.leaf_tests);
@@ -585,6 +622,101 @@ __device__ __forceinline__ float4 matmul_bw_quat(f3 p, f3 g, float4 q) {
     return make_float4(dr, dx, dy, dz);
 }
 
+struct BwdRay {
+    f3 rad_fin, rad_grad;
+    float T_fin, depth_fin, T_grad, depth_grad;
+    f3 rad;          // running
+    float T, depth;  // running
+};
+// processHitBwd (gaussianParticles.cuh:468-731) for one ray and one particle, gradients added with atomics
+template <int DEG>
+__device__ __forceinline__ void process_hit_bwd(const GrtTraceParams& P, const RayW& r, const float basis[16], int nact, uint32_t id,
+                                                const float4* __restrict__ density12, const float* __restrict__ sph, BwdRay& st,
+                                                float* __restrict__ g_density12, float* __restrict__ g_sph) {
+    const f3 rad_fin = st.rad_fin, rad_grad = st.rad_grad;
+    const float T_fin = st.T_fin, depth_fin = st.depth_fin, T_grad = st.T_grad, depth_grad = st.depth_grad;
+    f3 rad = st.rad;
+    float T = st.T, depth = st.depth;
+    const Particle p = load_particle(density12, id);
+    const HitGeom g = hit_geometry<DEG>(P, p, r);
+    if (g.accept) {
+        const f3 gscl = p.scl;
+        const float pdot = -dot(g.grd, g.gro);
+        const f3 grdd = g.grd * pdot;
+        const f3 grds = gscl * grdd;
+        const float gsq = dot(grds, grds);
+        const float gdist = sqrtf(gsq);
+        const float weight = g.galpha * T;
+        const float nextT = (1.f - g.galpha) * T;
+        depth = fmaf(weight, gdist, depth);
+        const float resHitT = fmaxf(nextT <= P.min_transmittance ? 0.f : (depth_fin - depth) / nextT, 0.f);
+        const float galphaRayHitGrd = (gdist - resHitT) * T * depth_grad;
+        const f3 grdsRayHitGrd = gsq > 0.f ? grds * ((2.f * weight) / (2.f * gdist) * depth_grad) : mk3(0.f, 0.f, 0.f);
+        const f3 gsclRayHitGrd = grdd * grdsRayHitGrd;
+        const float grdScaledDot = dot(grdsRayHitGrd * gscl, g.grd);
+        const f3 grdRayHitGrd = gscl * grdsRayHitGrd * pdot - g.gro * grdScaledDot;
+        const f3 groRayHitGrd = g.grd * (-grdScaledDot);
+        const float resTrm = g.galpha < 0.999999f ? T_fin / (1.f - g.galpha) : T;
+        const float galphaRayDnsGrd = resTrm * -T_grad;
+
+        // radianceFromSpHBwd (:101-177)
+        const f3 gradu = sh_radiance(P, sph, id, basis);
+        const f3 grad = mk3(fmaxf(gradu.x, 0.f), fmaxf(gradu.y, 0.f), fmaxf(gradu.z, 0.f));
+        f3 dL = rad_grad * weight;
+        if (!(gradu.x > 0.f)) dL.x = 0.f;
+        if (!(gradu.y > 0.f)) dL.y = 0.f;
+        if (!(gradu.z > 0.f)) dL.z = 0.f;
+        float* gs = g_sph + (size_t)id * 3 * P.ncoef;
+        for (int k = 0; k < nact; ++k) {
+            atomicAdd(gs + 3 * k, basis[k] * dL.x);
+            atomicAdd(gs + 3 * k + 1, basis[k] * dL.y);
+            atomicAdd(gs + 3 * k + 2, basis[k] * dL.z);
+        }
+        rad = rad + grad * weight;
+        f3 resRad = mk3(0.f, 0.f, 0.f);
+        if (!(nextT <= P.min_transmittance)) {
+            const float inT = 1.f / nextT;
+            resRad = mk3(fmaxf((rad_fin.x - rad.x) * inT, 0.f), fmaxf((rad_fin.y - rad.y) * inT, 0.f), fmaxf((rad_fin.z - rad.z) * inT, 0.f));
+        }
+        const float common = galphaRayHitGrd + galphaRayDnsGrd + T * (grad.x - resRad.x) * rad_grad.x + T * (grad.y - resRad.y) * rad_grad.y +
+                             T * (grad.z - resRad.z) * rad_grad.z;
+        float* gd = g_density12 + 12 * (size_t)id;
+        atomicAdd(gd + 3, g.gres * common);
+        const float gresGrd = p.density * common;
+        const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, gresGrd);
+        const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
+        const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x,
+                              gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
+        const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z,
+                              gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
+        const f3 groTot = groGrd + groRayHitGrd;
+        const f3 is2 = g.giscl * g.giscl;
+        const f3 gsclGrdGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;
+        const f3 gposcrGrd = g.giscl * groTot;
+        const f3 gposcGrd = mul_cols(p.rotT, gposcrGrd);
+        const float4 grotGrdPoscr = matmul_bw_quat(g.gposc, gposcrGrd, p.quat);
+        atomicAdd(gd + 0, -gposcGrd.x); atomicAdd(gd + 1, -gposcGrd.y); atomicAdd(gd + 2, -gposcGrd.z);
+        // safe_normalize_bw
+        const f3 dn = grdGrd + grdRayHitGrd;
+        const float l2 = dot(g.grdu, g.grdu);
+        f3 grduGrd = mk3(0.f, 0.f, 0.f);
+        if (l2 > 0.f) {
+            const float il = 1.f / sqrtf(l2), il3 = il * il * il;
+            const float sdot = dot(dn, g.grdu);
+            grduGrd = dn * il - g.grdu * (il3 * sdot);
+        }
+        atomicAdd(gd + 8, gsclRayHitGrd.x + gsclGrdGro.x + (-g.rdr.x * is2.x) * grduGrd.x);
+        atomicAdd(gd + 9, gsclRayHitGrd.y + gsclGrdGro.y + (-g.rdr.y * is2.y) * grduGrd.y);
+        atomicAdd(gd + 10, gsclRayHitGrd.z + gsclGrdGro.z + (-g.rdr.z * is2.z) * grduGrd.z);
+        const f3 rdrGrd = g.giscl * grduGrd;
+        const float4 grotGrdRd = matmul_bw_quat(r.d, rdrGrd, p.quat);
+        atomicAdd(gd + 4, grotGrdPoscr.x + grotGrdRd.x); atomicAdd(gd + 5, grotGrdPoscr.y + grotGrdRd.y);
+        atomicAdd(gd + 6, grotGrdPoscr.z + grotGrdRd.z); atomicAdd(gd + 7, grotGrdPoscr.w + grotGrdRd.w);
+        T = nextT;
+    }
+    st.rad = rad; st.T = T; st.depth = depth;
+}
+
 template <int DEG>
 __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
                                                            const float* __restrict__ sph, const float* __restrict__ ray_o,
@@ -592,8 +724,12 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
                                                            const float* __restrict__ in_dns, const float* __restrict__ in_hit2,
                                                            const float* __restrict__ g_rad, const float* __restrict__ g_dns,
                                                            const float* __restrict__ g_hit, float* __restrict__ g_density12,
-                                                           float* __restrict__ g_sph) {
+                                                           float* __restrict__ g_sph, const uint32_t* __restrict__ log_state) {
     __shared__ uint32_t s_stack[kGrtStackDepth];
+    __shared__ float s_hit_t[kGrtMaxHits * 64];
+    __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
+    // with a hit log this kernel is only the fallback for a frame whose log overflowed
+    if (log_state && log_state[1] == 0u) return;
     const int lane = threadIdx.x;
     const int px = (int)blockIdx.x * 8 + (lane & 7), py = (int)blockIdx.y * 8 + (lane >> 3);
     const bool in_image = (px < P.W) && (py < P.H);
@@ -603,13 +739,17 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
     sh_basis16(P.sph_degree, r.d, basis);
     const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
 
-    const f3 rad_fin = mk3(in_rad[3 * pix], in_rad[3 * pix + 1], in_rad[3 * pix + 2]);
-    const float T_fin = 1.f - in_dns[pix], depth_fin = in_hit2[2 * pix], max_hit = in_hit2[2 * pix + 1];
-    const f3 rad_grad = mk3(g_rad[3 * pix], g_rad[3 * pix + 1], g_rad[3 * pix + 2]);
-    const float T_grad = -g_dns[pix], depth_grad = g_hit ? g_hit[pix] : 0.f;
-
-    f3 rad = mk3(0.f, 0.f, 0.f);
-    float T = 1.f, depth = 0.f;
+    BwdRay ray_state;
+    ray_state.rad_fin = mk3(in_rad[3 * pix], in_rad[3 * pix + 1], in_rad[3 * pix + 2]);
+    ray_state.T_fin = 1.f - in_dns[pix];
+    ray_state.depth_fin = in_hit2[2 * pix];
+    const float max_hit = in_hit2[2 * pix + 1];
+    ray_state.rad_grad = mk3(g_rad[3 * pix], g_rad[3 * pix + 1], g_rad[3 * pix + 2]);
+    ray_state.T_grad = -g_dns[pix];
+    ray_state.depth_grad = g_hit ? g_hit[pix] : 0.f;
+    ray_state.rad = mk3(0.f, 0.f, 0.f);
+    ray_state.T = 1.f;
+    ray_state.depth = 0.f;
     float tEnter, tExit;
     scene_interval(bvh.scene, r, tEnter, tExit);
     constexpr float eps = 1e-9f;
@@ -623,89 +763,66 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
         TraceCounters tc;
         trace_round<false>(bvh, r, startT + eps, endT, running, lane, s_stack, buf, tc);
         if (buf.id[0] == 0xFFFFFFFFu) running = false;
-        if (!running) continue;
-#pragma unroll
+        buf.store(s_hit_t, s_hit_id, lane);
+#pragma unroll 1
         for (int i = 0; i < kGrtMaxHits; ++i) {
-            const uint32_t id = buf.id[i];
-            if (id == 0xFFFFFFFFu) continue;
-            const Particle p = load_particle(density12, id);
-            const HitGeom g = hit_geometry<DEG>(P, p, r);
-            if (g.accept) {
-                const f3 gscl = p.scl;
-                const float pdot = -dot(g.grd, g.gro);
-                const f3 grdd = g.grd * pdot;
-                const f3 grds = gscl * grdd;
-                const float gsq = dot(grds, grds);
-                const float gdist = sqrtf(gsq);
-                const float weight = g.galpha * T;
-                const float nextT = (1.f - g.galpha) * T;
-                depth = fmaf(weight, gdist, depth);
-                const float resHitT = fmaxf(nextT <= P.min_transmittance ? 0.f : (depth_fin - depth) / nextT, 0.f);
-                const float galphaRayHitGrd = (gdist - resHitT) * T * depth_grad;
-                const f3 grdsRayHitGrd = gsq > 0.f ? grds * ((2.f * weight) / (2.f * gdist) * depth_grad) : mk3(0.f, 0.f, 0.f);
-                const f3 gsclRayHitGrd = grdd * grdsRayHitGrd;
-                const float grdScaledDot = dot(grdsRayHitGrd * gscl, g.grd);
-                const f3 grdRayHitGrd = gscl * grdsRayHitGrd * pdot - g.gro * grdScaledDot;
-                const f3 groRayHitGrd = g.grd * (-grdScaledDot);
-                const float resTrm = g.galpha < 0.999999f ? T_fin / (1.f - g.galpha) : T;
-                const float galphaRayDnsGrd = resTrm * -T_grad;
-
-                // radianceFromSpHBwd (:101-177)
-                const f3 gradu = sh_radiance(P, sph, id, basis);
-                const f3 grad = mk3(fmaxf(gradu.x, 0.f), fmaxf(gradu.y, 0.f), fmaxf(gradu.z, 0.f));
-                f3 dL = rad_grad * weight;
-                if (!(gradu.x > 0.f)) dL.x = 0.f;
-                if (!(gradu.y > 0.f)) dL.y = 0.f;
-                if (!(gradu.z > 0.f)) dL.z = 0.f;
-                float* gs = g_sph + (size_t)id * 3 * P.ncoef;
-                for (int k = 0; k < nact; ++k) {
-                    atomicAdd(gs + 3 * k, basis[k] * dL.x);
-                    atomicAdd(gs + 3 * k + 1, basis[k] * dL.y);
-                    atomicAdd(gs + 3 * k + 2, basis[k] * dL.z);
-                }
-                rad = rad + grad * weight;
-                f3 resRad = mk3(0.f, 0.f, 0.f);
-                if (!(nextT <= P.min_transmittance)) {
-                    const float inT = 1.f / nextT;
-                    resRad = mk3(fmaxf((rad_fin.x - rad.x) * inT, 0.f), fmaxf((rad_fin.y - rad.y) * inT, 0.f), fmaxf((rad_fin.z - rad.z) * inT, 0.f));
-                }
-                const float common = galphaRayHitGrd + galphaRayDnsGrd + T * (grad.x - resRad.x) * rad_grad.x + T * (grad.y - resRad.y) * rad_grad.y +
-                                     T * (grad.z - resRad.z) * rad_grad.z;
-                float* gd = g_density12 + 12 * (size_t)id;
-                atomicAdd(gd + 3, g.gres * common);
-                const float gresGrd = p.density * common;
-                const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, gresGrd);
-                const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
-                const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x,
-                                      gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
-                const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z,
-                                      gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
-                const f3 groTot = groGrd + groRayHitGrd;
-                const f3 is2 = g.giscl * g.giscl;
-                const f3 gsclGrdGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;
-                const f3 gposcrGrd = g.giscl * groTot;
-                const f3 gposcGrd = mul_cols(p.rotT, gposcrGrd);
-                const float4 grotGrdPoscr = matmul_bw_quat(g.gposc, gposcrGrd, p.quat);
-                atomicAdd(gd + 0, -gposcGrd.x); atomicAdd(gd + 1, -gposcGrd.y); atomicAdd(gd + 2, -gposcGrd.z);
-                // safe_normalize_bw
-                const f3 dn = grdGrd + grdRayHitGrd;
-                const float l2 = dot(g.grdu, g.grdu);
-                f3 grduGrd = mk3(0.f, 0.f, 0.f);
-                if (l2 > 0.f) {
-                    const float il = 1.f / sqrtf(l2), il3 = il * il * il;
-                    const float sdot = dot(dn, g.grdu);
-                    grduGrd = dn * il - g.grdu * (il3 * sdot);
-                }
-                atomicAdd(gd + 8, gsclRayHitGrd.x + gsclGrdGro.x + (-g.rdr.x * is2.x) * grduGrd.x);
-                atomicAdd(gd + 9, gsclRayHitGrd.y + gsclGrdGro.y + (-g.rdr.y * is2.y) * grduGrd.y);
-                atomicAdd(gd + 10, gsclRayHitGrd.z + gsclGrdGro.z + (-g.rdr.z * is2.z) * grduGrd.z);
-                const f3 rdrGrd = g.giscl * grduGrd;
-                const float4 grotGrdRd = matmul_bw_quat(r.d, rdrGrd, p.quat);
-                atomicAdd(gd + 4, grotGrdPoscr.x + grotGrdRd.x); atomicAdd(gd + 5, grotGrdPoscr.y + grotGrdRd.y);
-                atomicAdd(gd + 6, grotGrdPoscr.z + grotGrdRd.z); atomicAdd(gd + 7, grotGrdPoscr.w + grotGrdRd.w);
-                T = nextT;
+            const uint32_t id = s_hit_id[i * 64 + lane];
+            const bool process = running && (id != 0xFFFFFFFFu);
+            if (!__any(process)) break;  // ascending list: nothing further for any lane
+            if (process) {
+                process_hit_bwd<DEG>(P, r, basis, nact, id, density12, sph, ray_state, g_density12, g_sph);
+                startT = fmaxf(startT, s_hit_t[i * 64 + lane]);
             }
-            startT = fmaxf(startT, buf.t[i]);
+        }
+    }
+}
+
+// backward from the forward's hit log: same per-hit math in the same order, no traversal
+template <int DEG>
+__global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
+                                                            const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                            const float* __restrict__ in_rad, const float* __restrict__ in_dns,
+                                                            const float* __restrict__ in_hit2, const float* __restrict__ g_rad,
+                                                            const float* __restrict__ g_dns, const float* __restrict__ g_hit,
+                                                            float* __restrict__ g_density12, float* __restrict__ g_sph, GrtHitLog log,
+                                                            const float* __restrict__ scene) {
+    if (log.state[1] != 0u) return;  // the log overflowed: the traversal kernel handles this frame
+    const int lane = threadIdx.x;
+    const int px = (int)blockIdx.x * 8 + (lane & 7), py = (int)blockIdx.y * 8 + (lane >> 3);
+    const bool in_image = (px < P.W) && (py < P.H);
+    const size_t pix = in_image ? (size_t)py * P.W + px : 0;
+    const RayW r = make_ray(P, ray_o, ray_d, pix);
+    float basis[16];
+    sh_basis16(P.sph_degree, r.d, basis);
+    const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
+    BwdRay st;
+    st.rad_fin = mk3(in_rad[3 * pix], in_rad[3 * pix + 1], in_rad[3 * pix + 2]);
+    st.T_fin = 1.f - in_dns[pix];
+    st.depth_fin = in_hit2[2 * pix];
+    st.rad_grad = mk3(g_rad[3 * pix], g_rad[3 * pix + 1], g_rad[3 * pix + 2]);
+    st.T_grad = -g_dns[pix];
+    st.depth_grad = g_hit ? g_hit[pix] : 0.f;
+    st.rad = mk3(0.f, 0.f, 0.f);
+    st.T = 1.f;
+    st.depth = 0.f;
+    uint32_t remaining = in_image ? log.nbwd[pix] : 0u;
+    float tEnter, tExit;
+    scene_interval(scene, r, tEnter, tExit);
+    const float endT = fminf(in_hit2[2 * pix + 1], tExit) + 1e-9f;
+    const uint32_t block = blockIdx.y * gridDim.x + blockIdx.x;
+    for (uint32_t round = 0; round < log.max_rounds; ++round) {
+        if (!__any(remaining > 0u)) break;
+        const uint32_t c = log.table[(size_t)block * log.max_rounds + round];
+        if (c == 0xFFFFFFFFu) break;
+        const uint32_t* chunk = log.pool + (size_t)c * (2 * kGrtMaxHits * 64) + lane;
+#pragma unroll 1
+        for (int i = 0; i < kGrtMaxHits; ++i) {
+            const uint32_t id = chunk[i * 64];
+            if (id != 0xFFFFFFFFu && remaining > 0u) {
+                remaining--;
+                const float tnear = __uint_as_float(chunk[(kGrtMaxHits + i) * 64]);
+                if (tnear <= endT) process_hit_bwd<DEG>(P, r, basis, nact, id, density12, sph, st, g_density12, g_sph);
+            }
         }
     }
 }
@@ -746,25 +863,31 @@ void grt_launch_refit(hipStream_t s, uint32_t N, const uint32_t* sorted_ids, con
 
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
-                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters) {
+                          float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters,
+                          const GrtHitLog& log) {
     const dim3 grid(div_up((uint32_t)P.W, 8), div_up((uint32_t)P.H, 8));
     if (counters) {
         GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, true>), grid, dim3(64), 0, s, P, bvh,
                                                          reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns,
-                                                         out_hit2, out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters));
+                                                         out_hit2, out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters, log));
     } else {
         GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, false>), grid, dim3(64), 0, s, P, bvh,
                                                          reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns,
-                                                         out_hit2, out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters));
+                                                         out_hit2, out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters, log));
     }
 }
 void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
-                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph) {
+                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log) {
     const dim3 grid(div_up((uint32_t)P.W, 8), div_up((uint32_t)P.H, 8));
+    if (log.pool) {  // replay the forward's hit log; the traversal kernel below then only runs if the log overflowed
+        GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_replay_bwd_kernel<D_>), grid, dim3(64), 0, s, P,
+                                                         reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad,
+                                                         g_dns, g_hit, g_density12, g_sph, log, bvh.scene));
+    }
     GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_>), grid, dim3(64), 0, s, P, bvh,
                                                      reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns,
-                                                     g_hit, g_density12, g_sph));
+                                                     g_hit, g_density12, g_sph, log.pool ? log.state : nullptr));
 }
 
 }  // namespace grut

@@ -192,6 +192,7 @@ class Tracer:
         if feats.shape[1] != 3 * native.ncoef:
             raise ValueError(f"features have {feats.shape[1]} columns, expected {3 * native.ncoef}")
         frame = native.make_frame(frame_id, gaussians.n_active_features, self._min_transmittance, gaussians.num_gaussians, H, W, T)
+        frame.keep_hits_for_backward = int(bool(train) and torch.is_grad_enabled())
         pred_features, pred_opacity, pred_dist, pred_normals, hits_count, mog_visibility = Tracer._Autograd.apply(
             native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(), gaussians.positions.contiguous(),
             gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(), gaussians.get_density().contiguous(), feats.contiguous())

@@ -204,6 +204,8 @@ typedef struct GrtFrame {
     uint32_t num_particles;
     int32_t  width, height;
     float    ray_to_world[12];    /* row-major 3x4 */
+    int32_t  keep_hits_for_backward; /* forward: record the processed hits so that grt_backward of the same frame
+                                      * replays them instead of traversing again (identical results) */
 } GrtFrame;
 
 typedef struct GrtStats {
