@@ -52,6 +52,17 @@ def byte_model(N, Nv, I, P, tile_bits, sph_coeffs=16):
     }
 
 
+def valu_fraction(stage, kernel_ms):
+    """Fraction of the VALU issue slots the dominant kernel used, from the committed SQ_INSTS_VALU count of the same launch."""
+    path = os.path.join(ROOT, "profiles", "sq_insts_valu.json")
+    try:
+        insts = json.load(open(path))[stage]
+    except Exception:
+        return None
+    simd_cycles = 1024 * 2.4e9 * kernel_ms * 1e-3
+    return {"insts_valu": insts, "cycles_per_inst": 4, "frac": insts * 4 / simd_cycles, "source": "profiles/sq_insts_valu.json"}
+
+
 def cpu_baseline(seconds_budget=20.0):
     """Oracle (CPU restatement of the reference) on a bounded sample: C1-sized frames, fwd+bwd."""
     import oracle
@@ -244,6 +255,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"gut_{dom}", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": model[dom], "kernel_ms": stages[dom]},
+            # the compositing sweeps are bound by fp32 VALU issue, not by HBM: wave-level VALU instructions per
+            # launch (rocprofv3 SQ_INSTS_VALU, profiles/) x 4 cycles / (1024 SIMDs x 2.4 GHz) against the measured kernel time
+            "valu": valu_fraction(dom, stages[dom]),
             "stages_ms": stages,
             "stage_bytes": model,
             "frame_algorithmic_gb": total_bytes / 1e9,
