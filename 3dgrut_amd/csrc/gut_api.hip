@@ -74,8 +74,8 @@ struct GutHandle {
 static int validate_config(const GutConfig& c) {
     GRUT_REQUIRE(c.ut_require_all_sigma_points_valid == 0, "ut_require_all_sigma_points_valid must be false (threedgut.cuh:78)");
     GRUT_REQUIRE(c.particle_radiance_sph_degree >= 0 && c.particle_radiance_sph_degree <= 3, "sph degree must be in [0,3]");
-    if (c.k_buffer_size != 0) {
-        set_last_error("k_buffer_size=%d: only the unsorted renderer (k_buffer_size=0) is implemented", c.k_buffer_size);
+    if (c.k_buffer_size != 0 && c.k_buffer_size != 4 && c.k_buffer_size != 8 && c.k_buffer_size != 16) {
+        set_last_error("k_buffer_size=%d: the hit buffer is instantiated for 0 (unsorted), 4, 8 and 16 entries", c.k_buffer_size);
         return GRUT_ERR_UNSUPPORTED;
     }
     const int d = c.particle_kernel_degree;
@@ -316,8 +316,12 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_RANGES, s, slot));
         // K7 compositing
         GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_FWD, s, slot));
-        launch_render_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, proj.rgb, ray_origin,
-                          ray_direction, out_feat_density, out_hit_distance, out_hit_count, h->checkpoints, true);
+        if (P.k_buffer > 0)
+            launch_render_k_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, proj.rgb, ray_origin,
+                                ray_direction, out_feat_density, out_hit_distance, out_hit_count);
+        else
+            launch_render_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, proj.rgb, ray_origin,
+                              ray_direction, out_feat_density, out_hit_distance, out_hit_count, h->checkpoints, true);
         GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_FWD, s, slot));
         return GRUT_OK;
     };
@@ -374,6 +378,25 @@ int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float
     slots.flag = nullptr;
     slots.pos_particle = h->pos_particle.as<uint32_t>();
     const size_t I = h->num_intersections;
+    if (P.k_buffer > 0) {
+        // sorted mode: per-hit atomics like the reference (gutKBufferRenderer.cuh:158-198), then the projection backward
+        GRUT_CHECK(h->g_rgb.ensure((size_t)P.N * 12, 1.25f));
+        GRUT_HIP(hipMemsetAsync(h->g_rgb.ptr, 0, (size_t)P.N * 12, s));
+        GRUT_HIP(hipMemsetAsync(grad_particle_density, 0, (size_t)P.N * 48, s));
+        if (I > 0) {
+            GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_BWD, s, slot));
+            launch_render_k_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_pos, h->pos_particle.as<uint32_t>(), particle_density, proj.rgb, ray_origin,
+                                ray_direction, feat_density, grad_feat_density, hit_distance, grad_hit_distance, grad_particle_density,
+                                h->g_rgb.as<float>());
+            GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_BWD, s, slot));
+        }
+        GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));
+        launch_project_bwd(s, P, proj, particle_density, particle_sph, h->g_rgb.as<float>(), grad_particle_density, grad_particle_sph);
+        GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT_BWD, s, slot));
+        GRUT_HIP(hipGetLastError());
+        if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
+        return GRUT_OK;
+    }
     if (I > 0) {
         // one slot per (tile entry, half tile); only flagged slots are ever read, so only the flags are cleared
         GRUT_CHECK(h->grad_partial.ensure(2 * I * (size_t)slots.stride * 4, 1.3f));

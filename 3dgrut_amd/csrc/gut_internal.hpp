@@ -77,6 +77,14 @@ void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
 void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const float* density12,
                        const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* dist,
                        const float* g_dist, const GutGradSlots& slots, const GutCheckpoints& ck);
+void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                         const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
+                         float* out_cnt);
+void launch_render_k_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                         const float* density12, const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd,
+                         const float* dist, const float* g_dist, float* g_density12, float* g_rgb);
+void launch_project_bwd(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
+                        const float* g_rgb, float* g_density12, float* g_sph);
 void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
                           const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, float* g_density12, float* g_sph);
 

@@ -595,6 +595,11 @@ void launch_tile_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32
                        reinterpret_cast<uint2*>(ranges), boundary_tile);
 }
 
+void launch_project_bwd(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
+                        const float* g_rgb, float* g_density12, float* g_sph) {
+    hipLaunchKernelGGL(gut_project_bwd_kernel, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
+                       reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_density12, g_sph);
+}
 void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
                           const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, float* g_density12, float* g_sph) {
     const dim3 grid(div_up(P.N, 256)), block(256);

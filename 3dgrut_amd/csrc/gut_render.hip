@@ -579,6 +579,258 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const u
         render_bwd_sweep<DEG, HAS_GDIST, false>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, px);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K > 0 ("sorted") compositing — HitParticleKBufferT<K> + evalKBuffer (gutKBufferRenderer.cuh:62-122, 273-352) and its
+// backward processHitParticle<Backward> (:158-198; Slang reverse mode of the back-to-front lerp form,
+// shRadiativeParticles.slang:210-256, gaussianParticles.slang:420-479).
+// Every pixel keeps the K nearest pending hits (by hitT) in registers and composites the nearest one when the buffer is
+// full, so neighbouring pixels pop DIFFERENT particles at the same step: there is nothing to reduce across the wave, and
+// the gradient is accumulated per hit with atomics exactly like the reference does in this mode.  One pixel per lane,
+// one wave64 per 16x4 strip; correctness-first kernel (the unsorted K = 0 path above is the tuned one).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float response_rt(int deg, float g) {
+    switch (deg) {
+    case 8: return particle_response<8>(g);
+    case 5: return particle_response<5>(g);
+    case 4: return particle_response<4>(g);
+    case 3: return particle_response<3>(g);
+    case 1: return particle_response<1>(g);
+    case 0: return particle_response<0>(g);
+    default: return particle_response<2>(g);
+    }
+}
+__device__ __forceinline__ float response_grd_rt(int deg, float g, float gres, float gresGrd) {
+    switch (deg) {
+    case 8: return particle_response_grd<8>(g, gres, gresGrd);
+    case 5: return particle_response_grd<5>(g, gres, gresGrd);
+    case 4: return particle_response_grd<4>(g, gres, gresGrd);
+    case 3: return particle_response_grd<3>(g, gres, gresGrd);
+    case 1: return particle_response_grd<1>(g, gres, gresGrd);
+    case 0: return particle_response_grd<0>(g, gres, gresGrd);
+    default: return particle_response_grd<2>(g, gres, gresGrd);
+    }
+}
+
+template <int K>
+struct KBuffer {   // ascending in hitT: slot 0 = nearest pending hit, empty slots hold hitT = -1 at the front
+    float hitT[K], alpha[K];
+    uint32_t idx[K];
+    int num;
+    __device__ __forceinline__ void clear() {
+        num = 0;
+#pragma unroll
+        for (int i = 0; i < K; ++i) { hitT[i] = -1.f; alpha[i] = 0.f; idx[i] = 0xFFFFFFFFu; }
+    }
+    // HitParticleKBufferT::insert (:76-91); the caller has already consumed slot 0 when the buffer was full
+    __device__ __forceinline__ void insert(float t, float a, uint32_t id) {
+#pragma unroll
+        for (int i = K - 1; i >= 0; --i) {
+            if (t > hitT[i]) {
+                const float tt = hitT[i], aa = alpha[i];
+                const uint32_t ii = idx[i];
+                hitT[i] = t; alpha[i] = a; idx[i] = id;
+                t = tt; a = aa; id = ii;
+            }
+        }
+    }
+};
+
+struct KFwdState {
+    float T, D, Cr, Cg, Cb, cnt;
+};
+struct KBwdState {
+    float T;                 // forward running transmittance (termination only)
+    float Tb, Db, gT, gD;    // "behind" values and running upstream gradients
+    f3 Cb, gC;
+};
+
+__device__ __forceinline__ void k_process_fwd(const GutParams& P, const float* __restrict__ rgb, float hitT, float alpha, uint32_t idx,
+                                              KFwdState& s, bool& alive) {
+    const float w = alpha * s.T;
+    s.D = fmaf(hitT, w, s.D);
+    s.T *= (1.f - alpha);
+    if (w > 0.f) {
+        s.Cr = fmaf(fmaxf(rgb[3 * (size_t)idx], 0.f), w, s.Cr);
+        s.Cg = fmaf(fmaxf(rgb[3 * (size_t)idx + 1], 0.f), w, s.Cg);
+        s.Cb = fmaf(fmaxf(rgb[3 * (size_t)idx + 2], 0.f), w, s.Cb);
+        s.cnt += 1.f;
+    }
+    if (s.T < P.min_transmittance) alive = false;
+}
+
+// gradient of sum_ij (b_i e_j) rotT_ij(q) w.r.t. q = (r,x,y,z)  (matmul_bw_quat, mathUtils.cuh:458-521)
+__device__ __forceinline__ float4 quat_outer_contract(f3 b, f3 e, float4 q) {
+    const float r = 2.f * q.x, x = 2.f * q.y, y = 2.f * q.z, z = 2.f * q.w;
+    const float m00 = b.x * e.x, m01 = b.x * e.y, m02 = b.x * e.z, m10 = b.y * e.x, m11 = b.y * e.y, m12 = b.y * e.z, m20 = b.z * e.x,
+                m21 = b.z * e.y, m22 = b.z * e.z;
+    const float s01 = m01 + m10, s02 = m02 + m20, s12 = m12 + m21, a01 = m01 - m10, a02 = m20 - m02, a12 = m12 - m21;
+    return make_float4(z * a01 + y * a02 + x * a12, y * s01 + z * s02 + r * a12 - 2.f * x * (m11 + m22),
+                       x * s01 + z * s12 + r * a02 - 2.f * y * (m00 + m22), x * s02 + y * s12 + r * a01 - 2.f * z * (m00 + m11));
+}
+
+__device__ __forceinline__ void k_process_bwd(const GutParams& P, const Ray& ray, const float4* __restrict__ density12, const float* __restrict__ rgb,
+                                              float hitT, float alpha, uint32_t idx, KBwdState& s, bool& alive, float* __restrict__ g_density12,
+                                              float* __restrict__ g_rgb) {
+    if (alpha > 0.f) {
+        const float w = 1.f / (1.f - alpha);
+        const f3 feat = mk3(fmaxf(rgb[3 * (size_t)idx], 0.f), fmaxf(rgb[3 * (size_t)idx + 1], 0.f), fmaxf(rgb[3 * (size_t)idx + 2], 0.f));
+        s.Cb = (s.Cb - feat * alpha) * w;
+        float dalpha = (feat.x - s.Cb.x) * s.gC.x + (feat.y - s.Cb.y) * s.gC.y + (feat.z - s.Cb.z) * s.gC.z;
+        float* gr = g_rgb + 3 * (size_t)idx;
+        atomicAdd(gr, alpha * s.gC.x); atomicAdd(gr + 1, alpha * s.gC.y); atomicAdd(gr + 2, alpha * s.gC.z);
+        s.gC = s.gC * (1.f - alpha);
+        s.Tb *= w;
+        s.Db = (s.Db - hitT * alpha) * w;
+        dalpha += (hitT - s.Db) * s.gD - s.Tb * s.gT;
+        const float ddepth = alpha * s.gD;
+        s.gD *= (1.f - alpha);
+        s.gT *= (1.f - alpha);
+
+        const float4 a = density12[3 * (size_t)idx], q = density12[3 * (size_t)idx + 1], sc = density12[3 * (size_t)idx + 2];
+        const m3 rotT = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
+        const f3 gscl = mk3(sc.x, sc.y, sc.z), giscl = mk3(1.f / sc.x, 1.f / sc.y, 1.f / sc.z);
+        const f3 gposc = ray.o - mk3(a.x, a.y, a.z);
+        const f3 gposcr = mul_rows(rotT, gposc);
+        const f3 gro = giscl * gposcr;
+        const f3 rdr = mul_rows(rotT, ray.d);
+        const f3 grdu = giscl * rdr;
+        const float l2 = dot(grdu, grdu);
+        const float il = 1.f / sqrtf(l2);
+        const f3 grd = grdu * il;
+        const f3 gcrod = cross(grd, gro);
+        const float gray = dot(gcrod, gcrod);
+        const float gres = response_rt(P.degree, gray);
+        float dres = 0.f, ddens = 0.f;  // reverse mode of min(MaxAlpha, .): only the smaller argument receives the gradient
+        if (gres * a.w < P.max_alpha) { dres = a.w * dalpha; ddens = gres * dalpha; }
+        const float grayGrd = response_grd_rt(P.degree, gray, gres, dres);
+        const float pdot = -dot(grd, gro);
+        const f3 grdd = grd * pdot;
+        const f3 grds = gscl * grdd;
+        const float gsq = dot(grds, grds);
+        const float gdist = sqrtf(gsq);
+        const f3 grdsGrd = gsq > 0.f ? grds * (ddepth / gdist) : mk3(0.f, 0.f, 0.f);
+        const f3 gsclHit = grdd * grdsGrd;
+        const float sdot = dot(grdsGrd * gscl, grd);
+        const f3 grdHit = gscl * grdsGrd * pdot - gro * sdot;
+        const f3 groHit = grd * (-sdot);
+        const f3 gcrodGrd = gcrod * (2.f * grayGrd);
+        const f3 grdGrd = mk3(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
+        const f3 groGrd = mk3(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+        const f3 groTot = groGrd + groHit;
+        const f3 is2 = giscl * giscl;
+        const f3 gsclGro = mk3(-gposcr.x * is2.x, -gposcr.y * is2.y, -gposcr.z * is2.z) * groTot;
+        const f3 gposcrGrd = giscl * groTot;
+        const f3 gposcGrd = mul_cols(rotT, gposcrGrd);
+        const f3 dn = grdGrd + grdHit;
+        const f3 grduGrd = dn * il - grdu * (il * il * il * dot(dn, grdu));   // normalize backward
+        const f3 sclGrd = gsclHit + gsclGro + mk3(-rdr.x * is2.x, -rdr.y * is2.y, -rdr.z * is2.z) * grduGrd;
+        const float4 gq1 = quat_outer_contract(gposcrGrd, gposc, q), gq2 = quat_outer_contract(giscl * grduGrd, ray.d, q);
+        float* gd = g_density12 + 12 * (size_t)idx;
+        atomicAdd(gd + 0, -gposcGrd.x); atomicAdd(gd + 1, -gposcGrd.y); atomicAdd(gd + 2, -gposcGrd.z); atomicAdd(gd + 3, ddens);
+        atomicAdd(gd + 4, gq1.x + gq2.x); atomicAdd(gd + 5, gq1.y + gq2.y); atomicAdd(gd + 6, gq1.z + gq2.z); atomicAdd(gd + 7, gq1.w + gq2.w);
+        atomicAdd(gd + 8, sclGrd.x); atomicAdd(gd + 9, sclGrd.y); atomicAdd(gd + 10, sclGrd.z);
+    }
+    s.T *= (1.f - alpha);
+    if (s.T < P.min_transmittance) alive = false;
+}
+
+template <int K, bool BWD>
+__global__ __launch_bounds__(64) void gut_render_k_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+                                                          const float4* __restrict__ density12, const float* __restrict__ rgb,
+                                                          const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                          float4* __restrict__ out_fd, float* __restrict__ out_dist, float* __restrict__ out_cnt,
+                                                          const float4* __restrict__ g_fd, const float* __restrict__ g_dist,
+                                                          float* __restrict__ g_density12, float* __restrict__ g_rgb) {
+    __shared__ float4 s_rec[64 * 5];
+    // strip -> (tile, strip-in-tile) with all four strips of a tile on one XCD
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t tile = ((slot >> 2) << 3) + xcd, strip = slot & 3u;
+    if (tile >= (uint32_t)(P.gx * P.gy)) return;
+    const int lane = threadIdx.x;
+    const int px = (int)(tile % P.gx) * 16 + (lane & 15);
+    const int py = (int)(tile / P.gx) * 16 + (int)strip * 4 + (lane >> 4);
+    const Ray ray = init_ray(P, ray_o, ray_d, px, py);
+    bool alive = ray.valid;
+    const size_t pix = ray.valid ? (size_t)py * P.W + px : 0;
+    KFwdState fs{1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    KBwdState bs;
+    bs.T = 1.f; bs.Tb = 0.f; bs.Db = 0.f; bs.gT = 0.f; bs.gD = 0.f; bs.Cb = mk3(0.f, 0.f, 0.f); bs.gC = mk3(0.f, 0.f, 0.f);
+    if (BWD && alive) {   // initializeBackwardRay (rayPayloadBackward.cuh:30-73); out_* hold the forward results here
+        const float4 f = out_fd[pix], g = g_fd[pix];
+        bs.Cb = mk3(f.x, f.y, f.z); bs.gC = mk3(g.x, g.y, g.z);
+        bs.Tb = 1.f - f.w; bs.gT = -g.w;
+        bs.Db = out_dist[pix]; bs.gD = g_dist ? g_dist[pix] : 0.f;
+    }
+    KBuffer<K> kb;
+    kb.clear();
+    const uint2 range = ranges[tile];
+    for (uint32_t b = range.x; b < range.y; b += 64) {
+        if (!__any(alive)) break;
+        {   // stage up to 64 entries
+            const RawEntry e = load_entry(b + lane, range.y, lists, density12, rgb);
+            float4 r0 = make_float4(1.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 1.f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
+            float4 r3 = make_float4(1.f, 1.f, 1.f, 0.f), r4 = make_float4(__uint_as_float(0xFFFFFFFFu), 0.f, 0.f, 0.f);
+            if (e.idx != 0xFFFFFFFFu) {
+                const m3 rt = quat_wxyz_to_rotT(e.q.x, e.q.y, e.q.z, e.q.w);
+                const float ix = 1.f / e.s.x, iy = 1.f / e.s.y, iz = 1.f / e.s.z;
+                r0 = make_float4(rt.r0.x * ix, rt.r0.y * ix, rt.r0.z * ix, e.a.x);
+                r1 = make_float4(rt.r1.x * iy, rt.r1.y * iy, rt.r1.z * iy, e.a.y);
+                r2 = make_float4(rt.r2.x * iz, rt.r2.y * iz, rt.r2.z * iz, e.a.z);
+                r3 = make_float4(e.s.x, e.s.y, e.s.z, e.a.w);
+                r4.x = __uint_as_float(e.idx);
+            }
+            float4* rec = &s_rec[lane * 5];
+            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4;
+        }
+        __syncthreads();
+        const int n = (int)min(64u, range.y - b);
+        for (int j = 0; j < n; ++j) {
+            if (!__any(alive)) break;
+            const float4* rec = &s_rec[j * 5];
+            const uint32_t idx = __float_as_uint(rec[4].x);
+            if (idx == 0xFFFFFFFFu) break;   // padding closes the list (gutKBufferRenderer.cuh:312-315)
+            if (alive) {
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+                const f3 dl = ray.o - mk3(q0.w, q1.w, q2.w);
+                const f3 gro = mk3(dot(mk3(q0.x, q0.y, q0.z), dl), dot(mk3(q1.x, q1.y, q1.z), dl), dot(mk3(q2.x, q2.y, q2.z), dl));
+                const f3 grdu = mk3(dot(mk3(q0.x, q0.y, q0.z), ray.d), dot(mk3(q1.x, q1.y, q1.z), ray.d), dot(mk3(q2.x, q2.y, q2.z), ray.d));
+                const f3 grd = grdu * (1.f / sqrtf(dot(grdu, grdu)));
+                const f3 gc = cross(grd, gro);
+                const float resp = response_rt(P.degree, dot(gc, gc));
+                const float alpha = fminf(P.max_alpha, resp * q3.w);
+                if ((resp > P.min_response) && (alpha > P.min_alpha)) {
+                    const f3 grds = mk3(q3.x, q3.y, q3.z) * grd * (-dot(grd, gro));
+                    const float hitT = sqrtf(dot(grds, grds));
+                    if ((hitT > ray.tmin) && (hitT < ray.tmax)) {
+                        if (kb.num == K) {   // full: composite the nearest pending hit, then take its slot
+                            if (BWD) k_process_bwd(P, ray, density12, rgb, kb.hitT[0], kb.alpha[0], kb.idx[0], bs, alive, g_density12, g_rgb);
+                            else k_process_fwd(P, rgb, kb.hitT[0], kb.alpha[0], kb.idx[0], fs, alive);
+                            kb.hitT[0] = -1.f;
+                        } else {
+                            kb.num++;
+                        }
+                        kb.insert(hitT, alpha, idx);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // drain what is left, nearest first (:343-351)
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        if (alive && i >= K - kb.num) {
+            if (BWD) k_process_bwd(P, ray, density12, rgb, kb.hitT[i], kb.alpha[i], kb.idx[i], bs, alive, g_density12, g_rgb);
+            else k_process_fwd(P, rgb, kb.hitT[i], kb.alpha[i], kb.idx[i], fs, alive);
+        }
+    }
+    if (!BWD && ray.valid) {
+        out_fd[pix] = make_float4(fs.Cr, fs.Cg, fs.Cb, 1.f - fs.T);
+        out_dist[pix] = fs.D;
+        if (P.hitcounts) out_cnt[pix] = fs.cnt;
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -640,6 +892,35 @@ void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
                                                           reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
                                                           g_dist, slots, ck));
     }
+}
+
+static uint32_t strip_grid(const GutParams& P) {
+    const uint32_t tiles = (uint32_t)(P.gx * P.gy);
+    return ((tiles + 7u) & ~7u) * 4u;
+}
+#define GRUT_DISPATCH_K(KK, ...)                               \
+    switch (KK) {                                              \
+    case 4: { constexpr int K_ = 4; __VA_ARGS__; } break;      \
+    case 8: { constexpr int K_ = 8; __VA_ARGS__; } break;      \
+    default: { constexpr int K_ = 16; __VA_ARGS__; } break;    \
+    }
+void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                         const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
+                         float* out_cnt) {
+    const EntryLists lists{sorted_pos, pos_particle};
+    GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_k_kernel<K_, false>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                   reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), rgb,
+                                                   ray_o, ray_d, reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, nullptr, nullptr, nullptr,
+                                                   nullptr));
+}
+void launch_render_k_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                         const float* density12, const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd,
+                         const float* dist, const float* g_dist, float* g_density12, float* g_rgb) {
+    const EntryLists lists{sorted_pos, pos_particle};
+    GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_k_kernel<K_, true>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                   reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), rgb,
+                                                   ray_o, ray_d, reinterpret_cast<float4*>(const_cast<float*>(fd)), const_cast<float*>(dist), nullptr,
+                                                   reinterpret_cast<const float4*>(g_fd), g_dist, g_density12, g_rgb));
 }
 
 }  // namespace grut

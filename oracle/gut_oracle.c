@@ -572,6 +572,83 @@ void orc_gut_process_hit_bwd(int degree, real min_response, real min_alpha, real
     state5[0] = r.T; state5[1] = r.feat.x; state5[2] = r.feat.y; state5[3] = r.feat.z; state5[4] = r.hitT;
 }
 
+/* --------------------------------------------------------------------------------------
+ * K > 0 ("sorted") backward per hit: processHitParticle<Backward> (gutKBufferRenderer.cuh:158-198) =
+ * particleFeaturesIntegrateBwd (shRadiativeParticles.slang:210-256) + particleDensityProcessHitBwdToBuffer
+ * (gaussianParticles.slang:420-479): Slang reverse-mode of the BACK-TO-FRONT lerp form, the ray state being un-blended
+ * by 1/(1-alpha) as the hits are visited front to back.  Differences to the K = 0 hand-written chain: no clamping of the
+ * residuals, and the gradient does not pass through alpha = min(MaxParticleAlpha, .) when the clamp is active.
+ * state: Tb, Cb, Db = "behind" values (start at the forward results); gT, gC, gD = running upstream gradients. */
+typedef struct {
+    real Tb; v3 Cb; real Db;
+    real gT; v3 gC; real gD;
+} orc_kbwd_ray;
+
+static void process_hit_bwd_k(const GutConfig* cfg, v3 ro, v3 rd, const orc_particle* p, v3 feat, real alpha, real hitT,
+                              orc_kbwd_ray* r, real* g_density12, real* g_feat) {
+    for (int k = 0; k < 12; ++k) g_density12[k] = 0;
+    g_feat[0] = g_feat[1] = g_feat[2] = 0;
+    if (!(alpha > 0)) return;
+    const real w = 1 / (1 - alpha);
+    /* features: I_front = lerp(I_behind, f, alpha) */
+    r->Cb = v3_scale(v3_sub(r->Cb, v3_scale(feat, alpha)), w);
+    real dalpha = (feat.x - r->Cb.x) * r->gC.x + (feat.y - r->Cb.y) * r->gC.y + (feat.z - r->Cb.z) * r->gC.z;
+    g_feat[0] = alpha * r->gC.x; g_feat[1] = alpha * r->gC.y; g_feat[2] = alpha * r->gC.z;
+    r->gC = v3_scale(r->gC, 1 - alpha);
+    /* density: T_out = T_in (1 - alpha), D_front = lerp(D_behind, depth, alpha) */
+    r->Tb *= w;
+    r->Db = (r->Db - hitT * alpha) * w;
+    dalpha += (hitT - r->Db) * r->gD - r->Tb * r->gT;
+    const real ddepth = alpha * r->gD;
+    r->gD *= (1 - alpha);
+    r->gT *= (1 - alpha);
+
+    /* hit(): recompute the canonical ray (gaussianParticles.slang:96-110, 207-242) */
+    const v3 gscl = p->scl;
+    const v3 giscl = v3_make(1 / gscl.x, 1 / gscl.y, 1 / gscl.z);
+    const v3 gposc = v3_sub(ro, p->pos);
+    const v3 gposcr = v3_mul_rows(gposc, &p->rotT);
+    const v3 gro = v3_mul(giscl, gposcr);
+    const v3 rdr = v3_mul_rows(rd, &p->rotT);
+    const v3 grdu = v3_mul(giscl, rdr);
+    const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
+    const v3 gcrod = v3_cross(grd, gro);
+    const real gray = v3_dot(gcrod, gcrod);
+    const real gres = particle_response(cfg->particle_kernel_degree, gray);
+    /* alpha = min(MaxAlpha, gres * density): reverse-mode of min passes the gradient to the smaller argument */
+    real dres = 0, ddens = 0;
+    if (gres * p->density < (real)cfg->particle_kernel_max_alpha) { dres = p->density * dalpha; ddens = gres * dalpha; }
+    g_density12[3] = ddens;
+    const real grayGrd = particle_response_grd(cfg->particle_kernel_degree, gray, gres, dres);
+    /* depth = |scale * grd * dot(grd, -gro)| */
+    const real pdot = v3_dot(grd, v3_scale(gro, -1));
+    const v3 grdd = v3_scale(grd, pdot);
+    const v3 grds = v3_mul(gscl, grdd);
+    const real gsq = v3_dot(grds, grds);
+    const real gdist = r_sqrt(gsq);
+    const v3 grdsGrd = gsq > 0 ? v3_scale(grds, ddepth / gdist) : v3_make(0, 0, 0);
+    const v3 gsclHit = v3_mul(grdd, grdsGrd);
+    const real sdot = v3_dot(v3_mul(grdsGrd, gscl), grd);
+    const v3 grdHit = v3_sub(v3_scale(v3_mul(gscl, grdsGrd), pdot), v3_scale(gro, sdot));
+    const v3 groHit = v3_scale(grd, -sdot);
+    /* grayDist = |cross(grd, gro)|^2 */
+    const v3 gcrodGrd = v3_scale(gcrod, 2 * grayGrd);
+    const v3 grdGrd = v3_make(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
+    const v3 groGrd = v3_make(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+    const v3 groTot = v3_add(groGrd, groHit);
+    const v3 gsclGro = v3_mul(v3_make(-gposcr.x / (gscl.x * gscl.x), -gposcr.y / (gscl.y * gscl.y), -gposcr.z / (gscl.z * gscl.z)), groTot);
+    const v3 gposcrGrd = v3_mul(giscl, groTot);
+    const v3 gposcGrd = matmul_bw_vec(&p->rotT, gposcrGrd);
+    const v4 gq1 = matmul_bw_quat(gposc, gposcrGrd, p->quat);
+    g_density12[0] = -gposcGrd.x; g_density12[1] = -gposcGrd.y; g_density12[2] = -gposcGrd.z;
+    const v3 grduGrd = v3_safe_normalize_bw(grdu, v3_add(grdGrd, grdHit));
+    const v3 sclGrd = v3_add(v3_add(gsclHit, gsclGro),
+                             v3_mul(v3_make(-rdr.x / (gscl.x * gscl.x), -rdr.y / (gscl.y * gscl.y), -rdr.z / (gscl.z * gscl.z)), grduGrd));
+    g_density12[8] = sclGrd.x; g_density12[9] = sclGrd.y; g_density12[10] = sclGrd.z;
+    const v4 gq2 = matmul_bw_quat(rd, v3_mul(giscl, grduGrd), p->quat);
+    g_density12[4] = gq1.x + gq2.x; g_density12[5] = gq1.y + gq2.y; g_density12[6] = gq1.z + gq2.z; g_density12[7] = gq1.w + gq2.w;
+}
+
 /* SH KATs: models/gaussianParticles.cuh:68-100 (radianceFromSpH) */
 void orc_sh_radiance(int deg, int max_deg, const real* coeffs, const real* dir3, int clamped, real* out3) {
     (void)max_deg;
@@ -681,12 +758,71 @@ int orc_gut_render_fwd(const GutConfig* cfg, int width, int height, const real* 
  * render backward (K=0, SH branch) — gutKBufferRenderer.cuh:642-716, rayPayloadBackward.cuh:30-73
  * g_density12 [N,12] and g_rgb [N,3] are accumulated into (must arrive zeroed).
  * ------------------------------------------------------------------------------------ */
+/* evalKBuffer<Backward> (gutKBufferRenderer.cuh:273-352): the forward's k-buffer walk, each popped hit differentiated */
+static int render_bwd_kbuffer(const GutConfig* cfg, int width, int height, const real* pose_start7, const real* pose_end7,
+                              const real* density12, const real* rgb, const uint32_t* sorted_idx, const uint32_t* tile_ranges,
+                              const real* ray_o, const real* ray_d, const real* fd, const real* g_fd, const real* dist, const real* g_dist,
+                              real* g_density12, real* g_rgb) {
+    const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
+    const int gx = tile_grid_dim(width);
+    const int K = cfg->k_buffer_size;
+    if (K > ORC_MAX_K) return -1;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int pix = 0; pix < width * height; ++pix) {
+        const int x = pix % width, y = pix / width;
+        const orc_ray ray = init_ray(&fp, ray_o + 3 * (size_t)pix, ray_d + 3 * (size_t)pix);
+        if (!ray.valid) continue;
+        const uint32_t tile = (uint32_t)((y / ORC_TILE) * gx + (x / ORC_TILE));
+        const uint32_t beg = tile_ranges[2 * tile], end = tile_ranges[2 * tile + 1];
+        orc_kbwd_ray r;
+        r.Cb = v3_make(fd[4 * (size_t)pix], fd[4 * (size_t)pix + 1], fd[4 * (size_t)pix + 2]);
+        r.gC = v3_make(g_fd[4 * (size_t)pix], g_fd[4 * (size_t)pix + 1], g_fd[4 * (size_t)pix + 2]);
+        r.Tb = 1 - fd[4 * (size_t)pix + 3];
+        r.gT = -g_fd[4 * (size_t)pix + 3];
+        r.Db = dist[pix]; r.gD = g_dist[pix];
+        real T = 1; int alive = 1;
+        orc_hit kbuf[ORC_MAX_K]; int nhits = 0;
+        for (int k = 0; k < K; ++k) { kbuf[k].idx = ORC_INVALID_IDX; kbuf[k].hitT = -1; kbuf[k].alpha = 0; }
+#define ORC_KBWD_PROCESS(h)                                                                                             \
+        do {                                                                                                                \
+            const orc_particle pp = load_particle(density12 + 12 * (size_t)(h).idx);                                        \
+            const real* c = rgb + 3 * (size_t)(h).idx;                                                                      \
+            real gd[12], gf[3];                                                                                             \
+            process_hit_bwd_k(cfg, ray.o, ray.d, &pp, v3_make(r_max(c[0], 0), r_max(c[1], 0), r_max(c[2], 0)), (h).alpha, (h).hitT, &r, gd, gf); \
+            for (int k = 0; k < 11; ++k) if (gd[k] != 0) { _Pragma("omp atomic") g_density12[12 * (size_t)(h).idx + k] += gd[k]; }             \
+            for (int k = 0; k < 3; ++k) if (gf[k] != 0) { _Pragma("omp atomic") g_rgb[3 * (size_t)(h).idx + k] += gf[k]; }                     \
+            T *= (1 - (h).alpha);                                                                                           \
+            if (T < (real)cfg->min_transmittance) alive = 0;                                                                \
+        } while (0)
+        for (uint32_t e = beg; e < end && alive; ++e) {
+            const uint32_t idx = sorted_idx[e];
+            if (idx == ORC_INVALID_IDX) break;
+            const orc_particle p = load_particle(density12 + 12 * (size_t)idx);
+            orc_hit h; h.idx = idx; h.hitT = -1; h.alpha = 0;
+            if (density_hit(cfg, ray.o, ray.d, &p, &h.alpha, &h.hitT) && h.hitT > ray.tmin && h.hitT < ray.tmax) {
+                const int full = nhits == K;
+                if (full) {
+                    ORC_KBWD_PROCESS(kbuf[0]);
+                    kbuf[0].hitT = -1;
+                } else nhits++;
+                for (int i = K - 1; i >= 0; --i)
+                    if (h.hitT > kbuf[i].hitT) { const orc_hit t = kbuf[i]; kbuf[i] = h; h = t; }
+            }
+        }
+        for (int i = 0; alive && i < nhits; ++i) ORC_KBWD_PROCESS(kbuf[K - nhits + i]);
+#undef ORC_KBWD_PROCESS
+    }
+    return 0;
+}
+
 int orc_gut_render_bwd(const GutConfig* cfg, int width, int height, const real* pose_start7, const real* pose_end7,
                        const real* density12, const real* rgb, const uint32_t* sorted_idx, const uint32_t* tile_ranges,
                        const real* ray_o, const real* ray_d,
                        const real* fd, const real* g_fd, const real* dist, const real* g_dist,
                        real* g_density12, real* g_rgb) {
-    if (cfg->k_buffer_size != 0) return -1;
+    if (cfg->k_buffer_size != 0)
+        return render_bwd_kbuffer(cfg, width, height, pose_start7, pose_end7, density12, rgb, sorted_idx, tile_ranges, ray_o, ray_d, fd, g_fd, dist,
+                                  g_dist, g_density12, g_rgb);
     const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
     const int gx = tile_grid_dim(width);
 #pragma omp parallel for schedule(dynamic, 16)

@@ -90,9 +90,9 @@ def test_gut_per_hit_live_against_reference_library():
         assert acc == acc_ref and _close(st, st_ref)
 
 
-def _fd_check(scene, n_probe=12, eps=1e-6):
+def _fd_check(scene, n_probe=12, eps=1e-6, **cfg_kw):
     """Oracle analytic gradient vs central differences of the oracle forward, float64, scalar loss <g, image>."""
-    cfg = oracle.default_gut_config()
+    cfg = oracle.default_gut_config(**cfg_kw)
     W, H = scene["W"], scene["H"]
     g_fd, g_dist = syn.upstream_grads(W, H)
     g_fd = g_fd.astype(np.float64) * W * H
@@ -130,6 +130,22 @@ def test_oracle_backward_is_the_gradient_of_oracle_forward():
     bad = [e for e in errs if e[0] > 2e-4 * max(colmax[e[3]], 1e-12) + 1e-7]
     # a probe may straddle a threshold (hit accepted on one side only): allow a small fraction of outliers
     assert len(bad) <= max(2, len(errs) // 20), bad[:5]
+
+
+def test_oracle_kbuffer_backward_is_the_gradient_of_kbuffer_forward():
+    """K = 16 "sorted" mode (gutKBufferRenderer.cuh:62-122, 158-198): the restated Slang reverse-mode of the back-to-front
+    lerp form against finite differences of the k-buffer forward."""
+    scene = make_scene(n=300, width=32, height=32, median_scale=0.12, max_density=0.6)
+    errs, colmax = _fd_check(scene, k_buffer_size=16)
+    bad = [e for e in errs if e[0] > 2e-4 * max(colmax[e[3]], 1e-12) + 1e-7]
+    assert len(bad) <= max(2, len(errs) // 20), bad[:5]
+    # and the sorted forward differs from the unsorted one only where centre-depth order and hit order disagree
+    cfg0, cfg16 = oracle.default_gut_config(), oracle.default_gut_config(k_buffer_size=16)
+    a = oracle.gut_forward(cfg0, scene["cam"], scene["pose_start"], scene["pose_end"], 3, scene["density12"], scene["sph"], *scene["rays"])
+    b = oracle.gut_forward(cfg16, scene["cam"], scene["pose_start"], scene["pose_end"], 3, scene["density12"], scene["sph"], *scene["rays"])
+    d = np.abs(a["feat_density"] - b["feat_density"]).max()
+    assert 0 < d < 0.5
+    np.testing.assert_allclose(a["feat_density"][..., 3], b["feat_density"][..., 3], atol=2e-5)  # opacity is order independent
 
 
 def test_binning_restatement_invariants():
