@@ -777,7 +777,19 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
     }
 }
 
-// backward from the forward's hit log: same per-hit math in the same order, no traversal
+// backward from the forward's hit log — no traversal, and the gradient traffic is aggregated per wave.
+// The reference issues 11 + 48 atomicAdds per hit and ray (gaussianParticles.cuh:468-731); the 64 rays of an 8x8 block
+// mostly hit the same particles, so per trace round the wave works in two phases:
+//   A. every lane walks ITS hits in order and advances its ray state (transmittance, radiance, depth), leaving per hit
+//      the five scalars the gradient is linear in: dL/d alpha ("common"), weight * dL/d depth, and the clamp-masked
+//      weight * dL/d radiance;
+//   B. particle by particle (taken from the first lane that still has one pending), every lane that holds the same
+//      particle at the same or a neighbouring slot joins in: the particle record is fetched once for the wave, each lane
+//      turns its five scalars into the 11 + 48 gradient terms, the terms are reduce-scattered over the wave with DPP
+//      and ONE atomic set per (wave, particle) goes to memory.  Lanes that hold the particle at a farther slot simply
+//      lead (or join) a later group: matching quality only affects how much is aggregated, never the result.
+constexpr int kAggWindow = 2;   // slots on either side of the leader's slot that are searched for the same particle
+
 template <int DEG>
 __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
@@ -786,6 +798,8 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
                                                             const float* __restrict__ g_dns, const float* __restrict__ g_hit,
                                                             float* __restrict__ g_density12, float* __restrict__ g_sph, GrtHitLog log,
                                                             const float* __restrict__ scene) {
+    __shared__ uint32_t s_id[kGrtMaxHits * 64];
+    __shared__ float s_sc[5 * kGrtMaxHits * 64];   // [scalar][slot][lane]: common, weight*depth_grad, dL.xyz
     if (log.state[1] != 0u) return;  // the log overflowed: the traversal kernel handles this frame
     const int lane = threadIdx.x;
     const int px = (int)blockIdx.x * 8 + (lane & 7), py = (int)blockIdx.y * 8 + (lane >> 3);
@@ -795,35 +809,165 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
     float basis[16];
     sh_basis16(P.sph_degree, r.d, basis);
     const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
-    BwdRay st;
-    st.rad_fin = mk3(in_rad[3 * pix], in_rad[3 * pix + 1], in_rad[3 * pix + 2]);
-    st.T_fin = 1.f - in_dns[pix];
-    st.depth_fin = in_hit2[2 * pix];
-    st.rad_grad = mk3(g_rad[3 * pix], g_rad[3 * pix + 1], g_rad[3 * pix + 2]);
-    st.T_grad = -g_dns[pix];
-    st.depth_grad = g_hit ? g_hit[pix] : 0.f;
-    st.rad = mk3(0.f, 0.f, 0.f);
-    st.T = 1.f;
-    st.depth = 0.f;
+    const f3 rad_fin = mk3(in_rad[3 * pix], in_rad[3 * pix + 1], in_rad[3 * pix + 2]);
+    const float T_fin = 1.f - in_dns[pix], depth_fin = in_hit2[2 * pix];
+    const f3 rad_grad = mk3(g_rad[3 * pix], g_rad[3 * pix + 1], g_rad[3 * pix + 2]);
+    const float T_grad = -g_dns[pix], depth_grad = g_hit ? g_hit[pix] : 0.f;
+    f3 rad = mk3(0.f, 0.f, 0.f);
+    float T = 1.f, depth = 0.f;
     uint32_t remaining = in_image ? log.nbwd[pix] : 0u;
     float tEnter, tExit;
     scene_interval(scene, r, tEnter, tExit);
     const float endT = fminf(in_hit2[2 * pix + 1], tExit) + 1e-9f;
     const uint32_t block = blockIdx.y * gridDim.x + blockIdx.x;
+    constexpr int S = kGrtMaxHits * 64;
     for (uint32_t round = 0; round < log.max_rounds; ++round) {
         if (!__any(remaining > 0u)) break;
         const uint32_t c = log.table[(size_t)block * log.max_rounds + round];
         if (c == 0xFFFFFFFFu) break;
         const uint32_t* chunk = log.pool + (size_t)c * (2 * kGrtMaxHits * 64) + lane;
+        // ---- phase A: per-lane state walk ----
+        uint32_t pending = 0u;
 #pragma unroll 1
         for (int i = 0; i < kGrtMaxHits; ++i) {
-            const uint32_t id = chunk[i * 64];
+            uint32_t id = chunk[i * 64];
+            float common = 0.f, wd = 0.f;
+            f3 dL = mk3(0.f, 0.f, 0.f);
+            bool contributes = false;
             if (id != 0xFFFFFFFFu && remaining > 0u) {
                 remaining--;
                 const float tnear = __uint_as_float(chunk[(kGrtMaxHits + i) * 64]);
-                if (tnear <= endT) process_hit_bwd<DEG>(P, r, basis, nact, id, density12, sph, st, g_density12, g_sph);
+                if (tnear <= endT) {
+                    const Particle p = load_particle(density12, id);
+                    const HitGeom g = hit_geometry<DEG>(P, p, r);
+                    if (g.accept) {
+                        const float pdot = -dot(g.grd, g.gro);
+                        const f3 grds = p.scl * g.grd * pdot;
+                        const float gdist = sqrtf(dot(grds, grds));
+                        const float weight = g.galpha * T;
+                        const float nextT = (1.f - g.galpha) * T;
+                        depth = fmaf(weight, gdist, depth);
+                        const float resHitT = fmaxf(nextT <= P.min_transmittance ? 0.f : (depth_fin - depth) / nextT, 0.f);
+                        const float galphaRayHitGrd = (gdist - resHitT) * T * depth_grad;
+                        const float resTrm = g.galpha < 0.999999f ? T_fin / (1.f - g.galpha) : T;
+                        const float galphaRayDnsGrd = resTrm * -T_grad;
+                        const f3 gradu = sh_radiance(P, sph, id, basis);
+                        const f3 grad = mk3(fmaxf(gradu.x, 0.f), fmaxf(gradu.y, 0.f), fmaxf(gradu.z, 0.f));
+                        dL = rad_grad * weight;
+                        if (!(gradu.x > 0.f)) dL.x = 0.f;
+                        if (!(gradu.y > 0.f)) dL.y = 0.f;
+                        if (!(gradu.z > 0.f)) dL.z = 0.f;
+                        rad = rad + grad * weight;
+                        f3 resRad = mk3(0.f, 0.f, 0.f);
+                        if (!(nextT <= P.min_transmittance)) {
+                            const float inT = 1.f / nextT;
+                            resRad = mk3(fmaxf((rad_fin.x - rad.x) * inT, 0.f), fmaxf((rad_fin.y - rad.y) * inT, 0.f), fmaxf((rad_fin.z - rad.z) * inT, 0.f));
+                        }
+                        common = galphaRayHitGrd + galphaRayDnsGrd + T * (grad.x - resRad.x) * rad_grad.x + T * (grad.y - resRad.y) * rad_grad.y +
+                                 T * (grad.z - resRad.z) * rad_grad.z;
+                        wd = weight * depth_grad;
+                        T = nextT;
+                        contributes = true;
+                    }
+                }
+            }
+            if (!contributes) id = 0xFFFFFFFFu;
+            else pending |= (1u << i);
+            s_id[i * 64 + lane] = id;
+            s_sc[0 * S + i * 64 + lane] = common;
+            s_sc[1 * S + i * 64 + lane] = wd;
+            s_sc[2 * S + i * 64 + lane] = dL.x;
+            s_sc[3 * S + i * 64 + lane] = dL.y;
+            s_sc[4 * S + i * 64 + lane] = dL.z;
+        }
+        __syncthreads();
+        // ---- phase B: particle-major aggregation ----
+#pragma unroll 1
+        for (int sl = 0; sl < kGrtMaxHits; ++sl) {
+            while (true) {
+                const unsigned long long m = __ballot((pending >> sl) & 1u);
+                if (!m) break;
+                const int leader = __ffsll((long long)m) - 1;
+                const uint32_t pid = s_id[sl * 64 + leader];   // wave-uniform
+                // find this particle among my pending hits near slot sl
+                int mine = -1;
+#pragma unroll
+                for (int d = -kAggWindow; d <= kAggWindow; ++d) {
+                    const int t = sl + d;
+                    if (t >= 0 && t < kGrtMaxHits && mine < 0 && ((pending >> t) & 1u) && s_id[t * 64 + lane] == pid) mine = t;
+                }
+                const bool part = mine >= 0;
+                const int t = part ? mine : 0;
+                const float common = part ? s_sc[0 * S + t * 64 + lane] : 0.f;
+                const float wd = part ? s_sc[1 * S + t * 64 + lane] : 0.f;
+                const f3 dL = part ? mk3(s_sc[2 * S + t * 64 + lane], s_sc[3 * S + t * 64 + lane], s_sc[4 * S + t * 64 + lane]) : mk3(0.f, 0.f, 0.f);
+                if (part) pending &= ~(1u << t);
+                // gradient terms of particle pid for this lane (zero for lanes that do not take part)
+                const uint32_t upid = (uint32_t)__builtin_amdgcn_readfirstlane((int)pid);
+                const Particle p = load_particle(density12, upid);
+                const HitGeom g = hit_geometry<DEG>(P, p, r);
+                const f3 gscl = p.scl;
+                const float pdot = -dot(g.grd, g.gro);
+                const f3 grdd = g.grd * pdot;
+                const f3 grds = gscl * grdd;
+                const float gsq = dot(grds, grds);
+                const float gdist = sqrtf(gsq);
+                const f3 grdsRayHitGrd = gsq > 0.f ? grds * (wd / gdist) : mk3(0.f, 0.f, 0.f);
+                const f3 gsclRayHitGrd = grdd * grdsRayHitGrd;
+                const float grdScaledDot = dot(grdsRayHitGrd * gscl, g.grd);
+                const f3 grdRayHitGrd = gscl * grdsRayHitGrd * pdot - g.gro * grdScaledDot;
+                const f3 groRayHitGrd = g.grd * (-grdScaledDot);
+                const float gresGrd = p.density * common;
+                const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, gresGrd);
+                const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
+                const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x,
+                                      gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
+                const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z,
+                                      gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
+                const f3 groTot = groGrd + groRayHitGrd;
+                const f3 is2 = g.giscl * g.giscl;
+                const f3 gsclGrdGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;
+                const f3 gposcrGrd = g.giscl * groTot;
+                const f3 gposcGrd = mul_cols(p.rotT, gposcrGrd);
+                const float4 gq1 = matmul_bw_quat(g.gposc, gposcrGrd, p.quat);
+                const f3 dn = grdGrd + grdRayHitGrd;
+                const float l2 = dot(g.grdu, g.grdu);
+                f3 grduGrd = mk3(0.f, 0.f, 0.f);
+                if (l2 > 0.f) {
+                    const float il = 1.f / sqrtf(l2);
+                    grduGrd = dn * il - g.grdu * (il * il * il * dot(dn, g.grdu));
+                }
+                const f3 sclGrd = gsclRayHitGrd + gsclGrdGro + mk3(-g.rdr.x * is2.x, -g.rdr.y * is2.y, -g.rdr.z * is2.z) * grduGrd;
+                const float4 gq2 = matmul_bw_quat(r.d, g.giscl * grduGrd, p.quat);
+                const float mk = part ? 1.f : 0.f;   // non-participants: every term is already zero except through NaN-free math
+                float terms[16];
+                terms[0] = -gposcGrd.x * mk; terms[1] = -gposcGrd.y * mk; terms[2] = -gposcGrd.z * mk; terms[3] = g.gres * common;
+                terms[4] = (gq1.x + gq2.x) * mk; terms[5] = (gq1.y + gq2.y) * mk; terms[6] = (gq1.z + gq2.z) * mk; terms[7] = (gq1.w + gq2.w) * mk;
+                terms[8] = sclGrd.x * mk; terms[9] = sclGrd.y * mk; terms[10] = sclGrd.z * mk;
+                terms[11] = terms[12] = terms[13] = terms[14] = terms[15] = 0.f;
+                const float tot = wave_reduce_scatter16(terms, lane);
+                if (lane < 11) atomicAdd(g_density12 + 12 * (size_t)upid + lane, tot);
+                // SH gradient: 3 * nact terms, 16 at a time
+                float* gs = g_sph + (size_t)upid * 3 * P.ncoef;
+#pragma unroll
+                for (int pass = 0; pass < 3; ++pass) {   // compile-time bases keep `basis` in registers
+                    constexpr int kDummy = 0;
+                    (void)kDummy;
+                    const int base = pass * 16;
+                    if (base < 3 * nact) {
+                        float st[16];
+#pragma unroll
+                        for (int k = 0; k < 16; ++k) {
+                            const int e = base + k, coef = e / 3, ch = e - 3 * coef;
+                            st[k] = (e < 3 * nact) ? basis[coef] * (ch == 0 ? dL.x : (ch == 1 ? dL.y : dL.z)) : 0.f;
+                        }
+                        const float ts = wave_reduce_scatter16(st, lane);
+                        if (lane < 16 && base + lane < 3 * nact) atomicAdd(gs + base + lane, ts);
+                    }
+                }
             }
         }
+        __syncthreads();
     }
 }
 
