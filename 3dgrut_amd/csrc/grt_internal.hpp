@@ -19,6 +19,7 @@ static_assert(sizeof(GrtNode) == 64, "GrtNode must be 64 bytes");
 constexpr uint32_t kGrtLeafBit = 0x80000000u;
 constexpr uint32_t kGrtNoChild = 0xFFFFFFFFu;
 constexpr int kGrtMaxHits = 16;       // PipelineParameters::MaxNumHitPerTrace (pipelineParameters.h:83)
+constexpr int kGrtGather = 16;        // forward: candidates per traversal (16 = one trace round, 32 = two rounds from one walk)
 constexpr int kGrtStackDepth = 64;    // a radix tree over 30+32-bit keys is at most 62 levels deep
 
 struct GrtBuildParams {

@@ -262,7 +262,10 @@ struct Cand {
     float t, tnear, tfar;
     bool ok;
 };
-__device__ __forceinline__ Cand candidate(const float* __restrict__ inst, const RayW& r) {
+// `t_lo` / (`t_hi`, `id_hi`): the caller only wants candidates with t_lo < t and (t, id) < (t_hi, id_hi); the hit distance
+// is evaluated first and the (division-heavy) box test only for those — the values themselves are unaffected.
+__device__ __forceinline__ Cand candidate(const float* __restrict__ inst, const RayW& r, float t_lo = -3.0e38f, float t_hi = 3.0e38f,
+                                          uint32_t id = 0u, uint32_t id_hi = 0xFFFFFFFFu) {
 #pragma clang fp contract(off)
     Cand c;
     c.ok = false; c.t = 0.f; c.tnear = 0.f; c.tfar = 0.f;
@@ -272,20 +275,22 @@ __device__ __forceinline__ Cand candidate(const float* __restrict__ inst, const 
     const float pox = a.x * dlx + a.y * dly + a.z * dlz, poy = a.w * dlx + b.x * dly + b.y * dlz, poz = b.z * dlx + b.w * dly + e.x * dlz;
     const float pdx = a.x * r.d.x + a.y * r.d.y + a.z * r.d.z, pdy = a.w * r.d.x + b.x * r.d.y + b.y * r.d.z,
                 pdz = b.z * r.d.x + b.w * r.d.y + e.x * r.d.z;
+    // intersectInstanceParticle: hit distance = closest approach in the proxy's frame
+    const float numerator = -(pox * pdx + poy * pdy + poz * pdz);
+    const float dd = pdx * pdx + pdy * pdy + pdz * pdz;
+    const float denominator = 1.f / dd;
+    c.t = numerator * denominator;
+    if (!(c.t > t_lo) || !((c.t < t_hi) || (c.t == t_hi && id < id_hi))) return c;
+    // slab test of the unit box; min / max are plain comparisons (a < b ? a : b), NaN-propagating like the checker's
     const float ax0 = (-1.f - pox) / pdx, ax1 = (1.f - pox) / pdx;
     const float ay0 = (-1.f - poy) / pdy, ay1 = (1.f - poy) / pdy;
     const float az0 = (-1.f - poz) / pdz, az1 = (1.f - poz) / pdz;
-    // r_min / r_max of the oracle are plain comparisons (a < b ? a : b), NaN-propagating in the same way
     auto mn = [](float x, float y) { return x < y ? x : y; };
     auto mx = [](float x, float y) { return x > y ? x : y; };
     const float tnear = mx(mx(mn(ax0, ax1), mn(ay0, ay1)), mn(az0, az1));
     const float tfar = mn(mn(mx(ax0, ax1), mx(ay0, ay1)), mx(az0, az1));
     if (!(tnear <= tfar)) return c;
     c.tnear = tnear; c.tfar = tfar;
-    const float numerator = -(pox * pdx + poy * pdy + poz * pdz);
-    const float dd = pdx * pdx + pdy * pdy + pdz * pdz;
-    const float denominator = 1.f / dd;
-    c.t = numerator * denominator;
     const float il = dd > 0.f ? 1.f / sqrtf(dd) : 1.f;
     const float nx = pdx * il, ny = pdy * il, nz = pdz * il;
     const float crx = ny * poz - nz * poy, cry = nz * pox - nx * poz, crz = nx * poy - ny * pox;
@@ -295,22 +300,25 @@ __device__ __forceinline__ Cand candidate(const float* __restrict__ inst, const 
 
 __device__ __forceinline__ bool hit_less(float t, uint32_t id, float bt, uint32_t bi) { return (t < bt) || (t == bt && id < bi); }
 
-struct HitBuffer {
-    float t[kGrtMaxHits];
-    uint32_t id[kGrtMaxHits];
+// G nearest candidates, ascending.  G = 16 is one trace of the reference; the forward gathers G = 32 per traversal and
+// carves two 16-hit rounds out of it (see grt_trace_fwd_kernel).
+template <int G>
+struct HitBufferT {
+    float t[G];
+    uint32_t id[G];
     __device__ __forceinline__ void clear() {
 #pragma unroll
-        for (int k = 0; k < kGrtMaxHits; ++k) { t[k] = 3.0e38f; id[k] = 0xFFFFFFFFu; }
+        for (int k = 0; k < G; ++k) { t[k] = 3.0e38f; id[k] = 0xFFFFFFFFu; }
     }
-    // park the sorted list in LDS ([slot][lane]) so that the per-hit code can loop over it instead of being unrolled 16x
+    // park the sorted list in LDS ([slot][lane]) so that the per-hit code can loop over it instead of being unrolled
     __device__ __forceinline__ void store(float* __restrict__ st, uint32_t* __restrict__ sid, int lane) const {
 #pragma unroll
-        for (int k = 0; k < kGrtMaxHits; ++k) { st[k * 64 + lane] = t[k]; sid[k * 64 + lane] = id[k]; }
+        for (int k = 0; k < G; ++k) { st[k * 64 + lane] = t[k]; sid[k * 64 + lane] = id[k]; }
     }
     // compare-exchange chain of __anyhit__ah (referenceOptix.cu:210-246), lexicographic in (distance, particle)
     __device__ __forceinline__ void insert(float ht, uint32_t hid) {
 #pragma unroll
-        for (int k = 0; k < kGrtMaxHits; ++k) {
+        for (int k = 0; k < G; ++k) {
             const bool lt = hit_less(ht, hid, t[k], id[k]);
             const float tt = lt ? t[k] : ht;
             const uint32_t ii = lt ? id[k] : hid;
@@ -320,6 +328,7 @@ struct HitBuffer {
         }
     }
 };
+using HitBuffer = HitBufferT<kGrtMaxHits>;
 
 // slab test of a child's world box; returns entry/exit distances
 __device__ __forceinline__ bool box_hit(const float* __restrict__ lo, const float* __restrict__ hi, const RayW& r, float& tn, float& tf) {
@@ -343,9 +352,9 @@ struct TraceCounters {
 // block are coherent, so the union of their paths is barely larger than one ray's path: the node fetches, the stack
 // traffic and the divergence of 64 independent walks collapse into one.  Pruning stays per lane (its own interval and
 // its own current 16th-nearest distance); lanes that are done (`active` false) just ride along.
-template <bool COUNT>
+template <bool COUNT, int G = kGrtMaxHits>
 __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, float tmin, float tmax, bool active, int lane,
-                                            uint32_t* __restrict__ stack /* [64] per wave */, HitBuffer& buf, TraceCounters& tc) {
+                                            uint32_t* __restrict__ stack /* [64] per wave */, HitBufferT<G>& buf, TraceCounters& tc) {
     buf.clear();
     if (COUNT && active) tc.rounds++;
     if (!__any(active)) return;
@@ -365,7 +374,7 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
         const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q1.x, q1.y, q1.z}, lo1[3] = {q2.x, q2.y, q2.z}, hi1[3] = {q3.x, q3.y, q3.z};
         const uint32_t c0 = __float_as_uint(q0.w), c1 = __float_as_uint(q2.w);
         float tn0, tf0, tn1, tf1;
-        const float bound = fminf(tmax, buf.t[kGrtMaxHits - 1]);
+        const float bound = fminf(tmax, buf.t[G - 1]);
         const bool h0 = active && (c0 != kGrtNoChild) && box_hit(lo0, hi0, r, tn0, tf0) && (tf0 >= tmin) && (tn0 <= tmax) && (tn0 - q1.w <= bound);
         const bool h1 = active && (c1 != kGrtNoChild) && box_hit(lo1, hi1, r, tn1, tf1) && (tf1 >= tmin) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
         bool a0 = __any(h0), a1 = __any(h1);
@@ -373,10 +382,10 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
         if (a0 && (c0 & kGrtLeafBit)) {
             const uint32_t id = c0 & ~kGrtLeafBit;
             if (h0) {
-                const Cand c = candidate(bvh.inst + 12 * (size_t)id, r);
+                const Cand c = candidate(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
                 if (COUNT) tc.leaf_tests++;
                 if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
-                    hit_less(c.t, id, buf.t[kGrtMaxHits - 1], buf.id[kGrtMaxHits - 1])) {
+                    hit_less(c.t, id, buf.t[G - 1], buf.id[G - 1])) {
                     buf.insert(c.t, id);
                     if (COUNT) tc.inserts++;
                 }
@@ -386,10 +395,10 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
         if (a1 && (c1 & kGrtLeafBit)) {
             const uint32_t id = c1 & ~kGrtLeafBit;
             if (h1) {
-                const Cand c = candidate(bvh.inst + 12 * (size_t)id, r);
+                const Cand c = candidate(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
                 if (COUNT) tc.leaf_tests++;
                 if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
-                    hit_less(c.t, id, buf.t[kGrtMaxHits - 1], buf.id[kGrtMaxHits - 1])) {
+                    hit_less(c.t, id, buf.t[G - 1], buf.id[G - 1])) {
                     buf.insert(c.t, id);
                     if (COUNT) tc.inserts++;
                 }
@@ -497,9 +506,10 @@ __global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, Grt
                                                            int32_t* __restrict__ visibility, uint32_t* __restrict__ dbg_ids,
                                                            uint32_t* __restrict__ dbg_count, unsigned long long* __restrict__ counters,
                                                            GrtHitLog log) {
+    constexpr int kGather = kGrtGather;   // candidates gathered per traversal: one or two trace rounds of the reference
     __shared__ uint32_t s_stack[kGrtStackDepth];
-    __shared__ float s_hit_t[kGrtMaxHits * 64];
-    __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
+    __shared__ float s_hit_t[kGather * 64];
+    __shared__ uint32_t s_hit_id[kGather * 64];
     TraceCounters tc;
     const int lane = threadIdx.x;
     const int px = (int)blockIdx.x * 8 + (lane & 7), py = (int)blockIdx.y * 8 + (lane >> 3);
@@ -516,71 +526,116 @@ __global__ __launch_bounds__(64) void grt_trace_fwd_kernel(GrtTraceParams P, Grt
     constexpr float eps = 1e-9f;
     float tLast = fmaxf(0.f, tEnter - eps);
     uint32_t ndbg = 0;
-    HitBuffer buf;
     bool running = in_image;
     const uint32_t block = blockIdx.y * gridDim.x + blockIdx.x;
     uint32_t round = 0, nproc = 0, nties = 0;  // processed hits, and how many of the last ones share t == tLast
+
+    // one chunk of the hit log per (wave, trace round)
+    auto open_chunk = [&]() -> uint32_t* {
+        if (!log.pool) return nullptr;
+        uint32_t c = 0xFFFFFFFFu;
+        if (lane == 0) {
+            if (round < log.max_rounds) c = atomicAdd(&log.state[0], 1u);
+            if (c >= log.capacity_chunks) { c = 0xFFFFFFFFu; log.state[1] = 1u; }
+            if (round < log.max_rounds) log.table[(size_t)block * log.max_rounds + round] = c;
+        }
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+        round++;
+        return c != 0xFFFFFFFFu ? log.pool + (size_t)c * (2 * kGrtMaxHits * 64) + lane : nullptr;
+    };
+    // one hit of a trace round: processHit (gaussianParticles.cuh:337-405) while the ray is above min_transmittance
+    auto process_slot = [&](uint32_t* chunk, int slot, bool take, uint32_t id, float hit_t) {
+        const bool process = take && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
+        if (chunk) {
+            chunk[slot * 64] = process ? id : 0xFFFFFFFFu;
+            // the backward's trace interval ends at endT: it does not see a proxy whose box the ray enters later
+            if (process) chunk[(kGrtMaxHits + slot) * 64] = __float_as_uint(candidate(bvh.inst + 12 * (size_t)id, r).tnear);
+        }
+        if (process) {
+            nproc++;
+            nties = (hit_t > tLast) ? 1u : (nties + 1u);
+            const Particle p = load_particle(density12, id);
+            const HitGeom g = hit_geometry<DEG>(P, p, r);
+            if (g.accept) {
+                const float weight = g.galpha * T;
+                const float pdot = -dot(g.grd, g.gro);
+                const f3 grds = p.scl * g.grd * pdot;
+                const float hitT = sqrtf(dot(grds, grds));
+                const f3 u = sh_radiance(P, sph, id, basis);
+                const f3 c = mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f));
+                rad = rad + c * weight;
+                T *= (1.f - g.galpha);
+                depth = fmaf(hitT, weight, depth);
+                if (P.normals) {  // gaussianParticles.cuh:398-402
+                    const f3 psr = mul_cols(p.rotT, p.scl);
+                    const f3 q = (g.gro + g.grd * (pdot - sqrtf(9.f - g.gray))) * psr;
+                    const float l2 = dot(q, q);
+                    const f3 n = l2 > 0.f ? q * (1.f / sqrtf(l2)) : q;
+                    nrm = nrm + n * weight;
+                }
+                visibility[id] = 1;  // benign race: every writer stores the same value (referenceOptix.cu:158-161)
+                cnt += 1.f;
+            }
+            tLast = fmaxf(tLast, hit_t);
+            if (COUNT) tc.processed++;
+            if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = id;
+            ndbg++;
+        }
+        return process;
+    };
+
+    // The reference traces 16 nearest candidates beyond the last hit distance, processes them, and traces again
+    // (referenceOptix.cu:128-180).  Every trace costs a full walk along the ray (proxy boxes are much longer than the
+    // spacing of the hits), so one traversal here gathers the 32 nearest and the SECOND round is carved out of the same
+    // list with the second trace's own interval conditions (t > tLast + eps, box exit >= tLast + eps).  That is exact
+    // whenever the list provably contains that round: the gather was not full (nothing lies beyond it), or 16 entries
+    // survive the conditions.  A ray whose gather was not full is finished after its list: the reference's next trace
+    // would come back empty.
     while (true) {
         running = running && (tLast <= tExit) && (T > P.min_transmittance);
         if (!__any(running)) break;
-        trace_round<COUNT>(bvh, r, tLast + eps, tExit + eps, running, lane, s_stack, buf, tc);
-        if (buf.id[0] == 0xFFFFFFFFu) running = false;
-        // hit log: one chunk per (wave, round)
-        uint32_t* chunk = nullptr;
-        if (log.pool) {
-            uint32_t c = 0xFFFFFFFFu;
-            if (lane == 0) {
-                if (round < log.max_rounds) c = atomicAdd(&log.state[0], 1u);
-                if (c >= log.capacity_chunks) { c = 0xFFFFFFFFu; log.state[1] = 1u; }
-                if (round < log.max_rounds) log.table[(size_t)block * log.max_rounds + round] = c;
-            }
-            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-            if (c != 0xFFFFFFFFu) chunk = log.pool + (size_t)c * (2 * kGrtMaxHits * 64) + lane;
-            round++;
+        {
+            HitBufferT<kGather> buf;
+            trace_round<COUNT, kGather>(bvh, r, tLast + eps, tExit + eps, running, lane, s_stack, buf, tc);
+            buf.store(s_hit_t, s_hit_id, lane);
         }
-        buf.store(s_hit_t, s_hit_id, lane);
+        if (s_hit_id[lane] == 0xFFFFFFFFu) running = false;
+        const bool full = s_hit_id[(kGather - 1) * 64 + lane] != 0xFFFFFFFFu;
+        // ---- first round: the 16 nearest ----
+        uint32_t* chunk = open_chunk();
 #pragma unroll 1
         for (int i = 0; i < kGrtMaxHits; ++i) {
             const uint32_t id = s_hit_id[i * 64 + lane];
-            const float hit_t = s_hit_t[i * 64 + lane];
-            const bool process = running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
-            if (!__any(process) && !chunk) break;  // ascending list: nothing further for any lane
-            if (chunk) {
-                chunk[i * 64] = process ? id : 0xFFFFFFFFu;
-                // the backward's trace interval ends at endT: it does not see a proxy whose box the ray enters later
-                if (process) chunk[(kGrtMaxHits + i) * 64] = __float_as_uint(candidate(bvh.inst + 12 * (size_t)id, r).tnear);
+            const bool any = __any(running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance));
+            if (!any && !chunk) break;  // ascending list: nothing further for any lane
+            process_slot(chunk, i, running, id, s_hit_t[i * 64 + lane]);
+        }
+        // ---- second round, from the same list ----
+        bool more = running && (tLast <= tExit) && (T > P.min_transmittance);
+        uint32_t mask2 = 0u;
+        if (more) {
+            const float tmin2 = tLast + eps;
+            int cnt2 = 0;
+            for (int i = kGrtMaxHits; i < kGather; ++i) {
+                const uint32_t id = s_hit_id[i * 64 + lane];
+                if (id == 0xFFFFFFFFu) break;
+                bool ok = s_hit_t[i * 64 + lane] > tmin2;
+                if (ok) ok = candidate(bvh.inst + 12 * (size_t)id, r).tfar >= tmin2;
+                if (ok) { mask2 |= (1u << (i - kGrtMaxHits)); cnt2++; }
             }
-            if (process) {
-                nproc++;
-                nties = (hit_t > tLast) ? 1u : (nties + 1u);
-                const Particle p = load_particle(density12, id);
-                const HitGeom g = hit_geometry<DEG>(P, p, r);
-                if (g.accept) {
-                    const float weight = g.galpha * T;
-                    const float pdot = -dot(g.grd, g.gro);
-                    const f3 grds = p.scl * g.grd * pdot;
-                    const float hitT = sqrtf(dot(grds, grds));
-                    const f3 u = sh_radiance(P, sph, id, basis);
-                    const f3 c = mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f));
-                    rad = rad + c * weight;
-                    T *= (1.f - g.galpha);
-                    depth = fmaf(hitT, weight, depth);
-                    if (P.normals) {  // gaussianParticles.cuh:398-402
-                        const f3 psr = mul_cols(p.rotT, p.scl);
-                        const f3 q = (g.gro + g.grd * (pdot - sqrtf(9.f - g.gray))) * psr;
-                        const float l2 = dot(q, q);
-                        const f3 n = l2 > 0.f ? q * (1.f / sqrtf(l2)) : q;
-                        nrm = nrm + n * weight;
-                    }
-                    visibility[id] = 1;  // benign race: every writer stores the same value (referenceOptix.cu:158-161)
-                    cnt += 1.f;
-                }
-                tLast = fmaxf(tLast, hit_t);
-                if (COUNT) tc.processed++;
-                if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = id;
-                ndbg++;
+            if (!full && cnt2 == 0) { running = false; more = false; }          // nothing lies beyond: the ray is done
+            else if (full && cnt2 < kGrtMaxHits) more = false;                  // the list may not hold the whole round: trace again
+        }
+        if (__any(more)) {
+            uint32_t* chunk2 = open_chunk();
+#pragma unroll 1
+            for (int i = 0; i < kGrtMaxHits; ++i) {
+                const bool take = more && ((mask2 >> i) & 1u);
+                const uint32_t id = s_hit_id[(kGrtMaxHits + i) * 64 + lane];
+                process_slot(chunk2, i, take, id, s_hit_t[(kGrtMaxHits + i) * 64 + lane]);
             }
         }
+        if (!full) running = false;   // the list held every remaining candidate of this ray
     }
     if (!in_image) return;
     out_rad[3 * pix] = rad.x; out_rad[3 * pix + 1] = rad.y; out_rad[3 * pix + 2] = rad.z;
