@@ -91,6 +91,15 @@ class GrtStats(C.Structure):
     ]
 
 
+class GrutAdamGroup(C.Structure):
+    _fields_ = [
+        ("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+        ("row_width", C.c_uint32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+    ]
+
+
+VIS_NONE, VIS_BOOL_U8, VIS_INT32, VIS_FLOAT_BITS = range(4)
+
 # every symbol include/grut_amd.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
     "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_timings", "gut_stats",
@@ -99,6 +108,7 @@ EXPORTED_SYMBOLS = [
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats",
     "grt_debug_forward_hits", "grt_debug_fetch_instances",
+    "grut_selective_adam_update",
     "grut_last_error", "grut_abi_version",
 ]
 
@@ -152,6 +162,8 @@ def _declare(lib):
     lib.grt_timings.restype = C.c_int
     lib.grt_stats.argtypes = [C.c_void_p, C.POINTER(GrtStats)]
     lib.grt_stats.restype = C.c_int
+    lib.grut_selective_adam_update.argtypes = [vp, C.POINTER(GrutAdamGroup), C.c_int, C.c_uint32, vp, C.c_int]
+    lib.grut_selective_adam_update.restype = C.c_int
     lib.grut_last_error.argtypes = []
     lib.grut_last_error.restype = C.c_char_p
     lib.grut_abi_version.argtypes = []

@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libgrut_amd.so")
-SOURCES = ["scan_sort.hip", "gut_kernels.hip", "gut_render.hip", "gut_api.hip", "grt_kernels.hip", "grt_api.hip"]
+SOURCES = ["scan_sort.hip", "gut_kernels.hip", "gut_render.hip", "gut_api.hip", "grt_kernels.hip", "grt_api.hip", "optim.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast",
          # SLP-packing scalar f32 math into v_pk_*_f32 costs register-pair shuffles (v_mov) and VGPRs on gfx950

@@ -1,0 +1,125 @@
+// optim.hip — visibility-masked Adam update of the Gaussian parameter tensors, all parameter groups in ONE launch.
+//
+// Replaces threedgrut/optimizers/optimizers.cu:49-77 (selective_adam_update_kernel) and the per-group launches of
+// threedgrut/optimizers/__init__.py:85-124: same arithmetic (no bias correction, rows with visibility == 0 keep their
+// parameter AND their moments), but
+//   * one launch walks every group (positions, density, rotation, scale, albedo, specular) instead of six,
+//   * each lane moves 16 bytes per stream (float4 over the flat [N*M] array; a float4 may straddle two rows, each
+//     element looks up its own row's flag),
+//   * a float4 whose rows are all invisible costs one flag read and nothing else.
+// HBM-bound: 28 B per visible element (read p, g, m, v; write p, m, v), DESIGN.md §7.
+#include "common.hpp"
+
+namespace grut {
+
+constexpr int kAdamMaxGroups = 8;
+constexpr int kAdamThreads = 256;
+
+struct AdamLaunch {
+    GrutAdamGroup g[kAdamMaxGroups];
+    uint32_t block_end[kAdamMaxGroups];  // exclusive prefix of blocks per group
+    int num_groups;
+    uint32_t rows;
+    const void* visibility;
+    uint32_t vis_mask;  // 0: all rows visible; otherwise AND-mask applied to the flag word / byte
+    int vis_bytes;
+};
+
+__device__ __forceinline__ bool row_visible(const AdamLaunch& L, uint32_t row) {
+    if (L.vis_mask == 0u) return true;
+    if (L.vis_bytes == 1) return (reinterpret_cast<const uint8_t*>(L.visibility)[row] & L.vis_mask) != 0;
+    return (reinterpret_cast<const uint32_t*>(L.visibility)[row] & L.vis_mask) != 0u;
+}
+
+// optimizers.cu:62-75, operation order kept ((1-b2)*g)*g, step = -lr*m/(sqrt(v)+eps)
+__device__ __forceinline__ void adam_element(float& p, float g, float& m, float& v, float lr, float b1, float b2, float eps) {
+    m = b1 * m + (1.0f - b1) * g;
+    v = b2 * v + (1.0f - b2) * g * g;
+    const float step = -lr * m / (sqrtf(v) + eps);
+    p += step;
+}
+
+__global__ __launch_bounds__(kAdamThreads) void selective_adam_kernel(const AdamLaunch L) {
+    int gi = 0;
+    while (gi + 1 < L.num_groups && blockIdx.x >= L.block_end[gi]) ++gi;
+    const GrutAdamGroup G = L.g[gi];
+    const uint32_t first_block = gi == 0 ? 0u : L.block_end[gi - 1];
+    const uint64_t total = (uint64_t)L.rows * G.row_width;
+    const uint64_t base = ((uint64_t)(blockIdx.x - first_block) * kAdamThreads + threadIdx.x) * 4ull;
+    if (base >= total) return;
+    const uint32_t M = G.row_width;
+    uint32_t row = (uint32_t)(base / M);
+    uint32_t rem = (uint32_t)(base - (uint64_t)row * M);
+    bool vis[4];
+    bool any = false;
+    const int cnt = (total - base) >= 4ull ? 4 : (int)(total - base);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        vis[k] = false;
+        if (k < cnt) {
+            vis[k] = (k > 0 && rem != 0u) ? vis[k - 1] : row_visible(L, row);   // same row as the previous element
+            any |= vis[k];
+            if (++rem == M) { rem = 0u; ++row; }
+        }
+    }
+    if (!any) return;
+    if (cnt == 4) {
+        float4 p = *reinterpret_cast<const float4*>(G.param + base);
+        const float4 g = *reinterpret_cast<const float4*>(G.grad + base);
+        float4 m = *reinterpret_cast<const float4*>(G.exp_avg + base);
+        float4 v = *reinterpret_cast<const float4*>(G.exp_avg_sq + base);
+        if (vis[0]) adam_element(p.x, g.x, m.x, v.x, G.lr, G.beta1, G.beta2, G.eps);
+        if (vis[1]) adam_element(p.y, g.y, m.y, v.y, G.lr, G.beta1, G.beta2, G.eps);
+        if (vis[2]) adam_element(p.z, g.z, m.z, v.z, G.lr, G.beta1, G.beta2, G.eps);
+        if (vis[3]) adam_element(p.w, g.w, m.w, v.w, G.lr, G.beta1, G.beta2, G.eps);
+        *reinterpret_cast<float4*>(G.param + base) = p;
+        *reinterpret_cast<float4*>(G.exp_avg + base) = m;
+        *reinterpret_cast<float4*>(G.exp_avg_sq + base) = v;
+    } else {
+        for (int k = 0; k < cnt; ++k) {
+            if (!vis[k]) continue;
+            float p = G.param[base + k], m = G.exp_avg[base + k], v = G.exp_avg_sq[base + k];
+            adam_element(p, G.grad[base + k], m, v, G.lr, G.beta1, G.beta2, G.eps);
+            G.param[base + k] = p;
+            G.exp_avg[base + k] = m;
+            G.exp_avg_sq[base + k] = v;
+        }
+    }
+}
+
+}  // namespace grut
+
+extern "C" int grut_selective_adam_update(void* stream, const GrutAdamGroup* groups, int num_groups, uint32_t num_rows,
+                                          const void* visibility, int visibility_kind) {
+    using namespace grut;
+    GRUT_REQUIRE(num_groups >= 0 && (num_groups == 0 || groups), "grut_selective_adam_update: groups is NULL");
+    GRUT_REQUIRE(visibility_kind >= GRUT_VIS_NONE && visibility_kind <= GRUT_VIS_FLOAT_BITS, "grut_selective_adam_update: visibility_kind %d", visibility_kind);
+    GRUT_REQUIRE(visibility_kind == GRUT_VIS_NONE || visibility || num_rows == 0, "grut_selective_adam_update: visibility is NULL");
+    if (num_rows == 0) return GRUT_OK;  // optimizers.cu:87-89
+    for (int first = 0; first < num_groups; first += kAdamMaxGroups) {
+        AdamLaunch L{};
+        L.rows = num_rows;
+        L.visibility = visibility;
+        L.vis_bytes = visibility_kind == GRUT_VIS_BOOL_U8 ? 1 : 4;
+        L.vis_mask = visibility_kind == GRUT_VIS_NONE ? 0u : visibility_kind == GRUT_VIS_BOOL_U8 ? 0xFFu
+                   : visibility_kind == GRUT_VIS_FLOAT_BITS ? 0x7FFFFFFFu : 0xFFFFFFFFu;
+        uint64_t blocks = 0;
+        for (int i = first; i < num_groups && L.num_groups < kAdamMaxGroups; ++i) {
+            const GrutAdamGroup& g = groups[i];
+            if (g.row_width == 0) continue;
+            GRUT_REQUIRE(g.param && g.grad && g.exp_avg && g.exp_avg_sq, "grut_selective_adam_update: group %d has a NULL tensor", i);
+            GRUT_REQUIRE(((uintptr_t)g.param | (uintptr_t)g.grad | (uintptr_t)g.exp_avg | (uintptr_t)g.exp_avg_sq) % 16 == 0,
+                         "grut_selective_adam_update: group %d tensors must be 16-byte aligned", i);
+            const uint64_t quads = ((uint64_t)num_rows * g.row_width + 3) / 4;
+            blocks += (quads + kAdamThreads - 1) / kAdamThreads;
+            GRUT_REQUIRE(blocks < 0x7FFFFFFFull, "grut_selective_adam_update: too many elements");
+            L.g[L.num_groups] = g;
+            L.block_end[L.num_groups] = (uint32_t)blocks;
+            ++L.num_groups;
+        }
+        if (L.num_groups == 0) continue;
+        hipLaunchKernelGGL(selective_adam_kernel, dim3((uint32_t)blocks), dim3(kAdamThreads), 0, reinterpret_cast<hipStream_t>(stream), L);
+        GRUT_HIP(hipGetLastError());
+    }
+    return GRUT_OK;
+}

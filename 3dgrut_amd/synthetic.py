@@ -187,3 +187,54 @@ class SimpleGaussians:
         g = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.parameters()]
         packed = torch.cat([g[0], g[3], g[1], g[2], z], dim=1)
         return packed.detach().cpu().numpy(), g[4].detach().cpu().numpy()
+
+
+class ActivatedGaussians:
+    """Stand-in for MixtureOfGaussians with RAW parameters and the reference's activations (threedgrut/model/model.py:
+    94-118, 262-274): density = sigmoid(raw), scale = exp(raw), rotation = normalize(raw), features = cat(albedo, specular).
+    Used by the training-loop tests and scripts/train_synthetic.py; the renderer plugins only see the activated tensors."""
+
+    def __init__(self, density12, sph, device="cuda", n_active_features=3):
+        import torch
+        d = torch.as_tensor(density12, dtype=torch.float32, device=device)
+        f = torch.as_tensor(sph, dtype=torch.float32, device=device)
+        self.positions = d[:, 0:3].clone().requires_grad_(True)
+        dn = d[:, 3:4].clamp(1e-4, 1 - 1e-4)
+        self.density = torch.log(dn / (1 - dn)).requires_grad_(True)
+        self.rotation = d[:, 4:8].clone().requires_grad_(True)
+        self.scale = torch.log(d[:, 8:11]).requires_grad_(True)
+        self.features_albedo = f[:, :3].clone().requires_grad_(True)
+        self.features_specular = f[:, 3:].clone().requires_grad_(True)
+        self.n_active_features = n_active_features
+        self.ray_feature_dim = 3
+        self.density_activation = torch.sigmoid
+        self.scale_activation = torch.exp
+        self.rotation_activation = torch.nn.functional.normalize
+
+    @property
+    def num_gaussians(self):
+        return self.positions.shape[0]
+
+    def get_rotation(self):
+        return self.rotation_activation(self.rotation)
+
+    def get_scale(self):
+        return self.scale_activation(self.scale)
+
+    def get_density(self):
+        return self.density_activation(self.density)
+
+    def get_features(self):
+        import torch
+        return torch.cat([self.features_albedo, self.features_specular], dim=1)
+
+    def parameters(self):
+        return [self.positions, self.density, self.rotation, self.scale, self.features_albedo, self.features_specular]
+
+    def packed(self):
+        """activated [N,12] rows + SH rows as numpy (what the oracle consumes)."""
+        import torch
+        with torch.no_grad():
+            z = torch.zeros_like(self.density)
+            d12 = torch.cat([self.positions, self.get_density(), self.get_rotation(), self.get_scale(), z], dim=1)
+            return d12.cpu().numpy(), self.get_features().cpu().numpy()

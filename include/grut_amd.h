@@ -258,6 +258,27 @@ int grt_debug_fetch_instances(GrtHandle* handle, void* stream, float* instances)
 int grt_timings(GrtHandle* handle, float* forward_ms, float* backward_ms, float* build_ms);
 int grt_stats(GrtHandle* handle, GrtStats* stats);
 
+/* ---- optimizer step --------------------------------------- */
+/* One parameter group of SelectiveAdam (threedgrut/optimizers/__init__.py:85-124): contiguous fp32 [num_rows, row_width]
+ * DEVICE tensors, 16-byte aligned. */
+typedef struct GrutAdamGroup {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    uint32_t row_width;
+    float lr, beta1, beta2, eps;
+} GrutAdamGroup;
+enum { GRUT_VIS_NONE = 0,        /* every row is updated */
+       GRUT_VIS_BOOL_U8 = 1,     /* visibility = bool[num_rows] (what `visibility.bool().squeeze()` yields) */
+       GRUT_VIS_INT32 = 2,       /* visibility = int32[num_rows], visible iff != 0 (gut_forward's out_visibility) */
+       GRUT_VIS_FLOAT_BITS = 3   /* visibility = float[num_rows], visible iff != 0.0f (the tracers' `mog_visibility`) */ };
+/* Replaces selective_adam_update_launch (threedgrut/optimizers/optimizers.cu:79-109, kernel :49-77), for ALL groups in
+ * one launch: rows whose flag is zero keep parameter and moments; visible rows get
+ * m = b1 m + (1-b1) g; v = b2 v + (1-b2) g g; param -= lr m / (sqrt(v) + eps)   (no bias correction, as the reference). */
+int grut_selective_adam_update(void* stream, const GrutAdamGroup* groups, int num_groups, uint32_t num_rows,
+                               const void* visibility, int visibility_kind);
+
 /* human-readable text of the last error raised on the calling thread */
 const char* grut_last_error(void);
 /* ABI version; bumped whenever a struct above changes */

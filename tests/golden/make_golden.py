@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Generates tests/golden/per_hit_deg{2,4}.npz from the REFERENCE's own per-hit math.
+"""Generates tests/golden/per_hit_deg{2,4}.npz and adam.npz from the REFERENCE's own per-hit math and optimizer kernel.
 
 Run in the build container only (needs /root/reference):
 
@@ -126,6 +126,36 @@ def run(degree, n=512, seed=1234):
     print(path, f"accepted gut {gut_fwd_acc.mean():.2f} grt {grt_acc.mean():.2f} custom {custom_ok.mean():.2f} instance {inst_ok.mean():.2f}")
 
 
+
+
+def make_adam():
+    """tests/golden/adam.npz: three consecutive steps of the reference's selective_adam_update_kernel (oracle/_ref/libref_adam.so)
+    on a [N, M] parameter for the row widths of the six Gaussian parameter groups."""
+    lib = C.CDLL(os.path.join(REF, "libref_adam.so"))
+    r = np.random.default_rng(11)
+    out = {}
+    for M in (1, 3, 4, 45):
+        N = 97
+        p = r.normal(size=(N, M)).astype(F)
+        m = np.zeros((N, M), F)
+        v = np.zeros((N, M), F)
+        lr, b1, b2, eps = F(10.0 ** r.uniform(-4, -2)), F(0.9), F(0.999), F(1e-15 if M == 3 else 1e-8)
+        out[f"M{M}_hyper"] = np.array([lr, b1, b2, eps], F)
+        out[f"M{M}_p0"] = p.copy()
+        for step in range(3):
+            g = (r.normal(size=(N, M)) * 10.0 ** r.uniform(-6, 0, (N, 1))).astype(F)
+            vis = r.uniform(size=N) < 0.6
+            lib.ref_selective_adam(_p(p), _p(g), _p(m), _p(v), _p(vis), C.c_float(lr), C.c_float(b1), C.c_float(b2), C.c_float(eps),
+                                   C.c_uint32(N), C.c_uint32(M))
+            out[f"M{M}_g{step}"], out[f"M{M}_vis{step}"] = g, vis
+            out[f"M{M}_p{step + 1}"], out[f"M{M}_m{step + 1}"], out[f"M{M}_v{step + 1}"] = p.copy(), m.copy(), v.copy()
+    np.savez_compressed(os.path.join(HERE, "adam.npz"), **out)
+    print("wrote adam.npz")
+
+
 if __name__ == "__main__":
-    for d in (2, 4):
-        run(d)
+    import sys
+    if "--adam-only" not in sys.argv:
+        for d in (2, 4):
+            run(d)
+    make_adam()

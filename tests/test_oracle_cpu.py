@@ -280,3 +280,24 @@ def test_grt_backward_is_the_gradient_of_forward_away_from_the_last_hit():
                 bad += 1
     # a probe particle still influences the (dropped) last hits of rays it precedes through their transmittance
     assert bad <= len(probes) * 11 // 4, bad
+
+
+# ---- SelectiveAdam -------------------------------------------------------------------------------
+def test_adam_oracle_matches_reference_kernel_golden():
+    """oracle/adam_oracle.py against three consecutive steps of the reference's own selective_adam_update_kernel
+    (tests/golden/adam.npz, produced by oracle/ref/ref_adam.cpp): bit-exact, invisible rows untouched."""
+    from oracle import adam_oracle
+    g = np.load(os.path.join(HERE, "golden", "adam.npz"))
+    for M in (1, 3, 4, 45):
+        lr, b1, b2, eps = g[f"M{M}_hyper"]
+        p = g[f"M{M}_p0"]
+        m = np.zeros_like(p)
+        v = np.zeros_like(p)
+        for step in range(3):
+            vis = g[f"M{M}_vis{step}"]
+            p1, m1, v1 = adam_oracle.selective_adam_update(p, g[f"M{M}_g{step}"], m, v, vis, lr, b1, b2, eps)
+            assert np.array_equal(p1[~vis], p[~vis]) and np.array_equal(m1[~vis], m[~vis])
+            assert np.array_equal(p1, g[f"M{M}_p{step + 1}"]), f"M={M} step {step}: parameter differs"
+            assert np.array_equal(m1, g[f"M{M}_m{step + 1}"]) and np.array_equal(v1, g[f"M{M}_v{step + 1}"])
+            p, m, v = p1, m1, v1
+        assert 0.3 < vis.mean() < 0.9
