@@ -400,7 +400,7 @@ int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float
     if (I > 0) {
         // one slot per (tile entry, half tile); only flagged slots are ever read, so only the flags are cleared
         GRUT_CHECK(h->grad_partial.ensure(2 * I * (size_t)slots.stride * 4, 1.3f));
-        GRUT_CHECK(h->grad_flag.ensure(2 * I + 32, 1.3f));  // + slack: flags are scanned 16 at a time
+        GRUT_CHECK(h->grad_flag.ensure(2 * I + 96, 1.3f));  // + slack: flags are scanned 64 at a time
         slots.partial = h->grad_partial.as<float>();
         slots.flag = h->grad_flag.as<uint8_t>();
         GRUT_HIP(hipMemsetAsync(slots.flag, 0, 2 * I, s));

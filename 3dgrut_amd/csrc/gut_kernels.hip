@@ -103,7 +103,15 @@ __device__ __forceinline__ float saturate(float x) { return fminf(fmaxf(x, 0.f),
 // expansion pass on identical stored inputs.  FP contraction is switched off inside so that both kernels
 // round identically whatever the surrounding code looks like after inlining (a disagreement would only
 // cost a padded or a dropped tile entry: the expansion bounds its writes by the counted range).
-__device__ __forceinline__ float tile_min_power(float tx, float ty, float4 co, float mx, float my) {
+struct TileConic {   // per-particle constants of the test; rcpx / rcpy are the two divisions of :63-64, done once per particle
+    float cx, cy, cz, rcpx, rcpy;
+};
+__device__ __forceinline__ TileConic tile_conic(float4 co) {
+#pragma clang fp contract(off)
+    const float ts = 16.f;
+    return {co.x, co.y, co.z, 1.f / (ts * ts * co.x), 1.f / (ts * ts * co.z)};
+}
+__device__ __forceinline__ float tile_min_power(float tx, float ty, const TileConic& co, float mx, float my) {
 #pragma clang fp contract(off)
     const float ts = 16.f;
     const float tminx = ts * tx, tminy = ts * ty, tmaxx = ts + tminx, tmaxy = ts + tminy;
@@ -114,11 +122,10 @@ __device__ __forceinline__ float tile_min_power(float tx, float ty, float4 co, f
         const float px = lax > 0.f ? tminx : tmaxx, py = lay > 0.f ? tminy : tmaxy;
         const float dx = copysignf(ts, offx), dy = copysignf(ts, offy);
         const float diffx = mx - px, diffy = my - py;
-        const float rcpx = 1.f / (ts * ts * co.x), rcpy = 1.f / (ts * ts * co.z);
-        const float tx_ = nry * saturate((dx * co.x * diffx + dx * co.y * diffy) * rcpx);
-        const float ty_ = nrx * saturate((dy * co.y * diffx + dy * co.z * diffy) * rcpy);
+        const float tx_ = nry * saturate((dx * co.cx * diffx + dx * co.cy * diffy) * co.rcpx);
+        const float ty_ = nrx * saturate((dy * co.cy * diffx + dy * co.cz * diffy) * co.rcpy);
         const float mdx = mx - (px + tx_ * dx), mdy = my - (py + ty_ * dy);
-        return 0.5f * (co.x * mdx * mdx + co.z * mdy * mdy) + co.y * mdx * mdy;
+        return 0.5f * (co.cx * mdx * mdx + co.cz * mdy * mdy) + co.cy * mdx * mdy;
     }
     return 0.f;
 }
@@ -130,7 +137,7 @@ __device__ __forceinline__ float tile_min_power(float tx, float ty, float4 co, f
 __device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ float bcast_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 template <typename Emit>
-__device__ __forceinline__ void coop_tile_walk(int lane, int gx, bool culling, TileBBox bb, float4 co, float cx, float cy, float pmax,
+__device__ __forceinline__ void coop_tile_walk(int lane, int gx, bool culling, TileBBox bb, const TileConic& co, float cx, float cy, float pmax,
                                                Emit&& emit) {
     const int lx = lane & 7, ly = lane >> 3;
     for (int by = bb.miny; by < bb.maxy; by += 8)
@@ -141,6 +148,35 @@ __device__ __forceinline__ void coop_tile_walk(int lane, int gx, bool culling, T
             emit(keep, (uint32_t)(y * gx + x));
         }
 }
+
+// Most boxes are a few tiles wide, where an 8x8 block leaves most lanes idle: boxes of at most kRowWalkSide x kRowWalkSide tiles
+// are walked by ONE 16-lane row as a 4x4 block, the four rows of the wave working on four different particles at once.
+// The arguments are uniform per row (the row's current particle); `active` rows take part, all lanes call `emit(keep,
+// tile)` once per step (it may ballot).
+constexpr int kRowWalkSide = 4;   // boxes up to 4x4 tiles: one step of a 16-lane row
+__device__ __forceinline__ int row_bcast_i(int v, int src_lane) { return __shfl(v, src_lane, 64); }
+__device__ __forceinline__ float row_bcast_f(float v, int src_lane) { return __shfl(v, src_lane, 64); }
+template <typename Emit>
+__device__ __forceinline__ void row_tile_walk(int lane, int gx, bool culling, bool active, TileBBox bb, const TileConic& co, float cx, float cy,
+                                              float pmax, Emit&& emit) {
+    const int lx = lane & 3, ly = (lane >> 2) & 3;
+    int bx = bb.minx, by = bb.miny;
+    bool run = active && bb.minx < bb.maxx && bb.miny < bb.maxy;
+    while (__ballot(run)) {
+        const int x = bx + lx, y = by + ly;
+        bool keep = run && (x < bb.maxx) && (y < bb.maxy);
+        if (keep && culling) keep = tile_min_power((float)x, (float)y, co, cx, cy) < pmax;
+        emit(keep, (uint32_t)(y * gx + x));
+        bx += 4;
+        if (bx >= bb.maxx) {
+            bx = bb.minx;
+            by += 4;
+            run = run && by < bb.maxy;
+        }
+    }
+}
+__device__ __forceinline__ int bbox_area(const TileBBox& b) { return (b.maxx - b.minx) * (b.maxy - b.miny); }
+__device__ __forceinline__ bool bbox_fits_row(const TileBBox& b) { return (b.maxx - b.minx) <= kRowWalkSide && (b.maxy - b.miny) <= kRowWalkSide; }
 
 // ---------------------------------------------------------------------------------------------
 // K1: projection onto tiles — GUTProjector::eval (gutProjector.cuh:217-322)
@@ -224,14 +260,32 @@ __global__ __launch_bounds__(256) void gut_project_kernel(GutParams P, const flo
             }
         }
     }
-    // per-tile culling count (gutProjector.cuh:279-293), one particle at a time across the wave
+    // per-tile culling count (gutProjector.cuh:279-293): small boxes four at a time (one per 16-lane row), the heavy
+    // tail one particle at a time across the whole wave
     if (P.tile_culling) {
-        unsigned long long todo = __ballot(vis != 0);
+        const TileConic tc = tile_conic(co);
+        const int area = vis ? bbox_area(bb) : 0;
+        const bool small = area > 0 && bbox_fits_row(bb);
+        const unsigned long long small_mask = __ballot(small);
+        const int row_shift = lane & 48;
+        for (int k = 0; k < 16; ++k) {
+            if (!(small_mask & (0x0001000100010001ull << k))) continue;
+            const int src = row_shift | k;
+            const bool act = row_bcast_i((int)small, src) != 0;
+            const TileBBox sb = {row_bcast_i(bb.minx, src), row_bcast_i(bb.miny, src), row_bcast_i(bb.maxx, src), row_bcast_i(bb.maxy, src)};
+            const TileConic sco = {row_bcast_f(tc.cx, src), row_bcast_f(tc.cy, src), row_bcast_f(tc.cz, src), row_bcast_f(tc.rcpx, src),
+                                   row_bcast_f(tc.rcpy, src)};
+            uint32_t cnt = 0;
+            row_tile_walk(lane, P.gx, true, act, sb, sco, row_bcast_f(cx, src), row_bcast_f(cy, src), row_bcast_f(pmax_tile, src),
+                          [&](bool keep, uint32_t) { cnt += (uint32_t)__popcll((__ballot(keep) >> row_shift) & 0xFFFFull); });
+            if (lane == src && small) ntiles = cnt;
+        }
+        unsigned long long todo = __ballot(area > 0 && !small);
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const TileBBox sb = {bcast_i(bb.minx, src), bcast_i(bb.miny, src), bcast_i(bb.maxx, src), bcast_i(bb.maxy, src)};
-            const float4 sco = make_float4(bcast_f(co.x, src), bcast_f(co.y, src), bcast_f(co.z, src), 0.f);
+            const TileConic sco = {bcast_f(tc.cx, src), bcast_f(tc.cy, src), bcast_f(tc.cz, src), bcast_f(tc.rcpx, src), bcast_f(tc.rcpy, src)};
             uint32_t cnt = 0;
             coop_tile_walk(lane, P.gx, true, sb, sco, bcast_f(cx, src), bcast_f(cy, src), bcast_f(pmax_tile, src),
                            [&](bool keep, uint32_t) { cnt += (uint32_t)__popcll(__ballot(keep)); });
@@ -257,10 +311,31 @@ __global__ __launch_bounds__(256) void gut_project_kernel(GutParams P, const flo
             const int nact = (P.n_active + 1) * (P.n_active + 1);
             const float* coef = sph + (size_t)i * 3 * P.ncoef;
             float r = 0.f, g = 0.f, bl = 0.f;
-            for (int k = 0; k < nact && k < P.ncoef; ++k) {
-                r = fmaf(basis[k], coef[3 * k + 0], r);
-                g = fmaf(basis[k], coef[3 * k + 1], g);
-                bl = fmaf(basis[k], coef[3 * k + 2], bl);
+            if (P.ncoef == 16) {
+                // a lane reads its own 192-byte row: 16-byte loads (12 requests per row instead of 48), accumulated in the
+                // same coefficient order as the scalar loop
+                const float4* row = reinterpret_cast<const float4*>(coef);
+                float acc[3] = {0.f, 0.f, 0.f};
+                const int nq = (3 * nact + 3) >> 2;
+#pragma unroll
+                for (int q = 0; q < 12; ++q) {
+                    if (q < nq) {
+                        const float4 v = row[q];
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int k = (4 * q + j) / 3, c = (4 * q + j) % 3;
+                            if (k < nact) acc[c] = fmaf(basis[k], e[j], acc[c]);
+                        }
+                    }
+                }
+                r = acc[0]; g = acc[1]; bl = acc[2];
+            } else {
+                for (int k = 0; k < nact && k < P.ncoef; ++k) {
+                    r = fmaf(basis[k], coef[3 * k + 0], r);
+                    g = fmaf(basis[k], coef[3 * k + 1], g);
+                    bl = fmaf(basis[k], coef[3 * k + 2], bl);
+                }
             }
             out.rgb[3 * (size_t)i + 0] = r + 0.5f;
             out.rgb[3 * (size_t)i + 1] = g + 0.5f;
@@ -308,33 +383,67 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
             }
         }
     }
-    // one particle at a time across the wave: its entries land contiguously at [off, max_off) (coalesced stores);
-    // their order inside the range is irrelevant, the tile sort that follows is stable per (tile) and each
-    // (tile, particle) pair occurs once
-    unsigned long long todo = __ballot(max_off > off);
+    // Entries of one particle land contiguously at [off, max_off); their order inside the range is irrelevant: the tile
+    // sort that follows is stable per tile and each (tile, particle) pair occurs once.  Small boxes: four particles at a
+    // time, one per 16-lane row; large boxes: one particle at a time across the wave (same split as the counting pass).
+    const TileConic tc = tile_conic(co);
+    const bool has = max_off > off;
+    const int area = has ? bbox_area(bb) : 0;
+    const bool small = has && bbox_fits_row(bb);
+    const bool culling = P.tile_culling != 0;
+    const int row_shift = lane & 48;
+    const unsigned long long small_mask = __ballot(small);
+    const uint32_t row_lt = (1u << (lane & 15)) - 1u;
+    for (int k = 0; k < 16; ++k) {
+        if (!(small_mask & (0x0001000100010001ull << k))) continue;
+        const int src = row_shift | k;
+        const bool act = row_bcast_i((int)small, src) != 0;
+        const TileBBox sb = {row_bcast_i(bb.minx, src), row_bcast_i(bb.miny, src), row_bcast_i(bb.maxx, src), row_bcast_i(bb.maxy, src)};
+        const TileConic sco = {row_bcast_f(tc.cx, src), row_bcast_f(tc.cy, src), row_bcast_f(tc.cz, src), row_bcast_f(tc.rcpx, src),
+                               row_bcast_f(tc.rcpy, src)};
+        const uint32_t sp = (uint32_t)row_bcast_i((int)p, src), send = act ? (uint32_t)row_bcast_i((int)max_off, src) : 0u;
+        uint32_t o = (uint32_t)row_bcast_i((int)off, src);
+        row_tile_walk(lane, P.gx, culling, act, sb, sco, row_bcast_f(cx, src), row_bcast_f(cy, src), row_bcast_f(pmax, src),
+                      [&](bool keep, uint32_t tile) {
+                          const uint32_t m = (uint32_t)((__ballot(keep) >> row_shift) & 0xFFFFull);
+                          const uint32_t slot = o + (uint32_t)__popc(m & row_lt);
+                          if (keep && slot < send) {  // the sort carries the expansion position, not the particle
+                              tile_keys[slot] = tile;
+                              tile_vals[slot] = slot;
+                              pos_particle[slot] = sp;
+                          }
+                          o += (uint32_t)__popc(m);
+                      });
+        for (uint32_t q = o + (lane & 15); q < send; q += 16) {  // gutProjector.cuh:372-376 padding
+            tile_keys[q] = 0xFFFFFFFFu;
+            tile_vals[q] = q;
+            pos_particle[q] = 0xFFFFFFFFu;
+        }
+    }
+    unsigned long long todo = __ballot(has && !small);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         const TileBBox sb = {bcast_i(bb.minx, src), bcast_i(bb.miny, src), bcast_i(bb.maxx, src), bcast_i(bb.maxy, src)};
-        const float4 sco = make_float4(bcast_f(co.x, src), bcast_f(co.y, src), bcast_f(co.z, src), 0.f);
+        const TileConic sco = {bcast_f(tc.cx, src), bcast_f(tc.cy, src), bcast_f(tc.cz, src), bcast_f(tc.rcpx, src), bcast_f(tc.rcpy, src)};
         const uint32_t sp = (uint32_t)bcast_i((int)p, src), send = (uint32_t)bcast_i((int)max_off, src);
         uint32_t o = (uint32_t)bcast_i((int)off, src);
-        coop_tile_walk(lane, P.gx, P.tile_culling != 0, sb, sco, bcast_f(cx, src), bcast_f(cy, src), bcast_f(pmax, src),
+        coop_tile_walk(lane, P.gx, culling, sb, sco, bcast_f(cx, src), bcast_f(cy, src), bcast_f(pmax, src),
                        [&](bool keep, uint32_t tile) {
                            const unsigned long long m = __ballot(keep);
                            const uint32_t slot = o + (uint32_t)__popcll(m & lt_mask);
-                           if (keep && slot < send) {  // the sort carries the expansion position, not the particle
+                           if (keep && slot < send) {
                                tile_keys[slot] = tile;
                                tile_vals[slot] = slot;
                                pos_particle[slot] = sp;
                            }
                            o += (uint32_t)__popcll(m);
                        });
-        for (uint32_t k = o + lane; k < send; k += 64) {  // gutProjector.cuh:372-376 padding
-            tile_keys[k] = 0xFFFFFFFFu;
-            tile_vals[k] = k;
-            pos_particle[k] = 0xFFFFFFFFu;
+        for (uint32_t q = o + lane; q < send; q += 64) {
+            tile_keys[q] = 0xFFFFFFFFu;
+            tile_vals[q] = q;
+            pos_particle[q] = 0xFFFFFFFFu;
         }
     }
 }
@@ -403,79 +512,142 @@ __device__ __forceinline__ float4 quat_contract(const float m[9], float4 q2) {
     return d;
 }
 
+// Four lanes per particle: lane c of a quad owns column c (one float4) of the 16-float slot rows, so that a row is ONE
+// 64-byte request of four neighbouring lanes (a lane per particle needed four requests per row, each touching a different
+// cache line in every lane: the texture path, not HBM, was the limit).  With hit-distance gradients the rows have a fifth
+// column, read by lane 0 of the quad.
 template <int STRIDE>
-__device__ __forceinline__ void add_slot(const float* __restrict__ partial, size_t slot, float (&acc)[STRIDE]) {
-    const float4* pp = reinterpret_cast<const float4*>(partial + slot * STRIDE);
-#pragma unroll
-    for (int k = 0; k < STRIDE / 4; ++k) {
-        const float4 v = pp[k];
-        acc[4 * k] += v.x; acc[4 * k + 1] += v.y; acc[4 * k + 2] += v.z; acc[4 * k + 3] += v.w;
+struct QuadAcc {
+    float4 a;
+    float4 x;  // fifth column (STRIDE == 20), lane c == 0 only
+    __device__ __forceinline__ void clear() { a = make_float4(0.f, 0.f, 0.f, 0.f); x = a; }
+    // rows sb+b0 .. sb+b3 (b < 0: none), requested together and summed in this order
+    __device__ __forceinline__ void add_rows4(const float* __restrict__ partial, size_t sb, int b0, int b1, int b2, int b3, int c) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* r0 = reinterpret_cast<const float4*>(partial + (sb + (size_t)b0) * STRIDE);
+        const float4* r1 = reinterpret_cast<const float4*>(partial + (sb + (size_t)(b1 < 0 ? b0 : b1)) * STRIDE);
+        const float4* r2 = reinterpret_cast<const float4*>(partial + (sb + (size_t)(b2 < 0 ? b0 : b2)) * STRIDE);
+        const float4* r3 = reinterpret_cast<const float4*>(partial + (sb + (size_t)(b3 < 0 ? b0 : b3)) * STRIDE);
+        const float4 v0 = r0[c], v1 = r1[c], v2 = r2[c], v3 = r3[c];
+        float4 w0 = z, w1 = z, w2 = z, w3 = z;
+        if (STRIDE > 16 && c == 0) { w0 = r0[4]; w1 = r1[4]; w2 = r2[4]; w3 = r3[4]; }
+        a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+        if (b1 >= 0) { a.x += v1.x; a.y += v1.y; a.z += v1.z; a.w += v1.w; }
+        if (b2 >= 0) { a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w; }
+        if (b3 >= 0) { a.x += v3.x; a.y += v3.y; a.z += v3.z; a.w += v3.w; }
+        if (STRIDE > 16 && c == 0) {
+            x.x += w0.x; x.y += w0.y; x.z += w0.z; x.w += w0.w;
+            if (b1 >= 0) { x.x += w1.x; x.y += w1.y; x.z += w1.z; x.w += w1.w; }
+            if (b2 >= 0) { x.x += w2.x; x.y += w2.y; x.z += w2.z; x.w += w2.w; }
+            if (b3 >= 0) { x.x += w3.x; x.y += w3.y; x.z += w3.z; x.w += w3.w; }
+        }
     }
+    __device__ __forceinline__ void add_row(const float* __restrict__ partial, size_t slot, int c) {
+        const float4* row = reinterpret_cast<const float4*>(partial + slot * STRIDE);
+        const float4 v = row[c];
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        if (STRIDE > 16 && c == 0) {
+            const float4 w = row[4];
+            x.x += w.x; x.y += w.y; x.z += w.z; x.w += w.w;
+        }
+    }
+};
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v) {  // value of lane J of the caller's quad
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false));
+}
+__device__ __forceinline__ float xor_sum_quads(float v) {  // sum over the 16 quads of a wave, same column: lanes c, c+4, ...
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
 }
 
 template <int STRIDE>
 __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutProjected proj, const float4* __restrict__ density12,
                                                               GutGradSlots slots, int have_partials, float* __restrict__ g_density12,
                                                               float* __restrict__ g_rgb) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, c = threadIdx.x & 3;
+    const uint32_t i = blockIdx.x * 64u + (threadIdx.x >> 2);
     const uint32_t count = (i < P.N) ? proj.tiles_count[i] : 0u;
     const bool has = count != 0;
-    float acc[STRIDE];
-#pragma unroll
-    for (int k = 0; k < STRIDE; ++k) acc[k] = 0.f;
+    QuadAcc<STRIDE> acc;
+    acc.clear();
     const uint32_t off = has ? proj.part_offset[i] : 0u;
+#ifdef GRUT_DIAG_NO_FLAGS
+    have_partials = 0;
+#endif
     if (have_partials) {
         if (has && count <= kGatherSmall) {
-            // 16 flags per (unaligned) load; set flags are rare (most tile entries lie behind the rays' termination)
+            // Set flags are rare (most tile entries lie behind the rays' termination) and every load here is a dependent
+            // round trip to HBM, so requests are issued in groups: 64 flags (four 16-byte loads) are packed into one bit
+            // mask, then the rows of up to four set bits are requested together before any of them is summed.
             const size_t s0 = 2 * (size_t)off;
             const uint32_t nb = 2 * count;
-            for (uint32_t c = 0; c < nb; c += 16) {
-                const FlagChunk w = *reinterpret_cast<const FlagChunk*>(slots.flag + s0 + c);  // buffer has 32 B of slack
-                const uint32_t rem = nb - c;
-                unsigned long long lo = w.lo, hi = w.hi;
-                if (rem < 8) { lo &= (1ull << (8 * rem)) - 1ull; hi = 0ull; }
-                else if (rem < 16) hi &= (rem == 8) ? 0ull : ((1ull << (8 * (rem - 8))) - 1ull);
-                while (lo) {
-                    const int b = (__ffsll((long long)lo) - 1) >> 3;
-                    lo &= ~(0xFFull << (8 * b));
-                    add_slot<STRIDE>(slots.partial, s0 + c + b, acc);
-                }
-                while (hi) {
-                    const int b = (__ffsll((long long)hi) - 1) >> 3;
-                    hi &= ~(0xFFull << (8 * b));
-                    add_slot<STRIDE>(slots.partial, s0 + c + 8 + b, acc);
+            for (uint32_t base = 0; base < nb; base += 64) {
+                const FlagChunk* fc = reinterpret_cast<const FlagChunk*>(slots.flag + s0 + base);  // buffer has 96 B of slack
+                const FlagChunk w0 = fc[0], w1 = fc[1], w2 = fc[2], w3 = fc[3];
+                // gather bit 0 of each of 8 flag bytes into one byte (bytes past the flag array are arbitrary: keep bit 0 only,
+                // or they would carry into their neighbours' bits)
+                constexpr unsigned long long kPack = 0x0102040810204080ull, kLsb = 0x0101010101010101ull;
+                auto pack8 = [](unsigned long long w) { return ((w & kLsb) * kPack) >> 56; };
+                unsigned long long m = pack8(w0.lo) | (pack8(w0.hi) << 8) | (pack8(w1.lo) << 16) | (pack8(w1.hi) << 24) |
+                                       (pack8(w2.lo) << 32) | (pack8(w2.hi) << 40) | (pack8(w3.lo) << 48) | (pack8(w3.hi) << 56);
+                const uint32_t rem = nb - base;
+                if (rem < 64) m &= (1ull << rem) - 1ull;
+                const size_t sb = s0 + base;
+                while (m) {
+                    const int b0 = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int b1 = m ? __ffsll((long long)m) - 1 : -1;
+                    m &= m - 1;   // m == 0 stays 0
+                    const int b2 = m ? __ffsll((long long)m) - 1 : -1;
+                    m &= m - 1;
+                    const int b3 = m ? __ffsll((long long)m) - 1 : -1;
+                    m &= m - 1;
+                    acc.add_rows4(slots.partial, sb, b0, b1, b2, b3, c);
                 }
             }
         }
-        unsigned long long big = __ballot(has && count > kGatherSmall);
+        // the heavy tail: all 16 quads of the wave share one particle's slots
+        unsigned long long big = __ballot(has && count > kGatherSmall && c == 0);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
             const size_t s0 = 2 * (size_t)(uint32_t)__builtin_amdgcn_readlane((int)off, src);
             const uint32_t n2 = 2u * (uint32_t)__builtin_amdgcn_readlane((int)count, src);
-            float part[STRIDE];
-#pragma unroll
-            for (int k = 0; k < STRIDE; ++k) part[k] = 0.f;
-            for (uint32_t k = lane; k < n2; k += 64)
-                if (slots.flag[s0 + k]) add_slot<STRIDE>(slots.partial, s0 + k, part);
-#pragma unroll
-            for (int k = 0; k < STRIDE; ++k) {
-                const float tot = wave_sum(part[k]);
-                if (lane == src) acc[k] = tot;
+            QuadAcc<STRIDE> part;
+            part.clear();
+            for (uint32_t k = lane >> 2; k < n2; k += 16)
+                if (slots.flag[s0 + k]) part.add_row(slots.partial, s0 + k, c);
+            part.a.x = xor_sum_quads(part.a.x); part.a.y = xor_sum_quads(part.a.y);
+            part.a.z = xor_sum_quads(part.a.z); part.a.w = xor_sum_quads(part.a.w);
+            if (STRIDE > 16) {
+                part.x.x = xor_sum_quads(part.x.x); part.x.y = xor_sum_quads(part.x.y);
+                part.x.z = xor_sum_quads(part.x.z); part.x.w = xor_sum_quads(part.x.w);
             }
+            if ((lane >> 2) == (src >> 2)) acc = part;
         }
     }
+    // every lane of the quad collects the whole row sum (column j from lane j) and redoes the small closing arithmetic;
+    // lane c then stores output column c, so a particle's 48 + 12 bytes leave as neighbouring requests
+    float r[20];
+    r[0] = quad_bcast<0>(acc.a.x); r[1] = quad_bcast<0>(acc.a.y); r[2] = quad_bcast<0>(acc.a.z); r[3] = quad_bcast<0>(acc.a.w);
+    r[4] = quad_bcast<1>(acc.a.x); r[5] = quad_bcast<1>(acc.a.y); r[6] = quad_bcast<1>(acc.a.z); r[7] = quad_bcast<1>(acc.a.w);
+    r[8] = quad_bcast<2>(acc.a.x); r[9] = quad_bcast<2>(acc.a.y); r[10] = quad_bcast<2>(acc.a.z); r[11] = quad_bcast<2>(acc.a.w);
+    r[12] = quad_bcast<3>(acc.a.x); r[13] = quad_bcast<3>(acc.a.y); r[14] = quad_bcast<3>(acc.a.z); r[15] = quad_bcast<3>(acc.a.w);
+    r[16] = quad_bcast<0>(acc.x.x); r[17] = quad_bcast<0>(acc.x.y); r[18] = quad_bcast<0>(acc.x.z); r[19] = 0.f;
     if (i >= P.N) return;
     float4* gd = reinterpret_cast<float4*>(g_density12 + 12 * (size_t)i);
     if (!has) {
-        gd[0] = gd[1] = gd[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < 3) gd[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     const float4 q = density12[3 * (size_t)i + 1], sc = density12[3 * (size_t)i + 2];
     const m3 rt = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
-    const f3 B = mk3(acc[0], acc[1], acc[2]);
-    const float* m = &acc[4];
+    const f3 B = mk3(r[0], r[1], r[2]);
+    const float* m = &r[4];
     // position = -R B  (matmul_bw_vec with rows of R^T); the SH direction term is added by the projection backward
     const f3 gpos = mk3(-(B.x * rt.r0.x + B.y * rt.r1.x + B.z * rt.r2.x), -(B.x * rt.r0.y + B.y * rt.r1.y + B.z * rt.r2.y),
                         -(B.x * rt.r0.z + B.y * rt.r1.z + B.z * rt.r2.z));
@@ -483,14 +655,16 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     float gsx = -(rt.r0.x * m[0] + rt.r0.y * m[1] + rt.r0.z * m[2]) / sc.x;
     float gsy = -(rt.r1.x * m[3] + rt.r1.y * m[4] + rt.r1.z * m[5]) / sc.y;
     float gsz = -(rt.r2.x * m[6] + rt.r2.y * m[7] + rt.r2.z * m[8]) / sc.z;
-    if (STRIDE > 16) { gsx += acc[16]; gsy += acc[17]; gsz += acc[18]; }
+    if (STRIDE > 16) { gsx += r[16]; gsy += r[17]; gsz += r[18]; }
     const float4 dq = quat_contract(m, make_float4(2.f * q.x, 2.f * q.y, 2.f * q.z, 2.f * q.w));
-    gd[0] = make_float4(gpos.x, gpos.y, gpos.z, acc[3]);
-    gd[1] = dq;
-    gd[2] = make_float4(gsx, gsy, gsz, 0.f);
-    g_rgb[3 * (size_t)i] = acc[13];
-    g_rgb[3 * (size_t)i + 1] = acc[14];
-    g_rgb[3 * (size_t)i + 2] = acc[15];
+    if (c == 0) gd[0] = make_float4(gpos.x, gpos.y, gpos.z, r[3]);
+    else if (c == 1) gd[1] = dq;
+    else if (c == 2) gd[2] = make_float4(gsx, gsy, gsz, 0.f);
+    else {
+        g_rgb[3 * (size_t)i] = r[13];
+        g_rgb[3 * (size_t)i + 1] = r[14];
+        g_rgb[3 * (size_t)i + 2] = r[15];
+    }
 }
 
 constexpr int kShStride = 49;
@@ -602,7 +776,7 @@ void launch_project_bwd(hipStream_t s, const GutParams& P, const GutProjected& p
 }
 void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
                           const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, float* g_density12, float* g_sph) {
-    const dim3 grid(div_up(P.N, 256)), block(256);
+    const dim3 grid(div_up(P.N, 64)), block(256);  // four lanes per particle
     if (has_gdist)
         hipLaunchKernelGGL(gut_grad_gather_kernel<20>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
                            have_partials ? 1 : 0, g_density12, g_rgb);
