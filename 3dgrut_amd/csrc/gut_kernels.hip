@@ -682,11 +682,29 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
     const FramePoses& FP = frame_poses(P);
     const bool has = (i < P.N) && (tiles_count[i] != 0);
     const unsigned long long has_mask = __ballot(has);
-    // stage in: one row per step, lanes across the row
-    for (unsigned long long m = has_mask; m;) {
-        const int row = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        if (lane < 3 * nact) rows[row * kShStride + lane] = sph[(size_t)(wave_base + row) * rowlen + lane];
+    const int nrows = (int)min(64u, P.N > wave_base ? P.N - wave_base : 0u);
+    // stage in.  48-float rows: the wave's rows are one contiguous, 16-byte aligned block, copied as independent float4
+    // requests (12 per lane in flight); rows of particles without tiles ride along.  Other row lengths: one row per step.
+    if (rowlen == 48) {
+        if (has_mask) {
+            const float4* src = reinterpret_cast<const float4*>(sph + (size_t)wave_base * 48);
+            const int total4 = nrows * 12;
+#pragma unroll
+            for (int it = 0; it < 12; ++it) {
+                const int q = lane + 64 * it;
+                if (q < total4) {
+                    const float4 v = src[q];
+                    float* d = rows + (q / 12) * kShStride + 4 * (q % 12);
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+            }
+        }
+    } else {
+        for (unsigned long long m = has_mask; m;) {
+            const int row = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (lane < 3 * nact) rows[row * kShStride + lane] = sph[(size_t)(wave_base + row) * rowlen + lane];
+        }
     }
     __syncthreads();
     float* myrow = rows + lane * kShStride;
@@ -725,9 +743,21 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
     }
     __syncthreads();
     // stage out: every row of the wave, zeros included (the caller does not pre-fill grad_sph)
-    const int nrows = (int)min(64u, P.N > wave_base ? P.N - wave_base : 0u);
-    for (int row = 0; row < nrows; ++row)
-        if (lane < rowlen) g_sph[(size_t)(wave_base + row) * rowlen + lane] = rows[row * kShStride + lane];
+    if (rowlen == 48) {
+        float4* dst = reinterpret_cast<float4*>(g_sph + (size_t)wave_base * 48);
+        const int total4 = nrows * 12;
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int q = lane + 64 * it;
+            if (q < total4) {
+                const float* d = rows + (q / 12) * kShStride + 4 * (q % 12);
+                dst[q] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    } else {
+        for (int row = 0; row < nrows; ++row)
+            if (lane < rowlen) g_sph[(size_t)(wave_base + row) * rowlen + lane] = rows[row * kShStride + lane];
+    }
 }
 
 // frame poses from camera-to-world matrices in device memory (no host round trip, no stream sync)
