@@ -191,10 +191,28 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint32_t
     hist[(size_t)d * nb + blockIdx.x] = s_hist[0][d] + s_hist[1][d] + s_hist[2][d] + s_hist[3][d];
 }
 
+// Exclusive scan of each digit's row of per-block counts (in place) + the digit totals: with the 256-entry scan of the
+// totals done inside the scatter kernel this replaces a generic three-kernel scan of the whole matrix per pass.
+__global__ __launch_bounds__(kSortThreads) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nb, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t s_wave[4];
+    uint32_t* row = hist + (size_t)blockIdx.x * nb;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += kSortThreads) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nb ? row[i] : 0u;
+        uint32_t total;
+        const uint32_t excl = block_excl_scan_256(v, &total, s_wave);
+        if (i < nb) row[i] = carry + excl;
+        carry += total;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in, uint32_t n,
                                                                      const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
                                                                      uint32_t nb, const uint32_t* __restrict__ hist_scanned,
+                                                                     const uint32_t* __restrict__ digit_totals,
                                                                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
     // per-wave digit counters; after the ranking phase they are turned into global scatter bases
     __shared__ uint32_t s_cnt[4][kRadix];
@@ -238,16 +256,26 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
         rank[r] = old + before;
     }
     __syncthreads();
-    // thread d: exclusive prefix of digit d over the 4 waves + global base of (digit, block)
+    // Reorder the block's pairs by digit in LDS first, then write them out in that order: neighbouring lanes then store to
+    // neighbouring addresses (a run per digit) instead of 64 unrelated lines per store instruction.
+    __shared__ uint32_t s_keys[kSortTile], s_vals[kSortTile];
+    __shared__ uint32_t s_dstart[kRadix];  // first slot of digit d in the block-sorted order
+    __shared__ uint32_t s_gdelta[kRadix];  // (global base of (digit, block)) - s_dstart[d]
+    __shared__ uint32_t s_wave_tot[4];
     {
         const uint32_t d = threadIdx.x;
-        uint32_t run = hist_scanned[(size_t)d * nb + blockIdx.x];
+        uint32_t run = 0;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < 4; ++w) {  // exclusive prefix of digit d over the 4 waves
             const uint32_t c = s_cnt[w][d];
             s_cnt[w][d] = run;
             run += c;
         }
+        uint32_t total;
+        const uint32_t excl = block_excl_scan_256(run, &total, s_wave_tot);
+        const uint32_t digit_base = block_excl_scan_256(digit_totals[d], &total, s_wave_tot);  // keys with a smaller digit, all blocks
+        s_dstart[d] = excl;
+        s_gdelta[d] = digit_base + hist_scanned[(size_t)d * nb + blockIdx.x] - excl;
     }
     __syncthreads();
 #pragma unroll
@@ -255,9 +283,21 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
         const uint32_t i = wbase + r * 64 + lane;
         if (i < ne) {
             const uint32_t d = (key[r] >> shift) & mask;
-            const uint32_t dst = s_cnt[wave][d] + rank[r];
-            keys_out[dst] = key[r];
-            vals_out[dst] = val[r];
+            const uint32_t pos = s_dstart[d] + s_cnt[wave][d] + rank[r];
+            s_keys[pos] = key[r];
+            s_vals[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t nvalid = min((uint32_t)kSortTile, ne - base);
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t idx = r * kSortThreads + threadIdx.x;
+        if (idx < nvalid) {
+            const uint32_t k = s_keys[idx];
+            const uint32_t dst = s_gdelta[(k >> shift) & mask] + idx;
+            keys_out[dst] = k;
+            vals_out[dst] = s_vals[idx];
         }
     }
 }
@@ -274,7 +314,7 @@ int inclusive_scan_u32(hipStream_t s, uint32_t n, const uint32_t* in, const uint
 size_t sort_scratch_bytes(uint32_t n) {
     const uint32_t nb = div_up(n, kSortTile);
     const size_t hist = (size_t)kRadix * nb * sizeof(uint32_t);
-    return hist + scan_scratch_bytes(kRadix * nb) + 256;
+    return hist + kRadix * sizeof(uint32_t) + 256;  // per-block digit counts + digit totals
 }
 
 int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_bit, int end_bit,
@@ -286,15 +326,14 @@ int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_b
     GRUT_REQUIRE(scratch_bytes >= sort_scratch_bytes(n), "sort scratch too small");
     const uint32_t nb = div_up(n, kSortTile);
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch);
-    void* scan_scratch = hist + (size_t)kRadix * nb;
-    const size_t scan_bytes = scan_scratch_bytes(kRadix * nb);
+    uint32_t* totals = hist + (size_t)kRadix * nb;
     uint32_t *ki = keys, *vi = vals, *ko = keys_tmp, *vo = vals_tmp;
     for (int bit = begin_bit; bit < end_bit; bit += 8) {
         const int nbits = (end_bit - bit) < 8 ? (end_bit - bit) : 8;
         const uint32_t mask = (1u << nbits) - 1u;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(kSortThreads), 0, s, ki, n, n_dev, bit, mask, nb, hist);
-        GRUT_CHECK(scan_impl(s, kRadix * nb, hist, nullptr, hist, true, scan_scratch, scan_bytes));
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(kSortThreads), 0, s, ki, vi, n, n_dev, bit, mask, nb, hist, ko, vo);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(kSortThreads), 0, s, hist, nb, totals);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(kSortThreads), 0, s, ki, vi, n, n_dev, bit, mask, nb, hist, totals, ko, vo);
         uint32_t* t;
         t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
