@@ -102,6 +102,8 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms):
     g_fd_np, _ = syn.upstream_grads(W, H)
     g_fd = torch.as_tensor(g_fd_np, device=dev)
 
+    exch = importlib.import_module("3dgrut_amd.dp").GradientExchange(g.parameters(), average=False) if world > 1 else None
+
     def step():
         g.zero_grad()
         tracer.build_acc(g, rebuild=True)
@@ -109,8 +111,7 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms):
         fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
         torch.autograd.backward([fd], [g_fd])
         if world > 1:
-            flat = torch.cat([p.grad.reshape(-1) for p in g.parameters()])
-            dist.all_reduce(flat)
+            exch.reduce()
 
     for _ in range(args.warmup):
         step()
@@ -159,13 +160,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; the modulo only matters for the plumbing check of the multi-rank path on a 1-GPU box
+    # (GRUT_BENCH_BACKEND=gloo, two ranks sharing the device), never on a node with >= N GPUs
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        backend = os.environ.get("GRUT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     syn = importlib.import_module("3dgrut_amd.synthetic")
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
@@ -185,19 +193,16 @@ def main():
     g_fd_np, g_dist_np = syn.upstream_grads(W, H)
     g_fd = torch.as_tensor(g_fd_np, device=dev)
     g_rgb, g_opa = g_fd[None, ..., :3].contiguous(), g_fd[None, ..., 3:].contiguous()
-    flat = None
+    exch = importlib.import_module("3dgrut_amd.dp").GradientExchange(g.parameters(), average=False) if world > 1 else None
 
     def step():
-        nonlocal flat
         g.zero_grad()
         out = tracer.render(g, batch, train=True)
         # upstream gradients per SURVEY §8d: d_rgb, d_opacity ~ N(0,1)/P and no gradient into the hit distance
         # (training never back-props depth: trainer.py:677-748)
         torch.autograd.backward([out["pred_features"], out["pred_opacity"]], [g_rgb, g_opa])
-        if world > 1:  # one fused all-reduce of all Gaussian gradients ([N,59] fp32)
-            grads = [p.grad for p in g.parameters()]
-            flat = torch.cat([x.reshape(-1) for x in grads])
-            dist.all_reduce(flat)
+        if world > 1:  # in-place all-reduce of the Gaussian gradients ([N,59] fp32 in five tensors)
+            exch.reduce()
 
     for _ in range(args.warmup):
         step()
