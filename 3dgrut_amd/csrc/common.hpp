@@ -41,6 +41,18 @@ void set_last_error(const char* fmt, ...);
         }                                      \
     } while (0)
 
+// ---- XCD-aware work assignment -----------------------------------------------------------------
+// The dispatcher deals workgroups to the 8 XCDs round-robin by linear id, and every XCD has its own L2.  Mapping
+// workgroup b of n to work item xcd_contiguous(b, n) gives each XCD ONE contiguous range of work items, so that the
+// workgroups resident on an XCD at any time are neighbours (image tiles / pixel blocks that share particles and BVH
+// nodes) instead of every 8th one of a range eight times as wide.  Bijective for any n.
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n) {
+    const uint32_t xcd = b & 7u, idx = b >> 3, q = n >> 3, rem = n & 7u;
+    return xcd * q + (xcd < rem ? xcd : rem) + idx;
+}
+#endif
+
 // ---- grow-only device scratch (the role of CudaBuffer::enlarge, src/cudaBuffer.cpp:44-60) ---
 struct DeviceBuffer {
     void* ptr = nullptr;
