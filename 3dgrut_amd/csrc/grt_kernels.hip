@@ -531,7 +531,10 @@ __device__ __forceinline__ HitGeom hit_geometry(const GrtTraceParams& P, const P
 template <int DEG, bool COUNT>
 // 4 waves per SIMD (128 VGPRs): the walk is a chain of dependent fetches, a fourth wave hides more of it than the few
 // spilled registers cost (measured: 65.8 -> 60.2 ms at 1M particles, 800x800; 5 waves: 69.9 ms)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void grt_trace_fwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
+#ifndef GRT_FWD_WAVES
+#define GRT_FWD_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVES, GRT_FWD_WAVES))) void grt_trace_fwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
                                                            const float* __restrict__ sph, const float* __restrict__ ray_o,
                                                            const float* __restrict__ ray_d, float* __restrict__ out_rad,
                                                            float* __restrict__ out_dns, float* __restrict__ out_hit2,
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const size_t pix = in_image ? (size_t)py * P.W + px : 0;  // out-of-image lanes shadow pixel 0 and never write
     const RayW r = make_ray(P, ray_o, ray_d, pix);
     float basis[16];
-    sh_basis16(P.sph_degree, r.d, basis);
+    // (filled at the start of each round's processing: 16 registers kept alive across the tree walk cost occupancy)
 
     f3 rad = mk3(0.f, 0.f, 0.f), nrm = mk3(0.f, 0.f, 0.f);
     float T = 1.f, depth = 0.f, cnt = 0.f;
@@ -638,6 +641,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const bool full = s_hit_id[(kGather - 1) * 64 + lane] != 0xFFFFFFFFu;
         // ---- first round: the 16 nearest ----
         uint32_t* chunk = open_chunk();
+        {
+            f3 dir = r.d;   // opaque copy: stops the compiler from hoisting the basis back out of the round loop
+            asm volatile("" : "+v"(dir.x), "+v"(dir.y), "+v"(dir.z));
+            sh_basis16(P.sph_degree, dir, basis);
+        }
 #pragma unroll 1
         for (int i = 0; i < kGrtMaxHits; ++i) {
             const uint32_t id = s_hit_id[i * 64 + lane];

@@ -4,6 +4,7 @@
     python scripts/rocprof_summary.py stats  <stats.db>  > profiles/rNN_kernel_stats.txt
     python scripts/rocprof_summary.py pmc    <fetch.db> <write.db>  > profiles/rNN_pmc_hbm.txt
     python scripts/rocprof_summary.py traffic <fetch.db> <write.db> <workload>   (writes profiles/pmc_traffic.json)
+    python scripts/rocprof_summary.py counters <pmc.db> [title]   > profiles/rNN_sq_counters.txt
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE tallies 128-B read requests at 64 B
 (MI355X_MICROARCH.md, "HBM"): the corrected column doubles it.  WRITE_SIZE is taken as reported (uncalibrated there).
@@ -46,6 +47,26 @@ def counter_avgs(db, counter):
     return {k: (n, v / n, d / n) for k, (n, v, d) in out.items()}
 
 
+def counters(db, title=""):
+    """every counter of a --pmc run, averaged per dispatch and per kernel"""
+    c = sqlite3.connect(db)
+    acc = {}
+    for name, counter, value, dur in c.execute("select kernel_name, counter_name, value, duration from counters_collection"):
+        k = acc.setdefault(short(name), {})
+        v = k.setdefault(counter, [0.0, 0])
+        v[0] += value; v[1] += 1
+        d = k.setdefault("dur_us", [0.0, 0])
+        d[0] += dur / 1e3; d[1] += 1
+    if title:
+        print(f"# {title}")
+    print("# averages per dispatch")
+    for kname in sorted(acc):
+        print(kname)
+        for cn in sorted(acc[kname]):
+            tot, n = acc[kname][cn]
+            print(f"   {cn:24s} {tot / max(n, 1):16.1f}")
+
+
 def pmc(fetch_db, write_db):
     f = counter_avgs(fetch_db, "FETCH_SIZE")
     w = counter_avgs(write_db, "WRITE_SIZE")
@@ -81,4 +102,4 @@ def traffic(fetch_db, write_db, workload):
 
 if __name__ == "__main__":
     cmd = sys.argv[1]
-    {"stats": stats, "pmc": pmc, "traffic": traffic}[cmd](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "traffic": traffic, "counters": counters}[cmd](*sys.argv[2:])
