@@ -264,12 +264,26 @@ struct Cand {
 };
 // `t_lo` / (`t_hi`, `id_hi`): the caller only wants candidates with t_lo < t and (t, id) < (t_hi, id_hi); the hit distance
 // is evaluated first and the (division-heavy) box test only for those — the values themselves are unaffected.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef const f4v __attribute__((address_space(4))) cfloat4;   // constant address space: uniform addresses load through the scalar cache
+__device__ __forceinline__ float4 ld4(const float4* p, int k) { return p[k]; }
+__device__ __forceinline__ float4 ld4(const cfloat4* p, int k) { const f4v v = p[k]; return make_float4(v.x, v.y, v.z, v.w); }
+// Q = const float4 (per-lane record) or cfloat4 (wave-uniform record of a read-only array: fetched once per wave)
+template <typename Q>
+__device__ __forceinline__ Cand candidate_q(const Q* __restrict__ rec, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi);
 __device__ __forceinline__ Cand candidate(const float* __restrict__ inst, const RayW& r, float t_lo = -3.0e38f, float t_hi = 3.0e38f,
                                           uint32_t id = 0u, uint32_t id_hi = 0xFFFFFFFFu) {
+    return candidate_q(reinterpret_cast<const float4*>(inst), r, t_lo, t_hi, id, id_hi);
+}
+__device__ __forceinline__ Cand candidate_uniform(const float* inst, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
+    return candidate_q(reinterpret_cast<const cfloat4*>(reinterpret_cast<uintptr_t>(inst)), r, t_lo, t_hi, id, id_hi);
+}
+template <typename Q>
+__device__ __forceinline__ Cand candidate_q(const Q* __restrict__ rec, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
 #pragma clang fp contract(off)
     Cand c;
     c.ok = false; c.t = 0.f; c.tnear = 0.f; c.tfar = 0.f;
-    const float4 a = reinterpret_cast<const float4*>(inst)[0], b = reinterpret_cast<const float4*>(inst)[1], e = reinterpret_cast<const float4*>(inst)[2];
+    const float4 a = ld4(rec, 0), b = ld4(rec, 1), e = ld4(rec, 2);
     // inst = {W00 W01 W02 W10 | W11 W12 W20 W21 | W22 mux muy muz}
     const float dlx = r.o.x - e.y, dly = r.o.y - e.z, dlz = r.o.z - e.w;
     const float pox = a.x * dlx + a.y * dly + a.z * dlz, poy = a.w * dlx + b.x * dly + b.y * dlz, poz = b.z * dlx + b.w * dly + e.x * dlz;
@@ -400,8 +414,10 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
         have = false;
         cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
         if (COUNT && lane == 0) tc.nodes++;
-        const float4* nq = reinterpret_cast<const float4*>(&bvh.nodes[cur]);
-        const float4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+        // `cur` is wave-uniform and the tree is read-only while rays are traced: the constant address space makes this ONE
+        // scalar fetch per wave (node in SGPRs) instead of four vector loads that occupy 16 VGPRs per lane
+        const cfloat4* nq = reinterpret_cast<const cfloat4*>(reinterpret_cast<uintptr_t>(&bvh.nodes[cur]));
+        const float4 q0 = ld4(nq, 0), q1 = ld4(nq, 1), q2 = ld4(nq, 2), q3 = ld4(nq, 3);
         const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q1.x, q1.y, q1.z}, lo1[3] = {q2.x, q2.y, q2.z}, hi1[3] = {q3.x, q3.y, q3.z};
         const uint32_t c0 = __float_as_uint(q0.w), c1 = __float_as_uint(q2.w);
         float tn0, tf0, tn1, tf1;
@@ -413,7 +429,7 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
         if (a0 && (c0 & kGrtLeafBit)) {
             const uint32_t id = c0 & ~kGrtLeafBit;
             if (h0) {
-                const Cand c = candidate(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
+                const Cand c = candidate_uniform(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
                 if (COUNT) tc.leaf_tests++;
                 if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
                     hit_less(c.t, id, buf.t[G - 1], buf.id[G - 1])) {
@@ -426,7 +442,7 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
         if (a1 && (c1 & kGrtLeafBit)) {
             const uint32_t id = c1 & ~kGrtLeafBit;
             if (h1) {
-                const Cand c = candidate(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
+                const Cand c = candidate_uniform(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
                 if (COUNT) tc.leaf_tests++;
                 if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
                     hit_less(c.t, id, buf.t[G - 1], buf.id[G - 1])) {
