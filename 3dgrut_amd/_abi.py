@@ -108,7 +108,7 @@ EXPORTED_SYMBOLS = [
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats",
     "grt_debug_forward_hits", "grt_debug_fetch_instances",
-    "grut_selective_adam_update",
+    "grut_selective_adam_update", "grut_pack_particles",
     "grut_last_error", "grut_abi_version",
 ]
 
@@ -164,6 +164,8 @@ def _declare(lib):
     lib.grt_stats.restype = C.c_int
     lib.grut_selective_adam_update.argtypes = [vp, C.POINTER(GrutAdamGroup), C.c_int, C.c_uint32, vp, C.c_int]
     lib.grut_selective_adam_update.restype = C.c_int
+    lib.grut_pack_particles.argtypes = [vp, C.c_uint32, fp, fp, fp, fp, fp]
+    lib.grut_pack_particles.restype = C.c_int
     lib.grut_last_error.argtypes = []
     lib.grut_last_error.restype = C.c_char_p
     lib.grut_abi_version.argtypes = []
@@ -192,6 +194,18 @@ def load_library(path: str | None = None):
     if path is None:
         _lib = lib
     return lib
+
+
+def pack_particles(mog_pos, mog_dns, mog_rot, mog_scl):
+    """[N,12] ParticleDensity rows from the four activated Gaussian tensors (CUDA fp32), one HIP pass instead of torch.cat."""
+    import torch
+    lib = load_library()
+    n = int(mog_pos.shape[0])
+    parts = [t.detach().reshape(n, -1).contiguous().float() for t in (mog_pos, mog_dns, mog_rot, mog_scl)]
+    out = torch.empty((n, 12), dtype=torch.float32, device=mog_pos.device)
+    stream = C.c_void_p(torch.cuda.current_stream(mog_pos.device).cuda_stream)
+    check(lib.grut_pack_particles(stream, n, *[C.c_void_p(p.data_ptr()) for p in parts], C.c_void_p(out.data_ptr())), "grut_pack_particles")
+    return out
 
 
 def check(status: int, what: str):

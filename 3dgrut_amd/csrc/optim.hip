@@ -87,7 +87,38 @@ __global__ __launch_bounds__(kAdamThreads) void selective_adam_kernel(const Adam
     }
 }
 
+// ---- parameter marshalling ---------------------------------------------------------------------
+// The renderers consume ParticleDensity rows {position, density, quaternion, scale, pad} (48 B); the model keeps the four
+// tensors apart and the reference's plugin concatenates them with torch.cat every call (threedgut_tracer/tracer.py:178,
+// threedgrt_tracer/tracer.py:93-96).  One pass, 44 B in / 48 B out per particle; a lane writes one float4 of a row.
+__global__ __launch_bounds__(256) void pack_particles_kernel(uint32_t n, const float* __restrict__ pos, const float* __restrict__ dns,
+                                                             const float* __restrict__ rot, const float* __restrict__ scl,
+                                                             float4* __restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;   // float4 index: row = q / 3, part = q % 3
+    if (q >= 3u * n) return;
+    const uint32_t i = q / 3u, part = q - 3u * i;
+    float4 v;
+    if (part == 0u) v = make_float4(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], dns[i]);
+    else if (part == 1u) v = reinterpret_cast<const float4*>(rot)[i];
+    else v = make_float4(scl[3 * (size_t)i], scl[3 * (size_t)i + 1], scl[3 * (size_t)i + 2], 0.f);
+    out[q] = v;
+}
+
 }  // namespace grut
+
+extern "C" int grut_pack_particles(void* stream, uint32_t num_particles, const float* positions, const float* density,
+                                   const float* rotation, const float* scale, float* particle_density) {
+    using namespace grut;
+    if (num_particles == 0) return GRUT_OK;
+    GRUT_REQUIRE(positions && density && rotation && scale && particle_density, "grut_pack_particles: null tensor");
+    GRUT_REQUIRE(((uintptr_t)rotation | (uintptr_t)particle_density) % 16 == 0, "grut_pack_particles: rotation / output must be 16-byte aligned");
+    GRUT_REQUIRE(num_particles <= 0x55555555u, "grut_pack_particles: too many particles");
+    const uint32_t quads = 3u * num_particles;
+    hipLaunchKernelGGL(pack_particles_kernel, dim3((quads + 255u) / 256u), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), num_particles,
+                       positions, density, rotation, scale, reinterpret_cast<float4*>(particle_density));
+    GRUT_HIP(hipGetLastError());
+    return GRUT_OK;
+}
 
 extern "C" int grut_selective_adam_update(void* stream, const GrutAdamGroup* groups, int num_groups, uint32_t num_rows,
                                           const void* visibility, int visibility_kind) {

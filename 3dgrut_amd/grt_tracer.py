@@ -129,7 +129,7 @@ class Tracer:
     class _Autograd(torch.autograd.Function):
         @staticmethod
         def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_sph):
-            particle_density = torch.cat([mog_pos, mog_dns, mog_rot, mog_scl, torch.zeros_like(mog_dns)], dim=1).contiguous()
+            particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)  # [N,12] rows, one pass (tracer.py's torch.cat)
             particle_sph = mog_sph.contiguous()
             feat, dns, hit, nrm, cnt, vis = native.trace(frame, particle_density, particle_sph, ray_ori, ray_dir)
             ctx.save_for_backward(ray_ori, ray_dir, feat, dns, hit, nrm, particle_density, particle_sph)

@@ -258,6 +258,13 @@ int grt_debug_fetch_instances(GrtHandle* handle, void* stream, float* instances)
 int grt_timings(GrtHandle* handle, float* forward_ms, float* backward_ms, float* build_ms);
 int grt_stats(GrtHandle* handle, GrtStats* stats);
 
+/* ---- parameter marshalling -------------------------------------------------- */
+/* [N,3] positions, [N,1] density, [N,4] rotation (wxyz), [N,3] scale (all contiguous fp32, DEVICE) -> [N,12] ParticleDensity
+ * rows {position, density, quaternion, scale, 0}: the torch.cat of threedgut_tracer/tracer.py:178 and
+ * threedgrt_tracer/tracer.py:93-96, in one pass. */
+int grut_pack_particles(void* stream, uint32_t num_particles, const float* positions, const float* density,
+                        const float* rotation, const float* scale, float* particle_density);
+
 /* ---- optimizer step --------------------------------------- */
 /* One parameter group of SelectiveAdam (threedgrut/optimizers/__init__.py:85-124): contiguous fp32 [num_rows, row_width]
  * DEVICE tensors, 16-byte aligned. */

@@ -93,7 +93,7 @@ def traffic(fetch_db, write_db, workload):
         base = re.sub(r"<.*", "", k)
         if base in STAGE_OF:
             res[STAGE_OF[base]] = int((2 * fv + w.get(k, (0, 0.0, 0.0))[1]) * 1024)
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    path = os.environ.get("GRUT_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     allw = json.load(open(path)) if os.path.exists(path) else {}
     allw[workload] = res
     json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
