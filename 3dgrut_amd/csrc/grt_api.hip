@@ -13,7 +13,7 @@ struct GrtHandle {
     uint32_t N = 0;
     bool built = false;
     hipStream_t build_stream = nullptr;
-    DeviceBuffer inst, aabb, slack, scene_enc, scene, codes, ids, codes_tmp, ids_tmp, sort_scratch, nodes, parent_internal, parent_leaf,
+    DeviceBuffer inst, aabb, slack, scene_enc, scene, codes, ids, codes_tmp, ids_tmp, sort_scratch, nodes,
         counters, dbg_ids, dbg_count;
     uint32_t* sorted_ids = nullptr;
     uint32_t* sorted_codes = nullptr;
@@ -95,7 +95,7 @@ int grt_create(const GrtConfig* config, GrtHandle** handle) {
 void grt_destroy(GrtHandle* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
-                            &h->sort_scratch, &h->nodes, &h->parent_internal, &h->parent_leaf, &h->counters, &h->dbg_ids, &h->dbg_count,
+                            &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
                             &h->work_counters, &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state};
     for (DeviceBuffer* b : bufs) b->release();
     if (h->log_state_host) (void)hipHostFree(h->log_state_host);
@@ -125,7 +125,7 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     GRUT_CHECK(h->inst.ensure(n * 48, 1.25f));
     GRUT_CHECK(h->aabb.ensure(n * 24, 1.25f));
     GRUT_CHECK(h->slack.ensure(n * 4, 1.25f));
-    GRUT_CHECK(h->scene_enc.ensure(64));
+    GRUT_CHECK(h->scene_enc.ensure(grt_scene_enc_bytes()));
     GRUT_CHECK(h->scene.ensure(64));
     GRUT_CHECK(h->codes.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->ids.ensure(n * 4, 1.25f));
@@ -133,8 +133,6 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     GRUT_CHECK(h->ids_tmp.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     GRUT_CHECK(h->nodes.ensure(n * sizeof(GrtNode), 1.25f));
-    GRUT_CHECK(h->parent_internal.ensure(n * 4, 1.25f));
-    GRUT_CHECK(h->parent_leaf.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->counters.ensure(n * 4, 1.25f));
 
     GrtBuildParams P;
@@ -143,8 +141,6 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     P.clamping = h->cfg.particle_kernel_density_clamping;
     P.min_response = h->cfg.particle_kernel_min_response;
     uint32_t* scene_enc = h->scene_enc.as<uint32_t>();
-    GRUT_HIP(hipMemsetAsync(scene_enc, 0xFF, 12, s));
-    GRUT_HIP(hipMemsetAsync(scene_enc + 3, 0x00, 12, s));
     grt_launch_proxies(s, P, positions, rotations, scales, densities, h->inst.as<float>(), h->aabb.as<float>(), h->slack.as<float>(), scene_enc);
     // refit-only updates keep the sorted order of the last full build, so the code / id buffers must stay untouched
     grt_launch_morton(s, N, h->aabb.as<float>(), scene_enc, h->scene.as<float>(), rebuild ? h->codes.as<uint32_t>() : nullptr,
@@ -155,13 +151,11 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
                                   h->ids_tmp.as<uint32_t>(), h->sort_scratch.ptr, h->sort_scratch.bytes, &sc, &si));
         h->sorted_codes = sc;
         h->sorted_ids = si;
-        GRUT_HIP(hipMemsetAsync(h->parent_internal.ptr, 0xFF, n * 4, s));
-        grt_launch_hierarchy(s, N, sc, h->nodes.as<GrtNode>(), h->parent_internal.as<uint32_t>(), h->parent_leaf.as<uint32_t>());
+        grt_launch_hierarchy(s, N, sc, si, h->nodes.as<GrtNode>());
     }
     // the refit re-derives every box from the fresh proxies; on rebuild = 0 the sorted order of the last build is reused
-    GRUT_HIP(hipMemsetAsync(h->counters.ptr, 0, n * 4, s));
-    grt_launch_refit(s, N, h->sorted_ids, h->aabb.as<float>(), h->slack.as<float>(), h->parent_internal.as<uint32_t>(),
-                     h->parent_leaf.as<uint32_t>(), h->nodes.as<GrtNode>(), h->counters.as<uint32_t>());
+    GRUT_HIP(hipMemsetAsync(h->counters.ptr, 0, n, s));   // per-node "done in pass" bytes
+    grt_launch_refit(s, N, h->aabb.as<float>(), h->slack.as<float>(), h->nodes.as<GrtNode>(), h->counters.as<uint8_t>());
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.end(s));
     h->N = N;

@@ -60,10 +60,9 @@ struct GrtHitLog {
 void grt_launch_proxies(hipStream_t s, const GrtBuildParams& P, const float* pos, const float* rot, const float* scl, const float* dns,
                         float* inst, float* aabb, float* slack, uint32_t* scene_enc);
 void grt_launch_morton(hipStream_t s, uint32_t N, const float* aabb, const uint32_t* scene_enc, float* scene, uint32_t* codes, uint32_t* ids);
-void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_codes, GrtNode* nodes, uint32_t* parent_internal,
-                          uint32_t* parent_leaf);
-void grt_launch_refit(hipStream_t s, uint32_t N, const uint32_t* sorted_ids, const float* aabb, const float* slack,
-                      const uint32_t* parent_internal, const uint32_t* parent_leaf, GrtNode* nodes, uint32_t* counters);
+void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_codes, const uint32_t* sorted_ids, GrtNode* nodes);
+void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float* slack, GrtNode* nodes, uint8_t* done);
+size_t grt_scene_enc_bytes();
 // trace
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,

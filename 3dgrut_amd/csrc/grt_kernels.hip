@@ -58,6 +58,8 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+constexpr int kSceneReplicas = 64, kSceneReplicaStride = 32;   // one 128-byte line per replica of the encoded scene box
+
 // computeGaussianEnclosingInstancesKernel (particlePrimitives.cu:543-610), emitted as the inverse instance map
 __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const float* __restrict__ pos, const float* __restrict__ rot,
                                                         const float* __restrict__ scl, const float* __restrict__ dns,
@@ -86,14 +88,25 @@ __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const 
         b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
         slack[i] = 1.41421356237f * 1.0001f * fmaxf(k0, fmaxf(k1, k2));
     }
+    // scene box: one set of atomics per wave, spread over kSceneReplicas cache lines (15 k waves hammering six words of
+    // ONE line serialised in L2 and cost 1 ms of this kernel's 1.07 ms); the Morton kernel folds the replicas
+    uint32_t* rep = scene_enc + (blockIdx.x % kSceneReplicas) * kSceneReplicaStride;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float mn = wave_min(lo[k]), mx = wave_max(hi[k]);
         if ((threadIdx.x & 63) == 0) {
-            atomicMin(&scene_enc[k], enc_ordered(mn));
-            atomicMax(&scene_enc[3 + k], enc_ordered(mx));
+            atomicMin(&rep[k], enc_ordered(mn));
+            atomicMax(&rep[3 + k], enc_ordered(mx));
         }
     }
+}
+__global__ void grt_scene_init_kernel(uint32_t* __restrict__ scene_enc) {
+    const uint32_t r = threadIdx.x;
+    if (r < (uint32_t)kSceneReplicas)
+        for (int k = 0; k < 3; ++k) {
+            scene_enc[r * kSceneReplicaStride + k] = 0xFFFFFFFFu;
+            scene_enc[r * kSceneReplicaStride + 3 + k] = 0u;
+        }
 }
 
 __device__ __forceinline__ uint32_t expand_bits9(uint32_t v) {  // 9 bits -> every third bit of 27
@@ -111,9 +124,19 @@ __device__ __forceinline__ uint32_t expand_bits9(uint32_t v) {  // 9 bits -> eve
 __global__ __launch_bounds__(256) void grt_morton_kernel(uint32_t N, const float* __restrict__ aabb, const uint32_t* __restrict__ scene_enc,
                                                          float* __restrict__ scene, uint32_t* __restrict__ codes, uint32_t* __restrict__ ids) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_scene[6];
+    if (threadIdx.x < 64) {  // fold the replicas (kSceneReplicas == 64: one per lane of the first wave)
+        const uint32_t* rep = scene_enc + threadIdx.x * kSceneReplicaStride;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float mn = wave_min(dec_ordered(rep[k])), mx = wave_max(dec_ordered(rep[3 + k]));
+            if (threadIdx.x == 0) { s_scene[k] = mn; s_scene[3 + k] = mx; }
+        }
+    }
+    __syncthreads();
     float s[6];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) s[k] = dec_ordered(scene_enc[k]);
+    for (int k = 0; k < 6; ++k) s[k] = s_scene[k];
     if (i == 0)
         for (int k = 0; k < 6; ++k) scene[k] = s[k];
     if (i >= N || !codes) return;  // codes == nullptr: refit-only update, just publish the scene box
@@ -144,8 +167,8 @@ __device__ __forceinline__ int delta_fn(const uint32_t* __restrict__ codes, int 
     if (a == b) return 32 + __clz((uint32_t)(i ^ j));
     return __clz(a ^ b);
 }
-__global__ __launch_bounds__(256) void grt_hierarchy_kernel(uint32_t Nu, const uint32_t* __restrict__ codes, GrtNode* __restrict__ nodes,
-                                                            uint32_t* __restrict__ parent_internal, uint32_t* __restrict__ parent_leaf) {
+__global__ __launch_bounds__(256) void grt_hierarchy_kernel(uint32_t Nu, const uint32_t* __restrict__ codes, const uint32_t* __restrict__ sorted_ids,
+                                                            GrtNode* __restrict__ nodes) {
     const int N = (int)Nu;
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (i >= N - 1) return;
@@ -165,10 +188,9 @@ __global__ __launch_bounds__(256) void grt_hierarchy_kernel(uint32_t Nu, const u
     } while (t > 1);
     const int gamma = i + s * d + min(d, 0);
     const bool left_leaf = min(i, j) == gamma, right_leaf = max(i, j) == gamma + 1;
-    if (left_leaf) parent_leaf[gamma] = (uint32_t)i;
-    else { parent_internal[gamma] = (uint32_t)i; nodes[i].c0 = (uint32_t)gamma; }
-    if (right_leaf) parent_leaf[gamma + 1] = (uint32_t)i | 0x80000000u;
-    else { parent_internal[gamma + 1] = (uint32_t)i | 0x80000000u; nodes[i].c1 = (uint32_t)(gamma + 1); }
+    // child codes: internal node index, or leaf bit | particle (the sorted order, hence these codes, survives refit-only updates)
+    nodes[i].c0 = left_leaf ? (kGrtLeafBit | sorted_ids[gamma]) : (uint32_t)gamma;
+    nodes[i].c1 = right_leaf ? (kGrtLeafBit | sorted_ids[gamma + 1]) : (uint32_t)(gamma + 1);
 }
 
 __device__ __forceinline__ void write_child(GrtNode* __restrict__ node, uint32_t side, const float lo[3], const float hi[3], float slack) {
@@ -176,51 +198,51 @@ __device__ __forceinline__ void write_child(GrtNode* __restrict__ node, uint32_t
     base[0] = lo[0]; base[1] = lo[1]; base[2] = lo[2];
     base[4] = hi[0]; base[5] = hi[1]; base[6] = hi[2]; base[7] = slack;
 }
-// bottom-up refit: the second thread to arrive at a node owns it (both child slots are then complete)
-__global__ __launch_bounds__(256) void grt_refit_kernel(uint32_t N, const uint32_t* __restrict__ sorted_ids, const float* __restrict__ aabb,
-                                                        const float* __restrict__ slack, const uint32_t* __restrict__ parent_internal,
-                                                        const uint32_t* __restrict__ parent_leaf, GrtNode* nodes, uint32_t* counters) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= N) return;
-    const uint32_t id = sorted_ids[j];
-    float lo[3], hi[3];
-    const float* b = aabb + 6 * (size_t)id;
-    lo[0] = b[0]; lo[1] = b[1]; lo[2] = b[2]; hi[0] = b[3]; hi[1] = b[4]; hi[2] = b[5];
-    float sl = slack[id];
+// Bottom-up refit in level-synchronous passes: pass p fills the two child slots of every node whose internal children
+// were finished by an EARLIER pass (`done[c]` holds pass + 1; a value written during the current launch is ignored, so
+// everything a thread relies on crossed a kernel boundary and is visible on every XCD).  The previous scheme — each leaf
+// thread climbing with an agent-scope acquire/release counter per node — spent 4.5 ms at 1 M particles in the cache
+// write-backs / invalidates those fences imply; ~height short launches cost a tenth of that.
+__device__ __forceinline__ void child_box(const GrtNode* __restrict__ nodes, const float* __restrict__ aabb, const float* __restrict__ slack,
+                                          uint32_t c, float lo[3], float hi[3], float& sl) {
+    if (c & kGrtLeafBit) {
+        const uint32_t id = c & ~kGrtLeafBit;
+        const float* b = aabb + 6 * (size_t)id;
+        lo[0] = b[0]; lo[1] = b[1]; lo[2] = b[2]; hi[0] = b[3]; hi[1] = b[4]; hi[2] = b[5];
+        sl = slack[id];
+    } else {
+        const float4* q = reinterpret_cast<const float4*>(&nodes[c]);
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        lo[0] = fminf(q0.x, q2.x); lo[1] = fminf(q0.y, q2.y); lo[2] = fminf(q0.z, q2.z);
+        hi[0] = fmaxf(q1.x, q3.x); hi[1] = fmaxf(q1.y, q3.y); hi[2] = fmaxf(q1.z, q3.z);
+        sl = fmaxf(q1.w, q3.w);
+    }
+}
+__global__ __launch_bounds__(256) void grt_refit_pass_kernel(uint32_t N, uint32_t pass, const float* __restrict__ aabb,
+                                                             const float* __restrict__ slack, GrtNode* nodes, uint8_t* done) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3], hi[3], sl;
     if (N == 1) {  // single particle: the root has one leaf and one empty slot
-        write_child(&nodes[0], 0, lo, hi, sl);
-        nodes[0].c0 = kGrtLeafBit | id;
-        const float elo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ehi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-        write_child(&nodes[0], 1, elo, ehi, 0.f);
-        nodes[0].c1 = kGrtNoChild;
+        if (i == 0 && pass == 0) {
+            child_box(nodes, aabb, slack, kGrtLeafBit | 0u, lo, hi, sl);
+            write_child(&nodes[0], 0, lo, hi, sl);
+            nodes[0].c0 = kGrtLeafBit | 0u;
+            const float elo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ehi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+            write_child(&nodes[0], 1, elo, ehi, 0.f);
+            nodes[0].c1 = kGrtNoChild;
+        }
         return;
     }
-    uint32_t p = parent_leaf[j];
-    uint32_t node = p & 0x7FFFFFFFu, side = p >> 31;
-    write_child(&nodes[node], side, lo, hi, sl);
-    if (side) nodes[node].c1 = kGrtLeafBit | id;
-    else nodes[node].c0 = kGrtLeafBit | id;
-    while (true) {
-        // release our child slot, acquire the sibling's (agent scope: the two threads may sit on different XCDs)
-        const uint32_t old = __hip_atomic_fetch_add(&counters[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 0) return;
-        float* other = reinterpret_cast<float*>(&nodes[node]) + (side ? 0 : 8);
-        const float o0 = __hip_atomic_load(other + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float o1 = __hip_atomic_load(other + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float o2 = __hip_atomic_load(other + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float o4 = __hip_atomic_load(other + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float o5 = __hip_atomic_load(other + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float o6 = __hip_atomic_load(other + 6, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float o7 = __hip_atomic_load(other + 7, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lo[0] = fminf(lo[0], o0); lo[1] = fminf(lo[1], o1); lo[2] = fminf(lo[2], o2);
-        hi[0] = fmaxf(hi[0], o4); hi[1] = fmaxf(hi[1], o5); hi[2] = fmaxf(hi[2], o6);
-        sl = fmaxf(sl, o7);
-        p = parent_internal[node];
-        if (p == 0xFFFFFFFFu) return;  // root finished
-        node = p & 0x7FFFFFFFu;
-        side = p >> 31;
-        write_child(&nodes[node], side, lo, hi, sl);
-    }
+    if (i >= N - 1 || done[i] != 0) return;
+    const uint32_t c0 = nodes[i].c0, c1 = nodes[i].c1;
+    const bool r0 = (c0 & kGrtLeafBit) || (done[c0] != 0 && done[c0] <= pass);
+    const bool r1 = (c1 & kGrtLeafBit) || (done[c1] != 0 && done[c1] <= pass);
+    if (!(r0 && r1)) return;
+    child_box(nodes, aabb, slack, c0, lo, hi, sl);
+    write_child(&nodes[i], 0, lo, hi, sl);
+    child_box(nodes, aabb, slack, c1, lo, hi, sl);
+    write_child(&nodes[i], 1, lo, hi, sl);
+    done[i] = (uint8_t)(pass + 1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1096,20 +1118,21 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
 // ---------------------------------------------------------------------------------------------
 void grt_launch_proxies(hipStream_t s, const GrtBuildParams& P, const float* pos, const float* rot, const float* scl, const float* dns,
                         float* inst, float* aabb, float* slack, uint32_t* scene_enc) {
+    hipLaunchKernelGGL(grt_scene_init_kernel, dim3(1), dim3(64), 0, s, scene_enc);
     hipLaunchKernelGGL(grt_proxy_kernel, dim3(div_up(P.N, 256)), dim3(256), 0, s, P, pos, rot, scl, dns, inst, aabb, slack, scene_enc);
 }
+size_t grt_scene_enc_bytes() { return (size_t)kSceneReplicas * kSceneReplicaStride * sizeof(uint32_t); }
 void grt_launch_morton(hipStream_t s, uint32_t N, const float* aabb, const uint32_t* scene_enc, float* scene, uint32_t* codes, uint32_t* ids) {
     hipLaunchKernelGGL(grt_morton_kernel, dim3(div_up(N, 256)), dim3(256), 0, s, N, aabb, scene_enc, scene, codes, ids);
 }
-void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_codes, GrtNode* nodes, uint32_t* parent_internal,
-                          uint32_t* parent_leaf) {
-    if (N > 1)
-        hipLaunchKernelGGL(grt_hierarchy_kernel, dim3(div_up(N - 1, 256)), dim3(256), 0, s, N, sorted_codes, nodes, parent_internal, parent_leaf);
+void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_codes, const uint32_t* sorted_ids, GrtNode* nodes) {
+    if (N > 1) hipLaunchKernelGGL(grt_hierarchy_kernel, dim3(div_up(N - 1, 256)), dim3(256), 0, s, N, sorted_codes, sorted_ids, nodes);
 }
-void grt_launch_refit(hipStream_t s, uint32_t N, const uint32_t* sorted_ids, const float* aabb, const float* slack,
-                      const uint32_t* parent_internal, const uint32_t* parent_leaf, GrtNode* nodes, uint32_t* counters) {
-    hipLaunchKernelGGL(grt_refit_kernel, dim3(div_up(N, 256)), dim3(256), 0, s, N, sorted_ids, aabb, slack, parent_internal, parent_leaf, nodes,
-                       counters);
+void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float* slack, GrtNode* nodes, uint8_t* done) {
+    // a radix tree over 30-bit keys + 32 index bits (duplicates) is at most 62 levels deep; finished passes cost a few us
+    const uint32_t passes = N <= 2 ? 1u : (uint32_t)kGrtStackDepth - 2u;
+    for (uint32_t p = 0; p < passes; ++p)
+        hipLaunchKernelGGL(grt_refit_pass_kernel, dim3(div_up(N > 1 ? N - 1 : 1u, 256)), dim3(256), 0, s, N, p, aabb, slack, nodes, done);
 }
 
 #define GRT_DISPATCH_DEGREE(DEG, ...)                          \
