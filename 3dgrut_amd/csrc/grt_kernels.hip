@@ -937,7 +937,10 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
                                                             float* __restrict__ g_density12, float* __restrict__ g_sph, GrtHitLog log,
                                                             const float* __restrict__ scene) {
     __shared__ uint32_t s_id[kGrtMaxHits * 64];
-    __shared__ float s_sc[5 * kGrtMaxHits * 64];   // [scalar][slot][lane]: common, weight*depth_grad, dL.xyz
+    // per (slot, lane): the two scalars every gradient term is built from, and which colour channels were not clamped
+    // (dL = rad_grad * weight on those).  13 KB per wave instead of 24.5 KB: LDS, not registers, capped the occupancy.
+    __shared__ float s_common[kGrtMaxHits * 64], s_weight[kGrtMaxHits * 64];
+    __shared__ uint8_t s_chan[kGrtMaxHits * 64];
     if (log.state[1] != 0u) return;  // the log overflowed: the traversal kernel handles this frame
     const int lane = threadIdx.x;
     const PixelBlock pb = pixel_block(P.W, P.H);
@@ -960,7 +963,6 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
     scene_interval(scene, r, tEnter, tExit);
     const float endT = fminf(in_hit2[2 * pix + 1], tExit) + 1e-9f;
     const uint32_t block = pb.index;
-    constexpr int S = kGrtMaxHits * 64;
     for (uint32_t round = 0; round < log.max_rounds; ++round) {
         if (!__any(remaining > 0u)) break;
         const uint32_t c = log.table[(size_t)block * log.max_rounds + round];
@@ -971,8 +973,8 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
 #pragma unroll 1
         for (int i = 0; i < kGrtMaxHits; ++i) {
             uint32_t id = chunk[i * 64];
-            float common = 0.f, wd = 0.f;
-            f3 dL = mk3(0.f, 0.f, 0.f);
+            float common = 0.f, wgt = 0.f;
+            uint32_t chan = 0u;
             bool contributes = false;
             if (id != 0xFFFFFFFFu && remaining > 0u) {
                 remaining--;
@@ -993,10 +995,7 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
                         const float galphaRayDnsGrd = resTrm * -T_grad;
                         const f3 gradu = sh_radiance(P, sph, id, basis);
                         const f3 grad = mk3(fmaxf(gradu.x, 0.f), fmaxf(gradu.y, 0.f), fmaxf(gradu.z, 0.f));
-                        dL = rad_grad * weight;
-                        if (!(gradu.x > 0.f)) dL.x = 0.f;
-                        if (!(gradu.y > 0.f)) dL.y = 0.f;
-                        if (!(gradu.z > 0.f)) dL.z = 0.f;
+                        chan = (gradu.x > 0.f ? 1u : 0u) | (gradu.y > 0.f ? 2u : 0u) | (gradu.z > 0.f ? 4u : 0u);
                         rad = rad + grad * weight;
                         f3 resRad = mk3(0.f, 0.f, 0.f);
                         if (!(nextT <= P.min_transmittance)) {
@@ -1005,7 +1004,7 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
                         }
                         common = galphaRayHitGrd + galphaRayDnsGrd + T * (grad.x - resRad.x) * rad_grad.x + T * (grad.y - resRad.y) * rad_grad.y +
                                  T * (grad.z - resRad.z) * rad_grad.z;
-                        wd = weight * depth_grad;
+                        wgt = weight;
                         T = nextT;
                         contributes = true;
                     }
@@ -1014,11 +1013,9 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
             if (!contributes) id = 0xFFFFFFFFu;
             else pending |= (1u << i);
             s_id[i * 64 + lane] = id;
-            s_sc[0 * S + i * 64 + lane] = common;
-            s_sc[1 * S + i * 64 + lane] = wd;
-            s_sc[2 * S + i * 64 + lane] = dL.x;
-            s_sc[3 * S + i * 64 + lane] = dL.y;
-            s_sc[4 * S + i * 64 + lane] = dL.z;
+            s_common[i * 64 + lane] = common;
+            s_weight[i * 64 + lane] = wgt;
+            s_chan[i * 64 + lane] = (uint8_t)chan;
         }
         __syncthreads();
         // ---- phase B: particle-major aggregation ----
@@ -1038,9 +1035,11 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
                 }
                 const bool part = mine >= 0;
                 const int t = part ? mine : 0;
-                const float common = part ? s_sc[0 * S + t * 64 + lane] : 0.f;
-                const float wd = part ? s_sc[1 * S + t * 64 + lane] : 0.f;
-                const f3 dL = part ? mk3(s_sc[2 * S + t * 64 + lane], s_sc[3 * S + t * 64 + lane], s_sc[4 * S + t * 64 + lane]) : mk3(0.f, 0.f, 0.f);
+                const float common = part ? s_common[t * 64 + lane] : 0.f;
+                const float wgt = part ? s_weight[t * 64 + lane] : 0.f;
+                const uint32_t chan = part ? (uint32_t)s_chan[t * 64 + lane] : 0u;
+                const float wd = wgt * depth_grad;
+                const f3 dL = mk3((chan & 1u) ? rad_grad.x * wgt : 0.f, (chan & 2u) ? rad_grad.y * wgt : 0.f, (chan & 4u) ? rad_grad.z * wgt : 0.f);
                 if (part) pending &= ~(1u << t);
                 // gradient terms of particle pid for this lane (zero for lanes that do not take part)
                 const uint32_t upid = (uint32_t)__builtin_amdgcn_readfirstlane((int)pid);
