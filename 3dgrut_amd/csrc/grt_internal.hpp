@@ -6,14 +6,16 @@
 namespace grut {
 
 // Binary BVH node, 64 bytes: the boxes of BOTH children live in the parent, so one 64-byte fetch serves two box tests.
+// The two children are interleaved component by component ({lo0.x, lo1.x}, {lo0.y, lo1.y}, ...): each pair lands in two
+// neighbouring registers, which is what the packed fp32 instructions of the slab test want (one instruction, both children).
 // child code: bit 31 set -> leaf, low bits = particle index; kGrtNoChild = empty slot (only in a one-particle tree).
 // slack = sqrt(2) * (largest proxy half axis below the child): lower bound of a candidate's hit distance is
 // (box entry distance - slack), see DESIGN.md "3DGRT traversal".
 struct GrtNode {
-    float lo0[3]; uint32_t c0;
-    float hi0[3]; float slack0;
-    float lo1[3]; uint32_t c1;
-    float hi1[3]; float slack1;
+    float lox[2], loy[2], loz[2];
+    float hix[2], hiy[2], hiz[2];
+    uint32_t c[2];
+    float slack[2];
 };
 static_assert(sizeof(GrtNode) == 64, "GrtNode must be 64 bytes");
 constexpr uint32_t kGrtLeafBit = 0x80000000u;

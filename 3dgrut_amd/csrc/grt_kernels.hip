@@ -189,14 +189,14 @@ __global__ __launch_bounds__(256) void grt_hierarchy_kernel(uint32_t Nu, const u
     const int gamma = i + s * d + min(d, 0);
     const bool left_leaf = min(i, j) == gamma, right_leaf = max(i, j) == gamma + 1;
     // child codes: internal node index, or leaf bit | particle (the sorted order, hence these codes, survives refit-only updates)
-    nodes[i].c0 = left_leaf ? (kGrtLeafBit | sorted_ids[gamma]) : (uint32_t)gamma;
-    nodes[i].c1 = right_leaf ? (kGrtLeafBit | sorted_ids[gamma + 1]) : (uint32_t)(gamma + 1);
+    nodes[i].c[0] = left_leaf ? (kGrtLeafBit | sorted_ids[gamma]) : (uint32_t)gamma;
+    nodes[i].c[1] = right_leaf ? (kGrtLeafBit | sorted_ids[gamma + 1]) : (uint32_t)(gamma + 1);
 }
 
 __device__ __forceinline__ void write_child(GrtNode* __restrict__ node, uint32_t side, const float lo[3], const float hi[3], float slack) {
-    float* base = reinterpret_cast<float*>(node) + (side ? 8 : 0);
-    base[0] = lo[0]; base[1] = lo[1]; base[2] = lo[2];
-    base[4] = hi[0]; base[5] = hi[1]; base[6] = hi[2]; base[7] = slack;
+    node->lox[side] = lo[0]; node->loy[side] = lo[1]; node->loz[side] = lo[2];
+    node->hix[side] = hi[0]; node->hiy[side] = hi[1]; node->hiz[side] = hi[2];
+    node->slack[side] = slack;
 }
 // Bottom-up refit in level-synchronous passes: pass p fills the two child slots of every node whose internal children
 // were finished by an EARLIER pass (`done[c]` holds pass + 1; a value written during the current launch is ignored, so
@@ -211,11 +211,11 @@ __device__ __forceinline__ void child_box(const GrtNode* __restrict__ nodes, con
         lo[0] = b[0]; lo[1] = b[1]; lo[2] = b[2]; hi[0] = b[3]; hi[1] = b[4]; hi[2] = b[5];
         sl = slack[id];
     } else {
-        const float4* q = reinterpret_cast<const float4*>(&nodes[c]);
+        const float4* q = reinterpret_cast<const float4*>(&nodes[c]);   // {lox, loy | loz, hix | hiy, hiz | c, slack} pairs
         const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-        lo[0] = fminf(q0.x, q2.x); lo[1] = fminf(q0.y, q2.y); lo[2] = fminf(q0.z, q2.z);
-        hi[0] = fmaxf(q1.x, q3.x); hi[1] = fmaxf(q1.y, q3.y); hi[2] = fmaxf(q1.z, q3.z);
-        sl = fmaxf(q1.w, q3.w);
+        lo[0] = fminf(q0.x, q0.y); lo[1] = fminf(q0.z, q0.w); lo[2] = fminf(q1.x, q1.y);
+        hi[0] = fmaxf(q1.z, q1.w); hi[1] = fmaxf(q2.x, q2.y); hi[2] = fmaxf(q2.z, q2.w);
+        sl = fmaxf(q3.z, q3.w);
     }
 }
 __global__ __launch_bounds__(256) void grt_refit_pass_kernel(uint32_t N, uint32_t pass, const float* __restrict__ aabb,
@@ -226,15 +226,15 @@ __global__ __launch_bounds__(256) void grt_refit_pass_kernel(uint32_t N, uint32_
         if (i == 0 && pass == 0) {
             child_box(nodes, aabb, slack, kGrtLeafBit | 0u, lo, hi, sl);
             write_child(&nodes[0], 0, lo, hi, sl);
-            nodes[0].c0 = kGrtLeafBit | 0u;
+            nodes[0].c[0] = kGrtLeafBit | 0u;
             const float elo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, ehi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
             write_child(&nodes[0], 1, elo, ehi, 0.f);
-            nodes[0].c1 = kGrtNoChild;
+            nodes[0].c[1] = kGrtNoChild;
         }
         return;
     }
     if (i >= N - 1 || done[i] != 0) return;
-    const uint32_t c0 = nodes[i].c0, c1 = nodes[i].c1;
+    const uint32_t c0 = nodes[i].c[0], c1 = nodes[i].c[1];
     const bool r0 = (c0 & kGrtLeafBit) || (done[c0] != 0 && done[c0] <= pass);
     const bool r1 = (c1 & kGrtLeafBit) || (done[c1] != 0 && done[c1] <= pass);
     if (!(r0 && r1)) return;
@@ -366,14 +366,29 @@ struct HitBufferT {
 };
 using HitBuffer = HitBufferT<kGrtMaxHits>;
 
-// slab test of a child's world box; returns entry/exit distances
-__device__ __forceinline__ bool box_hit(const float* __restrict__ lo, const float* __restrict__ hi, const RayW& r, float& tn, float& tf) {
-    const float x0 = (lo[0] - r.o.x) * r.inv.x, x1 = (hi[0] - r.o.x) * r.inv.x;
-    const float y0 = (lo[1] - r.o.y) * r.inv.y, y1 = (hi[1] - r.o.y) * r.inv.y;
-    const float z0 = (lo[2] - r.o.z) * r.inv.z, z1 = (hi[2] - r.o.z) * r.inv.z;
-    tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
-    tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
-    return tn <= tf * 1.0000004f + 1e-30f;
+// slab test of BOTH children of a node (GrtNode: q0 = {lo0.x, lo1.x, lo0.y, lo1.y}, q1 = {lo0.z, lo1.z, hi0.x, hi1.x},
+// q2 = {hi0.y, hi1.y, hi0.z, hi1.z}) in packed fp32: (plane - origin) * inverse direction, one instruction per plane pair
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float min3f(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void boxes_hit(const float4& q0, const float4& q1, const float4& q2, const RayW& r, float& tn0, float& tf0, float& tn1,
+                                          float& tf1, bool& ok0, bool& ok1) {
+    const v2f lx = {q0.x, q0.y}, ly = {q0.z, q0.w}, lz = {q1.x, q1.y}, hx = {q1.z, q1.w}, hy = {q2.x, q2.y}, hz = {q2.z, q2.w};
+    const v2f ox = splat(r.o.x), oy = splat(r.o.y), oz = splat(r.o.z), ix = splat(r.inv.x), iy = splat(r.inv.y), iz = splat(r.inv.z);
+    const v2f x0 = (lx - ox) * ix, x1 = (hx - ox) * ix, y0 = (ly - oy) * iy, y1 = (hy - oy) * iy, z0 = (lz - oz) * iz, z1 = (hz - oz) * iz;
+    tn0 = max3f(fminf(x0.x, x1.x), fminf(y0.x, y1.x), fminf(z0.x, z1.x));
+    tf0 = min3f(fmaxf(x0.x, x1.x), fmaxf(y0.x, y1.x), fmaxf(z0.x, z1.x));
+    tn1 = max3f(fminf(x0.y, x1.y), fminf(y0.y, y1.y), fminf(z0.y, z1.y));
+    tf1 = min3f(fmaxf(x0.y, x1.y), fmaxf(y0.y, y1.y), fmaxf(z0.y, z1.y));
+    ok0 = tn0 <= tf0 * 1.0000004f + 1e-30f;
+    ok1 = tn1 <= tf1 * 1.0000004f + 1e-30f;
 }
 
 // 8x8 pixel block of this workgroup.  The image is cut into super-tiles of 8x8 pixel blocks (64x64 pixels); workgroups
@@ -439,13 +454,14 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
         // `cur` is wave-uniform and the tree is read-only while rays are traced: the constant address space makes this ONE
         // scalar fetch per wave (node in SGPRs) instead of four vector loads that occupy 16 VGPRs per lane
         const cfloat4* nq = reinterpret_cast<const cfloat4*>(reinterpret_cast<uintptr_t>(&bvh.nodes[cur]));
-        const float4 q0 = ld4(nq, 0), q1 = ld4(nq, 1), q2 = ld4(nq, 2), q3 = ld4(nq, 3);
-        const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q1.x, q1.y, q1.z}, lo1[3] = {q2.x, q2.y, q2.z}, hi1[3] = {q3.x, q3.y, q3.z};
-        const uint32_t c0 = __float_as_uint(q0.w), c1 = __float_as_uint(q2.w);
+        const float4 q0 = ld4(nq, 0), q1 = ld4(nq, 1), q2 = ld4(nq, 2), q3 = ld4(nq, 3);   // q3 = {c0, c1, slack0, slack1}
+        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
         float tn0, tf0, tn1, tf1;
+        bool ok0, ok1;
+        boxes_hit(q0, q1, q2, r, tn0, tf0, tn1, tf1, ok0, ok1);
         const float bound = fminf(tmax, buf.t[G - 1]);
-        const bool h0 = active && (c0 != kGrtNoChild) && box_hit(lo0, hi0, r, tn0, tf0) && (tf0 >= tmin) && (tn0 <= tmax) && (tn0 - q1.w <= bound);
-        const bool h1 = active && (c1 != kGrtNoChild) && box_hit(lo1, hi1, r, tn1, tf1) && (tf1 >= tmin) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
+        const bool h0 = active && (c0 != kGrtNoChild) && ok0 && (tf0 >= tmin) && (tn0 <= tmax) && (tn0 - q3.z <= bound);
+        const bool h1 = active && (c1 != kGrtNoChild) && ok1 && (tf1 >= tmin) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
         bool a0 = __any(h0), a1 = __any(h1);
         // leaves are tested on the spot, by the lanes whose ray touches the leaf's box
         if (a0 && (c0 & kGrtLeafBit)) {
@@ -497,6 +513,18 @@ struct Particle {
     m3 rotT;
     float density;
 };
+template <typename Q>
+__device__ __forceinline__ Particle load_particle_q(const Q* __restrict__ rec) {
+    const float4 a = ld4(rec, 0), q = ld4(rec, 1), s = ld4(rec, 2);
+    Particle p;
+    p.pos = mk3(a.x, a.y, a.z); p.density = a.w; p.quat = q; p.scl = mk3(s.x, s.y, s.z);
+    p.rotT = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
+    return p;
+}
+// wave-uniform particle of a read-only parameter array: one scalar fetch per wave
+__device__ __forceinline__ Particle load_particle_uniform(const float4* density12, uint32_t id) {
+    return load_particle_q(reinterpret_cast<const cfloat4*>(reinterpret_cast<uintptr_t>(density12 + 3 * (size_t)id)));
+}
 __device__ __forceinline__ Particle load_particle(const float4* __restrict__ density12, uint32_t id) {
     const float4 a = density12[3 * (size_t)id], q = density12[3 * (size_t)id + 1], s = density12[3 * (size_t)id + 2];
     Particle p;
@@ -1043,7 +1071,7 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
                 if (part) pending &= ~(1u << t);
                 // gradient terms of particle pid for this lane (zero for lanes that do not take part)
                 const uint32_t upid = (uint32_t)__builtin_amdgcn_readfirstlane((int)pid);
-                const Particle p = load_particle(density12, upid);
+                const Particle p = load_particle_uniform(density12, upid);
                 const HitGeom g = hit_geometry<DEG>(P, p, r);
                 const f3 gscl = p.scl;
                 const float pdot = -dot(g.grd, g.gro);
