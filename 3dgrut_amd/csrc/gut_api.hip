@@ -332,13 +332,13 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     h->stats.num_visible = h->host_counters[1];
     h->stats.num_intersections = I;
     h->num_intersections = I;
-    if (I == 0) {  // gutRenderer.cu:323-325: nothing is composited, the hit distance keeps its initial value
-        if (speculative) {
-            const float far = 1e6f;
-            uint32_t bits;
-            memcpy(&bits, &far, 4);
-            GRUT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_hit_distance), (int)bits, (size_t)P.W * P.H, s));
-        }
+    if (I == 0) {  // gutRenderer.cu:323-325: nothing is composited, the outputs are the reference's initial values
+        const float far = 1e6f;
+        uint32_t bits;
+        memcpy(&bits, &far, 4);
+        GRUT_HIP(hipMemsetAsync(out_feat_density, 0, (size_t)P.W * P.H * 16, s));
+        GRUT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_hit_distance), (int)bits, (size_t)P.W * P.H, s));
+        GRUT_HIP(hipMemsetAsync(out_hit_count, 0, (size_t)P.W * P.H * 4, s));
         if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
         h->have_forward = true;
         return GRUT_OK;

@@ -33,16 +33,19 @@ struct Ray {
     f3 o, d;
     float tmin, tmax;
     bool valid;
+    bool inside;   // pixel lies in the image (a ray that misses the scene box is inside but not valid)
 };
 __device__ __forceinline__ void swapf(float& a, float& b) { const float t = a; a = b; b = t; }
 __device__ __forceinline__ Ray init_ray(const GutParams& P, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                         int px, int py) {
     Ray r;
     r.valid = false;
+    r.inside = false;
     r.o = mk3(0.f, 0.f, 0.f);
     r.d = mk3(0.f, 0.f, 1.f);
     r.tmin = r.tmax = 0.f;
     if (px >= P.W || py >= P.H) return r;
+    r.inside = true;
     const size_t pix = (size_t)py * P.W + px;
     const f3 so = mk3(ray_o[3 * pix], ray_o[3 * pix + 1], ray_o[3 * pix + 2]);
     const f3 sd = mk3(ray_d[3 * pix], ray_d[3 * pix + 1], ray_d[3 * pix + 2]);
@@ -76,6 +79,7 @@ struct RayPair {
     p3 o, d;
     v2f tmin, tmax;
     bool valid0, valid1;
+    bool inside0, inside1;
     int px, py0, py1;
     bool uniform_origin;  // every valid ray of the wave starts at `origin`
     f3 origin;
@@ -93,6 +97,8 @@ __device__ __forceinline__ RayPair init_ray_pair(const GutParams& P, const float
     rp.tmax = v2f{a.tmax, b.tmax};
     rp.valid0 = a.valid;
     rp.valid1 = b.valid;
+    rp.inside0 = a.inside;
+    rp.inside1 = b.inside;
     // wave-uniform origin?  take the first valid ray as the candidate
     const unsigned long long m0 = __ballot(a.valid), m1 = __ballot(b.valid);
     f3 cand = mk3(0.f, 0.f, 0.f);
@@ -311,17 +317,19 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
     // two copies of the sweep: the shared-origin one keeps the canonical origin out of the per-pixel math
     if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
     else render_fwd_sweep<DEG, CKPT, false>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
-    if (rp.valid0) {
+    // every pixel of the image is written (the caller does not pre-fill): rays that miss the scene box get the reference's
+    // initial values (splatRaster.cpp:211-214)
+    if (rp.inside0) {
         const size_t pix = (size_t)rp.py0 * P.W + rp.px;
-        out_fd[pix] = make_float4(st.Cr.x, st.Cg.x, st.Cb.x, 1.f - st.T.x);
-        out_dist[pix] = st.D.x;
-        if (P.hitcounts) out_cnt[pix] = st.cnt.x;
+        out_fd[pix] = rp.valid0 ? make_float4(st.Cr.x, st.Cg.x, st.Cb.x, 1.f - st.T.x) : make_float4(0.f, 0.f, 0.f, 0.f);
+        out_dist[pix] = rp.valid0 ? st.D.x : 1e6f;
+        if (P.hitcounts) out_cnt[pix] = rp.valid0 ? st.cnt.x : 0.f;
     }
-    if (rp.valid1) {
+    if (rp.inside1) {
         const size_t pix = (size_t)rp.py1 * P.W + rp.px;
-        out_fd[pix] = make_float4(st.Cr.y, st.Cg.y, st.Cb.y, 1.f - st.T.y);
-        out_dist[pix] = st.D.y;
-        if (P.hitcounts) out_cnt[pix] = st.cnt.y;
+        out_fd[pix] = rp.valid1 ? make_float4(st.Cr.y, st.Cg.y, st.Cb.y, 1.f - st.T.y) : make_float4(0.f, 0.f, 0.f, 0.f);
+        out_dist[pix] = rp.valid1 ? st.D.y : 1e6f;
+        if (P.hitcounts) out_cnt[pix] = rp.valid1 ? st.cnt.y : 0.f;
     }
 }
 
@@ -824,10 +832,11 @@ __global__ __launch_bounds__(64) void gut_render_k_kernel(GutParams P, const uin
             else k_process_fwd(P, rgb, kb.hitT[i], kb.alpha[i], kb.idx[i], fs, alive);
         }
     }
-    if (!BWD && ray.valid) {
-        out_fd[pix] = make_float4(fs.Cr, fs.Cg, fs.Cb, 1.f - fs.T);
-        out_dist[pix] = fs.D;
-        if (P.hitcounts) out_cnt[pix] = fs.cnt;
+    if (!BWD && ray.inside) {
+        const size_t opix = (size_t)py * P.W + px;
+        out_fd[opix] = ray.valid ? make_float4(fs.Cr, fs.Cg, fs.Cb, 1.f - fs.T) : make_float4(0.f, 0.f, 0.f, 0.f);
+        out_dist[opix] = ray.valid ? fs.D : 1e6f;
+        if (P.hitcounts) out_cnt[opix] = ray.valid ? fs.cnt : 0.f;
     }
 }
 

@@ -8,6 +8,7 @@ behind include/grut_amd.h.  PyTorch only owns tensors, the autograd graph and th
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -67,6 +68,13 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _uninitialised(shape, **opts):
+    """torch.empty, or NaN / -1 poison with GRUT_POISON_OUTPUTS=1 (tests: proves that the library overwrites everything)."""
+    if os.environ.get("GRUT_POISON_OUTPUTS"):
+        return torch.full(shape, float("nan") if opts.get("dtype") == torch.float32 else -1, **opts)
+    return torch.empty(shape, **opts)
+
+
 class _GutNative:
     """Owns the C handle (role of lib3dgut_cc.SplatRaster)."""
 
@@ -101,10 +109,18 @@ class _GutNative:
         H, W = frame.height, frame.width
         N = frame.num_particles
         opts = dict(dtype=torch.float32, device=dev)
-        out_fd = torch.zeros((H, W, 4), **opts)
-        out_dist = torch.full((H, W, 1), 1e6, **opts)  # splatRaster.cpp:213
-        out_cnt = torch.zeros((H, W, 1), **opts)
-        vis_i32 = torch.zeros((N, 1), dtype=torch.int32, device=dev)
+        if N == 0:  # nothing is launched: the outputs are the reference's initial values (splatRaster.cpp:211-215)
+            out_fd = torch.zeros((H, W, 4), **opts)
+            out_dist = torch.full((H, W, 1), 1e6, **opts)
+            out_cnt = torch.zeros((H, W, 1), **opts)
+            vis_i32 = torch.zeros((N, 1), dtype=torch.int32, device=dev)
+        else:
+            # every pixel / particle is written by the library (tiles cover the image; dead rays store their initial
+            # values), so no fill passes: the reference pays four torch::zeros / full per frame here
+            out_fd = _uninitialised((H, W, 4), **opts)
+            out_dist = _uninitialised((H, W, 1), **opts)
+            out_cnt = _uninitialised((H, W, 1), **opts) if self.cfg.enable_hitcounts else torch.zeros((H, W, 1), **opts)
+            vis_i32 = _uninitialised((N, 1), dtype=torch.int32, device=dev)
         _abi.check(self.lib.gut_forward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
                                         _ptr(ray_ori), _ptr(ray_dir), _ptr(out_fd), _ptr(out_dist), _ptr(out_cnt), _ptr(vis_i32)),
                    "gut_forward")
@@ -148,8 +164,8 @@ class Tracer:
             ctx.native, ctx.frame = native, frame
             # the op hands out features and opacity as separate tensors (what render() returns), so that autograd does not
             # have to route their gradients back through slice / contiguous nodes
-            feat = fd[..., :3].unsqueeze(0).contiguous()
-            opa = fd[..., 3:].unsqueeze(0).contiguous()
+            feat = fd[..., :3].unsqueeze(0)   # views of the packed output, as tracer.py:327-328 returns them
+            opa = fd[..., 3:].unsqueeze(0)
             ctx.mark_non_differentiable(cnt, vis)
             ctx.set_materialize_grads(False)
             return feat, opa, dist, cnt, vis

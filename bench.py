@@ -28,6 +28,7 @@ WORKLOADS = {
     # name: (num_gaussians, width, height, median_scale)
     "c4_1m_1080p": (1_000_000, 1920, 1080, 0.01),
     "c2_1m_800": (1_000_000, 800, 800, 0.01),
+    "c4_3m_1080p": (3_000_000, 1920, 1080, 0.007),  # BASELINE config 4's cloud size (one view per GPU)
     "c1_100k_400": (100_000, 400, 400, 0.01),
     # BASELINE config 3 (not the default bench line): 3DGRT software-BVH primary rays, forward + backward
     "c3_grt_1m_800": (1_000_000, 800, 800, 0.01),

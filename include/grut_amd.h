@@ -128,10 +128,11 @@ void gut_destroy(GutHandle* handle);
 /*  particle_density : [N,12] f32  {pos.xyz, density, quat.wxyz, scale.xyz, pad}
  *  particle_sph     : [N, 3*(deg+1)^2] f32, coefficient-major float3
  *  ray_origin/dir   : [H,W,3] f32, in sensor space (transformed by the inverse mid-exposure pose)
- *  out_feat_density : [H,W,4] f32  (rgb, 1-T)          must arrive zero-filled
- *  out_hit_distance : [H,W,1] f32                      must arrive filled with 1e6 (splatRaster.cpp:213)
- *  out_hit_count    : [H,W,1] f32                      must arrive zero-filled
- *  out_visibility   : [N]     i32 (bit pattern read by the caller as float, splatRaster.cpp:215)  */
+ *  out_feat_density : [H,W,4] f32  (rgb, 1-T)          fully overwritten when N > 0: rays that miss the scene box get 0
+ *  out_hit_distance : [H,W,1] f32                      fully overwritten when N > 0: missing rays get 1e6 (splatRaster.cpp:213)
+ *  out_hit_count    : [H,W,1] f32                      fully overwritten when N > 0 and hit counts are enabled; untouched otherwise
+ *  out_visibility   : [N]     i32 (bit pattern read by the caller as float, splatRaster.cpp:215), fully overwritten
+ *  With N == 0 nothing is launched and the outputs keep whatever the caller put there (the reference's zeros / 1e6). */
 int gut_forward(GutHandle* handle, void* stream, const GutFrame* frame,
                 const float* particle_density, const float* particle_sph,
                 const float* ray_origin, const float* ray_direction,

@@ -354,3 +354,21 @@ def test_timings_dict_contract():
     t = gpu["tracer"].timings
     assert "forward_render" in t and t["forward_render"] > 0
     assert gpu["out"]["frame_time_ms"] > 0
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(k_buffer_size=8), dict(enable_hitcounts=False)])
+def test_outputs_are_fully_overwritten(monkeypatch, kw):
+    """The plugin allocates its outputs without fill passes: with NaN / -1 poison in place of torch.empty every pixel and
+    every visibility flag must still come back defined and equal to the oracle's (dead pixels included)."""
+    monkeypatch.setenv("GRUT_POISON_OUTPUTS", "1")
+    scene = make_scene(n=1500, width=70, height=38, median_scale=0.06)   # not a multiple of the tile size
+    gpu = _run_gpu(scene, **kw)
+    ora = _run_oracle(scene, **{k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()})
+    out = gpu["out"]
+    for key in ("pred_features", "pred_opacity", "pred_dist", "hits_count"):
+        assert bool(np.isfinite(out[key].detach().cpu().numpy()).all()), key
+    vis = out["mog_visibility"].view(-1).view(np.__dict__.get("int32", None) and __import__("torch").int32).cpu().numpy()
+    assert set(np.unique(vis).tolist()) <= {0, 1}
+    _image_checks(out, ora["fwd"], max_flip_frac=5e-3)
+    if not kw.get("enable_hitcounts", True):
+        assert float(out["hits_count"].abs().max()) == 0.0
