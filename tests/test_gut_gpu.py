@@ -367,7 +367,8 @@ def test_outputs_are_fully_overwritten(monkeypatch, kw):
     out = gpu["out"]
     for key in ("pred_features", "pred_opacity", "pred_dist", "hits_count"):
         assert bool(np.isfinite(out[key].detach().cpu().numpy()).all()), key
-    vis = out["mog_visibility"].view(-1).view(np.__dict__.get("int32", None) and __import__("torch").int32).cpu().numpy()
+    import torch
+    vis = out["mog_visibility"].view(-1).view(torch.int32).cpu().numpy()
     assert set(np.unique(vis).tolist()) <= {0, 1}
     _image_checks(out, ora["fwd"], max_flip_frac=5e-3)
     if not kw.get("enable_hitcounts", True):
