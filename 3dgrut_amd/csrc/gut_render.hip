@@ -676,16 +676,18 @@ __device__ __forceinline__ float4 quat_outer_contract(f3 b, f3 e, float4 q) {
                        x * s01 + z * s12 + r * a02 - 2.f * y * (m00 + m22), x * s02 + y * s12 + r * a01 - 2.f * z * (m00 + m11));
 }
 
-__device__ __forceinline__ void k_process_bwd(const GutParams& P, const Ray& ray, const float4* __restrict__ density12, const float* __restrict__ rgb,
-                                              float hitT, float alpha, uint32_t idx, KBwdState& s, bool& alive, float* __restrict__ g_density12,
-                                              float* __restrict__ g_rgb) {
-    if (alpha > 0.f) {
+// One hit of one pixel in the sorted mode's backward: updates the running state and returns the hit's 14 gradient terms
+// (position 0-2, density 3, quaternion 4-7, scale 8-10, rgb 11-13) instead of adding them to memory; `k_bwd_flush` adds
+// them wave by wave.  Returns whether the hit contributed.
+__device__ __forceinline__ bool k_bwd_terms(const GutParams& P, const Ray& ray, const float4* __restrict__ density12, const float* __restrict__ rgb,
+                                            float hitT, float alpha, uint32_t idx, KBwdState& s, bool& alive, float (&terms)[16]) {
+    const bool contributes = alpha > 0.f;
+    if (contributes) {
         const float w = 1.f / (1.f - alpha);
         const f3 feat = mk3(fmaxf(rgb[3 * (size_t)idx], 0.f), fmaxf(rgb[3 * (size_t)idx + 1], 0.f), fmaxf(rgb[3 * (size_t)idx + 2], 0.f));
         s.Cb = (s.Cb - feat * alpha) * w;
         float dalpha = (feat.x - s.Cb.x) * s.gC.x + (feat.y - s.Cb.y) * s.gC.y + (feat.z - s.Cb.z) * s.gC.z;
-        float* gr = g_rgb + 3 * (size_t)idx;
-        atomicAdd(gr, alpha * s.gC.x); atomicAdd(gr + 1, alpha * s.gC.y); atomicAdd(gr + 2, alpha * s.gC.z);
+        terms[11] = alpha * s.gC.x; terms[12] = alpha * s.gC.y; terms[13] = alpha * s.gC.z;
         s.gC = s.gC * (1.f - alpha);
         s.Tb *= w;
         s.Db = (s.Db - hitT * alpha) * w;
@@ -733,13 +735,33 @@ __device__ __forceinline__ void k_process_bwd(const GutParams& P, const Ray& ray
         const f3 grduGrd = dn * il - grdu * (il * il * il * dot(dn, grdu));   // normalize backward
         const f3 sclGrd = gsclHit + gsclGro + mk3(-rdr.x * is2.x, -rdr.y * is2.y, -rdr.z * is2.z) * grduGrd;
         const float4 gq1 = quat_outer_contract(gposcrGrd, gposc, q), gq2 = quat_outer_contract(giscl * grduGrd, ray.d, q);
-        float* gd = g_density12 + 12 * (size_t)idx;
-        atomicAdd(gd + 0, -gposcGrd.x); atomicAdd(gd + 1, -gposcGrd.y); atomicAdd(gd + 2, -gposcGrd.z); atomicAdd(gd + 3, ddens);
-        atomicAdd(gd + 4, gq1.x + gq2.x); atomicAdd(gd + 5, gq1.y + gq2.y); atomicAdd(gd + 6, gq1.z + gq2.z); atomicAdd(gd + 7, gq1.w + gq2.w);
-        atomicAdd(gd + 8, sclGrd.x); atomicAdd(gd + 9, sclGrd.y); atomicAdd(gd + 10, sclGrd.z);
+        terms[0] = -gposcGrd.x; terms[1] = -gposcGrd.y; terms[2] = -gposcGrd.z; terms[3] = ddens;
+        terms[4] = gq1.x + gq2.x; terms[5] = gq1.y + gq2.y; terms[6] = gq1.z + gq2.z; terms[7] = gq1.w + gq2.w;
+        terms[8] = sclGrd.x; terms[9] = sclGrd.y; terms[10] = sclGrd.z;
     }
     s.T *= (1.f - alpha);
     if (s.T < P.min_transmittance) alive = false;
+    return contributes;
+}
+// Adds the terms of the lanes with `have` to the gradient buffers: lanes that processed the SAME particle in this step
+// (neighbouring pixels usually do) are summed with a DPP reduce-scatter first, one set of 14 atomics per (wave, particle)
+// instead of one per (pixel, particle) — the reference's per-hit atomics (gutKBufferRenderer.cuh:158-198) cost this path
+// 147 ms per 1080p frame on MI355X.
+__device__ __forceinline__ void k_bwd_flush(bool have, uint32_t idx, const float (&terms)[16], int lane, float* __restrict__ g_density12,
+                                            float* __restrict__ g_rgb) {
+    unsigned long long m = __ballot(have);
+    while (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)idx, leader);
+        const bool part = have && (idx == pid);
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = (part && k < 14) ? terms[k] : 0.f;
+        const float tot = wave_reduce_scatter16(t, lane);
+        if (lane < 11) atomicAdd(g_density12 + 12 * (size_t)pid + lane, tot);
+        else if (lane < 14) atomicAdd(g_rgb + 3 * (size_t)pid + (lane - 11), tot);
+        m &= ~__ballot(part);
+    }
 }
 
 template <int K, bool BWD>
@@ -797,6 +819,9 @@ __global__ __launch_bounds__(64) void gut_render_k_kernel(GutParams P, const uin
             const float4* rec = &s_rec[j * 5];
             const uint32_t idx = __float_as_uint(rec[4].x);
             if (idx == 0xFFFFFFFFu) break;   // padding closes the list (gutKBufferRenderer.cuh:312-315)
+            bool pop = false;
+            float pop_t = 0.f, pop_a = 0.f;
+            uint32_t pop_i = 0u;
             if (alive) {
                 const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
                 const f3 dl = ray.o - mk3(q0.w, q1.w, q2.w);
@@ -810,9 +835,8 @@ __global__ __launch_bounds__(64) void gut_render_k_kernel(GutParams P, const uin
                     const f3 grds = mk3(q3.x, q3.y, q3.z) * grd * (-dot(grd, gro));
                     const float hitT = sqrtf(dot(grds, grds));
                     if ((hitT > ray.tmin) && (hitT < ray.tmax)) {
-                        if (kb.num == K) {   // full: composite the nearest pending hit, then take its slot
-                            if (BWD) k_process_bwd(P, ray, density12, rgb, kb.hitT[0], kb.alpha[0], kb.idx[0], bs, alive, g_density12, g_rgb);
-                            else k_process_fwd(P, rgb, kb.hitT[0], kb.alpha[0], kb.idx[0], fs, alive);
+                        if (kb.num == K) {   // full: the nearest pending hit is composited (below), the new one takes its slot
+                            pop = true; pop_t = kb.hitT[0]; pop_a = kb.alpha[0]; pop_i = kb.idx[0];
                             kb.hitT[0] = -1.f;
                         } else {
                             kb.num++;
@@ -821,15 +845,30 @@ __global__ __launch_bounds__(64) void gut_render_k_kernel(GutParams P, const uin
                     }
                 }
             }
+            if (BWD) {
+                if (__any(pop)) {   // wave-level: gradients of lanes that popped the same particle are summed before the atomics
+                    float terms[16];
+                    const bool have = pop && k_bwd_terms(P, ray, density12, rgb, pop_t, pop_a, pop_i, bs, alive, terms);
+                    k_bwd_flush(have, pop_i, terms, lane, g_density12, g_rgb);
+                }
+            } else if (pop) {
+                k_process_fwd(P, rgb, pop_t, pop_a, pop_i, fs, alive);
+            }
         }
         __syncthreads();
     }
     // drain what is left, nearest first (:343-351)
 #pragma unroll
     for (int i = 0; i < K; ++i) {
-        if (alive && i >= K - kb.num) {
-            if (BWD) k_process_bwd(P, ray, density12, rgb, kb.hitT[i], kb.alpha[i], kb.idx[i], bs, alive, g_density12, g_rgb);
-            else k_process_fwd(P, rgb, kb.hitT[i], kb.alpha[i], kb.idx[i], fs, alive);
+        const bool act = alive && i >= K - kb.num;
+        if (BWD) {
+            if (__any(act)) {
+                float terms[16];
+                const bool have = act && k_bwd_terms(P, ray, density12, rgb, kb.hitT[i], kb.alpha[i], kb.idx[i], bs, alive, terms);
+                k_bwd_flush(have, kb.idx[i], terms, lane, g_density12, g_rgb);
+            }
+        } else if (act) {
+            k_process_fwd(P, rgb, kb.hitT[i], kb.alpha[i], kb.idx[i], fs, alive);
         }
     }
     if (!BWD && ray.inside) {

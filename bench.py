@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c4_1m_1080p", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k-buffer", type=int, default=0, help="3DGUT sorted mode (render.splat.k_buffer_size); 0 = the headline configuration")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,7 +189,7 @@ def main():
     K = syn.pinhole_intrinsics(W, H)
     ro, rd = syn.pinhole_rays(W, H, K)
     batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(rank, n_views=max(world, 8))[None], intrinsics=K), dev)
-    tracer = gt.Tracer({"render": {"splat": {}}})
+    tracer = gt.Tracer({"render": {"splat": {"k_buffer_size": args.k_buffer}}})
     nat = tracer.tracer_wrapper
     g = syn.SimpleGaussians(d12, sph, device=dev)
     g_fd_np, g_dist_np = syn.upstream_grads(W, H)
@@ -256,7 +257,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"3DGUT fwd+bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "
-                                   f"SH degree 3, k_buffer 0", "name": args.workload,
+                                   f"SH degree 3, k_buffer {args.k_buffer}", "name": args.workload,
                        "parallelism": f"view-dp{world}" + (" + RCCL grad all-reduce" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": f"gut_{dom}", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
