@@ -104,6 +104,61 @@ __global__ __launch_bounds__(256) void pack_particles_kernel(uint32_t n, const f
     out[q] = v;
 }
 
+// Activations of the model fused with the packing (threedgrut/model/model.py:102-118, utils/misc.py:44-49):
+// density = sigmoid(raw), scale = exp(raw), rotation = raw / max(|raw|, 1e-12) (torch.nn.functional.normalize).
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+__global__ __launch_bounds__(256) void activate_pack_kernel(uint32_t n, const float* __restrict__ pos, const float* __restrict__ raw_dns,
+                                                            const float* __restrict__ raw_rot, const float* __restrict__ raw_scl,
+                                                            float4* __restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= 3u * n) return;
+    const uint32_t i = q / 3u, part = q - 3u * i;
+    float4 v;
+    if (part == 0u) {
+        v = make_float4(pos[3 * (size_t)i], pos[3 * (size_t)i + 1], pos[3 * (size_t)i + 2], sigmoidf_(raw_dns[i]));
+    } else if (part == 1u) {
+        const float4 r = reinterpret_cast<const float4*>(raw_rot)[i];
+        const float inv = 1.f / fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);
+        v = make_float4(r.x * inv, r.y * inv, r.z * inv, r.w * inv);
+    } else {
+        v = make_float4(expf(raw_scl[3 * (size_t)i]), expf(raw_scl[3 * (size_t)i + 1]), expf(raw_scl[3 * (size_t)i + 2]), 0.f);
+    }
+    out[q] = v;
+}
+// chain rule back to the raw parameters, split into the model's four tensors (contiguous: the optimizer's AccumulateGrad
+// takes them without a copy)
+__global__ __launch_bounds__(256) void activate_pack_bwd_kernel(uint32_t n, const float* __restrict__ raw_dns, const float* __restrict__ raw_rot,
+                                                                const float* __restrict__ raw_scl, const float4* __restrict__ g_packed,
+                                                                float* __restrict__ g_pos, float* __restrict__ g_dns,
+                                                                float* __restrict__ g_rot, float* __restrict__ g_scl) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= 3u * n) return;
+    const uint32_t i = q / 3u, part = q - 3u * i;
+    const float4 g = g_packed[q];
+    if (part == 0u) {
+        g_pos[3 * (size_t)i] = g.x; g_pos[3 * (size_t)i + 1] = g.y; g_pos[3 * (size_t)i + 2] = g.z;
+        const float s = sigmoidf_(raw_dns[i]);
+        g_dns[i] = g.w * s * (1.f - s);
+    } else if (part == 1u) {
+        const float4 r = reinterpret_cast<const float4*>(raw_rot)[i];
+        const float len = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+        float4 o;
+        if (len > 1e-12f) {   // d(r/|r|) = (g - n (n.g)) / |r|
+            const float inv = 1.f / len;
+            const float nx = r.x * inv, ny = r.y * inv, nz = r.z * inv, nw = r.w * inv;
+            const float d = nx * g.x + ny * g.y + nz * g.z + nw * g.w;
+            o = make_float4((g.x - nx * d) * inv, (g.y - ny * d) * inv, (g.z - nz * d) * inv, (g.w - nw * d) * inv);
+        } else {              // clamped denominator: the map is linear there
+            o = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);
+        }
+        reinterpret_cast<float4*>(g_rot)[i] = o;
+    } else {
+        g_scl[3 * (size_t)i] = g.x * expf(raw_scl[3 * (size_t)i]);
+        g_scl[3 * (size_t)i + 1] = g.y * expf(raw_scl[3 * (size_t)i + 1]);
+        g_scl[3 * (size_t)i + 2] = g.z * expf(raw_scl[3 * (size_t)i + 2]);
+    }
+}
+
 }  // namespace grut
 
 extern "C" int grut_pack_particles(void* stream, uint32_t num_particles, const float* positions, const float* density,
@@ -116,6 +171,38 @@ extern "C" int grut_pack_particles(void* stream, uint32_t num_particles, const f
     const uint32_t quads = 3u * num_particles;
     hipLaunchKernelGGL(pack_particles_kernel, dim3((quads + 255u) / 256u), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), num_particles,
                        positions, density, rotation, scale, reinterpret_cast<float4*>(particle_density));
+    GRUT_HIP(hipGetLastError());
+    return GRUT_OK;
+}
+
+extern "C" int grut_activate_pack(void* stream, uint32_t num_particles, const float* positions, const float* raw_density,
+                                  const float* raw_rotation, const float* raw_scale, float* particle_density) {
+    using namespace grut;
+    if (num_particles == 0) return GRUT_OK;
+    GRUT_REQUIRE(positions && raw_density && raw_rotation && raw_scale && particle_density, "grut_activate_pack: null tensor");
+    GRUT_REQUIRE(((uintptr_t)raw_rotation | (uintptr_t)particle_density) % 16 == 0, "grut_activate_pack: rotation / output must be 16-byte aligned");
+    GRUT_REQUIRE(num_particles <= 0x55555555u, "grut_activate_pack: too many particles");
+    const uint32_t quads = 3u * num_particles;
+    hipLaunchKernelGGL(activate_pack_kernel, dim3((quads + 255u) / 256u), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), num_particles,
+                       positions, raw_density, raw_rotation, raw_scale, reinterpret_cast<float4*>(particle_density));
+    GRUT_HIP(hipGetLastError());
+    return GRUT_OK;
+}
+
+extern "C" int grut_activate_pack_backward(void* stream, uint32_t num_particles, const float* raw_density, const float* raw_rotation,
+                                           const float* raw_scale, const float* grad_particle_density, float* grad_positions,
+                                           float* grad_raw_density, float* grad_raw_rotation, float* grad_raw_scale) {
+    using namespace grut;
+    if (num_particles == 0) return GRUT_OK;
+    GRUT_REQUIRE(raw_density && raw_rotation && raw_scale && grad_particle_density && grad_positions && grad_raw_density && grad_raw_rotation &&
+                     grad_raw_scale, "grut_activate_pack_backward: null tensor");
+    GRUT_REQUIRE(((uintptr_t)raw_rotation | (uintptr_t)grad_particle_density | (uintptr_t)grad_raw_rotation) % 16 == 0,
+                 "grut_activate_pack_backward: rotation / packed gradient tensors must be 16-byte aligned");
+    GRUT_REQUIRE(num_particles <= 0x55555555u, "grut_activate_pack_backward: too many particles");
+    const uint32_t quads = 3u * num_particles;
+    hipLaunchKernelGGL(activate_pack_bwd_kernel, dim3((quads + 255u) / 256u), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), num_particles,
+                       raw_density, raw_rotation, raw_scale, reinterpret_cast<const float4*>(grad_particle_density), grad_positions,
+                       grad_raw_density, grad_raw_rotation, grad_raw_scale);
     GRUT_HIP(hipGetLastError());
     return GRUT_OK;
 }

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _abi
-from .gut_tracer import _conf_get, _ptr, _stream_ptr
+from .gut_tracer import _conf_get, _ptr, _stream_ptr, fused_activations_requested, has_standard_activations
 
 _DEFAULTS = dict(
     particle_kernel_degree=4, particle_kernel_min_response=0.0113, particle_kernel_min_alpha=1.0 / 255.0,
@@ -128,8 +128,12 @@ class _GrtNative:
 class Tracer:
     class _Autograd(torch.autograd.Function):
         @staticmethod
-        def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_sph):
-            particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)  # [N,12] rows, one pass (tracer.py's torch.cat)
+        def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_sph, raw=False):
+            if raw:   # RAW rotation / scale / density, activated inside the packing kernel
+                particle_density = _abi.activate_pack(mog_pos, mog_dns, mog_rot, mog_scl)
+            else:
+                particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)  # [N,12] rows, one pass (tracer.py's torch.cat)
+            ctx.raw = (mog_dns, mog_rot, mog_scl) if raw else None
             particle_sph = mog_sph.contiguous()
             feat, dns, hit, nrm, cnt, vis = native.trace(frame, particle_density, particle_sph, ray_ori, ray_dir)
             ctx.save_for_backward(ray_ori, ray_dir, feat, dns, hit, nrm, particle_density, particle_sph)
@@ -147,8 +151,11 @@ class Tracer:
             g_hit = None if g_hit is None else g_hit.contiguous()
             g_density, g_sph = ctx.native.trace_bwd(ctx.frame, particle_density, particle_sph, ray_ori, ray_dir, feat, dns, hit, nrm,
                                                     g_feat, g_dns, g_hit, None if g_nrm is None else g_nrm.contiguous())
+            if ctx.raw is not None:
+                g_pos, g_d, g_rot, g_scl = _abi.activate_pack_backward(*ctx.raw, g_density)
+                return None, None, None, None, g_pos, g_rot, g_scl, g_d, g_sph, None
             g_pos, g_d, g_rot, g_scl, _ = torch.split(g_density, [3, 1, 4, 3, 1], dim=1)
-            return None, None, None, None, g_pos.contiguous(), g_rot.contiguous(), g_scl.contiguous(), g_d.contiguous(), g_sph
+            return None, None, None, None, g_pos.contiguous(), g_rot.contiguous(), g_scl.contiguous(), g_d.contiguous(), g_sph, None
 
     def __init__(self, conf):
         self.device = "cuda"
@@ -162,6 +169,7 @@ class Tracer:
         self._max_updates = int(_conf_get(render, "max_consecutive_bvh_update", 15))
         self._min_transmittance = float(_conf_get(render, "min_transmittance", 0.001))
         self.tracer_wrapper = _GrtNative(grt_config_from_conf(conf))
+        self._fused_activations = fused_activations_requested(conf)
 
     @property
     def timings(self):
@@ -193,9 +201,14 @@ class Tracer:
             raise ValueError(f"features have {feats.shape[1]} columns, expected {3 * native.ncoef}")
         frame = native.make_frame(frame_id, gaussians.n_active_features, self._min_transmittance, gaussians.num_gaussians, H, W, T)
         frame.keep_hits_for_backward = int(bool(train) and torch.is_grad_enabled())
-        pred_features, pred_opacity, pred_dist, pred_normals, hits_count, mog_visibility = Tracer._Autograd.apply(
-            native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(), gaussians.positions.contiguous(),
-            gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(), gaussians.get_density().contiguous(), feats.contiguous())
+        if self._fused_activations and has_standard_activations(gaussians):
+            pred_features, pred_opacity, pred_dist, pred_normals, hits_count, mog_visibility = Tracer._Autograd.apply(
+                native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(), gaussians.positions.contiguous(),
+                gaussians.rotation.contiguous(), gaussians.scale.contiguous(), gaussians.density.contiguous(), feats.contiguous(), True)
+        else:
+            pred_features, pred_opacity, pred_dist, pred_normals, hits_count, mog_visibility = Tracer._Autograd.apply(
+                native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(), gaussians.positions.contiguous(),
+                gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(), gaussians.get_density().contiguous(), feats.contiguous())
         timings = native.collect_times()
         return {
             "pred_features": pred_features,

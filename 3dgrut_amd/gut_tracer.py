@@ -41,6 +41,21 @@ def _conf_get(node, name, default=None):
             return default
 
 
+def fused_activations_requested(conf) -> bool:
+    """`render.fused_activations: true` (a key of this plugin, absent from the reference's configs) or
+    GRUT_FUSED_ACTIVATIONS=1: take the model's RAW density / rotation / scale and apply sigmoid / normalize / exp inside
+    the packing kernel (and their chain rule inside the backward), SURVEY.md §8f-3."""
+    return bool(_conf_get(_conf_get(conf, "render"), "fused_activations", False)) or bool(os.environ.get("GRUT_FUSED_ACTIVATIONS"))
+
+
+def has_standard_activations(gaussians) -> bool:
+    """The model stores raw parameters and activates them with exactly the functions the fused kernels implement
+    (threedgrut/model/model.py:237-241 with configs/base_gs.yaml:77-78; utils/misc.py:44-49)."""
+    return (all(hasattr(gaussians, a) for a in ("density", "rotation", "scale", "density_activation", "scale_activation", "rotation_activation"))
+            and gaussians.density_activation is torch.sigmoid and gaussians.scale_activation is torch.exp
+            and gaussians.rotation_activation is torch.nn.functional.normalize)
+
+
 def gut_config_from_conf(conf) -> _abi.GutConfig:
     """conf.render.* -> GutConfig (the keys setup_3dgut.py:41-95 turns into -D macros)."""
     render = _conf_get(conf, "render")
@@ -156,8 +171,13 @@ class _GutNative:
 class Tracer:
     class _Autograd(torch.autograd.Function):
         @staticmethod
-        def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_sph):
-            particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)  # [N,12] rows, one pass (tracer.py's torch.cat)
+        def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_sph, raw=False):
+            # raw: mog_rot / mog_scl / mog_dns are the model's RAW parameters, activated inside the packing kernel
+            if raw:
+                particle_density = _abi.activate_pack(mog_pos, mog_dns, mog_rot, mog_scl)
+            else:
+                particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)  # [N,12] rows, one pass (tracer.py's torch.cat)
+            ctx.raw = (mog_dns, mog_rot, mog_scl) if raw else None
             particle_features = mog_sph.contiguous()
             fd, dist, cnt, vis = native.trace(frame, particle_density, particle_features, ray_ori, ray_dir)
             ctx.save_for_backward(ray_ori, ray_dir, fd, dist, particle_density, particle_features)
@@ -182,8 +202,11 @@ class Tracer:
             g_density, g_sph = ctx.native.trace_bwd(ctx.frame, particle_density, particle_features, ray_ori, ray_dir,
                                                     fd, g_fd, dist, None if g_dist is None else g_dist.contiguous())
             # views into the packed gradient, as the reference returns them (tracer.py:268-285): no copies
+            if ctx.raw is not None:   # chain rule to the raw parameters, four contiguous tensors in one pass
+                g_pos, g_dns, g_rot, g_scl = _abi.activate_pack_backward(*ctx.raw, g_density)
+                return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph, None
             g_pos, g_dns, g_rot, g_scl, _ = torch.split(g_density, [3, 1, 4, 3, 1], dim=1)
-            return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph
+            return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph, None
 
     def __init__(self, conf):
         self.device = "cuda"
@@ -192,6 +215,7 @@ class Tracer:
             raise RuntimeError("3dgrut_amd.Tracer needs a ROCm GPU (there is no CPU fallback)")
         torch.zeros(1, device=self.device)  # force context creation (tracer.py:292)
         self.tracer_wrapper = _GutNative(gut_config_from_conf(conf))
+        self._fused_activations = fused_activations_requested(conf)
 
     @property
     def timings(self):
@@ -229,10 +253,16 @@ class Tracer:
         if feats.shape[1] != 3 * native.ncoef:
             raise ValueError(f"features have {feats.shape[1]} columns, expected {3 * native.ncoef} for SH degree "
                              f"{native.cfg.particle_radiance_sph_degree}")
-        pred_features, pred_opacity, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
-            native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(),
-            gaussians.positions.contiguous(), gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(),
-            gaussians.get_density().contiguous(), feats.contiguous())
+        if self._fused_activations and has_standard_activations(gaussians):
+            pred_features, pred_opacity, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
+                native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(),
+                gaussians.positions.contiguous(), gaussians.rotation.contiguous(), gaussians.scale.contiguous(),
+                gaussians.density.contiguous(), feats.contiguous(), True)
+        else:
+            pred_features, pred_opacity, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
+                native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(),
+                gaussians.positions.contiguous(), gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(),
+                gaussians.get_density().contiguous(), feats.contiguous())
         if getattr(gaussians, "ray_feature_dim", 3) != 3:
             raise NotImplementedError("3dgrut_amd: only SH radiance features (ray_feature_dim = 3) are supported")
         timings = native.collect_times()

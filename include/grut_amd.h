@@ -266,6 +266,16 @@ int grt_stats(GrtHandle* handle, GrtStats* stats);
 int grut_pack_particles(void* stream, uint32_t num_particles, const float* positions, const float* density,
                         const float* rotation, const float* scale, float* particle_density);
 
+/* The same packing fused with the model's activations (threedgrut/model/model.py:102-118 with the defaults of
+ * configs/base_gs.yaml:77-78 and model.py:241): density = sigmoid(raw), scale = exp(raw), rotation = normalize(raw).
+ * Replaces three elementwise passes + the torch.cat per call. */
+int grut_activate_pack(void* stream, uint32_t num_particles, const float* positions, const float* raw_density,
+                       const float* raw_rotation, const float* raw_scale, float* particle_density);
+/* Chain rule of the above: the renderer's packed gradient [N,12] -> gradients of the four RAW tensors (all fully written). */
+int grut_activate_pack_backward(void* stream, uint32_t num_particles, const float* raw_density, const float* raw_rotation,
+                                const float* raw_scale, const float* grad_particle_density, float* grad_positions,
+                                float* grad_raw_density, float* grad_raw_rotation, float* grad_raw_scale);
+
 /* ---- optimizer step --------------------------------------- */
 /* One parameter group of SelectiveAdam (threedgrut/optimizers/__init__.py:85-124): contiguous fp32 [num_rows, row_width]
  * DEVICE tensors, 16-byte aligned. */

@@ -155,3 +155,60 @@ def test_training_recovers_a_teacher_scene(method):
     psnr_after = _psnr(oracle_images(d12_1, sph_1), teacher)
     print(f"{method}: PSNR vs oracle-rendered teacher {psnr_before:.2f} dB -> {psnr_after:.2f} dB")
     assert psnr_after > psnr_before + 6.0, (psnr_before, psnr_after)
+
+
+def test_pack_and_fused_activations_match_torch():
+    """grut_pack_particles against torch.cat, grut_activate_pack(_backward) against torch.sigmoid / exp / normalize and
+    their autograd (the functions the reference model applies, utils/misc.py:44-49)."""
+    import torch
+    abi = importlib.import_module("3dgrut_amd._abi")
+    n = 10007
+    g = torch.Generator(device="cuda").manual_seed(3)
+    pos = torch.randn(n, 3, device="cuda", generator=g)
+    raw_d = torch.randn(n, 1, device="cuda", generator=g) * 3
+    raw_r = torch.randn(n, 4, device="cuda", generator=g)
+    raw_s = torch.randn(n, 3, device="cuda", generator=g) - 3
+    raw_r[5] = 0.0   # degenerate quaternion: normalize clamps the denominator at 1e-12
+    zeros = torch.zeros(n, 1, device="cuda")
+    act = [torch.sigmoid(raw_d), torch.nn.functional.normalize(raw_r), torch.exp(raw_s)]
+    ref = torch.cat([pos, act[0], act[1], act[2], zeros], dim=1)
+    assert torch.equal(abi.pack_particles(pos, act[0], act[1], act[2]), ref)
+    got = abi.activate_pack(pos, raw_d, raw_r, raw_s)
+    assert float((got - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    # backward against autograd of the torch ops
+    leaves = [t.clone().requires_grad_(True) for t in (pos, raw_d, raw_r, raw_s)]
+    packed = torch.cat([leaves[0], torch.sigmoid(leaves[1]), torch.nn.functional.normalize(leaves[2]), torch.exp(leaves[3]), zeros], dim=1)
+    gp = torch.randn(n, 12, device="cuda", generator=g)
+    packed.backward(gp)
+    outs = abi.activate_pack_backward(raw_d, raw_r, raw_s, gp)
+    for o, l, name in zip(outs, leaves, ("positions", "density", "rotation", "scale")):
+        ok = torch.ones(n, dtype=torch.bool, device="cuda")
+        if name == "rotation":
+            ok[5] = False   # 0/0 in torch's backward
+        err = float((o[ok] - l.grad[ok]).abs().max()) / (float(l.grad[ok].abs().max()) + 1e-30)
+        assert err < 5e-6, (name, err)
+
+
+@pytest.mark.parametrize("method", ["3dgut", "3dgrt"])
+def test_fused_activation_path_matches_unfused(method, monkeypatch):
+    """render() with `render.fused_activations` (raw parameters into the packing kernel) against the default path
+    (torch activations + autograd): same images, same gradients of the raw parameters."""
+    import torch
+    scene = make_scene(n=1500, width=48, height=40, median_scale=0.07, max_density=0.9)
+    mod = importlib.import_module("3dgrut_amd.gut_tracer" if method == "3dgut" else "3dgrut_amd.grt_tracer")
+    batch = torch_batch(scene["batch"], "cuda")
+    w = torch.randn(1, 40, 48, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    res = []
+    for fused in (False, True):
+        render = {"fused_activations": fused}
+        if method == "3dgut":
+            render["splat"] = {}
+        tr = mod.Tracer({"render": render})
+        g = syn.ActivatedGaussians(scene["density12"], scene["sph"])
+        tr.build_acc(g, rebuild=True)
+        out = tr.render(g, batch, train=True)
+        ((out["pred_features"] * w).sum() + out["pred_opacity"].sum()).backward()
+        res.append((out["pred_features"].detach(), [p.grad.clone() for p in g.parameters()]))
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-5
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12
