@@ -88,6 +88,29 @@ def cpu_baseline(seconds_budget=20.0):
             "sample": f"{frames} fwd+bwd frames of {n} Gaussians at {w}x{h} (config C1) through the C oracle, OpenMP over pixels"}
 
 
+def grt_roofline(work, P, stages):
+    """Forward trace against the HBM roofline.  Algorithmic bytes (per wave where this design fetches per wave):
+    64 B per node visit of a wave (the 8x8 ray packet shares the fetch) + 240 B per processed hit (48 B particle + 192 B SH,
+    gathered per ray) + 64 B per ray of inputs / outputs.  Neither HBM nor VALU binds this kernel: the
+    fraction is reported as the contract asks, `traffic` is the measured HBM volume, `valu` the issue-slot fraction."""
+    if not work or "forward_render" not in stages:
+        return None
+    byts = work["wave_node_visits"] * 64 + work["processed_hits"] * 240 + P * 64
+    ms = stages["forward_render"]
+    achieved = byts / (ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("c3_grt_1m_800", {}).get("trace_fwd")
+    except Exception:
+        pass
+    r = {"bound": "hbm", "kernel": "grt_trace_fwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "algorithmic_bytes": byts, "kernel_ms": ms}
+    v = valu_fraction("grt_trace_fwd", ms)
+    if v:
+        r["valu"] = v
+    return r
+
+
 def bench_grt(args, world, rank, dev, dist, n, W, H, ms):
     """3DGRT: BVH build + forward + backward of one view per GPU per step (the reference rebuilds the BVH every iteration,
     trainer.py:1257-1263).  Traversal is latency / divergence bound; the line reports rays/s and per-stage ms."""
@@ -118,6 +141,18 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms):
         step()
     tracer.timings
     torch.cuda.synchronize()
+    # one instrumented frame (outside the timed region): the traversal's work counters for the byte model
+    work = None
+    if rank == 0:
+        os.environ["GRUT_GRT_COUNT"] = "1"
+        step()
+        torch.cuda.synchronize()
+        del os.environ["GRUT_GRT_COUNT"]
+        st = tracer.tracer_wrapper.stats()
+        work = {"wave_node_visits": int(st.nodes_visited), "leaf_tests": int(st.candidates), "processed_hits": int(st.processed_hits)}
+        step()  # back to the uninstrumented kernels before timing
+        tracer.timings
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -142,7 +177,7 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"3DGRT BVH build + fwd + bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "
                                    f"SH degree 3, k = 16 hits per trace", "name": args.workload, "parallelism": f"view-dp{world}"},
-            "stages_ms": stages}), flush=True)
+            "roofline": grt_roofline(work, P, stages), "stages_ms": stages, "work": work}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
