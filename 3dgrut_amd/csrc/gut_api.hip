@@ -325,6 +325,8 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_FWD, s, slot));
         return GRUT_OK;
     };
+    // the only per-tile buffer: a frame with more tiles than any before must find it large enough for the speculative tail
+    GRUT_CHECK(h->ranges.ensure((size_t)tiles * 8 + 8));
     const bool speculative = h->tile_capacity > 0;
     if (speculative) GRUT_CHECK(enqueue_tail(h->tile_capacity, h->offsets.as<uint32_t>() + (N - 1)));
     GRUT_HIP(hipEventSynchronize(h->count_event));

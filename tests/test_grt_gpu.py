@@ -165,3 +165,25 @@ def test_errors_are_loud():
     g = syn.SimpleGaussians(scene["density12"], scene["sph"])
     with pytest.raises(RuntimeError, match="build_bvh"):
         tr.render(g, torch_batch(scene["batch"], "cuda"))
+
+
+def test_one_tracer_across_different_scenes():
+    """Grow-only handle: a small scene, a larger one (BVH buffers and hit log regrow), then the small one again; every frame
+    against the oracle."""
+    import torch
+    tr = _tracer()
+    cfg = oracle.default_grt_config()
+    for n, w, h, scale, seed in [(300, 24, 16, 0.12, 21), (5000, 72, 48, 0.05, 22), (300, 24, 16, 0.12, 21)]:
+        scene = make_scene(n=n, width=w, height=h, median_scale=scale, max_density=0.8, seed=seed)
+        g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+        tr.build_acc(g, rebuild=True)
+        out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
+        (out["pred_features"].sum() + out["pred_opacity"].sum()).backward()
+        torch.cuda.synchronize()
+        ora = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["batch"]["T_to_world"][0], *scene["rays"])
+        f = out["pred_features"][0].detach().cpu().numpy()
+        bad = np.abs(f - ora["features"]).max(-1) > 1e-4
+        assert bad.mean() <= 5e-3, f"n={n}: {bad.sum()} pixels beyond tolerance"
+        gr = oracle.grt_backward(cfg, 3, 1e-3, ora, np.ones((h, w, 3), np.float32), np.ones((h, w, 1), np.float32), np.zeros((h, w, 1), np.float32))
+        gd, gs = g.grads_packed()
+        assert rel_err(gd[:, :11], gr[0][:, :11]) < 5e-3 and rel_err(gs, gr[1]) < 5e-3

@@ -341,11 +341,14 @@ def test_empty_and_degenerate_inputs():
     # no particle reaches the image: outputs keep their initial values (gutRenderer.cu:323-325, splatRaster.cpp:212-216)
     scene = make_scene(n=64, width=32, height=32, median_scale=0.05)
     scene["density12"][:, 3] = 0.001  # below 1/255
-    gpu = _run_gpu(scene)
+    g_fd, _ = syn.upstream_grads(32, 32)
+    gpu = _run_gpu(scene, g_fd * 1024)
     assert float(gpu["out"]["pred_opacity"].abs().max()) == 0.0
     assert float(gpu["out"]["pred_dist"].min()) == pytest.approx(1e6)
     assert int(gpu["tracer"].tracer_wrapper.stats().num_intersections) == 0
     assert not gpu["out"]["mog_visibility"].view(-1).bool().any()
+    gd, gs = gpu["grads"]   # the backward of a frame without intersections: exact zeros, not stale scratch
+    assert not gd.any() and not gs.any()
 
 
 def test_timings_dict_contract():
@@ -373,3 +376,30 @@ def test_outputs_are_fully_overwritten(monkeypatch, kw):
     _image_checks(out, ora["fwd"], max_flip_frac=5e-3)
     if not kw.get("enable_hitcounts", True):
         assert float(out["hits_count"].abs().max()) == 0.0
+
+
+def test_one_tracer_across_growing_and_shrinking_frames():
+    """The handle's scratch is grow-only and the tail of a frame is launched speculatively against the capacity left by
+    earlier frames: a small frame, a much larger one (capacity exceeded -> the tail is redone), then the small one again
+    (speculation against a generous capacity) must all match the oracle, with gradients."""
+    import torch
+    tr = _tracer()
+    scenes = [make_scene(n=300, width=48, height=32, median_scale=0.05, seed=11),
+              make_scene(n=6000, width=112, height=80, median_scale=0.08, seed=12),
+              make_scene(n=300, width=48, height=32, median_scale=0.05, seed=11)]
+    stats = []
+    for scene in scenes:
+        w, h = scene["W"], scene["H"]
+        g_fd, g_dist = syn.upstream_grads(w, h)
+        g_fd *= w * h
+        g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+        out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
+        fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
+        (fd * torch.as_tensor(g_fd, device="cuda")).sum().backward()
+        torch.cuda.synchronize()
+        gpu = dict(out=out, tracer=tr, gaussians=g, grads=g.grads_packed())
+        ora = _run_oracle(scene, g_fd, g_dist)
+        _image_checks(out, ora["fwd"])
+        _check_grads(scene, gpu, ora, g_fd, g_dist)
+        stats.append(int(tr.tracer_wrapper.stats().num_intersections))
+    assert stats[1] > 4 * stats[0] and stats[2] == stats[0]
