@@ -187,3 +187,20 @@ def test_one_tracer_across_different_scenes():
         gr = oracle.grt_backward(cfg, 3, 1e-3, ora, np.ones((h, w, 3), np.float32), np.ones((h, w, 1), np.float32), np.zeros((h, w, 1), np.float32))
         gd, gs = g.grads_packed()
         assert rel_err(gd[:, :11], gr[0][:, :11]) < 5e-3 and rel_err(gs, gr[1]) < 5e-3
+
+
+def test_runs_on_the_callers_stream():
+    """BVH build, forward and backward on a side stream: same image, gradients equal up to the order of float atomics."""
+    import torch
+    scene = _scene(2000, 48, 32, 0.07)
+    rng = np.random.default_rng(2)
+    g_rad = rng.normal(size=(32, 48, 3)).astype(np.float32)
+    g_dns = rng.normal(size=(32, 48, 1)).astype(np.float32)
+    ref = _render(scene, g_rad, g_dns)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = _render(scene, g_rad, g_dns)
+    side.synchronize()
+    assert torch.equal(ref["out"]["pred_features"], got["out"]["pred_features"])
+    assert rel_err(got["grads"][0], ref["grads"][0]) < 1e-5 and rel_err(got["grads"][1], ref["grads"][1]) < 1e-5

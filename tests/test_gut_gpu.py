@@ -403,3 +403,19 @@ def test_one_tracer_across_growing_and_shrinking_frames():
         _check_grads(scene, gpu, ora, g_fd, g_dist)
         stats.append(int(tr.tracer_wrapper.stats().num_intersections))
     assert stats[1] > 4 * stats[0] and stats[2] == stats[0]
+
+
+def test_runs_on_the_callers_stream():
+    """Everything is enqueued on torch's CURRENT stream (tracer.py / splatRaster.cpp use at::cuda::getCurrentCUDAStream):
+    a frame rendered and differentiated inside `torch.cuda.stream(side)` gives bit-identical results to the default stream."""
+    import torch
+    scene = make_scene(n=2500, width=80, height=48, median_scale=0.06)
+    g_fd, _ = syn.upstream_grads(80, 48)
+    ref = _run_gpu(scene, g_fd * 3840)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        got = _run_gpu(scene, g_fd * 3840)
+    side.synchronize()
+    assert torch.equal(ref["out"]["pred_features"], got["out"]["pred_features"])
+    assert np.array_equal(ref["grads"][0], got["grads"][0]) and np.array_equal(ref["grads"][1], got["grads"][1])
