@@ -224,7 +224,7 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // same half: 8+4+2+1 DPP adds instead of 16 x 6), then two cross-row exchanges of the single survivor.
 template <int CTRL>
 __device__ __forceinline__ float dpp_perm(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float wave_reduce_scatter16_rows(const float (&v)[16], int lane) {
     const bool b3 = lane & 8, b2 = lane & 4, b1 = lane & 2, b0 = lane & 1;
