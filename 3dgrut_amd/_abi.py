@@ -108,7 +108,7 @@ EXPORTED_SYMBOLS = [
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats",
     "grt_debug_forward_hits", "grt_debug_fetch_instances",
-    "grut_selective_adam_update", "grut_pack_particles", "grut_activate_pack", "grut_activate_pack_backward",
+    "grut_selective_adam_update", "grut_pack_particles", "grut_unpack_particle_grads", "grut_activate_pack", "grut_activate_pack_backward",
     "grut_last_error", "grut_abi_version",
 ]
 
@@ -166,6 +166,8 @@ def _declare(lib):
     lib.grut_selective_adam_update.restype = C.c_int
     lib.grut_pack_particles.argtypes = [vp, C.c_uint32, fp, fp, fp, fp, fp]
     lib.grut_pack_particles.restype = C.c_int
+    lib.grut_unpack_particle_grads.argtypes = [vp, C.c_uint32] + [fp] * 5
+    lib.grut_unpack_particle_grads.restype = C.c_int
     lib.grut_activate_pack.argtypes = [vp, C.c_uint32, fp, fp, fp, fp, fp]
     lib.grut_activate_pack.restype = C.c_int
     lib.grut_activate_pack_backward.argtypes = [vp, C.c_uint32] + [fp] * 8
@@ -210,6 +212,20 @@ def pack_particles(mog_pos, mog_dns, mog_rot, mog_scl):
     stream = C.c_void_p(torch.cuda.current_stream(mog_pos.device).cuda_stream)
     check(lib.grut_pack_particles(stream, n, *[C.c_void_p(p.data_ptr()) for p in parts], C.c_void_p(out.data_ptr())), "grut_pack_particles")
     return out
+
+
+def unpack_particle_grads(g_packed):
+    """packed [N,12] gradient -> (g_positions, g_density, g_rotation, g_scale), four contiguous tensors in one pass."""
+    import torch
+    lib = load_library()
+    n = int(g_packed.shape[0])
+    g_packed = g_packed.contiguous()
+    opts = dict(dtype=torch.float32, device=g_packed.device)
+    outs = [torch.empty((n, 3), **opts), torch.empty((n, 1), **opts), torch.empty((n, 4), **opts), torch.empty((n, 3), **opts)]
+    stream = C.c_void_p(torch.cuda.current_stream(g_packed.device).cuda_stream)
+    check(lib.grut_unpack_particle_grads(stream, n, C.c_void_p(g_packed.data_ptr()), *[C.c_void_p(o.data_ptr()) for o in outs]),
+          "grut_unpack_particle_grads")
+    return outs
 
 
 def activate_pack(pos, raw_dns, raw_rot, raw_scl):

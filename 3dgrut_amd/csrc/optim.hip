@@ -104,6 +104,24 @@ __global__ __launch_bounds__(256) void pack_particles_kernel(uint32_t n, const f
     out[q] = v;
 }
 
+// the inverse of pack_particles for gradients: [N,12] -> four contiguous tensors (autograd's AccumulateGrad then keeps
+// them as they are; handing it strided views of the packed gradient costs one clone kernel per tensor)
+__global__ __launch_bounds__(256) void unpack_grads_kernel(uint32_t n, const float4* __restrict__ g_packed, float* __restrict__ g_pos,
+                                                           float* __restrict__ g_dns, float* __restrict__ g_rot, float* __restrict__ g_scl) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= 3u * n) return;
+    const uint32_t i = q / 3u, part = q - 3u * i;
+    const float4 g = g_packed[q];
+    if (part == 0u) {
+        g_pos[3 * (size_t)i] = g.x; g_pos[3 * (size_t)i + 1] = g.y; g_pos[3 * (size_t)i + 2] = g.z;
+        g_dns[i] = g.w;
+    } else if (part == 1u) {
+        reinterpret_cast<float4*>(g_rot)[i] = g;
+    } else {
+        g_scl[3 * (size_t)i] = g.x; g_scl[3 * (size_t)i + 1] = g.y; g_scl[3 * (size_t)i + 2] = g.z;
+    }
+}
+
 // Activations of the model fused with the packing (threedgrut/model/model.py:102-118, utils/misc.py:44-49):
 // density = sigmoid(raw), scale = exp(raw), rotation = raw / max(|raw|, 1e-12) (torch.nn.functional.normalize).
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -171,6 +189,21 @@ extern "C" int grut_pack_particles(void* stream, uint32_t num_particles, const f
     const uint32_t quads = 3u * num_particles;
     hipLaunchKernelGGL(pack_particles_kernel, dim3((quads + 255u) / 256u), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), num_particles,
                        positions, density, rotation, scale, reinterpret_cast<float4*>(particle_density));
+    GRUT_HIP(hipGetLastError());
+    return GRUT_OK;
+}
+
+extern "C" int grut_unpack_particle_grads(void* stream, uint32_t num_particles, const float* grad_particle_density, float* grad_positions,
+                                         float* grad_density, float* grad_rotation, float* grad_scale) {
+    using namespace grut;
+    if (num_particles == 0) return GRUT_OK;
+    GRUT_REQUIRE(grad_particle_density && grad_positions && grad_density && grad_rotation && grad_scale, "grut_unpack_particle_grads: null tensor");
+    GRUT_REQUIRE(((uintptr_t)grad_particle_density | (uintptr_t)grad_rotation) % 16 == 0,
+                 "grut_unpack_particle_grads: packed / rotation gradients must be 16-byte aligned");
+    GRUT_REQUIRE(num_particles <= 0x55555555u, "grut_unpack_particle_grads: too many particles");
+    const uint32_t quads = 3u * num_particles;
+    hipLaunchKernelGGL(unpack_grads_kernel, dim3((quads + 255u) / 256u), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), num_particles,
+                       reinterpret_cast<const float4*>(grad_particle_density), grad_positions, grad_density, grad_rotation, grad_scale);
     GRUT_HIP(hipGetLastError());
     return GRUT_OK;
 }

@@ -154,8 +154,8 @@ class Tracer:
             if ctx.raw is not None:
                 g_pos, g_d, g_rot, g_scl = _abi.activate_pack_backward(*ctx.raw, g_density)
                 return None, None, None, None, g_pos, g_rot, g_scl, g_d, g_sph, None
-            g_pos, g_d, g_rot, g_scl, _ = torch.split(g_density, [3, 1, 4, 3, 1], dim=1)
-            return None, None, None, None, g_pos.contiguous(), g_rot.contiguous(), g_scl.contiguous(), g_d.contiguous(), g_sph, None
+            g_pos, g_d, g_rot, g_scl = _abi.unpack_particle_grads(g_density)
+            return None, None, None, None, g_pos, g_rot, g_scl, g_d, g_sph, None
 
     def __init__(self, conf):
         self.device = "cuda"

@@ -205,7 +205,9 @@ class Tracer:
             if ctx.raw is not None:   # chain rule to the raw parameters, four contiguous tensors in one pass
                 g_pos, g_dns, g_rot, g_scl = _abi.activate_pack_backward(*ctx.raw, g_density)
                 return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph, None
-            g_pos, g_dns, g_rot, g_scl, _ = torch.split(g_density, [3, 1, 4, 3, 1], dim=1)
+            # the reference returns strided slices of the packed gradient (tracer.py:268-285) and autograd clones each of
+            # them when it accumulates; one pass writes the four tensors contiguously instead
+            g_pos, g_dns, g_rot, g_scl = _abi.unpack_particle_grads(g_density)
             return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph, None
 
     def __init__(self, conf):

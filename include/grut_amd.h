@@ -266,6 +266,11 @@ int grt_stats(GrtHandle* handle, GrtStats* stats);
 int grut_pack_particles(void* stream, uint32_t num_particles, const float* positions, const float* density,
                         const float* rotation, const float* scale, float* particle_density);
 
+/* The inverse for gradients: packed [N,12] -> [N,3] positions, [N,1] density, [N,4] rotation, [N,3] scale, contiguous
+ * (what tracer.py:268-285 hands to autograd as strided slices). */
+int grut_unpack_particle_grads(void* stream, uint32_t num_particles, const float* grad_particle_density, float* grad_positions,
+                               float* grad_density, float* grad_rotation, float* grad_scale);
+
 /* The same packing fused with the model's activations (threedgrut/model/model.py:102-118 with the defaults of
  * configs/base_gs.yaml:77-78 and model.py:241): density = sigmoid(raw), scale = exp(raw), rotation = normalize(raw).
  * Replaces three elementwise passes + the torch.cat per call. */
