@@ -575,9 +575,6 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     QuadAcc<STRIDE> acc;
     acc.clear();
     const uint32_t off = has ? proj.part_offset[i] : 0u;
-#ifdef GRUT_DIAG_NO_FLAGS
-    have_partials = 0;
-#endif
     if (have_partials) {
         if (has && count <= kGatherSmall) {
             // Set flags are rare (most tile entries lie behind the rays' termination) and every load here is a dependent
