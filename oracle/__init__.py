@@ -276,3 +276,25 @@ def grt_kernel_scale(density, min_response, clamping, degree, dtype=np.float32):
     l, R = lib(dtype), _real(dtype)
     l.orc_grt_kernel_scale.restype = R
     return float(l.orc_grt_kernel_scale(R(density), R(min_response), C.c_int(int(clamping)), R(degree)))
+
+
+# ---- camera / pose known-answer wrappers (gut_oracle.c: orc_kat_*) ------------------------------------------------
+def kat_project_point_with_shutter(cam, pose_start7, pose_end7, n_iter, pos3, tol, dtype=np.float32):
+    """projectPointWithShutter (cameraProjections.cuh:218-257) for one world-space point -> (valid, [x, y])."""
+    l, R = lib(dtype), _real(dtype)
+    out = np.zeros(2, dtype)
+    ps, pe, p = _c(pose_start7, dtype), _c(pose_end7, dtype), _c(pos3, dtype)
+    ok = l.orc_kat_project_point_with_shutter(C.byref(cam), _p(ps), _p(pe), C.c_int(n_iter), _p(p), R(tol), _p(out))
+    return bool(ok), out
+
+
+def kat_pose_inverse(p7, dtype=np.float32):
+    out = np.zeros(7, dtype)
+    lib(dtype).orc_kat_pose_inverse(_p(_c(p7, dtype)), _p(out))
+    return out
+
+
+def kat_pose_interpolate(a7, b7, t, dtype=np.float32):
+    out = np.zeros(7, dtype)
+    lib(dtype).orc_kat_pose_interpolate(_p(_c(a7, dtype)), _p(_c(b7, dtype)), _real(dtype)(t), _p(out))
+    return out

@@ -906,4 +906,17 @@ int orc_gut_project_bwd(const GutConfig* cfg, const real* pose_start7, const rea
     return 0;
 }
 
+/* known-answer entry points for the camera / pose functions (pinned by tests/golden/camera.npz, which the reference's own
+ * cameraProjections.cuh + sensors.h produced on the host: oracle/ref/ref_camera.cpp) */
+int orc_kat_project_point_with_shutter(const GrutCamera* cam, const real* pose_start7, const real* pose_end7, int n_iter, const real* pos3,
+                                       real tol, real* out2) {
+    return project_point_with_shutter(cam, pose_from7(pose_start7), pose_from7(pose_end7), n_iter, v3_make(pos3[0], pos3[1], pos3[2]), tol,
+                                      &out2[0], &out2[1]);
+}
+static void pose_to7(orc_pose p, real* o) { o[0] = p.t.x; o[1] = p.t.y; o[2] = p.t.z; o[3] = p.q.x; o[4] = p.q.y; o[5] = p.q.z; o[6] = p.q.w; }
+void orc_kat_pose_inverse(const real* p7, real* out7) { pose_to7(pose_inverse(pose_from7(p7)), out7); }
+void orc_kat_pose_interpolate(const real* a7, const real* b7, real t, real* out7) {
+    pose_to7(pose_interpolate(pose_from7(a7), pose_from7(b7), t), out7);
+}
+
 int orc_sizeof_real(void) { return (int)sizeof(real); }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Generates tests/golden/per_hit_deg{2,4}.npz and adam.npz from the REFERENCE's own per-hit math and optimizer kernel.
+"""Generates tests/golden/per_hit_deg{2,4}.npz, adam.npz, camera.npz and projector.npz from the REFERENCE's own per-hit
+math, optimizer kernel, camera projection code and projection stage.
 
 Run in the build container only (needs /root/reference):
 
@@ -153,9 +154,114 @@ def make_adam():
     print("wrote adam.npz")
 
 
+def camera_cases(seed=21, n_points=160):
+    """Seeded camera models (three projection models x five shutter types), two sensor poses per case and points scattered
+    in and around the view frustum."""
+    r = np.random.default_rng(seed)
+    cases = []
+    W, H = 640, 400
+    for model in (0, 1, 2):
+        for shutter in range(5):
+            prm = np.zeros(33, F)
+            prm[0:2] = (W / 2 + r.normal() * 5, H / 2 + r.normal() * 5)
+            if model == 0:
+                prm[2:4] = (500 + r.normal() * 20, 510 + r.normal() * 20)
+                prm[4:10] = r.normal(size=6) * np.array([0.05, 0.02, 0.005, 0.04, 0.015, 0.004])
+                prm[10:12] = r.normal(size=2) * 1e-3
+                prm[12:16] = r.normal(size=4) * 1e-3
+            elif model == 1:
+                prm[2:4] = (300 + r.normal() * 10, 305 + r.normal() * 10)
+                prm[4:8] = r.normal(size=4) * np.array([0.03, 0.01, 0.003, 0.001])
+                prm[16] = 1.3
+            else:
+                f = 320.0
+                bw = np.array([0.0, 1.0 / f, 0.0, 2e-9, 0.0, 1e-15])       # pixel distance -> angle
+                fw = np.array([0.0, f, 0.0, -f * f * f * 2e-9 * f, 0.0, 0.0])  # angle -> pixel distance (approximate inverse)
+                prm[16] = 1.4
+                prm[17] = float(shutter % 2)
+                prm[18:24] = bw
+                prm[24:30] = fw
+                prm[30:33] = (1.0 + r.normal() * 1e-3, r.normal() * 1e-3, r.normal() * 1e-3)
+            def pose():
+                q = r.normal(size=4) * np.array([0.05, 0.05, 0.05, 0.0]) + np.array([0, 0, 0, 1.0])
+                q /= np.linalg.norm(q)
+                return np.concatenate([r.normal(size=3) * 0.1, q]).astype(F)
+            ps, pe = pose(), pose()
+            pts = np.concatenate([r.uniform(-2.5, 2.5, (n_points, 2)), r.uniform(-0.5, 6.0, (n_points, 1))], 1).astype(F)
+            cases.append(dict(model=model, shutter=shutter, W=W, H=H, prm=prm, ps=ps, pe=pe, pts=pts))
+    return cases
+
+
+def make_camera():
+    """tests/golden/camera.npz: projectPointWithShutter<5> / <0>, sensorPoseInverse, interpolatedSensorPose of the reference
+    (oracle/_ref/libref_camera.so = cameraProjections.cuh + sensors.h compiled on the host)."""
+    lib = C.CDLL(os.path.join(REF, "libref_camera.so"))
+    out = {}
+    for k, c in enumerate(camera_cases()):
+        n = len(c["pts"])
+        for n_iter in (5, 0):
+            xy = np.zeros((n, 2), F)
+            ok = np.zeros(n, np.int32)
+            for i in range(n):
+                o = np.zeros(2, F)
+                ok[i] = lib.ref_project_point_with_shutter(c["model"], c["shutter"], c["W"], c["H"], _p(c["prm"]), _p(c["ps"]), _p(c["pe"]),
+                                                           n_iter, _p(np.ascontiguousarray(c["pts"][i])), C.c_float(0.1), _p(o))
+                xy[i] = o
+            out[f"c{k}_xy{n_iter}"], out[f"c{k}_ok{n_iter}"] = xy, ok
+        inv, mid = np.zeros(7, F), np.zeros(7, F)
+        lib.ref_pose_inverse(_p(c["ps"]), _p(inv))
+        lib.ref_pose_interpolate(_p(c["ps"]), _p(c["pe"]), C.c_float(0.37), _p(mid))
+        out[f"c{k}_inv"], out[f"c{k}_mid"] = inv, mid
+    np.savez_compressed(os.path.join(HERE, "camera.npz"), **out)
+    print("wrote camera.npz", sum(int(v.sum()) for k, v in out.items() if "_ok" in k), "valid projections")
+
+
+def projector_cases(seed=33, n=700):
+    """Particle clouds in front of the cameras of camera_cases() (one shutter type per model is enough here: the shutter
+    logic itself is pinned by camera.npz): anisotropic scales, random rotations, densities on both sides of 1/255."""
+    r = np.random.default_rng(seed)
+    cases = []
+    for c in camera_cases():
+        if c["shutter"] not in (4, 0):   # global and rolling top-to-bottom
+            continue
+        pos = np.concatenate([r.uniform(-2.2, 2.2, (n, 2)), r.uniform(-0.3, 6.0, (n, 1))], 1)
+        scl = np.exp(r.normal(np.log(0.05), 0.8, (n, 3)))
+        q = r.normal(size=(n, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        dens = np.where(r.uniform(size=(n, 1)) < 0.1, r.uniform(0.0, 0.006, (n, 1)), r.uniform(0.01, 1.0, (n, 1)))
+        d12 = np.concatenate([pos, dens, q, scl, np.zeros((n, 1))], 1).astype(F)
+        cases.append(dict(c, d12=d12))
+    return cases
+
+
+def make_projector():
+    """tests/golden/projector.npz: GUTProjector::eval of the reference (oracle/_ref/libref_projector.so) — tiles count,
+    projected centre, conic + opacity, extent, depth and visibility of every particle."""
+    lib = C.CDLL(os.path.join(REF, "libref_projector.so"))
+    out = {}
+    for k, c in enumerate(projector_cases()):
+        n = len(c["d12"])
+        tc = np.zeros(n, np.uint32); pp = np.zeros((n, 2), F); co = np.zeros((n, 4), F); ex = np.zeros((n, 2), F)
+        dp = np.zeros(n, F); vis = np.zeros(n, np.int32)
+        lib.ref_project_particles(c["model"], c["shutter"], c["W"], c["H"], _p(c["prm"]), _p(c["ps"]), _p(c["pe"]), C.c_uint32(n), _p(c["d12"]),
+                                  _p(tc), _p(pp), _p(co), _p(ex), _p(dp), _p(vis))
+        out[f"p{k}_tiles"], out[f"p{k}_pos"], out[f"p{k}_conic"], out[f"p{k}_extent"], out[f"p{k}_depth"], out[f"p{k}_vis"] = tc, pp, co, ex, dp, vis
+    np.savez_compressed(os.path.join(HERE, "projector.npz"), **out)
+    print("wrote projector.npz:", {k: int((v > 0).sum()) for k, v in out.items() if k.endswith("_tiles")})
+
+
 if __name__ == "__main__":
     import sys
-    if "--adam-only" not in sys.argv:
+    only = [a for a in sys.argv[1:] if a.startswith("--only=")]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector"]
+    if "--adam-only" in sys.argv:
+        which = ["adam"]
+    if "per_hit" in which:
         for d in (2, 4):
             run(d)
-    make_adam()
+    if "adam" in which:
+        make_adam()
+    if "camera" in which:
+        make_camera()
+    if "projector" in which:
+        make_projector()
