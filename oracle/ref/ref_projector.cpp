@@ -127,4 +127,20 @@ void ref_project_particles(int model, int shutter, int width, int height, const 
     }
 }
 
+// GUTProjector::expand (gutProjector.cuh:324-388) for every particle: the unsorted (tile << 32 | depth bits, particle) lists.
+// offsets = inclusive prefix sum of tiles_count (gutRenderer.cu:302-310).
+void ref_expand_particles(int width, int height, uint32_t n, const uint32_t* offsets, const float* proj_pos, const float* conic_opacity,
+                          const float* extent, const float* depth, uint64_t* keys, uint32_t* idx) {
+    const tcnn::uvec2 tileGrid((uint32_t)(width + 15) / 16, (uint32_t)(height + 15) / 16);
+    TSensorModel m;
+    TSensorState st;
+    MemoryHandles mh{nullptr};
+    blockDim.x = 1; threadIdx.x = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        blockIdx.x = i;
+        Projector::expand(tileGrid, (int)n, tcnn::ivec2(width, height), m, st, offsets, reinterpret_cast<const tcnn::vec2*>(proj_pos),
+                          reinterpret_cast<const tcnn::vec4*>(conic_opacity), reinterpret_cast<const tcnn::vec2*>(extent), depth, mh, keys, idx);
+    }
+}
+
 }  // extern "C"

@@ -246,6 +246,13 @@ def make_projector():
         lib.ref_project_particles(c["model"], c["shutter"], c["W"], c["H"], _p(c["prm"]), _p(c["ps"]), _p(c["pe"]), C.c_uint32(n), _p(c["d12"]),
                                   _p(tc), _p(pp), _p(co), _p(ex), _p(dp), _p(vis))
         out[f"p{k}_tiles"], out[f"p{k}_pos"], out[f"p{k}_conic"], out[f"p{k}_extent"], out[f"p{k}_depth"], out[f"p{k}_vis"] = tc, pp, co, ex, dp, vis
+        # GUTProjector::expand on those outputs, then the stable sort by key of gutRenderer.cu:356-365 (CUB radix sort)
+        offsets = np.cumsum(tc, dtype=np.uint64).astype(np.uint32)
+        total = int(offsets[-1])
+        keys, idx = np.zeros(total, np.uint64), np.zeros(total, np.uint32)
+        lib.ref_expand_particles(c["W"], c["H"], C.c_uint32(n), _p(offsets), _p(pp), _p(co), _p(ex), _p(dp), _p(keys), _p(idx))
+        order = np.argsort(keys, kind="stable")
+        out[f"p{k}_sorted_keys"], out[f"p{k}_sorted_idx"] = keys[order], idx[order]
     np.savez_compressed(os.path.join(HERE, "projector.npz"), **out)
     print("wrote projector.npz:", {k: int((v > 0).sum()) for k, v in out.items() if k.endswith("_tiles")})
 

@@ -379,3 +379,10 @@ def test_projection_stage_matches_reference_code_golden():
             assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max()), f"case {k}: {name} differs by {np.abs(a - b).max()}"
         a, b = o["conic_opacity"][both], g[f"p{k}_conic"][both]
         assert (np.abs(a - b) / (np.abs(b) + 1e-6)).max() < 1e-3, f"case {k}: conic / opacity"
+        # binning on the REFERENCE's projection outputs: expansion keys (tile << 32 | depth bits), padding and the stable
+        # sort order must come out identical to GUTProjector::expand + a stable sort by key
+        proj = dict(tiles_count=tiles, proj_pos=g[f"p{k}_pos"], conic_opacity=g[f"p{k}_conic"], extent=g[f"p{k}_extent"], depth=g[f"p{k}_depth"])
+        bins = oracle.gut_bin(cfg, c["W"], c["H"], proj)
+        assert bins["num_intersections"] == int(tiles.sum()) == len(g[f"p{k}_sorted_keys"])
+        assert np.array_equal(bins["sorted_keys"], g[f"p{k}_sorted_keys"]), f"case {k}: sorted keys differ"
+        assert np.array_equal(bins["sorted_idx"], g[f"p{k}_sorted_idx"]), f"case {k}: sorted particle lists differ"
