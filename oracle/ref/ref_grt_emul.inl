@@ -1,0 +1,121 @@
+// ref_grt_emul.inl — the OptiX traversal emulation shared by ref_grt_trace.cpp (forward programs) and ref_grt_trace_bwd.cpp
+// (backward programs); included AFTER the reference's .cu, whose `params`, __intersection__is and __anyhit__ah it drives.
+// This file is the part that is NOT the reference's (see the header of ref_grt_trace.cpp).  TEST INFRASTRUCTURE ONLY.
+// the accessors have no constructors in a device compile (the host fills them): same layout, filled by copy
+template <class A>
+static void fill_accessor(A& acc, float* data, const int32_t* sizes, const int32_t* strides) {
+    struct Raw { float* data; int32_t sizes[4]; int32_t strides[4]; } raw;
+    raw.data = data;
+    for (int i = 0; i < 4; ++i) { raw.sizes[i] = sizes[i]; raw.strides[i] = strides[i]; }
+    static_assert(sizeof(Raw) == sizeof(A), "PackedTensorAccessor32<float, 4> layout");
+    std::memcpy(&acc, &raw, sizeof(raw));
+}
+
+// ---- the emulated traversal ---------------------------------------------------------------------------------------------
+namespace {
+struct Scene {
+    // Which far end the ray / box overlap test of the traversal uses once accepted hits have shrunk the ray: the CURRENT tmax
+    // (what a traversal that happens to reach the box late would do) or the tmax the trace call started with (what one that
+    // reaches it early would do).  OptiX leaves the order unspecified, so both are legal outcomes; they differ only for a
+    // proxy whose hit distance precedes the ray's entry into its box.  The oracle takes the second (order-independent) one.
+    bool box_test_uses_shrunk_tmax = false;
+    float trace_tmax = 0.f;
+    uint32_t n = 0;
+    std::vector<float> inv;   // [n][12]: rows of the inverse linear part, then the translation of the instance transform
+} g_scene;
+}  // namespace
+
+bool optixReportIntersection(float t, unsigned) {
+    if (!(t >= g_optix.tmin && t <= g_optix.tmax)) return false;
+    const float far_end = g_optix.tmax;
+    g_optix.tmax = t;          // the any-hit program sees the reported distance as the ray's tmax
+    g_optix.ignore = false;
+    __anyhit__ah();
+    if (g_optix.ignore) { g_optix.tmax = far_end; return false; }
+    return true;               // accepted: the ray now ends at t
+}
+
+void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tmax, float, OptixVisibilityMask, unsigned, unsigned, unsigned,
+                unsigned, uint32_t& p0, uint32_t& p1, uint32_t& p2, uint32_t& p3, uint32_t& p4, uint32_t& p5, uint32_t& p6, uint32_t& p7,
+                uint32_t& p8, uint32_t& p9, uint32_t& p10, uint32_t& p11, uint32_t& p12, uint32_t& p13, uint32_t& p14, uint32_t& p15,
+                uint32_t& p16, uint32_t& p17, uint32_t& p18, uint32_t& p19, uint32_t& p20, uint32_t& p21, uint32_t& p22, uint32_t& p23,
+                uint32_t& p24, uint32_t& p25, uint32_t& p26, uint32_t& p27, uint32_t& p28, uint32_t& p29, uint32_t& p30, uint32_t& p31) {
+    uint32_t* ps[32] = {&p0, &p1, &p2, &p3, &p4, &p5, &p6, &p7, &p8, &p9, &p10, &p11, &p12, &p13, &p14, &p15,
+                        &p16, &p17, &p18, &p19, &p20, &p21, &p22, &p23, &p24, &p25, &p26, &p27, &p28, &p29, &p30, &p31};
+    for (int k = 0; k < 32; ++k) g_optix.payload[k] = ps[k];
+    g_optix.worldOrigin = o; g_optix.worldDirection = d;
+    g_optix.tmin = tmin; g_optix.tmax = tmax;
+    g_scene.trace_tmax = tmax;
+    for (uint32_t i = 0; i < g_scene.n; ++i) {
+        const float* m = &g_scene.inv[12 * (size_t)i];
+        const float dx = o.x - m[9], dy = o.y - m[10], dz = o.z - m[11];
+        const float3 oo = make_float3(m[0] * dx + m[1] * dy + m[2] * dz, m[3] * dx + m[4] * dy + m[5] * dz, m[6] * dx + m[7] * dy + m[8] * dz);
+        const float3 od = make_float3(m[0] * d.x + m[1] * d.y + m[2] * d.z, m[3] * d.x + m[4] * d.y + m[5] * d.z, m[6] * d.x + m[7] * d.y + m[8] * d.z);
+        // ray / unit box overlap within the ray's current interval (the hardware's job)
+        const float ax0 = (-1.f - oo.x) / od.x, ax1 = (1.f - oo.x) / od.x, ay0 = (-1.f - oo.y) / od.y, ay1 = (1.f - oo.y) / od.y;
+        const float az0 = (-1.f - oo.z) / od.z, az1 = (1.f - oo.z) / od.z;
+        const float tn = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+        const float tf = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+        const float far_end = g_scene.box_test_uses_shrunk_tmax ? g_optix.tmax : g_scene.trace_tmax;
+        if (!(tn <= tf) || !(tf >= g_optix.tmin) || !(tn <= far_end)) continue;
+        g_optix.instance = i; g_optix.objectOrigin = oo; g_optix.objectDirection = od;
+        __intersection__is();
+    }
+}
+
+// instance matrices (object -> world, row-major 3x4, as the reference's instance kernel writes them) -> inverse maps
+static void set_scene(uint32_t n, const float* transforms) {
+    g_scene.n = n;
+    g_scene.inv.resize(12 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) {   // inverse of the 3x3 linear part by cofactors (double), translation kept
+        const float* t = &transforms[12 * (size_t)i];
+        const double a = t[0], b = t[1], c = t[2], d = t[4], e = t[5], f = t[6], g = t[8], h = t[9], k = t[10];
+        const double det = a * (e * k - f * h) - b * (d * k - f * g) + c * (d * h - e * g);
+        const double inv[9] = {(e * k - f * h) / det, (c * h - b * k) / det, (b * f - c * e) / det, (f * g - d * k) / det, (a * k - c * g) / det,
+                               (c * d - a * f) / det, (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+        float* m = &g_scene.inv[12 * (size_t)i];
+        for (int q = 0; q < 9; ++q) m[q] = (float)inv[q];
+        m[9] = t[3]; m[10] = t[7]; m[11] = t[11];
+    }
+}
+
+// the members of PipelineParameters shared by the forward and the backward launch
+static void set_common_params(int width, int height, const float* ray_to_world, const float* ray_o, const float* ray_d, const float* density12,
+                              const float* sph48, const float* scene_aabb6, float min_transmittance, float min_response, float min_alpha,
+                              unsigned sph_degree, float* features, float* density, float* hit_distance2, float* normals, float* hits_count,
+                              int32_t* visibility) {
+    static thread_local int32_t sz3[4], st3[4], sz1[4], st1[4], sz2[4], st2[4];
+    const int32_t a3[4] = {1, height, width, 3}, b3[4] = {height * width * 3, width * 3, 3, 1};
+    const int32_t a1[4] = {1, height, width, 1}, b1[4] = {height * width, width, 1, 1};
+    const int32_t a2[4] = {1, height, width, 2}, b2[4] = {height * width * 2, width * 2, 2, 1};
+    for (int i = 0; i < 4; ++i) { sz3[i] = a3[i]; st3[i] = b3[i]; sz1[i] = a1[i]; st1[i] = b1[i]; sz2[i] = a2[i]; st2[i] = b2[i]; }
+    for (int r = 0; r < 3; ++r) params.rayToWorld[r] = make_float4(ray_to_world[4 * r], ray_to_world[4 * r + 1], ray_to_world[4 * r + 2], ray_to_world[4 * r + 3]);
+    fill_accessor(params.rayOrigin, const_cast<float*>(ray_o), sz3, st3);
+    fill_accessor(params.rayDirection, const_cast<float*>(ray_d), sz3, st3);
+    params.particleDensity = reinterpret_cast<const ParticleDensity*>(density12);
+    params.particleFeatures = sph48;
+    params.particleExtendedData = nullptr;
+    params.particleVisibility = visibility;
+    fill_accessor(params.rayFeatures, features, sz3, st3);
+    fill_accessor(params.rayDensity, density, sz1, st1);
+    fill_accessor(params.rayHitDistance, hit_distance2, sz2, st2);
+    fill_accessor(params.rayNormal, normals, sz3, st3);
+    fill_accessor(params.rayHitsCount, hits_count, sz1, st1);
+    params.handle = 0;
+    params.aabb = OptixAabb{scene_aabb6[0], scene_aabb6[1], scene_aabb6[2], scene_aabb6[3], scene_aabb6[4], scene_aabb6[5]};
+    params.minTransmittance = min_transmittance;
+    params.hitMinGaussianResponse = min_response;
+    params.alphaMinThreshold = min_alpha;
+    params.sphDegree = sph_degree;
+    params.frameBounds = uint2{(unsigned)width - 1, (unsigned)height - 1};
+    params.frameNumber = 0;
+    params.gPrimNumTri = 0;
+}
+
+static void launch_raygen(int width, int height) {
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            g_optix.launchIndex = uint3{(unsigned)x, (unsigned)y, 0u};
+            __raygen__rg();
+        }
+}

@@ -14,6 +14,7 @@ produced by the reference's source, are what pins the oracle (tests/test_oracle_
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -257,10 +258,88 @@ def make_projector():
     print("wrote projector.npz:", {k: int((v > 0).sum()) for k, v in out.items() if k.endswith("_tiles")})
 
 
+def make_grt_proxies():
+    """tests/golden/grt_proxies.npz: kernelScale and the enclosing AABB / instance kernels of the reference
+    (threedgrt_tracer/src/particlePrimitives.cu through oracle/_ref/libref_grt_proxies.so)."""
+    lib = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    lib.ref_kernel_scale.restype = C.c_float
+    r = np.random.default_rng(44)
+    out = {}
+    dens = np.concatenate([r.uniform(0.001, 1.0, 200), [0.0113, 0.0116, 0.5, 1.0]]).astype(F)
+    for deg in (0, 1, 2, 3, 4, 5, 8):
+        for clamp in (0, 1):
+            out[f"ks_deg{deg}_c{clamp}"] = np.array([lib.ref_kernel_scale(C.c_float(d), C.c_float(MIN_RESPONSE), C.c_uint(clamp), C.c_float(deg))
+                                                     for d in dens], F)
+    out["ks_density"] = dens
+    n = 400
+    pos = r.uniform(-2, 2, (n, 3)).astype(F)
+    q = r.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True); q = q.astype(F)
+    scl = np.exp(r.normal(np.log(0.05), 0.8, (n, 3))).astype(F)
+    dn = r.uniform(0.005, 1.0, n).astype(F)
+    for deg, clamp in ((4, 1), (2, 0)):
+        aabb, tr = np.zeros((n, 6), F), np.zeros((n, 12), F)
+        lib.ref_enclosing_proxies(C.c_uint(n), _p(pos), _p(q), _p(scl), _p(dn), C.c_float(MIN_RESPONSE), C.c_uint(clamp), C.c_float(deg), _p(aabb), _p(tr))
+        out[f"px_deg{deg}_c{clamp}_aabb"], out[f"px_deg{deg}_c{clamp}_transform"] = aabb, tr
+    out["px_pos"], out["px_rot"], out["px_scl"], out["px_dns"] = pos, q, scl, dn
+    np.savez_compressed(os.path.join(HERE, "grt_proxies.npz"), **out)
+    print("wrote grt_proxies.npz")
+
+
+GRT_TRACE_SCENES = [dict(n=600, width=24, height=16, median_scale=0.10, max_density=0.8, kind="trained", seed=3),
+                    dict(n=900, width=20, height=20, median_scale=0.06, max_density=0.99, kind="random", seed=5)]
+
+
+def grt_trace_upstream(h, w, seed=17):
+    r = np.random.default_rng(seed)
+    return (r.normal(size=(h, w, 3)).astype(F), r.normal(size=(h, w, 1)).astype(F), (r.normal(size=(h, w, 1)) * 0.1).astype(F))
+
+
+def make_grt_trace():
+    """tests/golden/grt_trace.npz: the reference's 3DGRT forward and backward OptiX programs (raygen round loop, intersection,
+    any-hit k-buffer, processHit / processHitBwd) run on the host over an emulated OptiX traversal
+    (oracle/ref/ref_grt_trace*.cpp), on the proxy instances of the reference's own instance kernel."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import make_scene
+    px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    fw = C.CDLL(os.path.join(REF, "libref_grt_trace_deg4.so"))
+    bw = C.CDLL(os.path.join(REF, "libref_grt_trace_bwd_deg4.so"))
+    out = {}
+    for k, kw in enumerate(GRT_TRACE_SCENES):
+        sc = make_scene(**kw)
+        d12, sph = np.ascontiguousarray(sc["density12"]), np.ascontiguousarray(sc["sph"])
+        n, H, W = len(d12), kw["height"], kw["width"]
+        pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
+                              np.ascontiguousarray(d12[:, 3]))
+        aabb, tf = np.zeros((n, 6), F), np.zeros((n, 12), F)
+        px.ref_enclosing_proxies(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(aabb), _p(tf))
+        box = np.concatenate([aabb[:, :3].min(0), aabb[:, 3:].max(0)]).astype(F)
+        r2w = np.ascontiguousarray(np.asarray(sc["batch"]["T_to_world"][0], F)[:3, :4])
+        ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)) for a in sc["rays"])
+        feat, den, hit, nrm = np.zeros((H, W, 3), F), np.zeros((H, W, 1), F), np.zeros((H, W, 2), F), np.zeros((H, W, 3), F)
+        cnt, vis = np.zeros((H, W, 1), F), np.zeros(n, np.int32)
+        common = (C.c_uint(n), _p(tf), _p(d12), _p(sph), W, H, _p(r2w), _p(ro), _p(rd), _p(box), C.c_float(MIN_T_GRT), C.c_float(MIN_RESPONSE),
+                  C.c_float(MIN_ALPHA), C.c_uint(3))
+        # the other legal traversal outcome (boxes tested against the ray's shrunk far end): accepted-hit counts only, for the record
+        fw.ref_grt_set_box_test_uses_shrunk_tmax(1)
+        cnt_shrunk = np.zeros((H, W, 1), F)
+        fw.ref_grt_trace_fwd(*common, _p(feat.copy()), _p(den.copy()), _p(hit.copy()), _p(nrm.copy()), _p(cnt_shrunk), _p(vis.copy()))
+        out[f"s{k}_hits_count_shrunk_tmax"] = cnt_shrunk
+        fw.ref_grt_set_box_test_uses_shrunk_tmax(0)
+        fw.ref_grt_trace_fwd(*common, _p(feat), _p(den), _p(hit), _p(nrm), _p(cnt), _p(vis))
+        g_rad, g_dns, g_hit = grt_trace_upstream(H, W)
+        gd, gs = np.zeros((n, 12), F), np.zeros((n, 48), F)
+        bw.ref_grt_trace_bwd(*common, _p(feat), _p(den), _p(hit), _p(g_rad), _p(g_dns), _p(g_hit), _p(gd), _p(gs))
+        for name, a in dict(features=feat, density=den, hit_distance=hit, normals=nrm, hits_count=cnt, visibility=vis, grad_density=gd, grad_sph=gs).items():
+            out[f"s{k}_{name}"] = a
+    np.savez_compressed(os.path.join(HERE, "grt_trace.npz"), **out)
+    print("wrote grt_trace.npz; hits per ray:", [float(out[f"s{k}_hits_count"].mean()) for k in range(len(GRT_TRACE_SCENES))])
+
+
 if __name__ == "__main__":
     import sys
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
-    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector"]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace"]
     if "--adam-only" in sys.argv:
         which = ["adam"]
     if "per_hit" in which:
@@ -272,3 +351,7 @@ if __name__ == "__main__":
         make_camera()
     if "projector" in which:
         make_projector()
+    if "grt_proxies" in which:
+        make_grt_proxies()
+    if "grt_trace" in which:
+        make_grt_trace()
