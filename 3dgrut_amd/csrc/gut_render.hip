@@ -83,7 +83,6 @@ struct RayPair {
     int px, py0, py1;
     bool uniform_origin;  // every valid ray of the wave starts at `origin`
     f3 origin;
-    v2f dxx, dyy, dzz, dxy, dxz, dyz, dd;   // monomials of the directions (pair_prefilter)
 };
 __device__ __forceinline__ RayPair init_ray_pair(const GutParams& P, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                  uint32_t tile, uint32_t half, int lane) {
@@ -114,9 +113,6 @@ __device__ __forceinline__ RayPair init_ray_pair(const GutParams& P, const float
     const bool same1 = !b.valid || (b.o.x == cand.x && b.o.y == cand.y && b.o.z == cand.z);
     rp.uniform_origin = __all(same0 && same1);
     rp.origin = cand;
-    rp.dxx = rp.d.x * rp.d.x; rp.dyy = rp.d.y * rp.d.y; rp.dzz = rp.d.z * rp.d.z;
-    rp.dxy = rp.d.x * rp.d.y; rp.dxz = rp.d.x * rp.d.z; rp.dyz = rp.d.y * rp.d.z;
-    rp.dd = rp.dxx + rp.dyy + rp.dzz;
     return rp;
 }
 
@@ -128,15 +124,14 @@ __device__ __forceinline__ void half_mapping(uint32_t b, uint32_t& vtile, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-// staged tile entry: 8 x float4 in LDS
+// staged tile entry: 6 x float4 in LDS
 //   r0 = M.r0, pos.x | r1 = M.r1, pos.y | r2 = M.r2, pos.z      M = diag(1/scale) R^T  (gaussianParticles.slang:96-110)
 //   r3 = scale.xyz (fwd) or 1/scale.xyz (bwd), density
 //   r4 = clamped radiance rgb, g_max
 //   r5 = u0 = M (origin - pos) (uniform-origin waves), as_float(expansion position of the entry)
-//   r6, r7 = quadratic pre-filter of the accept test (uniform-origin waves), see stage_entry
 // Padding entries (index 0xFFFFFFFF) get M = I and g_max = 0: finite everywhere, never accepted.
 // ---------------------------------------------------------------------------------------------
-constexpr int kRecQuads = 8;
+constexpr int kRecQuads = 6;
 
 struct RawEntry {
     uint32_t idx, pos;   // particle, expansion position of the entry (its gradient slot)
@@ -172,7 +167,6 @@ __device__ __forceinline__ void stage_entry(const GutParams& P, const RawEntry& 
     float4 r0 = make_float4(1.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 1.f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
     float4 r3 = make_float4(1.f, 1.f, 1.f, 0.f), r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 r5 = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xFFFFFFFFu));
-    float4 r6 = make_float4(0.f, 0.f, 0.f, 0.f), r7 = make_float4(0.f, 0.f, -1.f, 0.f);   // padding: form 0 > -|d|^2 -> dropped
     if (r.idx != 0xFFFFFFFFu) {
         const m3 rt = quat_wxyz_to_rotT(r.q.x, r.q.y, r.q.z, r.q.w);
         const float ix = __builtin_amdgcn_rcpf(r.s.x), iy = __builtin_amdgcn_rcpf(r.s.y), iz = __builtin_amdgcn_rcpf(r.s.z);
@@ -188,37 +182,10 @@ __device__ __forceinline__ void stage_entry(const GutParams& P, const RawEntry& 
             r5.x = dot(mk3(r0.x, r0.y, r0.z), dl);
             r5.y = dot(mk3(r1.x, r1.y, r1.z), dl);
             r5.z = dot(mk3(r2.x, r2.y, r2.z), dl);
-            // With one origin for the whole wave, u = M (o - mu) is a constant of the entry and the accept test
-            //   |v x u|^2 < g_max |v|^2,  v = M d,   is the sign of a quadratic form of the pixel's direction d:
-            //   |u|^2 |v|^2 - (u.v)^2 - g_max |v|^2 = d^T Q d,   Q = (|u|^2 - g_max) M^T M - p p^T,  p = M^T u.
-            // Six FMAs per pixel pair instead of the full canonical-frame geometry.  Q loses digits to cancellation
-            // (|u| is the camera distance in units of the particle's scale), so the form is only a PRE-FILTER: a pixel is
-            // dropped when the form exceeds a rigorous bound on its own error, everything else takes the exact test.
-            const f3 m0 = mk3(r0.x, r0.y, r0.z), m1 = mk3(r1.x, r1.y, r1.z), m2 = mk3(r2.x, r2.y, r2.z);
-            const float g00 = m0.x * m0.x + m1.x * m1.x + m2.x * m2.x, g11 = m0.y * m0.y + m1.y * m1.y + m2.y * m2.y;
-            const float g22 = m0.z * m0.z + m1.z * m1.z + m2.z * m2.z, g01 = m0.x * m0.y + m1.x * m1.y + m2.x * m2.y;
-            const float g02 = m0.x * m0.z + m1.x * m1.z + m2.x * m2.z, g12 = m0.y * m0.z + m1.y * m1.z + m2.y * m2.z;
-            const f3 p = m0 * r5.x + m1 * r5.y + m2 * r5.z;
-            const float sc = (r5.x * r5.x + r5.y * r5.y + r5.z * r5.z) - gmax;
-            r6 = make_float4(sc * g00 - p.x * p.x, sc * g11 - p.y * p.y, sc * g22 - p.z * p.z, 2.f * (sc * g01 - p.x * p.y));
-            const float ap = fabsf(p.x) + fabsf(p.y) + fabsf(p.z);
-            // |computed form - exact form| <= ~16 eps * sum of the magnitudes that cancel; 64 eps leaves room for the rounding
-            // of the exact test itself
-            const float bound = 3.9e-6f * (fabsf(sc) * (g00 + g11 + g22 + 2.f * (fabsf(g01) + fabsf(g02) + fabsf(g12))) + ap * ap);
-            r7 = make_float4(2.f * (sc * g02 - p.x * p.z), 2.f * (sc * g12 - p.y * p.z), bound, 0.f);
         }
         r5.w = __uint_as_float(r.pos);
     }
-    rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4; rec[5] = r5; rec[6] = r6; rec[7] = r7;
-}
-
-// pre-filter of the accept test for uniform-origin waves: false = this pixel pair certainly rejects the staged entry
-__device__ __forceinline__ void pair_prefilter(const RayPair& rp, const float4* __restrict__ rec, bool& maybe0, bool& maybe1) {
-    const float4 q6 = rec[6], q7 = rec[7];
-    const v2f f = pfma(q6.x, rp.dxx, pfma(q6.y, rp.dyy, pfma(q6.z, rp.dzz, pfma(q6.w, rp.dxy, pfma(q7.x, rp.dxz, q7.y * rp.dyz)))));
-    const v2f lim = q7.z * rp.dd;
-    maybe0 = !(f.x > lim.x);
-    maybe1 = !(f.y > lim.y);
+    rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4; rec[5] = r5;
 }
 
 // canonical-frame ray of the pixel pair against one staged entry, and the accept test
@@ -300,11 +267,6 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         const int n = (int)(bend - b);
         for (int j = 0; j < n; ++j) {
             const float4* rec = &s_rec[j * kRecQuads];
-            if (UNI) {
-                bool m0, m1;
-                pair_prefilter(rp, rec, m0, m1);
-                if (!__any((m0 && alive0) || (m1 && alive1))) continue;
-            }
             const PairGeom g = pair_geometry<UNI>(rp, rec);
             const bool c0 = g.acc0 && alive0, c1 = g.acc1 && alive1;
             if (!__any(c0 || c1)) continue;
@@ -418,11 +380,6 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
         for (int j = 0; j < n; ++j) {
             if (!__any(alive0 || alive1)) break;
             const float4* rec = &s_rec[j * kRecQuads];
-            if (UNI) {
-                bool m0, m1;
-                pair_prefilter(rp, rec, m0, m1);
-                if (!__any((m0 && alive0) || (m1 && alive1))) continue;
-            }
             const PairGeom g = pair_geometry<UNI>(rp, rec);
             const bool h0 = g.acc0 && alive0, h1 = g.acc1 && alive1;
             if (!__any(h0 || h1)) continue;
