@@ -3,10 +3,15 @@
  * TEST INFRASTRUCTURE ONLY: used by tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg as the checker; never imported by the product package.
  *
- * Parity pinning: the per-hit math (orc_gut_process_hit_fwd/bwd, SH) is checked against
- * the reference's own headers compiled on the host (oracle/_ref, see oracle/ref/) and
- * against tests/golden/ known-answer vectors generated from them.  The reference ships
- * no tests or golden vectors for this path.
+ * Parity pinning: checked against the reference's own sources compiled on
+ * the host (oracle/_ref, recipes in oracle/ref/) and against the tests/golden/ vectors they
+ * produced — the per-hit math, the camera models, the projection + expansion stage, and the
+ * whole frame: the reference's projectOnTiles / render / renderBackward kernels run block by
+ * block on a fiber emulation of a CUDA thread block (tests/golden/gut_render.npz: sorted
+ * lists bit-identical, images within 2e-6, gradients within 2e-5).  Not pinned: what exists
+ * in the reference only as Slang source (the projection backward, the K > 0 per-hit
+ * backward).  The reference ships no tests or golden vectors of its own for this path
+ * (SURVEY.md §4, §8c).
  *
  * Sequence restated: gutRenderer.cu:241-520 (GUTRenderer::renderForward/Backward).
  */

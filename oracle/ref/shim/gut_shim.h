@@ -9,4 +9,5 @@ inline float3 operator-(const float3& a) { return {-a.x, -a.y, -a.z}; }
 inline float3 operator*(const float3& a, const float3& b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 inline float3 operator/(const float3& a, const float3& b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
 inline float3 make_float3(float s) { return {s, s, s}; }
+inline float4 make_float4(float s) { return {s, s, s, s}; }
 inline float3 make_float3(int s) { return {(float)s, (float)s, (float)s}; }

@@ -65,6 +65,7 @@ struct tvec<T, 4, A> {
     T x, y, z, w;
     tvec(T x_, T y_, T z_, T w_) : x(x_), y(y_), z(z_), w(w_) {}
     explicit tvec(T s) : x(s), y(s), z(s), w(s) {}
+    tvec(const tvec<T, 3, A>& v, T w_) : x(v.x), y(v.y), z(v.z), w(w_) {}   // GLM vec4(vec3, w)
     TCNN_SHIM_VEC_COMMON(4)
 };
 
@@ -107,10 +108,20 @@ TCNN_SHIM_VEC_FN2(max, a[i] > b[i] ? a[i] : b[i])
 TCNN_SHIM_VEC_FN2(copysign, std::copysign(a[i], b[i]))
 #undef TCNN_SHIM_VEC_FN2
 template <typename T, uint32_t N, size_t A>
+tvec<T, N, A> max(const tvec<T, N, A>& a, T b) { tvec<T, N, A> r; for (uint32_t i = 0; i < N; ++i) r[i] = a[i] > b ? a[i] : b; return r; }
+template <typename T, uint32_t N, size_t A>
 tvec<T, N, A> sqrt(const tvec<T, N, A>& a) { tvec<T, N, A> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::sqrt(a[i]); return r; }
 // per-component blend with a vector of weights (GLM mix(x, y, a) with vector a)
 template <typename T, uint32_t N, size_t A>
 tvec<T, N, A> mix(const tvec<T, N, A>& x, const tvec<T, N, A>& y, const tvec<T, N, A>& a) { return x * (tvec<T, N, A>(T(1)) - a) + y * a; }
+inline float sqrt(float a) { return std::sqrt(a); }
+template <typename T, uint32_t N, size_t A>
+T length2(const tvec<T, N, A>& a) { return dot(a, a); }
+template <typename T, uint32_t N, size_t A>
+tvec<T, N, A> abs(const tvec<T, N, A>& a) { tvec<T, N, A> r; for (uint32_t i = 0; i < N; ++i) r[i] = std::abs(a[i]); return r; }
+template <typename T, uint32_t N, size_t A>
+T max(const tvec<T, N, A>& a) { T r = a[0]; for (uint32_t i = 1; i < N; ++i) r = a[i] > r ? a[i] : r; return r; }   // largest component
+template <typename T> T div_round_up(T a, T b) { return (a + b - 1) / b; }
 template <typename T> void host_device_swap(T& a, T& b) { T t = a; a = b; b = t; }
 // GLM mix: x * (1 - a) + y * a
 template <typename T, uint32_t N, size_t A>
@@ -123,6 +134,9 @@ struct tmat {
     tmat() = default;
     tmat(const tvec<T, M>& c0, const tvec<T, M>& c1, const tvec<T, M>& c2) { m[0] = c0; m[1] = c1; m[2] = c2; }
     tmat(const tvec<T, M>& c0, const tvec<T, M>& c1, const tvec<T, M>& c2, const tvec<T, M>& c3) { m[0] = c0; m[1] = c1; m[2] = c2; m[3] = c3; }
+    // GLM matNxM(matPxQ): the upper-left block of a larger matrix
+    template <uint32_t P, uint32_t Q, typename = typename std::enable_if<(P >= N && Q >= M && (P != N || Q != M))>::type>
+    explicit tmat(const tmat<T, P, Q>& o) { for (uint32_t c = 0; c < N; ++c) for (uint32_t r = 0; r < M; ++r) m[c][r] = o[c][r]; }
     tvec<T, M>& operator[](uint32_t i) { return m[i]; }
     const tvec<T, M>& operator[](uint32_t i) const { return m[i]; }
 };

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Generates tests/golden/per_hit_deg{2,4}.npz, adam.npz, camera.npz and projector.npz from the REFERENCE's own per-hit
-math, optimizer kernel, camera projection code and projection stage.
+"""Generates tests/golden/per_hit_deg{2,4}.npz, adam.npz, camera.npz, projector.npz, grt_proxies.npz, grt_trace.npz and
+gut_render.npz from the REFERENCE's own per-hit math, optimizer kernel, camera projection code, projection stage, 3DGRT
+proxy kernels and OptiX programs, and 3DGUT projection / render / renderBackward kernels.
 
 Run in the build container only (needs /root/reference):
 
@@ -336,10 +337,108 @@ def make_grt_trace():
     print("wrote grt_trace.npz; hits per ray:", [float(out[f"s{k}_hits_count"].mean()) for k in range(len(GRT_TRACE_SCENES))])
 
 
+# ---- the reference's 3DGUT kernels (projection, render, renderBackward) on the host --------------------------------------------
+GUT_RENDER_SCENES = [
+    dict(n=300, width=40, height=36, median_scale=0.12, max_density=0.7),            # translucent: tens of hits per ray, ragged tiles
+    dict(n=1500, width=64, height=48, median_scale=0.06, max_density=0.99, seed=5),  # opaque: rays end on the transmittance threshold
+]
+
+
+def gut_render_upstream(h, w, seed=23):
+    r = np.random.default_rng(seed)
+    return r.normal(size=(h, w, 4)).astype(F), (r.normal(size=(h, w, 1)) * 0.1).astype(F)
+
+
+def gut_reference_frame(sc, k_buffer=0, backward=True):
+    """Runs the reference's kernels (oracle/_ref/libref_gut_render_deg2_k{K}.so) on a tests/scenes.make_scene() scene, following the
+    launch sequence of GUTRenderer::renderForward / renderBackward (gutRenderer.cu:258-413, 472-505): projectOnTiles, inclusive scan,
+    expandTileProjections, stable sort by key, tile ranges, render, renderBackward."""
+    lib = C.CDLL(os.path.join(REF, f"libref_gut_render_deg2_k{k_buffer}.so"))
+    plib = C.CDLL(os.path.join(REF, "libref_projector.so"))   # expandTileProjections (touches no particle data)
+    assert lib.ref_gut_k_buffer_size() == k_buffer
+    W, H = sc["W"], sc["H"]
+    d12, sph = np.ascontiguousarray(sc["density12"], F), np.ascontiguousarray(sc["sph"], F)
+    n = len(d12)
+    cam = sc["cam"]
+    prm = np.array([cam.principal_point[0], cam.principal_point[1], cam.focal_length[0], cam.focal_length[1]], F)
+    ps, pe = np.asarray(sc["pose_start"], F), np.asarray(sc["pose_end"], F)
+    ro, rd = (np.ascontiguousarray(a, F).reshape(H, W, 3) for a in sc["rays"])
+    o = dict(tiles_count=np.zeros(n, np.uint32), proj_pos=np.zeros((n, 2), F), conic_opacity=np.zeros((n, 4), F), extent=np.zeros((n, 2), F),
+             depth=np.zeros(n, F), features=np.zeros((n, 3), F), visibility=np.zeros(n, np.int32))
+    lib.ref_gut_project(W, H, _p(prm), _p(ps), _p(pe), C.c_uint32(n), _p(d12), _p(sph), 3, _p(o["tiles_count"]), _p(o["proj_pos"]),
+                        _p(o["conic_opacity"]), _p(o["extent"]), _p(o["depth"]), _p(o["features"]), _p(o["visibility"]))
+    offsets = np.cumsum(o["tiles_count"], dtype=np.uint64).astype(np.uint32)
+    total = int(offsets[-1])
+    keys, idx = np.zeros(total, np.uint64), np.zeros(total, np.uint32)
+    plib.ref_expand_particles(W, H, C.c_uint32(n), _p(offsets), _p(o["proj_pos"]), _p(o["conic_opacity"]), _p(o["extent"]), _p(o["depth"]),
+                              _p(keys), _p(idx))
+    order = np.argsort(keys, kind="stable")                      # cub::DeviceRadixSort::SortPairs, gutRenderer.cu:356-365
+    o["sorted_idx"] = np.ascontiguousarray(idx[order])
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    tile_of = (keys[order] >> np.uint64(32)).astype(np.int64)     # computeSortedTileRangeIndices, gutRenderer.cu:368-373
+    o["tile_ranges"] = np.stack([np.searchsorted(tile_of, np.arange(tiles), "left"),
+                                 np.searchsorted(tile_of, np.arange(tiles), "right")], 1).astype(np.uint32)
+    lo, hi = np.full(3, -1e6, F), np.full(3, 1e6, F)             # the scene box SplatRaster::trace passes, splatRaster.cpp:240
+    o["feat_density"], o["hit_distance"], o["hit_count"] = np.zeros((H, W, 4), F), np.full((H, W, 1), 1e6, F), np.zeros((H, W, 1), F)
+    common = (W, H, _p(ps), _p(pe), _p(lo), _p(hi), C.c_uint32(n), _p(d12), _p(sph), 3, _p(o["tile_ranges"]), _p(o["sorted_idx"]),
+              _p(o["features"]), _p(ro), _p(rd))
+    lib.ref_gut_render_fwd(*common, _p(o["feat_density"]), _p(o["hit_distance"]), _p(o["hit_count"]))
+    if backward:
+        assert k_buffer == 0, "the K > 0 backward is Slang autodiff output (not in the checkout)"
+        gfd, gdist = gut_render_upstream(H, W)
+        o["grad_density"], o["grad_features"] = np.zeros((n, 12), F), np.zeros((n, 3), F)
+        gsph = np.zeros_like(sph)     # untouched by renderBackward in the SH configuration (written by projectBackward)
+        lib.ref_gut_render_bwd(*common, _p(o["feat_density"]), _p(gfd), _p(o["hit_distance"]), _p(gdist), _p(o["grad_density"]), _p(gsph),
+                               _p(o["grad_features"]))
+        assert not gsph.any()
+    return o
+
+
+def gut_standin_check(lib, n=4000, seed=9):
+    """Largest difference between the Slang stand-in (oracle/ref/shim/threedgutSlang.cuh) and the reference's CUDA twin of the same
+    per-hit math, on random (ray, particle) pairs about half of which are accepted."""
+    r = np.random.default_rng(seed)
+    pos = r.uniform(-1, 1, (n, 3)); scl = np.exp(r.normal(np.log(0.25), 0.6, (n, 3)))
+    q = r.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    d12 = np.concatenate([pos, r.uniform(0.002, 1.0, (n, 1)), q, scl, np.zeros((n, 1))], 1).astype(F)
+    ro = r.uniform(-1, 1, (n, 3)) + np.array([0, 0, -4.0])
+    rd = pos + r.normal(size=(n, 3)) * scl * 1.8 - ro
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    ro, rd, feat = ro.astype(F), rd.astype(F), r.uniform(-0.3, 1.2, (n, 3)).astype(F)
+    a, b = C.c_uint32(0), C.c_uint32(0)
+    lib.ref_gut_standin_max_error.restype = C.c_float
+    err = lib.ref_gut_standin_max_error(C.c_uint32(n), _p(ro), _p(rd), _p(d12), _p(feat), C.byref(a), C.byref(b))
+    return float(err), a.value, b.value
+
+
+def make_gut_render():
+    """tests/golden/gut_render.npz: the reference's projectOnTiles / render / renderBackward kernels, with the real particle class,
+    tile loop, hit k-buffer and ray payload code under them, run on the host (oracle/ref/ref_gut_render.cpp) — every binning
+    product, the rendered outputs for K = 0 and K = 16, and the K = 0 gradients renderBackward accumulates."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import make_scene
+    err, acc_standin, acc_twin = gut_standin_check(C.CDLL(os.path.join(REF, "libref_gut_render_deg2_k0.so")))
+    assert acc_standin == acc_twin and 1000 < acc_twin < 3500 and err < 2e-6, (err, acc_standin, acc_twin)
+    out = dict(standin_check=np.array([err, acc_standin, acc_twin], np.float64))
+    for k, kw in enumerate(GUT_RENDER_SCENES):
+        sc = make_scene(**kw)
+        o = gut_reference_frame(sc, 0)
+        for name, a in o.items():
+            out[f"s{k}_{name}"] = a
+        o16 = gut_reference_frame(sc, 16, backward=False)
+        for name in ("feat_density", "hit_distance", "hit_count"):
+            out[f"s{k}_k16_{name}"] = o16[name]
+        print(f"scene {k}: {int(o['tiles_count'].sum())} tile entries, opacity {o['feat_density'][..., 3].mean():.3f}, "
+              f"hits/ray {o['hit_count'].mean():.1f}, |K16 - K0| {np.abs(o16['feat_density'] - o['feat_density']).max():.3g}")
+    np.savez_compressed(os.path.join(HERE, "gut_render.npz"), **out)
+    print("wrote gut_render.npz; stand-in vs CUDA twin:", err, acc_standin, acc_twin)
+
+
 if __name__ == "__main__":
     import sys
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
-    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace"]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "gut_render"]
     if "--adam-only" in sys.argv:
         which = ["adam"]
     if "per_hit" in which:
@@ -355,3 +454,5 @@ if __name__ == "__main__":
         make_grt_proxies()
     if "grt_trace" in which:
         make_grt_trace()
+    if "gut_render" in which:
+        make_gut_render()

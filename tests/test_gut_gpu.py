@@ -478,3 +478,47 @@ def test_projection_and_binning_match_reference_code_golden():
                 assert set(got[rng_h[t, 0]:rng_h[t, 1]].tolist()) == set(want.tolist()), f"case {k}, tile {t}: different members"
                 if np.array_equal(dp.cpu().numpy().view(np.uint32)[want], g[f"p{k}_depth"].view(np.uint32)[want]):
                     assert np.array_equal(got[rng_h[t, 0]:rng_h[t, 1]], want), f"case {k}, tile {t}: different order"
+
+
+def test_frame_matches_reference_kernels_golden():
+    """The HIP frame DIRECTLY against tests/golden/gut_render.npz = the reference's own projectOnTiles / render / renderBackward
+    kernels run on the host (oracle/ref/ref_gut_render.cpp).  Forward images for K = 0 and K = 16 against the reference's; the
+    gradients against what renderBackward accumulated there, carried through the projection backward (the one stage of the
+    backward that is Slang autodiff output in the reference, restated by the oracle) — BASELINE.json's tolerances."""
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    g = np.load(os.path.join(here, "golden", "gut_render.npz"))
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    F = np.float32
+    for k, kw in enumerate(make_golden.GUT_RENDER_SCENES):
+        scene = make_scene(**kw)
+        H, W = kw["height"], kw["width"]
+        g_fd, g_dist = make_golden.gut_render_upstream(H, W)
+        gpu = _run_gpu(scene, g_fd, g_dist)
+        ref = dict(feat_density=g[f"s{k}_feat_density"], hit_distance=g[f"s{k}_hit_distance"])
+        _image_checks(gpu["out"], ref)
+        cnt = gpu["out"]["hits_count"][0, ..., 0].detach().cpu().numpy()
+        n_flip = int((cnt != g[f"s{k}_hit_count"][..., 0]).sum())
+        assert n_flip <= max(2, 2e-3 * cnt.size), f"scene {k}: {n_flip} pixels with a different hit count"
+        st = gpu["tracer"].tracer_wrapper.stats()
+        assert abs(int(st.num_intersections) - len(g[f"s{k}_sorted_idx"])) <= 2
+        # reference gradients of renderBackward -> projection backward
+        n = len(scene["density12"])
+        cfg = oracle.default_gut_config()
+        ref_gd, ref_grgb = g[f"s{k}_grad_density"].copy(), np.ascontiguousarray(g[f"s{k}_grad_features"])
+        ref_gsph = np.zeros((n, 48), F)
+        ps, pe = np.asarray(scene["pose_start"], F), np.asarray(scene["pose_end"], F)
+        d12, sph = np.ascontiguousarray(scene["density12"], F), np.ascontiguousarray(scene["sph"], F)
+        oracle.lib(F).orc_gut_project_bwd(C.byref(cfg), p(ps), p(pe), C.c_uint32(n), C.c_int(3), p(g[f"s{k}_tiles_count"]), p(d12), p(sph),
+                                          p(ref_grgb), p(ref_gd), p(ref_gsph))
+        gd, gsph = gpu["grads"]
+        for name, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
+            e = _trimmed_rel_err(gd[:, sl], ref_gd[:, sl], 3 * n_flip)
+            assert e < 1e-3, f"scene {k}: grad {name} rel err {e:.3e}"
+        assert _trimmed_rel_err(gsph, ref_gsph, 3 * n_flip) < 1e-3
+        # sorted mode, K = 16
+        gpu16 = _run_gpu(scene, k_buffer_size=16)
+        _image_checks(gpu16["out"], dict(feat_density=g[f"s{k}_k16_feat_density"], hit_distance=g[f"s{k}_k16_hit_distance"]))
