@@ -102,7 +102,7 @@ VIS_NONE, VIS_BOOL_U8, VIS_INT32, VIS_FLOAT_BITS = range(4)
 
 # every symbol include/grut_amd.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
-    "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_timings", "gut_stats",
+    "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_backward_factored", "grut_sph_grad_from_views", "gut_timings", "gut_stats",
     "gut_profile_enable", "gut_profile_read",
     "gut_debug_fetch", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
@@ -125,6 +125,10 @@ def _declare(lib):
     lib.gut_forward.restype = C.c_int
     lib.gut_backward.argtypes = [C.c_void_p, vp, C.POINTER(GutFrame)] + [fp] * 10
     lib.gut_backward.restype = C.c_int
+    lib.gut_backward_factored.argtypes = [C.c_void_p, vp, C.POINTER(GutFrame)] + [fp] * 10
+    lib.gut_backward_factored.restype = C.c_int
+    lib.grut_sph_grad_from_views.argtypes = [vp, C.c_uint32, C.c_uint32, fp, fp, C.c_uint32, C.c_int32, C.c_int32, C.c_float, fp]
+    lib.grut_sph_grad_from_views.restype = C.c_int
     lib.gut_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.gut_timings.restype = C.c_int
     lib.gut_stats.argtypes = [C.c_void_p, C.POINTER(GutStats)]
@@ -211,6 +215,22 @@ def pack_particles(mog_pos, mog_dns, mog_rot, mog_scl):
     out = torch.empty((n, 12), dtype=torch.float32, device=mog_pos.device)
     stream = C.c_void_p(torch.cuda.current_stream(mog_pos.device).cuda_stream)
     check(lib.grut_pack_particles(stream, n, *[C.c_void_p(p.data_ptr()) for p in parts], C.c_void_p(out.data_ptr())), "grut_pack_particles")
+    return out
+
+
+def sph_grad_from_views(view_factors, positions, n_active_features, sph_degree, scale=1.0):
+    """Sum over views of the SH-coefficient gradients from the gathered view factors of gut_backward_factored:
+    view_factors [V, N+1, 3] (row N of each view = its sensor position), positions [N, 3] or packed [N, 12] rows."""
+    import torch
+    lib = load_library()
+    view_factors = view_factors.contiguous()
+    positions = positions.contiguous()
+    v, n = int(view_factors.shape[0]), int(view_factors.shape[1]) - 1
+    assert view_factors.shape[2] == 3 and positions.shape[0] == n and positions.shape[1] in (3, 12)
+    out = torch.empty((n, 3 * (sph_degree + 1) ** 2), dtype=torch.float32, device=view_factors.device)
+    stream = C.c_void_p(torch.cuda.current_stream(view_factors.device).cuda_stream)
+    check(lib.grut_sph_grad_from_views(stream, n, v, C.c_void_p(view_factors.data_ptr()), C.c_void_p(positions.data_ptr()), int(positions.shape[1]),
+                                       int(n_active_features), int(sph_degree), float(scale), C.c_void_p(out.data_ptr())), "grut_sph_grad_from_views")
     return out
 
 

@@ -356,9 +356,11 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     return GRUT_OK;
 }
 
-int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const float* particle_sph,
-                 const float* ray_origin, const float* ray_direction, const float* feat_density, const float* grad_feat_density,
-                 const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_particle_sph) {
+// gut_backward / gut_backward_factored: exactly one of grad_particle_sph and grad_radiance is non-null
+static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const float* particle_sph,
+                         const float* ray_origin, const float* ray_direction, const float* feat_density, const float* grad_feat_density,
+                         const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_particle_sph,
+                         float* grad_radiance) {
     GRUT_REQUIRE(h && frame, "gut_backward: null handle/frame");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     if (!h->have_forward || h->fwd_stream != s) {  // gutRenderer.cu:436-440
@@ -369,7 +371,7 @@ int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float
     GRUT_REQUIRE(frame->num_particles == P.N && frame->width == P.W && frame->height == P.H, "gut_backward: frame differs from the forward frame");
     if (P.N == 0) return GRUT_OK;
     GRUT_REQUIRE(particle_density && particle_sph && feat_density && grad_feat_density && hit_distance && grad_particle_density &&
-                     grad_particle_sph, "gut_backward: null buffer");  // grad_hit_distance may be NULL (no depth gradient)
+                     (grad_particle_sph || grad_radiance), "gut_backward: null buffer");  // grad_hit_distance may be NULL (no depth gradient)
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
     const GutProjected proj = projected_view(h);
     const int slot = h->prof_fwd_slot;
@@ -393,7 +395,7 @@ int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float
             GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_BWD, s, slot));
         }
         GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));
-        launch_project_bwd(s, P, proj, particle_density, particle_sph, h->g_rgb.as<float>(), grad_particle_density, grad_particle_sph);
+        launch_project_bwd(s, P, proj, particle_density, particle_sph, h->g_rgb.as<float>(), grad_particle_density, grad_particle_sph, grad_radiance);
         GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT_BWD, s, slot));
         GRUT_HIP(hipGetLastError());
         if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
@@ -414,10 +416,36 @@ int gut_backward(GutHandle* h, void* stream_, const GutFrame* frame, const float
     GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));
     GRUT_CHECK(h->g_rgb.ensure((size_t)P.N * 12, 1.25f));  // per-particle radiance gradient between gather and SH backward
     launch_grad_finalize(s, P, proj, particle_density, particle_sph, slots, has_gdist, I > 0, h->g_rgb.as<float>(), grad_particle_density,
-                         grad_particle_sph);
+                         grad_particle_sph, grad_radiance);
     GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT_BWD, s, slot));
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
+    return GRUT_OK;
+}
+
+int gut_backward(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const float* particle_sph,
+                 const float* ray_origin, const float* ray_direction, const float* feat_density, const float* grad_feat_density,
+                 const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_particle_sph) {
+    return backward_impl(h, stream, frame, particle_density, particle_sph, ray_origin, ray_direction, feat_density, grad_feat_density, hit_distance,
+                         grad_hit_distance, grad_particle_density, grad_particle_sph, nullptr);
+}
+
+int gut_backward_factored(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const float* particle_sph,
+                          const float* ray_origin, const float* ray_direction, const float* feat_density, const float* grad_feat_density,
+                          const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_radiance) {
+    GRUT_REQUIRE(grad_radiance, "gut_backward_factored: null buffer");
+    return backward_impl(h, stream, frame, particle_density, particle_sph, ray_origin, ray_direction, feat_density, grad_feat_density, hit_distance,
+                         grad_hit_distance, grad_particle_density, nullptr, grad_radiance);
+}
+
+int grut_sph_grad_from_views(void* stream, uint32_t num_particles, uint32_t num_views, const float* view_factors, const float* positions,
+                             uint32_t position_stride, int32_t n_active_features, int32_t sph_degree, float scale, float* grad_particle_sph) {
+    GRUT_REQUIRE(num_views > 0 && sph_degree >= 0 && sph_degree <= 3 && position_stride >= 3, "grut_sph_grad_from_views: bad arguments");
+    if (num_particles == 0) return GRUT_OK;
+    GRUT_REQUIRE(view_factors && positions && grad_particle_sph, "grut_sph_grad_from_views: null buffer");
+    launch_sph_grad_from_views(reinterpret_cast<hipStream_t>(stream), num_particles, num_views, view_factors, positions, position_stride,
+                               n_active_features, (sph_degree + 1) * (sph_degree + 1), scale, grad_particle_sph);
+    GRUT_HIP(hipGetLastError());
     return GRUT_OK;
 }
 

@@ -666,10 +666,16 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
 }
 
 constexpr int kShStride = 49;
+// FACTORED (view-sharded data parallelism, gut_backward_factored): the SH-coefficient gradient basis_k(dir) x g is NOT
+// expanded here (192 B per particle); the view-specific factor g — the radiance gradient behind the clamp — is written to
+// g_radiance [N+1,3] instead, with the sensor position of the view in row N, and grut_sph_grad_from_views rebuilds the sum
+// over views after the factors have been gathered.  The view-direction part of the position gradient stays here.
+template <bool FACTORED>
 __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const uint32_t* __restrict__ tiles_count,
                                                               const float4* __restrict__ density12, const float* __restrict__ sph,
                                                               const float* __restrict__ rgb, const float* __restrict__ g_rgb,
-                                                              float* __restrict__ g_density12, float* __restrict__ g_sph) {
+                                                              float* __restrict__ g_density12, float* __restrict__ g_sph,
+                                                              float* __restrict__ g_radiance) {
     __shared__ float s_rows[2][64 * kShStride];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t wave_base = blockIdx.x * 128u + (uint32_t)wave * 64u;
@@ -727,20 +733,85 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
             if (k < nact) {
                 const float s = g.x * myrow[3 * k] + g.y * myrow[3 * k + 1] + g.z * myrow[3 * k + 2];
                 gdir = gdir + dbasis[k] * s;
-                myrow[3 * k] = basis[k] * g.x; myrow[3 * k + 1] = basis[k] * g.y; myrow[3 * k + 2] = basis[k] * g.z;
+                if (!FACTORED) { myrow[3 * k] = basis[k] * g.x; myrow[3 * k + 1] = basis[k] * g.y; myrow[3 * k + 2] = basis[k] * g.z; }
             }
         }
-        for (int k = 3 * nact; k < rowlen; ++k) myrow[k] = 0.f;
+        if (!FACTORED)
+            for (int k = 3 * nact; k < rowlen; ++k) myrow[k] = 0.f;
         const float ng = dot(dir, gdir);
         const f3 gpos = (gdir - dir * ng) * ilen;
         g_density12[12 * (size_t)i + 0] += gpos.x;
         g_density12[12 * (size_t)i + 1] += gpos.y;
         g_density12[12 * (size_t)i + 2] += gpos.z;
-    } else {
+        if (FACTORED) { g_radiance[3 * (size_t)i] = g.x; g_radiance[3 * (size_t)i + 1] = g.y; g_radiance[3 * (size_t)i + 2] = g.z; }
+    } else if (!FACTORED) {
         for (int k = 0; k < rowlen; ++k) myrow[k] = 0.f;
+    } else if (i < P.N) {
+        g_radiance[3 * (size_t)i] = 0.f; g_radiance[3 * (size_t)i + 1] = 0.f; g_radiance[3 * (size_t)i + 2] = 0.f;
+    }
+    if (FACTORED) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {   // the view's sensor position rides along as row N
+            g_radiance[3 * (size_t)P.N] = FP.s2w_t[0]; g_radiance[3 * (size_t)P.N + 1] = FP.s2w_t[1]; g_radiance[3 * (size_t)P.N + 2] = FP.s2w_t[2];
+        }
+        return;
     }
     __syncthreads();
     // stage out: every row of the wave, zeros included (the caller does not pre-fill grad_sph)
+    if (rowlen == 48) {
+        float4* dst = reinterpret_cast<float4*>(g_sph + (size_t)wave_base * 48);
+        const int total4 = nrows * 12;
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+            const int q = lane + 64 * it;
+            if (q < total4) {
+                const float* d = rows + (q / 12) * kShStride + 4 * (q % 12);
+                dst[q] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    } else {
+        for (int row = 0; row < nrows; ++row)
+            if (lane < rowlen) g_sph[(size_t)(wave_base + row) * rowlen + lane] = rows[row * kShStride + lane];
+    }
+}
+
+// Sum over views of the SH-coefficient gradients from the gathered per-view factors (see gut_project_bwd_kernel<true>):
+//   g_sph[p][k] = scale * sum_v basis_k(normalize(mu_p - cam_v)) * g_v[p]
+// factors [n_views][N+1][3] (row N of each view = its sensor position).  Views are added in index order on every rank, so all
+// replicas end up with bitwise identical gradients.  Rows leave through LDS as 16-byte requests, as in the kernel above.
+__global__ __launch_bounds__(128) void sph_grad_from_views_kernel(uint32_t N, uint32_t n_views, const float* __restrict__ factors,
+                                                                  const float* __restrict__ positions, uint32_t pos_stride, int n_active,
+                                                                  int ncoef, float scale, float* __restrict__ g_sph) {
+    __shared__ float s_rows[2][64 * kShStride];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t wave_base = blockIdx.x * 128u + (uint32_t)wave * 64u;
+    const uint32_t i = wave_base + lane;
+    const int rowlen = 3 * ncoef;
+    const int nact = min((n_active + 1) * (n_active + 1), ncoef);
+    float* rows = s_rows[wave];
+    float* myrow = rows + lane * kShStride;
+    const int nrows = (int)min(64u, N > wave_base ? N - wave_base : 0u);
+    if (i < N) {
+        const f3 mu = mk3(positions[(size_t)i * pos_stride], positions[(size_t)i * pos_stride + 1], positions[(size_t)i * pos_stride + 2]);
+        float acc[48];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) acc[k] = 0.f;
+        for (uint32_t v = 0; v < n_views; ++v) {
+            const float* view = factors + (size_t)v * 3 * ((size_t)N + 1);
+            const f3 g = mk3(view[3 * (size_t)i], view[3 * (size_t)i + 1], view[3 * (size_t)i + 2]);
+            if (g.x == 0.f && g.y == 0.f && g.z == 0.f) continue;   // invisible or fully clamped in this view
+            const f3 d = mu - mk3(view[3 * (size_t)N], view[3 * (size_t)N + 1], view[3 * (size_t)N + 2]);
+            const f3 dir = d * (1.f / sqrtf(dot(d, d)));
+            float basis[16];
+            sh_basis(n_active, dir, basis);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k < nact) { acc[3 * k] += basis[k] * g.x; acc[3 * k + 1] += basis[k] * g.y; acc[3 * k + 2] += basis[k] * g.z; }
+        }
+#pragma unroll
+        for (int k = 0; k < 48; ++k)
+            if (k < rowlen) myrow[k] = acc[k] * scale;
+    }
+    __syncthreads();
     if (rowlen == 48) {
         float4* dst = reinterpret_cast<float4*>(g_sph + (size_t)wave_base * 48);
         const int total4 = nrows * 12;
@@ -797,13 +868,24 @@ void launch_tile_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32
                        reinterpret_cast<uint2*>(ranges), boundary_tile);
 }
 
+// exactly one of g_sph (expanded SH gradient) and g_radiance (view factor, see gut_project_bwd_kernel<true>) is non-null
 void launch_project_bwd(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
-                        const float* g_rgb, float* g_density12, float* g_sph) {
-    hipLaunchKernelGGL(gut_project_bwd_kernel, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
-                       reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_density12, g_sph);
+                        const float* g_rgb, float* g_density12, float* g_sph, float* g_radiance) {
+    if (g_radiance)
+        hipLaunchKernelGGL(gut_project_bwd_kernel<true>, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
+                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_density12, g_sph, g_radiance);
+    else
+        hipLaunchKernelGGL(gut_project_bwd_kernel<false>, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
+                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_density12, g_sph, g_radiance);
+}
+void launch_sph_grad_from_views(hipStream_t s, uint32_t N, uint32_t n_views, const float* factors, const float* positions, uint32_t pos_stride,
+                                int n_active, int ncoef, float scale, float* g_sph) {
+    hipLaunchKernelGGL(sph_grad_from_views_kernel, dim3(div_up(N, 128)), dim3(128), 0, s, N, n_views, factors, positions, pos_stride, n_active,
+                       ncoef, scale, g_sph);
 }
 void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
-                          const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, float* g_density12, float* g_sph) {
+                          const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, float* g_density12, float* g_sph,
+                          float* g_radiance) {
     const dim3 grid(div_up(P.N, 64)), block(256);  // four lanes per particle
     if (has_gdist)
         hipLaunchKernelGGL(gut_grad_gather_kernel<20>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
@@ -811,8 +893,7 @@ void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected&
     else
         hipLaunchKernelGGL(gut_grad_gather_kernel<16>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
                            have_partials ? 1 : 0, g_density12, g_rgb);
-    hipLaunchKernelGGL(gut_project_bwd_kernel, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
-                       reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_density12, g_sph);
+    launch_project_bwd(s, P, proj, density12, sph, g_rgb, g_density12, g_sph, g_radiance);
 }
 
 }  // namespace grut

@@ -49,6 +49,56 @@ class GradientExchange:
             torch._foreach_div_(grads, float(world))
 
 
+class FactoredGradientExchange:
+    """The 3DGUT plugin's exchange step, sized for xGMI (set `tracer.gradient_exchange = FactoredGradientExchange()`; the
+    plugin's backward then calls `reduce_packed` before it unpacks anything).
+
+    Per step and rank the all-reduce of the five Gaussian gradient tensors moves [N,59] floats — 236 B per particle, 192 B of
+    which are the SH-coefficient gradient.  Per view that gradient is an outer product: (SH basis at the particle's view
+    direction) x (3-float radiance gradient behind the clamp).  So instead:
+      * the packed geometric gradient [N,12] (position, density, rotation, scale) is all-reduced where it lies — one
+        collective instead of four;
+      * every rank contributes its view factor [N+1,3] (`gut_backward_factored`: radiance gradients + the view's sensor
+        position) to one all-gather — 12 B per particle and view on the links;
+      * every rank rebuilds sum_v basis(dir_v) x g_v locally (`grut_sph_grad_from_views`, one pass that writes [N,48] once).
+    At 8 ranks a ring moves 2*(7/8)*236 = 413 B per particle for the plain all-reduce, 2*(7/8)*48 + (7/8)*8*12 = 168 B this
+    way.  Views are added in rank order on every rank, so replicas stay bitwise identical, like after an all-reduce."""
+
+    def __init__(self, average: bool = False, group=None):
+        self.average = average
+        self.group = group
+
+    def _world(self):
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    @torch.no_grad()
+    def reduce_packed(self, g_density, g_radiance, positions, n_active_features, sph_degree):
+        """(packed gradient [N,12] of this view, view factor [N+1,3]) -> (sum / mean over views of the packed gradient,
+        SH-coefficient gradient [N, 3*(deg+1)^2] of all views).  `positions`: [N,3] or packed [N,12] particle rows."""
+        from . import _abi
+        world = self._world()
+        scale = 1.0 / world if self.average else 1.0
+        if world == 1:
+            return g_density, _abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active_features, sph_degree, 1.0)
+        nccl = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
+        w_geo = dist.all_reduce(g_density, op=op, group=self.group, async_op=True)
+        factors = torch.empty((world,) + tuple(g_radiance.shape), dtype=g_radiance.dtype, device=g_radiance.device)
+        if nccl:
+            w_rad = dist.all_gather_into_tensor(factors, g_radiance.contiguous(), group=self.group, async_op=True)
+        else:
+            # gloo (CPU-side test plumbing) has no all-gather on device tensors: every rank fills its own slice of a zeroed
+            # buffer and the slices are summed, which is the same gather
+            factors.zero_()
+            factors[dist.get_rank(self.group)].copy_(g_radiance)
+            w_rad = dist.all_reduce(factors, group=self.group, async_op=True)
+        w_geo.wait()
+        w_rad.wait()
+        if self.average and not nccl:
+            g_density.div_(float(world))
+        return g_density, _abi.sph_grad_from_views(factors, positions, n_active_features, sph_degree, scale)
+
+
 @torch.no_grad()
 def local_densify_stats(positions_grad: torch.Tensor, positions: torch.Tensor, camera_position: torch.Tensor):
     """Per-view densification statistic of strategy/gs.py:129-139: ||dL/dmu|| * dist(mu, camera) / 2 where the view's

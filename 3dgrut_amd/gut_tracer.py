@@ -151,6 +151,16 @@ class _GutNative:
                                          _ptr(g_density), _ptr(g_sph)), "gut_backward")
         return g_density, g_sph
 
+    def trace_bwd_factored(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_fd, dist, g_dist):
+        """gut_backward_factored: (packed gradient [N,12], view factor [N+1,3]) — see 3dgrut_amd/dp.py."""
+        dev = ray_ori.device
+        g_density = torch.empty_like(particle_density)
+        g_radiance = torch.empty((particle_density.shape[0] + 1, 3), dtype=torch.float32, device=dev)
+        _abi.check(self.lib.gut_backward_factored(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
+                                                  _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(g_fd), _ptr(dist), _ptr(g_dist),
+                                                  _ptr(g_density), _ptr(g_radiance)), "gut_backward_factored")
+        return g_density, g_radiance
+
     def collect_times(self):
         if not self.cfg.enable_kernel_timings:
             return {}
@@ -171,7 +181,7 @@ class _GutNative:
 class Tracer:
     class _Autograd(torch.autograd.Function):
         @staticmethod
-        def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_sph, raw=False):
+        def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_sph, raw=False, exchange=None):
             # raw: mog_rot / mog_scl / mog_dns are the model's RAW parameters, activated inside the packing kernel
             if raw:
                 particle_density = _abi.activate_pack(mog_pos, mog_dns, mog_rot, mog_scl)
@@ -181,7 +191,7 @@ class Tracer:
             particle_features = mog_sph.contiguous()
             fd, dist, cnt, vis = native.trace(frame, particle_density, particle_features, ray_ori, ray_dir)
             ctx.save_for_backward(ray_ori, ray_dir, fd, dist, particle_density, particle_features)
-            ctx.native, ctx.frame = native, frame
+            ctx.native, ctx.frame, ctx.exchange = native, frame, exchange
             # the op hands out features and opacity as separate tensors (what render() returns), so that autograd does not
             # have to route their gradients back through slice / contiguous nodes
             feat = fd[..., :3].unsqueeze(0)   # views of the packed output, as tracer.py:327-328 returns them
@@ -199,16 +209,24 @@ class Tracer:
             g_fd = torch.cat([g_feat, g_opa], dim=-1)
             # g_dist is None when the loss never touched pred_dist: the library then runs the variant without
             # hit-distance terms (autograd materialises zeros unless told otherwise, see set_materialize_grads)
-            g_density, g_sph = ctx.native.trace_bwd(ctx.frame, particle_density, particle_features, ray_ori, ray_dir,
-                                                    fd, g_fd, dist, None if g_dist is None else g_dist.contiguous())
+            g_dist = None if g_dist is None else g_dist.contiguous()
+            if ctx.exchange is None:
+                g_density, g_sph = ctx.native.trace_bwd(ctx.frame, particle_density, particle_features, ray_ori, ray_dir, fd, g_fd, dist, g_dist)
+            else:
+                # view-sharded data parallelism (3dgrut_amd/dp.py): the packed gradient is all-reduced and the SH gradient is
+                # rebuilt from the gathered per-view factors, before anything is unpacked
+                g_density, g_radiance = ctx.native.trace_bwd_factored(ctx.frame, particle_density, particle_features, ray_ori, ray_dir,
+                                                                      fd, g_fd, dist, g_dist)
+                g_density, g_sph = ctx.exchange.reduce_packed(g_density, g_radiance, particle_density, int(ctx.frame.n_active_features),
+                                                              int(ctx.native.cfg.particle_radiance_sph_degree))
             # views into the packed gradient, as the reference returns them (tracer.py:268-285): no copies
             if ctx.raw is not None:   # chain rule to the raw parameters, four contiguous tensors in one pass
                 g_pos, g_dns, g_rot, g_scl = _abi.activate_pack_backward(*ctx.raw, g_density)
-                return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph, None
+                return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph, None, None
             # the reference returns strided slices of the packed gradient (tracer.py:268-285) and autograd clones each of
             # them when it accumulates; one pass writes the four tensors contiguously instead
             g_pos, g_dns, g_rot, g_scl = _abi.unpack_particle_grads(g_density)
-            return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph, None
+            return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph, None, None
 
     def __init__(self, conf):
         self.device = "cuda"
@@ -218,6 +236,9 @@ class Tracer:
         torch.zeros(1, device=self.device)  # force context creation (tracer.py:292)
         self.tracer_wrapper = _GutNative(gut_config_from_conf(conf))
         self._fused_activations = fused_activations_requested(conf)
+        # set to a 3dgrut_amd.dp.FactoredGradientExchange to have the backward exchange its gradients across ranks (one view
+        # per GPU); None (default) = single-GPU behaviour, exactly the reference's
+        self.gradient_exchange = None
 
     @property
     def timings(self):
@@ -259,12 +280,12 @@ class Tracer:
             pred_features, pred_opacity, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
                 native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(),
                 gaussians.positions.contiguous(), gaussians.rotation.contiguous(), gaussians.scale.contiguous(),
-                gaussians.density.contiguous(), feats.contiguous(), True)
+                gaussians.density.contiguous(), feats.contiguous(), True, self.gradient_exchange)
         else:
             pred_features, pred_opacity, pred_dist, hits_count, mog_visibility = Tracer._Autograd.apply(
                 native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(),
                 gaussians.positions.contiguous(), gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(),
-                gaussians.get_density().contiguous(), feats.contiguous())
+                gaussians.get_density().contiguous(), feats.contiguous(), False, self.gradient_exchange)
         if getattr(gaussians, "ray_feature_dim", 3) != 3:
             raise NotImplementedError("3dgrut_amd: only SH radiance features (ray_feature_dim = 3) are supported")
         timings = native.collect_times()

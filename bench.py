@@ -232,7 +232,18 @@ def main():
     g_fd_np, g_dist_np = syn.upstream_grads(W, H)
     g_fd = torch.as_tensor(g_fd_np, device=dev)
     g_rgb, g_opa = g_fd[None, ..., :3].contiguous(), g_fd[None, ..., 3:].contiguous()
-    exch = importlib.import_module("3dgrut_amd.dp").GradientExchange(g.parameters(), average=False) if world > 1 else None
+    # the exchange step of the path.  Default: the packed geometric gradient is all-reduced and the SH gradient is
+    # rebuilt from gathered per-view factors inside the plugin's backward (dp.FactoredGradientExchange: 168 instead of 413 B per
+    # particle over the links at 8 ranks); GRUT_BENCH_EXCHANGE=allreduce selects the plain five-tensor all-reduce for comparison
+    dp = importlib.import_module("3dgrut_amd.dp")
+    exch = None
+    exchange_kind = "none"
+    if world > 1:
+        exchange_kind = os.environ.get("GRUT_BENCH_EXCHANGE", "factored")
+        if exchange_kind == "factored":
+            tracer.gradient_exchange = dp.FactoredGradientExchange(average=False)
+        else:
+            exch = dp.GradientExchange(g.parameters(), average=False)
 
     def step():
         g.zero_grad()
@@ -240,7 +251,7 @@ def main():
         # upstream gradients per SURVEY §8d: d_rgb, d_opacity ~ N(0,1)/P and no gradient into the hit distance
         # (training never back-props depth: trainer.py:677-748)
         torch.autograd.backward([out["pred_features"], out["pred_opacity"]], [g_rgb, g_opa])
-        if world > 1:  # in-place all-reduce of the Gaussian gradients ([N,59] fp32 in five tensors)
+        if exch is not None:  # in-place all-reduce of the Gaussian gradients ([N,59] fp32 in five tensors)
             exch.reduce()
 
     for _ in range(args.warmup):
@@ -295,7 +306,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"3DGUT fwd+bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "
                                    f"SH degree 3, k_buffer {args.k_buffer}", "name": args.workload,
-                       "parallelism": f"view-dp{world}" + (" + RCCL grad all-reduce" if world > 1 else "")},
+                       "parallelism": f"view-dp{world}" + ({"factored": " + RCCL all-reduce [N,12] + all-gather of view factors [N+1,3]",
+                                                                  "none": ""}.get(exchange_kind, " + RCCL grad all-reduce [N,59]"))},
             "roofline": {"bound": "hbm", "kernel": f"gut_{dom}", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes": model[dom], "kernel_ms": stages[dom]},

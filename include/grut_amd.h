@@ -152,6 +152,33 @@ int gut_backward(GutHandle* handle, void* stream, const GutFrame* frame,
                  const float* hit_distance, const float* grad_hit_distance,
                  float* grad_particle_density, float* grad_particle_sph);
 
+/* ---- view-sharded data parallelism: the radiance gradient in factored form (new surface; the reference is
+ * single-GPU) ------------------------------------------------------------------------------------------------------------------
+ * With one view per GPU, the gradient exchange of a step is dominated by grad_particle_sph: 3*(deg+1)^2 floats per particle
+ * (192 B at degree 3 of the 236 B total) that are, per view, the outer product of two small factors — the SH basis at the
+ * particle's view direction (a function of the particle and the sensor position alone) and the 3-float radiance gradient
+ * behind the clamp (GUTProjector::evalBackward, gutProjector.cuh:390-431).  gut_backward_factored is gut_backward without the
+ * expansion: it returns that view-specific factor,
+ *   grad_radiance [N+1,3] f32, fully overwritten: rows 0..N-1 = dL/d(unclamped per-particle radiance) of this view (0 where the
+ *                 radiance was clamped or the particle was not rendered), row N = the view's sensor position in world space,
+ * and grad_particle_density exactly as gut_backward does (including the view-direction part of the position gradient).
+ * Ranks gather the factors (12 B per particle and view over the links instead of 192 B through an all-reduce) and every rank
+ * rebuilds the sum over views locally with grut_sph_grad_from_views:
+ *   grad_particle_sph[p][k] = scale * sum_v basis_k(normalize(position_p - sensor_v)) * grad_radiance_v[p],  k < (n_active+1)^2
+ * view_factors [num_views, N+1, 3] (the gathered grad_radiance buffers, in rank order: every rank adds the views in the same
+ * order, so replicas stay bitwise identical); positions: N rows of position_stride floats whose first three are the particle
+ * position (3 for a [N,3] tensor, 12 for particle_density rows); scale: 1 for a sum over views, 1/num_views for a mean.
+ * With num_views = 1 and scale = 1 the result is bit for bit what gut_backward writes. */
+int gut_backward_factored(GutHandle* handle, void* stream, const GutFrame* frame,
+                          const float* particle_density, const float* particle_sph,
+                          const float* ray_origin, const float* ray_direction,
+                          const float* feat_density, const float* grad_feat_density,
+                          const float* hit_distance, const float* grad_hit_distance,
+                          float* grad_particle_density, float* grad_radiance);
+int grut_sph_grad_from_views(void* stream, uint32_t num_particles, uint32_t num_views, const float* view_factors,
+                             const float* positions, uint32_t position_stride, int32_t n_active_features, int32_t sph_degree,
+                             float scale, float* grad_particle_sph);
+
 /* average ms of the forward / backward launches since the last call (-1 if none). Synchronises. */
 int gut_timings(GutHandle* handle, float* forward_ms, float* backward_ms);
 int gut_stats(GutHandle* handle, GutStats* stats);

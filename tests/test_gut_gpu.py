@@ -522,3 +522,53 @@ def test_frame_matches_reference_kernels_golden():
         # sorted mode, K = 16
         gpu16 = _run_gpu(scene, k_buffer_size=16)
         _image_checks(gpu16["out"], dict(feat_density=g[f"s{k}_k16_feat_density"], hit_distance=g[f"s{k}_k16_hit_distance"]))
+
+
+def test_factored_backward_rebuilds_the_sph_gradient():
+    """gut_backward_factored + grut_sph_grad_from_views (the data-parallel exchange of 3dgrut_amd/dp.py): with one view the rebuilt
+    SH gradient is bit for bit gut_backward's; with two views it is the sum of the two per-view gradients; the packed geometric
+    gradient is untouched by the factoring."""
+    import torch
+    dp = importlib.import_module("3dgrut_amd.dp")
+    abi = importlib.import_module("3dgrut_amd._abi")
+    w, h = 96, 64
+    g_fd, _ = syn.upstream_grads(w, h)
+    g_fd *= w * h
+    per_view = []
+    for view in (0, 3):
+        scene = make_scene(n=3000, width=w, height=h, median_scale=0.06, view=view)
+        plain = _run_gpu(scene, g_fd, None, n_active=2)
+        tr = _tracer()
+        tr.gradient_exchange = dp.FactoredGradientExchange()          # no process group: one view, sum
+        g = syn.SimpleGaussians(scene["density12"], scene["sph"], n_active_features=2)
+        out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
+        fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
+        (fd * torch.as_tensor(g_fd, device="cuda")).sum().backward()
+        gd, gsph = g.grads_packed()
+        assert np.array_equal(gd, plain["grads"][0]) and np.array_equal(gsph, plain["grads"][1]), f"view {view}"
+        assert np.abs(gsph[:, 27:]).max() == 0 and np.abs(gsph[:, :27]).max() > 0     # n_active = 2: nine coefficients
+        per_view.append((scene, plain["grads"][1]))
+    # two views through the library entry points directly
+    factors = []
+    for scene, _ in per_view:
+        tr = _tracer()
+        captured = {}
+
+        class Capture:
+            def reduce_packed(self, g_density, g_radiance, positions, n_active, deg):
+                captured["f"], captured["pos"] = g_radiance.clone(), positions.clone()
+                return g_density, abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active, deg)
+        tr.gradient_exchange = Capture()
+        g = syn.SimpleGaussians(scene["density12"], scene["sph"], n_active_features=2)
+        out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
+        fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
+        (fd * torch.as_tensor(g_fd, device="cuda")).sum().backward()
+        factors.append(captured["f"])
+        # row N of the factor is the view's sensor position
+        cam = np.asarray(scene["batch"]["T_to_world"][0], np.float64)[:3, 3]
+        assert np.abs(captured["f"][-1].cpu().numpy() - cam).max() < 1e-5
+    both = abi.sph_grad_from_views(torch.stack(factors), captured["pos"], 2, 3).cpu().numpy()
+    want = per_view[0][1].astype(np.float64) + per_view[1][1].astype(np.float64)
+    assert np.abs(both - want).max() <= 1e-6 * np.abs(want).max()
+    mean = abi.sph_grad_from_views(torch.stack(factors), captured["pos"][:, :3].contiguous(), 2, 3, scale=0.5).cpu().numpy()
+    assert np.abs(mean - 0.5 * want).max() <= 1e-6 * np.abs(want).max()
