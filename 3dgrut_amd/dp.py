@@ -64,9 +64,12 @@ class FactoredGradientExchange:
     At 8 ranks a ring moves 2*(7/8)*236 = 413 B per particle for the plain all-reduce, 2*(7/8)*48 + (7/8)*8*12 = 168 B this
     way.  Views are added in rank order on every rank, so replicas stay bitwise identical, like after an all-reduce."""
 
-    def __init__(self, average: bool = False, group=None):
+    def __init__(self, average: bool = False, group=None, local_gradient_hook=None):
         self.average = average
         self.group = group
+        # called with this view's packed gradient [N,12] (columns 0..2 = dL/d position) BEFORE it is reduced: the place to take
+        # the densification statistics, which must come from the local view (local_densify_stats)
+        self.local_gradient_hook = local_gradient_hook
 
     def _world(self):
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -78,6 +81,8 @@ class FactoredGradientExchange:
         from . import _abi
         world = self._world()
         scale = 1.0 / world if self.average else 1.0
+        if self.local_gradient_hook is not None:
+            self.local_gradient_hook(g_density)
         if world == 1:
             return g_density, _abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active_features, sph_degree, 1.0)
         nccl = dist.get_backend(self.group) == "nccl"
