@@ -596,6 +596,17 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const u
 // the gradient is accumulated per hit with atomics exactly like the reference does in this mode.  One pixel per lane,
 // one wave64 per 16x4 strip; correctness-first kernel (the unsorted K = 0 path above is the tuned one).
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gray_limit_rt(int deg, float x) {
+    switch (deg) {
+    case 8: return response_gray_limit<8>(x);
+    case 5: return response_gray_limit<5>(x);
+    case 4: return response_gray_limit<4>(x);
+    case 3: return response_gray_limit<3>(x);
+    case 1: return response_gray_limit<1>(x);
+    case 0: return response_gray_limit<0>(x);
+    default: return response_gray_limit<2>(x);
+    }
+}
 __device__ __forceinline__ float response_rt(int deg, float g) {
     switch (deg) {
     case 8: return particle_response<8>(g);
@@ -630,15 +641,19 @@ struct KBuffer {   // ascending in hitT: slot 0 = nearest pending hit, empty slo
         for (int i = 0; i < K; ++i) { hitT[i] = -1.f; alpha[i] = 0.f; idx[i] = 0xFFFFFFFFu; }
     }
     // HitParticleKBufferT::insert (:76-91); the caller has already consumed slot 0 when the buffer was full
+    // branch-free: the keys move with min / max (no swap on equal keys, like the reference's strict `>`), the payloads
+    // with selects
     __device__ __forceinline__ void insert(float t, float a, uint32_t id) {
 #pragma unroll
         for (int i = K - 1; i >= 0; --i) {
-            if (t > hitT[i]) {
-                const float tt = hitT[i], aa = alpha[i];
-                const uint32_t ii = idx[i];
-                hitT[i] = t; alpha[i] = a; idx[i] = id;
-                t = tt; a = aa; id = ii;
-            }
+            const bool up = t > hitT[i];
+            const float lo = fminf(t, hitT[i]), hi = fmaxf(t, hitT[i]);
+            const float aa = up ? alpha[i] : a;
+            const uint32_t ii = up ? idx[i] : id;
+            alpha[i] = up ? a : alpha[i];
+            idx[i] = up ? id : idx[i];
+            hitT[i] = hi;
+            t = lo; a = aa; id = ii;
         }
     }
 };
@@ -683,7 +698,7 @@ __device__ __forceinline__ bool k_bwd_terms(const GutParams& P, const Ray& ray, 
                                             float hitT, float alpha, uint32_t idx, KBwdState& s, bool& alive, float (&terms)[16]) {
     const bool contributes = alpha > 0.f;
     if (contributes) {
-        const float w = 1.f / (1.f - alpha);
+        const float w = __builtin_amdgcn_rcpf(1.f - alpha);
         const f3 feat = mk3(fmaxf(rgb[3 * (size_t)idx], 0.f), fmaxf(rgb[3 * (size_t)idx + 1], 0.f), fmaxf(rgb[3 * (size_t)idx + 2], 0.f));
         s.Cb = (s.Cb - feat * alpha) * w;
         float dalpha = (feat.x - s.Cb.x) * s.gC.x + (feat.y - s.Cb.y) * s.gC.y + (feat.z - s.Cb.z) * s.gC.z;
@@ -698,14 +713,14 @@ __device__ __forceinline__ bool k_bwd_terms(const GutParams& P, const Ray& ray, 
 
         const float4 a = density12[3 * (size_t)idx], q = density12[3 * (size_t)idx + 1], sc = density12[3 * (size_t)idx + 2];
         const m3 rotT = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
-        const f3 gscl = mk3(sc.x, sc.y, sc.z), giscl = mk3(1.f / sc.x, 1.f / sc.y, 1.f / sc.z);
+        const f3 gscl = mk3(sc.x, sc.y, sc.z), giscl = mk3(__builtin_amdgcn_rcpf(sc.x), __builtin_amdgcn_rcpf(sc.y), __builtin_amdgcn_rcpf(sc.z));
         const f3 gposc = ray.o - mk3(a.x, a.y, a.z);
         const f3 gposcr = mul_rows(rotT, gposc);
         const f3 gro = giscl * gposcr;
         const f3 rdr = mul_rows(rotT, ray.d);
         const f3 grdu = giscl * rdr;
         const float l2 = dot(grdu, grdu);
-        const float il = 1.f / sqrtf(l2);
+        const float il = __builtin_amdgcn_rsqf(l2);
         const f3 grd = grdu * il;
         const f3 gcrod = cross(grd, gro);
         const float gray = dot(gcrod, gcrod);
@@ -717,8 +732,8 @@ __device__ __forceinline__ bool k_bwd_terms(const GutParams& P, const Ray& ray, 
         const f3 grdd = grd * pdot;
         const f3 grds = gscl * grdd;
         const float gsq = dot(grds, grds);
-        const float gdist = sqrtf(gsq);
-        const f3 grdsGrd = gsq > 0.f ? grds * (ddepth / gdist) : mk3(0.f, 0.f, 0.f);
+        const float gdist = __builtin_amdgcn_sqrtf(gsq);
+        const f3 grdsGrd = gsq > 0.f ? grds * (ddepth * __builtin_amdgcn_rcpf(gdist)) : mk3(0.f, 0.f, 0.f);
         const f3 gsclHit = grdd * grdsGrd;
         const float sdot = dot(grdsGrd * gscl, grd);
         const f3 grdHit = gscl * grdsGrd * pdot - gro * sdot;
@@ -746,7 +761,8 @@ __device__ __forceinline__ bool k_bwd_terms(const GutParams& P, const Ray& ray, 
 // Adds the terms of the lanes with `have` to the gradient buffers: lanes that processed the SAME particle in this step
 // (neighbouring pixels usually do) are summed with a DPP reduce-scatter first, one set of 14 atomics per (wave, particle)
 // instead of one per (pixel, particle) — the reference's per-hit atomics (gutKBufferRenderer.cuh:158-198) cost this path
-// 147 ms per 1080p frame on MI355X.
+// 147 ms per 1080p frame on MI355X.  (A further level — a per-wave LDS cache of per-particle totals across steps, evicted
+// to memory — was measured and dropped: 8.0 -> 9.6 ms; the atomics are not what bounds this kernel.)
 __device__ __forceinline__ void k_bwd_flush(bool have, uint32_t idx, const float (&terms)[16], int lane, float* __restrict__ g_density12,
                                             float* __restrict__ g_rgb) {
     unsigned long long m = __ballot(have);
@@ -802,12 +818,15 @@ __global__ __launch_bounds__(64) void gut_render_k_kernel(GutParams P, const uin
             float4 r3 = make_float4(1.f, 1.f, 1.f, 0.f), r4 = make_float4(__uint_as_float(0xFFFFFFFFu), 0.f, 0.f, 0.f);
             if (e.idx != 0xFFFFFFFFu) {
                 const m3 rt = quat_wxyz_to_rotT(e.q.x, e.q.y, e.q.z, e.q.w);
-                const float ix = 1.f / e.s.x, iy = 1.f / e.s.y, iz = 1.f / e.s.z;
+                const float ix = __builtin_amdgcn_rcpf(e.s.x), iy = __builtin_amdgcn_rcpf(e.s.y), iz = __builtin_amdgcn_rcpf(e.s.z);
                 r0 = make_float4(rt.r0.x * ix, rt.r0.y * ix, rt.r0.z * ix, e.a.x);
                 r1 = make_float4(rt.r1.x * iy, rt.r1.y * iy, rt.r1.z * iy, e.a.y);
                 r2 = make_float4(rt.r2.x * iz, rt.r2.y * iz, rt.r2.z * iz, e.a.z);
                 r3 = make_float4(e.s.x, e.s.y, e.s.z, e.a.w);
                 r4.x = __uint_as_float(e.idx);
+                // accept test on grayDist itself, as in the unsorted sweeps (stage_entry)
+                const float need = fmaxf(P.min_response, P.min_alpha / e.a.w);
+                r4.y = (P.max_alpha > P.min_alpha && e.a.w > 0.f) ? gray_limit_rt(P.degree, need) : 0.f;
             }
             float4* rec = &s_rec[lane * 5];
             rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4;
@@ -827,13 +846,17 @@ __global__ __launch_bounds__(64) void gut_render_k_kernel(GutParams P, const uin
                 const f3 dl = ray.o - mk3(q0.w, q1.w, q2.w);
                 const f3 gro = mk3(dot(mk3(q0.x, q0.y, q0.z), dl), dot(mk3(q1.x, q1.y, q1.z), dl), dot(mk3(q2.x, q2.y, q2.z), dl));
                 const f3 grdu = mk3(dot(mk3(q0.x, q0.y, q0.z), ray.d), dot(mk3(q1.x, q1.y, q1.z), ray.d), dot(mk3(q2.x, q2.y, q2.z), ray.d));
-                const f3 grd = grdu * (1.f / sqrtf(dot(grdu, grdu)));
-                const f3 gc = cross(grd, gro);
-                const float resp = response_rt(P.degree, dot(gc, gc));
-                const float alpha = fminf(P.max_alpha, resp * q3.w);
-                if ((resp > P.min_response) && (alpha > P.min_alpha)) {
-                    const f3 grds = mk3(q3.x, q3.y, q3.z) * grd * (-dot(grd, gro));
-                    const float hitT = sqrtf(dot(grds, grds));
+                const float l2 = dot(grdu, grdu);
+                const f3 gc = cross(grdu, gro);
+                const float cc = dot(gc, gc);
+                if (cc < rec[4].y * l2) {   // response > min_response && alpha > min_alpha
+                    const float il2 = __builtin_amdgcn_rcpf(l2);
+                    const float resp = response_rt(P.degree, cc * il2);
+                    const float alpha = fminf(P.max_alpha, resp * q3.w);
+                    // hit distance |S n (n.-u)| = |v.u| |S v| / |v|^2  (as in render_fwd_sweep)
+                    const float vu = dot(grdu, gro);
+                    const f3 sv = mk3(q3.x, q3.y, q3.z) * grdu;
+                    const float hitT = __builtin_amdgcn_sqrtf(dot(sv, sv) * (vu * vu)) * il2;
                     if ((hitT > ray.tmin) && (hitT < ray.tmax)) {
                         if (kb.num == K) {   // full: the nearest pending hit is composited (below), the new one takes its slot
                             pop = true; pop_t = kb.hitT[0]; pop_a = kb.alpha[0]; pop_i = kb.idx[0];
@@ -857,18 +880,25 @@ __global__ __launch_bounds__(64) void gut_render_k_kernel(GutParams P, const uin
         }
         __syncthreads();
     }
-    // drain what is left, nearest first (:343-351)
+    // drain what is left, nearest first (:343-351).  The buffer is ascending with the empty slots (hitT = -1) in front: K steps
+    // that each take slot 0 and shift the rest down visit the pending hits in order; one copy of the per-hit code instead of K
+    // (the gradient terms alone are ~600 instructions).
+#pragma unroll 1
+    for (int step = 0; step < K; ++step) {
+        const float t0 = kb.hitT[0], a0 = kb.alpha[0];
+        const uint32_t i0 = kb.idx[0];
 #pragma unroll
-    for (int i = 0; i < K; ++i) {
-        const bool act = alive && i >= K - kb.num;
+        for (int i = 0; i + 1 < K; ++i) { kb.hitT[i] = kb.hitT[i + 1]; kb.alpha[i] = kb.alpha[i + 1]; kb.idx[i] = kb.idx[i + 1]; }
+        kb.hitT[K - 1] = -1.f;
+        const bool act = alive && (t0 >= 0.f);
         if (BWD) {
             if (__any(act)) {
                 float terms[16];
-                const bool have = act && k_bwd_terms(P, ray, density12, rgb, kb.hitT[i], kb.alpha[i], kb.idx[i], bs, alive, terms);
-                k_bwd_flush(have, kb.idx[i], terms, lane, g_density12, g_rgb);
+                const bool have = act && k_bwd_terms(P, ray, density12, rgb, t0, a0, i0, bs, alive, terms);
+                k_bwd_flush(have, i0, terms, lane, g_density12, g_rgb);
             }
         } else if (act) {
-            k_process_fwd(P, rgb, kb.hitT[i], kb.alpha[i], kb.idx[i], fs, alive);
+            k_process_fwd(P, rgb, t0, a0, i0, fs, alive);
         }
     }
     if (!BWD && ray.inside) {
