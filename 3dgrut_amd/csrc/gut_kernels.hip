@@ -177,6 +177,50 @@ __device__ __forceinline__ void row_tile_walk(int lane, int gx, bool culling, bo
 }
 __device__ __forceinline__ int bbox_area(const TileBBox& b) { return (b.maxx - b.minx) * (b.maxy - b.miny); }
 __device__ __forceinline__ bool bbox_fits_row(const TileBBox& b) { return (b.maxx - b.minx) <= kRowWalkSide && (b.maxy - b.miny) <= kRowWalkSide; }
+// Boxes of at most 8x4 or 4x8 tiles (27 % of the visible particles of the bench cloud, next to 46 % that fit a row) take one
+// step of HALF a wave, laid out as an 8x4 or a 4x8 block: the two halves work on two different particles at once.
+__device__ __forceinline__ bool bbox_fits_half(const TileBBox& b) {
+    const int w = b.maxx - b.minx, h = b.maxy - b.miny;
+    return (w <= 8 && h <= 4) || (w <= 4 && h <= 8);
+}
+// tile of this lane inside a half-wave block over box b (arguments uniform per half); false when the lane falls outside
+__device__ __forceinline__ bool half_block_tile(int lane, const TileBBox& b, int& x, int& y) {
+    const int hl = lane & 31;
+    const bool wide = (b.maxx - b.minx) > 4;
+    x = b.minx + (wide ? (hl & 7) : (hl & 3));
+    y = b.miny + (wide ? (hl >> 3) : (hl >> 2));
+    return (x < b.maxx) && (y < b.maxy);
+}
+// The j-th member of a class inside each group of lanes (16-lane rows, 32-lane halves): `member` lanes are ranked inside their
+// group, and step j of a walk serves the rank-j member of every group at once — max-over-groups steps instead of one step
+// per lane position.  Returns the source lane of the caller's group for step j (valid when `act`).
+struct GroupPick {
+    int rank;        // rank of this lane among the members of its group (meaningful for members)
+    int steps;       // max over groups of the member count
+};
+template <int GROUP>
+__device__ __forceinline__ GroupPick group_rank(int lane, bool member) {
+    const unsigned long long m = __ballot(member);
+    const int shift = lane & ~(GROUP - 1) & 63;
+    const unsigned long long gmask = (GROUP == 64) ? ~0ull : ((1ull << GROUP) - 1ull);
+    const unsigned long long mine = (m >> shift) & gmask;
+    GroupPick g;
+    g.rank = __popcll(mine & ((1ull << (lane & (GROUP - 1))) - 1ull));
+    int steps = 0;
+#pragma unroll
+    for (int s = 0; s < 64; s += GROUP) steps = max(steps, (int)__popcll((m >> s) & gmask));
+    g.steps = steps;
+    return g;
+}
+template <int GROUP>
+__device__ __forceinline__ int group_source(int lane, bool member, const GroupPick& g, int j, bool& act) {
+    const unsigned long long sel = __ballot(member && g.rank == j);   // at most one lane per group
+    const int shift = lane & ~(GROUP - 1) & 63;
+    const unsigned long long gmask = (GROUP == 64) ? ~0ull : ((1ull << GROUP) - 1ull);
+    const unsigned long long mine = (sel >> shift) & gmask;
+    act = mine != 0;
+    return shift | (act ? (__ffsll((long long)mine) - 1) : 0);
+}
 
 // ---------------------------------------------------------------------------------------------
 // K1: projection onto tiles — GUTProjector::eval (gutProjector.cuh:217-322)
@@ -267,21 +311,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const TileConic tc = tile_conic(co);
         const int area = vis ? bbox_area(bb) : 0;
         const bool small = area > 0 && bbox_fits_row(bb);
-        const unsigned long long small_mask = __ballot(small);
         const int row_shift = lane & 48;
-        for (int k = 0; k < 16; ++k) {
-            if (!(small_mask & (0x0001000100010001ull << k))) continue;
-            const int src = row_shift | k;
-            const bool act = row_bcast_i((int)small, src) != 0;
+        const GroupPick rows = group_rank<16>(lane, small);
+        for (int k = 0; k < rows.steps; ++k) {
+            bool act;
+            const int src = group_source<16>(lane, small, rows, k, act);
             const TileBBox sb = {row_bcast_i(bb.minx, src), row_bcast_i(bb.miny, src), row_bcast_i(bb.maxx, src), row_bcast_i(bb.maxy, src)};
             const TileConic sco = {row_bcast_f(tc.cx, src), row_bcast_f(tc.cy, src), row_bcast_f(tc.cz, src), row_bcast_f(tc.rcpx, src),
                                    row_bcast_f(tc.rcpy, src)};
             uint32_t cnt = 0;
             row_tile_walk(lane, P.gx, true, act, sb, sco, row_bcast_f(cx, src), row_bcast_f(cy, src), row_bcast_f(pmax_tile, src),
                           [&](bool keep, uint32_t) { cnt += (uint32_t)__popcll((__ballot(keep) >> row_shift) & 0xFFFFull); });
-            if (lane == src && small) ntiles = cnt;
+            if (lane == src && act) ntiles = cnt;
         }
-        unsigned long long todo = __ballot(area > 0 && !small);
+        const bool halfc = area > 0 && !small && bbox_fits_half(bb);
+        const int half_shift = lane & 32;
+        const GroupPick halves = group_rank<32>(lane, halfc);
+        for (int k = 0; k < halves.steps; ++k) {
+            bool act;
+            const int src = group_source<32>(lane, halfc, halves, k, act);
+            const TileBBox sb = {row_bcast_i(bb.minx, src), row_bcast_i(bb.miny, src), row_bcast_i(bb.maxx, src), row_bcast_i(bb.maxy, src)};
+            const TileConic sco = {row_bcast_f(tc.cx, src), row_bcast_f(tc.cy, src), row_bcast_f(tc.cz, src), row_bcast_f(tc.rcpx, src),
+                                   row_bcast_f(tc.rcpy, src)};
+            const float scx = row_bcast_f(cx, src), scy = row_bcast_f(cy, src), spmax = row_bcast_f(pmax_tile, src);
+            int x, y;
+            bool keep = half_block_tile(lane, sb, x, y) && act;
+            if (keep) keep = tile_min_power((float)x, (float)y, sco, scx, scy) < spmax;
+            const uint32_t cnt = (uint32_t)__popcll((__ballot(keep) >> half_shift) & 0xFFFFFFFFull);
+            if (lane == src && act) ntiles = cnt;
+        }
+        unsigned long long todo = __ballot(area > 0 && !small && !halfc);
         while (todo) {
             const int src = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
@@ -393,12 +452,11 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
     const bool small = has && bbox_fits_row(bb);
     const bool culling = P.tile_culling != 0;
     const int row_shift = lane & 48;
-    const unsigned long long small_mask = __ballot(small);
     const uint32_t row_lt = (1u << (lane & 15)) - 1u;
-    for (int k = 0; k < 16; ++k) {
-        if (!(small_mask & (0x0001000100010001ull << k))) continue;
-        const int src = row_shift | k;
-        const bool act = row_bcast_i((int)small, src) != 0;
+    const GroupPick rows = group_rank<16>(lane, small);
+    for (int k = 0; k < rows.steps; ++k) {
+        bool act;
+        const int src = group_source<16>(lane, small, rows, k, act);
         const TileBBox sb = {row_bcast_i(bb.minx, src), row_bcast_i(bb.miny, src), row_bcast_i(bb.maxx, src), row_bcast_i(bb.maxy, src)};
         const TileConic sco = {row_bcast_f(tc.cx, src), row_bcast_f(tc.cy, src), row_bcast_f(tc.cz, src), row_bcast_f(tc.rcpx, src),
                                row_bcast_f(tc.rcpy, src)};
@@ -421,7 +479,36 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
             pos_particle[q] = 0xFFFFFFFFu;
         }
     }
-    unsigned long long todo = __ballot(has && !small);
+    const bool halfc = has && !small && bbox_fits_half(bb);
+    const int half_shift = lane & 32;
+    const uint32_t half_lt = (uint32_t)((1ull << (lane & 31)) - 1ull);
+    const GroupPick halves = group_rank<32>(lane, halfc);
+    for (int k = 0; k < halves.steps; ++k) {
+        bool act;
+        const int src = group_source<32>(lane, halfc, halves, k, act);
+        const TileBBox sb = {row_bcast_i(bb.minx, src), row_bcast_i(bb.miny, src), row_bcast_i(bb.maxx, src), row_bcast_i(bb.maxy, src)};
+        const TileConic sco = {row_bcast_f(tc.cx, src), row_bcast_f(tc.cy, src), row_bcast_f(tc.cz, src), row_bcast_f(tc.rcpx, src),
+                               row_bcast_f(tc.rcpy, src)};
+        const float scx = row_bcast_f(cx, src), scy = row_bcast_f(cy, src), spmax = row_bcast_f(pmax, src);
+        const uint32_t sp = (uint32_t)row_bcast_i((int)p, src), send = act ? (uint32_t)row_bcast_i((int)max_off, src) : 0u;
+        const uint32_t o = (uint32_t)row_bcast_i((int)off, src);
+        int x, y;
+        bool keep = half_block_tile(lane, sb, x, y) && act;
+        if (keep && culling) keep = tile_min_power((float)x, (float)y, sco, scx, scy) < spmax;
+        const uint32_t m = (uint32_t)((__ballot(keep) >> half_shift) & 0xFFFFFFFFull);
+        const uint32_t slot = o + (uint32_t)__popc(m & half_lt);
+        if (keep && slot < send) {
+            tile_keys[slot] = (uint32_t)(y * P.gx + x);
+            tile_vals[slot] = slot;
+            pos_particle[slot] = sp;
+        }
+        for (uint32_t q = o + (uint32_t)__popc(m) + (lane & 31); q < send; q += 32) {  // gutProjector.cuh:372-376 padding
+            tile_keys[q] = 0xFFFFFFFFu;
+            tile_vals[q] = q;
+            pos_particle[q] = 0xFFFFFFFFu;
+        }
+    }
+    unsigned long long todo = __ballot(has && !small && !halfc);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     while (todo) {
         const int src = __ffsll((long long)todo) - 1;
