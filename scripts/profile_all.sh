@@ -3,6 +3,7 @@
 # bench.py for both workloads; raw outputs under gpurun_out/prof_TAG_*, summarised later by scripts/rocprof_summary.py.
 # (PMC passes carry --kernel-trace only: gpurun refuses --pmc together with sys / runtime traces.)
 # profile_all.sh TAG gut — the 3DGUT workload only (when the 3DGRT kernels have not changed since the last profile).
+# profile_all.sh TAG stats — only the kernel-trace timing pass of the 3DGUT workload plus a plain bench line.
 TAG=${1:-rXX}
 ONLY=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -12,7 +13,9 @@ S=$R/gpurun_out/summ_$TAG  # text summaries travel back
 mkdir -p $O $S
 GUT="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
 GRT="python $R/bench.py --workload c3_grt_1m_800 --steps 2 --warmup 1 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_stats -o st -- $GUT > $O/prof_${TAG}_stats.log 2>&1
+# the timing pass runs bench.py's default step counts (clocks settle over the first steps; 4 steps read ~6 % slow)
+rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_stats -o st -- python $R/bench.py --no-cpu-baseline > $O/prof_${TAG}_stats.log 2>&1
+[ "$ONLY" = "stats" ] && { python $R/scripts/rocprof_summary.py stats $O/prof_${TAG}_stats/st_results.db > $S/kernel_stats.txt; python $R/bench.py > $S/bench.json 2> $S/bench.err; tail -c 300 $S/bench.json; exit 0; }
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_${TAG}_fetch -o f -- $GUT > $O/prof_${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_${TAG}_write -o w -- $GUT > $O/prof_${TAG}_write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES -d $O/prof_${TAG}_sq -o sq -- $GUT > $O/prof_${TAG}_sq.log 2>&1
