@@ -524,7 +524,8 @@ def test_frame_matches_reference_kernels_golden():
         _image_checks(gpu16["out"], dict(feat_density=g[f"s{k}_k16_feat_density"], hit_distance=g[f"s{k}_k16_hit_distance"]))
 
 
-def test_factored_backward_rebuilds_the_sph_gradient():
+@pytest.mark.parametrize("sph_degree,n_active", [(3, 2), (2, 2), (3, 0)])
+def test_factored_backward_rebuilds_the_sph_gradient(sph_degree, n_active):
     """gut_backward_factored + grut_sph_grad_from_views (the data-parallel exchange of 3dgrut_amd/dp.py): with one view the rebuilt
     SH gradient is bit for bit gut_backward's; with two views it is the sum of the two per-view gradients; the packed geometric
     gradient is untouched by the factoring."""
@@ -536,22 +537,24 @@ def test_factored_backward_rebuilds_the_sph_gradient():
     g_fd *= w * h
     per_view = []
     for view in (0, 3):
-        scene = make_scene(n=3000, width=w, height=h, median_scale=0.06, view=view)
-        plain = _run_gpu(scene, g_fd, None, n_active=2)
-        tr = _tracer()
+        scene = make_scene(n=3000, width=w, height=h, median_scale=0.06, view=view, sph_degree=sph_degree)
+        plain = _run_gpu(scene, g_fd, None, n_active=n_active, particle_radiance_sph_degree=sph_degree)
+        tr = _tracer(particle_radiance_sph_degree=sph_degree)
         tr.gradient_exchange = dp.FactoredGradientExchange()          # no process group: one view, sum
-        g = syn.SimpleGaussians(scene["density12"], scene["sph"], n_active_features=2)
+        g = syn.SimpleGaussians(scene["density12"], scene["sph"], n_active_features=n_active)
         out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
         fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
         (fd * torch.as_tensor(g_fd, device="cuda")).sum().backward()
         gd, gsph = g.grads_packed()
         assert np.array_equal(gd, plain["grads"][0]) and np.array_equal(gsph, plain["grads"][1]), f"view {view}"
-        assert np.abs(gsph[:, 27:]).max() == 0 and np.abs(gsph[:, :27]).max() > 0     # n_active = 2: nine coefficients
+        live = 3 * (n_active + 1) ** 2                                               # coefficients of the active degrees only
+        assert gsph.shape[1] == 3 * (sph_degree + 1) ** 2 and np.abs(gsph[:, :live]).max() > 0
+        assert live == gsph.shape[1] or np.abs(gsph[:, live:]).max() == 0
         per_view.append((scene, plain["grads"][1]))
     # two views through the library entry points directly
     factors = []
     for scene, _ in per_view:
-        tr = _tracer()
+        tr = _tracer(particle_radiance_sph_degree=sph_degree)
         captured = {}
 
         class Capture:
@@ -559,7 +562,7 @@ def test_factored_backward_rebuilds_the_sph_gradient():
                 captured["f"], captured["pos"] = g_radiance.clone(), positions.clone()
                 return g_density, abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active, deg)
         tr.gradient_exchange = Capture()
-        g = syn.SimpleGaussians(scene["density12"], scene["sph"], n_active_features=2)
+        g = syn.SimpleGaussians(scene["density12"], scene["sph"], n_active_features=n_active)
         out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
         fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
         (fd * torch.as_tensor(g_fd, device="cuda")).sum().backward()
@@ -567,8 +570,8 @@ def test_factored_backward_rebuilds_the_sph_gradient():
         # row N of the factor is the view's sensor position
         cam = np.asarray(scene["batch"]["T_to_world"][0], np.float64)[:3, 3]
         assert np.abs(captured["f"][-1].cpu().numpy() - cam).max() < 1e-5
-    both = abi.sph_grad_from_views(torch.stack(factors), captured["pos"], 2, 3).cpu().numpy()
+    both = abi.sph_grad_from_views(torch.stack(factors), captured["pos"], n_active, sph_degree).cpu().numpy()
     want = per_view[0][1].astype(np.float64) + per_view[1][1].astype(np.float64)
     assert np.abs(both - want).max() <= 1e-6 * np.abs(want).max()
-    mean = abi.sph_grad_from_views(torch.stack(factors), captured["pos"][:, :3].contiguous(), 2, 3, scale=0.5).cpu().numpy()
+    mean = abi.sph_grad_from_views(torch.stack(factors), captured["pos"][:, :3].contiguous(), n_active, sph_degree, scale=0.5).cpu().numpy()
     assert np.abs(mean - 0.5 * want).max() <= 1e-6 * np.abs(want).max()
