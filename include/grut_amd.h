@@ -168,7 +168,8 @@ int gut_backward(GutHandle* handle, void* stream, const GutFrame* frame,
  * view_factors [num_views, N+1, 3] (the gathered grad_radiance buffers, in rank order: every rank adds the views in the same
  * order, so replicas stay bitwise identical); positions: N rows of position_stride floats whose first three are the particle
  * position (3 for a [N,3] tensor, 12 for particle_density rows); scale: 1 for a sum over views, 1/num_views for a mean.
- * With num_views = 1 and scale = 1 the result is bit for bit what gut_backward writes. */
+ * With num_views = 1 and scale = 1 the result is bit for bit what gut_backward writes.  Same preconditions and errors as
+ * gut_backward (forward context on the same stream); with N == 0 nothing is launched and nothing is written. */
 int gut_backward_factored(GutHandle* handle, void* stream, const GutFrame* frame,
                           const float* particle_density, const float* particle_sph,
                           const float* ray_origin, const float* ray_direction,
