@@ -266,6 +266,7 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         next = load_entry(bend + lane, min(range.y, bend + 64u), lists, density12, rgb);
         const int n = (int)(bend - b);
         for (int j = 0; j < n; ++j) {
+            if (!__any(alive0 || alive1)) break;   // the rest of the round is behind every pixel's termination
             const float4* rec = &s_rec[j * kRecQuads];
             const PairGeom g = pair_geometry<UNI>(rp, rec);
             const bool c0 = g.acc0 && alive0, c1 = g.acc1 && alive1;
