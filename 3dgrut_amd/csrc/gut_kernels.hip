@@ -666,6 +666,10 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     QuadAcc<STRIDE> acc;
     acc.clear();
     const uint32_t off = has ? proj.part_offset[i] : 0u;
+    // the particle's own parameters are needed only by the closing arithmetic; requested here, their round trip overlaps the
+    // flag -> row chain below instead of following it
+    float4 q = make_float4(1.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 0.f);
+    if (has) { q = density12[3 * (size_t)i + 1]; sc = density12[3 * (size_t)i + 2]; }
     if (have_partials) {
         if (has && count <= kGatherSmall) {
             // Set flags are rare (most tile entries lie behind the rays' termination) and every load here is a dependent
@@ -744,7 +748,6 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
         if (c < 3) gd[c] = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
-    const float4 q = density12[3 * (size_t)i + 1], sc = density12[3 * (size_t)i + 2];
     const m3 rt = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
     const f3 B = mk3(r[0], r[1], r[2]);
     const float* m = &r[4];
