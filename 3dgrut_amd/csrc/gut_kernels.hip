@@ -445,10 +445,10 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
     }
     // Entries of one particle land contiguously at [off, max_off); their order inside the range is irrelevant: the tile
     // sort that follows is stable per tile and each (tile, particle) pair occurs once.  Small boxes: four particles at a
-    // time, one per 16-lane row; large boxes: one particle at a time across the wave (same split as the counting pass).
+    // time, one per 16-lane row; boxes up to 8x4 / 4x8: two at a time, one per half wave; large boxes: one particle at a
+    // time across the wave (same split as the counting pass).
     const TileConic tc = tile_conic(co);
     const bool has = max_off > off;
-    const int area = has ? bbox_area(bb) : 0;
     const bool small = has && bbox_fits_row(bb);
     const bool culling = P.tile_culling != 0;
     const int row_shift = lane & 48;
