@@ -69,15 +69,32 @@ TSensorState sensor_state(const float* pose_start7, const float* pose_end7) {
     for (int i = 0; i < 7; ++i) { st.startPose[i] = pose_start7[i]; st.endPose[i] = pose_end7[i]; }
     return st;
 }
-TSensorModel pinhole(const float* prm) {
+// camera parameter block as in ref_camera.cpp / ref_projector.cpp: prm[0..32]
+TSensorModel sensor_model(int model, int shutter, const float* prm) {
     TSensorModel m;
-    m.shutterType = TSensorModel::GlobalShutter;
-    m.modelType = TSensorModel::OpenCVPinholeModel;
-    auto& q = m.ocvPinholeParams;
-    q.principalPoint = tcnn::vec2(prm[0], prm[1]); q.focalLength = tcnn::vec2(prm[2], prm[3]);
-    for (int i = 0; i < 6; ++i) q.radialCoeffs[i] = 0.f;
-    q.tangentialCoeffs = tcnn::vec2(0.f, 0.f);
-    q.thinPrismCoeffs = tcnn::vec4(0.f, 0.f, 0.f, 0.f);
+    m.shutterType = (TSensorModel::ShutterType)shutter;
+    if (model == 0) {
+        m.modelType = TSensorModel::OpenCVPinholeModel;
+        auto& q = m.ocvPinholeParams;
+        q.principalPoint = tcnn::vec2(prm[0], prm[1]); q.focalLength = tcnn::vec2(prm[2], prm[3]);
+        for (int i = 0; i < 6; ++i) q.radialCoeffs[i] = prm[4 + i];
+        q.tangentialCoeffs = tcnn::vec2(prm[10], prm[11]);
+        q.thinPrismCoeffs = tcnn::vec4(prm[12], prm[13], prm[14], prm[15]);
+    } else if (model == 1) {
+        m.modelType = TSensorModel::OpenCVFisheyeModel;
+        auto& q = m.ocvFisheyeParams;
+        q.principalPoint = tcnn::vec2(prm[0], prm[1]); q.focalLength = tcnn::vec2(prm[2], prm[3]);
+        q.radialCoeffs = tcnn::vec4(prm[4], prm[5], prm[6], prm[7]);
+        q.maxAngle = prm[16];
+    } else {
+        m.modelType = TSensorModel::FThetaModel;
+        auto& q = m.fthetaParams;
+        q.principalPoint = tcnn::vec2(prm[0], prm[1]);
+        q.referencePoly = prm[17] != 0.f ? FThetaProjectionParameters::ANGLE_TO_PIXELDIST : FThetaProjectionParameters::PIXELDIST_TO_ANGLE;
+        for (int i = 0; i < 6; ++i) { q.pixeldistToAnglePoly[i] = prm[18 + i]; q.angleToPixeldistPoly[i] = prm[24 + i]; }
+        q.maxAngle = prm[16];
+        for (int i = 0; i < 3; ++i) q.linear_cde[i] = prm[30 + i];
+    }
     return m;
 }
 struct GlobalValues { int32_t pad; int32_t sh_degree; };   // FeatureShDegreeValueOffset = 4 bytes (threedgut.cuh:29)
@@ -97,11 +114,11 @@ extern "C" {
 int ref_gut_k_buffer_size(void) { return GAUSSIAN_K_BUFFER_SIZE; }
 int ref_gut_kernel_degree(void) { return GAUSSIAN_PARTICLE_KERNEL_DEGREE; }
 
-// projectOnTiles with the launch geometry of gutRenderer.cu:258-288 (pinhole, global shutter).  prm = {cx, cy, fx, fy}.
-void ref_gut_project(int width, int height, const float* prm, const float* pose_start7, const float* pose_end7, uint32_t n,
+// projectOnTiles with the launch geometry of gutRenderer.cu:258-288; any camera model / shutter type (prm as in ref_camera.cpp)
+void ref_gut_project(int model, int shutter, int width, int height, const float* prm, const float* pose_start7, const float* pose_end7, uint32_t n,
                      const float* density12, const float* sph, int sh_degree, uint32_t* tiles_count, float* proj_pos, float* conic_opacity,
                      float* extent, float* depth, float* features, int* visibility) {
-    const TSensorModel m = pinhole(prm);
+    const TSensorModel m = sensor_model(model, shutter, prm);
     const TSensorState st = sensor_state(pose_start7, pose_end7);
     const tcnn::uvec2 tileGrid((uint32_t)(width + 15) / 16, (uint32_t)(height + 15) / 16);
     const TSensorPose sensorPose = interpolatedSensorPose(st.startPose, st.endPose, 0.5f);

@@ -344,6 +344,20 @@ GUT_RENDER_SCENES = [
 ]
 
 
+# non-pinhole cameras and rolling shutters through the same kernels (tests/scenes.make_camera_scene)
+GUT_RENDER_CAMERA_SCENES = [("fisheye", dict(n=1200, w=64, h=48)), ("pinhole_rs", dict(n=1200, w=64, h=48)), ("ftheta", dict(n=1200, w=64, h=48))]
+
+
+def camera_prm(cam):
+    """The 33-float camera parameter block of oracle/ref/ref_camera.cpp from a GrutCamera (inverse of test_oracle_cpu._golden_camera)."""
+    prm = np.zeros(33, F)
+    prm[0:2], prm[2:4] = list(cam.principal_point), list(cam.focal_length)
+    prm[4:10], prm[10:12], prm[12:16] = list(cam.radial), list(cam.tangential), list(cam.thin_prism)
+    prm[16], prm[17] = cam.max_angle, float(cam.ftheta_reference_poly)
+    prm[18:24], prm[24:30], prm[30:33] = list(cam.ftheta_pixeldist_to_angle), list(cam.ftheta_angle_to_pixeldist), list(cam.ftheta_linear_cde)
+    return prm
+
+
 def gut_render_upstream(h, w, seed=23):
     r = np.random.default_rng(seed)
     return r.normal(size=(h, w, 4)).astype(F), (r.normal(size=(h, w, 1)) * 0.1).astype(F)
@@ -360,12 +374,12 @@ def gut_reference_frame(sc, k_buffer=0, backward=True):
     d12, sph = np.ascontiguousarray(sc["density12"], F), np.ascontiguousarray(sc["sph"], F)
     n = len(d12)
     cam = sc["cam"]
-    prm = np.array([cam.principal_point[0], cam.principal_point[1], cam.focal_length[0], cam.focal_length[1]], F)
+    prm = camera_prm(cam)
     ps, pe = np.asarray(sc["pose_start"], F), np.asarray(sc["pose_end"], F)
     ro, rd = (np.ascontiguousarray(a, F).reshape(H, W, 3) for a in sc["rays"])
     o = dict(tiles_count=np.zeros(n, np.uint32), proj_pos=np.zeros((n, 2), F), conic_opacity=np.zeros((n, 4), F), extent=np.zeros((n, 2), F),
              depth=np.zeros(n, F), features=np.zeros((n, 3), F), visibility=np.zeros(n, np.int32))
-    lib.ref_gut_project(W, H, _p(prm), _p(ps), _p(pe), C.c_uint32(n), _p(d12), _p(sph), 3, _p(o["tiles_count"]), _p(o["proj_pos"]),
+    lib.ref_gut_project(int(cam.model), int(cam.shutter), W, H, _p(prm), _p(ps), _p(pe), C.c_uint32(n), _p(d12), _p(sph), 3, _p(o["tiles_count"]), _p(o["proj_pos"]),
                         _p(o["conic_opacity"]), _p(o["extent"]), _p(o["depth"]), _p(o["features"]), _p(o["visibility"]))
     offsets = np.cumsum(o["tiles_count"], dtype=np.uint64).astype(np.uint32)
     total = int(offsets[-1])
@@ -378,6 +392,8 @@ def gut_reference_frame(sc, k_buffer=0, backward=True):
     tile_of = (keys[order] >> np.uint64(32)).astype(np.int64)     # computeSortedTileRangeIndices, gutRenderer.cu:368-373
     o["tile_ranges"] = np.stack([np.searchsorted(tile_of, np.arange(tiles), "left"),
                                  np.searchsorted(tile_of, np.arange(tiles), "right")], 1).astype(np.uint32)
+    # tiles without entries are not written by the kernel and keep the zeros of the freshly sized buffer (gutRenderer.cu:160-161)
+    o["tile_ranges"][o["tile_ranges"][:, 0] == o["tile_ranges"][:, 1]] = 0
     lo, hi = np.full(3, -1e6, F), np.full(3, 1e6, F)             # the scene box SplatRaster::trace passes, splatRaster.cpp:240
     o["feat_density"], o["hit_distance"], o["hit_count"] = np.zeros((H, W, 4), F), np.full((H, W, 1), 1e6, F), np.zeros((H, W, 1), F)
     common = (W, H, _p(ps), _p(pe), _p(lo), _p(hi), C.c_uint32(n), _p(d12), _p(sph), 3, _p(o["tile_ranges"]), _p(o["sorted_idx"]),
@@ -414,7 +430,10 @@ def gut_standin_check(lib, n=4000, seed=9):
 def make_gut_render():
     """tests/golden/gut_render.npz: the reference's projectOnTiles / render / renderBackward kernels, with the real particle class,
     tile loop, hit k-buffer and ray payload code under them, run on the host (oracle/ref/ref_gut_render.cpp) — every binning
-    product, the rendered outputs for K = 0 and K = 16, and the K = 0 gradients renderBackward accumulates."""
+    product, the rendered outputs for K = 0 and K = 16, and the K = 0 gradients renderBackward accumulates; then K = 0 frames
+    through the fisheye, distorted rolling-shutter pinhole and f-theta cameras.  (One field is not reproducible between runs
+    of this script: the visibility flag of a particle whose unscented projection failed is computed by the reference from an
+    uninitialised covariance, gutProjector.cuh:246-275; the tests only use it where it is defined.)"""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from scenes import make_scene
@@ -431,6 +450,14 @@ def make_gut_render():
             out[f"s{k}_k16_{name}"] = o16[name]
         print(f"scene {k}: {int(o['tiles_count'].sum())} tile entries, opacity {o['feat_density'][..., 3].mean():.3f}, "
               f"hits/ray {o['hit_count'].mean():.1f}, |K16 - K0| {np.abs(o16['feat_density'] - o['feat_density']).max():.3g}")
+    from scenes import make_camera_scene
+    for kind, kw in GUT_RENDER_CAMERA_SCENES:
+        sc = make_camera_scene(kind, **kw)
+        sc["W"], sc["H"] = kw["w"], kw["h"]
+        o = gut_reference_frame(sc, 0)
+        for name, a in o.items():
+            out[f"{kind}_{name}"] = a
+        print(f"camera scene {kind}: {int(o['tiles_count'].sum())} tile entries, opacity {o['feat_density'][..., 3].mean():.3f}")
     np.savez_compressed(os.path.join(HERE, "gut_render.npz"), **out)
     print("wrote gut_render.npz; stand-in vs CUDA twin:", err, acc_standin, acc_twin)
 

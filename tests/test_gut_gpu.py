@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle
-from scenes import make_scene, rel_err, torch_batch
+from scenes import make_camera_scene as _camera_scene, make_scene, rel_err, torch_batch
 
 pytestmark = pytest.mark.gpu
 syn = importlib.import_module("3dgrut_amd.synthetic")
@@ -216,46 +216,6 @@ def test_per_pixel_ray_origins_match_oracle():
         ora = _run_oracle(scene, g_fd, g_dist if gd_in is not None else np.zeros_like(g_dist))
         _image_checks(gpu["out"], ora["fwd"])
         _check_grads(scene, gpu, ora, g_fd, g_dist if gd_in is not None else np.zeros_like(g_dist))
-
-
-def _camera_scene(kind, n=4000, w=96, h=64):
-    """Scenes for the non-trivial camera models of cameraProjections.cuh: rays are generated by numerically inverting
-    nothing — the projection only drives binning (which particles land in which tile); compositing uses the rays given.
-    So any consistent ray field works; the fisheye one is the exact inverse, the others reuse pinhole rays."""
-    scene = make_scene(n=n, width=w, height=h, median_scale=0.06)
-    b = scene["batch"]
-    K = b.pop("intrinsics")
-    fx, fy, cx, cy = K
-    if kind == "fisheye":
-        Kf = syn.fisheye_intrinsics(w, h, fov_deg=120.0)
-        Kf["radial_coeffs"] = np.array([0.02, -0.01, 0.003, 0.0], np.float32)
-        b["intrinsics_OpenCVFisheyeCameraModelParameters"] = Kf
-        Kz = dict(Kf, radial_coeffs=np.zeros(4, np.float32))
-        ro, rd = syn.fisheye_rays(w, h, Kz)
-        b["rays_ori"], b["rays_dir"] = ro, rd
-        scene["rays"] = (ro, rd)
-    elif kind == "pinhole_rs":
-        b["intrinsics_OpenCVPinholeCameraModelParameters"] = dict(
-            resolution=np.array([w, h], np.uint32), shutter_type="ROLLING_TOP_TO_BOTTOM", principal_point=np.array([cx, cy], np.float32),
-            focal_length=np.array([fx, fy], np.float32), radial_coeffs=np.array([0.05, -0.02, 0.0, 0.01, 0.0, 0.0], np.float32),
-            tangential_coeffs=np.array([0.002, -0.001], np.float32), thin_prism_coeffs=np.array([0.001, 0.0, -0.001, 0.0], np.float32))
-        end = b["T_to_world"][0].copy()
-        end[:3, 3] += np.array([0.05, -0.03, 0.02], np.float32)   # camera moves during the exposure
-        b["T_to_world_end"] = end[None]
-    elif kind == "ftheta":
-        # equidistant model expressed as an f-theta polynomial: angle = pixeldist / f
-        f = fx
-        b["intrinsics_FThetaCameraModelParameters"] = dict(
-            resolution=np.array([w, h], np.uint32), shutter_type="ROLLING_LEFT_TO_RIGHT", principal_point=np.array([cx, cy], np.float32),
-            reference_poly="PIXELDIST_TO_ANGLE", pixeldist_to_angle_poly=np.array([0.0, 1.0 / f, 0.0, 1e-9, 0.0, 0.0], np.float32),
-            angle_to_pixeldist_poly=np.array([0.0, f, 0.0, 0.0, 0.0, 0.0], np.float32), max_angle=1.2,
-            linear_cde=np.array([1.0, 0.0, 0.0], np.float32))
-        end = b["T_to_world"][0].copy()
-        end[:3, 3] += np.array([-0.04, 0.02, 0.0], np.float32)
-        b["T_to_world_end"] = end[None]
-    cam_mod = importlib.import_module("3dgrut_amd.camera")
-    scene["cam"], scene["pose_start"], scene["pose_end"] = cam_mod.camera_from_batch(b)
-    return scene
 
 
 def torch_batch_rs(batch, device):
