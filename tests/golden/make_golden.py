@@ -363,13 +363,13 @@ def gut_render_upstream(h, w, seed=23):
     return r.normal(size=(h, w, 4)).astype(F), (r.normal(size=(h, w, 1)) * 0.1).astype(F)
 
 
-def gut_reference_frame(sc, k_buffer=0, backward=True):
+def gut_reference_frame(sc, k_buffer=0, backward=True, degree=2):
     """Runs the reference's kernels (oracle/_ref/libref_gut_render_deg2_k{K}.so) on a tests/scenes.make_scene() scene, following the
     launch sequence of GUTRenderer::renderForward / renderBackward (gutRenderer.cu:258-413, 472-505): projectOnTiles, inclusive scan,
     expandTileProjections, stable sort by key, tile ranges, render, renderBackward."""
-    lib = C.CDLL(os.path.join(REF, f"libref_gut_render_deg2_k{k_buffer}.so"))
+    lib = C.CDLL(os.path.join(REF, f"libref_gut_render_deg{degree}_k{k_buffer}.so"))
     plib = C.CDLL(os.path.join(REF, "libref_projector.so"))   # expandTileProjections (touches no particle data)
-    assert lib.ref_gut_k_buffer_size() == k_buffer
+    assert lib.ref_gut_k_buffer_size() == k_buffer and lib.ref_gut_kernel_degree() == degree
     W, H = sc["W"], sc["H"]
     d12, sph = np.ascontiguousarray(sc["density12"], F), np.ascontiguousarray(sc["sph"], F)
     n = len(d12)
@@ -450,6 +450,14 @@ def make_gut_render():
             out[f"s{k}_k16_{name}"] = o16[name]
         print(f"scene {k}: {int(o['tiles_count'].sum())} tile entries, opacity {o['feat_density'][..., 3].mean():.3f}, "
               f"hits/ray {o['hit_count'].mean():.1f}, |K16 - K0| {np.abs(o16['feat_density'] - o['feat_density']).max():.3g}")
+    # the quartic kernel (particle_kernel_degree 4) on the first scene; its stand-in is cross-checked like the quadratic one
+    err4, a4, b4 = gut_standin_check(C.CDLL(os.path.join(REF, "libref_gut_render_deg4_k0.so")))
+    assert a4 == b4 and 1000 < b4 < 3500 and err4 < 2e-6, (err4, a4, b4)
+    out["standin_check_deg4"] = np.array([err4, a4, b4], np.float64)
+    o = gut_reference_frame(make_scene(**GUT_RENDER_SCENES[0]), 0, degree=4)
+    for name, a in o.items():
+        out[f"deg4_{name}"] = a
+    print(f"degree 4: {int(o['tiles_count'].sum())} tile entries, opacity {o['feat_density'][..., 3].mean():.3f}, stand-in {err4:.2g}")
     from scenes import make_camera_scene
     for kind, kw in GUT_RENDER_CAMERA_SCENES:
         sc = make_camera_scene(kind, **kw)

@@ -546,3 +546,37 @@ def test_gut_frame_camera_models_match_reference_kernels_golden(kind):
     for name, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
         assert rel_err(gd[:, sl], ref_gd[:, sl]) < 2e-5, f"{kind}: grad {name} {rel_err(gd[:, sl], ref_gd[:, sl]):.2e}"
     assert rel_err(grgb, ref_grgb) < 2e-5
+
+
+def test_gut_frame_quartic_kernel_matches_reference_kernels_golden():
+    """The same frame pipeline with particle_kernel_degree = 4 (the reference's kernels built with
+    GAUSSIAN_PARTICLE_KERNEL_DEGREE=4): images, hit counts and renderBackward gradients."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = np.load(os.path.join(HERE, "golden", "gut_render.npz"))
+    err, a, b = g["standin_check_deg4"]
+    assert err < 2e-6 and a == b > 1000
+    kw = make_golden.GUT_RENDER_SCENES[0]
+    sc = make_scene(**kw)
+    H, W = kw["height"], kw["width"]
+    cfg = oracle.default_gut_config(enable_hitcounts=1, particle_kernel_degree=4)
+    o = oracle.gut_forward(cfg, sc["cam"], sc["pose_start"], sc["pose_end"], 3, sc["density12"], sc["sph"], *sc["rays"])
+    assert np.array_equal(o["proj"]["tiles_count"], g["deg4_tiles_count"]) and np.array_equal(o["bins"]["sorted_idx"], g["deg4_sorted_idx"])
+    assert np.abs(o["feat_density"] - g["deg4_feat_density"]).max() < 2e-6
+    assert np.abs(o["hit_distance"] - g["deg4_hit_distance"]).max() <= 2e-6 * max(1.0, np.abs(g["deg4_hit_distance"]).max())
+    assert np.array_equal(o["hit_count"], g["deg4_hit_count"])
+    assert np.abs(g["deg4_feat_density"] - g["s0_feat_density"]).max() > 0.02      # really a different kernel
+    F = np.float32
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    n = len(sc["density12"])
+    gfd, gdist = make_golden.gut_render_upstream(H, W)
+    gd, grgb = np.zeros((n, 12), F), np.zeros((n, 3), F)
+    ps, pe = np.asarray(sc["pose_start"], F), np.asarray(sc["pose_end"], F)
+    ro, rd = (np.ascontiguousarray(x, F).reshape(H, W, 3) for x in sc["rays"])
+    d12 = np.ascontiguousarray(sc["density12"], F)
+    assert oracle.lib(F).orc_gut_render_bwd(C.byref(cfg), W, H, p(ps), p(pe), p(d12), p(g["deg4_features"]), p(g["deg4_sorted_idx"]),
+                                            p(g["deg4_tile_ranges"]), p(ro), p(rd), p(g["deg4_feat_density"]), p(gfd), p(g["deg4_hit_distance"]),
+                                            p(gdist), p(gd), p(grgb)) == 0
+    for name, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
+        assert rel_err(gd[:, sl], g["deg4_grad_density"][:, sl]) < 2e-5, name
+    assert rel_err(grgb, g["deg4_grad_features"]) < 2e-5
