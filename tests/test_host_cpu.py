@@ -1,0 +1,143 @@
+"""CPU: the host side of the plugin boundary — pose / camera marshalling, configuration parsing, the drop-in package names,
+and the refusal to run without the HIP path (reference behaviour cited per test)."""
+import importlib
+import os
+import subprocess
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+camera = importlib.import_module("3dgrut_amd.camera")
+abi = importlib.import_module("3dgrut_amd._abi")
+syn = importlib.import_module("3dgrut_amd.synthetic")
+
+
+def _rot_from_xyzw(q):
+    x, y, z, w = [float(v) for v in q]
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def test_pose_marshalling_inverts_the_camera_to_world_matrix():
+    """tracer.py:413-423, 359-380: the plugin ships inv(T_to_world) as [t, q(x,y,z,w)]; every branch of the matrix -> quaternion
+    conversion (largest of the three diagonal entries / trace, tracer.py:88-136) is exercised by rotations about each axis."""
+    rng = np.random.default_rng(4)
+    cases = [syn.orbit_pose(i, n_views=7) for i in range(7)]
+    for axis in range(3):          # half turns about x, y, z: the trace is -1 and a diagonal entry wins
+        R = -np.eye(3)
+        R[axis, axis] = 1.0
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = rng.normal(size=3)
+        cases.append(T)
+    for _ in range(20):
+        A = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        if np.linalg.det(A) < 0:
+            A[:, 0] = -A[:, 0]
+        T = np.eye(4)
+        T[:3, :3] = A
+        T[:3, 3] = rng.normal(size=3) * 3
+        cases.append(T)
+    for T in cases:
+        tq = camera.world_to_sensor_tquat(np.asarray(T, np.float32))
+        assert tq.dtype == np.float32 and tq.shape == (7,)
+        w2c = np.linalg.inv(np.asarray(T, np.float64))
+        assert abs(np.linalg.norm(tq[3:]) - 1.0) < 1e-6
+        assert np.abs(_rot_from_xyzw(tq[3:]) - w2c[:3, :3]).max() < 2e-6
+        assert np.abs(tq[:3] - w2c[:3, 3]).max() < 1e-5
+
+
+def _batch(**kw):
+    H, W = 6, 8
+    base = dict(rays_ori=np.zeros((1, H, W, 3), np.float32), rays_dir=np.zeros((1, H, W, 3), np.float32), T_to_world=syn.orbit_pose(2)[None])
+    base.update(kw)
+    return base
+
+
+def test_plain_intrinsics_become_a_centred_pinhole():
+    """tracer.py:426-444: [fx, fy, cx, cy] -> OpenCV pinhole, resolution (int(2cx), int(2cy)), principal point at its centre,
+    focal lengths through the field of view, zero distortion, global shutter; start and end pose identical."""
+    cam, ps, pe = camera.camera_from_batch(_batch(intrinsics=[100.0, 110.0, 40.3, 30.2]))
+    assert cam.model == abi.CAMERA_OPENCV_PINHOLE and cam.shutter == abi.SHUTTER_GLOBAL
+    assert (cam.width, cam.height) == (80, 60)
+    assert list(cam.principal_point) == [40.0, 30.0]
+    assert abs(cam.focal_length[0] - 100.0) < 1e-4 and abs(cam.focal_length[1] - 110.0) < 1e-4
+    assert not any(cam.radial) and not any(cam.tangential) and not any(cam.thin_prism)
+    assert np.array_equal(ps, pe)
+    # dict and attribute batches are the same thing to the plugin
+    cam2, ps2, _ = camera.camera_from_batch(SimpleNamespace(**_batch(intrinsics=[100.0, 110.0, 40.3, 30.2])))
+    assert bytes(cam2) == bytes(cam) and np.array_equal(ps, ps2)
+
+
+def test_camera_model_dicts_and_rolling_shutter_poses():
+    """tracer.py:446-488: the three *CameraModelParameters dicts; shutter types by name or enum; T_to_world_end gives the end pose."""
+    end = syn.orbit_pose(3)[None]
+    pin = dict(resolution=np.array([64, 48], np.uint32), shutter_type="ROLLING_BOTTOM_TO_TOP", principal_point=np.array([31.0, 23.5], np.float32),
+               focal_length=np.array([70.0, 71.0], np.float32), radial_coeffs=np.arange(6, dtype=np.float32) * 0.01,
+               tangential_coeffs=np.array([0.001, -0.002], np.float32), thin_prism_coeffs=np.array([1e-3, 2e-3, 3e-3, 4e-3], np.float32))
+    cam, ps, pe = camera.camera_from_batch(_batch(intrinsics_OpenCVPinholeCameraModelParameters=pin, T_to_world_end=end))
+    assert cam.model == abi.CAMERA_OPENCV_PINHOLE and cam.shutter == abi.SHUTTER_ROLLING_BOTTOM_TO_TOP and (cam.width, cam.height) == (64, 48)
+    assert np.allclose(list(cam.radial), pin["radial_coeffs"]) and np.allclose(list(cam.thin_prism), pin["thin_prism_coeffs"])
+    assert not np.array_equal(ps, pe) and np.array_equal(pe, camera.world_to_sensor_tquat(end[0]))
+    fish = dict(resolution=np.array([64, 48], np.uint32), shutter_type=SimpleNamespace(name="GLOBAL"), principal_point=np.array([32.0, 24.0], np.float32),
+                focal_length=np.array([30.0, 30.0], np.float32), radial_coeffs=np.array([0.1, 0.01, 0.0, 0.0], np.float32), max_angle=1.3)
+    cam, _, _ = camera.camera_from_batch(_batch(intrinsics_OpenCVFisheyeCameraModelParameters=fish))
+    assert cam.model == abi.CAMERA_OPENCV_FISHEYE and cam.shutter == abi.SHUTTER_GLOBAL and abs(cam.max_angle - 1.3) < 1e-6
+    assert np.allclose(list(cam.radial)[:4], fish["radial_coeffs"]) and list(cam.radial)[4:] == [0.0, 0.0]
+    ft = dict(resolution=np.array([64, 48], np.uint32), shutter_type="ROLLING_RIGHT_TO_LEFT", principal_point=np.array([32.0, 24.0], np.float32),
+              reference_poly="ANGLE_TO_PIXELDIST", pixeldist_to_angle_poly=np.array([0, 0.02, 0, 0, 0, 0], np.float32),
+              angle_to_pixeldist_poly=np.array([0, 50.0, 0, 0, 0, 0], np.float32), max_angle=1.1, linear_cde=np.array([1.0, 0.0, 0.0], np.float32))
+    cam, _, _ = camera.camera_from_batch(_batch(intrinsics_FThetaCameraModelParameters=ft))
+    assert cam.model == abi.CAMERA_FTHETA and cam.shutter == abi.SHUTTER_ROLLING_RIGHT_TO_LEFT
+    assert cam.ftheta_reference_poly == abi.FTHETA_ANGLE_TO_PIXELDIST and list(cam.ftheta_linear_cde) == [1.0, 0.0, 0.0]
+    with pytest.raises(ValueError):          # tracer.py:486-488: no camera model in the batch
+        camera.camera_from_batch(_batch())
+    # rays already in world space: identity sensor poses (tracer.py:395-411)
+    _, ps, pe = camera.camera_from_batch(_batch(intrinsics=[50.0, 50.0, 4.0, 3.0], rays_in_world_space=True))
+    assert list(ps) == [0, 0, 0, 0, 0, 0, 1] and list(pe) == [0, 0, 0, 0, 0, 0, 1]
+
+
+def test_configuration_defaults_and_overrides():
+    """conf.render.* -> GutConfig: an empty conf gives the values of configs/render/3dgut.yaml (+ 3dgrt.yaml it inherits from);
+    dict and attribute configs are equivalent; unsupported settings raise instead of silently diverging."""
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    cfg = gt.gut_config_from_conf({"render": {"splat": {}}})
+    assert cfg.particle_kernel_degree == 2 and abs(cfg.particle_kernel_min_response - 0.0113) < 1e-9
+    assert abs(cfg.particle_kernel_min_alpha - 1.0 / 255.0) < 1e-9 and abs(cfg.particle_kernel_max_alpha - 0.99) < 1e-7
+    assert abs(cfg.min_transmittance - 1e-4) < 1e-10 and cfg.particle_radiance_sph_degree == 3
+    assert (cfg.ut_alpha, cfg.ut_beta, cfg.ut_kappa) == (1.0, 2.0, 0.0) and abs(cfg.ut_in_image_margin_factor - 0.1) < 1e-8
+    assert cfg.n_rolling_shutter_iterations == 5 and cfg.k_buffer_size == 0
+    assert cfg.global_z_order == cfg.rect_bounding == cfg.tight_opacity_bounding == cfg.tile_based_culling == 1
+    over = {"render": {"particle_kernel_degree": 4, "min_transmittance": 0.01, "splat": {"k_buffer_size": 16, "tile_based_culling": False}}}
+    a = gt.gut_config_from_conf(over)
+    ns = SimpleNamespace(render=SimpleNamespace(particle_kernel_degree=4, min_transmittance=0.01,
+                                                splat=SimpleNamespace(k_buffer_size=16, tile_based_culling=False)))
+    b = gt.gut_config_from_conf(ns)
+    assert bytes(a) == bytes(b) and a.particle_kernel_degree == 4 and a.k_buffer_size == 16 and a.tile_based_culling == 0
+    with pytest.raises(NotImplementedError):
+        gt.gut_config_from_conf({"render": {"particle_feature_half": True, "splat": {}}})
+    assert gt.fused_activations_requested({"render": {"fused_activations": True}}) and not gt.fused_activations_requested({"render": {}})
+
+
+def test_tracers_refuse_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU")
+    for mod, conf in (("3dgrut_amd.gut_tracer", {"render": {"splat": {}}}), ("3dgrut_amd.grt_tracer", {"render": {}})):
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            importlib.import_module(mod).Tracer(conf)
+
+
+def test_drop_in_package_names_resolve_to_the_plugins():
+    """model.py:23,25 `import threedgrt_tracer` / `import threedgut_tracer`, each exporting `Tracer` (their __init__.py:15-17):
+    with <repo>/shims first on PYTHONPATH those names bind to this repository's classes."""
+    code = ("import threedgut_tracer, threedgrt_tracer; "
+            "print(threedgut_tracer.Tracer.__module__, threedgrt_tracer.Tracer.__module__, threedgut_tracer.__all__, threedgrt_tracer.__all__)")
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "shims"))
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd="/tmp").decode().split()
+    assert out[0] == "3dgrut_amd.gut_tracer" and out[1] == "3dgrut_amd.grt_tracer"
+    assert "Tracer" in out[2] and "Tracer" in out[3]
