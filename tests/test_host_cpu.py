@@ -141,3 +141,17 @@ def test_drop_in_package_names_resolve_to_the_plugins():
     out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd="/tmp").decode().split()
     assert out[0] == "3dgrut_amd.gut_tracer" and out[1] == "3dgrut_amd.grt_tracer"
     assert "Tracer" in out[2] and "Tracer" in out[3]
+
+
+def test_grt_configuration_defaults_and_unsupported_pipelines():
+    """conf.render.* -> GrtConfig with the values of configs/render/3dgrt.yaml; pipelines / proxy primitives other than the
+    reference's defaults (`reference`, `instances`) raise rather than render something else."""
+    grt = importlib.import_module("3dgrut_amd.grt_tracer")
+    cfg = grt.grt_config_from_conf({"render": {}})
+    assert cfg.particle_kernel_degree == 4 and abs(cfg.particle_kernel_min_response - 0.0113) < 1e-9
+    assert abs(cfg.particle_kernel_max_alpha - 0.99) < 1e-7 and cfg.particle_kernel_density_clamping == 1
+    assert cfg.particle_radiance_sph_degree == 3 and cfg.max_hits_per_trace == 16
+    assert grt.grt_config_from_conf({"render": {"particle_kernel_degree": 2}}).particle_kernel_degree == 2
+    for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "icosahedron"}, {"particle_feature_half": True}):
+        with pytest.raises(NotImplementedError):
+            grt.grt_config_from_conf({"render": bad})
