@@ -119,6 +119,18 @@ static T shuffle(T v, int src_lane_of_me(int lane, int arg), int arg) {
 static inline void __syncthreads() { emu::arrive_and_wait(emu::g_block, 1); }
 static inline int __syncthreads_and(int pred) { return emu::arrive_and_wait(emu::g_block, pred); }
 static inline int __all_sync(unsigned, int pred) { return emu::arrive_and_wait(emu::g_warps[emu::self().warp], pred); }
+static inline unsigned __ballot_sync(unsigned, int pred) {   // one staging round: every lane posts its bit, then reads all 32
+    const unsigned mine = pred ? 1u : 0u;
+    emu::Fiber& f = emu::self();
+    emu::Group& w = emu::g_warps[f.warp];
+    uint32_t* buf = w.slots[f.shuffle_count++ & 1u];
+    buf[f.lane] = mine;
+    emu::arrive_and_wait(w, 1);
+    unsigned m = 0;
+    for (int l = 0; l < warpSize; ++l) m |= (buf[l] & 1u) << l;
+    return m;
+}
+static inline int __ffs(unsigned v) { return v ? __builtin_ctz(v) + 1 : 0; }
 template <class T> static inline T __shfl_xor_sync(unsigned, T v, int mask) {
     return emu::shuffle<T>(v, [](int lane, int m) { return lane ^ m; }, mask);
 }

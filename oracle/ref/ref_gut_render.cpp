@@ -40,7 +40,9 @@
 #define GAUSSIAN_ENABLE_HIT_COUNT true
 #define GAUSSIAN_N_ROLLING_SHUTTER_ITERATIONS 5
 #define GAUSSIAN_GLOBAL_Z_ORDER true
+#ifndef FINE_GRAINED_LOAD_BALANCING   // true in the K = 0 builds: adds renderBalanced next to render (Makefile)
 #define FINE_GRAINED_LOAD_BALANCING false
+#endif
 #define GAUSSIAN_UT_ALPHA 1.0f
 #define GAUSSIAN_UT_BETA 2.0f
 #define GAUSSIAN_UT_KAPPA 0.0f
@@ -155,6 +157,33 @@ void ref_gut_render_fwd(int width, int height, const float* pose_start7, const f
                nullptr, nullptr, nullptr, features, handles);
     });
 }
+
+#if FINE_GRAINED_LOAD_BALANCING
+// renderBalanced (gutRenderer.cu:380-397): the reference's other forward, `render.splat.fine_grained_load_balancing: true` —
+// one 32-lane warp per pixel, 2x2-pixel virtual tiles, warp-level prefix products instead of the sequential loop
+void ref_gut_render_fwd_balanced(int width, int height, const float* pose_start7, const float* pose_end7, const float* aabb_min3,
+                                 const float* aabb_max3, uint32_t n, const float* density12, const float* sph, int sh_degree,
+                                 const uint32_t* tile_ranges, const uint32_t* sorted_idx, const float* features, const float* ray_o,
+                                 const float* ray_d, float* out_feat_density, float* out_hit_distance, float* out_hit_count) {
+    RenderParameters params;
+    params.id = 0;
+    params.resolution = tcnn::ivec2(width, height);
+    params.hitTransmittance = 0.f;
+    params.objectAABB.min = tcnn::vec3(aabb_min3[0], aabb_min3[1], aabb_min3[2]);
+    params.objectAABB.max = tcnn::vec3(aabb_max3[0], aabb_max3[1], aabb_max3[2]);
+    params.sensorState = sensor_state(pose_start7, pose_end7);
+    const TSensorPose sensorPose = interpolatedSensorPose(params.sensorState.startPose, params.sensorState.endPose, 0.5f);
+    const TSensorPose sensorPoseInv = sensorPoseInverse(sensorPose);
+    GlobalValues gv = {0, sh_degree};
+    const uint64_t handles[3] = {(uint64_t)&gv, (uint64_t)density12, (uint64_t)sph};
+    const tcnn::uvec2 tileGrid((uint32_t)(width + 15) / 16, (uint32_t)(height + 15) / 16);
+    launch(tileGrid.x * tileGrid.y * GUTParameters::Tiling::VirtualTilesPerTile, 1, GUTParameters::Tiling::FineGrainedThreadsPerBlock, 1, [&] {
+        renderBalanced(params, reinterpret_cast<const tcnn::uvec2*>(tile_ranges), sorted_idx, reinterpret_cast<const tcnn::vec3*>(ray_o),
+                       reinterpret_cast<const tcnn::vec3*>(ray_d), sensorPoseToMat(sensorPoseInv), out_hit_count, out_hit_distance,
+                       out_feat_density, nullptr, nullptr, nullptr, features, handles, tileGrid);
+    });
+}
+#endif
 
 // renderBackward (gutRenderer.cu:472-505): g_density12 [n,12] and g_features [n,3] must arrive zeroed (gutRenderer.cu:458-466)
 void ref_gut_render_bwd(int width, int height, const float* pose_start7, const float* pose_end7, const float* aabb_min3, const float* aabb_max3,

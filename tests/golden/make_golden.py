@@ -363,7 +363,7 @@ def gut_render_upstream(h, w, seed=23):
     return r.normal(size=(h, w, 4)).astype(F), (r.normal(size=(h, w, 1)) * 0.1).astype(F)
 
 
-def gut_reference_frame(sc, k_buffer=0, backward=True, degree=2):
+def gut_reference_frame(sc, k_buffer=0, backward=True, degree=2, balanced=False):
     """Runs the reference's kernels (oracle/_ref/libref_gut_render_deg2_k{K}.so) on a tests/scenes.make_scene() scene, following the
     launch sequence of GUTRenderer::renderForward / renderBackward (gutRenderer.cu:258-413, 472-505): projectOnTiles, inclusive scan,
     expandTileProjections, stable sort by key, tile ranges, render, renderBackward."""
@@ -399,6 +399,10 @@ def gut_reference_frame(sc, k_buffer=0, backward=True, degree=2):
     common = (W, H, _p(ps), _p(pe), _p(lo), _p(hi), C.c_uint32(n), _p(d12), _p(sph), 3, _p(o["tile_ranges"]), _p(o["sorted_idx"]),
               _p(o["features"]), _p(ro), _p(rd))
     lib.ref_gut_render_fwd(*common, _p(o["feat_density"]), _p(o["hit_distance"]), _p(o["hit_count"]))
+    if balanced:   # the reference's other forward kernel (render.splat.fine_grained_load_balancing), K = 0 builds only
+        o["balanced_feat_density"], o["balanced_hit_distance"] = np.zeros((H, W, 4), F), np.full((H, W, 1), 1e6, F)
+        o["balanced_hit_count"] = np.zeros((H, W, 1), F)
+        lib.ref_gut_render_fwd_balanced(*common, _p(o["balanced_feat_density"]), _p(o["balanced_hit_distance"]), _p(o["balanced_hit_count"]))
     if backward:
         assert k_buffer == 0, "the K > 0 backward is Slang autodiff output (not in the checkout)"
         gfd, gdist = gut_render_upstream(H, W)
@@ -442,9 +446,12 @@ def make_gut_render():
     out = dict(standin_check=np.array([err, acc_standin, acc_twin], np.float64))
     for k, kw in enumerate(GUT_RENDER_SCENES):
         sc = make_scene(**kw)
-        o = gut_reference_frame(sc, 0)
+        o = gut_reference_frame(sc, 0, balanced=True)
         for name, a in o.items():
             out[f"s{k}_{name}"] = a
+        print(f"scene {k}: |renderBalanced - render| rgb/opacity {np.abs(o['balanced_feat_density'] - o['feat_density']).max():.3g}, "
+              f"distance {np.abs(o['balanced_hit_distance'] - o['hit_distance']).max():.3g}, "
+              f"hit counts differ on {int((o['balanced_hit_count'] != o['hit_count']).sum())} pixels")
         o16 = gut_reference_frame(sc, 16, backward=False)
         for name in ("feat_density", "hit_distance", "hit_count"):
             out[f"s{k}_k16_{name}"] = o16[name]
