@@ -455,6 +455,10 @@ def make_gut_render():
         o16 = gut_reference_frame(sc, 16, backward=False)
         for name in ("feat_density", "hit_distance", "hit_count"):
             out[f"s{k}_k16_{name}"] = o16[name]
+        for kk in (4, 8):   # the other two buffer sizes the plugin dispatches
+            ok = gut_reference_frame(sc, kk, backward=False)
+            for name in ("feat_density", "hit_distance", "hit_count"):
+                out[f"s{k}_k{kk}_{name}"] = ok[name]
         print(f"scene {k}: {int(o['tiles_count'].sum())} tile entries, opacity {o['feat_density'][..., 3].mean():.3f}, "
               f"hits/ray {o['hit_count'].mean():.1f}, |K16 - K0| {np.abs(o16['feat_density'] - o['feat_density']).max():.3g}")
     # the quartic kernel (particle_kernel_degree 4) on the first scene; its stand-in is cross-checked like the quadratic one

@@ -500,6 +500,12 @@ def test_gut_frame_matches_reference_kernels_golden():
         assert np.abs(o16["hit_distance"] - g[f"s{k}_k16_hit_distance"]).max() <= 2e-6 * max(1.0, np.abs(g[f"s{k}_k16_hit_distance"]).max())
         assert np.array_equal(o16["hit_count"], g[f"s{k}_k16_hit_count"])
         assert np.abs(g[f"s{k}_k16_feat_density"] - g[f"s{k}_feat_density"]).max() > 0.05   # the sorted image really is a different image
+        for kk in (4, 8):
+            ok = oracle.gut_forward(oracle.default_gut_config(enable_hitcounts=1, k_buffer_size=kk), sc["cam"], sc["pose_start"], sc["pose_end"], 3,
+                                    sc["density12"], sc["sph"], *sc["rays"])
+            assert np.abs(ok["feat_density"] - g[f"s{k}_k{kk}_feat_density"]).max() < 2e-6, kk
+            assert np.abs(ok["hit_distance"] - g[f"s{k}_k{kk}_hit_distance"]).max() <= 2e-6 * max(1.0, np.abs(g[f"s{k}_k{kk}_hit_distance"]).max())
+            assert np.array_equal(ok["hit_count"], g[f"s{k}_k{kk}_hit_count"])
 
 
 @pytest.mark.parametrize("kind", ["fisheye", "pinhole_rs", "ftheta"])
