@@ -759,6 +759,38 @@ int orc_gut_render_fwd(const GutConfig* cfg, int width, int height, const real* 
     return 0;
 }
 
+/* Analysis aid (scripts/slab_analysis.py): per pixel, how many entries of its tile list the K = 0 forward loop examines
+ * before the ray ends (the whole list if it never does).  Same loop as orc_gut_render_fwd. */
+int orc_gut_render_fwd_consumed(const GutConfig* cfg, int width, int height, const real* pose_start7, const real* pose_end7,
+                                const real* density12, const uint32_t* sorted_idx, const uint32_t* tile_ranges, const real* ray_o,
+                                const real* ray_d, uint32_t* out_consumed) {
+    const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
+    const int gx = tile_grid_dim(width);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int pix = 0; pix < width * height; ++pix) {
+        const int x = pix % width, y = pix / width;
+        const orc_ray ray = init_ray(&fp, ray_o + 3 * (size_t)pix, ray_d + 3 * (size_t)pix);
+        out_consumed[pix] = 0;
+        if (!ray.valid) continue;
+        const uint32_t tile = (uint32_t)((y / ORC_TILE) * gx + (x / ORC_TILE));
+        const uint32_t beg = tile_ranges[2 * tile], end = tile_ranges[2 * tile + 1];
+        real T = 1;
+        uint32_t e = beg;
+        for (; e < end; ++e) {
+            const uint32_t idx = sorted_idx[e];
+            if (idx == ORC_INVALID_IDX) break;
+            const orc_particle p = load_particle(density12 + 12 * (size_t)idx);
+            real alpha, hitT;
+            if (density_hit(cfg, ray.o, ray.d, &p, &alpha, &hitT) && hitT > ray.tmin && hitT < ray.tmax) {
+                T *= (1 - alpha);
+                if (T < (real)cfg->min_transmittance) { ++e; break; }
+            }
+        }
+        out_consumed[pix] = e - beg;
+    }
+    return 0;
+}
+
 /* --------------------------------------------------------------------------------------
  * render backward (K=0, SH branch) — gutKBufferRenderer.cuh:642-716, rayPayloadBackward.cuh:30-73
  * g_density12 [N,12] and g_rgb [N,3] are accumulated into (must arrive zeroed).
