@@ -151,6 +151,13 @@ __device__ __forceinline__ f3 operator*(f3 a, f3 b) { return f3{a.x * b.x, a.y *
 __device__ __forceinline__ f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ f3 operator*(float s, f3 a) { return f3{a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+// Separately rounded fp32 multiply / add.  The library is built with -ffp-contract=fast, under which the backend fuses a*b+c
+// regardless of pragmas; quantities whose BITS matter (sort keys) go through these so that they never contract.
+__device__ __forceinline__ float mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float add_rn(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// the same with a wave-uniform first operand kept in a scalar register (no VGPR copy of the uniform)
+__device__ __forceinline__ float mul_rn_u(float uniform, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(b)); return r; }
+__device__ __forceinline__ float add_rn_u(float uniform, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(b)); return r; }
 __device__ __forceinline__ f3 cross(f3 a, f3 b) {
     return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
@@ -255,6 +262,18 @@ __device__ __forceinline__ float wave_reduce_scatter16(const float (&v)[16], int
     z += __shfl_xor(z, 16, 64);
     z += __shfl_xor(z, 32, 64);
     return z;
+}
+
+// gfx950's lane-swap instructions finish the reduction on the VALU (no LDS crossbar round trip): v_permlane32_swap exchanges the
+// upper half of one register with the lower half of another, v_permlane16_swap the odd rows of one with the even rows of the
+// other; applied to two copies of the same value, the sum of the pair is (lane + lane ^ 32) resp. (lane + lane ^ 16).
+__device__ __forceinline__ float wave_reduce_scatter16_all(const float (&v)[16], int lane) {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    const float z = wave_reduce_scatter16_rows(v, lane);
+    const v2u a = __builtin_amdgcn_permlane32_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+    const float s = __uint_as_float(a.x) + __uint_as_float(a.y);
+    const v2u b = __builtin_amdgcn_permlane16_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b.x) + __uint_as_float(b.y);   // every lane: wave total of term (lane & 15)
 }
 
 // ---- packed fp32: two pixels per lane ---------------------------------------------------------

@@ -22,8 +22,21 @@ struct GrtHandle {
     EventTimer fwd_timer, bwd_timer, build_timer;
     DeviceBuffer log_pool, log_table, log_nbwd, log_state;  // forward hit log (grt_internal.hpp: GrtHitLog)
     GrtHitLog log = {nullptr, nullptr, nullptr, nullptr, 0, 0};
-    bool log_valid = false;        // the last forward recorded a log for exactly this frame geometry
+    bool log_valid = false;        // the last forward recorded a log ...
     int log_W = 0, log_H = 0;
+    // ... of exactly this forward: the backward replays the log only if it is handed the very buffers and frame the logging
+    // forward saw (two train-mode forwards may precede their backwards — gradient accumulation, multi-view losses; the
+    // reference re-traverses in its backward, so any order works there).  The packed particle buffer is a fresh allocation per
+    // forward that the caller keeps alive until the backward, which makes its address a per-forward token.
+    const void* log_density = nullptr;
+    const void* log_ray_o = nullptr;
+    const void* log_ray_d = nullptr;
+    GrtFrame log_frame;
+    bool log_matches(const GrtFrame& f, const void* density, const void* ray_o, const void* ray_d) const {
+        return log_valid && log_W == f.width && log_H == f.height && log_density == density && log_ray_o == ray_o && log_ray_d == ray_d &&
+               log_frame.frame_id == f.frame_id && log_frame.sph_degree == f.sph_degree && log_frame.min_transmittance == f.min_transmittance &&
+               memcmp(log_frame.ray_to_world, f.ray_to_world, sizeof(f.ray_to_world)) == 0;
+    }
     uint32_t* log_state_host = nullptr;  // pinned copy of {chunks used, overflow} of the last logged forward
     hipEvent_t log_event = nullptr;
     bool log_event_pending = false;
@@ -213,6 +226,10 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
         h->log_valid = true;
         h->log_W = P.W;
         h->log_H = P.H;
+        h->log_density = particle_density;
+        h->log_ray_o = ray_origin;
+        h->log_ray_d = ray_direction;
+        h->log_frame = *frame;
     }
     unsigned long long* counters = nullptr;
     if (getenv("GRUT_GRT_COUNT")) {  // development aid: work statistics of the traversal, read back by grt_stats
@@ -274,7 +291,8 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
     const GrtTraceParams P = trace_params(h, *frame);
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
     GrtHitLog log = {nullptr, nullptr, nullptr, nullptr, 0, 0};
-    if (h->log_valid && h->log_W == P.W && h->log_H == P.H) log = h->log;  // replay the hits the forward of this frame processed
+    // replay the hits the forward of THIS frame processed; any other backward (an older forward's, see log_matches) traverses again
+    if (h->log_matches(*frame, particle_density, ray_origin, ray_direction)) log = h->log;
     grt_launch_trace_bwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, features, density, hit_distance,
                          grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph, log);
     GRUT_HIP(hipGetLastError());

@@ -41,6 +41,14 @@ struct GutHandle {
     // forward context consumed by backward (role of GutRenderForwardContext)
     bool have_forward = false;
     hipStream_t fwd_stream = nullptr;
+    // identity of the forward the context belongs to: the backward must be handed the same frame and the very buffers that
+    // forward saw (the packed particle buffer is a fresh allocation per forward that the caller keeps alive until the backward,
+    // so its address is a per-forward token).  The reference keeps ONE context too (gutRenderer.cu:436-440) and silently
+    // differentiates the wrong frame when two forwards precede their backwards; here that is an error.
+    const void* fwd_density = nullptr;
+    const void* fwd_ray_o = nullptr;
+    const void* fwd_ray_d = nullptr;
+    uint32_t fwd_frame_id = 0;
     GutParams params;
     uint32_t num_intersections = 0;
     uint32_t tile_capacity = 0;  // entries the per-intersection scratch can hold (0 until the first frame sized it)
@@ -245,6 +253,10 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     h->stats.key_bits = bits_for(tiles);
     h->num_intersections = 0;
     h->fwd_stream = s;
+    h->fwd_density = particle_density;
+    h->fwd_ray_o = ray_origin;
+    h->fwd_ray_d = ray_direction;
+    h->fwd_frame_id = frame->frame_id;
     if (N == 0) {  // nothing to render: outputs keep their initial values
         h->have_forward = true;
         return GRUT_OK;
@@ -369,6 +381,11 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
     }
     const GutParams& P = h->params;
     GRUT_REQUIRE(frame->num_particles == P.N && frame->width == P.W && frame->height == P.H, "gut_backward: frame differs from the forward frame");
+    if (frame->frame_id != h->fwd_frame_id || (P.N > 0 && (particle_density != h->fwd_density || ray_origin != h->fwd_ray_o || ray_direction != h->fwd_ray_d))) {
+        set_last_error("gut_backward: the forward context belongs to another forward (a later gut_forward ran on this handle before this "
+                       "backward); run each backward before the next forward, or use one handle per in-flight frame");
+        return GRUT_ERR_NOT_READY;
+    }
     if (P.N == 0) return GRUT_OK;
     GRUT_REQUIRE(particle_density && particle_sph && feat_density && grad_feat_density && hit_distance && grad_particle_density &&
                      (grad_particle_sph || grad_radiance), "gut_backward: null buffer");  // grad_hit_distance may be NULL (no depth gradient)

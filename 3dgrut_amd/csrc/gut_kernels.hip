@@ -246,7 +246,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         pos = mk3(a.x, a.y, a.z);
         const float opacity = a.w;
 
-        const float view_z = fmaf(FP.view_R[6], pos.x, fmaf(FP.view_R[7], pos.y, fmaf(FP.view_R[8], pos.z, FP.view_t[2])));
+        // The depth is the sort key: its BITS define the per-tile compositing order, so it is evaluated with separately rounded
+        // multiplies and adds in the reference's source order, dot(R.row2, pos) + t.z (gutProjector.cuh:131-140, 315-321) — never
+        // contracted into FMAs, whatever -ffp-contract says — and the CPU checker reproduces every key bit for bit.
+        const float view_z = add_rn_u(FP.view_t[2], add_rn(add_rn(mul_rn_u(FP.view_R[6], pos.x), mul_rn_u(FP.view_R[7], pos.y)), mul_rn_u(FP.view_R[8], pos.z)));
         view_z_keep = view_z;
         bool ok = (opacity >= P.min_alpha) && (view_z >= 0.2f);
         if (ok) {
@@ -364,7 +367,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             out.depth_key[i] = 0xFFFFFFFFu;  // sorts behind every visible particle
         } else {
             const f3 ray = pos - mk3(FP.s2w_t[0], FP.s2w_t[1], FP.s2w_t[2]);
-            const float dist = sqrtf(dot(ray, ray));
+            // (also a sort key, with global_z_order off: same rule)
+            const float dist = __fsqrt_rn(add_rn(add_rn(mul_rn(ray.x, ray.x), mul_rn(ray.y, ray.y)), mul_rn(ray.z, ray.z)));
             const f3 dir = ray * (1.f / dist);
             float basis[16];
             sh_basis(P.n_active, dir, basis);

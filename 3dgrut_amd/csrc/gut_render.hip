@@ -22,6 +22,14 @@
 //     scale and position gradients are contracted from (B, M) once per flush, not per pixel.
 #include "gut_internal.hpp"
 
+// tuning switches of the gradient sweep (scripts/build_variant.sh -D...)
+#ifndef GRUT_BWD_FULL_REDUCE
+#define GRUT_BWD_FULL_REDUCE 1
+#endif
+#ifndef GRUT_BWD_WAVES
+#define GRUT_BWD_WAVES 4   // waves per SIMD the register allocator is held to (0: its own choice, 130 VGPRs = 3 waves); measured r02b:
+#endif                     // rows / 3 waves 0.917 ms, rows / 4 waves 0.910, lane-swap reduce / 3 waves 0.936, lane-swap reduce / 4 waves 0.891
+
 namespace grut {
 
 namespace {
@@ -478,9 +486,20 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
                 for (int k = 0; k < 16; ++k) extra[k] = 0.f;
                 extra[0] = sXm.x.x + sXm.x.y; extra[1] = sXm.y.x + sXm.y.y; extra[2] = sXm.z.x + sXm.z.y;
             }
+#if GRUT_BWD_FULL_REDUCE
+            // every lane ends with the wave total of term l & 15 (in-row DPP butterfly, then two lane-swap steps across the rows);
+            // one row of 16 lanes parks the totals of the entry in LDS for the flush
+            const float tot = wave_reduce_scatter16_all(terms, lane);
+            if (lane < 16) s_acc[j * 16 + lane] = tot;
+            if (HAS_GDIST) {
+                const float tot2 = wave_reduce_scatter16_all(extra, lane);
+                if (lane < 16) s_acc2[j * 16 + lane] = tot2;
+            }
+#else
             // lane l ends with the sum over its 16-lane row of term l & 15; the four rows are added by the flush
             s_acc[j * 64 + lane] = wave_reduce_scatter16_rows(terms, lane);
             if (HAS_GDIST) s_acc2[j * 64 + lane] = wave_reduce_scatter16_rows(extra, lane);
+#endif
             T = nextT;
             iT = inextT_raw;
             alive0 = alive0 && !(T.x < P.min_transmittance);
@@ -491,6 +510,10 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
         if (lane < (int)kBatch && ((hit_entries >> lane) & 1u)) {
             const float4* rec = &s_rec[lane * kRecQuads];
             const uint32_t pos = __float_as_uint(rec[5].w);
+#if GRUT_BWD_FULL_REDUCE
+            const float4* acc = reinterpret_cast<const float4*>(&s_acc[lane * 16]);
+            float4 a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+#else
             const float4* acc = reinterpret_cast<const float4*>(&s_acc[lane * 64]);
             float4 a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
 #pragma unroll
@@ -499,6 +522,7 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
                 a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w; a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
                 a2.x += b2.x; a2.y += b2.y; a2.z += b2.z; a2.w += b2.w; a3.x += b3.x; a3.y += b3.y; a3.z += b3.z; a3.w += b3.w;
             }
+#endif
             if (!HAS_GDIST && UNI) {  // complete M = (sum B) (x) (o - mu) - sum (t B) (x) d
                 const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                 const f3 dl = rp.origin - mk3(r0.w, r1.w, r2.w);
@@ -511,7 +535,11 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
             out[0] = a0; out[1] = a1; out[2] = a2; out[3] = a3;
             if (HAS_GDIST) {
                 float ex = 0.f, ey = 0.f, ez = 0.f;
+#if GRUT_BWD_FULL_REDUCE
+                ex = s_acc2[lane * 16]; ey = s_acc2[lane * 16 + 1]; ez = s_acc2[lane * 16 + 2];
+#else
                 for (int r = 0; r < 4; ++r) { ex += s_acc2[lane * 64 + 16 * r]; ey += s_acc2[lane * 64 + 16 * r + 1]; ez += s_acc2[lane * 64 + 16 * r + 2]; }
+#endif
                 out[4] = make_float4(ex, ey, ez, 0.f);
             }
             slots.flag[slot] = 1;
@@ -522,7 +550,12 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
 }
 
 template <int DEG, bool HAS_GDIST>
-__global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+#if GRUT_BWD_WAVES   // the depth-gradient variant (not the training path) needs ~160 registers: it keeps its 3 waves per SIMD
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_GDIST ? 3 : GRUT_BWD_WAVES, HAS_GDIST ? 3 : GRUT_BWD_WAVES))) void gut_render_bwd_kernel(
+#else
+__global__ __launch_bounds__(64) void gut_render_bwd_kernel(
+#endif
+                                                            GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                             const float4* __restrict__ fd, const float4* __restrict__ g_fd,
@@ -530,8 +563,13 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(GutParams P, const u
                                                             GutGradSlots slots, GutCheckpoints ck) {
     constexpr uint32_t kBatch = kBwdBatch;
     __shared__ float4 s_rec[kBatch * kRecQuads];
+#if GRUT_BWD_FULL_REDUCE
+    __shared__ float s_acc[kBatch * 16];                       // per staged entry: the wave totals of its 16 terms
+    __shared__ float s_acc2[HAS_GDIST ? kBatch * 16 : 1];      // depth-gradient extras (3 terms used)
+#else
     __shared__ float s_acc[kBatch * 64];                       // per staged entry: 16 terms x 4 row partials
     __shared__ float s_acc2[HAS_GDIST ? kBatch * 64 : 1];      // depth-gradient extras (3 terms used)
+#endif
     // task = (virtual tile, half).  Virtual tiles [0, bndPad) are the segments that start at segment boundary b (sorted
     // index b * kGutSegment): they are the long, dense tasks and are dispatched first so that the tail of the launch
     // is made of the short first segments of each tile list, virtual tiles [bndPad, bndPad + tiles).

@@ -247,7 +247,7 @@ extern "C" int grut_selective_adam_update(void* stream, const GrutAdamGroup* gro
     GRUT_REQUIRE(visibility_kind >= GRUT_VIS_NONE && visibility_kind <= GRUT_VIS_FLOAT_BITS, "grut_selective_adam_update: visibility_kind %d", visibility_kind);
     GRUT_REQUIRE(visibility_kind == GRUT_VIS_NONE || visibility || num_rows == 0, "grut_selective_adam_update: visibility is NULL");
     if (num_rows == 0) return GRUT_OK;  // optimizers.cu:87-89
-    for (int first = 0; first < num_groups; first += kAdamMaxGroups) {
+    for (int first = 0; first < num_groups;) {  // `first` resumes where the previous batch stopped consuming (empty groups do not count)
         AdamLaunch L{};
         L.rows = num_rows;
         L.visibility = visibility;
@@ -255,7 +255,8 @@ extern "C" int grut_selective_adam_update(void* stream, const GrutAdamGroup* gro
         L.vis_mask = visibility_kind == GRUT_VIS_NONE ? 0u : visibility_kind == GRUT_VIS_BOOL_U8 ? 0xFFu
                    : visibility_kind == GRUT_VIS_FLOAT_BITS ? 0x7FFFFFFFu : 0xFFFFFFFFu;
         uint64_t blocks = 0;
-        for (int i = first; i < num_groups && L.num_groups < kAdamMaxGroups; ++i) {
+        int i = first;
+        for (; i < num_groups && L.num_groups < kAdamMaxGroups; ++i) {
             const GrutAdamGroup& g = groups[i];
             if (g.row_width == 0) continue;
             GRUT_REQUIRE(g.param && g.grad && g.exp_avg && g.exp_avg_sq, "grut_selective_adam_update: group %d has a NULL tensor", i);
@@ -268,6 +269,7 @@ extern "C" int grut_selective_adam_update(void* stream, const GrutAdamGroup* gro
             L.block_end[L.num_groups] = (uint32_t)blocks;
             ++L.num_groups;
         }
+        first = i;
         if (L.num_groups == 0) continue;
         hipLaunchKernelGGL(selective_adam_kernel, dim3((uint32_t)blocks), dim3(kAdamThreads), 0, reinterpret_cast<hipStream_t>(stream), L);
         GRUT_HIP(hipGetLastError());

@@ -64,8 +64,8 @@ class FactoredGradientExchange:
     At 8 ranks a ring moves 2*(7/8)*236 = 413 B per particle for the plain all-reduce, 2*(7/8)*48 + (7/8)*8*12 = 168 B this
     way.  Views are added in rank order on every rank, so replicas stay bitwise identical, like after an all-reduce."""
 
-    def __init__(self, average: bool = False, group=None, local_gradient_hook=None):
-        self.average = average
+    def __init__(self, average: bool = True, group=None, local_gradient_hook=None):
+        self.average = average  # mean over views, like GradientExchange and the module docstring (keeps the single-view loss scale)
         self.group = group
         # called with this view's packed gradient [N,12] (columns 0..2 = dL/d position) BEFORE it is reduced: the place to take
         # the densification statistics, which must come from the local view (local_densify_stats)

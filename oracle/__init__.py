@@ -110,12 +110,21 @@ def gut_bin(cfg, width, height, proj, dtype=np.float32):
     return dict(num_intersections=total, sorted_keys=keys[:total], sorted_idx=idx[:total], tile_ranges=ranges)
 
 
-def gut_forward(cfg, cam, pose_start, pose_end, n_active, density12, sph, ray_o, ray_d, dtype=np.float32):
-    """Full reference forward (SplatRaster::trace semantics incl. output initial values)."""
+def gut_forward(cfg, cam, pose_start, pose_end, n_active, density12, sph, ray_o, ray_d, dtype=np.float32, proj=None, lists=None):
+    """Full reference forward (SplatRaster::trace semantics incl. output initial values).
+
+    `proj` reuses an earlier projection; `lists` = (sorted_idx u32[I], tile_ranges u32[tiles,2]) composites GIVEN per-tile
+    lists instead of the oracle's own binning (the full-size parity tests render the oracle on the lists the GPU built, so
+    that the compositing stage is compared on identical hit candidates and the binning stage separately, integer by integer)."""
     l = lib(dtype)
     H, W = cam.height, cam.width
-    proj = gut_project(cfg, cam, pose_start, pose_end, n_active, density12, sph, dtype)
-    bins = gut_bin(cfg, W, H, proj, dtype)
+    if proj is None:
+        proj = gut_project(cfg, cam, pose_start, pose_end, n_active, density12, sph, dtype)
+    if lists is None:
+        bins = gut_bin(cfg, W, H, proj, dtype)
+    else:
+        sidx, rng = np.ascontiguousarray(lists[0], np.uint32), np.ascontiguousarray(lists[1], np.uint32)
+        bins = dict(num_intersections=int(sidx.shape[0]), sorted_keys=None, sorted_idx=sidx, tile_ranges=rng)
     fd = np.zeros((H, W, 4), dtype)
     dist = np.full((H, W, 1), 1e6, dtype)
     cnt = np.zeros((H, W, 1), dtype)
@@ -298,3 +307,33 @@ def kat_pose_interpolate(a7, b7, t, dtype=np.float32):
     out = np.zeros(7, dtype)
     lib(dtype).orc_kat_pose_interpolate(_p(_c(a7, dtype)), _p(_c(b7, dtype)), _real(dtype)(t), _p(out))
     return out
+
+
+def gut_pixel_margins(cfg, cam, fwd, pixel_ids, rel_margin=2e-3, dtype=np.float32):
+    """Number of evaluated tile entries of each listed pixel (flat index y*W+x) that lie within `rel_margin` of an accept /
+    termination threshold (orc_gut_pixel_margins) — on the lists and rays of the forward `fwd`."""
+    l, R = lib(dtype), _real(dtype)
+    ids = np.ascontiguousarray(pixel_ids, np.uint32)
+    out = np.zeros(ids.shape[0], np.uint32)
+    ps, pe = fwd["poses"]
+    ro, rd = fwd["rays"]
+    if ids.size:
+        r = l.orc_gut_pixel_margins(C.byref(cfg), C.c_int(cam.width), C.c_int(cam.height), _p(ps), _p(pe), _p(fwd["density12"]),
+                                    _p(fwd["bins"]["sorted_idx"]), _p(fwd["bins"]["tile_ranges"]), _p(ro), _p(rd), C.c_uint32(ids.shape[0]), _p(ids),
+                                    R(rel_margin), _p(out))
+        assert r == 0
+    return out
+
+
+def gut_pixel_trace(cfg, cam, fwd, pixel, cap=4096, dtype=np.float32):
+    """Per-entry trace of one pixel's tile list (orc_gut_pixel_trace): particle ids, compositing alpha, hit distance, signed
+    relative margin of the accept test (accepted iff > 0) — for every entry of the tile, without early termination."""
+    l = lib(dtype)
+    idx = np.zeros(cap, np.uint32)
+    alpha, hit_t, margin = np.zeros(cap, dtype), np.zeros(cap, dtype), np.zeros(cap, dtype)
+    ps, pe = fwd["poses"]
+    ro, rd = fwd["rays"]
+    n = l.orc_gut_pixel_trace(C.byref(cfg), C.c_int(cam.width), C.c_int(cam.height), _p(ps), _p(pe), _p(fwd["density12"]),
+                              _p(fwd["bins"]["sorted_idx"]), _p(fwd["bins"]["tile_ranges"]), _p(ro), _p(rd), C.c_uint32(int(pixel)),
+                              C.c_uint32(cap), _p(idx), _p(alpha), _p(hit_t), _p(margin))
+    return dict(idx=idx[:n], alpha=alpha[:n], hit_t=hit_t[:n], margin=margin[:n])

@@ -385,6 +385,10 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
     if (K > GRT_MAX_K) return -1;
     const int ncoef = (cfg->particle_radiance_sph_degree + 1) * (cfg->particle_radiance_sph_degree + 1);
     const real eps = R_(1e-9);
+    /* per-hit gradients in `real`, SUMMED in double: the reference's float atomics add in a run-dependent order; the checker
+     * does not reproduce one sample of that rounding noise (same rule as gut_oracle.c: orc_gut_render_bwd) */
+    double* acc_d = (double*)calloc((size_t)N * 12 + 1, sizeof(double));
+    double* acc_s = (double*)calloc((size_t)N * 3 * ncoef + 1, sizeof(double));
 #pragma omp parallel
     {
         grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
@@ -417,12 +421,12 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
                     for (int c = 0; c < 11; ++c)
                         if (gd[c] != 0) {
 #pragma omp atomic
-                            g_density12[12 * (size_t)id + c] += gd[c];
+                            acc_d[12 * (size_t)id + c] += (double)gd[c];
                         }
                     for (int c = 0; c < 3 * ncoef; ++c)
                         if (gs[c] != 0) {
 #pragma omp atomic
-                            g_sph[(size_t)id * 3 * ncoef + c] += gs[c];
+                            acc_s[(size_t)id * 3 * ncoef + c] += (double)gs[c];
                         }
                     startT = r_max(startT, buf[i].t);
                 }
@@ -430,5 +434,8 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
         }
         free(cands);
     }
+    for (size_t k = 0; k < (size_t)N * 12; ++k) g_density12[k] += (real)acc_d[k];
+    for (size_t k = 0; k < (size_t)N * 3 * ncoef; ++k) g_sph[k] += (real)acc_s[k];
+    free(acc_d); free(acc_s);
     return 0;
 }

@@ -245,6 +245,7 @@ int orc_gut_project(const GutConfig* cfg, const GrutCamera* cam, const real* pos
     const real w0c = lambda / (D + lambda) + (1 - alpha_ut * alpha_ut + beta_ut); /* :201 */
     const real margin = (real)cfg->ut_in_image_margin_factor;
 
+#pragma omp parallel for schedule(static, 256)   /* particles are independent */
     for (uint32_t i = 0; i < N; ++i) {
         const real* pd = density12 + 12 * (size_t)i;
         const v3 pos = v3_make(pd[0], pd[1], pd[2]);
@@ -427,7 +428,12 @@ static orc_particle load_particle(const real* pd) {
 }
 
 /* gaussianParticles.slang:207-242 hit(): returns accept; alpha, hitT(depth) */
+static int density_hit_ex(const GutConfig* cfg, v3 ro, v3 rd, const orc_particle* p, real* alpha, real* hitT, real* resp_out);
 static int density_hit(const GutConfig* cfg, v3 ro, v3 rd, const orc_particle* p, real* alpha, real* hitT) {
+    real resp;
+    return density_hit_ex(cfg, ro, rd, p, alpha, hitT, &resp);
+}
+static int density_hit_ex(const GutConfig* cfg, v3 ro, v3 rd, const orc_particle* p, real* alpha, real* hitT, real* resp_out) {
     const v3 giscl = v3_make(1 / p->scl.x, 1 / p->scl.y, 1 / p->scl.z);
     const v3 gposc = v3_sub(ro, p->pos);
     const v3 gposcr = v3_mul_rows(gposc, &p->rotT);
@@ -438,6 +444,7 @@ static int density_hit(const GutConfig* cfg, v3 ro, v3 rd, const orc_particle* p
     const v3 gcrod = v3_cross(grd, gro);
     const real gray = v3_dot(gcrod, gcrod);
     const real resp = particle_response(cfg->particle_kernel_degree, gray);
+    *resp_out = resp;
     *alpha = r_min((real)cfg->particle_kernel_max_alpha, resp * p->density);
     const int accept = (resp > (real)cfg->particle_kernel_min_response) && (*alpha > (real)cfg->particle_kernel_min_alpha);
     if (accept) { /* :181-190 canonicalRayIntersection */
@@ -791,10 +798,101 @@ int orc_gut_render_fwd_consumed(const GutConfig* cfg, int width, int height, con
     return 0;
 }
 
+/* Threshold analysis for the full-size parity tests (tests/parity_util.py).  For each listed pixel the K = 0 forward loop is
+ * replayed and the evaluated entries that lie within a relative margin of one of the algorithm's discontinuities are counted:
+ * response vs min_response, alpha vs min_alpha, the running transmittance vs min_transmittance.  A pixel with fewer than two
+ * such entries cannot have had two opposite accept / reject flips, i.e. cannot differ with an unchanged hit count. */
+int orc_gut_pixel_margins(const GutConfig* cfg, int width, int height, const real* pose_start7, const real* pose_end7,
+                          const real* density12, const uint32_t* sorted_idx, const uint32_t* tile_ranges, const real* ray_o,
+                          const real* ray_d, uint32_t npix, const uint32_t* pix_ids, real rel_margin, uint32_t* out_borderline) {
+    const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
+    const int gx = tile_grid_dim(width);
+    const real min_resp = (real)cfg->particle_kernel_min_response, min_alpha = (real)cfg->particle_kernel_min_alpha;
+    const real min_T = (real)cfg->min_transmittance;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (uint32_t k = 0; k < npix; ++k) {
+        const int pix = (int)pix_ids[k];
+        const int x = pix % width, y = pix / width;
+        out_borderline[k] = 0;
+        const orc_ray ray = init_ray(&fp, ray_o + 3 * (size_t)pix, ray_d + 3 * (size_t)pix);
+        if (!ray.valid) continue;
+        const uint32_t tile = (uint32_t)((y / ORC_TILE) * gx + (x / ORC_TILE));
+        real T = 1;
+        uint32_t n = 0;
+        for (uint32_t e = tile_ranges[2 * tile]; e < tile_ranges[2 * tile + 1]; ++e) {
+            const uint32_t idx = sorted_idx[e];
+            if (idx == ORC_INVALID_IDX) break;
+            const orc_particle p = load_particle(density12 + 12 * (size_t)idx);
+            real alpha, hitT, resp;
+            const int acc = density_hit_ex(cfg, ray.o, ray.d, &p, &alpha, &hitT, &resp);
+            const real a_raw = resp * p.density;
+            /* the accept test is (resp > min_resp) && (alpha > min_alpha): the binding one of the two decides */
+            const real m1 = r_fabs(resp / min_resp - 1), m2 = r_fabs(a_raw / min_alpha - 1);
+            const int near_accept = (resp > min_resp * (1 - rel_margin) && a_raw > min_alpha * (1 - rel_margin)) &&
+                                    (m1 < rel_margin || m2 < rel_margin);
+            if (near_accept) n++;
+            if (acc && hitT > ray.tmin && hitT < ray.tmax) {
+                T *= (1 - alpha);
+                if (r_fabs(T / min_T - 1) < 100 * rel_margin) n++;   /* T carries the rounding of every factor before it */
+                if (T < min_T) break;
+            }
+        }
+        out_borderline[k] = n;
+    }
+    return 0;
+}
+
+/* Per-entry trace of ONE pixel's tile list for the flip identification of the full-size parity tests: for every entry of the
+ * tile (no early termination: a toggled decision may move the end) the particle, the alpha the hit would composite with
+ * (min(max_alpha, resp * density), 0 when the hit distance is outside the ray interval), the hit distance, and the signed
+ * relative margin of the accept test ( min(resp / min_response, resp * density / min_alpha) - 1 : accepted iff > 0 ).
+ * Returns the number of entries written (<= cap). */
+int orc_gut_pixel_trace(const GutConfig* cfg, int width, int height, const real* pose_start7, const real* pose_end7,
+                        const real* density12, const uint32_t* sorted_idx, const uint32_t* tile_ranges, const real* ray_o,
+                        const real* ray_d, uint32_t pix, uint32_t cap, uint32_t* out_idx, real* out_alpha, real* out_hitT, real* out_margin) {
+    const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
+    const int gx = tile_grid_dim(width);
+    const int x = (int)pix % width, y = (int)pix / width;
+    const orc_ray ray = init_ray(&fp, ray_o + 3 * (size_t)pix, ray_d + 3 * (size_t)pix);
+    if (!ray.valid) return 0;
+    const uint32_t tile = (uint32_t)((y / ORC_TILE) * gx + (x / ORC_TILE));
+    uint32_t n = 0;
+    for (uint32_t e = tile_ranges[2 * tile]; e < tile_ranges[2 * tile + 1] && n < cap; ++e) {
+        const uint32_t idx = sorted_idx[e];
+        if (idx == ORC_INVALID_IDX) break;
+        const orc_particle p = load_particle(density12 + 12 * (size_t)idx);
+        real alpha, hitT = 0, resp;
+        density_hit_ex(cfg, ray.o, ray.d, &p, &alpha, &hitT, &resp);
+        {   /* the hit distance of a rejected entry too (density_hit_ex only fills it on accept) */
+            GutConfig all = *cfg;
+            all.particle_kernel_min_response = 0; all.particle_kernel_min_alpha = -1;
+            real a2, r2;
+            density_hit_ex(&all, ray.o, ray.d, &p, &a2, &hitT, &r2);
+        }
+        const real m = r_min(resp / (real)cfg->particle_kernel_min_response, resp * p.density / (real)cfg->particle_kernel_min_alpha) - 1;
+        out_idx[n] = idx;
+        out_alpha[n] = (hitT > ray.tmin && hitT < ray.tmax) ? alpha : 0;
+        out_hitT[n] = hitT;
+        out_margin[n] = m;
+        n++;
+    }
+    return (int)n;
+}
+
 /* --------------------------------------------------------------------------------------
  * render backward (K=0, SH branch) — gutKBufferRenderer.cuh:642-716, rayPayloadBackward.cuh:30-73
  * g_density12 [N,12] and g_rgb [N,3] are accumulated into (must arrive zeroed).
  * ------------------------------------------------------------------------------------ */
+/* 1 + the largest particle index that occurs in the tile lists (the backward entry points are not told N) */
+static size_t list_particle_bound(int width, int height, const uint32_t* sorted_idx, const uint32_t* tile_ranges) {
+    const int tiles = tile_grid_dim(width) * tile_grid_dim(height);
+    size_t bound = 0;
+    for (int t = 0; t < tiles; ++t)
+        for (uint32_t e = tile_ranges[2 * t]; e < tile_ranges[2 * t + 1]; ++e)
+            if (sorted_idx[e] != ORC_INVALID_IDX && (size_t)sorted_idx[e] + 1 > bound) bound = (size_t)sorted_idx[e] + 1;
+    return bound;
+}
+
 /* evalKBuffer<Backward> (gutKBufferRenderer.cuh:273-352): the forward's k-buffer walk, each popped hit differentiated */
 static int render_bwd_kbuffer(const GutConfig* cfg, int width, int height, const real* pose_start7, const real* pose_end7,
                               const real* density12, const real* rgb, const uint32_t* sorted_idx, const uint32_t* tile_ranges,
@@ -804,6 +902,9 @@ static int render_bwd_kbuffer(const GutConfig* cfg, int width, int height, const
     const int gx = tile_grid_dim(width);
     const int K = cfg->k_buffer_size;
     if (K > ORC_MAX_K) return -1;
+    const size_t n_acc = list_particle_bound(width, height, sorted_idx, tile_ranges);   /* sums in double, see orc_gut_render_bwd */
+    double* acc_d = (double*)calloc(n_acc * 12 + 1, sizeof(double));
+    double* acc_c = (double*)calloc(n_acc * 3 + 1, sizeof(double));
 #pragma omp parallel for schedule(dynamic, 16)
     for (int pix = 0; pix < width * height; ++pix) {
         const int x = pix % width, y = pix / width;
@@ -826,8 +927,8 @@ static int render_bwd_kbuffer(const GutConfig* cfg, int width, int height, const
             const real* c = rgb + 3 * (size_t)(h).idx;                                                                      \
             real gd[12], gf[3];                                                                                             \
             process_hit_bwd_k(cfg, ray.o, ray.d, &pp, v3_make(r_max(c[0], 0), r_max(c[1], 0), r_max(c[2], 0)), (h).alpha, (h).hitT, &r, gd, gf); \
-            for (int k = 0; k < 11; ++k) if (gd[k] != 0) { _Pragma("omp atomic") g_density12[12 * (size_t)(h).idx + k] += gd[k]; }             \
-            for (int k = 0; k < 3; ++k) if (gf[k] != 0) { _Pragma("omp atomic") g_rgb[3 * (size_t)(h).idx + k] += gf[k]; }                     \
+            for (int k = 0; k < 11; ++k) if (gd[k] != 0) { _Pragma("omp atomic") acc_d[12 * (size_t)(h).idx + k] += (double)gd[k]; }           \
+            for (int k = 0; k < 3; ++k) if (gf[k] != 0) { _Pragma("omp atomic") acc_c[3 * (size_t)(h).idx + k] += (double)gf[k]; }             \
             T *= (1 - (h).alpha);                                                                                           \
             if (T < (real)cfg->min_transmittance) alive = 0;                                                                \
         } while (0)
@@ -849,6 +950,9 @@ static int render_bwd_kbuffer(const GutConfig* cfg, int width, int height, const
         for (int i = 0; alive && i < nhits; ++i) ORC_KBWD_PROCESS(kbuf[K - nhits + i]);
 #undef ORC_KBWD_PROCESS
     }
+    for (size_t k = 0; k < n_acc * 12; ++k) g_density12[k] += (real)acc_d[k];
+    for (size_t k = 0; k < n_acc * 3; ++k) g_rgb[k] += (real)acc_c[k];
+    free(acc_d); free(acc_c);
     return 0;
 }
 
@@ -862,6 +966,12 @@ int orc_gut_render_bwd(const GutConfig* cfg, int width, int height, const real* 
                                   g_dist, g_density12, g_rgb);
     const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
     const int gx = tile_grid_dim(width);
+    /* Per-hit gradients are computed in `real` (the reference's arithmetic type) but SUMMED in double: the reference adds them
+     * with float atomics in an order that changes from run to run, so its own sums carry an order-dependent rounding noise; the
+     * checker removes that noise instead of reproducing one sample of it. */
+    const size_t n_acc = list_particle_bound(width, height, sorted_idx, tile_ranges);
+    double* acc_d = (double*)calloc(n_acc * 12 + 1, sizeof(double));
+    double* acc_c = (double*)calloc(n_acc * 3 + 1, sizeof(double));
 #pragma omp parallel for schedule(dynamic, 16)
     for (int pix = 0; pix < width * height; ++pix) {
         const int x = pix % width, y = pix / width;
@@ -886,18 +996,21 @@ int orc_gut_render_bwd(const GutConfig* cfg, int width, int height, const real* 
             for (int k = 0; k < 11; ++k) {
                 if (gd[k] != 0) {
 #pragma omp atomic
-                    g_density12[12 * (size_t)idx + k] += gd[k];
+                    acc_d[12 * (size_t)idx + k] += (double)gd[k];
                 }
             }
             for (int k = 0; k < 3; ++k) {
                 if (gf[k] != 0) {
 #pragma omp atomic
-                    g_rgb[3 * (size_t)idx + k] += gf[k];
+                    acc_c[3 * (size_t)idx + k] += (double)gf[k];
                 }
             }
             if (r.T < (real)cfg->min_transmittance) break;
         }
     }
+    for (size_t k = 0; k < n_acc * 12; ++k) g_density12[k] += (real)acc_d[k];
+    for (size_t k = 0; k < n_acc * 3; ++k) g_rgb[k] += (real)acc_c[k];
+    free(acc_d); free(acc_c);
     return 0;
 }
 
