@@ -168,6 +168,12 @@ class Tracer:
         self._clamping = bool(_conf_get(render, "particle_kernel_density_clamping", True))
         self._max_updates = int(_conf_get(render, "max_consecutive_bvh_update", 15))
         self._min_transmittance = float(_conf_get(render, "min_transmittance", 0.001))
+        # render.backward_hit_replay (a key of this plugin, default true): the backward replays the hits the forward logged instead
+        # of traversing the BVH again (4x faster).  The two differ on ~0.3 % of the rays: where the end-of-ray clip of the
+        # reference's backward program (referenceBwdOptix.cu:123-128) removes a hit, every later k = 16 round boundary moves and a
+        # proxy the forward was never offered can be offered to the backward.  false = traverse again, exactly the reference's
+        # backward program (tests/parity_util.py: grt_full_parity checks both).
+        self._replay = bool(_conf_get(render, "backward_hit_replay", True))
         self.tracer_wrapper = _GrtNative(grt_config_from_conf(conf))
         self._fused_activations = fused_activations_requested(conf)
 
@@ -200,7 +206,7 @@ class Tracer:
         if feats.shape[1] != 3 * native.ncoef:
             raise ValueError(f"features have {feats.shape[1]} columns, expected {3 * native.ncoef}")
         frame = native.make_frame(frame_id, gaussians.n_active_features, self._min_transmittance, gaussians.num_gaussians, H, W, T)
-        frame.keep_hits_for_backward = int(bool(train) and torch.is_grad_enabled())
+        frame.keep_hits_for_backward = int(bool(train) and torch.is_grad_enabled() and self._replay)
         if self._fused_activations and has_standard_activations(gaussians):
             pred_features, pred_opacity, pred_dist, pred_normals, hits_count, mog_visibility = Tracer._Autograd.apply(
                 native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(), gaussians.positions.contiguous(),

@@ -238,19 +238,26 @@ def grt_forward(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, r
     return out
 
 
-def grt_backward(cfg, sph_deg, min_transmittance, fwd, g_features, g_density, g_hit_distance, dtype=np.float32):
-    """OptixTracer::trace_bwd: returns (grad_density12 [N,12], grad_sph [N,3*ncoef])."""
+def grt_backward(cfg, sph_deg, min_transmittance, fwd, g_features, g_density, g_hit_distance, dtype=np.float32, dbg_cap=0, round_shift=None):
+    """OptixTracer::trace_bwd: returns (grad_density12 [N,12], grad_sph [N,3*ncoef]); with dbg_cap > 0 additionally the particles
+    each ray's backward program processed, in order: (.., hit_ids [n, dbg_cap], hit_num [n]).  `round_shift`: optional uint8 [n]
+    output, 1 where the backward program's hit set differs from the forward's (see orc_grt_trace_bwd)."""
     l, R = lib(dtype), _real(dtype)
     d12, s = fwd["density12"], fwd["sph"]
     N = d12.shape[0]
     ro, rd = fwd["rays"]
     n = ro.shape[-3] * ro.shape[-2]
     gd, gs = np.zeros((N, 12), dtype), np.zeros_like(s)
+    dbg_ids = np.full((n, max(dbg_cap, 1)), 0xFFFFFFFF, np.uint32)
+    dbg_cnt = np.zeros(n, np.uint32)
     r = l.orc_grt_trace_bwd(C.byref(cfg), C.c_uint32(N), _p(d12), _p(s), C.c_int(sph_deg), R(min_transmittance), _p(fwd["inst"]),
                             _p(fwd["scene"]), _p(fwd["ray_to_world"]), C.c_uint32(n), _p(ro), _p(rd), _p(fwd["features"]),
                             _p(fwd["density"]), _p(fwd["hit_distance"]), _p(_c(g_features, dtype)), _p(_c(g_density, dtype)),
-                            _p(_c(g_hit_distance, dtype)), _p(gd), _p(gs))
+                            _p(_c(g_hit_distance, dtype)), _p(gd), _p(gs), _p(dbg_ids) if dbg_cap else None, _p(dbg_cnt), C.c_uint32(dbg_cap),
+                            _p(round_shift) if round_shift is not None else None)
     assert r == 0
+    if dbg_cap:
+        return gd, gs, dbg_ids, dbg_cnt
     return gd, gs
 
 

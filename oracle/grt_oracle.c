@@ -380,7 +380,8 @@ int orc_grt_trace_fwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
 int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, const real* sph, int sph_deg, real min_T,
                       const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
                       const real* ray_d, const real* rad, const real* dns, const real* hit2, const real* g_rad, const real* g_dns,
-                      const real* g_hit, real* g_density12, real* g_sph) {
+                      const real* g_hit, real* g_density12, real* g_sph, uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap,
+                      uint8_t* round_shift) {
     const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
     if (K > GRT_MAX_K) return -1;
     const int ncoef = (cfg->particle_radiance_sph_degree + 1) * (cfg->particle_radiance_sph_degree + 1);
@@ -411,11 +412,14 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
             const real endT = r_min(maxHit, tExit) + eps;
             const uint32_t n = ray_candidates(N, inst12, o, d, cands);
             grt_hit buf[GRT_MAX_K];
+            uint32_t ndbg = 0;
             while (startT < endT) {
                 const int k = trace_round(cands, n, startT + eps, endT, K, buf);
                 if (k == 0) break;
                 for (int i = 0; i < k; ++i) {
                     const uint32_t id = buf[i].id;
+                    if (dbg_ids && ndbg < dbg_cap) dbg_ids[(size_t)r * dbg_cap + ndbg] = id;
+                    ndbg++;
                     real gd[12] = {0}, gs[48] = {0};
                     process_hit_bwd(cfg, o, d, density12 + 12 * (size_t)id, sph + (size_t)id * 3 * ncoef, sph_deg, min_T, &b, gd, gs);
                     for (int c = 0; c < 11; ++c)
@@ -431,6 +435,34 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
                     startT = r_max(startT, buf[i].t);
                 }
             }
+            if (dbg_count) dbg_count[r] = ndbg;
+            if (round_shift) {
+                /* Does this program process exactly the hits the FORWARD program processed (minus the last one and minus those whose
+                 * box the ray enters after endT)?  Not necessarily: every hit that the endT clip removes lets its round take one
+                 * more candidate, which moves every later round boundary, and a candidate whose box the ray had already left at the
+                 * forward's boundary (tfar < tmin: never offered to the forward) can be offered here — or the other way round.
+                 * Flagged rays are where a backward that REPLAYS the forward's hit list differs from one that traverses again. */
+                uint32_t n_replay = 0, n_bwd = 0;
+                uint64_t h_replay = 0, h_bwd = 0;   /* order-independent set signatures */
+                real tl = r_max(0, tEnter - eps);
+                int done = 0;
+                while (!done && tl <= tExit) {
+                    const int k = trace_round(cands, n, tl + eps, tExit + eps, K, buf);
+                    if (k == 0) break;
+                    for (int i = 0; i < k && !done; ++i) {
+                        if (buf[i].t < endT && buf[i].tnear <= endT) { n_replay++; h_replay += (uint64_t)buf[i].id * 0x9E3779B97F4A7C15ull + 1; }
+                        tl = r_max(tl, buf[i].t);
+                        if (buf[i].t >= maxHit) done = 1;   /* the forward stopped at the hit it reported as its last */
+                    }
+                }
+                real st = r_max(0, tEnter - eps);
+                while (st < endT) {
+                    const int k = trace_round(cands, n, st + eps, endT, K, buf);
+                    if (k == 0) break;
+                    for (int i = 0; i < k; ++i) { n_bwd++; h_bwd += (uint64_t)buf[i].id * 0x9E3779B97F4A7C15ull + 1; st = r_max(st, buf[i].t); }
+                }
+                round_shift[r] = (uint8_t)((n_replay != n_bwd) || (h_replay != h_bwd));
+            }
         }
         free(cands);
     }
@@ -438,4 +470,18 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
     for (size_t k = 0; k < (size_t)N * 3 * ncoef; ++k) g_sph[k] += (real)acc_s[k];
     free(acc_d); free(acc_s);
     return 0;
+}
+
+/* Debug / analysis aid: the full candidate list of ONE ray, sorted by (t, id) — what every round of the forward and the
+ * backward selects from.  ray in ray space; returns the number of candidates written (<= cap). */
+int orc_grt_ray_candidates(uint32_t N, const real* inst12, const real* ray_to_world12, const real* ray_o3, const real* ray_d3, uint32_t cap,
+                           uint32_t* out_id, real* out_t, real* out_tnear, real* out_tfar) {
+    const v3 o = xform_point(ray_to_world12, v3_make(ray_o3[0], ray_o3[1], ray_o3[2]));
+    const v3 d = xform_dir(ray_to_world12, v3_make(ray_d3[0], ray_d3[1], ray_d3[2]));
+    grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+    const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+    uint32_t k = 0;
+    for (; k < n && k < cap; ++k) { out_id[k] = cands[k].id; out_t[k] = cands[k].t; out_tnear[k] = cands[k].tnear; out_tfar[k] = cands[k].tfar; }
+    free(cands);
+    return (int)k;
 }

@@ -68,6 +68,16 @@ for name, sl in pu.GRAD_SLICES.items():
     print(name, "rel err", float(err[:, sl].max() / np.abs(rdg[:, sl]).max()))
 worst = int(np.argmax((err / scale).max(1)))
 print("worst particle", worst, "hip", gd[worst, :11], "oracle", rdg[worst, :11], "density12", d12[worst])
+# the same backward through the traversal fallback instead of the hit-log replay
+os.environ["GRUT_GRT_LOG_CHUNKS"] = "3"
+gd_t, gs_t = hip_grad(g_rad, g_dns)
+del os.environ["GRUT_GRT_LOG_CHUNKS"]
+err_t = np.abs(gd_t[:, :11] - rdg[:, :11])
+for name, sl in pu.GRAD_SLICES.items():
+    print(name, "rel err (traversal backward)", float(err_t[:, sl].max() / np.abs(rdg[:, sl]).max()), " replay vs traversal", float(np.abs(gd - gd_t)[:, sl].max() / np.abs(rdg[:, sl]).max()))
+print("worst particle, traversal backward:", gd_t[worst, :11])
+gd2, _ = hip_grad(g_rad, g_dns)
+print("replay run-to-run:", float((np.abs(gd2 - gd)[:, :11] / scale).max()))
 rays = np.flatnonzero((ids == worst).any(1))
 print("rays that processed it:", rays.size)
 rows = []
@@ -79,6 +89,28 @@ for r in rays:
     b, _ = ora_grad(np.array([r]), gr, gdn)
     e = float((np.abs(a[worst, :11] - b[worst, :11]) / scale).max())
     rows.append((e, int(r)))
+tot_h = np.zeros(11); tot_o = np.zeros(11)
+for r in rays:
+    gr, gdn = np.zeros_like(g_rad), np.zeros_like(g_dns)
+    gr.reshape(-1, 3)[r] = g_rad.reshape(-1, 3)[r]
+    gdn.reshape(-1, 1)[r] = g_dns.reshape(-1, 1)[r]
+    tot_h += hip_grad(gr, gdn)[0][worst, :11]
+    tot_o += ora_grad(np.array([r]), gr, gdn)[0][worst, :11]
+print("sum of per-ray hip   :", tot_h)
+print("sum of per-ray oracle:", tot_o)
+# wave (8x8 pixel block) of each ray, and how many rays of the list share a block
+bx, by = (rays % w) // 8, (rays // w) // 8
+blk, cnts = np.unique(by * ((w + 7) // 8) + bx, return_counts=True)
+print("blocks:", dict(zip(blk.tolist(), cnts.tolist())))
+# per-block totals: all rays of one 8x8 block at once (what one wave aggregates) against the oracle
+for b in blk:
+    sel = rays[(by * ((w + 7) // 8) + bx) == b]
+    gr, gdn = np.zeros_like(g_rad), np.zeros_like(g_dns)
+    gr.reshape(-1, 3)[sel] = g_rad.reshape(-1, 3)[sel]
+    gdn.reshape(-1, 1)[sel] = g_dns.reshape(-1, 1)[sel]
+    a = hip_grad(gr, gdn)[0][worst, :11]
+    o = ora_grad(sel, gr, gdn)[0][worst, :11]
+    print(f"  block {b}: {sel.size} rays, slots {[int(np.flatnonzero(ids[r, :num[r]] == worst)[0]) for r in sel]}, err {float((np.abs(a - o) / scale).max()):.3e}")
 rows.sort(reverse=True)
 print("per-ray error of that particle's gradient (relative to the tensor maxima), worst first:", rows[:6])
 e, r = rows[0]

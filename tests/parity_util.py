@@ -129,7 +129,8 @@ def pixel_errors(fd, dist, ref_fd, ref_dist):
 def _composite(alpha, hit_t, colour, accept, min_T, end_shift=0):
     """The K = 0 compositing loop (gutKBufferRenderer.cuh:273-352) over one pixel's traced entries with the given accept decisions.
     end_shift toggles the OTHER discontinuity, the end of the ray at T < min_transmittance, when the transmittance is within
-    2 % of the threshold there: +1 = the first trigger is ignored (one more hit is composited), -1 = the ray ends one hit early."""
+    1e-3 (relative) of the threshold there — T is a product of ~100 fp32 factors: +1 = the first trigger is ignored (one more hit is
+    composited), -1 = the ray ends at the first hit that leaves T that close above the threshold."""
     T, D, cnt = 1.0, 0.0, 0
     C = np.zeros(3)
     skip = end_shift > 0
@@ -142,11 +143,11 @@ def _composite(alpha, hit_t, colour, accept, min_T, end_shift=0):
             C += w * colour[i]
             cnt += 1
         if T < min_T:
-            if skip and T > 0.98 * min_T:
+            if skip and T > (1.0 - 1e-3) * min_T:
                 skip = False
                 continue
             break
-        if end_shift < 0 and T < 1.02 * min_T:
+        if end_shift < 0 and T < (1.0 + 1e-3) * min_T:
             break
     return C, 1.0 - T, D, cnt
 
@@ -163,17 +164,27 @@ def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, margin=
     fd = hip_fd.reshape(-1, 4)
     cnt = hip_cnt.reshape(-1)
     out = np.full(len(pixels), -1, np.int32)
+    # the same trace in float64: the fp32 evaluation of alpha (|v x u|^2 / |v|^2 with |u| ~ 1e2..1e3 canonical units) carries up to
+    # ~1e-3 relative rounding for small, distant particles — on the GPU as in the oracle — so the GPU's pixel is accepted if it is
+    # within `tol` of the fp32 OR of the fp64 evaluation of the same decisions (the two bracket the rounding noise)
+    fwd64 = dict(fwd, density12=fwd["density12"].astype(np.float64), rays=tuple(r.astype(np.float64) for r in fwd["rays"]),
+                 poses=tuple(p.astype(np.float64) for p in fwd["poses"]))
     for k, pix in enumerate(pixels):
         tr = oracle.gut_pixel_trace(cfg, cam, fwd, pix)
+        tr64 = oracle.gut_pixel_trace(cfg, cam, fwd64, pix, dtype=np.float64)
         alpha, hit_t, m = tr["alpha"].astype(np.float64), tr["hit_t"].astype(np.float64), tr["margin"].astype(np.float64)
+        alpha64, hit_t64 = tr64["alpha"], tr64["hit_t"]
         colour = np.maximum(particle_rgb[tr["idx"]].astype(np.float64), 0.0)
         accept0 = m > 0
         near = np.flatnonzero((np.abs(m) < margin) & (alpha > 0))
         target, tcnt = fd[pix], int(cnt[pix])
 
         def matches(acc, end_shift):
-            C, opa, _, c = _composite(alpha, hit_t, colour, acc, min_T, end_shift)
-            return c == tcnt and np.abs(C - target[:3]).max() < tol and abs(opa - target[3]) < tol
+            for al, ht in ((alpha, hit_t), (alpha64, hit_t64)):
+                C, opa, _, c = _composite(al, ht, colour, acc, min_T, end_shift)
+                if c == tcnt and np.abs(C - target[:3]).max() < tol and abs(opa - target[3]) < tol:
+                    return True
+            return False
 
         found = -1
         for n_toggle in (0, 1, 2, 3):
@@ -292,7 +303,7 @@ def assert_gut_full_parity(stats, max_flip_frac=2e-3):
             if f"E_grad_{k}_rel_err_unmasked" in stats:
                 # every flip moves its particle's gradient by about one hit's worth: a sanity bound, not a parity bar
                 assert stats[f"E_grad_{k}_rel_err_unmasked"] < 0.1, (k, stats)
-        assert stats["C_grad_nonzero_particles"] > 0.2 * stats["A_particles_visible_oracle"]
+        assert stats["C_grad_nonzero_particles"] > 0.05 * stats["A_particles_visible_oracle"]   # (the particles in front of the terminations)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -360,6 +371,8 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
     stats["T_max_rgb_err_outside_flips"] = float(e_rgb[~F].max())
     stats["T_max_opacity_err_outside_flips"] = float(e_opa[~F].max())
     stats["T_max_dist_rel_err_outside_flips"] = float(e_dist[~F].max())
+    stats["T_max_integrated_depth_rel_err_outside_flips"] = float((np.abs(h_s - o_hit) / np.maximum(1.0, np.abs(o_hit)))[~F, 0].max())
+    stats["T_max_last_hit_t_abs_err_outside_flips"] = float(np.abs(h_s - o_hit)[~F, 1].max())
     stats["T_max_rgb_err_in_flips"] = float(e_rgb[F].max()) if F.any() else 0.0
     if ray_stride == 1:
         stats["T_visibility_differs"] = int((vis != (ora["visibility"] != 0)).sum())
@@ -372,17 +385,44 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
         Fm = F.reshape(h, w)
         g_rad[Fm] = 0.0
         g_dns[Fm] = 0.0
-        out = tr.render(g, batch, train=True)
-        loss = (out["pred_features"][0] * torch.as_tensor(g_rad, device="cuda")).sum() + (out["pred_opacity"][0] * torch.as_tensor(g_dns, device="cuda")).sum()
-        loss.backward()
-        torch.cuda.synchronize()
-        gd, gs = g.grads_packed()
         ora["rays"] = (ora["rays"][0].reshape(1, -1, 3), ora["rays"][1].reshape(1, -1, 3))
-        rdg, rsg = oracle.grt_backward(cfg, 3, tr._min_transmittance, ora, g_rad.reshape(1, -1, 3), g_dns.reshape(1, -1, 1),
-                                       np.zeros((1, w * h, 1), np.float32))
+        zero_hit = np.zeros((1, w * h, 1), np.float32)
+        shifted = np.zeros(w * h, np.uint8)
+        rdg, rsg = oracle.grt_backward(cfg, 3, tr._min_transmittance, ora, g_rad.reshape(1, -1, 3), g_dns.reshape(1, -1, 1), zero_hit,
+                                       round_shift=shifted)
+        shifted = shifted.astype(bool)
+        stats["G_round_shift_rays"] = int(shifted.sum())
+
+        def hip_grads(tracer, gr, gdn):
+            g.zero_grad()
+            out = tracer.render(g, batch, train=True)
+            loss = (out["pred_features"][0] * torch.as_tensor(gr, device="cuda")).sum() + (out["pred_opacity"][0] * torch.as_tensor(gdn, device="cuda")).sum()
+            loss.backward()
+            torch.cuda.synchronize()
+            return g.grads_packed()
+
+        # (1) the reference's backward program exactly: the plugin traverses again (render.backward_hit_replay = false)
+        tr_exact = grt.Tracer({"render": {"enable_hitcounts": True, "backward_hit_replay": False}})
+        tr_exact.build_acc(g, rebuild=True)
+        gd, gs = hip_grads(tr_exact, g_rad, g_dns)
         for kname, sl in GRAD_SLICES.items():
             stats[f"G_grad_{kname}_rel_err"] = rel_err(gd[:, sl], rdg[:, sl])
         stats["G_grad_sph_rel_err"] = rel_err(gs, rsg)
+        # (2) the default backward (hit-log replay) on the rays where replaying is the same program: upstream gradient also zeroed on
+        #     the rays the oracle flags as round-shifted (its backward program's hit set differs from its forward's)
+        Sm = shifted.reshape(h, w)
+        g_rad2, g_dns2 = g_rad.copy(), g_dns.copy()
+        g_rad2[Sm] = 0.0
+        g_dns2[Sm] = 0.0
+        rdg2, rsg2 = oracle.grt_backward(cfg, 3, tr._min_transmittance, ora, g_rad2.reshape(1, -1, 3), g_dns2.reshape(1, -1, 1), zero_hit)
+        gd2, gs2 = hip_grads(tr, g_rad2, g_dns2)
+        for kname, sl in GRAD_SLICES.items():
+            stats[f"G_replay_grad_{kname}_rel_err"] = rel_err(gd2[:, sl], rdg2[:, sl])
+        stats["G_replay_grad_sph_rel_err"] = rel_err(gs2, rsg2)
+        # (3) and what the default backward gives on the whole frame (round-shifted rays included): reported
+        gd3, gs3 = hip_grads(tr, g_rad, g_dns)
+        for kname, sl in GRAD_SLICES.items():
+            stats[f"G_replay_unmasked_grad_{kname}_rel_err"] = rel_err(gd3[:, sl], rdg[:, sl])
         stats["t_backward_s"] = time.time() - t0
     stats["t_total_s"] = time.time() - t_all
     if log:
@@ -399,8 +439,13 @@ def assert_grt_full_parity(stats):
     assert stats["T_flip_rays"] <= max(2, 1e-3 * stats["T_rays_compared"]), stats      # identified compositing flips, bounded
     assert stats["T_rays_hit_number_differs"] <= stats["T_flip_rays"]
     assert stats["T_max_rgb_err_outside_flips"] < 1e-4 and stats["T_max_opacity_err_outside_flips"] < 1e-4, stats
-    assert stats["T_max_dist_rel_err_outside_flips"] < 1e-4, stats
+    assert stats["T_max_dist_rel_err_outside_flips"] < 2e-4, stats   # integrated depth (~4 units, ~60 fp32 terms) and last-hit t, relative above 1
     assert stats.get("T_visibility_differs", 0) <= stats["T_flip_rays"], stats
     for kname in list(GRAD_SLICES) + ["sph"]:
         if f"G_grad_{kname}_rel_err" in stats:
-            assert stats[f"G_grad_{kname}_rel_err"] < 1e-3, (kname, stats)
+            assert stats[f"G_grad_{kname}_rel_err"] < 1e-3, (kname, stats)          # the reference's backward program
+            assert stats[f"G_replay_grad_{kname}_rel_err"] < 1e-3, (kname, stats)   # the default (replay) where it is the same program
+    if "G_round_shift_rays" in stats:
+        assert stats["G_round_shift_rays"] <= 5e-3 * stats["T_rays_compared"], stats
+        for kname in GRAD_SLICES:
+            assert stats[f"G_replay_unmasked_grad_{kname}_rel_err"] < 1e-2, (kname, stats)
