@@ -55,7 +55,7 @@ class GutFrame(C.Structure):
         ("frame_id", C.c_uint32), ("n_active_features", C.c_int32), ("num_particles", C.c_uint32),
         ("width", C.c_int32), ("height", C.c_int32), ("camera", GrutCamera),
         ("pose_start", C.c_float * 7), ("pose_end", C.c_float * 7),
-        ("device_T_to_world", C.c_void_p), ("device_T_to_world_end", C.c_void_p),
+        ("device_T_to_world", C.c_void_p), ("device_T_to_world_end", C.c_void_p), ("out_features", C.c_void_p), ("out_opacity", C.c_void_p),
     ]
 
 
@@ -100,9 +100,15 @@ class GrutAdamGroup(C.Structure):
 
 VIS_NONE, VIS_BOOL_U8, VIS_INT32, VIS_FLOAT_BITS = range(4)
 
+
+class GutGradIO(C.Structure):
+    """include/grut_amd.h: GutGradIO (gradient tensors of gut_backward_unpacked in the caller's own layout)."""
+    _fields_ = [("grad_features", C.c_void_p), ("grad_opacity", C.c_void_p), ("grad_positions", C.c_void_p), ("grad_density", C.c_void_p),
+                ("grad_rotation", C.c_void_p), ("grad_scale", C.c_void_p)]
+
 # every symbol include/grut_amd.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
-    "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_backward_factored", "grut_sph_grad_from_views", "gut_timings", "gut_stats",
+    "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_backward_unpacked", "gut_backward_factored", "grut_sph_grad_from_views", "gut_timings", "gut_stats",
     "gut_profile_enable", "gut_profile_read",
     "gut_debug_fetch", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
@@ -127,6 +133,8 @@ def _declare(lib):
     lib.gut_backward.restype = C.c_int
     lib.gut_backward_factored.argtypes = [C.c_void_p, vp, C.POINTER(GutFrame)] + [fp] * 10
     lib.gut_backward_factored.restype = C.c_int
+    lib.gut_backward_unpacked.argtypes = [C.c_void_p, vp, C.POINTER(GutFrame)] + [fp] * 7 + [C.POINTER(GutGradIO), fp]
+    lib.gut_backward_unpacked.restype = C.c_int
     lib.grut_sph_grad_from_views.argtypes = [vp, C.c_uint32, C.c_uint32, fp, fp, C.c_uint32, C.c_int32, C.c_int32, C.c_float, fp]
     lib.grut_sph_grad_from_views.restype = C.c_int
     lib.gut_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]

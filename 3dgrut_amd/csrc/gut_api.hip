@@ -125,6 +125,8 @@ static GutParams make_params(const GutConfig& c, const GutFrame& f) {
     P.cam = f.camera;
     P.poses = make_frame_poses(f.pose_start, f.pose_end);
     P.poses_dev = nullptr;
+    P.out_features = f.out_features;
+    P.out_opacity = f.out_opacity;
     return P;
 }
 
@@ -144,7 +146,10 @@ static int ensure_particle_scratch(GutHandle* h, uint32_t N) {
     GRUT_CHECK(h->part_offset.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     GRUT_CHECK(h->scan_scratch.ensure(scan_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
-    GRUT_CHECK(h->counters.ensure(64));
+    if (!h->counters.ptr) {   // [1] counts the visible particles of a frame: zero once here, re-armed on the device after every read
+        GRUT_CHECK(h->counters.ensure(64));
+        GRUT_HIP(hipMemset(h->counters.ptr, 0, 64));
+    }
     return GRUT_OK;
 }
 
@@ -271,8 +276,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         h->params.poses_dev = h->poses_dev.as<FramePoses>();
     }
     const GutProjected proj = projected_view(h);
-    uint32_t* d_counters = h->counters.as<uint32_t>();
-    GRUT_HIP(hipMemsetAsync(d_counters, 0, 64, s));
+    uint32_t* d_counters = h->counters.as<uint32_t>();   // [1] = visible particles: zero at allocation, re-armed by the tail preparation
 
     const int slot = h->prof_slot % GutHandle::kProfRing;
     if (h->profile) {
@@ -301,10 +305,13 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     // enqueued SPECULATIVELY against the current capacity of the per-intersection scratch, with the true count read on
     // the device, so the GPU never waits for the host to wake up and launch a dozen small kernels (the reference blocks
     // here, gutRenderer.cu:313-321).  Only if the count turns out to exceed the capacity is the tail redone.
-    GRUT_HIP(hipMemcpyAsync(&h->host_counters[0], h->offsets.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
-    GRUT_HIP(hipMemcpyAsync(&h->host_counters[1], d_counters + 1, 4, hipMemcpyDeviceToHost, s));
+    // the only per-tile buffer: a frame with more tiles than any before must find it large enough for the speculative tail
+    GRUT_CHECK(h->ranges.ensure((size_t)tiles * 8 + 8));
+    launch_prepare_tail(s, h->offsets.as<uint32_t>() + (N - 1), d_counters + 1, h->host_counters, h->ranges.as<uint32_t>(), tiles * 2u,
+                        h->ck_reached.as<uint32_t>(), h->ck_reached.ptr ? h->ck_boundaries_capacity : 0u);
     GRUT_HIP(hipEventRecord(h->count_event, s));
     const uint32_t tile_mask = (h->stats.key_bits >= 32) ? 0xFFFFFFFFu : ((1u << h->stats.key_bits) - 1u);
+    bool first_tail = true;
     auto enqueue_tail = [&](uint32_t n, const uint32_t* n_dev) -> int {
         // K4 expansion in rank order
         GRUT_CHECK(h->stage_begin(GUT_STAGE_EXPAND, s, slot));
@@ -322,8 +329,11 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_SORT, s, slot));
         // K6 tile ranges
         GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_RANGES, s, slot));
-        GRUT_HIP(hipMemsetAsync(h->ranges.ptr, 0, (size_t)tiles * 8, s));
-        GRUT_HIP(hipMemsetAsync(h->ck_reached.ptr, 0, (size_t)h->ck_boundaries_capacity * 4, s));
+        if (!first_tail) {   // (the first tail of a frame finds both tables cleared by the tail preparation)
+            GRUT_HIP(hipMemsetAsync(h->ranges.ptr, 0, (size_t)tiles * 8, s));
+            GRUT_HIP(hipMemsetAsync(h->ck_reached.ptr, 0, (size_t)h->ck_boundaries_capacity * 4, s));
+        }
+        first_tail = false;
         launch_tile_ranges(s, n, n_dev, tile_mask, tiles, sorted_tiles, h->ranges.as<uint32_t>(), h->checkpoints.boundary_tile);
         GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_RANGES, s, slot));
         // K7 compositing
@@ -337,8 +347,6 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_FWD, s, slot));
         return GRUT_OK;
     };
-    // the only per-tile buffer: a frame with more tiles than any before must find it large enough for the speculative tail
-    GRUT_CHECK(h->ranges.ensure((size_t)tiles * 8 + 8));
     const bool speculative = h->tile_capacity > 0;
     if (speculative) GRUT_CHECK(enqueue_tail(h->tile_capacity, h->offsets.as<uint32_t>() + (N - 1)));
     GRUT_HIP(hipEventSynchronize(h->count_event));
@@ -353,12 +361,15 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         GRUT_HIP(hipMemsetAsync(out_feat_density, 0, (size_t)P.W * P.H * 16, s));
         GRUT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_hit_distance), (int)bits, (size_t)P.W * P.H, s));
         GRUT_HIP(hipMemsetAsync(out_hit_count, 0, (size_t)P.W * P.H * 4, s));
+        if (P.out_features) GRUT_HIP(hipMemsetAsync(P.out_features, 0, (size_t)P.W * P.H * 12, s));
+        if (P.out_opacity) GRUT_HIP(hipMemsetAsync(P.out_opacity, 0, (size_t)P.W * P.H * 4, s));
         if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
         h->have_forward = true;
         return GRUT_OK;
     }
     if (!speculative || I > h->tile_capacity) {
         GRUT_CHECK(ensure_intersection_scratch(h, I + I / 2, tiles));  // head-room: the next frames speculate against it
+        first_tail = false;   // (re)allocated tables: clear them explicitly
         GRUT_CHECK(enqueue_tail(I, nullptr));
     }
     h->checkpoints.num_boundaries = I / kGutSegment + 1;  // what the gradient sweep iterates over
@@ -372,7 +383,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
 static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const float* particle_sph,
                          const float* ray_origin, const float* ray_direction, const float* feat_density, const float* grad_feat_density,
                          const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_particle_sph,
-                         float* grad_radiance) {
+                         float* grad_radiance, const GutGradIO* io = nullptr) {
     GRUT_REQUIRE(h && frame, "gut_backward: null handle/frame");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     if (!h->have_forward || h->fwd_stream != s) {  // gutRenderer.cu:436-440
@@ -387,7 +398,19 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
         return GRUT_ERR_NOT_READY;
     }
     if (P.N == 0) return GRUT_OK;
-    GRUT_REQUIRE(particle_density && particle_sph && feat_density && grad_feat_density && hit_distance && grad_particle_density &&
+    // the gradient tensors in the reference's packed layout, or (io) in the caller's own: see GutGradIO
+    const GutGradIn g_in = io ? GutGradIn{nullptr, io->grad_features, io->grad_opacity} : GutGradIn{grad_feat_density, nullptr, nullptr};
+    const GutGradOut g_out = io ? GutGradOut{nullptr, io->grad_positions, io->grad_density, io->grad_rotation, io->grad_scale}
+                                : GutGradOut{grad_particle_density, nullptr, nullptr, nullptr, nullptr};
+    if (io) {
+        GRUT_REQUIRE(io->grad_positions && io->grad_density && io->grad_rotation && io->grad_scale, "gut_backward_unpacked: null gradient output");
+        GRUT_REQUIRE((reinterpret_cast<uintptr_t>(io->grad_rotation) & 15u) == 0, "gut_backward_unpacked: grad_rotation must be 16-byte aligned");
+        if (P.k_buffer > 0) {
+            set_last_error("gut_backward_unpacked: the sorted (k_buffer_size > 0) backward accumulates into packed rows; use gut_backward");
+            return GRUT_ERR_UNSUPPORTED;
+        }
+    }
+    GRUT_REQUIRE(particle_density && particle_sph && feat_density && (io || grad_feat_density) && hit_distance && (io || grad_particle_density) &&
                      (grad_particle_sph || grad_radiance), "gut_backward: null buffer");  // grad_hit_distance may be NULL (no depth gradient)
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
     const GutProjected proj = projected_view(h);
@@ -412,7 +435,7 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
             GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_BWD, s, slot));
         }
         GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));
-        launch_project_bwd(s, P, proj, particle_density, particle_sph, h->g_rgb.as<float>(), grad_particle_density, grad_particle_sph, grad_radiance);
+        launch_project_bwd(s, P, proj, particle_density, particle_sph, h->g_rgb.as<float>(), g_out, grad_particle_sph, grad_radiance);
         GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT_BWD, s, slot));
         GRUT_HIP(hipGetLastError());
         if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
@@ -427,12 +450,12 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
         GRUT_HIP(hipMemsetAsync(slots.flag, 0, 2 * I, s));
         GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_BWD, s, slot));
         launch_render_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_pos, particle_density, proj.rgb, ray_origin, ray_direction, feat_density,
-                          grad_feat_density, hit_distance, grad_hit_distance, slots, h->checkpoints);
+                          g_in, hit_distance, grad_hit_distance, slots, h->checkpoints);
         GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_BWD, s, slot));
     }
     GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));
     GRUT_CHECK(h->g_rgb.ensure((size_t)P.N * 12, 1.25f));  // per-particle radiance gradient between gather and SH backward
-    launch_grad_finalize(s, P, proj, particle_density, particle_sph, slots, has_gdist, I > 0, h->g_rgb.as<float>(), grad_particle_density,
+    launch_grad_finalize(s, P, proj, particle_density, particle_sph, slots, has_gdist, I > 0, h->g_rgb.as<float>(), g_out,
                          grad_particle_sph, grad_radiance);
     GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT_BWD, s, slot));
     GRUT_HIP(hipGetLastError());
@@ -445,6 +468,14 @@ int gut_backward(GutHandle* h, void* stream, const GutFrame* frame, const float*
                  const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_particle_sph) {
     return backward_impl(h, stream, frame, particle_density, particle_sph, ray_origin, ray_direction, feat_density, grad_feat_density, hit_distance,
                          grad_hit_distance, grad_particle_density, grad_particle_sph, nullptr);
+}
+
+int gut_backward_unpacked(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const float* particle_sph,
+                          const float* ray_origin, const float* ray_direction, const float* feat_density, const float* hit_distance,
+                          const float* grad_hit_distance, const GutGradIO* io, float* grad_particle_sph) {
+    GRUT_REQUIRE(io, "gut_backward_unpacked: null GutGradIO");
+    return backward_impl(h, stream, frame, particle_density, particle_sph, ray_origin, ray_direction, feat_density, nullptr, hit_distance,
+                         grad_hit_distance, nullptr, grad_particle_sph, nullptr, io);
 }
 
 int gut_backward_factored(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const float* particle_sph,

@@ -17,12 +17,16 @@ struct GutParams {
     uint32_t N;
     GrutCamera cam;
     FramePoses poses;             // derived on the host from GutFrame::pose_start / pose_end ...
+    float* out_features;          // optional contiguous copies of the radiance / opacity outputs (GutFrame::out_features / out_opacity)
+    float* out_opacity;
     const FramePoses* poses_dev;  // ... or on the device from GutFrame::device_T_to_world[_end] (then this is non-null)
 };
 #ifdef __HIPCC__
 __device__ __forceinline__ const FramePoses& frame_poses(const GutParams& P) { return P.poses_dev ? *P.poses_dev : P.poses; }
 #endif
 void launch_frame_poses(hipStream_t s, const float* T_start, const float* T_end, FramePoses* out);
+void launch_prepare_tail(hipStream_t s, const uint32_t* last_offset, uint32_t* num_visible, uint32_t* host_counters, uint32_t* ranges_words,
+                         uint32_t n_ranges_words, uint32_t* reached_words, uint32_t n_reached_words);
 
 // per-particle products of the projection (role of GutRenderForwardContext's particle buffers, gutRenderer.cu:166-177)
 struct GutProjected {
@@ -47,6 +51,32 @@ struct GutGradSlots {
     const uint32_t* pos_particle;// [I]            particle of expansion position q (0xFFFFFFFF = padding)
     int stride;                  // floats per slot: 16, or 20 when a depth gradient flows in
 };
+
+// Where the geometric particle gradient goes: the reference's packed [N,12] rows, or (packed == nullptr) the model's four
+// tensors directly — positions [N,3], density [N,1], rotation [N,4], scale [N,3] — which saves the caller the unpack pass.
+struct GutGradOut {
+    float* packed;
+    float* pos;
+    float* dns;
+    float* rot;
+    float* scl;
+};
+// Upstream image gradient: one [H,W,4] tensor like the reference, or (fd == nullptr) separate [H,W,3] / [H,W,1] tensors as
+// autograd delivers them (either may be null = zero), which saves the caller a concatenation.
+struct GutGradIn {
+    const float* fd;
+    const float* rgb;
+    const float* opa;
+};
+#ifdef __HIPCC__
+__device__ __forceinline__ float4 load_grad_in(const GutGradIn& g, size_t pix) {
+    if (g.fd) return reinterpret_cast<const float4*>(g.fd)[pix];
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g.rgb) { r.x = g.rgb[3 * pix]; r.y = g.rgb[3 * pix + 1]; r.z = g.rgb[3 * pix + 2]; }
+    if (g.opa) r.w = g.opa[pix];
+    return r;
+}
+#endif
 
 // the gradient sweep runs a long tile list as independent segments of this many sorted entries
 constexpr uint32_t kGutSegment = 256;
@@ -75,7 +105,7 @@ void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
                        const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist, float* out_cnt,
                        const GutCheckpoints& ck, bool write_checkpoints);
 void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const float* density12,
-                       const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* dist,
+                       const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const GutGradIn& g_fd, const float* dist,
                        const float* g_dist, const GutGradSlots& slots, const GutCheckpoints& ck);
 void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
@@ -84,9 +114,9 @@ void launch_render_k_bwd(hipStream_t s, const GutParams& P, const uint32_t* rang
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd,
                          const float* dist, const float* g_dist, float* g_density12, float* g_rgb);
 void launch_project_bwd(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
-                        const float* g_rgb, float* g_density12, float* g_sph, float* g_radiance);
+                        const float* g_rgb, const GutGradOut& g_out, float* g_sph, float* g_radiance);
 void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
-                          const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, float* g_density12, float* g_sph,
+                          const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, const GutGradOut& g_out, float* g_sph,
                           float* g_radiance);
 void launch_sph_grad_from_views(hipStream_t s, uint32_t N, uint32_t n_views, const float* factors, const float* positions, uint32_t pos_stride,
                                 int n_active, int ncoef, float scale, float* g_sph);

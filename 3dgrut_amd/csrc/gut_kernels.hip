@@ -661,7 +661,7 @@ __device__ __forceinline__ float xor_sum_quads(float v) {  // sum over the 16 qu
 
 template <int STRIDE>
 __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutProjected proj, const float4* __restrict__ density12,
-                                                              GutGradSlots slots, int have_partials, float* __restrict__ g_density12,
+                                                              GutGradSlots slots, int have_partials, GutGradOut g_out,
                                                               float* __restrict__ g_rgb) {
     const int lane = threadIdx.x & 63, c = threadIdx.x & 3;
     const uint32_t i = blockIdx.x * 64u + (threadIdx.x >> 2);
@@ -747,9 +747,18 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     r[12] = quad_bcast<3>(acc.a.x); r[13] = quad_bcast<3>(acc.a.y); r[14] = quad_bcast<3>(acc.a.z); r[15] = quad_bcast<3>(acc.a.w);
     r[16] = quad_bcast<0>(acc.x.x); r[17] = quad_bcast<0>(acc.x.y); r[18] = quad_bcast<0>(acc.x.z); r[19] = 0.f;
     if (i >= P.N) return;
-    float4* gd = reinterpret_cast<float4*>(g_density12 + 12 * (size_t)i);
+    float4* gd = reinterpret_cast<float4*>(g_out.packed + 12 * (size_t)i);
     if (!has) {
-        if (c < 3) gd[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_out.packed) {
+            if (c < 3) gd[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (c == 0) {
+            g_out.pos[3 * (size_t)i] = 0.f; g_out.pos[3 * (size_t)i + 1] = 0.f; g_out.pos[3 * (size_t)i + 2] = 0.f;
+            g_out.dns[i] = 0.f;
+        } else if (c == 1) {
+            reinterpret_cast<float4*>(g_out.rot)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (c == 2) {
+            g_out.scl[3 * (size_t)i] = 0.f; g_out.scl[3 * (size_t)i + 1] = 0.f; g_out.scl[3 * (size_t)i + 2] = 0.f;
+        }
         return;
     }
     const m3 rt = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
@@ -764,10 +773,19 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     float gsz = -(rt.r2.x * m[6] + rt.r2.y * m[7] + rt.r2.z * m[8]) / sc.z;
     if (STRIDE > 16) { gsx += r[16]; gsy += r[17]; gsz += r[18]; }
     const float4 dq = quat_contract(m, make_float4(2.f * q.x, 2.f * q.y, 2.f * q.z, 2.f * q.w));
-    if (c == 0) gd[0] = make_float4(gpos.x, gpos.y, gpos.z, r[3]);
-    else if (c == 1) gd[1] = dq;
-    else if (c == 2) gd[2] = make_float4(gsx, gsy, gsz, 0.f);
-    else {
+    if (c == 0) {
+        if (g_out.packed) gd[0] = make_float4(gpos.x, gpos.y, gpos.z, r[3]);
+        else {
+            g_out.pos[3 * (size_t)i] = gpos.x; g_out.pos[3 * (size_t)i + 1] = gpos.y; g_out.pos[3 * (size_t)i + 2] = gpos.z;
+            g_out.dns[i] = r[3];
+        }
+    } else if (c == 1) {
+        if (g_out.packed) gd[1] = dq;
+        else reinterpret_cast<float4*>(g_out.rot)[i] = dq;
+    } else if (c == 2) {
+        if (g_out.packed) gd[2] = make_float4(gsx, gsy, gsz, 0.f);
+        else { g_out.scl[3 * (size_t)i] = gsx; g_out.scl[3 * (size_t)i + 1] = gsy; g_out.scl[3 * (size_t)i + 2] = gsz; }
+    } else {
         g_rgb[3 * (size_t)i] = r[13];
         g_rgb[3 * (size_t)i + 1] = r[14];
         g_rgb[3 * (size_t)i + 2] = r[15];
@@ -783,7 +801,7 @@ template <bool FACTORED>
 __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const uint32_t* __restrict__ tiles_count,
                                                               const float4* __restrict__ density12, const float* __restrict__ sph,
                                                               const float* __restrict__ rgb, const float* __restrict__ g_rgb,
-                                                              float* __restrict__ g_density12, float* __restrict__ g_sph,
+                                                              GutGradOut g_out, float* __restrict__ g_sph,
                                                               float* __restrict__ g_radiance) {
     __shared__ float s_rows[2][64 * kShStride];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -849,9 +867,10 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
             for (int k = 3 * nact; k < rowlen; ++k) myrow[k] = 0.f;
         const float ng = dot(dir, gdir);
         const f3 gpos = (gdir - dir * ng) * ilen;
-        g_density12[12 * (size_t)i + 0] += gpos.x;
-        g_density12[12 * (size_t)i + 1] += gpos.y;
-        g_density12[12 * (size_t)i + 2] += gpos.z;
+        float* gp = g_out.packed ? g_out.packed + 12 * (size_t)i : g_out.pos + 3 * (size_t)i;
+        gp[0] += gpos.x;
+        gp[1] += gpos.y;
+        gp[2] += gpos.z;
         if (FACTORED) { g_radiance[3 * (size_t)i] = g.x; g_radiance[3 * (size_t)i + 1] = g.y; g_radiance[3 * (size_t)i + 2] = g.z; }
     } else if (!FACTORED) {
         for (int k = 0; k < rowlen; ++k) myrow[k] = 0.f;
@@ -949,7 +968,30 @@ __global__ void gut_frame_poses_kernel(const float* __restrict__ T_start, const 
     *out = make_frame_poses(ps, pe);
 }
 
+// Between the scan and the tail of the frame: publishes the intersection count I and the visible-particle count straight into
+// the host's pinned counters (device-visible memory: no blit copies on the stream), re-arms the visible counter for the next
+// frame, and clears the two small per-frame tables of the tail (tile ranges, checkpoint "reached" marks) — one launch instead of
+// three fills and two copies.
+__global__ __launch_bounds__(256) void gut_prepare_tail_kernel(const uint32_t* __restrict__ last_offset, uint32_t* __restrict__ num_visible,
+                                                               uint32_t* __restrict__ host_counters, uint32_t* __restrict__ ranges_words,
+                                                               uint32_t n_ranges_words, uint32_t* __restrict__ reached_words, uint32_t n_reached_words) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    if (i == 0) {
+        __hip_atomic_store(&host_counters[0], *last_offset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_counters[1], *num_visible, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *num_visible = 0u;
+    }
+    for (uint32_t k = i; k < n_ranges_words; k += stride) ranges_words[k] = 0u;
+    for (uint32_t k = i; k < n_reached_words; k += stride) reached_words[k] = 0u;
+}
+
 }  // namespace
+
+void launch_prepare_tail(hipStream_t s, const uint32_t* last_offset, uint32_t* num_visible, uint32_t* host_counters, uint32_t* ranges_words,
+                         uint32_t n_ranges_words, uint32_t* reached_words, uint32_t n_reached_words) {
+    hipLaunchKernelGGL(gut_prepare_tail_kernel, dim3(64), dim3(256), 0, s, last_offset, num_visible, host_counters, ranges_words, n_ranges_words,
+                       reached_words, n_reached_words);
+}
 
 void launch_frame_poses(hipStream_t s, const float* T_start, const float* T_end, FramePoses* out) {
     hipLaunchKernelGGL(gut_frame_poses_kernel, dim3(1), dim3(64), 0, s, T_start, T_end, out);
@@ -979,13 +1021,13 @@ void launch_tile_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32
 
 // exactly one of g_sph (expanded SH gradient) and g_radiance (view factor, see gut_project_bwd_kernel<true>) is non-null
 void launch_project_bwd(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
-                        const float* g_rgb, float* g_density12, float* g_sph, float* g_radiance) {
+                        const float* g_rgb, const GutGradOut& g_out, float* g_sph, float* g_radiance) {
     if (g_radiance)
         hipLaunchKernelGGL(gut_project_bwd_kernel<true>, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
-                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_density12, g_sph, g_radiance);
+                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_out, g_sph, g_radiance);
     else
         hipLaunchKernelGGL(gut_project_bwd_kernel<false>, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
-                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_density12, g_sph, g_radiance);
+                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_out, g_sph, g_radiance);
 }
 void launch_sph_grad_from_views(hipStream_t s, uint32_t N, uint32_t n_views, const float* factors, const float* positions, uint32_t pos_stride,
                                 int n_active, int ncoef, float scale, float* g_sph) {
@@ -993,16 +1035,16 @@ void launch_sph_grad_from_views(hipStream_t s, uint32_t N, uint32_t n_views, con
                        ncoef, scale, g_sph);
 }
 void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
-                          const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, float* g_density12, float* g_sph,
+                          const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, const GutGradOut& g_out, float* g_sph,
                           float* g_radiance) {
     const dim3 grid(div_up(P.N, 64)), block(256);  // four lanes per particle
     if (has_gdist)
         hipLaunchKernelGGL(gut_grad_gather_kernel<20>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
-                           have_partials ? 1 : 0, g_density12, g_rgb);
+                           have_partials ? 1 : 0, g_out, g_rgb);
     else
         hipLaunchKernelGGL(gut_grad_gather_kernel<16>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
-                           have_partials ? 1 : 0, g_density12, g_rgb);
-    launch_project_bwd(s, P, proj, density12, sph, g_rgb, g_density12, g_sph, g_radiance);
+                           have_partials ? 1 : 0, g_out, g_rgb);
+    launch_project_bwd(s, P, proj, density12, sph, g_rgb, g_out, g_sph, g_radiance);
 }
 
 }  // namespace grut

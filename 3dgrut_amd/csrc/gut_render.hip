@@ -24,7 +24,7 @@
 
 // tuning switches of the gradient sweep (scripts/build_variant.sh -D...)
 #ifndef GRUT_BWD_FULL_REDUCE
-#define GRUT_BWD_FULL_REDUCE 1
+#define GRUT_BWD_FULL_REDUCE 2   // 0: row partials through LDS, 1: DPP butterfly + lane swaps, 2: transposition through LDS (r02j: 0.887 -> 0.85 ms)
 #endif
 #ifndef GRUT_BWD_WAVES
 #define GRUT_BWD_WAVES 4   // waves per SIMD the register allocator is held to (0: its own choice, 130 VGPRs = 3 waves); measured r02b:
@@ -239,6 +239,12 @@ __device__ __forceinline__ v2f pair_response(v2f g) {
     }
 }
 
+// the plugin's `pred_features` / `pred_opacity` as contiguous tensors of their own (GutFrame::out_features / out_opacity)
+__device__ __forceinline__ void write_split_outputs(const GutParams& P, size_t pix, float4 o) {
+    if (P.out_features) { P.out_features[3 * pix] = o.x; P.out_features[3 * pix + 1] = o.y; P.out_features[3 * pix + 2] = o.z; }
+    if (P.out_opacity) P.out_opacity[pix] = o.w;
+}
+
 // ---------------------------------------------------------------------------------------------
 // K7: compositing forward — GUTKBufferRenderer::evalKBuffer, K = 0 (gutKBufferRenderer.cuh:273-352)
 // Rounds are aligned to multiples of 64 in the global sorted list, so every segment boundary (multiple of
@@ -330,13 +336,17 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
     // initial values (splatRaster.cpp:211-214)
     if (rp.inside0) {
         const size_t pix = (size_t)rp.py0 * P.W + rp.px;
-        out_fd[pix] = rp.valid0 ? make_float4(st.Cr.x, st.Cg.x, st.Cb.x, 1.f - st.T.x) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 o = rp.valid0 ? make_float4(st.Cr.x, st.Cg.x, st.Cb.x, 1.f - st.T.x) : make_float4(0.f, 0.f, 0.f, 0.f);
+        out_fd[pix] = o;
+        write_split_outputs(P, pix, o);
         out_dist[pix] = rp.valid0 ? st.D.x : 1e6f;
         if (P.hitcounts) out_cnt[pix] = rp.valid0 ? st.cnt.x : 0.f;
     }
     if (rp.inside1) {
         const size_t pix = (size_t)rp.py1 * P.W + rp.px;
-        out_fd[pix] = rp.valid1 ? make_float4(st.Cr.y, st.Cg.y, st.Cb.y, 1.f - st.T.y) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 o = rp.valid1 ? make_float4(st.Cr.y, st.Cg.y, st.Cb.y, 1.f - st.T.y) : make_float4(0.f, 0.f, 0.f, 0.f);
+        out_fd[pix] = o;
+        write_split_outputs(P, pix, o);
         out_dist[pix] = rp.valid1 ? st.D.y : 1e6f;
         if (P.hitcounts) out_cnt[pix] = rp.valid1 ? st.cnt.y : 0.f;
     }
@@ -370,7 +380,7 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
                                                  uint32_t half, const EntryLists& lists, const float4* __restrict__ density12,
                                                  const float* __restrict__ rgb, const GutGradSlots& slots,
                                                  float4* __restrict__ s_rec, float* __restrict__ s_acc, float* __restrict__ s_acc2,
-                                                 const BwdPixels& px) {
+                                                 float* __restrict__ s_tr, const BwdPixels& px) {
     constexpr uint32_t kBatch = kBwdBatch;
     v2f T = px.T, D = px.D, Cr = px.Cr, Cg = px.Cg, Cb = px.Cb;
     const v2f T_fin = px.T_fin, D_fin = px.D_fin, gT = px.gT, gD = px.gD;
@@ -486,7 +496,32 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
                 for (int k = 0; k < 16; ++k) extra[k] = 0.f;
                 extra[0] = sXm.x.x + sXm.x.y; extra[1] = sXm.y.x + sXm.y.y; extra[2] = sXm.z.x + sXm.z.y;
             }
-#if GRUT_BWD_FULL_REDUCE
+#if GRUT_BWD_FULL_REDUCE == 2
+            // transpose through LDS instead of the DPP butterfly: the sweep is bound by VALU issue and the LDS pipe is idle, so the
+            // 16 x 64 -> 16 reduction is moved there: every lane parks its 16 terms (term-major, rows padded to 65 words: conflict-free
+            // both ways), lane l then sums 16 of the 64 values of term l & 15 and two lane-swap steps add the four quarters
+            {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) s_tr[k * 65 + lane] = terms[k];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                const float* col = &s_tr[(lane & 15) * 65 + (lane >> 4) * 16];
+                float part = col[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) part += col[k];
+                typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                const v2u sa = __builtin_amdgcn_permlane32_swap(__float_as_uint(part), __float_as_uint(part), false, false);
+                const float s2 = __uint_as_float(sa.x) + __uint_as_float(sa.y);
+                const v2u sb = __builtin_amdgcn_permlane16_swap(__float_as_uint(s2), __float_as_uint(s2), false, false);
+                const float tot = __uint_as_float(sb.x) + __uint_as_float(sb.y);
+                if (lane < 16) s_acc[j * 16 + lane] = tot;
+                __builtin_amdgcn_wave_barrier();   // the next entry overwrites s_tr
+            }
+            if (HAS_GDIST) {
+                const float tot2 = wave_reduce_scatter16_all(extra, lane);
+                if (lane < 16) s_acc2[j * 16 + lane] = tot2;
+            }
+#elif GRUT_BWD_FULL_REDUCE
             // every lane ends with the wave total of term l & 15 (in-row DPP butterfly, then two lane-swap steps across the rows);
             // one row of 16 lanes parks the totals of the entry in LDS for the flush
             const float tot = wave_reduce_scatter16_all(terms, lane);
@@ -558,11 +593,16 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
                                                             GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
-                                                            const float4* __restrict__ fd, const float4* __restrict__ g_fd,
+                                                            const float4* __restrict__ fd, GutGradIn g_in,
                                                             const float* __restrict__ dist, const float* __restrict__ g_dist,
                                                             GutGradSlots slots, GutCheckpoints ck) {
     constexpr uint32_t kBatch = kBwdBatch;
     __shared__ float4 s_rec[kBatch * kRecQuads];
+#if GRUT_BWD_FULL_REDUCE == 2
+    __shared__ float s_tr[16 * 65];                            // transposition buffer of the per-entry reduction
+#else
+    float* s_tr = nullptr;
+#endif
 #if GRUT_BWD_FULL_REDUCE
     __shared__ float s_acc[kBatch * 16];                       // per staged entry: the wave totals of its 16 terms
     __shared__ float s_acc2[HAS_GDIST ? kBatch * 16 : 1];      // depth-gradient extras (3 terms used)
@@ -603,14 +643,14 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
     p3 C_fin = p3{splat(0.f), splat(0.f), splat(0.f)}, gC = C_fin;
     if (alive0) {
         const size_t pix = (size_t)rp.py0 * P.W + rp.px;
-        const float4 f = fd[pix], g = g_fd[pix];
+        const float4 f = fd[pix], g = load_grad_in(g_in, pix);
         C_fin.x.x = f.x; C_fin.y.x = f.y; C_fin.z.x = f.z; gC.x.x = g.x; gC.y.x = g.y; gC.z.x = g.z;
         T_fin.x = 1.f - f.w; gT.x = -g.w;
         if (HAS_GDIST) { D_fin.x = dist[pix]; gD.x = g_dist[pix]; }
     }
     if (alive1) {
         const size_t pix = (size_t)rp.py1 * P.W + rp.px;
-        const float4 f = fd[pix], g = g_fd[pix];
+        const float4 f = fd[pix], g = load_grad_in(g_in, pix);
         C_fin.x.y = f.x; C_fin.y.y = f.y; C_fin.z.y = f.z; gC.x.y = g.x; gC.y.y = g.y; gC.z.y = g.z;
         T_fin.y = 1.f - f.w; gT.y = -g.w;
         if (HAS_GDIST) { D_fin.y = dist[pix]; gD.y = g_dist[pix]; }
@@ -626,9 +666,9 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
 
     BwdPixels px{T, D, Cr, Cg, Cb, T_fin, D_fin, gT, gD, C_fin, gC, alive0, alive1};
     if (rp.uniform_origin)
-        render_bwd_sweep<DEG, HAS_GDIST, true>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, px);
+        render_bwd_sweep<DEG, HAS_GDIST, true>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, s_tr, px);
     else
-        render_bwd_sweep<DEG, HAS_GDIST, false>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, px);
+        render_bwd_sweep<DEG, HAS_GDIST, false>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, s_tr, px);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -947,7 +987,9 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
     }
     if (!BWD && ray.inside) {
         const size_t opix = (size_t)py * P.W + px;
-        out_fd[opix] = ray.valid ? make_float4(fs.Cr, fs.Cg, fs.Cb, 1.f - fs.T) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 o = ray.valid ? make_float4(fs.Cr, fs.Cg, fs.Cb, 1.f - fs.T) : make_float4(0.f, 0.f, 0.f, 0.f);
+        out_fd[opix] = o;
+        write_split_outputs(P, opix, o);
         out_dist[opix] = ray.valid ? fs.D : 1e6f;
         if (P.hitcounts) out_cnt[opix] = ray.valid ? fs.cnt : 0.f;
     }
@@ -1016,7 +1058,7 @@ void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
     }
 }
 void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const float* density12,
-                       const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* dist,
+                       const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const GutGradIn& g_fd, const float* dist,
                        const float* g_dist, const GutGradSlots& slots, const GutCheckpoints& ck) {
     const dim3 grid(segment_grid(P, ck.num_boundaries));
     const EntryLists lists{sorted_pos, slots.pos_particle};
@@ -1024,13 +1066,13 @@ void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
         GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_bwd_kernel<D_, true>), grid, dim3(64), 0, s, P,
                                                           reinterpret_cast<const uint2*>(ranges), lists,
                                                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
-                                                          reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
+                                                          reinterpret_cast<const float4*>(fd), g_fd, dist,
                                                           g_dist, slots, ck));
     } else {  // no depth gradient flows in: the hit-distance terms vanish identically
         GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_bwd_kernel<D_, false>), grid, dim3(64), 0, s, P,
                                                           reinterpret_cast<const uint2*>(ranges), lists,
                                                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
-                                                          reinterpret_cast<const float4*>(fd), reinterpret_cast<const float4*>(g_fd), dist,
+                                                          reinterpret_cast<const float4*>(fd), g_fd, dist,
                                                           g_dist, slots, ck));
     }
 }

@@ -139,11 +139,19 @@ class _GutNative:
             out_dist = _uninitialised((H, W, 1), **opts)
             out_cnt = _uninitialised((H, W, 1), **opts) if self.cfg.enable_hitcounts else torch.zeros((H, W, 1), **opts)
             vis_i32 = _uninitialised((N, 1), dtype=torch.int32, device=dev)
+        # `pred_features` / `pred_opacity` as contiguous tensors of their own, like the reference's `.contiguous()` slices
+        # (tracer.py:334-337), written by the compositing kernel next to the packed image the backward reads
+        if N == 0:
+            out_feat, out_opa = torch.zeros((H, W, 3), **opts), torch.zeros((H, W, 1), **opts)
+        else:
+            out_feat, out_opa = _uninitialised((H, W, 3), **opts), _uninitialised((H, W, 1), **opts)
+        frame.out_features, frame.out_opacity = out_feat.data_ptr(), out_opa.data_ptr()
         _abi.check(self.lib.gut_forward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
                                         _ptr(ray_ori), _ptr(ray_dir), _ptr(out_fd), _ptr(out_dist), _ptr(out_cnt), _ptr(vis_i32)),
                    "gut_forward")
         # the reference returns a float tensor holding the int bit pattern (splatRaster.cpp:215,249); consumers call .bool()
-        return out_fd, out_dist, out_cnt, vis_i32.view(torch.float32)
+        frame.out_features, frame.out_opacity = None, None   # the frame outlives this call in the autograd context
+        return out_fd, out_dist, out_cnt, vis_i32.view(torch.float32), out_feat, out_opa
 
     def trace_bwd(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_fd, dist, g_dist):
         dev = ray_ori.device
@@ -153,6 +161,20 @@ class _GutNative:
                                          _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(g_fd), _ptr(dist), _ptr(g_dist),
                                          _ptr(g_density), _ptr(g_sph)), "gut_backward")
         return g_density, g_sph
+
+    def trace_bwd_unpacked(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_feat, g_opa, dist, g_dist):
+        """gut_backward_unpacked: upstream gradients as autograd hands them over ([H,W,3] / [H,W,1], either may be None), particle
+        gradients written straight into the model's four tensor shapes — no concatenation before, no unpack pass after."""
+        dev = ray_ori.device
+        n = particle_density.shape[0]
+        opts = dict(dtype=torch.float32, device=dev)
+        g_pos, g_dns, g_rot, g_scl = torch.empty((n, 3), **opts), torch.empty((n, 1), **opts), torch.empty((n, 4), **opts), torch.empty((n, 3), **opts)
+        g_sph = torch.empty_like(particle_sph)
+        io = _abi.GutGradIO(_ptr(g_feat), _ptr(g_opa), _ptr(g_pos), _ptr(g_dns), _ptr(g_rot), _ptr(g_scl))
+        _abi.check(self.lib.gut_backward_unpacked(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
+                                                  _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(dist), _ptr(g_dist), C.byref(io), _ptr(g_sph)),
+                   "gut_backward_unpacked")
+        return g_pos, g_dns, g_rot, g_scl, g_sph
 
     def trace_bwd_factored(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_fd, dist, g_dist):
         """gut_backward_factored: (packed gradient [N,12], view factor [N+1,3]) — see 3dgrut_amd/dp.py."""
@@ -192,13 +214,14 @@ class Tracer:
                 particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)  # [N,12] rows, one pass (tracer.py's torch.cat)
             ctx.raw = (mog_dns, mog_rot, mog_scl) if raw else None
             particle_features = mog_sph.contiguous()
-            fd, dist, cnt, vis = native.trace(frame, particle_density, particle_features, ray_ori, ray_dir)
+            fd, dist, cnt, vis, feat, opa = native.trace(frame, particle_density, particle_features, ray_ori, ray_dir)
             ctx.save_for_backward(ray_ori, ray_dir, fd, dist, particle_density, particle_features)
             ctx.native, ctx.frame, ctx.exchange = native, frame, exchange
-            # the op hands out features and opacity as separate tensors (what render() returns), so that autograd does not
-            # have to route their gradients back through slice / contiguous nodes
-            feat = fd[..., :3].unsqueeze(0)   # views of the packed output, as tracer.py:327-328 returns them
-            opa = fd[..., 3:].unsqueeze(0)
+            # the op hands out features and opacity as separate CONTIGUOUS tensors (what render() returns, tracer.py:334-337), so
+            # that autograd does not have to route their gradients back through slice / contiguous nodes and callers may
+            # .view() or modify them in place
+            feat = feat.unsqueeze(0)
+            opa = opa.unsqueeze(0)
             ctx.mark_non_differentiable(cnt, vis)
             ctx.set_materialize_grads(False)
             return feat, opa, dist, cnt, vis
@@ -207,12 +230,20 @@ class Tracer:
         def backward(ctx, g_feat, g_opa, g_dist, _g_cnt, _g_vis):
             ray_ori, ray_dir, fd, dist, particle_density, particle_features = ctx.saved_tensors
             H, W = fd.shape[0], fd.shape[1]
-            g_feat = fd.new_zeros((H, W, 3)) if g_feat is None else g_feat.reshape(H, W, 3)
-            g_opa = fd.new_zeros((H, W, 1)) if g_opa is None else g_opa.reshape(H, W, 1)
-            g_fd = torch.cat([g_feat, g_opa], dim=-1)
             # g_dist is None when the loss never touched pred_dist: the library then runs the variant without
             # hit-distance terms (autograd materialises zeros unless told otherwise, see set_materialize_grads)
             g_dist = None if g_dist is None else g_dist.contiguous()
+            if ctx.exchange is None and ctx.raw is None and int(ctx.native.cfg.k_buffer_size) == 0:
+                # the usual training path: gradients cross the boundary in autograd's own shapes (the reference concatenates the two
+                # upstream gradients and slices the packed result apart again, tracer.py:226-285: two passes saved per iteration)
+                g_pos, g_dns, g_rot, g_scl, g_sph = ctx.native.trace_bwd_unpacked(
+                    ctx.frame, particle_density, particle_features, ray_ori, ray_dir, fd,
+                    None if g_feat is None else g_feat.reshape(H, W, 3).contiguous(), None if g_opa is None else g_opa.reshape(H, W, 1).contiguous(),
+                    dist, g_dist)
+                return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_sph, None, None
+            g_feat = fd.new_zeros((H, W, 3)) if g_feat is None else g_feat.reshape(H, W, 3)
+            g_opa = fd.new_zeros((H, W, 1)) if g_opa is None else g_opa.reshape(H, W, 1)
+            g_fd = torch.cat([g_feat, g_opa], dim=-1)
             if ctx.exchange is None:
                 g_density, g_sph = ctx.native.trace_bwd(ctx.frame, particle_density, particle_features, ray_ori, ray_dir, fd, g_fd, dist, g_dist)
             else:

@@ -109,6 +109,11 @@ typedef struct GutFrame {
      * the caller never has to read the pose back to the host (the reference's `.cpu()` there drains the stream). */
     const float* device_T_to_world;
     const float* device_T_to_world_end; /* NULL: static sensor (end = start) */
+    /* Optional extra outputs of gut_forward (device pointers, may be NULL): the radiance [H,W,3] and the opacity [H,W,1] as
+     * separate CONTIGUOUS tensors next to out_feat_density [H,W,4] — what the reference plugin returns as `pred_features` /
+     * `pred_opacity` after `.contiguous()` (tracer.py:334-337), written by the compositing kernel itself. */
+    float* out_features;
+    float* out_opacity;
 } GutFrame;
 
 /* Measured work of the last forward (for the roofline byte model). */
@@ -151,6 +156,26 @@ int gut_backward(GutHandle* handle, void* stream, const GutFrame* frame,
                  const float* feat_density, const float* grad_feat_density,
                  const float* hit_distance, const float* grad_hit_distance,
                  float* grad_particle_density, float* grad_particle_sph);
+
+/* gut_backward with the gradient tensors in the CALLER's layout instead of the reference's packed one (new surface; the reference
+ * plugin concatenates the two upstream gradients into [H,W,4] and slices the packed [N,12] result apart again,
+ * threedgut_tracer/tracer.py:226-285 — two extra passes per iteration that this entry point makes unnecessary):
+ *   grad_features [H,W,3], grad_opacity [H,W,1]: upstream gradients as autograd delivers them; either may be NULL (= zero);
+ *   grad_positions [N,3], grad_density [N,1], grad_rotation [N,4] (16-byte aligned), grad_scale [N,3]: fully overwritten.
+ * Same preconditions, errors and results (bit for bit) as gut_backward; k_buffer_size > 0 is GRUT_ERR_UNSUPPORTED here. */
+typedef struct GutGradIO {
+    const float* grad_features;
+    const float* grad_opacity;
+    float* grad_positions;
+    float* grad_density;
+    float* grad_rotation;
+    float* grad_scale;
+} GutGradIO;
+int gut_backward_unpacked(GutHandle* handle, void* stream, const GutFrame* frame,
+                          const float* particle_density, const float* particle_sph,
+                          const float* ray_origin, const float* ray_direction,
+                          const float* feat_density, const float* hit_distance, const float* grad_hit_distance,
+                          const GutGradIO* io, float* grad_particle_sph);
 
 /* ---- view-sharded data parallelism: the radiance gradient in factored form (new surface; the reference is
  * single-GPU) ------------------------------------------------------------------------------------------------------------------

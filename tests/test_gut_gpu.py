@@ -562,3 +562,55 @@ def test_forward_matches_reference_kernels_golden_variants(case):
     _image_checks(out, dict(feat_density=g[f"{case}_feat_density"], hit_distance=g[f"{case}_hit_distance"]), max_flip_frac=5e-3)
     cnt = out["hits_count"][0, ..., 0].detach().cpu().numpy()
     assert (cnt != g[f"{case}_hit_count"][..., 0]).mean() < 1e-2
+
+
+@pytest.mark.parametrize("with_depth_grad,with_opacity_grad", [(False, True), (True, True), (False, False)])
+def test_unpacked_backward_is_the_packed_backward_bit_for_bit(with_depth_grad, with_opacity_grad):
+    """gut_backward_unpacked (split upstream gradients in, the model's four gradient tensors out: what the plugin calls on the
+    training path) against gut_backward (the reference's packed [H,W,4] / [N,12] layout) on one forward context."""
+    import torch
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    scene = make_scene(n=6000, width=112, height=72, median_scale=0.05)
+    nat = gt._GutNative(gt.gut_config_from_conf({"render": {"splat": {}}}))
+    n, W, H = scene["density12"].shape[0], scene["W"], scene["H"]
+    frame = nat.make_frame(7, 3, n, H, W, scene["cam"], scene["pose_start"], scene["pose_end"])
+    d12 = torch.as_tensor(scene["density12"], device="cuda")
+    sph = torch.as_tensor(scene["sph"], device="cuda")
+    ro, rd = (torch.as_tensor(r[0], device="cuda").contiguous() for r in scene["rays"])
+    fd, dist, cnt, vis, feat, opa = nat.trace(frame, d12, sph, ro, rd)
+    # the contiguous copies the plugin hands out are the packed image's channels
+    assert feat.is_contiguous() and opa.is_contiguous()
+    assert torch.equal(feat, fd[..., :3]) and torch.equal(opa, fd[..., 3:])
+    rng = np.random.default_rng(2)
+    g_feat = torch.as_tensor(rng.normal(size=(H, W, 3)).astype(np.float32), device="cuda")
+    g_opa = torch.as_tensor(rng.normal(size=(H, W, 1)).astype(np.float32), device="cuda") if with_opacity_grad else None
+    g_dist = torch.as_tensor((rng.normal(size=(H, W, 1)) * 0.1).astype(np.float32), device="cuda") if with_depth_grad else None
+    g_fd = torch.cat([g_feat, g_opa if g_opa is not None else torch.zeros((H, W, 1), device="cuda")], dim=-1)
+    gd, gs = nat.trace_bwd(frame, d12, sph, ro, rd, fd, g_fd, dist, g_dist)
+    g_pos, g_dns, g_rot, g_scl, gs2 = nat.trace_bwd_unpacked(frame, d12, sph, ro, rd, fd, g_feat, g_opa, dist, g_dist)
+    torch.cuda.synchronize()
+    assert float(gd.abs().max()) > 0
+    assert torch.equal(g_pos, gd[:, 0:3]) and torch.equal(g_dns, gd[:, 3:4]) and torch.equal(g_rot, gd[:, 4:8]) and torch.equal(g_scl, gd[:, 8:11])
+    assert torch.equal(gs, gs2)
+
+
+def test_plugin_outputs_are_contiguous_and_safe_to_modify():
+    """`pred_features` / `pred_opacity` are contiguous tensors of their own like the reference's (tracer.py:334-337): `.view()` and
+    in-place edits (e.g. compositing a background into them) work and do not disturb the backward."""
+    import torch
+    scene = make_scene(n=3000, width=80, height=48, median_scale=0.06)
+    g_fd, _ = syn.upstream_grads(80, 48)
+    g_fd *= 80 * 48
+    ref = _run_gpu(scene, g_fd)["grads"]
+    tr = _tracer()
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+    out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
+    assert out["pred_features"].is_contiguous() and out["pred_opacity"].is_contiguous()
+    flat = out["pred_features"].view(-1, 3)          # raises on a non-contiguous slice
+    fd = torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0]
+    loss = (fd * torch.as_tensor(g_fd, device="cuda")).sum()
+    with torch.no_grad():
+        flat.clamp_(0.0, 1.0)                          # in place, after the graph was recorded
+    loss.backward()
+    gd, gs = g.grads_packed()
+    assert np.array_equal(gd, ref[0]) and np.array_equal(gs, ref[1])
