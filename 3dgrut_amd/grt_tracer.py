@@ -46,6 +46,9 @@ class _GrtNative:
     """Owns the C handle (role of lib3dgrt_cc.OptixTracer)."""
 
     def __init__(self, cfg: _abi.GrtConfig):
+        if not torch.cuda.is_available():
+            raise RuntimeError("3dgrut_amd.Tracer needs a ROCm GPU (there is no CPU fallback)")
+        torch.zeros(1, device="cuda")
         self.lib = _abi.load_library()
         self.cfg = cfg
         self.handle = C.c_void_p()
@@ -161,9 +164,6 @@ class Tracer:
         self.device = "cuda"
         self.conf = conf
         self.num_update_bvh = 0
-        if not torch.cuda.is_available():
-            raise RuntimeError("3dgrut_amd.Tracer needs a ROCm GPU (there is no CPU fallback)")
-        torch.zeros(1, device=self.device)
         render = _conf_get(conf, "render")
         self._clamping = bool(_conf_get(render, "particle_kernel_density_clamping", True))
         self._max_updates = int(_conf_get(render, "max_consecutive_bvh_update", 15))

@@ -97,6 +97,9 @@ class _GutNative:
     """Owns the C handle (role of lib3dgut_cc.SplatRaster)."""
 
     def __init__(self, cfg: _abi.GutConfig):
+        if not torch.cuda.is_available():
+            raise RuntimeError("3dgrut_amd.Tracer needs a ROCm GPU (there is no CPU fallback)")
+        torch.zeros(1, device="cuda")  # force context creation (tracer.py:292)
         self.lib = _abi.load_library()
         self.cfg = cfg
         self.handle = C.c_void_p()
@@ -265,10 +268,7 @@ class Tracer:
     def __init__(self, conf):
         self.device = "cuda"
         self.conf = conf
-        if not torch.cuda.is_available():
-            raise RuntimeError("3dgrut_amd.Tracer needs a ROCm GPU (there is no CPU fallback)")
-        torch.zeros(1, device=self.device)  # force context creation (tracer.py:292)
-        self.tracer_wrapper = _GutNative(gut_config_from_conf(conf))
+        self.tracer_wrapper = _GutNative(gut_config_from_conf(conf))   # raises without a ROCm GPU: there is no CPU fallback
         self._fused_activations = fused_activations_requested(conf)
         # set to a 3dgrut_amd.dp.FactoredGradientExchange to have the backward exchange its gradients across ranks (one view
         # per GPU); None (default) = single-GPU behaviour, exactly the reference's
