@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrut_amd.so")
 
@@ -63,6 +63,8 @@ class GutStats(C.Structure):
     _fields_ = [
         ("num_particles", C.c_uint32), ("num_visible", C.c_uint32), ("num_intersections", C.c_uint64),
         ("num_tiles", C.c_uint32), ("key_bits", C.c_uint32),
+        ("fwd_entries_evaluated", C.c_uint64), ("fwd_entries_accepted", C.c_uint64),
+        ("bwd_entries_evaluated", C.c_uint64), ("bwd_entries_accepted", C.c_uint64),
     ]
 
 

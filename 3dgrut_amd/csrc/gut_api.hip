@@ -60,6 +60,10 @@ struct GutHandle {
     EventTimer fwd_timer, bwd_timer;
     // per-stage profiling (gut_profile_enable)
     bool profile = false;
+    bool count_work = false;            // gut_profile_enable(handle, 2): the sweeps count their evaluated / accepted entries
+    DeviceBuffer work_counters;
+    unsigned long long work_host[4] = {0, 0, 0, 0};
+    bool work_pending = false;
     static constexpr int kProfRing = 64;
     hipEvent_t prof_ev[kProfRing][GUT_NUM_STAGES][2];
     bool prof_used[kProfRing][GUT_NUM_STAGES];
@@ -125,6 +129,7 @@ static GutParams make_params(const GutConfig& c, const GutFrame& f) {
     P.cam = f.camera;
     P.poses = make_frame_poses(f.pose_start, f.pose_end);
     P.poses_dev = nullptr;
+    P.work = nullptr;
     P.out_features = f.out_features;
     P.out_opacity = f.out_opacity;
     return P;
@@ -222,7 +227,7 @@ void gut_destroy(GutHandle* h) {
     DeviceBuffer* bufs[] = {&h->tiles_count, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->rgb, &h->depth_key,
                             &h->particle_idx, &h->depth_key_tmp, &h->particle_idx_tmp, &h->offsets, &h->sort_scratch,
                             &h->scan_scratch, &h->counters, &h->part_offset, &h->pos_particle, &h->grad_partial, &h->grad_flag,
-                            &h->g_rgb, &h->poses_dev, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
+                            &h->g_rgb, &h->poses_dev, &h->work_counters, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
                             &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges, &h->ck_tc, &h->ck_d, &h->ck_reached,
                             &h->ck_boundary_tile};
     for (DeviceBuffer* b : bufs) b->release();
@@ -274,6 +279,12 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         GRUT_CHECK(h->poses_dev.ensure(sizeof(FramePoses)));
         launch_frame_poses(s, frame->device_T_to_world, frame->device_T_to_world_end, h->poses_dev.as<FramePoses>());
         h->params.poses_dev = h->poses_dev.as<FramePoses>();
+    }
+    if (h->count_work) {
+        GRUT_CHECK(h->work_counters.ensure(64));
+        GRUT_HIP(hipMemsetAsync(h->work_counters.ptr, 0, 64, s));
+        h->params.work = h->work_counters.as<unsigned long long>();
+        h->work_pending = true;
     }
     const GutProjected proj = projected_view(h);
     uint32_t* d_counters = h->counters.as<uint32_t>();   // [1] = visible particles: zero at allocation, re-armed by the tail preparation
@@ -516,6 +527,7 @@ int gut_profile_enable(GutHandle* h, int enable) {
         h->prof_created = 1;
     }
     h->profile = enable != 0;
+    h->count_work = enable >= 2;
     return GRUT_OK;
 }
 
@@ -542,7 +554,16 @@ int gut_profile_read(GutHandle* h, float* stage_ms) {
 
 int gut_stats(GutHandle* h, GutStats* stats) {
     GRUT_REQUIRE(h && stats, "gut_stats: null argument");
+    if (h->work_pending && h->work_counters.ptr) {   // instrumented frame: fetch the sweeps' counters (synchronises with the frame's stream)
+        GRUT_HIP(hipMemcpyAsync(h->work_host, h->work_counters.ptr, 32, hipMemcpyDeviceToHost, h->fwd_stream));
+        GRUT_HIP(hipStreamSynchronize(h->fwd_stream));
+        h->work_pending = false;
+    }
     *stats = h->stats;
+    stats->fwd_entries_evaluated = h->count_work ? h->work_host[0] : 0;
+    stats->fwd_entries_accepted = h->count_work ? h->work_host[1] : 0;
+    stats->bwd_entries_evaluated = h->count_work ? h->work_host[2] : 0;
+    stats->bwd_entries_accepted = h->count_work ? h->work_host[3] : 0;
     return GRUT_OK;
 }
 

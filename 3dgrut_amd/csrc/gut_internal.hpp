@@ -17,6 +17,7 @@ struct GutParams {
     uint32_t N;
     GrutCamera cam;
     FramePoses poses;             // derived on the host from GutFrame::pose_start / pose_end ...
+    unsigned long long* work;     // optional device counters {fwd evaluated, fwd accepted, bwd evaluated, bwd accepted} (gut_profile_enable level 2)
     float* out_features;          // optional contiguous copies of the radiance / opacity outputs (GutFrame::out_features / out_opacity)
     float* out_opacity;
     const FramePoses* poses_dev;  // ... or on the device from GutFrame::device_T_to_world[_end] (then this is non-null)

@@ -253,13 +253,14 @@ __device__ __forceinline__ void write_split_outputs(const GutParams& P, size_t p
 struct FwdState {
     v2f T, D, Cr, Cg, Cb, cnt;
 };
-template <int DEG, bool CKPT, bool UNI>
+template <int DEG, bool CKPT, bool UNI, bool COUNT = false>
 __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPair& rp, uint2 range, uint32_t half, int lane,
                                                  const EntryLists& lists, const float4* __restrict__ density12,
                                                  const float* __restrict__ rgb, const GutCheckpoints& ck, float4* __restrict__ s_rec,
                                                  FwdState& st) {
     bool alive0 = rp.valid0, alive1 = rp.valid1;
     v2f T = splat(1.f), D = splat(0.f), Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f), cnt = splat(0.f);
+    uint32_t n_eval = 0u, n_acc = 0u;   // wave-uniform work counters (scalar registers), reported when P.work is set
     uint32_t b = range.x;
     RawEntry next = load_entry(b + lane, min(range.y, (b & ~63u) + 64u), lists, density12, rgb);
     while (b < range.y) {
@@ -284,7 +285,9 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
             const float4* rec = &s_rec[j * kRecQuads];
             const PairGeom g = pair_geometry<UNI>(rp, rec);
             const bool c0 = g.acc0 && alive0, c1 = g.acc1 && alive1;
+            if (COUNT) ++n_eval;
             if (!__any(c0 || c1)) continue;
+            if (COUNT) ++n_acc;
             const float4 r3 = rec[3], r4 = rec[4];
             const v2f il2 = prcp(g.l2);
             const v2f gray = g.cc * il2;
@@ -313,9 +316,10 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         b = bend;
     }
     st = FwdState{T, D, Cr, Cg, Cb, cnt};
+    if (COUNT && P.work && lane == 0) { atomicAdd(&P.work[0], (unsigned long long)n_eval); atomicAdd(&P.work[1], (unsigned long long)n_acc); }
 }
 
-template <int DEG, bool CKPT>
+template <int DEG, bool CKPT, bool COUNT = false>
 __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
@@ -330,8 +334,8 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
     const uint2 range = ranges[tile];
     FwdState st;
     // two copies of the sweep: the shared-origin one keeps the canonical origin out of the per-pixel math
-    if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
-    else render_fwd_sweep<DEG, CKPT, false>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
+    if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
+    else render_fwd_sweep<DEG, CKPT, false, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
     // every pixel of the image is written (the caller does not pre-fill): rays that miss the scene box get the reference's
     // initial values (splatRaster.cpp:211-214)
     if (rp.inside0) {
@@ -375,7 +379,7 @@ struct BwdPixels {
     p3 C_fin, gC;
     bool alive0, alive1;
 };
-template <int DEG, bool HAS_GDIST, bool UNI>
+template <int DEG, bool HAS_GDIST, bool UNI, bool COUNT = false>
 __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPair& rp, uint32_t seg_begin, uint32_t seg_end, int lane,
                                                  uint32_t half, const EntryLists& lists, const float4* __restrict__ density12,
                                                  const float* __restrict__ rgb, const GutGradSlots& slots,
@@ -386,6 +390,7 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
     const v2f T_fin = px.T_fin, D_fin = px.D_fin, gT = px.gT, gD = px.gD;
     const p3 C_fin = px.C_fin, gC = px.gC;
     bool alive0 = px.alive0, alive1 = px.alive1;
+    uint32_t n_eval = 0u, n_acc = 0u;
     v2f iT = prcp(T);   // running 1 / T (a dead pixel restarts with T = 0: its reciprocal is never used, see inextT)
     uint32_t b = seg_begin;
     RawEntry next = load_entry(b + lane, min(seg_end, (b & ~(kBatch - 1u)) + kBatch), lists, density12, rgb);
@@ -402,7 +407,9 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
             const float4* rec = &s_rec[j * kRecQuads];
             const PairGeom g = pair_geometry<UNI>(rp, rec);
             const bool h0 = g.acc0 && alive0, h1 = g.acc1 && alive1;
+            if (COUNT) ++n_eval;
             if (!__any(h0 || h1)) continue;
+            if (COUNT) ++n_acc;
             hit_entries |= (1u << j);
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4];
             const v2f il2 = prcp(g.l2);
@@ -582,9 +589,10 @@ __device__ __forceinline__ void render_bwd_sweep(const GutParams& P, const RayPa
         __syncthreads();
         b = bend;
     }
+    if (COUNT && P.work && lane == 0) { atomicAdd(&P.work[2], (unsigned long long)n_eval); atomicAdd(&P.work[3], (unsigned long long)n_acc); }
 }
 
-template <int DEG, bool HAS_GDIST>
+template <int DEG, bool HAS_GDIST, bool COUNT = false>
 #if GRUT_BWD_WAVES   // the depth-gradient variant (not the training path) needs ~160 registers: it keeps its 3 waves per SIMD
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HAS_GDIST ? 3 : GRUT_BWD_WAVES, HAS_GDIST ? 3 : GRUT_BWD_WAVES))) void gut_render_bwd_kernel(
 #else
@@ -666,9 +674,9 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
 
     BwdPixels px{T, D, Cr, Cg, Cb, T_fin, D_fin, gT, gD, C_fin, gC, alive0, alive1};
     if (rp.uniform_origin)
-        render_bwd_sweep<DEG, HAS_GDIST, true>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, s_tr, px);
+        render_bwd_sweep<DEG, HAS_GDIST, true, COUNT>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, s_tr, px);
     else
-        render_bwd_sweep<DEG, HAS_GDIST, false>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, s_tr, px);
+        render_bwd_sweep<DEG, HAS_GDIST, false, COUNT>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, s_tr, px);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1045,6 +1053,11 @@ void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
                        const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                        float* out_cnt, const GutCheckpoints& ck, bool write_checkpoints) {
     const EntryLists lists{sorted_pos, pos_particle};
+    if (P.work && P.degree == 2 && write_checkpoints) {   // instrumented frame (gut_profile_enable level 2): the counting build of the default kernel
+        hipLaunchKernelGGL((gut_render_fwd_kernel<2, true, true>), dim3(half_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
+                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d, reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck);
+        return;
+    }
     if (write_checkpoints) {
         GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_fwd_kernel<D_, true>), dim3(half_grid(P)), dim3(64), 0, s, P,
                                                           reinterpret_cast<const uint2*>(ranges), lists,
@@ -1062,6 +1075,11 @@ void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
                        const float* g_dist, const GutGradSlots& slots, const GutCheckpoints& ck) {
     const dim3 grid(segment_grid(P, ck.num_boundaries));
     const EntryLists lists{sorted_pos, slots.pos_particle};
+    if (P.work && P.degree == 2 && !g_dist) {   // instrumented frame: the counting build of the training-path kernel
+        hipLaunchKernelGGL((gut_render_bwd_kernel<2, false, true>), grid, dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
+                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d, reinterpret_cast<const float4*>(fd), g_fd, dist, g_dist, slots, ck);
+        return;
+    }
     if (g_dist) {
         GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_bwd_kernel<D_, true>), grid, dim3(64), 0, s, P,
                                                           reinterpret_cast<const uint2*>(ranges), lists,

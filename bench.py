@@ -56,14 +56,32 @@ def byte_model(N, Nv, I, P, tile_bits, sph_coeffs=16):
 
 
 def valu_fraction(stage, kernel_ms):
-    """Fraction of the VALU issue slots the dominant kernel used, from the committed SQ_INSTS_VALU count of the same launch."""
-    path = os.path.join(ROOT, "profiles", "sq_insts_valu.json")
+    """Share of the kernel's duration that its VALU instructions alone keep the SIMDs busy.  Dynamic count: rocprofv3 SQ_INSTS_VALU
+    of the same launch (profiles/sq_insts_valu.json); cost per instruction: the kernel's static instruction mix priced with the
+    wave64 issue times MEASURED on this chip (scripts/valu_calib.hip -> profiles/r02a_valu_calib.json; scripts/valu_model.py ->
+    profiles/valu_model.json): v_mul 1.14 ns, v_fma 1.73 ns, v_pk_* 2.2 ns, v_exp / v_rcp 3.4 ns per instruction per SIMD at
+    saturation — not the 2 cycles a datasheet suggests for every fp32 op."""
     try:
-        insts = json.load(open(path))[stage]
+        insts = json.load(open(os.path.join(ROOT, "profiles", "sq_insts_valu.json")))[stage]
+        model = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))["kernels"][stage]
     except Exception:
         return None
-    simd_cycles = 1024 * 2.4e9 * kernel_ms * 1e-3
-    return {"insts_valu": insts, "cycles_per_inst": 4, "frac": insts * 4 / simd_cycles, "source": "profiles/sq_insts_valu.json"}
+    busy_ms = insts / 1024.0 * model["avg_ns_per_instruction"] * 1e-6
+    return {"insts_valu": insts, "avg_ns_per_inst": model["avg_ns_per_instruction"], "mix": model["mix"], "busy_ms_per_simd": busy_ms,
+            "frac": busy_ms / kernel_ms, "source": "profiles/sq_insts_valu.json x profiles/valu_model.json (profiles/r02a_valu_calib.json)"}
+
+
+def touched_bytes(stage, st, P, I):
+    """Bytes a sweep can actually touch: it stops at the rays' termination, so it evaluates E << I tile-list entries (counted on the
+    device in one instrumented frame, GutStats.fwd/bwd_entries_*).  Per evaluated entry of a half-tile wave: 4 B list entry + 4 B
+    particle index + 48 B particle row + 12 B radiance = 68 B; per accepted entry of the gradient sweep: one 64-B slot + 1 flag byte;
+    per pixel: rays 24 B + outputs 24 B (forward) or rays 24 B + image 16 B + upstream gradient 16 B + (checkpoint 40 B per pixel and
+    256-entry segment started) in the gradient sweep."""
+    if stage == "render_fwd" and st.fwd_entries_evaluated:
+        return int(st.fwd_entries_evaluated) * 68 + P * 48 + (int(st.fwd_entries_evaluated) // 256) * 128 * 20
+    if stage == "render_bwd" and st.bwd_entries_evaluated:
+        return int(st.bwd_entries_evaluated) * 68 + int(st.bwd_entries_accepted) * 65 + P * 56 + (int(st.bwd_entries_evaluated) // 256) * 128 * 20 + 2 * I
+    return None
 
 
 def cpu_baseline(seconds_budget=20.0):
@@ -113,9 +131,11 @@ def grt_roofline(work, P, stages):
     return r
 
 
-def bench_grt(args, world, rank, dev, dist, n, W, H, ms):
+def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
     """3DGRT: BVH build + forward + backward of one view per GPU per step (the reference rebuilds the BVH every iteration,
-    trainer.py:1257-1263).  Traversal is latency / divergence bound; the line reports rays/s and per-stage ms."""
+    trainer.py:1257-1263).  Traversal is latency / divergence bound; the line reports rays/s and per-stage ms.
+    emit=False: return the result object instead of printing it (the `secondary` entry of the default bench line)."""
+    name = name or args.workload
     syn = importlib.import_module("3dgrut_amd.synthetic")
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     from scenes import torch_batch
@@ -171,17 +191,21 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     stages = tracer.timings
+    result = None
     if rank == 0:
         P = W * H
-        print(json.dumps({
+        result = {
             "metric": "train rays/sec (3DGRT software-BVH forward+backward, primary rays)", "value": world * P * args.steps / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"3DGRT BVH build + fwd + bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "
-                                   f"SH degree 3, k = 16 hits per trace", "name": args.workload, "parallelism": f"view-dp{world}"},
-            "roofline": grt_roofline(work, P, stages), "stages_ms": stages, "work": work}), flush=True)
-    if world > 1:
+                                   f"SH degree 3, k = 16 hits per trace", "name": name, "parallelism": f"view-dp{world}"},
+            "roofline": grt_roofline(work, P, stages), "stages_ms": stages, "work": work}
+        if emit:
+            print(json.dumps(result), flush=True)
+    if world > 1 and emit:
         dist.destroy_process_group()
+    return result
 
 
 def main():
@@ -191,6 +215,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c4_1m_1080p", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short 3DGRT (BASELINE config 3) measurement appended to the default line")
     ap.add_argument("--k-buffer", type=int, default=0, help="3DGUT sorted mode (render.splat.k_buffer_size); 0 = the headline configuration")
     args = ap.parse_args()
 
@@ -256,7 +281,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # one instrumented frame outside the timed region: the sweeps count the tile entries they evaluate / accept (roofline.touched_bytes)
+    abi.check(nat.lib.gut_profile_enable(nat.handle, 2), "gut_profile_enable")
+    step()
+    torch.cuda.synchronize()
+    work = nat.stats()
     abi.check(nat.lib.gut_profile_enable(nat.handle, 1), "gut_profile_enable")
+    step()   # back on the uninstrumented kernels before timing
+    abi.check(nat.lib.gut_profile_read(nat.handle, (C.c_float * len(abi.GUT_STAGES))()), "gut_profile_read")   # drop the two frames' stage times
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -290,6 +322,7 @@ def main():
                 traffic = json.load(open(pmc)).get(args.workload, {}).get(dom)
             except Exception:
                 traffic = None
+        touched = touched_bytes(dom, work, P, int(st.num_intersections))
         total_bytes = sum(model.values())
         result = {
             "metric": "train rays/sec (3DGUT forward+backward, primary rays)",
@@ -308,11 +341,20 @@ def main():
                                    f"SH degree 3, k_buffer {args.k_buffer}", "name": args.workload,
                        "parallelism": f"view-dp{world}" + ({"factored": " + RCCL all-reduce [N,12] + all-gather of view factors [N+1,3]",
                                                                   "none": ""}.get(exchange_kind, " + RCCL grad all-reduce [N,59]"))},
-            "roofline": {"bound": "hbm", "kernel": f"gut_{dom}", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": model[dom], "kernel_ms": stages[dom]},
-            # the compositing sweeps are bound by fp32 VALU issue, not by HBM: wave-level VALU instructions per
-            # launch (rocprofv3 SQ_INSTS_VALU, profiles/) x 4 cycles / (1024 SIMDs x 2.4 GHz) against the measured kernel time
+            # `achieved` / `frac`: bytes the kernel can actually touch (evaluated entries, counted on the device) / its duration.
+            # `model_*`: SURVEY §8d's per-entry byte model applied to ALL I tile entries — an upper bound that charges the 88 % of the
+            # entries behind the rays' termination, which no kernel reads.  `traffic`: HBM bytes from rocprofv3 PMC (2 x FETCH_SIZE +
+            # WRITE_SIZE, profiles/pmc_traffic.json), `frac_traffic` = traffic / duration / peak.
+            "roofline": {"bound": "hbm", "kernel": f"gut_{dom}",
+                         "achieved": (touched if touched else model[dom]) / (stages[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (touched if touched else model[dom]) / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "touched_bytes": touched, "traffic": traffic,
+                         "frac_traffic": (traffic / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "model_bytes": model[dom], "model_frac": achieved / HBM_PEAK_GBS, "kernel_ms": stages[dom],
+                         "entries": {"I": int(st.num_intersections), "fwd_evaluated": int(work.fwd_entries_evaluated),
+                                     "fwd_accepted": int(work.fwd_entries_accepted), "bwd_evaluated": int(work.bwd_entries_evaluated),
+                                     "bwd_accepted": int(work.bwd_entries_accepted)}},
+            # the compositing sweeps are bound by fp32 VALU issue, not by HBM: see valu_fraction()
             "valu": valu_fraction(dom, stages[dom]),
             "stages_ms": stages,
             "stage_bytes": model,
@@ -323,6 +365,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not args.no_secondary and args.workload == "c4_1m_1080p":
+            # BASELINE config 3 in the same line (the driver runs the default command only): 3DGRT software-BVH primary rays,
+            # BVH rebuilt + forward + backward per step, 1 M Gaussians at 800x800 — few steps, ~1 s
+            sec = argparse.Namespace(steps=5, warmup=2, workload="c3_grt_1m_800")
+            gn, gw, gh, gms = WORKLOADS["c3_grt_1m_800"]
+            r = bench_grt(sec, 1, 0, dev, None, gn, gw, gh, gms, name="c3_grt_1m_800", emit=False)
+            result["secondary"] = {"c3_grt_1m_800": {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "stages_ms",
+                                                                        "roofline", "work")}}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -123,6 +123,13 @@ typedef struct GutStats {
     uint64_t num_intersections;  /* I  */
     uint32_t num_tiles;
     uint32_t key_bits;           /* bits of the tile part of the sort key */
+    /* Work the two compositing sweeps actually did in the last frame, counted on the device when gut_profile_enable(handle, 2)
+     * is in effect (0 otherwise): tile-list entries a half-tile wave EVALUATED (each one a 68-byte fetch: list entry, particle row,
+     * radiance) and, of those, the entries at least one of its 128 pixels ACCEPTED (each one a 64-byte gradient slot in the
+     * backward).  A sweep stops at the rays' termination, so these are far below the list length I; the roofline of the sweeps
+     * is priced with them (bench.py: roofline.touched_bytes). */
+    uint64_t fwd_entries_evaluated, fwd_entries_accepted;
+    uint64_t bwd_entries_evaluated, bwd_entries_accepted;
 } GutStats;
 
 typedef struct GutHandle GutHandle;
