@@ -21,10 +21,11 @@ class GradientExchange:
     concurrently with whatever is still queued on the compute stream; nothing is packed into or out of a staging buffer —
     at 1M Gaussians that staging alone would move 2 x 236 MB per step)."""
 
-    def __init__(self, params, average: bool = True, group=None):
+    def __init__(self, params, average: bool = True, group=None, timed: bool = False):
         self.params = list(params)
         self.average = average
         self.group = group
+        self.timer = _ExchangeTimer() if timed else None
 
     @torch.no_grad()
     def reduce(self):
@@ -42,11 +43,44 @@ class GradientExchange:
         # RCCL averages inside the collective; gloo (CPU tests) has no AVG
         native_avg = self.average and dist.get_backend(self.group) == "nccl"
         op = dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM
+        if self.timer:
+            self.timer.begin(grads[0].device)
         works = [dist.all_reduce(g, op=op, group=self.group, async_op=True) for g in grads]
         for w in works:
             w.wait()
+        if self.timer:
+            self.timer.end(sum(g.numel() * g.element_size() for g in grads))
         if self.average and not native_avg:
             torch._foreach_div_(grads, float(world))
+
+
+class _ExchangeTimer:
+    """Device time of the exchange step, per rank (bench.py reports the slowest rank's average): events on the stream the collectives
+    are issued from / waited on, read back lazily."""
+
+    def __init__(self):
+        self.pairs, self.bytes = [], 0
+
+    def begin(self, device):
+        self._start = torch.cuda.Event(enable_timing=True) if device.type == "cuda" else None
+        if self._start is not None:
+            self._start.record()
+
+    def end(self, payload_bytes):
+        if self._start is not None:
+            stop = torch.cuda.Event(enable_timing=True)
+            stop.record()
+            self.pairs.append((self._start, stop))
+        self.bytes = payload_bytes
+
+    def collect(self):
+        """(average ms per exchange, payload bytes of one exchange on this rank) since the last call."""
+        if not self.pairs:
+            return None, self.bytes
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.pairs) / len(self.pairs)
+        self.pairs = []
+        return ms, self.bytes
 
 
 class FactoredGradientExchange:
@@ -64,9 +98,10 @@ class FactoredGradientExchange:
     At 8 ranks a ring moves 2*(7/8)*236 = 413 B per particle for the plain all-reduce, 2*(7/8)*48 + (7/8)*8*12 = 168 B this
     way.  Views are added in rank order on every rank, so replicas stay bitwise identical, like after an all-reduce."""
 
-    def __init__(self, average: bool = True, group=None, local_gradient_hook=None):
+    def __init__(self, average: bool = True, group=None, local_gradient_hook=None, timed: bool = False):
         self.average = average  # mean over views, like GradientExchange and the module docstring (keeps the single-view loss scale)
         self.group = group
+        self.timer = _ExchangeTimer() if timed else None
         # called with this view's packed gradient [N,12] (columns 0..2 = dL/d position) BEFORE it is reduced: the place to take
         # the densification statistics, which must come from the local view (local_densify_stats)
         self.local_gradient_hook = local_gradient_hook
@@ -87,6 +122,8 @@ class FactoredGradientExchange:
             return g_density, _abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active_features, sph_degree, 1.0)
         nccl = dist.get_backend(self.group) == "nccl"
         op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
+        if self.timer:
+            self.timer.begin(g_density.device)
         w_geo = dist.all_reduce(g_density, op=op, group=self.group, async_op=True)
         factors = torch.empty((world,) + tuple(g_radiance.shape), dtype=g_radiance.dtype, device=g_radiance.device)
         if nccl:
@@ -99,6 +136,8 @@ class FactoredGradientExchange:
             w_rad = dist.all_reduce(factors, group=self.group, async_op=True)
         w_geo.wait()
         w_rad.wait()
+        if self.timer:
+            self.timer.end(g_density.numel() * 4 + g_radiance.numel() * 4)
         if self.average and not nccl:
             g_density.div_(float(world))
         return g_density, _abi.sph_grad_from_views(factors, positions, n_active_features, sph_degree, scale)

@@ -266,9 +266,9 @@ def main():
     if world > 1:
         exchange_kind = os.environ.get("GRUT_BENCH_EXCHANGE", "factored")
         if exchange_kind == "factored":
-            tracer.gradient_exchange = dp.FactoredGradientExchange(average=False)
+            tracer.gradient_exchange = dp.FactoredGradientExchange(average=False, timed=True)
         else:
-            exch = dp.GradientExchange(g.parameters(), average=False)
+            exch = dp.GradientExchange(g.parameters(), average=False, timed=True)
 
     def step():
         g.zero_grad()
@@ -309,6 +309,15 @@ def main():
     stage_ms = (C.c_float * len(abi.GUT_STAGES))()
     abi.check(nat.lib.gut_profile_read(nat.handle, stage_ms), "gut_profile_read")
     st = nat.stats()
+    exchange = None
+    if world > 1:   # device time of the exchange step: every rank's average, the slowest reported
+        timer = (tracer.gradient_exchange or exch).timer
+        ms, payload = timer.collect()
+        per_rank = torch.zeros(world, device=dev, dtype=torch.float64)
+        per_rank[rank] = ms if ms is not None else -1.0
+        dist.all_reduce(per_rank)   # (a gather written as a sum: works on every backend)
+        exchange = {"kind": exchange_kind, "ms_per_step_per_rank": [float(x) for x in per_rank.tolist()], "payload_bytes_per_rank": int(payload),
+                    "note": "device time between issuing the collectives and their completion on the compute stream (RCCL over xGMI)"}
     if rank == 0:
         P = W * H
         stages = {k: float(stage_ms[i]) for i, k in enumerate(abi.GUT_STAGES)}
@@ -363,6 +372,8 @@ def main():
             "work": {"N": int(st.num_particles), "Nv": int(st.num_visible), "I": int(st.num_intersections), "P": P,
                      "tiles": int(st.num_tiles), "tile_key_bits": int(st.key_bits)},
         }
+        if exchange is not None:
+            result["exchange"] = exchange
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline()
         if world == 1 and not args.no_secondary and args.workload == "c4_1m_1080p":

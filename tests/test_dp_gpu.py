@@ -140,3 +140,47 @@ def test_data_parallel_training_keeps_replicas_identical_and_converges():
     after = psnr(_oracle_images(d0, s0))
     print(f"2-rank DP training: PSNR vs oracle-rendered teacher {before:.2f} dB -> {after:.2f} dB")
     assert np.isfinite(d0).all() and after > before + 5.0, (before, after)
+
+
+def _rccl_rank(rank, world, port, out):
+    """One rank of the RCCL check (needs one GPU per rank): the factored exchange (ReduceOp.AVG all-reduce of [N,12] + all_gather_into_tensor
+    of the view factors, issued inside backward) against the plain five-tensor all-reduce of the same two views."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    dp = importlib.import_module("3dgrut_amd.dp")
+    syn = importlib.import_module("3dgrut_amd.synthetic")
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    res = {}
+    for kind in ("factored", "allreduce"):
+        scene = make_scene(n=4000, width=96, height=64, median_scale=0.06, view=2 * rank + 1)
+        tr = gt.Tracer({"render": {"splat": {}}})
+        g = syn.SimpleGaussians(scene["density12"], scene["sph"], device=f"cuda:{rank}")
+        if kind == "factored":
+            tr.gradient_exchange = dp.FactoredGradientExchange(average=True)
+        out_ = tr.render(g, torch_batch(scene["batch"], f"cuda:{rank}"), train=True)
+        (out_["pred_features"].sum() + out_["pred_opacity"].sum()).backward()
+        if kind == "allreduce":
+            dp.GradientExchange(g.parameters(), average=True).reduce()
+        torch.cuda.synchronize()
+        res[kind] = [p.grad.detach().cpu().numpy() for p in g.parameters()]
+    vis = dp.reduce_visibility(out_["mog_visibility"]).cpu().numpy()
+    out[rank] = (res, vis)
+    dist.destroy_process_group()
+
+
+def test_rccl_factored_exchange_equals_plain_allreduce():
+    """The `nccl` (= RCCL) branches of dp.py — ReduceOp.AVG, all_gather_into_tensor, collectives issued from inside autograd's backward
+    — need one GPU per rank: skipped on the single-GPU test box, run wherever two or more GPUs are visible."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("RCCL needs one GPU per rank (this box has one)")
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_rccl_rank, args=(2, _free_port(), out), nprocs=2, join=True)
+    (r0, v0), (r1, v1) = out[0], out[1]
+    for kind in ("factored", "allreduce"):
+        for a, b in zip(r0[kind], r1[kind]):
+            assert np.array_equal(a, b), "replicas differ after the exchange"
+    for a, b in zip(r0["factored"], r0["allreduce"]):
+        assert np.abs(a - b).max() <= 1e-5 * (np.abs(b).max() + 1e-12)   # same sum over two views, different summation order
+    assert np.array_equal(v0, v1)
