@@ -103,6 +103,16 @@ class GrutAdamGroup(C.Structure):
 VIS_NONE, VIS_BOOL_U8, VIS_INT32, VIS_FLOAT_BITS = range(4)
 
 
+class GrtMesh(C.Structure):
+    """include/grut_amd.h: GrtMesh (device pointers of the hybrid tracer's triangle mesh)."""
+    _fields_ = [("num_vertices", C.c_uint32), ("num_faces", C.c_uint32), ("vertices", C.c_void_p), ("triangles", C.c_void_p),
+                ("vertex_normals", C.c_void_p), ("prim_type", C.c_void_p), ("refractive_index", C.c_void_p), ("diffuse_color", C.c_void_p)]
+
+
+class GrtHybridOptions(C.Structure):
+    _fields_ = [("playground_opts", C.c_uint32), ("max_pbr_bounces", C.c_uint32), ("background", C.c_float * 3)]
+
+
 class GutGradIO(C.Structure):
     """include/grut_amd.h: GutGradIO (gradient tensors of gut_backward_unpacked in the caller's own layout)."""
     _fields_ = [("grad_features", C.c_void_p), ("grad_opacity", C.c_void_p), ("grad_positions", C.c_void_p), ("grad_density", C.c_void_p),
@@ -115,7 +125,7 @@ EXPORTED_SYMBOLS = [
     "gut_debug_fetch", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats",
-    "grt_debug_forward_hits", "grt_debug_fetch_instances",
+    "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_build_mesh_bvh", "grt_trace_hybrid",
     "grut_selective_adam_update", "grut_pack_particles", "grut_unpack_particle_grads", "grut_activate_pack", "grut_activate_pack_backward",
     "grut_last_error", "grut_abi_version",
 ]
@@ -172,6 +182,10 @@ def _declare(lib):
     lib.grt_debug_forward_hits.restype = C.c_int
     lib.grt_debug_fetch_instances.argtypes = [C.c_void_p, vp, fp]
     lib.grt_debug_fetch_instances.restype = C.c_int
+    lib.grt_build_mesh_bvh.argtypes = [C.c_void_p, vp, C.c_uint32, fp, C.c_uint32, ip]
+    lib.grt_build_mesh_bvh.restype = C.c_int
+    lib.grt_trace_hybrid.argtypes = [C.c_void_p, vp, C.POINTER(GrtFrame), fp, fp, fp, fp, fp, C.POINTER(GrtMesh), C.POINTER(GrtHybridOptions), fp, fp, fp, up]
+    lib.grt_trace_hybrid.restype = C.c_int
     lib.grt_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.grt_timings.restype = C.c_int
     lib.grt_stats.argtypes = [C.c_void_p, C.POINTER(GrtStats)]
@@ -221,6 +235,8 @@ def pack_particles(mog_pos, mog_dns, mog_rot, mog_scl):
     import torch
     lib = load_library()
     n = int(mog_pos.shape[0])
+    if n == 0:
+        return torch.empty((0, 12), dtype=torch.float32, device=mog_pos.device)
     parts = [t.detach().reshape(n, -1).contiguous().float() for t in (mog_pos, mog_dns, mog_rot, mog_scl)]
     out = torch.empty((n, 12), dtype=torch.float32, device=mog_pos.device)
     stream = C.c_void_p(torch.cuda.current_stream(mog_pos.device).cuda_stream)

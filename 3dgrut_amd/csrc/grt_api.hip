@@ -40,6 +40,10 @@ struct GrtHandle {
     uint32_t* log_state_host = nullptr;  // pinned copy of {chunks used, overflow} of the last logged forward
     hipEvent_t log_event = nullptr;
     bool log_event_pending = false;
+    // triangle mesh of the hybrid path (grt_build_mesh_bvh): its own LBVH
+    DeviceBuffer m_aabb, m_slack, m_scene_enc, m_scene, m_codes, m_ids, m_codes_tmp, m_ids_tmp, m_sort_scratch, m_nodes, m_done;
+    uint32_t mesh_faces = 0;
+    bool mesh_built = false;
     DeviceBuffer work_counters;  // instrumented launches (GRUT_GRT_COUNT=1): nodes, leaf tests, processed hits, rounds, inserts
     unsigned long long work_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -109,7 +113,8 @@ void grt_destroy(GrtHandle* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
                             &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
-                            &h->work_counters, &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state};
+                            &h->work_counters, &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state, &h->m_aabb, &h->m_slack, &h->m_scene_enc,
+                            &h->m_scene, &h->m_codes, &h->m_ids, &h->m_codes_tmp, &h->m_ids_tmp, &h->m_sort_scratch, &h->m_nodes, &h->m_done};
     for (DeviceBuffer* b : bufs) b->release();
     if (h->log_state_host) (void)hipHostFree(h->log_state_host);
     if (h->log_event) (void)hipEventDestroy(h->log_event);
@@ -297,6 +302,77 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
                          grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph, log);
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
+    return GRUT_OK;
+}
+
+// HybridOptixTracer::buildMeshBVH (threedgrut_playground/include/playground/hybridTracer.h:113-114): LBVH over the triangles' boxes
+// with the Gaussian builder's Morton / sort / hierarchy / refit stages.
+int grt_build_mesh_bvh(GrtHandle* h, void* stream_, uint32_t num_vertices, const float* vertices, uint32_t num_faces, const int32_t* triangles) {
+    GRUT_REQUIRE(h, "grt_build_mesh_bvh: null handle");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    h->mesh_faces = num_faces;
+    h->mesh_built = true;
+    if (num_faces == 0) return GRUT_OK;
+    GRUT_REQUIRE(vertices && triangles && num_vertices > 0, "grt_build_mesh_bvh: null buffer");
+    const size_t n = num_faces;
+    GRUT_CHECK(h->m_aabb.ensure(n * 24, 1.25f));
+    GRUT_CHECK(h->m_slack.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->m_scene_enc.ensure(grt_scene_enc_bytes()));
+    GRUT_CHECK(h->m_scene.ensure(64));
+    GRUT_CHECK(h->m_codes.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->m_ids.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->m_codes_tmp.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->m_ids_tmp.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->m_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
+    GRUT_CHECK(h->m_nodes.ensure(n * sizeof(GrtNode), 1.25f));
+    GRUT_CHECK(h->m_done.ensure(n * 4, 1.25f));
+    grt_launch_mesh_aabb(s, num_faces, vertices, triangles, h->m_aabb.as<float>(), h->m_slack.as<float>(), h->m_scene_enc.as<uint32_t>());
+    grt_launch_morton(s, num_faces, h->m_aabb.as<float>(), h->m_scene_enc.as<uint32_t>(), h->m_scene.as<float>(), h->m_codes.as<uint32_t>(),
+                      h->m_ids.as<uint32_t>());
+    uint32_t *sc = nullptr, *si = nullptr;
+    GRUT_CHECK(sort_pairs_u32(s, num_faces, nullptr, 0, 30, h->m_codes.as<uint32_t>(), h->m_ids.as<uint32_t>(), h->m_codes_tmp.as<uint32_t>(),
+                              h->m_ids_tmp.as<uint32_t>(), h->m_sort_scratch.ptr, h->m_sort_scratch.bytes, &sc, &si));
+    grt_launch_hierarchy(s, num_faces, sc, si, h->m_nodes.as<GrtNode>());
+    GRUT_HIP(hipMemsetAsync(h->m_done.ptr, 0, n, s));
+    grt_launch_refit(s, num_faces, h->m_aabb.as<float>(), h->m_slack.as<float>(), h->m_nodes.as<GrtNode>(), h->m_done.as<uint8_t>());
+    GRUT_HIP(hipGetLastError());
+    return GRUT_OK;
+}
+
+// HybridOptixTracer::traceHybrid (hybridTracer.h:120-141; playgroundKernel.cu:39-157): forward only, like the reference
+int grt_trace_hybrid(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
+                     const float* ray_origin, const float* ray_direction, const float* ray_max_t, const GrtMesh* mesh, const GrtHybridOptions* options,
+                     float* out_radiance, float* out_opacity, float* out_last_ray, uint32_t* out_bounces) {
+    GRUT_REQUIRE(h && frame && mesh && options, "grt_trace_hybrid: null argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (!h->built || !h->mesh_built) {
+        set_last_error("grt_trace_hybrid: build_bvh / build_mesh_bvh have not been called");
+        return GRUT_ERR_NOT_READY;
+    }
+    GRUT_REQUIRE(frame->width > 0 && frame->height > 0 && ray_origin && ray_direction && out_radiance && out_opacity, "grt_trace_hybrid: null buffer");
+    GRUT_REQUIRE(frame->num_particles == h->N, "grt_trace_hybrid: %u particles but the BVH holds %u", frame->num_particles, h->N);
+    GRUT_REQUIRE(mesh->num_faces == h->mesh_faces, "grt_trace_hybrid: %u faces but the mesh BVH holds %u", mesh->num_faces, h->mesh_faces);
+    GRUT_REQUIRE(h->N == 0 || (particle_density && particle_sph), "grt_trace_hybrid: null particle buffer");
+    GRUT_REQUIRE(mesh->num_faces == 0 || (mesh->vertices && mesh->triangles && mesh->prim_type && mesh->refractive_index && mesh->diffuse_color),
+                 "grt_trace_hybrid: null mesh buffer");
+    GRUT_REQUIRE(!(options->playground_opts & 1u) || mesh->num_faces == 0 || mesh->vertex_normals, "grt_trace_hybrid: smooth normals need vertex_normals");
+    const GrtTraceParams P = trace_params(h, *frame);
+    GrtBvh bvh = bvh_view(h);
+    static const float kEmptyScene[6] = {0, 0, 0, 0, 0, 0};
+    (void)kEmptyScene;
+    GrtMeshView mv;
+    mv.nodes = h->m_nodes.as<GrtNode>();
+    mv.vertices = mesh->vertices; mv.triangles = mesh->triangles; mv.vnormals = mesh->vertex_normals; mv.prim_type = mesh->prim_type;
+    mv.refr = mesh->refractive_index; mv.diffuse = mesh->diffuse_color; mv.F = mesh->num_faces;
+    GrtHybridParams hp;
+    hp.opts = options->playground_opts;
+    hp.max_pbr_bounces = options->max_pbr_bounces;
+    for (int k = 0; k < 3; ++k) hp.background[k] = options->background[k];
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
+    grt_launch_hybrid(s, P, bvh, mv, hp, particle_density, particle_sph, ray_origin, ray_direction, ray_max_t, out_radiance, out_opacity, out_last_ray,
+                      out_bounces);
+    GRUT_HIP(hipGetLastError());
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
     return GRUT_OK;
 }
 

@@ -58,6 +58,23 @@ struct GrtHitLog {
     uint32_t capacity_chunks, max_rounds;
 };
 
+// triangle mesh of the hybrid path (playground): its own LBVH over triangle boxes + the per-face / per-vertex attributes
+struct GrtMeshView {
+    const GrtNode* nodes;        // [max(F-1, 1)]
+    const float* vertices;       // [V,3]
+    const int32_t* triangles;    // [F,3]
+    const float* vnormals;       // [V,3]
+    const int32_t* prim_type;    // [F] PlaygroundPrimitiveTypes
+    const float* refr;           // [F]
+    const float* diffuse;        // [F,3]
+    uint32_t F;
+};
+struct GrtHybridParams {
+    uint32_t opts;               // PlaygroundRenderOptions: bit 0 smooth normals, bit 1 Gaussian tracing off
+    uint32_t max_pbr_bounces;
+    float background[3];
+};
+
 // build stages
 void grt_launch_proxies(hipStream_t s, const GrtBuildParams& P, const float* pos, const float* rot, const float* scl, const float* dns,
                         float* inst, float* aabb, float* slack, uint32_t* scene_enc);
@@ -73,5 +90,10 @@ void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& 
 void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
                           const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log);
+
+void grt_launch_mesh_aabb(hipStream_t s, uint32_t F, const float* vertices, const int32_t* triangles, float* aabb, float* slack, uint32_t* scene_enc);
+void grt_launch_hybrid(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const GrtMeshView& mesh, const GrtHybridParams& hp,
+                       const float* density12, const float* sph, const float* ray_o, const float* ray_d, const float* ray_max_t, float* out_rgb,
+                       float* out_alpha, float* out_last_ray, uint32_t* out_bounces);
 
 }  // namespace grut

@@ -1138,6 +1138,293 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Hybrid mesh + Gaussian path tracing (BASELINE config 5): threedgrut_playground/src/kernels/cuda/
+// playgroundKernel.cu:39-157 (path loop), :159-352 (materials, closest hit), include/playground/kernels/cuda/trace.cuh:175-231,
+// 3dgrtTracer.cuh:137-204 (traceVolumetricGS: the forward's k = 16 rounds on a sub-interval, continuing the transmittance).
+// Primitive types none / mirror / glass / diffuse; PBR primitives are refused by the host API.  The triangle mesh gets its own
+// LBVH (the Gaussian builder's Morton / hierarchy / refit stages over triangle boxes); OptiX's closest-hit is a packet walk
+// with a per-lane nearest distance.  Bounce rays of an 8x8 block diverge, the packet walk then visits the union of their
+// paths — correct for any ray set, tuned for none (first version: forward only, like the reference).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void grt_mesh_aabb_kernel(uint32_t F, const float* __restrict__ vertices, const int32_t* __restrict__ triangles,
+                                                            float* __restrict__ aabb, float* __restrict__ slack, uint32_t* __restrict__ scene_enc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (i < F) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const float* p = vertices + 3 * (size_t)triangles[3 * (size_t)i + v];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { lo[k] = fminf(lo[k], p[k]); hi[k] = fmaxf(hi[k], p[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {   // a hair of padding: culling must stay conservative, hits are decided on the triangle itself
+            const float pad = 1e-5f * (hi[k] - lo[k]) + 1e-6f * (fabsf(lo[k]) + fabsf(hi[k]) + 1.f);
+            lo[k] -= pad; hi[k] += pad;
+        }
+        float* b = aabb + 6 * (size_t)i;
+        b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+        slack[i] = 0.f;
+    }
+    uint32_t* rep = scene_enc + (blockIdx.x % kSceneReplicas) * kSceneReplicaStride;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float mn = wave_min(lo[k]), mx = wave_max(hi[k]);
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&rep[k], enc_ordered(mn));
+            atomicMax(&rep[3 + k], enc_ordered(mx));
+        }
+    }
+}
+
+struct MeshHit {
+    float t, u, v;
+    uint32_t tri;   // 0xFFFFFFFF: miss
+};
+// Moeller-Trumbore, written with explicit operation order and no contraction: the CPU checker evaluates bit-identical distances
+__device__ __forceinline__ bool tri_intersect(const GrtMeshView& m, uint32_t f, const RayW& r, float tmin, float tmax, float& t, float& u, float& v) {
+#pragma clang fp contract(off)
+    const int32_t i0 = m.triangles[3 * (size_t)f], i1 = m.triangles[3 * (size_t)f + 1], i2 = m.triangles[3 * (size_t)f + 2];
+    const float* p0 = m.vertices + 3 * (size_t)i0; const float* p1 = m.vertices + 3 * (size_t)i1; const float* p2 = m.vertices + 3 * (size_t)i2;
+    const float v0x = p0[0], v0y = p0[1], v0z = p0[2];
+    const float e1x = p1[0] - v0x, e1y = p1[1] - v0y, e1z = p1[2] - v0z, e2x = p2[0] - v0x, e2y = p2[1] - v0y, e2z = p2[2] - v0z;
+    const float pvx = r.d.y * e2z - r.d.z * e2y, pvy = r.d.z * e2x - r.d.x * e2z, pvz = r.d.x * e2y - r.d.y * e2x;
+    const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+    if (!(fabsf(det) > 1e-20f)) return false;
+    const float inv = 1.f / det;
+    const float tvx = r.o.x - v0x, tvy = r.o.y - v0y, tvz = r.o.z - v0z;
+    u = (tvx * pvx + tvy * pvy + tvz * pvz) * inv;
+    if (u < 0.f || u > 1.f) return false;
+    const float qx = tvy * e1z - tvz * e1y, qy = tvz * e1x - tvx * e1z, qz = tvx * e1y - tvy * e1x;
+    v = (r.d.x * qx + r.d.y * qy + r.d.z * qz) * inv;
+    if (v < 0.f || u + v > 1.f) return false;
+    t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+    return (t > tmin) && (t < tmax);
+}
+__device__ __forceinline__ MeshHit mesh_closest(const GrtMeshView& m, const RayW& r, float tmin, float tmax, bool active, int lane,
+                                                uint32_t* __restrict__ stack) {
+    MeshHit best;
+    best.t = 3.0e38f; best.u = 0.f; best.v = 0.f; best.tri = 0xFFFFFFFFu;
+    if (!__any(active) || m.F == 0) return best;
+    auto leaf = [&](uint32_t f, bool lane_on) {
+        float t, u, v;
+        if (lane_on && tri_intersect(m, f, r, tmin, tmax, t, u, v) && ((t < best.t) || (t == best.t && f < best.tri))) { best.t = t; best.u = u; best.v = v; best.tri = f; }
+    };
+    if (m.F == 1) { leaf(0u, active); return best; }
+    int sp = 0;
+    uint32_t cur = 0;
+    bool have = true;
+    while (true) {
+        if (!have) {
+            if (sp == 0) break;
+            cur = stack[--sp];
+        }
+        have = false;
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+        const cfloat4* nq = reinterpret_cast<const cfloat4*>(reinterpret_cast<uintptr_t>(&m.nodes[cur]));
+        const float4 q0 = ld4(nq, 0), q1 = ld4(nq, 1), q2 = ld4(nq, 2), q3 = ld4(nq, 3);
+        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+        float tn0, tf0, tn1, tf1;
+        bool ok0, ok1;
+        boxes_hit(q0, q1, q2, r, tn0, tf0, tn1, tf1, ok0, ok1);
+        const float bound = fminf(tmax, best.t);
+        const bool h0 = active && (c0 != kGrtNoChild) && ok0 && (tf0 >= tmin) && (tn0 <= bound);
+        const bool h1 = active && (c1 != kGrtNoChild) && ok1 && (tf1 >= tmin) && (tn1 <= bound);
+        bool a0 = __any(h0), a1 = __any(h1);
+        if (a0 && (c0 & kGrtLeafBit)) { leaf(c0 & ~kGrtLeafBit, h0); a0 = false; }
+        if (a1 && (c1 & kGrtLeafBit)) { leaf(c1 & ~kGrtLeafBit, h1); a1 = false; }
+        if (a0 && a1) {
+            const int v0 = __popcll(__ballot(h0 && (!h1 || tn0 <= tn1))), v1 = __popcll(__ballot(h1 && (!h0 || tn1 < tn0)));
+            const bool first0 = v0 >= v1;
+            if (lane == 0) stack[sp] = first0 ? c1 : c0;
+            sp++;
+            cur = first0 ? c0 : c1;
+            have = true;
+        } else if (a0 || a1) {
+            cur = a0 ? c0 : c1;
+            have = true;
+        }
+    }
+    return best;
+}
+
+// traceVolumetricGS (3dgrtTracer.cuh:137-204) on [tmin, tmax] of ray r for the lanes with `active`: continues T and rad
+template <int DEG>
+__device__ __forceinline__ void trace_segment(const GrtTraceParams& P, const GrtBvh& bvh, const float4* __restrict__ density12,
+                                              const float* __restrict__ sph, const RayW& r, float tmin, float tmax, bool active, int lane,
+                                              uint32_t* __restrict__ s_stack, float* __restrict__ s_hit_t, uint32_t* __restrict__ s_hit_id, float& T,
+                                              f3& rad) {
+    constexpr float eps = 1e-9f;
+    float t0, t1;
+    scene_interval(bvh.scene, r, t0, t1);
+    t0 = fmaxf(t0, tmin);
+    t1 = fminf(t1, tmax);
+    float tLast = fmaxf(0.f, t0 - eps);
+    float basis[16];
+    sh_basis16(P.sph_degree, r.d, basis);
+    TraceCounters tc;
+    bool running = active;
+    while (true) {
+        running = running && (tLast <= t1) && (T > P.min_transmittance);
+        if (!__any(running)) break;
+        {
+            HitBufferT<kGrtMaxHits> buf;
+            trace_round<false, kGrtMaxHits>(bvh, r, tLast + eps, t1 + eps, running, lane, s_stack, buf, tc);
+            buf.store(s_hit_t, s_hit_id, lane);
+        }
+        if (s_hit_id[lane] == 0xFFFFFFFFu) running = false;
+#pragma unroll 1
+        for (int i = 0; i < kGrtMaxHits; ++i) {
+            const uint32_t id = s_hit_id[i * 64 + lane];
+            const bool process = running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
+            if (!__any(process)) break;   // ascending lists: nothing further for any lane
+            if (process) {
+                const Particle p = load_particle(density12, id);
+                const HitGeom g = hit_geometry<DEG>(P, p, r);
+                if (g.accept) {
+                    const float weight = g.galpha * T;
+                    const f3 u = sh_radiance(P, sph, id, basis);
+                    rad = rad + mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f)) * weight;
+                    T *= (1.f - g.galpha);
+                }
+                tLast = fmaxf(tLast, s_hit_t[i * 64 + lane]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ f3 safe_normalize3(f3 v) {
+    const float l = dot(v, v);
+    return l > 0.f ? v * (1.f / sqrtf(l)) : v;
+}
+__device__ __forceinline__ f3 mirror_dir(f3 d, f3 n) {   // playgroundKernel.cu:190-198
+    const f3 nn = dot(d, n) < 0.f ? n : n * -1.f;
+    return safe_normalize3(d - nn * (2.f * dot(nn, d)));
+}
+__device__ __forceinline__ bool refract_dir(f3& out, f3 d, f3 n, float etai_over_etat) {   // :159-188
+    float ri;
+    if (dot(d, n) < 0.f) ri = 1.f / etai_over_etat;
+    else { ri = etai_over_etat; n = n * -1.f; }
+    const float cos_theta = fminf(dot(d * -1.f, n), 1.f);
+    const float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+    if (!(ri * sin_theta <= 1.f)) return false;
+    const f3 perp = (d + n * cos_theta) * ri;
+    const f3 par = n * (-sqrtf(fabsf(1.f - dot(perp, perp))));
+    out = safe_normalize3(perp + par);
+    return true;
+}
+
+template <int DEG>
+__global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh bvh, GrtMeshView mesh, GrtHybridParams hp,
+                                                        const float4* __restrict__ density12, const float* __restrict__ sph,
+                                                        const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                        const float* __restrict__ ray_max_t, float* __restrict__ out_rgb,
+                                                        float* __restrict__ out_alpha, float* __restrict__ out_last_ray,
+                                                        uint32_t* __restrict__ out_bounces) {
+    __shared__ uint32_t s_stack[kGrtStackDepth];
+    __shared__ float s_hit_t[kGrtMaxHits * 64];
+    __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
+    const int lane = threadIdx.x;
+    const PixelBlock pb = pixel_block(P.W, P.H);
+    if (!pb.inside) return;
+    const int px = pb.bx * 8 + (lane & 7), py = pb.by * 8 + (lane >> 3);
+    const bool in_image = (px < P.W) && (py < P.H);
+    const size_t pix = in_image ? (size_t)py * P.W + px : 0;
+    RayW r = make_ray(P, ray_o, ray_d, pix);
+    const float ray_t_max = ray_max_t ? ray_max_t[pix] : 1e30f;
+    const bool gaussians = !(hp.opts & 2u) && bvh.N > 0;
+    // payload (playgroundKernel.cu:51-68) and the ray's running volumetric state (RayData: radiance, density = 1 - T)
+    f3 accC = mk3(0.f, 0.f, 0.f), direct = accC, thr = mk3(1.f, 1.f, 1.f), rad = accC;
+    float accA = 0.f, T = 1.f;
+    uint32_t bounces = 0u, timeout = 0u;
+    bool missed = false, terminate = false;
+    f3 lastO = r.o, lastD = r.d;
+    while (true) {
+        const bool go = in_image && !missed && (sqrtf(dot(thr, thr)) > 0.0001f) && (accA < 0.995f) && (0u < hp.max_pbr_bounces) && (bounces < 32u) &&
+                        !terminate && (timeout <= 1000u);
+        if (!__any(go)) break;
+        // traceMesh + __closesthit__ch / __miss__ms
+        const MeshHit mh = mesh_closest(mesh, r, 1e-5f, 1e5f, go, lane, s_stack);
+        const bool hit = go && mh.tri != 0xFFFFFFFFu;
+        if (go && !hit) missed = true;
+        float hit_t = mh.t;
+        f3 new_dir = mk3(0.f, 0.f, 0.f);
+        int type = 0;
+        if (hit) {
+            const int32_t i0 = mesh.triangles[3 * (size_t)mh.tri], i1 = mesh.triangles[3 * (size_t)mh.tri + 1], i2 = mesh.triangles[3 * (size_t)mh.tri + 2];
+            f3 n;
+            if (hp.opts & 1u) {   // interpolated vertex normals
+                const float w0 = 1.f - mh.u - mh.v;
+                const float* n0 = mesh.vnormals + 3 * (size_t)i0; const float* n1 = mesh.vnormals + 3 * (size_t)i1; const float* n2 = mesh.vnormals + 3 * (size_t)i2;
+                n = mk3(w0 * n0[0] + mh.u * n1[0] + mh.v * n2[0], w0 * n0[1] + mh.u * n1[1] + mh.v * n2[1], w0 * n0[2] + mh.u * n1[2] + mh.v * n2[2]);
+                n = n * (1.f / sqrtf(dot(n, n)));
+            } else {
+                const float* p0 = mesh.vertices + 3 * (size_t)i0; const float* p1 = mesh.vertices + 3 * (size_t)i1; const float* p2 = mesh.vertices + 3 * (size_t)i2;
+                n = safe_normalize3(cross(mk3(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]), mk3(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2])));
+            }
+            type = mesh.prim_type[mh.tri];
+            if (type == 1) { new_dir = mirror_dir(r.d, n); bounces++; }
+            else if (type == 2) {
+                const float ior = mesh.refr[mh.tri] / 1.0003f;
+                if (refract_dir(new_dir, r.d, n, ior)) hit_t += 1e-5f;
+                else { new_dir = mirror_dir(r.d, n); bounces++; }
+            } else if (type != 3) new_dir = r.d;
+        }
+        // handleDiffuse: the Gaussians in front of the surface, then the opaque surface itself
+        const bool diffuse = hit && type == 3;
+        if (__any(diffuse)) {
+            const float T0 = T;
+            const f3 rad0 = rad;
+            if (gaussians) trace_segment<DEG>(P, bvh, density12, sph, r, 1e-9f, hit_t, diffuse, lane, s_stack, s_hit_t, s_hit_id, T, rad);
+            if (diffuse) {
+                accC = accC + (rad - rad0);
+                accA += (1.f - T) - (1.f - T0);
+                const float* dc = mesh.diffuse + 3 * (size_t)mh.tri;
+                const float sa = 1.f - accA;
+                accC = accC + mk3(sa * dc[0], sa * dc[1], sa * dc[2]);
+                accA += sa;
+                terminate = true;
+            }
+        }
+        // the Gaussians between the ray origin and the surface (or the ray's end)
+        {
+            const float next_t = missed ? ray_t_max : hit_t;
+            const float T0 = T;
+            const f3 rad0 = rad;
+            if (gaussians) trace_segment<DEG>(P, bvh, density12, sph, r, 1e-9f, next_t, go, lane, s_stack, s_hit_t, s_hit_id, T, rad);
+            if (go) {
+                const f3 radiance = rad - rad0;
+                const float density = (1.f - T) - (1.f - T0);
+                accA += density * (1.f - accA);
+                accC = accC + thr * radiance;
+                direct = direct + radiance;
+                thr = thr * (1.f - density);
+                accC = accC + thr * direct;   // nextEmissive = 0 and bsdfValue = 1 without PBR primitives
+                lastO = r.o; lastD = r.d;
+                timeout++;
+                if (hit) {   // next ray of the path
+                    r.o = r.o + r.d * hit_t;
+                    r.d = new_dir;
+                    r.inv = mk3(safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z));
+                }
+            }
+        }
+    }
+    if (!in_image) return;
+    direct = direct + mk3(hp.background[0], hp.background[1], hp.background[2]);
+    thr = thr * (1.f - accA);
+    accC = accC + thr * direct;
+    accA = fminf(fmaxf(accA, 0.f), 1.f);
+    out_rgb[3 * pix] = accC.x; out_rgb[3 * pix + 1] = accC.y; out_rgb[3 * pix + 2] = accC.z;
+    out_alpha[pix] = accA;
+    if (out_last_ray) {
+        float* q = out_last_ray + 6 * pix;
+        q[0] = lastO.x; q[1] = lastO.y; q[2] = lastO.z; q[3] = lastD.x; q[4] = lastD.y; q[5] = lastD.z;
+    }
+    if (out_bounces) out_bounces[pix] = bounces;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1200,6 +1487,20 @@ void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& 
     GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_>), grid, dim3(64), 0, s, P, bvh,
                                                      reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns,
                                                      g_hit, g_density12, g_sph, log.pool ? log.state : nullptr));
+}
+
+void grt_launch_mesh_aabb(hipStream_t s, uint32_t F, const float* vertices, const int32_t* triangles, float* aabb, float* slack,
+                          uint32_t* scene_enc) {
+    hipLaunchKernelGGL(grt_scene_init_kernel, dim3(1), dim3(64), 0, s, scene_enc);
+    hipLaunchKernelGGL(grt_mesh_aabb_kernel, dim3(div_up(F, 256)), dim3(256), 0, s, F, vertices, triangles, aabb, slack, scene_enc);
+}
+void grt_launch_hybrid(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const GrtMeshView& mesh, const GrtHybridParams& hp,
+                       const float* density12, const float* sph, const float* ray_o, const float* ray_d, const float* ray_max_t, float* out_rgb,
+                       float* out_alpha, float* out_last_ray, uint32_t* out_bounces) {
+    const dim3 grid(pixel_block_grid(P.W, P.H));
+    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_hybrid_kernel<D_>), grid, dim3(64), 0, s, P, bvh, mesh, hp,
+                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, ray_max_t, out_rgb, out_alpha,
+                                                     out_last_ray, out_bounces));
 }
 
 }  // namespace grut

@@ -35,6 +35,8 @@ WORKLOADS = {
     # BASELINE config 3 (not the default bench line): 3DGRT software-BVH primary rays, forward + backward
     "c3_grt_1m_800": (1_000_000, 800, 800, 0.01),
     "c3_grt_100k_400": (100_000, 400, 400, 0.01),
+    # BASELINE config 5: hybrid mesh + Gaussian path tracing (reflection / refraction), 2 M Gaussians + mesh, fisheye camera, 1080p, forward only
+    "c5_hybrid_2m_1080p": (2_000_000, 1920, 1080, 0.008),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -208,6 +210,75 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
     return result
 
 
+def hybrid_mesh(subdiv=24):
+    """Mesh of the config-5 workload: a mirror sphere (UV sphere, subdiv x 2 subdiv quads) at the cloud's centre, a glass slab in front of
+    the camera side and a diffuse floor — a few thousand triangles, the three non-PBR primitive types of the playground."""
+    V, F, prim = [], [], []
+    for i in range(subdiv + 1):
+        th = np.pi * i / subdiv
+        for j in range(2 * subdiv):
+            ph = np.pi * j / subdiv
+            V.append([0.45 * np.sin(th) * np.cos(ph), 0.45 * np.sin(th) * np.sin(ph), 0.45 * np.cos(th)])
+    for i in range(subdiv):
+        for j in range(2 * subdiv):
+            a, b = i * 2 * subdiv + j, i * 2 * subdiv + (j + 1) % (2 * subdiv)
+            c, d = a + 2 * subdiv, b + 2 * subdiv
+            F += [[a, c, b], [b, c, d]]
+            prim += [1, 1]
+    base = len(V)
+    V += [[-0.7, -0.7, 1.25], [0.7, -0.7, 1.25], [0.7, 0.7, 1.25], [-0.7, 0.7, 1.25]]          # glass slab (top side of the cube)
+    F += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
+    prim += [2, 2]
+    base = len(V)
+    V += [[-1.6, -1.6, -1.15], [1.6, -1.6, -1.15], [1.6, 1.6, -1.15], [-1.6, 1.6, -1.15]]      # diffuse floor
+    F += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
+    prim += [3, 3]
+    V = np.asarray(V, np.float32)
+    n = V / np.maximum(np.linalg.norm(V, axis=1, keepdims=True), 1e-9)
+    n[-8:] = [0, 0, 1]
+    return dict(vertices=V, triangles=np.asarray(F, np.int32), vertex_normals=n.astype(np.float32), prim_type=np.asarray(prim, np.int32),
+                refractive_index=np.full(len(F), 1.45, np.float32), diffuse_color=np.tile(np.array([[0.6, 0.6, 0.55]], np.float32), (len(F), 1)))
+
+
+def bench_hybrid(args, dev, n, W, H, ms, emit=True):
+    """BASELINE config 5 (forward only, like the reference's playground): world-space fisheye rays through the hybrid tracer."""
+    syn = importlib.import_module("3dgrut_amd.synthetic")
+    pt = importlib.import_module("3dgrut_amd.playground_tracer")
+    d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=ms)
+    Kf = syn.fisheye_intrinsics(W, H, fov_deg=140.0)
+    ro, rd = syn.fisheye_rays(W, H, Kf)
+    T = syn.orbit_pose(0, n_views=8, radius=2.4).astype(np.float32)   # close to the cloud: the fisheye frame is mostly covered
+    ro_w = (ro @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    rd_w = (rd @ T[:3, :3].T).astype(np.float32)
+    mesh = hybrid_mesh()
+    tr = pt.Tracer({"render": {"enable_kernel_timings": True}})
+    g = syn.SimpleGaussians(d12, sph, device=dev, requires_grad=False)
+    t = lambda a: torch.as_tensor(a, device=dev)
+    tr.build_gs_acc(g, rebuild=True)
+    tr.build_mesh_acc(t(mesh["vertices"]), t(mesh["triangles"]))
+    args_t = (g, t(ro_w), t(rd_w), 1, t(mesh["triangles"]), t(mesh["vertex_normals"]), None, None, t(mesh["prim_type"]))
+    kw = dict(refractive_index=t(mesh["refractive_index"]), max_pbr_bounces=7)
+    out = None
+    for _ in range(args.warmup):
+        out = tr.render_playground(*args_t, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.render_playground(*args_t, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    b = out["mirror_bounces"]
+    result = {"metric": "rays/sec (hybrid mesh + Gaussian path tracing, forward)", "value": W * H * args.steps / dt, "unit": "rays/s",
+              "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup, "n_gpus": 1, "higher_is_better": True, "dtype": "f32",
+              "data": "synthetic",
+              "config": {"workload": f"hybrid path tracing, {n} Gaussians + {len(mesh['triangles'])} triangles (mirror sphere, glass slab, diffuse floor), "
+                                     f"fisheye 140 deg, {W}x{H}, smooth normals, forward only", "name": "c5_hybrid_2m_1080p"},
+              "rays_with_mirror_bounce": float((b > 0).float().mean()), "mean_opacity": float(out["pred_opacity"].mean())}
+    if emit:
+        print(json.dumps(result), flush=True)
+    return result
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +318,8 @@ def main():
     n, W, H, ms = WORKLOADS[args.workload]
     if "grt" in args.workload:
         return bench_grt(args, world, rank, dev, dist, n, W, H, ms)
+    if "hybrid" in args.workload:
+        return bench_hybrid(args, dev, n, W, H, ms)
     d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=ms)
     K = syn.pinhole_intrinsics(W, H)
     ro, rd = syn.pinhole_rays(W, H, K)

@@ -280,6 +280,37 @@ typedef struct GrtStats {
 
 typedef struct GrtHandle GrtHandle;
 
+/* ---- hybrid mesh + Gaussian path tracing (BASELINE config 5) -------------------------------------------------------------------
+ * Replaces HybridOptixTracer::buildMeshBVH / traceHybrid (threedgrut_playground/include/playground/hybridTracer.h:113-141) and the
+ * OptiX programs of threedgrut_playground/src/kernels/cuda/playgroundKernel.cu:39-352: per ray a path loop — closest triangle,
+ * material (none / mirror / glass / diffuse), then the Gaussians between the ray origin and the surface with the forward program's
+ * k = 16 rounds (3dgrtTracer.cuh:137-204), transmittance carried along the whole path.  Forward only, like the reference.
+ * PBR primitives (PGRNDPrimitivePBR = 4: Cook-Torrance sampling, textures, emissive maps) are not implemented — the caller must not
+ * pass them (the Python wrapper refuses); the environment map is a solid colour; `diffuse_color` is the face's material.diffuseFactor
+ * (PGRNDRenderDisablePBRTextures semantics).  All pointers are device pointers owned by the caller. */
+typedef struct GrtMesh {
+    uint32_t num_vertices, num_faces;
+    const float*   vertices;          /* [V,3] */
+    const int32_t* triangles;         /* [F,3] vertex indices */
+    const float*   vertex_normals;    /* [V,3] (needed with playground_opts bit 0) */
+    const int32_t* prim_type;         /* [F] PlaygroundPrimitiveTypes (pipelineDefinitions.h:18-24): 0 none, 1 mirror, 2 glass, 3 diffuse */
+    const float*   refractive_index;  /* [F] */
+    const float*   diffuse_color;     /* [F,3] */
+} GrtMesh;
+typedef struct GrtHybridOptions {
+    uint32_t playground_opts;         /* PlaygroundRenderOptions: bit 0 smooth normals, bit 1 disable Gaussian tracing */
+    uint32_t max_pbr_bounces;         /* the path loop runs while 0 < max_pbr_bounces (no PBR primitive ever counts one) */
+    float    background[3];           /* colour of the (solid) environment */
+} GrtHybridOptions;
+int grt_build_mesh_bvh(GrtHandle* handle, void* stream, uint32_t num_vertices, const float* vertices, uint32_t num_faces,
+                       const int32_t* triangles);
+/* rays [H,W,3] in ray space (frame->ray_to_world applies); ray_max_t [H,W] or NULL; out_radiance [H,W,3], out_opacity [H,W,1] fully
+ * written; out_last_ray [H,W,6] (world-space origin + direction of the last segment, for an external background pass) and
+ * out_bounces [H,W] (mirror bounces) may be NULL. */
+int grt_trace_hybrid(GrtHandle* handle, void* stream, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
+                     const float* ray_origin, const float* ray_direction, const float* ray_max_t, const GrtMesh* mesh,
+                     const GrtHybridOptions* options, float* out_radiance, float* out_opacity, float* out_last_ray, uint32_t* out_bounces);
+
 int  grt_create(const GrtConfig* config, GrtHandle** handle);
 void grt_destroy(GrtHandle* handle);
 

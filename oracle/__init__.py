@@ -344,3 +344,40 @@ def gut_pixel_trace(cfg, cam, fwd, pixel, cap=4096, dtype=np.float32):
                               _p(fwd["bins"]["sorted_idx"]), _p(fwd["bins"]["tile_ranges"]), _p(ro), _p(rd), C.c_uint32(int(pixel)),
                               C.c_uint32(cap), _p(idx), _p(alpha), _p(hit_t), _p(margin))
     return dict(idx=idx[:n], alpha=alpha[:n], hit_t=hit_t[:n], margin=margin[:n])
+
+
+class _OrcMesh(C.Structure):
+    _fields_ = [("num_vertices", C.c_uint32), ("num_faces", C.c_uint32), ("vertices", C.c_void_p), ("triangles", C.c_void_p),
+                ("vertex_normals", C.c_void_p), ("prim_type", C.c_void_p), ("refractive_index", C.c_void_p), ("diffuse_color", C.c_void_p)]
+
+
+def grt_hybrid(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, ray_o, ray_d, mesh, opts=0, max_pbr_bounces=8,
+               background=(0.0, 0.0, 0.0), inst=None, scene=None, ray_max_t=None, dtype=np.float32):
+    """Hybrid mesh + Gaussian path tracing (orc_grt_hybrid_trace; playgroundKernel.cu:39-157).  mesh: dict with vertices [V,3] f32,
+    triangles [F,3] i32, vertex_normals [V,3] f32, prim_type [F] i32 (0 none, 1 mirror, 2 glass, 3 diffuse), refractive_index [F] f32,
+    diffuse_color [F,3] f32.  Returns dict(rgba [H,W,4], last_ray [H,W,6], bounces [H,W])."""
+    l, R = lib(dtype), _real(dtype)
+    d12, s = _c(density12, dtype), _c(sph, dtype)
+    N = d12.shape[0]
+    if inst is None:
+        pr = grt_proxies(cfg, d12[:, 0:3], d12[:, 4:8], d12[:, 8:11], d12[:, 3], dtype)
+        inst, scene = pr["inst"], pr["scene"]
+    inst, scene = _c(inst, dtype), _c(scene, dtype)
+    ro, rd = _c(ray_o, dtype), _c(ray_d, dtype)
+    H, W = ro.shape[-3], ro.shape[-2]
+    n = H * W
+    m = _c(np.asarray(ray_to_world)[:3, :4], dtype)
+    keep = dict(v=_c(mesh["vertices"], np.float32), t=_c(mesh["triangles"], np.int32), n=_c(mesh["vertex_normals"], np.float32),
+                p=_c(mesh["prim_type"], np.int32).reshape(-1), r=_c(mesh["refractive_index"], np.float32).reshape(-1),
+                d=_c(mesh["diffuse_color"], np.float32))
+    om = _OrcMesh(keep["v"].shape[0], keep["t"].shape[0], _p(keep["v"]), _p(keep["t"]), _p(keep["n"]), _p(keep["p"]), _p(keep["r"]), _p(keep["d"]))
+    rgba, last, bounces = np.zeros((H, W, 4), dtype), np.zeros((H, W, 6), dtype), np.zeros((H, W), np.uint32)
+    tmax = _c(ray_max_t, dtype).reshape(-1) if ray_max_t is not None else None
+    bg = _c(background, dtype)
+    r = l.orc_grt_hybrid_trace(C.byref(cfg), C.c_uint32(N), _p(d12), _p(s), C.c_int(sph_deg), R(min_transmittance), _p(inst), _p(scene), _p(m),
+                               C.c_uint32(n), _p(ro), _p(rd), _p(tmax), C.byref(om), C.c_uint32(opts), C.c_uint32(max_pbr_bounces), _p(bg),
+                               _p(rgba), _p(last), _p(bounces))
+    if r == -4:
+        raise NotImplementedError("PBR primitives are not restated")
+    assert r == 0
+    return dict(rgba=rgba, last_ray=last, bounces=bounces)

@@ -485,3 +485,182 @@ int orc_grt_ray_candidates(uint32_t N, const real* inst12, const real* ray_to_wo
     free(cands);
     return (int)k;
 }
+
+/* =====================================================================================================================
+ * Hybrid mesh + Gaussian path tracing (BASELINE config 5): threedgrut_playground/src/kernels/cuda/
+ * playgroundKernel.cu:39-157 (__raygen__rg path loop), :159-244 (refract / handleMirror / handleGlass / handleDiffuse),
+ * :246-352 (normals, __closesthit__ch, __miss__ms); include/playground/kernels/cuda/trace.cuh:175-231 (traceMesh,
+ * traceGaussians); threedgrt_tracer/include/3dgrt/kernels/cuda/3dgrtTracer.cuh:137-204 (traceVolumetricGS: the k = 16 rounds
+ * of the forward program on a sub-interval of the ray, continuing the ray's transmittance).
+ * Restated subset: primitive types none / mirror / glass / diffuse with per-face base colour (PGRNDRenderDisablePBRTextures
+ * semantics: diffuse = material.diffuseFactor); PBR primitives (Cook-Torrance sampling, textures, emissive) are NOT restated.
+ * The environment map is a solid colour.  The triangle intersection of OptiX's built-in triangle GAS is opaque: the closest
+ * hit is restated as Moeller-Trumbore over every triangle, ties resolved towards the lower triangle index.
+ * ===================================================================================================================== */
+typedef struct {
+    uint32_t num_vertices, num_faces;
+    const float* vertices;          /* [V,3] */
+    const int32_t* triangles;       /* [F,3] */
+    const float* vertex_normals;    /* [V,3] (smooth shading) */
+    const int32_t* prim_type;       /* [F] PlaygroundPrimitiveTypes */
+    const float* refractive_index;  /* [F] */
+    const float* diffuse_color;     /* [F,3] */
+} orc_mesh;
+
+static int tri_intersect(const orc_mesh* m, uint32_t f, v3 o, v3 d, real tmin, real tmax, real* t_out, real* u_out, real* v_out) {
+    const int32_t* tr = m->triangles + 3 * (size_t)f;
+    const float* p0 = m->vertices + 3 * (size_t)tr[0]; const float* p1 = m->vertices + 3 * (size_t)tr[1]; const float* p2 = m->vertices + 3 * (size_t)tr[2];
+    const v3 v0 = v3_make(p0[0], p0[1], p0[2]);
+    const v3 e1 = v3_sub(v3_make(p1[0], p1[1], p1[2]), v0), e2 = v3_sub(v3_make(p2[0], p2[1], p2[2]), v0);
+    const v3 pv = v3_cross(d, e2);
+    const real det = v3_dot(e1, pv);
+    if (!(r_fabs(det) > R_(1e-20))) return 0;
+    const real inv = 1 / det;
+    const v3 tv = v3_sub(o, v0);
+    const real u = v3_dot(tv, pv) * inv;
+    if (u < 0 || u > 1) return 0;
+    const v3 q = v3_cross(tv, e1);
+    const real v = v3_dot(d, q) * inv;
+    if (v < 0 || u + v > 1) return 0;
+    const real t = v3_dot(e2, q) * inv;
+    if (!(t > tmin && t < tmax)) return 0;
+    *t_out = t; *u_out = u; *v_out = v;
+    return 1;
+}
+
+/* traceVolumetricGS on [tmin, tmax] of the ray (o, d), continuing the ray's transmittance T and radiance */
+static void trace_segment(const GrtConfig* cfg, uint32_t N, const real* density12, const real* sph, int sph_deg, real min_T, const real* inst12,
+                          const real* scene6, v3 o, v3 d, real tmin, real tmax, grt_hit* cands, real* T, v3* rad) {
+    const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
+    const int ncoef = (cfg->particle_radiance_sph_degree + 1) * (cfg->particle_radiance_sph_degree + 1);
+    const real eps = R_(1e-9);
+    real t0, t1;
+    scene_interval(scene6, o, d, &t0, &t1);
+    t0 = r_max(t0, tmin); t1 = r_min(t1, tmax);
+    real tLast = r_max(0, t0 - eps);
+    grt_ray_state s; s.T = *T; s.rad = *rad; s.depth = 0; s.normal = v3_make(0, 0, 0);
+    const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+    grt_hit buf[GRT_MAX_K];
+    while ((tLast <= t1) && (s.T > min_T)) {
+        const int k = trace_round(cands, n, tLast + eps, t1 + eps, K, buf);
+        if (k == 0) break;
+        for (int i = 0; i < k; ++i) {
+            if (s.T > min_T) {
+                process_hit(cfg, o, d, density12 + 12 * (size_t)buf[i].id, sph + (size_t)buf[i].id * 3 * ncoef, sph_deg, &s, 0);
+                tLast = r_max(tLast, buf[i].t);
+            }
+        }
+    }
+    *T = s.T; *rad = s.rad;
+}
+
+static int refract_dir(v3* out_dir, v3 ray_d, v3 normal, real etai_over_etat) {   /* playgroundKernel.cu:159-188 */
+    real ri;
+    if (v3_dot(ray_d, normal) < 0) ri = 1 / etai_over_etat;
+    else { ri = etai_over_etat; normal = v3_scale(normal, -1); }
+    const real cos_theta = r_min(v3_dot(v3_scale(ray_d, -1), normal), 1);
+    const real sin_theta = r_sqrt(1 - cos_theta * cos_theta);
+    if (!(ri * sin_theta <= 1)) return 0;
+    const v3 perp = v3_scale(v3_add(ray_d, v3_scale(normal, cos_theta)), ri);
+    const v3 par = v3_scale(normal, -r_sqrt(r_fabs(1 - v3_dot(perp, perp))));
+    *out_dir = v3_safe_normalize(v3_add(perp, par));
+    return 1;
+}
+static v3 mirror_dir(v3 ray_d, v3 normal) {   /* :190-198: -reflect(d, n') with reflect(x, n) = 2 n (n.x) - x */
+    const v3 n = v3_dot(ray_d, normal) < 0 ? normal : v3_scale(normal, -1);
+    return v3_safe_normalize(v3_sub(ray_d, v3_scale(n, 2 * v3_dot(n, ray_d))));
+}
+
+/* rays [nrays,3] in ray space; ray_max_t [nrays] or NULL (= 1e30); opts: bit 0 smooth normals, bit 1 Gaussian tracing off.
+ * out_rgba [nrays,4], out_last_ray [nrays,6] (origin, direction of the last traced segment, world space), out_bounces [nrays]. */
+int orc_grt_hybrid_trace(const GrtConfig* cfg, uint32_t N, const real* density12, const real* sph, int sph_deg, real min_T,
+                         const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
+                         const real* ray_d, const real* ray_max_t, const orc_mesh* mesh, uint32_t opts, uint32_t max_pbr_bounces,
+                         const real* background3, real* out_rgba, real* out_last_ray, uint32_t* out_bounces) {
+    for (uint32_t f = 0; f < mesh->num_faces; ++f)
+        if (mesh->prim_type[f] == 4) return -4;   /* PGRNDPrimitivePBR: not restated */
+#pragma omp parallel
+    {
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+#pragma omp for schedule(dynamic, 8)
+        for (uint32_t r = 0; r < nrays; ++r) {
+            v3 rayOri = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
+            v3 rayDir = xform_dir(ray_to_world12, v3_make(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
+            const real ray_t_max = ray_max_t ? ray_max_t[r] : R_(1e30);
+            /* payload (playgroundKernel.cu:51-68) and the ray's running volumetric state (RayData) */
+            v3 accC = v3_make(0, 0, 0), direct = v3_make(0, 0, 0), thr = v3_make(1, 1, 1);
+            real accA = 0;
+            uint32_t numBounces = 0, pbrBounces = 0, timeout = 0;
+            int missed = 0, terminate = 0;
+            real T = 1; v3 rad = v3_make(0, 0, 0);   /* RayData: density = 1 - T, radiance */
+            v3 lastO = rayOri, lastD = rayDir;
+            while (!missed && (r_sqrt(v3_dot(thr, thr)) > R_(0.0001)) && accA < R_(0.995) && (pbrBounces < max_pbr_bounces) && (numBounces < 32) && !terminate) {
+                const v3 o = rayOri, d = rayDir;
+                /* traceMesh: closest triangle in (1e-5, 1e5) */
+                real best_t = R_(3.0e38), bu = 0, bv = 0; int best_f = -1;
+                for (uint32_t f = 0; f < mesh->num_faces; ++f) {
+                    real t, u, v;
+                    if (tri_intersect(mesh, f, o, d, R_(1e-5), R_(1e5), &t, &u, &v) && t < best_t) { best_t = t; bu = u; bv = v; best_f = (int)f; }
+                }
+                real t_hit = 0;
+                if (best_f < 0) missed = 1;
+                else {   /* __closesthit__ch */
+                    const int32_t* tr = mesh->triangles + 3 * (size_t)best_f;
+                    v3 normal;
+                    if (opts & 1u) {
+                        const float* n0 = mesh->vertex_normals + 3 * (size_t)tr[0]; const float* n1 = mesh->vertex_normals + 3 * (size_t)tr[1];
+                        const float* n2 = mesh->vertex_normals + 3 * (size_t)tr[2];
+                        const real w0 = 1 - bu - bv;
+                        normal = v3_make(w0 * n0[0] + bu * n1[0] + bv * n2[0], w0 * n0[1] + bu * n1[1] + bv * n2[1], w0 * n0[2] + bu * n1[2] + bv * n2[2]);
+                        normal = v3_scale(normal, 1 / r_sqrt(v3_dot(normal, normal)));
+                    } else {
+                        const float* p0 = mesh->vertices + 3 * (size_t)tr[0]; const float* p1 = mesh->vertices + 3 * (size_t)tr[1];
+                        const float* p2 = mesh->vertices + 3 * (size_t)tr[2];
+                        normal = v3_safe_normalize(v3_cross(v3_make(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]), v3_make(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2])));
+                    }
+                    real hit_t = best_t;
+                    v3 new_dir = v3_make(0, 0, 0);
+                    const int type = mesh->prim_type[best_f];
+                    if (type == 1) { new_dir = mirror_dir(d, normal); numBounces++; }
+                    else if (type == 2) {
+                        const real ior = (real)mesh->refractive_index[best_f] / R_(1.0003);
+                        if (refract_dir(&new_dir, d, normal, ior)) hit_t += R_(1e-5);
+                        else { new_dir = mirror_dir(d, normal); numBounces++; }
+                    } else if (type == 3) {   /* handleDiffuse: the Gaussians in front of the surface, then the surface itself */
+                        real T0 = T; v3 rad0 = rad;
+                        if (!(opts & 2u)) trace_segment(cfg, N, density12, sph, sph_deg, min_T, inst12, scene6, o, d, R_(1e-9), hit_t, cands, &T, &rad);
+                        const v3 vrad = v3_sub(rad, rad0); const real valpha = (1 - T) - (1 - T0);
+                        accC = v3_add(accC, vrad); accA += valpha;
+                        const float* dc = mesh->diffuse_color + 3 * (size_t)best_f;
+                        const real sa = 1 - accA;
+                        accC = v3_add(accC, v3_make(sa * dc[0], sa * dc[1], sa * dc[2])); accA += sa;
+                        terminate = 1;
+                    } else new_dir = d;
+                    t_hit = hit_t;
+                    rayOri = v3_add(o, v3_scale(d, hit_t)); rayDir = new_dir;
+                }
+                /* the Gaussians between the ray origin and the surface (or the ray's end) */
+                const real next_t = missed ? ray_t_max : t_hit;
+                real T0 = T; v3 rad0 = rad;
+                if (!(opts & 2u)) trace_segment(cfg, N, density12, sph, sph_deg, min_T, inst12, scene6, o, d, R_(1e-9), next_t, cands, &T, &rad);
+                const v3 radiance = v3_sub(rad, rad0); const real density = (1 - T) - (1 - T0);
+                accA += density * (1 - accA);
+                accC = v3_add(accC, v3_mul(thr, radiance));
+                direct = v3_add(direct, radiance);
+                thr = v3_scale(thr, 1 - density);
+                accC = v3_add(accC, v3_mul(thr, direct));   /* nextEmissive = 0, bsdfValue = 1 without PBR primitives */
+                lastO = o; lastD = d;
+                if (++timeout > 1000) break;
+            }
+            direct = v3_add(direct, v3_make(background3[0], background3[1], background3[2]));
+            thr = v3_scale(thr, 1 - accA);
+            accC = v3_add(accC, v3_mul(thr, direct));
+            accA = r_min(r_max(accA, 0), 1);
+            out_rgba[4 * r] = accC.x; out_rgba[4 * r + 1] = accC.y; out_rgba[4 * r + 2] = accC.z; out_rgba[4 * r + 3] = accA;
+            if (out_last_ray) { real* q = out_last_ray + 6 * (size_t)r; q[0] = lastO.x; q[1] = lastO.y; q[2] = lastO.z; q[3] = lastD.x; q[4] = lastD.y; q[5] = lastD.z; }
+            if (out_bounces) out_bounces[r] = numBounces;
+        }
+        free(cands);
+    }
+    return 0;
+}

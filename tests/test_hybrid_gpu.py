@@ -1,0 +1,100 @@
+"""GPU parity of the hybrid mesh + Gaussian tracer (BASELINE config 5) against the CPU oracle
+(oracle/grt_oracle.c: orc_grt_hybrid_trace, a restatement of playgroundKernel.cu:39-352 + trace.cuh + 3dgrtTracer.cuh:137-204).
+
+PARITY UNPINNED for this path: the reference's hybrid programs need OptiX (triangle GAS, closest-hit / miss programs, textures) and
+have no test vectors; the oracle is pinned only through the parts it shares with the 3DGRT forward (candidate test, k = 16 rounds,
+processHit — grt_trace.npz).  What is compared here: mirror-bounce counts and last-ray buffers exactly / to rounding, images within
+1e-4 outside a bounded set of threshold flips."""
+import importlib
+
+import numpy as np
+import pytest
+
+import oracle
+from scenes import make_scene
+
+pytestmark = pytest.mark.gpu
+syn = importlib.import_module("3dgrut_amd.synthetic")
+
+
+def _mesh(with_glass=True):
+    """A tilted mirror inside the cloud, a diffuse wall behind it, and a glass pane in front of the camera side."""
+    V = np.array([[-0.8, -0.8, 0.2], [0.8, -0.8, 0.2], [0.8, 0.8, 0.4], [-0.8, 0.8, 0.4],
+                  [1.2, -1, -1], [1.2, 1, -1], [1.2, 1, 1], [1.2, -1, 1],
+                  [-0.5, -0.5, 1.3], [0.5, -0.5, 1.3], [0.5, 0.5, 1.3], [-0.5, 0.5, 1.3]], np.float32)
+    F = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 10], [8, 10, 11]], np.int32)
+    n = np.zeros_like(V)
+    n[:4] = np.array([0.0, -0.12, 0.99]) / np.linalg.norm([0.0, -0.12, 0.99])
+    n[4:8] = [1, 0, 0]
+    n[8:] = [0, 0, 1]
+    prim = np.array([1, 1, 3, 3, 2, 2], np.int32)
+    if not with_glass:
+        V, F, n, prim = V[:8], F[:4], n[:8], prim[:4]
+    return dict(vertices=V, triangles=F, vertex_normals=n.astype(np.float32), prim_type=prim,
+                refractive_index=np.full(len(F), 1.45, np.float32),
+                diffuse_color=np.tile(np.array([[0.8, 0.3, 0.2]], np.float32), (len(F), 1)))
+
+
+def _world_rays(scene):
+    """camera-space rays of the scene moved to world space (render_playground takes world-space rays)."""
+    T = scene["batch"]["T_to_world"][0].astype(np.float32)
+    ro, rd = scene["rays"]
+    o = ro @ T[:3, :3].T + T[:3, 3]
+    d = rd @ T[:3, :3].T
+    return o.astype(np.float32), d.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,w,h,opts,with_glass", [(3000, 64, 48, 0, True), (3000, 64, 48, 1, True), (12000, 96, 64, 0, False), (0, 32, 24, 0, True)])
+def test_hybrid_trace_matches_oracle(n, w, h, opts, with_glass):
+    import torch
+    pt = importlib.import_module("3dgrut_amd.playground_tracer")
+    scene = make_scene(n=max(n, 1), width=w, height=h, median_scale=0.08, max_density=0.6)
+    d12, sph = (scene["density12"], scene["sph"]) if n else (scene["density12"][:0], scene["sph"][:0])
+    mesh = _mesh(with_glass)
+    ro, rd = _world_rays(scene)
+    bg = (0.1, 0.2, 0.3)
+    tr = pt.Tracer({"render": {}})
+    g = syn.SimpleGaussians(d12, sph, requires_grad=False)
+    tr.build_gs_acc(g, rebuild=True)
+    t = lambda a, dt=None: torch.as_tensor(a, device="cuda") if dt is None else torch.as_tensor(a, device="cuda").to(dt)
+    tr.build_mesh_acc(t(mesh["vertices"]), t(mesh["triangles"]))
+    envmap = torch.tensor(bg + (1.0,)).repeat(4, 4, 1)
+    from types import SimpleNamespace
+    mats = [SimpleNamespace(diffuseFactor=[0.8, 0.3, 0.2, 1.0])]
+    out = tr.render_playground(g, t(ro), t(rd), opts, t(mesh["triangles"]), t(mesh["vertex_normals"]), None, None, t(mesh["prim_type"]),
+                               materials=mats, material_id=torch.zeros((len(mesh["triangles"]), 1), dtype=torch.int32, device="cuda"),
+                               refractive_index=t(mesh["refractive_index"]), envmap=envmap, max_pbr_bounces=7)
+    torch.cuda.synchronize()
+    nat = tr.tracer_wrapper
+    inst = nat.instances(n, "cuda").cpu().numpy() if n else np.zeros((0, 12), np.float32)
+    scene_aabb = np.array(list(nat.stats().scene_aabb), np.float32)
+    ora = oracle.grt_hybrid(oracle.default_grt_config(), d12, sph, 3, tr._min_transmittance, np.eye(4, dtype=np.float32), ro, rd, mesh, opts=opts,
+                            max_pbr_bounces=7, background=bg, inst=inst, scene=scene_aabb)
+    rgb = out["pred_features"][0].cpu().numpy()
+    opa = out["pred_opacity"][0, ..., 0].cpu().numpy()
+    b = out["mirror_bounces"][0, ..., 0].cpu().numpy()
+    assert np.array_equal(b, ora["bounces"].astype(np.int32)), f"{(b != ora['bounces']).sum()} rays with a different number of mirror bounces"
+    assert b.max() >= 1 and (b == 0).any()                       # some rays bounce, some do not
+    err = np.maximum(np.abs(rgb - ora["rgba"][..., :3]).max(-1), np.abs(opa - ora["rgba"][..., 3]))
+    assert (err > 1e-4).mean() <= 5e-3, f"{(err > 1e-4).sum()} of {err.size} pixels beyond 1e-4 (max {err.max():.3e})"
+    last = np.concatenate([out["last_ray_o"][0].cpu().numpy(), out["last_ray_d"][0].cpu().numpy()], -1)
+    assert np.abs(last - ora["last_ray"]).max() < 1e-4
+    if n == 0:   # meshes only: what a ray sees is the surface colour or the background
+        assert np.abs(rgb - ora["rgba"][..., :3]).max() < 1e-6
+
+
+def test_pbr_primitives_are_refused():
+    import torch
+    pt = importlib.import_module("3dgrut_amd.playground_tracer")
+    scene = make_scene(n=100, width=16, height=16)
+    mesh = _mesh()
+    tr = pt.Tracer({"render": {}})
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"], requires_grad=False)
+    tr.build_gs_acc(g)
+    t = lambda a: torch.as_tensor(a, device="cuda")
+    tr.build_mesh_acc(t(mesh["vertices"]), t(mesh["triangles"]))
+    prim = mesh["prim_type"].copy()
+    prim[0] = 4
+    ro, rd = _world_rays(scene)
+    with pytest.raises(NotImplementedError):
+        tr.render_playground(g, t(ro), t(rd), 0, t(mesh["triangles"]), t(mesh["vertex_normals"]), None, None, t(prim))
