@@ -122,7 +122,7 @@ class GutGradIO(C.Structure):
 EXPORTED_SYMBOLS = [
     "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_backward_unpacked", "gut_backward_factored", "grut_sph_grad_from_views", "gut_timings", "gut_stats",
     "gut_profile_enable", "gut_profile_read",
-    "gut_debug_fetch", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
+    "gut_debug_fetch", "gut_debug_fetch_work", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats",
     "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_build_mesh_bvh", "grt_trace_hybrid",
@@ -157,6 +157,8 @@ def _declare(lib):
     lib.gut_profile_enable.restype = C.c_int
     lib.gut_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gut_profile_read.restype = C.c_int
+    lib.gut_debug_fetch_work.argtypes = [C.c_void_p, vp, up, C.c_uint64]
+    lib.gut_debug_fetch_work.restype = C.c_int
     lib.gut_debug_fetch.argtypes = [C.c_void_p, vp] + [up] * 8
     lib.gut_debug_fetch.restype = C.c_int
     lib.grut_sort_pairs_u32.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, up, up, up, up, vp, C.c_uint64,

@@ -281,8 +281,9 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         h->params.poses_dev = h->poses_dev.as<FramePoses>();
     }
     if (h->count_work) {
-        GRUT_CHECK(h->work_counters.ensure(64));
-        GRUT_HIP(hipMemsetAsync(h->work_counters.ptr, 0, 64, s));
+        // 4 counters + per-wave {lifetime, start, entries, list length} of the forward sweep + {lifetime, start} of the gradient sweep's tasks
+        GRUT_CHECK(h->work_counters.ensure(128 + (size_t)tiles * 2 * 32 + 8192 + ((size_t)h->tile_capacity / kGutSegment + tiles + 64) * 2 * 16, 1.2f));
+        GRUT_HIP(hipMemsetAsync(h->work_counters.ptr, 0, h->work_counters.bytes, s));
         h->params.work = h->work_counters.as<unsigned long long>();
         h->work_pending = true;
     }
@@ -555,8 +556,16 @@ int gut_profile_read(GutHandle* h, float* stage_ms) {
 int gut_stats(GutHandle* h, GutStats* stats) {
     GRUT_REQUIRE(h && stats, "gut_stats: null argument");
     if (h->work_pending && h->work_counters.ptr) {   // instrumented frame: fetch the sweeps' counters (synchronises with the frame's stream)
-        GRUT_HIP(hipMemcpyAsync(h->work_host, h->work_counters.ptr, 32, hipMemcpyDeviceToHost, h->fwd_stream));
+        std::vector<unsigned long long> all(h->work_counters.bytes / 8);
+        GRUT_HIP(hipMemcpyAsync(all.data(), h->work_counters.ptr, all.size() * 8, hipMemcpyDeviceToHost, h->fwd_stream));
         GRUT_HIP(hipStreamSynchronize(h->fwd_stream));
+        for (int k = 0; k < 4; ++k) h->work_host[k] = all[k];
+        // the forward sweep reports per workgroup (word 18 + 4 b = accepted << 32 | evaluated): sum here
+        const size_t n_fwd = (((size_t)h->params.gx * h->params.gy + 7) & ~(size_t)7) * 2;
+        for (size_t b = 0; b < n_fwd && 16 + 4 * b + 3 < all.size(); ++b) {
+            h->work_host[0] += all[16 + 4 * b + 2] & 0xFFFFFFFFull;
+            h->work_host[1] += all[16 + 4 * b + 2] >> 32;
+        }
         h->work_pending = false;
     }
     *stats = h->stats;
@@ -564,6 +573,13 @@ int gut_stats(GutHandle* h, GutStats* stats) {
     stats->fwd_entries_accepted = h->count_work ? h->work_host[1] : 0;
     stats->bwd_entries_evaluated = h->count_work ? h->work_host[2] : 0;
     stats->bwd_entries_accepted = h->count_work ? h->work_host[3] : 0;
+    return GRUT_OK;
+}
+
+int gut_debug_fetch_work(GutHandle* h, void* stream_, unsigned long long* out, uint64_t count) {
+    GRUT_REQUIRE(h && out, "gut_debug_fetch_work: null argument");
+    GRUT_REQUIRE(h->work_counters.ptr && count * 8 <= h->work_counters.bytes, "gut_debug_fetch_work: no instrumented frame / count too large");
+    GRUT_HIP(hipMemcpyAsync(out, h->work_counters.ptr, count * 8, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream_)));
     return GRUT_OK;
 }
 

@@ -316,7 +316,10 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         b = bend;
     }
     st = FwdState{T, D, Cr, Cg, Cb, cnt};
-    if (COUNT && P.work && lane == 0) { atomicAdd(&P.work[0], (unsigned long long)n_eval); atomicAdd(&P.work[1], (unsigned long long)n_acc); }
+    if (COUNT && P.work && lane == 0) {   // per-wave words, summed on the host (atomics on two shared counters would serialise the waves' exits)
+        P.work[16 + 4 * (size_t)blockIdx.x + 2] = ((unsigned long long)n_acc << 32) | n_eval;
+        P.work[16 + 4 * (size_t)blockIdx.x + 3] = range.y - range.x;
+    }
 }
 
 template <int DEG, bool CKPT, bool COUNT = false>
@@ -330,12 +333,18 @@ __global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const u
     half_mapping(blockIdx.x, tile, half);
     if (tile >= (uint32_t)(P.gx * P.gy)) return;
     const int lane = threadIdx.x;
+    const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;   // constant-rate (100 MHz) counter shared by the whole chip
     const RayPair rp = init_ray_pair(P, ray_o, ray_d, tile, half, lane);
     const uint2 range = ranges[tile];
     FwdState st;
     // two copies of the sweep: the shared-origin one keeps the canonical origin out of the per-pixel math
     if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
     else render_fwd_sweep<DEG, CKPT, false, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
+    if (COUNT && P.work && lane == 0) {   // diagnostics: this wave's lifetime (shader-clock ticks) and start time, for the balance analysis
+        const unsigned long long t_end = wall_clock64();
+        P.work[16 + 4 * (size_t)blockIdx.x] = t_end - t_begin;
+        P.work[16 + 4 * (size_t)blockIdx.x + 1] = t_begin;
+    }
     // every pixel of the image is written (the caller does not pre-fill): rays that miss the scene box get the reference's
     // initial values (splatRaster.cpp:211-214)
     if (rp.inside0) {
@@ -620,7 +629,10 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
 #endif
     // task = (virtual tile, half).  Virtual tiles [0, bndPad) are the segments that start at segment boundary b (sorted
     // index b * kGutSegment): they are the long, dense tasks and are dispatched first so that the tail of the launch
-    // is made of the short first segments of each tile list, virtual tiles [bndPad, bndPad + tiles).
+    // is made of the short first segments of each tile list, virtual tiles [bndPad, bndPad + tiles).  Only a quarter of the
+    // launched workgroups find work on the bench frame (the forward reached 26 k of the ~106 k possible tasks alive); compacting
+    // them into a task list first (persistent workers, or one workgroup per real task) was measured and is NOT faster: the empty
+    // workgroups retire in the shadow of the running ones (DESIGN.md "Gradient sweep: task dispatch").
     const uint32_t num_tiles = (uint32_t)(P.gx * P.gy), bnd_pad = (ck.num_boundaries + 7u) & ~7u;
     uint32_t vtile, half;
     half_mapping(blockIdx.x, vtile, half);
@@ -641,8 +653,9 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
         if (seg_begin <= ranges[tile].x) return;                     // the boundary is this tile's own list start
         from_checkpoint = true;
     }
-    const uint32_t seg_end = min(ranges[tile].y, (seg_begin / kGutSegment + 1u) * kGutSegment);
     const int lane = threadIdx.x;
+    const uint32_t seg_end = min(ranges[tile].y, (seg_begin / kGutSegment + 1u) * kGutSegment);
+    const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
     const RayPair rp = init_ray_pair(P, ray_o, ray_d, tile, half, lane);
     bool alive0 = rp.valid0, alive1 = rp.valid1;
 
@@ -677,6 +690,12 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
         render_bwd_sweep<DEG, HAS_GDIST, true, COUNT>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, s_tr, px);
     else
         render_bwd_sweep<DEG, HAS_GDIST, false, COUNT>(P, rp, seg_begin, seg_end, lane, half, lists, density12, rgb, slots, s_rec, s_acc, s_acc2, s_tr, px);
+    if (COUNT && P.work && lane == 0) {   // diagnostics (after the forward sweep's block of per-wave words): lifetime and start of this task
+        const size_t gid = (size_t)atomicAdd(&P.work[8], 1ull);
+        const size_t base = 16 + 4 * (size_t)(((num_tiles + 7u) & ~7u) * 2u) + 2 * gid;
+        P.work[base] = wall_clock64() - t_begin;
+        P.work[base + 1] = t_begin;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -240,6 +240,10 @@ uint64_t grut_scan_scratch_bytes(uint32_t n);
 /* Copies the binning products of the last gut_forward to caller DEVICE buffers (any may be NULL):
  * tiles_count[N] u32, proj_pos[N,2], conic_opacity[N,4], extent[N,2], depth[N], rgb[N,3],
  * sorted_particle_idx[I] u32, tile_ranges[tiles,2] u32. */
+/* Diagnostics of an instrumented frame (gut_profile_enable level 2): the raw counter block to a caller DEVICE buffer — words 0..3 =
+ * GutStats' four entry counters, words 16 + 4 b .. 19 + 4 b = lifetime and start (100 MHz ticks), accepted << 32 | evaluated entries and
+ * tile-list length of forward-sweep workgroup b. */
+int gut_debug_fetch_work(GutHandle* handle, void* stream, unsigned long long* out, uint64_t count);
 int gut_debug_fetch(GutHandle* handle, void* stream,
                     uint32_t* tiles_count, float* proj_pos, float* conic_opacity, float* extent,
                     float* depth, float* rgb, uint32_t* sorted_particle_idx, uint32_t* tile_ranges);
