@@ -121,10 +121,10 @@ class GutGradIO(C.Structure):
 # every symbol include/grut_amd.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
     "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_backward_unpacked", "gut_backward_factored", "grut_sph_grad_from_views", "gut_timings", "gut_stats",
-    "gut_profile_enable", "gut_profile_read",
+    "gut_profile_enable", "gut_profile_select", "gut_profile_read",
     "gut_debug_fetch", "gut_debug_fetch_work", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
-    "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats",
+    "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats", "grt_debug_fetch_work",
     "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_build_mesh_bvh", "grt_trace_hybrid",
     "grut_selective_adam_update", "grut_pack_particles", "grut_unpack_particle_grads", "grut_activate_pack", "grut_activate_pack_backward",
     "grut_last_error", "grut_abi_version",
@@ -155,6 +155,8 @@ def _declare(lib):
     lib.gut_stats.restype = C.c_int
     lib.gut_profile_enable.argtypes = [C.c_void_p, C.c_int]
     lib.gut_profile_enable.restype = C.c_int
+    lib.gut_profile_select.argtypes = [C.c_void_p, C.c_uint32]
+    lib.gut_profile_select.restype = C.c_int
     lib.gut_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gut_profile_read.restype = C.c_int
     lib.gut_debug_fetch_work.argtypes = [C.c_void_p, vp, up, C.c_uint64]
@@ -190,6 +192,8 @@ def _declare(lib):
     lib.grt_trace_hybrid.restype = C.c_int
     lib.grt_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.grt_timings.restype = C.c_int
+    lib.grt_debug_fetch_work.argtypes = [C.c_void_p, vp, up, C.c_uint64]
+    lib.grt_debug_fetch_work.restype = C.c_int
     lib.grt_stats.argtypes = [C.c_void_p, C.POINTER(GrtStats)]
     lib.grt_stats.restype = C.c_int
     lib.grut_selective_adam_update.argtypes = [vp, C.POINTER(GrutAdamGroup), C.c_int, C.c_uint32, vp, C.c_int]

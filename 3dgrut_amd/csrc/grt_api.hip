@@ -44,8 +44,13 @@ struct GrtHandle {
     DeviceBuffer m_aabb, m_slack, m_scene_enc, m_scene, m_codes, m_ids, m_codes_tmp, m_ids_tmp, m_sort_scratch, m_nodes, m_done;
     uint32_t mesh_faces = 0;
     bool mesh_built = false;
+    // packet lists of the forward (GrtLists): cones, per-particle bounds and records, the binning pipeline's buffers
+    DeviceBuffer l_flags, l_block_cones, l_super_cones, l_inst_rel, l_key_bits, l_bin_v, l_counts, l_pidx, l_key_tmp, l_pidx_tmp, l_offsets,
+        l_scan_scratch, l_sort_scratch, l_block_keys, l_vals, l_pos_particle, l_block_keys_tmp, l_vals_tmp, l_entries, l_ranges;
+    uint32_t* l_host = nullptr;          // pinned: {entries, uniform-origin flag}
+    uint64_t list_entries = 0;           // of the last forward (0: the BVH walk served it)
     DeviceBuffer work_counters;  // instrumented launches (GRUT_GRT_COUNT=1): nodes, leaf tests, processed hits, rounds, inserts
-    unsigned long long work_host[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long work_host[16] = {};
 };
 
 static int grt_validate(const GrtConfig& c) {
@@ -113,10 +118,14 @@ void grt_destroy(GrtHandle* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
                             &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
-                            &h->work_counters, &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state, &h->m_aabb, &h->m_slack, &h->m_scene_enc,
+                            &h->work_counters, &h->l_flags, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits, &h->l_bin_v,
+                            &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets, &h->l_scan_scratch, &h->l_sort_scratch,
+                            &h->l_block_keys, &h->l_vals, &h->l_pos_particle, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_entries, &h->l_ranges,
+                            &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state, &h->m_aabb, &h->m_slack, &h->m_scene_enc,
                             &h->m_scene, &h->m_codes, &h->m_ids, &h->m_codes_tmp, &h->m_ids_tmp, &h->m_sort_scratch, &h->m_nodes, &h->m_done};
     for (DeviceBuffer* b : bufs) b->release();
     if (h->log_state_host) (void)hipHostFree(h->log_state_host);
+    if (h->l_host) (void)hipHostFree(h->l_host);
     if (h->log_event) (void)hipEventDestroy(h->log_event);
     h->fwd_timer.destroy();
     h->bwd_timer.destroy();
@@ -238,22 +247,85 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     }
     unsigned long long* counters = nullptr;
     if (getenv("GRUT_GRT_COUNT")) {  // development aid: work statistics of the traversal, read back by grt_stats
-        GRUT_CHECK(h->work_counters.ensure(64));
+        const size_t wbytes = 128 + 24 * ((size_t)div_up((uint32_t)P.W, 64) * div_up((uint32_t)P.H, 64) * 64 + 512);   // + 3 words per pixel block
+        GRUT_CHECK(h->work_counters.ensure(wbytes));
         counters = h->work_counters.as<unsigned long long>();
-        GRUT_HIP(hipMemsetAsync(counters, 0, 64, s));
+        GRUT_HIP(hipMemsetAsync(counters, 0, wbytes, s));
     }
-    grt_launch_trace_fwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
-                         out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters, log);
+    // packet lists (GrtLists, DESIGN.md "3DGRT: packet lists"): for a frame with ONE ray origin the candidates of every 8x8 ray packet
+    // are binned once (cones x bounding spheres, the 3DGUT pipeline) and the rounds scan windows of a sorted list instead of walking the tree
+    GrtBvh bvh = bvh_view(h);
+    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    h->list_entries = 0;
+    if (!getenv("GRUT_GRT_NO_LISTS")) {
+        const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
+        if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
+        GRUT_CHECK(h->l_flags.ensure(64));
+        GRUT_CHECK(h->l_block_cones.ensure((size_t)nb * sizeof(GrtCone), 1.25f));
+        GRUT_CHECK(h->l_super_cones.ensure((size_t)ns * sizeof(GrtCone), 1.25f));
+        GRUT_CHECK(h->l_inst_rel.ensure((size_t)N * 48, 1.25f));
+        for (DeviceBuffer* b4 : {&h->l_key_bits, &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets})
+            GRUT_CHECK(b4->ensure((size_t)N * 4, 1.25f));
+        GRUT_CHECK(h->l_bin_v.ensure((size_t)N * 16, 1.25f));
+        GRUT_CHECK(h->l_scan_scratch.ensure(scan_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
+        uint32_t* flag = h->l_flags.as<uint32_t>();
+        uint32_t* dir_len = flag + 2;
+        grt_launch_list_cones(s, P, ray_origin, ray_direction, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>());
+        grt_launch_list_count(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
+                              h->l_inst_rel.as<float>(), h->l_key_bits.as<uint32_t>(), h->l_bin_v.as<float>(), h->l_counts.as<uint32_t>(),
+                              h->l_pidx.as<uint32_t>());
+        // particles in key order, then the offsets of their entries
+        GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
+        uint32_t *sorted_key = nullptr, *rank_to_particle = nullptr;
+        GRUT_CHECK(sort_pairs_u32(s, N, nullptr, 0, 32, h->l_key_bits.as<uint32_t>(), h->l_pidx.as<uint32_t>(), h->l_key_tmp.as<uint32_t>(),
+                                  h->l_pidx_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_key, &rank_to_particle));
+        GRUT_CHECK(inclusive_scan_u32(s, N, h->l_counts.as<uint32_t>(), rank_to_particle, h->l_offsets.as<uint32_t>(), h->l_scan_scratch.ptr,
+                                      h->l_scan_scratch.bytes));
+        // the entry count sizes the rest: one round trip to the host per frame (with the one-origin flag riding along)
+        GRUT_HIP(hipMemcpyAsync(&h->l_host[0], h->l_offsets.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipMemcpyAsync(&h->l_host[1], flag, 4, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipStreamSynchronize(s));
+        const uint64_t I = h->l_host[0];
+        if (h->l_host[1] != 0u && I > 0 && I < 0xFFFF0000ull) {
+            const uint32_t n = (uint32_t)I;
+            for (DeviceBuffer* b4 : {&h->l_block_keys, &h->l_vals, &h->l_pos_particle, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_entries})
+                GRUT_CHECK(b4->ensure((size_t)n * 4, 1.3f));
+            GRUT_CHECK(h->l_ranges.ensure((size_t)nb * 8, 1.25f));
+            GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.3f) + 4096)));
+            grt_launch_list_expand(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
+                                   rank_to_particle, h->l_offsets.as<uint32_t>(), n, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(),
+                                   h->l_pos_particle.as<uint32_t>());
+            int bits = 1;
+            while ((1u << bits) < nb) ++bits;
+            uint32_t *sorted_blocks = nullptr, *sorted_pos = nullptr;
+            GRUT_CHECK(sort_pairs_u32(s, n, nullptr, 0, bits, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(), h->l_block_keys_tmp.as<uint32_t>(),
+                                      h->l_vals_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_blocks, &sorted_pos));
+            GRUT_HIP(hipMemsetAsync(h->l_ranges.ptr, 0, (size_t)nb * 8, s));
+            grt_launch_list_ranges(s, n, nb, sorted_blocks, sorted_pos, h->l_pos_particle.as<uint32_t>(), h->l_ranges.as<uint32_t>(),
+                                   h->l_entries.as<uint32_t>());
+            lists.ranges = h->l_ranges.as<uint32_t>();
+            lists.entries = h->l_entries.as<uint32_t>();
+            lists.bin_v = h->l_bin_v.as<float>();
+            lists.inst_rel = h->l_inst_rel.as<float>();
+            lists.block_cones = h->l_block_cones.as<GrtCone>();
+            lists.dir_len_enc = dir_len;
+            h->list_entries = I;
+        }
+    }
+    grt_launch_trace_fwd(s, P, bvh, particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
+                         out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters, log, lists);
     if (log.pool && !h->log_event_pending) {  // how much of the pool the frame used, read lazily by a later forward
         GRUT_HIP(hipMemcpyAsync(h->log_state_host, log.state, 8, hipMemcpyDeviceToHost, s));
         GRUT_HIP(hipEventRecord(h->log_event, s));
         h->log_event_pending = true;
     }
     if (counters) {
-        GRUT_HIP(hipMemcpyAsync(h->work_host, counters, 64, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipMemcpyAsync(h->work_host, counters, 128, hipMemcpyDeviceToHost, s));
         GRUT_HIP(hipStreamSynchronize(s));
         fprintf(stderr, "[grut] grt fwd: nodes %llu, leaf tests %llu, processed %llu, rounds %llu, inserts %llu (rays %d)\n", h->work_host[0],
                 h->work_host[1], h->work_host[2], h->work_host[3], h->work_host[4], frame->width * frame->height);
+        fprintf(stderr, "[grut] grt fwd leaf tests: passed %llu, distance out of range %llu, box missed %llu, beyond 3 sigma %llu; wave-level leaf visits %llu, of which ran the box test %llu, the insert chain %llu\n",
+                h->work_host[5], h->work_host[6], h->work_host[7], h->work_host[8], h->work_host[9], h->work_host[10], h->work_host[11]);
     }
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
@@ -381,6 +453,13 @@ int grt_timings(GrtHandle* h, float* forward_ms, float* backward_ms, float* buil
     if (forward_ms) *forward_ms = h->fwd_timer.collect();
     if (backward_ms) *backward_ms = h->bwd_timer.collect();
     if (build_ms) *build_ms = h->build_timer.collect();
+    return GRUT_OK;
+}
+
+int grt_debug_fetch_work(GrtHandle* h, void* stream_, unsigned long long* out, uint64_t count) {
+    GRUT_REQUIRE(h && out, "grt_debug_fetch_work: null argument");
+    GRUT_REQUIRE(h->work_counters.ptr && count * 8 <= h->work_counters.bytes, "grt_debug_fetch_work: no instrumented frame / count too large");
+    GRUT_HIP(hipMemcpyAsync(out, h->work_counters.ptr, count * 8, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream_)));
     return GRUT_OK;
 }
 

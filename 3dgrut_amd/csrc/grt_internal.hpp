@@ -21,8 +21,12 @@ static_assert(sizeof(GrtNode) == 64, "GrtNode must be 64 bytes");
 constexpr uint32_t kGrtLeafBit = 0x80000000u;
 constexpr uint32_t kGrtNoChild = 0xFFFFFFFFu;
 constexpr int kGrtMaxHits = 16;       // PipelineParameters::MaxNumHitPerTrace (pipelineParameters.h:83)
-constexpr int kGrtGather = 16;        // forward: candidates per traversal (16 = one trace round, 32 = two rounds from one walk)
-constexpr int kGrtStackDepth = 64;    // a radix tree over 30+32-bit keys is at most 62 levels deep
+#ifndef GRT_GATHER
+#define GRT_GATHER 16
+#endif
+constexpr int kGrtGather = GRT_GATHER;        // forward: candidates per traversal (16 = one trace round, 32 = two rounds from one walk)
+constexpr int kGrtMaxDepth = 64;      // a radix tree over 30+32-bit keys is at most 62 levels deep
+constexpr int kGrtStackDepth = 3 * kGrtMaxDepth;   // the wide walk (trace_round4) parks up to 3 nodes per level
 
 struct GrtBuildParams {
     uint32_t N;
@@ -43,6 +47,25 @@ struct GrtTraceParams {
     int W, H;
     float ray_to_world[12];
     uint32_t dbg_cap;
+};
+
+// Candidate lists of the forward for frames whose rays all start at ONE point (every pinhole / fisheye camera) — see "3DGRT: packet
+// lists" in DESIGN.md.  Each 8x8-pixel ray packet (one wave) gets the list of the particles whose proxy can be touched by one of its rays
+// (the packet's bounding cone against the proxy's bounding sphere), ascending in `key`, a lower bound of the hit distance of that
+// particle for ANY ray of the frame; `ub` is the matching upper bound.  A k = 16 trace round is then a scan of a WINDOW of the list
+// (entries whose [key, ub] can still hold a hit beyond the ray's last one, up to the 16th-nearest distance found) instead of a tree
+// walk.  Built per frame with the 3DGUT binning pipeline (count / depth sort / scan / expand / stable sort by packet / ranges).
+struct GrtCone;
+struct GrtLists {
+    const uint32_t* ranges;          // [blocks][2]: entries [first, last) of packet b (row-major 8x8 block index) in `entries`
+    const uint32_t* entries;         // [I] particle of each entry; a packet's entries ascend in the particles' sort key
+    const float* bin_v;              // [N][4] {proxy centre - ray origin, sort key}: the key is a lower bound of the hit distance for every ray
+    const float* inst_rel;           // [N,12] {W rows, W (o - mu)}: the proxy-frame ray origin is the same for all rays, computed once
+    const GrtCone* block_cones;      // [blocks] bounding cone of each packet's rays (list_round derives packet-specific bounds from it)
+    const uint32_t* dir_len_enc;     // [2] float bits of the smallest / largest ray direction length of the frame
+};
+struct GrtCone {   // bounding cone of the rays of an 8x8 packet / of a 64x64-pixel super tile, apex at the common ray origin
+    float ax, ay, az, cos_t, sin_t, valid, pad0, pad1;
 };
 
 // Log of the forward's processed hits, so that the backward replays them instead of traversing again.  One chunk =
@@ -86,11 +109,24 @@ size_t grt_scene_enc_bytes();
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
                           float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters,
-                          const GrtHitLog& log);
+                          const GrtHitLog& log, const GrtLists& lists);
 void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
                           const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log);
 
+// packet lists (GrtLists)
+void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* ray_o, const float* ray_d, uint32_t* uniform_origin,
+                           uint32_t* dir_len_enc /* [2] */, GrtCone* block_cones, GrtCone* super_cones);
+void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
+                           const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, float* inst_rel, uint32_t* key_bits,
+                           float* bin_v, uint32_t* counts, uint32_t* particle_idx);
+void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
+                            const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, const uint32_t* rank_to_particle,
+                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals, uint32_t* pos_particle);
+void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, const uint32_t* sorted_pos,
+                            const uint32_t* pos_particle, uint32_t* ranges, uint32_t* entries);
+uint32_t grt_num_blocks(int W, int H);
+uint32_t grt_num_super(int W, int H);
 void grt_launch_mesh_aabb(hipStream_t s, uint32_t F, const float* vertices, const int32_t* triangles, float* aabb, float* slack, uint32_t* scene_enc);
 void grt_launch_hybrid(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const GrtMeshView& mesh, const GrtHybridParams& hp,
                        const float* density12, const float* sph, const float* ray_o, const float* ray_d, const float* ray_max_t, float* out_rgb,

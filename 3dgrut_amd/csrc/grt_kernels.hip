@@ -254,16 +254,21 @@ struct RayW {
 __device__ __forceinline__ float safe_rcp(float v) {
     return fabsf(v) > 1e-30f ? 1.0f / v : copysignf(1.0e30f, v);
 }
+// pipelineParameters.h:97-117 (no contraction: the oracle's candidate test starts from the same world-space ray)
+__device__ __forceinline__ f3 world_origin(const GrtTraceParams& P, f3 so) {
+#pragma clang fp contract(off)
+    const float* m = P.ray_to_world;
+    return mk3(m[0] * so.x + m[1] * so.y + m[2] * so.z + m[3], m[4] * so.x + m[5] * so.y + m[6] * so.z + m[7],
+               m[8] * so.x + m[9] * so.y + m[10] * so.z + m[11]);
+}
 __device__ __forceinline__ RayW make_ray(const GrtTraceParams& P, const float* __restrict__ ray_o, const float* __restrict__ ray_d, size_t pix) {
     const f3 so = mk3(ray_o[3 * pix], ray_o[3 * pix + 1], ray_o[3 * pix + 2]);
     const f3 sd = mk3(ray_d[3 * pix], ray_d[3 * pix + 1], ray_d[3 * pix + 2]);
     const float* m = P.ray_to_world;
     RayW r;
-    // pipelineParameters.h:97-117 (no contraction: the oracle's candidate test starts from the same world-space ray)
+    r.o = world_origin(P, so);
     {
 #pragma clang fp contract(off)
-        r.o = mk3(m[0] * so.x + m[1] * so.y + m[2] * so.z + m[3], m[4] * so.x + m[5] * so.y + m[6] * so.z + m[7],
-                  m[8] * so.x + m[9] * so.y + m[10] * so.z + m[11]);
         r.d = mk3(m[0] * sd.x + m[1] * sd.y + m[2] * sd.z, m[4] * sd.x + m[5] * sd.y + m[6] * sd.z, m[8] * sd.x + m[9] * sd.y + m[10] * sd.z);
     }
     r.inv = mk3(safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z));
@@ -283,6 +288,7 @@ __device__ __forceinline__ void scene_interval(const float* __restrict__ s, cons
 struct Cand {
     float t, tnear, tfar;
     bool ok;
+    int why;   // instrumented builds: 1 = distance outside the wanted range, 2 = the ray misses the proxy's box, 3 = farther than 3 sigma
 };
 // `t_lo` / (`t_hi`, `id_hi`): the caller only wants candidates with t_lo < t and (t, id) < (t_hi, id_hi); the hit distance
 // is evaluated first and the (division-heavy) box test only for those — the values themselves are unaffected.
@@ -291,7 +297,8 @@ typedef const f4v __attribute__((address_space(4))) cfloat4;   // constant addre
 __device__ __forceinline__ float4 ld4(const float4* p, int k) { return p[k]; }
 __device__ __forceinline__ float4 ld4(const cfloat4* p, int k) { const f4v v = p[k]; return make_float4(v.x, v.y, v.z, v.w); }
 // Q = const float4 (per-lane record) or cfloat4 (wave-uniform record of a read-only array: fetched once per wave)
-template <typename Q>
+// REL: the record is a frame-relative one {W rows, W (o - mu)} (GrtBvh::inst_rel) — the proxy-frame origin is read, not computed
+template <typename Q, bool REL = false>
 __device__ __forceinline__ Cand candidate_q(const Q* __restrict__ rec, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi);
 __device__ __forceinline__ Cand candidate(const float* __restrict__ inst, const RayW& r, float t_lo = -3.0e38f, float t_hi = 3.0e38f,
                                           uint32_t id = 0u, uint32_t id_hi = 0xFFFFFFFFu) {
@@ -300,15 +307,27 @@ __device__ __forceinline__ Cand candidate(const float* __restrict__ inst, const 
 __device__ __forceinline__ Cand candidate_uniform(const float* inst, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
     return candidate_q(reinterpret_cast<const cfloat4*>(reinterpret_cast<uintptr_t>(inst)), r, t_lo, t_hi, id, id_hi);
 }
-template <typename Q>
+// proxy-frame origin W (o - mu) of one record: the ONE definition shared by the candidate test and the frame-relative tables
+__device__ __forceinline__ f3 proxy_origin(const float4& a, const float4& b, const float4& e, f3 o) {
+#pragma clang fp contract(off)
+    const float dlx = o.x - e.y, dly = o.y - e.z, dlz = o.z - e.w;
+    return mk3(a.x * dlx + a.y * dly + a.z * dlz, a.w * dlx + b.x * dly + b.y * dlz, b.z * dlx + b.w * dly + e.x * dlz);
+}
+template <bool REL>
+__device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi);
+template <typename Q, bool REL>
 __device__ __forceinline__ Cand candidate_q(const Q* __restrict__ rec, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
+    const float4 a = ld4(rec, 0), b = ld4(rec, 1), e = ld4(rec, 2);
+    return candidate_abe<REL>(a, b, e, r, t_lo, t_hi, id, id_hi);
+}
+template <bool REL>
+__device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
 #pragma clang fp contract(off)
     Cand c;
-    c.ok = false; c.t = 0.f; c.tnear = 0.f; c.tfar = 0.f;
-    const float4 a = ld4(rec, 0), b = ld4(rec, 1), e = ld4(rec, 2);
+    c.ok = false; c.t = 0.f; c.tnear = 0.f; c.tfar = 0.f; c.why = 1;
     // inst = {W00 W01 W02 W10 | W11 W12 W20 W21 | W22 mux muy muz}
-    const float dlx = r.o.x - e.y, dly = r.o.y - e.z, dlz = r.o.z - e.w;
-    const float pox = a.x * dlx + a.y * dly + a.z * dlz, poy = a.w * dlx + b.x * dly + b.y * dlz, poz = b.z * dlx + b.w * dly + e.x * dlz;
+    const f3 po = REL ? mk3(e.y, e.z, e.w) : proxy_origin(a, b, e, r.o);
+    const float pox = po.x, poy = po.y, poz = po.z;
     const float pdx = a.x * r.d.x + a.y * r.d.y + a.z * r.d.z, pdy = a.w * r.d.x + b.x * r.d.y + b.y * r.d.z,
                 pdz = b.z * r.d.x + b.w * r.d.y + e.x * r.d.z;
     // intersectInstanceParticle: hit distance = closest approach in the proxy's frame
@@ -325,7 +344,9 @@ __device__ __forceinline__ Cand candidate_q(const Q* __restrict__ rec, const Ray
     auto mx = [](float x, float y) { return x > y ? x : y; };
     const float tnear = mx(mx(mn(ax0, ax1), mn(ay0, ay1)), mn(az0, az1));
     const float tfar = mn(mn(mx(ax0, ax1), mx(ay0, ay1)), mx(az0, az1));
+    c.why = 2;
     if (!(tnear <= tfar)) return c;
+    c.why = 3;
     c.tnear = tnear; c.tfar = tfar;
     const float il = dd > 0.f ? 1.f / sqrtf(dd) : 1.f;
     const float nx = pdx * il, ny = pdy * il, nz = pdz * il;
@@ -424,7 +445,7 @@ __device__ __forceinline__ PixelBlock pixel_block(int W, int H) {
 
 // one optixTrace: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in (t, particle)
 struct TraceCounters {
-    uint32_t nodes = 0, leaf_tests = 0, inserts = 0, rounds = 0, processed = 0;
+    uint32_t nodes = 0, leaf_tests = 0, inserts = 0, rounds = 0, processed = 0, rej[4] = {0, 0, 0, 0}, wave_leaves = 0, wave_slab = 0, wave_insert = 0;
 };
 
 // one optixTrace for every ray of the wave: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in
@@ -436,7 +457,7 @@ struct TraceCounters {
 // its own current 16th-nearest distance); lanes that are done (`active` false) just ride along.
 template <bool COUNT, int G = kGrtMaxHits>
 __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, float tmin, float tmax, bool active, int lane,
-                                            uint32_t* __restrict__ stack /* [64] per wave */, HitBufferT<G>& buf, TraceCounters& tc) {
+                                            uint32_t* __restrict__ stack /* [kGrtStackDepth] per wave */, HitBufferT<G>& buf, TraceCounters& tc) {
     buf.clear();
     if (COUNT && active) tc.rounds++;
     if (!__any(active)) return;
@@ -464,32 +485,27 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
         const bool h1 = active && (c1 != kGrtNoChild) && ok1 && (tf1 >= tmin) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
         bool a0 = __any(h0), a1 = __any(h1);
         // leaves are tested on the spot, by the lanes whose ray touches the leaf's box
-        if (a0 && (c0 & kGrtLeafBit)) {
-            const uint32_t id = c0 & ~kGrtLeafBit;
-            if (h0) {
-                const Cand c = candidate_uniform(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
-                if (COUNT) tc.leaf_tests++;
-                if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
-                    hit_less(c.t, id, buf.t[G - 1], buf.id[G - 1])) {
-                    buf.insert(c.t, id);
+        auto leaf = [&](uint32_t c, bool h) {
+            const uint32_t id = c & ~kGrtLeafBit;
+            if (h) {
+                const Cand cd = candidate_uniform(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
+                const bool ins = cd.ok && (cd.t > tmin) && (cd.t < tmax) && (cd.tfar >= tmin) && (cd.tnear <= tmax) &&
+                                 hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
+                if (COUNT) {   // per lane: outcome of the test; per wave (first active lane): did the box part / the insert chain run at all
+                    tc.leaf_tests++; tc.rej[cd.ok ? 0 : cd.why]++;
+                    const unsigned long long ms = __ballot(cd.ok || cd.why != 1), mi = __ballot(ins);
+                    if (ms && lane == __ffsll((long long)ms) - 1) tc.wave_slab++;
+                    if (mi && lane == __ffsll((long long)mi) - 1) tc.wave_insert++;
+                }
+                if (ins) {
+                    buf.insert(cd.t, id);
                     if (COUNT) tc.inserts++;
                 }
             }
-            a0 = false;
-        }
-        if (a1 && (c1 & kGrtLeafBit)) {
-            const uint32_t id = c1 & ~kGrtLeafBit;
-            if (h1) {
-                const Cand c = candidate_uniform(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
-                if (COUNT) tc.leaf_tests++;
-                if (c.ok && (c.t > tmin) && (c.t < tmax) && (c.tfar >= tmin) && (c.tnear <= tmax) &&
-                    hit_less(c.t, id, buf.t[G - 1], buf.id[G - 1])) {
-                    buf.insert(c.t, id);
-                    if (COUNT) tc.inserts++;
-                }
-            }
-            a1 = false;
-        }
+            if (COUNT && lane == 0) tc.wave_leaves++;
+        };
+        if (a0 && (c0 & kGrtLeafBit)) { leaf(c0, h0); a0 = false; }
+        if (a1 && (c1 & kGrtLeafBit)) { leaf(c1, h1); a1 = false; }
         if (a0 && a1) {  // enter the child most lanes reach first, keep the other
             const int v0 = __popcll(__ballot(h0 && (!h1 || tn0 <= tn1))), v1 = __popcll(__ballot(h1 && (!h0 || tn1 < tn0)));
             const bool first0 = v0 >= v1;
@@ -501,6 +517,138 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
             cur = a0 ? c0 : c1;
             have = true;
         }
+    }
+}
+
+// Tight bounds of the hit distance of one particle for the rays of ONE packet (cone axis `k`, half angle theta): the closest-approach point
+// x = o + t d - mu lies in the ellipsoid |W x| <= sqrt 3, so t |d| = v.dh + x.dh with |x.dh| <= sqrt 3 |S R^T dh| (support function);
+// over the cone, v.dh = |v| cos(phi) with phi within theta of the angle between v and the axis, and the support function is
+// kmax-Lipschitz in dh.  (S R^T dh)_i = kscl_i^2 (W_i . dh).
+__device__ __forceinline__ void packet_bounds(const GrtCone& k, f3 v, float L2, const float4& a, const float4& b, float w22, float key, float ub,
+                                              float dmin, float dmax, float& lo, float& hi) {
+    lo = key; hi = ub;
+    if (k.cos_t <= -1.f) return;   // cone of everything
+    const float L = sqrtf(L2);
+    const float k0 = 1.f / (a.x * a.x + a.y * a.y + a.z * a.z), k1 = 1.f / (a.w * a.w + b.x * b.x + b.y * b.y), k2 = 1.f / (b.z * b.z + b.w * b.w + w22 * w22);   // kscl^2
+    const float kmax = sqrtf(fmaxf(k0, fmaxf(k1, k2)));
+    const float s0 = k0 * (a.x * k.ax + a.y * k.ay + a.z * k.az), s1 = k1 * (a.w * k.ax + b.x * k.ay + b.y * k.az), s2 = k2 * (b.z * k.ax + b.w * k.ay + w22 * k.az);
+    const float chord = sqrtf(fmaxf(0.f, 2.f * (1.f - k.cos_t)));
+    const float h = 1.7320509f * (sqrtf(s0 * s0 + s1 * s1 + s2 * s2) + kmax * chord) * 1.00002f + 1e-7f * L;
+    const float ca = L > 0.f ? fminf(1.f, fmaxf(-1.f, (v.x * k.ax + v.y * k.ay + v.z * k.az) / L)) : 1.f;
+    const float sa = sqrtf(fmaxf(0.f, 1.f - ca * ca));
+    const float cmax = (ca >= k.cos_t) ? 1.f : fminf(1.f, ca * k.cos_t + sa * k.sin_t + 4e-6f);     // cos of (alpha - theta), or 1 inside the cone
+    const float cmin = (ca <= -k.cos_t) ? -1.f : fmaxf(-1.f, ca * k.cos_t - sa * k.sin_t - 4e-6f);  // cos of (alpha + theta), or -1 past pi
+    const float tl = L * cmin - h, th = L * cmax + h;   // bounds of t |d|
+    const float l2 = tl > 0.f ? (tl / dmax) * (1.f - 4e-6f) : 0.f;
+    const float h2 = th > 0.f ? (th / dmin) * (1.f + 4e-6f) + 1e-30f : 0.f;
+    lo = fmaxf(lo, l2);
+    hi = fminf(hi, h2);
+}
+// ---------------------------------------------------------------------------------------------
+// packet lists (GrtLists): one k = 16 trace round as a scan of a window of the packet's candidate list
+// ---------------------------------------------------------------------------------------------
+// max over the wave of non-negative floats (or any mix with at least one non-negative value): the four DPP steps leave each 16-lane
+// row's maximum in all its lanes, the rows meet on the scalar unit (the bit patterns of non-negative floats order like integers)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = fmaxf(v, dpp_perm<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_perm<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_perm<0x141>(v));   // row_half_mirror
+    v = fmaxf(v, dpp_perm<0x140>(v));   // row_mirror
+    const int a = __builtin_amdgcn_readlane(__float_as_int(v), 0), b = __builtin_amdgcn_readlane(__float_as_int(v), 16);
+    const int c = __builtin_amdgcn_readlane(__float_as_int(v), 32), d = __builtin_amdgcn_readlane(__float_as_int(v), 48);
+    return __int_as_float(max(max(a, b), max(c, d)));
+}
+struct ListEntry {
+    float4 a, b, e;    // proxy record {W rows, W (o - mu)}
+    uint32_t id;       // particle
+    float lo, hi, key; // hit-distance bounds for THIS packet's rays, and the list's sort key (a bound for every ray of the frame)
+};
+// one entry per lane: the particle's records are gathered and its packet-specific bounds computed on the spot (one lane per entry:
+// a few dozen operations per 64 entries of wave time)
+__device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const GrtCone& cone, float dmin, float dmax, uint32_t e, uint32_t end) {
+    ListEntry x;
+    x.a = x.b = x.e = make_float4(0.f, 0.f, 0.f, 0.f);
+    x.id = 0xFFFFFFFFu; x.lo = 3.0e38f; x.hi = -3.0e38f; x.key = 3.0e38f;   // dead for every ray, beyond every bound
+    if (e < end) {
+        x.id = L.entries[e];
+        if (x.id != 0xFFFFFFFFu) {
+            const float4* rec = reinterpret_cast<const float4*>(L.inst_rel) + 3 * (size_t)x.id;
+            x.a = rec[0]; x.b = rec[1]; x.e = rec[2];
+            const float4 vk = reinterpret_cast<const float4*>(L.bin_v)[x.id];
+            const f3 v = mk3(vk.x, vk.y, vk.z);
+            x.key = vk.w;
+            packet_bounds(cone, v, dot(v, v), x.a, x.b, x.e.x, vk.w, 3.0e38f, dmin, dmax, x.lo, x.hi);
+        }
+    }
+    return x;
+}
+// One optixTrace for every ray of the wave out of the packet's list [.., le) (ascending key): the 16 nearest candidates with t in
+// (tmin, tmax), per lane, with the candidate arithmetic and the buffers of trace_round — same sets, same order.  Entries are fetched
+// 64 at a time, one per lane (record gathered by particle), and parked in LDS; ONE vector compare per batch then tells which of them
+// can matter to some ray of the wave now — [lo, hi] reaches past the rays' last hit distances (hi >= min over lanes of tmin) and not
+// beyond every lane's current 16th-nearest distance (lo <= max over lanes of the bound) — and only those are tested, by all lanes,
+// against wave-uniform LDS reads (fetching the records through the scalar cache instead, one request ahead, was measured slower:
+// 22.6 vs 20.0 ms).  The scan starts at `start` (everything before it is dead for every ray for good: hi < the rays' last hit
+// distances, which only grow) and ends with the first key beyond the bound (keys are lower bounds of lo: nothing that follows can
+// enter a buffer).
+template <bool COUNT, int G>
+__device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& cone, float dmin, float dmax, uint32_t le, uint32_t& start, const RayW& r,
+                                           float tmin, float tmax, bool active, int lane, float4* __restrict__ s_ent /* [64][3] */, HitBufferT<G>& buf,
+                                           TraceCounters& tc) {
+    buf.clear();
+    if (COUNT && active) tc.rounds++;
+    if (!__any(active)) return;
+    const float wmin_tmin = wave_min(active ? tmin : 3.0e38f);
+    float wmax_bound = wave_max_nonneg(active ? tmax : -1.f);   // no lane holds 16 candidates yet
+    bool seen_live = false;
+    uint32_t base = start & ~63u;
+    ListEntry nxt = load_list_entry(L, cone, dmin, dmax, base + lane, le);
+    while (base < le) {
+        s_ent[lane * 3 + 0] = nxt.a; s_ent[lane * 3 + 1] = nxt.b; s_ent[lane * 3 + 2] = nxt.e;
+        const uint32_t my_id = nxt.id;
+        const float my_lo = nxt.lo, my_hi = nxt.hi, my_key = nxt.key;
+        __syncthreads();   // single-wave workgroup: orders the LDS hand-off
+        const uint32_t bend = min(le, base + 64u);
+        nxt = load_list_entry(L, cone, dmin, dmax, bend + lane, le);   // the following batch travels while this one is tested
+        const bool mine = (base + (uint32_t)lane >= start) && (base + (uint32_t)lane < bend);
+        const unsigned long long beyond = __ballot(mine && my_key > wmax_bound);           // a suffix of the batch (keys ascend)
+        const unsigned long long dead = __ballot(!mine || my_hi < wmin_tmin);              // behind every ray's last hit (or not in the scan)
+        unsigned long long live = __ballot(mine && !(my_hi < wmin_tmin) && !(my_lo > wmax_bound)) & (beyond ? ((1ull << (__ffsll((long long)beyond) - 1)) - 1ull) : ~0ull);
+        if (!seen_live) {   // the scan start moves past the leading entries that are dead for good
+            const unsigned long long alive = ~dead;
+            const uint32_t lead = alive ? (uint32_t)(__ffsll((long long)alive) - 1) : 64u;
+            start = max(start, min(base + lead, bend));
+            seen_live = alive != 0ull;
+        }
+        int tested = 0;
+        while (live) {
+            const int j = __ffsll((long long)live) - 1;
+            live &= live - 1;
+            const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
+            if (COUNT && lane == 0) tc.wave_leaves++;
+            if (active) {
+                const Cand cd = candidate_abe<true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
+                const bool ins = cd.ok && (cd.t > tmin) && (cd.t < tmax) && (cd.tfar >= tmin) && (cd.tnear <= tmax) && hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
+                if (COUNT) {
+                    tc.leaf_tests++; tc.rej[cd.ok ? 0 : cd.why]++;
+                    const unsigned long long ms = __ballot(cd.ok || cd.why != 1), mi = __ballot(ins);
+                    if (ms && lane == __ffsll((long long)ms) - 1) tc.wave_slab++;
+                    if (mi && lane == __ffsll((long long)mi) - 1) tc.wave_insert++;
+                }
+                if (ins) {
+                    buf.insert(cd.t, id);
+                    if (COUNT) tc.inserts++;
+                }
+            }
+            if ((++tested & 7) == 0 && live) {   // tighten the bound now and then: entries that fell beyond it leave the batch's work list
+                wmax_bound = wave_max_nonneg(active ? fminf(tmax, buf.t[G - 1]) : -1.f);
+                live &= __ballot(!(my_lo > wmax_bound));
+            }
+        }
+        __syncthreads();
+        if (beyond) break;
+        wmax_bound = wave_max_nonneg(active ? fminf(tmax, buf.t[G - 1]) : -1.f);
+        base = bend;
     }
 }
 
@@ -594,7 +742,7 @@ __device__ __forceinline__ HitGeom hit_geometry(const GrtTraceParams& P, const P
 // ---------------------------------------------------------------------------------------------
 // forward: __raygen__rg of referenceOptix.cu:103-186
 // ---------------------------------------------------------------------------------------------
-template <int DEG, bool COUNT>
+template <int DEG, bool COUNT, bool UNI>
 // 4 waves per SIMD (128 VGPRs): the walk is a chain of dependent fetches, a fourth wave hides more of it than the few
 // spilled registers cost (measured: 65.8 -> 60.2 ms at 1M particles, 800x800; 5 waves: 69.9 ms)
 #ifndef GRT_FWD_WAVES
@@ -607,19 +755,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                                                            float* __restrict__ out_nrm, float* __restrict__ out_cnt,
                                                            int32_t* __restrict__ visibility, uint32_t* __restrict__ dbg_ids,
                                                            uint32_t* __restrict__ dbg_count, unsigned long long* __restrict__ counters,
-                                                           GrtHitLog log) {
+                                                           GrtHitLog log, GrtLists lists) {
     constexpr int kGather = kGrtGather;   // candidates gathered per traversal: one or two trace rounds of the reference
-    __shared__ uint32_t s_stack[kGrtStackDepth];
-    __shared__ float s_hit_t[kGather * 64];
+    __shared__ uint32_t s_stack[UNI ? 1 : kGrtStackDepth];
+    __shared__ float s_hit_t[kGather * 64];      // (UNI: the round's staged list entries live here while it is scanned, float4 s_ent[64][3])
     __shared__ uint32_t s_hit_id[kGather * 64];
+    static_assert(kGather * 64 * 4 >= 64 * 3 * 16, "the staged list entries must fit the parked hit distances");
+    float4* s_ent = reinterpret_cast<float4*>(s_hit_t);
     TraceCounters tc;
     const int lane = threadIdx.x;
     const PixelBlock pb = pixel_block(P.W, P.H);
     if (!pb.inside) return;
+    const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
     const int px = pb.bx * 8 + (lane & 7), py = pb.by * 8 + (lane >> 3);
     const bool in_image = (px < P.W) && (py < P.H);
     const size_t pix = in_image ? (size_t)py * P.W + px : 0;  // out-of-image lanes shadow pixel 0 and never write
     const RayW r = make_ray(P, ray_o, ray_d, pix);
+    uint32_t list_end = 0u, list_start = 0u;   // UNI: this packet's candidate list and the scan start (see list_round)
+    GrtCone cone = {0.f, 0.f, 1.f, -1.f, 0.f, 1.f, 0.f, 0.f};
+    float dmin = 1.f, dmax = 1.f;
+    if (UNI) {
+        list_start = lists.ranges[2 * (size_t)pb.index];
+        list_end = lists.ranges[2 * (size_t)pb.index + 1];
+        cone = lists.block_cones[pb.index];
+        dmin = __uint_as_float(lists.dir_len_enc[0]); dmax = __uint_as_float(lists.dir_len_enc[1]);
+    }
     float basis[16];
     // (filled at the start of each round's processing: 16 registers kept alive across the tree walk cost occupancy)
 
@@ -700,7 +860,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         if (!__any(running)) break;
         {
             HitBufferT<kGather> buf;
-            trace_round<COUNT, kGather>(bvh, r, tLast + eps, tExit + eps, running, lane, s_stack, buf, tc);
+            if (UNI) list_round<COUNT, kGather>(lists, cone, dmin, dmax, list_end, list_start, r, tLast + eps, tExit + eps, running, lane, s_ent, buf, tc);
+            else trace_round<COUNT, kGather>(bvh, r, tLast + eps, tExit + eps, running, lane, s_stack, buf, tc);
             buf.store(s_hit_t, s_hit_id, lane);
         }
         if (s_hit_id[lane] == 0xFFFFFFFFu) running = false;
@@ -758,11 +919,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         log.nbwd[pix] = (tLast < endT) ? nproc : nproc - nties;
     }
     if (COUNT) {  // work statistics for GrtStats (instrumented launches only)
+        if (lane == 0) {   // per block: start and lifetime on the chip-wide 100 MHz counter, node visits (balance analysis, scripts/diag_grt_balance.py)
+            const unsigned long long t_end = wall_clock64();
+            counters[16 + 3 * (size_t)blockIdx.x] = t_begin;
+            counters[16 + 3 * (size_t)blockIdx.x + 1] = t_end - t_begin;
+            counters[16 + 3 * (size_t)blockIdx.x + 2] = ((unsigned long long)tc.nodes << 32) | tc.wave_leaves;
+        }
         atomicAdd(&counters[0], (unsigned long long)tc.nodes);
         atomicAdd(&counters[1], (unsigned long long)tc.leaf_tests);
         atomicAdd(&counters[2], (unsigned long long)tc.processed);
         atomicAdd(&counters[3], (unsigned long long)tc.rounds);
         atomicAdd(&counters[4], (unsigned long long)tc.inserts);
+        for (int k = 0; k < 4; ++k) atomicAdd(&counters[5 + k], (unsigned long long)tc.rej[k]);   // [5] = passed all three tests
+        atomicAdd(&counters[9], (unsigned long long)tc.wave_leaves);
+        atomicAdd(&counters[10], (unsigned long long)tc.wave_slab);
+        atomicAdd(&counters[11], (unsigned long long)tc.wave_insert);
     }
 }
 
@@ -1444,7 +1615,7 @@ void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_code
 }
 void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float* slack, GrtNode* nodes, uint8_t* done) {
     // a radix tree over 30-bit keys + 32 index bits (duplicates) is at most 62 levels deep; finished passes cost a few us
-    const uint32_t passes = N <= 2 ? 1u : (uint32_t)kGrtStackDepth - 2u;
+    const uint32_t passes = N <= 2 ? 1u : (uint32_t)kGrtMaxDepth - 2u;
     for (uint32_t p = 0; p < passes; ++p)
         hipLaunchKernelGGL(grt_refit_pass_kernel, dim3(div_up(N > 1 ? N - 1 : 1u, 256)), dim3(256), 0, s, N, p, aabb, slack, nodes, done);
 }
@@ -1460,20 +1631,271 @@ void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float*
     default: { constexpr int D_ = 4; __VA_ARGS__; } break;     \
     }
 
+// ---------------------------------------------------------------------------------------------
+// packet lists: bounding cones of the ray packets, particle binning (the 3DGUT pipeline over cones instead of screen tiles)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t blocks_x(int W) { return (uint32_t)(W + 7) / 8u; }
+__host__ __device__ __forceinline__ uint32_t blocks_y(int H) { return (uint32_t)(H + 7) / 8u; }
+uint32_t grt_num_blocks(int W, int H) { return blocks_x(W) * blocks_y(H); }
+uint32_t grt_num_super(int W, int H) { return ((blocks_x(W) + 7u) / 8u) * ((blocks_y(H) + 7u) / 8u); }
+
+__global__ void grt_list_init_kernel(uint32_t* __restrict__ flag, uint32_t* __restrict__ dir_len_enc) {
+    flag[0] = 1u;
+    dir_len_enc[0] = 0x7F7FFFFFu;   // min |d| (bit patterns of positive floats order like integers)
+    dir_len_enc[1] = 0u;            // max |d|
+}
+// one wave per 8x8 packet: bounding cone of its rays' directions, |d| range, and whether every ray starts where ray 0 does
+__global__ __launch_bounds__(64) void grt_block_cone_kernel(GrtTraceParams P, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                            uint32_t* __restrict__ flag, uint32_t* __restrict__ dir_len_enc, GrtCone* __restrict__ cones) {
+    const uint32_t b = blockIdx.x, gx = blocks_x(P.W);
+    const int lane = threadIdx.x;
+    const int px = (int)(b % gx) * 8 + (lane & 7), py = (int)(b / gx) * 8 + (lane >> 3);
+    const bool in_image = (px < P.W) && (py < P.H);
+    const size_t pix = in_image ? (size_t)py * P.W + px : 0;
+    const bool same = (__float_as_uint(ray_o[3 * pix]) == __float_as_uint(ray_o[0])) && (__float_as_uint(ray_o[3 * pix + 1]) == __float_as_uint(ray_o[1])) &&
+                      (__float_as_uint(ray_o[3 * pix + 2]) == __float_as_uint(ray_o[2]));
+    const RayW r = make_ray(P, ray_o, ray_d, pix);
+    const float len = sqrtf(dot(r.d, r.d));
+    const bool good = in_image && len > 0.f && len < 3.0e38f;
+    const f3 dh = good ? r.d * (1.f / len) : mk3(0.f, 0.f, 0.f);
+    const f3 sum = mk3(wave_sum(dh.x), wave_sum(dh.y), wave_sum(dh.z));
+    const float sl = sqrtf(dot(sum, sum));
+    const f3 axis = sl > 0.f ? sum * (1.f / sl) : mk3(0.f, 0.f, 1.f);
+    const float cmin = wave_min(good ? dot(dh, axis) : 1.f);
+    const float lmin = wave_min(good ? len : 3.0e38f), lmax = wave_max(good ? len : 0.f);
+    const bool bad = __any(in_image && !good);   // a degenerate direction: no cone, no lists for this frame
+    if (lane == 0) {
+        GrtCone c;
+        c.ax = axis.x; c.ay = axis.y; c.az = axis.z;
+        // widened by rounding margins; a cone of 90 degrees or more (or no axis) holds everything
+        const float ct = cmin * (1.f - 4e-6f) - 4e-6f;
+        const bool all = !(ct > 0.05f) || !(sl > 0.f);
+        c.cos_t = all ? -1.f : ct;
+        c.sin_t = all ? 0.f : sqrtf(fmaxf(0.f, 1.f - ct * ct));
+        c.valid = __any(in_image) ? 1.f : 0.f;
+        c.pad0 = c.pad1 = 0.f;
+        cones[b] = c;
+        if (lmin < 3.0e38f) {
+            atomicMin(&dir_len_enc[0], __float_as_uint(lmin));
+            atomicMax(&dir_len_enc[1], __float_as_uint(lmax));
+        }
+        if (bad) flag[0] = 0u;
+    }
+    if (__any(in_image && !same) && lane == 0) flag[0] = 0u;
+}
+// one wave per super tile (8x8 packets): cone around its packets' cones
+__global__ __launch_bounds__(64) void grt_super_cone_kernel(GrtTraceParams P, const GrtCone* __restrict__ cones, GrtCone* __restrict__ super_cones) {
+    const uint32_t s = blockIdx.x, gx = blocks_x(P.W), gy = blocks_y(P.H), sx = (gx + 7u) / 8u;
+    const int lane = threadIdx.x;
+    const uint32_t bx = (s % sx) * 8u + (uint32_t)(lane & 7), by = (s / sx) * 8u + (uint32_t)(lane >> 3);
+    const bool have = bx < gx && by < gy;
+    GrtCone c = {0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+    if (have) c = cones[by * gx + bx];
+    const bool use = have && c.valid != 0.f;
+    const f3 a = use ? mk3(c.ax, c.ay, c.az) : mk3(0.f, 0.f, 0.f);
+    const f3 sum = mk3(wave_sum(a.x), wave_sum(a.y), wave_sum(a.z));
+    const float sl = sqrtf(dot(sum, sum));
+    const f3 axis = sl > 0.f ? sum * (1.f / sl) : mk3(0.f, 0.f, 1.f);
+    float ang = 0.f;
+    if (use) ang = (c.cos_t <= -1.f) ? 4.f : acosf(fminf(1.f, fmaxf(-1.f, dot(a, axis)))) + acosf(fminf(1.f, c.cos_t)) + 1e-5f;
+    const float amax = wave_max(ang);
+    if (lane == 0) {
+        GrtCone o;
+        o.ax = axis.x; o.ay = axis.y; o.az = axis.z;
+        const bool all = !(amax < 1.5f) || !(sl > 0.f);
+        o.cos_t = all ? -1.f : cosf(amax);
+        o.sin_t = all ? 0.f : sinf(amax);
+        o.valid = __any(use) ? 1.f : 0.f;
+        o.pad0 = o.pad1 = 0.f;
+        super_cones[s] = o;
+    }
+}
+// does the sphere (centre v relative to the apex, |v|^2 = L2, radius R) reach into the cone?  distance from the centre to the cone's
+// surface <= s cos - c sin with c, s the centre's coordinates along / across the axis (a projection: never above the true distance)
+__device__ __forceinline__ bool cone_hit(const GrtCone& k, f3 v, float L2, float R) {
+    const float c = v.x * k.ax + v.y * k.ay + v.z * k.az;
+    const float sq = sqrtf(fmaxf(0.f, L2 - c * c));
+    return (k.valid != 0.f) && (sq * k.cos_t - c * k.sin_t <= R * 1.00001f + 1e-12f);
+}
+struct BinParticle {
+    f3 v;            // proxy centre relative to the ray origin
+    float L2, Rs;    // |v|^2, radius of the proxy box's bounding sphere
+    float key, ub;   // bounds of the hit distance t for any ray of the frame
+};
+// bounds: the hit "distance" t of a candidate is the ray parameter of the point closest to the centre in the proxy's metric; that point
+// lies within sqrt(3) max(kscl) of the centre whenever the ray touches the proxy box (the box holds a point of the ray at metric distance
+// <= sqrt 3 and the closest one is no farther), so |o + t d - mu| <= Rt and (|v| - Rt) / |d| <= t <= (|v| + Rt) / |d|
+__device__ __forceinline__ BinParticle bin_particle(const float4& a, const float4& b, const float4& e, f3 o, float dmin, float dmax) {
+    BinParticle q;
+    const float k0 = 1.f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), k1 = 1.f / sqrtf(a.w * a.w + b.x * b.x + b.y * b.y),
+                k2 = 1.f / sqrtf(b.z * b.z + b.w * b.w + e.x * e.x);   // rows of W = R^T / kscl
+    q.Rs = sqrtf(k0 * k0 + k1 * k1 + k2 * k2) * 1.00001f;
+    const float Rt = 1.7320509f * fmaxf(k0, fmaxf(k1, k2)) * 1.00001f;
+    q.v = mk3(e.y - o.x, e.z - o.y, e.w - o.z);
+    q.L2 = dot(q.v, q.v);
+    const float L = sqrtf(q.L2);
+    const float lo = L * (1.f - 2e-6f) - Rt;
+    q.key = lo > 0.f ? (lo / dmax) * (1.f - 2e-6f) : 0.f;           // (a hit needs t > 0)
+    q.ub = ((L * (1.f + 2e-6f) + Rt) / dmin) * (1.f + 2e-6f) + 1e-30f;
+    return q;
+}
+// The packets a particle's bounding sphere reaches, for the 64 particles of a wave: the super tiles are visited by all lanes together
+// (each lane tests its own particle against the super tile's cone); for every (particle, super tile) pair that passes, the 64 lanes
+// test the super tile's 64 packets for that one particle — a particle that covers the screen costs the wave one step per super tile,
+// not one lane 64 steps per super tile.  EMIT: write the entries (counting pass otherwise).
+struct BinOut {
+    uint32_t *block_keys, *vals, *pos_particle;
+};
+template <bool EMIT>
+__device__ __forceinline__ uint32_t bin_pairs(const GrtTraceParams& P, const GrtCone* __restrict__ block_cones, const GrtCone* __restrict__ super_cones,
+                                              int lane, bool have, const BinParticle& q, uint32_t pid, uint32_t off, uint32_t end, const BinOut& out) {
+    const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H), sx = (gx + 7u) / 8u, sy = (gy + 7u) / 8u;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint32_t n = 0;
+    auto bc = [](float x, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src)); };
+    for (uint32_t s = 0; s < sx * sy; ++s) {
+        unsigned long long m = __ballot(have && cone_hit(super_cones[s], q.v, q.L2, q.Rs));
+        const uint32_t bx = (s % sx) * 8u + (uint32_t)(lane & 7), by = (s / sx) * 8u + (uint32_t)(lane >> 3);
+        const bool exists = bx < gx && by < gy;
+        const uint32_t b = exists ? by * gx + bx : 0u;
+        GrtCone kc = {0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+        if (m && exists) kc = block_cones[b];
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const f3 v = mk3(bc(q.v.x, src), bc(q.v.y, src), bc(q.v.z, src));
+            const float L2 = bc(q.L2, src), Rs = bc(q.Rs, src);
+            const bool hit = exists && cone_hit(kc, v, L2, Rs);
+            const unsigned long long hm = __ballot(hit);
+            const uint32_t cnt = (uint32_t)__popcll(hm);
+            if (EMIT) {
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, src), e = (uint32_t)__builtin_amdgcn_readlane((int)end, src);
+                const uint32_t slot = o + (uint32_t)__popcll(hm & lt);
+                if (hit && slot < e) {
+                    out.block_keys[slot] = b;
+                    out.vals[slot] = slot;
+                    out.pos_particle[slot] = (uint32_t)__builtin_amdgcn_readlane((int)pid, src);
+                }
+                if (lane == src) off += cnt;
+            } else if (lane == src) {
+                n += cnt;
+            }
+        }
+    }
+    if (EMIT) {
+        for (; off < end; ++off) {   // (same tests as the counting pass: not expected)
+            out.block_keys[off] = 0xFFFFFFFFu; out.vals[off] = off; out.pos_particle[off] = 0xFFFFFFFFu;
+        }
+    }
+    return n;
+}
+__global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, GrtBvh bvh, const float* __restrict__ ray_o,
+                                                             const uint32_t* __restrict__ flag, const uint32_t* __restrict__ dir_len_enc,
+                                                             const GrtCone* __restrict__ block_cones, const GrtCone* __restrict__ super_cones,
+                                                             float* __restrict__ inst_rel, uint32_t* __restrict__ key_bits, float4* __restrict__ bin_v,
+                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ particle_idx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool have = i < bvh.N && flag[0] != 0u;
+    float4 a = make_float4(1.f, 0.f, 0.f, 0.f), b = make_float4(1.f, 0.f, 0.f, 0.f), e = make_float4(1.f, 0.f, 0.f, 0.f);
+    const f3 o = world_origin(P, mk3(ray_o[0], ray_o[1], ray_o[2]));
+    const float dmin = __uint_as_float(dir_len_enc[0]), dmax = __uint_as_float(dir_len_enc[1]);
+    if (have) {
+        const float4* rec = reinterpret_cast<const float4*>(bvh.inst) + 3 * (size_t)i;
+        a = rec[0]; b = rec[1]; e = rec[2];
+    }
+    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
+    const BinOut none = {nullptr, nullptr, nullptr};
+    const uint32_t n = bin_pairs<false>(P, block_cones, super_cones, lane, have, q, i, 0u, 0u, none);
+    if (i >= bvh.N) return;
+    particle_idx[i] = i;
+    counts[i] = have ? n : 0u;
+    key_bits[i] = (have && n) ? __float_as_uint(q.key) : 0xFFFFFFFFu;   // sort key (the sort consumes this array); particles no packet can reach go last
+    if (!have) return;
+    bin_v[i] = make_float4(q.v.x, q.v.y, q.v.z, q.key);   // proxy centre relative to the ray origin + the sort key: what list_round needs per entry
+    // {W rows, W (o - mu)}: the proxy-frame ray origin with the very operations of the candidate test (candidate_abe<true> reads it)
+    const f3 po = proxy_origin(a, b, e, o);
+    float4* out = reinterpret_cast<float4*>(inst_rel) + 3 * (size_t)i;
+    out[0] = a; out[1] = b; out[2] = make_float4(e.x, po.x, po.y, po.z);
+}
+// rank r of the key order writes its entries at [offsets[r-1], offsets[r]): (packet, expansion position) pairs, the position's particle
+// and its hit-distance bounds for that packet
+__global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, GrtBvh bvh, const float* __restrict__ ray_o,
+                                                              const uint32_t* __restrict__ flag, const uint32_t* __restrict__ dir_len_enc,
+                                                              const GrtCone* __restrict__ block_cones, const GrtCone* __restrict__ super_cones,
+                                                              const uint32_t* __restrict__ rank_to_particle, const uint32_t* __restrict__ offsets,
+                                                              uint32_t capacity, BinOut out) {
+    const uint32_t rk = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t off = 0u, end = 0u, p = 0u;
+    if (rk < bvh.N && flag[0] != 0u) {
+        off = rk == 0 ? 0u : offsets[rk - 1];
+        end = min(offsets[rk], capacity);
+    }
+    const bool have = end > off;
+    float4 a = make_float4(1.f, 0.f, 0.f, 0.f), b = make_float4(1.f, 0.f, 0.f, 0.f), e = make_float4(1.f, 0.f, 0.f, 0.f);
+    const f3 o = world_origin(P, mk3(ray_o[0], ray_o[1], ray_o[2]));
+    const float dmin = __uint_as_float(dir_len_enc[0]), dmax = __uint_as_float(dir_len_enc[1]);
+    if (have) {
+        p = rank_to_particle[rk];
+        const float4* rec = reinterpret_cast<const float4*>(bvh.inst) + 3 * (size_t)p;
+        a = rec[0]; b = rec[1]; e = rec[2];
+    }
+    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
+    bin_pairs<true>(P, block_cones, super_cones, lane, have, q, p, off, have ? end : off, out);
+}
+__global__ __launch_bounds__(256) void grt_list_ranges_kernel(uint32_t n, uint32_t num_blocks, const uint32_t* __restrict__ sorted_keys,
+                                                              const uint32_t* __restrict__ sorted_pos, const uint32_t* __restrict__ pos_particle,
+                                                              uint32_t* __restrict__ ranges, uint32_t* __restrict__ entries) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t k = sorted_keys[e];
+    entries[e] = pos_particle[sorted_pos[e]];
+    if (k >= num_blocks) return;
+    if (e == 0 || sorted_keys[e - 1] != k) ranges[2 * (size_t)k] = e;
+    if (e == n - 1 || sorted_keys[e + 1] != k) ranges[2 * (size_t)k + 1] = e + 1;
+}
+void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* ray_o, const float* ray_d, uint32_t* uniform_origin,
+                           uint32_t* dir_len_enc, GrtCone* block_cones, GrtCone* super_cones) {
+    hipLaunchKernelGGL(grt_list_init_kernel, dim3(1), dim3(1), 0, s, uniform_origin, dir_len_enc);
+    hipLaunchKernelGGL(grt_block_cone_kernel, dim3(grt_num_blocks(P.W, P.H)), dim3(64), 0, s, P, ray_o, ray_d, uniform_origin, dir_len_enc, block_cones);
+    hipLaunchKernelGGL(grt_super_cone_kernel, dim3(grt_num_super(P.W, P.H)), dim3(64), 0, s, P, block_cones, super_cones);
+}
+void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
+                           const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, float* inst_rel, uint32_t* key_bits,
+                           float* bin_v, uint32_t* counts, uint32_t* particle_idx) {
+    hipLaunchKernelGGL(grt_list_count_kernel, dim3(div_up(bvh.N, 256)), dim3(256), 0, s, P, bvh, ray_o, uniform_origin, dir_len_enc, block_cones,
+                       super_cones, inst_rel, key_bits, reinterpret_cast<float4*>(bin_v), counts, particle_idx);
+}
+void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
+                            const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, const uint32_t* rank_to_particle,
+                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals, uint32_t* pos_particle) {
+    const BinOut out = {block_keys, vals, pos_particle};
+    hipLaunchKernelGGL(grt_list_expand_kernel, dim3(div_up(bvh.N, 256)), dim3(256), 0, s, P, bvh, ray_o, uniform_origin, dir_len_enc, block_cones,
+                       super_cones, rank_to_particle, offsets, capacity, out);
+}
+void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, const uint32_t* sorted_pos,
+                            const uint32_t* pos_particle, uint32_t* ranges, uint32_t* entries) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(grt_list_ranges_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, num_blocks, sorted_keys, sorted_pos, pos_particle, ranges, entries);
+}
+
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
                           float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters,
-                          const GrtHitLog& log) {
+                          const GrtHitLog& log, const GrtLists& lists) {
     const dim3 grid(pixel_block_grid(P.W, P.H));
+    const bool uni = lists.ranges != nullptr;   // the host knows by now whether the frame has one ray origin (it sized the lists)
+#define GRT_FWD_LAUNCH(COUNT_, UNI_)                                                                                                              \
+    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, COUNT_, UNI_>), grid, dim3(64), 0, s, P, bvh,                     \
+                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns, out_hit2, \
+                                                     out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters, log, lists))
     if (counters) {
-        GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, true>), grid, dim3(64), 0, s, P, bvh,
-                                                         reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns,
-                                                         out_hit2, out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters, log));
+        if (uni) { GRT_FWD_LAUNCH(true, true); } else { GRT_FWD_LAUNCH(true, false); }
     } else {
-        GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, false>), grid, dim3(64), 0, s, P, bvh,
-                                                         reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns,
-                                                         out_hit2, out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters, log));
+        if (uni) { GRT_FWD_LAUNCH(false, true); } else { GRT_FWD_LAUNCH(false, false); }
     }
+#undef GRT_FWD_LAUNCH
 }
 void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,

@@ -70,13 +70,14 @@ struct GutHandle {
     int prof_slot = 0, prof_created = 0;
     int prof_fwd_slot = 0;
 
+    uint32_t profile_mask = 0xFFFFFFFFu;   // gut_profile_select: stages that get an event pair while profiling is on
     int stage_begin(int stage, hipStream_t s, int slot) {
-        if (!profile) return GRUT_OK;
+        if (!profile || !((profile_mask >> stage) & 1u)) return GRUT_OK;
         GRUT_HIP(hipEventRecord(prof_ev[slot][stage][0], s));
         return GRUT_OK;
     }
     int stage_end(int stage, hipStream_t s, int slot) {
-        if (!profile) return GRUT_OK;
+        if (!profile || !((profile_mask >> stage) & 1u)) return GRUT_OK;
         GRUT_HIP(hipEventRecord(prof_ev[slot][stage][1], s));
         prof_used[slot][stage] = true;
         return GRUT_OK;
@@ -529,6 +530,12 @@ int gut_profile_enable(GutHandle* h, int enable) {
     }
     h->profile = enable != 0;
     h->count_work = enable >= 2;
+    return GRUT_OK;
+}
+
+int gut_profile_select(GutHandle* h, uint32_t stage_mask) {
+    GRUT_REQUIRE(h, "gut_profile_select: null handle");
+    h->profile_mask = stage_mask;
     return GRUT_OK;
 }
 

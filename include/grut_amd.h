@@ -222,6 +222,9 @@ int gut_stats(GutHandle* handle, GutStats* stats);
 enum { GUT_STAGE_PROJECT = 0, GUT_STAGE_DEPTH_SORT, GUT_STAGE_SCAN, GUT_STAGE_EXPAND, GUT_STAGE_TILE_SORT,
        GUT_STAGE_TILE_RANGES, GUT_STAGE_RENDER_FWD, GUT_STAGE_RENDER_BWD, GUT_STAGE_PROJECT_BWD, GUT_NUM_STAGES };
 int gut_profile_enable(GutHandle* handle, int enable);
+/* Restrict the event pairs to the stages whose bit (1 << GUT_STAGE_*) is set (default: all).  Two event records between adjacent
+ * stages leave ~10 us of idle stream on MI355X; timing only the kernel of interest keeps the rest of the frame back to back. */
+int gut_profile_select(GutHandle* handle, uint32_t stage_mask);
 int gut_profile_read(GutHandle* handle, float* stage_ms /* [GUT_NUM_STAGES] */);
 
 /* ---- stage-level entry points (parity tests drive each stage alone) ------ */
@@ -353,6 +356,10 @@ int grt_debug_fetch_instances(GrtHandle* handle, void* stream, float* instances)
 
 int grt_timings(GrtHandle* handle, float* forward_ms, float* backward_ms, float* build_ms);
 int grt_stats(GrtHandle* handle, GrtStats* stats);
+/* Diagnostics of an instrumented forward (environment GRUT_GRT_COUNT=1): the raw counter block to a caller DEVICE buffer — words 0..11
+ * the totals grt_stats reports, then per launched workgroup {start, lifetime (10 ns ticks of the chip-wide counter), node visits << 32 |
+ * leaf visits}.  Development aid (scripts/diag_grt_balance.py). */
+int grt_debug_fetch_work(GrtHandle* handle, void* stream, unsigned long long* out, uint64_t count);
 
 /* ---- parameter marshalling -------------------------------------------------- */
 /* [N,3] positions, [N,1] density, [N,4] rotation (wxyz), [N,3] scale (all contiguous fp32, DEVICE) -> [N,12] ParticleDensity

@@ -100,6 +100,30 @@ def traffic(fetch_db, write_db, workload):
     print(json.dumps(res))
 
 
+def timeline(db, first="gut_project_kernel"):
+    """the kernels of the LAST step of a --kernel-trace run in launch order: start offset, duration and the idle gap in front of each"""
+    c = sqlite3.connect(db)
+    try:
+        rows = list(c.execute("select name, start, end from kernels order by start"))
+    except sqlite3.Error as e:
+        print("no `kernels` view:", e)
+        for (n,) in c.execute("select name from sqlite_master where type in ('table','view')"):
+            print("  ", n)
+        return
+    starts = [i for i, r in enumerate(rows) if first in r[0]]
+    if len(starts) < 2:
+        print("fewer than two steps in the trace"); return
+    a, b = starts[-2], starts[-1]
+    t0, prev_end = rows[a][1], rows[a][1]
+    print(f"# one step ({b - a} kernels) of {os.path.basename(os.path.dirname(db))}: start offset, duration, gap before (us)")
+    busy = gaps = 0.0
+    for n, st, en in rows[a:b]:
+        print(f"{short(n):58s} {(st - t0) / 1e3:9.1f} {(en - st) / 1e3:9.1f} {(st - prev_end) / 1e3:8.1f}")
+        busy += (en - st) / 1e3; gaps += max(0.0, (st - prev_end) / 1e3)
+        prev_end = max(prev_end, en)
+    print(f"# step period {(rows[b][1] - t0) / 1e3:.1f} us: kernels {busy:.1f} us, gaps inside the step {gaps:.1f} us, gap to the next step {(rows[b][1] - prev_end) / 1e3:.1f} us")
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
-    {"stats": stats, "pmc": pmc, "traffic": traffic, "counters": counters}[cmd](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "traffic": traffic, "counters": counters, "timeline": timeline}[cmd](*sys.argv[2:])
