@@ -90,6 +90,7 @@ class GrtStats(C.Structure):
     _fields_ = [
         ("num_particles", C.c_uint32), ("num_nodes", C.c_uint32), ("nodes_visited", C.c_uint64),
         ("candidates", C.c_uint64), ("processed_hits", C.c_uint64), ("scene_aabb", C.c_float * 6),
+        ("list_entries", C.c_uint64), ("packet_tests", C.c_uint64),
     ]
 
 

@@ -471,6 +471,8 @@ int grt_stats(GrtHandle* h, GrtStats* stats) {
     stats->nodes_visited = h->work_host[0];
     stats->candidates = h->work_host[1];
     stats->processed_hits = h->work_host[2];
+    stats->list_entries = h->list_entries;
+    stats->packet_tests = h->work_host[9];
     if (h->built && h->N > 0) {
         if (!h->scene_host_valid) {  // synchronises with the build stream
             GRUT_HIP(hipMemcpyAsync(h->scene_host, h->scene.ptr, 24, hipMemcpyDeviceToHost, h->build_stream));

@@ -520,20 +520,25 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
     }
 }
 
-// Tight bounds of the hit distance of one particle for the rays of ONE packet (cone axis `k`, half angle theta): the closest-approach point
-// x = o + t d - mu lies in the ellipsoid |W x| <= sqrt 3, so t |d| = v.dh + x.dh with |x.dh| <= sqrt 3 |S R^T dh| (support function);
-// over the cone, v.dh = |v| cos(phi) with phi within theta of the angle between v and the axis, and the support function is
-// kmax-Lipschitz in dh.  (S R^T dh)_i = kscl_i^2 (W_i . dh).
+// Tight bounds of the hit distance of one particle for the rays of ONE packet (cone axis `k`, half angle theta).  With x = o + t d - mu
+// the closest-approach point, y = W x and u = W dh (dh the unit direction): y is perpendicular to u (t minimises |W x|) and |y| <= sqrt 3
+// (the ray touches the proxy box), and t |d| = v.dh + x.dh with x.dh = y.(S e), e = R^T dh, u = S^-1 e, (S e).u = 1, hence
+//     |x.dh| <= sqrt 3 sqrt(|S e|^2 - 1 / |S^-1 e|^2)      (zero for a sphere: its hit distance IS v.dh)
+// Over the cone, v.dh = |v| cos(phi) with phi within theta of the angle between v and the axis; |S e| is kmax-Lipschitz and |S^-1 e|
+// (1/kmin)-Lipschitz in dh.  (S e)_i = kscl_i^2 (W_i . dh), (S^-1 e)_i = W_i . dh.
 __device__ __forceinline__ void packet_bounds(const GrtCone& k, f3 v, float L2, const float4& a, const float4& b, float w22, float key, float ub,
                                               float dmin, float dmax, float& lo, float& hi) {
     lo = key; hi = ub;
     if (k.cos_t <= -1.f) return;   // cone of everything
     const float L = sqrtf(L2);
     const float k0 = 1.f / (a.x * a.x + a.y * a.y + a.z * a.z), k1 = 1.f / (a.w * a.w + b.x * b.x + b.y * b.y), k2 = 1.f / (b.z * b.z + b.w * b.w + w22 * w22);   // kscl^2
-    const float kmax = sqrtf(fmaxf(k0, fmaxf(k1, k2)));
-    const float s0 = k0 * (a.x * k.ax + a.y * k.ay + a.z * k.az), s1 = k1 * (a.w * k.ax + b.x * k.ay + b.y * k.az), s2 = k2 * (b.z * k.ax + b.w * k.ay + w22 * k.az);
-    const float chord = sqrtf(fmaxf(0.f, 2.f * (1.f - k.cos_t)));
-    const float h = 1.7320509f * (sqrtf(s0 * s0 + s1 * s1 + s2 * s2) + kmax * chord) * 1.00002f + 1e-7f * L;
+    const float kmax = sqrtf(fmaxf(k0, fmaxf(k1, k2))), kmin = sqrtf(fminf(k0, fminf(k1, k2)));
+    const float w0 = a.x * k.ax + a.y * k.ay + a.z * k.az, w1 = a.w * k.ax + b.x * k.ay + b.y * k.az, w2 = b.z * k.ax + b.w * k.ay + w22 * k.az;
+    const float s0 = k0 * w0, s1 = k1 * w1, s2 = k2 * w2;
+    const float chord = sqrtf(fmaxf(0.f, 2.f * (1.f - k.cos_t))) * 1.00001f;
+    const float se = (sqrtf(s0 * s0 + s1 * s1 + s2 * s2) + kmax * chord) * 1.00001f;       // >= |S e| over the cone
+    const float sie = (sqrtf(w0 * w0 + w1 * w1 + w2 * w2) + chord / kmin) * 1.00001f;       // >= |S^-1 e| over the cone
+    const float h = 1.7320509f * sqrtf(fmaxf(0.f, se * se - (1.f - 1e-5f) / (sie * sie))) * 1.00002f + 2e-6f * L + 1e-30f;
     const float ca = L > 0.f ? fminf(1.f, fmaxf(-1.f, (v.x * k.ax + v.y * k.ay + v.z * k.az) / L)) : 1.f;
     const float sa = sqrtf(fmaxf(0.f, 1.f - ca * ca));
     const float cmax = (ca >= k.cos_t) ? 1.f : fminf(1.f, ca * k.cos_t + sa * k.sin_t + 4e-6f);     // cos of (alpha - theta), or 1 inside the cone
@@ -764,6 +769,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
     float4* s_ent = reinterpret_cast<float4*>(s_hit_t);
     TraceCounters tc;
     const int lane = threadIdx.x;
+    // (workgroups in the order of the packets' list lengths — longest first, or dealt alternately from both ends of the ranking — were
+    // measured slower than this locality-preserving order, 20.1 / 21.4 vs 18.2 ms, although the launch ends with its slowest packet)
     const PixelBlock pb = pixel_block(P.W, P.H);
     if (!pb.inside) return;
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
@@ -1884,8 +1891,8 @@ void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& 
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
                           float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters,
                           const GrtHitLog& log, const GrtLists& lists) {
-    const dim3 grid(pixel_block_grid(P.W, P.H));
     const bool uni = lists.ranges != nullptr;   // the host knows by now whether the frame has one ray origin (it sized the lists)
+    const dim3 grid(pixel_block_grid(P.W, P.H));
 #define GRT_FWD_LAUNCH(COUNT_, UNI_)                                                                                                              \
     GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, COUNT_, UNI_>), grid, dim3(64), 0, s, P, bvh,                     \
                                                      reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns, out_hit2, \

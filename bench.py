@@ -111,13 +111,14 @@ def cpu_baseline(seconds_budget=20.0):
 
 
 def grt_roofline(work, P, stages):
-    """Forward trace against the HBM roofline.  Algorithmic bytes (per wave where this design fetches per wave):
-    64 B per node visit of a wave (the 8x8 ray packet shares the fetch) + 240 B per processed hit (48 B particle + 192 B SH,
-    gathered per ray) + 64 B per ray of inputs / outputs.  Neither HBM nor VALU binds this kernel: the
-    fraction is reported as the contract asks, `traffic` is the measured HBM volume, `valu` the issue-slot fraction."""
+    """Forward trace against the HBM roofline.  Algorithmic bytes (SURVEY §8d restated for this design, per wave where the 8x8 ray packet
+    shares a fetch): 64 B per node visit of a wave (tree walk) or per candidate test of a packet (48 B proxy record + 16 B bounds, packet
+    lists); 40 B per list entry built (12 B written, the two sort passes, 4 B read back); 240 B per processed hit (48 B particle + 192 B
+    SH, gathered per ray); 64 B per ray of inputs / outputs.  Neither HBM nor VALU binds this kernel: the fraction is
+    reported as the contract asks, `traffic` is the measured HBM volume, `valu` the issue-slot fraction."""
     if not work or "forward_render" not in stages:
         return None
-    byts = work["wave_node_visits"] * 64 + work["processed_hits"] * 240 + P * 64
+    byts = (work["wave_node_visits"] + work.get("packet_tests", 0)) * 64 + work.get("list_entries", 0) * 40 + work["processed_hits"] * 240 + P * 64
     ms = stages["forward_render"]
     achieved = byts / (ms * 1e-3) / 1e9
     traffic = None
@@ -126,7 +127,8 @@ def grt_roofline(work, P, stages):
     except Exception:
         pass
     r = {"bound": "hbm", "kernel": "grt_trace_fwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "traffic": traffic, "algorithmic_bytes": byts, "kernel_ms": ms}
+         "traffic": traffic, "algorithmic_bytes": byts, "kernel_ms": ms,
+         "note": "forward_render = packet-list build (cones, binning, sorts) + trace"}
     v = valu_fraction("grt_trace_fwd", ms)
     if v:
         r["valu"] = v
@@ -173,7 +175,8 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
         torch.cuda.synchronize()
         del os.environ["GRUT_GRT_COUNT"]
         st = tracer.tracer_wrapper.stats()
-        work = {"wave_node_visits": int(st.nodes_visited), "leaf_tests": int(st.candidates), "processed_hits": int(st.processed_hits)}
+        work = {"wave_node_visits": int(st.nodes_visited), "leaf_tests": int(st.candidates), "processed_hits": int(st.processed_hits),
+                "list_entries": int(st.list_entries), "packet_tests": int(st.packet_tests)}
         step()  # back to the uninstrumented kernels before timing
         tracer.timings
         torch.cuda.synchronize()
@@ -197,7 +200,7 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
     if rank == 0:
         P = W * H
         result = {
-            "metric": "train rays/sec (3DGRT software-BVH forward+backward, primary rays)", "value": world * P * args.steps / dt,
+            "metric": "train rays/sec (3DGRT forward+backward, primary rays; software BVH + per-frame packet lists)", "value": world * P * args.steps / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"3DGRT BVH build + fwd + bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "

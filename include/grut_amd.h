@@ -283,6 +283,8 @@ typedef struct GrtStats {
     uint64_t candidates;
     uint64_t processed_hits;
     float    scene_aabb[6];
+    uint64_t list_entries;      /* last forward: entries of the packet lists (0: the tree walk served the frame — rays with different origins) */
+    uint64_t packet_tests;      /* only in instrumented launches: candidate tests of whole packets (list entries / leaves tested by a wave) */
 } GrtStats;
 
 typedef struct GrtHandle GrtHandle;

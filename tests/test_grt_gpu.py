@@ -236,3 +236,67 @@ def test_render_matches_reference_programs_golden():
             gd, gs = gpu["grads"]
             rd, rs = g[f"s{k}_grad_density"], g[f"s{k}_grad_sph"]
             assert rel_err(gd[:, :11], rd[:, :11]) < 1e-3 and rel_err(gs, rs) < 1e-3
+
+
+# ---- packet lists (frames with one ray origin) against the tree walk -------------------------------------------------------
+def _hits_with(scene, monkeypatch, no_lists, rays_ori=None):
+    import torch
+    if no_lists:
+        monkeypatch.setenv("GRUT_GRT_NO_LISTS", "1")
+    else:
+        monkeypatch.delenv("GRUT_GRT_NO_LISTS", raising=False)
+    tr = _tracer()
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+    tr.build_acc(g, rebuild=True)
+    nat = tr.tracer_wrapper
+    batch = torch_batch(scene["batch"], "cuda")
+    ro = batch.rays_ori.contiguous() if rays_ori is None else torch.as_tensor(rays_ori, device="cuda").contiguous()
+    frame = nat.make_frame(0, 3, tr._min_transmittance, g.num_gaussians, scene["H"], scene["W"], batch.T_to_world)
+    d12 = torch.as_tensor(scene["density12"], device="cuda").contiguous()
+    sph = torch.as_tensor(scene["sph"], device="cuda").contiguous()
+    res = nat.trace(frame, d12, sph, ro, batch.rays_dir.contiguous(), hit_capacity=128)
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in res], int(nat.stats().list_entries)
+
+
+@pytest.mark.parametrize("n,w,h,scale,kind", [(6000, 72, 56, 0.05, "trained"), (3000, 50, 30, 0.08, "random"), (1, 16, 16, 0.3, "trained"),
+                                              (40000, 96, 64, 0.02, "trained")])
+def test_packet_lists_equal_the_tree_walk(monkeypatch, n, w, h, scale, kind):
+    """One ray origin for the whole frame: the forward bins the particles per 8x8 ray packet and scans sorted lists instead of walking the
+    BVH.  Same candidate arithmetic, same per-ray buffers: every output and every ray's sequence of processed particles is identical,
+    bit for bit (image widths that are no multiple of 8 leave partial packets at the border)."""
+    scene = _scene(n, w, h, scale, kind=kind)
+    lists, n_entries = _hits_with(scene, monkeypatch, no_lists=False)
+    walk, n_walk = _hits_with(scene, monkeypatch, no_lists=True)
+    assert n_entries > 0 and n_walk == 0
+    for a, b, name in zip(lists, walk, ("features", "density", "hit_distance", "normals", "hit_count", "visibility", "ids", "num")):
+        if name == "ids":
+            num = lists[7].reshape(-1).astype(np.int64)
+            for r in range(h * w):
+                k = min(int(num[r]), 128)
+                assert np.array_equal(a.reshape(h * w, -1)[r, :k], b.reshape(h * w, -1)[r, :k]), f"ray {r}: order differs"
+        else:
+            assert np.array_equal(a, b), name
+
+
+def test_rays_with_different_origins_take_the_tree_walk(monkeypatch):
+    """Packet lists need one ray origin (the cones have one apex).  A frame in which a single ray starts elsewhere is served by the tree
+    walk — decided on the device, reported by grt_stats — and still matches the oracle's hit order."""
+    scene = _scene(3000, 40, 24, 0.08)
+    ro = scene["rays"][0].copy()
+    ro[0, 5, 7] += np.float32(0.01)
+    res, n_entries = _hits_with(scene, monkeypatch, no_lists=False, rays_ori=ro)
+    assert n_entries == 0
+    tr = _tracer()
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+    tr.build_acc(g, rebuild=True)
+    inst = tr.tracer_wrapper.instances(g.num_gaussians, "cuda").cpu().numpy()
+    scene_aabb = np.array(list(tr.tracer_wrapper.stats().scene_aabb), np.float32)
+    ora = oracle.grt_forward(oracle.default_grt_config(), scene["density12"], scene["sph"], 3, 1e-3, scene["T"], ro, scene["rays"][1], inst=inst,
+                             scene=scene_aabb, dbg_cap=128)
+    num = res[7].reshape(-1).astype(np.int64)
+    assert np.array_equal(num, ora["hit_num"].reshape(-1).astype(np.int64))
+    ids = res[6].view(np.uint32).reshape(num.size, -1)
+    for r in range(num.size):
+        k = min(int(num[r]), 128)
+        assert np.array_equal(ids[r, :k], ora["hit_ids"][r, :k])
