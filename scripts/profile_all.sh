@@ -11,10 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 O=/tmp/prof_$TAG          # raw rocprofv3 databases stay on the box (gpurun_out/ is capped at 64 MiB)
 S=$R/gpurun_out/summ_$TAG  # text summaries travel back
 mkdir -p $O $S
-GUT="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+GUT="python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-secondary"   # (--no-secondary: no 3DGRT / training-surrogate kernels in the averages)
 GRT="python $R/bench.py --workload c3_grt_1m_800 --steps 2 --warmup 1 --no-cpu-baseline"
 # the timing pass runs bench.py's default step counts (clocks settle over the first steps; 4 steps read ~6 % slow)
-rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_stats -o st -- python $R/bench.py --no-cpu-baseline > $O/prof_${TAG}_stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}_stats -o st -- python $R/bench.py --no-cpu-baseline --no-secondary > $O/prof_${TAG}_stats.log 2>&1
 [ "$ONLY" = "stats" ] && { python $R/scripts/rocprof_summary.py stats $O/prof_${TAG}_stats/st_results.db > $S/kernel_stats.txt; python $R/bench.py > $S/bench.json 2> $S/bench.err; tail -c 300 $S/bench.json; exit 0; }
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/prof_${TAG}_fetch -o f -- $GUT > $O/prof_${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/prof_${TAG}_write -o w -- $GUT > $O/prof_${TAG}_write.log 2>&1
@@ -35,7 +35,15 @@ $SUM pmc $O/prof_${TAG}_grt_fetch/f_results.db $O/prof_${TAG}_grt_write/w_result
 $SUM counters $O/prof_${TAG}_grt_sq/sq_results.db "rocprofv3 --kernel-trace --pmc SQ_* (one pass), bench.py c3_grt_1m_800" > $S/grt_sq_counters.txt
 fi
 cp $R/profiles/pmc_traffic.json $S/pmc_traffic.json 2>/dev/null
+cp $R/profiles/sq_insts_valu.json $S/sq_insts_valu.json 2>/dev/null
 GRUT_TRAFFIC_JSON=$S/pmc_traffic.json $SUM traffic $O/prof_${TAG}_fetch/f_results.db $O/prof_${TAG}_write/w_results.db c4_1m_1080p > /dev/null
+GRUT_VALU_JSON=$S/sq_insts_valu.json $SUM valu $O/prof_${TAG}_sq/sq_results.db > /dev/null
+$SUM timeline $O/prof_${TAG}_stats/st_results.db > $S/timeline.txt
+if [ "$ONLY" != "gut" ]; then
+GRUT_TRAFFIC_JSON=$S/pmc_traffic.json $SUM traffic $O/prof_${TAG}_grt_fetch/f_results.db $O/prof_${TAG}_grt_write/w_results.db c3_grt_1m_800 > /dev/null
+GRUT_VALU_JSON=$S/sq_insts_valu.json $SUM valu $O/prof_${TAG}_grt_sq/sq_results.db > /dev/null
+cp $S/pmc_traffic.json $R/profiles/pmc_traffic.json; cp $S/sq_insts_valu.json $R/profiles/sq_insts_valu.json   # the bench lines below read them
+fi
 python $R/bench.py > $S/bench.json 2> $S/bench.err
 [ "$ONLY" != "gut" ] && python $R/bench.py --workload c3_grt_1m_800 --no-cpu-baseline > $S/bench_grt.json 2> $S/bench_grt.err
 ls -la $S

@@ -5,6 +5,8 @@
     python scripts/rocprof_summary.py pmc    <fetch.db> <write.db>  > profiles/rNN_pmc_hbm.txt
     python scripts/rocprof_summary.py traffic <fetch.db> <write.db> <workload>   (writes profiles/pmc_traffic.json)
     python scripts/rocprof_summary.py counters <pmc.db> [title]   > profiles/rNN_sq_counters.txt
+    python scripts/rocprof_summary.py valu <sq.db> [<sq.db> ...]    (writes profiles/sq_insts_valu.json)
+    python scripts/rocprof_summary.py timeline <stats.db>           one step's kernels in launch order with the gaps between them
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  On gfx950 FETCH_SIZE tallies 128-B read requests at 64 B
 (MI355X_MICROARCH.md, "HBM"): the corrected column doubles it.  WRITE_SIZE is taken as reported (uncalibrated there).
@@ -82,22 +84,42 @@ def pmc(fetch_db, write_db):
 
 
 STAGE_OF = {"gut_project_kernel": "project", "gut_expand_kernel": "expand", "gut_tile_ranges_kernel": "tile_ranges",
-            "gut_render_fwd_kernel": "render_fwd", "gut_render_bwd_kernel": "render_bwd", "gut_project_bwd_kernel": "project_bwd"}
+            "gut_render_fwd_kernel": "render_fwd", "gut_render_bwd_kernel": "render_bwd", "gut_project_bwd_kernel": "project_bwd",
+            "grt_trace_fwd_kernel": "trace_fwd", "grt_replay_bwd_kernel": "replay_bwd"}
+VALU_KEY = {"gut_project_kernel": "project", "gut_expand_kernel": "expand", "gut_render_fwd_kernel": "render_fwd", "gut_render_bwd_kernel": "render_bwd",
+            "gut_project_bwd_kernel": "project_bwd", "grt_trace_fwd_kernel": "grt_trace_fwd"}
 
 
 def traffic(fetch_db, write_db, workload):
     f = counter_avgs(fetch_db, "FETCH_SIZE")
     w = counter_avgs(write_db, "WRITE_SIZE")
-    res = {}
+    res, calls = {}, {}
     for k, (n, fv, _) in f.items():
         base = re.sub(r"<.*", "", k)
-        if base in STAGE_OF:
+        if base in STAGE_OF and n > calls.get(STAGE_OF[base], 0):   # of several instantiations, the one the timed steps run
+            calls[STAGE_OF[base]] = n
             res[STAGE_OF[base]] = int((2 * fv + w.get(k, (0, 0.0, 0.0))[1]) * 1024)
     path = os.environ.get("GRUT_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "pmc_traffic.json"))
     allw = json.load(open(path)) if os.path.exists(path) else {}
     allw[workload] = res
     json.dump(allw, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(res))
+
+
+def valu(*dbs):
+    """profiles/sq_insts_valu.json: SQ_INSTS_VALU per dispatch of the kernels bench.py prices against the VALU model (the instantiation
+    with the most dispatches of each)"""
+    path = os.environ.get("GRUT_VALU_JSON", os.path.join(ROOT, "profiles", "sq_insts_valu.json"))
+    out = json.load(open(path)) if os.path.exists(path) else {}
+    for db in dbs:
+        best = {}
+        for k, (n, v, _) in counter_avgs(db, "SQ_INSTS_VALU").items():
+            base = re.sub(r"<.*", "", k)
+            if base in VALU_KEY and n > best.get(VALU_KEY[base], (0, 0))[0]:
+                best[VALU_KEY[base]] = (n, int(v))
+        out.update({k: v for k, (_, v) in best.items()})
+    json.dump(out, open(path, "w"), indent=1, sort_keys=True)
+    print(json.dumps(out))
 
 
 def timeline(db, first="gut_project_kernel"):
@@ -126,4 +148,4 @@ def timeline(db, first="gut_project_kernel"):
 
 if __name__ == "__main__":
     cmd = sys.argv[1]
-    {"stats": stats, "pmc": pmc, "traffic": traffic, "counters": counters, "timeline": timeline}[cmd](*sys.argv[2:])
+    {"stats": stats, "pmc": pmc, "traffic": traffic, "counters": counters, "timeline": timeline, "valu": valu}[cmd](*sys.argv[2:])

@@ -26,7 +26,7 @@ KERNELS = {  # bench stage -> (source file, mangled-name pattern of the kernel t
     "render_bwd": ("gut_render.hip", r"gut_render_bwd_kernelILi2ELb0ELb0E"),
     "project": ("gut_kernels.hip", r"gut_project_kernel"),
     "expand": ("gut_kernels.hip", r"gut_expand_kernel"),
-    "grt_trace_fwd": ("grt_kernels.hip", r"grt_trace_fwd_kernelILi4ELb0E"),
+    "grt_trace_fwd": ("grt_kernels.hip", r"grt_trace_fwd_kernelILi4ELb0ELb1E"),   # the packet-list build (frames with one ray origin)
 }
 TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
 THREE = ("v_fma_", "v_fmac_", "v_mad_", "v_min3_", "v_max3_", "v_med3_", "v_fmaak", "v_fmamk", "v_bfe_", "v_bfi_", "v_perm_", "v_alignbit", "v_lshl_add",
