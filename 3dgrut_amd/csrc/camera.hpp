@@ -208,8 +208,10 @@ __device__ inline bool project_ftheta(const GrutCamera& cam, f3 p, float tol, fl
     oy = s * (cam.ftheta_linear_cde[2] * p.x + p.y) + cam.principal_point[1] + 0.5f;
     return (theta < cam.max_angle) && within_resolution((float)cam.width, (float)cam.height, tol, ox, oy);
 }
+// MODEL: the camera model when the caller knows it at compile time (kernels specialised per model), -1: decided at run time
+template <int MODEL = -1>
 __device__ __forceinline__ bool project_point(const GrutCamera& cam, f3 p, float tol, float& ox, float& oy) {
-    switch (cam.model) {
+    switch (MODEL >= 0 ? MODEL : cam.model) {
     case GRUT_CAMERA_OPENCV_PINHOLE: return project_pinhole(cam, p, tol, ox, oy);
     case GRUT_CAMERA_OPENCV_FISHEYE: return project_fisheye(cam, p, tol, ox, oy);
     case GRUT_CAMERA_FTHETA: return project_ftheta(cam, p, tol, ox, oy);
@@ -230,14 +232,16 @@ __device__ __forceinline__ float relative_shutter_time(const GrutCamera& cam, fl
     }
 }
 // cameraProjections.cuh:218-257
+// ROLLING: 0 = the frame has a global shutter (compile-time knowledge), 1 = decided at run time
+template <int MODEL = -1, int ROLLING = 1>
 __device__ inline bool project_point_with_shutter(const GrutCamera& cam, const FramePoses& fp, int n_iter, f3 x, float tol,
                                                   float& ox, float& oy) {
-    bool valid = project_point(cam, apply_rows(fp.start_R, fp.start_t, x), tol, ox, oy);
-    if (cam.shutter == GRUT_SHUTTER_GLOBAL) return valid;
+    bool valid = project_point<MODEL>(cam, apply_rows(fp.start_R, fp.start_t, x), tol, ox, oy);
+    if (!ROLLING || cam.shutter == GRUT_SHUTTER_GLOBAL) return valid;
     if (!valid) {
         float Re[9];
         quat_xyzw_to_rows(fp.end_q, Re);
-        valid = project_point(cam, apply_rows(Re, fp.end_t, x), tol, ox, oy);
+        valid = project_point<MODEL>(cam, apply_rows(Re, fp.end_t, x), tol, ox, oy);
         if (!valid) return false;
     }
     for (int i = 0; i < n_iter; ++i) {
@@ -246,7 +250,7 @@ __device__ inline bool project_point_with_shutter(const GrutCamera& cam, const F
         quat_slerp(fp.start_q, fp.end_q, a, q);
         quat_xyzw_to_rows(q, R);
         for (int k = 0; k < 3; ++k) t[k] = fp.start_t[k] * (1.f - a) + fp.end_t[k] * a;
-        valid = project_point(cam, apply_rows(R, t, x), tol, ox, oy);
+        valid = project_point<MODEL>(cam, apply_rows(R, t, x), tol, ox, oy);
     }
     return valid;
 }

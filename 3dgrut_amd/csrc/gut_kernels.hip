@@ -225,7 +225,10 @@ __device__ __forceinline__ int group_source(int lane, bool member, const GroupPi
 // ---------------------------------------------------------------------------------------------
 // K1: projection onto tiles — GUTProjector::eval (gutProjector.cuh:217-322)
 // ---------------------------------------------------------------------------------------------
-// 6 waves/SIMD measured best (0.227 ms; 4: 0.239, 5: 0.232, 8: 0.261 with spills)
+// 6 waves/SIMD measured best (0.227 ms; 4: 0.239, 5: 0.232, 8: 0.261 with spills).  One instantiation per (camera model, global /
+// rolling shutter): with the three models and the shutter iterations in one body the kernel was 17 k instructions (140 KB of code
+// against a 64 KB instruction cache shared by two CUs).
+template <int MODEL, int ROLLING>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void gut_project_kernel(GutParams P, const float4* __restrict__ density12,
                                                           const float* __restrict__ sph, GutProjected out,
                                                           int32_t* __restrict__ visibility, uint32_t* __restrict__ num_visible) {
@@ -256,14 +259,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const m3 rotT = quat_wxyz_to_rotT(b.x, b.y, b.z, b.w);
             float spx[7], spy[7];
             int nvalid = 0;
-            nvalid += project_point_with_shutter(P.cam, FP, P.n_rs_iter, pos, P.ut_margin, spx[0], spy[0]) ? 1 : 0;
+            nvalid += project_point_with_shutter<MODEL, ROLLING>(P.cam, FP, P.n_rs_iter, pos, P.ut_margin, spx[0], spy[0]) ? 1 : 0;
             cx = spx[0] * P.ut_w0m; cy = spy[0] * P.ut_w0m;
             const f3 axes[3] = {rotT.r0 * (P.ut_delta * c.x), rotT.r1 * (P.ut_delta * c.y), rotT.r2 * (P.ut_delta * c.z)};
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                nvalid += project_point_with_shutter(P.cam, FP, P.n_rs_iter, pos + axes[k], P.ut_margin, spx[k + 1], spy[k + 1]) ? 1 : 0;
+                nvalid += project_point_with_shutter<MODEL, ROLLING>(P.cam, FP, P.n_rs_iter, pos + axes[k], P.ut_margin, spx[k + 1], spy[k + 1]) ? 1 : 0;
                 cx += P.ut_wi * spx[k + 1]; cy += P.ut_wi * spy[k + 1];
-                nvalid += project_point_with_shutter(P.cam, FP, P.n_rs_iter, pos - axes[k], P.ut_margin, spx[k + 4], spy[k + 4]) ? 1 : 0;
+                nvalid += project_point_with_shutter<MODEL, ROLLING>(P.cam, FP, P.n_rs_iter, pos - axes[k], P.ut_margin, spx[k + 4], spy[k + 4]) ? 1 : 0;
                 cx += P.ut_wi * spx[k + 4]; cy += P.ut_wi * spy[k + 4];
             }
             ok = P.ut_require_all ? (nvalid == 7) : (nvalid > 0);
@@ -1002,8 +1005,17 @@ void launch_frame_poses(hipStream_t s, const float* T_start, const float* T_end,
 // ---------------------------------------------------------------------------------------------
 void launch_project(hipStream_t s, const GutParams& P, const float* density12, const float* sph, const GutProjected& out,
                     int32_t* visibility, uint32_t* num_visible) {
-    hipLaunchKernelGGL(gut_project_kernel, dim3(div_up(P.N, 256)), dim3(256), 0, s, P, reinterpret_cast<const float4*>(density12), sph,
-                       out, visibility, num_visible);
+#define GRUT_PROJECT_LAUNCH(M_, R_)                                                                                                          \
+    hipLaunchKernelGGL((gut_project_kernel<M_, R_>), dim3(div_up(P.N, 256)), dim3(256), 0, s, P, reinterpret_cast<const float4*>(density12), \
+                       sph, out, visibility, num_visible)
+    const bool rolling = P.cam.shutter != GRUT_SHUTTER_GLOBAL;
+    switch (P.cam.model) {
+    case GRUT_CAMERA_OPENCV_PINHOLE: if (rolling) GRUT_PROJECT_LAUNCH(GRUT_CAMERA_OPENCV_PINHOLE, 1); else GRUT_PROJECT_LAUNCH(GRUT_CAMERA_OPENCV_PINHOLE, 0); break;
+    case GRUT_CAMERA_OPENCV_FISHEYE: if (rolling) GRUT_PROJECT_LAUNCH(GRUT_CAMERA_OPENCV_FISHEYE, 1); else GRUT_PROJECT_LAUNCH(GRUT_CAMERA_OPENCV_FISHEYE, 0); break;
+    case GRUT_CAMERA_FTHETA: if (rolling) GRUT_PROJECT_LAUNCH(GRUT_CAMERA_FTHETA, 1); else GRUT_PROJECT_LAUNCH(GRUT_CAMERA_FTHETA, 0); break;
+    default: GRUT_PROJECT_LAUNCH(-1, 1); break;
+    }
+#undef GRUT_PROJECT_LAUNCH
 }
 void launch_expand(hipStream_t s, const GutParams& P, const GutProjected& proj, const uint32_t* rank_to_particle,
                    const uint32_t* offsets, uint32_t capacity, uint32_t* tile_keys, uint32_t* tile_vals, uint32_t* pos_particle) {
