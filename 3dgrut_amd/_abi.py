@@ -82,7 +82,7 @@ class GrtFrame(C.Structure):
     _fields_ = [
         ("frame_id", C.c_uint32), ("sph_degree", C.c_int32), ("min_transmittance", C.c_float),
         ("num_particles", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
-        ("ray_to_world", C.c_float * 12), ("keep_hits_for_backward", C.c_int32),
+        ("ray_to_world", C.c_float * 12), ("keep_hits_for_backward", C.c_int32), ("device_ray_to_world", C.c_void_p),
     ]
 
 

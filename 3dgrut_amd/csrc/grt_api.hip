@@ -80,6 +80,7 @@ static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
     P.W = f.width;
     P.H = f.height;
     for (int k = 0; k < 12; ++k) P.ray_to_world[k] = f.ray_to_world[k];
+    P.ray_to_world_dev = f.device_ray_to_world;
     return P;
 }
 

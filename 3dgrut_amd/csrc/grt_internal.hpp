@@ -46,6 +46,7 @@ struct GrtTraceParams {
     float min_response, min_alpha, max_alpha, min_transmittance;
     int W, H;
     float ray_to_world[12];
+    const float* ray_to_world_dev;   // optional: the same matrix in device memory (GrtFrame::device_ray_to_world), used instead when set
     uint32_t dbg_cap;
 };
 

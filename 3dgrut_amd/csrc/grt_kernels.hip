@@ -257,14 +257,14 @@ __device__ __forceinline__ float safe_rcp(float v) {
 // pipelineParameters.h:97-117 (no contraction: the oracle's candidate test starts from the same world-space ray)
 __device__ __forceinline__ f3 world_origin(const GrtTraceParams& P, f3 so) {
 #pragma clang fp contract(off)
-    const float* m = P.ray_to_world;
+    const float* m = P.ray_to_world_dev ? P.ray_to_world_dev : P.ray_to_world;
     return mk3(m[0] * so.x + m[1] * so.y + m[2] * so.z + m[3], m[4] * so.x + m[5] * so.y + m[6] * so.z + m[7],
                m[8] * so.x + m[9] * so.y + m[10] * so.z + m[11]);
 }
 __device__ __forceinline__ RayW make_ray(const GrtTraceParams& P, const float* __restrict__ ray_o, const float* __restrict__ ray_d, size_t pix) {
     const f3 so = mk3(ray_o[3 * pix], ray_o[3 * pix + 1], ray_o[3 * pix + 2]);
     const f3 sd = mk3(ray_d[3 * pix], ray_d[3 * pix + 1], ray_d[3 * pix + 2]);
-    const float* m = P.ray_to_world;
+    const float* m = P.ray_to_world_dev ? P.ray_to_world_dev : P.ray_to_world;
     RayW r;
     r.o = world_origin(P, so);
     {
@@ -769,8 +769,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
     float4* s_ent = reinterpret_cast<float4*>(s_hit_t);
     TraceCounters tc;
     const int lane = threadIdx.x;
-    // (workgroups in the order of the packets' list lengths — longest first, or dealt alternately from both ends of the ranking — were
-    // measured slower than this locality-preserving order, 20.1 / 21.4 vs 18.2 ms, although the launch ends with its slowest packet)
+    // (starting the heavy packets first was measured slower than this fixed, locality-preserving order although the launch ends with its
+    // slowest packet: packets sorted by list length 20.1 ms, dealt alternately from both ends of the ranking 21.4, whole super tiles by
+    // total length 20.1, against 18.2-18.6 ms)
     const PixelBlock pb = pixel_block(P.W, P.H);
     if (!pb.inside) return;
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;

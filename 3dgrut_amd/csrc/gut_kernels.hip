@@ -1,16 +1,15 @@
 // gut_kernels.hip — 3DGUT device code for gfx950: unscented projection onto tiles, ordered tile
-// expansion, tile ranges, front-to-back compositing and its gradient sweep, projection backward.
+// expansion, tile ranges, gradient gather and projection backward (the compositing sweeps: gut_render.hip).
 //
 // Reference behaviour restated (not translated): threedgut_tracer/include/3dgut/kernels/cuda/renderers/
 // gutProjector.cuh:32-430, gutKBufferRenderer.cuh:199-352,642-716, common/rayPayload*.cuh,
 // models/gaussianParticles.cuh:484-751.  CDNA4 design:
 //   * binning key is (tile, depth-rank): particles are depth-sorted once (N keys), tile entries are
 //     emitted in rank order, so only the tile bits need stable radix passes over the I entries;
-//   * compositing runs one wave64 per 16x4 pixel strip (4 strips per 16x16 tile, same XCD), stages 64
-//     tile entries per round in LDS with wave-synchronous hand-off (no workgroup barriers between
-//     waves), and terminates per wave by ballot;
-//   * the gradient sweep reduces each particle's 14 gradient terms over the wave with DPP adds and
-//     flushes one atomic set per (strip, particle-with-hit) from an LDS accumulator.
+//   * the per-particle tile walks (culling count, expansion) are wave-cooperative: boxes of up to 4x4 tiles
+//     by one 16-lane row each, up to 8x4 by half a wave, larger ones by the whole wave;
+//   * the sweeps write one gradient slot per (tile entry, half tile); the gather kernel sums a
+//     particle's slots with four lanes per particle and contracts them into the parameter gradients.
 #include <cstdlib>
 
 #include "gut_internal.hpp"

@@ -17,9 +17,10 @@
 //     canonical origin u is per particle and is staged with the record instead of being recomputed per pixel;
 //   * gradient sweep: with a = u - v (v.u)/|v|^2 every geometric gradient is a multiple of a, so per hit a lane
 //     produces  B = dL/d(R^T(o-mu))  (3),  M = B (x) (o - mu - t d)  (9, d rotT = M),  d density (1), d radiance (3)
-//     = 16 terms; the two pixels are folded in-lane, reduce-scattered over the wave with DPP (lane l ends up with
-//     the wave total of term l mod 16) and flushed with ONE atomic set per (half tile, particle-with-hit); quaternion,
-//     scale and position gradients are contracted from (B, M) once per flush, not per pixel.
+//     = 16 terms; the two pixels are folded in-lane, summed over the wave through a transposition in LDS (lane l ends
+//     up with a quarter of the wave total of term l mod 16) and written to the tile entry's own SLOT (one per entry and
+//     half tile, no atomics: gradients are bitwise reproducible); quaternion, scale and position gradients are
+//     contracted from (B, M) once per particle by the gather kernel, not per pixel.
 #include "gut_internal.hpp"
 
 // tuning switches of the gradient sweep (scripts/build_variant.sh -D...)

@@ -72,10 +72,16 @@ class _GrtNative:
         f = _abi.GrtFrame()
         f.frame_id, f.sph_degree, f.min_transmittance = int(frame_id) & 0xFFFFFFFF, int(sph_degree), float(min_transmittance)
         f.num_particles, f.width, f.height = int(n), int(width), int(height)
-        m = ray_to_world.detach().reshape(-1, 4, 4)[0].to("cpu", torch.float32)  # rayToWorld.cpu() in optixTracer.cpp:931
-        for r in range(3):
-            for c in range(4):
-                f.ray_to_world[4 * r + c] = float(m[r, c])
+        m = ray_to_world.detach().reshape(-1, 4, 4)[0]
+        if m.is_cuda:   # the pose stays on the device (the reference copies it to the host per call: rayToWorld.cpu(), optixTracer.cpp:931)
+            md = m.to(torch.float32).contiguous()
+            f.device_ray_to_world = md.data_ptr()
+            f._keepalive = md   # the frame is kept for the backward: so is the matrix it points to
+        else:
+            m = m.to(torch.float32)
+            for r in range(3):
+                for c in range(4):
+                    f.ray_to_world[4 * r + c] = float(m[r, c])
         return f
 
     def trace(self, frame, particle_density, particle_sph, ray_ori, ray_dir, hit_capacity=0):

@@ -274,6 +274,9 @@ typedef struct GrtFrame {
     float    ray_to_world[12];    /* row-major 3x4 */
     int32_t  keep_hits_for_backward; /* forward: record the processed hits so that grt_backward of the same frame
                                       * replays them instead of traversing again (identical results) */
+    const float* device_ray_to_world; /* optional: row-major 4x4 (or 3x4) matrix in DEVICE memory, read by the kernels instead of
+                                       * ray_to_world — a pose that lives on the GPU needs no host copy (the reference does
+                                       * rayToWorld.cpu() per call, optixTracer.cpp:931) */
 } GrtFrame;
 
 typedef struct GrtStats {
