@@ -337,8 +337,15 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
     }
 }
 
+#ifndef GRUT_FWD_WAVES
+#define GRUT_FWD_WAVES 6   // held to 80 VGPRs (12 B of scratch): r02v 0.485 -> 0.472 ms; 0 = the allocator's own choice (90 VGPRs, 5 waves): 4 waves 0.508
+#endif
 template <int DEG, bool CKPT, bool COUNT = false>
-__global__ __launch_bounds__(64) void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+__global__ __launch_bounds__(64)
+#if GRUT_FWD_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(GRUT_FWD_WAVES, GRUT_FWD_WAVES)))
+#endif
+void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                             float4* __restrict__ out_fd, float* __restrict__ out_dist,
