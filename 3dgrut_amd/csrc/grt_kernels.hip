@@ -1134,6 +1134,7 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
 //      and ONE atomic set per (wave, particle) goes to memory.  Lanes that hold the particle at a farther slot simply
 //      lead (or join) a later group: matching quality only affects how much is aggregated, never the result.
 constexpr int kAggWindow = 2;   // slots on either side of the leader's slot that are searched for the same particle
+constexpr int kAggSlots = 8;    // hits of a round worked off together (two halves per round)
 
 template <int DEG>
 __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
@@ -1143,11 +1144,12 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
                                                             const float* __restrict__ g_dns, const float* __restrict__ g_hit,
                                                             float* __restrict__ g_density12, float* __restrict__ g_sph, GrtHitLog log,
                                                             const float* __restrict__ scene) {
-    __shared__ uint32_t s_id[kGrtMaxHits * 64];
     // per (slot, lane): the two scalars every gradient term is built from, and which colour channels were not clamped
-    // (dL = rad_grad * weight on those).  13 KB per wave instead of 24.5 KB: LDS, not registers, capped the occupancy.
-    __shared__ float s_common[kGrtMaxHits * 64], s_weight[kGrtMaxHits * 64];
-    __shared__ uint8_t s_chan[kGrtMaxHits * 64];
+    // (dL = rad_grad * weight on those).  A round is worked off in two halves of kAggSlots = 8 hits (state walk, then aggregation):
+    // 6.6 KB per wave instead of 13 (first version: 24.5) — LDS, not registers, capped the occupancy at three waves per SIMD.
+    __shared__ uint32_t s_id[kAggSlots * 64];
+    __shared__ float s_common[kAggSlots * 64], s_weight[kAggSlots * 64];
+    __shared__ uint8_t s_chan[kAggSlots * 64];
     if (log.state[1] != 0u) return;  // the log overflowed: the traversal kernel handles this frame
     const int lane = threadIdx.x;
     const PixelBlock pb = pixel_block(P.W, P.H);
@@ -1175,10 +1177,12 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
         const uint32_t c = log.table[(size_t)block * log.max_rounds + round];
         if (c == 0xFFFFFFFFu) break;
         const uint32_t* chunk = log.pool + (size_t)c * (2 * kGrtMaxHits * 64) + lane;
+      for (int half = 0; half < kGrtMaxHits; half += kAggSlots) {
         // ---- phase A: per-lane state walk ----
         uint32_t pending = 0u;
 #pragma unroll 1
-        for (int i = 0; i < kGrtMaxHits; ++i) {
+        for (int ii = 0; ii < kAggSlots; ++ii) {
+            const int i = half + ii;
             uint32_t id = chunk[i * 64];
             float common = 0.f, wgt = 0.f;
             uint32_t chan = 0u;
@@ -1218,16 +1222,16 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
                 }
             }
             if (!contributes) id = 0xFFFFFFFFu;
-            else pending |= (1u << i);
-            s_id[i * 64 + lane] = id;
-            s_common[i * 64 + lane] = common;
-            s_weight[i * 64 + lane] = wgt;
-            s_chan[i * 64 + lane] = (uint8_t)chan;
+            else pending |= (1u << ii);
+            s_id[ii * 64 + lane] = id;
+            s_common[ii * 64 + lane] = common;
+            s_weight[ii * 64 + lane] = wgt;
+            s_chan[ii * 64 + lane] = (uint8_t)chan;
         }
         __syncthreads();
         // ---- phase B: particle-major aggregation ----
 #pragma unroll 1
-        for (int sl = 0; sl < kGrtMaxHits; ++sl) {
+        for (int sl = 0; sl < kAggSlots; ++sl) {
             while (true) {
                 const unsigned long long m = __ballot((pending >> sl) & 1u);
                 if (!m) break;
@@ -1238,7 +1242,7 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
 #pragma unroll
                 for (int d = -kAggWindow; d <= kAggWindow; ++d) {
                     const int t = sl + d;
-                    if (t >= 0 && t < kGrtMaxHits && mine < 0 && ((pending >> t) & 1u) && s_id[t * 64 + lane] == pid) mine = t;
+                    if (t >= 0 && t < kAggSlots && mine < 0 && ((pending >> t) & 1u) && s_id[t * 64 + lane] == pid) mine = t;
                 }
                 const bool part = mine >= 0;
                 const int t = part ? mine : 0;
@@ -1314,6 +1318,7 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
             }
         }
         __syncthreads();
+      }
     }
 }
 
