@@ -193,6 +193,72 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     return GRUT_OK;
 }
 
+// Packet lists of a frame (GrtLists, DESIGN.md "3DGRT: packet lists"): for a frame with ONE ray origin the candidates of every 8x8 ray packet
+// are binned once (cones x bounding spheres, the 3DGUT pipeline) and the rounds scan windows of a sorted list instead of walking the tree.
+// `lists->ranges` stays null when the frame does not qualify (rays with different origins, no particle in view) or GRUT_GRT_NO_LISTS is set.
+static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_origin, const float* ray_direction,
+                       GrtLists* out) {
+    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    h->list_entries = 0;
+    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0) {
+        const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
+        if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
+        GRUT_CHECK(h->l_flags.ensure(64));
+        GRUT_CHECK(h->l_block_cones.ensure((size_t)nb * sizeof(GrtCone), 1.25f));
+        GRUT_CHECK(h->l_super_cones.ensure((size_t)ns * sizeof(GrtCone), 1.25f));
+        GRUT_CHECK(h->l_inst_rel.ensure((size_t)N * 48, 1.25f));
+        for (DeviceBuffer* b4 : {&h->l_key_bits, &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets})
+            GRUT_CHECK(b4->ensure((size_t)N * 4, 1.25f));
+        GRUT_CHECK(h->l_bin_v.ensure((size_t)N * 16, 1.25f));
+        GRUT_CHECK(h->l_scan_scratch.ensure(scan_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
+        uint32_t* flag = h->l_flags.as<uint32_t>();
+        uint32_t* dir_len = flag + 2;
+        grt_launch_list_cones(s, P, ray_origin, ray_direction, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>());
+        grt_launch_list_count(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
+                              h->l_inst_rel.as<float>(), h->l_key_bits.as<uint32_t>(), h->l_bin_v.as<float>(), h->l_counts.as<uint32_t>(),
+                              h->l_pidx.as<uint32_t>());
+        // particles in key order, then the offsets of their entries
+        GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
+        uint32_t *sorted_key = nullptr, *rank_to_particle = nullptr;
+        GRUT_CHECK(sort_pairs_u32(s, N, nullptr, 0, 32, h->l_key_bits.as<uint32_t>(), h->l_pidx.as<uint32_t>(), h->l_key_tmp.as<uint32_t>(),
+                                  h->l_pidx_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_key, &rank_to_particle));
+        GRUT_CHECK(inclusive_scan_u32(s, N, h->l_counts.as<uint32_t>(), rank_to_particle, h->l_offsets.as<uint32_t>(), h->l_scan_scratch.ptr,
+                                      h->l_scan_scratch.bytes));
+        // the entry count sizes the rest: one round trip to the host per frame (with the one-origin flag riding along)
+        GRUT_HIP(hipMemcpyAsync(&h->l_host[0], h->l_offsets.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipMemcpyAsync(&h->l_host[1], flag, 4, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipStreamSynchronize(s));
+        const uint64_t I = h->l_host[0];
+        if (h->l_host[1] != 0u && I > 0 && I < 0xFFFF0000ull) {
+            const uint32_t n = (uint32_t)I;
+            for (DeviceBuffer* b4 : {&h->l_block_keys, &h->l_vals, &h->l_pos_particle, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_entries})
+                GRUT_CHECK(b4->ensure((size_t)n * 4, 1.3f));
+            GRUT_CHECK(h->l_ranges.ensure((size_t)nb * 8, 1.25f));
+            GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.3f) + 4096)));
+            grt_launch_list_expand(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
+                                   rank_to_particle, h->l_offsets.as<uint32_t>(), n, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(),
+                                   h->l_pos_particle.as<uint32_t>());
+            int bits = 1;
+            while ((1u << bits) < nb) ++bits;
+            uint32_t *sorted_blocks = nullptr, *sorted_pos = nullptr;
+            GRUT_CHECK(sort_pairs_u32(s, n, nullptr, 0, bits, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(), h->l_block_keys_tmp.as<uint32_t>(),
+                                      h->l_vals_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_blocks, &sorted_pos));
+            GRUT_HIP(hipMemsetAsync(h->l_ranges.ptr, 0, (size_t)nb * 8, s));
+            grt_launch_list_ranges(s, n, nb, sorted_blocks, sorted_pos, h->l_pos_particle.as<uint32_t>(), h->l_ranges.as<uint32_t>(),
+                                   h->l_entries.as<uint32_t>());
+            lists.ranges = h->l_ranges.as<uint32_t>();
+            lists.entries = h->l_entries.as<uint32_t>();
+            lists.bin_v = h->l_bin_v.as<float>();
+            lists.inst_rel = h->l_inst_rel.as<float>();
+            lists.block_cones = h->l_block_cones.as<GrtCone>();
+            lists.dir_len_enc = dir_len;
+            h->list_entries = I;
+        }
+    }
+    *out = lists;
+    return GRUT_OK;
+}
+
 static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
                             const float* ray_origin, const float* ray_direction, float* out_features, float* out_density,
                             float* out_hit_distance, float* out_normals, float* out_hits_count, int32_t* out_visibility,
@@ -253,66 +319,9 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
         counters = h->work_counters.as<unsigned long long>();
         GRUT_HIP(hipMemsetAsync(counters, 0, wbytes, s));
     }
-    // packet lists (GrtLists, DESIGN.md "3DGRT: packet lists"): for a frame with ONE ray origin the candidates of every 8x8 ray packet
-    // are binned once (cones x bounding spheres, the 3DGUT pipeline) and the rounds scan windows of a sorted list instead of walking the tree
     GrtBvh bvh = bvh_view(h);
-    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    h->list_entries = 0;
-    if (!getenv("GRUT_GRT_NO_LISTS")) {
-        const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
-        if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
-        GRUT_CHECK(h->l_flags.ensure(64));
-        GRUT_CHECK(h->l_block_cones.ensure((size_t)nb * sizeof(GrtCone), 1.25f));
-        GRUT_CHECK(h->l_super_cones.ensure((size_t)ns * sizeof(GrtCone), 1.25f));
-        GRUT_CHECK(h->l_inst_rel.ensure((size_t)N * 48, 1.25f));
-        for (DeviceBuffer* b4 : {&h->l_key_bits, &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets})
-            GRUT_CHECK(b4->ensure((size_t)N * 4, 1.25f));
-        GRUT_CHECK(h->l_bin_v.ensure((size_t)N * 16, 1.25f));
-        GRUT_CHECK(h->l_scan_scratch.ensure(scan_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
-        uint32_t* flag = h->l_flags.as<uint32_t>();
-        uint32_t* dir_len = flag + 2;
-        grt_launch_list_cones(s, P, ray_origin, ray_direction, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>());
-        grt_launch_list_count(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
-                              h->l_inst_rel.as<float>(), h->l_key_bits.as<uint32_t>(), h->l_bin_v.as<float>(), h->l_counts.as<uint32_t>(),
-                              h->l_pidx.as<uint32_t>());
-        // particles in key order, then the offsets of their entries
-        GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
-        uint32_t *sorted_key = nullptr, *rank_to_particle = nullptr;
-        GRUT_CHECK(sort_pairs_u32(s, N, nullptr, 0, 32, h->l_key_bits.as<uint32_t>(), h->l_pidx.as<uint32_t>(), h->l_key_tmp.as<uint32_t>(),
-                                  h->l_pidx_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_key, &rank_to_particle));
-        GRUT_CHECK(inclusive_scan_u32(s, N, h->l_counts.as<uint32_t>(), rank_to_particle, h->l_offsets.as<uint32_t>(), h->l_scan_scratch.ptr,
-                                      h->l_scan_scratch.bytes));
-        // the entry count sizes the rest: one round trip to the host per frame (with the one-origin flag riding along)
-        GRUT_HIP(hipMemcpyAsync(&h->l_host[0], h->l_offsets.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
-        GRUT_HIP(hipMemcpyAsync(&h->l_host[1], flag, 4, hipMemcpyDeviceToHost, s));
-        GRUT_HIP(hipStreamSynchronize(s));
-        const uint64_t I = h->l_host[0];
-        if (h->l_host[1] != 0u && I > 0 && I < 0xFFFF0000ull) {
-            const uint32_t n = (uint32_t)I;
-            for (DeviceBuffer* b4 : {&h->l_block_keys, &h->l_vals, &h->l_pos_particle, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_entries})
-                GRUT_CHECK(b4->ensure((size_t)n * 4, 1.3f));
-            GRUT_CHECK(h->l_ranges.ensure((size_t)nb * 8, 1.25f));
-            GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.3f) + 4096)));
-            grt_launch_list_expand(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
-                                   rank_to_particle, h->l_offsets.as<uint32_t>(), n, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(),
-                                   h->l_pos_particle.as<uint32_t>());
-            int bits = 1;
-            while ((1u << bits) < nb) ++bits;
-            uint32_t *sorted_blocks = nullptr, *sorted_pos = nullptr;
-            GRUT_CHECK(sort_pairs_u32(s, n, nullptr, 0, bits, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(), h->l_block_keys_tmp.as<uint32_t>(),
-                                      h->l_vals_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_blocks, &sorted_pos));
-            GRUT_HIP(hipMemsetAsync(h->l_ranges.ptr, 0, (size_t)nb * 8, s));
-            grt_launch_list_ranges(s, n, nb, sorted_blocks, sorted_pos, h->l_pos_particle.as<uint32_t>(), h->l_ranges.as<uint32_t>(),
-                                   h->l_entries.as<uint32_t>());
-            lists.ranges = h->l_ranges.as<uint32_t>();
-            lists.entries = h->l_entries.as<uint32_t>();
-            lists.bin_v = h->l_bin_v.as<float>();
-            lists.inst_rel = h->l_inst_rel.as<float>();
-            lists.block_cones = h->l_block_cones.as<GrtCone>();
-            lists.dir_len_enc = dir_len;
-            h->list_entries = I;
-        }
-    }
+    GrtLists lists;
+    GRUT_CHECK(build_lists(h, s, P, bvh, ray_origin, ray_direction, &lists));
     grt_launch_trace_fwd(s, P, bvh, particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
                          out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters, log, lists);
     if (log.pool && !h->log_event_pending) {  // how much of the pool the frame used, read lazily by a later forward
@@ -442,8 +451,10 @@ int grt_trace_hybrid(GrtHandle* h, void* stream_, const GrtFrame* frame, const f
     hp.max_pbr_bounces = options->max_pbr_bounces;
     for (int k = 0; k < 3; ++k) hp.background[k] = options->background[k];
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
+    GrtLists lists;   // the primary segment of every path scans the frame's packet lists when the rays share their origin
+    GRUT_CHECK(build_lists(h, s, P, bvh, ray_origin, ray_direction, &lists));
     grt_launch_hybrid(s, P, bvh, mv, hp, particle_density, particle_sph, ray_origin, ray_direction, ray_max_t, out_radiance, out_opacity, out_last_ray,
-                      out_bounces);
+                      out_bounces, lists);
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
     return GRUT_OK;

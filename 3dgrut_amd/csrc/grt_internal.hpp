@@ -131,6 +131,6 @@ uint32_t grt_num_super(int W, int H);
 void grt_launch_mesh_aabb(hipStream_t s, uint32_t F, const float* vertices, const int32_t* triangles, float* aabb, float* slack, uint32_t* scene_enc);
 void grt_launch_hybrid(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const GrtMeshView& mesh, const GrtHybridParams& hp,
                        const float* density12, const float* sph, const float* ray_o, const float* ray_d, const float* ray_max_t, float* out_rgb,
-                       float* out_alpha, float* out_last_ray, uint32_t* out_bounces);
+                       float* out_alpha, float* out_last_ray, uint32_t* out_bounces, const GrtLists& lists);
 
 }  // namespace grut

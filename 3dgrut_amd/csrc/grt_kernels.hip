@@ -1434,11 +1434,12 @@ __device__ __forceinline__ MeshHit mesh_closest(const GrtMeshView& m, const RayW
 }
 
 // traceVolumetricGS (3dgrtTracer.cuh:137-204) on [tmin, tmax] of ray r for the lanes with `active`: continues T and rad
-template <int DEG>
+template <int DEG, bool LISTS = false>
 __device__ __forceinline__ void trace_segment(const GrtTraceParams& P, const GrtBvh& bvh, const float4* __restrict__ density12,
                                               const float* __restrict__ sph, const RayW& r, float tmin, float tmax, bool active, int lane,
                                               uint32_t* __restrict__ s_stack, float* __restrict__ s_hit_t, uint32_t* __restrict__ s_hit_id, float& T,
-                                              f3& rad) {
+                                              f3& rad, const GrtLists* lists = nullptr, const GrtCone* cone = nullptr, float dmin = 1.f,
+                                              float dmax = 1.f, uint32_t list_begin = 0u, uint32_t list_end = 0u) {
     constexpr float eps = 1e-9f;
     float t0, t1;
     scene_interval(bvh.scene, r, t0, t1);
@@ -1449,12 +1450,15 @@ __device__ __forceinline__ void trace_segment(const GrtTraceParams& P, const Grt
     sh_basis16(P.sph_degree, r.d, basis);
     TraceCounters tc;
     bool running = active;
+    uint32_t list_start = list_begin;   // LISTS: a segment scans the packet's list from its beginning (see list_round)
     while (true) {
         running = running && (tLast <= t1) && (T > P.min_transmittance);
         if (!__any(running)) break;
         {
             HitBufferT<kGrtMaxHits> buf;
-            trace_round<false, kGrtMaxHits>(bvh, r, tLast + eps, t1 + eps, running, lane, s_stack, buf, tc);
+            if (LISTS) list_round<false, kGrtMaxHits>(*lists, *cone, dmin, dmax, list_end, list_start, r, tLast + eps, t1 + eps, running, lane,
+                                                      reinterpret_cast<float4*>(s_hit_t), buf, tc);
+            else trace_round<false, kGrtMaxHits>(bvh, r, tLast + eps, t1 + eps, running, lane, s_stack, buf, tc);
             buf.store(s_hit_t, s_hit_id, lane);
         }
         if (s_hit_id[lane] == 0xFFFFFFFFu) running = false;
@@ -1505,7 +1509,7 @@ __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh
                                                         const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                         const float* __restrict__ ray_max_t, float* __restrict__ out_rgb,
                                                         float* __restrict__ out_alpha, float* __restrict__ out_last_ray,
-                                                        uint32_t* __restrict__ out_bounces) {
+                                                        uint32_t* __restrict__ out_bounces, GrtLists lists) {
     __shared__ uint32_t s_stack[kGrtStackDepth];
     __shared__ float s_hit_t[kGrtMaxHits * 64];
     __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
@@ -1524,6 +1528,18 @@ __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh
     uint32_t bounces = 0u, timeout = 0u;
     bool missed = false, terminate = false;
     f3 lastO = r.o, lastD = r.d;
+    // the primary segment of every path (all rays of the frame start at one point) scans the packet's candidate list instead of walking the
+    // tree; after the first surface the rays have their own origins
+    const bool use_lists = lists.ranges != nullptr;
+    GrtCone cone = {0.f, 0.f, 1.f, -1.f, 0.f, 1.f, 0.f, 0.f};
+    float dmin = 1.f, dmax = 1.f;
+    uint32_t list_begin = 0u, list_end = 0u;
+    if (use_lists) {
+        list_begin = lists.ranges[2 * (size_t)pb.index]; list_end = lists.ranges[2 * (size_t)pb.index + 1];
+        cone = lists.block_cones[pb.index];
+        dmin = __uint_as_float(lists.dir_len_enc[0]); dmax = __uint_as_float(lists.dir_len_enc[1]);
+    }
+    bool primary = true;
     while (true) {
         const bool go = in_image && !missed && (sqrtf(dot(thr, thr)) > 0.0001f) && (accA < 0.995f) && (0u < hp.max_pbr_bounces) && (bounces < 32u) &&
                         !terminate && (timeout <= 1000u);
@@ -1560,7 +1576,10 @@ __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh
         if (__any(diffuse)) {
             const float T0 = T;
             const f3 rad0 = rad;
-            if (gaussians) trace_segment<DEG>(P, bvh, density12, sph, r, 1e-9f, hit_t, diffuse, lane, s_stack, s_hit_t, s_hit_id, T, rad);
+            if (gaussians) {
+                if (primary && use_lists) trace_segment<DEG, true>(P, bvh, density12, sph, r, 1e-9f, hit_t, diffuse, lane, s_stack, s_hit_t, s_hit_id, T, rad, &lists, &cone, dmin, dmax, list_begin, list_end);
+                else trace_segment<DEG>(P, bvh, density12, sph, r, 1e-9f, hit_t, diffuse, lane, s_stack, s_hit_t, s_hit_id, T, rad);
+            }
             if (diffuse) {
                 accC = accC + (rad - rad0);
                 accA += (1.f - T) - (1.f - T0);
@@ -1576,7 +1595,11 @@ __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh
             const float next_t = missed ? ray_t_max : hit_t;
             const float T0 = T;
             const f3 rad0 = rad;
-            if (gaussians) trace_segment<DEG>(P, bvh, density12, sph, r, 1e-9f, next_t, go, lane, s_stack, s_hit_t, s_hit_id, T, rad);
+            if (gaussians) {
+                if (primary && use_lists) trace_segment<DEG, true>(P, bvh, density12, sph, r, 1e-9f, next_t, go, lane, s_stack, s_hit_t, s_hit_id, T, rad, &lists, &cone, dmin, dmax, list_begin, list_end);
+                else trace_segment<DEG>(P, bvh, density12, sph, r, 1e-9f, next_t, go, lane, s_stack, s_hit_t, s_hit_id, T, rad);
+            }
+            primary = false;
             if (go) {
                 const f3 radiance = rad - rad0;
                 const float density = (1.f - T) - (1.f - T0);
@@ -1931,11 +1954,11 @@ void grt_launch_mesh_aabb(hipStream_t s, uint32_t F, const float* vertices, cons
 }
 void grt_launch_hybrid(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const GrtMeshView& mesh, const GrtHybridParams& hp,
                        const float* density12, const float* sph, const float* ray_o, const float* ray_d, const float* ray_max_t, float* out_rgb,
-                       float* out_alpha, float* out_last_ray, uint32_t* out_bounces) {
+                       float* out_alpha, float* out_last_ray, uint32_t* out_bounces, const GrtLists& lists) {
     const dim3 grid(pixel_block_grid(P.W, P.H));
     GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_hybrid_kernel<D_>), grid, dim3(64), 0, s, P, bvh, mesh, hp,
                                                      reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, ray_max_t, out_rgb, out_alpha,
-                                                     out_last_ray, out_bounces));
+                                                     out_last_ray, out_bounces, lists));
 }
 
 }  // namespace grut

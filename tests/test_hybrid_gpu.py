@@ -83,6 +83,38 @@ def test_hybrid_trace_matches_oracle(n, w, h, opts, with_glass):
         assert np.abs(rgb - ora["rgba"][..., :3]).max() < 1e-6
 
 
+def _render_hybrid(scene, mesh, opts=0):
+    import torch
+    from types import SimpleNamespace
+    pt = importlib.import_module("3dgrut_amd.playground_tracer")
+    ro, rd = _world_rays(scene)
+    tr = pt.Tracer({"render": {}})
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"], requires_grad=False)
+    tr.build_gs_acc(g, rebuild=True)
+    t = lambda a: torch.as_tensor(a, device="cuda")
+    tr.build_mesh_acc(t(mesh["vertices"]), t(mesh["triangles"]))
+    out = tr.render_playground(g, t(ro), t(rd), opts, t(mesh["triangles"]), t(mesh["vertex_normals"]), None, None, t(mesh["prim_type"]),
+                               materials=[SimpleNamespace(diffuseFactor=[0.8, 0.3, 0.2, 1.0])],
+                               material_id=torch.zeros((len(mesh["triangles"]), 1), dtype=torch.int32, device="cuda"),
+                               refractive_index=t(mesh["refractive_index"]), envmap=torch.tensor((0.1, 0.2, 0.3, 1.0)).repeat(4, 4, 1), max_pbr_bounces=7)
+    torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items() if hasattr(v, "cpu")}, int(tr.tracer_wrapper.stats().list_entries)
+
+
+def test_primary_segment_through_packet_lists_equals_the_tree_walk(monkeypatch):
+    """The first segment of every path starts at the camera: it scans the frame's packet lists (3DGRT forward) up to the
+    surface the ray hits; bounced rays walk the tree.  Same candidates, same order: every output is identical to the all-walk run."""
+    scene = make_scene(n=9000, width=88, height=60, median_scale=0.07, max_density=0.6)
+    mesh = _mesh(True)
+    monkeypatch.delenv("GRUT_GRT_NO_LISTS", raising=False)
+    a, n_lists = _render_hybrid(scene, mesh)
+    monkeypatch.setenv("GRUT_GRT_NO_LISTS", "1")
+    b, n_walk = _render_hybrid(scene, mesh)
+    assert n_lists > 0 and n_walk == 0
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 def test_pbr_primitives_are_refused():
     import torch
     pt = importlib.import_module("3dgrut_amd.playground_tracer")
