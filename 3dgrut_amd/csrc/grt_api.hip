@@ -46,7 +46,7 @@ struct GrtHandle {
     bool mesh_built = false;
     // packet lists of the forward (GrtLists): cones, per-particle bounds and records, the binning pipeline's buffers
     DeviceBuffer l_flags, l_block_cones, l_super_cones, l_inst_rel, l_key_bits, l_bin_v, l_counts, l_pidx, l_key_tmp, l_pidx_tmp, l_offsets,
-        l_scan_scratch, l_sort_scratch, l_block_keys, l_vals, l_pos_particle, l_block_keys_tmp, l_vals_tmp, l_entries, l_ranges;
+        l_scan_scratch, l_sort_scratch, l_block_keys, l_vals, l_block_keys_tmp, l_vals_tmp, l_ranges;
     uint32_t* l_host = nullptr;          // pinned: {entries, uniform-origin flag}
     uint64_t list_entries = 0;           // of the last forward (0: the BVH walk served it)
     DeviceBuffer work_counters;  // instrumented launches (GRUT_GRT_COUNT=1): nodes, leaf tests, processed hits, rounds, inserts
@@ -121,7 +121,7 @@ void grt_destroy(GrtHandle* h) {
                             &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
                             &h->work_counters, &h->l_flags, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits, &h->l_bin_v,
                             &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets, &h->l_scan_scratch, &h->l_sort_scratch,
-                            &h->l_block_keys, &h->l_vals, &h->l_pos_particle, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_entries, &h->l_ranges,
+                            &h->l_block_keys, &h->l_vals, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_ranges,
                             &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state, &h->m_aabb, &h->m_slack, &h->m_scene_enc,
                             &h->m_scene, &h->m_codes, &h->m_ids, &h->m_codes_tmp, &h->m_ids_tmp, &h->m_sort_scratch, &h->m_nodes, &h->m_done};
     for (DeviceBuffer* b : bufs) b->release();
@@ -231,23 +231,21 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
         const uint64_t I = h->l_host[0];
         if (h->l_host[1] != 0u && I > 0 && I < 0xFFFF0000ull) {
             const uint32_t n = (uint32_t)I;
-            for (DeviceBuffer* b4 : {&h->l_block_keys, &h->l_vals, &h->l_pos_particle, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_entries})
+            for (DeviceBuffer* b4 : {&h->l_block_keys, &h->l_vals, &h->l_block_keys_tmp, &h->l_vals_tmp})
                 GRUT_CHECK(b4->ensure((size_t)n * 4, 1.3f));
             GRUT_CHECK(h->l_ranges.ensure((size_t)nb * 8, 1.25f));
             GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.3f) + 4096)));
             grt_launch_list_expand(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
-                                   rank_to_particle, h->l_offsets.as<uint32_t>(), n, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(),
-                                   h->l_pos_particle.as<uint32_t>());
+                                   rank_to_particle, h->l_offsets.as<uint32_t>(), n, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>());
             int bits = 1;
             while ((1u << bits) < nb) ++bits;
-            uint32_t *sorted_blocks = nullptr, *sorted_pos = nullptr;
+            uint32_t *sorted_blocks = nullptr, *sorted_ids = nullptr;   // the payload of the sort is the particle: sorted payloads = the lists
             GRUT_CHECK(sort_pairs_u32(s, n, nullptr, 0, bits, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(), h->l_block_keys_tmp.as<uint32_t>(),
-                                      h->l_vals_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_blocks, &sorted_pos));
+                                      h->l_vals_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_blocks, &sorted_ids));
             GRUT_HIP(hipMemsetAsync(h->l_ranges.ptr, 0, (size_t)nb * 8, s));
-            grt_launch_list_ranges(s, n, nb, sorted_blocks, sorted_pos, h->l_pos_particle.as<uint32_t>(), h->l_ranges.as<uint32_t>(),
-                                   h->l_entries.as<uint32_t>());
+            grt_launch_list_ranges(s, n, nb, sorted_blocks, h->l_ranges.as<uint32_t>());
             lists.ranges = h->l_ranges.as<uint32_t>();
-            lists.entries = h->l_entries.as<uint32_t>();
+            lists.entries = sorted_ids;
             lists.bin_v = h->l_bin_v.as<float>();
             lists.inst_rel = h->l_inst_rel.as<float>();
             lists.block_cones = h->l_block_cones.as<GrtCone>();

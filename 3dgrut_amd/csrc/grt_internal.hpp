@@ -123,9 +123,8 @@ void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh&
                            float* bin_v, uint32_t* counts, uint32_t* particle_idx);
 void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                             const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, const uint32_t* rank_to_particle,
-                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals, uint32_t* pos_particle);
-void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, const uint32_t* sorted_pos,
-                            const uint32_t* pos_particle, uint32_t* ranges, uint32_t* entries);
+                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals);
+void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, uint32_t* ranges);
 uint32_t grt_num_blocks(int W, int H);
 uint32_t grt_num_super(int W, int H);
 void grt_launch_mesh_aabb(hipStream_t s, uint32_t F, const float* vertices, const int32_t* triangles, float* aabb, float* slack, uint32_t* scene_enc);

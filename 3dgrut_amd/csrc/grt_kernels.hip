@@ -1682,7 +1682,7 @@ __global__ void grt_list_init_kernel(uint32_t* __restrict__ flag, uint32_t* __re
 }
 // one wave per 8x8 packet: bounding cone of its rays' directions, |d| range, and whether every ray starts where ray 0 does
 __global__ __launch_bounds__(64) void grt_block_cone_kernel(GrtTraceParams P, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
-                                                            uint32_t* __restrict__ flag, uint32_t* __restrict__ dir_len_enc, GrtCone* __restrict__ cones) {
+                                                            uint32_t* __restrict__ flag, GrtCone* __restrict__ cones) {
     const uint32_t b = blockIdx.x, gx = blocks_x(P.W);
     const int lane = threadIdx.x;
     const int px = (int)(b % gx) * 8 + (lane & 7), py = (int)(b / gx) * 8 + (lane >> 3);
@@ -1709,18 +1709,15 @@ __global__ __launch_bounds__(64) void grt_block_cone_kernel(GrtTraceParams P, co
         c.cos_t = all ? -1.f : ct;
         c.sin_t = all ? 0.f : sqrtf(fmaxf(0.f, 1.f - ct * ct));
         c.valid = __any(in_image) ? 1.f : 0.f;
-        c.pad0 = c.pad1 = 0.f;
+        c.pad0 = lmin; c.pad1 = lmax;   // |d| range of the packet: reduced per super tile (10 k atomics on two words cost 0.2 ms here)
         cones[b] = c;
-        if (lmin < 3.0e38f) {
-            atomicMin(&dir_len_enc[0], __float_as_uint(lmin));
-            atomicMax(&dir_len_enc[1], __float_as_uint(lmax));
-        }
         if (bad) flag[0] = 0u;
     }
     if (__any(in_image && !same) && lane == 0) flag[0] = 0u;
 }
 // one wave per super tile (8x8 packets): cone around its packets' cones
-__global__ __launch_bounds__(64) void grt_super_cone_kernel(GrtTraceParams P, const GrtCone* __restrict__ cones, GrtCone* __restrict__ super_cones) {
+__global__ __launch_bounds__(64) void grt_super_cone_kernel(GrtTraceParams P, const GrtCone* __restrict__ cones, GrtCone* __restrict__ super_cones,
+                                                            uint32_t* __restrict__ dir_len_enc) {
     const uint32_t s = blockIdx.x, gx = blocks_x(P.W), gy = blocks_y(P.H), sx = (gx + 7u) / 8u;
     const int lane = threadIdx.x;
     const uint32_t bx = (s % sx) * 8u + (uint32_t)(lane & 7), by = (s / sx) * 8u + (uint32_t)(lane >> 3);
@@ -1735,7 +1732,12 @@ __global__ __launch_bounds__(64) void grt_super_cone_kernel(GrtTraceParams P, co
     float ang = 0.f;
     if (use) ang = (c.cos_t <= -1.f) ? 4.f : acosf(fminf(1.f, fmaxf(-1.f, dot(a, axis)))) + acosf(fminf(1.f, c.cos_t)) + 1e-5f;
     const float amax = wave_max(ang);
+    const float lmin = wave_min(use ? c.pad0 : 3.0e38f), lmax = wave_max(use ? c.pad1 : 0.f);
     if (lane == 0) {
+        if (lmin < 3.0e38f) {
+            atomicMin(&dir_len_enc[0], __float_as_uint(lmin));
+            atomicMax(&dir_len_enc[1], __float_as_uint(lmax));
+        }
         GrtCone o;
         o.ax = axis.x; o.ay = axis.y; o.az = axis.z;
         const bool all = !(amax < 1.5f) || !(sl > 0.f);
@@ -1780,7 +1782,7 @@ __device__ __forceinline__ BinParticle bin_particle(const float4& a, const float
 // test the super tile's 64 packets for that one particle — a particle that covers the screen costs the wave one step per super tile,
 // not one lane 64 steps per super tile.  EMIT: write the entries (counting pass otherwise).
 struct BinOut {
-    uint32_t *block_keys, *vals, *pos_particle;
+    uint32_t *block_keys, *vals;   // sort key = packet, payload = particle (the sorted payloads ARE the lists)
 };
 template <bool EMIT>
 __device__ __forceinline__ uint32_t bin_pairs(const GrtTraceParams& P, const GrtCone* __restrict__ block_cones, const GrtCone* __restrict__ super_cones,
@@ -1809,8 +1811,7 @@ __device__ __forceinline__ uint32_t bin_pairs(const GrtTraceParams& P, const Grt
                 const uint32_t slot = o + (uint32_t)__popcll(hm & lt);
                 if (hit && slot < e) {
                     out.block_keys[slot] = b;
-                    out.vals[slot] = slot;
-                    out.pos_particle[slot] = (uint32_t)__builtin_amdgcn_readlane((int)pid, src);
+                    out.vals[slot] = (uint32_t)__builtin_amdgcn_readlane((int)pid, src);
                 }
                 if (lane == src) off += cnt;
             } else if (lane == src) {
@@ -1820,7 +1821,7 @@ __device__ __forceinline__ uint32_t bin_pairs(const GrtTraceParams& P, const Grt
     }
     if (EMIT) {
         for (; off < end; ++off) {   // (same tests as the counting pass: not expected)
-            out.block_keys[off] = 0xFFFFFFFFu; out.vals[off] = off; out.pos_particle[off] = 0xFFFFFFFFu;
+            out.block_keys[off] = 0xFFFFFFFFu; out.vals[off] = 0xFFFFFFFFu;
         }
     }
     return n;
@@ -1841,7 +1842,7 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
         a = rec[0]; b = rec[1]; e = rec[2];
     }
     const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
-    const BinOut none = {nullptr, nullptr, nullptr};
+    const BinOut none = {nullptr, nullptr};
     const uint32_t n = bin_pairs<false>(P, block_cones, super_cones, lane, have, q, i, 0u, 0u, none);
     if (i >= bvh.N) return;
     particle_idx[i] = i;
@@ -1881,12 +1882,10 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
     bin_pairs<true>(P, block_cones, super_cones, lane, have, q, p, off, have ? end : off, out);
 }
 __global__ __launch_bounds__(256) void grt_list_ranges_kernel(uint32_t n, uint32_t num_blocks, const uint32_t* __restrict__ sorted_keys,
-                                                              const uint32_t* __restrict__ sorted_pos, const uint32_t* __restrict__ pos_particle,
-                                                              uint32_t* __restrict__ ranges, uint32_t* __restrict__ entries) {
+                                                              uint32_t* __restrict__ ranges) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const uint32_t k = sorted_keys[e];
-    entries[e] = pos_particle[sorted_pos[e]];
     if (k >= num_blocks) return;
     if (e == 0 || sorted_keys[e - 1] != k) ranges[2 * (size_t)k] = e;
     if (e == n - 1 || sorted_keys[e + 1] != k) ranges[2 * (size_t)k + 1] = e + 1;
@@ -1894,8 +1893,8 @@ __global__ __launch_bounds__(256) void grt_list_ranges_kernel(uint32_t n, uint32
 void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* ray_o, const float* ray_d, uint32_t* uniform_origin,
                            uint32_t* dir_len_enc, GrtCone* block_cones, GrtCone* super_cones) {
     hipLaunchKernelGGL(grt_list_init_kernel, dim3(1), dim3(1), 0, s, uniform_origin, dir_len_enc);
-    hipLaunchKernelGGL(grt_block_cone_kernel, dim3(grt_num_blocks(P.W, P.H)), dim3(64), 0, s, P, ray_o, ray_d, uniform_origin, dir_len_enc, block_cones);
-    hipLaunchKernelGGL(grt_super_cone_kernel, dim3(grt_num_super(P.W, P.H)), dim3(64), 0, s, P, block_cones, super_cones);
+    hipLaunchKernelGGL(grt_block_cone_kernel, dim3(grt_num_blocks(P.W, P.H)), dim3(64), 0, s, P, ray_o, ray_d, uniform_origin, block_cones);
+    hipLaunchKernelGGL(grt_super_cone_kernel, dim3(grt_num_super(P.W, P.H)), dim3(64), 0, s, P, block_cones, super_cones, dir_len_enc);
 }
 void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                            const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, float* inst_rel, uint32_t* key_bits,
@@ -1905,15 +1904,14 @@ void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh&
 }
 void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                             const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, const uint32_t* rank_to_particle,
-                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals, uint32_t* pos_particle) {
-    const BinOut out = {block_keys, vals, pos_particle};
+                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals) {
+    const BinOut out = {block_keys, vals};
     hipLaunchKernelGGL(grt_list_expand_kernel, dim3(div_up(bvh.N, 256)), dim3(256), 0, s, P, bvh, ray_o, uniform_origin, dir_len_enc, block_cones,
                        super_cones, rank_to_particle, offsets, capacity, out);
 }
-void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, const uint32_t* sorted_pos,
-                            const uint32_t* pos_particle, uint32_t* ranges, uint32_t* entries) {
+void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, uint32_t* ranges) {
     if (n == 0) return;
-    hipLaunchKernelGGL(grt_list_ranges_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, num_blocks, sorted_keys, sorted_pos, pos_particle, ranges, entries);
+    hipLaunchKernelGGL(grt_list_ranges_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, num_blocks, sorted_keys, ranges);
 }
 
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
