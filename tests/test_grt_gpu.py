@@ -279,6 +279,28 @@ def test_packet_lists_equal_the_tree_walk(monkeypatch, n, w, h, scale, kind):
             assert np.array_equal(a, b), name
 
 
+def test_packet_lists_with_the_camera_inside_the_cloud(monkeypatch):
+    """Ray origin in the middle of the particles: proxies that contain the apex of the cones (key 0, every packet reaches them) and
+    particles behind the camera.  Lists and tree walk still agree bit for bit."""
+    scene = _scene(8000, 64, 48, 0.06)
+    T = scene["batch"]["T_to_world"].copy()
+    T[0, :3, 3] = np.float32(0.05)           # the cloud is centred on the origin
+    scene["batch"] = dict(scene["batch"], T_to_world=T)
+    scene["T"] = T[0]
+    lists, n_entries = _hits_with(scene, monkeypatch, no_lists=False)
+    walk, n_walk = _hits_with(scene, monkeypatch, no_lists=True)
+    assert n_entries > 0 and n_walk == 0
+    num = lists[7].reshape(-1).astype(np.int64)
+    assert num.max() > 16                     # several trace rounds per ray
+    for a, b, name in zip(lists, walk, ("features", "density", "hit_distance", "normals", "hit_count", "visibility", "ids", "num")):
+        if name == "ids":
+            for r in range(num.size):
+                k = min(int(num[r]), 128)
+                assert np.array_equal(a.reshape(num.size, -1)[r, :k], b.reshape(num.size, -1)[r, :k]), f"ray {r}: order differs"
+        else:
+            assert np.array_equal(a, b), name
+
+
 def test_rays_with_different_origins_take_the_tree_walk(monkeypatch):
     """Packet lists need one ray origin (the cones have one apex).  A frame in which a single ray starts elsewhere is served by the tree
     walk — decided on the device, reported by grt_stats — and still matches the oracle's hit order."""
