@@ -239,7 +239,7 @@ def test_render_matches_reference_programs_golden():
 
 
 # ---- packet lists (frames with one ray origin) against the tree walk -------------------------------------------------------
-def _hits_with(scene, monkeypatch, no_lists, rays_ori=None):
+def _hits_with(scene, monkeypatch, no_lists, rays_ori=None, rays_dir=None):
     import torch
     if no_lists:
         monkeypatch.setenv("GRUT_GRT_NO_LISTS", "1")
@@ -254,7 +254,8 @@ def _hits_with(scene, monkeypatch, no_lists, rays_ori=None):
     frame = nat.make_frame(0, 3, tr._min_transmittance, g.num_gaussians, scene["H"], scene["W"], batch.T_to_world)
     d12 = torch.as_tensor(scene["density12"], device="cuda").contiguous()
     sph = torch.as_tensor(scene["sph"], device="cuda").contiguous()
-    res = nat.trace(frame, d12, sph, ro, batch.rays_dir.contiguous(), hit_capacity=128)
+    rd = batch.rays_dir.contiguous() if rays_dir is None else torch.as_tensor(rays_dir, device="cuda").contiguous()
+    res = nat.trace(frame, d12, sph, ro, rd, hit_capacity=128)
     torch.cuda.synchronize()
     return [t.cpu().numpy() for t in res], int(nat.stats().list_entries)
 
@@ -292,6 +293,26 @@ def test_packet_lists_with_the_camera_inside_the_cloud(monkeypatch):
     assert n_entries > 0 and n_walk == 0
     num = lists[7].reshape(-1).astype(np.int64)
     assert num.max() > 16                     # several trace rounds per ray
+    for a, b, name in zip(lists, walk, ("features", "density", "hit_distance", "normals", "hit_count", "visibility", "ids", "num")):
+        if name == "ids":
+            for r in range(num.size):
+                k = min(int(num[r]), 128)
+                assert np.array_equal(a.reshape(num.size, -1)[r, :k], b.reshape(num.size, -1)[r, :k]), f"ray {r}: order differs"
+        else:
+            assert np.array_equal(a, b), name
+
+
+def test_packet_lists_with_unnormalised_directions(monkeypatch):
+    """Hit distances are ray parameters: with directions of different lengths (0.4 .. 2.5 here, varying per pixel) the lists' distance
+    bounds must scale with the frame's smallest / largest |d|.  Lists and tree walk agree bit for bit."""
+    scene = _scene(6000, 56, 40, 0.06)
+    rng = np.random.default_rng(3)
+    rd = (scene["rays"][1] * rng.uniform(0.4, 2.5, size=scene["rays"][1].shape[:-1] + (1,))).astype(np.float32)
+    lists, n_entries = _hits_with(scene, monkeypatch, no_lists=False, rays_dir=rd)
+    walk, n_walk = _hits_with(scene, monkeypatch, no_lists=True, rays_dir=rd)
+    assert n_entries > 0 and n_walk == 0
+    num = lists[7].reshape(-1).astype(np.int64)
+    assert num.max() > 16
     for a, b, name in zip(lists, walk, ("features", "density", "hit_distance", "normals", "hit_count", "visibility", "ids", "num")):
         if name == "ids":
             for r in range(num.size):
