@@ -153,8 +153,8 @@ static int ensure_particle_scratch(GutHandle* h, uint32_t N) {
     GRUT_CHECK(h->sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     GRUT_CHECK(h->scan_scratch.ensure(scan_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     if (!h->counters.ptr) {   // [1] counts the visible particles of a frame: zero once here, re-armed on the device after every read
-        GRUT_CHECK(h->counters.ensure(64));
-        GRUT_HIP(hipMemset(h->counters.ptr, 0, 64));
+        GRUT_CHECK(h->counters.ensure(kGutCounterWords * 4));   // 64 replicas of the counter, one 128-byte line each (gut_project_kernel)
+        GRUT_HIP(hipMemset(h->counters.ptr, 0, kGutCounterWords * 4));
     }
     return GRUT_OK;
 }
@@ -289,7 +289,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         h->work_pending = true;
     }
     const GutProjected proj = projected_view(h);
-    uint32_t* d_counters = h->counters.as<uint32_t>();   // [1] = visible particles: zero at allocation, re-armed by the tail preparation
+    uint32_t* d_counters = h->counters.as<uint32_t>();   // [1 + 32 r] = visible particles, replica r: zero at allocation, re-armed by the tail preparation
 
     const int slot = h->prof_slot % GutHandle::kProfRing;
     if (h->profile) {

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     // Nv for the byte model: one atomic per wave
     const unsigned long long m = __ballot(has_tiles);
-    if (lane_id() == 0 && m) atomicAdd(num_visible, (uint32_t)__popcll(m));
+    if (lane_id() == 0 && m) atomicAdd(num_visible + (blockIdx.x % kGutCounterReplicas) * kGutCounterStride, (uint32_t)__popcll(m));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -978,10 +978,15 @@ __global__ __launch_bounds__(256) void gut_prepare_tail_kernel(const uint32_t* _
                                                                uint32_t* __restrict__ host_counters, uint32_t* __restrict__ ranges_words,
                                                                uint32_t n_ranges_words, uint32_t* __restrict__ reached_words, uint32_t n_reached_words) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    if (i == 0) {
-        __hip_atomic_store(&host_counters[0], *last_offset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_counters[1], *num_visible, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        *num_visible = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {   // one wave: the counter's replicas summed and re-armed
+        uint32_t v = 0u;
+        if (threadIdx.x < kGutCounterReplicas) { v = num_visible[threadIdx.x * kGutCounterStride]; num_visible[threadIdx.x * kGutCounterStride] = 0u; }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&host_counters[0], *last_offset, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_counters[1], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     for (uint32_t k = i; k < n_ranges_words; k += stride) ranges_words[k] = 0u;
     for (uint32_t k = i; k < n_reached_words; k += stride) reached_words[k] = 0u;
