@@ -554,23 +554,36 @@ __global__ __launch_bounds__(256) void gut_gather_particle_idx_kernel(uint32_t n
 __global__ __launch_bounds__(256) void gut_tile_ranges_kernel(uint32_t n_cap, const uint32_t* __restrict__ n_dev, uint32_t tile_mask,
                                                               uint32_t num_tiles, const uint32_t* __restrict__ sorted_tile_keys,
                                                               uint2* __restrict__ ranges, uint32_t* __restrict__ boundary_tile) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    // four consecutive keys per thread (one 16-byte load + the key in front of them)
+    const uint32_t k0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
     const uint32_t n = n_dev ? min(n_cap, *n_dev) : n_cap;  // n_cap may be a capacity bound (speculative launch)
-    if (k >= n) return;
-    const uint32_t t = sorted_tile_keys[k] & tile_mask;
-    const bool valid = t < num_tiles;
-    // segment boundary b sits at sorted index b * kGutSegment; remember which tile's list it cuts
-    if ((k % kGutSegment) == 0) boundary_tile[k / kGutSegment] = valid ? t : 0xFFFFFFFFu;
-    if (k == 0) {
-        if (valid) ranges[t].x = 0;
+    if (k0 >= n) return;
+    uint32_t key[4];
+    if (k0 + 4u <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(sorted_tile_keys + k0);
+        key[0] = v.x; key[1] = v.y; key[2] = v.z; key[3] = v.w;
     } else {
-        const uint32_t pt = sorted_tile_keys[k - 1] & tile_mask;
-        if (pt != t) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) key[j] = (k0 + j < n) ? sorted_tile_keys[k0 + j] : 0u;
+    }
+    uint32_t pt = k0 ? (sorted_tile_keys[k0 - 1] & tile_mask) : 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t k = k0 + j;
+        if (k >= n) break;
+        const uint32_t t = key[j] & tile_mask;
+        const bool valid = t < num_tiles;
+        // segment boundary b sits at sorted index b * kGutSegment; remember which tile's list it cuts
+        if ((k % kGutSegment) == 0) boundary_tile[k / kGutSegment] = valid ? t : 0xFFFFFFFFu;
+        if (k == 0) {
+            if (valid) ranges[t].x = 0;
+        } else if (pt != t) {
             if (pt < num_tiles) ranges[pt].y = k;
             if (valid) ranges[t].x = k;
         }
+        if (valid && k == n - 1) ranges[t].y = n;
+        pt = t;
     }
-    if (valid && k == n - 1) ranges[t].y = n;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1031,7 +1044,7 @@ void launch_gather_particle_idx(hipStream_t s, uint32_t n, const uint32_t* sorte
 }
 void launch_tile_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32_t tile_mask, uint32_t num_tiles,
                         const uint32_t* sorted_tile_keys, uint32_t* ranges, uint32_t* boundary_tile) {
-    hipLaunchKernelGGL(gut_tile_ranges_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, n_dev, tile_mask, num_tiles, sorted_tile_keys,
+    hipLaunchKernelGGL(gut_tile_ranges_kernel, dim3(div_up(div_up(n, 4u), 256)), dim3(256), 0, s, n, n_dev, tile_mask, num_tiles, sorted_tile_keys,
                        reinterpret_cast<uint2*>(ranges), boundary_tile);
 }
 
