@@ -97,7 +97,9 @@ __global__ __launch_bounds__(kScanThreads) void scan_block_sums_kernel(uint32_t*
     }
 }
 
-template <bool EXCLUSIVE>
+// FUSED: block_sums holds the raw per-block totals and every block adds up the ones in front of it itself (a few loads per thread for
+// the array sizes of this path) — the single-block scan of the totals and its launch are skipped
+template <bool EXCLUSIVE, bool FUSED>
 __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(const uint32_t* __restrict__ in,
                                                                   const uint32_t* __restrict__ gather, uint32_t n,
                                                                   const uint32_t* __restrict__ block_sums,
@@ -110,7 +112,15 @@ __global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(const uint32_t
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) s += x[k];
     uint32_t total;
-    uint32_t run = block_excl_scan_256(s, &total, s_wave) + block_sums[blockIdx.x];
+    uint32_t block_base;
+    if (FUSED) {
+        uint32_t pre = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += kScanThreads) pre += block_sums[i];
+        (void)block_excl_scan_256(pre, &block_base, s_wave);
+    } else {
+        block_base = block_sums[blockIdx.x];
+    }
+    uint32_t run = block_excl_scan_256(s, &total, s_wave) + block_base;
     const uint32_t i0 = base + threadIdx.x * kScanItems;
     uint32_t y[kScanItems];
 #pragma unroll
@@ -135,11 +145,15 @@ int scan_impl(hipStream_t s, uint32_t n, const uint32_t* in, const uint32_t* gat
     GRUT_REQUIRE(scratch_bytes >= (size_t)nb * sizeof(uint32_t), "scan scratch too small");
     uint32_t* sums = reinterpret_cast<uint32_t*>(scratch);
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kScanThreads), 0, s, sums, nb);
-    if (exclusive)
-        hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums, out);
-    else
-        hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums, out);
+    const bool fused = nb <= 8192u;   // (<= 32 loads per thread for the prefix of the block totals)
+    if (!fused) hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(kScanThreads), 0, s, sums, nb);
+    if (exclusive) {
+        if (fused) hipLaunchKernelGGL((scan_apply_kernel<true, true>), dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums, out);
+        else hipLaunchKernelGGL((scan_apply_kernel<true, false>), dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums, out);
+    } else {
+        if (fused) hipLaunchKernelGGL((scan_apply_kernel<false, true>), dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums, out);
+        else hipLaunchKernelGGL((scan_apply_kernel<false, false>), dim3(nb), dim3(kScanThreads), 0, s, in, gather, n, sums, out);
+    }
     GRUT_HIP(hipGetLastError());
     return GRUT_OK;
 }
