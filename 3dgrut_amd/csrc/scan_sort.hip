@@ -207,8 +207,11 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint32_t
 
 // Exclusive scan of each digit's row of per-block counts (in place) + the digit totals: with the 256-entry scan of the
 // totals done inside the scatter kernel this replaces a generic three-kernel scan of the whole matrix per pass.
+// One workgroup per digit that can occur (2^nbits of them: the rows of the other digits are all zero and stay untouched; their totals
+// are zeroed by workgroup 0).
 __global__ __launch_bounds__(kSortThreads) void radix_rowscan_kernel(uint32_t* __restrict__ hist, uint32_t nb, uint32_t* __restrict__ totals) {
     __shared__ uint32_t s_wave[4];
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x) totals[threadIdx.x] = 0u;
     uint32_t* row = hist + (size_t)blockIdx.x * nb;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nb; base += kSortThreads) {
@@ -342,11 +345,13 @@ int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_b
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch);
     uint32_t* totals = hist + (size_t)kRadix * nb;
     uint32_t *ki = keys, *vi = vals, *ko = keys_tmp, *vo = vals_tmp;
-    for (int bit = begin_bit; bit < end_bit; bit += 8) {
-        const int nbits = (end_bit - bit) < 8 ? (end_bit - bit) : 8;
+    // digits of equal width: 13 tile bits are sorted as 7 + 6, not 8 + 5 — the row scan works on 128 + 64 rows instead of 256 + 256
+    const int total_bits = end_bit - begin_bit, passes = (total_bits + 7) / 8, width = (total_bits + passes - 1) / passes;
+    for (int bit = begin_bit; bit < end_bit; bit += width) {
+        const int nbits = (end_bit - bit) < width ? (end_bit - bit) : width;
         const uint32_t mask = (1u << nbits) - 1u;
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(kSortThreads), 0, s, ki, n, n_dev, bit, mask, nb, hist);
-        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(kRadix), dim3(kSortThreads), 0, s, hist, nb, totals);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1u << nbits), dim3(kSortThreads), 0, s, hist, nb, totals);
         hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(kSortThreads), 0, s, ki, vi, n, n_dev, bit, mask, nb, hist, totals, ko, vo);
         uint32_t* t;
         t = ki; ki = ko; ko = t;
