@@ -162,9 +162,11 @@ int scan_impl(hipStream_t s, uint32_t n, const uint32_t* in, const uint32_t* gat
 // radix sort
 // ---------------------------------------------------------------------------------------------
 constexpr int kSortThreads = 256;
-constexpr int kSortRounds  = 16;                         // keys per lane
-constexpr int kSortTile    = kSortThreads * kSortRounds;  // 4096 keys per workgroup
-constexpr int kSortWaveKeys = 64 * kSortRounds;           // 1024 contiguous keys per wave
+// keys per lane (ROUNDS): 16 (4096 keys per workgroup) for large arrays; 8 for small ones (<= 2 M keys: the depth sort of 1 M particles
+// is 245 workgroups of 4096 keys — fewer than the chip has CUs; with 2048 keys it is 0.082 instead of 0.095 ms, while the 11.5 M-entry tile
+// sort loses with them, 0.210 vs 0.164 ms)
+constexpr int kSortRoundsLarge = 16, kSortRoundsSmall = 8;
+constexpr uint32_t kSortSmallLimit = 2u << 20;
 constexpr int kRadix       = 256;
 
 __device__ __forceinline__ uint32_t eff_count(uint32_t n, const uint32_t* n_dev) {
@@ -174,6 +176,7 @@ __device__ __forceinline__ uint32_t eff_count(uint32_t n, const uint32_t* n_dev)
 }
 
 // histogram matrix is digit-major: hist[d * nb + b]
+template <int kSortRounds>
 __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                   const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
                                                                   uint32_t nb, uint32_t* __restrict__ hist) {
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_hist_kernel(const uint32_t
 #pragma unroll
     for (int w = 0; w < 4; ++w) s_hist[w][threadIdx.x] = 0;
     __syncthreads();
+    constexpr int kSortTile = kSortThreads * kSortRounds;
     const uint32_t base = blockIdx.x * kSortTile;
     if (base < ne) {
         // 16 B per lane, 4 loads per thread
@@ -225,12 +229,14 @@ __global__ __launch_bounds__(kSortThreads) void radix_rowscan_kernel(uint32_t* _
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+template <int kSortRounds>
 __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                      const uint32_t* __restrict__ vals_in, uint32_t n,
                                                                      const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
                                                                      uint32_t nb, const uint32_t* __restrict__ hist_scanned,
                                                                      const uint32_t* __restrict__ digit_totals,
                                                                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    constexpr int kSortTile = kSortThreads * kSortRounds, kSortWaveKeys = 64 * kSortRounds;
     // per-wave digit counters; after the ranking phase they are turned into global scatter bases
     __shared__ uint32_t s_cnt[4][kRadix];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -329,7 +335,7 @@ int inclusive_scan_u32(hipStream_t s, uint32_t n, const uint32_t* in, const uint
 }
 
 size_t sort_scratch_bytes(uint32_t n) {
-    const uint32_t nb = div_up(n, kSortTile);
+    const uint32_t nb = div_up(n, (uint32_t)(kSortThreads * kSortRoundsSmall));   // (the smaller tile: an upper bound for either layout)
     const size_t hist = (size_t)kRadix * nb * sizeof(uint32_t);
     return hist + kRadix * sizeof(uint32_t) + 256;  // per-block digit counts + digit totals
 }
@@ -341,7 +347,8 @@ int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_b
     *out_vals = vals;
     if (n == 0 || end_bit <= begin_bit) return GRUT_OK;
     GRUT_REQUIRE(scratch_bytes >= sort_scratch_bytes(n), "sort scratch too small");
-    const uint32_t nb = div_up(n, kSortTile);
+    const bool small = n <= kSortSmallLimit;
+    const uint32_t nb = div_up(n, (uint32_t)(kSortThreads * (small ? kSortRoundsSmall : kSortRoundsLarge)));
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch);
     uint32_t* totals = hist + (size_t)kRadix * nb;
     uint32_t *ki = keys, *vi = vals, *ko = keys_tmp, *vo = vals_tmp;
@@ -350,9 +357,11 @@ int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_b
     for (int bit = begin_bit; bit < end_bit; bit += width) {
         const int nbits = (end_bit - bit) < width ? (end_bit - bit) : width;
         const uint32_t mask = (1u << nbits) - 1u;
-        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(kSortThreads), 0, s, ki, n, n_dev, bit, mask, nb, hist);
+        if (small) hipLaunchKernelGGL(radix_hist_kernel<kSortRoundsSmall>, dim3(nb), dim3(kSortThreads), 0, s, ki, n, n_dev, bit, mask, nb, hist);
+        else hipLaunchKernelGGL(radix_hist_kernel<kSortRoundsLarge>, dim3(nb), dim3(kSortThreads), 0, s, ki, n, n_dev, bit, mask, nb, hist);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1u << nbits), dim3(kSortThreads), 0, s, hist, nb, totals);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(kSortThreads), 0, s, ki, vi, n, n_dev, bit, mask, nb, hist, totals, ko, vo);
+        if (small) hipLaunchKernelGGL(radix_scatter_kernel<kSortRoundsSmall>, dim3(nb), dim3(kSortThreads), 0, s, ki, vi, n, n_dev, bit, mask, nb, hist, totals, ko, vo);
+        else hipLaunchKernelGGL(radix_scatter_kernel<kSortRoundsLarge>, dim3(nb), dim3(kSortThreads), 0, s, ki, vi, n, n_dev, bit, mask, nb, hist, totals, ko, vo);
         uint32_t* t;
         t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
