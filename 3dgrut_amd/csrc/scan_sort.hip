@@ -165,7 +165,10 @@ constexpr int kSortThreads = 256;
 // keys per lane (ROUNDS): 16 (4096 keys per workgroup) for large arrays; 8 for small ones (<= 2 M keys: the depth sort of 1 M particles
 // is 245 workgroups of 4096 keys — fewer than the chip has CUs; with 2048 keys it is 0.082 instead of 0.095 ms, while the 11.5 M-entry tile
 // sort loses with them, 0.210 vs 0.164 ms)
-constexpr int kSortRoundsLarge = 16, kSortRoundsSmall = 8;
+#ifndef GRUT_SORT_SMALL
+#define GRUT_SORT_SMALL 8
+#endif
+constexpr int kSortRoundsLarge = 16, kSortRoundsSmall = GRUT_SORT_SMALL;
 constexpr uint32_t kSortSmallLimit = 2u << 20;
 constexpr int kRadix       = 256;
 
