@@ -1883,12 +1883,30 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
 }
 __global__ __launch_bounds__(256) void grt_list_ranges_kernel(uint32_t n, uint32_t num_blocks, const uint32_t* __restrict__ sorted_keys,
                                                               uint32_t* __restrict__ ranges) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    const uint32_t k = sorted_keys[e];
-    if (k >= num_blocks) return;
-    if (e == 0 || sorted_keys[e - 1] != k) ranges[2 * (size_t)k] = e;
-    if (e == n - 1 || sorted_keys[e + 1] != k) ranges[2 * (size_t)k + 1] = e + 1;
+    // four consecutive keys per thread (one 16-byte load + the key in front of them)
+    const uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
+    if (e0 >= n) return;
+    uint32_t key[4];
+    if (e0 + 4u <= n) {
+        const uint4 v = *reinterpret_cast<const uint4*>(sorted_keys + e0);
+        key[0] = v.x; key[1] = v.y; key[2] = v.z; key[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) key[j] = (e0 + j < n) ? sorted_keys[e0 + j] : 0xFFFFFFFFu;
+    }
+    uint32_t prev = e0 ? sorted_keys[e0 - 1] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t e = e0 + j;
+        if (e >= n) break;
+        const uint32_t k = key[j];
+        if (k != prev || e == 0) {
+            if (e != 0 && prev < num_blocks) ranges[2 * (size_t)prev + 1] = e;
+            if (k < num_blocks) ranges[2 * (size_t)k] = e;
+        }
+        if (e == n - 1 && k < num_blocks) ranges[2 * (size_t)k + 1] = n;
+        prev = k;
+    }
 }
 void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* ray_o, const float* ray_d, uint32_t* uniform_origin,
                            uint32_t* dir_len_enc, GrtCone* block_cones, GrtCone* super_cones) {
@@ -1911,7 +1929,7 @@ void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh
 }
 void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, uint32_t* ranges) {
     if (n == 0) return;
-    hipLaunchKernelGGL(grt_list_ranges_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, num_blocks, sorted_keys, ranges);
+    hipLaunchKernelGGL(grt_list_ranges_kernel, dim3(div_up(div_up(n, 4u), 256)), dim3(256), 0, s, n, num_blocks, sorted_keys, ranges);
 }
 
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
