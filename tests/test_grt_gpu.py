@@ -322,6 +322,22 @@ def test_packet_lists_with_unnormalised_directions(monkeypatch):
             assert np.array_equal(a, b), name
 
 
+def test_a_degenerate_direction_sends_the_frame_to_the_tree_walk(monkeypatch):
+    """A ray with a zero direction has no place in a bounding cone: the frame is served by the tree walk (decided on the device) and the
+    other rays are rendered as if nothing had happened."""
+    scene = _scene(3000, 40, 24, 0.08)
+    rd = scene["rays"][1].copy()
+    rd[0, 3, 5] = 0.0
+    res, n_entries = _hits_with(scene, monkeypatch, no_lists=False, rays_dir=rd)
+    ref, _ = _hits_with(scene, monkeypatch, no_lists=True, rays_dir=rd)
+    assert n_entries == 0
+    keep = np.ones((24, 40), bool)
+    keep[3, 5] = False
+    for a, b, name in zip(res[:5], ref[:5], ("features", "density", "hit_distance", "normals", "hit_count")):
+        assert np.array_equal(a[0][keep], b[0][keep]), name
+    assert np.isfinite(res[0][0][keep]).all()
+
+
 def test_rays_with_different_origins_take_the_tree_walk(monkeypatch):
     """Packet lists need one ray origin (the cones have one apex).  A frame in which a single ray starts elsewhere is served by the tree
     walk — decided on the device, reported by grt_stats — and still matches the oracle's hit order."""
