@@ -133,7 +133,9 @@ int inclusive_scan_u32(hipStream_t s, uint32_t n, const uint32_t* in, const uint
 size_t sort_scratch_bytes(uint32_t n);
 int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_bit, int end_bit,
                    uint32_t* keys, uint32_t* vals, uint32_t* keys_tmp, uint32_t* vals_tmp,
-                   void* scratch, size_t scratch_bytes, uint32_t** out_keys, uint32_t** out_vals);
+                   void* scratch, size_t scratch_bytes, uint32_t** out_keys, uint32_t** out_vals, bool vals_iota = false);
+// vals_iota: the payload of element i is i itself — `vals` is then never read (the first pass generates it) and need not be written
+// by the producer of the keys; it is still used as one of the two ping-pong buffers.
 
 }  // namespace grut
 

@@ -1845,8 +1845,7 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
     const BinOut none = {nullptr, nullptr};
     const uint32_t n = bin_pairs<false>(P, block_cones, super_cones, lane, have, q, i, 0u, 0u, none);
     if (i >= bvh.N) return;
-    particle_idx[i] = i;
-    counts[i] = have ? n : 0u;
+    counts[i] = have ? n : 0u;   // (particle_idx, the payload of the key sort, is an iota: generated by the sort's first pass)
     key_bits[i] = (have && n) ? __float_as_uint(q.key) : 0xFFFFFFFFu;   // sort key (the sort consumes this array); particles no packet can reach go last
     if (!have) return;
     bin_v[i] = make_float4(q.v.x, q.v.y, q.v.z, q.key);   // proxy centre relative to the ray origin + the sort key: what list_round needs per entry

@@ -306,7 +306,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     uint32_t *sorted_depth = nullptr, *rank_to_particle = nullptr;
     GRUT_CHECK(sort_pairs_u32(s, N, nullptr, 0, 32, proj.depth_key, proj.particle_idx, h->depth_key_tmp.as<uint32_t>(),
                               h->particle_idx_tmp.as<uint32_t>(), h->sort_scratch.ptr, h->sort_scratch.bytes, &sorted_depth,
-                              &rank_to_particle));
+                              &rank_to_particle, true));
     h->rank_to_particle = rank_to_particle;
     GRUT_CHECK(h->stage_end(GUT_STAGE_DEPTH_SORT, s, slot));
     GRUT_CHECK(h->stage_begin(GUT_STAGE_SCAN, s, slot));
@@ -328,15 +328,15 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     auto enqueue_tail = [&](uint32_t n, const uint32_t* n_dev) -> int {
         // K4 expansion in rank order
         GRUT_CHECK(h->stage_begin(GUT_STAGE_EXPAND, s, slot));
-        launch_expand(s, P, proj, rank_to_particle, h->offsets.as<uint32_t>(), n, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>(),
-                      h->pos_particle.as<uint32_t>());
+        launch_expand(s, P, proj, rank_to_particle, h->offsets.as<uint32_t>(), n, h->tile_keys.as<uint32_t>(), nullptr /* payload = position:
+                      generated by the sort */, h->pos_particle.as<uint32_t>());
         GRUT_CHECK(h->stage_end(GUT_STAGE_EXPAND, s, slot));
         // K5 stable radix passes over the tile bits only
         GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_SORT, s, slot));
         uint32_t *sorted_tiles = nullptr, *sorted_idx = nullptr;
         GRUT_CHECK(sort_pairs_u32(s, n, n_dev, 0, (int)h->stats.key_bits, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>(),
                                   h->tile_keys_tmp.as<uint32_t>(), h->tile_vals_tmp.as<uint32_t>(), h->tile_sort_scratch.ptr,
-                                  h->tile_sort_scratch.bytes, &sorted_tiles, &sorted_idx));
+                                  h->tile_sort_scratch.bytes, &sorted_tiles, &sorted_idx, true));
         h->sorted_tile_keys = sorted_tiles;
         h->sorted_pos = sorted_idx;
         GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_SORT, s, slot));

@@ -413,8 +413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             out.depth[i] = depth;
             out.depth_key[i] = __float_as_uint(depth);
         }
-        out.particle_idx[i] = i;
-    }
+    }   // (particle_idx, the payload of the depth sort, is an iota: generated by the sort's first pass)
     // Nv for the byte model: one atomic per wave
     const unsigned long long m = __ballot(has_tiles);
     if (lane_id() == 0 && m) atomicAdd(num_visible + (blockIdx.x % kGutCounterReplicas) * kGutCounterStride, (uint32_t)__popcll(m));
@@ -474,14 +473,14 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
                           const uint32_t slot = o + (uint32_t)__popc(m & row_lt);
                           if (keep && slot < send) {  // the sort carries the expansion position, not the particle
                               tile_keys[slot] = tile;
-                              tile_vals[slot] = slot;
+                              if (tile_vals) tile_vals[slot] = slot;
                               pos_particle[slot] = sp;
                           }
                           o += (uint32_t)__popc(m);
                       });
         for (uint32_t q = o + (lane & 15); q < send; q += 16) {  // gutProjector.cuh:372-376 padding
             tile_keys[q] = 0xFFFFFFFFu;
-            tile_vals[q] = q;
+            if (tile_vals) tile_vals[q] = q;
             pos_particle[q] = 0xFFFFFFFFu;
         }
     }
@@ -505,12 +504,12 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
         const uint32_t slot = o + (uint32_t)__popc(m & half_lt);
         if (keep && slot < send) {
             tile_keys[slot] = (uint32_t)(y * P.gx + x);
-            tile_vals[slot] = slot;
+            if (tile_vals) tile_vals[slot] = slot;
             pos_particle[slot] = sp;
         }
         for (uint32_t q = o + (uint32_t)__popc(m) + (lane & 31); q < send; q += 32) {  // gutProjector.cuh:372-376 padding
             tile_keys[q] = 0xFFFFFFFFu;
-            tile_vals[q] = q;
+            if (tile_vals) tile_vals[q] = q;
             pos_particle[q] = 0xFFFFFFFFu;
         }
     }
@@ -529,14 +528,14 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
                            const uint32_t slot = o + (uint32_t)__popcll(m & lt_mask);
                            if (keep && slot < send) {
                                tile_keys[slot] = tile;
-                               tile_vals[slot] = slot;
+                               if (tile_vals) tile_vals[slot] = slot;
                                pos_particle[slot] = sp;
                            }
                            o += (uint32_t)__popcll(m);
                        });
         for (uint32_t q = o + lane; q < send; q += 64) {
             tile_keys[q] = 0xFFFFFFFFu;
-            tile_vals[q] = q;
+            if (tile_vals) tile_vals[q] = q;
             pos_particle[q] = 0xFFFFFFFFu;
         }
     }

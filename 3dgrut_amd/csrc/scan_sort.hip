@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
         const uint32_t i = wbase + r * 64 + lane;
         const bool valid = i < ne;
         key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
-        val[r] = valid ? vals_in[i] : 0u;
+        val[r] = valid ? (vals_in ? vals_in[i] : i) : 0u;   // vals_in == nullptr: the values are the positions themselves (first pass of an iota payload)
     }
 #pragma unroll
     for (int r = 0; r < kSortRounds; ++r) {
@@ -345,7 +345,7 @@ size_t sort_scratch_bytes(uint32_t n) {
 
 int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_bit, int end_bit,
                    uint32_t* keys, uint32_t* vals, uint32_t* keys_tmp, uint32_t* vals_tmp,
-                   void* scratch, size_t scratch_bytes, uint32_t** out_keys, uint32_t** out_vals) {
+                   void* scratch, size_t scratch_bytes, uint32_t** out_keys, uint32_t** out_vals, bool vals_iota) {
     *out_keys = keys;
     *out_vals = vals;
     if (n == 0 || end_bit <= begin_bit) return GRUT_OK;
@@ -363,8 +363,9 @@ int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_b
         if (small) hipLaunchKernelGGL(radix_hist_kernel<kSortRoundsSmall>, dim3(nb), dim3(kSortThreads), 0, s, ki, n, n_dev, bit, mask, nb, hist);
         else hipLaunchKernelGGL(radix_hist_kernel<kSortRoundsLarge>, dim3(nb), dim3(kSortThreads), 0, s, ki, n, n_dev, bit, mask, nb, hist);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(1u << nbits), dim3(kSortThreads), 0, s, hist, nb, totals);
-        if (small) hipLaunchKernelGGL(radix_scatter_kernel<kSortRoundsSmall>, dim3(nb), dim3(kSortThreads), 0, s, ki, vi, n, n_dev, bit, mask, nb, hist, totals, ko, vo);
-        else hipLaunchKernelGGL(radix_scatter_kernel<kSortRoundsLarge>, dim3(nb), dim3(kSortThreads), 0, s, ki, vi, n, n_dev, bit, mask, nb, hist, totals, ko, vo);
+        const uint32_t* vin = (vals_iota && bit == begin_bit) ? nullptr : vi;   // iota payload: generated by the first pass, never read
+        if (small) hipLaunchKernelGGL(radix_scatter_kernel<kSortRoundsSmall>, dim3(nb), dim3(kSortThreads), 0, s, ki, vin, n, n_dev, bit, mask, nb, hist, totals, ko, vo);
+        else hipLaunchKernelGGL(radix_scatter_kernel<kSortRoundsLarge>, dim3(nb), dim3(kSortThreads), 0, s, ki, vin, n, n_dev, bit, mask, nb, hist, totals, ko, vo);
         uint32_t* t;
         t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
