@@ -1134,7 +1134,10 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
 //      and ONE atomic set per (wave, particle) goes to memory.  Lanes that hold the particle at a farther slot simply
 //      lead (or join) a later group: matching quality only affects how much is aggregated, never the result.
 constexpr int kAggWindow = 2;   // slots on either side of the leader's slot that are searched for the same particle
-constexpr int kAggSlots = 8;    // hits of a round worked off together (two halves per round)
+#ifndef GRT_AGG_SLOTS
+#define GRT_AGG_SLOTS 8
+#endif
+constexpr int kAggSlots = GRT_AGG_SLOTS;    // hits of a round worked off together (two halves per round)
 
 template <int DEG>
 __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
