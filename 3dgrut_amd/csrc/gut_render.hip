@@ -354,10 +354,10 @@ void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryL
     uint32_t tile, half;
     half_mapping(blockIdx.x, tile, half);
     if (tile >= (uint32_t)(P.gx * P.gy)) return;
-#ifndef GRUT_FWD_ROW_STRIDE
-#define GRUT_FWD_ROW_STRIDE 21   // tile rows visited with a stride (r02t/r02u: 0.517 -> 0.490 ms with 21 or 5 of 68 rows; 33: no gain)
-#endif
-    if (GRUT_FWD_ROW_STRIDE > 1) tile = stride_permute(tile / (uint32_t)P.gx, (uint32_t)P.gy, GRUT_FWD_ROW_STRIDE) * (uint32_t)P.gx + tile % (uint32_t)P.gx;
+#ifndef GRUT_FWD_TILE_STRIDE
+#define GRUT_FWD_TILE_STRIDE 997   // tiles visited with a stride: r02t/r02u rows only, stride 21 of 68: 0.517 -> 0.490 ms; r02ah every tile,
+#endif                             // stride 997 of 8160: another 0.017 ms (strides 61 / 499 / 1777 / 3001: no better than the rows)
+    if (GRUT_FWD_TILE_STRIDE > 1) tile = stride_permute(tile, (uint32_t)(P.gx * P.gy), GRUT_FWD_TILE_STRIDE);
     const int lane = threadIdx.x;
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;   // constant-rate (100 MHz) counter shared by the whole chip
     const RayPair rp = init_ray_pair(P, ray_o, ray_d, tile, half, lane);
