@@ -333,7 +333,12 @@ int grt_build_bvh(GrtHandle* handle, void* stream, uint32_t num_particles,
                   int rebuild, int allow_update);
 
 /*  out_features [H,W,3], out_density [H,W,1], out_hit_distance [H,W,2] (integrated depth, last hit t),
- *  out_normals [H,W,3], out_hits_count [H,W,1], out_visibility [N] i32 — all must arrive zero-filled */
+ *  out_normals [H,W,3], out_hits_count [H,W,1], out_visibility [N] i32 — all must arrive zero-filled.
+ *  Replaces OptixTracer::trace (optixTracer.h:150-163, optixTracer.cpp:890-1000).  When every ray of the frame starts at the same
+ *  point (decided on the device from ray_origin) the candidates of each 8x8 ray packet are binned once per frame and the k = 16 trace
+ *  rounds scan sorted per-packet lists instead of walking the BVH (identical results; GrtStats::list_entries tells which path ran; the
+ *  call then waits once for the list size — a 4-byte read-back — before it enqueues the trace).  Environment GRUT_GRT_NO_LISTS=1
+ *  forces the tree walk. */
 int grt_forward(GrtHandle* handle, void* stream, const GrtFrame* frame,
                 const float* particle_density, const float* particle_sph,
                 const float* ray_origin, const float* ray_direction,
