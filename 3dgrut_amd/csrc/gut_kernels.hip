@@ -228,7 +228,10 @@ __device__ __forceinline__ int group_source(int lane, bool member, const GroupPi
 // rolling shutter): with the three models and the shutter iterations in one body the kernel was 17 k instructions (140 KB of code
 // against a 64 KB instruction cache shared by two CUs).
 template <int MODEL, int ROLLING>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void gut_project_kernel(GutParams P, const float4* __restrict__ density12,
+#ifndef GRUT_PROJECT_WAVES_MAX
+#define GRUT_PROJECT_WAVES_MAX 6   // (8 fits the specialised kernels, 60 VGPRs, and changes nothing: 0.122 vs 0.120 ms)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, GRUT_PROJECT_WAVES_MAX))) void gut_project_kernel(GutParams P, const float4* __restrict__ density12,
                                                           const float* __restrict__ sph, GutProjected out,
                                                           int32_t* __restrict__ visibility, uint32_t* __restrict__ num_visible) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
