@@ -975,7 +975,7 @@ __global__ __launch_bounds__(128) void sph_grad_from_views_kernel(uint32_t N, ui
 }
 
 // frame poses from camera-to-world matrices in device memory (no host round trip, no stream sync)
-__global__ void gut_frame_poses_kernel(const float* __restrict__ T_start, const float* __restrict__ T_end, FramePoses* __restrict__ out) {
+__global__ __launch_bounds__(64) void gut_frame_poses_kernel(const float* __restrict__ T_start, const float* __restrict__ T_end, FramePoses* __restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float ps[7], pe[7];
     c2w_to_world_to_sensor(T_start, ps);
