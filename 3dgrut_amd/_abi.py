@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrut_amd.so")
 
@@ -90,7 +90,7 @@ class GrtStats(C.Structure):
     _fields_ = [
         ("num_particles", C.c_uint32), ("num_nodes", C.c_uint32), ("nodes_visited", C.c_uint64),
         ("candidates", C.c_uint64), ("processed_hits", C.c_uint64), ("scene_aabb", C.c_float * 6),
-        ("list_entries", C.c_uint64), ("packet_tests", C.c_uint64),
+        ("list_entries", C.c_uint64), ("packet_tests", C.c_uint64), ("list_batches", C.c_uint64),
     ]
 
 

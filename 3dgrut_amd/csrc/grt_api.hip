@@ -32,9 +32,11 @@ struct GrtHandle {
     const void* log_ray_o = nullptr;
     const void* log_ray_d = nullptr;
     GrtFrame log_frame;
+    GrtLists log_lists = {nullptr, nullptr, nullptr, nullptr, nullptr};   // packet lists of the logged forward (cleared when the list scratch is rebuilt)
     bool log_matches(const GrtFrame& f, const void* density, const void* ray_o, const void* ray_d) const {
         return log_valid && log_W == f.width && log_H == f.height && log_density == density && log_ray_o == ray_o && log_ray_d == ray_d &&
                log_frame.frame_id == f.frame_id && log_frame.sph_degree == f.sph_degree && log_frame.min_transmittance == f.min_transmittance &&
+               log_frame.device_ray_to_world == f.device_ray_to_world &&
                memcmp(log_frame.ray_to_world, f.ray_to_world, sizeof(f.ray_to_world)) == 0;
     }
     uint32_t* log_state_host = nullptr;  // pinned copy of {chunks used, overflow} of the last logged forward
@@ -45,7 +47,7 @@ struct GrtHandle {
     uint32_t mesh_faces = 0;
     bool mesh_built = false;
     // packet lists of the forward (GrtLists): cones, per-particle bounds and records, the binning pipeline's buffers
-    DeviceBuffer l_flags, l_block_cones, l_super_cones, l_inst_rel, l_key_bits, l_bin_v, l_counts, l_pidx, l_key_tmp, l_pidx_tmp, l_offsets,
+    DeviceBuffer l_flags, l_block_cones, l_super_cones, l_inst_rel, l_key_bits, l_counts, l_pidx, l_key_tmp, l_pidx_tmp, l_offsets,
         l_scan_scratch, l_sort_scratch, l_block_keys, l_vals, l_block_keys_tmp, l_vals_tmp, l_ranges;
     uint32_t* l_host = nullptr;          // pinned: {entries, uniform-origin flag}
     uint64_t list_entries = 0;           // of the last forward (0: the BVH walk served it)
@@ -119,7 +121,7 @@ void grt_destroy(GrtHandle* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
                             &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
-                            &h->work_counters, &h->l_flags, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits, &h->l_bin_v,
+                            &h->work_counters, &h->l_flags, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits,
                             &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets, &h->l_scan_scratch, &h->l_sort_scratch,
                             &h->l_block_keys, &h->l_vals, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_ranges,
                             &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state, &h->m_aabb, &h->m_slack, &h->m_scene_enc,
@@ -198,25 +200,24 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
 // `lists->ranges` stays null when the frame does not qualify (rays with different origins, no particle in view) or GRUT_GRT_NO_LISTS is set.
 static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_origin, const float* ray_direction,
                        GrtLists* out) {
-    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr};
     h->list_entries = 0;
+    h->log_lists = lists;   // the list scratch is about to be overwritten: a pending backward of an older forward walks the tree
     if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0) {
         const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
         if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
         GRUT_CHECK(h->l_flags.ensure(64));
         GRUT_CHECK(h->l_block_cones.ensure((size_t)nb * sizeof(GrtCone), 1.25f));
         GRUT_CHECK(h->l_super_cones.ensure((size_t)ns * sizeof(GrtCone), 1.25f));
-        GRUT_CHECK(h->l_inst_rel.ensure((size_t)N * 48, 1.25f));
+        GRUT_CHECK(h->l_inst_rel.ensure((size_t)N * 64, 1.25f));
         for (DeviceBuffer* b4 : {&h->l_key_bits, &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets})
             GRUT_CHECK(b4->ensure((size_t)N * 4, 1.25f));
-        GRUT_CHECK(h->l_bin_v.ensure((size_t)N * 16, 1.25f));
         GRUT_CHECK(h->l_scan_scratch.ensure(scan_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
         uint32_t* flag = h->l_flags.as<uint32_t>();
         uint32_t* dir_len = flag + 2;
         grt_launch_list_cones(s, P, ray_origin, ray_direction, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>());
         grt_launch_list_count(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
-                              h->l_inst_rel.as<float>(), h->l_key_bits.as<uint32_t>(), h->l_bin_v.as<float>(), h->l_counts.as<uint32_t>(),
-                              h->l_pidx.as<uint32_t>());
+                              h->l_inst_rel.as<float>(), h->l_key_bits.as<uint32_t>(), h->l_counts.as<uint32_t>(), h->l_pidx.as<uint32_t>());
         // particles in key order, then the offsets of their entries
         GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
         uint32_t *sorted_key = nullptr, *rank_to_particle = nullptr;
@@ -238,7 +239,7 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
             grt_launch_list_expand(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
                                    rank_to_particle, h->l_offsets.as<uint32_t>(), n, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>());
             int bits = 1;
-            while ((1u << bits) < nb) ++bits;
+            while ((1ull << bits) <= nb) ++bits;   // smallest b with (1 << b) > nb: the all-ones pad key never aliases a packet
             uint32_t *sorted_blocks = nullptr, *sorted_ids = nullptr;   // the payload of the sort is the particle: sorted payloads = the lists
             GRUT_CHECK(sort_pairs_u32(s, n, nullptr, 0, bits, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(), h->l_block_keys_tmp.as<uint32_t>(),
                                       h->l_vals_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_blocks, &sorted_ids));
@@ -246,7 +247,6 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
             grt_launch_list_ranges(s, n, nb, sorted_blocks, h->l_ranges.as<uint32_t>());
             lists.ranges = h->l_ranges.as<uint32_t>();
             lists.entries = sorted_ids;
-            lists.bin_v = h->l_bin_v.as<float>();
             lists.inst_rel = h->l_inst_rel.as<float>();
             lists.block_cones = h->l_block_cones.as<GrtCone>();
             lists.dir_len_enc = dir_len;
@@ -289,7 +289,7 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
         }
         if (h->log.capacity_chunks > want) want = h->log.capacity_chunks;
         if (const char* e = getenv("GRUT_GRT_LOG_CHUNKS")) want = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 1u;  // tests: force the overflow fallback
-        GRUT_CHECK(h->log_pool.ensure((size_t)want * 2 * kGrtMaxHits * 64 * 4));  // ids + box entry distances
+        GRUT_CHECK(h->log_pool.ensure((size_t)want * kGrtMaxHits * 64 * 4));
         GRUT_CHECK(h->log_table.ensure((size_t)blocks * kMaxRounds * 4, 1.25f));
         GRUT_CHECK(h->log_nbwd.ensure((size_t)P.W * P.H * 4, 1.25f));
         GRUT_CHECK(h->log_state.ensure(64));
@@ -320,6 +320,7 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     GrtBvh bvh = bvh_view(h);
     GrtLists lists;
     GRUT_CHECK(build_lists(h, s, P, bvh, ray_origin, ray_direction, &lists));
+    if (h->log_valid) h->log_lists = lists;   // the backward's exact rounds (flagged rays) scan the same lists
     grt_launch_trace_fwd(s, P, bvh, particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
                          out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters, log, lists);
     if (log.pool && !h->log_event_pending) {  // how much of the pool the frame used, read lazily by a later forward
@@ -332,6 +333,7 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
         GRUT_HIP(hipStreamSynchronize(s));
         fprintf(stderr, "[grut] grt fwd: nodes %llu, leaf tests %llu, processed %llu, rounds %llu, inserts %llu (rays %d)\n", h->work_host[0],
                 h->work_host[1], h->work_host[2], h->work_host[3], h->work_host[4], frame->width * frame->height);
+        fprintf(stderr, "[grut] grt fwd list batches fetched (64 entries each) %llu\n", h->work_host[12]);
         fprintf(stderr, "[grut] grt fwd leaf tests: passed %llu, distance out of range %llu, box missed %llu, beyond 3 sigma %llu; wave-level leaf visits %llu, of which ran the box test %llu, the insert chain %llu\n",
                 h->work_host[5], h->work_host[6], h->work_host[7], h->work_host[8], h->work_host[9], h->work_host[10], h->work_host[11]);
     }
@@ -376,10 +378,14 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
     const GrtTraceParams P = trace_params(h, *frame);
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
     GrtHitLog log = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // replay the hits the forward of THIS frame processed; any other backward (an older forward's, see log_matches) traverses again
-    if (h->log_matches(*frame, particle_density, ray_origin, ray_direction)) log = h->log;
+    if (h->log_matches(*frame, particle_density, ray_origin, ray_direction)) {
+        log = h->log;
+        lists = h->log_lists;
+    }
     grt_launch_trace_bwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, features, density, hit_distance,
-                         grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph, log);
+                         grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph, log, lists);
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
     return GRUT_OK;
@@ -390,9 +396,12 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
 int grt_build_mesh_bvh(GrtHandle* h, void* stream_, uint32_t num_vertices, const float* vertices, uint32_t num_faces, const int32_t* triangles) {
     GRUT_REQUIRE(h, "grt_build_mesh_bvh: null handle");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
-    h->mesh_faces = num_faces;
-    h->mesh_built = true;
-    if (num_faces == 0) return GRUT_OK;
+    h->mesh_built = false;   // raised again only when every stage below was enqueued
+    if (num_faces == 0) {
+        h->mesh_faces = 0;
+        h->mesh_built = true;
+        return GRUT_OK;
+    }
     GRUT_REQUIRE(vertices && triangles && num_vertices > 0, "grt_build_mesh_bvh: null buffer");
     const size_t n = num_faces;
     GRUT_CHECK(h->m_aabb.ensure(n * 24, 1.25f));
@@ -416,6 +425,8 @@ int grt_build_mesh_bvh(GrtHandle* h, void* stream_, uint32_t num_vertices, const
     GRUT_HIP(hipMemsetAsync(h->m_done.ptr, 0, n, s));
     grt_launch_refit(s, num_faces, h->m_aabb.as<float>(), h->m_slack.as<float>(), h->m_nodes.as<GrtNode>(), h->m_done.as<uint8_t>());
     GRUT_HIP(hipGetLastError());
+    h->mesh_faces = num_faces;
+    h->mesh_built = true;
     return GRUT_OK;
 }
 
@@ -483,6 +494,7 @@ int grt_stats(GrtHandle* h, GrtStats* stats) {
     stats->processed_hits = h->work_host[2];
     stats->list_entries = h->list_entries;
     stats->packet_tests = h->work_host[9];
+    stats->list_batches = h->work_host[12];
     if (h->built && h->N > 0) {
         if (!h->scene_host_valid) {  // synchronises with the build stream
             GRUT_HIP(hipMemcpyAsync(h->scene_host, h->scene.ptr, 24, hipMemcpyDeviceToHost, h->build_stream));

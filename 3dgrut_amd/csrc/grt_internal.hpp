@@ -60,8 +60,9 @@ struct GrtCone;
 struct GrtLists {
     const uint32_t* ranges;          // [blocks][2]: entries [first, last) of packet b (row-major 8x8 block index) in `entries`
     const uint32_t* entries;         // [I] particle of each entry; a packet's entries ascend in the particles' sort key
-    const float* bin_v;              // [N][4] {proxy centre - ray origin, sort key}: the key is a lower bound of the hit distance for every ray
-    const float* inst_rel;           // [N,12] {W rows, W (o - mu)}: the proxy-frame ray origin is the same for all rays, computed once
+    const float* inst_rel;           // [N,16], one 64-byte line per particle: {W rows, W (o - mu)} (the proxy-frame ray origin is the same for
+                                     // all rays, computed once) + {proxy centre - ray origin, sort key} (the key is a lower bound of the hit
+                                     // distance for every ray)
     const GrtCone* block_cones;      // [blocks] bounding cone of each packet's rays (list_round derives packet-specific bounds from it)
     const uint32_t* dir_len_enc;     // [2] float bits of the smallest / largest ray direction length of the frame
 };
@@ -72,10 +73,14 @@ struct GrtCone {   // bounding cone of the rays of an 8x8 packet / of a 64x64-pi
 // Log of the forward's processed hits, so that the backward replays them instead of traversing again.  One chunk =
 // the 16 x 64 particle ids a wave processed in one trace round ([slot][lane], 0xFFFFFFFF = not processed); a wave's
 // chunks are listed in `table[block][round]`.  `nbwd[ray]` = how many of a ray's processed hits the backward visits
-// (those with t < endT, referenceBwdOptix.cu:126-131).  If the pool or the table overflows, `state[1]` is raised and
-// the backward falls back to traversal.
+// (those with t < endT, referenceBwdOptix.cu:126-131), with bit 31 (kGrtShiftedRay) raised on the rays for which replaying is
+// NOT the reference's backward program: one of their processed hits has its proxy box entered beyond endT, so the backward's
+// trace (tmax = endT) is never offered it and all later rounds of 16 shift.  Those rays get their backward rounds re-derived
+// exactly (grt_trace_bwd_kernel), the others are replayed.  If the pool or the table overflows, `state[1]` is raised and
+// the backward re-derives every ray.
+constexpr uint32_t kGrtShiftedRay = 0x80000000u;
 struct GrtHitLog {
-    uint32_t* pool;      // [capacity_chunks][2][16][64]: particle ids, then the ray's entry distance into each proxy box
+    uint32_t* pool;      // [capacity_chunks][16][64] particle ids
     uint32_t* table;     // [num_blocks][max_rounds]
     uint32_t* nbwd;      // [W*H]
     uint32_t* state;     // [0] = chunks allocated, [1] = overflow flag
@@ -111,16 +116,17 @@ void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& 
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
                           float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters,
                           const GrtHitLog& log, const GrtLists& lists);
+// `lists`: the packet lists of the forward this backward belongs to (ranges == nullptr: none — the exact rounds walk the tree)
 void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
-                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log);
+                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log, const GrtLists& lists);
 
 // packet lists (GrtLists)
 void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* ray_o, const float* ray_d, uint32_t* uniform_origin,
                            uint32_t* dir_len_enc /* [2] */, GrtCone* block_cones, GrtCone* super_cones);
 void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                            const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, float* inst_rel, uint32_t* key_bits,
-                           float* bin_v, uint32_t* counts, uint32_t* particle_idx);
+                           uint32_t* counts, uint32_t* particle_idx);
 void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                             const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, const uint32_t* rank_to_particle,
                             const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals);

@@ -445,7 +445,7 @@ __device__ __forceinline__ PixelBlock pixel_block(int W, int H) {
 
 // one optixTrace: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in (t, particle)
 struct TraceCounters {
-    uint32_t nodes = 0, leaf_tests = 0, inserts = 0, rounds = 0, processed = 0, rej[4] = {0, 0, 0, 0}, wave_leaves = 0, wave_slab = 0, wave_insert = 0;
+    uint32_t nodes = 0, leaf_tests = 0, inserts = 0, rounds = 0, processed = 0, rej[4] = {0, 0, 0, 0}, wave_leaves = 0, wave_slab = 0, wave_insert = 0, batch_loads = 0;
 };
 
 // one optixTrace for every ray of the wave: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in
@@ -577,9 +577,9 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
     if (e < end) {
         x.id = L.entries[e];
         if (x.id != 0xFFFFFFFFu) {
-            const float4* rec = reinterpret_cast<const float4*>(L.inst_rel) + 3 * (size_t)x.id;
+            const float4* rec = reinterpret_cast<const float4*>(L.inst_rel) + 4 * (size_t)x.id;   // one 64-byte line per entry
             x.a = rec[0]; x.b = rec[1]; x.e = rec[2];
-            const float4 vk = reinterpret_cast<const float4*>(L.bin_v)[x.id];
+            const float4 vk = rec[3];
             const f3 v = mk3(vk.x, vk.y, vk.z);
             x.key = vk.w;
             packet_bounds(cone, v, dot(v, v), x.a, x.b, x.e.x, vk.w, 3.0e38f, dmin, dmax, x.lo, x.hi);
@@ -608,6 +608,7 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
     bool seen_live = false;
     uint32_t base = start & ~63u;
     ListEntry nxt = load_list_entry(L, cone, dmin, dmax, base + lane, le);
+    if (COUNT && lane == 0) tc.batch_loads++;
     while (base < le) {
         s_ent[lane * 3 + 0] = nxt.a; s_ent[lane * 3 + 1] = nxt.b; s_ent[lane * 3 + 2] = nxt.e;
         const uint32_t my_id = nxt.id;
@@ -615,6 +616,7 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
         __syncthreads();   // single-wave workgroup: orders the LDS hand-off
         const uint32_t bend = min(le, base + 64u);
         nxt = load_list_entry(L, cone, dmin, dmax, bend + lane, le);   // the following batch travels while this one is tested
+        if (COUNT && lane == 0 && bend < le) tc.batch_loads++;
         const bool mine = (base + (uint32_t)lane >= start) && (base + (uint32_t)lane < bend);
         const unsigned long long beyond = __ballot(mine && my_key > wmax_bound);           // a suffix of the batch (keys ascend)
         const unsigned long long dead = __ballot(!mine || my_hi < wmin_tmin);              // behind every ray's last hit (or not in the scan)
@@ -714,6 +716,20 @@ __device__ __forceinline__ f3 sh_radiance(const GrtTraceParams& P, const float* 
     const float* c = sph + (size_t)id * 3 * P.ncoef;
     const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
     f3 rad = mk3(0.f, 0.f, 0.f);
+    if (nact == 16 && (reinterpret_cast<uintptr_t>(sph) & 15u) == 0) {
+        // the full degree-3 row is 192 bytes at a 16-byte-aligned address: twelve 16-byte requests per lane instead of 48 dword
+        // loads (the per-hit gathers are the trace's vector-memory instruction stream), same order of accumulation
+        const float4* q = reinterpret_cast<const float4*>(c);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 q0 = q[3 * g], q1 = q[3 * g + 1], q2 = q[3 * g + 2];   // coefficients 4g .. 4g+3, rgb interleaved
+            rad.x = fmaf(b[4 * g], q0.x, rad.x); rad.y = fmaf(b[4 * g], q0.y, rad.y); rad.z = fmaf(b[4 * g], q0.z, rad.z);
+            rad.x = fmaf(b[4 * g + 1], q0.w, rad.x); rad.y = fmaf(b[4 * g + 1], q1.x, rad.y); rad.z = fmaf(b[4 * g + 1], q1.y, rad.z);
+            rad.x = fmaf(b[4 * g + 2], q1.z, rad.x); rad.y = fmaf(b[4 * g + 2], q1.w, rad.y); rad.z = fmaf(b[4 * g + 2], q2.x, rad.z);
+            rad.x = fmaf(b[4 * g + 3], q2.y, rad.x); rad.y = fmaf(b[4 * g + 3], q2.z, rad.y); rad.z = fmaf(b[4 * g + 3], q2.w, rad.z);
+        }
+        return rad + mk3(0.5f, 0.5f, 0.5f);
+    }
     for (int k = 0; k < nact; ++k) {
         rad.x = fmaf(b[k], c[3 * k], rad.x); rad.y = fmaf(b[k], c[3 * k + 1], rad.y); rad.z = fmaf(b[k], c[3 * k + 2], rad.z);
     }
@@ -801,6 +817,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
     bool running = in_image;
     const uint32_t block = pb.index;
     uint32_t round = 0, nproc = 0, nties = 0;  // processed hits, and how many of the last ones share t == tLast
+    float tnear_max = -3.0e38f;                // largest box-entry distance among the processed hits (hit log: see the end of the kernel)
 
     // one chunk of the hit log per (wave, trace round)
     auto open_chunk = [&]() -> uint32_t* {
@@ -813,15 +830,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         }
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
         round++;
-        return c != 0xFFFFFFFFu ? log.pool + (size_t)c * (2 * kGrtMaxHits * 64) + lane : nullptr;
+        return c != 0xFFFFFFFFu ? log.pool + (size_t)c * (kGrtMaxHits * 64) + lane : nullptr;
     };
     // one hit of a trace round: processHit (gaussianParticles.cuh:337-405) while the ray is above min_transmittance
     auto process_slot = [&](uint32_t* chunk, int slot, bool take, uint32_t id, float hit_t) {
         const bool process = take && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
         if (chunk) {
             chunk[slot * 64] = process ? id : 0xFFFFFFFFu;
-            // the backward's trace interval ends at endT: it does not see a proxy whose box the ray enters later
-            if (process) chunk[(kGrtMaxHits + slot) * 64] = __float_as_uint(candidate(bvh.inst + 12 * (size_t)id, r).tnear);
+            // the backward's trace interval ends at endT: it is not offered a proxy whose box the ray enters later (see below)
+            if (process) tnear_max = fmaxf(tnear_max, candidate(bvh.inst + 12 * (size_t)id, r).tnear);
         }
         if (process) {
             nproc++;
@@ -924,7 +941,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
     if (dbg_count) dbg_count[pix] = ndbg;
     if (log.pool) {  // the backward visits hits with t < endT = tLast + 1e-9: in fp32 that usually excludes the hits AT tLast
         const float endT = fminf(tLast, tExit) + eps;
-        log.nbwd[pix] = (tLast < endT) ? nproc : nproc - nties;
+        // The reference's backward program traces with tmax = endT (referenceBwdOptix.cu:123-131): a processed hit whose proxy box the
+        // ray ENTERS beyond endT is never offered to it, which moves every later k = 16 round boundary — its hit set is then no longer
+        // a prefix of the forward's.  Such rays (0.3 % of a frame) are flagged; the backward re-derives their rounds exactly
+        // (grt_trace_bwd_kernel) and replays the log for all the others, for which replaying IS the reference's program.
+        log.nbwd[pix] = ((tLast < endT) ? nproc : nproc - nties) | ((tnear_max > endT) ? kGrtShiftedRay : 0u);
     }
     if (COUNT) {  // work statistics for GrtStats (instrumented launches only)
         if (lane == 0) {   // per block: start and lifetime on the chip-wide 100 MHz counter, node visits (balance analysis, scripts/diag_grt_balance.py)
@@ -942,6 +963,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         atomicAdd(&counters[9], (unsigned long long)tc.wave_leaves);
         atomicAdd(&counters[10], (unsigned long long)tc.wave_slab);
         atomicAdd(&counters[11], (unsigned long long)tc.wave_insert);
+        atomicAdd(&counters[12], (unsigned long long)tc.batch_loads);
     }
 }
 
@@ -1060,25 +1082,33 @@ __device__ __forceinline__ void process_hit_bwd(const GrtTraceParams& P, const R
     st.rad = rad; st.T = T; st.depth = depth;
 }
 
-template <int DEG>
+// The reference's backward program, round by round.  Without a hit log it serves every ray (render.backward_hit_replay = false, or
+// a backward that is not the last logged forward's); with one it serves the rays the forward flagged (kGrtShiftedRay: the replay
+// would not be the reference's program for them) — or every ray if the log overflowed.  UNI: the frame's packet lists are at hand, a
+// round is a window scan of the packet's list (list_round: same candidate sets and order as the tree walk) — with one or two live
+// lanes per wave the window is those rays' own, a few dozen entries.
+template <int DEG, bool UNI>
 __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
                                                            const float* __restrict__ sph, const float* __restrict__ ray_o,
                                                            const float* __restrict__ ray_d, const float* __restrict__ in_rad,
                                                            const float* __restrict__ in_dns, const float* __restrict__ in_hit2,
                                                            const float* __restrict__ g_rad, const float* __restrict__ g_dns,
                                                            const float* __restrict__ g_hit, float* __restrict__ g_density12,
-                                                           float* __restrict__ g_sph, const uint32_t* __restrict__ log_state) {
-    __shared__ uint32_t s_stack[kGrtStackDepth];
-    __shared__ float s_hit_t[kGrtMaxHits * 64];
+                                                           float* __restrict__ g_sph, const uint32_t* __restrict__ log_state,
+                                                           const uint32_t* __restrict__ log_nbwd, GrtLists lists) {
+    __shared__ uint32_t s_stack[UNI ? 1 : kGrtStackDepth];
+    __shared__ float s_hit_t[kGrtMaxHits * 64];      // (UNI: a round's staged list entries live here while it is scanned)
     __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
-    // with a hit log this kernel is only the fallback for a frame whose log overflowed
-    if (log_state && log_state[1] == 0u) return;
+    static_assert(kGrtMaxHits * 64 * 4 >= 64 * 3 * 16, "the staged list entries must fit the parked hit distances");
     const int lane = threadIdx.x;
     const PixelBlock pb = pixel_block(P.W, P.H);
     if (!pb.inside) return;
     const int px = pb.bx * 8 + (lane & 7), py = pb.by * 8 + (lane >> 3);
     const bool in_image = (px < P.W) && (py < P.H);
     const size_t pix = in_image ? (size_t)py * P.W + px : 0;  // out-of-image lanes shadow pixel 0 and never write
+    bool running = in_image;
+    if (log_state && log_state[1] == 0u) running = running && (log_nbwd[pix] & kGrtShiftedRay) != 0u;   // the replay serves the rest
+    if (!__any(running)) return;
     const RayW r = make_ray(P, ray_o, ray_d, pix);
     float basis[16];
     sh_basis16(P.sph_degree, r.d, basis);
@@ -1100,15 +1130,27 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
     constexpr float eps = 1e-9f;
     float startT = fmaxf(0.f, tEnter - eps);
     const float endT = fminf(max_hit, tExit) + eps;
-    HitBuffer buf;
-    bool running = in_image;
+    uint32_t list_end = 0u, list_start = 0u;
+    GrtCone cone = {0.f, 0.f, 1.f, -1.f, 0.f, 1.f, 0.f, 0.f};
+    float dmin = 1.f, dmax = 1.f;
+    if (UNI) {
+        list_start = lists.ranges[2 * (size_t)pb.index];
+        list_end = lists.ranges[2 * (size_t)pb.index + 1];
+        cone = lists.block_cones[pb.index];
+        dmin = __uint_as_float(lists.dir_len_enc[0]); dmax = __uint_as_float(lists.dir_len_enc[1]);
+    }
     while (true) {
         running = running && (startT < endT);
         if (!__any(running)) break;
         TraceCounters tc;
-        trace_round<false>(bvh, r, startT + eps, endT, running, lane, s_stack, buf, tc);
-        if (buf.id[0] == 0xFFFFFFFFu) running = false;
-        buf.store(s_hit_t, s_hit_id, lane);
+        {
+            HitBuffer buf;
+            if (UNI) list_round<false, kGrtMaxHits>(lists, cone, dmin, dmax, list_end, list_start, r, startT + eps, endT, running, lane,
+                                                    reinterpret_cast<float4*>(s_hit_t), buf, tc);
+            else trace_round<false>(bvh, r, startT + eps, endT, running, lane, s_stack, buf, tc);
+            if (buf.id[0] == 0xFFFFFFFFu) running = false;
+            buf.store(s_hit_t, s_hit_id, lane);
+        }
 #pragma unroll 1
         for (int i = 0; i < kGrtMaxHits; ++i) {
             const uint32_t id = s_hit_id[i * 64 + lane];
@@ -1145,8 +1187,7 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
                                                             const float* __restrict__ in_rad, const float* __restrict__ in_dns,
                                                             const float* __restrict__ in_hit2, const float* __restrict__ g_rad,
                                                             const float* __restrict__ g_dns, const float* __restrict__ g_hit,
-                                                            float* __restrict__ g_density12, float* __restrict__ g_sph, GrtHitLog log,
-                                                            const float* __restrict__ scene) {
+                                                            float* __restrict__ g_density12, float* __restrict__ g_sph, GrtHitLog log) {
     // per (slot, lane): the two scalars every gradient term is built from, and which colour channels were not clamped
     // (dL = rad_grad * weight on those).  A round is worked off in two halves of kAggSlots = 8 hits (state walk, then aggregation):
     // 6.6 KB per wave instead of 13 (first version: 24.5) — LDS, not registers, capped the occupancy at three waves per SIMD.
@@ -1171,15 +1212,13 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
     f3 rad = mk3(0.f, 0.f, 0.f);
     float T = 1.f, depth = 0.f;
     uint32_t remaining = in_image ? log.nbwd[pix] : 0u;
-    float tEnter, tExit;
-    scene_interval(scene, r, tEnter, tExit);
-    const float endT = fminf(in_hit2[2 * pix + 1], tExit) + 1e-9f;
+    if (remaining & kGrtShiftedRay) remaining = 0u;   // the exact rounds of grt_trace_bwd_kernel serve this ray
     const uint32_t block = pb.index;
     for (uint32_t round = 0; round < log.max_rounds; ++round) {
         if (!__any(remaining > 0u)) break;
         const uint32_t c = log.table[(size_t)block * log.max_rounds + round];
         if (c == 0xFFFFFFFFu) break;
-        const uint32_t* chunk = log.pool + (size_t)c * (2 * kGrtMaxHits * 64) + lane;
+        const uint32_t* chunk = log.pool + (size_t)c * (kGrtMaxHits * 64) + lane;
       for (int half = 0; half < kGrtMaxHits; half += kAggSlots) {
         // ---- phase A: per-lane state walk ----
         uint32_t pending = 0u;
@@ -1192,8 +1231,7 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
             bool contributes = false;
             if (id != 0xFFFFFFFFu && remaining > 0u) {
                 remaining--;
-                const float tnear = __uint_as_float(chunk[(kGrtMaxHits + i) * 64]);
-                if (tnear <= endT) {
+                {
                     const Particle p = load_particle(density12, id);
                     const HitGeom g = hit_geometry<DEG>(P, p, r);
                     if (g.accept) {
@@ -1832,7 +1870,7 @@ __device__ __forceinline__ uint32_t bin_pairs(const GrtTraceParams& P, const Grt
 __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, GrtBvh bvh, const float* __restrict__ ray_o,
                                                              const uint32_t* __restrict__ flag, const uint32_t* __restrict__ dir_len_enc,
                                                              const GrtCone* __restrict__ block_cones, const GrtCone* __restrict__ super_cones,
-                                                             float* __restrict__ inst_rel, uint32_t* __restrict__ key_bits, float4* __restrict__ bin_v,
+                                                             float* __restrict__ inst_rel, uint32_t* __restrict__ key_bits,
                                                              uint32_t* __restrict__ counts, uint32_t* __restrict__ particle_idx) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -1851,11 +1889,13 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
     counts[i] = have ? n : 0u;   // (particle_idx, the payload of the key sort, is an iota: generated by the sort's first pass)
     key_bits[i] = (have && n) ? __float_as_uint(q.key) : 0xFFFFFFFFu;   // sort key (the sort consumes this array); particles no packet can reach go last
     if (!have) return;
-    bin_v[i] = make_float4(q.v.x, q.v.y, q.v.z, q.key);   // proxy centre relative to the ray origin + the sort key: what list_round needs per entry
-    // {W rows, W (o - mu)}: the proxy-frame ray origin with the very operations of the candidate test (candidate_abe<true> reads it)
+    // the frame-relative record of the particle, one 64-byte line: {W rows, W (o - mu)} — the proxy-frame ray origin with the very
+    // operations of the candidate test (candidate_abe<true> reads it) — and {proxy centre relative to the ray origin, sort key},
+    // what list_round needs per entry for its packet-specific bounds
     const f3 po = proxy_origin(a, b, e, o);
-    float4* out = reinterpret_cast<float4*>(inst_rel) + 3 * (size_t)i;
+    float4* out = reinterpret_cast<float4*>(inst_rel) + 4 * (size_t)i;
     out[0] = a; out[1] = b; out[2] = make_float4(e.x, po.x, po.y, po.z);
+    out[3] = make_float4(q.v.x, q.v.y, q.v.z, q.key);
 }
 // rank r of the key order writes its entries at [offsets[r-1], offsets[r]): (packet, expansion position) pairs, the position's particle
 // and its hit-distance bounds for that packet
@@ -1918,9 +1958,9 @@ void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* 
 }
 void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                            const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, float* inst_rel, uint32_t* key_bits,
-                           float* bin_v, uint32_t* counts, uint32_t* particle_idx) {
+                           uint32_t* counts, uint32_t* particle_idx) {
     hipLaunchKernelGGL(grt_list_count_kernel, dim3(div_up(bvh.N, 256)), dim3(256), 0, s, P, bvh, ray_o, uniform_origin, dir_len_enc, block_cones,
-                       super_cones, inst_rel, key_bits, reinterpret_cast<float4*>(bin_v), counts, particle_idx);
+                       super_cones, inst_rel, key_bits, counts, particle_idx);
 }
 void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                             const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, const uint32_t* rank_to_particle,
@@ -1953,16 +1993,19 @@ void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& 
 }
 void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
-                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log) {
+                          const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log, const GrtLists& lists) {
     const dim3 grid(pixel_block_grid(P.W, P.H));
-    if (log.pool) {  // replay the forward's hit log; the traversal kernel below then only runs if the log overflowed
+    if (log.pool) {  // replay the forward's hit log; the exact rounds below then serve the flagged rays (or all, if the log overflowed)
         GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_replay_bwd_kernel<D_>), grid, dim3(64), 0, s, P,
                                                          reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad,
-                                                         g_dns, g_hit, g_density12, g_sph, log, bvh.scene));
+                                                         g_dns, g_hit, g_density12, g_sph, log));
     }
-    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_>), grid, dim3(64), 0, s, P, bvh,
-                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns,
-                                                     g_hit, g_density12, g_sph, log.pool ? log.state : nullptr));
+#define GRT_BWD_LAUNCH(UNI_)                                                                                                                     \
+    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_, UNI_>), grid, dim3(64), 0, s, P, bvh,                            \
+                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns, \
+                                                     g_hit, g_density12, g_sph, log.pool ? log.state : nullptr, log.pool ? log.nbwd : nullptr, lists))
+    if (lists.ranges) { GRT_BWD_LAUNCH(true); } else { GRT_BWD_LAUNCH(false); }
+#undef GRT_BWD_LAUNCH
 }
 
 void grt_launch_mesh_aabb(hipStream_t s, uint32_t F, const float* vertices, const int32_t* triangles, float* aabb, float* slack,

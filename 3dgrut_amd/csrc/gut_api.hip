@@ -283,9 +283,12 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     }
     if (h->count_work) {
         // 4 counters + per-wave {lifetime, start, entries, list length} of the forward sweep + {lifetime, start} of the gradient sweep's tasks
-        GRUT_CHECK(h->work_counters.ensure(128 + (size_t)tiles * 2 * 32 + 8192 + ((size_t)h->tile_capacity / kGutSegment + tiles + 64) * 2 * 16, 1.2f));
+        // (the gradient sweep runs up to 2 (I / 256 + tiles) tasks and I is not known yet: the kernel drops the records that do not fit)
+        const size_t fwd_words = 16 + 4 * ((((size_t)tiles + 7) & ~(size_t)7) * 2);
+        GRUT_CHECK(h->work_counters.ensure(fwd_words * 8 + 8192 + ((size_t)h->tile_capacity / kGutSegment + tiles + 64) * 2 * 16, 1.2f));
         GRUT_HIP(hipMemsetAsync(h->work_counters.ptr, 0, h->work_counters.bytes, s));
         h->params.work = h->work_counters.as<unsigned long long>();
+        h->params.work_task_capacity = (uint32_t)((h->work_counters.bytes / 8 - fwd_words) / 2);
         h->work_pending = true;
     }
     const GutProjected proj = projected_view(h);

@@ -722,8 +722,10 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
     if (COUNT && P.work && lane == 0) {   // diagnostics (after the forward sweep's block of per-wave words): lifetime and start of this task
         const size_t gid = (size_t)atomicAdd(&P.work[8], 1ull);
         const size_t base = 16 + 4 * (size_t)(((num_tiles + 7u) & ~7u) * 2u) + 2 * gid;
-        P.work[base] = wall_clock64() - t_begin;
-        P.work[base + 1] = t_begin;
+        if (gid < P.work_task_capacity) {   // (the block was sized from an earlier frame's list length: records beyond it are dropped)
+            P.work[base] = wall_clock64() - t_begin;
+            P.work[base + 1] = t_begin;
+        }
     }
 }
 

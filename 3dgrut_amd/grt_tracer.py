@@ -74,7 +74,7 @@ class _GrtNative:
         f.num_particles, f.width, f.height = int(n), int(width), int(height)
         m = ray_to_world.detach().reshape(-1, 4, 4)[0]
         if m.is_cuda:   # the pose stays on the device (the reference copies it to the host per call: rayToWorld.cpu(), optixTracer.cpp:931)
-            md = m.to(torch.float32).contiguous()
+            md = m.to(torch.float32).clone()   # a snapshot, like the reference's .cpu(): the backward reads it again
             f.device_ray_to_world = md.data_ptr()
             f._keepalive = md   # the frame is kept for the backward: so is the matrix it points to
         else:
@@ -175,10 +175,10 @@ class Tracer:
         self._max_updates = int(_conf_get(render, "max_consecutive_bvh_update", 15))
         self._min_transmittance = float(_conf_get(render, "min_transmittance", 0.001))
         # render.backward_hit_replay (a key of this plugin, default true): the backward replays the hits the forward logged instead
-        # of traversing the BVH again (4x faster).  The two differ on ~0.3 % of the rays: where the end-of-ray clip of the
-        # reference's backward program (referenceBwdOptix.cu:123-128) removes a hit, every later k = 16 round boundary moves and a
-        # proxy the forward was never offered can be offered to the backward.  false = traverse again, exactly the reference's
-        # backward program (tests/parity_util.py: grt_full_parity checks both).
+        # of traversing the BVH again (4x faster).  Replaying is the reference's backward program except on ~0.3 % of the rays:
+        # where the end-of-ray clip of that program (referenceBwdOptix.cu:123-128) removes a hit, every later k = 16 round
+        # boundary moves.  The forward flags those rays and the backward re-derives their rounds exactly, so both settings give
+        # the reference's backward; false = re-derive every ray (tests/parity_util.py: grt_full_parity checks both).
         self._replay = bool(_conf_get(render, "backward_hit_replay", True))
         self.tracer_wrapper = _GrtNative(grt_config_from_conf(conf))
         self._fused_activations = fused_activations_requested(conf)

@@ -176,7 +176,7 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
         del os.environ["GRUT_GRT_COUNT"]
         st = tracer.tracer_wrapper.stats()
         work = {"wave_node_visits": int(st.nodes_visited), "leaf_tests": int(st.candidates), "processed_hits": int(st.processed_hits),
-                "list_entries": int(st.list_entries), "packet_tests": int(st.packet_tests)}
+                "list_entries": int(st.list_entries), "packet_tests": int(st.packet_tests), "list_batches": int(st.list_batches)}
         step()  # back to the uninstrumented kernels before timing
         tracer.timings
         torch.cuda.synchronize()
@@ -282,6 +282,25 @@ def bench_hybrid(args, dev, n, W, H, ms, emit=True):
     return result
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run (one rank per GPU, rendezvous on
+    127.0.0.1 at a free port) and pass its output through.  On a box with fewer than N GPUs the RCCL backend cannot place the ranks:
+    that is an error unless GRUT_BENCH_BACKEND=gloo asks for the plumbing check (ranks share the devices there are)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("GRUT_BENCH_BACKEND", "nccl") == "nccl":
+        raise SystemExit(f"--gpus {n}: only {have} GPU(s) visible (RCCL needs one device per rank; GRUT_BENCH_BACKEND=gloo runs the "
+                         f"multi-rank plumbing on the devices there are)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,8 +315,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started from a bare shell (`python bench.py --gpus N`): launch ourselves, one rank per GPU, and relay rank 0's line
+        return self_launch(args.gpus)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE={world})")
     # one rank per GPU; the modulo only matters for the plumbing check of the multi-rank path on a 1-GPU box
     # (GRUT_BENCH_BACKEND=gloo, two ranks sharing the device), never on a node with >= N GPUs
     dev_index = local_rank % max(torch.cuda.device_count(), 1)

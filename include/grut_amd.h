@@ -288,6 +288,7 @@ typedef struct GrtStats {
     float    scene_aabb[6];
     uint64_t list_entries;      /* last forward: entries of the packet lists (0: the tree walk served the frame — rays with different origins) */
     uint64_t packet_tests;      /* only in instrumented launches: candidate tests of whole packets (list entries / leaves tested by a wave) */
+    uint64_t list_batches;      /* only in instrumented launches: 64-entry batches of packet lists fetched by the trace rounds (one 64-byte record per entry) */
 } GrtStats;
 
 typedef struct GrtHandle GrtHandle;

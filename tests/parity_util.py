@@ -419,10 +419,12 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
         for kname, sl in GRAD_SLICES.items():
             stats[f"G_replay_grad_{kname}_rel_err"] = rel_err(gd2[:, sl], rdg2[:, sl])
         stats["G_replay_grad_sph_rel_err"] = rel_err(gs2, rsg2)
-        # (3) and what the default backward gives on the whole frame (round-shifted rays included): reported
+        # (3) the default backward on the whole frame, round-shifted rays included: the forward flags those rays and the backward
+        #     re-derives their rounds (grt_trace_bwd_kernel over the frame's packet lists), everything else is replayed
         gd3, gs3 = hip_grads(tr, g_rad, g_dns)
         for kname, sl in GRAD_SLICES.items():
             stats[f"G_replay_unmasked_grad_{kname}_rel_err"] = rel_err(gd3[:, sl], rdg[:, sl])
+        stats["G_replay_unmasked_grad_sph_rel_err"] = rel_err(gs3, rsg)
         stats["t_backward_s"] = time.time() - t0
     stats["t_total_s"] = time.time() - t_all
     if log:
@@ -447,5 +449,5 @@ def assert_grt_full_parity(stats):
             assert stats[f"G_replay_grad_{kname}_rel_err"] < 1e-3, (kname, stats)   # the default (replay) where it is the same program
     if "G_round_shift_rays" in stats:
         assert stats["G_round_shift_rays"] <= 5e-3 * stats["T_rays_compared"], stats
-        for kname in GRAD_SLICES:
-            assert stats[f"G_replay_unmasked_grad_{kname}_rel_err"] < 1e-2, (kname, stats)
+        for kname in list(GRAD_SLICES) + ["sph"]:   # BASELINE's bar for the DEFAULT configuration, no ray exempted but the compositing flips
+            assert stats[f"G_replay_unmasked_grad_{kname}_rel_err"] < 1e-3, (kname, stats)

@@ -139,6 +139,30 @@ def test_backward_replay_and_traversal_fallback_agree(monkeypatch):
     assert np.abs(b[0]).max() > 0
 
 
+@pytest.mark.parametrize("no_lists", [False, True])
+def test_default_backward_is_the_reference_backward_program(monkeypatch, no_lists):
+    """The default backward replays the forward's hit log except on the rays the forward flags (a processed hit whose proxy box
+    the ray enters beyond endT is never offered to the reference's backward trace, which shifts its later rounds of 16,
+    referenceBwdOptix.cu:123-131); those get their rounds re-derived — over the frame's packet lists, or by the tree walk when there
+    are none.  On a scene with such rays (long, thin, overlapping proxies) the result must be the exact-traversal backward's."""
+    if no_lists:
+        monkeypatch.setenv("GRUT_GRT_NO_LISTS", "1")
+    scene = _scene(2500, 64, 48, 0.09)
+    rng = np.random.default_rng(11)
+    g_rad = rng.normal(size=(48, 64, 3)).astype(np.float32)
+    g_dns = rng.normal(size=(48, 64, 1)).astype(np.float32)
+    cfg = oracle.default_grt_config()
+    ora = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"])
+    ora["rays"] = (ora["rays"][0].reshape(1, -1, 3), ora["rays"][1].reshape(1, -1, 3))
+    shifted = np.zeros(48 * 64, np.uint8)
+    oracle.grt_backward(cfg, 3, 1e-3, ora, g_rad.reshape(1, -1, 3), g_dns.reshape(1, -1, 1), np.zeros((1, 48 * 64, 1), np.float32), round_shift=shifted)
+    assert shifted.sum() >= 3, "the scene must contain round-shifted rays for this test to mean anything"
+    default = _render(scene, g_rad, g_dns)["grads"]
+    exact = _render(scene, g_rad, g_dns, backward_hit_replay=False)["grads"]
+    assert rel_err(default[0], exact[0]) < 2e-5 and rel_err(default[1], exact[1]) < 2e-5   # same hits in the same rounds; atomics order differs
+    assert np.abs(exact[0]).max() > 0
+
+
 def test_refit_update_matches_full_rebuild():
     """rebuild=False keeps the tree topology and refits the boxes (OPTIX_BUILD_OPERATION_UPDATE); results must not change."""
     import torch

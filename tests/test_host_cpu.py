@@ -155,3 +155,17 @@ def test_grt_configuration_defaults_and_unsupported_pipelines():
     for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "icosahedron"}, {"particle_feature_half": True}):
         with pytest.raises(NotImplementedError):
             grt.grt_config_from_conf({"render": bad})
+
+
+def test_bench_launches_itself_for_multi_gpu_runs():
+    """`python bench.py --gpus N` from a bare shell must start its own ranks (torch.distributed.run); without enough devices for RCCL it
+    says so instead of dying in a launcher it never started."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GRUT_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout), r.stderr[-500:]
