@@ -91,6 +91,7 @@ class GrtStats(C.Structure):
         ("num_particles", C.c_uint32), ("num_nodes", C.c_uint32), ("nodes_visited", C.c_uint64),
         ("candidates", C.c_uint64), ("processed_hits", C.c_uint64), ("scene_aabb", C.c_float * 6),
         ("list_entries", C.c_uint64), ("packet_tests", C.c_uint64), ("list_batches", C.c_uint64),
+        ("bwd_rederived_rays", C.c_uint32), ("bwd_premise_rays", C.c_uint32),
     ]
 
 
@@ -126,7 +127,7 @@ EXPORTED_SYMBOLS = [
     "gut_debug_fetch", "gut_debug_fetch_work", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats", "grt_debug_fetch_work",
-    "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_build_mesh_bvh", "grt_trace_hybrid",
+    "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_debug_backward_signature", "grt_build_mesh_bvh", "grt_trace_hybrid",
     "grut_selective_adam_update", "grut_pack_particles", "grut_unpack_particle_grads", "grut_activate_pack", "grut_activate_pack_backward",
     "grut_last_error", "grut_abi_version",
 ]
@@ -187,6 +188,8 @@ def _declare(lib):
     lib.grt_debug_forward_hits.restype = C.c_int
     lib.grt_debug_fetch_instances.argtypes = [C.c_void_p, vp, fp]
     lib.grt_debug_fetch_instances.restype = C.c_int
+    lib.grt_debug_backward_signature.argtypes = [C.c_void_p, up, up]
+    lib.grt_debug_backward_signature.restype = C.c_int
     lib.grt_build_mesh_bvh.argtypes = [C.c_void_p, vp, C.c_uint32, fp, C.c_uint32, ip]
     lib.grt_build_mesh_bvh.restype = C.c_int
     lib.grt_trace_hybrid.argtypes = [C.c_void_p, vp, C.POINTER(GrtFrame), fp, fp, fp, fp, fp, C.POINTER(GrtMesh), C.POINTER(GrtHybridOptions), fp, fp, fp, up]

@@ -2,6 +2,7 @@
 // Plays the role of OptixTracer (threedgrt_tracer/src/optixTracer.cpp:616-1031: buildBVH / trace / traceBwd) without
 // OptiX and without libtorch: all I/O buffers belong to the caller, the handle owns the BVH and scratch.
 #include <cstdlib>
+#include <vector>
 
 #include "grt_internal.hpp"
 
@@ -51,6 +52,8 @@ struct GrtHandle {
         l_scan_scratch, l_sort_scratch, l_block_keys, l_vals, l_block_keys_tmp, l_vals_tmp, l_ranges;
     uint32_t* l_host = nullptr;          // pinned: {entries, uniform-origin flag}
     uint64_t list_entries = 0;           // of the last forward (0: the BVH walk served it)
+    unsigned long long* dbg_bwd_sig = nullptr;   // grt_debug_backward_signature: caller DEVICE buffers the next backward fills
+    uint32_t* dbg_bwd_cnt = nullptr;
     DeviceBuffer work_counters;  // instrumented launches (GRUT_GRT_COUNT=1): nodes, leaf tests, processed hits, rounds, inserts
     unsigned long long work_host[16] = {};
 };
@@ -289,13 +292,13 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
         }
         if (h->log.capacity_chunks > want) want = h->log.capacity_chunks;
         if (const char* e = getenv("GRUT_GRT_LOG_CHUNKS")) want = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 1u;  // tests: force the overflow fallback
-        GRUT_CHECK(h->log_pool.ensure((size_t)want * kGrtMaxHits * 64 * 4));
+        GRUT_CHECK(h->log_pool.ensure((size_t)want * kGrtLogSlots * 64 * 4));
         GRUT_CHECK(h->log_table.ensure((size_t)blocks * kMaxRounds * 4, 1.25f));
         GRUT_CHECK(h->log_nbwd.ensure((size_t)P.W * P.H * 4, 1.25f));
         GRUT_CHECK(h->log_state.ensure(64));
         h->log.pool = h->log_pool.as<uint32_t>();
         h->log.table = h->log_table.as<uint32_t>();
-        h->log.nbwd = h->log_nbwd.as<uint32_t>();
+        h->log.ray_flags = h->log_nbwd.as<uint32_t>();
         h->log.state = h->log_state.as<uint32_t>();
         h->log.capacity_chunks = want;
         h->log.max_rounds = kMaxRounds;
@@ -375,7 +378,9 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
     if (h->N == 0) return GRUT_OK;
     GRUT_REQUIRE(particle_density && particle_sph && ray_origin && ray_direction && features && density && hit_distance && grad_features &&
                      grad_density && grad_particle_density && grad_particle_sph, "grt_backward: null buffer");
-    const GrtTraceParams P = trace_params(h, *frame);
+    GrtTraceParams P = trace_params(h, *frame);
+    P.bwd_sig = h->dbg_bwd_sig;
+    P.bwd_cnt = h->dbg_bwd_cnt;
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
     GrtHitLog log = {nullptr, nullptr, nullptr, nullptr, 0, 0};
     GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -383,6 +388,17 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
     if (h->log_matches(*frame, particle_density, ray_origin, ray_direction)) {
         log = h->log;
         lists = h->log_lists;
+    }
+    if (log.pool && getenv("GRUT_GRT_COUNT")) {   // development aid: how many rays the forward flagged for exact backward rounds
+        std::vector<uint32_t> nb((size_t)P.W * P.H);
+        uint32_t st[2] = {0, 0};
+        GRUT_HIP(hipMemcpyAsync(nb.data(), log.ray_flags, nb.size() * 4, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipMemcpyAsync(st, log.state, 8, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipStreamSynchronize(s));
+        size_t flagged = 0;
+        for (uint32_t v : nb) flagged += (v >> 31);
+        fprintf(stderr, "[grut] grt bwd: %zu of %zu rays re-derive their rounds (log chunks %u, overflow %u, lists %s)\n", flagged, nb.size(), st[0], st[1],
+                lists.ranges ? "yes" : "no");
     }
     grt_launch_trace_bwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, features, density, hit_distance,
                          grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph, log, lists);
@@ -469,6 +485,13 @@ int grt_trace_hybrid(GrtHandle* h, void* stream_, const GrtFrame* frame, const f
     return GRUT_OK;
 }
 
+int grt_debug_backward_signature(GrtHandle* h, unsigned long long* ray_signature, uint32_t* ray_hit_count) {
+    GRUT_REQUIRE(h && ((ray_signature != nullptr) == (ray_hit_count != nullptr)), "grt_debug_backward_signature: both buffers or none");
+    h->dbg_bwd_sig = ray_signature;
+    h->dbg_bwd_cnt = ray_hit_count;
+    return GRUT_OK;
+}
+
 int grt_timings(GrtHandle* h, float* forward_ms, float* backward_ms, float* build_ms) {
     GRUT_REQUIRE(h, "grt_timings: null handle");
     if (forward_ms) *forward_ms = h->fwd_timer.collect();
@@ -495,6 +518,18 @@ int grt_stats(GrtHandle* h, GrtStats* stats) {
     stats->list_entries = h->list_entries;
     stats->packet_tests = h->work_host[9];
     stats->list_batches = h->work_host[12];
+    if (h->log_valid && h->log.pool) {   // (synchronises: a diagnostics call)
+        const size_t rays = (size_t)h->log_W * h->log_H;
+        std::vector<uint32_t> flags(rays);
+        uint32_t st[4] = {0, 0, 0, 0};
+        GRUT_HIP(hipDeviceSynchronize());
+        GRUT_HIP(hipMemcpy(flags.data(), h->log.ray_flags, rays * 4, hipMemcpyDeviceToHost));
+        GRUT_HIP(hipMemcpy(st, h->log.state, 16, hipMemcpyDeviceToHost));
+        uint32_t n = 0;
+        for (uint32_t v : flags) n += v >> 31;
+        stats->bwd_rederived_rays = n;
+        stats->bwd_premise_rays = st[2];
+    }
     if (h->built && h->N > 0) {
         if (!h->scene_host_valid) {  // synchronises with the build stream
             GRUT_HIP(hipMemcpyAsync(h->scene_host, h->scene.ptr, 24, hipMemcpyDeviceToHost, h->build_stream));

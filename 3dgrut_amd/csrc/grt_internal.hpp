@@ -21,10 +21,6 @@ static_assert(sizeof(GrtNode) == 64, "GrtNode must be 64 bytes");
 constexpr uint32_t kGrtLeafBit = 0x80000000u;
 constexpr uint32_t kGrtNoChild = 0xFFFFFFFFu;
 constexpr int kGrtMaxHits = 16;       // PipelineParameters::MaxNumHitPerTrace (pipelineParameters.h:83)
-#ifndef GRT_GATHER
-#define GRT_GATHER 16
-#endif
-constexpr int kGrtGather = GRT_GATHER;        // forward: candidates per traversal (16 = one trace round, 32 = two rounds from one walk)
 constexpr int kGrtMaxDepth = 64;      // a radix tree over 30+32-bit keys is at most 62 levels deep
 constexpr int kGrtStackDepth = 3 * kGrtMaxDepth;   // the wide walk (trace_round4) parks up to 3 nodes per level
 
@@ -48,6 +44,10 @@ struct GrtTraceParams {
     float ray_to_world[12];
     const float* ray_to_world_dev;   // optional: the same matrix in device memory (GrtFrame::device_ray_to_world), used instead when set
     uint32_t dbg_cap;
+    // optional (grt_debug_backward_signature): per ray, how many hits the backward differentiated and an order-independent
+    // signature of which particles they were — the parity tests compare the replayed backward with the re-derived one ray by ray
+    unsigned long long* bwd_sig;
+    uint32_t* bwd_cnt;
 };
 
 // Candidate lists of the forward for frames whose rays all start at ONE point (every pinhole / fisheye camera) — see "3DGRT: packet
@@ -70,19 +70,25 @@ struct GrtCone {   // bounding cone of the rays of an 8x8 packet / of a 64x64-pi
     float ax, ay, az, cos_t, sin_t, valid, pad0, pad1;
 };
 
-// Log of the forward's processed hits, so that the backward replays them instead of traversing again.  One chunk =
-// the 16 x 64 particle ids a wave processed in one trace round ([slot][lane], 0xFFFFFFFF = not processed); a wave's
-// chunks are listed in `table[block][round]`.  `nbwd[ray]` = how many of a ray's processed hits the backward visits
-// (those with t < endT, referenceBwdOptix.cu:126-131), with bit 31 (kGrtShiftedRay) raised on the rays for which replaying is
-// NOT the reference's backward program: one of their processed hits has its proxy box entered beyond endT, so the backward's
-// trace (tmax = endT) is never offered it and all later rounds of 16 shift.  Those rays get their backward rounds re-derived
-// exactly (grt_trace_bwd_kernel), the others are replayed.  If the pool or the table overflows, `state[1]` is raised and
-// the backward re-derives every ray.
-constexpr uint32_t kGrtShiftedRay = 0x80000000u;
+// Log of a training forward, so that the backward replays the hits instead of traversing again.  One chunk = what a wave met in one
+// trace round, [slot][lane]: the (up to 16) candidates of each ray's round and the round's ghosts — candidates the round was not
+// offered because the ray had left their proxy box before the round's tmin — merged in (hit distance, particle) order; ghosts carry
+// kGrtGhostBit, unused slots are 0xFFFFFFFF.  A wave's chunks are listed in `table[block][round]`.
+// Why ghosts: the reference's backward program (referenceBwdOptix.cu:103-170) traces again with tmax = endT, the last hit distance.
+// Hits whose box the ray enters beyond endT are not offered to it (at 1 M particles / 800x800 that happens on 70 % of the rays), its
+// rounds of 16 therefore end elsewhere than the forward's, and with other round boundaries other candidates pass the box-exit test
+// (tfar >= tmin): processed hits drop out and ghosts come in (8 % of the rays at that size).  Walking a chunk sequence front to back
+// with the backward's own intervals (grt_replay_bwd_kernel) reproduces that program exactly: every candidate it can be offered is a
+// processed hit or a ghost of the forward.  `ray_flags[ray]` = kGrtRederiveRay where a round saw more ghosts than a chunk holds:
+// those rays (and every ray if the pool or the table overflowed: `state[1]`) get their rounds re-derived by grt_trace_bwd_kernel.
+constexpr int kGrtMaxGhosts = 8;
+constexpr int kGrtLogSlots = kGrtMaxHits + kGrtMaxGhosts;
+constexpr uint32_t kGrtGhostBit = 0x80000000u;
+constexpr uint32_t kGrtRederiveRay = 0x80000000u;
 struct GrtHitLog {
-    uint32_t* pool;      // [capacity_chunks][16][64] particle ids
+    uint32_t* pool;      // [capacity_chunks][kGrtLogSlots][64]
     uint32_t* table;     // [num_blocks][max_rounds]
-    uint32_t* nbwd;      // [W*H]
+    uint32_t* ray_flags; // [W*H]
     uint32_t* state;     // [0] = chunks allocated, [1] = overflow flag
     uint32_t capacity_chunks, max_rounds;
 };

@@ -298,14 +298,15 @@ __device__ __forceinline__ float4 ld4(const float4* p, int k) { return p[k]; }
 __device__ __forceinline__ float4 ld4(const cfloat4* p, int k) { const f4v v = p[k]; return make_float4(v.x, v.y, v.z, v.w); }
 // Q = const float4 (per-lane record) or cfloat4 (wave-uniform record of a read-only array: fetched once per wave)
 // REL: the record is a frame-relative one {W rows, W (o - mu)} (GrtBvh::inst_rel) — the proxy-frame origin is read, not computed
-template <typename Q, bool REL = false>
+template <typename Q, bool REL = false, bool TIES = false>
 __device__ __forceinline__ Cand candidate_q(const Q* __restrict__ rec, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi);
 __device__ __forceinline__ Cand candidate(const float* __restrict__ inst, const RayW& r, float t_lo = -3.0e38f, float t_hi = 3.0e38f,
                                           uint32_t id = 0u, uint32_t id_hi = 0xFFFFFFFFu) {
     return candidate_q(reinterpret_cast<const float4*>(inst), r, t_lo, t_hi, id, id_hi);
 }
+template <bool TIES = false>
 __device__ __forceinline__ Cand candidate_uniform(const float* inst, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
-    return candidate_q(reinterpret_cast<const cfloat4*>(reinterpret_cast<uintptr_t>(inst)), r, t_lo, t_hi, id, id_hi);
+    return candidate_q<cfloat4, false, TIES>(reinterpret_cast<const cfloat4*>(reinterpret_cast<uintptr_t>(inst)), r, t_lo, t_hi, id, id_hi);
 }
 // proxy-frame origin W (o - mu) of one record: the ONE definition shared by the candidate test and the frame-relative tables
 __device__ __forceinline__ f3 proxy_origin(const float4& a, const float4& b, const float4& e, f3 o) {
@@ -313,14 +314,15 @@ __device__ __forceinline__ f3 proxy_origin(const float4& a, const float4& b, con
     const float dlx = o.x - e.y, dly = o.y - e.z, dlz = o.z - e.w;
     return mk3(a.x * dlx + a.y * dly + a.z * dlz, a.w * dlx + b.x * dly + b.y * dlz, b.z * dlx + b.w * dly + e.x * dlz);
 }
-template <bool REL>
+// (TIES: candidates AT t_lo are evaluated too — t_lo is then the ray's last hit distance, see GhostLog)
+template <bool REL, bool TIES = false>
 __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi);
-template <typename Q, bool REL>
+template <typename Q, bool REL, bool TIES>
 __device__ __forceinline__ Cand candidate_q(const Q* __restrict__ rec, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
     const float4 a = ld4(rec, 0), b = ld4(rec, 1), e = ld4(rec, 2);
-    return candidate_abe<REL>(a, b, e, r, t_lo, t_hi, id, id_hi);
+    return candidate_abe<REL, TIES>(a, b, e, r, t_lo, t_hi, id, id_hi);
 }
-template <bool REL>
+template <bool REL, bool TIES>
 __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
 #pragma clang fp contract(off)
     Cand c;
@@ -335,7 +337,7 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     const float dd = pdx * pdx + pdy * pdy + pdz * pdz;
     const float denominator = 1.f / dd;
     c.t = numerator * denominator;
-    if (!(c.t > t_lo) || !((c.t < t_hi) || (c.t == t_hi && id < id_hi))) return c;
+    if (!(TIES ? (c.t >= t_lo) : (c.t > t_lo)) || !((c.t < t_hi) || (c.t == t_hi && id < id_hi))) return c;
     // slab test of the unit box; min / max are plain comparisons (a < b ? a : b), NaN-propagating like the checker's
     const float ax0 = (-1.f - pox) / pdx, ax1 = (1.f - pox) / pdx;
     const float ay0 = (-1.f - poy) / pdy, ay1 = (1.f - poy) / pdy;
@@ -443,6 +445,32 @@ __device__ __forceinline__ PixelBlock pixel_block(int W, int H) {
     return pb;
 }
 
+// "Ghosts" of a trace round (training forwards only): candidates the round was NOT offered because the ray had left their proxy box
+// before the round's tmin (tfar < tmin) although their hit distance lies in the round's range.  The reference's backward program
+// traces with other round boundaries (its rounds skip the hits whose box the ray enters beyond endT, referenceBwdOptix.cu:123-131), so a
+// ghost of the forward can be a hit of the backward: the forward logs them next to the processed hits (GrtHitLog) and the replay decides
+// with the backward's own intervals.  Per lane: up to kGrtMaxGhosts per round, parked in LDS ([slot][lane]); `n` counts all that were
+// seen (n > kGrtMaxGhosts: the ray is flagged and its backward rounds are re-derived instead).
+// Only ghosts the backward can possibly be offered are kept: its trace that reaches a ghost of forward round q starts no earlier than
+// forward round q - 2 did unless more than 16 hits of rounds q - 2 and q - 1 are missing from its own sequence, so a ghost whose box the
+// ray left before THAT round's tmin (`min_tfar`) stays a ghost (the replay checks the premise per ray and counts the rays it fails for:
+// GrtHitLog::state[2], expected 0).
+// A second kind of ghost: a candidate whose hit distance EQUALS that of the 16th hit of a full round (larger particle index) is the 17th
+// of that round and fails t > tmin in the next one — skipped for good by the forward, but not necessarily by a backward whose rounds
+// end elsewhere.  The round after (tie_t, tie_id) = the last processed hit logs those as its first entries.
+struct GhostLog {
+    uint32_t* id;    // LDS [kGrtMaxGhosts][64] + lane
+    uint32_t n;
+    float min_tfar;
+    float tie_t;
+    uint32_t tie_id;
+    __device__ __forceinline__ void add(float tfar, uint32_t gid) {
+        if (!(tfar >= min_tfar)) return;
+        if (n < (uint32_t)kGrtMaxGhosts) id[n * 64] = gid;
+        ++n;
+    }
+};
+
 // one optixTrace: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in (t, particle)
 struct TraceCounters {
     uint32_t nodes = 0, leaf_tests = 0, inserts = 0, rounds = 0, processed = 0, rej[4] = {0, 0, 0, 0}, wave_leaves = 0, wave_slab = 0, wave_insert = 0, batch_loads = 0;
@@ -455,9 +483,10 @@ struct TraceCounters {
 // block are coherent, so the union of their paths is barely larger than one ray's path: the node fetches, the stack
 // traffic and the divergence of 64 independent walks collapse into one.  Pruning stays per lane (its own interval and
 // its own current 16th-nearest distance); lanes that are done (`active` false) just ride along.
-template <bool COUNT, int G = kGrtMaxHits>
+template <bool COUNT, int G = kGrtMaxHits, bool GHOST = false>
 __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, float tmin, float tmax, bool active, int lane,
-                                            uint32_t* __restrict__ stack /* [kGrtStackDepth] per wave */, HitBufferT<G>& buf, TraceCounters& tc) {
+                                            uint32_t* __restrict__ stack /* [kGrtStackDepth] per wave */, HitBufferT<G>& buf, TraceCounters& tc,
+                                            GhostLog* ghosts = nullptr) {
     buf.clear();
     if (COUNT && active) tc.rounds++;
     if (!__any(active)) return;
@@ -481,16 +510,21 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
         bool ok0, ok1;
         boxes_hit(q0, q1, q2, r, tn0, tf0, tn1, tf1, ok0, ok1);
         const float bound = fminf(tmax, buf.t[G - 1]);
-        const bool h0 = active && (c0 != kGrtNoChild) && ok0 && (tf0 >= tmin) && (tn0 <= tmax) && (tn0 - q3.z <= bound);
-        const bool h1 = active && (c1 != kGrtNoChild) && ok1 && (tf1 >= tmin) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
+        // (GHOST: the walk must also reach the proxies whose box the ray has left before tmin, as far back as the ghosts that are kept)
+        const float exit_min = GHOST ? fminf(tmin, ghosts->min_tfar) : tmin;
+        const bool h0 = active && (c0 != kGrtNoChild) && ok0 && (tf0 >= exit_min) && (tn0 <= tmax) && (tn0 - q3.z <= bound);
+        const bool h1 = active && (c1 != kGrtNoChild) && ok1 && (tf1 >= exit_min) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
         bool a0 = __any(h0), a1 = __any(h1);
         // leaves are tested on the spot, by the lanes whose ray touches the leaf's box
         auto leaf = [&](uint32_t c, bool h) {
             const uint32_t id = c & ~kGrtLeafBit;
             if (h) {
-                const Cand cd = candidate_uniform(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
-                const bool ins = cd.ok && (cd.t > tmin) && (cd.t < tmax) && (cd.tfar >= tmin) && (cd.tnear <= tmax) &&
-                                 hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
+                const Cand cd = GHOST ? candidate_uniform<true>(bvh.inst + 12 * (size_t)id, r, ghosts->tie_t, buf.t[G - 1], id, buf.id[G - 1])
+                                      : candidate_uniform(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
+                const bool reach = cd.ok && (cd.t < tmax) && (cd.tnear <= tmax) && hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
+                const bool in_range = reach && (cd.t > tmin);
+                const bool ins = in_range && (cd.tfar >= tmin);
+                if (GHOST && ((in_range && !ins) || (reach && !in_range && hit_less(ghosts->tie_t, ghosts->tie_id, cd.t, id)))) ghosts->add(cd.tfar, id);
                 if (COUNT) {   // per lane: outcome of the test; per wave (first active lane): did the box part / the insert chain run at all
                     tc.leaf_tests++; tc.rej[cd.ok ? 0 : cd.why]++;
                     const unsigned long long ms = __ballot(cd.ok || cd.why != 1), mi = __ballot(ins);
@@ -596,10 +630,10 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
 // 22.6 vs 20.0 ms).  The scan starts at `start` (everything before it is dead for every ray for good: hi < the rays' last hit
 // distances, which only grow) and ends with the first key beyond the bound (keys are lower bounds of lo: nothing that follows can
 // enter a buffer).
-template <bool COUNT, int G>
+template <bool COUNT, int G, bool GHOST = false>
 __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& cone, float dmin, float dmax, uint32_t le, uint32_t& start, const RayW& r,
                                            float tmin, float tmax, bool active, int lane, float4* __restrict__ s_ent /* [64][3] */, HitBufferT<G>& buf,
-                                           TraceCounters& tc) {
+                                           TraceCounters& tc, GhostLog* ghosts = nullptr) {
     buf.clear();
     if (COUNT && active) tc.rounds++;
     if (!__any(active)) return;
@@ -634,8 +668,12 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
             const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
             if (COUNT && lane == 0) tc.wave_leaves++;
             if (active) {
-                const Cand cd = candidate_abe<true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
-                const bool ins = cd.ok && (cd.t > tmin) && (cd.t < tmax) && (cd.tfar >= tmin) && (cd.tnear <= tmax) && hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
+                const Cand cd = GHOST ? candidate_abe<true, true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, ghosts->tie_t, buf.t[G - 1], id, buf.id[G - 1])
+                                      : candidate_abe<true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
+                const bool reach = cd.ok && (cd.t < tmax) && (cd.tnear <= tmax) && hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
+                const bool in_range = reach && (cd.t > tmin);
+                const bool ins = in_range && (cd.tfar >= tmin);
+                if (GHOST && ((in_range && !ins) || (reach && !in_range && hit_less(ghosts->tie_t, ghosts->tie_id, cd.t, id)))) ghosts->add(cd.tfar, id);
                 if (COUNT) {
                     tc.leaf_tests++; tc.rej[cd.ok ? 0 : cd.why]++;
                     const unsigned long long ms = __ballot(cd.ok || cd.why != 1), mi = __ballot(ins);
@@ -763,7 +801,7 @@ __device__ __forceinline__ HitGeom hit_geometry(const GrtTraceParams& P, const P
 // ---------------------------------------------------------------------------------------------
 // forward: __raygen__rg of referenceOptix.cu:103-186
 // ---------------------------------------------------------------------------------------------
-template <int DEG, bool COUNT, bool UNI>
+template <int DEG, bool COUNT, bool UNI, bool LOG>
 // 4 waves per SIMD (128 VGPRs): the walk is a chain of dependent fetches, a fourth wave hides more of it than the few
 // spilled registers cost (measured: 65.8 -> 60.2 ms at 1M particles, 800x800; 5 waves: 69.9 ms)
 #ifndef GRT_FWD_WAVES
@@ -777,11 +815,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                                                            int32_t* __restrict__ visibility, uint32_t* __restrict__ dbg_ids,
                                                            uint32_t* __restrict__ dbg_count, unsigned long long* __restrict__ counters,
                                                            GrtHitLog log, GrtLists lists) {
-    constexpr int kGather = kGrtGather;   // candidates gathered per traversal: one or two trace rounds of the reference
     __shared__ uint32_t s_stack[UNI ? 1 : kGrtStackDepth];
-    __shared__ float s_hit_t[kGather * 64];      // (UNI: the round's staged list entries live here while it is scanned, float4 s_ent[64][3])
-    __shared__ uint32_t s_hit_id[kGather * 64];
-    static_assert(kGather * 64 * 4 >= 64 * 3 * 16, "the staged list entries must fit the parked hit distances");
+    __shared__ float s_hit_t[kGrtMaxHits * 64];      // (UNI: the round's staged list entries live here while it is scanned, float4 s_ent[64][3])
+    __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
+    static_assert(kGrtMaxHits * 64 * 4 >= 64 * 3 * 16, "the staged list entries must fit the parked hit distances");
     float4* s_ent = reinterpret_cast<float4*>(s_hit_t);
     TraceCounters tc;
     const int lane = threadIdx.x;
@@ -816,12 +853,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
     uint32_t ndbg = 0;
     bool running = in_image;
     const uint32_t block = pb.index;
-    uint32_t round = 0, nproc = 0, nties = 0;  // processed hits, and how many of the last ones share t == tLast
-    float tnear_max = -3.0e38f;                // largest box-entry distance among the processed hits (hit log: see the end of the kernel)
+    uint32_t round = 0;
+    bool ghost_overflow = false;   // LOG: a round of this ray saw more ghosts than a chunk holds
+    float tmin_prev1 = -3.0e38f, tmin_prev2 = -3.0e38f;   // LOG: tmin of the previous round and of the one before (GhostLog::min_tfar)
+    uint32_t last_id = 0xFFFFFFFFu;                       // LOG: the last processed hit is (tLast, last_id)
 
     // one chunk of the hit log per (wave, trace round)
     auto open_chunk = [&]() -> uint32_t* {
-        if (!log.pool) return nullptr;
         uint32_t c = 0xFFFFFFFFu;
         if (lane == 0) {
             if (round < log.max_rounds) c = atomicAdd(&log.state[0], 1u);
@@ -830,107 +868,124 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         }
         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
         round++;
-        return c != 0xFFFFFFFFu ? log.pool + (size_t)c * (kGrtMaxHits * 64) + lane : nullptr;
-    };
-    // one hit of a trace round: processHit (gaussianParticles.cuh:337-405) while the ray is above min_transmittance
-    auto process_slot = [&](uint32_t* chunk, int slot, bool take, uint32_t id, float hit_t) {
-        const bool process = take && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
-        if (chunk) {
-            chunk[slot * 64] = process ? id : 0xFFFFFFFFu;
-            // the backward's trace interval ends at endT: it is not offered a proxy whose box the ray enters later (see below)
-            if (process) tnear_max = fmaxf(tnear_max, candidate(bvh.inst + 12 * (size_t)id, r).tnear);
-        }
-        if (process) {
-            nproc++;
-            nties = (hit_t > tLast) ? 1u : (nties + 1u);
-            const Particle p = load_particle(density12, id);
-            const HitGeom g = hit_geometry<DEG>(P, p, r);
-            if (g.accept) {
-                const float weight = g.galpha * T;
-                const float pdot = -dot(g.grd, g.gro);
-                const f3 grds = p.scl * g.grd * pdot;
-                const float hitT = sqrtf(dot(grds, grds));
-                const f3 u = sh_radiance(P, sph, id, basis);
-                const f3 c = mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f));
-                rad = rad + c * weight;
-                T *= (1.f - g.galpha);
-                depth = fmaf(hitT, weight, depth);
-                if (P.normals) {  // gaussianParticles.cuh:398-402
-                    const f3 psr = mul_cols(p.rotT, p.scl);
-                    const f3 q = (g.gro + g.grd * (pdot - sqrtf(9.f - g.gray))) * psr;
-                    const float l2 = dot(q, q);
-                    const f3 n = l2 > 0.f ? q * (1.f / sqrtf(l2)) : q;
-                    nrm = nrm + n * weight;
-                }
-                visibility[id] = 1;  // benign race: every writer stores the same value (referenceOptix.cu:158-161)
-                cnt += 1.f;
-            }
-            tLast = fmaxf(tLast, hit_t);
-            if (COUNT) tc.processed++;
-            if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = id;
-            ndbg++;
-        }
-        return process;
+        return c != 0xFFFFFFFFu ? log.pool + (size_t)c * (kGrtLogSlots * 64) + lane : nullptr;
     };
 
-    // The reference traces 16 nearest candidates beyond the last hit distance, processes them, and traces again
-    // (referenceOptix.cu:128-180).  Every trace costs a full walk along the ray (proxy boxes are much longer than the
-    // spacing of the hits), so one traversal here gathers the 32 nearest and the SECOND round is carved out of the same
-    // list with the second trace's own interval conditions (t > tLast + eps, box exit >= tLast + eps).  That is exact
-    // whenever the list provably contains that round: the gather was not full (nothing lies beyond it), or 16 entries
-    // survive the conditions.  A ray whose gather was not full is finished after its list: the reference's next trace
-    // would come back empty.
+    // The reference traces the 16 nearest candidates beyond the last hit distance, processes them, and traces again
+    // (referenceOptix.cu:128-180).
     while (true) {
         running = running && (tLast <= tExit) && (T > P.min_transmittance);
         if (!__any(running)) break;
+        // (the round's ghosts are parked in the LDS words of the hit ids, which are only written when the round is over)
+        GhostLog ghosts = {s_hit_id + lane, 0u, tmin_prev2, tLast, last_id};
+        if (LOG) { tmin_prev2 = tmin_prev1; tmin_prev1 = tLast + eps; }
+        uint32_t g_id[kGrtMaxGhosts];
         {
-            HitBufferT<kGather> buf;
-            if (UNI) list_round<COUNT, kGather>(lists, cone, dmin, dmax, list_end, list_start, r, tLast + eps, tExit + eps, running, lane, s_ent, buf, tc);
-            else trace_round<COUNT, kGather>(bvh, r, tLast + eps, tExit + eps, running, lane, s_stack, buf, tc);
+            HitBuffer buf;
+            if (UNI) list_round<COUNT, kGrtMaxHits, LOG>(lists, cone, dmin, dmax, list_end, list_start, r, tLast + eps, tExit + eps, running, lane, s_ent, buf, tc, &ghosts);
+            else trace_round<COUNT, kGrtMaxHits, LOG>(bvh, r, tLast + eps, tExit + eps, running, lane, s_stack, buf, tc, &ghosts);
+            if (LOG) {
+#pragma unroll
+                for (int g = 0; g < kGrtMaxGhosts; ++g) g_id[g] = (running && (uint32_t)g < ghosts.n) ? s_hit_id[g * 64 + lane] : 0xFFFFFFFFu;
+            }
             buf.store(s_hit_t, s_hit_id, lane);
         }
         if (s_hit_id[lane] == 0xFFFFFFFFu) running = false;
-        const bool full = s_hit_id[(kGather - 1) * 64 + lane] != 0xFFFFFFFFu;
-        // ---- first round: the 16 nearest ----
-        uint32_t* chunk = open_chunk();
+        const bool full = s_hit_id[(kGrtMaxHits - 1) * 64 + lane] != 0xFFFFFFFFu;
+        // LOG: the round's chunk holds the round's candidates AND its ghosts, merged in (t, particle) order — the replay walks a chunk
+        // front to back and decides with the backward program's own intervals which entries that program is offered (the candidates
+        // behind the ray's termination are among them: whether the backward reaches one is a matter of ITS interval, t < endT)
+        if (LOG) {
+            uint32_t* chunk = open_chunk();
+            if (ghosts.n > (uint32_t)kGrtMaxGhosts) ghost_overflow = true;
+            const float t16 = s_hit_t[(kGrtMaxHits - 1) * 64 + lane];
+            const uint32_t id16 = s_hit_id[(kGrtMaxHits - 1) * 64 + lane];
+            float g_t[kGrtMaxGhosts];
+            uint32_t g_pos[kGrtMaxGhosts];
+            uint32_t ng = 0u;
+#pragma unroll
+            for (int g = 0; g < kGrtMaxGhosts; ++g) {
+                const bool have = g_id[g] != 0xFFFFFFFFu;
+                g_t[g] = have ? candidate(bvh.inst + 12 * (size_t)g_id[g], r).t : 3.0e38f;   // (the very value the round computed: same arithmetic, same inputs)
+                // beyond the 16th candidate of a full round: not this round's business (the next round meets it again)
+                if (have && full && !hit_less(g_t[g], g_id[g], t16, id16)) { g_id[g] = 0xFFFFFFFFu; g_t[g] = 3.0e38f; }
+                ng += g_id[g] != 0xFFFFFFFFu ? 1u : 0u;
+                g_pos[g] = 0u;
+            }
+            const bool any_ghost = __any(ng != 0u);
+            if (chunk) {
+#pragma unroll 1
+                for (int i = 0; i < kGrtMaxHits; ++i) {
+                    const float ft = s_hit_t[i * 64 + lane];
+                    const uint32_t fid = s_hit_id[i * 64 + lane];
+                    uint32_t pos = (uint32_t)i;   // + the ghosts in front of this candidate
+                    if (any_ghost) {
+#pragma unroll
+                        for (int g = 0; g < kGrtMaxGhosts; ++g) {
+                            const bool ghost_first = g_id[g] != 0xFFFFFFFFu && hit_less(g_t[g], g_id[g], ft, fid);
+                            pos += ghost_first ? 1u : 0u;
+                            g_pos[g] += (g_id[g] != 0xFFFFFFFFu && !ghost_first && fid != 0xFFFFFFFFu) ? 1u : 0u;
+                        }
+                    }
+                    chunk[pos * 64] = running ? fid : 0xFFFFFFFFu;
+                }
+                if (any_ghost) {
+#pragma unroll
+                    for (int g = 0; g < kGrtMaxGhosts; ++g) {
+#pragma unroll
+                        for (int h = 0; h < kGrtMaxGhosts; ++h)
+                            if (h != g) g_pos[g] += (g_id[h] != 0xFFFFFFFFu && hit_less(g_t[h], g_id[h], g_t[g], g_id[g])) ? 1u : 0u;
+                        if (g_id[g] != 0xFFFFFFFFu) chunk[g_pos[g] * 64] = g_id[g] | kGrtGhostBit;
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < kGrtMaxGhosts; ++g)
+                    if ((uint32_t)g >= ng) chunk[(kGrtMaxHits + g) * 64] = 0xFFFFFFFFu;   // the unused tail of the chunk
+            }
+        }
         {
             f3 dir = r.d;   // opaque copy: stops the compiler from hoisting the basis back out of the round loop
             asm volatile("" : "+v"(dir.x), "+v"(dir.y), "+v"(dir.z));
             sh_basis16(P.sph_degree, dir, basis);
         }
+        // processHit (gaussianParticles.cuh:337-405) for the round's hits in order, while the ray is above min_transmittance
 #pragma unroll 1
         for (int i = 0; i < kGrtMaxHits; ++i) {
             const uint32_t id = s_hit_id[i * 64 + lane];
-            const bool any = __any(running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance));
-            if (!any && !chunk) break;  // ascending list: nothing further for any lane
-            process_slot(chunk, i, running, id, s_hit_t[i * 64 + lane]);
-        }
-        // ---- second round, from the same list ----
-        bool more = running && (tLast <= tExit) && (T > P.min_transmittance);
-        uint32_t mask2 = 0u;
-        if (more) {
-            const float tmin2 = tLast + eps;
-            int cnt2 = 0;
-            for (int i = kGrtMaxHits; i < kGather; ++i) {
-                const uint32_t id = s_hit_id[i * 64 + lane];
-                if (id == 0xFFFFFFFFu) break;
-                bool ok = s_hit_t[i * 64 + lane] > tmin2;
-                if (ok) ok = candidate(bvh.inst + 12 * (size_t)id, r).tfar >= tmin2;
-                if (ok) { mask2 |= (1u << (i - kGrtMaxHits)); cnt2++; }
+            const float hit_t = s_hit_t[i * 64 + lane];
+            const bool process = running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
+            if (!__any(process)) break;  // ascending list: nothing further for any lane
+            if (process) {
+                const Particle p = load_particle(density12, id);
+                const HitGeom g = hit_geometry<DEG>(P, p, r);
+                if (g.accept) {
+                    const float weight = g.galpha * T;
+                    const float pdot = -dot(g.grd, g.gro);
+                    const f3 grds = p.scl * g.grd * pdot;
+                    const float hitT = sqrtf(dot(grds, grds));
+                    const f3 u = sh_radiance(P, sph, id, basis);
+                    const f3 c = mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f));
+                    rad = rad + c * weight;
+                    T *= (1.f - g.galpha);
+                    depth = fmaf(hitT, weight, depth);
+                    if (P.normals) {  // gaussianParticles.cuh:398-402
+                        const f3 psr = mul_cols(p.rotT, p.scl);
+                        const f3 q = (g.gro + g.grd * (pdot - sqrtf(9.f - g.gray))) * psr;
+                        const float l2 = dot(q, q);
+                        const f3 n = l2 > 0.f ? q * (1.f / sqrtf(l2)) : q;
+                        nrm = nrm + n * weight;
+                    }
+                    visibility[id] = 1;  // benign race: every writer stores the same value (referenceOptix.cu:158-161)
+                    cnt += 1.f;
+                }
+                tLast = fmaxf(tLast, hit_t);
+                if (LOG) last_id = id;
+                if (COUNT) tc.processed++;
+                if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = id;
+                ndbg++;
             }
-            if (!full && cnt2 == 0) { running = false; more = false; }          // nothing lies beyond: the ray is done
-            else if (full && cnt2 < kGrtMaxHits) more = false;                  // the list may not hold the whole round: trace again
         }
-        if (__any(more)) {
-            uint32_t* chunk2 = open_chunk();
-#pragma unroll 1
-            for (int i = 0; i < kGrtMaxHits; ++i) {
-                const bool take = more && ((mask2 >> i) & 1u);
-                const uint32_t id = s_hit_id[(kGrtMaxHits + i) * 64 + lane];
-                process_slot(chunk2, i, take, id, s_hit_t[(kGrtMaxHits + i) * 64 + lane]);
-            }
-        }
-        if (!full) running = false;   // the list held every remaining candidate of this ray
+        if (!full) running = false;   // the round held every remaining candidate of this ray
     }
     if (!in_image) return;
     out_rad[3 * pix] = rad.x; out_rad[3 * pix + 1] = rad.y; out_rad[3 * pix + 2] = rad.z;
@@ -939,14 +994,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
     if (P.normals) { out_nrm[3 * pix] = nrm.x; out_nrm[3 * pix + 1] = nrm.y; out_nrm[3 * pix + 2] = nrm.z; }
     if (P.hitcounts) out_cnt[pix] = cnt;
     if (dbg_count) dbg_count[pix] = ndbg;
-    if (log.pool) {  // the backward visits hits with t < endT = tLast + 1e-9: in fp32 that usually excludes the hits AT tLast
-        const float endT = fminf(tLast, tExit) + eps;
-        // The reference's backward program traces with tmax = endT (referenceBwdOptix.cu:123-131): a processed hit whose proxy box the
-        // ray ENTERS beyond endT is never offered to it, which moves every later k = 16 round boundary — its hit set is then no longer
-        // a prefix of the forward's.  Such rays (0.3 % of a frame) are flagged; the backward re-derives their rounds exactly
-        // (grt_trace_bwd_kernel) and replays the log for all the others, for which replaying IS the reference's program.
-        log.nbwd[pix] = ((tLast < endT) ? nproc : nproc - nties) | ((tnear_max > endT) ? kGrtShiftedRay : 0u);
-    }
+    if (LOG) log.ray_flags[pix] = ghost_overflow ? kGrtRederiveRay : 0u;   // (a chunk could not hold a round's ghosts: no replay for this ray)
     if (COUNT) {  // work statistics for GrtStats (instrumented launches only)
         if (lane == 0) {   // per block: start and lifetime on the chip-wide 100 MHz counter, node visits (balance analysis, scripts/diag_grt_balance.py)
             const unsigned long long t_end = wall_clock64();
@@ -1083,8 +1131,8 @@ __device__ __forceinline__ void process_hit_bwd(const GrtTraceParams& P, const R
 }
 
 // The reference's backward program, round by round.  Without a hit log it serves every ray (render.backward_hit_replay = false, or
-// a backward that is not the last logged forward's); with one it serves the rays the forward flagged (kGrtShiftedRay: the replay
-// would not be the reference's program for them) — or every ray if the log overflowed.  UNI: the frame's packet lists are at hand, a
+// a backward that is not the last logged forward's); with one it serves the rays the forward flagged (kGrtRederiveRay: a chunk could
+// not hold all the ghosts of one of their rounds) — or every ray if the log overflowed.  UNI: the frame's packet lists are at hand, a
 // round is a window scan of the packet's list (list_round: same candidate sets and order as the tree walk) — with one or two live
 // lanes per wave the window is those rays' own, a few dozen entries.
 template <int DEG, bool UNI>
@@ -1095,7 +1143,7 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
                                                            const float* __restrict__ g_rad, const float* __restrict__ g_dns,
                                                            const float* __restrict__ g_hit, float* __restrict__ g_density12,
                                                            float* __restrict__ g_sph, const uint32_t* __restrict__ log_state,
-                                                           const uint32_t* __restrict__ log_nbwd, GrtLists lists) {
+                                                           const uint32_t* __restrict__ log_flags, GrtLists lists) {
     __shared__ uint32_t s_stack[UNI ? 1 : kGrtStackDepth];
     __shared__ float s_hit_t[kGrtMaxHits * 64];      // (UNI: a round's staged list entries live here while it is scanned)
     __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
@@ -1107,8 +1155,11 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
     const bool in_image = (px < P.W) && (py < P.H);
     const size_t pix = in_image ? (size_t)py * P.W + px : 0;  // out-of-image lanes shadow pixel 0 and never write
     bool running = in_image;
-    if (log_state && log_state[1] == 0u) running = running && (log_nbwd[pix] & kGrtShiftedRay) != 0u;   // the replay serves the rest
+    if (log_state && log_state[1] == 0u) running = running && (log_flags[pix] & kGrtRederiveRay) != 0u;   // the replay serves the rest
     if (!__any(running)) return;
+    const bool handled = running;
+    unsigned long long dbg_sig = 0ull;
+    uint32_t dbg_n = 0u;
     const RayW r = make_ray(P, ray_o, ray_d, pix);
     float basis[16];
     sh_basis16(P.sph_degree, r.d, basis);
@@ -1159,14 +1210,20 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
             if (process) {
                 process_hit_bwd<DEG>(P, r, basis, nact, id, density12, sph, ray_state, g_density12, g_sph);
                 startT = fmaxf(startT, s_hit_t[i * 64 + lane]);
+                dbg_n++; dbg_sig += (unsigned long long)id * 0x9E3779B97F4A7C15ull + 1ull;
             }
         }
     }
+    if (P.bwd_sig && handled) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
 }
 
 // backward from the forward's hit log — no traversal, and the gradient traffic is aggregated per wave.
+// Every lane walks ITS chunk sequence (processed hits and ghosts in hit-distance order, GrtHitLog) with the state machine of the
+// reference's backward program (referenceBwdOptix.cu:123-166): a trace from startT + eps to endT returns the 16 nearest candidates
+// whose hit distance lies in that interval and whose box interval touches it, every returned hit is differentiated, startT moves to
+// the largest of their distances.  Candidates arrive in ascending order, so "the 16 nearest of a trace" is a running count.
 // The reference issues 11 + 48 atomicAdds per hit and ray (gaussianParticles.cuh:468-731); the 64 rays of an 8x8 block
-// mostly hit the same particles, so per trace round the wave works in two phases:
+// mostly hit the same particles, so per group of slots the wave works in two phases:
 //   A. every lane walks ITS hits in order and advances its ray state (transmittance, radiance, depth), leaving per hit
 //      the five scalars the gradient is linear in: dL/d alpha ("common"), weight * dL/d depth, and the clamp-masked
 //      weight * dL/d radiance;
@@ -1182,12 +1239,13 @@ constexpr int kAggWindow = 2;   // slots on either side of the leader's slot tha
 constexpr int kAggSlots = GRT_AGG_SLOTS;    // hits of a round worked off together (two halves per round)
 
 template <int DEG>
-__global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                             const float* __restrict__ in_rad, const float* __restrict__ in_dns,
                                                             const float* __restrict__ in_hit2, const float* __restrict__ g_rad,
                                                             const float* __restrict__ g_dns, const float* __restrict__ g_hit,
-                                                            float* __restrict__ g_density12, float* __restrict__ g_sph, GrtHitLog log) {
+                                                            float* __restrict__ g_density12, float* __restrict__ g_sph, GrtHitLog log,
+                                                            const float* __restrict__ inst, const float* __restrict__ scene) {
     // per (slot, lane): the two scalars every gradient term is built from, and which colour channels were not clamped
     // (dL = rad_grad * weight on those).  A round is worked off in two halves of kAggSlots = 8 hits (state walk, then aggregation):
     // 6.6 KB per wave instead of 13 (first version: 24.5) — LDS, not registers, capped the occupancy at three waves per SIMD.
@@ -1211,27 +1269,48 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
     const float T_grad = -g_dns[pix], depth_grad = g_hit ? g_hit[pix] : 0.f;
     f3 rad = mk3(0.f, 0.f, 0.f);
     float T = 1.f, depth = 0.f;
-    uint32_t remaining = in_image ? log.nbwd[pix] : 0u;
-    if (remaining & kGrtShiftedRay) remaining = 0u;   // the exact rounds of grt_trace_bwd_kernel serve this ray
+    const bool replayed = in_image && !(log.ray_flags[pix] & kGrtRederiveRay);   // (else: the exact rounds of grt_trace_bwd_kernel serve this ray)
+    // the backward program's trace state
+    constexpr float eps = 1e-9f;
+    float tEnter, tExit;
+    scene_interval(scene, r, tEnter, tExit);
+    const float endT = fminf(in_hit2[2 * pix + 1], tExit) + eps;
+    float bw_start = fmaxf(0.f, tEnter - eps), bw_max = bw_start;   // startT of the running trace, largest hit distance it returned so far
+    uint32_t bw_cnt = 0u;                                           // hits the running trace returned so far
+    // the forward kept the ghosts of its round q whose box exit reaches back to the tmin of round q - 2 (GhostLog): premise = the running
+    // trace never started before that
+    float fw_start0 = bw_start, fw_start1 = bw_start, fw_start2 = bw_start, fw_last = bw_start;   // startT of forward rounds q, q - 1, q - 2; last hit distance met
+    bool premise_broken = false;
+    unsigned long long dbg_sig = 0ull;
+    uint32_t dbg_n = 0u;
     const uint32_t block = pb.index;
     for (uint32_t round = 0; round < log.max_rounds; ++round) {
-        if (!__any(remaining > 0u)) break;
         const uint32_t c = log.table[(size_t)block * log.max_rounds + round];
         if (c == 0xFFFFFFFFu) break;
-        const uint32_t* chunk = log.pool + (size_t)c * (kGrtMaxHits * 64) + lane;
-      for (int half = 0; half < kGrtMaxHits; half += kAggSlots) {
+        const uint32_t* chunk = log.pool + (size_t)c * (kGrtLogSlots * 64) + lane;
+        fw_start2 = fw_start1; fw_start1 = fw_start0; fw_start0 = fw_last;
+        if (replayed && chunk[0] != 0xFFFFFFFFu && bw_start < fw_start2) premise_broken = true;
+      for (int half = 0; half < kGrtLogSlots; half += kAggSlots) {
         // ---- phase A: per-lane state walk ----
         uint32_t pending = 0u;
 #pragma unroll 1
         for (int ii = 0; ii < kAggSlots; ++ii) {
             const int i = half + ii;
-            uint32_t id = chunk[i * 64];
+            uint32_t id = (i < kGrtLogSlots && replayed) ? chunk[i * 64] : 0xFFFFFFFFu;
             float common = 0.f, wgt = 0.f;
             uint32_t chan = 0u;
             bool contributes = false;
-            if (id != 0xFFFFFFFFu && remaining > 0u) {
-                remaining--;
-                {
+            if (id != 0xFFFFFFFFu) {
+                const bool ghost = (id & kGrtGhostBit) != 0u;
+                id &= ~kGrtGhostBit;
+                // is this candidate offered to the backward's running trace?  (same arithmetic as the traces themselves: candidate())
+                const Cand cd = candidate(inst + 12 * (size_t)id, r);
+                if (!ghost) fw_last = fmaxf(fw_last, cd.t);
+                const float tmin = bw_start + eps;
+                if (cd.ok && (cd.t > tmin) && (cd.t < endT) && (cd.tfar >= tmin) && (cd.tnear <= endT)) {
+                    bw_max = fmaxf(bw_max, cd.t);
+                    if (++bw_cnt == (uint32_t)kGrtMaxHits) { bw_start = bw_max; bw_cnt = 0u; }   // the trace is full: the next one starts behind its last hit
+                    dbg_n++; dbg_sig += (unsigned long long)id * 0x9E3779B97F4A7C15ull + 1ull;
                     const Particle p = load_particle(density12, id);
                     const HitGeom g = hit_geometry<DEG>(P, p, r);
                     if (g.accept) {
@@ -1361,6 +1440,10 @@ __global__ __launch_bounds__(64) void grt_replay_bwd_kernel(GrtTraceParams P, co
         __syncthreads();
       }
     }
+    if (P.bwd_sig && replayed) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
+    // rays whose ghost premise failed (see GhostLog): their gradient may miss a hit the reference's backward would have been offered
+    const unsigned long long broken = __ballot(premise_broken);
+    if (broken && lane == 0) atomicAdd(&log.state[2], (uint32_t)__popcll(broken));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1980,14 +2063,19 @@ void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& 
                           const GrtHitLog& log, const GrtLists& lists) {
     const bool uni = lists.ranges != nullptr;   // the host knows by now whether the frame has one ray origin (it sized the lists)
     const dim3 grid(pixel_block_grid(P.W, P.H));
-#define GRT_FWD_LAUNCH(COUNT_, UNI_)                                                                                                              \
-    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, COUNT_, UNI_>), grid, dim3(64), 0, s, P, bvh,                     \
+#define GRT_FWD_LAUNCH(COUNT_, UNI_, LOG_)                                                                                                        \
+    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_fwd_kernel<D_, COUNT_, UNI_, LOG_>), grid, dim3(64), 0, s, P, bvh,               \
                                                      reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, out_rad, out_dns, out_hit2, \
                                                      out_nrm, out_cnt, visibility, dbg_ids, dbg_count, counters, log, lists))
-    if (counters) {
-        if (uni) { GRT_FWD_LAUNCH(true, true); } else { GRT_FWD_LAUNCH(true, false); }
+    // (the instrumented build exists for the default configuration only: the counters are a development aid)
+    if (counters && log.pool) {
+        if (uni) { GRT_FWD_LAUNCH(true, true, true); } else { GRT_FWD_LAUNCH(true, false, true); }
+    } else if (counters) {
+        if (uni) { GRT_FWD_LAUNCH(true, true, false); } else { GRT_FWD_LAUNCH(true, false, false); }
+    } else if (log.pool) {
+        if (uni) { GRT_FWD_LAUNCH(false, true, true); } else { GRT_FWD_LAUNCH(false, false, true); }
     } else {
-        if (uni) { GRT_FWD_LAUNCH(false, true); } else { GRT_FWD_LAUNCH(false, false); }
+        if (uni) { GRT_FWD_LAUNCH(false, true, false); } else { GRT_FWD_LAUNCH(false, false, false); }
     }
 #undef GRT_FWD_LAUNCH
 }
@@ -1998,12 +2086,12 @@ void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& 
     if (log.pool) {  // replay the forward's hit log; the exact rounds below then serve the flagged rays (or all, if the log overflowed)
         GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_replay_bwd_kernel<D_>), grid, dim3(64), 0, s, P,
                                                          reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad,
-                                                         g_dns, g_hit, g_density12, g_sph, log));
+                                                         g_dns, g_hit, g_density12, g_sph, log, bvh.inst, bvh.scene));
     }
 #define GRT_BWD_LAUNCH(UNI_)                                                                                                                     \
     GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_, UNI_>), grid, dim3(64), 0, s, P, bvh,                            \
                                                      reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns, \
-                                                     g_hit, g_density12, g_sph, log.pool ? log.state : nullptr, log.pool ? log.nbwd : nullptr, lists))
+                                                     g_hit, g_density12, g_sph, log.pool ? log.state : nullptr, log.pool ? log.ray_flags : nullptr, lists))
     if (lists.ranges) { GRT_BWD_LAUNCH(true); } else { GRT_BWD_LAUNCH(false); }
 #undef GRT_BWD_LAUNCH
 }

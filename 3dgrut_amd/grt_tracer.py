@@ -128,6 +128,19 @@ class _GrtNative:
         _abi.check(self.lib.grt_stats(self.handle, C.byref(s)), "grt_stats")
         return s
 
+    def backward_signature(self, num_rays, device):
+        """Parity aid: from now on every backward also records, per ray, how many hits it differentiated and an order-independent
+        signature of the particles (two tensors, filled by the next backward; call with num_rays = 0 to stop)."""
+        if not num_rays:
+            self._sig = None
+            _abi.check(self.lib.grt_debug_backward_signature(self.handle, None, None), "grt_debug_backward_signature")
+            return None
+        sig = torch.zeros(num_rays, dtype=torch.int64, device=device)
+        cnt = torch.zeros(num_rays, dtype=torch.int32, device=device)
+        self._sig = (sig, cnt)   # kept alive while the library writes into them
+        _abi.check(self.lib.grt_debug_backward_signature(self.handle, _ptr(sig), _ptr(cnt)), "grt_debug_backward_signature")
+        return sig, cnt
+
     def instances(self, n, device):
         out = torch.zeros((n, 12), dtype=torch.float32, device=device)
         _abi.check(self.lib.grt_debug_fetch_instances(self.handle, _stream_ptr(device), _ptr(out)), "grt_debug_fetch_instances")

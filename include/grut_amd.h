@@ -289,6 +289,8 @@ typedef struct GrtStats {
     uint64_t list_entries;      /* last forward: entries of the packet lists (0: the tree walk served the frame — rays with different origins) */
     uint64_t packet_tests;      /* only in instrumented launches: candidate tests of whole packets (list entries / leaves tested by a wave) */
     uint64_t list_batches;      /* only in instrumented launches: 64-entry batches of packet lists fetched by the trace rounds (one 64-byte record per entry) */
+    uint32_t bwd_rederived_rays;   /* last logged forward: rays whose backward rounds are re-derived instead of replayed (a round met more ghosts than a log chunk holds) */
+    uint32_t bwd_premise_rays;     /* last replayed backward: rays for which the ghost filter's premise failed (DESIGN.md "3DGRT backward"; expected 0) */
 } GrtStats;
 
 typedef struct GrtHandle GrtHandle;
@@ -362,6 +364,10 @@ int grt_debug_forward_hits(GrtHandle* handle, void* stream, const GrtFrame* fram
                            float* out_features, float* out_density, float* out_hit_distance,
                            float* out_normals, float* out_hits_count, int32_t* out_visibility,
                            uint32_t* hit_ids, uint32_t* hit_counts, uint32_t capacity);
+/* Parity aid: until called again with NULLs, every grt_backward also writes, per ray (caller DEVICE buffers of W*H entries, zero-filled
+ * by the caller), how many hits it differentiated and an order-independent signature of which particles they were
+ * (sum of particle * 0x9E3779B97F4A7C15 + 1, mod 2^64) — the tests compare the replayed backward with the re-derived one ray by ray. */
+int grt_debug_backward_signature(GrtHandle* handle, unsigned long long* ray_signature, uint32_t* ray_hit_count);
 /* proxy instance records of the last build: [N,12] f32 = rows of W = diag(1/kscl) R^T, then mu (object ray: o' = W (o - mu)) */
 int grt_debug_fetch_instances(GrtHandle* handle, void* stream, float* instances);
 

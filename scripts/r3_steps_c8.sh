@@ -1,0 +1,6 @@
+step() { name=$1; shift; echo "=== $name"; ( time timeout 900 "$@" ) > $O/$name.log 2>&1; echo "rc=$? $(tail -n 4 $O/$name.log | cut -c1-300)"; }
+step grt_tests python -m pytest tests/test_grt_gpu.py -x -q
+step grt_full python -m pytest tests/test_full_size_gpu.py -x -q -s -k "grt"
+grep "re-derived\|differs\|Error" $O/grt_full.log | head
+step bench_grt python bench.py --workload c3_grt_1m_800 --no-cpu-baseline
+grep -o '"stages_ms": {[^}]*}' $O/bench_grt.log

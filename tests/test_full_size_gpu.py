@@ -155,6 +155,48 @@ def test_grt_full_size_forward_is_reproducible_and_backward_is_stable():
     for a, b in zip(g1, g2):
         assert bool(torch.isfinite(a).all())
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12
-    # particles no ray processed receive no gradient at all
+    # particles no ray of the FORWARD processed: the reference's backward program can still be offered one (its traces end at other
+    # distances than the forward's, so a candidate whose box the ray had left at a forward round's tmin can pass a backward round's
+    # box-exit test, referenceBwdOptix.cu:123-131) — rarely
     unseen = ~o1["mog_visibility"].bool().view(-1)
-    assert float(g1[0][unseen].abs().max()) == 0.0 and float(g1[4][unseen].abs().max()) == 0.0
+    with_grad = (g1[0].abs().amax(1) > 0) & unseen
+    assert float(with_grad.float().sum()) <= 0.02 * float((~unseen).float().sum())
+
+
+def test_grt_default_backward_equals_the_rederived_backward_at_full_size():
+    """BASELINE config 3's frame (1 M Gaussians, 800x800): the default backward — the forward's log of processed hits and ghosts walked
+    with the backward program's own trace intervals — against the backward that traverses again round by round
+    (render.backward_hit_replay = false: the reference's program literally, checked against the oracle at 100 k particles where the
+    oracle can afford every ray).  At this size 70 % of the rays lose a hit to the endT clip of the backward's traces and 8 % of them
+    process another hit SET than the forward (oracle statistics); all of it must come out the same."""
+    import torch
+    syn = importlib.import_module("3dgrut_amd.synthetic")
+    grt = importlib.import_module("3dgrut_amd.grt_tracer")
+    n, w, h = 1_000_000, 800, 800
+    d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=0.01)
+    K = syn.pinhole_intrinsics(w, h)
+    ro, rd = syn.pinhole_rays(w, h, K)
+    batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(0, n_views=8)[None], intrinsics=K), "cuda")
+    rng = np.random.default_rng(5)
+    g_rgb = torch.as_tensor(rng.normal(size=(1, h, w, 3)).astype(np.float32), device="cuda")
+    g_opa = torch.as_tensor(rng.normal(size=(1, h, w, 1)).astype(np.float32), device="cuda")
+
+    def grads(**kw):
+        tracer = grt.Tracer({"render": dict(enable_hitcounts=True, **kw)})
+        g = syn.SimpleGaussians(d12, sph)
+        tracer.build_acc(g, rebuild=True)
+        sig, cnt = tracer.tracer_wrapper.backward_signature(w * h, "cuda")
+        out = tracer.render(g, batch, train=True)
+        ((out["pred_features"] * g_rgb).sum() + (out["pred_opacity"] * g_opa).sum()).backward()
+        torch.cuda.synchronize()
+        return [p.grad.double() for p in g.parameters()], tracer.tracer_wrapper.stats(), sig.cpu().numpy(), cnt.cpu().numpy()
+    (a, st, sig_a, cnt_a), (b, _, sig_b, cnt_b) = grads(), grads(backward_hit_replay=False)
+    print(f"rays with re-derived rounds {st.bwd_rederived_rays}, ghost-premise failures {st.bwd_premise_rays}")
+    assert st.bwd_premise_rays == 0 and st.bwd_rederived_rays <= 5e-2 * w * h
+    # ray by ray: the SAME hits were differentiated (count and order-independent signature of the particle set)
+    differs = (cnt_a != cnt_b) | (sig_a != sig_b)
+    print(f"rays whose differentiated hit set differs: {int(differs.sum())} of {w * h}; hits per ray: mean {cnt_b.mean():.1f}, max {cnt_b.max()}")
+    assert not differs.any(), [(int(r), int(cnt_a[r]), int(cnt_b[r])) for r in np.flatnonzero(differs)[:12]]
+    for x, y in zip(a, b):
+        err = float((x - y).abs().max()) / (float(y.abs().max()) + 1e-30)
+        assert err < 1e-4, err   # same hits in the same traces; float atomics add in another order (measured ~1e-5)
