@@ -52,6 +52,10 @@ struct GrtHandle {
         l_scan_scratch, l_sort_scratch, l_block_keys, l_vals, l_block_keys_tmp, l_vals_tmp, l_ranges;
     uint32_t* l_host = nullptr;          // pinned: {entries, uniform-origin flag}
     uint64_t list_entries = 0;           // of the last forward (0: the BVH walk served it)
+    // the backward's re-derivation kernel serves a handful of rays per frame, each for milliseconds: it runs on a stream of its own
+    // next to the replay instead of behind it
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     unsigned long long* dbg_bwd_sig = nullptr;   // grt_debug_backward_signature: caller DEVICE buffers the next backward fills
     uint32_t* dbg_bwd_cnt = nullptr;
     DeviceBuffer work_counters;  // instrumented launches (GRUT_GRT_COUNT=1): nodes, leaf tests, processed hits, rounds, inserts
@@ -133,6 +137,9 @@ void grt_destroy(GrtHandle* h) {
     if (h->log_state_host) (void)hipHostFree(h->log_state_host);
     if (h->l_host) (void)hipHostFree(h->l_host);
     if (h->log_event) (void)hipEventDestroy(h->log_event);
+    if (h->side_fork) (void)hipEventDestroy(h->side_fork);
+    if (h->side_join) (void)hipEventDestroy(h->side_join);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
     h->fwd_timer.destroy();
     h->bwd_timer.destroy();
     h->build_timer.destroy();
@@ -400,8 +407,23 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
         fprintf(stderr, "[grut] grt bwd: %zu of %zu rays re-derive their rounds (log chunks %u, overflow %u, lists %s)\n", flagged, nb.size(), st[0], st[1],
                 lists.ranges ? "yes" : "no");
     }
-    grt_launch_trace_bwd(s, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, features, density, hit_distance,
+    hipStream_t rederive = s;
+    if (log.pool) {   // fork: the re-derivation of the flagged rays next to the replay (both only ADD to the gradient buffers)
+        if (!h->side_stream) {
+            GRUT_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+            GRUT_HIP(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
+            GRUT_HIP(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
+        }
+        GRUT_HIP(hipEventRecord(h->side_fork, s));
+        GRUT_HIP(hipStreamWaitEvent(h->side_stream, h->side_fork, 0));
+        rederive = h->side_stream;
+    }
+    grt_launch_trace_bwd(s, rederive, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, features, density, hit_distance,
                          grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph, log, lists);
+    if (log.pool) {   // join
+        GRUT_HIP(hipEventRecord(h->side_join, h->side_stream));
+        GRUT_HIP(hipStreamWaitEvent(s, h->side_join, 0));
+    }
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
     return GRUT_OK;

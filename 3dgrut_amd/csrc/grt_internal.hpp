@@ -122,8 +122,9 @@ void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& 
                           const float* ray_o, const float* ray_d, float* out_rad, float* out_dns, float* out_hit2, float* out_nrm,
                           float* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, unsigned long long* counters,
                           const GrtHitLog& log, const GrtLists& lists);
-// `lists`: the packet lists of the forward this backward belongs to (ranges == nullptr: none — the exact rounds walk the tree)
-void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
+// `lists`: the packet lists of the forward this backward belongs to (ranges == nullptr: none — the exact rounds walk the tree);
+// the replay goes to stream `s`, the re-derivation of the flagged rays (or of every ray without a log) to `s_rederive`
+void grt_launch_trace_bwd(hipStream_t s, hipStream_t s_rederive, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
                           const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log, const GrtLists& lists);
 

@@ -2079,20 +2079,22 @@ void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& 
     }
 #undef GRT_FWD_LAUNCH
 }
-void grt_launch_trace_bwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
+void grt_launch_trace_bwd(hipStream_t s, hipStream_t s_rederive, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
                           const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log, const GrtLists& lists) {
     const dim3 grid(pixel_block_grid(P.W, P.H));
-    if (log.pool) {  // replay the forward's hit log; the exact rounds below then serve the flagged rays (or all, if the log overflowed)
+    // the re-derivation first: with a log it serves a handful of rays (every ray if the log overflowed) and runs, on its own stream,
+    // next to the replay that follows
+#define GRT_BWD_LAUNCH(UNI_)                                                                                                                     \
+    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_, UNI_>), grid, dim3(64), 0, s_rederive, P, bvh,                   \
+                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns, \
+                                                     g_hit, g_density12, g_sph, log.pool ? log.state : nullptr, log.pool ? log.ray_flags : nullptr, lists))
+    if (lists.ranges) { GRT_BWD_LAUNCH(true); } else { GRT_BWD_LAUNCH(false); }
+    if (log.pool) {
         GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_replay_bwd_kernel<D_>), grid, dim3(64), 0, s, P,
                                                          reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad,
                                                          g_dns, g_hit, g_density12, g_sph, log, bvh.inst, bvh.scene));
     }
-#define GRT_BWD_LAUNCH(UNI_)                                                                                                                     \
-    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_, UNI_>), grid, dim3(64), 0, s, P, bvh,                            \
-                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns, \
-                                                     g_hit, g_density12, g_sph, log.pool ? log.state : nullptr, log.pool ? log.ray_flags : nullptr, lists))
-    if (lists.ranges) { GRT_BWD_LAUNCH(true); } else { GRT_BWD_LAUNCH(false); }
 #undef GRT_BWD_LAUNCH
 }
 

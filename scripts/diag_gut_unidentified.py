@@ -17,7 +17,7 @@ d_img, d_dist = pu.pixel_errors(hip["fd"], hip["dist"], shared["feat_density"], 
 X = hip["cnt"] != shared["hit_count"][..., 0]
 bad = (d_img > 1e-4) | (d_dist > 1e-4)
 exempt = np.flatnonzero((X | bad).reshape(-1))
-tg = pu.identify_flips(cfg, inp["cam"], shared, proj_shared["rgb"], exempt, hip["fd"], hip["cnt"])
+tg, _, _ = pu.identify_flips(cfg, inp["cam"], shared, proj_shared["rgb"], exempt, hip["fd"], hip["cnt"], hip["dist"])
 un = exempt[tg < 0]
 print("exempt", exempt.size, "unidentified", un.size)
 out = {}
