@@ -346,16 +346,38 @@ def gut_pixel_trace(cfg, cam, fwd, pixel, cap=4096, dtype=np.float32):
     return dict(idx=idx[:n], alpha=alpha[:n], hit_t=hit_t[:n], margin=margin[:n])
 
 
+class _OrcTexture(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32)]
+
+
+class _OrcMaterial(C.Structure):
+    _fields_ = [("diffuse", _OrcTexture), ("emissive", _OrcTexture), ("metallic_roughness", _OrcTexture), ("normal", _OrcTexture),
+                ("diffuse_factor", C.c_float * 4), ("emissive_factor", C.c_float * 3), ("metallic_factor", C.c_float), ("roughness_factor", C.c_float),
+                ("transmission_factor", C.c_float), ("ior", C.c_float), ("alpha_cutoff", C.c_float), ("alpha_mode", C.c_uint32)]
+
+
 class _OrcMesh(C.Structure):
     _fields_ = [("num_vertices", C.c_uint32), ("num_faces", C.c_uint32), ("vertices", C.c_void_p), ("triangles", C.c_void_p),
-                ("vertex_normals", C.c_void_p), ("prim_type", C.c_void_p), ("refractive_index", C.c_void_p), ("diffuse_color", C.c_void_p)]
+                ("vertex_normals", C.c_void_p), ("vertex_tangents", C.c_void_p), ("vertex_has_tangents", C.c_void_p), ("prim_type", C.c_void_p),
+                ("mat_uv", C.c_void_p), ("mat_id", C.c_void_p), ("refractive_index", C.c_void_p), ("num_materials", C.c_uint32),
+                ("materials", C.c_void_p), ("envmap", _OrcTexture), ("envmap_offset", C.c_float * 2)]
 
 
-def grt_hybrid(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, ray_o, ray_d, mesh, opts=0, max_pbr_bounces=8,
-               background=(0.0, 0.0, 0.0), inst=None, scene=None, ray_max_t=None, dtype=np.float32):
-    """Hybrid mesh + Gaussian path tracing (orc_grt_hybrid_trace; playgroundKernel.cu:39-157).  mesh: dict with vertices [V,3] f32,
-    triangles [F,3] i32, vertex_normals [V,3] f32, prim_type [F] i32 (0 none, 1 mirror, 2 glass, 3 diffuse), refractive_index [F] f32,
-    diffuse_color [F,3] f32.  Returns dict(rgba [H,W,4], last_ray [H,W,6], bounces [H,W])."""
+def _orc_texture(a, channels, keep):
+    if a is None:
+        return _OrcTexture(None, 0, 0, channels)
+    a = _c(a, np.float32)
+    keep.append(a)
+    return _OrcTexture(a.ctypes.data, a.shape[0], a.shape[1], channels)
+
+
+def grt_hybrid(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, ray_o, ray_d, mesh, opts=0, max_pbr_bounces=8, materials=None,
+               envmap=None, envmap_offset=(0.0, 0.0), frame_number=0, inst=None, scene=None, ray_max_t=None, dtype=np.float32):
+    """Hybrid mesh + Gaussian path tracing (orc_grt_hybrid_trace; playgroundKernel.cu:39-352, materials.cuh, trace.cuh).
+    mesh: dict with vertices [V,3] f32, triangles [F,3] i32, vertex_normals [V,3], prim_type [F] i32 (0 none, 1 mirror, 2 glass, 3 diffuse,
+    4 PBR), refractive_index [F] and optionally vertex_tangents [V,3], vertex_has_tangents [V] u8, mat_uv [F,3,2], mat_id [F];
+    materials: list of dicts as tests/playground_scenes.material() builds them (factors + optional textures [H,W,C]); envmap [EH,EW,4] or
+    None (black).  Rays [H,W,3]; pixel (x, y) seeds the random streams.  Returns dict(rgba [H,W,4], last_ray [H,W,6], bounces [H,W])."""
     l, R = lib(dtype), _real(dtype)
     d12, s = _c(density12, dtype), _c(sph, dtype)
     N = d12.shape[0]
@@ -365,19 +387,37 @@ def grt_hybrid(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, ra
     inst, scene = _c(inst, dtype), _c(scene, dtype)
     ro, rd = _c(ray_o, dtype), _c(ray_d, dtype)
     H, W = ro.shape[-3], ro.shape[-2]
-    n = H * W
     m = _c(np.asarray(ray_to_world)[:3, :4], dtype)
-    keep = dict(v=_c(mesh["vertices"], np.float32), t=_c(mesh["triangles"], np.int32), n=_c(mesh["vertex_normals"], np.float32),
-                p=_c(mesh["prim_type"], np.int32).reshape(-1), r=_c(mesh["refractive_index"], np.float32).reshape(-1),
-                d=_c(mesh["diffuse_color"], np.float32))
-    om = _OrcMesh(keep["v"].shape[0], keep["t"].shape[0], _p(keep["v"]), _p(keep["t"]), _p(keep["n"]), _p(keep["p"]), _p(keep["r"]), _p(keep["d"]))
+    V, Fn = np.asarray(mesh["vertices"]).reshape(-1, 3).shape[0], np.asarray(mesh["triangles"]).reshape(-1, 3).shape[0]
+    keep = []
+    arr = lambda key, dt, default: (keep.append(_c(mesh[key] if mesh.get(key) is not None else default, dt)) or keep[-1])
+    v, t = arr("vertices", np.float32, None), arr("triangles", np.int32, None)
+    vn = arr("vertex_normals", np.float32, np.zeros((V, 3)))
+    vt = arr("vertex_tangents", np.float32, np.zeros((V, 3)))
+    vh = arr("vertex_has_tangents", np.uint8, np.zeros(V))
+    pt = arr("prim_type", np.int32, None).reshape(-1)
+    uv = arr("mat_uv", np.float32, np.zeros((Fn, 3, 2)))
+    mid = arr("mat_id", np.int32, np.zeros(Fn)).reshape(-1)
+    ri = arr("refractive_index", np.float32, np.ones(Fn)).reshape(-1)
+    mats = list(materials) if materials else [dict(diffuse_factor=(0.8, 0.8, 0.8, 1.0), emissive_factor=(0, 0, 0), metallic_factor=0.0, roughness_factor=0.5,
+                                                   transmission_factor=0.0, ior=1.5, alpha_mode=0, alpha_cutoff=0.5)]
+    marr = (_OrcMaterial * len(mats))()
+    for i, mt in enumerate(mats):
+        o = marr[i]
+        o.diffuse, o.emissive = _orc_texture(mt.get("diffuse_tex"), 4, keep), _orc_texture(mt.get("emissive_tex"), 4, keep)
+        o.metallic_roughness, o.normal = _orc_texture(mt.get("metallic_roughness_tex"), 2, keep), _orc_texture(mt.get("normal_tex"), 4, keep)
+        for k in range(4):
+            o.diffuse_factor[k] = float(mt["diffuse_factor"][k])
+        for k in range(3):
+            o.emissive_factor[k] = float(mt["emissive_factor"][k])
+        o.metallic_factor, o.roughness_factor, o.transmission_factor = float(mt["metallic_factor"]), float(mt["roughness_factor"]), float(mt["transmission_factor"])
+        o.ior, o.alpha_cutoff, o.alpha_mode = float(mt["ior"]), float(mt["alpha_cutoff"]), int(mt["alpha_mode"])
+    om = _OrcMesh(V, Fn, _p(v), _p(t), _p(vn), _p(vt), _p(vh), _p(pt), _p(uv), _p(mid), _p(ri), len(mats), C.cast(marr, C.c_void_p),
+                  _orc_texture(envmap, 4, keep), (C.c_float * 2)(float(envmap_offset[0]), float(envmap_offset[1])))
     rgba, last, bounces = np.zeros((H, W, 4), dtype), np.zeros((H, W, 6), dtype), np.zeros((H, W), np.uint32)
     tmax = _c(ray_max_t, dtype).reshape(-1) if ray_max_t is not None else None
-    bg = _c(background, dtype)
     r = l.orc_grt_hybrid_trace(C.byref(cfg), C.c_uint32(N), _p(d12), _p(s), C.c_int(sph_deg), R(min_transmittance), _p(inst), _p(scene), _p(m),
-                               C.c_uint32(n), _p(ro), _p(rd), _p(tmax), C.byref(om), C.c_uint32(opts), C.c_uint32(max_pbr_bounces), _p(bg),
-                               _p(rgba), _p(last), _p(bounces))
-    if r == -4:
-        raise NotImplementedError("PBR primitives are not restated")
+                               C.c_uint32(W), C.c_uint32(H), _p(ro), _p(rd), _p(tmax), C.byref(om), C.c_uint32(opts), C.c_uint32(max_pbr_bounces),
+                               C.c_uint32(frame_number), _p(rgba), _p(last), _p(bounces))
     assert r == 0
     return dict(rgba=rgba, last_ray=last, bounces=bounces)

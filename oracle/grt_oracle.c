@@ -488,23 +488,41 @@ int orc_grt_ray_candidates(uint32_t N, const real* inst12, const real* ray_to_wo
 
 /* =====================================================================================================================
  * Hybrid mesh + Gaussian path tracing (BASELINE config 5): threedgrut_playground/src/kernels/cuda/
- * playgroundKernel.cu:39-157 (__raygen__rg path loop), :159-244 (refract / handleMirror / handleGlass / handleDiffuse),
- * :246-352 (normals, __closesthit__ch, __miss__ms); include/playground/kernels/cuda/trace.cuh:175-231 (traceMesh,
- * traceGaussians); threedgrt_tracer/include/3dgrt/kernels/cuda/3dgrtTracer.cuh:137-204 (traceVolumetricGS: the k = 16 rounds
- * of the forward program on a sub-interval of the ray, continuing the ray's transmittance).
- * Restated subset: primitive types none / mirror / glass / diffuse with per-face base colour (PGRNDRenderDisablePBRTextures
- * semantics: diffuse = material.diffuseFactor); PBR primitives (Cook-Torrance sampling, textures, emissive) are NOT restated.
- * The environment map is a solid colour.  The triangle intersection of OptiX's built-in triangle GAS is opaque: the closest
- * hit is restated as Moeller-Trumbore over every triangle, ties resolved towards the lower triangle index.
+ * playgroundKernel.cu:39-157 (__raygen__rg path loop), :159-251 (refract / handleMirror / handleGlass / handlePBR / handleDiffuse),
+ * :253-352 (normals, __closesthit__ch, __miss__ms); include/playground/kernels/cuda/trace.cuh:175-259 (traceMesh, traceGaussians,
+ * getBackgroundColor), materials.cuh:34-442 (get_diffuse_color, tangent frames, GGX importance sampling, alpha test, Cook-Torrance
+ * sampling), rng.cuh:21-78 (tea, lcg, rnd, rnd_pcg3d); threedgrt_tracer/include/3dgrt/kernels/cuda/3dgrtTracer.cuh:137-204
+ * (traceVolumetricGS: the k = 16 rounds of the forward program on a sub-interval of the ray, continuing the ray's transmittance).
+ * PINNED by tests/golden/playground.npz: the reference's own programs compiled on the host over an emulated OptiX
+ * (oracle/ref/ref_playground.cpp).  What the emulation defines (not the reference): the triangle intersection of OptiX's built-in
+ * triangle GAS — Moeller-Trumbore over every triangle, ties to the lower triangle index — and the texture filter: bilinear with float
+ * weights, clamp-to-edge, normalised coordinates (CUDA hardware filters with 8 fractional bits; cutexture.h:54-60 sets the modes).
  * ===================================================================================================================== */
 typedef struct {
+    const float* data;       /* [height, width, channels] or NULL (no texture) */
+    int32_t height, width, channels;
+} orc_texture;
+typedef struct {             /* PBRMaterial, pipelineParameters.h:26-52 */
+    orc_texture diffuse, emissive, metallic_roughness, normal;   /* 4, 4, 2, 4 channels */
+    float diffuse_factor[4], emissive_factor[3];
+    float metallic_factor, roughness_factor, transmission_factor, ior, alpha_cutoff;
+    uint32_t alpha_mode;     /* GltfAlphaMode: 0 opaque, 1 blend, 2 mask */
+} orc_material;
+typedef struct {
     uint32_t num_vertices, num_faces;
-    const float* vertices;          /* [V,3] */
-    const int32_t* triangles;       /* [F,3] */
-    const float* vertex_normals;    /* [V,3] (smooth shading) */
-    const int32_t* prim_type;       /* [F] PlaygroundPrimitiveTypes */
-    const float* refractive_index;  /* [F] */
-    const float* diffuse_color;     /* [F,3] */
+    const float* vertices;            /* [V,3] */
+    const int32_t* triangles;         /* [F,3] */
+    const float* vertex_normals;      /* [V,3] */
+    const float* vertex_tangents;     /* [V,3] */
+    const uint8_t* vertex_has_tangents; /* [V] */
+    const int32_t* prim_type;         /* [F] PlaygroundPrimitiveTypes */
+    const float* mat_uv;              /* [F,3,2] */
+    const int32_t* mat_id;            /* [F] */
+    const float* refractive_index;    /* [F] */
+    uint32_t num_materials;
+    const orc_material* materials;
+    orc_texture envmap;               /* 4 channels, or data == NULL: black */
+    float envmap_offset[2];
 } orc_mesh;
 
 static int tri_intersect(const orc_mesh* m, uint32_t f, v3 o, v3 d, real tmin, real tmax, real* t_out, real* u_out, real* v_out) {
@@ -526,6 +544,23 @@ static int tri_intersect(const orc_mesh* m, uint32_t f, v3 o, v3 d, real tmin, r
     if (!(t > tmin && t < tmax)) return 0;
     *t_out = t; *u_out = u; *v_out = v;
     return 1;
+}
+
+/* tex2D with the modes of cutexture.h:54-60: normalised coordinates, clamp-to-edge, bilinear, element type float */
+static void tex_fetch(const orc_texture* t, real u, real v, real out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (!t->data) return;
+    const real x = u * (real)t->width - R_(0.5), y = v * (real)t->height - R_(0.5);
+    const real fx = r_floor(x), fy = r_floor(y);
+    const real ax = x - fx, ay = y - fy;
+    int x0 = (int)fx, x1 = (int)fx + 1, y0 = (int)fy, y1 = (int)fy + 1;
+    x0 = x0 < 0 ? 0 : (x0 >= t->width ? t->width - 1 : x0); x1 = x1 < 0 ? 0 : (x1 >= t->width ? t->width - 1 : x1);
+    y0 = y0 < 0 ? 0 : (y0 >= t->height ? t->height - 1 : y0); y1 = y1 < 0 ? 0 : (y1 >= t->height ? t->height - 1 : y1);
+    for (int c = 0; c < t->channels && c < 4; ++c) {
+        const real t00 = t->data[((size_t)y0 * t->width + x0) * t->channels + c], t10 = t->data[((size_t)y0 * t->width + x1) * t->channels + c];
+        const real t01 = t->data[((size_t)y1 * t->width + x0) * t->channels + c], t11 = t->data[((size_t)y1 * t->width + x1) * t->channels + c];
+        out[c] = (1 - ay) * ((1 - ax) * t00 + ax * t10) + ay * ((1 - ax) * t01 + ax * t11);
+    }
 }
 
 /* traceVolumetricGS on [tmin, tmax] of the ray (o, d), continuing the ray's transmittance T and radiance */
@@ -566,53 +601,270 @@ static int refract_dir(v3* out_dir, v3 ray_d, v3 normal, real etai_over_etat) { 
     *out_dir = v3_safe_normalize(v3_add(perp, par));
     return 1;
 }
-static v3 mirror_dir(v3 ray_d, v3 normal) {   /* :190-198: -reflect(d, n') with reflect(x, n) = 2 n (n.x) - x */
+static v3 mirror_dir(v3 ray_d, v3 normal) {   /* :190-198: -reflect(d, n') with reflect(x, n) = 2 n (n.x) - x (mathUtils.cuh:384-387) */
     const v3 n = v3_dot(ray_d, normal) < 0 ? normal : v3_scale(normal, -1);
     return v3_safe_normalize(v3_sub(ray_d, v3_scale(n, 2 * v3_dot(n, ray_d))));
 }
 
-/* rays [nrays,3] in ray space; ray_max_t [nrays] or NULL (= 1e30); opts: bit 0 smooth normals, bit 1 Gaussian tracing off.
- * out_rgba [nrays,4], out_last_ray [nrays,6] (origin, direction of the last traced segment, world space), out_bounces [nrays]. */
+/* ---- rng.cuh ---- */
+static uint32_t pg_tea16(uint32_t val0, uint32_t val1) {   /* tea<16>, :21-35 */
+    uint32_t v0 = val0, v1 = val1, s0 = 0;
+    for (int n = 0; n < 16; ++n) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+static real pg_rnd(uint32_t* prev) {   /* lcg + rnd, :38-54 */
+    *prev = 1664525u * *prev + 1013904223u;
+    return (real)((float)(*prev & 0x00FFFFFFu) / (float)0x01000000);
+}
+static v3 pg_rnd_pcg3d(uint32_t x, uint32_t y, uint32_t z) {   /* :62-76 */
+    x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u; z = z * 1664525u + 1013904223u;
+    x += y * z; y += z * x; z += x * y;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16;
+    x += y * z; y += z * x; z += x * y;
+    /* make_float3(v.x, v.y, v.z) * (1.0 / float(0xffffffffu)): uint -> float conversions, then a float scale by 2^-32 (float(0xffffffff) = 2^32) */
+    const float k = (float)(1.0 / (double)(float)0xffffffffu);
+    return v3_make((real)((float)x * k), (real)((float)y * k), (real)((float)z * k));
+}
+
+/* ---- materials.cuh ---- */
+/* (the reference's trigonometry is single precision: asin / acos / sin / cos of float arguments) */
+static real pg_sin(real x) { return sizeof(real) == 4 ? (real)sinf((float)x) : (real)sin((double)x); }
+static real pg_cos(real x) { return sizeof(real) == 4 ? (real)cosf((float)x) : (real)cos((double)x); }
+static real pg_asin(real x) { return sizeof(real) == 4 ? (real)asinf((float)x) : (real)asin((double)x); }
+static real pg_acos(real x) { return sizeof(real) == 4 ? (real)acosf((float)x) : (real)acos((double)x); }
+#define PG_PBR_EPS R_(1e-6)
+#define PG_PI R_(3.141592654)
+static v3 pg_normalize(v3 v) {   /* :79-82 (not safe_normalize: threshold 1e-6 on the squared norm) */
+    const real n = v3_dot(v, v);
+    return (n > PG_PBR_EPS) ? v3_scale(v, 1 / r_sqrt(n)) : v;
+}
+static real pg_clamp01(real x) { return r_min(1, r_max(0, x)); }
+static real pg_pdot(v3 a, v3 b) { return pg_clamp01(v3_dot(a, b)); }   /* positive_dot, :68-71 */
+
+typedef struct {   /* what the closest-hit program knows about the hit (OptiX getters) */
+    uint32_t tri;
+    real bu, bv;       /* optixGetTriangleBarycentrics */
+} pg_hit;
+
+static void pg_tex_coords(const orc_mesh* m, const pg_hit* h, real* u, real* v) {   /* :41-48 */
+    const float* uv = m->mat_uv + 6 * (size_t)h->tri;
+    const real w0 = 1 - h->bu - h->bv;
+    *u = w0 * uv[0] + h->bu * uv[2] + h->bv * uv[4];
+    *v = w0 * uv[1] + h->bu * uv[3] + h->bv * uv[5];
+}
+static v3 pg_diffuse_color(const orc_mesh* m, const pg_hit* h, uint32_t opts, v3 ray_d, v3 normal) {   /* get_diffuse_color, :34-66 */
+    const orc_material* mat = &m->materials[m->mat_id[h->tri]];
+    real u, v;
+    pg_tex_coords(m, h, &u, &v);
+    v3 diffuse = v3_make(mat->diffuse_factor[0], mat->diffuse_factor[1], mat->diffuse_factor[2]);
+    if (mat->diffuse.data && !(opts & 4u)) {
+        real t[4];
+        tex_fetch(&mat->diffuse, u, v, t);
+        diffuse = v3_mul(v3_make(t[0], t[1], t[2]), diffuse);
+    }
+    return v3_scale(diffuse, r_fabs(v3_dot(ray_d, normal)));
+}
+static v3 pg_normal_space(const orc_mesh* m, const pg_hit* h, v3 normal, v3 dir) {   /* compute_normal_space, :84-135 */
+    const int32_t* tr = m->triangles + 3 * (size_t)h->tri;
+    v3 tangent;
+    if (m->vertex_has_tangents[tr[0]] && m->vertex_has_tangents[tr[1]] && m->vertex_has_tangents[tr[2]]) {   /* get_smooth_tangent */
+        const float* t0 = m->vertex_tangents + 3 * (size_t)tr[0]; const float* t1 = m->vertex_tangents + 3 * (size_t)tr[1];
+        const float* t2 = m->vertex_tangents + 3 * (size_t)tr[2];
+        const real w0 = 1 - h->bu - h->bv;
+        tangent = v3_make(w0 * t0[0] + h->bu * t1[0] + h->bv * t2[0], w0 * t0[1] + h->bu * t1[1] + h->bv * t2[1], w0 * t0[2] + h->bu * t1[2] + h->bv * t2[2]);
+        { const real len = r_sqrt(v3_dot(tangent, tangent)); tangent = v3_make(tangent.x / len, tangent.y / len, tangent.z / len); }   /* `/= length(...)` */
+    } else if (r_fabs(normal.x) > r_fabs(normal.z)) tangent = v3_make(-normal.y, normal.x, 0);
+    else tangent = v3_make(0, -normal.z, normal.y);
+    tangent = pg_normalize(tangent);
+    const v3 bitangent = pg_normalize(v3_cross(normal, tangent));
+    return pg_normalize(v3_make(tangent.x * dir.x + bitangent.x * dir.y + normal.x * dir.z, tangent.y * dir.x + bitangent.y * dir.y + normal.y * dir.z,
+                                tangent.z * dir.x + bitangent.z * dir.y + normal.z * dir.z));
+}
+static v3 pg_sample_diffuse(const orc_mesh* m, const pg_hit* h, v3 normal, real theta_seed, real phi_seed) {   /* :137-149 */
+    const real theta = pg_asin(theta_seed), phi = R_(2.0) * PG_PI * phi_seed;
+    return pg_normal_space(m, h, normal, v3_make(pg_sin(theta) * pg_cos(phi), pg_sin(theta) * pg_sin(phi), pg_cos(theta)));
+}
+static v3 pg_sample_specular(const orc_mesh* m, const pg_hit* h, v3 normal, real theta_seed, real phi_seed, real roughness) {   /* :151-164 */
+    const real alpha = roughness * roughness;
+    const real theta = pg_acos(r_sqrt((R_(1.0) - theta_seed) / (R_(1.0) + (alpha * alpha - R_(1.0)) * theta_seed)));
+    const real phi = R_(2.0) * PG_PI * phi_seed;
+    return pg_normal_space(m, h, normal, v3_make(pg_sin(theta) * pg_cos(phi), pg_sin(theta) * pg_sin(phi), pg_cos(theta)));
+}
+static real pg_ggx_d(v3 hv, v3 normal, real roughness) {   /* trowbridge_reitz_ggx, :184-193 */
+    const real alpha = roughness * roughness, a2 = alpha * alpha, ndh = pg_pdot(normal, hv);
+    const real denom = ndh * ndh * (a2 - 1) + 1;
+    return a2 / r_max(PG_PI * denom * denom, PG_PBR_EPS);
+}
+static real pg_g1(real ndv, real roughness) {   /* geometry_schlick_ggx, :196-201 */
+    const real alpha = R_(0.5) * roughness * roughness;
+    return ndv / r_max(ndv * (1 - alpha) + alpha, PG_PBR_EPS);
+}
+static v3 pg_fresnel(real cosine, v3 f0) {   /* fresnel_schlick, :212-215 */
+    const real p = r_pow(1 - cosine, 5);
+    return v3_make(f0.x + (1 - f0.x) * p, f0.y + (1 - f0.y) * p, f0.z + (1 - f0.z) * p);
+}
+static v3 pg_lerp3(v3 a, v3 b, real t) { return v3_make(a.x + t * (b.x - a.x), a.y + t * (b.y - a.y), a.z + t * (b.z - a.z)); }
+
+typedef struct {   /* the fields of HybridRayPayload the PBR branch writes */
+    v3 bsdf, emissive;
+    uint32_t pbr_bounces, rnd_seed;
+} pg_pbr_state;
+
+/* sampled_microfacet_brdf, :231-340 */
+static v3 pg_microfacet(const orc_mesh* m, const pg_hit* h, v3 wo, v3 normal, v3 base, real metalness, real roughness, real transmission, real ior,
+                        uint32_t px, uint32_t py, uint32_t frame, pg_pbr_state* st, v3* next_dir) {
+    const real fr = R_(0.5);
+    const v3 rnd = pg_rnd_pcg3d(px, py, frame + st->pbr_bounces);
+    const real phi_seed = rnd.x, theta_seed = rnd.y, ray_prob = rnd.z;
+    v3 out, L;
+    v3 f0 = v3_make(R_(0.16) * fr * fr, R_(0.16) * fr * fr, R_(0.16) * fr * fr);
+    f0 = pg_lerp3(f0, base, metalness);
+    if ((ray_prob < R_(0.5)) && ((R_(2.0) * ray_prob) < transmission)) {   /* transmissive */
+        const real front = v3_dot(wo, normal);
+        const v3 fn = front >= 0 ? normal : v3_scale(normal, -1);
+        const real eta = front >= 0 ? 1 / ior : ior;
+        const v3 H = pg_sample_specular(m, h, fn, theta_seed, phi_seed, roughness);
+        {   /* pbr_refract(-wo, H, eta), :217-222 */
+            const v3 wi = v3_scale(wo, -1);
+            const real ndi = v3_dot(H, wi);
+            const real k = 1 - eta * eta * (1 - ndi * ndi);
+            L = (k < 0) ? v3_make(0, 0, 0) : v3_sub(v3_scale(wi, eta), v3_scale(H, eta * ndi + r_sqrt(k)));
+        }
+        const real ndo = pg_pdot(fn, wo), ndl = pg_pdot(v3_scale(fn, -1), L), ndh = pg_pdot(fn, H), odh = pg_pdot(wo, H);
+        const v3 Fv = pg_fresnel(odh, f0);
+        const real G = pg_g1(ndo, roughness) * pg_g1(ndl, roughness);
+        (void)pg_ggx_d(H, fn, roughness);
+        const real k = G * odh / r_max(ndh * ndo, R_(0.001));
+        out = v3_make(base.x * (1 - Fv.x) * k, base.y * (1 - Fv.y) * k, base.z * (1 - Fv.z) * k);
+    } else if ((ray_prob < R_(0.5)) && ((R_(2.0) * ray_prob) >= transmission)) {   /* diffuse */
+        L = pg_sample_diffuse(m, h, normal, theta_seed, phi_seed);
+        const v3 H = pg_normalize(v3_add(wo, L));
+        const v3 Fv = pg_fresnel(pg_pdot(wo, H), f0);
+        const real nm = 1 - metalness;
+        out = v3_make((1 - Fv.x) * nm * base.x, (1 - Fv.y) * nm * base.y, (1 - Fv.z) * nm * base.z);
+    } else {   /* specular */
+        const v3 H = pg_sample_specular(m, h, normal, theta_seed, phi_seed, roughness);
+        const v3 mwo = v3_scale(wo, -1);
+        L = v3_sub(mwo, v3_scale(H, R_(2.0) * v3_dot(H, mwo)));
+        const real ndo = pg_pdot(normal, wo), ndh = pg_pdot(normal, H), ndl = pg_pdot(normal, L), odh = pg_pdot(wo, H);
+        const v3 Fv = pg_fresnel(odh, f0);
+        const real G = pg_g1(ndo, roughness) * pg_g1(ndl, roughness);
+        const real k = G * odh / r_max(ndh * ndo, R_(0.001));
+        out = v3_scale(Fv, k);
+    }
+    *next_dir = L;
+    st->pbr_bounces += 1;
+    return v3_scale(out, 2);   /* compensates for splitting diffuse and specular */
+}
+
+/* sampled_cook_torrance_brdf, :344-440: material fetch (factors x textures), normal map, alpha test, the sampled BRDF */
+static void pg_cook_torrance(const orc_mesh* m, const pg_hit* h, uint32_t opts, v3 ray_d, v3 normal, uint32_t px, uint32_t py, uint32_t frame,
+                             pg_pbr_state* st, v3* new_dir) {
+    const v3 wo = pg_normalize(v3_scale(ray_d, -1));
+    const orc_material* mat = &m->materials[m->mat_id[h->tri]];
+    const int notex = (opts & 4u) != 0;
+    real u, v, t[4];
+    pg_tex_coords(m, h, &u, &v);
+    v3 diffuse = v3_make(mat->diffuse_factor[0], mat->diffuse_factor[1], mat->diffuse_factor[2]);
+    real alpha = mat->diffuse_factor[3];
+    if (mat->diffuse.data && !notex) {
+        tex_fetch(&mat->diffuse, u, v, t);
+        diffuse = v3_mul(v3_make(t[0], t[1], t[2]), diffuse);
+        alpha *= t[3];
+    }
+    v3 emissive = v3_make(mat->emissive_factor[0], mat->emissive_factor[1], mat->emissive_factor[2]);
+    if (mat->emissive.data && !notex) {
+        tex_fetch(&mat->emissive, u, v, t);
+        emissive = v3_mul(v3_make(t[0], t[1], t[2]), emissive);
+    }
+    real metallic = mat->metallic_factor, roughness = mat->roughness_factor;
+    if (mat->metallic_roughness.data && !notex) {
+        tex_fetch(&mat->metallic_roughness, u, v, t);
+        metallic = t[0] * mat->metallic_factor;
+        roughness = t[1] * mat->roughness_factor;
+    }
+    if (mat->normal.data && !notex) {
+        tex_fetch(&mat->normal, u, v, t);
+        normal = pg_normal_space(m, h, normal, v3_make(t[0], t[1], t[2]));
+    }
+    /* alpha_test, :166-181 */
+    int pass = 1;
+    if (mat->alpha_mode == 1u) pass = alpha > pg_rnd(&st->rnd_seed);
+    else if (mat->alpha_mode == 2u) pass = alpha > (real)mat->alpha_cutoff;
+    if (!pass) { *new_dir = ray_d; return; }
+    const v3 scatter = pg_microfacet(m, h, wo, normal, diffuse, metallic, roughness, mat->transmission_factor, mat->ior, px, py, frame, st, new_dir);
+    st->bsdf = v3_make(r_max(scatter.x, 0), r_max(scatter.y, 0), r_max(scatter.z, 0));
+    st->emissive = emissive;
+}
+
+static v3 pg_background(const orc_mesh* m, v3 d) {   /* getBackgroundColor, trace.cuh:233-257 */
+    const real rotY = (real)m->envmap_offset[0] * R_(2.0) * R_(3.14159265358979323846), rotX = R_(2.0) * (real)m->envmap_offset[1] * R_(3.14159265358979323846);
+    const real cy = pg_cos(rotY), sy = pg_sin(rotY), cx = pg_cos(rotX), sx = pg_sin(rotX);
+    const v3 r1 = v3_make(d.x * cy - d.z * sy, d.y, d.x * sy + d.z * cy);
+    const v3 r2 = v3_make(r1.x, r1.y * cx - r1.z * sx, r1.y * sx + r1.z * cx);
+    const real theta = r_atan2(r2.x, r2.z);
+    const real phi = R_(3.14159265358979323846) * R_(0.5) - pg_acos(r_min(1, r_max(-1, r2.y)));
+    const real u = (theta + R_(3.14159265358979323846)) * (R_(0.5) * R_(0.318309886183790671538));
+    const real v = R_(0.5) * (1 + pg_sin(phi));
+    real t[4];
+    tex_fetch(&m->envmap, u, v, t);
+    return v3_make(t[0], t[1], t[2]);
+}
+
+/* rays [height*width,3] in ray space, pixel (x, y) = ray y*width + x (the random streams are seeded per pixel); ray_max_t [rays] or NULL
+ * (= 1e30); opts: PlaygroundRenderOptions (1 smooth normals, 2 Gaussian tracing off, 4 PBR textures off).
+ * out_rgba [rays,4], out_last_ray [rays,6] (origin, direction of the last traced segment, world space), out_bounces [rays] (mirror bounces). */
 int orc_grt_hybrid_trace(const GrtConfig* cfg, uint32_t N, const real* density12, const real* sph, int sph_deg, real min_T,
-                         const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
+                         const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t width, uint32_t height, const real* ray_o,
                          const real* ray_d, const real* ray_max_t, const orc_mesh* mesh, uint32_t opts, uint32_t max_pbr_bounces,
-                         const real* background3, real* out_rgba, real* out_last_ray, uint32_t* out_bounces) {
-    for (uint32_t f = 0; f < mesh->num_faces; ++f)
-        if (mesh->prim_type[f] == 4) return -4;   /* PGRNDPrimitivePBR: not restated */
+                         uint32_t frame_number, real* out_rgba, real* out_last_ray, uint32_t* out_bounces) {
+    const uint32_t nrays = width * height;
 #pragma omp parallel
     {
         grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
 #pragma omp for schedule(dynamic, 8)
         for (uint32_t r = 0; r < nrays; ++r) {
+            const uint32_t px = r % width, py = r / width;
             v3 rayOri = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
             v3 rayDir = xform_dir(ray_to_world12, v3_make(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
             const real ray_t_max = ray_max_t ? ray_max_t[r] : R_(1e30);
             /* payload (playgroundKernel.cu:51-68) and the ray's running volumetric state (RayData) */
             v3 accC = v3_make(0, 0, 0), direct = v3_make(0, 0, 0), thr = v3_make(1, 1, 1);
             real accA = 0;
-            uint32_t numBounces = 0, pbrBounces = 0, timeout = 0;
-            int missed = 0, terminate = 0;
+            uint32_t numBounces = 0, timeout = 0;
+            pg_pbr_state pbr; pbr.pbr_bounces = 0; pbr.rnd_seed = pg_tea16(width * py + px, frame_number);
+            pbr.bsdf = v3_make(1, 1, 1); pbr.emissive = v3_make(0, 0, 0);
+            int missed = 0;
+            int state = 0;   /* PlaygroundTraceState: 0 primitives pass, 1 Gaussians pass, 2 terminate (params.trace_state) */
             real T = 1; v3 rad = v3_make(0, 0, 0);   /* RayData: density = 1 - T, radiance */
             v3 lastO = rayOri, lastD = rayDir;
-            while (!missed && (r_sqrt(v3_dot(thr, thr)) > R_(0.0001)) && accA < R_(0.995) && (pbrBounces < max_pbr_bounces) && (numBounces < 32) && !terminate) {
+            while (!missed && (r_sqrt(v3_dot(thr, thr)) > R_(0.0001)) && accA < R_(0.995) && (pbr.pbr_bounces < max_pbr_bounces) && (numBounces < 32) &&
+                   (state != 2)) {
                 const v3 o = rayOri, d = rayDir;
+                pbr.bsdf = v3_make(1, 1, 1); pbr.emissive = v3_make(0, 0, 0);
                 /* traceMesh: closest triangle in (1e-5, 1e5) */
+                state = 0;
                 real best_t = R_(3.0e38), bu = 0, bv = 0; int best_f = -1;
                 for (uint32_t f = 0; f < mesh->num_faces; ++f) {
                     real t, u, v;
                     if (tri_intersect(mesh, f, o, d, R_(1e-5), R_(1e5), &t, &u, &v) && t < best_t) { best_t = t; bu = u; bv = v; best_f = (int)f; }
                 }
                 real t_hit = 0;
-                if (best_f < 0) missed = 1;
+                if (best_f < 0) missed = 1;   /* __miss__ms */
                 else {   /* __closesthit__ch */
                     const int32_t* tr = mesh->triangles + 3 * (size_t)best_f;
+                    pg_hit h; h.tri = (uint32_t)best_f; h.bu = bu; h.bv = bv;
                     v3 normal;
                     if (opts & 1u) {
                         const float* n0 = mesh->vertex_normals + 3 * (size_t)tr[0]; const float* n1 = mesh->vertex_normals + 3 * (size_t)tr[1];
                         const float* n2 = mesh->vertex_normals + 3 * (size_t)tr[2];
                         const real w0 = 1 - bu - bv;
                         normal = v3_make(w0 * n0[0] + bu * n1[0] + bv * n2[0], w0 * n0[1] + bu * n1[1] + bv * n2[1], w0 * n0[2] + bu * n1[2] + bv * n2[2]);
-                        normal = v3_scale(normal, 1 / r_sqrt(v3_dot(normal, normal)));
+                        { const real len = r_sqrt(v3_dot(normal, normal)); normal = v3_make(normal.x / len, normal.y / len, normal.z / len); }   /* `/= length(...)` */
                     } else {
                         const float* p0 = mesh->vertices + 3 * (size_t)tr[0]; const float* p1 = mesh->vertices + 3 * (size_t)tr[1];
                         const float* p2 = mesh->vertices + 3 * (size_t)tr[2];
@@ -621,6 +873,7 @@ int orc_grt_hybrid_trace(const GrtConfig* cfg, uint32_t N, const real* density12
                     real hit_t = best_t;
                     v3 new_dir = v3_make(0, 0, 0);
                     const int type = mesh->prim_type[best_f];
+                    int next_state = 1;
                     if (type == 1) { new_dir = mirror_dir(d, normal); numBounces++; }
                     else if (type == 2) {
                         const real ior = (real)mesh->refractive_index[best_f] / R_(1.0003);
@@ -628,31 +881,36 @@ int orc_grt_hybrid_trace(const GrtConfig* cfg, uint32_t N, const real* density12
                         else { new_dir = mirror_dir(d, normal); numBounces++; }
                     } else if (type == 3) {   /* handleDiffuse: the Gaussians in front of the surface, then the surface itself */
                         real T0 = T; v3 rad0 = rad;
-                        if (!(opts & 2u)) trace_segment(cfg, N, density12, sph, sph_deg, min_T, inst12, scene6, o, d, R_(1e-9), hit_t, cands, &T, &rad);
+                        if (!(opts & 2u)) { state = 1; trace_segment(cfg, N, density12, sph, sph_deg, min_T, inst12, scene6, o, d, R_(1e-9), hit_t, cands, &T, &rad); }
                         const v3 vrad = v3_sub(rad, rad0); const real valpha = (1 - T) - (1 - T0);
                         accC = v3_add(accC, vrad); accA += valpha;
-                        const float* dc = mesh->diffuse_color + 3 * (size_t)best_f;
+                        const v3 dc = pg_diffuse_color(mesh, &h, opts, d, normal);
                         const real sa = 1 - accA;
-                        accC = v3_add(accC, v3_make(sa * dc[0], sa * dc[1], sa * dc[2])); accA += sa;
-                        terminate = 1;
+                        accC = v3_add(accC, v3_scale(dc, sa)); accA += sa;
+                        next_state = 2;
+                    } else if (type == 4) {   /* handlePBR */
+                        pg_cook_torrance(mesh, &h, opts, d, normal, px, py, frame_number, &pbr, &new_dir);
+                        { const real len = r_sqrt(v3_dot(new_dir, new_dir)); new_dir = v3_make(new_dir.x / len, new_dir.y / len, new_dir.z / len); }
                     } else new_dir = d;
                     t_hit = hit_t;
                     rayOri = v3_add(o, v3_scale(d, hit_t)); rayDir = new_dir;
+                    state = next_state;
                 }
-                /* the Gaussians between the ray origin and the surface (or the ray's end) */
+                /* the Gaussians between the ray origin and the surface (or the ray's end): traceGaussians sets the trace state itself */
                 const real next_t = missed ? ray_t_max : t_hit;
                 real T0 = T; v3 rad0 = rad;
-                if (!(opts & 2u)) trace_segment(cfg, N, density12, sph, sph_deg, min_T, inst12, scene6, o, d, R_(1e-9), next_t, cands, &T, &rad);
+                if (!(opts & 2u)) { state = 1; trace_segment(cfg, N, density12, sph, sph_deg, min_T, inst12, scene6, o, d, R_(1e-9), next_t, cands, &T, &rad); }
                 const v3 radiance = v3_sub(rad, rad0); const real density = (1 - T) - (1 - T0);
                 accA += density * (1 - accA);
                 accC = v3_add(accC, v3_mul(thr, radiance));
                 direct = v3_add(direct, radiance);
                 thr = v3_scale(thr, 1 - density);
-                accC = v3_add(accC, v3_mul(thr, direct));   /* nextEmissive = 0, bsdfValue = 1 without PBR primitives */
+                accC = v3_add(accC, v3_mul(thr, v3_add(direct, pbr.emissive)));
+                thr = v3_mul(thr, pbr.bsdf);
                 lastO = o; lastD = d;
                 if (++timeout > 1000) break;
             }
-            direct = v3_add(direct, v3_make(background3[0], background3[1], background3[2]));
+            direct = v3_add(direct, pg_background(mesh, lastD));
             thr = v3_scale(thr, 1 - accA);
             accC = v3_add(accC, v3_mul(thr, direct));
             accA = r_min(r_max(accA, 0), 1);

@@ -24,6 +24,7 @@ inline float3 make_float3(float x, float y, float z) { return {x, y, z}; }
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 inline int3 make_int3(int x, int y, int z) { return {x, y, z}; }
 inline int2 make_int2(int x, int y) { return {x, y}; }
+inline uint3 make_uint3(unsigned x, unsigned y, unsigned z) { return {x, y, z}; }
 inline float rsqrtf(float x) { return 1.0f / std::sqrt(x); }
 inline float atomicAdd(float* a, float v) { float o = *a; *a += v; return o; }
 template <class T> inline T atomicMin(T* a, T v) { T o = *a; *a = std::min(o, v); return o; }

@@ -25,6 +25,11 @@ struct ShimOptix {
     unsigned instance;
     uint32_t* payload[32];
     bool ignore;
+    // playground (closest-hit programs over a triangle GAS): launch size, the hit triangle, its barycentrics and vertices
+    uint3 launchDim;
+    unsigned primitive;
+    float2 barycentrics;
+    float3 triangle[3];
 };
 extern thread_local ShimOptix g_optix;
 typedef unsigned OptixVisibilityMask;
@@ -33,7 +38,20 @@ inline uint3 optixGetLaunchIndex() { return g_optix.launchIndex; }
 inline float optixGetRayTmin() { return g_optix.tmin; }
 inline float optixGetRayTmax() { return g_optix.tmax; }
 inline unsigned optixGetInstanceIndex() { return g_optix.instance; }
+#ifdef SHIM_OPTIX_PLAYGROUND
+inline unsigned optixGetPrimitiveIndex() { return g_optix.primitive; }   // the hit triangle (closest-hit) / 0 for the one custom primitive of a particle
+inline uint3 optixGetLaunchDimensions() { return g_optix.launchDim; }
+inline float2 optixGetTriangleBarycentrics() { return g_optix.barycentrics; }
+inline OptixTraversableHandle optixGetGASTraversableHandle() { return 0; }
+inline unsigned optixGetSbtGASIndex() { return 0; }
+inline void optixGetTriangleVertexData(OptixTraversableHandle, unsigned, unsigned, float, float3 v[3]) { v[0] = g_optix.triangle[0]; v[1] = g_optix.triangle[1]; v[2] = g_optix.triangle[2]; }
+enum { OPTIX_RAY_FLAG_DISABLE_ANYHIT = 1 << 0 };
+// the two-register trace of the mesh pass (trace.cuh:175-195)
+void optixTrace(OptixTraversableHandle handle, float3 origin, float3 direction, float tmin, float tmax, float time, OptixVisibilityMask mask,
+                unsigned flags, unsigned sbtOffset, unsigned sbtStride, unsigned missIndex, uint32_t& p0, uint32_t& p1);
+#else
 inline unsigned optixGetPrimitiveIndex() { return 0; }   // the instanced BLAS holds one custom primitive (optixTracer.cpp:551-563)
+#endif
 inline float3 optixGetObjectRayOrigin() { return g_optix.objectOrigin; }
 inline float3 optixGetObjectRayDirection() { return g_optix.objectDirection; }
 inline float3 optixGetWorldRayOrigin() { return g_optix.worldOrigin; }

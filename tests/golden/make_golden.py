@@ -481,10 +481,98 @@ def make_gut_render():
     print("wrote gut_render.npz; stand-in vs CUDA twin:", err, acc_standin, acc_twin)
 
 
+# ---- the reference's hybrid mesh + Gaussian path tracer (playground) on the host ----------------------------------------------------
+class RefMaterial(C.Structure):   # oracle/ref/ref_playground.cpp: RefMaterial
+    _fields_ = [("diffuse_tex", C.c_void_p), ("emissive_tex", C.c_void_p), ("mr_tex", C.c_void_p), ("normal_tex", C.c_void_p),
+                ("diffuse_hw", C.c_int32 * 2), ("emissive_hw", C.c_int32 * 2), ("mr_hw", C.c_int32 * 2), ("normal_hw", C.c_int32 * 2),
+                ("diffuse_factor", C.c_float * 4), ("emissive_factor", C.c_float * 3), ("metallic", C.c_float), ("roughness", C.c_float),
+                ("transmission", C.c_float), ("ior", C.c_float), ("alpha_cutoff", C.c_float), ("alpha_mode", C.c_uint32)]
+
+
+def playground_reference(sc, opts, bounces, frame):
+    """One frame of a tests/playground_scenes.make_playground_scene() scene through the reference's own programs
+    (oracle/_ref/libref_playground_deg4.so) over the proxy instances of the reference's instance kernel."""
+    px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    pg = C.CDLL(os.path.join(REF, "libref_playground_deg4.so"))
+    d12, sph = sc["density12"], sc["sph"]
+    n = len(d12)
+    pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]), np.ascontiguousarray(d12[:, 3]))
+    aabb, tf = np.zeros((n, 6), F), np.zeros((n, 12), F)
+    px.ref_enclosing_proxies(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(aabb), _p(tf))
+    box = np.concatenate([aabb[:, :3].min(0), aabb[:, 3:].max(0)]).astype(F)
+    H, W, m = sc["H"], sc["W"], sc["mesh"]
+    ro, rd = sc["ray_o"].copy(), sc["ray_d"].copy()   # overwritten with the last traced segment, like the reference's buffers
+    rgb, alpha = np.zeros((H, W, 3), F), np.zeros((H, W, 1), F)
+    mats = (RefMaterial * max(len(sc["materials"]), 1))()
+    for i, mt in enumerate(sc["materials"]):
+        r = mats[i]
+        for name, key in (("diffuse", "diffuse_tex"), ("emissive", "emissive_tex"), ("mr", "metallic_roughness_tex"), ("normal", "normal_tex")):
+            t = mt[key]
+            setattr(r, name + "_tex", t.ctypes.data if t is not None else None)
+            hw = getattr(r, name + "_hw")
+            hw[0], hw[1] = (t.shape[0], t.shape[1]) if t is not None else (0, 0)
+        for k in range(4):
+            r.diffuse_factor[k] = float(mt["diffuse_factor"][k])
+        for k in range(3):
+            r.emissive_factor[k] = float(mt["emissive_factor"][k])
+        r.metallic, r.roughness, r.transmission, r.ior = mt["metallic_factor"], mt["roughness_factor"], mt["transmission_factor"], mt["ior"]
+        r.alpha_cutoff, r.alpha_mode = mt["alpha_cutoff"], mt["alpha_mode"]
+    env = sc["envmap"]
+    pg.ref_playground_trace(C.c_uint(n), _p(tf), _p(d12), _p(sph), W, H, _p(ro), _p(rd), _p(sc["ray_max_t"]), _p(box), C.c_float(MIN_T_GRT), C.c_uint(3),
+                            C.c_uint(frame), C.c_uint(len(m["vertices"])), _p(m["vertices"]), C.c_uint(len(m["triangles"])), _p(m["triangles"]),
+                            _p(m["vertex_normals"]), _p(m["vertex_tangents"]), _p(m["vertex_has_tangents"]), _p(m["prim_type"]), _p(m["mat_uv"]),
+                            _p(m["mat_id"]), _p(m["refractive_index"]), C.c_uint(len(sc["materials"])), mats, _p(env), env.shape[0], env.shape[1],
+                            _p(sc["envmap_offset"]), C.c_uint(opts), C.c_uint(bounces), _p(rgb), _p(alpha))
+    return dict(rgb=rgb, alpha=alpha, last_o=ro, last_d=rd)
+
+
+def playground_standin_check(n=3000, seed=12):
+    """The Slang stand-in of the playground build (shim/3dgrt_slang/...) against the reference's hand-written CUDA twin (processHit of
+    3dgrt/kernels/cuda/gaussianParticles.cuh through libref_hit_deg4.so): same rays, same particles -> (largest state difference, accepted by
+    the stand-in, accepted by the twin)."""
+    pg = C.CDLL(os.path.join(REF, "libref_playground_deg4.so"))
+    grt = C.CDLL(os.path.join(REF, "libref_hit_deg4.so"))
+    pg.ref_playground_standin_process_hit.restype = C.c_float
+    c = cases(n, seed)
+    worst, acc_s, acc_t = 0.0, 0, 0
+    for i in range(n):
+        o, d, prm, sph = (np.ascontiguousarray(c[k][i]) for k in ("ray_o", "ray_d", "density12", "sph48"))
+        T, D = np.ones(1, F), np.zeros(1, F)
+        w = pg.ref_playground_standin_process_hit(_p(o), _p(d), _p(prm), _p(T), _p(D))
+        rad = np.zeros(3, F)
+        pg.ref_playground_standin_integrate(_p(d), C.c_float(w), _p(sph), C.c_uint(3), _p(rad))
+        st = np.array([1, 0, 0, 0, 0, 0, 0, 0], F)   # transmittance, radiance(3), depth, normal(3)
+        acc = grt.ref_process_hit(_p(o), _p(d), _p(prm), _p(sph), C.c_float(MIN_RESPONSE), C.c_float(MIN_ALPHA), C.c_int(3), C.c_int(0), _p(st))
+        acc_s += int(w > 0)
+        acc_t += int(acc)
+        worst = max(worst, abs(float(T[0]) - float(st[0])), float(np.abs(rad - st[1:4]).max()), abs(float(D[0]) - float(st[4])))
+    return worst, acc_s, acc_t
+
+
+def make_playground():
+    """tests/golden/playground.npz: the reference's hybrid mesh + Gaussian path tracer (playgroundKernel.cu: raygen path loop, closest-hit
+    material dispatch, miss; materials.cuh; trace.cuh; 3dgrtTracer.cuh) run on the host over an emulated OptiX (oracle/ref/ref_playground.cpp)
+    on the seeded scenes of tests/playground_scenes.py: mirror / glass / textured diffuse, five PBR materials (metal, transmissive dielectric,
+    fully textured with tangents, alpha-masked, alpha-blended), smooth and hard normals, textures on and off, with and without Gaussians."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import playground_scenes as ps
+    out = {}
+    for name, kind, opts, bounces, frame in ps.GOLDEN_CASES:
+        sc = ps.make_playground_scene(kind)
+        o = playground_reference(sc, opts, bounces, frame)
+        for k, a in o.items():
+            out[f"{name}_{k}"] = a
+    worst, acc_s, acc_t = playground_standin_check()
+    out["standin_vs_cuda_twin"] = np.array([worst, acc_s, acc_t], np.float64)
+    np.savez_compressed(os.path.join(HERE, "playground.npz"), **out)
+    print("wrote playground.npz; Slang stand-in vs CUDA twin: largest difference", worst, "accepted", acc_s, acc_t)
+
+
 if __name__ == "__main__":
     import sys
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
-    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "gut_render"]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "gut_render", "playground"]
     if "--adam-only" in sys.argv:
         which = ["adam"]
     if "per_hit" in which:
@@ -502,3 +590,5 @@ if __name__ == "__main__":
         make_grt_trace()
     if "gut_render" in which:
         make_gut_render()
+    if "playground" in which:
+        make_playground()
