@@ -105,14 +105,29 @@ class GrutAdamGroup(C.Structure):
 VIS_NONE, VIS_BOOL_U8, VIS_INT32, VIS_FLOAT_BITS = range(4)
 
 
+class GrtTexture(C.Structure):
+    """include/grut_amd.h: GrtTexture — [height, width, channels] f32 in device memory (data = None: no texture)."""
+    _fields_ = [("data", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32)]
+
+
+class GrtMaterial(C.Structure):
+    """include/grut_amd.h: GrtMaterial (PBRMaterial of the reference's playground)."""
+    _fields_ = [("diffuse", GrtTexture), ("emissive", GrtTexture), ("metallic_roughness", GrtTexture), ("normal", GrtTexture),
+                ("diffuse_factor", C.c_float * 4), ("emissive_factor", C.c_float * 3), ("metallic_factor", C.c_float), ("roughness_factor", C.c_float),
+                ("transmission_factor", C.c_float), ("ior", C.c_float), ("alpha_cutoff", C.c_float), ("alpha_mode", C.c_uint32)]
+
+
 class GrtMesh(C.Structure):
-    """include/grut_amd.h: GrtMesh (device pointers of the hybrid tracer's triangle mesh)."""
+    """include/grut_amd.h: GrtMesh (device pointers of the hybrid tracer's triangle mesh; the material table is a host array)."""
     _fields_ = [("num_vertices", C.c_uint32), ("num_faces", C.c_uint32), ("vertices", C.c_void_p), ("triangles", C.c_void_p),
-                ("vertex_normals", C.c_void_p), ("prim_type", C.c_void_p), ("refractive_index", C.c_void_p), ("diffuse_color", C.c_void_p)]
+                ("vertex_normals", C.c_void_p), ("vertex_tangents", C.c_void_p), ("vertex_has_tangents", C.c_void_p), ("prim_type", C.c_void_p),
+                ("mat_uv", C.c_void_p), ("mat_id", C.c_void_p), ("refractive_index", C.c_void_p), ("num_materials", C.c_uint32),
+                ("materials", C.POINTER(GrtMaterial)), ("envmap", GrtTexture), ("envmap_offset", C.c_float * 2)]
 
 
 class GrtHybridOptions(C.Structure):
-    _fields_ = [("playground_opts", C.c_uint32), ("max_pbr_bounces", C.c_uint32), ("background", C.c_float * 3)]
+    _fields_ = [("playground_opts", C.c_uint32), ("max_pbr_bounces", C.c_uint32), ("frame_number", C.c_uint32)]
+
 
 
 class GutGradIO(C.Structure):
@@ -190,7 +205,7 @@ def _declare(lib):
     lib.grt_debug_fetch_instances.restype = C.c_int
     lib.grt_debug_backward_signature.argtypes = [C.c_void_p, up, up]
     lib.grt_debug_backward_signature.restype = C.c_int
-    lib.grt_build_mesh_bvh.argtypes = [C.c_void_p, vp, C.c_uint32, fp, C.c_uint32, ip]
+    lib.grt_build_mesh_bvh.argtypes = [C.c_void_p, vp, C.c_uint32, fp, C.c_uint32, ip, C.c_int, C.c_int]
     lib.grt_build_mesh_bvh.restype = C.c_int
     lib.grt_trace_hybrid.argtypes = [C.c_void_p, vp, C.POINTER(GrtFrame), fp, fp, fp, fp, fp, C.POINTER(GrtMesh), C.POINTER(GrtHybridOptions), fp, fp, fp, up]
     lib.grt_trace_hybrid.restype = C.c_int

@@ -44,7 +44,8 @@ struct GrtHandle {
     hipEvent_t log_event = nullptr;
     bool log_event_pending = false;
     // triangle mesh of the hybrid path (grt_build_mesh_bvh): its own LBVH
-    DeviceBuffer m_aabb, m_slack, m_scene_enc, m_scene, m_codes, m_ids, m_codes_tmp, m_ids_tmp, m_sort_scratch, m_nodes, m_done;
+    DeviceBuffer m_aabb, m_slack, m_scene_enc, m_scene, m_codes, m_ids, m_codes_tmp, m_ids_tmp, m_sort_scratch, m_nodes, m_done, m_materials;
+    uint32_t* m_sorted_ids = nullptr;
     uint32_t mesh_faces = 0;
     bool mesh_built = false;
     // packet lists of the forward (GrtLists): cones, per-particle bounds and records, the binning pipeline's buffers
@@ -132,7 +133,7 @@ void grt_destroy(GrtHandle* h) {
                             &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets, &h->l_scan_scratch, &h->l_sort_scratch,
                             &h->l_block_keys, &h->l_vals, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_ranges,
                             &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state, &h->m_aabb, &h->m_slack, &h->m_scene_enc,
-                            &h->m_scene, &h->m_codes, &h->m_ids, &h->m_codes_tmp, &h->m_ids_tmp, &h->m_sort_scratch, &h->m_nodes, &h->m_done};
+                            &h->m_scene, &h->m_codes, &h->m_ids, &h->m_codes_tmp, &h->m_ids_tmp, &h->m_sort_scratch, &h->m_nodes, &h->m_done, &h->m_materials};
     for (DeviceBuffer* b : bufs) b->release();
     if (h->log_state_host) (void)hipHostFree(h->log_state_host);
     if (h->l_host) (void)hipHostFree(h->l_host);
@@ -429,11 +430,13 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
     return GRUT_OK;
 }
 
-// HybridOptixTracer::buildMeshBVH (threedgrut_playground/include/playground/hybridTracer.h:113-114): LBVH over the triangles' boxes
-// with the Gaussian builder's Morton / sort / hierarchy / refit stages.
-int grt_build_mesh_bvh(GrtHandle* h, void* stream_, uint32_t num_vertices, const float* vertices, uint32_t num_faces, const int32_t* triangles) {
+// HybridOptixTracer::buildMeshBVH (threedgrut_playground/include/playground/hybridTracer.h:121-122): LBVH over the triangles' boxes
+// with the Gaussian builder's Morton / sort / hierarchy / refit stages; rebuild = 0 + allow_update refits the existing tree.
+int grt_build_mesh_bvh(GrtHandle* h, void* stream_, uint32_t num_vertices, const float* vertices, uint32_t num_faces, const int32_t* triangles,
+                       int rebuild, int allow_update) {
     GRUT_REQUIRE(h, "grt_build_mesh_bvh: null handle");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    const bool refit_only = !rebuild && allow_update && h->mesh_built && h->mesh_faces == num_faces && num_faces > 0;
     h->mesh_built = false;   // raised again only when every stage below was enqueued
     if (num_faces == 0) {
         h->mesh_faces = 0;
@@ -454,12 +457,15 @@ int grt_build_mesh_bvh(GrtHandle* h, void* stream_, uint32_t num_vertices, const
     GRUT_CHECK(h->m_nodes.ensure(n * sizeof(GrtNode), 1.25f));
     GRUT_CHECK(h->m_done.ensure(n * 4, 1.25f));
     grt_launch_mesh_aabb(s, num_faces, vertices, triangles, h->m_aabb.as<float>(), h->m_slack.as<float>(), h->m_scene_enc.as<uint32_t>());
-    grt_launch_morton(s, num_faces, h->m_aabb.as<float>(), h->m_scene_enc.as<uint32_t>(), h->m_scene.as<float>(), h->m_codes.as<uint32_t>(),
-                      h->m_ids.as<uint32_t>());
-    uint32_t *sc = nullptr, *si = nullptr;
-    GRUT_CHECK(sort_pairs_u32(s, num_faces, nullptr, 0, 30, h->m_codes.as<uint32_t>(), h->m_ids.as<uint32_t>(), h->m_codes_tmp.as<uint32_t>(),
-                              h->m_ids_tmp.as<uint32_t>(), h->m_sort_scratch.ptr, h->m_sort_scratch.bytes, &sc, &si));
-    grt_launch_hierarchy(s, num_faces, sc, si, h->m_nodes.as<GrtNode>());
+    // (a refit keeps the sorted order, hence the child codes, of the last full build: the code / id buffers stay untouched)
+    grt_launch_morton(s, num_faces, h->m_aabb.as<float>(), h->m_scene_enc.as<uint32_t>(), h->m_scene.as<float>(),
+                      refit_only ? nullptr : h->m_codes.as<uint32_t>(), refit_only ? nullptr : h->m_ids.as<uint32_t>());
+    if (!refit_only) {
+        uint32_t *sc = nullptr, *si = nullptr;
+        GRUT_CHECK(sort_pairs_u32(s, num_faces, nullptr, 0, 30, h->m_codes.as<uint32_t>(), h->m_ids.as<uint32_t>(), h->m_codes_tmp.as<uint32_t>(),
+                                  h->m_ids_tmp.as<uint32_t>(), h->m_sort_scratch.ptr, h->m_sort_scratch.bytes, &sc, &si));
+        grt_launch_hierarchy(s, num_faces, sc, si, h->m_nodes.as<GrtNode>());
+    }
     GRUT_HIP(hipMemsetAsync(h->m_done.ptr, 0, n, s));
     grt_launch_refit(s, num_faces, h->m_aabb.as<float>(), h->m_slack.as<float>(), h->m_nodes.as<GrtNode>(), h->m_done.as<uint8_t>());
     GRUT_HIP(hipGetLastError());
@@ -468,7 +474,7 @@ int grt_build_mesh_bvh(GrtHandle* h, void* stream_, uint32_t num_vertices, const
     return GRUT_OK;
 }
 
-// HybridOptixTracer::traceHybrid (hybridTracer.h:120-141; playgroundKernel.cu:39-157): forward only, like the reference
+// HybridOptixTracer::traceHybrid (hybridTracer.h:129-141; playgroundKernel.cu:39-352): forward only, like the reference
 int grt_trace_hybrid(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
                      const float* ray_origin, const float* ray_direction, const float* ray_max_t, const GrtMesh* mesh, const GrtHybridOptions* options,
                      float* out_radiance, float* out_opacity, float* out_last_ray, uint32_t* out_bounces) {
@@ -482,21 +488,33 @@ int grt_trace_hybrid(GrtHandle* h, void* stream_, const GrtFrame* frame, const f
     GRUT_REQUIRE(frame->num_particles == h->N, "grt_trace_hybrid: %u particles but the BVH holds %u", frame->num_particles, h->N);
     GRUT_REQUIRE(mesh->num_faces == h->mesh_faces, "grt_trace_hybrid: %u faces but the mesh BVH holds %u", mesh->num_faces, h->mesh_faces);
     GRUT_REQUIRE(h->N == 0 || (particle_density && particle_sph), "grt_trace_hybrid: null particle buffer");
-    GRUT_REQUIRE(mesh->num_faces == 0 || (mesh->vertices && mesh->triangles && mesh->prim_type && mesh->refractive_index && mesh->diffuse_color),
-                 "grt_trace_hybrid: null mesh buffer");
+    GRUT_REQUIRE(mesh->num_faces == 0 || (mesh->vertices && mesh->triangles && mesh->prim_type && mesh->refractive_index), "grt_trace_hybrid: null mesh buffer");
     GRUT_REQUIRE(!(options->playground_opts & 1u) || mesh->num_faces == 0 || mesh->vertex_normals, "grt_trace_hybrid: smooth normals need vertex_normals");
+    GRUT_REQUIRE((mesh->vertex_tangents != nullptr) == (mesh->vertex_has_tangents != nullptr), "grt_trace_hybrid: vertex_tangents and vertex_has_tangents go together");
+    GRUT_REQUIRE(mesh->num_materials == 0 || mesh->materials, "grt_trace_hybrid: null material table");
     const GrtTraceParams P = trace_params(h, *frame);
     GrtBvh bvh = bvh_view(h);
-    static const float kEmptyScene[6] = {0, 0, 0, 0, 0, 0};
-    (void)kEmptyScene;
+    // the material table travels with the launch (a default material stands in when the caller has none: faces that need one then
+    // shade with the reference's own fallback values, tracer.py:150-170)
+    GrtMaterial fallback;
+    memset(&fallback, 0, sizeof(fallback));
+    fallback.diffuse_factor[0] = fallback.diffuse_factor[1] = fallback.diffuse_factor[2] = fallback.diffuse_factor[3] = 1.f;
+    fallback.alpha_cutoff = 0.5f;
+    const uint32_t nm = mesh->num_materials ? mesh->num_materials : 1u;
+    GRUT_CHECK(h->m_materials.ensure((size_t)nm * sizeof(GrtMaterial), 2.f));
+    GRUT_HIP(hipMemcpyAsync(h->m_materials.ptr, mesh->num_materials ? mesh->materials : &fallback, (size_t)nm * sizeof(GrtMaterial), hipMemcpyHostToDevice, s));
+    GRUT_HIP(hipStreamSynchronize(s));   // (the source is the caller's pageable host memory)
     GrtMeshView mv;
     mv.nodes = h->m_nodes.as<GrtNode>();
-    mv.vertices = mesh->vertices; mv.triangles = mesh->triangles; mv.vnormals = mesh->vertex_normals; mv.prim_type = mesh->prim_type;
-    mv.refr = mesh->refractive_index; mv.diffuse = mesh->diffuse_color; mv.F = mesh->num_faces;
+    mv.vertices = mesh->vertices; mv.triangles = mesh->triangles; mv.vnormals = mesh->vertex_normals; mv.vtangents = mesh->vertex_tangents;
+    mv.vhas_tangents = mesh->vertex_has_tangents; mv.prim_type = mesh->prim_type; mv.mat_uv = mesh->mat_uv; mv.mat_id = mesh->mat_id;
+    mv.refr = mesh->refractive_index; mv.materials = h->m_materials.as<GrtMaterial>(); mv.num_materials = nm; mv.envmap = mesh->envmap;
+    mv.envmap_offset[0] = mesh->envmap_offset[0]; mv.envmap_offset[1] = mesh->envmap_offset[1];
+    mv.F = mesh->num_faces;
     GrtHybridParams hp;
     hp.opts = options->playground_opts;
     hp.max_pbr_bounces = options->max_pbr_bounces;
-    for (int k = 0; k < 3; ++k) hp.background[k] = options->background[k];
+    hp.frame_number = options->frame_number;
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
     GrtLists lists;   // the primary segment of every path scans the frame's packet lists when the rays share their origin
     GRUT_CHECK(build_lists(h, s, P, bvh, ray_origin, ray_direction, &lists));

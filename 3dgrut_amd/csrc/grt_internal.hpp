@@ -93,21 +93,29 @@ struct GrtHitLog {
     uint32_t capacity_chunks, max_rounds;
 };
 
-// triangle mesh of the hybrid path (playground): its own LBVH over triangle boxes + the per-face / per-vertex attributes
+// triangle mesh of the hybrid path (playground): its own LBVH over triangle boxes + the per-face / per-vertex attributes, the material
+// table (device copy of the caller's GrtMaterial array) and the environment map
 struct GrtMeshView {
     const GrtNode* nodes;        // [max(F-1, 1)]
     const float* vertices;       // [V,3]
     const int32_t* triangles;    // [F,3]
     const float* vnormals;       // [V,3]
+    const float* vtangents;      // [V,3] or null
+    const uint8_t* vhas_tangents;// [V] or null
     const int32_t* prim_type;    // [F] PlaygroundPrimitiveTypes
+    const float* mat_uv;         // [F,3,2] or null
+    const int32_t* mat_id;       // [F] or null
     const float* refr;           // [F]
-    const float* diffuse;        // [F,3]
+    const GrtMaterial* materials;// device
+    uint32_t num_materials;
+    GrtTexture envmap;
+    float envmap_offset[2];
     uint32_t F;
 };
 struct GrtHybridParams {
-    uint32_t opts;               // PlaygroundRenderOptions: bit 0 smooth normals, bit 1 Gaussian tracing off
+    uint32_t opts;               // PlaygroundRenderOptions
     uint32_t max_pbr_bounces;
-    float background[3];
+    uint32_t frame_number;
 };
 
 // build stages

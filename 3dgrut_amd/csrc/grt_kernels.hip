@@ -1627,6 +1627,205 @@ __device__ __forceinline__ bool refract_dir(f3& out, f3 d, f3 n, float etai_over
     return true;
 }
 
+// ---- materials of the playground (materials.cuh), random streams (rng.cuh), textures, environment ------------------------------------
+// tex2D with the modes of playground/cutexture.h:54-60: normalised coordinates, clamp-to-edge, bilinear (float weights), float texels
+__device__ __forceinline__ float4 tex_fetch(const GrtTexture& t, float u, float v) {
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t.data) {
+        const float x = u * (float)t.width - 0.5f, y = v * (float)t.height - 0.5f;
+        const float fx = floorf(x), fy = floorf(y);
+        const float ax = x - fx, ay = y - fy;
+        const int x0 = min(max((int)fx, 0), t.width - 1), x1 = min(max((int)fx + 1, 0), t.width - 1);
+        const int y0 = min(max((int)fy, 0), t.height - 1), y1 = min(max((int)fy + 1, 0), t.height - 1);
+        for (int c = 0; c < t.channels && c < 4; ++c) {
+            const float t00 = t.data[((size_t)y0 * t.width + x0) * t.channels + c], t10 = t.data[((size_t)y0 * t.width + x1) * t.channels + c];
+            const float t01 = t.data[((size_t)y1 * t.width + x0) * t.channels + c], t11 = t.data[((size_t)y1 * t.width + x1) * t.channels + c];
+            o[c] = (1.f - ay) * ((1.f - ax) * t00 + ax * t10) + ay * ((1.f - ax) * t01 + ax * t11);
+        }
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ uint32_t pg_tea16(uint32_t val0, uint32_t val1) {   // tea<16>, rng.cuh:21-35
+    uint32_t v0 = val0, v1 = val1, s0 = 0u;
+#pragma unroll 1
+    for (int n = 0; n < 16; ++n) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+__device__ __forceinline__ float pg_rnd(uint32_t& prev) {   // lcg + rnd, rng.cuh:38-54
+    prev = 1664525u * prev + 1013904223u;
+    return (float)(prev & 0x00FFFFFFu) / (float)0x01000000;
+}
+__device__ __forceinline__ f3 pg_rnd_pcg3d(uint32_t x, uint32_t y, uint32_t z) {   // rng.cuh:62-76
+    x = x * 1664525u + 1013904223u; y = y * 1664525u + 1013904223u; z = z * 1664525u + 1013904223u;
+    x += y * z; y += z * x; z += x * y;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16;
+    x += y * z; y += z * x; z += x * y;
+    const float k = 2.3283064365386963e-10f;   // 1 / float(0xffffffff) = 2^-32
+    return mk3((float)x * k, (float)y * k, (float)z * k);
+}
+constexpr float kPbrEps = 1e-6f, kPgPi = 3.141592654f;
+__device__ __forceinline__ f3 pg_normalize(f3 v) {   // materials.cuh:79-82 (threshold on the squared norm, not safe_normalize)
+    const float n = dot(v, v);
+    return (n > kPbrEps) ? v * (1.f / sqrtf(n)) : v;
+}
+__device__ __forceinline__ float pg_pdot(f3 a, f3 b) { return fminf(1.f, fmaxf(0.f, dot(a, b))); }   // positive_dot
+struct PgHit {
+    uint32_t tri;
+    float bu, bv;
+};
+__device__ __forceinline__ void pg_tex_coords(const GrtMeshView& m, const PgHit& h, float& u, float& v) {   // materials.cuh:41-48
+    u = v = 0.f;
+    if (!m.mat_uv) return;
+    const float* uv = m.mat_uv + 6 * (size_t)h.tri;
+    const float w0 = 1.f - h.bu - h.bv;
+    u = w0 * uv[0] + h.bu * uv[2] + h.bv * uv[4];
+    v = w0 * uv[1] + h.bu * uv[3] + h.bv * uv[5];
+}
+__device__ __forceinline__ const GrtMaterial& pg_material(const GrtMeshView& m, uint32_t tri) {
+    const uint32_t id = m.mat_id ? (uint32_t)m.mat_id[tri] : 0u;
+    return m.materials[id < m.num_materials ? id : 0u];
+}
+__device__ __forceinline__ f3 pg_diffuse_color(const GrtMeshView& m, const PgHit& h, uint32_t opts, f3 ray_d, f3 normal) {   // get_diffuse_color, :34-66
+    const GrtMaterial& mat = pg_material(m, h.tri);
+    float u, v;
+    pg_tex_coords(m, h, u, v);
+    f3 diffuse = mk3(mat.diffuse_factor[0], mat.diffuse_factor[1], mat.diffuse_factor[2]);
+    if (mat.diffuse.data && !(opts & 4u)) {
+        const float4 t = tex_fetch(mat.diffuse, u, v);
+        diffuse = mk3(t.x, t.y, t.z) * diffuse;
+    }
+    return diffuse * fabsf(dot(ray_d, normal));
+}
+__device__ __forceinline__ f3 pg_normal_space(const GrtMeshView& m, const PgHit& h, f3 normal, f3 dir) {   // compute_normal_space, :84-135
+    const int32_t i0 = m.triangles[3 * (size_t)h.tri], i1 = m.triangles[3 * (size_t)h.tri + 1], i2 = m.triangles[3 * (size_t)h.tri + 2];
+    f3 tangent;
+    if (m.vhas_tangents && m.vhas_tangents[i0] && m.vhas_tangents[i1] && m.vhas_tangents[i2]) {   // get_smooth_tangent
+        const float* t0 = m.vtangents + 3 * (size_t)i0; const float* t1 = m.vtangents + 3 * (size_t)i1; const float* t2 = m.vtangents + 3 * (size_t)i2;
+        const float w0 = 1.f - h.bu - h.bv;
+        tangent = mk3(w0 * t0[0] + h.bu * t1[0] + h.bv * t2[0], w0 * t0[1] + h.bu * t1[1] + h.bv * t2[1], w0 * t0[2] + h.bu * t1[2] + h.bv * t2[2]);
+        const float len = sqrtf(dot(tangent, tangent));
+        tangent = mk3(tangent.x / len, tangent.y / len, tangent.z / len);
+    } else if (fabsf(normal.x) > fabsf(normal.z)) tangent = mk3(-normal.y, normal.x, 0.f);
+    else tangent = mk3(0.f, -normal.z, normal.y);
+    tangent = pg_normalize(tangent);
+    const f3 bitangent = pg_normalize(cross(normal, tangent));
+    return pg_normalize(mk3(tangent.x * dir.x + bitangent.x * dir.y + normal.x * dir.z, tangent.y * dir.x + bitangent.y * dir.y + normal.y * dir.z,
+                            tangent.z * dir.x + bitangent.z * dir.y + normal.z * dir.z));
+}
+__device__ __forceinline__ f3 pg_sample_specular(const GrtMeshView& m, const PgHit& h, f3 normal, float theta_seed, float phi_seed, float roughness) {   // :151-164
+    const float alpha = roughness * roughness;
+    const float theta = acosf(sqrtf((1.f - theta_seed) / (1.f + (alpha * alpha - 1.f) * theta_seed)));
+    const float phi = 2.f * kPgPi * phi_seed;
+    return pg_normal_space(m, h, normal, mk3(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta)));
+}
+__device__ __forceinline__ float pg_g1(float ndv, float roughness) {   // geometry_schlick_ggx, :196-201
+    const float alpha = 0.5f * roughness * roughness;
+    return ndv / fmaxf(ndv * (1.f - alpha) + alpha, kPbrEps);
+}
+__device__ __forceinline__ f3 pg_fresnel(float cosine, f3 f0) {   // fresnel_schlick, :212-215
+    const float p = powf(1.f - cosine, 5.f);
+    return mk3(f0.x + (1.f - f0.x) * p, f0.y + (1.f - f0.y) * p, f0.z + (1.f - f0.z) * p);
+}
+struct PgPbr {   // the fields of HybridRayPayload the PBR branch writes
+    f3 bsdf, emissive;
+    uint32_t pbr_bounces, rnd_seed;
+};
+// sampled_cook_torrance_brdf + sampled_microfacet_brdf (materials.cuh:231-440): material fetch (factors x textures), normal map, alpha
+// test, one of the three sampled lobes (transmission / diffuse / specular) chosen by the pixel's random stream
+__device__ __noinline__ void pg_cook_torrance(const GrtMeshView& m, const PgHit& h, uint32_t opts, f3 ray_d, f3 normal, uint32_t px, uint32_t py,
+                                              uint32_t frame, PgPbr& st, f3& new_dir) {
+    const f3 wo = pg_normalize(ray_d * -1.f);
+    const GrtMaterial& mat = pg_material(m, h.tri);
+    const bool notex = (opts & 4u) != 0u;
+    float u, v;
+    pg_tex_coords(m, h, u, v);
+    f3 base = mk3(mat.diffuse_factor[0], mat.diffuse_factor[1], mat.diffuse_factor[2]);
+    float alpha = mat.diffuse_factor[3];
+    if (mat.diffuse.data && !notex) {
+        const float4 t = tex_fetch(mat.diffuse, u, v);
+        base = mk3(t.x, t.y, t.z) * base;
+        alpha *= t.w;
+    }
+    f3 emissive = mk3(mat.emissive_factor[0], mat.emissive_factor[1], mat.emissive_factor[2]);
+    if (mat.emissive.data && !notex) {
+        const float4 t = tex_fetch(mat.emissive, u, v);
+        emissive = mk3(t.x, t.y, t.z) * emissive;
+    }
+    float metalness = mat.metallic_factor, roughness = mat.roughness_factor;
+    if (mat.metallic_roughness.data && !notex) {
+        const float4 t = tex_fetch(mat.metallic_roughness, u, v);
+        metalness = t.x * mat.metallic_factor;
+        roughness = t.y * mat.roughness_factor;
+    }
+    if (mat.normal.data && !notex) {
+        const float4 t = tex_fetch(mat.normal, u, v);
+        normal = pg_normal_space(m, h, normal, mk3(t.x, t.y, t.z));
+    }
+    bool pass = true;   // alpha_test, :166-181
+    if (mat.alpha_mode == 1u) pass = alpha > pg_rnd(st.rnd_seed);
+    else if (mat.alpha_mode == 2u) pass = alpha > mat.alpha_cutoff;
+    if (!pass) { new_dir = ray_d; return; }
+    const float transmission = mat.transmission_factor, ior = mat.ior;
+    const f3 rnd = pg_rnd_pcg3d(px, py, frame + st.pbr_bounces);
+    const float phi_seed = rnd.x, theta_seed = rnd.y, ray_prob = rnd.z;
+    const float fr = 0.5f;
+    f3 f0 = mk3(0.16f * fr * fr, 0.16f * fr * fr, 0.16f * fr * fr);
+    f0 = mk3(f0.x + metalness * (base.x - f0.x), f0.y + metalness * (base.y - f0.y), f0.z + metalness * (base.z - f0.z));
+    f3 out, L;
+    if ((ray_prob < 0.5f) && ((2.f * ray_prob) < transmission)) {   // transmissive
+        const float front = dot(wo, normal);
+        const f3 fn = front >= 0.f ? normal : normal * -1.f;
+        const float eta = front >= 0.f ? 1.f / ior : ior;
+        const f3 H = pg_sample_specular(m, h, fn, theta_seed, phi_seed, roughness);
+        const f3 wi = wo * -1.f;   // pbr_refract(-wo, H, eta), :217-222
+        const float ndi = dot(H, wi);
+        const float kk = 1.f - eta * eta * (1.f - ndi * ndi);
+        L = (kk < 0.f) ? mk3(0.f, 0.f, 0.f) : (wi * eta - H * (eta * ndi + sqrtf(kk)));
+        const float ndo = pg_pdot(fn, wo), ndl = pg_pdot(fn * -1.f, L), ndh = pg_pdot(fn, H), odh = pg_pdot(wo, H);
+        const f3 Fv = pg_fresnel(odh, f0);
+        const float G = pg_g1(ndo, roughness) * pg_g1(ndl, roughness);
+        const float k = G * odh / fmaxf(ndh * ndo, 0.001f);
+        out = mk3(base.x * (1.f - Fv.x) * k, base.y * (1.f - Fv.y) * k, base.z * (1.f - Fv.z) * k);
+    } else if ((ray_prob < 0.5f) && ((2.f * ray_prob) >= transmission)) {   // diffuse (importance_sample_diffuse_ggx, :137-149)
+        const float theta = asinf(theta_seed), phi = 2.f * kPgPi * phi_seed;
+        L = pg_normal_space(m, h, normal, mk3(sinf(theta) * cosf(phi), sinf(theta) * sinf(phi), cosf(theta)));
+        const f3 H = pg_normalize(wo + L);
+        const f3 Fv = pg_fresnel(pg_pdot(wo, H), f0);
+        const float nm = 1.f - metalness;
+        out = mk3((1.f - Fv.x) * nm * base.x, (1.f - Fv.y) * nm * base.y, (1.f - Fv.z) * nm * base.z);
+    } else {   // specular
+        const f3 H = pg_sample_specular(m, h, normal, theta_seed, phi_seed, roughness);
+        const f3 mwo = wo * -1.f;
+        L = mwo - H * (2.f * dot(H, mwo));
+        const float ndo = pg_pdot(normal, wo), ndh = pg_pdot(normal, H), ndl = pg_pdot(normal, L), odh = pg_pdot(wo, H);
+        const f3 Fv = pg_fresnel(odh, f0);
+        const float G = pg_g1(ndo, roughness) * pg_g1(ndl, roughness);
+        out = Fv * (G * odh / fmaxf(ndh * ndo, 0.001f));
+    }
+    new_dir = L;
+    st.pbr_bounces += 1u;
+    out = out * 2.f;   // compensates for splitting diffuse and specular
+    st.bsdf = mk3(fmaxf(out.x, 0.f), fmaxf(out.y, 0.f), fmaxf(out.z, 0.f));
+    st.emissive = emissive;
+}
+__device__ __forceinline__ f3 pg_background(const GrtMeshView& m, f3 d) {   // getBackgroundColor, trace.cuh:233-257
+    const float kPi = 3.14159265358979323846f;
+    const float rotY = m.envmap_offset[0] * 2.0f * kPi, rotX = 2.0f * m.envmap_offset[1] * kPi;
+    const float cy = cosf(rotY), sy = sinf(rotY), cx = cosf(rotX), sx = sinf(rotX);
+    const f3 r1 = mk3(d.x * cy - d.z * sy, d.y, d.x * sy + d.z * cy);
+    const f3 r2 = mk3(r1.x, r1.y * cx - r1.z * sx, r1.y * sx + r1.z * cx);
+    const float theta = atan2f(r2.x, r2.z);
+    const float phi = kPi * 0.5f - acosf(fminf(1.f, fmaxf(-1.f, r2.y)));
+    const float u = (theta + kPi) * (0.5f * 0.318309886183790671538f);
+    const float v = 0.5f * (1.0f + sinf(phi));
+    const float4 t = tex_fetch(m.envmap, u, v);
+    return mk3(t.x, t.y, t.z);
+}
+
 template <int DEG>
 __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh bvh, GrtMeshView mesh, GrtHybridParams hp,
                                                         const float4* __restrict__ density12, const float* __restrict__ sph,
@@ -1645,12 +1844,18 @@ __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh
     const size_t pix = in_image ? (size_t)py * P.W + px : 0;
     RayW r = make_ray(P, ray_o, ray_d, pix);
     const float ray_t_max = ray_max_t ? ray_max_t[pix] : 1e30f;
-    const bool gaussians = !(hp.opts & 2u) && bvh.N > 0;
+    const bool gaussians = !(hp.opts & 2u);        // PGRNDRenderDisableGaussianTracing
+    const bool trace_gs = gaussians && bvh.N > 0;   // (an empty cloud has no tree to walk)
     // payload (playgroundKernel.cu:51-68) and the ray's running volumetric state (RayData: radiance, density = 1 - T)
     f3 accC = mk3(0.f, 0.f, 0.f), direct = accC, thr = mk3(1.f, 1.f, 1.f), rad = accC;
     float accA = 0.f, T = 1.f;
     uint32_t bounces = 0u, timeout = 0u;
-    bool missed = false, terminate = false;
+    PgPbr pbr;
+    pbr.pbr_bounces = 0u;
+    pbr.rnd_seed = pg_tea16((uint32_t)P.W * (uint32_t)py + (uint32_t)px, hp.frame_number);
+    pbr.bsdf = mk3(1.f, 1.f, 1.f); pbr.emissive = mk3(0.f, 0.f, 0.f);
+    bool missed = false, timed_out = false;
+    int state = 0;   // PlaygroundTraceState: 0 primitives pass, 1 Gaussians pass, 2 terminate
     f3 lastO = r.o, lastD = r.d;
     // the primary segment of every path (all rays of the frame start at one point) scans the packet's candidate list instead of walking the
     // tree; after the first surface the rays have their own origins
@@ -1665,75 +1870,84 @@ __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh
     }
     bool primary = true;
     while (true) {
-        const bool go = in_image && !missed && (sqrtf(dot(thr, thr)) > 0.0001f) && (accA < 0.995f) && (0u < hp.max_pbr_bounces) && (bounces < 32u) &&
-                        !terminate && (timeout <= 1000u);
+        const bool go = in_image && !missed && !timed_out && (sqrtf(dot(thr, thr)) > 0.0001f) && (accA < 0.995f) && (pbr.pbr_bounces < hp.max_pbr_bounces) &&
+                        (bounces < 32u) && (state != 2);
         if (!__any(go)) break;
+        if (go) { pbr.bsdf = mk3(1.f, 1.f, 1.f); pbr.emissive = mk3(0.f, 0.f, 0.f); state = 0; }
         // traceMesh + __closesthit__ch / __miss__ms
         const MeshHit mh = mesh_closest(mesh, r, 1e-5f, 1e5f, go, lane, s_stack);
         const bool hit = go && mh.tri != 0xFFFFFFFFu;
         if (go && !hit) missed = true;
         float hit_t = mh.t;
-        f3 new_dir = mk3(0.f, 0.f, 0.f);
+        f3 new_dir = mk3(0.f, 0.f, 0.f), normal = mk3(0.f, 0.f, 1.f);
         int type = 0;
+        PgHit ph = {0u, 0.f, 0.f};
         if (hit) {
+            ph.tri = mh.tri; ph.bu = mh.u; ph.bv = mh.v;
             const int32_t i0 = mesh.triangles[3 * (size_t)mh.tri], i1 = mesh.triangles[3 * (size_t)mh.tri + 1], i2 = mesh.triangles[3 * (size_t)mh.tri + 2];
-            f3 n;
-            if (hp.opts & 1u) {   // interpolated vertex normals
+            if (hp.opts & 1u) {   // interpolated vertex normals (getSmoothNormal, playgroundKernel.cu:253-274)
                 const float w0 = 1.f - mh.u - mh.v;
                 const float* n0 = mesh.vnormals + 3 * (size_t)i0; const float* n1 = mesh.vnormals + 3 * (size_t)i1; const float* n2 = mesh.vnormals + 3 * (size_t)i2;
-                n = mk3(w0 * n0[0] + mh.u * n1[0] + mh.v * n2[0], w0 * n0[1] + mh.u * n1[1] + mh.v * n2[1], w0 * n0[2] + mh.u * n1[2] + mh.v * n2[2]);
-                n = n * (1.f / sqrtf(dot(n, n)));
-            } else {
+                normal = mk3(w0 * n0[0] + mh.u * n1[0] + mh.v * n2[0], w0 * n0[1] + mh.u * n1[1] + mh.v * n2[1], w0 * n0[2] + mh.u * n1[2] + mh.v * n2[2]);
+                const float len = sqrtf(dot(normal, normal));
+                normal = mk3(normal.x / len, normal.y / len, normal.z / len);
+            } else {              // getHardNormal (:276-286)
                 const float* p0 = mesh.vertices + 3 * (size_t)i0; const float* p1 = mesh.vertices + 3 * (size_t)i1; const float* p2 = mesh.vertices + 3 * (size_t)i2;
-                n = safe_normalize3(cross(mk3(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]), mk3(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2])));
+                normal = safe_normalize3(cross(mk3(p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]), mk3(p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2])));
             }
             type = mesh.prim_type[mh.tri];
-            if (type == 1) { new_dir = mirror_dir(r.d, n); bounces++; }
+            state = (type == 3) ? 2 : 1;
+            if (type == 1) { new_dir = mirror_dir(r.d, normal); bounces++; }
             else if (type == 2) {
                 const float ior = mesh.refr[mh.tri] / 1.0003f;
-                if (refract_dir(new_dir, r.d, n, ior)) hit_t += 1e-5f;
-                else { new_dir = mirror_dir(r.d, n); bounces++; }
+                if (refract_dir(new_dir, r.d, normal, ior)) hit_t += 1e-5f;
+                else { new_dir = mirror_dir(r.d, normal); bounces++; }
+            } else if (type == 4) {   // handlePBR (:226-233)
+                pg_cook_torrance(mesh, ph, hp.opts, r.d, normal, (uint32_t)px, (uint32_t)py, hp.frame_number, pbr, new_dir);
+                const float len = sqrtf(dot(new_dir, new_dir));
+                new_dir = mk3(new_dir.x / len, new_dir.y / len, new_dir.z / len);
             } else if (type != 3) new_dir = r.d;
         }
-        // handleDiffuse: the Gaussians in front of the surface, then the opaque surface itself
+        // handleDiffuse (:235-251): the Gaussians in front of the surface, then the opaque surface itself
         const bool diffuse = hit && type == 3;
         if (__any(diffuse)) {
             const float T0 = T;
             const f3 rad0 = rad;
-            if (gaussians) {
+            if (trace_gs) {
                 if (primary && use_lists) trace_segment<DEG, true>(P, bvh, density12, sph, r, 1e-9f, hit_t, diffuse, lane, s_stack, s_hit_t, s_hit_id, T, rad, &lists, &cone, dmin, dmax, list_begin, list_end);
                 else trace_segment<DEG>(P, bvh, density12, sph, r, 1e-9f, hit_t, diffuse, lane, s_stack, s_hit_t, s_hit_id, T, rad);
             }
             if (diffuse) {
                 accC = accC + (rad - rad0);
                 accA += (1.f - T) - (1.f - T0);
-                const float* dc = mesh.diffuse + 3 * (size_t)mh.tri;
+                const f3 dc = pg_diffuse_color(mesh, ph, hp.opts, r.d, normal);
                 const float sa = 1.f - accA;
-                accC = accC + mk3(sa * dc[0], sa * dc[1], sa * dc[2]);
+                accC = accC + dc * sa;
                 accA += sa;
-                terminate = true;
             }
         }
-        // the Gaussians between the ray origin and the surface (or the ray's end)
+        // the Gaussians between the ray origin and the surface (or the ray's end); traceGaussians sets the trace state itself (trace.cuh:209)
         {
             const float next_t = missed ? ray_t_max : hit_t;
             const float T0 = T;
             const f3 rad0 = rad;
-            if (gaussians) {
+            if (trace_gs) {
                 if (primary && use_lists) trace_segment<DEG, true>(P, bvh, density12, sph, r, 1e-9f, next_t, go, lane, s_stack, s_hit_t, s_hit_id, T, rad, &lists, &cone, dmin, dmax, list_begin, list_end);
                 else trace_segment<DEG>(P, bvh, density12, sph, r, 1e-9f, next_t, go, lane, s_stack, s_hit_t, s_hit_id, T, rad);
             }
             primary = false;
             if (go) {
+                if (gaussians) state = 1;
                 const f3 radiance = rad - rad0;
                 const float density = (1.f - T) - (1.f - T0);
                 accA += density * (1.f - accA);
                 accC = accC + thr * radiance;
                 direct = direct + radiance;
                 thr = thr * (1.f - density);
-                accC = accC + thr * direct;   // nextEmissive = 0 and bsdfValue = 1 without PBR primitives
+                accC = accC + thr * (direct + pbr.emissive);
+                thr = thr * pbr.bsdf;
                 lastO = r.o; lastD = r.d;
-                timeout++;
+                if (++timeout > 1000u) timed_out = true;
                 if (hit) {   // next ray of the path
                     r.o = r.o + r.d * hit_t;
                     r.d = new_dir;
@@ -1743,7 +1957,7 @@ __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh
         }
     }
     if (!in_image) return;
-    direct = direct + mk3(hp.background[0], hp.background[1], hp.background[2]);
+    direct = direct + pg_background(mesh, lastD);
     thr = thr * (1.f - accA);
     accC = accC + thr * direct;
     accA = fminf(fmaxf(accA, 0.f), 1.f);

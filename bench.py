@@ -213,69 +213,74 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
     return result
 
 
-def hybrid_mesh(subdiv=24):
-    """Mesh of the config-5 workload: a mirror sphere (UV sphere, subdiv x 2 subdiv quads) at the cloud's centre, a glass slab in front of
-    the camera side and a diffuse floor — a few thousand triangles, the three non-PBR primitive types of the playground."""
-    V, F, prim = [], [], []
-    for i in range(subdiv + 1):
-        th = np.pi * i / subdiv
-        for j in range(2 * subdiv):
-            ph = np.pi * j / subdiv
-            V.append([0.45 * np.sin(th) * np.cos(ph), 0.45 * np.sin(th) * np.sin(ph), 0.45 * np.cos(th)])
-    for i in range(subdiv):
-        for j in range(2 * subdiv):
-            a, b = i * 2 * subdiv + j, i * 2 * subdiv + (j + 1) % (2 * subdiv)
-            c, d = a + 2 * subdiv, b + 2 * subdiv
-            F += [[a, c, b], [b, c, d]]
-            prim += [1, 1]
-    base = len(V)
-    V += [[-0.7, -0.7, 1.25], [0.7, -0.7, 1.25], [0.7, 0.7, 1.25], [-0.7, 0.7, 1.25]]          # glass slab (top side of the cube)
-    F += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
-    prim += [2, 2]
-    base = len(V)
-    V += [[-1.6, -1.6, -1.15], [1.6, -1.6, -1.15], [1.6, 1.6, -1.15], [-1.6, 1.6, -1.15]]      # diffuse floor
-    F += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
-    prim += [3, 3]
-    V = np.asarray(V, np.float32)
-    n = V / np.maximum(np.linalg.norm(V, axis=1, keepdims=True), 1e-9)
-    n[-8:] = [0, 0, 1]
-    return dict(vertices=V, triangles=np.asarray(F, np.int32), vertex_normals=n.astype(np.float32), prim_type=np.asarray(prim, np.int32),
-                refractive_index=np.full(len(F), 1.45, np.float32), diffuse_color=np.tile(np.array([[0.6, 0.6, 0.55]], np.float32), (len(F), 1)))
-
-
-def bench_hybrid(args, dev, n, W, H, ms, emit=True):
-    """BASELINE config 5 (forward only, like the reference's playground): world-space fisheye rays through the hybrid tracer."""
+def hybrid_scene(n, W, H, ms):
+    """BASELINE config 5: `n` trained-like Gaussians + a triangle mesh with every primitive type of the playground — a mirror sphere, a
+    glass pane, a textured diffuse floor and PBR spheres (metal, transmissive dielectric, fully textured) with a material table,
+    textures and an environment map — seen through a 140-degree fisheye from inside the cloud; world-space rays."""
+    import playground_scenes as ps
     syn = importlib.import_module("3dgrut_amd.synthetic")
-    pt = importlib.import_module("3dgrut_amd.playground_tracer")
     d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=ms)
     Kf = syn.fisheye_intrinsics(W, H, fov_deg=140.0)
     ro, rd = syn.fisheye_rays(W, H, Kf)
     T = syn.orbit_pose(0, n_views=8, radius=2.4).astype(np.float32)   # close to the cloud: the fisheye frame is mostly covered
-    ro_w = (ro @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
-    rd_w = (rd @ T[:3, :3].T).astype(np.float32)
-    mesh = hybrid_mesh()
+    ro_w = (ro @ T[:3, :3].T + T[:3, 3]).astype(np.float32).reshape(H, W, 3)
+    rd_w = (rd @ T[:3, :3].T).astype(np.float32).reshape(H, W, 3)
+    mats = [ps.material(diffuse=(0.9, 0.8, 0.7, 1.0), diffuse_tex=ps.texture(64, 64, 4, 1, 0.2, 1.0)),                        # 0 diffuse floor
+            ps.material(diffuse=(0.95, 0.75, 0.3, 1.0), metallic=1.0, roughness=0.25),                                         # 1 metal
+            ps.material(diffuse=(0.9, 0.95, 1.0, 1.0), roughness=0.1, transmission=0.85, ior=1.4),                             # 2 transmissive
+            ps.material(diffuse=(1.0, 1.0, 1.0, 1.0), emissive=(0.3, 0.25, 0.2), metallic=0.6, roughness=0.8,
+                        diffuse_tex=ps.texture(128, 128, 4, 2, 0.1, 1.0), emissive_tex=ps.texture(32, 32, 4, 3, 0.0, 0.5),
+                        metallic_roughness_tex=ps.texture(64, 64, 2, 4, 0.05, 1.0), normal_tex=ps.texture(64, 64, 4, 5, 0.3, 1.0))]   # 3 textured
+    parts = []
+    v, f, nn, uv = ps.uv_sphere((0.0, 0.0, 0.0), 0.45, 24)
+    parts.append((v, f, nn, uv, ps.PRIM_MIRROR, 0, 1.0, None))
+    for k, (c, m) in enumerate([((0.9, 0.3, 0.2), 1), ((-0.8, 0.5, 0.1), 2), ((0.2, -0.9, 0.3), 3)]):
+        v, f, nn, uv = ps.uv_sphere(c, 0.3, 16)
+        parts.append((v, f, nn, uv, ps.PRIM_PBR, m, 1.0, None))
+    v, f, nn, uv = ps.quad([[-0.7, -0.7, 1.25], [0.7, -0.7, 1.25], [0.7, 0.7, 1.25], [-0.7, 0.7, 1.25]], (0, 0, 1))
+    parts.append((v, f, nn, uv, ps.PRIM_GLASS, 0, 1.45, None))
+    v, f, nn, uv = ps.quad([[-1.6, -1.6, -1.15], [1.6, -1.6, -1.15], [1.6, 1.6, -1.15], [-1.6, 1.6, -1.15]], (0, 0, 1))
+    parts.append((v, f, nn, uv, ps.PRIM_DIFFUSE, 0, 1.0, None))
+    return dict(density12=d12, sph=sph, ray_o=np.ascontiguousarray(ro_w), ray_d=np.ascontiguousarray(rd_w), W=W, H=H, mesh=ps._assemble(parts),
+                materials=mats, envmap=ps.texture(64, 128, 4, 9, 0.05, 0.9), envmap_offset=np.array([0.13, 0.04], np.float32),
+                ray_max_t=np.full((H, W), 1e9, np.float32))
+
+
+def bench_hybrid(args, dev, n, W, H, ms, emit=True):
+    """BASELINE config 5 (forward only, like the reference's playground): world-space fisheye rays through the hybrid tracer."""
+    import playground_scenes as ps
+    syn = importlib.import_module("3dgrut_amd.synthetic")
+    pt = importlib.import_module("3dgrut_amd.playground_tracer")
+    sc = hybrid_scene(n, W, H, ms)
+    mesh = sc["mesh"]
     tr = pt.Tracer({"render": {"enable_kernel_timings": True}})
-    g = syn.SimpleGaussians(d12, sph, device=dev, requires_grad=False)
-    t = lambda a: torch.as_tensor(a, device=dev)
+    g = syn.SimpleGaussians(sc["density12"], sc["sph"], device=dev, requires_grad=False)
+    t = lambda a: None if a is None else torch.as_tensor(a, device=dev)
     tr.build_gs_acc(g, rebuild=True)
     tr.build_mesh_acc(t(mesh["vertices"]), t(mesh["triangles"]))
-    args_t = (g, t(ro_w), t(rd_w), 1, t(mesh["triangles"]), t(mesh["vertex_normals"]), None, None, t(mesh["prim_type"]))
-    kw = dict(refractive_index=t(mesh["refractive_index"]), max_pbr_bounces=7)
+    mats = [dict(diffuse_map=t(x["diffuse_tex"]), emissive_map=t(x["emissive_tex"]), metallic_roughness_map=t(x["metallic_roughness_tex"]),
+                 normal_map=t(x["normal_tex"]), diffuse_factor=x["diffuse_factor"], emissive_factor=x["emissive_factor"], metallic_factor=x["metallic_factor"],
+                 roughness_factor=x["roughness_factor"], alpha_mode=x["alpha_mode"], alpha_cutoff=x["alpha_cutoff"],
+                 transmission_factor=x["transmission_factor"], ior=x["ior"]) for x in sc["materials"]]
+    args_t = (g, t(sc["ray_o"])[None], t(sc["ray_d"])[None], ps.OPT_SMOOTH_NORMALS, t(mesh["triangles"]), t(mesh["vertex_normals"]), None, None, t(mesh["prim_type"]))
+    kw = dict(material_uv=t(mesh["mat_uv"]), material_id=t(mesh["mat_id"])[:, None], materials=mats, refractive_index=t(mesh["refractive_index"]),
+              envmap=t(sc["envmap"]), envmap_offset=t(sc["envmap_offset"]), max_pbr_bounces=7)
     out = None
     for _ in range(args.warmup):
         out = tr.render_playground(*args_t, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = tr.render_playground(*args_t, **kw)
+    for k in range(args.steps):
+        out = tr.render_playground(*args_t, frame_id=k, **kw)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     b = out["mirror_bounces"]
     result = {"metric": "rays/sec (hybrid mesh + Gaussian path tracing, forward)", "value": W * H * args.steps / dt, "unit": "rays/s",
               "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup, "n_gpus": 1, "higher_is_better": True, "dtype": "f32",
               "data": "synthetic",
-              "config": {"workload": f"hybrid path tracing, {n} Gaussians + {len(mesh['triangles'])} triangles (mirror sphere, glass slab, diffuse floor), "
-                                     f"fisheye 140 deg, {W}x{H}, smooth normals, forward only", "name": "c5_hybrid_2m_1080p"},
+              "config": {"workload": f"hybrid path tracing, {n} Gaussians + {len(mesh['triangles'])} triangles (mirror sphere, glass pane, textured diffuse floor, "
+                                     f"three PBR spheres: metal / transmissive / textured), environment map, fisheye 140 deg, {W}x{H}, smooth normals, "
+                                     f"7 PBR bounces, forward only", "name": "c5_hybrid_2m_1080p"},
               "rays_with_mirror_bounce": float((b > 0).float().mean()), "mean_opacity": float(out["pred_opacity"].mean())}
     if emit:
         print(json.dumps(result), flush=True)

@@ -296,32 +296,54 @@ typedef struct GrtStats {
 typedef struct GrtHandle GrtHandle;
 
 /* ---- hybrid mesh + Gaussian path tracing (BASELINE config 5) -------------------------------------------------------------------
- * Replaces HybridOptixTracer::buildMeshBVH / traceHybrid (threedgrut_playground/include/playground/hybridTracer.h:113-141) and the
- * OptiX programs of threedgrut_playground/src/kernels/cuda/playgroundKernel.cu:39-352: per ray a path loop — closest triangle,
- * material (none / mirror / glass / diffuse), then the Gaussians between the ray origin and the surface with the forward program's
- * k = 16 rounds (3dgrtTracer.cuh:137-204), transmittance carried along the whole path.  Forward only, like the reference.
- * PBR primitives (PGRNDPrimitivePBR = 4: Cook-Torrance sampling, textures, emissive maps) are not implemented — the caller must not
- * pass them (the Python wrapper refuses); the environment map is a solid colour; `diffuse_color` is the face's material.diffuseFactor
- * (PGRNDRenderDisablePBRTextures semantics).  All pointers are device pointers owned by the caller. */
+ * Replaces HybridOptixTracer::buildMeshBVH / traceHybrid (threedgrut_playground/include/playground/hybridTracer.h:121-141) and the
+ * OptiX programs of threedgrut_playground/src/kernels/cuda/playgroundKernel.cu:39-352 with materials.cuh, trace.cuh, rng.cuh under
+ * them: per ray a path loop — closest triangle, the face's primitive type (none / mirror / glass / diffuse / PBR: Cook-Torrance
+ * sampling with GGX importance sampling, glTF alpha modes, diffuse / emissive / metallic-roughness / normal textures, vertex tangents),
+ * then the Gaussians between the ray origin and the surface with the forward program's k = 16 rounds (3dgrtTracer.cuh:137-204),
+ * transmittance and path throughput carried along the whole path; the environment map is looked up along the last ray.  Forward
+ * only, like the reference.  All array pointers are DEVICE pointers owned by the caller; the GrtMaterial table itself is a HOST
+ * array (the library uploads it with the launch: a few hundred bytes, as HybridOptixTracer::syncMaterials does).
+ * Textures: row-major [height, width, channels] f32, sampled with normalised coordinates, clamp-to-edge, bilinear — the modes
+ * playground/cutexture.h:54-60 sets (CUDA filters with 8 fractional weight bits; here the float weights themselves). */
+typedef struct GrtTexture {
+    const float* data;                /* NULL: no texture */
+    int32_t height, width, channels;
+} GrtTexture;
+typedef struct GrtMaterial {          /* PBRMaterial, playground/pipelineParameters.h:26-52 */
+    GrtTexture diffuse, emissive, metallic_roughness, normal;   /* 4, 4, 2, 4 channels */
+    float diffuse_factor[4], emissive_factor[3];
+    float metallic_factor, roughness_factor, transmission_factor, ior, alpha_cutoff;
+    uint32_t alpha_mode;              /* GltfAlphaMode (pipelineDefinitions.h:42-48): 0 opaque, 1 blend, 2 mask */
+} GrtMaterial;
 typedef struct GrtMesh {
     uint32_t num_vertices, num_faces;
-    const float*   vertices;          /* [V,3] */
-    const int32_t* triangles;         /* [F,3] vertex indices */
-    const float*   vertex_normals;    /* [V,3] (needed with playground_opts bit 0) */
-    const int32_t* prim_type;         /* [F] PlaygroundPrimitiveTypes (pipelineDefinitions.h:18-24): 0 none, 1 mirror, 2 glass, 3 diffuse */
-    const float*   refractive_index;  /* [F] */
-    const float*   diffuse_color;     /* [F,3] */
+    const float*   vertices;            /* [V,3] */
+    const int32_t* triangles;           /* [F,3] vertex indices */
+    const float*   vertex_normals;      /* [V,3] (needed with playground_opts bit 0) */
+    const float*   vertex_tangents;     /* [V,3] or NULL */
+    const uint8_t* vertex_has_tangents; /* [V]   or NULL (no precomputed tangents) */
+    const int32_t* prim_type;           /* [F] PlaygroundPrimitiveTypes (pipelineDefinitions.h:18-24): 0 none, 1 mirror, 2 glass, 3 diffuse, 4 PBR */
+    const float*   mat_uv;              /* [F,3,2] texture coordinates per face corner, or NULL (0) */
+    const int32_t* mat_id;              /* [F] row of `materials`, or NULL (0) */
+    const float*   refractive_index;    /* [F] */
+    uint32_t num_materials;
+    const GrtMaterial* materials;       /* HOST array [num_materials] (needed when a diffuse or PBR face exists) */
+    GrtTexture envmap;                  /* [EH,EW,4]; data == NULL: black */
+    float envmap_offset[2];             /* rotates the environment (trace.cuh:233-257) */
 } GrtMesh;
 typedef struct GrtHybridOptions {
-    uint32_t playground_opts;         /* PlaygroundRenderOptions: bit 0 smooth normals, bit 1 disable Gaussian tracing */
-    uint32_t max_pbr_bounces;         /* the path loop runs while 0 < max_pbr_bounces (no PBR primitive ever counts one) */
-    float    background[3];           /* colour of the (solid) environment */
+    uint32_t playground_opts;         /* PlaygroundRenderOptions: bit 0 smooth normals, bit 1 disable Gaussian tracing, bit 2 disable PBR textures */
+    uint32_t max_pbr_bounces;         /* the path loop runs while pbrNumBounces < max_pbr_bounces */
+    uint32_t frame_number;            /* seeds the per-pixel random streams (rng.cuh; playgroundKernel.cu:59, materials.cuh:224-228) */
 } GrtHybridOptions;
+/* rebuild = 0 with allow_update != 0 and an unchanged face count refits the boxes of the existing tree (OPTIX_BUILD_OPERATION_UPDATE,
+ * hybridTracer.cpp buildMeshBVH); anything else builds from scratch */
 int grt_build_mesh_bvh(GrtHandle* handle, void* stream, uint32_t num_vertices, const float* vertices, uint32_t num_faces,
-                       const int32_t* triangles);
+                       const int32_t* triangles, int rebuild, int allow_update);
 /* rays [H,W,3] in ray space (frame->ray_to_world applies); ray_max_t [H,W] or NULL; out_radiance [H,W,3], out_opacity [H,W,1] fully
- * written; out_last_ray [H,W,6] (world-space origin + direction of the last segment, for an external background pass) and
- * out_bounces [H,W] (mirror bounces) may be NULL. */
+ * written; out_last_ray [H,W,6] (world-space origin + direction of the last segment: what the reference writes back into its ray
+ * buffers, trace.cuh:158-173) and out_bounces [H,W] (mirror bounces) may be NULL. */
 int grt_trace_hybrid(GrtHandle* handle, void* stream, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
                      const float* ray_origin, const float* ray_direction, const float* ray_max_t, const GrtMesh* mesh,
                      const GrtHybridOptions* options, float* out_radiance, float* out_opacity, float* out_last_ray, uint32_t* out_bounces);

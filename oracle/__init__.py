@@ -372,12 +372,14 @@ def _orc_texture(a, channels, keep):
 
 
 def grt_hybrid(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, ray_o, ray_d, mesh, opts=0, max_pbr_bounces=8, materials=None,
-               envmap=None, envmap_offset=(0.0, 0.0), frame_number=0, inst=None, scene=None, ray_max_t=None, dtype=np.float32):
+               envmap=None, envmap_offset=(0.0, 0.0), frame_number=0, inst=None, scene=None, ray_max_t=None, pixel_xy=None, launch_width=0,
+               dtype=np.float32):
     """Hybrid mesh + Gaussian path tracing (orc_grt_hybrid_trace; playgroundKernel.cu:39-352, materials.cuh, trace.cuh).
     mesh: dict with vertices [V,3] f32, triangles [F,3] i32, vertex_normals [V,3], prim_type [F] i32 (0 none, 1 mirror, 2 glass, 3 diffuse,
     4 PBR), refractive_index [F] and optionally vertex_tangents [V,3], vertex_has_tangents [V] u8, mat_uv [F,3,2], mat_id [F];
     materials: list of dicts as tests/playground_scenes.material() builds them (factors + optional textures [H,W,C]); envmap [EH,EW,4] or
-    None (black).  Rays [H,W,3]; pixel (x, y) seeds the random streams.  Returns dict(rgba [H,W,4], last_ray [H,W,6], bounces [H,W])."""
+    None (black).  Rays [H,W,3]; pixel (x, y) seeds the random streams — for a subset of a larger launch pass pixel_xy [H,W,2] (u32 launch
+    coordinates) and launch_width.  Returns dict(rgba [H,W,4], last_ray [H,W,6], bounces [H,W])."""
     l, R = lib(dtype), _real(dtype)
     d12, s = _c(density12, dtype), _c(sph, dtype)
     N = d12.shape[0]
@@ -416,8 +418,9 @@ def grt_hybrid(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, ra
                   _orc_texture(envmap, 4, keep), (C.c_float * 2)(float(envmap_offset[0]), float(envmap_offset[1])))
     rgba, last, bounces = np.zeros((H, W, 4), dtype), np.zeros((H, W, 6), dtype), np.zeros((H, W), np.uint32)
     tmax = _c(ray_max_t, dtype).reshape(-1) if ray_max_t is not None else None
+    pxy = np.ascontiguousarray(pixel_xy, np.uint32).reshape(-1, 2) if pixel_xy is not None else None
     r = l.orc_grt_hybrid_trace(C.byref(cfg), C.c_uint32(N), _p(d12), _p(s), C.c_int(sph_deg), R(min_transmittance), _p(inst), _p(scene), _p(m),
                                C.c_uint32(W), C.c_uint32(H), _p(ro), _p(rd), _p(tmax), C.byref(om), C.c_uint32(opts), C.c_uint32(max_pbr_bounces),
-                               C.c_uint32(frame_number), _p(rgba), _p(last), _p(bounces))
+                               C.c_uint32(frame_number), _p(pxy), C.c_uint32(launch_width), _p(rgba), _p(last), _p(bounces))
     assert r == 0
     return dict(rgba=rgba, last_ray=last, bounces=bounces)

@@ -815,20 +815,23 @@ static v3 pg_background(const orc_mesh* m, v3 d) {   /* getBackgroundColor, trac
     return v3_make(t[0], t[1], t[2]);
 }
 
-/* rays [height*width,3] in ray space, pixel (x, y) = ray y*width + x (the random streams are seeded per pixel); ray_max_t [rays] or NULL
- * (= 1e30); opts: PlaygroundRenderOptions (1 smooth normals, 2 Gaussian tracing off, 4 PBR textures off).
+/* rays [height*width,3] in ray space, pixel (x, y) = ray y*width + x (the random streams are seeded per pixel); to trace a SUBSET of a
+ * larger launch pass pixel_xy [rays,2] (the launch coordinates of each ray) and launch_width (0: the frame is the launch);
+ * ray_max_t [rays] or NULL (= 1e30); opts: PlaygroundRenderOptions (1 smooth normals, 2 Gaussian tracing off, 4 PBR textures off).
  * out_rgba [rays,4], out_last_ray [rays,6] (origin, direction of the last traced segment, world space), out_bounces [rays] (mirror bounces). */
 int orc_grt_hybrid_trace(const GrtConfig* cfg, uint32_t N, const real* density12, const real* sph, int sph_deg, real min_T,
                          const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t width, uint32_t height, const real* ray_o,
                          const real* ray_d, const real* ray_max_t, const orc_mesh* mesh, uint32_t opts, uint32_t max_pbr_bounces,
-                         uint32_t frame_number, real* out_rgba, real* out_last_ray, uint32_t* out_bounces) {
+                         uint32_t frame_number, const uint32_t* pixel_xy, uint32_t launch_width, real* out_rgba, real* out_last_ray,
+                         uint32_t* out_bounces) {
     const uint32_t nrays = width * height;
+    const uint32_t seed_width = launch_width ? launch_width : width;
 #pragma omp parallel
     {
         grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
 #pragma omp for schedule(dynamic, 8)
         for (uint32_t r = 0; r < nrays; ++r) {
-            const uint32_t px = r % width, py = r / width;
+            const uint32_t px = pixel_xy ? pixel_xy[2 * r] : r % width, py = pixel_xy ? pixel_xy[2 * r + 1] : r / width;
             v3 rayOri = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
             v3 rayDir = xform_dir(ray_to_world12, v3_make(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
             const real ray_t_max = ray_max_t ? ray_max_t[r] : R_(1e30);
@@ -836,7 +839,7 @@ int orc_grt_hybrid_trace(const GrtConfig* cfg, uint32_t N, const real* density12
             v3 accC = v3_make(0, 0, 0), direct = v3_make(0, 0, 0), thr = v3_make(1, 1, 1);
             real accA = 0;
             uint32_t numBounces = 0, timeout = 0;
-            pg_pbr_state pbr; pbr.pbr_bounces = 0; pbr.rnd_seed = pg_tea16(width * py + px, frame_number);
+            pg_pbr_state pbr; pbr.pbr_bounces = 0; pbr.rnd_seed = pg_tea16(seed_width * py + px, frame_number);
             pbr.bsdf = v3_make(1, 1, 1); pbr.emissive = v3_make(0, 0, 0);
             int missed = 0;
             int state = 0;   /* PlaygroundTraceState: 0 primitives pass, 1 Gaussians pass, 2 terminate (params.trace_state) */
