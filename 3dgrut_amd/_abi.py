@@ -47,6 +47,7 @@ class GutConfig(C.Structure):
         ("n_rolling_shutter_iterations", C.c_int32), ("k_buffer_size", C.c_int32),
         ("global_z_order", C.c_int32), ("rect_bounding", C.c_int32),
         ("tight_opacity_bounding", C.c_int32), ("tile_based_culling", C.c_int32),
+        ("particle_feature_half", C.c_int32), ("feature_output_half", C.c_int32),
     ]
 
 
@@ -74,7 +75,7 @@ class GrtConfig(C.Structure):
         ("particle_kernel_min_alpha", C.c_float), ("particle_kernel_max_alpha", C.c_float),
         ("particle_kernel_density_clamping", C.c_int32), ("particle_radiance_sph_degree", C.c_int32),
         ("enable_normals", C.c_int32), ("enable_hitcounts", C.c_int32), ("enable_kernel_timings", C.c_int32),
-        ("max_hits_per_trace", C.c_int32),
+        ("max_hits_per_trace", C.c_int32), ("particle_feature_half", C.c_int32), ("feature_output_half", C.c_int32),
     ]
 
 

@@ -91,6 +91,8 @@ static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
     P.H = f.height;
     for (int k = 0; k < 12; ++k) P.ray_to_world[k] = f.ray_to_world[k];
     P.ray_to_world_dev = f.device_ray_to_world;
+    P.sph_half = h->cfg.particle_feature_half;
+    P.out_half = h->cfg.feature_output_half;
     return P;
 }
 
@@ -353,27 +355,31 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     return GRUT_OK;
 }
 
-int grt_forward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
-                const float* ray_origin, const float* ray_direction, float* out_features, float* out_density, float* out_hit_distance,
+// (particle_sph / out_features: fp32, or IEEE half with GrtConfig::particle_feature_half / feature_output_half — the kernels look at
+// GrtTraceParams::sph_half / out_half)
+int grt_forward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const void* particle_sph,
+                const float* ray_origin, const float* ray_direction, void* out_features, float* out_density, float* out_hit_distance,
                 float* out_normals, float* out_hits_count, int32_t* out_visibility) {
-    return grt_forward_impl(h, reinterpret_cast<hipStream_t>(stream_), frame, particle_density, particle_sph, ray_origin, ray_direction,
-                            out_features, out_density, out_hit_distance, out_normals, out_hits_count, out_visibility, nullptr, nullptr, 0);
+    return grt_forward_impl(h, reinterpret_cast<hipStream_t>(stream_), frame, particle_density, reinterpret_cast<const float*>(particle_sph), ray_origin, ray_direction,
+                            reinterpret_cast<float*>(out_features), out_density, out_hit_distance, out_normals, out_hits_count, out_visibility, nullptr, nullptr, 0);
 }
 
-int grt_debug_forward_hits(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
-                           const float* ray_origin, const float* ray_direction, float* out_features, float* out_density,
+int grt_debug_forward_hits(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const void* particle_sph,
+                           const float* ray_origin, const float* ray_direction, void* out_features, float* out_density,
                            float* out_hit_distance, float* out_normals, float* out_hits_count, int32_t* out_visibility,
                            uint32_t* hit_ids, uint32_t* hit_counts, uint32_t capacity) {
     GRUT_REQUIRE(hit_ids && hit_counts && capacity > 0, "grt_debug_forward_hits: null hit buffers");
-    return grt_forward_impl(h, reinterpret_cast<hipStream_t>(stream_), frame, particle_density, particle_sph, ray_origin, ray_direction,
-                            out_features, out_density, out_hit_distance, out_normals, out_hits_count, out_visibility, hit_ids, hit_counts,
+    return grt_forward_impl(h, reinterpret_cast<hipStream_t>(stream_), frame, particle_density, reinterpret_cast<const float*>(particle_sph), ray_origin, ray_direction,
+                            reinterpret_cast<float*>(out_features), out_density, out_hit_distance, out_normals, out_hits_count, out_visibility, hit_ids, hit_counts,
                             capacity);
 }
 
-int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
-                 const float* ray_origin, const float* ray_direction, const float* features, const float* density, const float* hit_distance,
+int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const void* particle_sph_,
+                 const float* ray_origin, const float* ray_direction, const void* features_, const float* density, const float* hit_distance,
                  const float* normals, const float* grad_features, const float* grad_density, const float* grad_hit_distance,
                  const float* grad_normals, float* grad_particle_density, float* grad_particle_sph) {
+    const float* particle_sph = reinterpret_cast<const float*>(particle_sph_);
+    const float* features = reinterpret_cast<const float*>(features_);
     (void)normals;
     (void)grad_normals;  // the reference's backward does not propagate the normal gradient either (referenceBwdOptix.cu:103-170)
     GRUT_REQUIRE(h && frame, "grt_backward: null handle/frame");
@@ -475,10 +481,11 @@ int grt_build_mesh_bvh(GrtHandle* h, void* stream_, uint32_t num_vertices, const
 }
 
 // HybridOptixTracer::traceHybrid (hybridTracer.h:129-141; playgroundKernel.cu:39-352): forward only, like the reference
-int grt_trace_hybrid(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
+int grt_trace_hybrid(GrtHandle* h, void* stream_, const GrtFrame* frame, const float* particle_density, const void* particle_sph_,
                      const float* ray_origin, const float* ray_direction, const float* ray_max_t, const GrtMesh* mesh, const GrtHybridOptions* options,
                      float* out_radiance, float* out_opacity, float* out_last_ray, uint32_t* out_bounces) {
     GRUT_REQUIRE(h && frame && mesh && options, "grt_trace_hybrid: null argument");
+    const float* particle_sph = reinterpret_cast<const float*>(particle_sph_);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     if (!h->built || !h->mesh_built) {
         set_last_error("grt_trace_hybrid: build_bvh / build_mesh_bvh have not been called");

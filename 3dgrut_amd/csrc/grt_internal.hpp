@@ -46,6 +46,7 @@ struct GrtTraceParams {
     uint32_t dbg_cap;
     // optional (grt_debug_backward_signature): per ray, how many hits the backward differentiated and an order-independent
     // signature of which particles they were — the parity tests compare the replayed backward with the re-derived one ray by ray
+    int sph_half, out_half;   // fp16 feature I/O (GrtConfig::particle_feature_half / feature_output_half)
     unsigned long long* bwd_sig;
     uint32_t* bwd_cnt;
 };

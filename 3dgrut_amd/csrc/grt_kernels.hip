@@ -17,6 +17,8 @@
 //   * A candidate's hit distance t (closest approach in the proxy's scaled frame) can precede the entry of the ray
 //     into the proxy's box by at most sqrt(2) * (largest proxy half axis); nodes store that slack, and a subtree is
 //     pruned only when (box entry - slack) exceeds the current 16th-nearest distance.
+#include <hip/hip_fp16.h>
+
 #include "grt_internal.hpp"
 
 namespace grut {
@@ -749,11 +751,36 @@ __device__ __forceinline__ void sh_basis16(int deg, f3 d, float b[16]) {
         }
     }
 }
+// the [H,W,3] integrated radiance: fp32, or IEEE half with FEATURE_OUTPUT_HALF (referenceSlangOptix.cu:183-184 / referenceSlangBwdOptix.cu:116-117)
+__device__ __forceinline__ void store_radiance(const GrtTraceParams& P, float* __restrict__ out_rad, size_t pix, f3 rad) {
+    if (P.out_half) {
+        __half* h = reinterpret_cast<__half*>(out_rad) + 3 * pix;
+        h[0] = __float2half(rad.x); h[1] = __float2half(rad.y); h[2] = __float2half(rad.z);
+    } else {
+        out_rad[3 * pix] = rad.x; out_rad[3 * pix + 1] = rad.y; out_rad[3 * pix + 2] = rad.z;
+    }
+}
+__device__ __forceinline__ f3 load_radiance(const GrtTraceParams& P, const float* __restrict__ in_rad, size_t pix) {
+    if (P.out_half) {
+        const __half* h = reinterpret_cast<const __half*>(in_rad) + 3 * pix;
+        return mk3(__half2float(h[0]), __half2float(h[1]), __half2float(h[2]));
+    }
+    return mk3(in_rad[3 * pix], in_rad[3 * pix + 1], in_rad[3 * pix + 2]);
+}
 // unclamped radiance along direction d
 __device__ __forceinline__ f3 sh_radiance(const GrtTraceParams& P, const float* __restrict__ sph, uint32_t id, const float b[16]) {
     const float* c = sph + (size_t)id * 3 * P.ncoef;
     const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
     f3 rad = mk3(0.f, 0.f, 0.f);
+    if (P.sph_half) {   // PARTICLE_FEATURE_HALF (optixTracer.cpp:54-56): half coefficients, fp32 arithmetic in the same order
+        const __half* hc = reinterpret_cast<const __half*>(sph) + (size_t)id * 3 * P.ncoef;
+        for (int k = 0; k < nact; ++k) {
+            rad.x = fmaf(b[k], __half2float(hc[3 * k]), rad.x);
+            rad.y = fmaf(b[k], __half2float(hc[3 * k + 1]), rad.y);
+            rad.z = fmaf(b[k], __half2float(hc[3 * k + 2]), rad.z);
+        }
+        return rad + mk3(0.5f, 0.5f, 0.5f);
+    }
     if (nact == 16 && (reinterpret_cast<uintptr_t>(sph) & 15u) == 0) {
         // the full degree-3 row is 192 bytes at a 16-byte-aligned address: twelve 16-byte requests per lane instead of 48 dword
         // loads (the per-hit gathers are the trace's vector-memory instruction stream), same order of accumulation
@@ -988,7 +1015,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         if (!full) running = false;   // the round held every remaining candidate of this ray
     }
     if (!in_image) return;
-    out_rad[3 * pix] = rad.x; out_rad[3 * pix + 1] = rad.y; out_rad[3 * pix + 2] = rad.z;
+    store_radiance(P, out_rad, pix, rad);
     out_dns[pix] = 1.f - T;
     out_hit2[2 * pix] = depth; out_hit2[2 * pix + 1] = tLast;
     if (P.normals) { out_nrm[3 * pix] = nrm.x; out_nrm[3 * pix + 1] = nrm.y; out_nrm[3 * pix + 2] = nrm.z; }
@@ -1166,7 +1193,7 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
     const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
 
     BwdRay ray_state;
-    ray_state.rad_fin = mk3(in_rad[3 * pix], in_rad[3 * pix + 1], in_rad[3 * pix + 2]);
+    ray_state.rad_fin = load_radiance(P, in_rad, pix);
     ray_state.T_fin = 1.f - in_dns[pix];
     ray_state.depth_fin = in_hit2[2 * pix];
     const float max_hit = in_hit2[2 * pix + 1];
@@ -1263,7 +1290,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     float basis[16];
     sh_basis16(P.sph_degree, r.d, basis);
     const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
-    const f3 rad_fin = mk3(in_rad[3 * pix], in_rad[3 * pix + 1], in_rad[3 * pix + 2]);
+    const f3 rad_fin = load_radiance(P, in_rad, pix);
     const float T_fin = 1.f - in_dns[pix], depth_fin = in_hit2[2 * pix];
     const f3 rad_grad = mk3(g_rad[3 * pix], g_rad[3 * pix + 1], g_rad[3 * pix + 2]);
     const float T_grad = -g_dns[pix], depth_grad = g_hit ? g_hit[pix] : 0.f;

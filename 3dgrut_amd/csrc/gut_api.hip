@@ -133,6 +133,8 @@ static GutParams make_params(const GutConfig& c, const GutFrame& f) {
     P.work = nullptr;
     P.out_features = f.out_features;
     P.out_opacity = f.out_opacity;
+    P.sph_half = c.particle_feature_half;
+    P.out_half = c.feature_output_half;
     return P;
 }
 
@@ -245,9 +247,12 @@ void gut_destroy(GutHandle* h) {
     delete h;
 }
 
-int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const float* particle_sph,
-                const float* ray_origin, const float* ray_direction, float* out_feat_density, float* out_hit_distance,
+int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const void* particle_sph_,
+                const float* ray_origin, const float* ray_direction, void* out_feat_density_, float* out_hit_distance,
                 float* out_hit_count, int32_t* out_visibility) {
+    // (fp32 buffers by default; IEEE half with particle_feature_half / feature_output_half: the kernels look at GutParams::sph_half / out_half)
+    const float* particle_sph = reinterpret_cast<const float*>(particle_sph_);
+    float* out_feat_density = reinterpret_cast<float*>(out_feat_density_);
     GRUT_REQUIRE(h && frame, "gut_forward: null handle/frame");
     GRUT_REQUIRE(frame->width > 0 && frame->height > 0, "gut_forward: empty image");
     GRUT_REQUIRE(ray_origin && ray_direction && out_feat_density && out_hit_distance && out_hit_count, "gut_forward: null ray/output buffer");
@@ -273,6 +278,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         return GRUT_OK;
     }
     GRUT_REQUIRE(particle_density && particle_sph && out_visibility, "gut_forward: null particle buffer");
+    GRUT_REQUIRE(!h->cfg.feature_output_half || (!frame->out_features && !frame->out_opacity), "gut_forward: feature_output_half excludes out_features / out_opacity");
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
 
     GRUT_CHECK(ensure_particle_scratch(h, N));
@@ -374,7 +380,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         const float far = 1e6f;
         uint32_t bits;
         memcpy(&bits, &far, 4);
-        GRUT_HIP(hipMemsetAsync(out_feat_density, 0, (size_t)P.W * P.H * 16, s));
+        GRUT_HIP(hipMemsetAsync(out_feat_density, 0, (size_t)P.W * P.H * (P.out_half ? 8 : 16), s));
         GRUT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_hit_distance), (int)bits, (size_t)P.W * P.H, s));
         GRUT_HIP(hipMemsetAsync(out_hit_count, 0, (size_t)P.W * P.H * 4, s));
         if (P.out_features) GRUT_HIP(hipMemsetAsync(P.out_features, 0, (size_t)P.W * P.H * 12, s));
@@ -396,10 +402,12 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
 }
 
 // gut_backward / gut_backward_factored: exactly one of grad_particle_sph and grad_radiance is non-null
-static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const float* particle_sph,
-                         const float* ray_origin, const float* ray_direction, const float* feat_density, const float* grad_feat_density,
+static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const void* particle_sph_,
+                         const float* ray_origin, const float* ray_direction, const void* feat_density_, const float* grad_feat_density,
                          const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_particle_sph,
                          float* grad_radiance, const GutGradIO* io = nullptr) {
+    const float* particle_sph = reinterpret_cast<const float*>(particle_sph_);       // (fp32, or half with particle_feature_half)
+    const float* feat_density = reinterpret_cast<const float*>(feat_density_);       // (fp32, or half with feature_output_half)
     GRUT_REQUIRE(h && frame, "gut_backward: null handle/frame");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     if (!h->have_forward || h->fwd_stream != s) {  // gutRenderer.cu:436-440
@@ -479,23 +487,23 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
     return GRUT_OK;
 }
 
-int gut_backward(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const float* particle_sph,
-                 const float* ray_origin, const float* ray_direction, const float* feat_density, const float* grad_feat_density,
+int gut_backward(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const void* particle_sph,
+                 const float* ray_origin, const float* ray_direction, const void* feat_density, const float* grad_feat_density,
                  const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_particle_sph) {
     return backward_impl(h, stream, frame, particle_density, particle_sph, ray_origin, ray_direction, feat_density, grad_feat_density, hit_distance,
                          grad_hit_distance, grad_particle_density, grad_particle_sph, nullptr);
 }
 
-int gut_backward_unpacked(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const float* particle_sph,
-                          const float* ray_origin, const float* ray_direction, const float* feat_density, const float* hit_distance,
+int gut_backward_unpacked(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const void* particle_sph,
+                          const float* ray_origin, const float* ray_direction, const void* feat_density, const float* hit_distance,
                           const float* grad_hit_distance, const GutGradIO* io, float* grad_particle_sph) {
     GRUT_REQUIRE(io, "gut_backward_unpacked: null GutGradIO");
     return backward_impl(h, stream, frame, particle_density, particle_sph, ray_origin, ray_direction, feat_density, nullptr, hit_distance,
                          grad_hit_distance, nullptr, grad_particle_sph, nullptr, io);
 }
 
-int gut_backward_factored(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const float* particle_sph,
-                          const float* ray_origin, const float* ray_direction, const float* feat_density, const float* grad_feat_density,
+int gut_backward_factored(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const void* particle_sph,
+                          const float* ray_origin, const float* ray_direction, const void* feat_density, const float* grad_feat_density,
                           const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_radiance) {
     GRUT_REQUIRE(grad_radiance, "gut_backward_factored: null buffer");
     return backward_impl(h, stream, frame, particle_density, particle_sph, ray_origin, ray_direction, feat_density, grad_feat_density, hit_distance,

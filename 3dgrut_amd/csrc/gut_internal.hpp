@@ -18,6 +18,7 @@ struct GutParams {
     GrutCamera cam;
     FramePoses poses;             // derived on the host from GutFrame::pose_start / pose_end ...
     unsigned long long* work;     // optional device counters {fwd evaluated, fwd accepted, bwd evaluated, bwd accepted} (gut_profile_enable level 2)
+    int sph_half, out_half;       // fp16 feature I/O (GutConfig::particle_feature_half / feature_output_half): the SH buffer / the [H,W,4] image are IEEE half
     uint32_t work_task_capacity;  // ... and how many {lifetime, start} records of gradient-sweep tasks fit behind the forward sweep's block
     float* out_features;          // optional contiguous copies of the radiance / opacity outputs (GutFrame::out_features / out_opacity)
     float* out_opacity;

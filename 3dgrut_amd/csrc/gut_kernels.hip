@@ -12,6 +12,8 @@
 //     particle's slots with four lanes per particle and contracts them into the parameter gradients.
 #include <cstdlib>
 
+#include <hip/hip_fp16.h>
+
 #include "gut_internal.hpp"
 
 namespace grut {
@@ -380,7 +382,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, GRUT_PRO
             const int nact = (P.n_active + 1) * (P.n_active + 1);
             const float* coef = sph + (size_t)i * 3 * P.ncoef;
             float r = 0.f, g = 0.f, bl = 0.f;
-            if (P.ncoef == 16) {
+            if (P.sph_half) {   // PARTICLE_FEATURE_HALF: the coefficients are stored as IEEE half, the arithmetic stays fp32
+                const __half* hc = reinterpret_cast<const __half*>(sph) + (size_t)i * 3 * P.ncoef;
+                for (int k = 0; k < nact && k < P.ncoef; ++k) {
+                    r = fmaf(basis[k], __half2float(hc[3 * k + 0]), r);
+                    g = fmaf(basis[k], __half2float(hc[3 * k + 1]), g);
+                    bl = fmaf(basis[k], __half2float(hc[3 * k + 2]), bl);
+                }
+            } else if (P.ncoef == 16) {
                 // a lane reads its own 192-byte row: 16-byte loads (12 requests per row instead of 48), accumulated in the
                 // same coefficient order as the scalar loop
                 const float4* row = reinterpret_cast<const float4*>(coef);
@@ -833,7 +842,14 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
     const int nrows = (int)min(64u, P.N > wave_base ? P.N - wave_base : 0u);
     // stage in.  48-float rows: the wave's rows are one contiguous, 16-byte aligned block, copied as independent float4
     // requests (12 per lane in flight); rows of particles without tiles ride along.  Other row lengths: one row per step.
-    if (rowlen == 48) {
+    if (P.sph_half) {
+        const __half* hs = reinterpret_cast<const __half*>(sph);
+        for (unsigned long long m = has_mask; m;) {
+            const int row = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if (lane < 3 * nact) rows[row * kShStride + lane] = __half2float(hs[(size_t)(wave_base + row) * rowlen + lane]);
+        }
+    } else if (rowlen == 48) {
         if (has_mask) {
             const float4* src = reinterpret_cast<const float4*>(sph + (size_t)wave_base * 48);
             const int total4 = nrows * 12;

@@ -21,6 +21,8 @@
 //     up with a quarter of the wave total of term l mod 16) and written to the tile entry's own SLOT (one per entry and
 //     half tile, no atomics: gradients are bitwise reproducible); quaternion, scale and position gradients are
 //     contracted from (B, M) once per particle by the gather kernel, not per pixel.
+#include <hip/hip_fp16.h>
+
 #include "gut_internal.hpp"
 
 // tuning switches of the gradient sweep (scripts/build_variant.sh -D...)
@@ -254,6 +256,23 @@ __device__ __forceinline__ v2f pair_response(v2f g) {
     }
 }
 
+// the [H,W,4] image: fp32, or IEEE half with FEATURE_OUTPUT_HALF (rayPayload.cuh:176-186 writes __float2half of every component;
+// rayPayloadBackward.cuh:50-58 reads them back)
+__device__ __forceinline__ void store_fd(const GutParams& P, float4* __restrict__ out_fd, size_t pix, float4 o) {
+    if (P.out_half) {
+        __half* h = reinterpret_cast<__half*>(out_fd) + 4 * pix;
+        h[0] = __float2half(o.x); h[1] = __float2half(o.y); h[2] = __float2half(o.z); h[3] = __float2half(o.w);
+    } else {
+        out_fd[pix] = o;
+    }
+}
+__device__ __forceinline__ float4 load_fd(const GutParams& P, const float4* __restrict__ fd, size_t pix) {
+    if (P.out_half) {
+        const __half* h = reinterpret_cast<const __half*>(fd) + 4 * pix;
+        return make_float4(__half2float(h[0]), __half2float(h[1]), __half2float(h[2]), __half2float(h[3]));
+    }
+    return fd[pix];
+}
 // the plugin's `pred_features` / `pred_opacity` as contiguous tensors of their own (GutFrame::out_features / out_opacity)
 __device__ __forceinline__ void write_split_outputs(const GutParams& P, size_t pix, float4 o) {
     if (P.out_features) { P.out_features[3 * pix] = o.x; P.out_features[3 * pix + 1] = o.y; P.out_features[3 * pix + 2] = o.z; }
@@ -376,7 +395,7 @@ void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryL
     if (rp.inside0) {
         const size_t pix = (size_t)rp.py0 * P.W + rp.px;
         const float4 o = rp.valid0 ? make_float4(st.Cr.x, st.Cg.x, st.Cb.x, 1.f - st.T.x) : make_float4(0.f, 0.f, 0.f, 0.f);
-        out_fd[pix] = o;
+        store_fd(P, out_fd, pix, o);
         write_split_outputs(P, pix, o);
         out_dist[pix] = rp.valid0 ? st.D.x : 1e6f;
         if (P.hitcounts) out_cnt[pix] = rp.valid0 ? st.cnt.x : 0.f;
@@ -384,7 +403,7 @@ void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryL
     if (rp.inside1) {
         const size_t pix = (size_t)rp.py1 * P.W + rp.px;
         const float4 o = rp.valid1 ? make_float4(st.Cr.y, st.Cg.y, st.Cb.y, 1.f - st.T.y) : make_float4(0.f, 0.f, 0.f, 0.f);
-        out_fd[pix] = o;
+        store_fd(P, out_fd, pix, o);
         write_split_outputs(P, pix, o);
         out_dist[pix] = rp.valid1 ? st.D.y : 1e6f;
         if (P.hitcounts) out_cnt[pix] = rp.valid1 ? st.cnt.y : 0.f;
@@ -693,14 +712,14 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
     p3 C_fin = p3{splat(0.f), splat(0.f), splat(0.f)}, gC = C_fin;
     if (alive0) {
         const size_t pix = (size_t)rp.py0 * P.W + rp.px;
-        const float4 f = fd[pix], g = load_grad_in(g_in, pix);
+        const float4 f = load_fd(P, fd, pix), g = load_grad_in(g_in, pix);
         C_fin.x.x = f.x; C_fin.y.x = f.y; C_fin.z.x = f.z; gC.x.x = g.x; gC.y.x = g.y; gC.z.x = g.z;
         T_fin.x = 1.f - f.w; gT.x = -g.w;
         if (HAS_GDIST) { D_fin.x = dist[pix]; gD.x = g_dist[pix]; }
     }
     if (alive1) {
         const size_t pix = (size_t)rp.py1 * P.W + rp.px;
-        const float4 f = fd[pix], g = load_grad_in(g_in, pix);
+        const float4 f = load_fd(P, fd, pix), g = load_grad_in(g_in, pix);
         C_fin.x.y = f.x; C_fin.y.y = f.y; C_fin.z.y = f.z; gC.x.y = g.x; gC.y.y = g.y; gC.z.y = g.z;
         T_fin.y = 1.f - f.w; gT.y = -g.w;
         if (HAS_GDIST) { D_fin.y = dist[pix]; gD.y = g_dist[pix]; }
@@ -944,7 +963,7 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
     KBwdState bs;
     bs.T = 1.f; bs.Tb = 0.f; bs.Db = 0.f; bs.gT = 0.f; bs.gD = 0.f; bs.Cb = mk3(0.f, 0.f, 0.f); bs.gC = mk3(0.f, 0.f, 0.f);
     if (BWD && alive) {   // initializeBackwardRay (rayPayloadBackward.cuh:30-73); out_* hold the forward results here
-        const float4 f = out_fd[pix], g = g_fd[pix];
+        const float4 f = load_fd(P, out_fd, pix), g = g_fd[pix];
         bs.Cb = mk3(f.x, f.y, f.z); bs.gC = mk3(g.x, g.y, g.z);
         bs.Tb = 1.f - f.w; bs.gT = -g.w;
         bs.Db = out_dist[pix]; bs.gD = g_dist ? g_dist[pix] : 0.f;
@@ -1046,7 +1065,7 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
     if (!BWD && ray.inside) {
         const size_t opix = (size_t)py * P.W + px;
         const float4 o = ray.valid ? make_float4(fs.Cr, fs.Cg, fs.Cb, 1.f - fs.T) : make_float4(0.f, 0.f, 0.f, 0.f);
-        out_fd[opix] = o;
+        store_fd(P, out_fd, opix, o);
         write_split_outputs(P, opix, o);
         out_dist[opix] = ray.valid ? fs.D : 1e6f;
         if (P.hitcounts) out_cnt[opix] = ray.valid ? fs.cnt : 0.f;

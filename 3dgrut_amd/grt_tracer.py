@@ -37,9 +37,18 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
     if prim not in _SUPPORTED_PRIMITIVES:
         raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (only {_SUPPORTED_PRIMITIVES}: "
                                   "the software BVH bounds each particle by its oriented proxy box)")
-    if _conf_get(render, "particle_feature_half", False) or _conf_get(render, "feature_output_half", False):
-        raise NotImplementedError("3dgrut_amd: fp16 particle features / outputs are not supported (fp32 only)")
+    # fp16 feature I/O (setup_3dgrt.py:41-44): run-time switches here, compile-time macros in the reference
+    cfg.particle_feature_half = int(bool(_conf_get(render, "particle_feature_half", False)))
+    cfg.feature_output_half = int(bool(_conf_get(render, "feature_output_half", False)))
     return cfg
+
+
+def features_for_kernel(cfg, sph):
+    """optixTracer.cpp:52-60 particleFeaturesKernelTensor: the SH buffer the kernels read (half with PARTICLE_FEATURE_HALF)."""
+    sph = sph.contiguous()
+    if cfg.particle_feature_half and sph.dtype != torch.float16:
+        sph = sph.to(torch.float16)
+    return sph
 
 
 class _GrtNative:
@@ -88,7 +97,8 @@ class _GrtNative:
         dev = ray_ori.device
         H, W, N = frame.height, frame.width, frame.num_particles
         opts = dict(dtype=torch.float32, device=dev)
-        feat = torch.zeros((1, H, W, 3), **opts)
+        # (optixTracer.cpp:903-909: the integrated features are a half tensor with FEATURE_OUTPUT_HALF)
+        feat = torch.zeros((1, H, W, 3), dtype=torch.float16 if self.cfg.feature_output_half else torch.float32, device=dev)
         dns = torch.zeros((1, H, W, 1), **opts)
         hit = torch.zeros((1, H, W, 2), **opts)
         nrm = torch.zeros((1, H, W, 3), **opts)
@@ -107,7 +117,7 @@ class _GrtNative:
     def trace_bwd(self, frame, particle_density, particle_sph, ray_ori, ray_dir, feat, dns, hit, nrm, g_feat, g_dns, g_hit, g_nrm):
         dev = ray_ori.device
         g_density = torch.zeros_like(particle_density)   # accumulated with atomics (optixTracer.cpp:982-983)
-        g_sph = torch.zeros_like(particle_sph)
+        g_sph = torch.zeros_like(particle_sph, dtype=torch.float32)   # (fp32 also for half coefficients)
         _abi.check(self.lib.grt_backward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
                                          _ptr(ray_ori), _ptr(ray_dir), _ptr(feat), _ptr(dns), _ptr(hit), _ptr(nrm), _ptr(g_feat), _ptr(g_dns),
                                          _ptr(g_hit), _ptr(g_nrm), _ptr(g_density), _ptr(g_sph)), "grt_backward")
@@ -156,9 +166,11 @@ class Tracer:
             else:
                 particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)  # [N,12] rows, one pass (tracer.py's torch.cat)
             ctx.raw = (mog_dns, mog_rot, mog_scl) if raw else None
-            particle_sph = mog_sph.contiguous()
+            particle_sph = features_for_kernel(native.cfg, mog_sph)
             feat, dns, hit, nrm, cnt, vis = native.trace(frame, particle_density, particle_sph, ray_ori, ray_dir)
             ctx.save_for_backward(ray_ori, ray_dir, feat, dns, hit, nrm, particle_density, particle_sph)
+            if feat.dtype != torch.float32:   # fp32 to the caller, the half image stays in the context for the backward (tracer.py:98)
+                feat = feat.float()
             ctx.native, ctx.frame = native, frame
             ctx.mark_non_differentiable(cnt, vis)
             ctx.set_materialize_grads(False)
@@ -168,7 +180,7 @@ class Tracer:
         @staticmethod
         def backward(ctx, g_feat, g_dns, g_hit, g_nrm, _g_cnt, _g_vis):
             ray_ori, ray_dir, feat, dns, hit, nrm, particle_density, particle_sph = ctx.saved_tensors
-            g_feat = torch.zeros_like(feat) if g_feat is None else g_feat.contiguous()
+            g_feat = torch.zeros_like(feat, dtype=torch.float32) if g_feat is None else g_feat.contiguous()
             g_dns = torch.zeros_like(dns) if g_dns is None else g_dns.contiguous()
             g_hit = None if g_hit is None else g_hit.contiguous()
             g_density, g_sph = ctx.native.trace_bwd(ctx.frame, particle_density, particle_sph, ray_ori, ray_dir, feat, dns, hit, nrm,

@@ -67,8 +67,9 @@ def gut_config_from_conf(conf) -> _abi.GutConfig:
     for k, d in _SPLAT_DEFAULTS.items():
         v = _conf_get(splat, k, d)
         setattr(cfg, k, type(d)(v) if not isinstance(d, bool) else int(bool(v)))
-    if _conf_get(render, "particle_feature_half", False) or _conf_get(render, "feature_output_half", False):
-        raise NotImplementedError("3dgrut_amd: fp16 particle features / outputs are not supported (fp32 only)")
+    # fp16 feature I/O (setup_3dgut.py:60-61): run-time switches here, compile-time macros in the reference
+    cfg.particle_feature_half = int(bool(_conf_get(render, "particle_feature_half", False)))
+    cfg.feature_output_half = int(bool(_conf_get(render, "feature_output_half", False)))
     if _conf_get(splat, "fine_grained_load_balancing", False):
         # Accepted and ignored: the flag selects the reference's warp-per-pixel forward (renderBalanced), whose images differ
         # from its sequential kernel's only in the opacity of rays that end on the transmittance threshold, by < 1e-4
@@ -130,36 +131,43 @@ class _GutNative:
         H, W = frame.height, frame.width
         N = frame.num_particles
         opts = dict(dtype=torch.float32, device=dev)
+        half_out = bool(self.cfg.feature_output_half)
+        fd_opts = dict(dtype=torch.float16 if half_out else torch.float32, device=dev)   # (splatRaster.cpp:198-206)
         if N == 0:  # nothing is launched: the outputs are the reference's initial values (splatRaster.cpp:211-215)
-            out_fd = torch.zeros((H, W, 4), **opts)
+            out_fd = torch.zeros((H, W, 4), **fd_opts)
             out_dist = torch.full((H, W, 1), 1e6, **opts)
             out_cnt = torch.zeros((H, W, 1), **opts)
             vis_i32 = torch.zeros((N, 1), dtype=torch.int32, device=dev)
         else:
             # every pixel / particle is written by the library (tiles cover the image; dead rays store their initial
             # values), so no fill passes: the reference pays four torch::zeros / full per frame here
-            out_fd = _uninitialised((H, W, 4), **opts)
+            out_fd = _uninitialised((H, W, 4), **fd_opts)
             out_dist = _uninitialised((H, W, 1), **opts)
             out_cnt = _uninitialised((H, W, 1), **opts) if self.cfg.enable_hitcounts else torch.zeros((H, W, 1), **opts)
             vis_i32 = _uninitialised((N, 1), dtype=torch.int32, device=dev)
         # `pred_features` / `pred_opacity` as contiguous tensors of their own, like the reference's `.contiguous()` slices
         # (tracer.py:334-337), written by the compositing kernel next to the packed image the backward reads
-        if N == 0:
+        if half_out:   # the caller's fp32 tensors are converted from the half image afterwards (tracer.py:214-215 `.float()`)
+            out_feat = out_opa = None
+        elif N == 0:
             out_feat, out_opa = torch.zeros((H, W, 3), **opts), torch.zeros((H, W, 1), **opts)
         else:
             out_feat, out_opa = _uninitialised((H, W, 3), **opts), _uninitialised((H, W, 1), **opts)
-        frame.out_features, frame.out_opacity = out_feat.data_ptr(), out_opa.data_ptr()
+        frame.out_features, frame.out_opacity = (None, None) if half_out else (out_feat.data_ptr(), out_opa.data_ptr())
         _abi.check(self.lib.gut_forward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
                                         _ptr(ray_ori), _ptr(ray_dir), _ptr(out_fd), _ptr(out_dist), _ptr(out_cnt), _ptr(vis_i32)),
                    "gut_forward")
         # the reference returns a float tensor holding the int bit pattern (splatRaster.cpp:215,249); consumers call .bool()
         frame.out_features, frame.out_opacity = None, None   # the frame outlives this call in the autograd context
+        if half_out:
+            f32 = out_fd.float()
+            out_feat, out_opa = f32[..., :3].contiguous(), f32[..., 3:].contiguous()
         return out_fd, out_dist, out_cnt, vis_i32.view(torch.float32), out_feat, out_opa
 
     def trace_bwd(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_fd, dist, g_dist):
         dev = ray_ori.device
         g_density = torch.empty_like(particle_density)  # both fully overwritten by the gradient-finalisation kernel
-        g_sph = torch.empty_like(particle_sph)
+        g_sph = torch.empty_like(particle_sph, dtype=torch.float32)   # (fp32 also for half coefficients, splatRaster.cpp:300-312)
         _abi.check(self.lib.gut_backward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
                                          _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(g_fd), _ptr(dist), _ptr(g_dist),
                                          _ptr(g_density), _ptr(g_sph)), "gut_backward")
@@ -172,7 +180,7 @@ class _GutNative:
         n = particle_density.shape[0]
         opts = dict(dtype=torch.float32, device=dev)
         g_pos, g_dns, g_rot, g_scl = torch.empty((n, 3), **opts), torch.empty((n, 1), **opts), torch.empty((n, 4), **opts), torch.empty((n, 3), **opts)
-        g_sph = torch.empty_like(particle_sph)
+        g_sph = torch.empty_like(particle_sph, dtype=torch.float32)
         io = _abi.GutGradIO(_ptr(g_feat), _ptr(g_opa), _ptr(g_pos), _ptr(g_dns), _ptr(g_rot), _ptr(g_scl))
         _abi.check(self.lib.gut_backward_unpacked(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
                                                   _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(dist), _ptr(g_dist), C.byref(io), _ptr(g_sph)),
@@ -217,6 +225,8 @@ class Tracer:
                 particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)  # [N,12] rows, one pass (tracer.py's torch.cat)
             ctx.raw = (mog_dns, mog_rot, mog_scl) if raw else None
             particle_features = mog_sph.contiguous()
+            if native.cfg.particle_feature_half and particle_features.dtype != torch.float16:
+                particle_features = particle_features.to(torch.float16)   # per call, like splatRaster.cpp:90-98
             fd, dist, cnt, vis, feat, opa = native.trace(frame, particle_density, particle_features, ray_ori, ray_dir)
             ctx.save_for_backward(ray_ori, ray_dir, fd, dist, particle_density, particle_features)
             ctx.native, ctx.frame, ctx.exchange = native, frame, exchange

@@ -14,7 +14,7 @@ import ctypes as C
 import torch
 
 from . import _abi
-from .grt_tracer import Tracer as _GrtTracer
+from .grt_tracer import Tracer as _GrtTracer, features_for_kernel
 from .gut_tracer import _ptr, _stream_ptr
 
 
@@ -100,7 +100,7 @@ class Tracer(_GrtTracer):
         mats, n_mats = native_materials(materials or [], dev, keep)
         env = _texture(envmap, 4, dev, keep) if (envmap is not None and envmap.dim() == 3) else _abi.GrtTexture(None, 0, 0, 4)
         off = [0.0, 0.0] if envmap_offset is None else [float(x) for x in envmap_offset.detach().flatten().tolist()[:2]]
-        features = gaussians.get_features()
+        sph = features_for_kernel(nat.cfg, gaussians.get_features())
         particle_density = _abi.pack_particles(gaussians.positions.contiguous(), gaussians.get_density().contiguous(),
                                                gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous())
         frame = nat.make_frame(frame_id, gaussians.n_active_features, self._min_transmittance, gaussians.num_gaussians, H, W,
@@ -114,7 +114,7 @@ class Tracer(_GrtTracer):
         bounces = torch.empty((1, H, W, 1), dtype=torch.int32, device=dev)
         ro, rd = ray_o.detach().contiguous().float(), ray_d.detach().contiguous().float()
         tmax = None if ray_max_t is None else ray_max_t.detach().contiguous().float()
-        _abi.check(nat.lib.grt_trace_hybrid(nat.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(features.contiguous()), _ptr(ro),
+        _abi.check(nat.lib.grt_trace_hybrid(nat.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(sph), _ptr(ro),
                                             _ptr(rd), _ptr(tmax), C.byref(mesh), C.byref(opts), _ptr(rgb), _ptr(opa), _ptr(last), _ptr(bounces)),
                    "grt_trace_hybrid")
         zeros = lambda c: torch.zeros((1, H, W, c), device=dev)

@@ -93,6 +93,13 @@ typedef struct GutConfig {
     int32_t rect_bounding;               /* 1 */
     int32_t tight_opacity_bounding;      /* 1 */
     int32_t tile_based_culling;          /* 1 */
+    /* fp16 feature I/O (setup_3dgut.py:60-61 PARTICLE_FEATURE_HALF / FEATURE_OUTPUT_HALF; defaults 0).
+     * particle_feature_half: particle_sph is [N, 3*(deg+1)^2] IEEE half (splatRaster.cpp:90-98 converts the model's tensor per call);
+     *   everything is computed in fp32 from the rounded coefficients, gradients stay fp32.
+     * feature_output_half: out_feat_density (and feat_density of the backward) is [H,W,4] IEEE half (rayPayload.cuh:176-186,
+     *   rayPayloadBackward.cuh:50-58); GutFrame::out_features / out_opacity must then be NULL.  Hit distance / count stay fp32. */
+    int32_t particle_feature_half;
+    int32_t feature_output_half;
 } GutConfig;
 
 /* Per-call frame description: SplatRaster::trace's non-tensor arguments. */
@@ -145,10 +152,11 @@ void gut_destroy(GutHandle* handle);
  *  out_hit_count    : [H,W,1] f32                      fully overwritten when N > 0 and hit counts are enabled; untouched otherwise
  *  out_visibility   : [N]     i32 (bit pattern read by the caller as float, splatRaster.cpp:215), fully overwritten
  *  With N == 0 nothing is launched and the outputs keep whatever the caller put there (the reference's zeros / 1e6). */
+/*  (particle_sph / out_feat_density are void*: fp32 by default, IEEE half with GutConfig::particle_feature_half / feature_output_half) */
 int gut_forward(GutHandle* handle, void* stream, const GutFrame* frame,
-                const float* particle_density, const float* particle_sph,
+                const float* particle_density, const void* particle_sph,
                 const float* ray_origin, const float* ray_direction,
-                float* out_feat_density, float* out_hit_distance,
+                void* out_feat_density, float* out_hit_distance,
                 float* out_hit_count, int32_t* out_visibility);
 
 /*  grad_hit_distance     : [H,W,1] f32 or NULL when no gradient flows into the hit distance (the usual
@@ -158,9 +166,9 @@ int gut_forward(GutHandle* handle, void* stream, const GutFrame* frame,
  *                          needed): gradients are gathered per particle from per-tile-entry partials, not accumulated
  *                          with atomics, so they are bitwise reproducible from run to run */
 int gut_backward(GutHandle* handle, void* stream, const GutFrame* frame,
-                 const float* particle_density, const float* particle_sph,
+                 const float* particle_density, const void* particle_sph,
                  const float* ray_origin, const float* ray_direction,
-                 const float* feat_density, const float* grad_feat_density,
+                 const void* feat_density, const float* grad_feat_density,
                  const float* hit_distance, const float* grad_hit_distance,
                  float* grad_particle_density, float* grad_particle_sph);
 
@@ -179,9 +187,9 @@ typedef struct GutGradIO {
     float* grad_scale;
 } GutGradIO;
 int gut_backward_unpacked(GutHandle* handle, void* stream, const GutFrame* frame,
-                          const float* particle_density, const float* particle_sph,
+                          const float* particle_density, const void* particle_sph,
                           const float* ray_origin, const float* ray_direction,
-                          const float* feat_density, const float* hit_distance, const float* grad_hit_distance,
+                          const void* feat_density, const float* hit_distance, const float* grad_hit_distance,
                           const GutGradIO* io, float* grad_particle_sph);
 
 /* ---- view-sharded data parallelism: the radiance gradient in factored form (new surface; the reference is
@@ -203,9 +211,9 @@ int gut_backward_unpacked(GutHandle* handle, void* stream, const GutFrame* frame
  * With num_views = 1 and scale = 1 the result is bit for bit what gut_backward writes.  Same preconditions and errors as
  * gut_backward (forward context on the same stream); with N == 0 nothing is launched and nothing is written. */
 int gut_backward_factored(GutHandle* handle, void* stream, const GutFrame* frame,
-                          const float* particle_density, const float* particle_sph,
+                          const float* particle_density, const void* particle_sph,
                           const float* ray_origin, const float* ray_direction,
-                          const float* feat_density, const float* grad_feat_density,
+                          const void* feat_density, const float* grad_feat_density,
                           const float* hit_distance, const float* grad_hit_distance,
                           float* grad_particle_density, float* grad_radiance);
 int grut_sph_grad_from_views(void* stream, uint32_t num_particles, uint32_t num_views, const float* view_factors,
@@ -263,6 +271,10 @@ typedef struct GrtConfig {
     int32_t enable_hitcounts;
     int32_t enable_kernel_timings;
     int32_t max_hits_per_trace;            /* 16 (pipelineParameters.h:83) */
+    /* fp16 feature I/O (setup_3dgrt.py:42-43; 3dgrt/pipelineParameters.h:24-46): particle_sph as IEEE half / out_features (and the
+     * `features` input of the backward) as [H,W,3] IEEE half; arithmetic and gradients stay fp32 */
+    int32_t particle_feature_half;
+    int32_t feature_output_half;
 } GrtConfig;
 
 typedef struct GrtFrame {
@@ -344,7 +356,8 @@ int grt_build_mesh_bvh(GrtHandle* handle, void* stream, uint32_t num_vertices, c
 /* rays [H,W,3] in ray space (frame->ray_to_world applies); ray_max_t [H,W] or NULL; out_radiance [H,W,3], out_opacity [H,W,1] fully
  * written; out_last_ray [H,W,6] (world-space origin + direction of the last segment: what the reference writes back into its ray
  * buffers, trace.cuh:158-173) and out_bounces [H,W] (mirror bounces) may be NULL. */
-int grt_trace_hybrid(GrtHandle* handle, void* stream, const GrtFrame* frame, const float* particle_density, const float* particle_sph,
+/* (particle_sph: IEEE half with GrtConfig::particle_feature_half; the four outputs are always fp32) */
+int grt_trace_hybrid(GrtHandle* handle, void* stream, const GrtFrame* frame, const float* particle_density, const void* particle_sph,
                      const float* ray_origin, const float* ray_direction, const float* ray_max_t, const GrtMesh* mesh,
                      const GrtHybridOptions* options, float* out_radiance, float* out_opacity, float* out_last_ray, uint32_t* out_bounces);
 
@@ -364,16 +377,17 @@ int grt_build_bvh(GrtHandle* handle, void* stream, uint32_t num_particles,
  *  rounds scan sorted per-packet lists instead of walking the BVH (identical results; GrtStats::list_entries tells which path ran; the
  *  call then waits once for the list size — a 4-byte read-back — before it enqueues the trace).  Environment GRUT_GRT_NO_LISTS=1
  *  forces the tree walk. */
+/*  (particle_sph / out_features are void*: fp32 by default, IEEE half with GrtConfig::particle_feature_half / feature_output_half) */
 int grt_forward(GrtHandle* handle, void* stream, const GrtFrame* frame,
-                const float* particle_density, const float* particle_sph,
+                const float* particle_density, const void* particle_sph,
                 const float* ray_origin, const float* ray_direction,
-                float* out_features, float* out_density, float* out_hit_distance,
+                void* out_features, float* out_density, float* out_hit_distance,
                 float* out_normals, float* out_hits_count, int32_t* out_visibility);
 
 int grt_backward(GrtHandle* handle, void* stream, const GrtFrame* frame,
-                 const float* particle_density, const float* particle_sph,
+                 const float* particle_density, const void* particle_sph,
                  const float* ray_origin, const float* ray_direction,
-                 const float* features, const float* density, const float* hit_distance, const float* normals,
+                 const void* features, const float* density, const float* hit_distance, const float* normals,
                  const float* grad_features, const float* grad_density,
                  const float* grad_hit_distance, const float* grad_normals,
                  float* grad_particle_density, float* grad_particle_sph);
@@ -381,9 +395,9 @@ int grt_backward(GrtHandle* handle, void* stream, const GrtFrame* frame,
 /* grt_forward that also records, per ray, the particles it processed in order (the BVH hit-order parity test):
  * hit_ids [H*W, capacity] u32, hit_counts [H*W] u32 (counts may exceed capacity; only the first `capacity` are stored) */
 int grt_debug_forward_hits(GrtHandle* handle, void* stream, const GrtFrame* frame,
-                           const float* particle_density, const float* particle_sph,
+                           const float* particle_density, const void* particle_sph,
                            const float* ray_origin, const float* ray_direction,
-                           float* out_features, float* out_density, float* out_hit_distance,
+                           void* out_features, float* out_density, float* out_hit_distance,
                            float* out_normals, float* out_hits_count, int32_t* out_visibility,
                            uint32_t* hit_ids, uint32_t* hit_counts, uint32_t capacity);
 /* Parity aid: until called again with NULLs, every grt_backward also writes, per ray (caller DEVICE buffers of W*H entries, zero-filled

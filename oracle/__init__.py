@@ -54,6 +54,15 @@ def _c(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+def round_to_half(a):
+    """The reference's fp16 feature I/O as the oracle sees it: values stored through IEEE half (round to nearest even, what
+    `.to(torch::kHalf)` of splatRaster.cpp:90-98 / optixTracer.cpp:52-60 and `__float2half` of rayPayload.cuh:176-186 /
+    referenceSlangOptix.cu:183-184 do) and read back as fp32 — all arithmetic stays fp32, so a half-mode run of the oracle is an
+    fp32 run on rounded coefficients (PARTICLE_FEATURE_HALF) whose image is rounded once at the end (FEATURE_OUTPUT_HALF) and
+    handed to the backward in that rounded form (rayPayloadBackward.cuh:50-58, referenceSlangBwdOptix.cu:116-117)."""
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
 def default_gut_config(**kw) -> GutConfig:
     """configs/render/3dgut.yaml + configs/render/3dgrt.yaml defaults (reference)."""
     cfg = GutConfig(

@@ -383,3 +383,45 @@ def test_rays_with_different_origins_take_the_tree_walk(monkeypatch):
     for r in range(num.size):
         k = min(int(num[r]), 128)
         assert np.array_equal(ids[r, :k], ora["hit_ids"][r, :k])
+
+
+@pytest.mark.parametrize("sph_half,out_half", [(True, False), (False, True), (True, True)])
+def test_fp16_feature_io_matches_the_fp32_path_and_the_oracle(sph_half, out_half):
+    """render.particle_feature_half / feature_output_half (setup_3dgrt.py:41-44; optixTracer.cpp:52-60, 903-909): half coefficient
+    buffer, half [H,W,3] feature image, fp32 arithmetic.  Half coefficients = the fp32 path on the rounded coefficients bit for bit;
+    the half image = the fp32 image rounded once; the backward starts from the rounded image (referenceSlangBwdOptix.cu:116-117)."""
+    import torch
+    n, w, h = 800, 48, 32
+    scene = _scene(n, w, h, 0.1)
+    rng = np.random.default_rng(4)
+    g_rad = rng.normal(size=(h, w, 3)).astype(np.float32)
+    g_dns = rng.normal(size=(h, w, 1)).astype(np.float32)
+    rounded = dict(scene, sph=oracle.round_to_half(scene["sph"])) if sph_half else scene
+    ref32 = _render(rounded, g_rad, g_dns)
+    gpu = _render(scene, g_rad, g_dns, particle_feature_half=sph_half, feature_output_half=out_half)
+    f32, f = ref32["out"]["pred_features"], gpu["out"]["pred_features"]
+    assert f.dtype == torch.float32   # always fp32 to the caller (threedgrt_tracer/tracer.py:98)
+    assert torch.equal(f, f32.half().float() if out_half else f32)
+    for k in ("pred_opacity", "pred_dist", "hits_count"):
+        assert torch.equal(gpu["out"][k], ref32["out"][k]), k
+    if not out_half:   # same hits, same values; the gradient atomics commute only up to rounding
+        assert rel_err(gpu["grads"][0], ref32["grads"][0]) < 2e-5 and rel_err(gpu["grads"][1], ref32["grads"][1]) < 2e-5
+    cfg = oracle.default_grt_config()
+    ora = oracle.grt_forward(cfg, rounded["density12"], rounded["sph"], 3, 1e-3, scene["T"], *scene["rays"])
+    got = f[0].detach().cpu().numpy()
+    ulp = np.spacing(np.abs(got).astype(np.float16)).astype(np.float32) if out_half else 0.0
+    assert (np.abs(got - ora["features"]) > 1e-4 + 0.5 * ulp).mean() <= 5e-3
+    if out_half:
+        ora = dict(ora, features=oracle.round_to_half(ora["features"]))
+    rd, rs = oracle.grt_backward(cfg, 3, 1e-3, ora, g_rad, g_dns, np.zeros((h, w, 1), np.float32))
+    n_flip = int((gpu["out"]["hits_count"][0, ..., 0].detach().cpu().numpy() != ora["hit_count"][..., 0]).sum())
+
+    def trimmed(a, b, drop):
+        e = np.abs(np.asarray(a, np.float64) - b).reshape(a.shape[0], -1).max(1)
+        e = np.sort(e)[: max(1, len(e) - drop)]
+        return float(e.max() / (np.abs(b).max() + 1e-12))
+
+    gd, gs = gpu["grads"]
+    for name, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
+        assert trimmed(gd[:, sl], rd[:, sl], 3 * n_flip) < 1e-3, name
+    assert trimmed(gs, rs, 3 * n_flip) < 1e-3 and gs.dtype == np.float32

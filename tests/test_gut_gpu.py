@@ -636,3 +636,48 @@ def test_gradients_match_autograd_golden(name):
     for kname, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
         assert _trimmed_rel_err(gd[:, sl], ref[:, sl], drop) < 1e-3, (name, kname)
     assert _trimmed_rel_err(gsph, g[f"{name}_grad_sph"], drop) < 1e-3
+
+
+@pytest.mark.parametrize("sph_half,out_half", [(True, False), (False, True), (True, True)])
+def test_fp16_feature_io_matches_the_fp32_path_and_the_oracle(sph_half, out_half):
+    """render.particle_feature_half / feature_output_half (setup_3dgut.py:60-61): coefficients are read from a half buffer and the
+    [H,W,4] image is stored as half, arithmetic stays fp32.  So (i) half coefficients give BIT-identical results to the fp32 path fed
+    the rounded coefficients, (ii) the half image is the fp32 image rounded once, (iii) the backward differentiates from the rounded
+    image (rayPayloadBackward.cuh:50-58): oracle backward on the rounded finals, 1e-3 relative."""
+    import torch
+    n, w, h = 3000, 96, 64
+    scene = make_scene(n=n, width=w, height=h, median_scale=0.06)
+    g_fd, g_dist = syn.upstream_grads(w, h)
+    g_fd *= w * h
+    rounded = dict(scene, sph=oracle.round_to_half(scene["sph"])) if sph_half else scene
+    assert not sph_half or np.abs(rounded["sph"] - scene["sph"]).max() > 1e-5   # the rounding is visible in the input
+    ref32 = _run_gpu(rounded, g_fd, None)                                         # the fp32 path on the coefficients the kernels see
+    gpu = _run_gpu(scene, g_fd, None, particle_feature_half=sph_half, feature_output_half=out_half)
+    cat = lambda out: torch.cat([out["pred_features"], out["pred_opacity"]], dim=-1)[0].detach()
+    fd32, fd = cat(ref32["out"]), cat(gpu["out"])
+    assert fd.dtype == torch.float32   # always fp32 to the caller (tracer.py:214-215)
+    if out_half:
+        assert torch.equal(fd, fd32.half().float()), "the half image must be the fp32 image rounded once"
+    else:
+        assert torch.equal(fd, fd32), "half coefficients: same arithmetic on the rounded values"
+    assert torch.equal(gpu["out"]["pred_dist"], ref32["out"]["pred_dist"]) and torch.equal(gpu["out"]["hits_count"], ref32["out"]["hits_count"])
+    if not out_half:
+        assert np.array_equal(gpu["grads"][0], ref32["grads"][0]) and np.array_equal(gpu["grads"][1], ref32["grads"][1])
+    assert gpu["grads"][1].dtype == np.float32
+    # oracle, half mode
+    ora = _run_oracle(rounded)
+    fwd = ora["fwd"]
+    if out_half:
+        fwd = dict(fwd, feat_density=oracle.round_to_half(fwd["feat_density"]))
+        got = fd.detach().cpu().numpy()
+        ulp = np.spacing(np.abs(got).astype(np.float16)).astype(np.float32)
+        assert (np.abs(got - ora["fwd"]["feat_density"]) > 1e-4 + 0.5 * ulp).mean() <= 2e-3
+    else:
+        _image_checks(gpu["out"], fwd)
+    ora = dict(ora, fwd=fwd, grads=oracle.gut_backward(ora["cfg"], scene["cam"], 3, fwd, g_fd, g_dist * 0))
+    names = {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}
+    cnt = gpu["out"]["hits_count"][0, ..., 0].detach().cpu().numpy()
+    drop = 3 * int((cnt != fwd["hit_count"][..., 0]).sum())
+    for k, sl in names.items():
+        assert _trimmed_rel_err(gpu["grads"][0][:, sl], ora["grads"][0][:, sl], drop) < 1e-3, k
+    assert _trimmed_rel_err(gpu["grads"][1], ora["grads"][1], drop) < 1e-3

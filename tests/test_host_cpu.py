@@ -118,8 +118,8 @@ def test_configuration_defaults_and_overrides():
                                                 splat=SimpleNamespace(k_buffer_size=16, tile_based_culling=False)))
     b = gt.gut_config_from_conf(ns)
     assert bytes(a) == bytes(b) and a.particle_kernel_degree == 4 and a.k_buffer_size == 16 and a.tile_based_culling == 0
-    with pytest.raises(NotImplementedError):
-        gt.gut_config_from_conf({"render": {"particle_feature_half": True, "splat": {}}})
+    half = gt.gut_config_from_conf({"render": {"particle_feature_half": True, "splat": {}}})   # (setup_3dgut.py:60-61)
+    assert (half.particle_feature_half, half.feature_output_half) == (1, 0) and (cfg.particle_feature_half, cfg.feature_output_half) == (0, 0)
     assert gt.fused_activations_requested({"render": {"fused_activations": True}}) and not gt.fused_activations_requested({"render": {}})
 
 
@@ -152,7 +152,9 @@ def test_grt_configuration_defaults_and_unsupported_pipelines():
     assert abs(cfg.particle_kernel_max_alpha - 0.99) < 1e-7 and cfg.particle_kernel_density_clamping == 1
     assert cfg.particle_radiance_sph_degree == 3 and cfg.max_hits_per_trace == 16
     assert grt.grt_config_from_conf({"render": {"particle_kernel_degree": 2}}).particle_kernel_degree == 2
-    for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "icosahedron"}, {"particle_feature_half": True}):
+    half = grt.grt_config_from_conf({"render": {"feature_output_half": True}})   # (setup_3dgrt.py:41-44)
+    assert (half.particle_feature_half, half.feature_output_half) == (0, 1) and cfg.feature_output_half == 0
+    for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "icosahedron"}):
         with pytest.raises(NotImplementedError):
             grt.grt_config_from_conf({"render": bad})
 
