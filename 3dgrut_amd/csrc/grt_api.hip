@@ -92,6 +92,8 @@ static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
     for (int k = 0; k < 12; ++k) P.ray_to_world[k] = f.ray_to_world[k];
     P.ray_to_world_dev = f.device_ray_to_world;
     P.sph_half = h->cfg.particle_feature_half;
+    static const int sphere_lists = getenv("GRUT_GRT_SPHERE_LISTS") ? 1 : 0;
+    P.sphere_lists = sphere_lists;
     P.out_half = h->cfg.feature_output_half;
     return P;
 }
@@ -220,7 +222,7 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
         const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
         if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
         GRUT_CHECK(h->l_flags.ensure(64));
-        GRUT_CHECK(h->l_block_cones.ensure((size_t)nb * sizeof(GrtCone), 1.25f));
+        GRUT_CHECK(h->l_block_cones.ensure((size_t)nb * (sizeof(GrtCone) + sizeof(GrtPyramid)), 1.25f));   // cones, then pyramids
         GRUT_CHECK(h->l_super_cones.ensure((size_t)ns * sizeof(GrtCone), 1.25f));
         GRUT_CHECK(h->l_inst_rel.ensure((size_t)N * 64, 1.25f));
         for (DeviceBuffer* b4 : {&h->l_key_bits, &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets})

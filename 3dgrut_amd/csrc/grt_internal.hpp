@@ -47,6 +47,7 @@ struct GrtTraceParams {
     // optional (grt_debug_backward_signature): per ray, how many hits the backward differentiated and an order-independent
     // signature of which particles they were — the parity tests compare the replayed backward with the re-derived one ray by ray
     int sph_half, out_half;   // fp16 feature I/O (GrtConfig::particle_feature_half / feature_output_half)
+    int sphere_lists;         // development switch (GRUT_GRT_SPHERE_LISTS=1): bin by the proxies' bounding spheres only
     unsigned long long* bwd_sig;
     uint32_t* bwd_cnt;
 };
@@ -70,6 +71,17 @@ struct GrtLists {
 struct GrtCone {   // bounding cone of the rays of an 8x8 packet / of a 64x64-pixel super tile, apex at the common ray origin
     float ax, ay, az, cos_t, sin_t, valid, pad0, pad1;
 };
+// Bounding pyramid of a packet's rays, apex at the common origin: in the frame (u, w, cone axis a) every ray direction d has
+// x0 <= (d.u)/(d.a) <= x1 and y0 <= (d.w)/(d.a) <= y1 (u follows the packet's pixel rows, so for a pinhole grid the pyramid is the
+// packet's own frustum, where the cone circumscribes it).  The binning tests the proxy BOX against its four side planes and the
+// cone's tangent plane; [blocks] of them follow the [blocks] cones in the same allocation (grt_block_pyramids).  ok = 0: no pyramid
+// (a packet whose cone is 90 degrees or wider), only the cone test applies.
+struct GrtPyramid {
+    float ux, uy, uz, x0, wx, wy, wz, x1, y0, y1, ok, pad;
+};
+__host__ __device__ inline const GrtPyramid* grt_block_pyramids(const GrtCone* block_cones, uint32_t num_blocks) {
+    return reinterpret_cast<const GrtPyramid*>(block_cones + num_blocks);
+}
 
 // Log of a training forward, so that the backward replays the hits instead of traversing again.  One chunk = what a wave met in one
 // trace round, [slot][lane]: the (up to 16) candidates of each ray's round and the round's ghosts — candidates the round was not

@@ -2079,6 +2079,34 @@ __global__ __launch_bounds__(64) void grt_block_cone_kernel(GrtTraceParams P, co
         if (bad) flag[0] = 0u;
     }
     if (__any(in_image && !same) && lane == 0) flag[0] = 0u;
+    // the packet's bounding pyramid (GrtPyramid): u along the pixel rows (the x-weighted mean of the directions, made perpendicular to
+    // the axis), w = axis x u; the tangents of every ray against both, widened by rounding margins
+    const float wx = good ? (float)(lane & 7) - 3.5f : 0.f;
+    f3 u = mk3(wave_sum(wx * dh.x), wave_sum(wx * dh.y), wave_sum(wx * dh.z));
+    u = u - axis * dot(u, axis);
+    float ul = sqrtf(dot(u, u));
+    if (!(ul > 1e-12f)) {   // (a one-column packet, or parallel rays: any perpendicular will do)
+        u = fabsf(axis.x) < 0.6f ? mk3(1.f, 0.f, 0.f) : mk3(0.f, 1.f, 0.f);
+        u = u - axis * dot(u, axis);
+        ul = sqrtf(dot(u, u));
+    }
+    u = u * (1.f / ul);
+    const f3 w = cross(axis, u);
+    const float dz = dot(dh, axis);
+    const bool fits = good && dz > 0.05f;
+    const float tx = fits ? dot(dh, u) / dz : 0.f, ty = fits ? dot(dh, w) / dz : 0.f;
+    const float x0 = wave_min(good ? tx : 3.0e38f), x1 = wave_max(good ? tx : -3.0e38f);
+    const float y0 = wave_min(good ? ty : 3.0e38f), y1 = wave_max(good ? ty : -3.0e38f);
+    const bool pyr_ok = !__any(good && !fits) && __any(good) && sl > 0.f;
+    if (lane == 0) {
+        GrtPyramid py;
+        py.ux = u.x; py.uy = u.y; py.uz = u.z; py.wx = w.x; py.wy = w.y; py.wz = w.z;
+        const float mx = 1e-5f * (1.f + fmaxf(fabsf(x0), fabsf(x1))), my = 1e-5f * (1.f + fmaxf(fabsf(y0), fabsf(y1)));
+        py.x0 = x0 - mx; py.x1 = x1 + mx; py.y0 = y0 - my; py.y1 = y1 + my;
+        py.ok = pyr_ok ? 1.f : 0.f;
+        py.pad = 0.f;
+        const_cast<GrtPyramid*>(grt_block_pyramids(cones, gridDim.x))[b] = py;
+    }
 }
 // one wave per super tile (8x8 packets): cone around its packets' cones
 __global__ __launch_bounds__(64) void grt_super_cone_kernel(GrtTraceParams P, const GrtCone* __restrict__ cones, GrtCone* __restrict__ super_cones,
@@ -2124,7 +2152,44 @@ struct BinParticle {
     f3 v;            // proxy centre relative to the ray origin
     float L2, Rs;    // |v|^2, radius of the proxy box's bounding sphere
     float key, ub;   // bounds of the hit distance t for any ray of the frame
+    f3 h0, h1, h2;   // the proxy box's half axes in world space: box = centre + s0 h0 + s1 h1 + s2 h2, |s| <= 1
 };
+// Does the proxy BOX reach into the packet?  Every ray of the packet lies in the cone and in the pyramid, both convex with the apex at
+// the common origin; a plane through the apex with the whole packet on one side and the whole box strictly on the other separates
+// them, and a separated box cannot be hit by any ray of the packet.  Tested: the cone's tangent plane facing the box centre (normal
+// n = cos r - sin a, r the unit vector from the axis to the centre: n.v is the sphere test's distance, here compared with the box's
+// half width along n instead of the sphere's radius), the pyramid's four side planes and the plane behind the apex.  Each comparison
+// carries a margin above the rounding of its two sides (relative 1e-5 of |v| + R, i.e. about 1/100 of a pixel).
+__device__ __forceinline__ bool packet_hit(const GrtCone& k, const GrtPyramid& py, f3 v, float L2, float Rs, f3 h0, f3 h1, f3 h2, bool sphere_only) {
+    const f3 a = mk3(k.ax, k.ay, k.az);
+    const float c = dot(v, a);
+    const float sq = sqrtf(fmaxf(0.f, L2 - c * c));
+    const float s = sq * k.cos_t - c * k.sin_t;
+    if (k.valid == 0.f || !(s <= Rs * 1.00001f + 1e-12f)) return false;
+    if (sphere_only || k.cos_t <= -1.f) return true;
+    const float L = sqrtf(L2), margin = 1e-5f * (L + Rs);
+    const float ha0 = dot(h0, a), ha1 = dot(h1, a), ha2 = dot(h2, a);
+    if (sq > 1e-4f * L) {
+        const float ic = k.cos_t / sq;
+        // n.h = cos (h.v - c h.a) / sq - sin h.a
+        const float w0 = (dot(h0, v) - c * ha0) * ic - k.sin_t * ha0, w1 = (dot(h1, v) - c * ha1) * ic - k.sin_t * ha1,
+                    w2 = (dot(h2, v) - c * ha2) * ic - k.sin_t * ha2;
+        if (s > (fabsf(w0) + fabsf(w1) + fabsf(w2)) * 1.00001f + margin) return false;
+    }
+    if (-c > (fabsf(ha0) + fabsf(ha1) + fabsf(ha2)) * 1.00001f + margin) return false;   // wholly behind the apex
+    if (py.ok != 0.f) {
+        const f3 u = mk3(py.ux, py.uy, py.uz), w = mk3(py.wx, py.wy, py.wz);
+        const float vu = dot(v, u), vw = dot(v, w);
+        const float hu0 = dot(h0, u), hu1 = dot(h1, u), hu2 = dot(h2, u), hw0 = dot(h0, w), hw1 = dot(h1, w), hw2 = dot(h2, w);
+        const float m2 = margin * 2.f;   // (|u - x a| <= sqrt(1 + x^2) < 2 for tangents below 1.7)
+        // plane u - x1 a: the packet has n.p <= 0
+        if (vu - py.x1 * c > (fabsf(hu0 - py.x1 * ha0) + fabsf(hu1 - py.x1 * ha1) + fabsf(hu2 - py.x1 * ha2)) * 1.00001f + m2 * (1.f + fabsf(py.x1))) return false;
+        if (py.x0 * c - vu > (fabsf(hu0 - py.x0 * ha0) + fabsf(hu1 - py.x0 * ha1) + fabsf(hu2 - py.x0 * ha2)) * 1.00001f + m2 * (1.f + fabsf(py.x0))) return false;
+        if (vw - py.y1 * c > (fabsf(hw0 - py.y1 * ha0) + fabsf(hw1 - py.y1 * ha1) + fabsf(hw2 - py.y1 * ha2)) * 1.00001f + m2 * (1.f + fabsf(py.y1))) return false;
+        if (py.y0 * c - vw > (fabsf(hw0 - py.y0 * ha0) + fabsf(hw1 - py.y0 * ha1) + fabsf(hw2 - py.y0 * ha2)) * 1.00001f + m2 * (1.f + fabsf(py.y0))) return false;
+    }
+    return true;
+}
 // bounds: the hit "distance" t of a candidate is the ray parameter of the point closest to the centre in the proxy's metric; that point
 // lies within sqrt(3) max(kscl) of the centre whenever the ray touches the proxy box (the box holds a point of the ray at metric distance
 // <= sqrt 3 and the closest one is no farther), so |o + t d - mu| <= Rt and (|v| - Rt) / |d| <= t <= (|v| + Rt) / |d|
@@ -2133,6 +2198,8 @@ __device__ __forceinline__ BinParticle bin_particle(const float4& a, const float
     const float k0 = 1.f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), k1 = 1.f / sqrtf(a.w * a.w + b.x * b.x + b.y * b.y),
                 k2 = 1.f / sqrtf(b.z * b.z + b.w * b.w + e.x * e.x);   // rows of W = R^T / kscl
     q.Rs = sqrtf(k0 * k0 + k1 * k1 + k2 * k2) * 1.00001f;
+    // half axis i = (row i of W) / |row i|^2: W h_i = e_i, the box is |W (x - mu)|_inf <= 1
+    q.h0 = mk3(a.x, a.y, a.z) * (k0 * k0); q.h1 = mk3(a.w, b.x, b.y) * (k1 * k1); q.h2 = mk3(b.z, b.w, e.x) * (k2 * k2);
     const float Rt = 1.7320509f * fmaxf(k0, fmaxf(k1, k2)) * 1.00001f;
     q.v = mk3(e.y - o.x, e.z - o.y, e.w - o.z);
     q.L2 = dot(q.v, q.v);
@@ -2162,13 +2229,19 @@ __device__ __forceinline__ uint32_t bin_pairs(const GrtTraceParams& P, const Grt
         const bool exists = bx < gx && by < gy;
         const uint32_t b = exists ? by * gx + bx : 0u;
         GrtCone kc = {0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f};
-        if (m && exists) kc = block_cones[b];
+        GrtPyramid kp = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (m && exists) {
+            kc = block_cones[b];
+            kp = grt_block_pyramids(block_cones, gx * gy)[b];
+        }
         while (m) {
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
             const f3 v = mk3(bc(q.v.x, src), bc(q.v.y, src), bc(q.v.z, src));
             const float L2 = bc(q.L2, src), Rs = bc(q.Rs, src);
-            const bool hit = exists && cone_hit(kc, v, L2, Rs);
+            const f3 h0 = mk3(bc(q.h0.x, src), bc(q.h0.y, src), bc(q.h0.z, src)), h1 = mk3(bc(q.h1.x, src), bc(q.h1.y, src), bc(q.h1.z, src)),
+                     h2 = mk3(bc(q.h2.x, src), bc(q.h2.y, src), bc(q.h2.z, src));
+            const bool hit = exists && packet_hit(kc, kp, v, L2, Rs, h0, h1, h2, P.sphere_lists != 0);
             const unsigned long long hm = __ballot(hit);
             const uint32_t cnt = (uint32_t)__popcll(hm);
             if (EMIT) {
