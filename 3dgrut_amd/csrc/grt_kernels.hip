@@ -1244,26 +1244,24 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
     if (P.bwd_sig && handled) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
 }
 
-// backward from the forward's hit log — no traversal, and the gradient traffic is aggregated per wave.
+// backward from the forward's hit log — no traversal.
 // Every lane walks ITS chunk sequence (processed hits and ghosts in hit-distance order, GrtHitLog) with the state machine of the
 // reference's backward program (referenceBwdOptix.cu:123-166): a trace from startT + eps to endT returns the 16 nearest candidates
 // whose hit distance lies in that interval and whose box interval touches it, every returned hit is differentiated, startT moves to
 // the largest of their distances.  Candidates arrive in ascending order, so "the 16 nearest of a trace" is a running count.
-// The reference issues 11 + 48 atomicAdds per hit and ray (gaussianParticles.cuh:468-731); the 64 rays of an 8x8 block
-// mostly hit the same particles, so per group of slots the wave works in two phases:
-//   A. every lane walks ITS hits in order and advances its ray state (transmittance, radiance, depth), leaving per hit
-//      the five scalars the gradient is linear in: dL/d alpha ("common"), weight * dL/d depth, and the clamp-masked
-//      weight * dL/d radiance;
-//   B. particle by particle (taken from the first lane that still has one pending), every lane that holds the same
-//      particle at the same or a neighbouring slot joins in: the particle record is fetched once for the wave, each lane
-//      turns its five scalars into the 11 + 48 gradient terms, the terms are reduce-scattered over the wave with DPP
-//      and ONE atomic set per (wave, particle) goes to memory.  Lanes that hold the particle at a farther slot simply
-//      lead (or join) a later group: matching quality only affects how much is aggregated, never the result.
-constexpr int kAggWindow = 2;   // slots on either side of the leader's slot that are searched for the same particle
-#ifndef GRT_AGG_SLOTS
-#define GRT_AGG_SLOTS 8
-#endif
-constexpr int kAggSlots = GRT_AGG_SLOTS;    // hits of a round worked off together (two halves per round)
+// Gradient traffic.  The reference issues 11 + 48 atomicAdds per hit from the hit's own lane (gaussianParticles.cuh:468-731): 59
+// instructions per slot whose 64 lanes address 64 different particles — 64 cache lines each (79 ms at 1 M particles, round 2).
+// Round 2 went particle-major: per distinct particle of a slot group the whole wave re-derived the gradient terms and reduce-
+// scattered them with DPP.  That pays when many rays of a packet hit the same particle; on the million-particle frames a particle
+// covers 1.9 of the packet's 64 rays, and the wave spent 4.9 G instructions on 23 M groups of two lanes (10.2 ms, 77 % VALU-busy).
+// Now hit-major with TRANSPOSED atomics: per slot
+//   A. every lane advances its ray state over its hit and computes that hit's own 11 geometry-gradient terms and the three
+//      clamp-masked colour weights (dL/d radiance * weight), once, in parallel over the lanes, and leaves them in LDS;
+//   B. hit by hit (ballot order) the wave turns ONE lane's hit into its 11 + 3 * nact gradient words, lane j holding word j
+//      (SH words = the hit ray's basis value, kept in LDS per ray, times the colour weight): one atomic instruction whose lanes
+//      address consecutive words of one particle — four cache lines per hit instead of 59 x 1.
+constexpr int kTermStride = 15;    // per lane: 11 geometry terms + 3 colour weights, padded to an odd stride (LDS banks)
+constexpr int kBasisStride = 17;
 
 template <int DEG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
@@ -1273,12 +1271,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                                             const float* __restrict__ g_dns, const float* __restrict__ g_hit,
                                                             float* __restrict__ g_density12, float* __restrict__ g_sph, GrtHitLog log,
                                                             const float* __restrict__ inst, const float* __restrict__ scene) {
-    // per (slot, lane): the two scalars every gradient term is built from, and which colour channels were not clamped
-    // (dL = rad_grad * weight on those).  A round is worked off in two halves of kAggSlots = 8 hits (state walk, then aggregation):
-    // 6.6 KB per wave instead of 13 (first version: 24.5) — LDS, not registers, capped the occupancy at three waves per SIMD.
-    __shared__ uint32_t s_id[kAggSlots * 64];
-    __shared__ float s_common[kAggSlots * 64], s_weight[kAggSlots * 64];
-    __shared__ uint8_t s_chan[kAggSlots * 64];
+    __shared__ float s_terms[64 * kTermStride], s_basis[64 * kBasisStride];
     if (log.state[1] != 0u) return;  // the log overflowed: the traversal kernel handles this frame
     const int lane = threadIdx.x;
     const PixelBlock pb = pixel_block(P.W, P.H);
@@ -1289,6 +1282,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const RayW r = make_ray(P, ray_o, ray_d, pix);
     float basis[16];
     sh_basis16(P.sph_degree, r.d, basis);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s_basis[lane * kBasisStride + k] = basis[k];
     const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
     const f3 rad_fin = load_radiance(P, in_rad, pix);
     const float T_fin = 1.f - in_dns[pix], depth_fin = in_hit2[2 * pix];
@@ -1297,6 +1292,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     f3 rad = mk3(0.f, 0.f, 0.f);
     float T = 1.f, depth = 0.f;
     const bool replayed = in_image && !(log.ray_flags[pix] & kGrtRederiveRay);   // (else: the exact rounds of grt_trace_bwd_kernel serve this ray)
+    // the scatter's lane roles: word j of a hit's gradient — SH words first (their row is 3 * ncoef floats), then the 11 packed terms
+    const bool sh_lane = lane < 48;
+    const int coef = lane / 3, chn = lane - 3 * coef;
+    const bool word_used = sh_lane ? (lane < 3 * nact) : (lane < 59);
+    const int term_word = sh_lane ? 11 + chn : (lane < 59 ? lane - 48 : 0);
+    const int basis_word = sh_lane ? coef : 0;
+    float* const row_base = sh_lane ? g_sph + lane : g_density12 + (lane < 59 ? lane - 48 : 0);
+    const uint32_t row_stride = sh_lane ? (uint32_t)(3 * P.ncoef) : 12u;
     // the backward program's trace state
     constexpr float eps = 1e-9f;
     float tEnter, tExit;
@@ -1311,21 +1314,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     unsigned long long dbg_sig = 0ull;
     uint32_t dbg_n = 0u;
     const uint32_t block = pb.index;
+    __syncthreads();
     for (uint32_t round = 0; round < log.max_rounds; ++round) {
         const uint32_t c = log.table[(size_t)block * log.max_rounds + round];
         if (c == 0xFFFFFFFFu) break;
         const uint32_t* chunk = log.pool + (size_t)c * (kGrtLogSlots * 64) + lane;
         fw_start2 = fw_start1; fw_start1 = fw_start0; fw_start0 = fw_last;
         if (replayed && chunk[0] != 0xFFFFFFFFu && bw_start < fw_start2) premise_broken = true;
-      for (int half = 0; half < kGrtLogSlots; half += kAggSlots) {
-        // ---- phase A: per-lane state walk ----
-        uint32_t pending = 0u;
 #pragma unroll 1
-        for (int ii = 0; ii < kAggSlots; ++ii) {
-            const int i = half + ii;
-            uint32_t id = (i < kGrtLogSlots && replayed) ? chunk[i * 64] : 0xFFFFFFFFu;
-            float common = 0.f, wgt = 0.f;
-            uint32_t chan = 0u;
+        for (int i = 0; i < kGrtLogSlots; ++i) {
+            // ---- A: the lane's own hit ----
+            uint32_t id = replayed ? chunk[i * 64] : 0xFFFFFFFFu;
+            if (!__any(id != 0xFFFFFFFFu)) break;   // (a chunk's slots are filled from the front on every lane)
             bool contributes = false;
             if (id != 0xFFFFFFFFu) {
                 const bool ghost = (id & kGrtGhostBit) != 0u;
@@ -1342,8 +1342,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     const HitGeom g = hit_geometry<DEG>(P, p, r);
                     if (g.accept) {
                         const float pdot = -dot(g.grd, g.gro);
-                        const f3 grds = p.scl * g.grd * pdot;
-                        const float gdist = sqrtf(dot(grds, grds));
+                        const f3 grdd = g.grd * pdot;
+                        const f3 grds = p.scl * grdd;
+                        const float gsq = dot(grds, grds);
+                        const float gdist = sqrtf(gsq);
                         const float weight = g.galpha * T;
                         const float nextT = (1.f - g.galpha) * T;
                         depth = fmaf(weight, gdist, depth);
@@ -1353,119 +1355,68 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                         const float galphaRayDnsGrd = resTrm * -T_grad;
                         const f3 gradu = sh_radiance(P, sph, id, basis);
                         const f3 grad = mk3(fmaxf(gradu.x, 0.f), fmaxf(gradu.y, 0.f), fmaxf(gradu.z, 0.f));
-                        chan = (gradu.x > 0.f ? 1u : 0u) | (gradu.y > 0.f ? 2u : 0u) | (gradu.z > 0.f ? 4u : 0u);
                         rad = rad + grad * weight;
                         f3 resRad = mk3(0.f, 0.f, 0.f);
                         if (!(nextT <= P.min_transmittance)) {
                             const float inT = 1.f / nextT;
                             resRad = mk3(fmaxf((rad_fin.x - rad.x) * inT, 0.f), fmaxf((rad_fin.y - rad.y) * inT, 0.f), fmaxf((rad_fin.z - rad.z) * inT, 0.f));
                         }
-                        common = galphaRayHitGrd + galphaRayDnsGrd + T * (grad.x - resRad.x) * rad_grad.x + T * (grad.y - resRad.y) * rad_grad.y +
-                                 T * (grad.z - resRad.z) * rad_grad.z;
-                        wgt = weight;
+                        const float common = galphaRayHitGrd + galphaRayDnsGrd + T * (grad.x - resRad.x) * rad_grad.x + T * (grad.y - resRad.y) * rad_grad.y +
+                                             T * (grad.z - resRad.z) * rad_grad.z;
                         T = nextT;
                         contributes = true;
-                    }
-                }
-            }
-            if (!contributes) id = 0xFFFFFFFFu;
-            else pending |= (1u << ii);
-            s_id[ii * 64 + lane] = id;
-            s_common[ii * 64 + lane] = common;
-            s_weight[ii * 64 + lane] = wgt;
-            s_chan[ii * 64 + lane] = (uint8_t)chan;
-        }
-        __syncthreads();
-        // ---- phase B: particle-major aggregation ----
-#pragma unroll 1
-        for (int sl = 0; sl < kAggSlots; ++sl) {
-            while (true) {
-                const unsigned long long m = __ballot((pending >> sl) & 1u);
-                if (!m) break;
-                const int leader = __ffsll((long long)m) - 1;
-                const uint32_t pid = s_id[sl * 64 + leader];   // wave-uniform
-                // find this particle among my pending hits near slot sl
-                int mine = -1;
-#pragma unroll
-                for (int d = -kAggWindow; d <= kAggWindow; ++d) {
-                    const int t = sl + d;
-                    if (t >= 0 && t < kAggSlots && mine < 0 && ((pending >> t) & 1u) && s_id[t * 64 + lane] == pid) mine = t;
-                }
-                const bool part = mine >= 0;
-                const int t = part ? mine : 0;
-                const float common = part ? s_common[t * 64 + lane] : 0.f;
-                const float wgt = part ? s_weight[t * 64 + lane] : 0.f;
-                const uint32_t chan = part ? (uint32_t)s_chan[t * 64 + lane] : 0u;
-                const float wd = wgt * depth_grad;
-                const f3 dL = mk3((chan & 1u) ? rad_grad.x * wgt : 0.f, (chan & 2u) ? rad_grad.y * wgt : 0.f, (chan & 4u) ? rad_grad.z * wgt : 0.f);
-                if (part) pending &= ~(1u << t);
-                // gradient terms of particle pid for this lane (zero for lanes that do not take part)
-                const uint32_t upid = (uint32_t)__builtin_amdgcn_readfirstlane((int)pid);
-                const Particle p = load_particle_uniform(density12, upid);
-                const HitGeom g = hit_geometry<DEG>(P, p, r);
-                const f3 gscl = p.scl;
-                const float pdot = -dot(g.grd, g.gro);
-                const f3 grdd = g.grd * pdot;
-                const f3 grds = gscl * grdd;
-                const float gsq = dot(grds, grds);
-                const float gdist = sqrtf(gsq);
-                const f3 grdsRayHitGrd = gsq > 0.f ? grds * (wd / gdist) : mk3(0.f, 0.f, 0.f);
-                const f3 gsclRayHitGrd = grdd * grdsRayHitGrd;
-                const float grdScaledDot = dot(grdsRayHitGrd * gscl, g.grd);
-                const f3 grdRayHitGrd = gscl * grdsRayHitGrd * pdot - g.gro * grdScaledDot;
-                const f3 groRayHitGrd = g.grd * (-grdScaledDot);
-                const float gresGrd = p.density * common;
-                const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, gresGrd);
-                const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
-                const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x,
-                                      gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
-                const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z,
-                                      gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
-                const f3 groTot = groGrd + groRayHitGrd;
-                const f3 is2 = g.giscl * g.giscl;
-                const f3 gsclGrdGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;
-                const f3 gposcrGrd = g.giscl * groTot;
-                const f3 gposcGrd = mul_cols(p.rotT, gposcrGrd);
-                const float4 gq1 = matmul_bw_quat(g.gposc, gposcrGrd, p.quat);
-                const f3 dn = grdGrd + grdRayHitGrd;
-                const float l2 = dot(g.grdu, g.grdu);
-                f3 grduGrd = mk3(0.f, 0.f, 0.f);
-                if (l2 > 0.f) {
-                    const float il = 1.f / sqrtf(l2);
-                    grduGrd = dn * il - g.grdu * (il * il * il * dot(dn, g.grdu));
-                }
-                const f3 sclGrd = gsclRayHitGrd + gsclGrdGro + mk3(-g.rdr.x * is2.x, -g.rdr.y * is2.y, -g.rdr.z * is2.z) * grduGrd;
-                const float4 gq2 = matmul_bw_quat(r.d, g.giscl * grduGrd, p.quat);
-                const float mk = part ? 1.f : 0.f;   // non-participants: every term is already zero except through NaN-free math
-                float terms[16];
-                terms[0] = -gposcGrd.x * mk; terms[1] = -gposcGrd.y * mk; terms[2] = -gposcGrd.z * mk; terms[3] = g.gres * common;
-                terms[4] = (gq1.x + gq2.x) * mk; terms[5] = (gq1.y + gq2.y) * mk; terms[6] = (gq1.z + gq2.z) * mk; terms[7] = (gq1.w + gq2.w) * mk;
-                terms[8] = sclGrd.x * mk; terms[9] = sclGrd.y * mk; terms[10] = sclGrd.z * mk;
-                terms[11] = terms[12] = terms[13] = terms[14] = terms[15] = 0.f;
-                const float tot = wave_reduce_scatter16(terms, lane);
-                if (lane < 11) atomicAdd(g_density12 + 12 * (size_t)upid + lane, tot);
-                // SH gradient: 3 * nact terms, 16 at a time
-                float* gs = g_sph + (size_t)upid * 3 * P.ncoef;
-#pragma unroll
-                for (int pass = 0; pass < 3; ++pass) {   // compile-time bases keep `basis` in registers
-                    constexpr int kDummy = 0;
-                    (void)kDummy;
-                    const int base = pass * 16;
-                    if (base < 3 * nact) {
-                        float st[16];
-#pragma unroll
-                        for (int k = 0; k < 16; ++k) {
-                            const int e = base + k, coef = e / 3, ch = e - 3 * coef;
-                            st[k] = (e < 3 * nact) ? basis[coef] * (ch == 0 ? dL.x : (ch == 1 ? dL.y : dL.z)) : 0.f;
+                        // the hit's gradient words (gaussianParticles.cuh:468-731), left in LDS for the scatter
+                        float* const tw = s_terms + lane * kTermStride;
+                        tw[11] = gradu.x > 0.f ? rad_grad.x * weight : 0.f;
+                        tw[12] = gradu.y > 0.f ? rad_grad.y * weight : 0.f;
+                        tw[13] = gradu.z > 0.f ? rad_grad.z * weight : 0.f;
+                        const float wd = weight * depth_grad;
+                        const f3 gscl = p.scl;
+                        const f3 grdsRayHitGrd = gsq > 0.f ? grds * (wd / gdist) : mk3(0.f, 0.f, 0.f);
+                        const f3 gsclRayHitGrd = grdd * grdsRayHitGrd;
+                        const float grdScaledDot = dot(grdsRayHitGrd * gscl, g.grd);
+                        const f3 grdRayHitGrd = gscl * grdsRayHitGrd * pdot - g.gro * grdScaledDot;
+                        const f3 groRayHitGrd = g.grd * (-grdScaledDot);
+                        const float gresGrd = p.density * common;
+                        const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, gresGrd);
+                        const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
+                        const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x,
+                                              gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
+                        const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z,
+                                              gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
+                        const f3 groTot = groGrd + groRayHitGrd;
+                        const f3 is2 = g.giscl * g.giscl;
+                        const f3 gsclGrdGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;
+                        const f3 gposcrGrd = g.giscl * groTot;
+                        const f3 gposcGrd = mul_cols(p.rotT, gposcrGrd);
+                        const float4 gq1 = matmul_bw_quat(g.gposc, gposcrGrd, p.quat);
+                        const f3 dn = grdGrd + grdRayHitGrd;
+                        const float l2 = dot(g.grdu, g.grdu);
+                        f3 grduGrd = mk3(0.f, 0.f, 0.f);
+                        if (l2 > 0.f) {
+                            const float il = 1.f / sqrtf(l2);
+                            grduGrd = dn * il - g.grdu * (il * il * il * dot(dn, g.grdu));
                         }
-                        const float ts = wave_reduce_scatter16(st, lane);
-                        if (lane < 16 && base + lane < 3 * nact) atomicAdd(gs + base + lane, ts);
+                        const f3 sclGrd = gsclRayHitGrd + gsclGrdGro + mk3(-g.rdr.x * is2.x, -g.rdr.y * is2.y, -g.rdr.z * is2.z) * grduGrd;
+                        const float4 gq2 = matmul_bw_quat(r.d, g.giscl * grduGrd, p.quat);
+                        tw[0] = -gposcGrd.x; tw[1] = -gposcGrd.y; tw[2] = -gposcGrd.z; tw[3] = g.gres * common;
+                        tw[4] = gq1.x + gq2.x; tw[5] = gq1.y + gq2.y; tw[6] = gq1.z + gq2.z; tw[7] = gq1.w + gq2.w;
+                        tw[8] = sclGrd.x; tw[9] = sclGrd.y; tw[10] = sclGrd.z;
                     }
                 }
             }
+            // ---- B: one atomic instruction per hit, lanes = the words of its gradient ----
+            unsigned long long m = __ballot(contributes);
+            __syncthreads();
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
+                const float v = s_terms[src * kTermStride + term_word] * (sh_lane ? s_basis[src * kBasisStride + basis_word] : 1.f);
+                if (word_used && v != 0.f) atomicAdd(row_base + (size_t)pid * row_stride, v);
+            }
+            __syncthreads();
         }
-        __syncthreads();
-      }
     }
     if (P.bwd_sig && replayed) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
     // rays whose ghost premise failed (see GhostLog): their gradient may miss a hit the reference's backward would have been offered
