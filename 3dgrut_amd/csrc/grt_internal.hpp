@@ -154,10 +154,11 @@ void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* 
                            uint32_t* dir_len_enc /* [2] */, GrtCone* block_cones, GrtCone* super_cones);
 void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                            const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, float* inst_rel, uint32_t* key_bits,
-                           uint32_t* counts, uint32_t* particle_idx);
+                           uint32_t* counts, uint32_t* particle_idx, void* pair_cache /* grt_pair_cache_bytes(N) */);
 void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                             const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, const uint32_t* rank_to_particle,
-                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals);
+                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals, void* pair_cache);
+size_t grt_pair_cache_bytes(uint32_t N);
 void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, uint32_t* ranges);
 uint32_t grt_num_blocks(int W, int H);
 uint32_t grt_num_super(int W, int H);

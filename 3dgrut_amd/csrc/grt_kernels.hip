@@ -1989,6 +1989,7 @@ void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float*
 __host__ __device__ __forceinline__ uint32_t blocks_x(int W) { return (uint32_t)(W + 7) / 8u; }
 __host__ __device__ __forceinline__ uint32_t blocks_y(int H) { return (uint32_t)(H + 7) / 8u; }
 uint32_t grt_num_blocks(int W, int H) { return blocks_x(W) * blocks_y(H); }
+size_t grt_pair_cache_bytes(uint32_t N) { return (size_t)N * (4 * 16 + 4); }   // kBinCachedPairs uint4 + the pair count, per particle
 uint32_t grt_num_super(int W, int H) { return ((blocks_x(W) + 7u) / 8u) * ((blocks_y(H) + 7u) / 8u); }
 
 __global__ void grt_list_init_kernel(uint32_t* __restrict__ flag, uint32_t* __restrict__ dir_len_enc) {
@@ -2166,16 +2167,24 @@ __device__ __forceinline__ BinParticle bin_particle(const float4& a, const float
 // not one lane 64 steps per super tile.  EMIT: write the entries (counting pass otherwise).
 struct BinOut {
     uint32_t *block_keys, *vals;   // sort key = packet, payload = particle (the sorted payloads ARE the lists)
+    // The counting pass leaves what it found — per particle up to kBinCachedPairs (super tile, 64-bit packet mask) pairs and their number —
+    // so that the emitting pass writes the entries from the masks instead of testing every packet again (1.28 -> ms; a particle with
+    // more pairs than the cache holds is tested again)
+    uint4* pairs;       // [N][kBinCachedPairs] {super tile, mask lo, mask hi, -}
+    uint32_t* pair_n;   // [N] pairs found (may exceed the cache)
 };
+constexpr int kBinCachedPairs = 4;
 template <bool EMIT>
 __device__ __forceinline__ uint32_t bin_pairs(const GrtTraceParams& P, const GrtCone* __restrict__ block_cones, const GrtCone* __restrict__ super_cones,
                                               int lane, bool have, const BinParticle& q, uint32_t pid, uint32_t off, uint32_t end, const BinOut& out) {
     const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H), sx = (gx + 7u) / 8u, sy = (gy + 7u) / 8u;
     const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    uint32_t n = 0;
+    uint32_t n = 0, np = 0;
     auto bc = [](float x, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src)); };
     for (uint32_t s = 0; s < sx * sy; ++s) {
-        unsigned long long m = __ballot(have && cone_hit(super_cones[s], q.v, q.L2, q.Rs));
+        // (the super tile's cone against the box too: the bounding sphere of a needle reaches super tiles its box stays clear of)
+        const GrtPyramid no_pyramid = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        unsigned long long m = __ballot(have && packet_hit(super_cones[s], no_pyramid, q.v, q.L2, q.Rs, q.h0, q.h1, q.h2, P.sphere_lists != 0));
         const uint32_t bx = (s % sx) * 8u + (uint32_t)(lane & 7), by = (s / sx) * 8u + (uint32_t)(lane >> 3);
         const bool exists = bx < gx && by < gy;
         const uint32_t b = exists ? by * gx + bx : 0u;
@@ -2205,6 +2214,10 @@ __device__ __forceinline__ uint32_t bin_pairs(const GrtTraceParams& P, const Grt
                 if (lane == src) off += cnt;
             } else if (lane == src) {
                 n += cnt;
+                if (cnt) {
+                    if (np < (uint32_t)kBinCachedPairs) out.pairs[(size_t)pid * kBinCachedPairs + np] = make_uint4(s, (uint32_t)hm, (uint32_t)(hm >> 32), 0u);
+                    np++;
+                }
             }
         }
     }
@@ -2212,14 +2225,45 @@ __device__ __forceinline__ uint32_t bin_pairs(const GrtTraceParams& P, const Grt
         for (; off < end; ++off) {   // (same tests as the counting pass: not expected)
             out.block_keys[off] = 0xFFFFFFFFu; out.vals[off] = 0xFFFFFFFFu;
         }
+    } else if (have) {
+        out.pair_n[pid] = np;
     }
     return n;
+}
+// the emitting pass for the particles whose pairs the counting pass cached: pair by pair, the wave writes the packets of one mask
+__device__ __forceinline__ void emit_cached_pairs(const GrtTraceParams& P, int lane, bool cached, uint32_t pid, uint32_t np, uint32_t& off, uint32_t end,
+                                                  const BinOut& out) {
+    const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H), sx = (gx + 7u) / 8u;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 1
+    for (int k = 0; k < kBinCachedPairs; ++k) {
+        unsigned long long m = __ballot(cached && (uint32_t)k < np);
+        if (!m) break;
+        uint4 pr = make_uint4(0u, 0u, 0u, 0u);
+        if (cached && (uint32_t)k < np) pr = out.pairs[(size_t)pid * kBinCachedPairs + k];
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)pr.x, src);
+            const unsigned long long hm = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pr.y, src) |
+                                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)pr.z, src) << 32);
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, src), e = (uint32_t)__builtin_amdgcn_readlane((int)end, src);
+            const uint32_t bx = (s % sx) * 8u + (uint32_t)(lane & 7), by = (s / sx) * 8u + (uint32_t)(lane >> 3);
+            const uint32_t slot = o + (uint32_t)__popcll(hm & lt);
+            if (((hm >> lane) & 1ull) && slot < e) {
+                out.block_keys[slot] = by * gx + bx;
+                out.vals[slot] = (uint32_t)__builtin_amdgcn_readlane((int)pid, src);
+            }
+            if (lane == src) off += (uint32_t)__popcll(hm);
+        }
+    }
 }
 __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, GrtBvh bvh, const float* __restrict__ ray_o,
                                                              const uint32_t* __restrict__ flag, const uint32_t* __restrict__ dir_len_enc,
                                                              const GrtCone* __restrict__ block_cones, const GrtCone* __restrict__ super_cones,
                                                              float* __restrict__ inst_rel, uint32_t* __restrict__ key_bits,
-                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ particle_idx) {
+                                                             uint32_t* __restrict__ counts, uint32_t* __restrict__ particle_idx, uint4* __restrict__ pairs,
+                                                             uint32_t* __restrict__ pair_n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool have = i < bvh.N && flag[0] != 0u;
@@ -2231,8 +2275,8 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
         a = rec[0]; b = rec[1]; e = rec[2];
     }
     const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
-    const BinOut none = {nullptr, nullptr};
-    const uint32_t n = bin_pairs<false>(P, block_cones, super_cones, lane, have, q, i, 0u, 0u, none);
+    const BinOut cache = {nullptr, nullptr, pairs, pair_n};
+    const uint32_t n = bin_pairs<false>(P, block_cones, super_cones, lane, have, q, i, 0u, 0u, cache);
     if (i >= bvh.N) return;
     counts[i] = have ? n : 0u;   // (particle_idx, the payload of the key sort, is an iota: generated by the sort's first pass)
     key_bits[i] = (have && n) ? __float_as_uint(q.key) : 0xFFFFFFFFu;   // sort key (the sort consumes this array); particles no packet can reach go last
@@ -2268,8 +2312,16 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
         const float4* rec = reinterpret_cast<const float4*>(bvh.inst) + 3 * (size_t)p;
         a = rec[0]; b = rec[1]; e = rec[2];
     }
+    const uint32_t np = have ? out.pair_n[p] : 0u;
+    const bool cached = have && np <= (uint32_t)kBinCachedPairs;
+    emit_cached_pairs(P, lane, cached, p, np, off, end, out);
+    // (what the cache did not hold: tested again; pads whatever the masks left unwritten, which is not expected)
     const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
-    bin_pairs<true>(P, block_cones, super_cones, lane, have, q, p, off, have ? end : off, out);
+    const bool again = have && !cached;
+    if (__any(again)) bin_pairs<true>(P, block_cones, super_cones, lane, again, q, p, off, again ? end : off, out);
+    if (cached) {
+        for (; off < end; ++off) { out.block_keys[off] = 0xFFFFFFFFu; out.vals[off] = 0xFFFFFFFFu; }
+    }
 }
 __global__ __launch_bounds__(256) void grt_list_ranges_kernel(uint32_t n, uint32_t num_blocks, const uint32_t* __restrict__ sorted_keys,
                                                               uint32_t* __restrict__ ranges) {
@@ -2306,14 +2358,16 @@ void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* 
 }
 void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                            const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, float* inst_rel, uint32_t* key_bits,
-                           uint32_t* counts, uint32_t* particle_idx) {
+                           uint32_t* counts, uint32_t* particle_idx, void* pair_cache) {
     hipLaunchKernelGGL(grt_list_count_kernel, dim3(div_up(bvh.N, 256)), dim3(256), 0, s, P, bvh, ray_o, uniform_origin, dir_len_enc, block_cones,
-                       super_cones, inst_rel, key_bits, counts, particle_idx);
+                       super_cones, inst_rel, key_bits, counts, particle_idx, reinterpret_cast<uint4*>(pair_cache),
+                       reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(pair_cache) + (size_t)bvh.N * kBinCachedPairs));
 }
 void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                             const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, const uint32_t* rank_to_particle,
-                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals) {
-    const BinOut out = {block_keys, vals};
+                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals, void* pair_cache) {
+    const BinOut out = {block_keys, vals, reinterpret_cast<uint4*>(pair_cache),
+                        reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(pair_cache) + (size_t)bvh.N * kBinCachedPairs)};
     hipLaunchKernelGGL(grt_list_expand_kernel, dim3(div_up(bvh.N, 256)), dim3(256), 0, s, P, bvh, ray_o, uniform_origin, dir_len_enc, block_cones,
                        super_cones, rank_to_particle, offsets, capacity, out);
 }

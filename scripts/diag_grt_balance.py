@@ -49,3 +49,6 @@ for name, order in (("launch order", np.argsort(start)), ("longest first", np.ar
         t = heapq.heappop(slots)
         heapq.heappush(slots, t + life[i])
     print(f"greedy schedule of the measured lifetimes, {name}: makespan {max(slots) / 1e3:.2f} ms")
+names = ["wave_node_visits", "lane_tests", "processed_hits", "lane_rounds", "lane_inserts", "lane_passed_all", "lane_rej_t_range", "lane_rej_box", "lane_rej_distance",
+         "wave_tests", "wave_tests_with_a_lane_in_t_range", "wave_tests_with_an_insert", "list_batches"]
+print({k: int(v) for k, v in zip(names, raw[:13])})
