@@ -31,6 +31,7 @@ struct GutHandle {
     // per-particle scratch
     DeviceBuffer tiles_count, proj_pos, conic_opacity, extent, depth, rgb, depth_key, particle_idx;
     DeviceBuffer depth_key_tmp, particle_idx_tmp, offsets, sort_scratch, scan_scratch, counters;
+    DeviceBuffer rec64;   // [N][4] float4: the per-particle 64-byte records of the direct tile lists (GutParams::rec64)
     DeviceBuffer part_offset, pos_particle, grad_partial, grad_flag, g_rgb, poses_dev;
     // per-intersection scratch
     DeviceBuffer tile_keys, tile_vals, tile_keys_tmp, tile_vals_tmp, tile_sort_scratch, ranges;
@@ -152,6 +153,7 @@ static int ensure_particle_scratch(GutHandle* h, uint32_t N) {
     GRUT_CHECK(h->particle_idx_tmp.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->offsets.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->part_offset.ensure(n * 4, 1.25f));
+    GRUT_CHECK(h->rec64.ensure(n * 64, 1.25f));
     GRUT_CHECK(h->sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     GRUT_CHECK(h->scan_scratch.ensure(scan_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     if (!h->counters.ptr) {   // [1] counts the visible particles of a frame: zero once here, re-armed on the device after every read
@@ -196,6 +198,7 @@ static GutProjected projected_view(GutHandle* h) {
     p.depth_key = h->depth_key.as<uint32_t>();
     p.particle_idx = h->particle_idx.as<uint32_t>();
     p.part_offset = h->part_offset.as<uint32_t>();
+    p.rec64 = h->rec64.as<float4>();
     return p;
 }
 
@@ -229,7 +232,7 @@ void gut_destroy(GutHandle* h) {
     if (!h) return;
     DeviceBuffer* bufs[] = {&h->tiles_count, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->rgb, &h->depth_key,
                             &h->particle_idx, &h->depth_key_tmp, &h->particle_idx_tmp, &h->offsets, &h->sort_scratch,
-                            &h->scan_scratch, &h->counters, &h->part_offset, &h->pos_particle, &h->grad_partial, &h->grad_flag,
+                            &h->scan_scratch, &h->counters, &h->rec64, &h->part_offset, &h->pos_particle, &h->grad_partial, &h->grad_flag,
                             &h->g_rgb, &h->poses_dev, &h->work_counters, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
                             &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges, &h->ck_tc, &h->ck_d, &h->ck_reached,
                             &h->ck_boundary_tile};
@@ -282,6 +285,13 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
 
     GRUT_CHECK(ensure_particle_scratch(h, N));
+    // direct tile lists: tile and ordinal share the 32-bit sort key (an ordinal is below the tile count), frames beyond 65536 tiles keep
+    // the position-payload lists
+    static const bool legacy_lists = getenv("GRUT_GUT_LEGACY_LISTS") != nullptr;   // (development switch)
+    const bool direct = h->stats.key_bits <= 16 && !legacy_lists;
+    h->params.rec64 = direct ? h->rec64.as<float4>() : nullptr;
+    h->params.ord_shift = h->stats.key_bits;
+    h->params.sorted_keys = nullptr;
     if (frame->device_T_to_world) {  // poses stay on the device
         GRUT_CHECK(h->poses_dev.ensure(sizeof(FramePoses)));
         launch_frame_poses(s, frame->device_T_to_world, frame->device_T_to_world_end, h->poses_dev.as<FramePoses>());
@@ -337,16 +347,17 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     auto enqueue_tail = [&](uint32_t n, const uint32_t* n_dev) -> int {
         // K4 expansion in rank order
         GRUT_CHECK(h->stage_begin(GUT_STAGE_EXPAND, s, slot));
-        launch_expand(s, P, proj, rank_to_particle, h->offsets.as<uint32_t>(), n, h->tile_keys.as<uint32_t>(), nullptr /* payload = position:
-                      generated by the sort */, h->pos_particle.as<uint32_t>());
+        launch_expand(s, P, proj, rank_to_particle, h->offsets.as<uint32_t>(), n, h->tile_keys.as<uint32_t>(),
+                      direct ? h->tile_vals.as<uint32_t>() : nullptr /* legacy payload = position: generated by the sort */, h->pos_particle.as<uint32_t>());
         GRUT_CHECK(h->stage_end(GUT_STAGE_EXPAND, s, slot));
         // K5 stable radix passes over the tile bits only
         GRUT_CHECK(h->stage_begin(GUT_STAGE_TILE_SORT, s, slot));
         uint32_t *sorted_tiles = nullptr, *sorted_idx = nullptr;
         GRUT_CHECK(sort_pairs_u32(s, n, n_dev, 0, (int)h->stats.key_bits, h->tile_keys.as<uint32_t>(), h->tile_vals.as<uint32_t>(),
                                   h->tile_keys_tmp.as<uint32_t>(), h->tile_vals_tmp.as<uint32_t>(), h->tile_sort_scratch.ptr,
-                                  h->tile_sort_scratch.bytes, &sorted_tiles, &sorted_idx, true));
+                                  h->tile_sort_scratch.bytes, &sorted_tiles, &sorted_idx, !direct));
         h->sorted_tile_keys = sorted_tiles;
+        h->params.sorted_keys = sorted_tiles;
         h->sorted_pos = sorted_idx;
         GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_SORT, s, slot));
         // K6 tile ranges
@@ -618,7 +629,7 @@ int gut_debug_fetch(GutHandle* h, void* stream_, uint32_t* tiles_count, float* p
         if (rgb) GRUT_HIP(hipMemcpyAsync(rgb, h->rgb.ptr, N * 12, k, s));
     }
     if (I) {
-        if (sorted_particle_idx) launch_gather_particle_idx(s, (uint32_t)I, h->sorted_pos, h->pos_particle.as<uint32_t>(), sorted_particle_idx);
+        if (sorted_particle_idx) launch_gather_particle_idx(s, (uint32_t)I, h->sorted_pos, h->params.rec64 ? nullptr : h->pos_particle.as<uint32_t>(), sorted_particle_idx);
         if (tile_ranges) GRUT_HIP(hipMemcpyAsync(tile_ranges, h->ranges.ptr, tiles * 8, k, s));
     }
     return GRUT_OK;

@@ -18,6 +18,12 @@ struct GutParams {
     GrutCamera cam;
     FramePoses poses;             // derived on the host from GutFrame::pose_start / pose_end ...
     unsigned long long* work;     // optional device counters {fwd evaluated, fwd accepted, bwd evaluated, bwd accepted} (gut_profile_enable level 2)
+    // "direct" tile lists (frames of at most 65536 tiles): the tile sort's payload is the PARTICLE and the upper bits of its key carry the
+    // entry's ordinal among the particle's tiles, so a list entry resolves to the particle's 64-byte record in one dependent load
+    // (legacy: payload = expansion position -> pos_particle[] -> three parameter rows) and the gradient slot is part_offset + ordinal
+    const float4* rec64;          // [N][4] {pos, density | quat | scale, bits(part_offset) | unclamped rgb, -}: written by the projection for visible particles; null = legacy lists
+    const uint32_t* sorted_keys;  // [I] sorted tile keys (the backward reads the ordinals)
+    uint32_t ord_shift;           // ordinal = key >> ord_shift
     int sph_half, out_half;       // fp16 feature I/O (GutConfig::particle_feature_half / feature_output_half): the SH buffer / the [H,W,4] image are IEEE half
     uint32_t work_task_capacity;  // ... and how many {lifetime, start} records of gradient-sweep tasks fit behind the forward sweep's block
     float* out_features;          // optional contiguous copies of the radiance / opacity outputs (GutFrame::out_features / out_opacity)
@@ -42,6 +48,7 @@ struct GutProjected {
     uint32_t* depth_key;     // [N] float bits of depth, 0xFFFFFFFF when the particle touches no tile
     uint32_t* particle_idx;  // [N] identity, value array of the depth sort
     uint32_t* part_offset;   // [N] start of the particle's tile entries in expansion order (valid where tiles_count > 0)
+    float4* rec64;           // [N][4] see GutParams::rec64
 };
 
 // Gradient partials of the compositing sweep.  Tile entries are identified by their position q in EXPANSION order

@@ -246,10 +246,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, GRUT_PRO
     float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
     TileBBox bb = {0, 0, 0, 0};
     f3 pos = mk3(0.f, 0.f, 0.f);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a;
     if (i < P.N) {
-        const float4 a = density12[3 * (size_t)i + 0];  // pos.xyz, density
-        const float4 b = density12[3 * (size_t)i + 1];  // quat wxyz
-        const float4 c = density12[3 * (size_t)i + 2];  // scale.xyz, pad
+        a = density12[3 * (size_t)i + 0];  // pos.xyz, density
+        b = density12[3 * (size_t)i + 1];  // quat wxyz
+        c = density12[3 * (size_t)i + 2];  // scale.xyz, pad
         pos = mk3(a.x, a.y, a.z);
         const float opacity = a.w;
 
@@ -418,6 +419,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, GRUT_PRO
             out.rgb[3 * (size_t)i + 0] = r + 0.5f;
             out.rgb[3 * (size_t)i + 1] = g + 0.5f;
             out.rgb[3 * (size_t)i + 2] = bl + 0.5f;
+            if (P.rec64) {   // everything the compositing sweeps need of this particle, on one 64-byte line (scale.w: the expansion fills in part_offset)
+                float4* rec = out.rec64 + 4 * (size_t)i;
+                rec[0] = a; rec[1] = b; rec[2] = make_float4(c.x, c.y, c.z, 0.f);
+                rec[3] = make_float4(r + 0.5f, g + 0.5f, bl + 0.5f, 0.f);
+            }
             out.proj_pos[i] = make_float2(cx, cy);
             out.conic_opacity[i] = co;
             out.extent[i] = make_float2(ex, ey);
@@ -431,6 +437,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, GRUT_PRO
     if (lane_id() == 0 && m) atomicAdd(num_visible + (blockIdx.x % kGutCounterReplicas) * kGutCounterStride, (uint32_t)__popcll(m));
 }
 
+// one tile entry / one padding entry of the expansion (see gut_expand_kernel)
+__device__ __forceinline__ void emit_entry(bool direct, uint32_t ord_shift, uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_vals,
+                                           uint32_t* __restrict__ pos_particle, uint32_t slot, uint32_t ordinal, uint32_t tile, uint32_t particle) {
+    if (direct) {
+        tile_keys[slot] = tile | (ordinal << ord_shift);
+        tile_vals[slot] = particle;
+    } else {   // the sort carries the expansion position, not the particle
+        tile_keys[slot] = tile;
+        if (tile_vals) tile_vals[slot] = slot;
+        pos_particle[slot] = particle;
+    }
+}
+__device__ __forceinline__ void emit_padding(bool direct, uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ tile_vals,
+                                             uint32_t* __restrict__ pos_particle, uint32_t q) {
+    tile_keys[q] = 0xFFFFFFFFu;
+    if (direct) {
+        tile_vals[q] = 0xFFFFFFFFu;
+    } else {
+        if (tile_vals) tile_vals[q] = q;
+        pos_particle[q] = 0xFFFFFFFFu;
+    }
+}
 // ---------------------------------------------------------------------------------------------
 // K4: ordered expansion — GUTProjector::expand (gutProjector.cuh:324-388), iterated in depth-rank order
 // ---------------------------------------------------------------------------------------------
@@ -444,12 +472,17 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
     float cx = 0.f, cy = 0.f, pmax = 0.f;
     float4 co = make_float4(0.f, 0.f, 0.f, 0.f);
     TileBBox bb = {0, 0, 0, 0};
+    // direct lists (GutParams::rec64): key = tile | ordinal << ord_shift (the ordinal of a particle's entry is below its tile count, hence below
+    // 1 << ord_shift), payload = particle; legacy: key = tile, payload = the expansion position (an iota the sort generates), pos_particle[]
+    const bool direct = P.rec64 != nullptr;
+    const uint32_t osh = P.ord_shift;
     if (r < P.N) {
         off = r == 0 ? 0u : offsets[r - 1];
         max_off = min(offsets[r], capacity);
         if (max_off > off) {
             p = rank_to_particle[r];
             proj.part_offset[p] = off;
+            if (direct) reinterpret_cast<uint32_t*>(proj.rec64 + 4 * (size_t)p + 2)[3] = off;
             const float2 ext = proj.extent[p];
             if (!(ext.x <= 1e-06f)) {
                 const float2 c = proj.proj_pos[p];
@@ -479,22 +512,15 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
                                row_bcast_f(tc.rcpy, src)};
         const uint32_t sp = (uint32_t)row_bcast_i((int)p, src), send = act ? (uint32_t)row_bcast_i((int)max_off, src) : 0u;
         uint32_t o = (uint32_t)row_bcast_i((int)off, src);
+        const uint32_t o0 = o;
         row_tile_walk(lane, P.gx, culling, act, sb, sco, row_bcast_f(cx, src), row_bcast_f(cy, src), row_bcast_f(pmax, src),
                       [&](bool keep, uint32_t tile) {
                           const uint32_t m = (uint32_t)((__ballot(keep) >> row_shift) & 0xFFFFull);
                           const uint32_t slot = o + (uint32_t)__popc(m & row_lt);
-                          if (keep && slot < send) {  // the sort carries the expansion position, not the particle
-                              tile_keys[slot] = tile;
-                              if (tile_vals) tile_vals[slot] = slot;
-                              pos_particle[slot] = sp;
-                          }
+                          if (keep && slot < send) emit_entry(direct, osh, tile_keys, tile_vals, pos_particle, slot, slot - o0, tile, sp);
                           o += (uint32_t)__popc(m);
                       });
-        for (uint32_t q = o + (lane & 15); q < send; q += 16) {  // gutProjector.cuh:372-376 padding
-            tile_keys[q] = 0xFFFFFFFFu;
-            if (tile_vals) tile_vals[q] = q;
-            pos_particle[q] = 0xFFFFFFFFu;
-        }
+        for (uint32_t q = o + (lane & 15); q < send; q += 16) emit_padding(direct, tile_keys, tile_vals, pos_particle, q);  // gutProjector.cuh:372-376 padding
     }
     const bool halfc = has && !small && bbox_fits_half(bb);
     const int half_shift = lane & 32;
@@ -514,16 +540,8 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
         if (keep && culling) keep = tile_min_power((float)x, (float)y, sco, scx, scy) < spmax;
         const uint32_t m = (uint32_t)((__ballot(keep) >> half_shift) & 0xFFFFFFFFull);
         const uint32_t slot = o + (uint32_t)__popc(m & half_lt);
-        if (keep && slot < send) {
-            tile_keys[slot] = (uint32_t)(y * P.gx + x);
-            if (tile_vals) tile_vals[slot] = slot;
-            pos_particle[slot] = sp;
-        }
-        for (uint32_t q = o + (uint32_t)__popc(m) + (lane & 31); q < send; q += 32) {  // gutProjector.cuh:372-376 padding
-            tile_keys[q] = 0xFFFFFFFFu;
-            if (tile_vals) tile_vals[q] = q;
-            pos_particle[q] = 0xFFFFFFFFu;
-        }
+        if (keep && slot < send) emit_entry(direct, osh, tile_keys, tile_vals, pos_particle, slot, slot - o, (uint32_t)(y * P.gx + x), sp);
+        for (uint32_t q = o + (uint32_t)__popc(m) + (lane & 31); q < send; q += 32) emit_padding(direct, tile_keys, tile_vals, pos_particle, q);  // gutProjector.cuh:372-376 padding
     }
     unsigned long long todo = __ballot(has && !small && !halfc);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -534,29 +552,22 @@ __global__ __launch_bounds__(256) void gut_expand_kernel(GutParams P, GutProject
         const TileConic sco = {bcast_f(tc.cx, src), bcast_f(tc.cy, src), bcast_f(tc.cz, src), bcast_f(tc.rcpx, src), bcast_f(tc.rcpy, src)};
         const uint32_t sp = (uint32_t)bcast_i((int)p, src), send = (uint32_t)bcast_i((int)max_off, src);
         uint32_t o = (uint32_t)bcast_i((int)off, src);
+        const uint32_t o0 = o;
         coop_tile_walk(lane, P.gx, culling, sb, sco, bcast_f(cx, src), bcast_f(cy, src), bcast_f(pmax, src),
                        [&](bool keep, uint32_t tile) {
                            const unsigned long long m = __ballot(keep);
                            const uint32_t slot = o + (uint32_t)__popcll(m & lt_mask);
-                           if (keep && slot < send) {
-                               tile_keys[slot] = tile;
-                               if (tile_vals) tile_vals[slot] = slot;
-                               pos_particle[slot] = sp;
-                           }
+                           if (keep && slot < send) emit_entry(direct, osh, tile_keys, tile_vals, pos_particle, slot, slot - o0, tile, sp);
                            o += (uint32_t)__popcll(m);
                        });
-        for (uint32_t q = o + lane; q < send; q += 64) {
-            tile_keys[q] = 0xFFFFFFFFu;
-            if (tile_vals) tile_vals[q] = q;
-            pos_particle[q] = 0xFFFFFFFFu;
-        }
+        for (uint32_t q = o + lane; q < send; q += 64) emit_padding(direct, tile_keys, tile_vals, pos_particle, q);
     }
 }
 
 __global__ __launch_bounds__(256) void gut_gather_particle_idx_kernel(uint32_t n, const uint32_t* __restrict__ sorted_pos,
                                                                       const uint32_t* __restrict__ pos_particle, uint32_t* __restrict__ out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) out[k] = pos_particle[sorted_pos[k]];
+    if (k < n) out[k] = pos_particle ? pos_particle[sorted_pos[k]] : sorted_pos[k];   // (direct lists: the payload is the particle already)
 }
 
 // ---------------------------------------------------------------------------------------------

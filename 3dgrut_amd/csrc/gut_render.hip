@@ -164,10 +164,19 @@ struct RawEntry {
     f3 rgb;
 };
 // the sorted lists carry expansion positions; pos_particle maps them to particles (0xFFFFFFFF = padding)
+// direct lists (rec64 != null, GutParams::rec64): the sorted payloads ARE the particles, one 64-byte record each; the gradient slot
+// of an entry is the particle's part_offset (in the record) + the ordinal in the upper key bits
 struct EntryLists {
     const uint32_t* __restrict__ sorted_pos;
     const uint32_t* __restrict__ pos_particle;
+    const float4* __restrict__ rec64;
+    const uint32_t* __restrict__ sorted_keys;
+    uint32_t ord_shift;
 };
+__host__ __device__ inline EntryLists entry_lists(const GutParams& P, const uint32_t* sorted_pos, const uint32_t* pos_particle) {
+    return EntryLists{sorted_pos, P.rec64 ? nullptr : pos_particle, P.rec64, P.sorted_keys, P.ord_shift};
+}
+template <bool WITH_POS = true>
 __device__ __forceinline__ RawEntry load_entry(uint32_t e, uint32_t end, const EntryLists& lists,
                                                const float4* __restrict__ density12, const float* __restrict__ rgb) {
     RawEntry r;
@@ -175,7 +184,16 @@ __device__ __forceinline__ RawEntry load_entry(uint32_t e, uint32_t end, const E
     r.pos = 0u;
     r.a = r.q = r.s = make_float4(0.f, 0.f, 0.f, 0.f);
     r.rgb = mk3(0.f, 0.f, 0.f);
-    if (e < end) {
+    if (e < end && lists.rec64) {
+        r.idx = lists.sorted_pos[e];
+        if (r.idx != 0xFFFFFFFFu) {
+            const float4* rec = lists.rec64 + 4 * (size_t)r.idx;
+            r.a = rec[0]; r.q = rec[1]; r.s = rec[2];
+            const float4 c = rec[3];
+            r.rgb = mk3(c.x, c.y, c.z);
+            if (WITH_POS) r.pos = __float_as_uint(r.s.w) + (lists.sorted_keys[e] >> lists.ord_shift);
+        }
+    } else if (e < end) {
         r.pos = lists.sorted_pos[e];
         r.idx = lists.pos_particle[r.pos];
         if (r.idx != 0xFFFFFFFFu) {
@@ -296,7 +314,7 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
     v2f T = splat(1.f), D = splat(0.f), Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f), cnt = splat(0.f);
     uint32_t n_eval = 0u, n_acc = 0u;   // wave-uniform work counters (scalar registers), reported when P.work is set
     uint32_t b = range.x;
-    RawEntry next = load_entry(b + lane, min(range.y, (b & ~63u) + 64u), lists, density12, rgb);
+    RawEntry next = load_entry<false>(b + lane, min(range.y, (b & ~63u) + 64u), lists, density12, rgb);
     while (b < range.y) {
         if (!__any(alive0 || alive1)) break;
         const uint32_t bend = min(range.y, (b & ~63u) + 64u);
@@ -312,7 +330,7 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         stage_entry<DEG, false>(P, next, UNI, rp.origin, &s_rec[lane * kRecQuads]);
         __syncthreads();  // single-wave workgroup: orders the LDS hand-off
         // fetch the following round while this one is being composited
-        next = load_entry(bend + lane, min(range.y, bend + 64u), lists, density12, rgb);
+        next = load_entry<false>(bend + lane, min(range.y, bend + 64u), lists, density12, rgb);
         const int n = (int)(bend - b);
         for (int j = 0; j < n; ++j) {
             if (!__any(alive0 || alive1)) break;   // the rest of the round is behind every pixel's termination
@@ -1121,7 +1139,7 @@ static uint32_t segment_grid(const GutParams& P, uint32_t num_boundaries) {
 void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                        const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                        float* out_cnt, const GutCheckpoints& ck, bool write_checkpoints) {
-    const EntryLists lists{sorted_pos, pos_particle};
+    const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
     if (P.work && P.degree == 2 && write_checkpoints) {   // instrumented frame (gut_profile_enable level 2): the counting build of the default kernel
         hipLaunchKernelGGL((gut_render_fwd_kernel<2, true, true>), dim3(half_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
                            reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d, reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck);
@@ -1143,7 +1161,7 @@ void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
                        const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const GutGradIn& g_fd, const float* dist,
                        const float* g_dist, const GutGradSlots& slots, const GutCheckpoints& ck) {
     const dim3 grid(segment_grid(P, ck.num_boundaries));
-    const EntryLists lists{sorted_pos, slots.pos_particle};
+    const EntryLists lists = entry_lists(P, sorted_pos, slots.pos_particle);
     if (P.work && P.degree == 2 && !g_dist) {   // instrumented frame: the counting build of the training-path kernel
         hipLaunchKernelGGL((gut_render_bwd_kernel<2, false, true>), grid, dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
                            reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d, reinterpret_cast<const float4*>(fd), g_fd, dist, g_dist, slots, ck);
@@ -1177,7 +1195,7 @@ static uint32_t strip_grid(const GutParams& P) {
 void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                          float* out_cnt) {
-    const EntryLists lists{sorted_pos, pos_particle};
+    const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
     GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_k_fwd_kernel<K_>), dim3(strip_grid(P)), dim3(64), 0, s, P,
                                                    reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), rgb,
                                                    ray_o, ray_d, reinterpret_cast<float4*>(out_fd), out_dist, out_cnt));
@@ -1185,7 +1203,7 @@ void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* rang
 void launch_render_k_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd,
                          const float* dist, const float* g_dist, float* g_density12, float* g_rgb) {
-    const EntryLists lists{sorted_pos, pos_particle};
+    const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
     GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_k_bwd_kernel<K_>), dim3(strip_grid(P)), dim3(64), 0, s, P,
                                                    reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), rgb,
                                                    ray_o, ray_d, reinterpret_cast<float4*>(const_cast<float*>(fd)), const_cast<float*>(dist),
