@@ -120,27 +120,161 @@ class FactoredGradientExchange:
             self.local_gradient_hook(g_density)
         if world == 1:
             return g_density, _abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active_features, sph_degree, 1.0)
-        nccl = dist.get_backend(self.group) == "nccl"
-        op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
         if self.timer:
             self.timer.begin(g_density.device)
-        w_geo = dist.all_reduce(g_density, op=op, group=self.group, async_op=True)
-        factors = torch.empty((world,) + tuple(g_radiance.shape), dtype=g_radiance.dtype, device=g_radiance.device)
-        if nccl:
-            w_rad = dist.all_gather_into_tensor(factors, g_radiance.contiguous(), group=self.group, async_op=True)
-        else:
-            # gloo (CPU-side test plumbing) has no all-gather on device tensors: every rank fills its own slice of a zeroed
-            # buffer and the slices are summed, which is the same gather
-            factors.zero_()
-            factors[dist.get_rank(self.group)].copy_(g_radiance)
-            w_rad = dist.all_reduce(factors, group=self.group, async_op=True)
-        w_geo.wait()
-        w_rad.wait()
+        g_density, factors, payload = self.exchange(g_density, g_radiance)
         if self.timer:
-            self.timer.end(g_density.numel() * 4 + g_radiance.numel() * 4)
+            self.timer.end(payload)
+        return g_density, _abi.sph_grad_from_views(factors, positions, n_active_features, sph_degree, scale)
+
+    @torch.no_grad()
+    def exchange(self, g_density, g_radiance):
+        """The collectives alone (no kernel of the library: runs on CPU tensors over gloo too): (reduced packed gradient [N,12], the
+        views' factors [world, N+1, 3], bytes this rank handed to the collectives)."""
+        world = self._world()
+        nccl = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
+        w_geo = dist.all_reduce(g_density, op=op, group=self.group, async_op=True)
+        factors = _all_gather_rows(g_radiance, self.group, nccl)
+        w_geo.wait()
         if self.average and not nccl:
             g_density.div_(float(world))
-        return g_density, _abi.sph_grad_from_views(factors, positions, n_active_features, sph_degree, scale)
+        return g_density, factors, g_density.numel() * 4 + g_radiance.numel() * 4
+
+
+def _all_gather_rows(t, group, nccl):
+    """[...] of every rank -> [world, ...] on every rank."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    if nccl:
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    else:
+        # gloo (CPU-side test plumbing) has no all-gather on device tensors: every rank fills its own slice of a zeroed
+        # buffer and the slices are summed, which is the same gather
+        out.zero_()
+        out[dist.get_rank(group)].copy_(t)
+        dist.all_reduce(out, group=group)
+    return out
+
+
+class VisibleRowsExchange(FactoredGradientExchange):
+    """The factored exchange restricted to the rows some view touched (DESIGN.md "Multi-GPU"): a view's gradient is zero on every
+    particle its rays did not reach, so the masks of the non-zero rows are OR-reduced (one byte per particle on the links), every rank
+    derives the same index list from the union, and the two collectives of the factored exchange run on the compacted rows — [M,12]
+    all-reduced, [M+1,3] gathered — before the results are scattered back.  Pays when the union of the views leaves a good part of
+    the scene untouched (a large scene seen from nearby cameras); on the bench cloud the union of 8 orbit views is nearly everything."""
+
+    @torch.no_grad()
+    def exchange(self, g_density, g_radiance):
+        world = self._world()
+        nccl = dist.get_backend(self.group) == "nccl"
+        n = g_density.shape[0]
+        touched = ((g_density != 0).any(dim=1) | (g_radiance[:n] != 0).any(dim=1)).to(torch.uint8)
+        dist.all_reduce(touched, op=dist.ReduceOp.MAX, group=self.group)
+        idx = touched.nonzero(as_tuple=True)[0]                      # identical on every rank (one host round trip for its length)
+        m = int(idx.numel())
+        geo = g_density.index_select(0, idx)
+        fac = torch.cat([g_radiance.index_select(0, idx), g_radiance[n:n + 1]], dim=0)   # + the view's sensor position row
+        op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
+        w_geo = dist.all_reduce(geo, op=op, group=self.group, async_op=True)
+        gathered = _all_gather_rows(fac, self.group, nccl)           # [world, M+1, 3]
+        w_geo.wait()
+        if self.average and not nccl:
+            geo.div_(float(world))
+        g_density.zero_()
+        g_density.index_copy_(0, idx, geo)
+        factors = torch.zeros((world, n + 1, 3), dtype=g_radiance.dtype, device=g_radiance.device)
+        factors[:, :n].index_copy_(1, idx, gathered[:, :m])
+        factors[:, n] = gathered[:, m]
+        self.last_rows = m
+        return g_density, factors, n + geo.numel() * 4 + fac.numel() * 4
+
+
+class ShardedGradientExchange(FactoredGradientExchange):
+    """Reduce-scatter / all-gather form (DESIGN.md "Multi-GPU"): rank r owns the particle rows [r S, (r+1) S), S = ceil(N / world).
+    The packed gradient is reduce-scattered (every rank receives the sum of ITS rows), the view factors travel all-to-all (every rank
+    receives every view's factors of its rows: 12 B x (world-1)/world per particle on the links instead of 12 B x (world-1) for the
+    all-gather), each rank rebuilds the SH gradient of its S rows only — `reduce_shard` stops there: the owner can step its rows and
+    all-gather PARAMETERS — and `reduce_packed` (what the plugin's backward calls, which must hand autograd full tensors) all-gathers
+    the two gradient shards.  Links per particle at 8 ranks: 42 B (reduce-scatter) + 10.5 B (all-to-all) + 210 B (all-gather of
+    [S,60] gradients) against 168 B for the factored exchange: it only pays together with a sharded optimizer step."""
+
+    def shard_rows(self, n):
+        world = self._world()
+        s = (n + world - 1) // world
+        r = dist.get_rank(self.group) if world > 1 else 0
+        return s, r * s, min(n, (r + 1) * s)
+
+    @torch.no_grad()
+    def exchange_shard(self, g_density, g_radiance):
+        """-> (sum / mean over views of this rank's rows [S,12] (rows past N are zero), every view's factors of those rows
+        [world, S+1, 3] with the views' sensor positions in row S, bytes handed to the collectives)."""
+        world = self._world()
+        nccl = dist.get_backend(self.group) == "nccl"
+        rank = dist.get_rank(self.group)
+        n = g_density.shape[0]
+        s, lo, hi = self.shard_rows(n)
+        pad = s * world - n
+        geo = torch.cat([g_density, g_density.new_zeros((pad, g_density.shape[1]))]) if pad else g_density
+        fac = torch.cat([g_radiance[:n], g_radiance.new_zeros((pad, 3))]) if pad else g_radiance[:n]
+        fac = fac.contiguous()
+        sensors = _all_gather_rows(g_radiance[n].contiguous(), self.group, nccl)     # [world, 3]
+        if nccl:
+            mine = torch.empty((s, geo.shape[1]), dtype=geo.dtype, device=geo.device)
+            dist.reduce_scatter_tensor(mine, geo.contiguous(), op=dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM, group=self.group)
+            views = torch.empty((world, s, 3), dtype=fac.dtype, device=fac.device)
+            dist.all_to_all_single(views, fac, group=self.group)
+        else:   # gloo: the same results from the collectives it has
+            total = geo.clone()
+            dist.all_reduce(total, group=self.group)
+            mine = total[rank * s:(rank + 1) * s].clone()
+            if self.average:
+                mine.div_(float(world))
+            views = _all_gather_rows(fac, self.group, False)[:, rank * s:(rank + 1) * s].contiguous()
+        factors = torch.cat([views, sensors[:, None, :]], dim=1)
+        return mine, factors, geo.numel() * 4 + fac.numel() * 4
+
+    @torch.no_grad()
+    def reduce_shard(self, g_density, g_radiance, positions, n_active_features, sph_degree):
+        """-> ((lo, hi) rows owned by this rank, packed gradient of those rows [hi-lo,12], SH gradient of those rows [hi-lo, 3(deg+1)^2])."""
+        from . import _abi
+        world = self._world()
+        n = g_density.shape[0]
+        s, lo, hi = self.shard_rows(n)
+        mine, factors, payload = self.exchange_shard(g_density, g_radiance)
+        pos = positions[lo:hi]
+        if hi - lo < s:
+            pos = torch.cat([pos, pos.new_zeros((s - (hi - lo), pos.shape[1]))])
+        g_sph = _abi.sph_grad_from_views(factors, pos, n_active_features, sph_degree, 1.0 / world if self.average else 1.0)
+        self._payload = payload
+        return (lo, hi), mine[:hi - lo], g_sph[:hi - lo]
+
+    @torch.no_grad()
+    def all_gather_rows(self, shard, n):
+        """[<= S, k] of every rank (its owned rows) -> [N, k] on every rank (gradients here; parameters after a sharded optimizer step)."""
+        world = self._world()
+        nccl = dist.get_backend(self.group) == "nccl"
+        s = (n + world - 1) // world
+        if shard.shape[0] < s:
+            shard = torch.cat([shard, shard.new_zeros((s - shard.shape[0],) + tuple(shard.shape[1:]))])
+        return _all_gather_rows(shard.contiguous(), self.group, nccl).reshape((world * s,) + tuple(shard.shape[1:]))[:n]
+
+    @torch.no_grad()
+    def reduce_packed(self, g_density, g_radiance, positions, n_active_features, sph_degree):
+        from . import _abi
+        world = self._world()
+        if self.local_gradient_hook is not None:
+            self.local_gradient_hook(g_density)
+        if world == 1:
+            return g_density, _abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active_features, sph_degree, 1.0)
+        n = g_density.shape[0]
+        if self.timer:
+            self.timer.begin(g_density.device)
+        _, geo, g_sph = self.reduce_shard(g_density, g_radiance, positions, n_active_features, sph_degree)
+        both = self.all_gather_rows(torch.cat([geo, g_sph], dim=1), n)
+        if self.timer:
+            self.timer.end(self._payload + both.shape[1] * 4 * ((n + world - 1) // world))
+        return both[:, :12].contiguous(), both[:, 12:].contiguous()
 
 
 @torch.no_grad()

@@ -365,7 +365,8 @@ def main():
     g_rgb, g_opa = g_fd[None, ..., :3].contiguous(), g_fd[None, ..., 3:].contiguous()
     # the exchange step of the path.  Default: the packed geometric gradient is all-reduced and the SH gradient is
     # rebuilt from gathered per-view factors inside the plugin's backward (dp.FactoredGradientExchange: 168 instead of 413 B per
-    # particle over the links at 8 ranks); GRUT_BENCH_EXCHANGE=allreduce selects the plain five-tensor all-reduce for comparison
+    # particle over the links at 8 ranks); GRUT_BENCH_EXCHANGE=allreduce selects the plain five-tensor all-reduce for comparison,
+    # =visible / =sharded the two variants of 3dgrut_amd/dp.py (tests/test_dp_gloo.py)
     dp = importlib.import_module("3dgrut_amd.dp")
     exch = None
     exchange_kind = "none"
@@ -373,6 +374,10 @@ def main():
         exchange_kind = os.environ.get("GRUT_BENCH_EXCHANGE", "factored")
         if exchange_kind == "factored":
             tracer.gradient_exchange = dp.FactoredGradientExchange(average=False, timed=True)
+        elif exchange_kind == "visible":    # the factored exchange on the rows some view touched (OR-reduced masks -> index list)
+            tracer.gradient_exchange = dp.VisibleRowsExchange(average=False, timed=True)
+        elif exchange_kind == "sharded":    # reduce-scatter + all-to-all + shard-local SH rebuild + all-gather
+            tracer.gradient_exchange = dp.ShardedGradientExchange(average=False, timed=True)
         else:
             exch = dp.GradientExchange(g.parameters(), average=False, timed=True)
 
@@ -469,6 +474,8 @@ def main():
             "config": {"workload": f"3DGUT fwd+bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "
                                    f"SH degree 3, k_buffer {args.k_buffer}", "name": args.workload,
                        "parallelism": f"view-dp{world}" + ({"factored": " + RCCL all-reduce [N,12] + all-gather of view factors [N+1,3]",
+                                                                  "visible": " + OR-reduced row masks, then RCCL all-reduce / all-gather of the touched rows only",
+                                                                  "sharded": " + RCCL reduce-scatter [N,12] + all-to-all of view factors + all-gather of the rebuilt shards",
                                                                   "none": ""}.get(exchange_kind, " + RCCL grad all-reduce [N,59]"))},
             # `achieved` / `frac`: bytes the kernel can actually touch (evaluated entries, counted on the device) / its duration.
             # `model_*`: SURVEY §8d's per-entry byte model applied to ALL I tile entries — an upper bound that charges the 88 % of the

@@ -59,3 +59,62 @@ def test_gradient_exchange_world2():
     np.testing.assert_array_equal(r0["den"], np.full_like(r0["den"], 2.0))
     assert r0["vis"].all() and r1["vis"].all()
     assert r0["views"] == [0, 2, 4] and r1["views"] == [1, 3]
+
+
+def _variant_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module("3dgrut_amd.dp")
+    n = 257   # odd on purpose: the shards are padded
+    g = torch.Generator().manual_seed(7 + rank)
+    geo = torch.randn(n, 12, generator=g)
+    fac = torch.randn(n + 1, 3, generator=g)          # row n: this view's sensor position
+    seen = torch.rand(n, generator=g) < 0.4           # rows this view touched
+    geo[~seen] = 0
+    fac[:n][~seen] = 0
+    res = dict(geo=geo.numpy().copy(), fac=fac.numpy().copy())
+    ref_geo, ref_fac, _ = dp.FactoredGradientExchange(average=True).exchange(geo.clone(), fac.clone())
+    res["ref_geo"], res["ref_fac"] = ref_geo.numpy(), ref_fac.numpy()
+    vis = dp.VisibleRowsExchange(average=True)
+    v_geo, v_fac, v_bytes = vis.exchange(geo.clone(), fac.clone())
+    res["vis_geo"], res["vis_fac"], res["vis_rows"], res["vis_bytes"] = v_geo.numpy(), v_fac.numpy(), vis.last_rows, v_bytes
+    sh = dp.ShardedGradientExchange(average=True)
+    s, lo, hi = sh.shard_rows(n)
+    mine, factors, _ = sh.exchange_shard(geo.clone(), fac.clone())
+    res["shard"] = (s, lo, hi)
+    res["sh_geo"], res["sh_fac"] = mine.numpy(), factors.numpy()
+    res["sh_full"] = sh.all_gather_rows(mine[:hi - lo], n).numpy()
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_variants_world2():
+    """GRUT_BENCH_EXCHANGE=visible / sharded (dp.VisibleRowsExchange, dp.ShardedGradientExchange): their collectives deliver what the
+    factored exchange delivers — the mean packed gradient and every view's factors — on the touched rows only, resp. shard by shard."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_variant_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = [out[0], out[1]]
+    n = 257
+    mean_geo = (r[0]["geo"] + r[1]["geo"]) / 2
+    facs = np.stack([r[0]["fac"], r[1]["fac"]])
+    for k in range(world):
+        np.testing.assert_allclose(r[k]["ref_geo"], mean_geo, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(r[k]["ref_fac"], facs)
+        # visible rows: same results, fewer rows on the wire
+        np.testing.assert_allclose(r[k]["vis_geo"], mean_geo, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(r[k]["vis_fac"], facs)
+        touched = int(((r[0]["geo"] != 0).any(1) | (r[1]["geo"] != 0).any(1) | (r[0]["fac"][:n] != 0).any(1) | (r[1]["fac"][:n] != 0).any(1)).sum())
+        assert r[k]["vis_rows"] == touched and touched < 0.8 * n
+        assert r[k]["vis_bytes"] == n + touched * 48 + (touched + 1) * 12
+        # shards: this rank's rows of the mean, every view's factors of those rows + the sensor positions
+        s, lo, hi = r[k]["shard"]
+        assert (s, lo) == (129, 129 * k) and hi == min(n, 129 * (k + 1))
+        np.testing.assert_allclose(r[k]["sh_geo"][:hi - lo], mean_geo[lo:hi], rtol=1e-6, atol=1e-7)
+        assert not r[k]["sh_geo"][hi - lo:].any()
+        np.testing.assert_array_equal(r[k]["sh_fac"][:, :hi - lo], facs[:, lo:hi])
+        np.testing.assert_array_equal(r[k]["sh_fac"][:, s], facs[:, n])
+        np.testing.assert_allclose(r[k]["sh_full"], mean_geo, rtol=1e-6, atol=1e-7)
