@@ -145,10 +145,12 @@ EXPORTED_SYMBOLS = [
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats", "grt_debug_fetch_work",
     "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_debug_backward_signature", "grt_build_mesh_bvh", "grt_trace_hybrid",
     "grut_selective_adam_update", "grut_pack_particles", "grut_unpack_particle_grads", "grut_activate_pack", "grut_activate_pack_backward",
-    "grut_last_error", "grut_abi_version",
+    "grut_last_error", "grut_abi_version", "grut_set_allocator", "gut_trim", "grt_trim",
 ]
 
 _lib = None
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)   # GrutAllocFn / GrutFreeFn of include/grut_amd.h
+FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 
 
 def _declare(lib):
@@ -212,6 +214,12 @@ def _declare(lib):
     lib.grt_trace_hybrid.restype = C.c_int
     lib.grt_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.grt_timings.restype = C.c_int
+    lib.grut_set_allocator.argtypes = [ALLOC_FN, FREE_FN, C.c_void_p]
+    lib.grut_set_allocator.restype = C.c_int
+    lib.gut_trim.argtypes = [C.c_void_p]
+    lib.gut_trim.restype = C.c_int
+    lib.grt_trim.argtypes = [C.c_void_p]
+    lib.grt_trim.restype = C.c_int
     lib.grt_debug_fetch_work.argtypes = [C.c_void_p, vp, up, C.c_uint64]
     lib.grt_debug_fetch_work.restype = C.c_int
     lib.grt_stats.argtypes = [C.c_void_p, C.POINTER(GrtStats)]
@@ -253,7 +261,53 @@ def load_library(path: str | None = None):
         raise RuntimeError(f"3dgrut_amd: ABI mismatch, library {ver} vs python {ABI_VERSION}; rebuild")
     if path is None:
         _lib = lib
+        if torch.cuda.is_available() and not os.environ.get("GRUT_AMD_HIP_MALLOC"):
+            use_torch_allocator(lib)
     return lib
+
+
+# ---- scratch through the caller's allocator (grut_set_allocator) ----------------------------------------------------------------
+allocator_stats = {"allocs": 0, "frees": 0, "live_bytes": 0}   # (tests: no allocator traffic in steady state)
+_allocator_keepalive = {}
+
+
+def use_torch_allocator(lib=None, enable=True):
+    """Route the library's grow-only scratch through torch's caching allocator (blocks belong to the stream that is current when the
+    library asks, which is the stream the plugins pass to every call): a grown buffer's old block returns to the pool the caller's
+    tensors come from, and no hipMalloc / hipFree — each an implicit device synchronisation — happens once the pool is warm.
+    GRUT_AMD_HIP_MALLOC=1 (or enable=False) keeps hipMalloc / hipFree."""
+    import atexit
+    import torch
+    lib = lib or load_library()
+    if not enable:
+        check(lib.grut_set_allocator(ALLOC_FN(0), FREE_FN(0), None), "grut_set_allocator")
+        _allocator_keepalive.clear()
+        return
+    sizes = {}
+
+    def _alloc(_user, nbytes):
+        try:
+            ptr = torch.cuda.caching_allocator_alloc(int(nbytes))
+        except Exception:   # out of memory: the library reports the failed size
+            return None
+        sizes[ptr] = int(nbytes)
+        allocator_stats["allocs"] += 1
+        allocator_stats["live_bytes"] += int(nbytes)
+        return ptr
+
+    def _free(_user, ptr):
+        try:
+            allocator_stats["frees"] += 1
+            allocator_stats["live_bytes"] -= sizes.pop(ptr, 0)
+            torch.cuda.caching_allocator_delete(ptr)
+        except Exception:
+            pass
+
+    a, f = ALLOC_FN(_alloc), FREE_FN(_free)
+    check(lib.grut_set_allocator(a, f, None), "grut_set_allocator")
+    if not _allocator_keepalive:   # at interpreter exit the callbacks go away first: handles destroyed later must not call them
+        atexit.register(lambda: lib.grut_set_allocator(ALLOC_FN(0), FREE_FN(0), None))
+    _allocator_keepalive["fns"] = (a, f, sizes)
 
 
 def pack_particles(mog_pos, mog_dns, mog_rot, mog_scl):

@@ -54,22 +54,48 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t b, uint32_t n) {
 #endif
 
 // ---- grow-only device scratch (the role of CudaBuffer::enlarge, src/cudaBuffer.cpp:44-60) ---
+// Where the scratch comes from: hipMalloc / hipFree, or the caller's allocator (grut_set_allocator, include/grut_amd.h — the Python
+// plugins install torch's caching allocator, so a grown buffer's old block goes back to the pool the caller's tensors come from and
+// no hipMalloc / hipFree — an implicit device synchronisation each — happens once the pool is warm).
+struct ScratchAllocator {
+    void* (*alloc)(void* user, uint64_t bytes) = nullptr;
+    void (*release)(void* user, void* ptr) = nullptr;
+    void* user = nullptr;
+};
+ScratchAllocator& scratch_allocator();   // (gut_api.hip)
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;
+    bool external = false;   // ptr came from the caller's allocator
     int ensure(size_t need, float growth = 1.0f) {
         if (need <= bytes) return GRUT_OK;
         size_t n = (size_t)((double)need * growth);
         n = (n + 255) & ~(size_t)255;
-        if (ptr) GRUT_HIP(hipFree(ptr));
-        ptr = nullptr;
-        bytes = 0;
-        GRUT_HIP(hipMalloc(&ptr, n));
+        release();
+        const ScratchAllocator& a = scratch_allocator();
+        if (a.alloc) {
+            ptr = a.alloc(a.user, n);
+            if (!ptr) {
+                set_last_error("scratch allocation of %zu bytes failed in the caller's allocator", n);
+                return GRUT_ERR_RUNTIME;
+            }
+            external = true;
+            // recycled memory of the caller's pool: start from zeros like the fresh pages of a first hipMalloc (allocations are rare —
+            // growth steps of 1.25x — so the synchronous fill costs nothing per frame)
+            GRUT_HIP(hipMemset(ptr, getenv("GRUT_POISON_SCRATCH") ? 0xFF : 0, n));
+        } else {
+            GRUT_HIP(hipMalloc(&ptr, n));
+            external = false;
+        }
         bytes = n;
         return GRUT_OK;
     }
     void release() {
-        if (ptr) (void)hipFree(ptr);
+        if (ptr) {
+            const ScratchAllocator& a = scratch_allocator();
+            if (external && a.release) a.release(a.user, ptr);
+            else if (!external) (void)hipFree(ptr);
+        }
         ptr = nullptr;
         bytes = 0;
     }

@@ -129,8 +129,7 @@ int grt_create(const GrtConfig* config, GrtHandle** handle) {
     return GRUT_OK;
 }
 
-void grt_destroy(GrtHandle* h) {
-    if (!h) return;
+static void release_scratch(GrtHandle* h) {
     DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
                             &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
                             &h->work_counters, &h->l_flags, &h->l_pair_cache, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits,
@@ -139,6 +138,31 @@ void grt_destroy(GrtHandle* h) {
                             &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state, &h->m_aabb, &h->m_slack, &h->m_scene_enc,
                             &h->m_scene, &h->m_codes, &h->m_ids, &h->m_codes_tmp, &h->m_ids_tmp, &h->m_sort_scratch, &h->m_nodes, &h->m_done, &h->m_materials};
     for (DeviceBuffer* b : bufs) b->release();
+}
+
+// Hand every scratch buffer back (hipFree or the caller's allocator, grut_set_allocator); the handle stays usable but its BVHs are gone:
+// grt_build_bvh (and grt_build_mesh_bvh) must run again before the next trace.
+int grt_trim(GrtHandle* h) {
+    GRUT_REQUIRE(h, "grt_trim: null handle");
+    GRUT_HIP(hipDeviceSynchronize());
+    release_scratch(h);
+    h->built = false;
+    h->mesh_built = false;
+    h->N = 0;
+    h->log_valid = false;
+    h->log_event_pending = false;
+    h->scene_host_valid = false;
+    h->list_entries = 0;
+    h->log = GrtHitLog{nullptr, nullptr, nullptr, nullptr, 0, 0};
+    h->log_lists = GrtLists{nullptr, nullptr, nullptr, nullptr, nullptr};
+    h->sorted_codes = nullptr;
+    h->sorted_ids = nullptr;
+    return GRUT_OK;
+}
+
+void grt_destroy(GrtHandle* h) {
+    if (!h) return;
+    release_scratch(h);
     if (h->log_state_host) (void)hipHostFree(h->log_state_host);
     if (h->l_host) (void)hipHostFree(h->l_host);
     if (h->log_event) (void)hipEventDestroy(h->log_event);

@@ -8,6 +8,10 @@
 namespace grut {
 
 static thread_local char g_last_error[512] = "";
+ScratchAllocator& scratch_allocator() {
+    static ScratchAllocator a;
+    return a;
+}
 void set_last_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -205,6 +209,14 @@ static GutProjected projected_view(GutHandle* h) {
 extern "C" {
 
 int grut_abi_version(void) { return GRUT_ABI_VERSION; }
+int grut_set_allocator(GrutAllocFn alloc_fn, GrutFreeFn free_fn, void* user) {
+    GRUT_REQUIRE((alloc_fn == nullptr) == (free_fn == nullptr), "grut_set_allocator: give both functions or neither");
+    grut::ScratchAllocator& a = grut::scratch_allocator();
+    a.alloc = alloc_fn;
+    a.release = free_fn;
+    a.user = user;
+    return GRUT_OK;
+}
 const char* grut_last_error(void) { return grut::g_last_error; }
 
 int gut_create(const GutConfig* config, GutHandle** handle) {
@@ -228,8 +240,7 @@ int gut_create(const GutConfig* config, GutHandle** handle) {
     return GRUT_OK;
 }
 
-void gut_destroy(GutHandle* h) {
-    if (!h) return;
+static void release_scratch(GutHandle* h) {
     DeviceBuffer* bufs[] = {&h->tiles_count, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->rgb, &h->depth_key,
                             &h->particle_idx, &h->depth_key_tmp, &h->particle_idx_tmp, &h->offsets, &h->sort_scratch,
                             &h->scan_scratch, &h->counters, &h->rec64, &h->part_offset, &h->pos_particle, &h->grad_partial, &h->grad_flag,
@@ -237,6 +248,29 @@ void gut_destroy(GutHandle* h) {
                             &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges, &h->ck_tc, &h->ck_d, &h->ck_reached,
                             &h->ck_boundary_tile};
     for (DeviceBuffer* b : bufs) b->release();
+}
+
+// Hand every scratch buffer back (to hipFree or the caller's allocator); the handle stays usable, the next frame allocates afresh.
+// For callers that hold a tracer across phases of very different size (a 3 M-particle evaluation between 100 k-particle jobs).
+int gut_trim(GutHandle* h) {
+    GRUT_REQUIRE(h, "gut_trim: null handle");
+    if (h->fwd_stream) GRUT_HIP(hipStreamSynchronize(h->fwd_stream));
+    else GRUT_HIP(hipDeviceSynchronize());
+    release_scratch(h);
+    h->tile_capacity = 0;
+    h->have_forward = false;
+    h->num_intersections = 0;
+    h->sorted_pos = nullptr;
+    h->sorted_tile_keys = nullptr;
+    h->work_pending = false;
+    h->ck_boundaries_capacity = 0;
+    memset(&h->checkpoints, 0, sizeof(h->checkpoints));
+    return GRUT_OK;
+}
+
+void gut_destroy(GutHandle* h) {
+    if (!h) return;
+    release_scratch(h);
     if (h->host_counters) (void)hipHostFree(h->host_counters);
     if (h->count_event) (void)hipEventDestroy(h->count_event);
     h->fwd_timer.destroy();

@@ -133,6 +133,10 @@ class _GrtNative:
                 self._timings[k] = v
         return dict(self._timings)
 
+    def trim(self):
+        """grt_trim: hand all scratch back to the allocator (torch's pool by default); the next frame allocates afresh and the BVH must be rebuilt."""
+        _abi.check(self.lib.grt_trim(self.handle), "grt_trim")
+
     def stats(self) -> _abi.GrtStats:
         s = _abi.GrtStats()
         _abi.check(self.lib.grt_stats(self.handle, C.byref(s)), "grt_stats")

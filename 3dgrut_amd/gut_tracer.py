@@ -208,6 +208,10 @@ class _GutNative:
             self._timings["backward_render"] = b.value
         return dict(self._timings)
 
+    def trim(self):
+        """gut_trim: hand all scratch back to the allocator (torch's pool by default); the next frame allocates afresh."""
+        _abi.check(self.lib.gut_trim(self.handle), "gut_trim")
+
     def stats(self) -> _abi.GutStats:
         s = _abi.GutStats()
         _abi.check(self.lib.gut_stats(self.handle, C.byref(s)), "gut_stats")

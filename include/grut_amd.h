@@ -143,6 +143,7 @@ typedef struct GutHandle GutHandle;
 
 int  gut_create(const GutConfig* config, GutHandle** handle);
 void gut_destroy(GutHandle* handle);
+int  gut_trim(GutHandle* handle);   /* release all scratch (see grut_set_allocator); the next frame allocates afresh */
 
 /*  particle_density : [N,12] f32  {pos.xyz, density, quat.wxyz, scale.xyz, pad}
  *  particle_sph     : [N, 3*(deg+1)^2] f32, coefficient-major float3
@@ -362,6 +363,7 @@ int grt_trace_hybrid(GrtHandle* handle, void* stream, const GrtFrame* frame, con
                      const GrtHybridOptions* options, float* out_radiance, float* out_opacity, float* out_last_ray, uint32_t* out_bounces);
 
 int  grt_create(const GrtConfig* config, GrtHandle** handle);
+int  grt_trim(GrtHandle* handle);
 void grt_destroy(GrtHandle* handle);
 
 /* positions[N,3], rotations[N,4] wxyz normalised, scales[N,3], densities[N] — activated values */
@@ -461,6 +463,15 @@ int grut_selective_adam_update(void* stream, const GrutAdamGroup* groups, int nu
 const char* grut_last_error(void);
 /* ABI version; bumped whenever a struct above changes */
 int grut_abi_version(void);
+
+/* Scratch memory.  Every per-frame buffer of the two renderers is grow-only device scratch (the role of the reference's CudaBuffer,
+ * src/cudaBuffer.cpp:44-60, which calls cudaMalloc / cudaFree).  By default it comes from hipMalloc / hipFree; a host that has its own
+ * device allocator — PyTorch's caching allocator in the plugins — installs it here BEFORE creating handles: alloc_fn returns device
+ * memory usable on the stream of the API call it is made from (NULL = failure), free_fn takes it back.  Process-wide; NULL, NULL
+ * restores hipMalloc.  gut_trim / grt_trim release everything a handle holds (the handle stays valid; 3DGRT needs its BVH rebuilt). */
+typedef void* (*GrutAllocFn)(void* user, uint64_t bytes);
+typedef void  (*GrutFreeFn)(void* user, void* ptr);
+int grut_set_allocator(GrutAllocFn alloc_fn, GrutFreeFn free_fn, void* user);
 
 #ifdef __cplusplus
 }

@@ -425,3 +425,22 @@ def test_fp16_feature_io_matches_the_fp32_path_and_the_oracle(sph_half, out_half
     for name, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
         assert trimmed(gd[:, sl], rd[:, sl], 3 * n_flip) < 1e-3, name
     assert trimmed(gs, rs, 3 * n_flip) < 1e-3 and gs.dtype == np.float32
+
+
+def test_trim_releases_the_scratch_and_requires_a_new_bvh():
+    import torch
+    abi = importlib.import_module("3dgrut_amd._abi")
+    scene = _scene(3000, 48, 32, 0.06)
+    tr = _tracer()
+    g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+    batch = torch_batch(scene["batch"], "cuda")
+    tr.build_acc(g, rebuild=True)
+    a = tr.render(g, batch)["pred_features"].detach().clone()
+    live = abi.allocator_stats["live_bytes"]
+    assert live > 0
+    tr.tracer_wrapper.trim()
+    assert abi.allocator_stats["live_bytes"] < live
+    with pytest.raises(RuntimeError, match="build_bvh"):
+        tr.render(g, batch)
+    tr.build_acc(g, rebuild=True)
+    assert torch.equal(tr.render(g, batch)["pred_features"].detach(), a)

@@ -681,3 +681,37 @@ def test_fp16_feature_io_matches_the_fp32_path_and_the_oracle(sph_half, out_half
     for k, sl in names.items():
         assert _trimmed_rel_err(gpu["grads"][0][:, sl], ora["grads"][0][:, sl], drop) < 1e-3, k
     assert _trimmed_rel_err(gpu["grads"][1], ora["grads"][1], drop) < 1e-3
+
+
+def test_scratch_comes_from_the_callers_allocator_and_is_quiet_in_steady_state():
+    """grut_set_allocator (include/grut_amd.h): the plugins route the library's grow-only scratch through torch's caching allocator.
+    Steady state = no allocator traffic at all; a growing scene re-allocates a buffer only when it outgrows its head-room (a handful of
+    events over +50 % of growth, not one per step); trim hands everything back and the tracer keeps working."""
+    import torch
+    abi = importlib.import_module("3dgrut_amd._abi")
+    stats = abi.allocator_stats
+    scene = make_scene(n=20000, width=160, height=96, median_scale=0.05)
+    tr = _tracer()
+    batch = torch_batch(scene["batch"], "cuda")
+
+    def frame(n):
+        g = syn.SimpleGaussians(scene["density12"][:n], scene["sph"][:n])
+        out = tr.render(g, batch, train=True)
+        (out["pred_features"].sum() + out["pred_opacity"].sum()).backward()
+        return out["pred_features"].detach().clone()
+    ref = frame(12000)
+    assert stats["allocs"] > 10 and stats["live_bytes"] > 0, "the scratch did not come from torch's allocator"
+    frame(12000)
+    before = dict(stats)
+    for _ in range(10):
+        frame(12000)
+    assert stats["allocs"] == before["allocs"] and stats["frees"] == before["frees"], "allocator traffic in steady state"
+    for k in range(50):           # +1 % per step
+        frame(12000 + 120 * (k + 1))
+    grown = stats["allocs"] - before["allocs"]
+    assert 0 < grown <= 80, f"{grown} allocations over 50 growing frames"   # ~30 buffers x at most two growth steps of 1.25x
+    live = stats["live_bytes"]
+    tr.tracer_wrapper.trim()
+    assert stats["live_bytes"] < 0.05 * live
+    torch.cuda.synchronize()
+    assert torch.equal(frame(12000), ref)
