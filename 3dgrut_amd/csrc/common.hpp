@@ -82,7 +82,16 @@ struct DeviceBuffer {
             external = true;
             // recycled memory of the caller's pool: start from zeros like the fresh pages of a first hipMalloc (allocations are rare —
             // growth steps of 1.25x — so the synchronous fill costs nothing per frame)
-            GRUT_HIP(hipMemset(ptr, getenv("GRUT_POISON_SCRATCH") ? 0xFF : 0, n));
+            // (development: GRUT_POISON_SCRATCH=<byte> fills with that byte instead; GRUT_POISON_INDEX=<k> only the k-th allocation)
+            {
+                static int count = 0;
+                const char* pz = getenv("GRUT_POISON_SCRATCH");
+                const char* pi = getenv("GRUT_POISON_INDEX");
+                const bool poison = pz && (!pi || atoi(pi) == count);
+                if (pz && pi && atoi(pi) == count) fprintf(stderr, "[grut] poisoned allocation %d: %zu bytes\n", count, n);
+                ++count;
+                GRUT_HIP(hipMemset(ptr, poison ? atoi(pz) : 0, n));
+            }
         } else {
             GRUT_HIP(hipMalloc(&ptr, n));
             external = false;
