@@ -76,7 +76,7 @@ def valu_fraction(stage, kernel_ms):
 def touched_bytes(stage, st, P, I):
     """Bytes a sweep can actually touch: it stops at the rays' termination, so it evaluates E << I tile-list entries (counted on the
     device in one instrumented frame, GutStats.fwd/bwd_entries_*).  Per evaluated entry of a half-tile wave: 4 B list entry + 4 B
-    particle index + 48 B particle row + 12 B radiance = 68 B; per accepted entry of the gradient sweep: one 64-B slot + 1 flag byte;
+    particle index + 48 B particle row + 12 B radiance = 68 B (round 3's direct lists: 4 B list entry + one 64-B particle record, the same 68 B); per accepted entry of the gradient sweep: one 64-B slot + 1 flag byte;
     per pixel: rays 24 B + outputs 24 B (forward) or rays 24 B + image 16 B + upstream gradient 16 B + (checkpoint 40 B per pixel and
     256-entry segment started) in the gradient sweep."""
     if stage == "render_fwd" and st.fwd_entries_evaluated:
@@ -133,6 +133,28 @@ def grt_roofline(work, P, stages):
     if v:
         r["valu"] = v
     return r
+
+
+def grt_backward_roofline(work, P, stages):
+    """Replay backward.  What binds it is the atomic units, not HBM or VALU (0.92 G VALU instructions, 22 % of the issue
+    time): every differentiated hit adds 11 + 48 float words to its particle's gradient rows.  Algorithmic bytes per the contract: per
+    processed hit 240 B of parameters read (48 B particle + 192 B SH) + 48 B proxy record (the round-structure test) + 236 B of gradient
+    words (read-modify-write at the memory side: counted once) + 4 B of log; per ray 64 B.  `atomic_words_per_s` is the rate the kernel
+    actually lives by."""
+    if not work or "backward_render" not in stages:
+        return None
+    hits = work["processed_hits"]
+    byts = hits * (240 + 48 + 236 + 4) + P * 64
+    ms = stages["backward_render"]
+    achieved = byts / (ms * 1e-3) / 1e9
+    traffic = None
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("c3_grt_1m_800", {}).get("replay_bwd")
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": "grt_replay_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "algorithmic_bytes": byts, "kernel_ms": ms, "atomic_words": hits * 59, "atomic_words_per_s": hits * 59 / (ms * 1e-3),
+            "note": "bound by float atomics (59 words per differentiated hit), see DESIGN.md §5"}
 
 
 def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
@@ -205,7 +227,7 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"3DGRT BVH build + fwd + bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "
                                    f"SH degree 3, k = 16 hits per trace", "name": name, "parallelism": f"view-dp{world}"},
-            "roofline": grt_roofline(work, P, stages), "stages_ms": stages, "work": work}
+            "roofline": grt_roofline(work, P, stages), "roofline_backward": grt_backward_roofline(work, P, stages), "stages_ms": stages, "work": work}
         if emit:
             print(json.dumps(result), flush=True)
     if world > 1 and emit:
