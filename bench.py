@@ -547,7 +547,17 @@ def main():
             gn, gw, gh, gms = WORKLOADS["c3_grt_1m_800"]
             r = bench_grt(sec, 1, 0, dev, None, gn, gw, gh, gms, name="c3_grt_1m_800", emit=False)
             result["secondary"] = {"c3_grt_1m_800": {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "stages_ms",
-                                                                        "roofline", "work")}}
+                                                                        "roofline", "roofline_backward", "work")}}
+            # BASELINE config 2 (1 M Gaussians, 800x800: one wave per half tile leaves the chip short of waves), same code
+            # path as the headline, run as its own process so that nothing of this one's state is shared
+            import subprocess
+            try:
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c2_1m_800", "--no-cpu-baseline", "--no-secondary",
+                                      "--steps", str(args.steps), "--warmup", str(args.warmup)], capture_output=True, text=True, timeout=300).stdout
+                c2 = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+                result["secondary"]["c2_1m_800"] = {k: c2[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "stages_ms", "work")}
+            except Exception as e:   # the headline line must not depend on it
+                result["secondary"]["c2_1m_800"] = {"error": repr(e)[:200]}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
