@@ -149,6 +149,39 @@ def gut_forward(cfg, cam, pose_start, pose_end, n_active, density12, sph, ray_o,
                 proj=proj, bins=bins, rays=(ro, rd), density12=d12, sph=_c(sph, dtype), poses=(ps, pe))
 
 
+NHT_DEFAULT = dict(particle_feature_dim=48, interp_point_dim=12, support=1, activation=2, num_frequencies=1)   # configs/base_gs.yaml:96-103
+
+
+def nht_ray_feature_dim(nht):
+    """threedgrut/model/features.py:152-161."""
+    return nht["interp_point_dim"] * (nht["num_frequencies"] * 2 if nht["activation"] == 2 else (nht["num_frequencies"] if nht["activation"] == 1 else 1))
+
+
+def gut_forward_nht(cfg, cam, pose_start, pose_end, density12, features, ray_o, ray_d, nht=None, dtype=np.float32, lists=None):
+    """Reference forward in the neural-harmonic-features configuration (model.feature_type = nht, K = 0): projection and binning as for
+    SH (no per-particle radiance), per-hit features interpolated at the canonical intersection -> [H, W, ray_dim + 1]."""
+    nht = dict(NHT_DEFAULT, **(nht or {}))
+    l = lib(dtype)
+    H, W = cam.height, cam.width
+    n = len(density12)
+    if lists is None:
+        proj = gut_project(cfg, cam, pose_start, pose_end, 0, density12, np.zeros((n, 48), np.float32), dtype)
+        bins = gut_bin(cfg, W, H, proj, dtype)
+    else:
+        proj = None
+        bins = dict(sorted_idx=np.ascontiguousarray(lists[0], np.uint32), tile_ranges=np.ascontiguousarray(lists[1], np.uint32))
+    nr = nht_ray_feature_dim(nht)
+    fd = np.zeros((H, W, nr + 1), dtype)
+    dist = np.full((H, W, 1), 1e6, dtype)
+    cnt = np.zeros((H, W, 1), dtype)
+    prm = np.array([nht["particle_feature_dim"], nht["interp_point_dim"], nht["support"], nht["activation"], nht["num_frequencies"]], np.int32)
+    ro, rd = _c(ray_o, dtype).reshape(H, W, 3), _c(ray_d, dtype).reshape(H, W, 3)
+    rc = l.orc_gut_render_nht_fwd(C.byref(cfg), _p(prm), W, H, _p(_c(pose_start, dtype)), _p(_c(pose_end, dtype)), _p(_c(density12, dtype)),
+                                  _p(_c(features, dtype)), _p(bins["sorted_idx"]), _p(bins["tile_ranges"]), _p(ro), _p(rd), _p(fd), _p(dist), _p(cnt))
+    assert rc == 0
+    return dict(feat_density=fd, hit_distance=dist, hit_count=cnt, sorted_idx=bins["sorted_idx"], tile_ranges=bins["tile_ranges"], proj=proj)
+
+
 def gut_backward(cfg, cam, n_active, fwd, g_feat_density, g_hit_distance, dtype=np.float32):
     """Reference backward (SplatRaster::trace_bwd): returns (grad_density12 [N,12], grad_sph [N,3*ncoef])."""
     l = lib(dtype)

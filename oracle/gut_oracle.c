@@ -766,6 +766,108 @@ int orc_gut_render_fwd(const GutConfig* cfg, int width, int height, const real* 
     return 0;
 }
 
+/* --------------------------------------------------------------------------------------
+ * render forward with NEURAL HARMONIC FEATURES (model.feature_type = nht, FEATURE_TRANSFORM_TYPE 1), K = 0:
+ * gutKBufferRenderer.cuh:199-225 processHitParticle (featureIntegrateFwd of featuresFromBuffer at the hit's canonical intersection),
+ * :228-352 the tile loop; canonical intersection gaussianParticles.slang:181-190; the feature model
+ * neuralHarmonicFeaturesParticle.slang:85-97 (fetch), :117-127 (barycentric weights in the canonical tetrahedron :47-66),
+ * :146-196 (blend + activation), :198-211 (integration: += features * weight if weight > 0); write-out of
+ * RAY_FEATURE_DIM + 1 channels rayPayload.cuh:160-193.  Pinned by tests/golden/gut_nht.npz (the reference's renderer around a
+ * restatement of the .slang feature model, oracle/ref/shim/threedgutSlang.cuh).
+ * nht = {particle_feature_dim K, interp_point_dim, support (0 centre, 1 tetrahedra), activation (0 none, 1 siren, 2 sincos, 3 relu),
+ *        num_frequencies}; features [N, K]; out_fd [H, W, ray_dim + 1]. */
+#define ORC_NHT_MAX_RAY_DIM 64
+static int nht_ray_dim(const int* nht) {
+    return nht[3] == 2 ? nht[1] * nht[4] * 2 : ((nht[3] == 0 || nht[3] == 3) ? nht[1] : nht[1] * nht[4]);
+}
+static void nht_features_at(const int* nht, const real* row, v3 P, real* out) {
+    const int ipd = nht[1], act = nht[3], nf = nht[4];
+    real base[ORC_NHT_MAX_RAY_DIM];
+    for (int n = 0; n < ipd; ++n) base[n] = row[n];
+    if (nht[2] == 1) {
+        const real edge = R_(4.898979485566356), face_h = R_(4.242640687119285), height = R_(4.0), face_in = R_(1.4142135623730951), in_r = R_(1.0);
+        const v3 v0 = v3_make(R_(0.5) * edge, -face_in, R_(-1.0)), v1 = v3_make(R_(-0.5) * edge, -face_in, R_(-1.0));
+        const v3 v2 = v3_make(0, face_h - face_in, R_(-1.0)), v3_ = v3_make(0, 0, height - in_r);
+        const v3 e1 = v3_sub(v1, v0), e2 = v3_sub(v2, v0), e3 = v3_sub(v3_, v0);
+        const v3 c23 = v3_cross(e2, e3);
+        const real inv_det = 1 / v3_dot(e1, c23);
+        const v3 d = v3_sub(P, v0);
+        real w[4];
+        w[1] = v3_dot(d, c23) * inv_det;
+        w[2] = v3_dot(e1, v3_cross(d, e3)) * inv_det;
+        w[3] = v3_dot(e1, v3_cross(e2, d)) * inv_det;
+        w[0] = 1 - w[1] - w[2] - w[3];
+        for (int n = 0; n < ipd; ++n) base[n] *= w[0];
+        for (int k = 1; k < 4; ++k)
+            for (int n = 0; n < ipd; ++n) base[n] += w[k] * row[k * ipd + n];
+    }
+    if (act == 0) { for (int i = 0; i < ipd; ++i) out[i] = base[i]; }
+    else if (act == 3) { for (int i = 0; i < ipd; ++i) out[i] = r_max(0, base[i]); }
+    else if (act == 2) {
+        for (int k = 0; k < ipd; ++k)
+            for (int f = 0; f < nf; ++f) {
+                const real angle = base[k] * (real)(f + 1);
+                out[k * nf * 2 + f * 2] = r_sin(angle); out[k * nf * 2 + f * 2 + 1] = r_cos(angle);
+            }
+    } else {
+        for (int k = 0; k < ipd; ++k)
+            for (int f = 0; f < nf; ++f) out[k * nf + f] = r_sin(base[k] * (real)ldexp(1.0, f));
+    }
+}
+int orc_gut_render_nht_fwd(const GutConfig* cfg, const int* nht, int width, int height, const real* pose_start7, const real* pose_end7,
+                           const real* density12, const real* features, const uint32_t* sorted_idx, const uint32_t* tile_ranges,
+                           const real* ray_o, const real* ray_d, real* out_fd, real* out_dist, real* out_cnt) {
+    const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
+    const int gx = tile_grid_dim(width);
+    const int nr = nht_ray_dim(nht);
+    if (cfg->k_buffer_size != 0 || nr > ORC_NHT_MAX_RAY_DIM || nht[1] > ORC_NHT_MAX_RAY_DIM) return -1;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int pix = 0; pix < width * height; ++pix) {
+        const int x = pix % width, y = pix / width;
+        const orc_ray ray = init_ray(&fp, ray_o + 3 * (size_t)pix, ray_d + 3 * (size_t)pix);
+        if (!ray.valid) continue;
+        const uint32_t tile = (uint32_t)((y / ORC_TILE) * gx + (x / ORC_TILE));
+        const uint32_t beg = tile_ranges[2 * tile], end = tile_ranges[2 * tile + 1];
+        real T = 1, D = 0, acc[ORC_NHT_MAX_RAY_DIM]; uint32_t cnt = 0; int alive = 1;
+        for (int i = 0; i < nr; ++i) acc[i] = 0;
+        for (uint32_t e = beg; e < end && alive; ++e) {
+            const uint32_t idx = sorted_idx[e];
+            if (idx == ORC_INVALID_IDX) break;
+            const orc_particle p = load_particle(density12 + 12 * (size_t)idx);
+            /* density_hit_ex with the canonical intersection kept (gaussianParticles.slang:181-190) */
+            const v3 giscl = v3_make(1 / p.scl.x, 1 / p.scl.y, 1 / p.scl.z);
+            const v3 gro = v3_mul(giscl, v3_mul_rows(v3_sub(ray.o, p.pos), &p.rotT));
+            const v3 grdu = v3_mul(giscl, v3_mul_rows(ray.d, &p.rotT));
+            const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
+            const v3 gcrod = v3_cross(grd, gro);
+            const real resp = particle_response(cfg->particle_kernel_degree, v3_dot(gcrod, gcrod));
+            const real alpha = r_min((real)cfg->particle_kernel_max_alpha, resp * p.density);
+            if (!((resp > (real)cfg->particle_kernel_min_response) && (alpha > (real)cfg->particle_kernel_min_alpha))) continue;
+            const v3 cg = v3_scale(grd, v3_dot(grd, v3_scale(gro, -1)));
+            const v3 P = v3_add(gro, cg);
+            const v3 grds = v3_mul(p.scl, cg);
+            const real hitT = r_sqrt(v3_dot(grds, grds));
+            if (!(hitT > ray.tmin && hitT < ray.tmax)) continue;
+            const real w = alpha * T;
+            D += hitT * w;
+            T *= (1 - alpha);
+            if (w > 0) {
+                real f[ORC_NHT_MAX_RAY_DIM];
+                nht_features_at(nht, features + (size_t)nht[0] * idx, P, f);
+                for (int i = 0; i < nr; ++i) acc[i] += f[i] * w;
+                cnt++;
+            }
+            if (T < (real)cfg->min_transmittance) alive = 0;
+        }
+        real* o = out_fd + (size_t)(nr + 1) * pix;
+        for (int i = 0; i < nr; ++i) o[i] = acc[i];
+        o[nr] = 1 - T;
+        out_dist[pix] = D;
+        if (cfg->enable_hitcounts) out_cnt[pix] = (real)cnt;
+    }
+    return 0;
+}
+
 /* Analysis aid (scripts/slab_analysis.py): per pixel, how many entries of its tile list the K = 0 forward loop examines
  * before the ray ends (the whole list if it never does).  Same loop as orc_gut_render_fwd. */
 int orc_gut_render_fwd_consumed(const GutConfig* cfg, int width, int height, const real* pose_start7, const real* pose_end7,

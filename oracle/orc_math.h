@@ -39,6 +39,7 @@ static inline real r_fabs(real x) { return x < 0 ? -x : x; }
 static inline real r_min(real a, real b) { return a < b ? a : b; }
 static inline real r_max(real a, real b) { return a > b ? a : b; }
 static inline real r_sin(real x) { return (real)sin((double)x); }
+static inline real r_cos(real x) { return (real)cos((double)x); }
 static inline real r_acos(real x) { return (real)acos((double)x); }
 static inline real r_hypot(real x, real y) { return (real)hypot((double)x, (double)y); }
 

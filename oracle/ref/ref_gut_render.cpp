@@ -25,9 +25,11 @@
 #include "ref_block_emul.inl"
 
 // ---- the -D set of setup_3dgut.py:47-95 for configs/render/3dgut.yaml (degree and K come from the Makefile) ----------------
+#ifndef FEATURE_TRANSFORM_TYPE   // (the NHT build passes its feature macros from the Makefile: setup_3dgut.py:47-57 for model.feature_type nht)
 #define PARTICLE_FEATURE_DIM 48
 #define RAY_FEATURE_DIM 3
 #define FEATURE_TRANSFORM_TYPE 0
+#endif
 #define PARTICLE_FEATURE_HALF 0
 #define FEATURE_OUTPUT_HALF 0
 #define PARTICLE_RADIANCE_NUM_COEFFS 16
@@ -215,6 +217,10 @@ void ref_gut_render_bwd(int width, int height, const float* pose_start7, const f
 // threedgut::processHitFwd<DEG, false, false> (gaussianParticles.cuh:350-421): for each of n (ray, particle) pairs, one hit
 // integrated into state {T, rgb, depth} both ways; returns the largest absolute difference over all state components and
 // writes how many pairs were accepted by each side.
+int ref_gut_ray_feature_dim(void) { return RAY_FEATURE_DIM; }
+int ref_gut_particle_feature_dim(void) { return PARTICLE_FEATURE_DIM; }
+
+#if FEATURE_TRANSFORM_TYPE == 0
 float ref_gut_standin_max_error(uint32_t n, const float* ray_o, const float* ray_d, const float* density12, const float* feat3,
                                 uint32_t* accepted_standin, uint32_t* accepted_twin) {
     float worst = 0.f;
@@ -251,5 +257,6 @@ float ref_gut_standin_max_error(uint32_t n, const float* ray_o, const float* ray
     }
     return worst;
 }
+#endif
 
 }  // extern "C"

@@ -124,6 +124,62 @@ inline void particleFeaturesIntegrateFwd(float weight, const FixedArray<float, N
         for (int i = 0; i < N; ++i) (*integratedFeatures)[i] += features[i] * weight;
 }
 
+#if defined(FEATURE_TRANSFORM_TYPE) && FEATURE_TRANSFORM_TYPE == 1
+// particleFeaturesFromBuffer of the NEURAL HARMONIC FEATURES model (kernels/slang/models/neuralHarmonicFeaturesParticle.slang:233-251 ->
+// featuresFromParametersBuffer :146-196: fetchParametersFromBuffer :85-97, barycentricTetrahedronCanonical :117-127 over the canonical
+// tetrahedron of :47-66, then the activation).  This model has NO hand-written CUDA twin in the checkout, so unlike the entry points
+// above this restatement cannot be cross-checked against reference code: what libref_gut_render_nht pins is the renderer around it
+// (tile loop, hit test, canonical intersection, integration order, ray set-up and write-out of RAY_FEATURE_DIM + 1 channels).
+namespace slang_standin {
+inline float3 sub3(const float3& a, const float3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline float3 cross3(const float3& a, const float3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+}
+template <typename TElem>
+inline void particleFeaturesFromBuffer(uint32_t particleIdx, TElem* featuresBufferPtr, int /*auxParam*/, float3 /*incidentDirection*/,
+                                       float3 canonicalPosition, FixedArray<float, RAY_FEATURE_DIM>* features) {
+    using namespace slang_standin;
+    constexpr int IPD = INTERP_POINT_FEATURE_DIM;
+    const TElem* row = featuresBufferPtr + (size_t)particleIdx * PARTICLE_FEATURE_DIM;
+    float base[IPD];
+    for (int n = 0; n < IPD; ++n) base[n] = (float)row[n];
+#if FEATURE_INTERPOLATION_SUPPORT == 1 && FEATURE_INTERPOLATION_TYPE == 0
+    {
+        const float edge = 4.898979485566356f, faceHeight = 4.242640687119285f, height = 4.0f, faceInRadius = 1.4142135623730951f, inRadius = 1.0f;
+        const float3 v0 = {0.5f * edge, -faceInRadius, -1.0f}, v1 = {-0.5f * edge, -faceInRadius, -1.0f},
+                     v2 = {0.0f, faceHeight - faceInRadius, -1.0f}, v3 = {0.0f, 0.0f, height - inRadius};
+        const float3 e1 = sub3(v1, v0), e2 = sub3(v2, v0), e3 = sub3(v3, v0);
+        const float3 c23 = cross3(e2, e3);
+        const float invDet = 1.0f / dot3(e1, c23);
+        const float3 d = sub3(canonicalPosition, v0);
+        float w[4];
+        w[1] = dot3(d, c23) * invDet;
+        w[2] = dot3(e1, cross3(d, e3)) * invDet;
+        w[3] = dot3(e1, cross3(e2, d)) * invDet;
+        w[0] = 1.0f - w[1] - w[2] - w[3];
+        for (int n = 0; n < IPD; ++n) base[n] *= w[0];
+        for (int k = 1; k < 4; ++k)
+            for (int n = 0; n < IPD; ++n) base[n] += w[k] * (float)row[k * IPD + n];
+    }
+#endif
+#if FEATURE_ACTIVATION_TYPE == 0
+    for (int i = 0; i < IPD; ++i) (*features)[i] = base[i];
+#elif FEATURE_ACTIVATION_TYPE == 3
+    for (int i = 0; i < IPD; ++i) (*features)[i] = std::max(0.0f, base[i]);
+#elif FEATURE_ACTIVATION_TYPE == 2
+    for (int k = 0; k < IPD; ++k)
+        for (int f = 0; f < FEATURE_ACTIVATION_NUM_FREQUENCIES; ++f) {
+            const float angle = base[k] * (float)(f + 1);
+            (*features)[k * FEATURE_ACTIVATION_NUM_FREQUENCIES * 2 + f * 2 + 0] = std::sin(angle);
+            (*features)[k * FEATURE_ACTIVATION_NUM_FREQUENCIES * 2 + f * 2 + 1] = std::cos(angle);
+        }
+#else   // siren: sin(b 2^f)
+    for (int k = 0; k < IPD; ++k)
+        for (int f = 0; f < FEATURE_ACTIVATION_NUM_FREQUENCIES; ++f)
+            (*features)[k * FEATURE_ACTIVATION_NUM_FREQUENCIES + f] = std::sin(base[k] * std::ldexp(1.0f, f));
+#endif
+}
+#endif
+
 // ---- autodiff products: declared so that the reference's non-template kernels parse, never reached ------------------------
 template <int N>
 inline void particleFeaturesBwdToBuffer(uint32_t, float*, float*, int, bool, const FixedArray<float, N>&, float3, float3*) {
@@ -131,6 +187,11 @@ inline void particleFeaturesBwdToBuffer(uint32_t, float*, float*, int, bool, con
 }
 inline void particleDensityIncidentDirectionBwdToBuffer(uint32_t, gaussianParticle_CommonParameters_0, float3, float3) {
     slang_standin::unreachable("particleDensityIncidentDirectionBwdToBuffer");
+}
+template <typename TElem, int N>
+inline void particleFeaturesIntegrateBwdToBuffer(float3, float3, float3*, float, float*, uint32_t, TElem*, float*, int, bool, const FixedArray<float, N>&,
+                                                 FixedArray<float, N>*, FixedArray<float, N>*) {
+    slang_standin::unreachable("particleFeaturesIntegrateBwdToBuffer");
 }
 template <int N>
 inline void particleFeaturesIntegrateBwd(float, float*, const FixedArray<float, N>&, FixedArray<float, N>*, FixedArray<float, N>*,

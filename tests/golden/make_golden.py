@@ -489,6 +489,72 @@ class RefMaterial(C.Structure):   # oracle/ref/ref_playground.cpp: RefMaterial
                 ("transmission", C.c_float), ("ior", C.c_float), ("alpha_cutoff", C.c_float), ("alpha_mode", C.c_uint32)]
 
 
+def nht_features(n, seed=77, dim=48):
+    """[n, dim] per-particle neural-harmonic features in the range the model initialises them to (configs/base_gs.yaml:97-99)."""
+    return np.random.default_rng(seed).uniform(-np.pi / 2, np.pi / 2, size=(n, dim)).astype(F)
+
+
+def gut_reference_frame_nht(sc, feats):
+    """The reference's 3DGUT kernels built for model.feature_type = nht (oracle/_ref/libref_gut_render_nht_deg2_k0.so: FEATURE_TRANSFORM_TYPE 1,
+    48 floats per particle = 4 tetrahedron vertices x 12, sincos x 1 frequency -> 24 ray features): projectOnTiles (no per-particle
+    radiance), expansion, sort, ranges, render -> [H,W,25] features + opacity, hit distance, hit count."""
+    lib = C.CDLL(os.path.join(REF, "libref_gut_render_nht_deg2_k0.so"))
+    plib = C.CDLL(os.path.join(REF, "libref_projector.so"))
+    nf = lib.ref_gut_ray_feature_dim()
+    assert nf == 24 and lib.ref_gut_particle_feature_dim() == feats.shape[1] == 48 and lib.ref_gut_k_buffer_size() == 0
+    W, H = sc["W"], sc["H"]
+    d12, feats = np.ascontiguousarray(sc["density12"], F), np.ascontiguousarray(feats, F)
+    n = len(d12)
+    cam = sc["cam"]
+    prm = camera_prm(cam)
+    ps, pe = np.asarray(sc["pose_start"], F), np.asarray(sc["pose_end"], F)
+    ro, rd = (np.ascontiguousarray(a, F).reshape(H, W, 3) for a in sc["rays"])
+    o = dict(tiles_count=np.zeros(n, np.uint32), proj_pos=np.zeros((n, 2), F), conic_opacity=np.zeros((n, 4), F), extent=np.zeros((n, 2), F),
+             depth=np.zeros(n, F), visibility=np.zeros(n, np.int32))
+    unused = np.zeros((n, nf), F)   # the per-particle feature cache of the SH configuration: not written with per-ray features (gutProjector.cuh:306)
+    lib.ref_gut_project(int(cam.model), int(cam.shutter), W, H, _p(prm), _p(ps), _p(pe), C.c_uint32(n), _p(d12), _p(feats), 3, _p(o["tiles_count"]), _p(o["proj_pos"]),
+                        _p(o["conic_opacity"]), _p(o["extent"]), _p(o["depth"]), _p(unused), _p(o["visibility"]))
+    assert not unused.any()
+    offsets = np.cumsum(o["tiles_count"], dtype=np.uint64).astype(np.uint32)
+    total = int(offsets[-1])
+    keys, idx = np.zeros(total, np.uint64), np.zeros(total, np.uint32)
+    plib.ref_expand_particles(W, H, C.c_uint32(n), _p(offsets), _p(o["proj_pos"]), _p(o["conic_opacity"]), _p(o["extent"]), _p(o["depth"]),
+                              _p(keys), _p(idx))
+    order = np.argsort(keys, kind="stable")
+    o["sorted_idx"] = np.ascontiguousarray(idx[order])
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
+    tile_of = (keys[order] >> np.uint64(32)).astype(np.int64)
+    o["tile_ranges"] = np.stack([np.searchsorted(tile_of, np.arange(tiles), "left"),
+                                 np.searchsorted(tile_of, np.arange(tiles), "right")], 1).astype(np.uint32)
+    o["tile_ranges"][o["tile_ranges"][:, 0] == o["tile_ranges"][:, 1]] = 0
+    lo, hi = np.full(3, -1e6, F), np.full(3, 1e6, F)
+    o["feat_density"], o["hit_distance"], o["hit_count"] = np.zeros((H, W, nf + 1), F), np.full((H, W, 1), 1e6, F), np.zeros((H, W, 1), F)
+    lib.ref_gut_render_fwd(W, H, _p(ps), _p(pe), _p(lo), _p(hi), C.c_uint32(n), _p(d12), _p(feats), 3, _p(o["tile_ranges"]), _p(o["sorted_idx"]),
+                           None, _p(ro), _p(rd), _p(o["feat_density"]), _p(o["hit_distance"]), _p(o["hit_count"]))
+    return o
+
+
+def make_gut_nht():
+    """tests/golden/gut_nht.npz: the reference's 3DGUT forward in its neural-harmonic-features configuration (see gut_reference_frame_nht;
+    the feature model itself — barycentric interpolation in the canonical tetrahedron + sincos — is the stand-in's restatement of
+    neuralHarmonicFeaturesParticle.slang, the renderer around it is the reference's code)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import make_scene
+    out = {}
+    for k, kw in enumerate(GUT_RENDER_SCENES):
+        sc = make_scene(**kw)
+        feats = nht_features(len(sc["density12"]), seed=77 + k)
+        o = gut_reference_frame_nht(sc, feats)
+        out[f"s{k}_features"] = feats
+        for name in ("tiles_count", "sorted_idx", "tile_ranges", "feat_density", "hit_distance", "hit_count"):
+            out[f"s{k}_{name}"] = o[name]
+        print(f"nht scene {k}: opacity {o['feat_density'][..., -1].mean():.3f}, |features| mean {np.abs(o['feat_density'][..., :-1]).mean():.3f}, "
+              f"hits/ray {o['hit_count'].mean():.1f}")
+    np.savez_compressed(os.path.join(HERE, "gut_nht.npz"), **out)
+    print("wrote gut_nht.npz")
+
+
 def playground_reference(sc, opts, bounces, frame):
     """One frame of a tests/playground_scenes.make_playground_scene() scene through the reference's own programs
     (oracle/_ref/libref_playground_deg4.so) over the proxy instances of the reference's instance kernel."""
@@ -572,7 +638,7 @@ def make_playground():
 if __name__ == "__main__":
     import sys
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
-    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "gut_render", "playground"]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "gut_render", "playground", "gut_nht"]
     if "--adam-only" in sys.argv:
         which = ["adam"]
     if "per_hit" in which:
@@ -592,3 +658,5 @@ if __name__ == "__main__":
         make_gut_render()
     if "playground" in which:
         make_playground()
+    if "gut_nht" in which:
+        make_gut_nht()

@@ -641,3 +641,26 @@ def test_backward_matches_autograd_of_the_restated_reference_forward(name):
         # the per-particle radiance gradient between the two stages (render backward output = projection backward input), taken
         # on the clamped radiance on both sides
         assert rel_err(grgb, g[f"{name}_grad_radiance"]) < tol
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_nht_forward_matches_reference_kernels_golden(k):
+    """model.feature_type = nht (FEATURE_TRANSFORM_TYPE 1): the reference's projectOnTiles / render kernels built with the NHT macro set
+    (oracle/ref: libref_gut_render_nht_deg2_k0, tests/golden/make_golden.py: make_gut_nht) against orc_gut_render_nht_fwd — first on the
+    reference's own tile lists, then end to end through the oracle's binning."""
+    from scenes import make_scene
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gut_nht.npz"))
+    sc = make_scene(**mg.GUT_RENDER_SCENES[k])
+    feats = g[f"s{k}_features"]
+    cfg = oracle.default_gut_config()
+    on_lists = oracle.gut_forward_nht(cfg, sc["cam"], sc["pose_start"], sc["pose_end"], sc["density12"], feats, *sc["rays"],
+                                      lists=(g[f"s{k}_sorted_idx"], g[f"s{k}_tile_ranges"]))
+    ref = g[f"s{k}_feat_density"]
+    assert ref.shape[-1] == 25 and np.abs(ref[..., :24]).max() > 0.5
+    assert np.array_equal(on_lists["hit_count"], g[f"s{k}_hit_count"])
+    assert np.abs(on_lists["feat_density"] - ref).max() < 2e-5 and np.abs(on_lists["hit_distance"] - g[f"s{k}_hit_distance"]).max() < 2e-5
+    full = oracle.gut_forward_nht(cfg, sc["cam"], sc["pose_start"], sc["pose_end"], sc["density12"], feats, *sc["rays"])
+    assert np.array_equal(full["sorted_idx"], g[f"s{k}_sorted_idx"])
+    assert np.abs(full["feat_density"] - ref).max() < 2e-5
