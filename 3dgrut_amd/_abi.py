@@ -48,6 +48,8 @@ class GutConfig(C.Structure):
         ("global_z_order", C.c_int32), ("rect_bounding", C.c_int32),
         ("tight_opacity_bounding", C.c_int32), ("tile_based_culling", C.c_int32),
         ("particle_feature_half", C.c_int32), ("feature_output_half", C.c_int32),
+        ("feature_transform_type", C.c_int32), ("particle_feature_dim", C.c_int32), ("interp_point_feature_dim", C.c_int32),
+        ("feature_interpolation_support", C.c_int32), ("feature_activation_type", C.c_int32), ("feature_activation_num_frequencies", C.c_int32),
     ]
 
 

@@ -96,6 +96,18 @@ static int validate_config(const GutConfig& c) {
         set_last_error("k_buffer_size=%d: the hit buffer is instantiated for 0 (unsorted), 4, 8 and 16 entries", c.k_buffer_size);
         return GRUT_ERR_UNSUPPORTED;
     }
+    if (c.feature_transform_type != 0) {
+        GRUT_REQUIRE(c.feature_transform_type == 1, "feature_transform_type %d: 0 (SH) or 1 (neural harmonic features)", c.feature_transform_type);
+        GRUT_REQUIRE(c.k_buffer_size == 0, "neural harmonic features: k_buffer_size must be 0");
+        GRUT_REQUIRE(c.feature_interpolation_support == 0 || c.feature_interpolation_support == 1, "feature_interpolation_support must be 0 (centre) or 1 (tetrahedra)");
+        GRUT_REQUIRE(c.feature_activation_type >= 0 && c.feature_activation_type <= 3, "feature_activation_type must be 0..3");
+        const int points = c.feature_interpolation_support == 1 ? 4 : 1;
+        GRUT_REQUIRE(c.interp_point_feature_dim >= 1 && c.interp_point_feature_dim <= 16 && c.particle_feature_dim == points * c.interp_point_feature_dim,
+                     "particle_feature_dim %d must be %d x interp_point_feature_dim (1..16)", c.particle_feature_dim, points);
+        const int nf = c.feature_activation_num_frequencies;
+        const int nr = c.interp_point_feature_dim * (c.feature_activation_type == 2 ? 2 * nf : (c.feature_activation_type == 1 ? nf : 1));
+        GRUT_REQUIRE(nf >= 1 && nr >= 1 && nr <= 32, "ray feature dim %d: 1..32 supported", nr);
+    }
     const int d = c.particle_kernel_degree;
     GRUT_REQUIRE(d == 0 || d == 1 || d == 2 || d == 3 || d == 4 || d == 5 || d == 8, "unsupported particle_kernel_degree %d", d);
     return GRUT_OK;
@@ -140,6 +152,12 @@ static GutParams make_params(const GutConfig& c, const GutFrame& f) {
     P.out_opacity = f.out_opacity;
     P.sph_half = c.particle_feature_half;
     P.out_half = c.feature_output_half;
+    P.nht = c.feature_transform_type;
+    if (P.nht) {
+        P.nht_k = c.particle_feature_dim; P.nht_ipd = c.interp_point_feature_dim; P.nht_support = c.feature_interpolation_support;
+        P.nht_act = c.feature_activation_type; P.nht_nf = c.feature_activation_num_frequencies;
+        P.nht_ray_dim = P.nht_ipd * (P.nht_act == 2 ? 2 * P.nht_nf : (P.nht_act == 1 ? P.nht_nf : 1));
+    }
     return P;
 }
 
@@ -316,6 +334,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     }
     GRUT_REQUIRE(particle_density && particle_sph && out_visibility, "gut_forward: null particle buffer");
     GRUT_REQUIRE(!h->cfg.feature_output_half || (!frame->out_features && !frame->out_opacity), "gut_forward: feature_output_half excludes out_features / out_opacity");
+    GRUT_REQUIRE(!h->cfg.feature_transform_type || (!frame->out_features && !frame->out_opacity), "gut_forward: neural harmonic features exclude out_features / out_opacity");
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.begin(s));
 
     GRUT_CHECK(ensure_particle_scratch(h, N));
@@ -405,7 +424,10 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_RANGES, s, slot));
         // K7 compositing
         GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_FWD, s, slot));
-        if (P.k_buffer > 0)
+        if (P.nht)
+            launch_render_nht_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, particle_sph, ray_origin,
+                                  ray_direction, out_feat_density, out_hit_distance, out_hit_count);
+        else if (P.k_buffer > 0)
             launch_render_k_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, proj.rgb, ray_origin,
                                 ray_direction, out_feat_density, out_hit_distance, out_hit_count);
         else
@@ -425,7 +447,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         const float far = 1e6f;
         uint32_t bits;
         memcpy(&bits, &far, 4);
-        GRUT_HIP(hipMemsetAsync(out_feat_density, 0, (size_t)P.W * P.H * (P.out_half ? 8 : 16), s));
+        GRUT_HIP(hipMemsetAsync(out_feat_density, 0, (size_t)P.W * P.H * (P.nht ? P.nht_ray_dim + 1 : 4) * (P.out_half ? 2 : 4), s));
         GRUT_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out_hit_distance), (int)bits, (size_t)P.W * P.H, s));
         GRUT_HIP(hipMemsetAsync(out_hit_count, 0, (size_t)P.W * P.H * 4, s));
         if (P.out_features) GRUT_HIP(hipMemsetAsync(P.out_features, 0, (size_t)P.W * P.H * 12, s));
@@ -460,6 +482,10 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
         return GRUT_ERR_NOT_READY;
     }
     const GutParams& P = h->params;
+    if (P.nht) {
+        set_last_error("gut_backward: the neural-harmonic-features configuration is forward only in this version");
+        return GRUT_ERR_UNSUPPORTED;
+    }
     GRUT_REQUIRE(frame->num_particles == P.N && frame->width == P.W && frame->height == P.H, "gut_backward: frame differs from the forward frame");
     if (frame->frame_id != h->fwd_frame_id || (P.N > 0 && (particle_density != h->fwd_density || ray_origin != h->fwd_ray_o || ray_direction != h->fwd_ray_d))) {
         set_last_error("gut_backward: the forward context belongs to another forward (a later gut_forward ran on this handle before this "

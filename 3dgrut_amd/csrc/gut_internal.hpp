@@ -24,6 +24,8 @@ struct GutParams {
     const float4* rec64;          // [N][4] {pos, density | quat | scale, bits(part_offset) | unclamped rgb, -}: written by the projection for visible particles; null = legacy lists
     const uint32_t* sorted_keys;  // [I] sorted tile keys (the backward reads the ordinals)
     uint32_t ord_shift;           // ordinal = key >> ord_shift
+    // neural harmonic features (GutConfig::feature_transform_type 1): 0 = SH radiance
+    int nht, nht_k, nht_ipd, nht_support, nht_act, nht_nf, nht_ray_dim;
     int sph_half, out_half;       // fp16 feature I/O (GutConfig::particle_feature_half / feature_output_half): the SH buffer / the [H,W,4] image are IEEE half
     uint32_t work_task_capacity;  // ... and how many {lifetime, start} records of gradient-sweep tasks fit behind the forward sweep's block
     float* out_features;          // optional contiguous copies of the radiance / opacity outputs (GutFrame::out_features / out_opacity)
@@ -120,6 +122,9 @@ void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
 void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const float* density12,
                        const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const GutGradIn& g_fd, const float* dist,
                        const float* g_dist, const GutGradSlots& slots, const GutCheckpoints& ck);
+void launch_render_nht_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                           const float* density12, const float* features, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
+                           float* out_cnt);
 void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                          float* out_cnt);

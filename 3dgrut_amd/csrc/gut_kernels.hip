@@ -383,7 +383,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, GRUT_PRO
             const int nact = (P.n_active + 1) * (P.n_active + 1);
             const float* coef = sph + (size_t)i * 3 * P.ncoef;
             float r = 0.f, g = 0.f, bl = 0.f;
-            if (P.sph_half) {   // PARTICLE_FEATURE_HALF: the coefficients are stored as IEEE half, the arithmetic stays fp32
+            if (P.nht) {        // per-ray features: no per-particle radiance (gutProjector.cuh:306)
+                r = g = bl = -0.5f;
+            } else if (P.sph_half) {   // PARTICLE_FEATURE_HALF: the coefficients are stored as IEEE half, the arithmetic stays fp32
                 const __half* hc = reinterpret_cast<const __half*>(sph) + (size_t)i * 3 * P.ncoef;
                 for (int k = 0; k < nact && k < P.ncoef; ++k) {
                     r = fmaf(basis[k], __half2float(hc[3 * k + 0]), r);

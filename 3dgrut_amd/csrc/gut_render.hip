@@ -200,7 +200,7 @@ __device__ __forceinline__ RawEntry load_entry(uint32_t e, uint32_t end, const E
             r.a = density12[3 * (size_t)r.idx + 0];
             r.q = density12[3 * (size_t)r.idx + 1];
             r.s = density12[3 * (size_t)r.idx + 2];
-            r.rgb = mk3(rgb[3 * (size_t)r.idx], rgb[3 * (size_t)r.idx + 1], rgb[3 * (size_t)r.idx + 2]);
+            if (rgb) r.rgb = mk3(rgb[3 * (size_t)r.idx], rgb[3 * (size_t)r.idx + 1], rgb[3 * (size_t)r.idx + 2]);
         }
     }
     return r;
@@ -1182,6 +1182,164 @@ void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Neural harmonic features, forward (model.feature_type = nht; gutKBufferRenderer.cuh:199-225, :228-352 with PerRayParticleFeatures):
+// the unsorted tile loop, but a hit's features are not a per-particle colour: they are interpolated at the hit's CANONICAL INTERSECTION
+// (the point of the ray closest to the particle centre, in the particle's scaled frame; gaussianParticles.slang:181-190) from the four
+// feature vectors at the vertices of the canonical tetrahedron (neuralHarmonicFeaturesParticle.slang:47-66, :117-127), passed through
+// the activation (:146-196) and integrated with the hit's weight into ray_dim accumulators per pixel (:198-211).  One pixel per lane,
+// one wave per 16x4 strip (the k-buffer kernels' layout); the entry's K feature floats are wave-uniform and read through the scalar
+// cache.  First version: correctness first, ray_dim <= 32.
+// ---------------------------------------------------------------------------------------------
+constexpr int kNhtMaxRay = 32, kNhtMaxIpd = 16;
+__global__ __launch_bounds__(64) void gut_render_nht_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+                                                                const float4* __restrict__ density12, const float* __restrict__ features,
+                                                                const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                                float* __restrict__ out_fd, float* __restrict__ out_dist, float* __restrict__ out_cnt) {
+    __shared__ float4 s_rec[64 * 5];
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t tile = ((slot >> 2) << 3) + xcd, strip = slot & 3u;
+    if (tile >= (uint32_t)(P.gx * P.gy)) return;
+    const int lane = threadIdx.x;
+    const int px = (int)(tile % P.gx) * 16 + (lane & 15);
+    const int py = (int)(tile / P.gx) * 16 + (int)strip * 4 + (lane >> 4);
+    const Ray ray = init_ray(P, ray_o, ray_d, px, py);
+    bool alive = ray.valid;
+    float T = 1.f, D = 0.f, cnt = 0.f;
+    float acc[kNhtMaxRay];
+#pragma unroll
+    for (int i = 0; i < kNhtMaxRay; ++i) acc[i] = 0.f;
+    const int ipd = P.nht_ipd, nf = P.nht_nf, nr = P.nht_ray_dim;
+    // the canonical tetrahedron's Cramer terms (constants of the model)
+    const float edge = 4.898979485566356f, face_h = 4.242640687119285f, face_in = 1.4142135623730951f;
+    const f3 v0 = mk3(0.5f * edge, -face_in, -1.f), v1 = mk3(-0.5f * edge, -face_in, -1.f), v2 = mk3(0.f, face_h - face_in, -1.f), v3 = mk3(0.f, 0.f, 3.f);
+    const f3 e1 = v1 - v0, e2 = v2 - v0, e3 = v3 - v0;
+    const f3 c23 = cross(e2, e3);
+    const float inv_det = 1.f / dot(e1, c23);
+    const uint2 range = ranges[tile];
+    for (uint32_t b = range.x; b < range.y; b += 64) {
+        if (!__any(alive)) break;
+        {   // stage up to 64 entries (as gut_render_k_body)
+            const RawEntry e = load_entry<false>(b + lane, range.y, lists, density12, nullptr);
+            float4 r0 = make_float4(1.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 1.f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
+            float4 r3 = make_float4(1.f, 1.f, 1.f, 0.f), r4 = make_float4(__uint_as_float(0xFFFFFFFFu), 0.f, 0.f, 0.f);
+            if (e.idx != 0xFFFFFFFFu) {
+                const m3 rt = quat_wxyz_to_rotT(e.q.x, e.q.y, e.q.z, e.q.w);
+                const float ix = 1.f / e.s.x, iy = 1.f / e.s.y, iz = 1.f / e.s.z;
+                r0 = make_float4(rt.r0.x * ix, rt.r0.y * ix, rt.r0.z * ix, e.a.x);
+                r1 = make_float4(rt.r1.x * iy, rt.r1.y * iy, rt.r1.z * iy, e.a.y);
+                r2 = make_float4(rt.r2.x * iz, rt.r2.y * iz, rt.r2.z * iz, e.a.z);
+                r3 = make_float4(e.s.x, e.s.y, e.s.z, e.a.w);
+                r4.x = __uint_as_float(e.idx);
+                const float need = fmaxf(P.min_response, P.min_alpha / e.a.w);
+                r4.y = (P.max_alpha > P.min_alpha && e.a.w > 0.f) ? gray_limit_rt(P.degree, need) : 0.f;
+            }
+            float4* rec = &s_rec[lane * 5];
+            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4;
+        }
+        __syncthreads();
+        const int n = (int)min(64u, range.y - b);
+        for (int j = 0; j < n; ++j) {
+            if (!__any(alive)) break;
+            const float4* rec = &s_rec[j * 5];
+            const uint32_t idx = __float_as_uint(rec[4].x);
+            if (idx == 0xFFFFFFFFu) break;   // padding closes the list (gutKBufferRenderer.cuh:312-315)
+            bool hit = false;
+            float w = 0.f;
+            f3 Pc = mk3(0.f, 0.f, 0.f);
+            if (alive) {
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+                const f3 dl = ray.o - mk3(q0.w, q1.w, q2.w);
+                const f3 gro = mk3(dot(mk3(q0.x, q0.y, q0.z), dl), dot(mk3(q1.x, q1.y, q1.z), dl), dot(mk3(q2.x, q2.y, q2.z), dl));
+                const f3 grdu = mk3(dot(mk3(q0.x, q0.y, q0.z), ray.d), dot(mk3(q1.x, q1.y, q1.z), ray.d), dot(mk3(q2.x, q2.y, q2.z), ray.d));
+                const float l2 = dot(grdu, grdu);
+                const f3 gc = cross(grdu, gro);
+                const float cc = dot(gc, gc);
+                if (cc < rec[4].y * l2) {   // response > min_response && alpha > min_alpha
+                    const float il2 = 1.f / l2;
+                    const float resp = response_rt(P.degree, cc * il2);
+                    const float alpha = fminf(P.max_alpha, resp * q3.w);
+                    // canonical intersection gro + grd (grd . -gro) = gro - grdu (grdu . gro) / |grdu|^2; hit distance |S (that offset)|
+                    const float along = -dot(grdu, gro) * il2;
+                    const f3 cg = grdu * along;
+                    const f3 sv = mk3(q3.x, q3.y, q3.z) * cg;
+                    const float hitT = sqrtf(dot(sv, sv));
+                    if ((hitT > ray.tmin) && (hitT < ray.tmax)) {
+                        w = alpha * T;
+                        D = fmaf(hitT, w, D);
+                        T *= (1.f - alpha);
+                        hit = w > 0.f;
+                        Pc = gro + cg;
+                        if (hit) cnt += 1.f;
+                        if (T < P.min_transmittance) alive = false;
+                    }
+                }
+            }
+            if (!__any(hit)) continue;
+            // the entry's feature vectors (wave-uniform address) and this lane's barycentric weights
+            const uint32_t uidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+            float wq[4] = {1.f, 0.f, 0.f, 0.f};
+            if (P.nht_support == 1) {
+                const f3 d = Pc - v0;
+                wq[1] = dot(d, c23) * inv_det;
+                wq[2] = dot(e1, cross(d, e3)) * inv_det;
+                wq[3] = dot(e1, cross(e2, d)) * inv_det;
+                wq[0] = 1.f - wq[1] - wq[2] - wq[3];
+            }
+            const int points = P.nht_support == 1 ? 4 : 1;
+            float base[kNhtMaxIpd];
+#pragma unroll
+            for (int m = 0; m < kNhtMaxIpd; ++m) {
+                base[m] = 0.f;
+                if (m < ipd) {
+                    for (int k = 0; k < points; ++k) {
+                        const size_t at = (size_t)uidx * P.nht_k + (size_t)k * ipd + m;
+                        const float fv = P.sph_half ? __half2float(reinterpret_cast<const __half*>(features)[at]) : features[at];
+                        base[m] = k == 0 ? fv * wq[0] : fmaf(wq[k], fv, base[m]);   // (:166-176: base = f0 w0, then += wk fk)
+                    }
+                }
+            }
+            if (hit) {
+#pragma unroll
+                for (int i = 0; i < kNhtMaxRay; ++i) {
+                    if (i < nr) {
+                        float f;
+                        if (P.nht_act == 0) f = base[i < kNhtMaxIpd ? i : 0];
+                        else if (P.nht_act == 3) f = fmaxf(0.f, base[i < kNhtMaxIpd ? i : 0]);
+                        else if (P.nht_act == 2) {
+                            const int k = i / (2 * nf), rem = i - k * 2 * nf, fq = rem >> 1;
+                            const float angle = base[k < kNhtMaxIpd ? k : 0] * (float)(fq + 1);
+                            f = (rem & 1) ? cosf(angle) : sinf(angle);
+                        } else {
+                            const int k = i / nf, fq = i - k * nf;
+                            f = sinf(base[k < kNhtMaxIpd ? k : 0] * ldexpf(1.f, fq));
+                        }
+                        acc[i] = fmaf(f, w, acc[i]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (ray.inside) {
+        const size_t opix = (size_t)py * P.W + px;
+        const size_t stride = (size_t)nr + 1;
+#pragma unroll
+        for (int i = 0; i < kNhtMaxRay; ++i) {
+            if (i < nr) {
+                const float v = ray.valid ? acc[i] : 0.f;
+                if (P.out_half) reinterpret_cast<__half*>(out_fd)[opix * stride + i] = __float2half(v);
+                else out_fd[opix * stride + i] = v;
+            }
+        }
+        const float op = ray.valid ? 1.f - T : 0.f;
+        if (P.out_half) reinterpret_cast<__half*>(out_fd)[opix * stride + nr] = __float2half(op);
+        else out_fd[opix * stride + nr] = op;
+        out_dist[opix] = ray.valid ? D : 1e6f;
+        if (P.hitcounts) out_cnt[opix] = ray.valid ? cnt : 0.f;
+    }
+}
+
 static uint32_t strip_grid(const GutParams& P) {
     const uint32_t tiles = (uint32_t)(P.gx * P.gy);
     return ((tiles + 7u) & ~7u) * 4u;
@@ -1192,6 +1350,13 @@ static uint32_t strip_grid(const GutParams& P) {
     case 8: { constexpr int K_ = 8; __VA_ARGS__; } break;      \
     default: { constexpr int K_ = 16; __VA_ARGS__; } break;    \
     }
+void launch_render_nht_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                           const float* density12, const float* features, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
+                           float* out_cnt) {
+    const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
+    hipLaunchKernelGGL(gut_render_nht_fwd_kernel, dim3(strip_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
+                       reinterpret_cast<const float4*>(density12), features, ray_o, ray_d, out_fd, out_dist, out_cnt);
+}
 void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                          float* out_cnt) {

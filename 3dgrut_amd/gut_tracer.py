@@ -67,6 +67,21 @@ def gut_config_from_conf(conf) -> _abi.GutConfig:
     for k, d in _SPLAT_DEFAULTS.items():
         v = _conf_get(splat, k, d)
         setattr(cfg, k, type(d)(v) if not isinstance(d, bool) else int(bool(v)))
+    # neural harmonic features (model.feature_type = nht; the macro set of threedgrut/model/features.py:133-175, setup_3dgut.py:47-57)
+    model = _conf_get(conf, "model")
+    if str(_conf_get(model, "feature_type", "sh")).lower() == "nht":
+        nf = _conf_get(model, "nht_features")
+        act = _conf_get(nf, "activation")
+        interp = str(_conf_get(nf, "interpolation_type", "none")).lower()
+        if interp not in ("none", "barycentric"):
+            raise NotImplementedError(f"3dgrut_amd: nht_features.interpolation_type={interp!r} (the reference supports none / barycentric)")
+        points = 4 if interp == "barycentric" else 1
+        cfg.feature_transform_type = 1
+        cfg.particle_feature_dim = int(_conf_get(nf, "dim", 48))
+        cfg.interp_point_feature_dim = cfg.particle_feature_dim // points
+        cfg.feature_interpolation_support = 1 if points == 4 else 0
+        cfg.feature_activation_type = {"none": 0, "siren": 1, "sincos": 2, "relu": 3}[str(_conf_get(act, "type", "sincos")).lower()]
+        cfg.feature_activation_num_frequencies = int(_conf_get(act, "num_frequencies", 1))
     # fp16 feature I/O (setup_3dgut.py:60-61): run-time switches here, compile-time macros in the reference
     cfg.particle_feature_half = int(bool(_conf_get(render, "particle_feature_half", False)))
     cfg.feature_output_half = int(bool(_conf_get(render, "feature_output_half", False)))
@@ -163,6 +178,29 @@ class _GutNative:
             f32 = out_fd.float()
             out_feat, out_opa = f32[..., :3].contiguous(), f32[..., 3:].contiguous()
         return out_fd, out_dist, out_cnt, vis_i32.view(torch.float32), out_feat, out_opa
+
+    @property
+    def ray_feature_dim(self):
+        c = self.cfg
+        if not c.feature_transform_type:
+            return 3
+        a, n = c.feature_activation_type, c.feature_activation_num_frequencies
+        return c.interp_point_feature_dim * (2 * n if a == 2 else (n if a == 1 else 1))
+
+    def trace_nht(self, frame, particle_density, particle_features, ray_ori, ray_dir):
+        """Forward of the neural-harmonic-features configuration (GutConfig::feature_transform_type 1): [H,W,ray_dim+1] features + opacity."""
+        dev = ray_ori.device
+        H, W, N = frame.height, frame.width, frame.num_particles
+        nr = self.ray_feature_dim
+        fd = torch.zeros((H, W, nr + 1), dtype=torch.float16 if self.cfg.feature_output_half else torch.float32, device=dev)
+        dist = torch.full((H, W, 1), 1e6, dtype=torch.float32, device=dev)
+        cnt = torch.zeros((H, W, 1), dtype=torch.float32, device=dev)
+        vis = torch.zeros((N, 1), dtype=torch.int32, device=dev)
+        if self.cfg.particle_feature_half and particle_features.dtype != torch.float16:
+            particle_features = particle_features.to(torch.float16)
+        _abi.check(self.lib.gut_forward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_features.contiguous()),
+                                        _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(dist), _ptr(cnt), _ptr(vis)), "gut_forward")
+        return fd.float(), dist, cnt, vis.view(torch.float32)
 
     def trace_bwd(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_fd, dist, g_dist):
         dev = ray_ori.device
@@ -321,6 +359,21 @@ class Tracer:
             frame.device_T_to_world_end = None if t1 is None else t1.data_ptr()
             frame._keepalive = (t0, t1)
         feats = gaussians.get_features()
+        if native.cfg.feature_transform_type:   # neural harmonic features: forward only in this version
+            if feats.shape[1] != native.cfg.particle_feature_dim:
+                raise ValueError(f"features have {feats.shape[1]} columns, expected nht_features.dim = {native.cfg.particle_feature_dim}")
+            if torch.is_grad_enabled() and any(t.requires_grad for t in (feats, gaussians.positions)):
+                raise NotImplementedError("3dgrut_amd: the neural-harmonic-features (nht) path is forward only; render under torch.no_grad()")
+            with torch.no_grad():
+                pd = _abi.pack_particles(gaussians.positions.contiguous(), gaussians.get_density().contiguous(), gaussians.get_rotation().contiguous(),
+                                         gaussians.get_scale().contiguous())
+                fd, dist, cnt, vis = native.trace_nht(frame, pd, feats.detach(), rays_o.contiguous().float(), rays_d.contiguous().float())
+            nr = native.ray_feature_dim
+            pred_features = fd[..., :nr].unsqueeze(0).contiguous()
+            timings = native.collect_times()
+            return {"pred_features": pred_features, "pred_opacity": fd[..., nr:].unsqueeze(0).contiguous(), "pred_dist": dist.unsqueeze(0),
+                    "pred_normals": torch.nn.functional.normalize(torch.ones_like(pred_features), dim=3), "hits_count": cnt.unsqueeze(0),
+                    "frame_time_ms": timings["forward_render"] if "forward_render" in timings else 0.0, "mog_visibility": vis}
         if feats.shape[1] != 3 * native.ncoef:
             raise ValueError(f"features have {feats.shape[1]} columns, expected {3 * native.ncoef} for SH degree "
                              f"{native.cfg.particle_radiance_sph_degree}")

@@ -715,3 +715,79 @@ def test_scratch_comes_from_the_callers_allocator_and_is_quiet_in_steady_state()
     assert stats["live_bytes"] < 0.05 * live
     torch.cuda.synchronize()
     assert torch.equal(frame(12000), ref)
+
+
+NHT_MODEL = {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1}, "interpolation_type": "barycentric"}}
+
+
+def _nht_render(scene, feats, model=NHT_MODEL, **render_kw):
+    import torch
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    tr = gt.Tracer({"render": dict(render_kw, splat={}), "model": model})
+    g = syn.SimpleGaussians(scene["density12"], feats, requires_grad=False)
+    with torch.no_grad():
+        out = tr.render(g, torch_batch(scene["batch"], "cuda"))
+    torch.cuda.synchronize()
+    return tr, out
+
+
+@pytest.mark.parametrize("k", [0, 1])
+def test_nht_forward_matches_reference_kernels_golden(k):
+    """model.feature_type = nht through the plugin against tests/golden/gut_nht.npz — the reference's own render kernel built with the
+    nht macro set (tests/test_oracle_cpu.py pins the oracle on the same file): [1,H,W,24] ray features + opacity, hit distance, counts."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gut_nht.npz"))
+    scene = make_scene(**mg.GUT_RENDER_SCENES[k])
+    tr, out = _nht_render(scene, g[f"s{k}_features"])
+    ref = g[f"s{k}_feat_density"]
+    assert tuple(out["pred_features"].shape) == (1,) + ref.shape[:2] + (24,) and tuple(out["pred_opacity"].shape) == (1,) + ref.shape[:2] + (1,)
+    f = out["pred_features"][0].cpu().numpy()
+    o = out["pred_opacity"][0].cpu().numpy()
+    cnt = out["hits_count"][0].cpu().numpy()
+    flips = cnt != g[f"s{k}_hit_count"]
+    assert flips.mean() <= 2e-3
+    bad = (np.abs(f - ref[..., :24]).max(-1) > 1e-4) | (np.abs(o - ref[..., 24:])[..., 0] > 1e-4) | \
+          (np.abs(out["pred_dist"][0].cpu().numpy() - g[f"s{k}_hit_distance"])[..., 0] > 1e-4)
+    assert (bad & ~flips[..., 0]).sum() == 0 and bad.mean() <= 2e-3, f"{bad.sum()} pixels beyond 1e-4"
+
+
+@pytest.mark.parametrize("model_kw,half", [({}, False), ({}, True),
+                                           ({"nht_features": {"dim": 8, "activation": {"type": "relu", "num_frequencies": 1}, "interpolation_type": "none"}}, False),
+                                           ({"nht_features": {"dim": 16, "activation": {"type": "siren", "num_frequencies": 3}, "interpolation_type": "barycentric"}}, False)])
+def test_nht_forward_matches_oracle(model_kw, half):
+    """Larger frame and the other feature-model variants (centre support, relu / siren, several frequencies; fp16 feature buffer + fp16
+    output) against the oracle's orc_gut_render_nht_fwd on the GPU's own tile lists' twin (the oracle bins for itself: binning is pinned
+    integer-exactly elsewhere)."""
+    import torch
+    model = dict(NHT_MODEL, **model_kw)
+    nf = model["nht_features"]
+    scene = make_scene(n=6000, width=120, height=72, median_scale=0.05)
+    feats = np.random.default_rng(3).uniform(-np.pi / 2, np.pi / 2, size=(6000, nf["dim"])).astype(np.float32)
+    points = 4 if nf["interpolation_type"] == "barycentric" else 1
+    nht = dict(particle_feature_dim=nf["dim"], interp_point_dim=nf["dim"] // points, support=int(points == 4),
+               activation={"none": 0, "siren": 1, "sincos": 2, "relu": 3}[nf["activation"]["type"]], num_frequencies=nf["activation"]["num_frequencies"])
+    kw = dict(particle_feature_half=True, feature_output_half=True) if half else {}
+    tr, out = _nht_render(scene, feats, model, **kw)
+    ofeats = oracle.round_to_half(feats) if half else feats
+    ora = oracle.gut_forward_nht(oracle.default_gut_config(), scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], ofeats,
+                                 *scene["rays"], nht=nht)
+    nr = oracle.nht_ray_feature_dim(nht)
+    assert tr.tracer_wrapper.ray_feature_dim == nr and out["pred_features"].shape[-1] == nr and out["pred_features"].dtype == torch.float32
+    got = np.concatenate([out["pred_features"][0].cpu().numpy(), out["pred_opacity"][0].cpu().numpy()], -1)
+    ulp = np.spacing(np.abs(got).astype(np.float16)).astype(np.float32) if half else 0.0
+    flips = (out["hits_count"][0].cpu().numpy() != ora["hit_count"])[..., 0]
+    bad = (np.abs(got - ora["feat_density"]) > 1e-4 + 0.5 * ulp).any(-1)
+    assert flips.mean() <= 2e-3 and (bad & ~flips).mean() <= 1e-3, f"{bad.sum()} pixels beyond tolerance, {flips.sum()} flips"
+    assert np.abs(got[..., :nr]).max() > 0.3
+
+
+def test_nht_is_forward_only_and_says_so():
+    import torch
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    scene = make_scene(n=500, width=32, height=32, median_scale=0.1)
+    tr = gt.Tracer({"render": {"splat": {}}, "model": NHT_MODEL})
+    g = syn.SimpleGaussians(scene["density12"], np.zeros((500, 48), np.float32))
+    with pytest.raises(NotImplementedError, match="forward only"):
+        tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)

@@ -121,6 +121,12 @@ def test_configuration_defaults_and_overrides():
     half = gt.gut_config_from_conf({"render": {"particle_feature_half": True, "splat": {}}})   # (setup_3dgut.py:60-61)
     assert (half.particle_feature_half, half.feature_output_half) == (1, 0) and (cfg.particle_feature_half, cfg.feature_output_half) == (0, 0)
     assert gt.fused_activations_requested({"render": {"fused_activations": True}}) and not gt.fused_activations_requested({"render": {}})
+    # model.feature_type = nht -> the macro set of threedgrut/model/features.py:133-175 (defaults of configs/base_gs.yaml:96-103)
+    assert cfg.feature_transform_type == 0
+    nht = gt.gut_config_from_conf({"render": {"splat": {}}, "model": {"feature_type": "nht", "nht_features": {
+        "dim": 48, "activation": {"type": "sincos", "num_frequencies": 1}, "interpolation_type": "barycentric"}}})
+    assert (nht.feature_transform_type, nht.particle_feature_dim, nht.interp_point_feature_dim, nht.feature_interpolation_support,
+            nht.feature_activation_type, nht.feature_activation_num_frequencies) == (1, 48, 12, 1, 2, 1)
 
 
 def test_tracers_refuse_to_run_without_a_gpu():
