@@ -1410,9 +1410,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             __syncthreads();
             while (m) {
                 const int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
                 const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
-                const float v = s_terms[src * kTermStride + term_word] * (sh_lane ? s_basis[src * kBasisStride + basis_word] : 1.f);
+                // the lanes that hold the same particle in this slot (neighbouring rays meet a particle at the same position of their
+                // sequences more often than not) go out together: the kernel is bound by the atomic words it sends
+                unsigned long long same = __ballot(contributes && id == pid);
+                m &= ~same;
+                float v = 0.f;
+                while (same) {
+                    const int s2 = __ffsll((long long)same) - 1;
+                    same &= same - 1;
+                    v = fmaf(s_terms[s2 * kTermStride + term_word], sh_lane ? s_basis[s2 * kBasisStride + basis_word] : 1.f, v);
+                }
                 if (word_used && v != 0.f) atomicAdd(row_base + (size_t)pid * row_stride, v);
             }
             __syncthreads();
