@@ -182,6 +182,23 @@ def gut_forward_nht(cfg, cam, pose_start, pose_end, density12, features, ray_o, 
     return dict(feat_density=fd, hit_distance=dist, hit_count=cnt, sorted_idx=bins["sorted_idx"], tile_ranges=bins["tile_ranges"], proj=proj)
 
 
+def gut_backward_nht(cfg, cam, pose_start, pose_end, density12, features, ray_o, ray_d, fwd, g_feat_density, g_hit_distance=None, nht=None, dtype=np.float32):
+    """Gradients of the nht forward (K = 0): (grad_density12 [N,12], grad_features [N,K])."""
+    nht = dict(NHT_DEFAULT, **(nht or {}))
+    l = lib(dtype)
+    H, W = cam.height, cam.width
+    n = len(density12)
+    prm = np.array([nht["particle_feature_dim"], nht["interp_point_dim"], nht["support"], nht["activation"], nht["num_frequencies"]], np.int32)
+    gd, gf = np.zeros((n, 12), dtype), np.zeros((n, nht["particle_feature_dim"]), dtype)
+    gdist = np.zeros((H, W, 1), dtype) if g_hit_distance is None else _c(g_hit_distance, dtype)
+    ro, rd = _c(ray_o, dtype).reshape(H, W, 3), _c(ray_d, dtype).reshape(H, W, 3)
+    rc = l.orc_gut_render_nht_bwd(C.byref(cfg), _p(prm), W, H, _p(_c(pose_start, dtype)), _p(_c(pose_end, dtype)), _p(_c(density12, dtype)),
+                                  _p(_c(features, dtype)), _p(fwd["sorted_idx"]), _p(fwd["tile_ranges"]), _p(ro), _p(rd),
+                                  _p(_c(fwd["feat_density"], dtype)), _p(_c(g_feat_density, dtype)), _p(_c(fwd["hit_distance"], dtype)), _p(gdist), _p(gd), _p(gf))
+    assert rc == 0
+    return gd, gf
+
+
 def gut_backward(cfg, cam, n_active, fwd, g_feat_density, g_hit_distance, dtype=np.float32):
     """Reference backward (SplatRaster::trace_bwd): returns (grad_density12 [N,12], grad_sph [N,3*ncoef])."""
     l = lib(dtype)

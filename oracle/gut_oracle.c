@@ -868,6 +868,184 @@ int orc_gut_render_nht_fwd(const GutConfig* cfg, const int* nht, int width, int 
     return 0;
 }
 
+static size_t list_particle_bound(int width, int height, const uint32_t* sorted_idx, const uint32_t* tile_ranges);
+/* --------------------------------------------------------------------------------------
+ * render backward with neural harmonic features (K = 0): evalBackwardNoKBuffer's PerRayParticleFeatures branch
+ * (gutKBufferRenderer.cuh:546-641): per hit featuresIntegrateBwdToLocalGrad (Slang reverse mode of integrateFeaturesFromBuffer<true>,
+ * neuralHarmonicFeaturesParticle.slang:198-228, 277-320: the ray state is un-blended front to back like in the K > 0 path) and
+ * densityProcessHitBwdToBuffer with the gradient of the canonical intersection (gaussianParticles.slang:420-479).  Those are autodiff
+ * products that are not in the checkout: like process_hit_bwd_k this is the reverse mode of the restated forward, checked against
+ * float64 torch.autograd of that forward (tests/golden/autograd_gut_nht.npz, make_autograd_golden.py --nht).
+ * fd [H,W,nr+1] = forward results, g_fd their upstream gradients; g_density12 [N,12] and g_features [N,K] are ADDED to. */
+int orc_gut_render_nht_bwd(const GutConfig* cfg, const int* nht, int width, int height, const real* pose_start7, const real* pose_end7,
+                           const real* density12, const real* features, const uint32_t* sorted_idx, const uint32_t* tile_ranges,
+                           const real* ray_o, const real* ray_d, const real* fd, const real* g_fd, const real* dist, const real* g_dist,
+                           real* g_density12, real* g_features) {
+    const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
+    const int gx = tile_grid_dim(width);
+    const int nr = nht_ray_dim(nht), K = nht[0], ipd = nht[1], act = nht[3], nf = nht[4];
+    const int points = nht[2] == 1 ? 4 : 1;
+    if (cfg->k_buffer_size != 0 || nr > ORC_NHT_MAX_RAY_DIM || ipd > ORC_NHT_MAX_RAY_DIM) return -1;
+    const size_t n_acc = list_particle_bound(width, height, sorted_idx, tile_ranges);
+    double* acc_d = (double*)calloc(n_acc * 12 + 1, sizeof(double));
+    double* acc_f = (double*)calloc(n_acc * (size_t)K + 1, sizeof(double));
+    if (!acc_d || !acc_f) { free(acc_d); free(acc_f); return -2; }
+    /* canonical tetrahedron: gradients of the barycentric weights (constant vectors) */
+    const real edge = R_(4.898979485566356), face_h = R_(4.242640687119285), face_in = R_(1.4142135623730951);
+    const v3 v0 = v3_make(R_(0.5) * edge, -face_in, R_(-1.0)), v1 = v3_make(R_(-0.5) * edge, -face_in, R_(-1.0));
+    const v3 v2 = v3_make(0, face_h - face_in, R_(-1.0)), v3_ = v3_make(0, 0, R_(3.0));
+    const v3 e1 = v3_sub(v1, v0), e2 = v3_sub(v2, v0), e3 = v3_sub(v3_, v0);
+    const v3 c23 = v3_cross(e2, e3);
+    const real inv_det = 1 / v3_dot(e1, c23);
+    v3 gw[4];
+    gw[1] = v3_scale(c23, inv_det); gw[2] = v3_scale(v3_cross(e3, e1), inv_det); gw[3] = v3_scale(v3_cross(e1, e2), inv_det);
+    gw[0] = v3_scale(v3_add(v3_add(gw[1], gw[2]), gw[3]), -1);
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int pix = 0; pix < width * height; ++pix) {
+        const int x = pix % width, y = pix / width;
+        const orc_ray ray = init_ray(&fp, ray_o + 3 * (size_t)pix, ray_d + 3 * (size_t)pix);
+        if (!ray.valid) continue;
+        const uint32_t tile = (uint32_t)((y / ORC_TILE) * gx + (x / ORC_TILE));
+        const uint32_t beg = tile_ranges[2 * tile], end = tile_ranges[2 * tile + 1];
+        real Cb[ORC_NHT_MAX_RAY_DIM], gC[ORC_NHT_MAX_RAY_DIM];
+        const real* f_in = fd + (size_t)(nr + 1) * pix;
+        const real* g_in = g_fd + (size_t)(nr + 1) * pix;
+        for (int i = 0; i < nr; ++i) { Cb[i] = f_in[i]; gC[i] = g_in[i]; }
+        real Tb = 1 - f_in[nr], gT = -g_in[nr], Db = dist[pix], gD = g_dist ? g_dist[pix] : 0;
+        real T = 1; int alive = 1;
+        for (uint32_t e = beg; e < end && alive; ++e) {
+            const uint32_t idx = sorted_idx[e];
+            if (idx == ORC_INVALID_IDX) break;
+            const orc_particle p = load_particle(density12 + 12 * (size_t)idx);
+            const v3 gscl = p.scl;
+            const v3 giscl = v3_make(1 / gscl.x, 1 / gscl.y, 1 / gscl.z);
+            const v3 gposc = v3_sub(ray.o, p.pos);
+            const v3 gposcr = v3_mul_rows(gposc, &p.rotT);
+            const v3 gro = v3_mul(giscl, gposcr);
+            const v3 rdr = v3_mul_rows(ray.d, &p.rotT);
+            const v3 grdu = v3_mul(giscl, rdr);
+            const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
+            const v3 gcrod = v3_cross(grd, gro);
+            const real gray = v3_dot(gcrod, gcrod);
+            const real gres = particle_response(cfg->particle_kernel_degree, gray);
+            const real alpha = r_min((real)cfg->particle_kernel_max_alpha, gres * p.density);
+            if (!((gres > (real)cfg->particle_kernel_min_response) && (alpha > (real)cfg->particle_kernel_min_alpha))) continue;
+            const real pdot = v3_dot(grd, v3_scale(gro, -1));
+            const v3 grdd = v3_scale(grd, pdot);
+            const v3 P = v3_add(gro, grdd);
+            const v3 grds = v3_mul(gscl, grdd);
+            const real gsq = v3_dot(grds, grds);
+            const real hitT = r_sqrt(gsq);
+            if (!(hitT > ray.tmin && hitT < ray.tmax)) continue;
+            /* ---- the hit's features and the reverse of their integration (lerp form, un-blending front to back) ---- */
+            const real* row = features + (size_t)K * idx;
+            real wq[4] = {1, 0, 0, 0};
+            if (points == 4) {
+                const v3 d = v3_sub(P, v0);
+                wq[1] = v3_dot(d, c23) * inv_det; wq[2] = v3_dot(e1, v3_cross(d, e3)) * inv_det; wq[3] = v3_dot(e1, v3_cross(e2, d)) * inv_det;
+                wq[0] = 1 - wq[1] - wq[2] - wq[3];
+            }
+            real base[ORC_NHT_MAX_RAY_DIM], f[ORC_NHT_MAX_RAY_DIM], gf[ORC_NHT_MAX_RAY_DIM], gbase[ORC_NHT_MAX_RAY_DIM];
+            for (int n = 0; n < ipd; ++n) {
+                base[n] = row[n] * wq[0];
+                for (int k = 1; k < points; ++k) base[n] += wq[k] * row[k * ipd + n];
+            }
+            nht_features_at(nht, row, P, f);
+            const real w = 1 / (1 - alpha);
+            real dalpha = 0;
+            if (alpha > 0) {   /* (particleFeaturesIntegrateBwdToBuffer: if (alpha > 0)) */
+                for (int i = 0; i < nr; ++i) {
+                    Cb[i] = (Cb[i] - f[i] * alpha) * w;
+                    dalpha += (f[i] - Cb[i]) * gC[i];
+                    gf[i] = alpha * gC[i];
+                    gC[i] *= (1 - alpha);
+                }
+            } else {
+                for (int i = 0; i < nr; ++i) gf[i] = 0;
+            }
+            /* activation backward */
+            for (int n = 0; n < ipd; ++n) gbase[n] = 0;
+            if (act == 0) { for (int i = 0; i < ipd; ++i) gbase[i] = gf[i]; }
+            else if (act == 3) { for (int i = 0; i < ipd; ++i) gbase[i] = base[i] > 0 ? gf[i] : 0; }
+            else if (act == 2) {
+                for (int k = 0; k < ipd; ++k)
+                    for (int q = 0; q < nf; ++q) {
+                        const real fr = (real)(q + 1), ang = base[k] * fr;
+                        gbase[k] += fr * (r_cos(ang) * gf[k * nf * 2 + q * 2] - r_sin(ang) * gf[k * nf * 2 + q * 2 + 1]);
+                    }
+            } else {
+                for (int k = 0; k < ipd; ++k)
+                    for (int q = 0; q < nf; ++q) {
+                        const real fr = (real)ldexp(1.0, q);
+                        gbase[k] += fr * r_cos(base[k] * fr) * gf[k * nf + q];
+                    }
+            }
+            /* blend backward: feature rows and the canonical position */
+            v3 dP = v3_make(0, 0, 0);
+            for (int k = 0; k < points; ++k) {
+                real dwk = 0;
+                for (int n = 0; n < ipd; ++n) {
+                    const real g = wq[k] * gbase[n];
+                    if (g != 0) {
+#pragma omp atomic
+                        acc_f[(size_t)K * idx + k * ipd + n] += (double)g;
+                    }
+                    dwk += row[k * ipd + n] * gbase[n];
+                }
+                if (points == 4) dP = v3_add(dP, v3_scale(gw[k], dwk));
+            }
+            /* ---- density: T_out = T_in (1 - alpha), D_front = lerp(D_behind, depth, alpha) (as process_hit_bwd_k) ---- */
+            Tb *= w;
+            Db = (Db - hitT * alpha) * w;
+            dalpha += (hitT - Db) * gD - Tb * gT;
+            const real ddepth = alpha * gD;
+            gD *= (1 - alpha);
+            gT *= (1 - alpha);
+            real gd[12];
+            for (int k = 0; k < 12; ++k) gd[k] = 0;
+            real dres = 0, ddens = 0;
+            if (gres * p.density < (real)cfg->particle_kernel_max_alpha) { dres = p.density * dalpha; ddens = gres * dalpha; }
+            gd[3] = ddens;
+            const real grayGrd = particle_response_grd(cfg->particle_kernel_degree, gray, gres, dres);
+            const v3 grdsGrd = gsq > 0 ? v3_scale(grds, ddepth / hitT) : v3_make(0, 0, 0);
+            const v3 gsclHit = v3_mul(grdd, grdsGrd);
+            const real sdot = v3_dot(v3_mul(grdsGrd, gscl), grd);
+            v3 grdHit = v3_sub(v3_scale(v3_mul(gscl, grdsGrd), pdot), v3_scale(gro, sdot));
+            v3 groHit = v3_scale(grd, -sdot);
+            /* canonical intersection P = gro + grd (grd . -gro) */
+            const real gdP = v3_dot(grd, dP);
+            groHit = v3_add(groHit, v3_sub(dP, v3_scale(grd, gdP)));
+            grdHit = v3_add(grdHit, v3_sub(v3_scale(dP, pdot), v3_scale(gro, gdP)));
+            const v3 gcrodGrd = v3_scale(gcrod, 2 * grayGrd);
+            const v3 grdGrd = v3_make(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
+            const v3 groGrd = v3_make(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+            const v3 groTot = v3_add(groGrd, groHit);
+            const v3 gsclGro = v3_mul(v3_make(-gposcr.x / (gscl.x * gscl.x), -gposcr.y / (gscl.y * gscl.y), -gposcr.z / (gscl.z * gscl.z)), groTot);
+            const v3 gposcrGrd = v3_mul(giscl, groTot);
+            const v3 gposcGrd = matmul_bw_vec(&p.rotT, gposcrGrd);
+            const v4 gq1 = matmul_bw_quat(gposc, gposcrGrd, p.quat);
+            gd[0] = -gposcGrd.x; gd[1] = -gposcGrd.y; gd[2] = -gposcGrd.z;
+            const v3 grduGrd = v3_safe_normalize_bw(grdu, v3_add(grdGrd, grdHit));
+            const v3 sclGrd = v3_add(v3_add(gsclHit, gsclGro),
+                                     v3_mul(v3_make(-rdr.x / (gscl.x * gscl.x), -rdr.y / (gscl.y * gscl.y), -rdr.z / (gscl.z * gscl.z)), grduGrd));
+            gd[8] = sclGrd.x; gd[9] = sclGrd.y; gd[10] = sclGrd.z;
+            const v4 gq2 = matmul_bw_quat(ray.d, v3_mul(giscl, grduGrd), p.quat);
+            gd[4] = gq1.x + gq2.x; gd[5] = gq1.y + gq2.y; gd[6] = gq1.z + gq2.z; gd[7] = gq1.w + gq2.w;
+            for (int k = 0; k < 11; ++k)
+                if (gd[k] != 0) {
+#pragma omp atomic
+                    acc_d[12 * (size_t)idx + k] += (double)gd[k];
+                }
+            T *= (1 - alpha);
+            if (T < (real)cfg->min_transmittance) alive = 0;
+        }
+    }
+    for (size_t k = 0; k < n_acc * 12; ++k) g_density12[k] += (real)acc_d[k];
+    for (size_t k = 0; k < n_acc * (size_t)K; ++k) g_features[k] += (real)acc_f[k];
+    free(acc_d); free(acc_f);
+    return 0;
+}
+
 /* Analysis aid (scripts/slab_analysis.py): per pixel, how many entries of its tile list the K = 0 forward loop examines
  * before the ray ends (the whole list if it never does).  Same loop as orc_gut_render_fwd. */
 int orc_gut_render_fwd_consumed(const GutConfig* cfg, int width, int height, const real* pose_start7, const real* pose_end7,

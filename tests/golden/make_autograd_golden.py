@@ -146,6 +146,96 @@ def render(K, d12, coeffs, cam_pos, lists, ranges, rays_o, rays_d, W, H):
     return torch.stack(fd_rows), torch.stack(dist_rows), rgb
 
 
+# ---- neural harmonic features (model.feature_type = nht): the K = 0 backward with per-ray features is Slang autodiff output too -----------
+#   * canonical intersection             .../slang/models/gaussianParticles.slang:181-190 (gro + grd (grd . -gro))
+#   * barycentric weights, blend, sincos  .../slang/models/neuralHarmonicFeaturesParticle.slang:47-66, :117-127, :146-196
+#   * integration                         :198-211 (+= features * weight), processHitParticle gutKBufferRenderer.cuh:199-225
+SQ6, SQ2 = 24.0 ** 0.5 / 2, 2.0 ** 0.5
+TET = torch.tensor([[SQ6, -SQ2, -1.0], [-SQ6, -SQ2, -1.0], [0.0, 24.0 ** 0.5 * 3 ** 0.5 / 2 - SQ2, -1.0], [0.0, 0.0, 3.0]])
+
+
+def nht_features(feat_rows, P, ipd=12, nf=1):
+    """feat_rows [48] of one particle, canonical position P [3] -> [ipd * nf * 2] sincos features."""
+    e1, e2, e3 = TET[1] - TET[0], TET[2] - TET[0], TET[3] - TET[0]
+    c23 = torch.linalg.cross(e2, e3)
+    inv_det = 1.0 / (e1 * c23).sum()
+    d = P - TET[0]
+    w1 = (d * c23).sum() * inv_det
+    w2 = (e1 * torch.linalg.cross(d, e3)).sum() * inv_det
+    w3 = (e1 * torch.linalg.cross(e2, d)).sum() * inv_det
+    w0 = 1.0 - w1 - w2 - w3
+    F = feat_rows.reshape(4, ipd)
+    base = F[0] * w0 + F[1] * w1 + F[2] * w2 + F[3] * w3
+    out = []
+    for f in range(nf):
+        ang = base * (f + 1)
+        out.append(torch.stack([torch.sin(ang), torch.cos(ang)], -1))           # [ipd, 2]
+    return torch.stack(out, 1).reshape(-1)                                       # index k*nf*2 + f*2 + {0,1}
+
+
+def render_nht(d12, feats, lists, ranges, rays_o, rays_d, W, H, nr=24):
+    pos, density, quat, scale = d12[:, 0:3], d12[:, 3], d12[:, 4:8], d12[:, 8:11]
+    gx = (W + 15) // 16
+    fd_rows, dist_rows = [], []
+    for y in range(H):
+        fd_row, dist_row = [], []
+        for x in range(W):
+            tile = (y // 16) * gx + (x // 16)
+            idx = torch.as_tensor(lists[ranges[tile, 0]:ranges[tile, 1]].astype(np.int64))
+            T, C, D = torch.ones(()), torch.zeros(nr), torch.zeros(())
+            if idx.numel():
+                rot_t = rotation_transpose(quat[idx])
+                giscl = 1.0 / scale[idx]
+                gro = giscl * torch.einsum("eij,ej->ei", rot_t, rays_o[y, x][None, :] - pos[idx])
+                grdu = giscl * torch.einsum("eij,j->ei", rot_t, rays_d[y, x])
+                grd = grdu / grdu.norm(dim=1, keepdim=True)
+                gcrod = torch.cross(grd, gro, dim=1)
+                resp = torch.exp(-0.5 * (gcrod * gcrod).sum(1))
+                alpha = torch.clamp(resp * density[idx], max=MAX_ALPHA)
+                accept = (resp > MIN_RESPONSE) & (alpha > MIN_ALPHA)
+                cg = grd * (grd * (-gro)).sum(1, keepdim=True)
+                Pc = gro + cg
+                grds = scale[idx] * cg
+                hit_t = (grds * grds).sum(1).clamp_min(1e-300).sqrt()
+                for e in [int(e) for e in torch.nonzero(accept & (hit_t > 0)).flatten()]:
+                    w = alpha[e] * T
+                    D = D + hit_t[e] * w
+                    T = T * (1 - alpha[e])
+                    if float(w) > 0:
+                        C = C + nht_features(feats[idx[e]], Pc[e]) * w
+                    if float(T) < MIN_T:
+                        break
+            fd_row.append(torch.cat([C, (1 - T).reshape(1)]))
+            dist_row.append(D)
+        fd_rows.append(torch.stack(fd_row))
+        dist_rows.append(torch.stack(dist_row))
+    return torch.stack(fd_rows), torch.stack(dist_rows)
+
+
+def case_nht(with_depth_grad, n=260, w=32, h=24, seed=5):
+    scene = make_scene(n=n, width=w, height=h, median_scale=0.16, seed=seed)
+    cfg = oracle.default_gut_config()
+    feats_np = np.random.default_rng(91).uniform(-np.pi / 2, np.pi / 2, size=(n, 48))
+    fwd = oracle.gut_forward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats_np, *scene["rays"], dtype=np.float64)
+    T = scene["batch"]["T_to_world"][0].astype(np.float64)
+    ro, rd = scene["rays"]
+    rays_o = torch.as_tensor(ro[0].astype(np.float64) @ T[:3, :3].T + T[:3, 3])
+    rays_d = torch.as_tensor(rd[0].astype(np.float64) @ T[:3, :3].T)
+    d12 = torch.as_tensor(scene["density12"].astype(np.float64)).requires_grad_(True)
+    feats = torch.as_tensor(feats_np).requires_grad_(True)
+    fd, dist = render_nht(d12, feats, fwd["sorted_idx"], fwd["tile_ranges"].astype(np.int64), rays_o, rays_d, w, h)
+    e_img = np.abs(fd.detach().numpy() - fwd["feat_density"]).max()
+    e_dist = np.abs(dist.detach().numpy() - fwd["hit_distance"][..., 0]).max()
+    assert e_img < 1e-6 and e_dist < 1e-6, (e_img, e_dist)
+    rng = np.random.default_rng(23)
+    g_fd = rng.normal(size=(h, w, 25))
+    g_dist = rng.normal(size=(h, w)) * (0.1 if with_depth_grad else 0.0)
+    ((fd * torch.as_tensor(g_fd)).sum() + (dist * torch.as_tensor(g_dist)).sum()).backward()
+    print(f"nht depth_grad={with_depth_grad}: forward agrees to {e_img:.1e} / {e_dist:.1e}; hits per pixel mean {fwd['hit_count'].mean():.1f}")
+    return dict(density12=scene["density12"], features=feats_np.astype(np.float32), g_fd=g_fd.astype(np.float32), g_dist=g_dist.astype(np.float32)[..., None],
+                grad_density12=d12.grad.numpy().copy(), grad_features=feats.grad.numpy().copy(), n=n, w=w, h=h, seed=seed)
+
+
 def case(K, with_depth_grad, n=260, w=32, h=24, seed=5):
     scene = make_scene(n=n, width=w, height=h, median_scale=0.16, seed=seed)
     cfg = oracle.default_gut_config(k_buffer_size=K)
@@ -177,6 +267,14 @@ def case(K, with_depth_grad, n=260, w=32, h=24, seed=5):
 
 
 if __name__ == "__main__":
+    if "--nht" in sys.argv:
+        out = {}
+        for name, dg in (("nht", False), ("nht_depth", True)):
+            for k, v in case_nht(dg).items():
+                out[f"{name}_{k}"] = v
+        np.savez_compressed(os.path.join(HERE, "autograd_gut_nht.npz"), **out)
+        print("wrote tests/golden/autograd_gut_nht.npz")
+        sys.exit(0)
     out = {}
     for name, K, dg in (("k0", 0, False), ("k4", 4, False), ("k16", 16, False), ("k16_depth", 16, True)):
         for k, v in case(K, dg).items():

@@ -664,3 +664,24 @@ def test_nht_forward_matches_reference_kernels_golden(k):
     full = oracle.gut_forward_nht(cfg, sc["cam"], sc["pose_start"], sc["pose_end"], sc["density12"], feats, *sc["rays"])
     assert np.array_equal(full["sorted_idx"], g[f"s{k}_sorted_idx"])
     assert np.abs(full["feat_density"] - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("name", ["nht", "nht_depth"])
+def test_nht_backward_matches_autograd_of_the_restated_reference_forward(name):
+    """The nht backward is Slang autodiff output in the reference (not in the checkout): the oracle's reverse mode against float64
+    torch.autograd of the restated forward (tests/golden/make_autograd_golden.py --nht), gradients w.r.t. the particle rows and the
+    per-particle feature buffer, with and without a hit-distance gradient."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "autograd_gut_nht.npz"))
+    n, w, h, seed = (int(g[f"{name}_{k}"]) for k in ("n", "w", "h", "seed"))
+    scene = make_scene(n=n, width=w, height=h, median_scale=0.16, seed=seed)
+    cfg = oracle.default_gut_config()
+    feats = g[f"{name}_features"]
+    for dtype, tol in ((np.float64, 2e-6), (np.float32, 3e-4)):
+        fwd = oracle.gut_forward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats, *scene["rays"], dtype=dtype)
+        gd, gf = oracle.gut_backward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats, *scene["rays"], fwd,
+                                         g[f"{name}_g_fd"], g[f"{name}_g_dist"], dtype=dtype)
+        ref_d, ref_f = g[f"{name}_grad_density12"], g[f"{name}_grad_features"]
+        for sl in (slice(0, 3), slice(3, 4), slice(4, 8), slice(8, 11)):
+            assert rel_err(gd[:, sl], ref_d[:, sl]) < tol, (dtype, sl, rel_err(gd[:, sl], ref_d[:, sl]))
+        assert rel_err(gf, ref_f) < tol, (dtype, rel_err(gf, ref_f))
+        assert np.abs(ref_f).max() > 0 and np.abs(ref_d[:, :3]).max() > 0
