@@ -482,10 +482,6 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
         return GRUT_ERR_NOT_READY;
     }
     const GutParams& P = h->params;
-    if (P.nht) {
-        set_last_error("gut_backward: the neural-harmonic-features configuration is forward only in this version");
-        return GRUT_ERR_UNSUPPORTED;
-    }
     GRUT_REQUIRE(frame->num_particles == P.N && frame->width == P.W && frame->height == P.H, "gut_backward: frame differs from the forward frame");
     if (frame->frame_id != h->fwd_frame_id || (P.N > 0 && (particle_density != h->fwd_density || ray_origin != h->fwd_ray_o || ray_direction != h->fwd_ray_d))) {
         set_last_error("gut_backward: the forward context belongs to another forward (a later gut_forward ran on this handle before this "
@@ -493,6 +489,25 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
         return GRUT_ERR_NOT_READY;
     }
     if (P.N == 0) return GRUT_OK;
+    if (P.nht) {
+        // neural harmonic features: grad_particle_density [N,12] and grad_particle_sph = the feature buffer's gradient [N, particle_feature_dim],
+        // both fp32 and fully written here (zero-filled, then accumulated per (wave, entry)); grad_feat_density is [H,W,ray_dim+1]
+        if (io || grad_radiance) {
+            set_last_error("gut_backward: with neural harmonic features only gut_backward (packed gradients) is provided");
+            return GRUT_ERR_UNSUPPORTED;
+        }
+        GRUT_REQUIRE(particle_density && particle_sph && feat_density && grad_feat_density && hit_distance && grad_particle_density && grad_particle_sph,
+                     "gut_backward: null buffer");
+        if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
+        GRUT_HIP(hipMemsetAsync(grad_particle_density, 0, (size_t)P.N * 48, s));
+        GRUT_HIP(hipMemsetAsync(grad_particle_sph, 0, (size_t)P.N * P.nht_k * 4, s));
+        if (h->num_intersections > 0)
+            launch_render_nht_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_pos, h->pos_particle.as<uint32_t>(), particle_density, particle_sph, ray_origin,
+                                  ray_direction, feat_density, grad_feat_density, hit_distance, grad_hit_distance, grad_particle_density, grad_particle_sph);
+        GRUT_HIP(hipGetLastError());
+        if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
+        return GRUT_OK;
+    }
     // the gradient tensors in the reference's packed layout, or (io) in the caller's own: see GutGradIO
     const GutGradIn g_in = io ? GutGradIn{nullptr, io->grad_features, io->grad_opacity} : GutGradIn{grad_feat_density, nullptr, nullptr};
     const GutGradOut g_out = io ? GutGradOut{nullptr, io->grad_positions, io->grad_density, io->grad_rotation, io->grad_scale}

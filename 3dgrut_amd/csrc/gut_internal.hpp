@@ -125,6 +125,9 @@ void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
 void launch_render_nht_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                            const float* density12, const float* features, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                            float* out_cnt);
+void launch_render_nht_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                           const float* density12, const float* features, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd,
+                           const float* dist, const float* g_dist, float* g_density12, float* g_features);
 void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                          float* out_cnt);

@@ -1340,6 +1340,222 @@ __global__ __launch_bounds__(64) void gut_render_nht_fwd_kernel(GutParams P, con
     }
 }
 
+// Neural harmonic features, backward (evalBackwardNoKBuffer's per-ray-features branch, gutKBufferRenderer.cuh:546-641): the forward's
+// sweep again, front to back, un-blending the ray state hit by hit (the reverse mode of the lerp form, like the sorted mode's backward);
+// per hit and pixel the gradient of the ray features flows through the activation and the barycentric blend into (i) the particle's
+// feature rows, (ii) the canonical intersection and from there, with dL/d alpha and dL/d depth, into the particle's 11 geometric terms
+// (restated and checked against float64 autograd in the oracle: orc_gut_render_nht_bwd).  All 64 pixels of the strip meet a list entry
+// at the same time, so the wave sums each of the entry's words over its lanes (DPP reduce-scatter, 16 words at a time) before ONE set
+// of atomics per (wave, entry) — the reference does the same with warp shuffles (shRadiativeGaussianParticles.cuh:421-441).
+// First version: no checkpoints (every wave sweeps its tile's list from the start), correctness first.
+__global__ __launch_bounds__(64) void gut_render_nht_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+                                                                const float4* __restrict__ density12, const float* __restrict__ features,
+                                                                const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                                const float* __restrict__ fd, const float* __restrict__ g_fd,
+                                                                const float* __restrict__ dist, const float* __restrict__ g_dist,
+                                                                float* __restrict__ g_density12, float* __restrict__ g_features) {
+    __shared__ float4 s_rec[64 * 5];
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t tile = ((slot >> 2) << 3) + xcd, strip = slot & 3u;
+    if (tile >= (uint32_t)(P.gx * P.gy)) return;
+    const int lane = threadIdx.x;
+    const int px = (int)(tile % P.gx) * 16 + (lane & 15);
+    const int py = (int)(tile / P.gx) * 16 + (int)strip * 4 + (lane >> 4);
+    const Ray ray = init_ray(P, ray_o, ray_d, px, py);
+    bool alive = ray.valid;
+    const int ipd = P.nht_ipd, nf = P.nht_nf, nr = P.nht_ray_dim;
+    const int points = P.nht_support == 1 ? 4 : 1;
+    const size_t pix = ray.valid ? (size_t)py * P.W + px : 0;
+    float Cb[kNhtMaxRay], gC[kNhtMaxRay];
+#pragma unroll
+    for (int i = 0; i < kNhtMaxRay; ++i) {
+        const bool use = alive && i < nr;
+        Cb[i] = use ? (P.out_half ? __half2float(reinterpret_cast<const __half*>(fd)[pix * (nr + 1) + i]) : fd[pix * (nr + 1) + i]) : 0.f;
+        gC[i] = use ? g_fd[pix * (nr + 1) + i] : 0.f;
+    }
+    float Tb = 1.f, gT = 0.f, Db = 0.f, gD = 0.f, T = 1.f;
+    if (alive) {
+        const float op = P.out_half ? __half2float(reinterpret_cast<const __half*>(fd)[pix * (nr + 1) + nr]) : fd[pix * (nr + 1) + nr];
+        Tb = 1.f - op; gT = -g_fd[pix * (nr + 1) + nr];
+        Db = dist[pix]; gD = g_dist ? g_dist[pix] : 0.f;
+    }
+    const float edge = 4.898979485566356f, face_h = 4.242640687119285f, face_in = 1.4142135623730951f;
+    const f3 v0 = mk3(0.5f * edge, -face_in, -1.f), v1 = mk3(-0.5f * edge, -face_in, -1.f), v2 = mk3(0.f, face_h - face_in, -1.f), v3 = mk3(0.f, 0.f, 3.f);
+    const f3 e1 = v1 - v0, e2 = v2 - v0, e3 = v3 - v0;
+    const f3 c23 = cross(e2, e3);
+    const float inv_det = 1.f / dot(e1, c23);
+    const f3 gw1 = c23 * inv_det, gw2 = cross(e3, e1) * inv_det, gw3 = cross(e1, e2) * inv_det;
+    const f3 gw0 = (gw1 + gw2 + gw3) * -1.f;
+    const uint2 range = ranges[tile];
+    for (uint32_t b = range.x; b < range.y; b += 64) {
+        if (!__any(alive)) break;
+        {
+            const RawEntry e = load_entry<false>(b + lane, range.y, lists, density12, nullptr);
+            float4 r0 = make_float4(1.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 1.f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
+            float4 r3 = make_float4(1.f, 1.f, 1.f, 0.f), r4 = make_float4(__uint_as_float(0xFFFFFFFFu), 0.f, 0.f, 0.f);
+            if (e.idx != 0xFFFFFFFFu) {   // raw rows: the gradient chain needs the quaternion and the scale themselves
+                r0 = e.a; r1 = e.q; r2 = make_float4(e.s.x, e.s.y, e.s.z, 0.f);
+                r4.x = __uint_as_float(e.idx);
+                const float need = fmaxf(P.min_response, P.min_alpha / e.a.w);
+                r4.y = (P.max_alpha > P.min_alpha && e.a.w > 0.f) ? gray_limit_rt(P.degree, need) : 0.f;
+            }
+            float4* rec = &s_rec[lane * 5];
+            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4;
+        }
+        __syncthreads();
+        const int n = (int)min(64u, range.y - b);
+        for (int j = 0; j < n; ++j) {
+            if (!__any(alive)) break;
+            const float4* rec = &s_rec[j * 5];
+            const uint32_t idx = __float_as_uint(rec[4].x);
+            if (idx == 0xFFFFFFFFu) break;
+            const float4 a = rec[0], q = rec[1], sc = rec[2];
+            bool hit = false;
+            float gd[16], gbase[kNhtMaxIpd], wq[4] = {1.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) gd[k] = 0.f;
+#pragma unroll
+            for (int m = 0; m < kNhtMaxIpd; ++m) gbase[m] = 0.f;
+            if (alive) {
+                const m3 rotT = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
+                const f3 gscl = mk3(sc.x, sc.y, sc.z), giscl = mk3(1.f / sc.x, 1.f / sc.y, 1.f / sc.z);
+                const f3 gposc = ray.o - mk3(a.x, a.y, a.z);
+                const f3 gposcr = mul_rows(rotT, gposc);
+                const f3 gro = giscl * gposcr;
+                const f3 rdr = mul_rows(rotT, ray.d);
+                const f3 grdu = giscl * rdr;
+                const float l2 = dot(grdu, grdu);
+                const float il = 1.f / sqrtf(l2);
+                const f3 grd = grdu * il;
+                const f3 gcrod = cross(grd, gro);
+                const float gray = dot(gcrod, gcrod);
+                if (gray < rec[4].y) {
+                    const float gres = response_rt(P.degree, gray);
+                    const float alpha = fminf(P.max_alpha, gres * a.w);
+                    const float pdot = -dot(grd, gro);
+                    const f3 grdd = grd * pdot;
+                    const f3 Pc = gro + grdd;
+                    const f3 grds = gscl * grdd;
+                    const float gsq = dot(grds, grds);
+                    const float hitT = sqrtf(gsq);
+                    if ((hitT > ray.tmin) && (hitT < ray.tmax)) {
+                        hit = alpha > 0.f;
+                        if (P.nht_support == 1) {
+                            const f3 d = Pc - v0;
+                            wq[1] = dot(d, c23) * inv_det; wq[2] = dot(e1, cross(d, e3)) * inv_det; wq[3] = dot(e1, cross(e2, d)) * inv_det;
+                            wq[0] = 1.f - wq[1] - wq[2] - wq[3];
+                        }
+                        float base[kNhtMaxIpd];
+#pragma unroll
+                        for (int m = 0; m < kNhtMaxIpd; ++m) {
+                            base[m] = 0.f;
+                            if (m < ipd)
+                                for (int k = 0; k < points; ++k) {
+                                    const size_t at = (size_t)idx * P.nht_k + (size_t)k * ipd + m;
+                                    const float fv = P.sph_half ? __half2float(reinterpret_cast<const __half*>(features)[at]) : features[at];
+                                    base[m] = k == 0 ? fv * wq[0] : fmaf(wq[k], fv, base[m]);
+                                }
+                        }
+                        const float w = 1.f / (1.f - alpha);
+                        float dalpha = 0.f;
+#pragma unroll
+                        for (int i = 0; i < kNhtMaxRay; ++i) {
+                            if (i < nr) {
+                                // feature i and d feature i / d base (sincos: index k*nf*2 + f*2 + {0,1}; siren: k*nf + f)
+                                float f, df;
+                                int kb;
+                                if (P.nht_act == 0) { kb = i; f = base[kb < kNhtMaxIpd ? kb : 0]; df = 1.f; }
+                                else if (P.nht_act == 3) { kb = i; const float bv = base[kb < kNhtMaxIpd ? kb : 0]; f = fmaxf(0.f, bv); df = bv > 0.f ? 1.f : 0.f; }
+                                else if (P.nht_act == 2) {
+                                    kb = i / (2 * nf);
+                                    const int rem = i - kb * 2 * nf, fq = rem >> 1;
+                                    const float fr = (float)(fq + 1), ang = base[kb < kNhtMaxIpd ? kb : 0] * fr;
+                                    const float sn = sinf(ang), cs = cosf(ang);
+                                    f = (rem & 1) ? cs : sn; df = (rem & 1) ? -fr * sn : fr * cs;
+                                } else {
+                                    kb = i / nf;
+                                    const float fr = ldexpf(1.f, i - kb * nf), ang = base[kb < kNhtMaxIpd ? kb : 0] * fr;
+                                    f = sinf(ang); df = fr * cosf(ang);
+                                }
+                                if (hit) {
+                                    Cb[i] = (Cb[i] - f * alpha) * w;
+                                    dalpha = fmaf(f - Cb[i], gC[i], dalpha);
+                                    const float gf = alpha * gC[i];
+                                    gC[i] *= (1.f - alpha);
+#pragma unroll
+                                    for (int m = 0; m < kNhtMaxIpd; ++m)
+                                        if (m == kb) gbase[m] = fmaf(df, gf, gbase[m]);
+                                }
+                            }
+                        }
+                        // blend backward: the canonical position's gradient (the feature rows' gradient is wq[k] * gbase, summed over the wave below)
+                        f3 dP = mk3(0.f, 0.f, 0.f);
+                        if (P.nht_support == 1 && hit) {
+                            float dw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int m = 0; m < kNhtMaxIpd; ++m)
+                                if (m < ipd)
+                                    for (int k = 0; k < 4; ++k) {
+                                        const size_t at = (size_t)idx * P.nht_k + (size_t)k * ipd + m;
+                                        const float fv = P.sph_half ? __half2float(reinterpret_cast<const __half*>(features)[at]) : features[at];
+                                        dw[k] = fmaf(fv, gbase[m], dw[k]);
+                                    }
+                            dP = gw0 * dw[0] + gw1 * dw[1] + gw2 * dw[2] + gw3 * dw[3];
+                        }
+                        // density: T_out = T_in (1 - alpha), D_front = lerp(D_behind, depth, alpha)
+                        Tb *= w;
+                        Db = (Db - hitT * alpha) * w;
+                        dalpha += (hitT - Db) * gD - Tb * gT;
+                        const float ddepth = alpha * gD;
+                        gD *= (1.f - alpha);
+                        gT *= (1.f - alpha);
+                        if (hit) {
+                            float dres = 0.f, ddens = 0.f;
+                            if (gres * a.w < P.max_alpha) { dres = a.w * dalpha; ddens = gres * dalpha; }
+                            const float grayGrd = response_grd_rt(P.degree, gray, gres, dres);
+                            const f3 grdsGrd = gsq > 0.f ? grds * (ddepth / hitT) : mk3(0.f, 0.f, 0.f);
+                            const f3 gsclHit = grdd * grdsGrd;
+                            const float sdot = dot(grdsGrd * gscl, grd);
+                            const float gdP = dot(grd, dP);
+                            const f3 grdHit = gscl * grdsGrd * pdot - gro * sdot + dP * pdot - gro * gdP;
+                            const f3 groHit = grd * (-sdot) + dP - grd * gdP;
+                            const f3 gcrodGrd = gcrod * (2.f * grayGrd);
+                            const f3 grdGrd = mk3(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
+                            const f3 groGrd = mk3(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+                            const f3 groTot = groGrd + groHit;
+                            const f3 is2 = giscl * giscl;
+                            const f3 gsclGro = mk3(-gposcr.x * is2.x, -gposcr.y * is2.y, -gposcr.z * is2.z) * groTot;
+                            const f3 gposcrGrd = giscl * groTot;
+                            const f3 gposcGrd = mul_cols(rotT, gposcrGrd);
+                            const f3 dn = grdGrd + grdHit;
+                            const f3 grduGrd = dn * il - grdu * (il * il * il * dot(dn, grdu));   // normalize backward
+                            const f3 sclGrd = gsclHit + gsclGro + mk3(-rdr.x * is2.x, -rdr.y * is2.y, -rdr.z * is2.z) * grduGrd;
+                            const float4 gq1 = quat_outer_contract(gposcrGrd, gposc, q), gq2 = quat_outer_contract(giscl * grduGrd, ray.d, q);
+                            gd[0] = -gposcGrd.x; gd[1] = -gposcGrd.y; gd[2] = -gposcGrd.z; gd[3] = ddens;
+                            gd[4] = gq1.x + gq2.x; gd[5] = gq1.y + gq2.y; gd[6] = gq1.z + gq2.z; gd[7] = gq1.w + gq2.w;
+                            gd[8] = sclGrd.x; gd[9] = sclGrd.y; gd[10] = sclGrd.z;
+                        }
+                        T *= (1.f - alpha);
+                        if (T < P.min_transmittance) alive = false;
+                    }
+                }
+            }
+            if (!__any(hit)) continue;
+            // one set of atomics per (wave, entry): 11 geometric words, then the feature rows point by point
+            const float tot = wave_reduce_scatter16(gd, lane);
+            if (lane < 11) atomicAdd(g_density12 + 12 * (size_t)idx + lane, tot);
+            for (int k = 0; k < points; ++k) {
+                float gfk[16];
+#pragma unroll
+                for (int m = 0; m < 16; ++m) gfk[m] = (hit && m < ipd) ? wq[k] * gbase[m < kNhtMaxIpd ? m : 0] : 0.f;
+                const float t2 = wave_reduce_scatter16(gfk, lane);
+                if (lane < ipd) atomicAdd(g_features + (size_t)idx * P.nht_k + (size_t)k * ipd + lane, t2);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static uint32_t strip_grid(const GutParams& P) {
     const uint32_t tiles = (uint32_t)(P.gx * P.gy);
     return ((tiles + 7u) & ~7u) * 4u;
@@ -1356,6 +1572,13 @@ void launch_render_nht_fwd(hipStream_t s, const GutParams& P, const uint32_t* ra
     const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
     hipLaunchKernelGGL(gut_render_nht_fwd_kernel, dim3(strip_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
                        reinterpret_cast<const float4*>(density12), features, ray_o, ray_d, out_fd, out_dist, out_cnt);
+}
+void launch_render_nht_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                           const float* density12, const float* features, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd,
+                           const float* dist, const float* g_dist, float* g_density12, float* g_features) {
+    const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
+    hipLaunchKernelGGL(gut_render_nht_bwd_kernel, dim3(strip_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
+                       reinterpret_cast<const float4*>(density12), features, ray_o, ray_d, fd, g_fd, dist, g_dist, g_density12, g_features);
 }
 void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,

@@ -200,7 +200,17 @@ class _GutNative:
             particle_features = particle_features.to(torch.float16)
         _abi.check(self.lib.gut_forward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_features.contiguous()),
                                         _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(dist), _ptr(cnt), _ptr(vis)), "gut_forward")
-        return fd.float(), dist, cnt, vis.view(torch.float32)
+        return fd, dist, cnt, vis.view(torch.float32), particle_features
+
+    def trace_bwd_nht(self, frame, particle_density, particle_features, ray_ori, ray_dir, fd, g_fd, dist, g_dist):
+        """gut_backward of the nht configuration: (packed gradient [N,12], feature-buffer gradient [N,K] fp32), both fully written."""
+        dev = ray_ori.device
+        g_density = torch.empty_like(particle_density)
+        g_feat = torch.empty(particle_features.shape, dtype=torch.float32, device=dev)
+        _abi.check(self.lib.gut_backward(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_features),
+                                         _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(g_fd), _ptr(dist), _ptr(g_dist),
+                                         _ptr(g_density), _ptr(g_feat)), "gut_backward")
+        return g_density, g_feat
 
     def trace_bwd(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_fd, dist, g_dist):
         dev = ray_ori.device
@@ -254,6 +264,34 @@ class _GutNative:
         s = _abi.GutStats()
         _abi.check(self.lib.gut_stats(self.handle, C.byref(s)), "gut_stats")
         return s
+
+
+class _NhtAutograd(torch.autograd.Function):
+    """model.feature_type = nht: the op of threedgut_tracer/tracer.py:166-300 with per-ray features ([H,W,ray_dim] + opacity)."""
+
+    @staticmethod
+    def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_feat):
+        particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)
+        fd, dist, cnt, vis, feats_k = native.trace_nht(frame, particle_density, mog_feat.contiguous(), ray_ori, ray_dir)
+        ctx.save_for_backward(ray_ori, ray_dir, fd, dist, particle_density, feats_k)
+        ctx.native, ctx.frame = native, frame
+        nr = native.ray_feature_dim
+        f32 = fd.float()   # always fp32 to the caller; the (possibly half) image stays in the context for the backward
+        ctx.mark_non_differentiable(cnt, vis)
+        ctx.set_materialize_grads(False)
+        return f32[..., :nr].unsqueeze(0).contiguous(), f32[..., nr:].unsqueeze(0).contiguous(), dist, cnt, vis
+
+    @staticmethod
+    def backward(ctx, g_feat, g_opa, g_dist, _g_cnt, _g_vis):
+        ray_ori, ray_dir, fd, dist, particle_density, feats_k = ctx.saved_tensors
+        H, W, nr = fd.shape[0], fd.shape[1], fd.shape[2] - 1
+        g_feat = fd.new_zeros((H, W, nr), dtype=torch.float32) if g_feat is None else g_feat.reshape(H, W, nr).float()
+        g_opa = fd.new_zeros((H, W, 1), dtype=torch.float32) if g_opa is None else g_opa.reshape(H, W, 1).float()
+        g_fd = torch.cat([g_feat, g_opa], dim=-1).contiguous()
+        g_density, g_features = ctx.native.trace_bwd_nht(ctx.frame, particle_density, feats_k, ray_ori, ray_dir, fd, g_fd, dist,
+                                                         None if g_dist is None else g_dist.contiguous())
+        g_pos, g_dns, g_rot, g_scl = _abi.unpack_particle_grads(g_density)
+        return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_features
 
 
 class Tracer:
@@ -359,21 +397,16 @@ class Tracer:
             frame.device_T_to_world_end = None if t1 is None else t1.data_ptr()
             frame._keepalive = (t0, t1)
         feats = gaussians.get_features()
-        if native.cfg.feature_transform_type:   # neural harmonic features: forward only in this version
+        if native.cfg.feature_transform_type:   # neural harmonic features (K = 0)
             if feats.shape[1] != native.cfg.particle_feature_dim:
                 raise ValueError(f"features have {feats.shape[1]} columns, expected nht_features.dim = {native.cfg.particle_feature_dim}")
-            if torch.is_grad_enabled() and any(t.requires_grad for t in (feats, gaussians.positions)):
-                raise NotImplementedError("3dgrut_amd: the neural-harmonic-features (nht) path is forward only; render under torch.no_grad()")
-            with torch.no_grad():
-                pd = _abi.pack_particles(gaussians.positions.contiguous(), gaussians.get_density().contiguous(), gaussians.get_rotation().contiguous(),
-                                         gaussians.get_scale().contiguous())
-                fd, dist, cnt, vis = native.trace_nht(frame, pd, feats.detach(), rays_o.contiguous().float(), rays_d.contiguous().float())
-            nr = native.ray_feature_dim
-            pred_features = fd[..., :nr].unsqueeze(0).contiguous()
+            pred_features, pred_opacity, pred_dist, hits_count, mog_visibility = _NhtAutograd.apply(
+                native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(), gaussians.positions.contiguous(),
+                gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(), gaussians.get_density().contiguous(), feats.contiguous())
             timings = native.collect_times()
-            return {"pred_features": pred_features, "pred_opacity": fd[..., nr:].unsqueeze(0).contiguous(), "pred_dist": dist.unsqueeze(0),
-                    "pred_normals": torch.nn.functional.normalize(torch.ones_like(pred_features), dim=3), "hits_count": cnt.unsqueeze(0),
-                    "frame_time_ms": timings["forward_render"] if "forward_render" in timings else 0.0, "mog_visibility": vis}
+            return {"pred_features": pred_features, "pred_opacity": pred_opacity, "pred_dist": pred_dist.unsqueeze(0),
+                    "pred_normals": torch.nn.functional.normalize(torch.ones_like(pred_features), dim=3), "hits_count": hits_count.unsqueeze(0),
+                    "frame_time_ms": timings["forward_render"] if "forward_render" in timings else 0.0, "mog_visibility": mog_visibility}
         if feats.shape[1] != 3 * native.ncoef:
             raise ValueError(f"features have {feats.shape[1]} columns, expected {3 * native.ncoef} for SH degree "
                              f"{native.cfg.particle_radiance_sph_degree}")

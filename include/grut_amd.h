@@ -100,12 +100,13 @@ typedef struct GutConfig {
      *   rayPayloadBackward.cuh:50-58); GutFrame::out_features / out_opacity must then be NULL.  Hit distance / count stay fp32. */
     int32_t particle_feature_half;
     int32_t feature_output_half;
-    /* Neural harmonic features (model.feature_type = nht; setup_3dgut.py:47-57, threedgrut/model/features.py:133-175; round 3: FORWARD only,
-     * k_buffer_size 0).  feature_transform_type 1: `particle_sph` is the per-particle feature buffer [N, particle_feature_dim] (fp32 or
+    /* Neural harmonic features (model.feature_type = nht; setup_3dgut.py:47-57, threedgrut/model/features.py:133-175; round 3: k_buffer_size 0 only).  feature_transform_type 1: `particle_sph` is the per-particle feature buffer [N, particle_feature_dim] (fp32 or
      * half), features are interpolated per hit at the canonical intersection (gutKBufferRenderer.cuh:199-225,
      * neuralHarmonicFeaturesParticle.slang:146-196) and out_feat_density is [H, W, ray_feature_dim + 1] with
      * ray_feature_dim = interp_point_feature_dim x (2 x num_frequencies for sincos | num_frequencies for siren | 1), at most 32;
-     * GutFrame::out_features / out_opacity must be NULL and gut_backward* return GRUT_ERR_UNSUPPORTED.  All zero = SH radiance. */
+     * GutFrame::out_features / out_opacity must be NULL.  Backward: gut_backward only (gutKBufferRenderer.cuh:546-641): grad_feat_density is
+     * [H, W, ray_feature_dim + 1], grad_particle_sph receives the feature buffer's gradient [N, particle_feature_dim] fp32, both gradient
+     * outputs are fully written; gut_backward_unpacked / _factored return GRUT_ERR_UNSUPPORTED.  All zero = SH radiance. */
     int32_t feature_transform_type;              /* 0 SH radiance (default), 1 neural harmonic features */
     int32_t particle_feature_dim;                /* K: floats per particle (nht_features.dim, 48) */
     int32_t interp_point_feature_dim;            /* K / interpolation points (12) */

@@ -6,6 +6,7 @@ T < 1e-4, tile culling) are evaluated in fp32 with different rounding on the two
 vanishing fraction of pixels / tile entries may flip; those are bounded explicitly below.
 """
 import ctypes as C
+import os
 import importlib
 from types import SimpleNamespace
 
@@ -783,11 +784,58 @@ def test_nht_forward_matches_oracle(model_kw, half):
     assert np.abs(got[..., :nr]).max() > 0.3
 
 
-def test_nht_is_forward_only_and_says_so():
+@pytest.mark.parametrize("name", ["nht", "nht_depth"])
+def test_nht_gradients_match_autograd_golden(name):
+    """The nht backward (Slang autodiff output in the reference) against float64 torch.autograd of the restated forward
+    (tests/golden/autograd_gut_nht.npz) and against the oracle's reverse mode: particle rows and the feature buffer."""
     import torch
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "autograd_gut_nht.npz"))
+    n, w, h, seed = (int(g[f"{name}_{k}"]) for k in ("n", "w", "h", "seed"))
+    scene = make_scene(n=n, width=w, height=h, median_scale=0.16, seed=seed)
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
-    scene = make_scene(n=500, width=32, height=32, median_scale=0.1)
     tr = gt.Tracer({"render": {"splat": {}}, "model": NHT_MODEL})
-    g = syn.SimpleGaussians(scene["density12"], np.zeros((500, 48), np.float32))
-    with pytest.raises(NotImplementedError, match="forward only"):
-        tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
+    gs = syn.SimpleGaussians(scene["density12"], g[f"{name}_features"])
+    out = tr.render(gs, torch_batch(scene["batch"], "cuda"), train=True)
+    g_fd, g_dist = torch.as_tensor(g[f"{name}_g_fd"], device="cuda"), torch.as_tensor(g[f"{name}_g_dist"], device="cuda")
+    loss = (out["pred_features"][0] * g_fd[..., :24]).sum() + (out["pred_opacity"][0] * g_fd[..., 24:]).sum()
+    if name == "nht_depth":
+        loss = loss + (out["pred_dist"][0] * g_dist).sum()
+    loss.backward()
+    gd, gf = gs.grads_packed()
+    ref_d, ref_f = g[f"{name}_grad_density12"], g[f"{name}_grad_features"]
+    for key, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
+        assert rel_err(gd[:, sl], ref_d[:, sl]) < 1e-3, (key, rel_err(gd[:, sl], ref_d[:, sl]))
+    assert rel_err(gf, ref_f) < 1e-3 and gf.shape == (n, 48) and gf.dtype == np.float32
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_nht_backward_matches_oracle_on_a_larger_frame(half):
+    import torch
+    scene = make_scene(n=5000, width=112, height=64, median_scale=0.05)
+    feats = np.random.default_rng(5).uniform(-np.pi / 2, np.pi / 2, size=(5000, 48)).astype(np.float32)
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    kw = dict(particle_feature_half=True, feature_output_half=True) if half else {}
+    tr = gt.Tracer({"render": dict(kw, splat={}), "model": NHT_MODEL})
+    gs = syn.SimpleGaussians(scene["density12"], feats)
+    out = tr.render(gs, torch_batch(scene["batch"], "cuda"), train=True)
+    rng = np.random.default_rng(8)
+    g_fd = rng.normal(size=(64, 112, 25)).astype(np.float32)
+    t = torch.as_tensor(g_fd, device="cuda")
+    ((out["pred_features"][0] * t[..., :24]).sum() + (out["pred_opacity"][0] * t[..., 24:]).sum()).backward()
+    gd, gf = gs.grads_packed()
+    cfg = oracle.default_gut_config()
+    ofeats = oracle.round_to_half(feats) if half else feats
+    fwd = oracle.gut_forward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], ofeats, *scene["rays"])
+    if half:   # the backward starts from the rounded image (rayPayloadBackward.cuh:50-58)
+        fwd = dict(fwd, feat_density=oracle.round_to_half(fwd["feat_density"]))
+    rd, rf = oracle.gut_backward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], ofeats, *scene["rays"], fwd, g_fd)
+    flips = int((out["hits_count"][0, ..., 0].detach().cpu().numpy() != fwd["hit_count"][..., 0]).sum())
+    for key, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
+        assert _trimmed_rel_err(gd[:, sl], rd[:, sl], 3 * flips) < 1e-3, key
+    assert _trimmed_rel_err(gf, rf, 3 * flips) < 1e-3
+
+
+def test_nht_refuses_what_it_does_not_provide():
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    with pytest.raises(RuntimeError, match="k_buffer_size must be 0"):
+        gt.Tracer({"render": {"splat": {"k_buffer_size": 16}}, "model": NHT_MODEL})
