@@ -1192,6 +1192,11 @@ void launch_render_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
 // cache.  First version: correctness first, ray_dim <= 32.
 // ---------------------------------------------------------------------------------------------
 constexpr int kNhtMaxRay = 32, kNhtMaxIpd = 16;
+// sin / cos of the activation on the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions; absolute error ~1e-6 for the |angle| < 256
+// this model produces — features are initialised in [-pi/2, pi/2] and multiplied by at most the frequency index): the library sinf / cosf
+// cost ~40 instructions each, 48 of them per hit and pixel made up five sixths of the first version's forward
+__device__ __forceinline__ float nht_sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189535f); }
+__device__ __forceinline__ float nht_cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
 __global__ __launch_bounds__(64) void gut_render_nht_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                                 const float4* __restrict__ density12, const float* __restrict__ features,
                                                                 const float* __restrict__ ray_o, const float* __restrict__ ray_d,
@@ -1309,10 +1314,10 @@ __global__ __launch_bounds__(64) void gut_render_nht_fwd_kernel(GutParams P, con
                         else if (P.nht_act == 2) {
                             const int k = i / (2 * nf), rem = i - k * 2 * nf, fq = rem >> 1;
                             const float angle = base[k < kNhtMaxIpd ? k : 0] * (float)(fq + 1);
-                            f = (rem & 1) ? cosf(angle) : sinf(angle);
+                            f = (rem & 1) ? nht_cos(angle) : nht_sin(angle);
                         } else {
                             const int k = i / nf, fq = i - k * nf;
-                            f = sinf(base[k < kNhtMaxIpd ? k : 0] * ldexpf(1.f, fq));
+                            f = nht_sin(base[k < kNhtMaxIpd ? k : 0] * ldexpf(1.f, fq));
                         }
                         acc[i] = fmaf(f, w, acc[i]);
                     }
@@ -1348,7 +1353,7 @@ __global__ __launch_bounds__(64) void gut_render_nht_fwd_kernel(GutParams P, con
 // at the same time, so the wave sums each of the entry's words over its lanes (DPP reduce-scatter, 16 words at a time) before ONE set
 // of atomics per (wave, entry) — the reference does the same with warp shuffles (shRadiativeGaussianParticles.cuh:421-441).
 // First version: no checkpoints (every wave sweeps its tile's list from the start), correctness first.
-__global__ __launch_bounds__(64) void gut_render_nht_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gut_render_nht_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                                 const float4* __restrict__ density12, const float* __restrict__ features,
                                                                 const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                                 const float* __restrict__ fd, const float* __restrict__ g_fd,
@@ -1470,12 +1475,12 @@ __global__ __launch_bounds__(64) void gut_render_nht_bwd_kernel(GutParams P, con
                                     kb = i / (2 * nf);
                                     const int rem = i - kb * 2 * nf, fq = rem >> 1;
                                     const float fr = (float)(fq + 1), ang = base[kb < kNhtMaxIpd ? kb : 0] * fr;
-                                    const float sn = sinf(ang), cs = cosf(ang);
+                                    const float sn = nht_sin(ang), cs = nht_cos(ang);
                                     f = (rem & 1) ? cs : sn; df = (rem & 1) ? -fr * sn : fr * cs;
                                 } else {
                                     kb = i / nf;
                                     const float fr = ldexpf(1.f, i - kb * nf), ang = base[kb < kNhtMaxIpd ? kb : 0] * fr;
-                                    f = sinf(ang); df = fr * cosf(ang);
+                                    f = nht_sin(ang); df = fr * nht_cos(ang);
                                 }
                                 if (hit) {
                                     Cb[i] = (Cb[i] - f * alpha) * w;

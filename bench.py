@@ -37,6 +37,8 @@ WORKLOADS = {
     "c3_grt_100k_400": (100_000, 400, 400, 0.01),
     # BASELINE config 5: hybrid mesh + Gaussian path tracing (reflection / refraction), 2 M Gaussians + mesh, fisheye camera, 1080p, forward only
     "c5_hybrid_2m_1080p": (2_000_000, 1920, 1080, 0.008),
+    # model.feature_type = nht at the headline size
+    "c4_nht_1m_1080p": (1_000_000, 1920, 1080, 0.01),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -309,6 +311,50 @@ def bench_hybrid(args, dev, n, W, H, ms, emit=True):
     return result
 
 
+def bench_nht(args, dev, n, W, H, ms, emit=True):
+    """3DGUT with neural harmonic features (model.feature_type = nht, defaults of configs/base_gs.yaml: 48 floats per particle, sincos x 1 ->
+    24 ray features): forward + backward of one view.  First version of these kernels (one pixel per lane, no checkpoints)."""
+    syn = importlib.import_module("3dgrut_amd.synthetic")
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    from scenes import torch_batch
+    d12, _ = syn.cloud_trained_like(n, seed=42, median_scale=ms)
+    feats = np.random.default_rng(7).uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)
+    K = syn.pinhole_intrinsics(W, H)
+    ro, rd = syn.pinhole_rays(W, H, K)
+    batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(0, n_views=8)[None], intrinsics=K), dev)
+    tracer = gt.Tracer({"render": {"enable_kernel_timings": True, "splat": {}},
+                        "model": {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1},
+                                                                          "interpolation_type": "barycentric"}}})
+    g = syn.SimpleGaussians(d12, feats, device=dev)
+    g_feat = torch.randn((1, H, W, 24), device=dev) / (W * H)
+    g_opa = torch.randn((1, H, W, 1), device=dev) / (W * H)
+
+    def step():
+        g.zero_grad()
+        out = tracer.render(g, batch, train=True)
+        torch.autograd.backward([out["pred_features"], out["pred_opacity"]], [g_feat, g_opa])
+
+    for _ in range(args.warmup):
+        step()
+    tracer.timings
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    st = tracer.tracer_wrapper.stats()
+    result = {"metric": "train rays/sec (3DGUT, neural harmonic features, forward+backward)", "value": W * H * args.steps / dt, "unit": "rays/s",
+              "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup, "n_gpus": 1, "higher_is_better": True, "dtype": "f32",
+              "data": "synthetic", "stages_ms": tracer.timings,
+              "config": {"workload": f"3DGUT fwd+bwd with neural harmonic features, {n} Gaussians, {W}x{H}, 48 feature floats per particle -> 24 ray features",
+                         "name": args.workload},
+              "work": {"N": int(st.num_particles), "Nv": int(st.num_visible), "I": int(st.num_intersections)}}
+    if emit:
+        print(json.dumps(result), flush=True)
+    return result
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run (one rank per GPU, rendezvous on
     127.0.0.1 at a free port) and pass its output through.  On a box with fewer than N GPUs the RCCL backend cannot place the ranks:
@@ -372,6 +418,8 @@ def main():
         return bench_grt(args, world, rank, dev, dist, n, W, H, ms)
     if "hybrid" in args.workload:
         return bench_hybrid(args, dev, n, W, H, ms)
+    if args.workload.startswith("c4_nht"):
+        return bench_nht(args, dev, n, W, H, ms)
     d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=ms)
     K = syn.pinhole_intrinsics(W, H)
     ro, rd = syn.pinhole_rays(W, H, K)
