@@ -266,16 +266,22 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
         GRUT_CHECK(inclusive_scan_u32(s, N, h->l_counts.as<uint32_t>(), rank_to_particle, h->l_offsets.as<uint32_t>(), h->l_scan_scratch.ptr,
                                       h->l_scan_scratch.bytes));
         // the entry count sizes the rest: one round trip to the host per frame (with the one-origin flag riding along)
+        grt_launch_list_check(s, N, h->l_offsets.as<uint32_t>(), flag);   // (a wrapped 32-bit total would otherwise pass for a small one)
         GRUT_HIP(hipMemcpyAsync(&h->l_host[0], h->l_offsets.as<uint32_t>() + (N - 1), 4, hipMemcpyDeviceToHost, s));
-        GRUT_HIP(hipMemcpyAsync(&h->l_host[1], flag, 4, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipMemcpyAsync(&h->l_host[1], flag, 8, hipMemcpyDeviceToHost, s));   // {one origin, entry count overflowed}
         GRUT_HIP(hipStreamSynchronize(s));
         const uint64_t I = h->l_host[0];
-        if (h->l_host[1] != 0u && I > 0 && I < 0xFFFF0000ull) {
+        bool usable = h->l_host[1] != 0u && h->l_host[2] == 0u && I > 0 && I < 0xFFFF0000ull;
+        if (usable) {   // the per-entry buffers: a frame whose lists do not fit walks the tree instead of failing
             const uint32_t n = (uint32_t)I;
             for (DeviceBuffer* b4 : {&h->l_block_keys, &h->l_vals, &h->l_block_keys_tmp, &h->l_vals_tmp})
-                GRUT_CHECK(b4->ensure((size_t)n * 4, 1.3f));
-            GRUT_CHECK(h->l_ranges.ensure((size_t)nb * 8, 1.25f));
-            GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.3f) + 4096)));
+                usable = usable && b4->ensure((size_t)n * 4, 1.3f) == GRUT_OK;
+            usable = usable && h->l_ranges.ensure((size_t)nb * 8, 1.25f) == GRUT_OK;
+            usable = usable && h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.3f) + 4096)) == GRUT_OK;
+            if (!usable) (void)hipGetLastError();
+        }
+        if (usable) {
+            const uint32_t n = (uint32_t)I;
             grt_launch_list_expand(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
                                    rank_to_particle, h->l_offsets.as<uint32_t>(), n, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(), h->l_pair_cache.ptr);
             int bits = 1;

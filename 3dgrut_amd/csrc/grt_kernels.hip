@@ -2000,8 +2000,17 @@ uint32_t grt_num_blocks(int W, int H) { return blocks_x(W) * blocks_y(H); }
 size_t grt_pair_cache_bytes(uint32_t N) { return (size_t)N * (4 * 16 + 4); }   // kBinCachedPairs uint4 + the pair count, per particle
 uint32_t grt_num_super(int W, int H) { return ((blocks_x(W) + 7u) / 8u) * ((blocks_y(H) + 7u) / 8u); }
 
+// the entry offsets come from a 32-bit inclusive scan: a total beyond 2^32 shows as a descent somewhere in them
+__global__ __launch_bounds__(256) void grt_list_check_kernel(uint32_t n, const uint32_t* __restrict__ offsets, uint32_t* __restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > 0 && i < n && offsets[i] < offsets[i - 1]) flag[1] = 1u;
+}
+void grt_launch_list_check(hipStream_t s, uint32_t n, const uint32_t* offsets, uint32_t* flag) {
+    hipLaunchKernelGGL(grt_list_check_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, offsets, flag);
+}
 __global__ void grt_list_init_kernel(uint32_t* __restrict__ flag, uint32_t* __restrict__ dir_len_enc) {
     flag[0] = 1u;
+    flag[1] = 0u;   // set when the 32-bit entry count wrapped (grt_list_check_kernel)
     dir_len_enc[0] = 0x7F7FFFFFu;   // min |d| (bit patterns of positive floats order like integers)
     dir_len_enc[1] = 0u;            // max |d|
 }
