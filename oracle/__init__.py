@@ -297,6 +297,55 @@ def grt_forward(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, r
     return out
 
 
+def _nht_prm(nht):
+    nht = dict(NHT_DEFAULT, **(nht or {}))
+    return nht, np.array([nht["particle_feature_dim"], nht["interp_point_dim"], nht["support"], nht["activation"], nht["num_frequencies"]], np.int32)
+
+
+def grt_forward_nht(cfg, density12, features, min_transmittance, ray_to_world, ray_o, ray_d, nht=None, inst=None, scene=None, dbg_cap=0, dtype=np.float32):
+    """The Slang pipeline with neural harmonic features (referenceSlangOptix.cu): like grt_forward, `features` [N, K] -> out features [H, W, ray_dim]."""
+    l, R = lib(dtype), _real(dtype)
+    nht, prm = _nht_prm(nht)
+    d12, f = _c(density12, dtype), _c(features, dtype)
+    N = d12.shape[0]
+    if inst is None:
+        pr = grt_proxies(cfg, d12[:, 0:3], d12[:, 4:8], d12[:, 8:11], d12[:, 3], dtype)
+        inst, scene = pr["inst"], pr["scene"]
+    inst, scene = _c(inst, dtype), _c(scene, dtype)
+    ro, rd = _c(ray_o, dtype), _c(ray_d, dtype)
+    H, W = ro.shape[-3], ro.shape[-2]
+    n = H * W
+    m = _c(np.asarray(ray_to_world)[:3, :4], dtype)
+    nr = nht_ray_feature_dim(nht)
+    out = dict(features=np.zeros((H, W, nr), dtype), density=np.zeros((H, W, 1), dtype), hit_distance=np.zeros((H, W, 2), dtype),
+               hit_count=np.zeros((H, W, 1), dtype), visibility=np.zeros(N, np.int32))
+    dbg_ids = np.full((n, max(dbg_cap, 1)), 0xFFFFFFFF, np.uint32)
+    dbg_cnt = np.zeros(n, np.uint32)
+    r = l.orc_grt_trace_nht_fwd(C.byref(cfg), _p(prm), C.c_uint32(N), _p(d12), _p(f), R(min_transmittance), _p(inst), _p(scene), _p(m), C.c_uint32(n),
+                                _p(ro), _p(rd), _p(out["features"]), _p(out["density"]), _p(out["hit_distance"]), _p(out["hit_count"]),
+                                _p(out["visibility"]), _p(dbg_ids) if dbg_cap else None, _p(dbg_cnt), C.c_uint32(dbg_cap))
+    assert r == 0
+    out.update(hit_ids=dbg_ids, hit_num=dbg_cnt, inst=inst, scene=scene, density12=d12, nht_features=f, rays=(ro, rd), ray_to_world=m, nht=nht)
+    return out
+
+
+def grt_backward_nht(cfg, min_transmittance, fwd, g_features, g_density, g_hit_distance=None, dtype=np.float32):
+    """referenceSlangBwdOptix.cu with neural harmonic features: (grad_density12 [N,12], grad_features [N,K])."""
+    l, R = lib(dtype), _real(dtype)
+    nht, prm = _nht_prm(fwd["nht"])
+    d12, f = fwd["density12"], fwd["nht_features"]
+    N = d12.shape[0]
+    ro, rd = fwd["rays"]
+    n = ro.shape[-3] * ro.shape[-2]
+    gd, gf = np.zeros((N, 12), dtype), np.zeros_like(f)
+    gh = np.zeros((n,), dtype) if g_hit_distance is None else _c(g_hit_distance, dtype)
+    r = l.orc_grt_trace_nht_bwd(C.byref(cfg), _p(prm), C.c_uint32(N), _p(d12), _p(f), R(min_transmittance), _p(fwd["inst"]), _p(fwd["scene"]),
+                                _p(fwd["ray_to_world"]), C.c_uint32(n), _p(ro), _p(rd), _p(_c(fwd["features"], dtype)), _p(_c(fwd["density"], dtype)),
+                                _p(_c(fwd["hit_distance"], dtype)), _p(_c(g_features, dtype)), _p(_c(g_density, dtype)), _p(gh), _p(gd), _p(gf))
+    assert r == 0
+    return gd, gf
+
+
 def grt_backward(cfg, sph_deg, min_transmittance, fwd, g_features, g_density, g_hit_distance, dtype=np.float32, dbg_cap=0, round_shift=None):
     """OptixTracer::trace_bwd: returns (grad_density12 [N,12], grad_sph [N,3*ncoef]); with dbg_cap > 0 additionally the particles
     each ray's backward program processed, in order: (.., hit_ids [n, dbg_cap], hit_num [n]).  `round_shift`: optional uint8 [n]

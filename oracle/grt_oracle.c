@@ -14,6 +14,7 @@
  * referenceBwdOptix.cu:103-170 (backward), 3dgrt/kernels/cuda/gaussianParticles.cuh:337-731 (per-hit math).
  */
 #include "orc_math.h"
+#include "orc_nht.h"
 #include "../include/grut_amd.h"
 
 #include <stdio.h>
@@ -469,6 +470,216 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
     for (size_t k = 0; k < (size_t)N * 12; ++k) g_density12[k] += (real)acc_d[k];
     for (size_t k = 0; k < (size_t)N * 3 * ncoef; ++k) g_sph[k] += (real)acc_s[k];
     free(acc_d); free(acc_s);
+    return 0;
+}
+
+/* --------------------------------------------------------------------------------------------------------------------------------
+ * The Slang pipelines with NEURAL HARMONIC FEATURES (render.pipeline_type referenceSlang / referenceSlangBwd, model.feature_type nht):
+ * referenceSlangOptix.cu:103-186 — the same k = 16 rounds as the reference pipeline; per processed hit
+ * particleDensityProcessHitFwdFromBuffer (gaussianParticles.slang:284-316, 404-425: hit(), integrateHit<false>, canonical intersection)
+ * and particleFeaturesIntegrateFwdFromBuffer (neuralHarmonicFeaturesParticle.slang:213-228, 253-270) — and
+ * referenceSlangBwdOptix.cu:70-185 — the backward program's rounds (as referenceBwdOptix.cu), per returned hit particleDensityHit,
+ * particleFeaturesFromBuffer, particleFeaturesIntegrateBwdToBuffer (:272-320, lerp form un-blended front to back) and
+ * particleDensityProcessHitBwdToBuffer (gaussianParticles.slang:420-479) with the canonical intersection's gradient.  The backward
+ * functions are Slang autodiff output: this is the reverse mode of the restated forward, the same per-hit formulas that the 3DGUT
+ * restatement checks against float64 torch.autograd (tests/golden/autograd_gut_nht.npz).
+ * out_feat [nrays, ray_dim]; features [N, K]; g_features [N, K] accumulated into.
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+int orc_grt_trace_nht_fwd(const GrtConfig* cfg, const int* nht, uint32_t N, const real* density12, const real* features, real min_T,
+                          const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
+                          const real* ray_d, real* out_feat, real* out_dns, real* out_hit2, real* out_cnt, int32_t* visibility,
+                          uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap) {
+    const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
+    const int nr = orc_nht_ray_dim(nht), KF = nht[0];
+    if (K > GRT_MAX_K || nr > ORC_NHT_MAX_DIM || nht[1] > ORC_NHT_MAX_DIM) return -1;
+    const real eps = R_(1e-9);
+    const orc_nht_tet tet = orc_nht_tetra();
+#pragma omp parallel
+    {
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+#pragma omp for schedule(dynamic, 8)
+        for (uint32_t r = 0; r < nrays; ++r) {
+            const v3 o = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
+            const v3 d = xform_dir(ray_to_world12, v3_make(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
+            real T = 1, depth = 0, cnt = 0, acc[ORC_NHT_MAX_DIM];
+            for (int i = 0; i < nr; ++i) acc[i] = 0;
+            real tEnter, tExit;
+            scene_interval(scene6, o, d, &tEnter, &tExit);
+            real tLast = r_max(0, tEnter - eps);
+            const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+            uint32_t ndbg = 0;
+            grt_hit buf[GRT_MAX_K];
+            while ((tLast <= tExit) && (T > min_T)) {
+                const int k = trace_round(cands, n, tLast + eps, tExit + eps, K, buf);
+                if (k == 0) break;
+                for (int i = 0; i < k; ++i) {
+                    if (T > min_T) {
+                        const uint32_t id = buf[i].id;
+                        const grt_particle p = load_particle(density12 + 12 * (size_t)id);
+                        const v3 giscl = v3_make(1 / p.scl.x, 1 / p.scl.y, 1 / p.scl.z);
+                        const v3 gro = v3_mul(giscl, v3_mul_rows(v3_sub(o, p.pos), &p.rotT));
+                        const v3 grdu = v3_mul(giscl, v3_mul_rows(d, &p.rotT));
+                        const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
+                        const v3 gcrod = v3_cross(grd, gro);
+                        const real gres = particle_response(cfg->particle_kernel_degree, v3_dot(gcrod, gcrod));
+                        const real alpha = r_min((real)cfg->particle_kernel_max_alpha, gres * p.density);
+                        real w = 0;
+                        if ((gres > (real)cfg->particle_kernel_min_response) && (alpha > (real)cfg->particle_kernel_min_alpha)) {
+                            const v3 cg = v3_scale(grd, v3_dot(grd, v3_scale(gro, -1)));
+                            const v3 P = v3_add(gro, cg);
+                            const v3 grds = v3_mul(p.scl, cg);
+                            w = alpha * T;
+                            depth += r_sqrt(v3_dot(grds, grds)) * w;
+                            T *= (1 - alpha);
+                            if (w > 0) {
+                                real wq[4], base[ORC_NHT_MAX_DIM], f[ORC_NHT_MAX_DIM];
+                                orc_nht_weights(nht, &tet, P, wq);
+                                orc_nht_features(nht, features + (size_t)KF * id, wq, base, f);
+                                for (int c = 0; c < nr; ++c) acc[c] += f[c] * w;
+#pragma omp atomic write
+                                visibility[id] = 1;
+                                cnt += 1;
+                            }
+                        }
+                        tLast = r_max(tLast, buf[i].t);
+                        if (dbg_ids && ndbg < dbg_cap) dbg_ids[(size_t)r * dbg_cap + ndbg] = id;
+                        ndbg++;
+                    }
+                }
+            }
+            for (int c = 0; c < nr; ++c) out_feat[(size_t)nr * r + c] = acc[c];
+            out_dns[r] = 1 - T;
+            out_hit2[2 * r] = depth; out_hit2[2 * r + 1] = tLast;
+            if (cfg->enable_hitcounts) out_cnt[r] = cnt;
+            if (dbg_count) dbg_count[r] = ndbg;
+        }
+        free(cands);
+    }
+    return 0;
+}
+
+int orc_grt_trace_nht_bwd(const GrtConfig* cfg, const int* nht, uint32_t N, const real* density12, const real* features, real min_T,
+                          const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
+                          const real* ray_d, const real* feat, const real* dns, const real* hit2, const real* g_feat, const real* g_dns,
+                          const real* g_hit, real* g_density12, real* g_features) {
+    (void)min_T;
+    const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
+    const int nr = orc_nht_ray_dim(nht), KF = nht[0];
+    if (K > GRT_MAX_K || nr > ORC_NHT_MAX_DIM || nht[1] > ORC_NHT_MAX_DIM) return -1;
+    const real eps = R_(1e-9);
+    const orc_nht_tet tet = orc_nht_tetra();
+    double* acc_d = (double*)calloc((size_t)N * 12 + 1, sizeof(double));
+    double* acc_f = (double*)calloc((size_t)N * KF + 1, sizeof(double));
+#pragma omp parallel
+    {
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+#pragma omp for schedule(dynamic, 8)
+        for (uint32_t r = 0; r < nrays; ++r) {
+            const v3 o = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
+            const v3 d = xform_dir(ray_to_world12, v3_make(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
+            real Cb[ORC_NHT_MAX_DIM], gC[ORC_NHT_MAX_DIM];
+            for (int c = 0; c < nr; ++c) { Cb[c] = feat[(size_t)nr * r + c]; gC[c] = g_feat[(size_t)nr * r + c]; }
+            real Tb = 1 - dns[r], gT = -g_dns[r], Db = hit2[2 * r], gD = g_hit ? g_hit[r] : 0;
+            const real maxHit = hit2[2 * r + 1];
+            real tEnter, tExit;
+            scene_interval(scene6, o, d, &tEnter, &tExit);
+            real startT = r_max(0, tEnter - eps);
+            const real endT = r_min(maxHit, tExit) + eps;
+            const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+            grt_hit buf[GRT_MAX_K];
+            while (startT < endT) {
+                const int k = trace_round(cands, n, startT + eps, endT, K, buf);
+                if (k == 0) break;
+                for (int i = 0; i < k; ++i) {
+                    const uint32_t id = buf[i].id;
+                    startT = r_max(startT, buf[i].t);
+                    const grt_particle p = load_particle(density12 + 12 * (size_t)id);
+                    const v3 gscl = p.scl;
+                    const v3 giscl = v3_make(1 / gscl.x, 1 / gscl.y, 1 / gscl.z);
+                    const v3 gposc = v3_sub(o, p.pos);
+                    const v3 gposcr = v3_mul_rows(gposc, &p.rotT);
+                    const v3 gro = v3_mul(giscl, gposcr);
+                    const v3 rdr = v3_mul_rows(d, &p.rotT);
+                    const v3 grdu = v3_mul(giscl, rdr);
+                    const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
+                    const v3 gcrod = v3_cross(grd, gro);
+                    const real gray = v3_dot(gcrod, gcrod);
+                    const real gres = particle_response(cfg->particle_kernel_degree, gray);
+                    const real alpha = r_min((real)cfg->particle_kernel_max_alpha, gres * p.density);
+                    if (!((gres > (real)cfg->particle_kernel_min_response) && (alpha > (real)cfg->particle_kernel_min_alpha))) continue;
+                    const real pdot = v3_dot(grd, v3_scale(gro, -1));
+                    const v3 grdd = v3_scale(grd, pdot);
+                    const v3 P = v3_add(gro, grdd);
+                    const v3 grds = v3_mul(gscl, grdd);
+                    const real gsq = v3_dot(grds, grds);
+                    const real hitT = r_sqrt(gsq);
+                    const real* row = features + (size_t)KF * id;
+                    real wq[4], base[ORC_NHT_MAX_DIM], f[ORC_NHT_MAX_DIM], gf[ORC_NHT_MAX_DIM], g_row[ORC_NHT_MAX_DIM * 4];
+                    orc_nht_weights(nht, &tet, P, wq);
+                    orc_nht_features(nht, row, wq, base, f);
+                    const real w = 1 / (1 - alpha);
+                    real dalpha = 0;
+                    if (alpha > 0) {
+                        for (int c = 0; c < nr; ++c) {
+                            Cb[c] = (Cb[c] - f[c] * alpha) * w;
+                            dalpha += (f[c] - Cb[c]) * gC[c];
+                            gf[c] = alpha * gC[c];
+                            gC[c] *= (1 - alpha);
+                        }
+                    } else {
+                        for (int c = 0; c < nr; ++c) gf[c] = 0;
+                    }
+                    const v3 dP = orc_nht_features_bwd(nht, &tet, row, wq, base, gf, g_row);
+                    for (int c = 0; c < KF; ++c)
+                        if (g_row[c] != 0) {
+#pragma omp atomic
+                            acc_f[(size_t)KF * id + c] += (double)g_row[c];
+                        }
+                    Tb *= w;
+                    Db = (Db - hitT * alpha) * w;
+                    dalpha += (hitT - Db) * gD - Tb * gT;
+                    const real ddepth = alpha * gD;
+                    gD *= (1 - alpha);
+                    gT *= (1 - alpha);
+                    real gd[12] = {0};
+                    real dres = 0, ddens = 0;
+                    if (gres * p.density < (real)cfg->particle_kernel_max_alpha) { dres = p.density * dalpha; ddens = gres * dalpha; }
+                    gd[3] = ddens;
+                    const real grayGrd = particle_response_grd(cfg->particle_kernel_degree, gray, gres, dres);
+                    const v3 grdsGrd = gsq > 0 ? v3_scale(grds, ddepth / hitT) : v3_make(0, 0, 0);
+                    const v3 gsclHit = v3_mul(grdd, grdsGrd);
+                    const real sdot = v3_dot(v3_mul(grdsGrd, gscl), grd);
+                    const real gdP = v3_dot(grd, dP);
+                    const v3 grdHit = v3_add(v3_sub(v3_scale(v3_mul(gscl, grdsGrd), pdot), v3_scale(gro, sdot)), v3_sub(v3_scale(dP, pdot), v3_scale(gro, gdP)));
+                    const v3 groHit = v3_add(v3_scale(grd, -sdot), v3_sub(dP, v3_scale(grd, gdP)));
+                    const v3 gcrodGrd = v3_scale(gcrod, 2 * grayGrd);
+                    const v3 grdGrd = v3_make(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
+                    const v3 groGrd = v3_make(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+                    const v3 groTot = v3_add(groGrd, groHit);
+                    const v3 gsclGro = v3_mul(v3_make(-gposcr.x / (gscl.x * gscl.x), -gposcr.y / (gscl.y * gscl.y), -gposcr.z / (gscl.z * gscl.z)), groTot);
+                    const v3 gposcrGrd = v3_mul(giscl, groTot);
+                    const v3 gposcGrd = matmul_bw_vec(&p.rotT, gposcrGrd);
+                    const v4 gq1 = matmul_bw_quat(gposc, gposcrGrd, p.quat);
+                    gd[0] = -gposcGrd.x; gd[1] = -gposcGrd.y; gd[2] = -gposcGrd.z;
+                    const v3 grduGrd = v3_safe_normalize_bw(grdu, v3_add(grdGrd, grdHit));
+                    const v3 sclGrd = v3_add(v3_add(gsclHit, gsclGro),
+                                             v3_mul(v3_make(-rdr.x / (gscl.x * gscl.x), -rdr.y / (gscl.y * gscl.y), -rdr.z / (gscl.z * gscl.z)), grduGrd));
+                    gd[8] = sclGrd.x; gd[9] = sclGrd.y; gd[10] = sclGrd.z;
+                    const v4 gq2 = matmul_bw_quat(d, v3_mul(giscl, grduGrd), p.quat);
+                    gd[4] = gq1.x + gq2.x; gd[5] = gq1.y + gq2.y; gd[6] = gq1.z + gq2.z; gd[7] = gq1.w + gq2.w;
+                    for (int c = 0; c < 11; ++c)
+                        if (gd[c] != 0) {
+#pragma omp atomic
+                            acc_d[12 * (size_t)id + c] += (double)gd[c];
+                        }
+                }
+            }
+        }
+        free(cands);
+    }
+    for (size_t k = 0; k < (size_t)N * 12; ++k) g_density12[k] += (real)acc_d[k];
+    for (size_t k = 0; k < (size_t)N * KF; ++k) g_features[k] += (real)acc_f[k];
+    free(acc_d); free(acc_f);
     return 0;
 }
 

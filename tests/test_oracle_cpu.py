@@ -685,3 +685,75 @@ def test_nht_backward_matches_autograd_of_the_restated_reference_forward(name):
             assert rel_err(gd[:, sl], ref_d[:, sl]) < tol, (dtype, sl, rel_err(gd[:, sl], ref_d[:, sl]))
         assert rel_err(gf, ref_f) < tol, (dtype, rel_err(gf, ref_f))
         assert np.abs(ref_f).max() > 0 and np.abs(ref_d[:, :3]).max() > 0
+
+
+def test_grt_nht_forward_uses_the_feature_model_pinned_by_the_gut_golden():
+    """The 3DGRT restatement of the Slang pipeline with neural harmonic features (orc_grt_trace_nht_fwd, oracle/orc_nht.h) shares no code
+    with the 3DGUT one, which the reference's own render kernel pins (gut_nht.npz).  On a scene where both renderers process the same hits
+    in the same order per ray — well separated particles, every ray's candidates far fewer than 16 per round — the two must agree."""
+    rng = np.random.default_rng(3)
+    n, w, h = 60, 24, 16
+    scene = make_scene(n=n, width=w, height=h, median_scale=0.07, max_density=0.6, seed=11)
+    feats = rng.uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)
+    T = scene["batch"]["T_to_world"][0]
+    gcfg = oracle.default_gut_config(particle_kernel_degree=4, min_transmittance=1e-3)
+    rcfg = oracle.default_grt_config()
+    gut = oracle.gut_forward_nht(gcfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats, *scene["rays"], dtype=np.float64)
+    grt = oracle.grt_forward_nht(rcfg, scene["density12"], feats, 1e-3, T, *scene["rays"], dtype=np.float64)
+    # the two renderers order overlapping hits differently (3DGUT: by particle depth, 3DGRT: by hit distance): rays on which the order
+    # matters differ legitimately; on all the others the 24 features agree to rounding, which no error in the feature model would allow
+    same = (gut["hit_count"][..., 0] == grt["hit_count"][..., 0])
+    close = np.abs(gut["feat_density"][..., :24] - grt["features"]).max(-1) < 1e-6
+    assert same.mean() > 0.9 and close.mean() > 0.75, (same.mean(), close.mean())
+    assert np.abs(gut["feat_density"][..., 24] - grt["density"][..., 0]).max() < 1e-6 or close.mean() > 0.75
+    assert np.abs(grt["features"]).max() > 0.3
+
+
+def test_grt_nht_backward_is_the_gradient_of_forward_away_from_the_last_hit():
+    """Central finite differences (float64) of the 3DGRT nht forward against orc_grt_trace_nht_bwd — the reverse mode of the lerp form with
+    the canonical-intersection path — for the feature rows and the particle rows; the backward program drops each ray's last hit
+    (endT = tLast + 1e-9), so particles that are some ray's last hit are not probed (as in the SH test above)."""
+    rng = np.random.default_rng(5)
+    n, w, h = 200, 10, 8
+    scene = make_scene(n=n, width=w, height=h, median_scale=0.2, max_density=0.5, seed=2)
+    feats = rng.uniform(-np.pi / 2, np.pi / 2, size=(n, 48))
+    T = scene["batch"]["T_to_world"][0]
+    cfg = oracle.default_grt_config()
+    d12 = scene["density12"].astype(np.float64)
+    g_f, g_d, g_h = rng.normal(size=(h, w, 24)), rng.normal(size=(h, w, 1)), rng.normal(size=(h, w, 1)) * 0.1
+
+    def run(d, f):
+        return oracle.grt_forward_nht(cfg, d, f, 1e-3, T, *scene["rays"], dbg_cap=512, dtype=np.float64)
+
+    f0 = run(d12, feats)
+    gd, gf = oracle.grt_backward_nht(cfg, 1e-3, f0, g_f, g_d, g_h.reshape(-1), dtype=np.float64)
+    last = set()
+    for r in range(h * w):
+        k = int(f0["hit_num"][r])
+        if k:
+            last.add(int(f0["hit_ids"][r, k - 1]))
+    probes = [i for i in np.nonzero(np.abs(gd).sum(1) > 0)[0] if i not in last][:5]
+    assert probes and np.abs(gf).max() > 0
+
+    def loss(d, f):
+        o = run(d, f)
+        return float((o["features"] * g_f).sum() + (o["density"] * g_d).sum() + (o["hit_distance"][..., :1] * g_h).sum())
+
+    bad = total = 0
+    for i in probes:
+        for col in list(range(11)):
+            hstep = 1e-6 * max(1.0, abs(d12[i, col]))
+            dp, dm = d12.copy(), d12.copy()
+            dp[i, col] += hstep
+            dm[i, col] -= hstep
+            fd = (loss(dp, feats) - loss(dm, feats)) / (2 * hstep)
+            total += 1
+            bad += abs(fd - gd[i, col]) > 2e-4 * np.abs(gd[:, col]).max() + 1e-7
+        for col in (0, 13, 29, 47):
+            fp, fm = feats.copy(), feats.copy()
+            fp[i, col] += 1e-6
+            fm[i, col] -= 1e-6
+            fd = (loss(d12, fp) - loss(d12, fm)) / 2e-6
+            total += 1
+            bad += abs(fd - gf[i, col]) > 2e-4 * np.abs(gf).max() + 1e-7
+    assert bad <= total // 4, (bad, total)
