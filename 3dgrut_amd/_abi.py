@@ -78,6 +78,8 @@ class GrtConfig(C.Structure):
         ("particle_kernel_density_clamping", C.c_int32), ("particle_radiance_sph_degree", C.c_int32),
         ("enable_normals", C.c_int32), ("enable_hitcounts", C.c_int32), ("enable_kernel_timings", C.c_int32),
         ("max_hits_per_trace", C.c_int32), ("particle_feature_half", C.c_int32), ("feature_output_half", C.c_int32),
+        ("feature_transform_type", C.c_int32), ("particle_feature_dim", C.c_int32), ("interp_point_feature_dim", C.c_int32),
+        ("feature_interpolation_support", C.c_int32), ("feature_activation_type", C.c_int32), ("feature_activation_num_frequencies", C.c_int32),
     ]
 
 

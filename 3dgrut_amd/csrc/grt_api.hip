@@ -67,6 +67,18 @@ static int grt_validate(const GrtConfig& c) {
     GRUT_REQUIRE(c.particle_radiance_sph_degree >= 0 && c.particle_radiance_sph_degree <= 3, "sph degree must be in [0,3]");
     const int d = c.particle_kernel_degree;
     GRUT_REQUIRE(d == 0 || d == 1 || d == 2 || d == 3 || d == 4 || d == 5 || d == 8, "unsupported particle_kernel_degree %d", d);
+    if (c.feature_transform_type != 0) {
+        GRUT_REQUIRE(c.feature_transform_type == 1, "feature_transform_type %d: 0 (SH) or 1 (neural harmonic features)", c.feature_transform_type);
+        GRUT_REQUIRE(!c.enable_normals, "neural harmonic features: enable_normals must be off");
+        GRUT_REQUIRE(c.feature_interpolation_support == 0 || c.feature_interpolation_support == 1, "feature_interpolation_support must be 0 (centre) or 1 (tetrahedra)");
+        GRUT_REQUIRE(c.feature_activation_type >= 0 && c.feature_activation_type <= 3, "feature_activation_type must be 0..3");
+        const int points = c.feature_interpolation_support == 1 ? 4 : 1;
+        GRUT_REQUIRE(c.interp_point_feature_dim >= 1 && c.interp_point_feature_dim <= 16 && c.particle_feature_dim == points * c.interp_point_feature_dim,
+                     "particle_feature_dim %d must be %d x interp_point_feature_dim (1..16)", c.particle_feature_dim, points);
+        const int nf = c.feature_activation_num_frequencies;
+        const int nr = c.interp_point_feature_dim * (c.feature_activation_type == 2 ? 2 * nf : (c.feature_activation_type == 1 ? nf : 1));
+        GRUT_REQUIRE(nf >= 1 && nr >= 1 && nr <= 32, "ray feature dim %d: 1..32 supported", nr);
+    }
     if (c.max_hits_per_trace != 0 && c.max_hits_per_trace != kGrtMaxHits) {
         set_last_error("max_hits_per_trace=%d: the hit buffer is %d entries (PipelineParameters::MaxNumHitPerTrace)", c.max_hits_per_trace, kGrtMaxHits);
         return GRUT_ERR_UNSUPPORTED;
@@ -92,6 +104,13 @@ static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
     for (int k = 0; k < 12; ++k) P.ray_to_world[k] = f.ray_to_world[k];
     P.ray_to_world_dev = f.device_ray_to_world;
     P.sph_half = h->cfg.particle_feature_half;
+    P.nht = h->cfg.feature_transform_type;
+    if (P.nht) {
+        const GrtConfig& c = h->cfg;
+        P.nht_k = c.particle_feature_dim; P.nht_ipd = c.interp_point_feature_dim; P.nht_support = c.feature_interpolation_support;
+        P.nht_act = c.feature_activation_type; P.nht_nf = c.feature_activation_num_frequencies;
+        P.nht_ray_dim = P.nht_ipd * (P.nht_act == 2 ? 2 * P.nht_nf : (P.nht_act == 1 ? P.nht_nf : 1));
+    }
     static const int sphere_lists = getenv("GRUT_GRT_SPHERE_LISTS") ? 1 : 0;
     P.sphere_lists = sphere_lists;
     P.out_half = h->cfg.feature_output_half;
@@ -324,7 +343,9 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     // hit log for the backward (only when the caller announces one: GrtFrame::keep_hits_for_backward)
     GrtHitLog log = {nullptr, nullptr, nullptr, nullptr, 0, 0};
     h->log_valid = false;
-    if (frame->keep_hits_for_backward && !dbg_ids) {
+    GRUT_REQUIRE(!(P.nht && dbg_ids), "grt_debug_forward_hits: not provided with neural harmonic features");
+    // (neural harmonic features: the ray features are computed FROM the log, so every forward keeps one)
+    if ((frame->keep_hits_for_backward || P.nht) && !dbg_ids) {
         const uint32_t blocks = div_up((uint32_t)P.W, 8) * div_up((uint32_t)P.H, 8);
         constexpr uint32_t kMaxRounds = 48;
         uint32_t want = blocks * 10u;  // first guess; grown from the measured use of earlier frames
@@ -369,6 +390,29 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     if (h->log_valid) h->log_lists = lists;   // the backward's exact rounds (flagged rays) scan the same lists
     grt_launch_trace_fwd(s, P, bvh, particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
                          out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters, log, lists);
+    if (P.nht) {
+        // Transmittance, hit distance, counts and visibility are the trace kernel's; the per-ray features are integrated by a pass over
+        // the hit log.  The log must hold the whole frame: if the pool overflowed, grow it and trace again (a host round trip per frame
+        // on this path — first version).
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            uint32_t st[4] = {0, 0, 0, 0};
+            GRUT_HIP(hipMemcpyAsync(st, log.state, 16, hipMemcpyDeviceToHost, s));
+            GRUT_HIP(hipStreamSynchronize(s));
+            if (st[1] == 0u) break;
+            GRUT_REQUIRE(attempt < 7, "grt_forward: the hit log does not fit (neural harmonic features)");
+            const uint32_t want = h->log.capacity_chunks * 2u;
+            GRUT_CHECK(h->log_pool.ensure((size_t)want * kGrtLogSlots * 64 * 4));
+            h->log.pool = h->log_pool.as<uint32_t>();
+            h->log.capacity_chunks = want;
+            const uint32_t blocks = div_up((uint32_t)P.W, 8) * div_up((uint32_t)P.H, 8);
+            GRUT_HIP(hipMemsetAsync(h->log.table, 0xFF, (size_t)blocks * h->log.max_rounds * 4, s));
+            GRUT_HIP(hipMemsetAsync(h->log.state, 0, 64, s));
+            log = h->log;
+            grt_launch_trace_fwd(s, P, bvh, particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
+                                 out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters, log, lists);
+        }
+        grt_launch_nht_fwd(s, P, particle_density, particle_sph, ray_origin, ray_direction, out_features, log);
+    }
     if (log.pool && !h->log_event_pending) {  // how much of the pool the frame used, read lazily by a later forward
         GRUT_HIP(hipMemcpyAsync(h->log_state_host, log.state, 8, hipMemcpyDeviceToHost, s));
         GRUT_HIP(hipEventRecord(h->log_event, s));

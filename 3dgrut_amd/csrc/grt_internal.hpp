@@ -47,6 +47,7 @@ struct GrtTraceParams {
     // optional (grt_debug_backward_signature): per ray, how many hits the backward differentiated and an order-independent
     // signature of which particles they were — the parity tests compare the replayed backward with the re-derived one ray by ray
     int sph_half, out_half;   // fp16 feature I/O (GrtConfig::particle_feature_half / feature_output_half)
+    int nht, nht_k, nht_ipd, nht_support, nht_act, nht_nf, nht_ray_dim;   // neural harmonic features (GrtConfig::feature_transform_type 1)
     int sphere_lists;         // development switch (GRUT_GRT_SPHERE_LISTS=1): bin by the proxies' bounding spheres only
     unsigned long long* bwd_sig;
     uint32_t* bwd_cnt;
@@ -149,6 +150,9 @@ void grt_launch_trace_bwd(hipStream_t s, hipStream_t s_rederive, const GrtTraceP
                           const float* ray_o, const float* ray_d, const float* rad, const float* dns, const float* hit2, const float* g_rad,
                           const float* g_dns, const float* g_hit, float* g_density12, float* g_sph, const GrtHitLog& log, const GrtLists& lists);
 
+// neural harmonic features: the ray features of a frame from the forward's hit log (grt_nht_fwd_kernel)
+void grt_launch_nht_fwd(hipStream_t s, const GrtTraceParams& P, const float* density12, const float* features, const float* ray_o, const float* ray_d,
+                        float* out_feat, const GrtHitLog& log);
 // packet lists (GrtLists)
 void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* ray_o, const float* ray_d, uint32_t* uniform_origin,
                            uint32_t* dir_len_enc /* [2] */, GrtCone* block_cones, GrtCone* super_cones);

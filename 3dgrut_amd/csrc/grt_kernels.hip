@@ -990,7 +990,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                     const float pdot = -dot(g.grd, g.gro);
                     const f3 grds = p.scl * g.grd * pdot;
                     const float hitT = sqrtf(dot(grds, grds));
-                    const f3 u = sh_radiance(P, sph, id, basis);
+                    const f3 u = P.nht ? mk3(0.f, 0.f, 0.f) : sh_radiance(P, sph, id, basis);   // (nht: the features come from the log, grt_nht_fwd_kernel)
                     const f3 c = mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f));
                     rad = rad + c * weight;
                     T *= (1.f - g.galpha);
@@ -1244,6 +1244,132 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
     if (P.bwd_sig && handled) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Neural harmonic features (model.feature_type = nht, the Slang pipelines: referenceSlangOptix.cu:103-186): the per-ray features are not a
+// per-particle colour but are interpolated per hit at the hit's canonical intersection (neuralHarmonicFeaturesParticle.slang:146-196,
+// see gut_render.hip: gut_render_nht_fwd_kernel for the model).  The trace kernel stays what it is — transmittance, hit distance,
+// counts, visibility, and the LOG of every round's candidates — and this pass walks each ray's log like the forward did (the round's
+// candidates in hit order, processed while the ray is above min_transmittance; the same arithmetic, so the same decisions) and
+// integrates ray_dim features per ray: the trace kernel's register budget (128, four waves per SIMD) has no room for 24 accumulators.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGrtNhtMaxRay = 32, kGrtNhtMaxIpd = 16;
+__device__ __forceinline__ float grt_nht_sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189535f); }
+__device__ __forceinline__ float grt_nht_cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
+struct NhtTetra {
+    f3 v0, e1, e2, e3, c23, gw0, gw1, gw2, gw3;
+    float inv_det;
+};
+__device__ __forceinline__ NhtTetra nht_tetra() {
+    NhtTetra t;
+    const float edge = 4.898979485566356f, face_h = 4.242640687119285f, face_in = 1.4142135623730951f;
+    t.v0 = mk3(0.5f * edge, -face_in, -1.f);
+    const f3 v1 = mk3(-0.5f * edge, -face_in, -1.f), v2 = mk3(0.f, face_h - face_in, -1.f), v3 = mk3(0.f, 0.f, 3.f);
+    t.e1 = v1 - t.v0; t.e2 = v2 - t.v0; t.e3 = v3 - t.v0;
+    t.c23 = cross(t.e2, t.e3);
+    t.inv_det = 1.f / dot(t.e1, t.c23);
+    t.gw1 = t.c23 * t.inv_det; t.gw2 = cross(t.e3, t.e1) * t.inv_det; t.gw3 = cross(t.e1, t.e2) * t.inv_det;
+    t.gw0 = (t.gw1 + t.gw2 + t.gw3) * -1.f;
+    return t;
+}
+__device__ __forceinline__ void nht_weights(const GrtTraceParams& P, const NhtTetra& t, f3 Pc, float (&wq)[4]) {
+    wq[0] = 1.f; wq[1] = wq[2] = wq[3] = 0.f;
+    if (P.nht_support == 1) {
+        const f3 d = Pc - t.v0;
+        wq[1] = dot(d, t.c23) * t.inv_det; wq[2] = dot(t.e1, cross(d, t.e3)) * t.inv_det; wq[3] = dot(t.e1, cross(t.e2, d)) * t.inv_det;
+        wq[0] = 1.f - wq[1] - wq[2] - wq[3];
+    }
+}
+__device__ __forceinline__ float nht_feature_value(const GrtTraceParams& P, const float* __restrict__ features, uint32_t id, int word) {
+    const size_t at = (size_t)id * P.nht_k + word;
+    return P.sph_half ? __half2float(reinterpret_cast<const __half*>(features)[at]) : features[at];
+}
+__device__ __forceinline__ void nht_base(const GrtTraceParams& P, const float* __restrict__ features, uint32_t id, const float (&wq)[4], float (&base)[kGrtNhtMaxIpd]) {
+    const int points = P.nht_support == 1 ? 4 : 1;
+#pragma unroll
+    for (int m = 0; m < kGrtNhtMaxIpd; ++m) {
+        base[m] = 0.f;
+        if (m < P.nht_ipd)
+            for (int k = 0; k < points; ++k) {
+                const float fv = nht_feature_value(P, features, id, k * P.nht_ipd + m);
+                base[m] = k == 0 ? fv * wq[0] : fmaf(wq[k], fv, base[m]);
+            }
+    }
+}
+// feature i of the activated vector and its derivative w.r.t. its base feature kb (sincos: i = kb*nf*2 + f*2 + {0,1}; siren: i = kb*nf + f)
+__device__ __forceinline__ void nht_activation(const GrtTraceParams& P, const float (&base)[kGrtNhtMaxIpd], int i, float& f, float& df, int& kb) {
+    const int nf = P.nht_nf;
+    if (P.nht_act == 0) { kb = i; f = base[kb < kGrtNhtMaxIpd ? kb : 0]; df = 1.f; }
+    else if (P.nht_act == 3) { kb = i; const float bv = base[kb < kGrtNhtMaxIpd ? kb : 0]; f = fmaxf(0.f, bv); df = bv > 0.f ? 1.f : 0.f; }
+    else if (P.nht_act == 2) {
+        kb = i / (2 * nf);
+        const int rem = i - kb * 2 * nf, fq = rem >> 1;
+        const float fr = (float)(fq + 1), ang = base[kb < kGrtNhtMaxIpd ? kb : 0] * fr;
+        const float sn = grt_nht_sin(ang), cs = grt_nht_cos(ang);
+        f = (rem & 1) ? cs : sn; df = (rem & 1) ? -fr * sn : fr * cs;
+    } else {
+        kb = i / nf;
+        const float fr = ldexpf(1.f, i - kb * nf), ang = base[kb < kGrtNhtMaxIpd ? kb : 0] * fr;
+        f = grt_nht_sin(ang); df = fr * grt_nht_cos(ang);
+    }
+}
+template <int DEG>
+__global__ __launch_bounds__(64) void grt_nht_fwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ features,
+                                                         const float* __restrict__ ray_o, const float* __restrict__ ray_d, float* __restrict__ out_feat,
+                                                         GrtHitLog log) {
+    const int lane = threadIdx.x;
+    const PixelBlock pb = pixel_block(P.W, P.H);
+    if (!pb.inside) return;
+    const int px = pb.bx * 8 + (lane & 7), py = pb.by * 8 + (lane >> 3);
+    const bool in_image = (px < P.W) && (py < P.H);
+    const size_t pix = in_image ? (size_t)py * P.W + px : 0;
+    const RayW r = make_ray(P, ray_o, ray_d, pix);
+    const NhtTetra tet = nht_tetra();
+    const int nr = P.nht_ray_dim;
+    float acc[kGrtNhtMaxRay];
+#pragma unroll
+    for (int i = 0; i < kGrtNhtMaxRay; ++i) acc[i] = 0.f;
+    float T = 1.f;
+    for (uint32_t round = 0; round < log.max_rounds; ++round) {
+        const uint32_t c = log.table[(size_t)pb.index * log.max_rounds + round];
+        if (c == 0xFFFFFFFFu) break;
+        const uint32_t* chunk = log.pool + (size_t)c * (kGrtLogSlots * 64) + lane;
+#pragma unroll 1
+        for (int i = 0; i < kGrtLogSlots; ++i) {
+            const uint32_t id = in_image ? chunk[i * 64] : 0xFFFFFFFFu;
+            if (!__any(id != 0xFFFFFFFFu)) break;
+            // the forward processed the round's CANDIDATES (not its ghosts) in this order while the ray was above min_transmittance
+            if (id != 0xFFFFFFFFu && !(id & kGrtGhostBit) && (T > P.min_transmittance)) {
+                const Particle p = load_particle(density12, id);
+                const HitGeom g = hit_geometry<DEG>(P, p, r);
+                if (g.accept) {
+                    const float weight = g.galpha * T;
+                    T *= (1.f - g.galpha);
+                    if (weight > 0.f) {
+                        const float pdot = -dot(g.grd, g.gro);
+                        float wq[4], base[kGrtNhtMaxIpd];
+                        nht_weights(P, tet, g.gro + g.grd * pdot, wq);
+                        nht_base(P, features, id, wq, base);
+#pragma unroll
+                        for (int k = 0; k < kGrtNhtMaxRay; ++k)
+                            if (k < nr) {
+                                float f, df;
+                                int kb;
+                                nht_activation(P, base, k, f, df, kb);
+                                acc[k] = fmaf(f, weight, acc[k]);
+                            }
+                    }
+                }
+            }
+        }
+    }
+    if (!in_image) return;
+#pragma unroll
+    for (int k = 0; k < kGrtNhtMaxRay; ++k)
+        if (k < nr) {
+            if (P.out_half) reinterpret_cast<__half*>(out_feat)[pix * nr + k] = __float2half(acc[k]);
+            else out_feat[pix * nr + k] = acc[k];
+        }
+}
 // backward from the forward's hit log — no traversal.
 // Every lane walks ITS chunk sequence (processed hits and ghosts in hit-distance order, GrtHitLog) with the state machine of the
 // reference's backward program (referenceBwdOptix.cu:123-166): a trace from startT + eps to endT returns the 16 nearest candidates
@@ -2391,6 +2517,13 @@ void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh
 void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, uint32_t* ranges) {
     if (n == 0) return;
     hipLaunchKernelGGL(grt_list_ranges_kernel, dim3(div_up(div_up(n, 4u), 256)), dim3(256), 0, s, n, num_blocks, sorted_keys, ranges);
+}
+
+void grt_launch_nht_fwd(hipStream_t s, const GrtTraceParams& P, const float* density12, const float* features, const float* ray_o, const float* ray_d,
+                        float* out_feat, const GrtHitLog& log) {
+    const dim3 grid(pixel_block_grid(P.W, P.H));
+    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_nht_fwd_kernel<D_>), grid, dim3(64), 0, s, P, reinterpret_cast<const float4*>(density12), features,
+                                                     ray_o, ray_d, out_feat, log));
 }
 
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,

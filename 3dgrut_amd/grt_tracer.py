@@ -12,7 +12,8 @@ import ctypes as C
 import torch
 
 from . import _abi
-from .gut_tracer import _conf_get, _ptr, _stream_ptr, fused_activations_requested, has_standard_activations
+from .gut_tracer import (_conf_get, _ptr, _stream_ptr, fused_activations_requested, has_standard_activations, nht_config_from_conf,
+                         ray_feature_dim_of)
 
 _DEFAULTS = dict(
     particle_kernel_degree=4, particle_kernel_min_response=0.0113, particle_kernel_min_alpha=1.0 / 255.0,
@@ -30,9 +31,14 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
         v = _conf_get(render, k, d)
         setattr(cfg, k, type(d)(v) if not isinstance(d, bool) else int(bool(v)))
     cfg.max_hits_per_trace = 16
+    # neural harmonic features ride on the Slang pipelines (configs/apps/*_3dgrt_mcmc_nht.yaml: pipeline_type referenceSlang,
+    # backward_pipeline_type referenceSlangBwd); SH radiance on the `reference` pipelines
+    nht = nht_config_from_conf(conf, cfg)
     pipeline = _conf_get(render, "pipeline_type", "reference")
-    if pipeline not in _SUPPORTED_PIPELINES:
-        raise NotImplementedError(f"3dgrut_amd: render.pipeline_type={pipeline!r} is not supported (only {_SUPPORTED_PIPELINES})")
+    allowed = ("referenceSlang", "reference") if nht else _SUPPORTED_PIPELINES
+    if pipeline not in allowed:
+        raise NotImplementedError(f"3dgrut_amd: render.pipeline_type={pipeline!r} is not supported (only {allowed} with model.feature_type "
+                                  f"{'nht' if nht else 'sh'})")
     prim = _conf_get(render, "primitive_type", "instances")
     if prim not in _SUPPORTED_PRIMITIVES:
         raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (only {_SUPPORTED_PRIMITIVES}: "
@@ -98,7 +104,7 @@ class _GrtNative:
         H, W, N = frame.height, frame.width, frame.num_particles
         opts = dict(dtype=torch.float32, device=dev)
         # (optixTracer.cpp:903-909: the integrated features are a half tensor with FEATURE_OUTPUT_HALF)
-        feat = torch.zeros((1, H, W, 3), dtype=torch.float16 if self.cfg.feature_output_half else torch.float32, device=dev)
+        feat = torch.zeros((1, H, W, ray_feature_dim_of(self.cfg)), dtype=torch.float16 if self.cfg.feature_output_half else torch.float32, device=dev)
         dns = torch.zeros((1, H, W, 1), **opts)
         hit = torch.zeros((1, H, W, 2), **opts)
         nrm = torch.zeros((1, H, W, 3), **opts)
@@ -238,8 +244,9 @@ class Tracer:
         H, W = int(rays_o.shape[1]), int(rays_o.shape[2])
         native = self.tracer_wrapper
         feats = gaussians.get_features()
-        if feats.shape[1] != 3 * native.ncoef:
-            raise ValueError(f"features have {feats.shape[1]} columns, expected {3 * native.ncoef}")
+        want = native.cfg.particle_feature_dim if native.cfg.feature_transform_type else 3 * native.ncoef
+        if feats.shape[1] != want:
+            raise ValueError(f"features have {feats.shape[1]} columns, expected {want}")
         frame = native.make_frame(frame_id, gaussians.n_active_features, self._min_transmittance, gaussians.num_gaussians, H, W, T)
         frame.keep_hits_for_backward = int(bool(train) and torch.is_grad_enabled() and self._replay)
         if self._fused_activations and has_standard_activations(gaussians):

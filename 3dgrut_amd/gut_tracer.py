@@ -56,6 +56,34 @@ def has_standard_activations(gaussians) -> bool:
             and gaussians.rotation_activation is torch.nn.functional.normalize)
 
 
+def nht_config_from_conf(conf, cfg) -> bool:
+    """model.feature_type = nht -> the six feature fields of GutConfig / GrtConfig (the macro set of threedgrut/model/features.py:133-175,
+    setup_3dgut.py:47-57 / setup_3dgrt.py); returns whether neural harmonic features are on."""
+    model = _conf_get(conf, "model")
+    if str(_conf_get(model, "feature_type", "sh")).lower() != "nht":
+        return False
+    nf = _conf_get(model, "nht_features")
+    act = _conf_get(nf, "activation")
+    interp = str(_conf_get(nf, "interpolation_type", "none")).lower()
+    if interp not in ("none", "barycentric"):
+        raise NotImplementedError(f"3dgrut_amd: nht_features.interpolation_type={interp!r} (the reference supports none / barycentric)")
+    points = 4 if interp == "barycentric" else 1
+    cfg.feature_transform_type = 1
+    cfg.particle_feature_dim = int(_conf_get(nf, "dim", 48))
+    cfg.interp_point_feature_dim = cfg.particle_feature_dim // points
+    cfg.feature_interpolation_support = 1 if points == 4 else 0
+    cfg.feature_activation_type = {"none": 0, "siren": 1, "sincos": 2, "relu": 3}[str(_conf_get(act, "type", "sincos")).lower()]
+    cfg.feature_activation_num_frequencies = int(_conf_get(act, "num_frequencies", 1))
+    return True
+
+
+def ray_feature_dim_of(cfg) -> int:
+    if not cfg.feature_transform_type:
+        return 3
+    a, n = cfg.feature_activation_type, cfg.feature_activation_num_frequencies
+    return cfg.interp_point_feature_dim * (2 * n if a == 2 else (n if a == 1 else 1))
+
+
 def gut_config_from_conf(conf) -> _abi.GutConfig:
     """conf.render.* -> GutConfig (the keys setup_3dgut.py:41-95 turns into -D macros)."""
     render = _conf_get(conf, "render")
@@ -67,21 +95,7 @@ def gut_config_from_conf(conf) -> _abi.GutConfig:
     for k, d in _SPLAT_DEFAULTS.items():
         v = _conf_get(splat, k, d)
         setattr(cfg, k, type(d)(v) if not isinstance(d, bool) else int(bool(v)))
-    # neural harmonic features (model.feature_type = nht; the macro set of threedgrut/model/features.py:133-175, setup_3dgut.py:47-57)
-    model = _conf_get(conf, "model")
-    if str(_conf_get(model, "feature_type", "sh")).lower() == "nht":
-        nf = _conf_get(model, "nht_features")
-        act = _conf_get(nf, "activation")
-        interp = str(_conf_get(nf, "interpolation_type", "none")).lower()
-        if interp not in ("none", "barycentric"):
-            raise NotImplementedError(f"3dgrut_amd: nht_features.interpolation_type={interp!r} (the reference supports none / barycentric)")
-        points = 4 if interp == "barycentric" else 1
-        cfg.feature_transform_type = 1
-        cfg.particle_feature_dim = int(_conf_get(nf, "dim", 48))
-        cfg.interp_point_feature_dim = cfg.particle_feature_dim // points
-        cfg.feature_interpolation_support = 1 if points == 4 else 0
-        cfg.feature_activation_type = {"none": 0, "siren": 1, "sincos": 2, "relu": 3}[str(_conf_get(act, "type", "sincos")).lower()]
-        cfg.feature_activation_num_frequencies = int(_conf_get(act, "num_frequencies", 1))
+    nht_config_from_conf(conf, cfg)
     # fp16 feature I/O (setup_3dgut.py:60-61): run-time switches here, compile-time macros in the reference
     cfg.particle_feature_half = int(bool(_conf_get(render, "particle_feature_half", False)))
     cfg.feature_output_half = int(bool(_conf_get(render, "feature_output_half", False)))
@@ -181,11 +195,7 @@ class _GutNative:
 
     @property
     def ray_feature_dim(self):
-        c = self.cfg
-        if not c.feature_transform_type:
-            return 3
-        a, n = c.feature_activation_type, c.feature_activation_num_frequencies
-        return c.interp_point_feature_dim * (2 * n if a == 2 else (n if a == 1 else 1))
+        return ray_feature_dim_of(self.cfg)
 
     def trace_nht(self, frame, particle_density, particle_features, ray_ori, ray_dir):
         """Forward of the neural-harmonic-features configuration (GutConfig::feature_transform_type 1): [H,W,ray_dim+1] features + opacity."""

@@ -289,6 +289,16 @@ typedef struct GrtConfig {
      * `features` input of the backward) as [H,W,3] IEEE half; arithmetic and gradients stay fp32 */
     int32_t particle_feature_half;
     int32_t feature_output_half;
+    /* Neural harmonic features (model.feature_type = nht with render.pipeline_type referenceSlang / referenceSlangBwd:
+     * referenceSlangOptix.cu:103-186, referenceSlangBwdOptix.cu:70-185), same fields and meaning as in GutConfig: particle_sph is the
+     * feature buffer [N, particle_feature_dim], out_features / features are [H, W, ray_feature_dim] (at most 32), grad_particle_sph the
+     * feature buffer's gradient; enable_normals must be 0.  All zero = SH radiance (the `reference` pipeline). */
+    int32_t feature_transform_type;
+    int32_t particle_feature_dim;
+    int32_t interp_point_feature_dim;
+    int32_t feature_interpolation_support;
+    int32_t feature_activation_type;
+    int32_t feature_activation_num_frequencies;
 } GrtConfig;
 
 typedef struct GrtFrame {

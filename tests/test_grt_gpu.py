@@ -444,3 +444,38 @@ def test_trim_releases_the_scratch_and_requires_a_new_bvh():
         tr.render(g, batch)
     tr.build_acc(g, rebuild=True)
     assert torch.equal(tr.render(g, batch)["pred_features"].detach(), a)
+
+
+NHT_CONF = {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1}, "interpolation_type": "barycentric"}}
+
+
+def _nht_tracer(**render_kw):
+    gt = importlib.import_module("3dgrut_amd.grt_tracer")
+    return gt.Tracer({"render": dict({"pipeline_type": "referenceSlang"}, **render_kw), "model": NHT_CONF})
+
+
+@pytest.mark.parametrize("half", [False, True])
+def test_nht_forward_matches_oracle(half):
+    """model.feature_type = nht on the Slang pipeline (referenceSlangOptix.cu): [1,H,W,24] ray features against orc_grt_trace_nht_fwd
+    fed the GPU's proxies (same hit sequences: the trace kernel is the SH one, the features are integrated from its hit log)."""
+    import torch
+    n, w, h = 3000, 64, 40
+    scene = _scene(n, w, h, 0.06)
+    feats = np.random.default_rng(12).uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)
+    tr = _nht_tracer(**(dict(particle_feature_half=True, feature_output_half=True) if half else {}))
+    g = syn.SimpleGaussians(scene["density12"], feats, requires_grad=False)
+    tr.build_acc(g, rebuild=True)
+    with torch.no_grad():
+        out = tr.render(g, torch_batch(scene["batch"], "cuda"))
+    nat = tr.tracer_wrapper
+    inst = nat.instances(n, "cuda").cpu().numpy()
+    aabb = np.array(list(nat.stats().scene_aabb), np.float32)
+    ofeats = oracle.round_to_half(feats) if half else feats
+    ora = oracle.grt_forward_nht(oracle.default_grt_config(), scene["density12"], ofeats, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=aabb)
+    f = out["pred_features"][0].cpu().numpy()
+    assert f.shape == (h, w, 24) and out["pred_features"].dtype == torch.float32
+    ulp = np.spacing(np.abs(f).astype(np.float16)).astype(np.float32) if half else 0.0
+    flips = (out["hits_count"][0].cpu().numpy() != ora["hit_count"])[..., 0]
+    bad = (np.abs(f - ora["features"]) > 1e-4 + 0.5 * ulp).any(-1) | (np.abs(out["pred_opacity"][0].cpu().numpy() - ora["density"])[..., 0] > 1e-4)
+    assert flips.mean() <= 5e-3 and (bad & ~flips).mean() <= 2e-3, f"{bad.sum()} pixels beyond tolerance, {flips.sum()} flips"
+    assert np.abs(f).max() > 0.3
