@@ -78,6 +78,7 @@ static int grt_validate(const GrtConfig& c) {
         const int nf = c.feature_activation_num_frequencies;
         const int nr = c.interp_point_feature_dim * (c.feature_activation_type == 2 ? 2 * nf : (c.feature_activation_type == 1 ? nf : 1));
         GRUT_REQUIRE(nf >= 1 && nr >= 1 && nr <= 32, "ray feature dim %d: 1..32 supported", nr);
+        GRUT_REQUIRE(c.particle_feature_dim + 11 <= 64, "particle_feature_dim %d: at most 53 (one wave carries a hit's gradient words)", c.particle_feature_dim);
     }
     if (c.max_hits_per_trace != 0 && c.max_hits_per_trace != kGrtMaxHits) {
         set_last_error("max_hits_per_trace=%d: the hit buffer is %d entries (PipelineParameters::MaxNumHitPerTrace)", c.max_hits_per_trace, kGrtMaxHits);

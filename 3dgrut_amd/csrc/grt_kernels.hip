@@ -1157,93 +1157,6 @@ __device__ __forceinline__ void process_hit_bwd(const GrtTraceParams& P, const R
     st.rad = rad; st.T = T; st.depth = depth;
 }
 
-// The reference's backward program, round by round.  Without a hit log it serves every ray (render.backward_hit_replay = false, or
-// a backward that is not the last logged forward's); with one it serves the rays the forward flagged (kGrtRederiveRay: a chunk could
-// not hold all the ghosts of one of their rounds) — or every ray if the log overflowed.  UNI: the frame's packet lists are at hand, a
-// round is a window scan of the packet's list (list_round: same candidate sets and order as the tree walk) — with one or two live
-// lanes per wave the window is those rays' own, a few dozen entries.
-template <int DEG, bool UNI>
-__global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
-                                                           const float* __restrict__ sph, const float* __restrict__ ray_o,
-                                                           const float* __restrict__ ray_d, const float* __restrict__ in_rad,
-                                                           const float* __restrict__ in_dns, const float* __restrict__ in_hit2,
-                                                           const float* __restrict__ g_rad, const float* __restrict__ g_dns,
-                                                           const float* __restrict__ g_hit, float* __restrict__ g_density12,
-                                                           float* __restrict__ g_sph, const uint32_t* __restrict__ log_state,
-                                                           const uint32_t* __restrict__ log_flags, GrtLists lists) {
-    __shared__ uint32_t s_stack[UNI ? 1 : kGrtStackDepth];
-    __shared__ float s_hit_t[kGrtMaxHits * 64];      // (UNI: a round's staged list entries live here while it is scanned)
-    __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
-    static_assert(kGrtMaxHits * 64 * 4 >= 64 * 3 * 16, "the staged list entries must fit the parked hit distances");
-    const int lane = threadIdx.x;
-    const PixelBlock pb = pixel_block(P.W, P.H);
-    if (!pb.inside) return;
-    const int px = pb.bx * 8 + (lane & 7), py = pb.by * 8 + (lane >> 3);
-    const bool in_image = (px < P.W) && (py < P.H);
-    const size_t pix = in_image ? (size_t)py * P.W + px : 0;  // out-of-image lanes shadow pixel 0 and never write
-    bool running = in_image;
-    if (log_state && log_state[1] == 0u) running = running && (log_flags[pix] & kGrtRederiveRay) != 0u;   // the replay serves the rest
-    if (!__any(running)) return;
-    const bool handled = running;
-    unsigned long long dbg_sig = 0ull;
-    uint32_t dbg_n = 0u;
-    const RayW r = make_ray(P, ray_o, ray_d, pix);
-    float basis[16];
-    sh_basis16(P.sph_degree, r.d, basis);
-    const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
-
-    BwdRay ray_state;
-    ray_state.rad_fin = load_radiance(P, in_rad, pix);
-    ray_state.T_fin = 1.f - in_dns[pix];
-    ray_state.depth_fin = in_hit2[2 * pix];
-    const float max_hit = in_hit2[2 * pix + 1];
-    ray_state.rad_grad = mk3(g_rad[3 * pix], g_rad[3 * pix + 1], g_rad[3 * pix + 2]);
-    ray_state.T_grad = -g_dns[pix];
-    ray_state.depth_grad = g_hit ? g_hit[pix] : 0.f;
-    ray_state.rad = mk3(0.f, 0.f, 0.f);
-    ray_state.T = 1.f;
-    ray_state.depth = 0.f;
-    float tEnter, tExit;
-    scene_interval(bvh.scene, r, tEnter, tExit);
-    constexpr float eps = 1e-9f;
-    float startT = fmaxf(0.f, tEnter - eps);
-    const float endT = fminf(max_hit, tExit) + eps;
-    uint32_t list_end = 0u, list_start = 0u;
-    GrtCone cone = {0.f, 0.f, 1.f, -1.f, 0.f, 1.f, 0.f, 0.f};
-    float dmin = 1.f, dmax = 1.f;
-    if (UNI) {
-        list_start = lists.ranges[2 * (size_t)pb.index];
-        list_end = lists.ranges[2 * (size_t)pb.index + 1];
-        cone = lists.block_cones[pb.index];
-        dmin = __uint_as_float(lists.dir_len_enc[0]); dmax = __uint_as_float(lists.dir_len_enc[1]);
-    }
-    while (true) {
-        running = running && (startT < endT);
-        if (!__any(running)) break;
-        TraceCounters tc;
-        {
-            HitBuffer buf;
-            if (UNI) list_round<false, kGrtMaxHits>(lists, cone, dmin, dmax, list_end, list_start, r, startT + eps, endT, running, lane,
-                                                    reinterpret_cast<float4*>(s_hit_t), buf, tc);
-            else trace_round<false>(bvh, r, startT + eps, endT, running, lane, s_stack, buf, tc);
-            if (buf.id[0] == 0xFFFFFFFFu) running = false;
-            buf.store(s_hit_t, s_hit_id, lane);
-        }
-#pragma unroll 1
-        for (int i = 0; i < kGrtMaxHits; ++i) {
-            const uint32_t id = s_hit_id[i * 64 + lane];
-            const bool process = running && (id != 0xFFFFFFFFu);
-            if (!__any(process)) break;  // ascending list: nothing further for any lane
-            if (process) {
-                process_hit_bwd<DEG>(P, r, basis, nact, id, density12, sph, ray_state, g_density12, g_sph);
-                startT = fmaxf(startT, s_hit_t[i * 64 + lane]);
-                dbg_n++; dbg_sig += (unsigned long long)id * 0x9E3779B97F4A7C15ull + 1ull;
-            }
-        }
-    }
-    if (P.bwd_sig && handled) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Neural harmonic features (model.feature_type = nht, the Slang pipelines: referenceSlangOptix.cu:103-186): the per-ray features are not a
 // per-particle colour but are interpolated per hit at the hit's canonical intersection (neuralHarmonicFeaturesParticle.slang:146-196,
@@ -1370,6 +1283,226 @@ __global__ __launch_bounds__(64) void grt_nht_fwd_kernel(GrtTraceParams P, const
             else out_feat[pix * nr + k] = acc[k];
         }
 }
+// One hit of the Slang backward pipeline with neural harmonic features (referenceSlangBwdOptix.cu:118-178): particleDensityHit,
+// particleFeaturesFromBuffer, particleFeaturesIntegrateBwdToBuffer (the lerp form un-blended front to back) and
+// particleDensityProcessHitBwdToBuffer with the canonical intersection's gradient — the reverse mode restated in oracle/grt_oracle.c
+// (orc_grt_trace_nht_bwd; same formulas as the 3DGUT nht backward, which float64 autograd pins).  Advances the ray state and returns the
+// hit's gradient as {11 geometric terms, the four barycentric weights, d L / d base feature}: the feature rows' gradient is
+// wq[k] * gbase[n] for row word k * ipd + n.
+struct NhtBwdRay {
+    float Cb[kGrtNhtMaxRay], gC[kGrtNhtMaxRay];   // "behind" features (start at the forward's result) and their running upstream gradient
+    float Tb, gT, Db, gD;
+};
+template <int DEG>
+__device__ __forceinline__ bool nht_hit_bwd(const GrtTraceParams& P, const RayW& r, const Particle& p, const HitGeom& g, const float* __restrict__ features,
+                                            uint32_t id, const NhtTetra& tet, NhtBwdRay& st, float (&gd)[11], float (&wq)[4], float (&gbase)[kGrtNhtMaxIpd]) {
+#pragma unroll
+    for (int m = 0; m < kGrtNhtMaxIpd; ++m) gbase[m] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) gd[k] = 0.f;
+    wq[0] = 1.f; wq[1] = wq[2] = wq[3] = 0.f;
+    if (!g.accept) return false;
+    const float alpha = g.galpha;
+    const float pdot = -dot(g.grd, g.gro);
+    const f3 grdd = g.grd * pdot;
+    const f3 grds = p.scl * grdd;
+    const float gsq = dot(grds, grds);
+    const float hitT = sqrtf(gsq);
+    nht_weights(P, tet, g.gro + grdd, wq);
+    float base[kGrtNhtMaxIpd];
+    nht_base(P, features, id, wq, base);
+    const float w = 1.f / (1.f - alpha);
+    const bool contributes = alpha > 0.f;
+    float dalpha = 0.f;
+#pragma unroll
+    for (int i = 0; i < kGrtNhtMaxRay; ++i)
+        if (i < P.nht_ray_dim && contributes) {
+            float f, df;
+            int kb;
+            nht_activation(P, base, i, f, df, kb);
+            st.Cb[i] = (st.Cb[i] - f * alpha) * w;
+            dalpha = fmaf(f - st.Cb[i], st.gC[i], dalpha);
+            const float gf = alpha * st.gC[i];
+            st.gC[i] *= (1.f - alpha);
+#pragma unroll
+            for (int m = 0; m < kGrtNhtMaxIpd; ++m)
+                if (m == kb) gbase[m] = fmaf(df, gf, gbase[m]);
+        }
+    f3 dP = mk3(0.f, 0.f, 0.f);
+    if (P.nht_support == 1) {
+        float dw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < kGrtNhtMaxIpd; ++m)
+            if (m < P.nht_ipd)
+                for (int k = 0; k < 4; ++k) dw[k] = fmaf(nht_feature_value(P, features, id, k * P.nht_ipd + m), gbase[m], dw[k]);
+        dP = tet.gw0 * dw[0] + tet.gw1 * dw[1] + tet.gw2 * dw[2] + tet.gw3 * dw[3];
+    }
+    st.Tb *= w;
+    st.Db = (st.Db - hitT * alpha) * w;
+    dalpha += (hitT - st.Db) * st.gD - st.Tb * st.gT;
+    const float ddepth = alpha * st.gD;
+    st.gD *= (1.f - alpha);
+    st.gT *= (1.f - alpha);
+    float dres = 0.f, ddens = 0.f;
+    if (g.gres * p.density < P.max_alpha) { dres = p.density * dalpha; ddens = g.gres * dalpha; }
+    const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, dres);
+    const f3 grdsGrd = gsq > 0.f ? grds * (ddepth / hitT) : mk3(0.f, 0.f, 0.f);
+    const f3 gsclHit = grdd * grdsGrd;
+    const float sdot = dot(grdsGrd * p.scl, g.grd);
+    const float gdP = dot(g.grd, dP);
+    const f3 grdHit = p.scl * grdsGrd * pdot - g.gro * sdot + dP * pdot - g.gro * gdP;
+    const f3 groHit = g.grd * (-sdot) + dP - g.grd * gdP;
+    const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
+    const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x, gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
+    const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z, gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
+    const f3 groTot = groGrd + groHit;
+    const f3 is2 = g.giscl * g.giscl;
+    const f3 gsclGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;
+    const f3 gposcrGrd = g.giscl * groTot;
+    const f3 gposcGrd = mul_cols(p.rotT, gposcrGrd);
+    const float4 gq1 = matmul_bw_quat(g.gposc, gposcrGrd, p.quat);
+    const f3 dn = grdGrd + grdHit;
+    const float l2 = dot(g.grdu, g.grdu);
+    f3 grduGrd = mk3(0.f, 0.f, 0.f);
+    if (l2 > 0.f) {
+        const float il = 1.f / sqrtf(l2);
+        grduGrd = dn * il - g.grdu * (il * il * il * dot(dn, g.grdu));
+    }
+    const f3 sclGrd = gsclHit + gsclGro + mk3(-g.rdr.x * is2.x, -g.rdr.y * is2.y, -g.rdr.z * is2.z) * grduGrd;
+    const float4 gq2 = matmul_bw_quat(r.d, g.giscl * grduGrd, p.quat);
+    gd[0] = -gposcGrd.x; gd[1] = -gposcGrd.y; gd[2] = -gposcGrd.z; gd[3] = ddens;
+    gd[4] = gq1.x + gq2.x; gd[5] = gq1.y + gq2.y; gd[6] = gq1.z + gq2.z; gd[7] = gq1.w + gq2.w;
+    gd[8] = sclGrd.x; gd[9] = sclGrd.y; gd[10] = sclGrd.z;
+    return contributes;
+}
+__device__ __forceinline__ NhtBwdRay nht_bwd_ray_init(const GrtTraceParams& P, bool use, size_t pix, const float* __restrict__ in_feat,
+                                                      const float* __restrict__ in_dns, const float* __restrict__ in_hit2,
+                                                      const float* __restrict__ g_feat, const float* __restrict__ g_dns, const float* __restrict__ g_hit) {
+    NhtBwdRay st;
+    const int nr = P.nht_ray_dim;
+#pragma unroll
+    for (int i = 0; i < kGrtNhtMaxRay; ++i) {
+        const bool u = use && i < nr;
+        st.Cb[i] = u ? (P.out_half ? __half2float(reinterpret_cast<const __half*>(in_feat)[pix * nr + i]) : in_feat[pix * nr + i]) : 0.f;
+        st.gC[i] = u ? g_feat[pix * nr + i] : 0.f;
+    }
+    st.Tb = 1.f - in_dns[pix]; st.gT = -g_dns[pix];
+    st.Db = in_hit2[2 * pix]; st.gD = g_hit ? g_hit[pix] : 0.f;
+    return st;
+}
+// lane-level version for the traversal backward (the rays the replay does not serve): the reference's per-hit atomics
+template <int DEG>
+__device__ __forceinline__ void process_hit_bwd_nht(const GrtTraceParams& P, const RayW& r, uint32_t id, const float4* __restrict__ density12,
+                                                    const float* __restrict__ features, const NhtTetra& tet, NhtBwdRay& st,
+                                                    float* __restrict__ g_density12, float* __restrict__ g_features) {
+    const Particle p = load_particle(density12, id);
+    const HitGeom g = hit_geometry<DEG>(P, p, r);
+    float gd[11], wq[4], gbase[kGrtNhtMaxIpd];
+    if (!nht_hit_bwd<DEG>(P, r, p, g, features, id, tet, st, gd, wq, gbase)) return;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) atomicAdd(g_density12 + 12 * (size_t)id + k, gd[k]);
+    const int points = P.nht_support == 1 ? 4 : 1;
+    for (int k = 0; k < points; ++k)
+#pragma unroll
+        for (int m = 0; m < kGrtNhtMaxIpd; ++m)
+            if (m < P.nht_ipd) atomicAdd(g_features + (size_t)id * P.nht_k + k * P.nht_ipd + m, wq[k] * gbase[m]);
+}
+
+// The reference's backward program, round by round.  Without a hit log it serves every ray (render.backward_hit_replay = false, or
+// a backward that is not the last logged forward's); with one it serves the rays the forward flagged (kGrtRederiveRay: a chunk could
+// not hold all the ghosts of one of their rounds) — or every ray if the log overflowed.  UNI: the frame's packet lists are at hand, a
+// round is a window scan of the packet's list (list_round: same candidate sets and order as the tree walk) — with one or two live
+// lanes per wave the window is those rays' own, a few dozen entries.
+template <int DEG, bool UNI, bool NHT = false>
+__global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
+                                                           const float* __restrict__ sph, const float* __restrict__ ray_o,
+                                                           const float* __restrict__ ray_d, const float* __restrict__ in_rad,
+                                                           const float* __restrict__ in_dns, const float* __restrict__ in_hit2,
+                                                           const float* __restrict__ g_rad, const float* __restrict__ g_dns,
+                                                           const float* __restrict__ g_hit, float* __restrict__ g_density12,
+                                                           float* __restrict__ g_sph, const uint32_t* __restrict__ log_state,
+                                                           const uint32_t* __restrict__ log_flags, GrtLists lists) {
+    __shared__ uint32_t s_stack[UNI ? 1 : kGrtStackDepth];
+    __shared__ float s_hit_t[kGrtMaxHits * 64];      // (UNI: a round's staged list entries live here while it is scanned)
+    __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
+    static_assert(kGrtMaxHits * 64 * 4 >= 64 * 3 * 16, "the staged list entries must fit the parked hit distances");
+    const int lane = threadIdx.x;
+    const PixelBlock pb = pixel_block(P.W, P.H);
+    if (!pb.inside) return;
+    const int px = pb.bx * 8 + (lane & 7), py = pb.by * 8 + (lane >> 3);
+    const bool in_image = (px < P.W) && (py < P.H);
+    const size_t pix = in_image ? (size_t)py * P.W + px : 0;  // out-of-image lanes shadow pixel 0 and never write
+    bool running = in_image;
+    if (log_state && log_state[1] == 0u) running = running && (log_flags[pix] & kGrtRederiveRay) != 0u;   // the replay serves the rest
+    if (!__any(running)) return;
+    const bool handled = running;
+    unsigned long long dbg_sig = 0ull;
+    uint32_t dbg_n = 0u;
+    const RayW r = make_ray(P, ray_o, ray_d, pix);
+    float basis[16];
+    sh_basis16(P.sph_degree, r.d, basis);
+    const int nact = min((P.sph_degree + 1) * (P.sph_degree + 1), P.ncoef);
+
+    BwdRay ray_state;
+    NhtBwdRay nht_state;   // (NHT: in_rad / g_rad are the [H,W,ray_dim] feature image and its gradient, sph / g_sph the feature buffer and its gradient)
+    NhtTetra tet;
+    const float max_hit = in_hit2[2 * pix + 1];
+    if constexpr (NHT) {
+        nht_state = nht_bwd_ray_init(P, in_image, pix, in_rad, in_dns, in_hit2, g_rad, g_dns, g_hit);
+        tet = nht_tetra();
+    } else {
+        ray_state.rad_fin = load_radiance(P, in_rad, pix);
+        ray_state.T_fin = 1.f - in_dns[pix];
+        ray_state.depth_fin = in_hit2[2 * pix];
+        ray_state.rad_grad = mk3(g_rad[3 * pix], g_rad[3 * pix + 1], g_rad[3 * pix + 2]);
+        ray_state.T_grad = -g_dns[pix];
+        ray_state.depth_grad = g_hit ? g_hit[pix] : 0.f;
+        ray_state.rad = mk3(0.f, 0.f, 0.f);
+        ray_state.T = 1.f;
+        ray_state.depth = 0.f;
+    }
+    float tEnter, tExit;
+    scene_interval(bvh.scene, r, tEnter, tExit);
+    constexpr float eps = 1e-9f;
+    float startT = fmaxf(0.f, tEnter - eps);
+    const float endT = fminf(max_hit, tExit) + eps;
+    uint32_t list_end = 0u, list_start = 0u;
+    GrtCone cone = {0.f, 0.f, 1.f, -1.f, 0.f, 1.f, 0.f, 0.f};
+    float dmin = 1.f, dmax = 1.f;
+    if (UNI) {
+        list_start = lists.ranges[2 * (size_t)pb.index];
+        list_end = lists.ranges[2 * (size_t)pb.index + 1];
+        cone = lists.block_cones[pb.index];
+        dmin = __uint_as_float(lists.dir_len_enc[0]); dmax = __uint_as_float(lists.dir_len_enc[1]);
+    }
+    while (true) {
+        running = running && (startT < endT);
+        if (!__any(running)) break;
+        TraceCounters tc;
+        {
+            HitBuffer buf;
+            if (UNI) list_round<false, kGrtMaxHits>(lists, cone, dmin, dmax, list_end, list_start, r, startT + eps, endT, running, lane,
+                                                    reinterpret_cast<float4*>(s_hit_t), buf, tc);
+            else trace_round<false>(bvh, r, startT + eps, endT, running, lane, s_stack, buf, tc);
+            if (buf.id[0] == 0xFFFFFFFFu) running = false;
+            buf.store(s_hit_t, s_hit_id, lane);
+        }
+#pragma unroll 1
+        for (int i = 0; i < kGrtMaxHits; ++i) {
+            const uint32_t id = s_hit_id[i * 64 + lane];
+            const bool process = running && (id != 0xFFFFFFFFu);
+            if (!__any(process)) break;  // ascending list: nothing further for any lane
+            if (process) {
+                if constexpr (NHT) process_hit_bwd_nht<DEG>(P, r, id, density12, sph, tet, nht_state, g_density12, g_sph);
+                else process_hit_bwd<DEG>(P, r, basis, nact, id, density12, sph, ray_state, g_density12, g_sph);
+                startT = fmaxf(startT, s_hit_t[i * 64 + lane]);
+                dbg_n++; dbg_sig += (unsigned long long)id * 0x9E3779B97F4A7C15ull + 1ull;
+            }
+        }
+    }
+    if (P.bwd_sig && handled) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
+}
+
 // backward from the forward's hit log — no traversal.
 // Every lane walks ITS chunk sequence (processed hits and ghosts in hit-distance order, GrtHitLog) with the state machine of the
 // reference's backward program (referenceBwdOptix.cu:123-166): a trace from startT + eps to endT returns the 16 nearest candidates
@@ -1554,6 +1687,106 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     }
     if (P.bwd_sig && replayed) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
     // rays whose ghost premise failed (see GhostLog): their gradient may miss a hit the reference's backward would have been offered
+    const unsigned long long broken = __ballot(premise_broken);
+    if (broken && lane == 0) atomicAdd(&log.state[2], (uint32_t)__popcll(broken));
+}
+
+// The replay backward for neural harmonic features (referenceSlangBwdOptix.cu:70-185): the log walk and the backward program's trace
+// state machine of grt_replay_bwd_kernel, per hit nht_hit_bwd instead of the reference pipeline's processHitBwd, and the same hit-major
+// transposed atomics: lane j < K carries word j of the particle's feature-row gradient (= barycentric weight x d L / d base feature,
+// both left in LDS by the hit's lane), lanes K .. K + 10 its 11 geometric terms.  (K + 11 <= 64.)
+constexpr int kNhtTermStride = 33;   // per lane: 11 geometric terms + 4 barycentric weights + 16 base-feature gradients, odd stride
+template <int DEG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void grt_replay_nht_bwd_kernel(
+    GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ features, const float* __restrict__ ray_o,
+    const float* __restrict__ ray_d, const float* __restrict__ in_feat, const float* __restrict__ in_dns, const float* __restrict__ in_hit2,
+    const float* __restrict__ g_feat, const float* __restrict__ g_dns, const float* __restrict__ g_hit, float* __restrict__ g_density12,
+    float* __restrict__ g_features, GrtHitLog log, const float* __restrict__ inst, const float* __restrict__ scene) {
+    __shared__ float s_terms[64 * kNhtTermStride];
+    if (log.state[1] != 0u) return;  // the log overflowed: the traversal kernel handles this frame
+    const int lane = threadIdx.x;
+    const PixelBlock pb = pixel_block(P.W, P.H);
+    if (!pb.inside) return;
+    const int px = pb.bx * 8 + (lane & 7), py = pb.by * 8 + (lane >> 3);
+    const bool in_image = (px < P.W) && (py < P.H);
+    const size_t pix = in_image ? (size_t)py * P.W + px : 0;
+    const RayW r = make_ray(P, ray_o, ray_d, pix);
+    const NhtTetra tet = nht_tetra();
+    NhtBwdRay st = nht_bwd_ray_init(P, in_image, pix, in_feat, in_dns, in_hit2, g_feat, g_dns, g_hit);
+    const bool replayed = in_image && !(log.ray_flags[pix] & kGrtRederiveRay);
+    // the scatter's lane roles
+    const int K = P.nht_k, ipd = P.nht_ipd;
+    const bool row_lane = lane < K;
+    const int kq = row_lane ? lane / ipd : 0, nq = row_lane ? lane - kq * ipd : 0;
+    const bool word_used = lane < K + 11;
+    float* const row_base = row_lane ? g_features + lane : g_density12 + (word_used ? lane - K : 0);
+    const uint32_t row_stride = row_lane ? (uint32_t)K : 12u;
+    constexpr float eps = 1e-9f;
+    float tEnter, tExit;
+    scene_interval(scene, r, tEnter, tExit);
+    const float endT = fminf(in_hit2[2 * pix + 1], tExit) + eps;
+    float bw_start = fmaxf(0.f, tEnter - eps), bw_max = bw_start;
+    uint32_t bw_cnt = 0u;
+    float fw_start0 = bw_start, fw_start1 = bw_start, fw_start2 = bw_start, fw_last = bw_start;
+    bool premise_broken = false;
+    unsigned long long dbg_sig = 0ull;
+    uint32_t dbg_n = 0u;
+    for (uint32_t round = 0; round < log.max_rounds; ++round) {
+        const uint32_t c = log.table[(size_t)pb.index * log.max_rounds + round];
+        if (c == 0xFFFFFFFFu) break;
+        const uint32_t* chunk = log.pool + (size_t)c * (kGrtLogSlots * 64) + lane;
+        fw_start2 = fw_start1; fw_start1 = fw_start0; fw_start0 = fw_last;
+        if (replayed && chunk[0] != 0xFFFFFFFFu && bw_start < fw_start2) premise_broken = true;
+#pragma unroll 1
+        for (int i = 0; i < kGrtLogSlots; ++i) {
+            uint32_t id = replayed ? chunk[i * 64] : 0xFFFFFFFFu;
+            if (!__any(id != 0xFFFFFFFFu)) break;
+            bool contributes = false;
+            if (id != 0xFFFFFFFFu) {
+                const bool ghost = (id & kGrtGhostBit) != 0u;
+                id &= ~kGrtGhostBit;
+                const Cand cd = candidate(inst + 12 * (size_t)id, r);
+                if (!ghost) fw_last = fmaxf(fw_last, cd.t);
+                const float tmin = bw_start + eps;
+                if (cd.ok && (cd.t > tmin) && (cd.t < endT) && (cd.tfar >= tmin) && (cd.tnear <= endT)) {
+                    bw_max = fmaxf(bw_max, cd.t);
+                    if (++bw_cnt == (uint32_t)kGrtMaxHits) { bw_start = bw_max; bw_cnt = 0u; }
+                    dbg_n++; dbg_sig += (unsigned long long)id * 0x9E3779B97F4A7C15ull + 1ull;
+                    const Particle p = load_particle(density12, id);
+                    const HitGeom g = hit_geometry<DEG>(P, p, r);
+                    float gd[11], wq[4], gbase[kGrtNhtMaxIpd];
+                    contributes = nht_hit_bwd<DEG>(P, r, p, g, features, id, tet, st, gd, wq, gbase);
+                    if (contributes) {
+                        float* const tw = s_terms + lane * kNhtTermStride;
+#pragma unroll
+                        for (int k = 0; k < 11; ++k) tw[k] = gd[k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) tw[11 + k] = wq[k];
+#pragma unroll
+                        for (int m = 0; m < kGrtNhtMaxIpd; ++m) tw[15 + m] = gbase[m];
+                    }
+                }
+            }
+            unsigned long long m = __ballot(contributes);
+            __syncthreads();
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)id, src);
+                unsigned long long same = __ballot(contributes && id == pid);   // lanes that hold the same particle in this slot go out together
+                m &= ~same;
+                float v = 0.f;
+                while (same) {
+                    const int s2 = __ffsll((long long)same) - 1;
+                    same &= same - 1;
+                    const float* tw = s_terms + s2 * kNhtTermStride;
+                    v += row_lane ? tw[11 + kq] * tw[15 + nq] : tw[word_used ? lane - K : 0];
+                }
+                if (word_used && v != 0.f) atomicAdd(row_base + (size_t)pid * row_stride, v);
+            }
+            __syncthreads();
+        }
+    }
+    if (P.bwd_sig && replayed) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
     const unsigned long long broken = __ballot(premise_broken);
     if (broken && lane == 0) atomicAdd(&log.state[2], (uint32_t)__popcll(broken));
 }
@@ -2558,6 +2791,20 @@ void grt_launch_trace_bwd(hipStream_t s, hipStream_t s_rederive, const GrtTraceP
     GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_, UNI_>), grid, dim3(64), 0, s_rederive, P, bvh,                   \
                                                      reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns, \
                                                      g_hit, g_density12, g_sph, log.pool ? log.state : nullptr, log.pool ? log.ray_flags : nullptr, lists))
+#define GRT_BWD_LAUNCH_NHT(UNI_)                                                                                                                 \
+    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_trace_bwd_kernel<D_, UNI_, true>), grid, dim3(64), 0, s_rederive, P, bvh,             \
+                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad, g_dns, \
+                                                     g_hit, g_density12, g_sph, log.pool ? log.state : nullptr, log.pool ? log.ray_flags : nullptr, lists))
+    if (P.nht) {   // neural harmonic features: the Slang backward pipeline (sph / g_sph = feature buffer and its gradient, rad / g_rad = [H,W,ray_dim])
+        if (lists.ranges) { GRT_BWD_LAUNCH_NHT(true); } else { GRT_BWD_LAUNCH_NHT(false); }
+        if (log.pool) {
+            GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_replay_nht_bwd_kernel<D_>), grid, dim3(64), 0, s, P,
+                                                             reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad,
+                                                             g_dns, g_hit, g_density12, g_sph, log, bvh.inst, bvh.scene));
+        }
+        return;
+    }
+#undef GRT_BWD_LAUNCH_NHT
     if (lists.ranges) { GRT_BWD_LAUNCH(true); } else { GRT_BWD_LAUNCH(false); }
     if (log.pool) {
         GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_replay_bwd_kernel<D_>), grid, dim3(64), 0, s, P,

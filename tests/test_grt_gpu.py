@@ -479,3 +479,45 @@ def test_nht_forward_matches_oracle(half):
     bad = (np.abs(f - ora["features"]) > 1e-4 + 0.5 * ulp).any(-1) | (np.abs(out["pred_opacity"][0].cpu().numpy() - ora["density"])[..., 0] > 1e-4)
     assert flips.mean() <= 5e-3 and (bad & ~flips).mean() <= 2e-3, f"{bad.sum()} pixels beyond tolerance, {flips.sum()} flips"
     assert np.abs(f).max() > 0.3
+
+
+@pytest.mark.parametrize("replay,half", [(True, False), (False, False), (True, True)])
+def test_nht_backward_matches_oracle(replay, half):
+    """The Slang backward pipeline with neural harmonic features (referenceSlangBwdOptix.cu) — by replay of the forward's log (default)
+    and by traversal (render.backward_hit_replay: false) — against orc_grt_trace_nht_bwd: particle rows and feature buffer, 1e-3."""
+    import torch
+    n, w, h = 2500, 56, 40
+    scene = _scene(n, w, h, 0.07)
+    feats = np.random.default_rng(21).uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)
+    kw = dict(particle_feature_half=True, feature_output_half=True) if half else {}
+    tr = _nht_tracer(backward_hit_replay=replay, **kw)
+    g = syn.SimpleGaussians(scene["density12"], feats)
+    tr.build_acc(g, rebuild=True)
+    out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
+    rng = np.random.default_rng(4)
+    g_f = rng.normal(size=(h, w, 24)).astype(np.float32)
+    g_d = rng.normal(size=(h, w, 1)).astype(np.float32)
+    g_h = (rng.normal(size=(h, w, 1)) * 0.1).astype(np.float32)
+    loss = (out["pred_features"][0] * torch.as_tensor(g_f, device="cuda")).sum() + (out["pred_opacity"][0] * torch.as_tensor(g_d, device="cuda")).sum() + \
+           (out["pred_dist"][0] * torch.as_tensor(g_h, device="cuda")).sum()
+    loss.backward()
+    gd, gf = g.grads_packed()
+    nat = tr.tracer_wrapper
+    inst = nat.instances(n, "cuda").cpu().numpy()
+    aabb = np.array(list(nat.stats().scene_aabb), np.float32)
+    cfg = oracle.default_grt_config()
+    ofeats = oracle.round_to_half(feats) if half else feats
+    ora = oracle.grt_forward_nht(cfg, scene["density12"], ofeats, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=aabb)
+    n_flip = int((out["hits_count"][0, ..., 0].detach().cpu().numpy() != ora["hit_count"][..., 0]).sum())
+    if half:
+        ora = dict(ora, features=oracle.round_to_half(ora["features"]))
+    rd, rf = oracle.grt_backward_nht(cfg, 1e-3, ora, g_f, g_d, g_h.reshape(-1))
+
+    def trimmed(a, b, drop):
+        e = np.abs(np.asarray(a, np.float64) - b).reshape(a.shape[0], -1).max(1)
+        e = np.sort(e)[: max(1, len(e) - drop)]
+        return float(e.max() / (np.abs(b).max() + 1e-12))
+
+    for name, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
+        assert trimmed(gd[:, sl], rd[:, sl], 3 * n_flip) < 1e-3, (name, trimmed(gd[:, sl], rd[:, sl], 3 * n_flip))
+    assert trimmed(gf, rf, 3 * n_flip) < 1e-3 and gf.shape == (n, 48) and np.abs(rf).max() > 0
