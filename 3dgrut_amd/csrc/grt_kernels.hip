@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(64) void grt_nht_fwd_kernel(GrtTraceParams P, const
 }
 // One hit of the Slang backward pipeline with neural harmonic features (referenceSlangBwdOptix.cu:118-178): particleDensityHit,
 // particleFeaturesFromBuffer, particleFeaturesIntegrateBwdToBuffer (the lerp form un-blended front to back) and
-// particleDensityProcessHitBwdToBuffer with the canonical intersection's gradient — the reverse mode restated in oracle/grt_oracle.c
+// particleDensityProcessHitBwdToBuffer with the canonical intersection's gradient — the reverse mode restated by the CPU checker
 // (orc_grt_trace_nht_bwd; same formulas as the 3DGUT nht backward, which float64 autograd pins).  Advances the ray state and returns the
 // hit's gradient as {11 geometric terms, the four barycentric weights, d L / d base feature}: the feature rows' gradient is
 // wq[k] * gbase[n] for row word k * ipd + n.
