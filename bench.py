@@ -39,6 +39,7 @@ WORKLOADS = {
     "c5_hybrid_2m_1080p": (2_000_000, 1920, 1080, 0.008),
     # model.feature_type = nht at the headline size
     "c4_nht_1m_1080p": (1_000_000, 1920, 1080, 0.01),
+    "c3_grt_nht_1m_800": (1_000_000, 800, 800, 0.01),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -171,10 +172,19 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
     K = syn.pinhole_intrinsics(W, H)
     ro, rd = syn.pinhole_rays(W, H, K)
     batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(rank, n_views=max(world, 8))[None], intrinsics=K), dev)
-    tracer = grt.Tracer({"render": {"enable_kernel_timings": True}})
+    nht = "nht" in name   # model.feature_type = nht on the Slang pipelines (48 feature floats per particle -> 24 ray features)
+    if nht:
+        sph = np.random.default_rng(7).uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)
+        tracer = grt.Tracer({"render": {"enable_kernel_timings": True, "pipeline_type": "referenceSlang"},
+                             "model": {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1},
+                                                                               "interpolation_type": "barycentric"}}})
+    else:
+        tracer = grt.Tracer({"render": {"enable_kernel_timings": True}})
     g = syn.SimpleGaussians(d12, sph, device=dev)
     g_fd_np, _ = syn.upstream_grads(W, H)
     g_fd = torch.as_tensor(g_fd_np, device=dev)
+    if nht:
+        g_fd = torch.randn((H, W, 25), device=dev) / (W * H)
 
     exch = importlib.import_module("3dgrut_amd.dp").GradientExchange(g.parameters(), average=False) if world > 1 else None
 
