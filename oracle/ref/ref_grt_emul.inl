@@ -84,7 +84,9 @@ static void set_common_params(int width, int height, const float* ray_to_world, 
                               const float* sph48, const float* scene_aabb6, float min_transmittance, float min_response, float min_alpha,
                               unsigned sph_degree, float* features, float* density, float* hit_distance2, float* normals, float* hits_count,
                               int32_t* visibility) {
-    static thread_local int32_t sz3[4], st3[4], sz1[4], st1[4], sz2[4], st2[4];
+    static thread_local int32_t sz3[4], st3[4], sz1[4], st1[4], sz2[4], st2[4], szf[4], stf[4];
+    const int32_t af[4] = {1, height, width, RAY_FEATURE_DIM}, bf[4] = {height * width * RAY_FEATURE_DIM, width * RAY_FEATURE_DIM, RAY_FEATURE_DIM, 1};
+    for (int i = 0; i < 4; ++i) { szf[i] = af[i]; stf[i] = bf[i]; }
     const int32_t a3[4] = {1, height, width, 3}, b3[4] = {height * width * 3, width * 3, 3, 1};
     const int32_t a1[4] = {1, height, width, 1}, b1[4] = {height * width, width, 1, 1};
     const int32_t a2[4] = {1, height, width, 2}, b2[4] = {height * width * 2, width * 2, 2, 1};
@@ -96,7 +98,7 @@ static void set_common_params(int width, int height, const float* ray_to_world, 
     params.particleFeatures = sph48;
     params.particleExtendedData = nullptr;
     params.particleVisibility = visibility;
-    fill_accessor(params.rayFeatures, features, sz3, st3);
+    fill_accessor(params.rayFeatures, features, szf, stf);
     fill_accessor(params.rayDensity, density, sz1, st1);
     fill_accessor(params.rayHitDistance, hit_distance2, sz2, st2);
     fill_accessor(params.rayNormal, normals, sz3, st3);

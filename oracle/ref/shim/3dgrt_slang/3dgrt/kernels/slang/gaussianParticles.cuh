@@ -112,6 +112,87 @@ inline float particleDensityProcessHitFwdFromBuffer(float3 rayOrigin, float3 ray
     return weight;
 }
 
+#if defined(FEATURE_TRANSFORM_TYPE) && FEATURE_TRANSFORM_TYPE == 1
+// ---- the Slang forward pipeline with neural harmonic features (referenceSlangOptix.cu:147-175) -------------------------------------
+template <typename T, int N>
+struct FixedArray {
+    T m_data[N];
+    T& operator[](int i) { return m_data[i]; }
+    const T& operator[](int i) const { return m_data[i]; }
+};
+// particleDensityProcessHitFwdFromBuffer with the canonical intersection (gaussianParticles.slang:404-425 -> processHitFromBuffer<false>
+// :284-316): the function above + canonicalIntersection = gro + grd (grd . -gro) (:181-190), written when the hit is accepted
+inline float particleDensityProcessHitFwdFromBuffer(float3 rayOrigin, float3 rayDirection, uint32_t particleIdx, gaussianParticle_CommonParameters_0 common,
+                                                    float* transmittance, float* integratedDepth, float3* canonicalIntersection, bool /*enableNormal*/,
+                                                    float3* /*integratedNormal*/) {
+    using namespace grt_slang_standin;
+    const gaussianParticle_RawParameters_0 raw = common.parametersBuffer_0._dataPtr_0[particleIdx];
+    const Rot rotT = rotation_transpose(raw.quaternion_0);
+    const float3 giscl = {1.0f / raw.scale_0.x, 1.0f / raw.scale_0.y, 1.0f / raw.scale_0.z};
+    const float3 gposc = {rayOrigin.x - raw.position_0.x, rayOrigin.y - raw.position_0.y, rayOrigin.z - raw.position_0.z};
+    const float3 gposcr = mul33(rotT, gposc);
+    const float3 o = {giscl.x * gposcr.x, giscl.y * gposcr.y, giscl.z * gposcr.z};
+    const float3 rayDirR = mul33(rotT, rayDirection);
+    const float3 grdu = {giscl.x * rayDirR.x, giscl.y * rayDirR.y, giscl.z * rayDirR.z};
+    const float inv_len = 1.0f / std::sqrt(dot3(grdu, grdu));
+    const float3 d = {grdu.x * inv_len, grdu.y * inv_len, grdu.z * inv_len};
+    const float3 gcrod = {d.y * o.z - d.z * o.y, d.z * o.x - d.x * o.z, d.x * o.y - d.y * o.x};
+    const float maxResponse = max_response(dot3(gcrod, gcrod));
+    const float alpha = std::min((float)GAUSSIAN_PARTICLE_MAX_ALPHA, maxResponse * raw.density_0);
+    if (!((maxResponse > (float)GAUSSIAN_PARTICLE_MIN_KERNEL_DENSITY) && (alpha > (float)GAUSSIAN_PARTICLE_MIN_ALPHA))) return 0.0f;
+    const float along = dot3(d, {-1.f * o.x, -1.f * o.y, -1.f * o.z});
+    const float3 cg = {d.x * along, d.y * along, d.z * along};
+    *canonicalIntersection = {o.x + cg.x, o.y + cg.y, o.z + cg.z};
+    const float3 grds = {raw.scale_0.x * cg.x, raw.scale_0.y * cg.y, raw.scale_0.z * cg.z};
+    const float depth = std::sqrt(dot3(grds, grds));
+    const float weight = alpha * *transmittance;
+    *integratedDepth += depth * weight;
+    *transmittance *= (1 - alpha);
+    return weight;
+}
+// particleFeaturesIntegrateFwdFromBuffer of the neural-harmonic-features model (neuralHarmonicFeaturesParticle.slang:253-270 ->
+// integrateFeaturesFromBuffer<false> :213-228 -> featuresFromParametersBuffer :146-196).  No CUDA twin in the checkout: a restatement.
+template <typename TElem>
+inline void particleFeaturesIntegrateFwdFromBuffer(float3 /*incidentDirection*/, float3 canonicalPosition, float weight, uint32_t particleIdx,
+                                                   TElem* featuresBufferPtr, int /*auxParam*/, FixedArray<float, RAY_FEATURE_DIM>* integrated) {
+    if (!(weight > 0.0f)) return;
+    constexpr int IPD = INTERP_POINT_FEATURE_DIM;
+    const TElem* row = featuresBufferPtr + (size_t)particleIdx * PARTICLE_FEATURE_DIM;
+    float base[IPD];
+    for (int n = 0; n < IPD; ++n) base[n] = (float)row[n];
+#if FEATURE_INTERPOLATION_SUPPORT == 1 && FEATURE_INTERPOLATION_TYPE == 0
+    {
+        using namespace grt_slang_standin;
+        auto sub = [](float3 a, float3 b) { return float3{a.x - b.x, a.y - b.y, a.z - b.z}; };
+        auto crs = [](float3 a, float3 b) { return float3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+        const float edge = 4.898979485566356f, faceHeight = 4.242640687119285f, faceInRadius = 1.4142135623730951f;
+        const float3 v0 = {0.5f * edge, -faceInRadius, -1.0f}, v1 = {-0.5f * edge, -faceInRadius, -1.0f}, v2 = {0.0f, faceHeight - faceInRadius, -1.0f},
+                     v3 = {0.0f, 0.0f, 3.0f};
+        const float3 e1 = sub(v1, v0), e2 = sub(v2, v0), e3 = sub(v3, v0);
+        const float3 c23 = crs(e2, e3);
+        const float invDet = 1.0f / dot3(e1, c23);
+        const float3 d = sub(canonicalPosition, v0);
+        float w[4];
+        w[1] = dot3(d, c23) * invDet; w[2] = dot3(e1, crs(d, e3)) * invDet; w[3] = dot3(e1, crs(e2, d)) * invDet;
+        w[0] = 1.0f - w[1] - w[2] - w[3];
+        for (int n = 0; n < IPD; ++n) base[n] *= w[0];
+        for (int k = 1; k < 4; ++k)
+            for (int n = 0; n < IPD; ++n) base[n] += w[k] * (float)row[k * IPD + n];
+    }
+#endif
+#if FEATURE_ACTIVATION_TYPE == 2
+    for (int k = 0; k < IPD; ++k)
+        for (int f = 0; f < FEATURE_ACTIVATION_NUM_FREQUENCIES; ++f) {
+            const float angle = base[k] * (float)(f + 1);
+            (*integrated)[k * FEATURE_ACTIVATION_NUM_FREQUENCIES * 2 + f * 2 + 0] += std::sin(angle) * weight;
+            (*integrated)[k * FEATURE_ACTIVATION_NUM_FREQUENCIES * 2 + f * 2 + 1] += std::cos(angle) * weight;
+        }
+#else
+#error "ref_grt_trace_slang builds the sincos configuration"
+#endif
+}
+#endif
+
 // "particleFeaturesIntegrateFwdGeneric" (3dgrtTracer.cuh:185-191; not in the checkout's .slang files): for FEATURE_TRANSFORM_TYPE 0 it
 // is integrateRadianceFromBuffer<false> (shRadiativeParticles.slang:117-130) -> sphericalHarmonics.decode (sphericalHarmonics.slang:21-64)
 // with the RAY direction as the incident direction, front to back

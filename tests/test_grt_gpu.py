@@ -521,3 +521,32 @@ def test_nht_backward_matches_oracle(replay, half):
     for name, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
         assert trimmed(gd[:, sl], rd[:, sl], 3 * n_flip) < 1e-3, (name, trimmed(gd[:, sl], rd[:, sl], 3 * n_flip))
     assert trimmed(gf, rf, 3 * n_flip) < 1e-3 and gf.shape == (n, 48) and np.abs(rf).max() > 0
+
+
+def test_nht_forward_matches_reference_slang_programs_golden():
+    """The HIP 3DGRT path with neural harmonic features DIRECTLY against tests/golden/grt_trace_nht.npz — the reference's Slang forward
+    pipeline (referenceSlangOptix.cu) run on the host over the emulated traversal: accepted-hit counts, visibility, 24 ray features."""
+    import os
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    gold = np.load(os.path.join(here, "golden", "grt_trace_nht.npz"))
+    for k, kw in enumerate(make_golden.GRT_TRACE_SCENES):
+        scene = make_scene(**kw)
+        tr = _nht_tracer()
+        g = syn.SimpleGaussians(scene["density12"], gold[f"s{k}_nht_features"], requires_grad=False)
+        tr.build_acc(g, rebuild=True)
+        with torch.no_grad():
+            out = tr.render(g, torch_batch(scene["batch"], "cuda"))
+        cnt = out["hits_count"][0].cpu().numpy()
+        flips = cnt != gold[f"s{k}_hits_count"]
+        assert flips.mean() <= 0.01, f"scene {k}: {int(flips.sum())} rays with a different number of accepted hits"
+        ok = ~flips[..., 0]
+        assert np.abs(out["pred_features"][0].cpu().numpy() - gold[f"s{k}_features"])[ok].max() < 1e-4
+        assert np.abs(out["pred_opacity"][0].cpu().numpy() - gold[f"s{k}_density"])[ok].max() < 1e-4
+        hd = gold[f"s{k}_hit_distance"]
+        assert np.abs(out["pred_dist"][0].cpu().numpy() - hd[..., :1])[ok].max() <= 1e-4 * max(1.0, np.abs(hd).max())
+        vis = out["mog_visibility"].view(-1).view(torch.int32).cpu().numpy() != 0
+        assert (vis != (gold[f"s{k}_visibility"] != 0)).sum() <= 3 * int(flips.sum())

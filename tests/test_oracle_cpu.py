@@ -757,3 +757,22 @@ def test_grt_nht_backward_is_the_gradient_of_forward_away_from_the_last_hit():
             total += 1
             bad += abs(fd - gf[i, col]) > 2e-4 * np.abs(gf).max() + 1e-7
     assert bad <= total // 4, (bad, total)
+
+
+def test_grt_nht_forward_matches_reference_slang_programs_golden():
+    """orc_grt_trace_nht_fwd against tests/golden/grt_trace_nht.npz = the reference's Slang forward pipeline (referenceSlangOptix.cu: raygen
+    round loop, intersection, any-hit k-buffer) with neural harmonic features, run on the host over the emulated traversal
+    (oracle/ref/ref_grt_trace_slang.cpp): accepted-hit counts and visibility identical, 24 ray features / opacity / distances to rounding."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = np.load(os.path.join(HERE, "golden", "grt_trace_nht.npz"))
+    cfg = oracle.default_grt_config()
+    for k, kw in enumerate(make_golden.GRT_TRACE_SCENES):
+        sc = make_scene(**kw)
+        o = oracle.grt_forward_nht(cfg, sc["density12"], g[f"s{k}_nht_features"], 1e-3, sc["batch"]["T_to_world"][0], *sc["rays"])
+        assert np.array_equal(o["hit_count"], g[f"s{k}_hits_count"]), f"scene {k}: accepted-hit counts differ"
+        assert np.array_equal(o["visibility"] != 0, g[f"s{k}_visibility"] != 0)
+        assert np.abs(o["features"] - g[f"s{k}_features"]).max() < 5e-6 and np.abs(o["density"] - g[f"s{k}_density"]).max() < 2e-6
+        hd = g[f"s{k}_hit_distance"]
+        assert np.abs(o["hit_distance"] - hd).max() <= 5e-6 * max(1.0, np.abs(hd).max())
+        assert g[f"s{k}_hits_count"].max() >= 20 and np.abs(g[f"s{k}_features"]).max() > 0.5
