@@ -49,7 +49,7 @@ struct GrtHandle {
     uint32_t mesh_faces = 0;
     bool mesh_built = false;
     // packet lists of the forward (GrtLists): cones, per-particle bounds and records, the binning pipeline's buffers
-    DeviceBuffer l_flags, l_block_cones, l_super_cones, l_pair_cache, l_inst_rel, l_key_bits, l_counts, l_pidx, l_key_tmp, l_pidx_tmp, l_offsets,
+    DeviceBuffer l_flags, l_block_cones, l_super_cones, l_pair_cache, l_inst_rel, l_key_bits, l_counts, l_pidx, l_key_tmp, l_pidx_tmp, l_offsets, l_starts,
         l_scan_scratch, l_sort_scratch, l_block_keys, l_vals, l_block_keys_tmp, l_vals_tmp, l_ranges;
     uint32_t* l_host = nullptr;          // pinned: {entries, uniform-origin flag}
     uint64_t list_entries = 0;           // of the last forward (0: the BVH walk served it)
@@ -152,7 +152,7 @@ int grt_create(const GrtConfig* config, GrtHandle** handle) {
 static void release_scratch(GrtHandle* h) {
     DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
                             &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
-                            &h->work_counters, &h->l_flags, &h->l_pair_cache, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits,
+                            &h->work_counters, &h->l_flags, &h->l_starts, &h->l_pair_cache, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits,
                             &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets, &h->l_scan_scratch, &h->l_sort_scratch,
                             &h->l_block_keys, &h->l_vals, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_ranges,
                             &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state, &h->m_aabb, &h->m_slack, &h->m_scene_enc,
@@ -266,11 +266,11 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
         const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
         if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
         GRUT_CHECK(h->l_flags.ensure(64));
-        GRUT_CHECK(h->l_block_cones.ensure((size_t)nb * (sizeof(GrtCone) + sizeof(GrtPyramid)), 1.25f));   // cones, then pyramids
+        GRUT_CHECK(h->l_block_cones.ensure(grt_cone_table_bytes(P.W, P.H), 1.25f));   // cones, pyramids, tangent-plane tables
         GRUT_CHECK(h->l_super_cones.ensure((size_t)ns * sizeof(GrtCone), 1.25f));
         GRUT_CHECK(h->l_inst_rel.ensure((size_t)N * 64, 1.25f));
         GRUT_CHECK(h->l_pair_cache.ensure(grt_pair_cache_bytes(N), 1.25f));
-        for (DeviceBuffer* b4 : {&h->l_key_bits, &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets})
+        for (DeviceBuffer* b4 : {&h->l_key_bits, &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets, &h->l_starts})
             GRUT_CHECK(b4->ensure((size_t)N * 4, 1.25f));
         GRUT_CHECK(h->l_scan_scratch.ensure(scan_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
         uint32_t* flag = h->l_flags.as<uint32_t>();
@@ -303,7 +303,8 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
         if (usable) {
             const uint32_t n = (uint32_t)I;
             grt_launch_list_expand(s, P, bvh, ray_origin, flag, dir_len, h->l_block_cones.as<GrtCone>(), h->l_super_cones.as<GrtCone>(),
-                                   rank_to_particle, h->l_offsets.as<uint32_t>(), n, h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(), h->l_pair_cache.ptr);
+                                   rank_to_particle, h->l_offsets.as<uint32_t>(), h->l_counts.as<uint32_t>(), h->l_starts.as<uint32_t>(), n,
+                                   h->l_block_keys.as<uint32_t>(), h->l_vals.as<uint32_t>(), h->l_pair_cache.ptr);
             int bits = 1;
             while ((1ull << bits) <= nb) ++bits;   // smallest b with (1 << b) > nb: the all-ones pad key never aliases a packet
             uint32_t *sorted_blocks = nullptr, *sorted_ids = nullptr;   // the payload of the sort is the particle: sorted payloads = the lists

@@ -18,6 +18,7 @@
 //     into the proxy's box by at most sqrt(2) * (largest proxy half axis); nodes store that slack, and a subtree is
 //     pruned only when (box entry - slack) exceeds the current 16th-nearest distance.
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 
 #include "grt_internal.hpp"
 
@@ -2357,6 +2358,10 @@ __host__ __device__ __forceinline__ uint32_t blocks_x(int W) { return (uint32_t)
 __host__ __device__ __forceinline__ uint32_t blocks_y(int H) { return (uint32_t)(H + 7) / 8u; }
 uint32_t grt_num_blocks(int W, int H) { return blocks_x(W) * blocks_y(H); }
 size_t grt_pair_cache_bytes(uint32_t N) { return (size_t)N * (4 * 16 + 4); }   // kBinCachedPairs uint4 + the pair count, per particle
+size_t grt_cone_table_bytes(int W, int H) {
+    const size_t nb = grt_num_blocks(W, H);
+    return nb * (sizeof(GrtCone) + sizeof(GrtPyramid) + sizeof(float4)) + 64 + (size_t)(blocks_x(W) + blocks_y(H)) * sizeof(float2);
+}
 uint32_t grt_num_super(int W, int H) { return ((blocks_x(W) + 7u) / 8u) * ((blocks_y(H) + 7u) / 8u); }
 
 // the entry offsets come from a 32-bit inclusive scan: a total beyond 2^32 shows as a descent somewhere in them
@@ -2367,7 +2372,8 @@ __global__ __launch_bounds__(256) void grt_list_check_kernel(uint32_t n, const u
 void grt_launch_list_check(hipStream_t s, uint32_t n, const uint32_t* offsets, uint32_t* flag) {
     hipLaunchKernelGGL(grt_list_check_kernel, dim3(div_up(n, 256)), dim3(256), 0, s, n, offsets, flag);
 }
-__global__ void grt_list_init_kernel(uint32_t* __restrict__ flag, uint32_t* __restrict__ dir_len_enc) {
+__global__ void grt_list_init_kernel(uint32_t* __restrict__ flag, uint32_t* __restrict__ dir_len_enc, float* __restrict__ grid_hdr, uint32_t grid_ok) {
+    grid_hdr[9] = __uint_as_float(grid_ok);   // cleared by a packet with a ray too far off the centre direction (grt_block_cone_kernel)
     flag[0] = 1u;
     flag[1] = 0u;   // set when the 32-bit entry count wrapped (grt_list_check_kernel)
     dir_len_enc[0] = 0x7F7FFFFFu;   // min |d| (bit patterns of positive floats order like integers)
@@ -2434,6 +2440,54 @@ __global__ __launch_bounds__(64) void grt_block_cone_kernel(GrtTraceParams P, co
         py.ok = pyr_ok ? 1.f : 0.f;
         py.pad = 0.f;
         const_cast<GrtPyramid*>(grt_block_pyramids(cones, gridDim.x))[b] = py;
+    }
+    // the packet in the frame's tangent plane (GrtGrid): a = the centre pixel's direction, u = towards its neighbour in the row (every
+    // wave derives the same frame from the same two rays)
+    const GrtGrid G = grt_block_grid(cones, gridDim.x, gx);
+    const int cpx = P.W / 2, cpy = P.H / 2, npx = cpx + 1 < P.W ? cpx + 1 : (cpx > 0 ? cpx - 1 : cpx);
+    const RayW rc = make_ray(P, ray_o, ray_d, (size_t)cpy * P.W + cpx), rn = make_ray(P, ray_o, ray_d, (size_t)cpy * P.W + npx);
+    const float lc = sqrtf(dot(rc.d, rc.d)), ln = sqrtf(dot(rn.d, rn.d));
+    const bool frame_ok = lc > 0.f && lc < 3.0e38f;
+    const f3 ag = frame_ok ? rc.d * (1.f / lc) : mk3(0.f, 0.f, 1.f);
+    f3 ug = (ln > 0.f && ln < 3.0e38f) ? (rn.d * (1.f / ln) - ag) * (npx > cpx ? 1.f : -1.f) : mk3(0.f, 0.f, 0.f);
+    ug = ug - ag * dot(ug, ag);
+    float ugl = sqrtf(dot(ug, ug));
+    if (!(ugl > 1e-12f)) {
+        ug = fabsf(ag.x) < 0.6f ? mk3(1.f, 0.f, 0.f) : mk3(0.f, 1.f, 0.f);
+        ug = ug - ag * dot(ug, ag);
+        ugl = sqrtf(dot(ug, ug));
+    }
+    ug = ug * (1.f / ugl);
+    const f3 wg = cross(ag, ug);
+    const float gz = dot(dh, ag);
+    const bool gfits = good && gz > 0.05f;
+    const float gtx = gfits ? dot(dh, ug) / gz : 0.f, gty = gfits ? dot(dh, wg) / gz : 0.f;
+    const float gx0 = wave_min(gfits ? gtx : 3.0e38f), gx1 = wave_max(gfits ? gtx : -3.0e38f);
+    const float gy0 = wave_min(gfits ? gty : 3.0e38f), gy1 = wave_max(gfits ? gty : -3.0e38f);
+    const bool grid_bad = __any(good && !gfits) || !frame_ok;
+    if (lane == 0) {
+        const float mx = 2e-5f * (1.f + fmaxf(fabsf(gx0), fabsf(gx1))), my = 2e-5f * (1.f + fmaxf(fabsf(gy0), fabsf(gy1)));
+        G.rects[b] = make_float4(gx0 - mx, gx1 + mx, gy0 - my, gy1 + my);   // (a packet without a usable ray: an empty rectangle)
+        if (grid_bad) G.hdr[9] = __uint_as_float(0u);
+        if (b == 0) {
+            G.hdr[0] = ag.x; G.hdr[1] = ag.y; G.hdr[2] = ag.z; G.hdr[3] = ug.x; G.hdr[4] = ug.y; G.hdr[5] = ug.z;
+            G.hdr[6] = wg.x; G.hdr[7] = wg.y; G.hdr[8] = wg.z;
+        }
+    }
+}
+// the union of the tangent-plane rectangles over each packet column and each packet row
+__global__ __launch_bounds__(64) void grt_grid_tables_kernel(GrtTraceParams P, GrtCone* __restrict__ cones) {
+    const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H), i = blockIdx.x * blockDim.x + threadIdx.x;
+    const GrtGrid G = grt_block_grid(cones, gx * gy, gx);
+    if (i >= gx + gy) return;
+    float lo = 3.0e38f, hi = -3.0e38f;
+    if (i < gx) {
+        for (uint32_t r = 0; r < gy; ++r) { const float4 q = G.rects[r * gx + i]; lo = fminf(lo, q.x); hi = fmaxf(hi, q.y); }
+        G.cols[i] = make_float2(lo, hi);
+    } else {
+        const uint32_t r = i - gx;
+        for (uint32_t c = 0; c < gx; ++c) { const float4 q = G.rects[r * gx + c]; lo = fminf(lo, q.z); hi = fmaxf(hi, q.w); }
+        G.rows[r] = make_float2(lo, hi);
     }
 }
 // one wave per super tile (8x8 packets): cone around its packets' cones
@@ -2634,6 +2688,162 @@ __device__ __forceinline__ void emit_cached_pairs(const GrtTraceParams& P, int l
         }
     }
 }
+// ---- binning over the frame's tangent plane (GrtGrid) ---------------------------------------------------------------------------
+// The particle's candidate packets: the 8 corners of its proxy box projected onto the plane give a rectangle [px0, px1] x [py0, py1]
+// that holds (d.u)/(d.a), (d.w)/(d.a) of every ray through the box; only packets whose own rectangle overlaps it can hold such a ray.
+//   kind 0  no packet (the box lies behind the apex plane: every ray of the frame has d.a > 0)
+//   kind 1  the packets of at most kBinLaneArea (column, row) cells: the lane tests them itself
+//   kind 2  more cells: the wave tests them together, 64 at a time
+//   kind 3  no rectangle — the box comes within 2 % of its distance of the apex plane, where the projection blows up: the wave walks
+//           the super tiles for it (super tile cones, then the packets of those it reaches)
+// The rectangle only SELECTS candidates; what enters a list is decided by packet_hit, as in the super tile scan.
+constexpr uint32_t kBinLaneArea = 32;
+struct GridParticle {
+    int kind;
+    uint32_t bx0, by0, wdt, hgt;
+    float px0, px1, py0, py1;
+};
+__device__ __forceinline__ GridParticle grid_particle(const GrtGrid& G, uint32_t gx, uint32_t gy, bool have, const BinParticle& q) {
+    GridParticle g;
+    g.kind = 0; g.bx0 = g.by0 = 0u; g.wdt = g.hgt = 1u; g.px0 = g.py0 = 0.f; g.px1 = g.py1 = 0.f;
+    const f3 a = mk3(G.hdr[0], G.hdr[1], G.hdr[2]), u = mk3(G.hdr[3], G.hdr[4], G.hdr[5]), w = mk3(G.hdr[6], G.hdr[7], G.hdr[8]);
+    const float va = dot(q.v, a), vu = dot(q.v, u), vw = dot(q.v, w);
+    const float a0 = dot(q.h0, a), a1 = dot(q.h1, a), a2 = dot(q.h2, a), u0 = dot(q.h0, u), u1 = dot(q.h1, u), u2 = dot(q.h2, u),
+                w0 = dot(q.h0, w), w1 = dot(q.h1, w), w2 = dot(q.h2, w);
+    float zmin = 3.0e38f, zmax = -3.0e38f, x0 = 3.0e38f, x1 = -3.0e38f, y0 = 3.0e38f, y1 = -3.0e38f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float s0 = (c & 1) ? 1.f : -1.f, s1 = (c & 2) ? 1.f : -1.f, s2 = (c & 4) ? 1.f : -1.f;
+        const float z = va + s0 * a0 + s1 * a1 + s2 * a2, xx = vu + s0 * u0 + s1 * u1 + s2 * u2, yy = vw + s0 * w0 + s1 * w1 + s2 * w2;
+        zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+        const float iz = __builtin_amdgcn_rcpf(fmaxf(z, 1e-30f));
+        x0 = fminf(x0, xx * iz); x1 = fmaxf(x1, xx * iz); y0 = fminf(y0, yy * iz); y1 = fmaxf(y1, yy * iz);
+    }
+    const float ext = sqrtf(q.L2) + q.Rs;
+    if (!have || !(zmax > -1e-5f * ext)) return g;
+    // (rounding: a corner's z carries ~3e-7 ext, so with z >= 0.02 ext the quotients are good to 2e-5 (1 + |x|); NaNs take the walk)
+    const float mx = 1e-4f * (1.f + fmaxf(fabsf(x0), fabsf(x1))), my = 1e-4f * (1.f + fmaxf(fabsf(y0), fabsf(y1)));
+    g.px0 = x0 - mx; g.px1 = x1 + mx; g.py0 = y0 - my; g.py1 = y1 + my;
+    if (!(zmin >= 0.02f * ext) || !(g.px0 <= g.px1) || !(g.py0 <= g.py1)) { g.kind = 3; return g; }
+    uint32_t bx0 = gx, bx1 = 0u, by0 = gy, by1 = 0u;
+    for (uint32_t c = 0; c < gx; ++c) {
+        const float2 iv = G.cols[c];
+        if (iv.x <= g.px1 && iv.y >= g.px0) { bx0 = min(bx0, c); bx1 = c; }
+    }
+    for (uint32_t r = 0; r < gy; ++r) {
+        const float2 iv = G.rows[r];
+        if (iv.x <= g.py1 && iv.y >= g.py0) { by0 = min(by0, r); by1 = r; }
+    }
+    if (bx0 >= gx || by0 >= gy) return g;   // outside the frame
+    g.bx0 = bx0; g.by0 = by0; g.wdt = bx1 - bx0 + 1u; g.hgt = by1 - by0 + 1u;
+    g.kind = (g.wdt * g.hgt <= kBinLaneArea) ? 1 : 2;
+    return g;
+}
+__device__ __forceinline__ bool rect_overlap(const float4& rc, float px0, float px1, float py0, float py1) {
+    return rc.x <= px1 && rc.y >= px0 && rc.z <= py1 && rc.w >= py0;
+}
+// kind 1, counting pass: the lane's own cells, first against the packets' rectangles, then the survivors against packet_hit;
+// returns the mask of the cells (row-major in the particle's rectangle) whose packets the box reaches
+__device__ __forceinline__ unsigned long long grid_lane_cells(const GrtGrid& G, const GrtCone* __restrict__ block_cones, uint32_t gx, uint32_t gy,
+                                                              const GridParticle& g, const BinParticle& q) {
+    const bool mine = g.kind == 1;
+    const uint32_t area = mine ? g.wdt * g.hgt : 0u;
+    unsigned long long cand = 0ull;
+    uint32_t cx = 0u, cy = 0u;
+    for (uint32_t j = 0; __any(j < area); ++j) {
+        if (j < area) {
+            const float4 rc = G.rects[(g.by0 + cy) * gx + g.bx0 + cx];
+            if (rect_overlap(rc, g.px0, g.px1, g.py0, g.py1)) cand |= 1ull << j;
+            if (++cx == g.wdt) { cx = 0u; ++cy; }
+        }
+    }
+    const GrtPyramid* pyramids = grt_block_pyramids(block_cones, gx * gy);
+    const float iw = 1.f / (float)g.wdt;
+    unsigned long long hm = 0ull;
+    while (__any(cand != 0ull)) {
+        const bool act = cand != 0ull;
+        const int j = act ? __ffsll((long long)cand) - 1 : 0;
+        cand &= cand - 1ull;   // (0 stays 0)
+        const uint32_t ry = (uint32_t)(((float)j + 0.5f) * iw), rx = (uint32_t)j - ry * g.wdt;   // exact: j < 64, the quotient stays 1/128 clear of an integer
+        const uint32_t b = act ? (g.by0 + ry) * gx + g.bx0 + rx : 0u;
+        const GrtCone kc = block_cones[b];
+        const GrtPyramid kp = pyramids[b];
+        if (act && packet_hit(kc, kp, q.v, q.L2, q.Rs, q.h0, q.h1, q.h2, false)) hm |= 1ull << j;
+    }
+    return hm;
+}
+// kinds 2 and 3: one particle at a time, the 64 lanes on 64 of its candidate packets.  EMIT: the entries are written at the
+// particle's [off, end); the number of packets reached is added to lane src's n
+template <bool EMIT>
+__device__ __forceinline__ void grid_wave_cells(const GrtTraceParams& P, const GrtGrid& G, const GrtCone* __restrict__ block_cones,
+                                                const GrtCone* __restrict__ super_cones, int lane, const GridParticle& g, const BinParticle& q,
+                                                uint32_t pid, uint32_t& n, uint32_t& off, uint32_t end, const BinOut& out) {
+    const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H), sx = (gx + 7u) / 8u, sy = (gy + 7u) / 8u;
+    const GrtPyramid* pyramids = grt_block_pyramids(block_cones, gx * gy);
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    auto bc = [](float x, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src)); };
+    auto bu = [](uint32_t x, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)x, src); };
+    unsigned long long m = __ballot(g.kind >= 2);
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const f3 v = mk3(bc(q.v.x, src), bc(q.v.y, src), bc(q.v.z, src));
+        const float L2 = bc(q.L2, src), Rs = bc(q.Rs, src);
+        const f3 h0 = mk3(bc(q.h0.x, src), bc(q.h0.y, src), bc(q.h0.z, src)), h1 = mk3(bc(q.h1.x, src), bc(q.h1.y, src), bc(q.h1.z, src)),
+                 h2 = mk3(bc(q.h2.x, src), bc(q.h2.y, src), bc(q.h2.z, src));
+        const uint32_t o = EMIT ? bu(off, src) : 0u, e = EMIT ? bu(end, src) : 0u, id = EMIT ? bu(pid, src) : 0u;
+        uint32_t found = 0u;
+        auto take = [&](bool hit, uint32_t b) {
+            const unsigned long long hm = __ballot(hit);
+            if (EMIT) {
+                const uint32_t slot = o + found + (uint32_t)__popcll(hm & lt);
+                if (hit && slot < e) { out.block_keys[slot] = b; out.vals[slot] = id; }
+            }
+            found += (uint32_t)__popcll(hm);
+        };
+        if (bu((uint32_t)g.kind, src) == 2u) {
+            const uint32_t bx0 = bu(g.bx0, src), by0 = bu(g.by0, src), wdt = bu(g.wdt, src), total = wdt * bu(g.hgt, src);
+            const float px0 = bc(g.px0, src), px1 = bc(g.px1, src), py0 = bc(g.py0, src), py1 = bc(g.py1, src);
+            for (uint32_t c0 = 0; c0 < total; c0 += 64u) {
+                const uint32_t c = c0 + (uint32_t)lane;
+                const bool valid = c < total;
+                const uint32_t cc = valid ? c : 0u, ry = cc / wdt, rx = cc - ry * wdt;
+                const uint32_t b = (by0 + ry) * gx + bx0 + rx;
+                bool hit = valid && rect_overlap(G.rects[b], px0, px1, py0, py1);
+                if (__any(hit)) {
+                    GrtCone kc = {0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+                    GrtPyramid kp = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (hit) { kc = block_cones[b]; kp = pyramids[b]; }
+                    hit = hit && packet_hit(kc, kp, v, L2, Rs, h0, h1, h2, false);
+                }
+                take(hit, b);
+            }
+        } else {
+            const GrtPyramid no_pyramid = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (uint32_t s0 = 0; s0 < sx * sy; s0 += 64u) {
+                const uint32_t sl = s0 + (uint32_t)lane;
+                const bool reach = sl < sx * sy && packet_hit(super_cones[sl < sx * sy ? sl : 0u], no_pyramid, v, L2, Rs, h0, h1, h2, false);
+                unsigned long long sm = __ballot(reach);
+                while (sm) {
+                    const uint32_t s = s0 + (uint32_t)(__ffsll((long long)sm) - 1);
+                    sm &= sm - 1;
+                    const uint32_t bx = (s % sx) * 8u + (uint32_t)(lane & 7), by = (s / sx) * 8u + (uint32_t)(lane >> 3);
+                    const bool exists = bx < gx && by < gy;
+                    const uint32_t b = exists ? by * gx + bx : 0u;
+                    GrtCone kc = {0.f, 0.f, 1.f, 1.f, 0.f, 0.f, 0.f, 0.f};
+                    GrtPyramid kp = {1.f, 0.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    if (exists) { kc = block_cones[b]; kp = pyramids[b]; }
+                    take(exists && packet_hit(kc, kp, v, L2, Rs, h0, h1, h2, false), b);
+                }
+            }
+        }
+        if (lane == src) { n += found; if (EMIT) off += found; }
+    }
+}
+// cache word of a kind-1 particle: its rectangle's corner and width (the mask of cells follows in the same uint4)
+__device__ __forceinline__ uint32_t grid_pack(const GridParticle& g) { return g.bx0 | (g.by0 << 12) | ((g.wdt - 1u) << 24); }
+constexpr uint32_t kGridWaveTested = 0xFFFFFFFFu;   // pair_n of a particle of kind 2 / 3: the emitting pass tests again
+
 __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, GrtBvh bvh, const float* __restrict__ ray_o,
                                                              const uint32_t* __restrict__ flag, const uint32_t* __restrict__ dir_len_enc,
                                                              const GrtCone* __restrict__ block_cones, const GrtCone* __restrict__ super_cones,
@@ -2652,7 +2862,22 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
     }
     const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
     const BinOut cache = {nullptr, nullptr, pairs, pair_n};
-    const uint32_t n = bin_pairs<false>(P, block_cones, super_cones, lane, have, q, i, 0u, 0u, cache);
+    const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H);
+    const GrtGrid G = grt_block_grid(block_cones, gx * gy, gx);
+    uint32_t n = 0u;
+    if (__float_as_uint(G.hdr[9]) != 0u) {   // the frame has a tangent plane
+        const GridParticle g = grid_particle(G, gx, gy, have, q);
+        const unsigned long long hm = grid_lane_cells(G, block_cones, gx, gy, g, q);
+        n = (uint32_t)__popcll(hm);
+        uint32_t off = 0u;
+        grid_wave_cells<false>(P, G, block_cones, super_cones, lane, g, q, i, n, off, 0u, cache);
+        if (have) {
+            pairs[(size_t)i * kBinCachedPairs] = make_uint4(grid_pack(g), (uint32_t)hm, (uint32_t)(hm >> 32), 0u);
+            pair_n[i] = g.kind >= 2 ? kGridWaveTested : 0u;
+        }
+    } else {
+        n = bin_pairs<false>(P, block_cones, super_cones, lane, have, q, i, 0u, 0u, cache);
+    }
     if (i >= bvh.N) return;
     counts[i] = have ? n : 0u;   // (particle_idx, the payload of the key sort, is an iota: generated by the sort's first pass)
     key_bits[i] = (have && n) ? __float_as_uint(q.key) : 0xFFFFFFFFu;   // sort key (the sort consumes this array); particles no packet can reach go last
@@ -2665,30 +2890,64 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
     out[0] = a; out[1] = b; out[2] = make_float4(e.x, po.x, po.y, po.z);
     out[3] = make_float4(q.v.x, q.v.y, q.v.z, q.key);
 }
-// rank r of the key order writes its entries at [offsets[r-1], offsets[r]): (packet, expansion position) pairs, the position's particle
-// and its hit-distance bounds for that packet
+// where each particle's entries go: rank r of the key order owns [offsets[r-1], offsets[r])
+__global__ __launch_bounds__(256) void grt_list_starts_kernel(uint32_t N, const uint32_t* __restrict__ rank_to_particle, const uint32_t* __restrict__ offsets,
+                                                              uint32_t* __restrict__ starts) {
+    const uint32_t rk = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rk < N) starts[rank_to_particle[rk]] = rk == 0 ? 0u : offsets[rk - 1];
+}
+// particle p writes its entries at [starts[p], starts[p] + counts[p]): (packet, particle) pairs.  The threads follow the PARTICLE
+// order, not the key order: the nearest particles are the ones that cover hundreds of packets, and in key order they all sat in
+// the first few waves (0.69 -> ms)
 __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, GrtBvh bvh, const float* __restrict__ ray_o,
                                                               const uint32_t* __restrict__ flag, const uint32_t* __restrict__ dir_len_enc,
                                                               const GrtCone* __restrict__ block_cones, const GrtCone* __restrict__ super_cones,
-                                                              const uint32_t* __restrict__ rank_to_particle, const uint32_t* __restrict__ offsets,
+                                                              const uint32_t* __restrict__ starts, const uint32_t* __restrict__ counts,
                                                               uint32_t capacity, BinOut out) {
-    const uint32_t rk = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    uint32_t off = 0u, end = 0u, p = 0u;
-    if (rk < bvh.N && flag[0] != 0u) {
-        off = rk == 0 ? 0u : offsets[rk - 1];
-        end = min(offsets[rk], capacity);
+    uint32_t off = 0u, end = 0u;
+    if (p < bvh.N && flag[0] != 0u) {
+        off = min(starts[p], capacity);
+        end = min(off + counts[p], capacity);
     }
     const bool have = end > off;
     float4 a = make_float4(1.f, 0.f, 0.f, 0.f), b = make_float4(1.f, 0.f, 0.f, 0.f), e = make_float4(1.f, 0.f, 0.f, 0.f);
     const f3 o = world_origin(P, mk3(ray_o[0], ray_o[1], ray_o[2]));
     const float dmin = __uint_as_float(dir_len_enc[0]), dmax = __uint_as_float(dir_len_enc[1]);
     if (have) {
-        p = rank_to_particle[rk];
         const float4* rec = reinterpret_cast<const float4*>(bvh.inst) + 3 * (size_t)p;
         a = rec[0]; b = rec[1]; e = rec[2];
     }
     const uint32_t np = have ? out.pair_n[p] : 0u;
+    const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H);
+    const GrtGrid G = grt_block_grid(block_cones, gx * gy, gx);
+    if (__float_as_uint(G.hdr[9]) != 0u) {   // lists over the frame's tangent plane: a lane writes the cells its counting pass found
+        if (have && np != kGridWaveTested) {
+            const uint4 pr = out.pairs[(size_t)p * kBinCachedPairs];
+            const uint32_t bx0 = pr.x & 0xFFFu, by0 = (pr.x >> 12) & 0xFFFu, wdt = (pr.x >> 24) + 1u;
+            const float iw = 1.f / (float)wdt;
+            unsigned long long hm = (unsigned long long)pr.y | ((unsigned long long)pr.z << 32);
+            while (hm && off < end) {
+                const int j = __ffsll((long long)hm) - 1;
+                hm &= hm - 1ull;
+                const uint32_t ry = (uint32_t)(((float)j + 0.5f) * iw), rx = (uint32_t)j - ry * wdt;
+                out.block_keys[off] = (by0 + ry) * gx + bx0 + rx;
+                out.vals[off] = p;
+                ++off;
+            }
+        }
+        const bool again = have && np == kGridWaveTested;
+        if (__any(again)) {
+            const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
+            GridParticle g = grid_particle(G, gx, gy, again, q);
+            if (!again) g.kind = 0;
+            uint32_t n = 0u;
+            grid_wave_cells<true>(P, G, block_cones, super_cones, lane, g, q, p, n, off, end, out);
+        }
+        for (; off < end; ++off) { out.block_keys[off] = 0xFFFFFFFFu; out.vals[off] = 0xFFFFFFFFu; }   // (not expected)
+        return;
+    }
     const bool cached = have && np <= (uint32_t)kBinCachedPairs;
     emit_cached_pairs(P, lane, cached, p, np, off, end, out);
     // (what the cache did not hold: tested again; pads whatever the masks left unwritten, which is not expected)
@@ -2728,8 +2987,11 @@ __global__ __launch_bounds__(256) void grt_list_ranges_kernel(uint32_t n, uint32
 }
 void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* ray_o, const float* ray_d, uint32_t* uniform_origin,
                            uint32_t* dir_len_enc, GrtCone* block_cones, GrtCone* super_cones) {
-    hipLaunchKernelGGL(grt_list_init_kernel, dim3(1), dim3(1), 0, s, uniform_origin, dir_len_enc);
+    const GrtGrid G = grt_block_grid(block_cones, grt_num_blocks(P.W, P.H), blocks_x(P.W));
+    static const bool no_grid = getenv("GRUT_GRT_NO_GRID") != nullptr;   // (development switch: the super tile scan for every frame)
+    hipLaunchKernelGGL(grt_list_init_kernel, dim3(1), dim3(1), 0, s, uniform_origin, dir_len_enc, G.hdr, (no_grid || P.sphere_lists) ? 0u : 1u);
     hipLaunchKernelGGL(grt_block_cone_kernel, dim3(grt_num_blocks(P.W, P.H)), dim3(64), 0, s, P, ray_o, ray_d, uniform_origin, block_cones);
+    hipLaunchKernelGGL(grt_grid_tables_kernel, dim3(div_up(blocks_x(P.W) + blocks_y(P.H), 64u)), dim3(64), 0, s, P, block_cones);
     hipLaunchKernelGGL(grt_super_cone_kernel, dim3(grt_num_super(P.W, P.H)), dim3(64), 0, s, P, block_cones, super_cones, dir_len_enc);
 }
 void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
@@ -2741,11 +3003,13 @@ void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh&
 }
 void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,
                             const uint32_t* dir_len_enc, const GrtCone* block_cones, const GrtCone* super_cones, const uint32_t* rank_to_particle,
-                            const uint32_t* offsets, uint32_t capacity, uint32_t* block_keys, uint32_t* vals, void* pair_cache) {
+                            const uint32_t* offsets, const uint32_t* counts, uint32_t* starts, uint32_t capacity, uint32_t* block_keys, uint32_t* vals,
+                            void* pair_cache) {
     const BinOut out = {block_keys, vals, reinterpret_cast<uint4*>(pair_cache),
                         reinterpret_cast<uint32_t*>(reinterpret_cast<uint4*>(pair_cache) + (size_t)bvh.N * kBinCachedPairs)};
+    hipLaunchKernelGGL(grt_list_starts_kernel, dim3(div_up(bvh.N, 256)), dim3(256), 0, s, bvh.N, rank_to_particle, offsets, starts);
     hipLaunchKernelGGL(grt_list_expand_kernel, dim3(div_up(bvh.N, 256)), dim3(256), 0, s, P, bvh, ray_o, uniform_origin, dir_len_enc, block_cones,
-                       super_cones, rank_to_particle, offsets, capacity, out);
+                       super_cones, starts, counts, capacity, out);
 }
 void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, uint32_t* ranges) {
     if (n == 0) return;

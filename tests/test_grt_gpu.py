@@ -346,6 +346,66 @@ def test_packet_lists_with_unnormalised_directions(monkeypatch):
             assert np.array_equal(a, b), name
 
 
+def _assert_same_hits(lists, walk):
+    num = lists[7].reshape(-1).astype(np.int64)
+    for a, b, name in zip(lists, walk, ("features", "density", "hit_distance", "normals", "hit_count", "visibility", "ids", "num")):
+        if name == "ids":
+            for r in range(num.size):
+                k = min(int(num[r]), 128)
+                assert np.array_equal(a.reshape(num.size, -1)[r, :k], b.reshape(num.size, -1)[r, :k]), f"ray {r}: order differs"
+        else:
+            assert np.array_equal(a, b), name
+
+
+def _fan_rays(h, w, half_angle_deg, roll_deg=0.0):
+    """Directions on an equidistant fan (a fisheye): pixel offset from the centre = angle off the axis, rolled about the axis."""
+    ys, xs = np.meshgrid(np.arange(h) - (h - 1) / 2, np.arange(w) - (w - 1) / 2, indexing="ij")
+    r = np.hypot(xs, ys) + 1e-9
+    theta = r / r.max() * np.deg2rad(half_angle_deg)
+    phi = np.arctan2(ys, xs) + np.deg2rad(roll_deg)
+    d = np.stack([np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi), np.cos(theta)], -1)
+    return d[None].astype(np.float32)
+
+
+@pytest.mark.parametrize("half_angle,roll,expect_plane", [(60.0, 33.0, True), (84.0, 0.0, True), (120.0, 10.0, False)])
+def test_packet_lists_over_a_fisheye_fan(monkeypatch, half_angle, roll, expect_plane):
+    """The binning selects a particle's candidate packets on the frame's tangent plane (GrtGrid) when every ray is within 87 degrees of
+    the centre pixel's direction — rolled and strongly distorted grids included — and by scanning the super tiles' cones otherwise
+    (a fan of 240 degrees here).  The camera sits inside the cloud, so some proxy boxes straddle the apex plane.  Either way the lists
+    hold what the tree walk finds."""
+    scene = _scene(8000, 72, 56, 0.06)
+    T = scene["batch"]["T_to_world"].copy()
+    T[0, :3, 3] = np.float32(0.03)
+    scene["batch"] = dict(scene["batch"], T_to_world=T)
+    scene["T"] = T[0]
+    rd = _fan_rays(56, 72, half_angle, roll)
+    lists, n_entries = _hits_with(scene, monkeypatch, no_lists=False, rays_dir=rd)
+    walk, n_walk = _hits_with(scene, monkeypatch, no_lists=True, rays_dir=rd)
+    assert n_entries > 0 and n_walk == 0
+    _assert_same_hits(lists, walk)
+    # the super tile scan on the same frame: sound too, and never shorter than the tangent-plane lists (which also drop the packets
+    # a separating plane of the FRAME's axes excludes)
+    monkeypatch.setenv("GRUT_GRT_NO_GRID", "1")
+    scan, n_scan = _hits_with(scene, monkeypatch, no_lists=False, rays_dir=rd)
+    _assert_same_hits(scan, walk)
+    assert (n_entries <= n_scan) if expect_plane else (n_entries == n_scan)
+
+
+def test_packet_lists_with_large_and_small_particles(monkeypatch):
+    """Particles from a fraction of a packet to a third of the frame in one cloud: the lane-tested rectangles (<= 32 packets), the
+    wave-tested ones and the border packets of an image whose sides are no multiples of 8."""
+    scene = _scene(5000, 150, 91, 0.03)
+    d12 = scene["density12"].copy()
+    rng = np.random.default_rng(11)
+    big = rng.choice(d12.shape[0], 150, replace=False)
+    d12[big, 8:11] *= rng.uniform(4.0, 30.0, size=(150, 1)).astype(np.float32)   # scales
+    scene["density12"] = d12
+    lists, n_entries = _hits_with(scene, monkeypatch, no_lists=False)
+    walk, n_walk = _hits_with(scene, monkeypatch, no_lists=True)
+    assert n_entries > 0 and n_walk == 0
+    _assert_same_hits(lists, walk)
+
+
 def test_a_degenerate_direction_sends_the_frame_to_the_tree_walk(monkeypatch):
     """A ray with a zero direction has no place in a bounding cone: the frame is served by the tree walk (decided on the device) and the
     other rays are rendered as if nothing had happened."""
