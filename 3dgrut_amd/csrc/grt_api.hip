@@ -49,7 +49,7 @@ struct GrtHandle {
     uint32_t mesh_faces = 0;
     bool mesh_built = false;
     // packet lists of the forward (GrtLists): cones, per-particle bounds and records, the binning pipeline's buffers
-    DeviceBuffer l_flags, l_block_cones, l_super_cones, l_pair_cache, l_inst_rel, l_key_bits, l_counts, l_pidx, l_key_tmp, l_pidx_tmp, l_offsets, l_starts,
+    DeviceBuffer l_flags, l_block_cones, l_super_cones, l_pair_cache, l_inst_rel, l_key_bits, l_counts, l_pidx, l_key_tmp, l_pidx_tmp, l_offsets, l_starts, l_bounds,
         l_scan_scratch, l_sort_scratch, l_block_keys, l_vals, l_block_keys_tmp, l_vals_tmp, l_ranges;
     uint32_t* l_host = nullptr;          // pinned: {entries, uniform-origin flag}
     uint64_t list_entries = 0;           // of the last forward (0: the BVH walk served it)
@@ -152,7 +152,7 @@ int grt_create(const GrtConfig* config, GrtHandle** handle) {
 static void release_scratch(GrtHandle* h) {
     DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
                             &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
-                            &h->work_counters, &h->l_flags, &h->l_starts, &h->l_pair_cache, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits,
+                            &h->work_counters, &h->l_flags, &h->l_starts, &h->l_bounds, &h->l_pair_cache, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits,
                             &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets, &h->l_scan_scratch, &h->l_sort_scratch,
                             &h->l_block_keys, &h->l_vals, &h->l_block_keys_tmp, &h->l_vals_tmp, &h->l_ranges,
                             &h->log_pool, &h->log_table, &h->log_nbwd, &h->log_state, &h->m_aabb, &h->m_slack, &h->m_scene_enc,
@@ -259,7 +259,7 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
 // `lists->ranges` stays null when the frame does not qualify (rays with different origins, no particle in view) or GRUT_GRT_NO_LISTS is set.
 static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_origin, const float* ray_direction,
                        GrtLists* out) {
-    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     h->list_entries = 0;
     h->log_lists = lists;   // the list scratch is about to be overwritten: a pending backward of an older forward walks the tree
     if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0) {
@@ -297,6 +297,7 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
             for (DeviceBuffer* b4 : {&h->l_block_keys, &h->l_vals, &h->l_block_keys_tmp, &h->l_vals_tmp})
                 usable = usable && b4->ensure((size_t)n * 4, 1.3f) == GRUT_OK;
             usable = usable && h->l_ranges.ensure((size_t)nb * 8, 1.25f) == GRUT_OK;
+            usable = usable && h->l_bounds.ensure((size_t)n * 8, 1.3f) == GRUT_OK;
             usable = usable && h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.3f) + 4096)) == GRUT_OK;
             if (!usable) (void)hipGetLastError();
         }
@@ -317,6 +318,8 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
             lists.inst_rel = h->l_inst_rel.as<float>();
             lists.block_cones = h->l_block_cones.as<GrtCone>();
             lists.dir_len_enc = dir_len;
+            GRUT_HIP(hipMemsetAsync(h->l_bounds.ptr, 0xFF, (size_t)n * 8, s));   // "not tested yet"
+            lists.bounds = h->l_bounds.as<float2>();
             h->list_entries = I;
         }
     }
@@ -476,7 +479,7 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
     P.bwd_cnt = h->dbg_bwd_cnt;
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
     GrtHitLog log = {nullptr, nullptr, nullptr, nullptr, 0, 0};
-    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // replay the hits the forward of THIS frame processed; any other backward (an older forward's, see log_matches) traverses again
     if (h->log_matches(*frame, particle_density, ray_origin, ray_direction)) {
         log = h->log;

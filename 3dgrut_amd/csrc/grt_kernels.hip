@@ -291,6 +291,7 @@ __device__ __forceinline__ void scene_interval(const float* __restrict__ s, cons
 struct Cand {
     float t, tnear, tfar;
     bool ok;
+    bool box;   // `always_box` calls: the ray meets the proxy (whatever its hit distance)
     int why;   // instrumented builds: 1 = distance outside the wanted range, 2 = the ray misses the proxy's box, 3 = farther than 3 sigma
 };
 // `t_lo` / (`t_hi`, `id_hi`): the caller only wants candidates with t_lo < t and (t, id) < (t_hi, id_hi); the hit distance
@@ -319,17 +320,21 @@ __device__ __forceinline__ f3 proxy_origin(const float4& a, const float4& b, con
 }
 // (TIES: candidates AT t_lo are evaluated too — t_lo is then the ray's last hit distance, see GhostLog)
 template <bool REL, bool TIES = false>
-__device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi);
+__device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi,
+                                              bool always_box = false);
 template <typename Q, bool REL, bool TIES>
 __device__ __forceinline__ Cand candidate_q(const Q* __restrict__ rec, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
     const float4 a = ld4(rec, 0), b = ld4(rec, 1), e = ld4(rec, 2);
     return candidate_abe<REL, TIES>(a, b, e, r, t_lo, t_hi, id, id_hi);
 }
+// always_box (wave-uniform): the box test runs for rays outside the wanted range too and its outcome is reported in `box`; `ok` and
+// everything else are what the plain call returns
 template <bool REL, bool TIES>
-__device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
+__device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi,
+                                              bool always_box) {
 #pragma clang fp contract(off)
     Cand c;
-    c.ok = false; c.t = 0.f; c.tnear = 0.f; c.tfar = 0.f; c.why = 1;
+    c.ok = false; c.box = false; c.t = 0.f; c.tnear = 0.f; c.tfar = 0.f; c.why = 1;
     // inst = {W00 W01 W02 W10 | W11 W12 W20 W21 | W22 mux muy muz}
     const f3 po = REL ? mk3(e.y, e.z, e.w) : proxy_origin(a, b, e, r.o);
     const float pox = po.x, poy = po.y, poz = po.z;
@@ -340,7 +345,8 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     const float dd = pdx * pdx + pdy * pdy + pdz * pdz;
     const float denominator = 1.f / dd;
     c.t = numerator * denominator;
-    if (!(TIES ? (c.t >= t_lo) : (c.t > t_lo)) || !((c.t < t_hi) || (c.t == t_hi && id < id_hi))) return c;
+    const bool wanted = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
+    if (!wanted && !always_box) return c;
     // slab test of the unit box; min / max are plain comparisons (a < b ? a : b), NaN-propagating like the checker's
     const float ax0 = (-1.f - pox) / pdx, ax1 = (1.f - pox) / pdx;
     const float ay0 = (-1.f - poy) / pdy, ay1 = (1.f - poy) / pdy;
@@ -349,14 +355,14 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     auto mx = [](float x, float y) { return x > y ? x : y; };
     const float tnear = mx(mx(mn(ax0, ax1), mn(ay0, ay1)), mn(az0, az1));
     const float tfar = mn(mn(mx(ax0, ax1), mx(ay0, ay1)), mx(az0, az1));
-    c.why = 2;
+    if (wanted) c.why = 2;
     if (!(tnear <= tfar)) return c;
-    c.why = 3;
-    c.tnear = tnear; c.tfar = tfar;
+    if (wanted) { c.why = 3; c.tnear = tnear; c.tfar = tfar; }
     const float il = dd > 0.f ? 1.f / sqrtf(dd) : 1.f;
     const float nx = pdx * il, ny = pdy * il, nz = pdz * il;
     const float crx = ny * poz - nz * poy, cry = nz * pox - nx * poz, crz = nx * poy - ny * pox;
-    c.ok = ((crx * crx + cry * cry + crz * crz) * denominator < 9.0f);  // hitMaxParticleSquaredDistance, pipelineParameters.h:71
+    c.box = ((crx * crx + cry * cry + crz * crz) * denominator < 9.0f);  // hitMaxParticleSquaredDistance, pipelineParameters.h:71
+    c.ok = c.box && wanted;
     return c;
 }
 
@@ -600,10 +606,22 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
     const int c = __builtin_amdgcn_readlane(__float_as_int(v), 32), d = __builtin_amdgcn_readlane(__float_as_int(v), 48);
     return __int_as_float(max(max(a, b), max(c, d)));
 }
+// min / max over the wave of any floats (DPP within the rows of 16, the four rows meet through scalar registers)
+template <bool MAX>
+__device__ __forceinline__ float wave_extreme(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+    v = op(v, dpp_perm<0xB1>(v));
+    v = op(v, dpp_perm<0x4E>(v));
+    v = op(v, dpp_perm<0x141>(v));
+    v = op(v, dpp_perm<0x140>(v));
+    auto rl = [](float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); };
+    return op(op(rl(v, 0), rl(v, 16)), op(rl(v, 32), rl(v, 48)));
+}
 struct ListEntry {
     float4 a, b, e;    // proxy record {W rows, W (o - mu)}
     uint32_t id;       // particle
     float lo, hi, key; // hit-distance bounds for THIS packet's rays, and the list's sort key (a bound for every ray of the frame)
+    bool fresh;        // the bounds are the geometric ones: no round of this packet has tested the entry yet
 };
 // one entry per lane: the particle's records are gathered and its packet-specific bounds computed on the spot (one lane per entry:
 // a few dozen operations per 64 entries of wave time)
@@ -611,6 +629,7 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
     ListEntry x;
     x.a = x.b = x.e = make_float4(0.f, 0.f, 0.f, 0.f);
     x.id = 0xFFFFFFFFu; x.lo = 3.0e38f; x.hi = -3.0e38f; x.key = 3.0e38f;   // dead for every ray, beyond every bound
+    x.fresh = false;
     if (e < end) {
         x.id = L.entries[e];
         if (x.id != 0xFFFFFFFFu) {
@@ -619,7 +638,12 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
             const float4 vk = rec[3];
             const f3 v = mk3(vk.x, vk.y, vk.z);
             x.key = vk.w;
-            packet_bounds(cone, v, dot(v, v), x.a, x.b, x.e.x, vk.w, 3.0e38f, dmin, dmax, x.lo, x.hi);
+            // (device-scope accesses: the words were written by this packet's own wave in an earlier round — never serve them from a stale L1 line)
+            const unsigned long long raw = __hip_atomic_load(reinterpret_cast<unsigned long long*>(L.bounds + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float2 known = make_float2(__uint_as_float((uint32_t)raw), __uint_as_float((uint32_t)(raw >> 32)));
+            if (known.y == known.y) { x.lo = known.x; x.hi = known.y; }   // the packet's own rays have been through this entry (see list_round)
+            else packet_bounds(cone, v, dot(v, v), x.a, x.b, x.e.x, vk.w, 3.0e38f, dmin, dmax, x.lo, x.hi);
+            x.fresh = !(known.y == known.y);
         }
     }
     return x;
@@ -633,7 +657,14 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
 // 22.6 vs 20.0 ms).  The scan starts at `start` (everything before it is dead for every ray for good: hi < the rays' last hit
 // distances, which only grow) and ends with the first key beyond the bound (keys are lower bounds of lo: nothing that follows can
 // enter a buffer).
-template <bool COUNT, int G, bool GHOST = false>
+// REFINE (the forward): the first time an entry is tested, every running ray takes the box test, and the smallest and largest hit
+// distance over the rays that MEET the proxy are kept (GrtLists::bounds; an empty interval when none does) and replace the geometric
+// [lo, hi] from then on — in every later round of this launch and in the backward's
+// re-derivations.  Rays only ever stop, and a ray needs an entry no later than the round whose window holds its hit distance, so the
+// rays that were running at the first test are all the rays that can ever want the entry: the interval is exact for them.  (A needle's
+// geometric interval spans its whole length; the window of a round slides through it in up to ten rounds, each of which tested the
+// entry against all 64 rays for nothing.)
+template <bool COUNT, int G, bool GHOST = false, bool REFINE = false>
 __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& cone, float dmin, float dmax, uint32_t le, uint32_t& start, const RayW& r,
                                            float tmin, float tmax, bool active, int lane, float4* __restrict__ s_ent /* [64][3] */, HitBufferT<G>& buf,
                                            TraceCounters& tc, GhostLog* ghosts = nullptr) {
@@ -650,6 +681,7 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
         s_ent[lane * 3 + 0] = nxt.a; s_ent[lane * 3 + 1] = nxt.b; s_ent[lane * 3 + 2] = nxt.e;
         const uint32_t my_id = nxt.id;
         const float my_lo = nxt.lo, my_hi = nxt.hi, my_key = nxt.key;
+        const unsigned long long fresh = REFINE ? __ballot(nxt.fresh) : 0ull;
         __syncthreads();   // single-wave workgroup: orders the LDS hand-off
         const uint32_t bend = min(le, base + 64u);
         nxt = load_list_entry(L, cone, dmin, dmax, bend + lane, le);   // the following batch travels while this one is tested
@@ -670,9 +702,12 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
             live &= live - 1;
             const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j);
             if (COUNT && lane == 0) tc.wave_leaves++;
+            float t_mine_lo = 3.0e38f, t_mine_hi = -3.0e38f;
+            const bool first_test = REFINE && ((fresh >> j) & 1ull);
             if (active) {
-                const Cand cd = GHOST ? candidate_abe<true, true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, ghosts->tie_t, buf.t[G - 1], id, buf.id[G - 1])
-                                      : candidate_abe<true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
+                const Cand cd = GHOST ? candidate_abe<true, true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, ghosts->tie_t, buf.t[G - 1], id, buf.id[G - 1], first_test)
+                                      : candidate_abe<true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, tmin, buf.t[G - 1], id, buf.id[G - 1], first_test);
+                if (REFINE && cd.box) { t_mine_lo = cd.t; t_mine_hi = cd.t; }
                 const bool reach = cd.ok && (cd.t < tmax) && (cd.tnear <= tmax) && hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
                 const bool in_range = reach && (cd.t > tmin);
                 const bool ins = in_range && (cd.tfar >= tmin);
@@ -687,6 +722,14 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
                     buf.insert(cd.t, id);
                     if (COUNT) tc.inserts++;
                 }
+            }
+            if (first_test) {
+                // (a NaN distance fails every comparison of the candidate test: such a ray never wants the entry; fminf / fmaxf drop it)
+                const float lo_all = wave_extreme<false>(t_mine_lo), hi_all = wave_extreme<true>(t_mine_hi);
+                if (lane == 0)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.bounds + base + (uint32_t)j),
+                                       (unsigned long long)__float_as_uint(lo_all) | ((unsigned long long)__float_as_uint(hi_all) << 32), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             }
             if ((++tested & 7) == 0 && live) {   // tighten the bound now and then: entries that fell beyond it leave the batch's work list
                 wmax_bound = wave_max_nonneg(active ? fminf(tmax, buf.t[G - 1]) : -1.f);
@@ -910,7 +953,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         uint32_t g_id[kGrtMaxGhosts];
         {
             HitBuffer buf;
-            if (UNI) list_round<COUNT, kGrtMaxHits, LOG>(lists, cone, dmin, dmax, list_end, list_start, r, tLast + eps, tExit + eps, running, lane, s_ent, buf, tc, &ghosts);
+            if (UNI) list_round<COUNT, kGrtMaxHits, LOG, true>(lists, cone, dmin, dmax, list_end, list_start, r, tLast + eps, tExit + eps, running, lane, s_ent, buf, tc, &ghosts);
             else trace_round<COUNT, kGrtMaxHits, LOG>(bvh, r, tLast + eps, tExit + eps, running, lane, s_stack, buf, tc, &ghosts);
             if (LOG) {
 #pragma unroll
