@@ -318,7 +318,6 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
             lists.inst_rel = h->l_inst_rel.as<float>();
             lists.block_cones = h->l_block_cones.as<GrtCone>();
             lists.dir_len_enc = dir_len;
-            GRUT_HIP(hipMemsetAsync(h->l_bounds.ptr, 0xFF, (size_t)n * 8, s));   // "not tested yet"
             lists.bounds = h->l_bounds.as<float2>();
             h->list_entries = I;
         }

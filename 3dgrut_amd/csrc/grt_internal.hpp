@@ -68,9 +68,11 @@ struct GrtLists {
                                      // distance for every ray)
     const GrtCone* block_cones;      // [blocks] bounding cone of each packet's rays (list_round derives packet-specific bounds from it)
     const uint32_t* dir_len_enc;     // [2] float bits of the smallest / largest ray direction length of the frame
-    float2* bounds;                  // [I] per entry: the smallest / largest hit distance over the packet's rays, written by the forward
-                                     // the first time the packet tests the entry (all ones = not tested yet: geometric bounds apply)
+    float2* bounds;                  // [I] per entry: the smallest / largest hit distance over the packet's rays that meet the proxy,
+                                     // written by the forward the first time the packet tests the entry, which then sets
+                                     // kGrtEntryRefined in the entry's word (entries without the bit: geometric bounds apply)
 };
+constexpr uint32_t kGrtEntryRefined = 0x80000000u;   // (particle indices stay below 2^31; the pad entry is all ones)
 struct GrtCone {   // bounding cone of the rays of an 8x8 packet / of a 64x64-pixel super tile, apex at the common ray origin
     float ax, ay, az, cos_t, sin_t, valid, pad0, pad1;
 };

@@ -631,19 +631,24 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
     x.id = 0xFFFFFFFFu; x.lo = 3.0e38f; x.hi = -3.0e38f; x.key = 3.0e38f;   // dead for every ray, beyond every bound
     x.fresh = false;
     if (e < end) {
-        x.id = L.entries[e];
-        if (x.id != 0xFFFFFFFFu) {
+        // (device-scope accesses: the flag and the interval were written by this packet's own wave in an earlier round — never serve them
+        // from a stale L1 line)
+        const uint32_t word = __hip_atomic_load(const_cast<uint32_t*>(L.entries) + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x.id = word;
+        if (word != 0xFFFFFFFFu) {
+            x.id = word & ~kGrtEntryRefined;
             const float4* rec = reinterpret_cast<const float4*>(L.inst_rel) + 4 * (size_t)x.id;   // one 64-byte line per entry
             x.a = rec[0]; x.b = rec[1]; x.e = rec[2];
             const float4 vk = rec[3];
             const f3 v = mk3(vk.x, vk.y, vk.z);
             x.key = vk.w;
-            // (device-scope accesses: the words were written by this packet's own wave in an earlier round — never serve them from a stale L1 line)
-            const unsigned long long raw = __hip_atomic_load(reinterpret_cast<unsigned long long*>(L.bounds + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float2 known = make_float2(__uint_as_float((uint32_t)raw), __uint_as_float((uint32_t)(raw >> 32)));
-            if (known.y == known.y) { x.lo = known.x; x.hi = known.y; }   // the packet's own rays have been through this entry (see list_round)
-            else packet_bounds(cone, v, dot(v, v), x.a, x.b, x.e.x, vk.w, 3.0e38f, dmin, dmax, x.lo, x.hi);
-            x.fresh = !(known.y == known.y);
+            if (word & kGrtEntryRefined) {   // the packet's own rays have been through this entry (see list_round)
+                const unsigned long long raw = __hip_atomic_load(reinterpret_cast<unsigned long long*>(L.bounds + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                x.lo = __uint_as_float((uint32_t)raw); x.hi = __uint_as_float((uint32_t)(raw >> 32));
+            } else {
+                packet_bounds(cone, v, dot(v, v), x.a, x.b, x.e.x, vk.w, 3.0e38f, dmin, dmax, x.lo, x.hi);
+                x.fresh = true;
+            }
         }
     }
     return x;
@@ -726,10 +731,12 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
             if (first_test) {
                 // (a NaN distance fails every comparison of the candidate test: such a ray never wants the entry; fminf / fmaxf drop it)
                 const float lo_all = wave_extreme<false>(t_mine_lo), hi_all = wave_extreme<true>(t_mine_hi);
-                if (lane == 0)
+                if (lane == 0) {
                     __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.bounds + base + (uint32_t)j),
                                        (unsigned long long)__float_as_uint(lo_all) | ((unsigned long long)__float_as_uint(hi_all) << 32), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(const_cast<uint32_t*>(L.entries) + base + (uint32_t)j, id | kGrtEntryRefined, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             if ((++tested & 7) == 0 && live) {   // tighten the bound now and then: entries that fell beyond it leave the batch's work list
                 wmax_bound = wave_max_nonneg(active ? fminf(tmax, buf.t[G - 1]) : -1.f);
