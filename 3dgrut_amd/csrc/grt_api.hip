@@ -114,6 +114,8 @@ static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
     }
     static const int sphere_lists = getenv("GRUT_GRT_SPHERE_LISTS") ? 1 : 0;
     P.sphere_lists = sphere_lists;
+    static const float list_mark = getenv("GRUT_GRT_LIST_MARK") ? (float)atof(getenv("GRUT_GRT_LIST_MARK")) : 1.0f;
+    P.list_mark = list_mark;
     P.out_half = h->cfg.feature_output_half;
     return P;
 }
