@@ -104,3 +104,100 @@ def test_bounds_are_exact_for_a_sphere_seen_along_the_axis():
     v = np.array([0.0, 0.0, 5.0])
     lo, hi = _packet_bounds(axis, 0.0, v, W, k, 1.0, 1.0)
     assert abs(lo - 5.0) < 1e-9 and abs(hi - 5.0) < 1e-9
+
+
+def test_tangent_plane_rectangles_select_every_packet_a_ray_can_hit_from():
+    """The candidate selection of the binning (grt_kernels.hip: grid_particle, rect_overlap; DESIGN.md §5 "late round 3"): in a frame
+    (u, w, a) with d.a > 0 for every ray, a ray that touches the proxy box has its tangent-plane coordinates ((d.u)/(d.a), (d.w)/(d.a))
+    inside the bounding rectangle of the box's 8 projected corners whenever the whole box lies in front of the apex plane — so a packet
+    whose own rectangle of ray coordinates misses that rectangle holds no such ray.  Checked in float64 against brute force; boxes that
+    come near the plane (the device walks the super tiles for those) are checked to be recognised by the zmin test."""
+    rng = np.random.default_rng(5)
+    checked = rejected = 0
+    for case in range(500):
+        k = np.exp(rng.normal(size=3) * rng.choice([0.2, 0.8, 1.6])) * rng.choice([0.01, 0.05, 0.3])
+        R = _rot(rng)
+        W = (R / k).T
+        a = _rot(rng)[:, 2]
+        u = np.cross(a, [1.0, 0.0, 0.0] if abs(a[0]) < 0.9 else [0.0, 1.0, 0.0])
+        u /= np.linalg.norm(u)
+        w = np.cross(a, u)
+        # a proxy somewhere in front of (or beside) the apex, seen under up to ~85 degrees off the axis
+        dirc = _cone_rays(rng, a, np.deg2rad(rng.choice([20, 60, 85])), 1)[0]
+        v = dirc * rng.uniform(0.05, 3.0)
+        H = R * k                                       # columns = the box's half axes in world space
+        corners = np.array([v + H @ np.array([s0, s1, s2]) for s0 in (-1, 1) for s1 in (-1, 1) for s2 in (-1, 1)])
+        z = corners @ a
+        ext = np.linalg.norm(v) + np.linalg.norm(k)
+        if z.min() < 0.02 * ext:
+            rejected += 1                               # no rectangle: the walk through the super tiles serves this box
+            continue
+        x0, x1 = (corners @ u / z).min(), (corners @ u / z).max()
+        y0, y1 = (corners @ w / z).min(), (corners @ w / z).max()
+        # rays through random points of the box (all of them touch it), and rays aimed around it
+        pts = v + (H @ rng.uniform(-1, 1, size=(3, 400))).T
+        pts = np.concatenate([pts, v + (H @ (rng.uniform(-1, 1, size=(3, 400)) * 1.5)).T])
+        d = pts / np.linalg.norm(pts, axis=1, keepdims=True)
+        d = d[d @ a > 0.05]
+        po, pd = W @ (-v), (W @ d.T).T                  # the ray in the proxy's frame: origin W (o - mu), direction W d
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t0, t1 = (-1 - po) / pd, (1 - po) / pd
+        tn, tf = np.minimum(t0, t1).max(axis=1), np.maximum(t0, t1).min(axis=1)
+        touch = (tn <= tf) & (tf > 0)
+        tx, ty = d @ u / (d @ a), d @ w / (d @ a)
+        inside = (tx >= x0 - 1e-9) & (tx <= x1 + 1e-9) & (ty >= y0 - 1e-9) & (ty <= y1 + 1e-9)
+        assert inside[touch].all(), f"case {case}: a ray touching the box lies outside the projected rectangle"
+        checked += int(touch.sum())
+    assert checked > 50_000 and rejected > 20
+
+
+def test_refined_intervals_cover_every_ray_that_can_want_the_entry():
+    """list_round<REFINE> replaces an entry's geometric hit-distance interval by [min, max] of t over the rays that were running AND met
+    the proxy at the packet's first test of the entry.  The argument that this loses nothing, as a simulation: rays advance through a
+    shared list in rounds of k candidates, stop at random, and an entry is only offered while its interval overlaps the union of the
+    running rays' windows — every ray must still receive exactly the candidates a brute-force per-ray scan gives it."""
+    rng = np.random.default_rng(23)
+    for case in range(60):
+        n_rays, n_ent, k = 16, int(rng.integers(20, 200)), 4
+        t = rng.uniform(0, 10, size=(n_ent, n_rays))                    # hit distance of entry e for ray r
+        meets = rng.uniform(size=(n_ent, n_rays)) < rng.choice([0.1, 0.5, 0.9])
+        stop_after = rng.integers(1, 40, size=n_rays)                   # a ray terminates after this many processed hits
+        geo_lo, geo_hi = t.min(axis=1) - rng.uniform(0, 3, n_ent), t.max(axis=1) + rng.uniform(0, 3, n_ent)
+        want = []
+        for r in range(n_rays):                                         # brute force: the ray's hits in order, cut at its termination
+            order = [e for e in np.argsort(t[:, r], kind="stable") if meets[e, r]]
+            want.append(order[: stop_after[r]])
+        lo, hi = geo_lo.copy(), geo_hi.copy()
+        refined = np.zeros(n_ent, bool)
+        tmin = np.full(n_rays, -1.0)
+        running = np.ones(n_rays, bool)
+        got = [[] for _ in range(n_rays)]
+        while running.any():
+            wmin = tmin[running].min()
+            bufs = [[] for _ in range(n_rays)]
+            bound = np.full(n_rays, np.inf)
+            for e in range(n_ent):                                      # the scan: entries whose interval overlaps the wave's window
+                wmax = bound[running].max()
+                if hi[e] < wmin or lo[e] > wmax:
+                    continue
+                if not refined[e]:
+                    m = running & meets[e]
+                    lo[e], hi[e] = (t[e, m].min(), t[e, m].max()) if m.any() else (np.inf, -np.inf)
+                    refined[e] = True
+                for r in np.nonzero(running & meets[e])[0]:
+                    if tmin[r] < t[e, r] < bound[r]:
+                        bufs[r] = sorted(bufs[r] + [(t[e, r], e)])[:k]
+                        if len(bufs[r]) == k:
+                            bound[r] = bufs[r][-1][0]
+            for r in np.nonzero(running)[0]:
+                if not bufs[r]:
+                    running[r] = False
+                    continue
+                for tt, e in bufs[r]:
+                    if len(got[r]) < stop_after[r]:
+                        got[r].append(e)
+                        tmin[r] = tt
+                if len(got[r]) >= stop_after[r]:
+                    running[r] = False
+        for r in range(n_rays):
+            assert got[r] == want[r], f"case {case}, ray {r}"
