@@ -3071,7 +3071,7 @@ __global__ __launch_bounds__(256) void grt_list_ranges_kernel(uint32_t n, uint32
 void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* ray_o, const float* ray_d, uint32_t* uniform_origin,
                            uint32_t* dir_len_enc, GrtCone* block_cones, GrtCone* super_cones) {
     const GrtGrid G = grt_block_grid(block_cones, grt_num_blocks(P.W, P.H), blocks_x(P.W));
-    static const bool no_grid = getenv("GRUT_GRT_NO_GRID") != nullptr;   // (development switch: the super tile scan for every frame)
+    const bool no_grid = getenv("GRUT_GRT_NO_GRID") != nullptr;   // (development switch, read per frame: the super tile scan for every frame)
     const bool packable = blocks_x(P.W) <= 4096u && blocks_y(P.H) <= 4096u;   // grid_pack keeps 12 bits per coordinate (frames up to 32768 pixels a side)
     hipLaunchKernelGGL(grt_list_init_kernel, dim3(1), dim3(1), 0, s, uniform_origin, dir_len_enc, G.hdr, (no_grid || P.sphere_lists || !packable) ? 0u : 1u);
     hipLaunchKernelGGL(grt_block_cone_kernel, dim3(grt_num_blocks(P.W, P.H)), dim3(64), 0, s, P, ray_o, ray_d, uniform_origin, block_cones);
