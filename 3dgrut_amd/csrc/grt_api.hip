@@ -116,6 +116,8 @@ static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
     P.sphere_lists = sphere_lists;
     static const float list_mark = getenv("GRUT_GRT_LIST_MARK") ? (float)atof(getenv("GRUT_GRT_LIST_MARK")) : 1.0f;
     P.list_mark = list_mark;
+    static const uint32_t lane_area = getenv("GRUT_GRT_LANE_AREA") ? (uint32_t)atoi(getenv("GRUT_GRT_LANE_AREA")) : 32u;
+    P.bin_lane_area = lane_area < 1u ? 1u : (lane_area > 64u ? 64u : lane_area);
     P.out_half = h->cfg.feature_output_half;
     return P;
 }

@@ -49,6 +49,7 @@ struct GrtTraceParams {
     int sph_half, out_half;   // fp16 feature I/O (GrtConfig::particle_feature_half / feature_output_half)
     int nht, nht_k, nht_ipd, nht_support, nht_act, nht_nf, nht_ray_dim;   // neural harmonic features (GrtConfig::feature_transform_type 1)
     int sphere_lists;         // development switch (GRUT_GRT_SPHERE_LISTS=1): bin by the proxies' bounding spheres only
+    uint32_t bin_lane_area;   // binning: a particle with at most this many candidate cells is tested by its own lane (development switch GRUT_GRT_LANE_AREA, <= 64)
     float list_mark;          // list_round's first pass reaches list_mark x the previous round's span (development switch GRUT_GRT_LIST_MARK, default 1: measured 0.5 / 0.8 / 1 / 1.25 / 2 / off = 10.8 / 10.0 / 9.36 / 9.45 / 9.53 / 9.75 ms forward)
     unsigned long long* bwd_sig;
     uint32_t* bwd_cnt;

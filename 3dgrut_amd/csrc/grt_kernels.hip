@@ -2780,13 +2780,13 @@ __device__ __forceinline__ void emit_cached_pairs(const GrtTraceParams& P, int l
 //   kind 3  no rectangle — the box comes within 2 % of its distance of the apex plane, where the projection blows up: the wave walks
 //           the super tiles for it (super tile cones, then the packets of those it reaches)
 // The rectangle only SELECTS candidates; what enters a list is decided by packet_hit, as in the super tile scan.
-constexpr uint32_t kBinLaneArea = 32;
+constexpr uint32_t kBinLaneArea = 32;   // (GRUT_GRT_LANE_AREA: 8 / 16 / 32 / 64 cells -> count + expand 1.07 / 0.85 / 0.72 / 0.77 ms at 1 M particles, 800x800)
 struct GridParticle {
     int kind;
     uint32_t bx0, by0, wdt, hgt;
     float px0, px1, py0, py1;
 };
-__device__ __forceinline__ GridParticle grid_particle(const GrtGrid& G, uint32_t gx, uint32_t gy, bool have, const BinParticle& q) {
+__device__ __forceinline__ GridParticle grid_particle(const GrtGrid& G, uint32_t gx, uint32_t gy, bool have, const BinParticle& q, uint32_t lane_area = kBinLaneArea) {
     GridParticle g;
     g.kind = 0; g.bx0 = g.by0 = 0u; g.wdt = g.hgt = 1u; g.px0 = g.py0 = 0.f; g.px1 = g.py1 = 0.f;
     const f3 a = mk3(G.hdr[0], G.hdr[1], G.hdr[2]), u = mk3(G.hdr[3], G.hdr[4], G.hdr[5]), w = mk3(G.hdr[6], G.hdr[7], G.hdr[8]);
@@ -2819,7 +2819,7 @@ __device__ __forceinline__ GridParticle grid_particle(const GrtGrid& G, uint32_t
     }
     if (bx0 >= gx || by0 >= gy) return g;   // outside the frame
     g.bx0 = bx0; g.by0 = by0; g.wdt = bx1 - bx0 + 1u; g.hgt = by1 - by0 + 1u;
-    g.kind = (g.wdt * g.hgt <= kBinLaneArea) ? 1 : 2;
+    g.kind = (g.wdt * g.hgt <= lane_area) ? 1 : 2;
     return g;
 }
 __device__ __forceinline__ bool rect_overlap(const float4& rc, float px0, float px1, float py0, float py1) {
@@ -2949,7 +2949,7 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
     const GrtGrid G = grt_block_grid(block_cones, gx * gy, gx);
     uint32_t n = 0u;
     if (__float_as_uint(G.hdr[9]) != 0u) {   // the frame has a tangent plane
-        const GridParticle g = grid_particle(G, gx, gy, have, q);
+        const GridParticle g = grid_particle(G, gx, gy, have, q, P.bin_lane_area);
         const unsigned long long hm = grid_lane_cells(G, block_cones, gx, gy, g, q);
         n = (uint32_t)__popcll(hm);
         uint32_t off = 0u;
@@ -3023,7 +3023,7 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
         const bool again = have && np == kGridWaveTested;
         if (__any(again)) {
             const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
-            GridParticle g = grid_particle(G, gx, gy, again, q);
+            GridParticle g = grid_particle(G, gx, gy, again, q, P.bin_lane_area);
             if (!again) g.kind = 0;
             uint32_t n = 0u;
             grid_wave_cells<true>(P, G, block_cones, super_cones, lane, g, q, p, n, off, end, out);
