@@ -193,7 +193,8 @@ void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh
                             uint32_t* block_keys, uint32_t* vals, void* pair_cache);
 size_t grt_pair_cache_bytes(uint32_t N);
 void grt_launch_list_check(hipStream_t s, uint32_t n, const uint32_t* offsets, uint32_t* flag /* [1] = 1 on overflow */);
-void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, uint32_t* ranges);
+void grt_launch_list_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev /* nullptr: n is the count */, uint32_t num_blocks, const uint32_t* sorted_keys,
+                            uint32_t* ranges);
 uint32_t grt_num_blocks(int W, int H);
 uint32_t grt_num_super(int W, int H);
 void grt_launch_mesh_aabb(hipStream_t s, uint32_t F, const float* vertices, const int32_t* triangles, float* aabb, float* slack, uint32_t* scene_enc);

@@ -3041,9 +3041,11 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
         for (; off < end; ++off) { out.block_keys[off] = 0xFFFFFFFFu; out.vals[off] = 0xFFFFFFFFu; }
     }
 }
-__global__ __launch_bounds__(256) void grt_list_ranges_kernel(uint32_t n, uint32_t num_blocks, const uint32_t* __restrict__ sorted_keys,
-                                                              uint32_t* __restrict__ ranges) {
-    // four consecutive keys per thread (one 16-byte load + the key in front of them)
+__global__ __launch_bounds__(256) void grt_list_ranges_kernel(uint32_t n_max, const uint32_t* __restrict__ n_dev, uint32_t num_blocks,
+                                                              const uint32_t* __restrict__ sorted_keys, uint32_t* __restrict__ ranges) {
+    // four consecutive keys per thread (one 16-byte load + the key in front of them); n_dev: the entry count, read on the device
+    // (a speculative launch against the buffers' capacity n_max)
+    const uint32_t n = n_dev ? min(*n_dev, n_max) : n_max;
     const uint32_t e0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4u;
     if (e0 >= n) return;
     uint32_t key[4];
@@ -3095,9 +3097,9 @@ void grt_launch_list_expand(hipStream_t s, const GrtTraceParams& P, const GrtBvh
     hipLaunchKernelGGL(grt_list_expand_kernel, dim3(div_up(bvh.N, 256)), dim3(256), 0, s, P, bvh, ray_o, uniform_origin, dir_len_enc, block_cones,
                        super_cones, starts, counts, capacity, out);
 }
-void grt_launch_list_ranges(hipStream_t s, uint32_t n, uint32_t num_blocks, const uint32_t* sorted_keys, uint32_t* ranges) {
+void grt_launch_list_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32_t num_blocks, const uint32_t* sorted_keys, uint32_t* ranges) {
     if (n == 0) return;
-    hipLaunchKernelGGL(grt_list_ranges_kernel, dim3(div_up(div_up(n, 4u), 256)), dim3(256), 0, s, n, num_blocks, sorted_keys, ranges);
+    hipLaunchKernelGGL(grt_list_ranges_kernel, dim3(div_up(div_up(n, 4u), 256)), dim3(256), 0, s, n, n_dev, num_blocks, sorted_keys, ranges);
 }
 
 void grt_launch_nht_fwd(hipStream_t s, const GrtTraceParams& P, const float* density12, const float* features, const float* ray_o, const float* ray_d,

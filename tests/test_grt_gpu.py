@@ -406,6 +406,34 @@ def test_packet_lists_with_large_and_small_particles(monkeypatch):
     _assert_same_hits(lists, walk)
 
 
+def test_packet_lists_over_frames_of_changing_size(monkeypatch):
+    """One tracer, frames of different sizes, with the speculative list tail on (GRUT_GRT_SPECULATE: expansion, entry sort and ranges are
+    enqueued against the capacity of the per-entry buffers while the entry count travels to the host; off by default — it measured no
+    faster): a frame that needs more than the buffers hold runs the tail again after growing them, a smaller one leaves the excess
+    untouched.  Every frame matches its tree walk."""
+    import torch
+    monkeypatch.delenv("GRUT_GRT_NO_LISTS", raising=False)
+    monkeypatch.setenv("GRUT_GRT_SPECULATE", "1")
+    tr = _tracer()
+    nat = tr.tracer_wrapper
+    for n, w, h, scale in [(3000, 48, 32, 0.05), (20000, 96, 64, 0.04), (1500, 40, 24, 0.08), (20000, 96, 64, 0.04)]:
+        scene = _scene(n, w, h, scale)
+        g = syn.SimpleGaussians(scene["density12"], scene["sph"])
+        tr.build_acc(g, rebuild=True)
+        batch = torch_batch(scene["batch"], "cuda")
+        frame = nat.make_frame(0, 3, tr._min_transmittance, g.num_gaussians, h, w, batch.T_to_world)
+        d12 = torch.as_tensor(scene["density12"], device="cuda").contiguous()
+        sph = torch.as_tensor(scene["sph"], device="cuda").contiguous()
+        res = nat.trace(frame, d12, sph, batch.rays_ori.contiguous(), batch.rays_dir.contiguous(), hit_capacity=128)
+        torch.cuda.synchronize()
+        lists = [t.cpu().numpy() for t in res]
+        assert int(nat.stats().list_entries) > 0
+        walk, n_walk = _hits_with(scene, monkeypatch, no_lists=True)
+        monkeypatch.delenv("GRUT_GRT_NO_LISTS", raising=False)
+        assert n_walk == 0
+        _assert_same_hits(lists, walk)
+
+
 def test_a_degenerate_direction_sends_the_frame_to_the_tree_walk(monkeypatch):
     """A ray with a zero direction has no place in a bounding cone: the frame is served by the tree walk (decided on the device) and the
     other rays are rendered as if nothing had happened."""
