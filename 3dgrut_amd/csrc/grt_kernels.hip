@@ -1987,7 +1987,10 @@ __device__ __forceinline__ MeshHit mesh_closest(const GrtMeshView& m, const RayW
 }
 
 // traceVolumetricGS (3dgrtTracer.cuh:137-204) on [tmin, tmax] of ray r for the lanes with `active`: continues T and rad
-template <int DEG, bool LISTS = false>
+// REFINE (LISTS only): this call is the LAST scan of the packet's list by a set of rays that contains every ray of any later scan —
+// list_round may then keep exact per-entry intervals (see there).  The hybrid tracer scans the list twice in its first iteration
+// (the diffuse rays, then all rays): only the second scan refines.
+template <int DEG, bool LISTS = false, bool REFINE = false>
 __device__ __forceinline__ void trace_segment(const GrtTraceParams& P, const GrtBvh& bvh, const float4* __restrict__ density12,
                                               const float* __restrict__ sph, const RayW& r, float tmin, float tmax, bool active, int lane,
                                               uint32_t* __restrict__ s_stack, float* __restrict__ s_hit_t, uint32_t* __restrict__ s_hit_id, float& T,
@@ -2004,13 +2007,15 @@ __device__ __forceinline__ void trace_segment(const GrtTraceParams& P, const Grt
     TraceCounters tc;
     bool running = active;
     uint32_t list_start = list_begin;   // LISTS: a segment scans the packet's list from its beginning (see list_round)
+    float list_span = 3.0e38f;
     while (true) {
         running = running && (tLast <= t1) && (T > P.min_transmittance);
         if (!__any(running)) break;
         {
             HitBufferT<kGrtMaxHits> buf;
-            if (LISTS) list_round<false, kGrtMaxHits>(*lists, *cone, dmin, dmax, list_end, list_start, r, tLast + eps, t1 + eps, running, lane,
-                                                      reinterpret_cast<float4*>(s_hit_t), buf, tc);
+            if (LISTS) list_round<false, kGrtMaxHits, false, REFINE>(*lists, *cone, dmin, dmax, list_end, list_start, r, tLast + eps, t1 + eps, running, lane,
+                                                                     reinterpret_cast<float4*>(s_hit_t), buf, tc, nullptr, s_hit_id + kGrtMaxGhosts * 64, &list_span,
+                                                                     P.list_mark);
             else trace_round<false, kGrtMaxHits>(bvh, r, tLast + eps, t1 + eps, running, lane, s_stack, buf, tc);
             buf.store(s_hit_t, s_hit_id, lane);
         }
@@ -2361,7 +2366,7 @@ __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh
             const float T0 = T;
             const f3 rad0 = rad;
             if (trace_gs) {
-                if (primary && use_lists) trace_segment<DEG, true>(P, bvh, density12, sph, r, 1e-9f, next_t, go, lane, s_stack, s_hit_t, s_hit_id, T, rad, &lists, &cone, dmin, dmax, list_begin, list_end);
+                if (primary && use_lists) trace_segment<DEG, true, true>(P, bvh, density12, sph, r, 1e-9f, next_t, go, lane, s_stack, s_hit_t, s_hit_id, T, rad, &lists, &cone, dmin, dmax, list_begin, list_end);
                 else trace_segment<DEG>(P, bvh, density12, sph, r, 1e-9f, next_t, go, lane, s_stack, s_hit_t, s_hit_id, T, rad);
             }
             primary = false;
