@@ -214,6 +214,7 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
         return GRUT_OK;
     }
     GRUT_REQUIRE(positions && rotations && scales && densities, "grt_build_bvh: null buffer");
+    GRUT_REQUIRE(N <= 0x1FFFFFFEu, "grt_build_bvh: %u particles (the hit buffers keep 29 bits of particle index)", N);
     if (!rebuild && (!h->built || h->N != N)) rebuild = 1;  // "cannot refit GAS with a different number of gaussian" (optixTracer.cpp:629-632)
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.begin(s));
     const size_t n = N;

@@ -370,30 +370,48 @@ __device__ __forceinline__ bool hit_less(float t, uint32_t id, float bt, uint32_
 
 // G nearest candidates, ascending.  G = 16 is one trace of the reference; the forward gathers G = 32 per traversal and
 // carves two 16-hit rounds out of it (see grt_trace_fwd_kernel).
+// The per-ray buffer of one trace: the G nearest candidates in (distance, particle) order — the payload registers and the
+// compare-exchange chain of __anyhit__ah (referenceOptix.cu:210-246).  A slot is ONE ordered word: the distance widened to a double
+// (exact; a float leaves the low 29 mantissa bits of the double zero) with the particle index in those 29 bits — for the positive
+// distances a candidate has, doubles compare like the pair (distance, particle) does lexicographically.  Inserting K into the sorted
+// slots a[0..G) is then a[k] = max(a[k-1], min(a[k], K)): two instructions per slot instead of the five compares and four selects of
+// the pairwise chain (144 -> 32 per insertion; the forward makes 5.4 M wave-level insertions per frame at 1 M particles).
+constexpr uint32_t kGrtHitIdMask = 0x1FFFFFFFu;   // (grt_validate refuses more than 2^29 - 2 particles)
+__device__ __forceinline__ double hit_min(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double hit_max(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <int G>
 struct HitBufferT {
-    float t[G];
-    uint32_t id[G];
-    __device__ __forceinline__ void clear() {
-#pragma unroll
-        for (int k = 0; k < G; ++k) { t[k] = 3.0e38f; id[k] = 0xFFFFFFFFu; }
+    struct Last { float v; __device__ __forceinline__ float operator[](int) const { return v; } };      // buf.t[G - 1]
+    struct LastId { uint32_t v; __device__ __forceinline__ uint32_t operator[](int) const { return v; } };
+    double key[G];
+    Last t;        // distance of the farthest slot (3.0e38f while the buffer is not full): the only one the rounds read
+    LastId id;     // ... and its particle (0xFFFFFFFF: empty)
+    static __device__ __forceinline__ double make(float ht, uint32_t hid) {
+        return __longlong_as_double(__double_as_longlong((double)ht) | (long long)(hid & kGrtHitIdMask));
     }
+    static __device__ __forceinline__ float key_t(double k) { return (float)__longlong_as_double(__double_as_longlong(k) & ~(long long)kGrtHitIdMask); }
+    static __device__ __forceinline__ uint32_t key_id(double k) {
+        const uint32_t v = (uint32_t)__double_as_longlong(k) & kGrtHitIdMask;
+        return v == kGrtHitIdMask ? 0xFFFFFFFFu : v;
+    }
+    __device__ __forceinline__ void clear() {
+        const double empty = make(3.0e38f, kGrtHitIdMask);
+#pragma unroll
+        for (int k = 0; k < G; ++k) key[k] = empty;
+        t.v = 3.0e38f; id.v = 0xFFFFFFFFu;
+    }
+    __device__ __forceinline__ uint32_t first_id() const { return key_id(key[0]); }
     // park the sorted list in LDS ([slot][lane]) so that the per-hit code can loop over it instead of being unrolled
     __device__ __forceinline__ void store(float* __restrict__ st, uint32_t* __restrict__ sid, int lane) const {
 #pragma unroll
-        for (int k = 0; k < G; ++k) { st[k * 64 + lane] = t[k]; sid[k * 64 + lane] = id[k]; }
+        for (int k = 0; k < G; ++k) { st[k * 64 + lane] = key_t(key[k]); sid[k * 64 + lane] = key_id(key[k]); }
     }
-    // compare-exchange chain of __anyhit__ah (referenceOptix.cu:210-246), lexicographic in (distance, particle)
     __device__ __forceinline__ void insert(float ht, uint32_t hid) {
+        const double K = make(ht, hid);
 #pragma unroll
-        for (int k = 0; k < G; ++k) {
-            const bool lt = hit_less(ht, hid, t[k], id[k]);
-            const float tt = lt ? t[k] : ht;
-            const uint32_t ii = lt ? id[k] : hid;
-            t[k] = lt ? ht : t[k];
-            id[k] = lt ? hid : id[k];
-            ht = tt; hid = ii;
-        }
+        for (int k = G - 1; k >= 1; --k) key[k] = hit_max(key[k - 1], hit_min(key[k], K));
+        key[0] = hit_min(key[0], K);
+        t.v = key_t(key[G - 1]); id.v = key_id(key[G - 1]);
     }
 };
 using HitBuffer = HitBufferT<kGrtMaxHits>;
@@ -1568,7 +1586,7 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
             if (UNI) list_round<false, kGrtMaxHits>(lists, cone, dmin, dmax, list_end, list_start, r, startT + eps, endT, running, lane,
                                                     reinterpret_cast<float4*>(s_hit_t), buf, tc);
             else trace_round<false>(bvh, r, startT + eps, endT, running, lane, s_stack, buf, tc);
-            if (buf.id[0] == 0xFFFFFFFFu) running = false;
+            if (buf.first_id() == 0xFFFFFFFFu) running = false;
             buf.store(s_hit_t, s_hit_id, lane);
         }
 #pragma unroll 1
