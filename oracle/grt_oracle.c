@@ -69,8 +69,13 @@ int orc_grt_proxies(const GrtConfig* cfg, uint32_t N, const real* positions, con
 
 /* ---- candidate test -------------------------------------------------------------------------
  * Instance traversal: transform the ray with the instance's inverse map, slab-test the unit box [-1,1]^3 over the
- * current interval, then intersectInstanceParticle (gaussianParticles.cuh:449-466).  All in one arithmetic type, no
- * contraction (the HIP kernel evaluates the same expressions in the same order: hit order is compared bit-exactly). */
+ * current interval, then intersectInstanceParticle (gaussianParticles.cuh:449-466).  All in one arithmetic type.
+ * The HIP kernel (grt_kernels.hip: candidate_abe) evaluates EXACTLY these operations in this order — hit order is compared
+ * bit for bit — so the sequence is written out: fused multiply-adds where the device code has them (the reference's own
+ * device code is compiled with nvcc's default contraction, its box test runs in the RT cores: neither fixes a rounding),
+ * one correctly rounded division for the distance and one reciprocal per axis for the slabs, IEEE minNum / maxNum, and
+ * the 3-sigma test |pd x po|^2 < 9 |pd|^4 without the normalisation (the same inequality as
+ * |normalize(pd) x po|^2 / |pd|^2 < 9). */
 typedef struct { real t, tnear, tfar; int ok; } grt_cand;
 
 static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist) {
@@ -78,24 +83,23 @@ static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist) {
     const v3 dl = v3_make(o.x - inst[9], o.y - inst[10], o.z - inst[11]);
     const v3 po = v3_make(inst[0] * dl.x + inst[1] * dl.y + inst[2] * dl.z, inst[3] * dl.x + inst[4] * dl.y + inst[5] * dl.z,
                           inst[6] * dl.x + inst[7] * dl.y + inst[8] * dl.z);
-    const v3 pd = v3_make(inst[0] * d.x + inst[1] * d.y + inst[2] * d.z, inst[3] * d.x + inst[4] * d.y + inst[5] * d.z,
-                          inst[6] * d.x + inst[7] * d.y + inst[8] * d.z);
+    const v3 pd = v3_make(r_fma(inst[2], d.z, r_fma(inst[1], d.y, inst[0] * d.x)), r_fma(inst[5], d.z, r_fma(inst[4], d.y, inst[3] * d.x)),
+                          r_fma(inst[8], d.z, r_fma(inst[7], d.y, inst[6] * d.x)));
     /* slab test of the unit box */
-    const real ax0 = (-1 - po.x) / pd.x, ax1 = (1 - po.x) / pd.x;
-    const real ay0 = (-1 - po.y) / pd.y, ay1 = (1 - po.y) / pd.y;
-    const real az0 = (-1 - po.z) / pd.z, az1 = (1 - po.z) / pd.z;
-    const real tnear = r_max(r_max(r_min(ax0, ax1), r_min(ay0, ay1)), r_min(az0, az1));
-    const real tfar  = r_min(r_min(r_max(ax0, ax1), r_max(ay0, ay1)), r_max(az0, az1));
+    const real ix = 1 / pd.x, iy = 1 / pd.y, iz = 1 / pd.z;
+    const real ax0 = (-1 - po.x) * ix, ax1 = (1 - po.x) * ix;
+    const real ay0 = (-1 - po.y) * iy, ay1 = (1 - po.y) * iy;
+    const real az0 = (-1 - po.z) * iz, az1 = (1 - po.z) * iz;
+    const real tnear = r_fmax(r_fmax(r_fmin(ax0, ax1), r_fmin(ay0, ay1)), r_fmin(az0, az1));
+    const real tfar  = r_fmin(r_fmin(r_fmax(ax0, ax1), r_fmax(ay0, ay1)), r_fmax(az0, az1));
     if (!(tnear <= tfar)) return c;
     c.tnear = tnear; c.tfar = tfar;
     /* intersectInstanceParticle */
-    const real numerator = -(po.x * pd.x + po.y * pd.y + po.z * pd.z);
-    const real dd = pd.x * pd.x + pd.y * pd.y + pd.z * pd.z;
-    const real denominator = 1 / dd;
-    c.t = numerator * denominator;
-    const v3 n = dd > 0 ? v3_scale(pd, 1 / r_sqrt(dd)) : pd;
-    const v3 cr = v3_cross(n, po);
-    c.ok = (v3_dot(cr, cr) * denominator < max_sqdist);
+    const real numerator = -r_fma(po.z, pd.z, r_fma(po.y, pd.y, po.x * pd.x));
+    const real dd = r_fma(pd.z, pd.z, r_fma(pd.y, pd.y, pd.x * pd.x));
+    c.t = numerator / dd;
+    const v3 cr = v3_make(r_fma(pd.y, po.z, -(pd.z * po.y)), r_fma(pd.z, po.x, -(pd.x * po.z)), r_fma(pd.x, po.y, -(pd.y * po.x)));
+    c.ok = (r_fma(cr.z, cr.z, r_fma(cr.y, cr.y, cr.x * cr.x)) < max_sqdist * (dd * dd));
     return c;
 }
 
