@@ -38,7 +38,11 @@ static inline real r_ceil(real x) { return sizeof(real) == 4 ? (real)ceilf((floa
 static inline real r_fabs(real x) { return x < 0 ? -x : x; }
 /* fused multiply-add and IEEE minNum / maxNum in the oracle's arithmetic type (what v_fma_f32 / v_min_f32 / v_max_f32 compute) */
 /* (the hardware instruction where the host has it — same correctly rounded result as libm's software fmaf, 20x faster) */
-#if defined(__x86_64__) && defined(__GNUC__)
+#if defined(__FMA__)   /* built with -mfma (oracle/Makefile does when the build host has the unit): the instruction, inline */
+static inline float orc_fmaf_hw(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static inline double orc_fma_hw(double a, double b, double c) { return __builtin_fma(a, b, c); }
+static inline int orc_have_fma(void) { return 1; }
+#elif defined(__x86_64__) && defined(__GNUC__)
 __attribute__((target("fma"))) static float orc_fmaf_hw(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __attribute__((target("fma"))) static double orc_fma_hw(double a, double b, double c) { return __builtin_fma(a, b, c); }
 static inline int orc_have_fma(void) { static int have = -1; if (have < 0) have = __builtin_cpu_supports("fma") ? 1 : 0; return have; }
