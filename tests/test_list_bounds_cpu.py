@@ -201,3 +201,38 @@ def test_refined_intervals_cover_every_ray_that_can_want_the_entry():
                     running[r] = False
         for r in range(n_rays):
             assert got[r] == want[r], f"case {case}, ray {r}"
+
+
+def test_ordered_hit_words_sort_like_distance_particle_pairs():
+    """HitBufferT (grt_kernels.hip) keeps a candidate as ONE double: the float distance widened (exact) with the particle index in the
+    29 low mantissa bits the widening leaves zero, and inserts with a[k] = max(a[k-1], min(a[k], K)).  Checked here: the widening leaves
+    those bits zero for every positive float (normal or denormal), the words order exactly like (distance, particle) pairs do — ties in
+    the distance included — and the min / max recurrence IS the sorted insertion that drops the largest."""
+    rng = np.random.default_rng(2)
+    t = np.concatenate([rng.uniform(1e-3, 50, 4000), np.exp(rng.uniform(-100, 80, 4000)), [1e-45, 1.4e-45, 3e-39, 3.0e38, 1.0, 1.0, 1.0]]).astype(np.float32)
+    t = np.concatenate([t, rng.choice(t, 3000)])                     # plenty of equal distances
+    ids = rng.integers(0, 2**29 - 1, size=t.size, dtype=np.uint64)
+    wide = t.astype(np.float64).view(np.uint64)
+    assert not np.any(wide & np.uint64(0x1FFFFFFF)), "a widened float has bits in the index field"
+    words = (wide | ids).view(np.float64)
+    order_words = np.argsort(words, kind="stable")
+    order_pairs = np.lexsort((ids, t))
+    assert np.array_equal(words[order_words], words[order_pairs])
+    assert np.array_equal(t[order_words], t[order_pairs]) and np.array_equal(ids[order_words], ids[order_pairs])
+    # decoding gives the pair back
+    back_t = (words.view(np.uint64) & ~np.uint64(0x1FFFFFFF)).view(np.float64).astype(np.float32)
+    assert np.array_equal(back_t, t) and np.array_equal(words.view(np.uint64) & np.uint64(0x1FFFFFFF), ids)
+    # the recurrence against a sort, 16 slots, a stream of 300 candidates
+    empty = (np.float32(3.0e38).astype(np.float64).view(np.uint64) | np.uint64(0x1FFFFFFF)).view(np.float64)
+    a = np.full(16, empty)
+    seen = []
+    for K in words[rng.permutation(words.size)[:300]]:
+        if K >= empty:
+            continue
+        seen.append(K)
+        prev = a.copy()
+        for k in range(15, 0, -1):
+            a[k] = max(prev[k - 1], min(prev[k], K))
+        a[0] = min(prev[0], K)
+        want = np.sort(np.array(seen))[:16]
+        assert np.array_equal(a[:want.size], want)
