@@ -19,7 +19,7 @@ _DEFAULTS = dict(
     particle_kernel_degree=4, particle_kernel_min_response=0.0113, particle_kernel_min_alpha=1.0 / 255.0,
     particle_kernel_max_alpha=0.99, particle_kernel_density_clamping=True, particle_radiance_sph_degree=3,
     enable_normals=False, enable_hitcounts=True, enable_kernel_timings=False)
-_SUPPORTED_PIPELINES = ("reference",)
+_SUPPORTED_PIPELINES = ("reference", "referenceSlang")
 _SUPPORTED_PRIMITIVES = ("instances",)
 
 
@@ -35,10 +35,16 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
     # backward_pipeline_type referenceSlangBwd); SH radiance on the `reference` pipelines
     nht = nht_config_from_conf(conf, cfg)
     pipeline = _conf_get(render, "pipeline_type", "reference")
-    allowed = ("referenceSlang", "reference") if nht else _SUPPORTED_PIPELINES
+    # `referenceSlang` with SH radiance: the Slang programs (referenceSlangOptix.cu + gaussianParticles.slang / shRadiativeParticles.slang)
+    # integrate the same function as the hand-written ones — same hit test, response, alpha clamps, weights and radiance — in another
+    # rounding order; both names are served by the same kernels (the SH path is pinned by the `reference` programs only)
+    allowed = _SUPPORTED_PIPELINES
     if pipeline not in allowed:
-        raise NotImplementedError(f"3dgrut_amd: render.pipeline_type={pipeline!r} is not supported (only {allowed} with model.feature_type "
-                                  f"{'nht' if nht else 'sh'})")
+        raise NotImplementedError(f"3dgrut_amd: render.pipeline_type={pipeline!r} is not supported (only {allowed})")
+    bwd_pipeline = _conf_get(render, "backward_pipeline_type", pipeline + "Bwd")
+    if bwd_pipeline not in tuple(p + "Bwd" for p in allowed):
+        raise NotImplementedError(f"3dgrut_amd: render.backward_pipeline_type={bwd_pipeline!r} is not supported "
+                                  f"(only {tuple(p + 'Bwd' for p in allowed)})")
     prim = _conf_get(render, "primitive_type", "instances")
     if prim not in _SUPPORTED_PRIMITIVES:
         raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (only {_SUPPORTED_PRIMITIVES}: "

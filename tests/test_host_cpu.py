@@ -160,7 +160,11 @@ def test_grt_configuration_defaults_and_unsupported_pipelines():
     assert grt.grt_config_from_conf({"render": {"particle_kernel_degree": 2}}).particle_kernel_degree == 2
     half = grt.grt_config_from_conf({"render": {"feature_output_half": True}})   # (setup_3dgrt.py:41-44)
     assert (half.particle_feature_half, half.feature_output_half) == (0, 1) and cfg.feature_output_half == 0
-    for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "icosahedron"}):
+    # the Slang pipelines' names are accepted (same function, same kernels); other pipelines and proxies are refused
+    grt.grt_config_from_conf({"render": {"pipeline_type": "referenceSlang", "backward_pipeline_type": "referenceSlangBwd"}})
+    grt.grt_config_from_conf({"render": {"pipeline_type": "reference", "backward_pipeline_type": "referenceBwd"}})
+    for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "icosahedron"}, {"backward_pipeline_type": "referenceB2FSlangBwd"},
+                {"pipeline_type": "barycentricSurfels"}):
         with pytest.raises(NotImplementedError):
             grt.grt_config_from_conf({"render": bad})
 
