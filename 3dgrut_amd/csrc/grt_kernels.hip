@@ -931,7 +931,8 @@ __device__ __forceinline__ HitGeom hit_geometry(const GrtTraceParams& P, const P
 // ---------------------------------------------------------------------------------------------
 template <int DEG, bool COUNT, bool UNI, bool LOG>
 // 4 waves per SIMD (128 VGPRs): the walk is a chain of dependent fetches, a fourth wave hides more of it than the few
-// spilled registers cost (measured: 65.8 -> 60.2 ms at 1M particles, 800x800; 5 waves: 69.9 ms)
+// spilled registers cost (measured: 65.8 -> 60.2 ms at 1M particles, 800x800; 5 waves: 69.9 ms; again on the list path at the end of
+// round 3: 3 / 4 / 5 waves = 7.46 / 6.85 / 7.47 ms forward)
 #ifndef GRT_FWD_WAVES
 #define GRT_FWD_WAVES 4
 #endif
