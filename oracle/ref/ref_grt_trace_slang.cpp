@@ -5,7 +5,8 @@
 // shim/3dgrt_slang/.../gaussianParticles.cuh restates the entry points the programs call (the density functions are cross-checked against
 // the CUDA twin for the playground build; the feature model has no twin).  What this library pins is the program around them: the
 // round loop, the k = 16 payload and its insertion chain, which hits are processed, the integration order and the write-out.
-// TEST INFRASTRUCTURE ONLY: tests/golden/grt_trace_nht.npz.
+// -DREF_SLANG_SH builds the same programs with SH radiance (libref_grt_trace_slangsh_deg4.so, tests/golden/grt_trace_slang_sh.npz).
+// TEST INFRASTRUCTURE ONLY: tests/golden/grt_trace_nht.npz, grt_trace_slang_sh.npz.
 #include <math.h>
 #include <type_traits>
 #include <vector>
@@ -20,6 +21,11 @@
 #define GAUSSIAN_PARTICLE_KERNEL_DEGREE PARTICLE_KERNEL_DEGREE
 #define PARTICLE_RADIANCE_NUM_COEFFS 16
 #define PARTICLE_FEATURE_DIM 48
+#define GRT_SLANG_RAYGEN_BUILD
+#ifdef REF_SLANG_SH   // the same programs with SH radiance (model.feature_type sh): three ray features, the [n,48] buffer holds the coefficients
+#define RAY_FEATURE_DIM 3
+#define FEATURE_TRANSFORM_TYPE 0
+#else
 #define RAY_FEATURE_DIM 24
 #define INTERP_POINT_FEATURE_DIM 12
 #define FEATURE_TRANSFORM_TYPE 1
@@ -27,6 +33,7 @@
 #define FEATURE_INTERPOLATION_SUPPORT 1
 #define FEATURE_ACTIVATION_TYPE 2
 #define FEATURE_ACTIVATION_NUM_FREQUENCIES 1
+#endif
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingInstances
 #define PARTICLE_PRIMITIVE_CLAMPED 1
 #define ENABLE_HIT_COUNTS

@@ -112,8 +112,8 @@ inline float particleDensityProcessHitFwdFromBuffer(float3 rayOrigin, float3 ray
     return weight;
 }
 
-#if defined(FEATURE_TRANSFORM_TYPE) && FEATURE_TRANSFORM_TYPE == 1
-// ---- the Slang forward pipeline with neural harmonic features (referenceSlangOptix.cu:147-175) -------------------------------------
+#if defined(GRT_SLANG_RAYGEN_BUILD)
+// ---- the Slang forward pipeline (referenceSlangOptix.cu:147-175), neural harmonic features or SH radiance ---------------------------
 template <typename T, int N>
 struct FixedArray {
     T m_data[N];
@@ -150,6 +150,8 @@ inline float particleDensityProcessHitFwdFromBuffer(float3 rayOrigin, float3 ray
     *transmittance *= (1 - alpha);
     return weight;
 }
+#endif
+#if defined(GRT_SLANG_RAYGEN_BUILD) && FEATURE_TRANSFORM_TYPE == 1
 // particleFeaturesIntegrateFwdFromBuffer of the neural-harmonic-features model (neuralHarmonicFeaturesParticle.slang:253-270 ->
 // integrateFeaturesFromBuffer<false> :213-228 -> featuresFromParametersBuffer :146-196).  No CUDA twin in the checkout: a restatement.
 template <typename TElem>
@@ -223,6 +225,17 @@ inline void particleFeaturesIntegrateFwdGeneric(float3 dir, float weight, uint32
         integrated[ch] += std::max(f + 0.5f, 0.0f) * weight;
     }
 }
+
+#if defined(GRT_SLANG_RAYGEN_BUILD) && FEATURE_TRANSFORM_TYPE == 0
+// particleFeaturesIntegrateFwdFromBuffer of the SH model (shRadiativeParticles.slang:117-130): the radiance decoded with the RAY
+// direction as the incident direction, integrated front to back — the function above behind the Slang raygen's signature
+template <typename TElem>
+inline void particleFeaturesIntegrateFwdFromBuffer(float3 incidentDirection, float3 /*canonicalPosition*/, float weight, uint32_t particleIdx,
+                                                   TElem* featuresBufferPtr, int sphDegree, FixedArray<float, RAY_FEATURE_DIM>* integrated) {
+    static_assert(RAY_FEATURE_DIM == 3, "SH radiance integrates three channels");
+    particleFeaturesIntegrateFwdGeneric(incidentDirection, weight, particleIdx, featuresBufferPtr, (unsigned)sphDegree, &(*integrated)[0]);
+}
+#endif
 
 // particleDensityHitInstance (gaussianParticles.slang:525-541): the hit distance is the closest approach to the proxy's centre in its
 // own (scaled) frame; canonicalRayMinSquaredDistance (:118-132, volumetric) on the NORMALISED direction

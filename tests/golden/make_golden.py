@@ -371,6 +371,43 @@ def make_grt_trace_nht():
     print("wrote grt_trace_nht.npz")
 
 
+def make_grt_trace_slang_sh():
+    """tests/golden/grt_trace_slang_sh.npz: the reference's SLANG forward pipeline (referenceSlangOptix.cu) with SH radiance — the
+    configuration render.pipeline_type = referenceSlang of a model.feature_type = sh run — on the scenes of grt_trace.npz, so that the two
+    pipelines' outputs can be laid side by side (they integrate the same function; the plugin serves both names with one set of kernels)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import make_scene
+    px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    fw = C.CDLL(os.path.join(REF, "libref_grt_trace_slangsh_deg4.so"))
+    assert fw.ref_grt_slang_ray_feature_dim() == 3
+    ref = np.load(os.path.join(HERE, "grt_trace.npz"))
+    out = {}
+    for k, kw in enumerate(GRT_TRACE_SCENES):
+        sc = make_scene(**kw)
+        d12, sph = np.ascontiguousarray(sc["density12"]), np.ascontiguousarray(sc["sph"])
+        n, H, W = len(d12), kw["height"], kw["width"]
+        pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
+                              np.ascontiguousarray(d12[:, 3]))
+        aabb, tf = np.zeros((n, 6), F), np.zeros((n, 12), F)
+        px.ref_enclosing_proxies(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(aabb), _p(tf))
+        box = np.concatenate([aabb[:, :3].min(0), aabb[:, 3:].max(0)]).astype(F)
+        r2w = np.ascontiguousarray(np.asarray(sc["batch"]["T_to_world"][0], F)[:3, :4])
+        ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)) for a in sc["rays"])
+        feat, den, hit = np.zeros((H, W, 3), F), np.zeros((H, W, 1), F), np.zeros((H, W, 2), F)
+        cnt, vis = np.zeros((H, W, 1), F), np.zeros(n, np.int32)
+        fw.ref_grt_trace_slang_fwd(C.c_uint(n), _p(tf), _p(d12), _p(sph), W, H, _p(r2w), _p(ro), _p(rd), _p(box), C.c_float(MIN_T_GRT), C.c_float(MIN_RESPONSE),
+                                   C.c_float(MIN_ALPHA), _p(feat), _p(den), _p(hit), _p(cnt), _p(vis))
+        for name, a in dict(features=feat, density=den, hit_distance=hit, hits_count=cnt, visibility=vis).items():
+            out[f"s{k}_{name}"] = a
+        print(f"grt slang-sh scene {k}: hits per ray {cnt.mean():.1f}; against the reference pipeline: max |d features| "
+              f"{np.abs(feat - ref[f's{k}_features']).max():.2e}, |d density| {np.abs(den - ref[f's{k}_density']).max():.2e}, "
+              f"|d hit distance| {np.abs(hit - ref[f's{k}_hit_distance']).max():.2e}, hit counts differ on "
+              f"{int((cnt != ref[f's{k}_hits_count']).sum())} rays")
+    np.savez_compressed(os.path.join(HERE, "grt_trace_slang_sh.npz"), **out)
+    print("wrote grt_trace_slang_sh.npz")
+
+
 # ---- the reference's 3DGUT kernels (projection, render, renderBackward) on the host --------------------------------------------
 GUT_RENDER_SCENES = [
     dict(n=300, width=40, height=36, median_scale=0.12, max_density=0.7),            # translucent: tens of hits per ray, ragged tiles
@@ -672,7 +709,7 @@ def make_playground():
 if __name__ == "__main__":
     import sys
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
-    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "gut_render", "playground", "gut_nht", "grt_trace_nht"]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "gut_render", "playground", "gut_nht", "grt_trace_nht", "grt_trace_slang_sh"]
     if "--adam-only" in sys.argv:
         which = ["adam"]
     if "per_hit" in which:
@@ -696,3 +733,5 @@ if __name__ == "__main__":
         make_gut_nht()
     if "grt_trace_nht" in which:
         make_grt_trace_nht()
+    if "grt_trace_slang_sh" in which:
+        make_grt_trace_slang_sh()

@@ -776,3 +776,22 @@ def test_grt_nht_forward_matches_reference_slang_programs_golden():
         hd = g[f"s{k}_hit_distance"]
         assert np.abs(o["hit_distance"] - hd).max() <= 5e-6 * max(1.0, np.abs(hd).max())
         assert g[f"s{k}_hits_count"].max() >= 20 and np.abs(g[f"s{k}_features"]).max() > 0.5
+
+
+def test_slang_forward_with_sh_radiance_is_the_reference_forward():
+    """render.pipeline_type = referenceSlang with model.feature_type = sh is served by the kernels of the `reference` pipeline
+    (3dgrut_amd/grt_tracer.py): the two reference programs integrate the same function.  Pinned here program against program —
+    referenceSlangOptix.cu (tests/golden/grt_trace_slang_sh.npz) against referenceOptix.cu (grt_trace.npz), both run on the host over
+    the same emulated traversal on the same scenes: radiance and opacity bit for bit, integrated depth to an ulp, the same rays'
+    accepted-hit counts and the same visible particles."""
+    a = np.load(os.path.join(HERE, "golden", "grt_trace_slang_sh.npz"))
+    b = np.load(os.path.join(HERE, "golden", "grt_trace.npz"))
+    k = 0
+    while f"s{k}_features" in a:
+        assert np.array_equal(a[f"s{k}_features"], b[f"s{k}_features"])
+        assert np.array_equal(a[f"s{k}_density"], b[f"s{k}_density"])
+        assert np.array_equal(a[f"s{k}_hits_count"], b[f"s{k}_hits_count"])
+        assert np.array_equal(a[f"s{k}_visibility"], b[f"s{k}_visibility"])
+        assert np.abs(a[f"s{k}_hit_distance"] - b[f"s{k}_hit_distance"]).max() <= 1e-6
+        k += 1
+    assert k == 2
