@@ -144,7 +144,7 @@ class GutGradIO(C.Structure):
 EXPORTED_SYMBOLS = [
     "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_backward_unpacked", "gut_backward_factored", "grut_sph_grad_from_views", "gut_timings", "gut_stats",
     "gut_profile_enable", "gut_profile_select", "gut_profile_read",
-    "gut_debug_fetch", "gut_debug_fetch_work", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
+    "gut_debug_fetch", "gut_debug_fetch_work", "grut_debug_pose_from_c2w", "grut_debug_frame_poses", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats", "grt_debug_fetch_work",
     "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_debug_backward_signature", "grt_build_mesh_bvh", "grt_trace_hybrid",
@@ -185,6 +185,10 @@ def _declare(lib):
     lib.gut_profile_read.restype = C.c_int
     lib.gut_debug_fetch_work.argtypes = [C.c_void_p, vp, up, C.c_uint64]
     lib.gut_debug_fetch_work.restype = C.c_int
+    lib.grut_debug_pose_from_c2w.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.grut_debug_pose_from_c2w.restype = C.c_int
+    lib.grut_debug_frame_poses.argtypes = [vp, C.c_int, vp, vp, C.POINTER(C.c_float)]
+    lib.grut_debug_frame_poses.restype = C.c_int
     lib.gut_debug_fetch.argtypes = [C.c_void_p, vp] + [up] * 8
     lib.gut_debug_fetch.restype = C.c_int
     lib.grut_sort_pairs_u32.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, up, up, up, up, vp, C.c_uint64,

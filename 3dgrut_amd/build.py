@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(CSRC, "libgrut_amd.so")
-SOURCES = ["scan_sort.hip", "gut_kernels.hip", "gut_render.hip", "gut_api.hip", "grt_kernels.hip", "grt_api.hip", "optim.hip"]
+SOURCES = ["scan_sort.hip", "gut_kernels.hip", "gut_poses.hip", "gut_render.hip", "gut_api.hip", "grt_kernels.hip", "grt_api.hip", "optim.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-ffp-contract=fast",
          # SLP-packing scalar f32 math into v_pk_*_f32 costs register-pair shuffles (v_mov) and VGPRs on gfx950
@@ -24,7 +24,8 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-at
 # per-file additions.  grt_kernels.hip evaluates hit distances under `#pragma clang fp contract(off)` so that the per-ray
 # hit ORDER is reproducible bit for bit by the CPU checker; the pragma is only honoured when the command-line mode is
 # `on` (with `fast` the backend fuses regardless), so that file is built with -ffp-contract=on.
-FILE_FLAGS = {"grt_kernels.hip": ["-ffp-contract=on"]}
+# gut_poses.hip derives the frame's poses the way the reference's HOST code does (numpy / torch / host C++: nothing contracts there).
+FILE_FLAGS = {"grt_kernels.hip": ["-ffp-contract=on"], "gut_poses.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc() -> str:

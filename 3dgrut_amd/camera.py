@@ -22,15 +22,21 @@ _SHUTTER = {
 _FTHETA_POLY = {"PIXELDIST_TO_ANGLE": _abi.FTHETA_PIXELDIST_TO_ANGLE, "ANGLE_TO_PIXELDIST": _abi.FTHETA_ANGLE_TO_PIXELDIST}
 
 
+_F = np.float32
+
+
 def so3_matrix_to_quat_xyzw(R: np.ndarray) -> np.ndarray:
-    """Unit quaternion (x,y,z,w) of a rotation matrix (tracer.py:88-136, single matrix)."""
-    R = np.asarray(R, np.float64).reshape(3, 3)
-    dm = np.array([R[0, 0], R[1, 1], R[2, 2], R[0, 0] + R[1, 1] + R[2, 2]])
+    """Unit quaternion (x,y,z,w) of a rotation matrix, in FLOAT32 and in the operation order of
+    SensorPose3DModel.__so3_matrix_to_quat (tracer.py:88-136, single matrix): the reference rounds the matrix to float32 first
+    (tracer.py:366-367) and runs torch float32 arithmetic on it, so the quaternion's low bits - which reach the depth keys - depend
+    on that order.  Pinned bit for bit by tests/golden/pose.npz (tests/test_host_cpu.py)."""
+    R = np.asarray(R, _F).reshape(3, 3)
+    dm = [R[0, 0], R[1, 1], R[2, 2], (R[0, 0] + R[1, 1]) + R[2, 2]]
     c = int(np.argmax(dm))
-    q = np.empty(4)
+    q = np.empty(4, _F)
     if c != 3:
         i, j, k = c, (c + 1) % 3, (c + 2) % 3
-        q[i] = 1 - dm[3] + 2 * R[i, i]
+        q[i] = (_F(1) - dm[3]) + _F(2) * R[i, i]
         q[j] = R[j, i] + R[i, j]
         q[k] = R[k, i] + R[i, k]
         q[3] = R[k, j] - R[j, k]
@@ -38,16 +44,18 @@ def so3_matrix_to_quat_xyzw(R: np.ndarray) -> np.ndarray:
         q[0] = R[2, 1] - R[1, 2]
         q[1] = R[0, 2] - R[2, 0]
         q[2] = R[1, 0] - R[0, 1]
-        q[3] = 1 + dm[3]
-    return (q / np.linalg.norm(q)).astype(np.float32)
+        q[3] = _F(1) + dm[3]
+    s = q * q
+    return q / np.sqrt(((s[0] + s[1]) + s[2]) + s[3])
 
 
 def world_to_sensor_tquat(c2w) -> np.ndarray:
-    """[t(3), q(xyzw)] of inv(C2W) (tracer.py:414-423, 359-380)."""
+    """[t(3), q(xyzw)] of inv(C2W) as the reference plugin derives it (tracer.py:413-419, 359-380): float64 general inverse
+    (np.linalg.inv), one rounding to float32, float32 quaternion."""
     m = np.eye(4)
     m[:3, :4] = np.asarray(c2w, np.float64).reshape(-1, 4)[:3, :4]
     w2c = np.linalg.inv(m)
-    return np.concatenate([w2c[:3, 3].astype(np.float32), so3_matrix_to_quat_xyzw(w2c[:3, :3])]).astype(np.float32)
+    return np.concatenate([w2c[:3, 3].astype(_F), so3_matrix_to_quat_xyzw(w2c[:3, :3].astype(_F))])
 
 
 def _get(batch, name, default=None):

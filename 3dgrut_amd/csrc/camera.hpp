@@ -101,23 +101,63 @@ __host__ __device__ inline FramePoses make_frame_poses(const float ps7[7], const
     return f;
 }
 
-// [t, q(x,y,z,w)] of the inverse of a rigid camera-to-world matrix (row-major 4x4): what the plugin's host code
-// derives with numpy (threedgut_tracer/tracer.py:88-136, 359-380, 414-423), here for poses that live in device memory.
+// [t, q(x,y,z,w)] of the inverse of a camera-to-world matrix (row-major 4x4, rows 0-2 are read): the arithmetic of the reference
+// plugin's host code, step by step, for poses that live in device memory —
+//   (1) threedgut_tracer/tracer.py:413-419: the float32 pose is widened to FLOAT64 (np.concatenate with a float64 row promotes), row 3
+//       is set to (0,0,0,1) and the GENERAL 4x4 inverse is taken with np.linalg.inv (LAPACK dgesv: LU with partial pivoting, solve
+//       against the identity) — not a rigid R^T: a float32 rotation is orthogonal to ~6e-8 only, and the general inverse differs from the
+//       transpose at exactly that level;
+//   (2) tracer.py:366-367: ONE rounding of t and R to float32;
+//   (3) tracer.py:88-136 (SensorPose3DModel.__so3_matrix_to_quat): the quaternion from the ROUNDED matrix in float32, operation by
+//       operation (decision sums left to right, `(1 - tr) + 2 r_ii`, squared norm summed left to right, one sqrt, one division each).
+// LAPACK's float64 BITS depend on the BLAS build; after the rounding of (2) every LU of that kind gives the same float32 values except
+// where an entry is a cancellation residue (|x| < 1e-9, absolute difference < 1e-15): tests/test_host_cpu.py pins this function against
+// tests/golden/pose.npz (produced by the reference's own Python), bit for bit outside that class.
+// Must be compiled WITHOUT floating-point contraction (csrc/gut_poses.hip, -ffp-contract=off).
 __host__ __device__ inline void c2w_to_world_to_sensor(const float* m, float out7[7]) {
-    // rigid inverse: R^T, -R^T t
+    double A[4][4], B[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            A[i][j] = i < 3 ? (double)m[4 * i + j] : (j == 3 ? 1.0 : 0.0);
+            B[i][j] = i == j ? 1.0 : 0.0;
+        }
+    for (int k = 0; k < 4; ++k) {   // dgetf2: pivot = largest magnitude of the column, scale by the reciprocal, rank-1 update
+        int p = k;
+        for (int i = k + 1; i < 4; ++i)
+            if (fabs(A[i][k]) > fabs(A[p][k])) p = i;
+        if (p != k)
+            for (int j = 0; j < 4; ++j) {
+                const double ta = A[k][j], tb = B[k][j];
+                A[k][j] = A[p][j]; A[p][j] = ta;
+                B[k][j] = B[p][j]; B[p][j] = tb;
+            }
+        const double r = 1.0 / A[k][k];
+        for (int i = k + 1; i < 4; ++i) A[i][k] = A[i][k] * r;
+        for (int i = k + 1; i < 4; ++i)
+            for (int j = k + 1; j < 4; ++j) A[i][j] = A[i][j] - A[i][k] * A[k][j];
+    }
+    for (int c = 0; c < 4; ++c) {   // dgetrs: unit-lower forward substitution, upper back substitution, column by column
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < i; ++j) B[i][c] = B[i][c] - A[i][j] * B[j][c];
+        for (int i = 3; i >= 0; --i) {
+            for (int j = i + 1; j < 4; ++j) B[i][c] = B[i][c] - A[i][j] * B[j][c];
+            B[i][c] = B[i][c] / A[i][i];
+        }
+    }
     float R[9];
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) R[3 * i + j] = m[4 * j + i];
-    for (int i = 0; i < 3; ++i) out7[i] = -(R[3 * i] * m[3] + R[3 * i + 1] * m[7] + R[3 * i + 2] * m[11]);
-    // SensorPose3DModel.__so3_matrix_to_quat (tracer.py:88-136)
-    const float dm[4] = {R[0], R[4], R[8], R[0] + R[4] + R[8]};
+    for (int i = 0; i < 3; ++i) {
+        out7[i] = (float)B[i][3];
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = (float)B[i][j];
+    }
+    float dm[4] = {R[0], R[4], R[8], 0.f};
+    dm[3] = (dm[0] + dm[1]) + dm[2];
     int c = 0;
     for (int k = 1; k < 4; ++k)
         if (dm[k] > dm[c]) c = k;
     float q[4];
     if (c != 3) {
         const int i = c, j = (c + 1) % 3, k = (c + 2) % 3;
-        q[i] = 1.f - dm[3] + 2.f * R[3 * i + i];
+        q[i] = (1.f - dm[3]) + 2.f * R[3 * i + i];
         q[j] = R[3 * j + i] + R[3 * i + j];
         q[k] = R[3 * k + i] + R[3 * i + k];
         q[3] = R[3 * k + j] - R[3 * j + k];
@@ -127,8 +167,11 @@ __host__ __device__ inline void c2w_to_world_to_sensor(const float* m, float out
         q[2] = R[3] - R[1];
         q[3] = 1.f + dm[3];
     }
-    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-    for (int k = 0; k < 4; ++k) out7[3 + k] = q[k] / n;
+    const float n2 = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+    // correctly rounded float sqrt and quotients through float64 (53 >= 2*24 + 2 bits: no double rounding), whatever the
+    // compiler's float sqrt / division expansion is
+    const double n = (double)(float)sqrt((double)n2);
+    for (int k = 0; k < 4; ++k) out7[3 + k] = (float)((double)q[k] / n);
 }
 
 #ifdef __HIPCC__

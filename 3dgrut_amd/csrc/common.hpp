@@ -63,6 +63,21 @@ struct ScratchAllocator {
     void* user = nullptr;
 };
 ScratchAllocator& scratch_allocator();   // (gut_api.hip)
+// The stream of the API call in progress on this thread: a block that comes out of the caller's pool is zero-filled ON THAT STREAM
+// (hipMemsetAsync), i.e. after whatever the block's previous owner still has queued there - torch's caching allocator hands a freed
+// block straight back for reuse on the same stream - and before the first kernel of this call.  (A blocking hipMemset runs on the NULL
+// stream, which torch's pooled non-blocking streams are not ordered against.)
+inline hipStream_t& scratch_stream() {
+    static thread_local hipStream_t s = nullptr;
+    return s;
+}
+struct ScratchStreamScope {
+    hipStream_t prev;
+    explicit ScratchStreamScope(hipStream_t s) : prev(scratch_stream()) { scratch_stream() = s; }
+    ~ScratchStreamScope() { scratch_stream() = prev; }
+    ScratchStreamScope(const ScratchStreamScope&) = delete;
+    ScratchStreamScope& operator=(const ScratchStreamScope&) = delete;
+};
 struct DeviceBuffer {
     void* ptr = nullptr;
     size_t bytes = 0;
@@ -80,8 +95,8 @@ struct DeviceBuffer {
                 return GRUT_ERR_RUNTIME;
             }
             external = true;
-            // recycled memory of the caller's pool: start from zeros like the fresh pages of a first hipMalloc (allocations are rare —
-            // growth steps of 1.25x — so the synchronous fill costs nothing per frame)
+            // recycled memory of the caller's pool: start from zeros like the fresh pages of a first hipMalloc, filled on the stream
+            // of the API call that asked (scratch_stream(): ordered against the block's previous use and this call's kernels)
             // (development: GRUT_POISON_SCRATCH=<byte> fills with that byte instead; GRUT_POISON_INDEX=<k> only the k-th allocation)
             {
                 static int count = 0;
@@ -90,7 +105,7 @@ struct DeviceBuffer {
                 const bool poison = pz && (!pi || atoi(pi) == count);
                 if (pz && pi && atoi(pi) == count) fprintf(stderr, "[grut] poisoned allocation %d: %zu bytes\n", count, n);
                 ++count;
-                GRUT_HIP(hipMemset(ptr, poison ? atoi(pz) : 0, n));
+                GRUT_HIP(hipMemsetAsync(ptr, poison ? atoi(pz) : 0, n, scratch_stream()));
             }
         } else {
             GRUT_HIP(hipMalloc(&ptr, n));

@@ -208,6 +208,7 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     (void)allow_update;
     GRUT_REQUIRE(h, "grt_build_bvh: null handle");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    ScratchStreamScope scratch_scope(s);
     if (N == 0) {
         h->N = 0;
         h->built = true;
@@ -362,6 +363,7 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
                             const float* ray_origin, const float* ray_direction, float* out_features, float* out_density,
                             float* out_hit_distance, float* out_normals, float* out_hits_count, int32_t* out_visibility,
                             uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap) {
+    ScratchStreamScope scratch_scope(s);
     GRUT_REQUIRE(h && frame, "grt_forward: null handle/frame");
     if (!h->built) {
         set_last_error("grt_forward: build_bvh has not been called");
@@ -497,6 +499,7 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
     (void)grad_normals;  // the reference's backward does not propagate the normal gradient either (referenceBwdOptix.cu:103-170)
     GRUT_REQUIRE(h && frame, "grt_backward: null handle/frame");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    ScratchStreamScope scratch_scope(s);
     if (!h->built) {
         set_last_error("grt_backward: build_bvh has not been called");
         return GRUT_ERR_NOT_READY;
@@ -555,6 +558,7 @@ int grt_build_mesh_bvh(GrtHandle* h, void* stream_, uint32_t num_vertices, const
                        int rebuild, int allow_update) {
     GRUT_REQUIRE(h, "grt_build_mesh_bvh: null handle");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    ScratchStreamScope scratch_scope(s);
     const bool refit_only = !rebuild && allow_update && h->mesh_built && h->mesh_faces == num_faces && num_faces > 0;
     h->mesh_built = false;   // raised again only when every stage below was enqueued
     if (num_faces == 0) {
@@ -600,6 +604,7 @@ int grt_trace_hybrid(GrtHandle* h, void* stream_, const GrtFrame* frame, const f
     GRUT_REQUIRE(h && frame && mesh && options, "grt_trace_hybrid: null argument");
     const float* particle_sph = reinterpret_cast<const float*>(particle_sph_);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    ScratchStreamScope scratch_scope(s);
     if (!h->built || !h->mesh_built) {
         set_last_error("grt_trace_hybrid: build_bvh / build_mesh_bvh have not been called");
         return GRUT_ERR_NOT_READY;

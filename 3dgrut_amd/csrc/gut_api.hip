@@ -312,6 +312,7 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
     GRUT_REQUIRE(frame->width > 0 && frame->height > 0, "gut_forward: empty image");
     GRUT_REQUIRE(ray_origin && ray_direction && out_feat_density && out_hit_distance && out_hit_count, "gut_forward: null ray/output buffer");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    ScratchStreamScope scratch_scope(s);
     h->have_forward = false;
     const uint32_t N = frame->num_particles;
     h->params = make_params(h->cfg, *frame);
@@ -477,6 +478,7 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
     const float* feat_density = reinterpret_cast<const float*>(feat_density_);       // (fp32, or half with feature_output_half)
     GRUT_REQUIRE(h && frame, "gut_backward: null handle/frame");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    ScratchStreamScope scratch_scope(s);
     if (!h->have_forward || h->fwd_stream != s) {  // gutRenderer.cu:436-440
         set_last_error("gut_backward: no forward context on this stream");
         return GRUT_ERR_NOT_READY;
@@ -691,6 +693,7 @@ int gut_debug_fetch(GutHandle* h, void* stream_, uint32_t* tiles_count, float* p
                     float* depth, float* rgb, uint32_t* sorted_particle_idx, uint32_t* tile_ranges) {
     GRUT_REQUIRE(h && h->have_forward, "gut_debug_fetch: no forward context");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    ScratchStreamScope scratch_scope(s);
     const size_t N = h->params.N;
     const size_t I = h->num_intersections;
     const size_t tiles = (size_t)h->params.gx * h->params.gy;

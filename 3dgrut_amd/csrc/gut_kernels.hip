@@ -1003,17 +1003,6 @@ __global__ __launch_bounds__(128) void sph_grad_from_views_kernel(uint32_t N, ui
     }
 }
 
-// frame poses from camera-to-world matrices in device memory (no host round trip, no stream sync)
-__global__ __launch_bounds__(64) void gut_frame_poses_kernel(const float* __restrict__ T_start, const float* __restrict__ T_end, FramePoses* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float ps[7], pe[7];
-    c2w_to_world_to_sensor(T_start, ps);
-    if (T_end) c2w_to_world_to_sensor(T_end, pe);
-    else
-        for (int k = 0; k < 7; ++k) pe[k] = ps[k];
-    *out = make_frame_poses(ps, pe);
-}
-
 // Between the scan and the tail of the frame: publishes the intersection count I and the visible-particle count straight into
 // the host's pinned counters (device-visible memory: no blit copies on the stream), re-arms the visible counter for the next
 // frame, and clears the two small per-frame tables of the tail (tile ranges, checkpoint "reached" marks) — one launch instead of
@@ -1042,10 +1031,6 @@ void launch_prepare_tail(hipStream_t s, const uint32_t* last_offset, uint32_t* n
                          uint32_t n_ranges_words, uint32_t* reached_words, uint32_t n_reached_words) {
     hipLaunchKernelGGL(gut_prepare_tail_kernel, dim3(64), dim3(256), 0, s, last_offset, num_visible, host_counters, ranges_words, n_ranges_words,
                        reached_words, n_reached_words);
-}
-
-void launch_frame_poses(hipStream_t s, const float* T_start, const float* T_end, FramePoses* out) {
-    hipLaunchKernelGGL(gut_frame_poses_kernel, dim3(1), dim3(64), 0, s, T_start, T_end, out);
 }
 
 // ---------------------------------------------------------------------------------------------

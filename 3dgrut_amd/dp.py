@@ -128,6 +128,30 @@ class FactoredGradientExchange:
         return g_density, _abi.sph_grad_from_views(factors, positions, n_active_features, sph_degree, scale)
 
     @torch.no_grad()
+    def reduce_dense(self, g_density, *others):
+        """Plain in-place sum / mean of dense per-particle gradients - for features without a per-view factorisation (neural harmonic
+        features: the [N,48] feature-row gradient is a sum over hits of hit-dependent weights, gut_tracer._NhtAutograd).  The packed
+        gradient goes first (the local hook sees it before the reduction).  Returns the tensors."""
+        world = self._world()
+        if self.local_gradient_hook is not None:
+            self.local_gradient_hook(g_density)
+        tensors = [g_density, *others]
+        if world == 1:
+            return tensors
+        nccl = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
+        if self.timer:
+            self.timer.begin(g_density.device)
+        works = [dist.all_reduce(t, op=op, group=self.group, async_op=True) for t in tensors]
+        for w in works:
+            w.wait()
+        if self.timer:
+            self.timer.end(sum(t.numel() * t.element_size() for t in tensors))
+        if self.average and not nccl:
+            torch._foreach_div_(tensors, float(world))
+        return tensors
+
+    @torch.no_grad()
     def exchange(self, g_density, g_radiance):
         """The collectives alone (no kernel of the library: runs on CPU tensors over gloo too): (reduced packed gradient [N,12], the
         views' factors [world, N+1, 3], bytes this rank handed to the collectives)."""
@@ -203,7 +227,7 @@ class ShardedGradientExchange(FactoredGradientExchange):
         world = self._world()
         s = (n + world - 1) // world
         r = dist.get_rank(self.group) if world > 1 else 0
-        return s, r * s, min(n, (r + 1) * s)
+        return s, min(n, r * s), min(n, (r + 1) * s)   # (a rank past the end owns the empty range [n, n): N < world * (world - 1))
 
     @torch.no_grad()
     def exchange_shard(self, g_density, g_radiance):

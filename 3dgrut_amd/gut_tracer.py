@@ -68,12 +68,19 @@ def nht_config_from_conf(conf, cfg) -> bool:
     if interp not in ("none", "barycentric"):
         raise NotImplementedError(f"3dgrut_amd: nht_features.interpolation_type={interp!r} (the reference supports none / barycentric)")
     points = 4 if interp == "barycentric" else 1
+    dim = int(_conf_get(nf, "dim", 48))
+    if dim % points:
+        raise ValueError(f"nht_features.dim = {dim} is not divisible by the {points} interpolation points of interpolation_type={interp!r}")
     cfg.feature_transform_type = 1
-    cfg.particle_feature_dim = int(_conf_get(nf, "dim", 48))
-    cfg.interp_point_feature_dim = cfg.particle_feature_dim // points
+    cfg.particle_feature_dim = dim
+    cfg.interp_point_feature_dim = dim // points
     cfg.feature_interpolation_support = 1 if points == 4 else 0
-    cfg.feature_activation_type = {"none": 0, "siren": 1, "sincos": 2, "relu": 3}[str(_conf_get(act, "type", "sincos")).lower()]
-    cfg.feature_activation_num_frequencies = int(_conf_get(act, "num_frequencies", 1))
+    # defaults as threedgrut/model/features.py:62-77, 97-110: no activation node / no type -> none; none and relu have one "frequency"
+    act_name = str(_conf_get(act, "type", "none") if act is not None else "none").lower()
+    if act_name not in ("none", "siren", "sincos", "relu"):
+        raise ValueError(f"Unknown nht_features.activation.type: {act_name}")
+    cfg.feature_activation_type = {"none": 0, "siren": 1, "sincos": 2, "relu": 3}[act_name]
+    cfg.feature_activation_num_frequencies = 1 if act_name in ("none", "relu") else int(_conf_get(act, "num_frequencies", 1))
     return True
 
 
@@ -280,11 +287,11 @@ class _NhtAutograd(torch.autograd.Function):
     """model.feature_type = nht: the op of threedgut_tracer/tracer.py:166-300 with per-ray features ([H,W,ray_dim] + opacity)."""
 
     @staticmethod
-    def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_feat):
+    def forward(ctx, native, frame, ray_ori, ray_dir, mog_pos, mog_rot, mog_scl, mog_dns, mog_feat, exchange=None):
         particle_density = _abi.pack_particles(mog_pos, mog_dns, mog_rot, mog_scl)
         fd, dist, cnt, vis, feats_k = native.trace_nht(frame, particle_density, mog_feat.contiguous(), ray_ori, ray_dir)
         ctx.save_for_backward(ray_ori, ray_dir, fd, dist, particle_density, feats_k)
-        ctx.native, ctx.frame = native, frame
+        ctx.native, ctx.frame, ctx.exchange = native, frame, exchange
         nr = native.ray_feature_dim
         f32 = fd.float()   # always fp32 to the caller; the (possibly half) image stays in the context for the backward
         ctx.mark_non_differentiable(cnt, vis)
@@ -300,8 +307,12 @@ class _NhtAutograd(torch.autograd.Function):
         g_fd = torch.cat([g_feat, g_opa], dim=-1).contiguous()
         g_density, g_features = ctx.native.trace_bwd_nht(ctx.frame, particle_density, feats_k, ray_ori, ray_dir, fd, g_fd, dist,
                                                          None if g_dist is None else g_dist.contiguous())
+        if ctx.exchange is not None:
+            # view-sharded data parallelism: the feature-row gradient has no per-view factorisation (it sums hit-dependent barycentric
+            # weights), so both tensors are reduced densely, in place, before anything is unpacked
+            g_density, g_features = ctx.exchange.reduce_dense(g_density, g_features)
         g_pos, g_dns, g_rot, g_scl = _abi.unpack_particle_grads(g_density)
-        return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_features
+        return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_features, None
 
 
 class Tracer:
@@ -412,7 +423,8 @@ class Tracer:
                 raise ValueError(f"features have {feats.shape[1]} columns, expected nht_features.dim = {native.cfg.particle_feature_dim}")
             pred_features, pred_opacity, pred_dist, hits_count, mog_visibility = _NhtAutograd.apply(
                 native, frame, rays_o.contiguous().float(), rays_d.contiguous().float(), gaussians.positions.contiguous(),
-                gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(), gaussians.get_density().contiguous(), feats.contiguous())
+                gaussians.get_rotation().contiguous(), gaussians.get_scale().contiguous(), gaussians.get_density().contiguous(), feats.contiguous(),
+                self.gradient_exchange)
             timings = native.collect_times()
             return {"pred_features": pred_features, "pred_opacity": pred_opacity, "pred_dist": pred_dist.unsqueeze(0),
                     "pred_normals": torch.nn.functional.normalize(torch.ones_like(pred_features), dim=3), "hits_count": hits_count.unsqueeze(0),

@@ -269,6 +269,14 @@ uint64_t grut_scan_scratch_bytes(uint32_t n);
  * GutStats' four entry counters, words 16 + 4 b .. 19 + 4 b = lifetime and start (100 MHz ticks), accepted << 32 | evaluated entries and
  * tile-list length of forward-sweep workgroup b. */
 int gut_debug_fetch_work(GutHandle* handle, void* stream, unsigned long long* out, uint64_t count);
+/* HOST function, no device work: the world->sensor pose [t(3), q(x,y,z,w)] the library derives from a camera-to-world matrix handed
+ * over as GutFrame::device_T_to_world (row-major 4x4, rows 0-2 read) - the host twin of the device code, same arithmetic: float64
+ * general inverse, one rounding to float32, float32 quaternion (threedgut_tracer/tracer.py:88-136, 359-380, 413-423). */
+int grut_debug_pose_from_c2w(const float* c2w16, float* out7);
+/* The whole per-frame pose block the kernels read (47 floats: start R[9] t[3] q[4], end t[3] q[4], mid-exposure world->sensor
+ * R[9] t[3], sensor->world R[9] t[3]; sensors.h:44-73, gutRenderer.cu:266-267) from camera-to-world matrices: on_device != 0 runs the
+ * device code on DEVICE matrices and synchronises the stream, on_device == 0 its host twin on HOST matrices.  T_end may be NULL. */
+int grut_debug_frame_poses(void* stream, int on_device, const float* T_start, const float* T_end, float* host_out47);
 int gut_debug_fetch(GutHandle* handle, void* stream,
                     uint32_t* tiles_count, float* proj_pos, float* conic_opacity, float* extent,
                     float* depth, float* rgb, uint32_t* sorted_particle_idx, uint32_t* tile_ranges);

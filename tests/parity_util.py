@@ -20,12 +20,15 @@ every difference is attributed:
 """
 import ctypes as C
 import importlib
+import os
 import time
 
 import numpy as np
 
 import oracle
 from scenes import rel_err, torch_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 syn = importlib.import_module("3dgrut_amd.synthetic")
 camera = importlib.import_module("3dgrut_amd.camera")
@@ -42,18 +45,23 @@ def make_frame_inputs(n, w, h, median_scale, seed=42, view=0, n_views=8):
     return dict(d12=d12, sph=sph, batch=batch, cam=cam, ps=ps, pe=pe, rays=(ro, rd), W=w, H=h, N=n)
 
 
-def hip_forward(inp, tracer=None):
+def hip_forward(inp, tracer=None, device_pose=False):
     """One train-mode forward through the plugin; returns images as numpy plus the binning products of that forward.
 
-    The camera-to-world matrix is handed over as a HOST tensor, so the plugin derives the sensor pose exactly as the reference
-    plugin does (numpy, tracer.py:359-423) and both sides of the comparison start from bit-identical pose values (with a device
-    tensor the library inverts the matrix on the GPU in fp32: same pose to ~1e-7, different low bits, different depth keys)."""
+    device_pose=False: the camera-to-world matrix is handed over as a HOST tensor and the plugin derives the sensor pose exactly as the
+    reference plugin does (numpy float64 inverse, float32 quaternion: tracer.py:359-423, pinned by tests/golden/pose.npz).
+    device_pose=True: the matrix stays on the GPU (what bench.py and a GPU-resident trainer do) and the library derives the same pose
+    there (csrc/gut_poses.hip: float64 LU inverse, one rounding, float32 quaternion, nothing contracted) - since round 4 with the SAME
+    bits, so both parametrisations meet the same integer-exact stage A."""
     import torch
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
     tracer = tracer or gt.Tracer({"render": {"enable_hitcounts": True, "splat": {}}})
     g = syn.SimpleGaussians(inp["d12"], inp["sph"])
     batch = torch_batch(inp["batch"], "cuda")
-    batch.T_to_world = torch.as_tensor(inp["batch"]["T_to_world"])
+    if not device_pose:
+        batch.T_to_world = torch.as_tensor(inp["batch"]["T_to_world"])
+    else:
+        assert batch.T_to_world.is_cuda
     out = tracer.render(g, batch, train=True)
     torch.cuda.synchronize()
     nat = tracer.tracer_wrapper
@@ -241,15 +249,15 @@ def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dis
     return out, rounding, ratio
 
 
-def gut_full_parity(n, w, h, median_scale, seed=42, view=0, log=None, with_backward=True, end_to_end=True):
+def gut_full_parity(n, w, h, median_scale, seed=42, view=0, log=None, with_backward=True, end_to_end=True, device_pose=False):
     """Runs stages A-C (module docstring) and returns a flat dict of the measured statistics."""
     t_all = time.time()
     inp = make_frame_inputs(n, w, h, median_scale, seed=seed, view=view)
     cfg = oracle.default_gut_config()
-    hip = hip_forward(inp)
+    hip = hip_forward(inp, device_pose=device_pose)
     t0 = time.time()
     proj = oracle.gut_project(cfg, inp["cam"], inp["ps"], inp["pe"], 3, inp["d12"], inp["sph"])
-    stats = dict(N=n, W=w, H=h, P=w * h)
+    stats = dict(N=n, W=w, H=h, P=w * h, pose="device" if device_pose else "host")
     gx = (w + 15) // 16
     # ---- stage A -------------------------------------------------------------------------------------------------------
     own = oracle.gut_forward(cfg, inp["cam"], inp["ps"], inp["pe"], 3, inp["d12"], inp["sph"], *inp["rays"], proj=proj) if end_to_end else None
@@ -322,6 +330,20 @@ def gut_full_parity(n, w, h, median_scale, seed=42, view=0, log=None, with_backw
         for k, v in stats.items():
             log(f"  {k:38s} {v}")
     return stats
+
+
+def record_full_parity(name, stats):
+    """Appends one configuration's measured statistics (exemption classes included) to gpurun_out/full_parity.json, which travels back
+    from the GPU box; the round's copy is committed as profiles/rNN_full_parity.json."""
+    import json
+    path = os.path.join(ROOT, "gpurun_out", "full_parity.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    try:
+        allstats = json.load(open(path))
+    except (OSError, ValueError):
+        allstats = {}
+    allstats[name] = {k: (v if isinstance(v, (int, float, str, dict, list)) else str(v)) for k, v in stats.items()}
+    json.dump(allstats, open(path, "w"), indent=1, default=str)
 
 
 def assert_gut_full_parity(stats, max_flip_frac=2e-3):

@@ -441,6 +441,35 @@ def test_projection_and_binning_match_reference_code_golden():
                     assert np.array_equal(got[rng_h[t, 0]:rng_h[t, 1]], want), f"case {k}, tile {t}: different order"
 
 
+def test_device_poses_equal_host_poses_bit_for_bit():
+    """GutFrame::device_T_to_world: the pose kernel (csrc/gut_poses.hip, built without contraction) against its host twin, which
+    tests/test_host_cpu.py pins to the reference's Python bit for bit (tests/golden/pose.npz).  Global shutter (one pose): the whole
+    47-float pose block - start / end [t, q], mid-exposure view matrix, sensor-to-world matrix - must be bit-identical for all 1033
+    golden poses.  Two different poses (rolling shutter): the [t, q] pairs are still bit-identical; the interpolated mid-exposure
+    pose passes through sinf / acosf (glm::slerp), whose device and host implementations round differently: within 1e-6."""
+    import torch
+    lib = importlib.import_module("3dgrut_amd._abi").load_library()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose.npz"))
+    fp = C.POINTER(C.c_float)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dev_s, dev_e = torch.as_tensor(g["c2w"], device="cuda").contiguous(), torch.as_tensor(g["c2w_end"], device="cuda").contiguous()
+    worst = 0.0
+    for i in range(len(g["c2w"])):
+        a, b = np.ascontiguousarray(g["c2w"][i]), np.ascontiguousarray(g["c2w_end"][i])
+        host, dev = np.zeros(47, np.float32), np.zeros(47, np.float32)
+        assert lib.grut_debug_frame_poses(None, 0, a.ctypes.data, None, host.ctypes.data_as(fp)) == 0
+        assert lib.grut_debug_frame_poses(stream, 1, dev_s[i].data_ptr(), None, dev.ctypes.data_as(fp)) == 0
+        assert np.array_equal(host.view(np.uint32), dev.view(np.uint32)), (i, np.flatnonzero(host.view(np.uint32) != dev.view(np.uint32)))
+        assert np.array_equal(dev[9:16].view(np.uint32), g["tquat_start"][i].view(np.uint32))   # = the reference plugin's pose
+        if i % 8 == 0:   # rolling shutter pairs
+            assert lib.grut_debug_frame_poses(None, 0, a.ctypes.data, b.ctypes.data, host.ctypes.data_as(fp)) == 0
+            assert lib.grut_debug_frame_poses(stream, 1, dev_s[i].data_ptr(), dev_e[i].data_ptr(), dev.ctypes.data_as(fp)) == 0
+            assert np.array_equal(host[:23].view(np.uint32), dev[:23].view(np.uint32))           # start R / t / q, end t / q
+            scale = 1.0 + np.abs(host[23:]).max()
+            worst = max(worst, float(np.abs(host[23:] - dev[23:]).max() / scale))
+    assert worst < 1e-6, worst
+
+
 def test_frame_matches_reference_kernels_golden():
     """The HIP frame DIRECTLY against tests/golden/gut_render.npz = the reference's own projectOnTiles / render / renderBackward
     kernels run on the host (oracle/ref/ref_gut_render.cpp).  Forward images for K = 0 and K = 16 against the reference's; the

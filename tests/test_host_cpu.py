@@ -51,6 +51,33 @@ def test_pose_marshalling_inverts_the_camera_to_world_matrix():
         assert np.abs(tq[:3] - w2c[:3, 3]).max() < 1e-5
 
 
+def test_sensor_poses_equal_the_reference_plugins_bit_for_bit(grut_lib):
+    """tests/golden/pose.npz holds what the REFERENCE's own Python (Tracer.__create_camera_parameters executed from the checkout,
+    tests/golden/make_pose_golden.py) makes of 1033 start / end camera-to-world pairs: float64 np.linalg.inv, one rounding, float32 torch
+    quaternion.  Both of this library's derivations - the plugin's host code (camera.py) and the host twin of the device code
+    (csrc/camera.hpp: c2w_to_world_to_sensor, float64 LU inverse) - must return the SAME BITS: the pose's low bits reach the depth keys
+    and with them the compositing order (round 3 derived the quaternion in float64 on the host and inverted in float32 on the device:
+    929 of 1033 poses differed from the reference's in the last bits)."""
+    import ctypes as C
+    g = np.load(os.path.join(ROOT, "tests", "golden", "pose.npz"))
+    fp = C.POINTER(C.c_float)
+    for c2w, want in ((g["c2w"], g["tquat_start"]), (g["c2w_end"], g["tquat_end"])):
+        host = np.stack([camera.world_to_sensor_tquat(m) for m in c2w])
+        assert host.dtype == np.float32 and np.array_equal(host.view(np.uint32), want.view(np.uint32))
+        twin = np.zeros_like(want)
+        for i, m in enumerate(c2w):
+            m = np.ascontiguousarray(m, np.float32)
+            assert grut_lib.grut_debug_pose_from_c2w(m.ctypes.data_as(fp), twin[i].ctypes.data_as(fp)) == 0
+        assert np.array_equal(twin.view(np.uint32), want.view(np.uint32)), int((twin.view(np.uint32) != want.view(np.uint32)).any(1).sum())
+    # the pose block the kernels read, host twin: the same call on the pairs as 4x4 matrices (used by the GPU test as its reference)
+    out = np.zeros(47, np.float32)
+    a, b = np.ascontiguousarray(g["c2w"][3], np.float32), np.ascontiguousarray(g["c2w_end"][3], np.float32)
+    assert grut_lib.grut_debug_frame_poses(None, 0, a.ctypes.data, b.ctypes.data, out.ctypes.data_as(fp)) == 0
+    assert np.array_equal(out[9:12].view(np.uint32), g["tquat_start"][3, :3].view(np.uint32))      # start_t
+    assert np.array_equal(out[12:16].view(np.uint32), g["tquat_start"][3, 3:].view(np.uint32))     # start_q
+    assert np.array_equal(out[16:19].view(np.uint32), g["tquat_end"][3, :3].view(np.uint32))       # end_t
+
+
 def _batch(**kw):
     H, W = 6, 8
     base = dict(rays_ori=np.zeros((1, H, W, 3), np.float32), rays_dir=np.zeros((1, H, W, 3), np.float32), T_to_world=syn.orbit_pose(2)[None])

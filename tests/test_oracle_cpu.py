@@ -676,7 +676,9 @@ def test_nht_backward_matches_autograd_of_the_restated_reference_forward(name):
     scene = make_scene(n=n, width=w, height=h, median_scale=0.16, seed=seed)
     cfg = oracle.default_gut_config()
     feats = g[f"{name}_features"]
-    for dtype, tol in ((np.float64, 2e-6), (np.float32, 3e-4)):
+    # float64 build: 5e-6, not 1e-9 - the two sides share float32 INPUTS but the golden carries the ray through the frame's float32
+    # pose block while the double build re-derives that block in double (their forwards agree to 8e-7, printed by the generator)
+    for dtype, tol in ((np.float64, 5e-6), (np.float32, 3e-4)):
         fwd = oracle.gut_forward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats, *scene["rays"], dtype=dtype)
         gd, gf = oracle.gut_backward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats, *scene["rays"], fwd,
                                          g[f"{name}_g_fd"], g[f"{name}_g_dist"], dtype=dtype)
