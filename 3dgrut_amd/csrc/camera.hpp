@@ -26,6 +26,13 @@ __host__ __device__ inline void quat_xyzw_to_rows(const float q[4], float R[9]) 
     R[6] = 2.f * (xz - wy); R[7] = 2.f * (yz + wx); R[8] = 1.f - 2.f * (xx + yy);
 }
 
+// sinf / acosf of the pose interpolation, evaluated in float64 and rounded once: the reference interpolates its poses on the HOST
+// (sensors.h:53-66 through glibc, whose float functions are correctly rounded in all but ~1e-8 of the cases); the device's own
+// sinf / acosf round differently, and at a slerp angle of ~5e-4 - the "angle" between a unit quaternion and itself when its float32
+// norm is a few ulp below one - the quotient sin(t a) / sin(a) passes such a difference on to every entry of the view matrix.
+__host__ __device__ inline float pose_sinf(float x) { return (float)sin((double)x); }
+__host__ __device__ inline float pose_acosf(float x) { return (float)acos((double)x); }
+
 // tcnn::slerp (glm::slerp)
 __host__ __device__ inline void quat_slerp(const float a[4], const float b_in[4], float t, float o[4]) {
     float b[4] = {b_in[0], b_in[1], b_in[2], b_in[3]};
@@ -37,7 +44,7 @@ __host__ __device__ inline void quat_slerp(const float a[4], const float b_in[4]
     if (c > 1.f - FLT_EPSILON) {
         for (int i = 0; i < 4; ++i) o[i] = a[i] * (1.f - t) + b[i] * t;
     } else {
-        const float ang = acosf(c), s0 = sinf((1.f - t) * ang), s1 = sinf(t * ang), is = 1.f / sinf(ang);
+        const float ang = pose_acosf(c), s0 = pose_sinf((1.f - t) * ang), s1 = pose_sinf(t * ang), is = 1.f / pose_sinf(ang);
         for (int i = 0; i < 4; ++i) o[i] = (s0 * a[i] + s1 * b[i]) * is;
     }
 }

@@ -39,7 +39,7 @@ struct GutHandle {
     DeviceBuffer part_offset, pos_particle, grad_partial, grad_flag, g_rgb, poses_dev;
     // per-intersection scratch
     DeviceBuffer tile_keys, tile_vals, tile_keys_tmp, tile_vals_tmp, tile_sort_scratch, ranges;
-    DeviceBuffer ck_tc, ck_d, ck_reached, ck_boundary_tile;
+    DeviceBuffer ck_tc, ck_d, ck_reached, ck_boundary_tile, ck_nht;
     GutCheckpoints checkpoints;
     uint32_t* host_counters = nullptr;  // pinned: [0] = I (last offset), [1] = Nv
     hipEvent_t count_event = nullptr;
@@ -206,6 +206,7 @@ static int ensure_intersection_scratch(GutHandle* h, uint32_t I, uint32_t tiles)
     h->checkpoints.boundary_tile = h->ck_boundary_tile.as<uint32_t>();
     h->checkpoints.num_boundaries = (uint32_t)nb;
     h->ck_boundaries_capacity = (uint32_t)nb;
+    if (nht_fast_path(h->params)) GRUT_CHECK(h->ck_nht.ensure(nht_checkpoint_bytes((uint32_t)nb), 1.3f));   // {T, D, 24 partial sums} per pixel
     return GRUT_OK;
 }
 
@@ -263,7 +264,7 @@ static void release_scratch(GutHandle* h) {
                             &h->particle_idx, &h->depth_key_tmp, &h->particle_idx_tmp, &h->offsets, &h->sort_scratch,
                             &h->scan_scratch, &h->counters, &h->rec64, &h->part_offset, &h->pos_particle, &h->grad_partial, &h->grad_flag,
                             &h->g_rgb, &h->poses_dev, &h->work_counters, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
-                            &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges, &h->ck_tc, &h->ck_d, &h->ck_reached,
+                            &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges, &h->ck_tc, &h->ck_d, &h->ck_nht, &h->ck_reached,
                             &h->ck_boundary_tile};
     for (DeviceBuffer* b : bufs) b->release();
 }
@@ -425,7 +426,10 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
         GRUT_CHECK(h->stage_end(GUT_STAGE_TILE_RANGES, s, slot));
         // K7 compositing
         GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_FWD, s, slot));
-        if (P.nht)
+        if (nht_fast_path(P))
+            launch_render_nhtp_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, particle_sph, ray_origin,
+                                   ray_direction, out_feat_density, out_hit_distance, out_hit_count, h->ck_nht.ptr, h->checkpoints, true);
+        else if (P.nht)
             launch_render_nht_fwd(s, P, h->ranges.as<uint32_t>(), sorted_idx, h->pos_particle.as<uint32_t>(), particle_density, particle_sph, ray_origin,
                                   ray_direction, out_feat_density, out_hit_distance, out_hit_count);
         else if (P.k_buffer > 0)
@@ -492,20 +496,57 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
     }
     if (P.N == 0) return GRUT_OK;
     if (P.nht) {
-        // neural harmonic features: grad_particle_density [N,12] and grad_particle_sph = the feature buffer's gradient [N, particle_feature_dim],
-        // both fp32 and fully written here (zero-filled, then accumulated per (wave, entry)); grad_feat_density is [H,W,ray_dim+1]
-        if (io || grad_radiance) {
-            set_last_error("gut_backward: with neural harmonic features only gut_backward (packed gradients) is provided");
+        // neural harmonic features: grad_particle_density [N,12] (or the four tensors of io) and grad_particle_sph = the feature buffer's
+        // gradient [N, particle_feature_dim], fp32, fully written here; grad_feat_density is [H,W,ray_dim+1] (io: [H,W,ray_dim] + [H,W,1])
+        if (grad_radiance) {
+            set_last_error("gut_backward_factored: neural harmonic features have no per-view factorisation; reduce the dense gradients");
             return GRUT_ERR_UNSUPPORTED;
         }
-        GRUT_REQUIRE(particle_density && particle_sph && feat_density && grad_feat_density && hit_distance && grad_particle_density && grad_particle_sph,
-                     "gut_backward: null buffer");
+        const bool fast = nht_fast_path(P);
+        if (io && !fast) {
+            set_last_error("gut_backward_unpacked: this feature shape runs on the generic kernels, which write packed gradients only");
+            return GRUT_ERR_UNSUPPORTED;
+        }
+        GRUT_REQUIRE(particle_density && particle_sph && feat_density && (io || grad_feat_density) && hit_distance && (io || grad_particle_density) &&
+                         grad_particle_sph, "gut_backward: null buffer");
         if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.begin(s));
-        GRUT_HIP(hipMemsetAsync(grad_particle_density, 0, (size_t)P.N * 48, s));
         GRUT_HIP(hipMemsetAsync(grad_particle_sph, 0, (size_t)P.N * P.nht_k * 4, s));
-        if (h->num_intersections > 0)
-            launch_render_nht_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_pos, h->pos_particle.as<uint32_t>(), particle_density, particle_sph, ray_origin,
-                                  ray_direction, feat_density, grad_feat_density, hit_distance, grad_hit_distance, grad_particle_density, grad_particle_sph);
+        const size_t I = h->num_intersections;
+        if (fast) {
+            const int slot = h->prof_fwd_slot;
+            const GutProjected proj = projected_view(h);
+            const GutGradOut g_out = io ? GutGradOut{nullptr, io->grad_positions, io->grad_density, io->grad_rotation, io->grad_scale}
+                                        : GutGradOut{grad_particle_density, nullptr, nullptr, nullptr, nullptr};
+            if (io) {
+                GRUT_REQUIRE(io->grad_positions && io->grad_density && io->grad_rotation && io->grad_scale, "gut_backward_unpacked: null gradient output");
+                GRUT_REQUIRE((reinterpret_cast<uintptr_t>(io->grad_rotation) & 15u) == 0, "gut_backward_unpacked: grad_rotation must be 16-byte aligned");
+            }
+            GutGradSlots slots;
+            slots.stride = 16;
+            slots.partial = nullptr;
+            slots.flag = nullptr;
+            slots.pos_particle = h->pos_particle.as<uint32_t>();
+            if (I > 0) {
+                GRUT_CHECK(h->grad_partial.ensure(2 * I * (size_t)slots.stride * 4, 1.3f));
+                GRUT_CHECK(h->grad_flag.ensure(2 * I + 96, 1.3f));
+                slots.partial = h->grad_partial.as<float>();
+                slots.flag = h->grad_flag.as<uint8_t>();
+                GRUT_HIP(hipMemsetAsync(slots.flag, 0, 2 * I, s));
+                GRUT_CHECK(h->stage_begin(GUT_STAGE_RENDER_BWD, s, slot));
+                launch_render_nhtp_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_pos, particle_density, particle_sph, ray_origin, ray_direction, feat_density,
+                                       io ? nullptr : grad_feat_density, io ? io->grad_features : nullptr, io ? io->grad_opacity : nullptr, hit_distance,
+                                       grad_hit_distance, slots, grad_particle_sph, h->ck_nht.ptr, h->checkpoints);
+                GRUT_CHECK(h->stage_end(GUT_STAGE_RENDER_BWD, s, slot));
+            }
+            GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));
+            launch_grad_finalize_nht(s, P, proj, particle_density, slots, I > 0, g_out);
+            GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT_BWD, s, slot));
+        } else {
+            GRUT_HIP(hipMemsetAsync(grad_particle_density, 0, (size_t)P.N * 48, s));
+            if (I > 0)
+                launch_render_nht_bwd(s, P, h->ranges.as<uint32_t>(), h->sorted_pos, h->pos_particle.as<uint32_t>(), particle_density, particle_sph, ray_origin,
+                                      ray_direction, feat_density, grad_feat_density, hit_distance, grad_hit_distance, grad_particle_density, grad_particle_sph);
+        }
         GRUT_HIP(hipGetLastError());
         if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
         return GRUT_OK;

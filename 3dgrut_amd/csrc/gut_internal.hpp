@@ -128,6 +128,18 @@ void launch_render_nht_fwd(hipStream_t s, const GutParams& P, const uint32_t* ra
 void launch_render_nht_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                            const float* density12, const float* features, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd,
                            const float* dist, const float* g_dist, float* g_density12, float* g_features);
+// the pixel-pair sweeps for the reference's default feature model (48 = 4 x 12 floats, sincos, one frequency; gut_render_nht.inl)
+bool nht_fast_path(const GutParams& P);
+uint64_t nht_checkpoint_bytes(uint32_t num_boundaries);
+void launch_render_nhtp_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                            const float* density12, const float* features, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
+                            float* out_cnt, void* ck_nht, const GutCheckpoints& ck, bool write_checkpoints);
+void launch_render_nhtp_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const float* density12,
+                            const float* features, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* g_feat,
+                            const float* g_opa, const float* dist, const float* g_dist, const GutGradSlots& slots, float* g_features,
+                            const void* ck_nht, const GutCheckpoints& ck);
+void launch_grad_finalize_nht(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const GutGradSlots& slots,
+                              bool have_partials, const GutGradOut& g_out);
 void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                          float* out_cnt);

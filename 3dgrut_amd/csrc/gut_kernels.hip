@@ -698,7 +698,9 @@ __device__ __forceinline__ float xor_sum_quads(float v) {  // sum over the 16 qu
     return v;
 }
 
-template <int STRIDE>
+// NHT (neural harmonic features, gut_render_nht.inl): slot words 13..15 carry the direct hit-distance scale terms instead of a radiance
+// gradient, and nothing is handed on to the SH backward.
+template <int STRIDE, bool NHT = false>
 __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutProjected proj, const float4* __restrict__ density12,
                                                               GutGradSlots slots, int have_partials, GutGradOut g_out,
                                                               float* __restrict__ g_rgb) {
@@ -811,6 +813,7 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     float gsy = -(rt.r1.x * m[3] + rt.r1.y * m[4] + rt.r1.z * m[5]) / sc.y;
     float gsz = -(rt.r2.x * m[6] + rt.r2.y * m[7] + rt.r2.z * m[8]) / sc.z;
     if (STRIDE > 16) { gsx += r[16]; gsy += r[17]; gsz += r[18]; }
+    if (NHT) { gsx += r[13]; gsy += r[14]; gsz += r[15]; }
     const float4 dq = quat_contract(m, make_float4(2.f * q.x, 2.f * q.y, 2.f * q.z, 2.f * q.w));
     if (c == 0) {
         if (g_out.packed) gd[0] = make_float4(gpos.x, gpos.y, gpos.z, r[3]);
@@ -824,7 +827,7 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     } else if (c == 2) {
         if (g_out.packed) gd[2] = make_float4(gsx, gsy, gsz, 0.f);
         else { g_out.scl[3 * (size_t)i] = gsx; g_out.scl[3 * (size_t)i + 1] = gsy; g_out.scl[3 * (size_t)i + 2] = gsz; }
-    } else {
+    } else if (!NHT) {
         g_rgb[3 * (size_t)i] = r[13];
         g_rgb[3 * (size_t)i + 1] = r[14];
         g_rgb[3 * (size_t)i + 2] = r[15];
@@ -1078,6 +1081,12 @@ void launch_sph_grad_from_views(hipStream_t s, uint32_t N, uint32_t n_views, con
                                 int n_active, int ncoef, float scale, float* g_sph) {
     hipLaunchKernelGGL(sph_grad_from_views_kernel, dim3(div_up(N, 128)), dim3(128), 0, s, N, n_views, factors, positions, pos_stride, n_active,
                        ncoef, scale, g_sph);
+}
+// neural harmonic features: the geometric gradient alone (the feature rows' gradient is accumulated by the sweep itself)
+void launch_grad_finalize_nht(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const GutGradSlots& slots,
+                              bool have_partials, const GutGradOut& g_out) {
+    hipLaunchKernelGGL((gut_grad_gather_kernel<16, true>), dim3(div_up(P.N, 64)), dim3(256), 0, s, P, proj, reinterpret_cast<const float4*>(density12),
+                       slots, have_partials ? 1 : 0, g_out, static_cast<float*>(nullptr));
 }
 void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
                           const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, const GutGradOut& g_out, float* g_sph,

@@ -1561,6 +1561,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+#include "gut_render_nht.inl"
+
 static uint32_t strip_grid(const GutParams& P) {
     const uint32_t tiles = (uint32_t)(P.gx * P.gy);
     return ((tiles + 7u) & ~7u) * 4u;
@@ -1571,6 +1573,44 @@ static uint32_t strip_grid(const GutParams& P) {
     case 8: { constexpr int K_ = 8; __VA_ARGS__; } break;      \
     default: { constexpr int K_ = 16; __VA_ARGS__; } break;    \
     }
+bool nht_fast_path(const GutParams& P) {
+    const bool generic = getenv("GRUT_NHT_GENERIC") != nullptr;   // (development / test switch, read per call: the strip kernels for every shape)
+    return P.nht && !generic && P.nht_k == kNhtK && P.nht_ipd == kNhtIpd && P.nht_support == 1 && P.nht_act == 2 && P.nht_nf == 1 && P.k_buffer == 0;
+}
+uint64_t nht_checkpoint_bytes(uint32_t num_boundaries) { return (uint64_t)num_boundaries * 2u * kNhtCkQuads * 64u * sizeof(float4); }
+void launch_render_nhtp_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
+                            const float* density12, const float* features, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
+                            float* out_cnt, void* ck_nht, const GutCheckpoints& ck, bool write_checkpoints) {
+    const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
+    if (write_checkpoints && ck_nht) {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_nhtp_fwd_kernel<D_, true>), dim3(half_grid(P)), dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12),
+                                                          features, ray_o, ray_d, out_fd, out_dist, out_cnt, reinterpret_cast<float4*>(ck_nht), ck));
+    } else {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_nhtp_fwd_kernel<D_, false>), dim3(half_grid(P)), dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12),
+                                                          features, ray_o, ray_d, out_fd, out_dist, out_cnt, reinterpret_cast<float4*>(ck_nht), ck));
+    }
+}
+void launch_render_nhtp_bwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const float* density12,
+                            const float* features, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* g_feat,
+                            const float* g_opa, const float* dist, const float* g_dist, const GutGradSlots& slots, float* g_features,
+                            const void* ck_nht, const GutCheckpoints& ck) {
+    const dim3 grid(segment_grid(P, ck.num_boundaries));
+    const EntryLists lists = entry_lists(P, sorted_pos, slots.pos_particle);
+    const NhtGradIn g_in{g_fd, g_feat, g_opa};
+    if (g_dist) {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_nhtp_bwd_kernel<D_, true>), grid, dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12),
+                                                          features, ray_o, ray_d, fd, g_in, dist, g_dist, slots, g_features,
+                                                          reinterpret_cast<const float4*>(ck_nht), ck));
+    } else {
+        GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_nhtp_bwd_kernel<D_, false>), grid, dim3(64), 0, s, P,
+                                                          reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12),
+                                                          features, ray_o, ray_d, fd, g_in, dist, g_dist, slots, g_features,
+                                                          reinterpret_cast<const float4*>(ck_nht), ck));
+    }
+}
 void launch_render_nht_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                            const float* density12, const float* features, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                            float* out_cnt) {
