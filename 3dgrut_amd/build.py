@@ -36,7 +36,7 @@ def _hipcc() -> str:
 
 
 def _deps():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))] + \
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h", ".inl"))] + \
            [os.path.join(HERE, "..", "include", "grut_amd.h")]
 
 

@@ -121,64 +121,104 @@ __host__ __device__ inline FramePoses make_frame_poses(const float ps7[7], const
 // where an entry is a cancellation residue (|x| < 1e-9, absolute difference < 1e-15): tests/test_host_cpu.py pins this function against
 // tests/golden/pose.npz (produced by the reference's own Python), bit for bit outside that class.
 // Must be compiled WITHOUT floating-point contraction (csrc/gut_poses.hip, -ffp-contract=off).
-__host__ __device__ inline void c2w_to_world_to_sensor(const float* m, float out7[7]) {
-    double A[4][4], B[4][4];
-    for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-            A[i][j] = i < 3 ? (double)m[4 * i + j] : (j == 3 ? 1.0 : 0.0);
-            B[i][j] = i == j ? 1.0 : 0.0;
-        }
-    for (int k = 0; k < 4; ++k) {   // dgetf2: pivot = largest magnitude of the column, scale by the reciprocal, rank-1 update
+// LU with partial pivoting of [rows 0-2 of m | 0 0 0 1] (dgetf2: pivot = largest magnitude of the column, scale by the reciprocal,
+// rank-1 update); perm[i] = original row now in position i
+struct PoseLU {
+    double A[4][4];
+    int perm[4];
+};
+// (every index below is a compile-time constant after unrolling - row exchanges and the quaternion's branch are written with selects /
+// a switch - so that the device keeps the matrices in registers: one dynamically indexed access would put them in scratch memory, a
+// dependent ~1 us round trip each; measured 22 us for this kernel against 5)
+__host__ __device__ inline PoseLU pose_lu_factor(const float* m) {
+    PoseLU f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f.perm[i] = i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f.A[i][j] = i < 3 ? (double)m[4 * i + j] : (j == 3 ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
         int p = k;
-        for (int i = k + 1; i < 4; ++i)
-            if (fabs(A[i][k]) > fabs(A[p][k])) p = i;
-        if (p != k)
-            for (int j = 0; j < 4; ++j) {
-                const double ta = A[k][j], tb = B[k][j];
-                A[k][j] = A[p][j]; A[p][j] = ta;
-                B[k][j] = B[p][j]; B[p][j] = tb;
-            }
-        const double r = 1.0 / A[k][k];
-        for (int i = k + 1; i < 4; ++i) A[i][k] = A[i][k] * r;
-        for (int i = k + 1; i < 4; ++i)
-            for (int j = k + 1; j < 4; ++j) A[i][j] = A[i][j] - A[i][k] * A[k][j];
-    }
-    for (int c = 0; c < 4; ++c) {   // dgetrs: unit-lower forward substitution, upper back substitution, column by column
-        for (int i = 0; i < 4; ++i)
-            for (int j = 0; j < i; ++j) B[i][c] = B[i][c] - A[i][j] * B[j][c];
-        for (int i = 3; i >= 0; --i) {
-            for (int j = i + 1; j < 4; ++j) B[i][c] = B[i][c] - A[i][j] * B[j][c];
-            B[i][c] = B[i][c] / A[i][i];
+        double best = fabs(f.A[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) {
+            const double v = fabs(f.A[i][k]);
+            if (v > best) { best = v; p = i; }
         }
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) {   // exchange rows k and p
+            const bool sw = p == i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const double a = f.A[k][j], b = f.A[i][j];
+                f.A[k][j] = sw ? b : a;
+                f.A[i][j] = sw ? a : b;
+            }
+            const int pa = f.perm[k], pb = f.perm[i];
+            f.perm[k] = sw ? pb : pa;
+            f.perm[i] = sw ? pa : pb;
+        }
+        const double r = 1.0 / f.A[k][k];
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i) f.A[i][k] = f.A[i][k] * r;
+#pragma unroll
+        for (int i = k + 1; i < 4; ++i)
+#pragma unroll
+            for (int j = k + 1; j < 4; ++j) f.A[i][j] = f.A[i][j] - f.A[i][k] * f.A[k][j];
     }
-    float R[9];
-    for (int i = 0; i < 3; ++i) {
-        out7[i] = (float)B[i][3];
-        for (int j = 0; j < 3; ++j) R[3 * i + j] = (float)B[i][j];
+    return f;
+}
+// column c of the inverse (dgetrs against the permuted identity: unit-lower forward substitution, upper back substitution)
+__host__ __device__ inline void pose_lu_solve_column(const PoseLU& f, int c, double x[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = f.perm[i] == c ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) x[i] = x[i] - f.A[i][j] * x[j];
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+#pragma unroll
+        for (int j = i + 1; j < 4; ++j) x[i] = x[i] - f.A[i][j] * x[j];
+        x[i] = x[i] / f.A[i][i];
     }
-    float dm[4] = {R[0], R[4], R[8], 0.f};
-    dm[3] = (dm[0] + dm[1]) + dm[2];
+}
+// steps (2) and (3): [t, q] from the float32-rounded rows {R | t} of the inverse
+__host__ __device__ inline void pose_tquat_from_rows(const float R[9], const float t[3], float out7[7]) {
+    out7[0] = t[0]; out7[1] = t[1]; out7[2] = t[2];
+    const float d0 = R[0], d1 = R[4], d2 = R[8], d3 = (d0 + d1) + d2;
     int c = 0;
-    for (int k = 1; k < 4; ++k)
-        if (dm[k] > dm[c]) c = k;
-    float q[4];
-    if (c != 3) {
-        const int i = c, j = (c + 1) % 3, k = (c + 2) % 3;
-        q[i] = (1.f - dm[3]) + 2.f * R[3 * i + i];
-        q[j] = R[3 * j + i] + R[3 * i + j];
-        q[k] = R[3 * k + i] + R[3 * i + k];
-        q[3] = R[3 * k + j] - R[3 * j + k];
-    } else {
-        q[0] = R[7] - R[5];
-        q[1] = R[2] - R[6];
-        q[2] = R[3] - R[1];
-        q[3] = 1.f + dm[3];
+    float best = d0;
+    if (d1 > best) { best = d1; c = 1; }
+    if (d2 > best) { best = d2; c = 2; }
+    if (d3 > best) { best = d3; c = 3; }
+    float q0, q1, q2, q3;
+    switch (c) {   // i = c, j = (c + 1) % 3, k = (c + 2) % 3 of tracer.py:117-124, spelled out
+    case 0: q0 = (1.f - d3) + 2.f * R[0]; q1 = R[3] + R[1]; q2 = R[6] + R[2]; q3 = R[7] - R[5]; break;
+    case 1: q1 = (1.f - d3) + 2.f * R[4]; q2 = R[7] + R[5]; q0 = R[1] + R[3]; q3 = R[2] - R[6]; break;
+    case 2: q2 = (1.f - d3) + 2.f * R[8]; q0 = R[2] + R[6]; q1 = R[5] + R[7]; q3 = R[3] - R[1]; break;
+    default: q0 = R[7] - R[5]; q1 = R[2] - R[6]; q2 = R[3] - R[1]; q3 = 1.f + d3; break;
     }
-    const float n2 = ((q[0] * q[0] + q[1] * q[1]) + q[2] * q[2]) + q[3] * q[3];
+    const float n2 = ((q0 * q0 + q1 * q1) + q2 * q2) + q3 * q3;
     // correctly rounded float sqrt and quotients through float64 (53 >= 2*24 + 2 bits: no double rounding), whatever the
     // compiler's float sqrt / division expansion is
     const double n = (double)(float)sqrt((double)n2);
-    for (int k = 0; k < 4; ++k) out7[3 + k] = (float)((double)q[k] / n);
+    out7[3] = (float)((double)q0 / n); out7[4] = (float)((double)q1 / n); out7[5] = (float)((double)q2 / n); out7[6] = (float)((double)q3 / n);
+}
+__host__ __device__ inline void c2w_to_world_to_sensor(const float* m, float out7[7]) {
+    const PoseLU f = pose_lu_factor(m);
+    float R[9], t[3];
+    for (int c = 0; c < 4; ++c) {
+        double x[4];
+        pose_lu_solve_column(f, c, x);
+        for (int i = 0; i < 3; ++i) {
+            if (c < 3) R[3 * i + c] = (float)x[i];
+            else t[i] = (float)x[i];
+        }
+    }
+    pose_tquat_from_rows(R, t, out7);
 }
 
 #ifdef __HIPCC__

@@ -11,14 +11,36 @@
 namespace grut {
 namespace {
 
+// One wave.  Everything here is a chain of dependent float64 operations (a float64 division alone is ~25 dependent instructions), so the
+// kernel's time is its longest chain, not its work: lanes 0-7 take (pose, column of the inverse) - each factors its pose's matrix
+// (redundantly: no extra latency) and solves ONE column - then lanes 0 and 4 collect their pose's columns and lane 0 builds the block.
+// Same functions, same operation order per value as the sequential host twin (c2w_to_world_to_sensor): identical bits.
 __global__ __launch_bounds__(64) void gut_frame_poses_kernel(const float* __restrict__ T_start, const float* __restrict__ T_end, FramePoses* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x, pose = (lane >> 2) & 1, col = lane & 3;
+    const float* m = (pose && T_end) ? T_end : T_start;
+    const PoseLU f = pose_lu_factor(m);
+    double x[4];
+    pose_lu_solve_column(f, col, x);
+    const float xf[3] = {(float)x[0], (float)x[1], (float)x[2]};
+    float R[9], t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int base = lane & 4;   // first lane of this lane's pose
+        R[3 * i + 0] = __shfl(xf[i], base + 0, 64);
+        R[3 * i + 1] = __shfl(xf[i], base + 1, 64);
+        R[3 * i + 2] = __shfl(xf[i], base + 2, 64);
+        t[i] = __shfl(xf[i], base + 3, 64);
+    }
+    float tq[7];
+    pose_tquat_from_rows(R, t, tq);
     float ps[7], pe[7];
-    c2w_to_world_to_sensor(T_start, ps);
-    if (T_end) c2w_to_world_to_sensor(T_end, pe);
-    else
-        for (int k = 0; k < 7; ++k) pe[k] = ps[k];
-    *out = make_frame_poses(ps, pe);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        ps[k] = __shfl(tq[k], 0, 64);
+        pe[k] = __shfl(tq[k], 4, 64);
+    }
+    if (lane == 0) *out = make_frame_poses(ps, pe);
 }
 
 }  // namespace

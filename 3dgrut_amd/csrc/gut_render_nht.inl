@@ -245,7 +245,7 @@ __device__ __forceinline__ void nht_bwd_sweep(const GutParams& P, const RayPair&
                                               const EntryLists& lists, const float4* __restrict__ density12, const float* __restrict__ features,
                                               const GutGradSlots& slots, float* __restrict__ g_features, float4* __restrict__ s_rec,
                                               float4* __restrict__ s_feat, float* __restrict__ s_acc, float* __restrict__ s_tr, v2f T, v2f D,
-                                              v2f (&Rem)[kNhtRay], const v2f (&gC)[kNhtRay], v2f T_fin, v2f D_fin, v2f gT, v2f gD, bool alive0,
+                                              v2f Q, const v2f (&gC)[kNhtRay], v2f T_fin, v2f D_fin, v2f gT, v2f gD, bool alive0,
                                               bool alive1) {
     const NhtTet tet = nht_tet();
     v2f iT = prcp(T);
@@ -299,22 +299,39 @@ __device__ __forceinline__ void nht_bwd_sweep(const GutParams& P, const RayPair&
             const v2f w0 = nht_weight(tet.gw0, tet.c0, a), w1 = nht_weight(tet.gw1, tet.c1, a), w2 = nht_weight(tet.gw2, tet.c2, a),
                       w3 = nht_weight(tet.gw3, tet.c3, a);
             const float4* fj = &s_feat[j * kNhtIpd];
-            v2f gb[kNhtIpd];
-            v2f fsum = splat(0.f), rsum = splat(0.f), dw0 = splat(0.f), dw1 = splat(0.f), dw2 = splat(0.f), dw3 = splat(0.f);
+            // three groups of four dimensions; after each group its 16 feature-row words (vertex k, dimension 4 c + ml -> word 4 k + ml of
+            // the pass) are summed over the wave, so that d base lives for one group only
+            v2f fsum = splat(0.f), dw0 = splat(0.f), dw1 = splat(0.f), dw2 = splat(0.f), dw3 = splat(0.f);
+            float fw = 0.f;
 #pragma unroll
-            for (int m = 0; m < kNhtIpd; ++m) {
-                const float4 F = fj[m];
-                const v2f base = pfma(F.w, w3, pfma(F.z, w2, pfma(F.y, w1, F.x * w0)));
-                const v2f rev = base * kInvTwoPi;
-                const v2f sn = nht_sin2(rev), cs = nht_cos2(rev);
-                Rem[2 * m] = pfma(-weight, sn, Rem[2 * m]);
-                Rem[2 * m + 1] = pfma(-weight, cs, Rem[2 * m + 1]);
-                fsum = pfma(sn, gC[2 * m], pfma(cs, gC[2 * m + 1], fsum));
-                rsum = pfma(Rem[2 * m], gC[2 * m], pfma(Rem[2 * m + 1], gC[2 * m + 1], rsum));
-                gb[m] = weight * pfma(cs, gC[2 * m], -(sn * gC[2 * m + 1]));
-                dw0 = pfma(F.x, gb[m], dw0); dw1 = pfma(F.y, gb[m], dw1); dw2 = pfma(F.z, gb[m], dw2); dw3 = pfma(F.w, gb[m], dw3);
+            for (int c = 0; c < 3; ++c) {
+                v2f gb[4];
+#pragma unroll
+                for (int ml = 0; ml < 4; ++ml) {
+                    const int m = 4 * c + ml;
+                    const float4 F = fj[m];
+                    const v2f base = pfma(F.w, w3, pfma(F.z, w2, pfma(F.y, w1, F.x * w0)));
+                    const v2f rev = base * kInvTwoPi;
+                    const v2f sn = nht_sin2(rev), cs = nht_cos2(rev);
+                    fsum = pfma(sn, gC[2 * m], pfma(cs, gC[2 * m + 1], fsum));
+                    gb[ml] = weight * pfma(cs, gC[2 * m], -(sn * gC[2 * m + 1]));
+                    dw0 = pfma(F.x, gb[ml], dw0); dw1 = pfma(F.y, gb[ml], dw1); dw2 = pfma(F.z, gb[ml], dw2); dw3 = pfma(F.w, gb[ml], dw3);
+                }
+                float ft[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int k = q >> 2, ml = q & 3;
+                    const v2f wk = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
+                    const v2f pr = wk * gb[ml];
+                    ft[q] = pr.x + pr.y;
+                }
+                const float ftot = nht_wave_sum16(ft, s_tr, lane);
+                if ((lane >> 4) == c) fw = ftot;
             }
-            dalpha = pfma(T, pfma(-inextT, rsum, fsum), dalpha);
+            // sum_i (C_fin_i - partial sums_i) gC_i as ONE running scalar: Q -= w sum_i f_i gC_i (no residual clamps, so the channels need
+            // not be kept apart - the 24 remainders would cost 48 registers and 48 packed operations per hit)
+            Q = pfma(-weight, fsum, Q);
+            dalpha = pfma(T, pfma(-inextT, Q, fsum), dalpha);
             const p3 gP = p3{pfma(tet.gw0.x, dw0, pfma(tet.gw1.x, dw1, pfma(tet.gw2.x, dw2, tet.gw3.x * dw3))),
                              pfma(tet.gw0.y, dw0, pfma(tet.gw1.y, dw1, pfma(tet.gw2.y, dw2, tet.gw3.y * dw3))),
                              pfma(tet.gw0.z, dw0, pfma(tet.gw1.z, dw1, pfma(tet.gw2.z, dw2, tet.gw3.z * dw3)))};
@@ -386,24 +403,10 @@ __device__ __forceinline__ void nht_bwd_sweep(const GutParams& P, const RayPair&
             }
             const float tot = nht_wave_sum16(terms, s_tr, lane);
             if (lane < 16) s_acc[j * 16 + lane] = tot;
-            // the entry's 48 feature-row words, three passes of 16: word 12 k + m = sum over the wave's pixels of w_k d base_m
-            float fw = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float ft[16];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int word = 16 * c + q, k = word / kNhtIpd, m = word - k * kNhtIpd;
-                    const v2f wk = k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3));
-                    const v2f pr = wk * gb[m];
-                    ft[q] = pr.x + pr.y;
-                }
-                const float ftot = nht_wave_sum16(ft, s_tr, lane);
-                if ((lane >> 4) == c) fw = ftot;
-            }
             {
+                // lane l < 48 holds the wave total of vertex (l & 15) >> 2, dimension 4 (l >> 4) + (l & 3)
                 const uint32_t pid = reinterpret_cast<const uint32_t*>(&rec[4])[0];
-                if (lane < kNhtK) atomicAdd(g_features + (size_t)pid * kNhtK + lane, fw);
+                if (lane < kNhtK) atomicAdd(g_features + (size_t)pid * kNhtK + ((lane & 15) >> 2) * kNhtIpd + 4 * (lane >> 4) + (lane & 3), fw);
             }
             T = nextT;
             iT = inextT_raw;
@@ -469,39 +472,40 @@ void gut_render_nhtp_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, E
     const RayPair rp = init_ray_pair(P, ray_o, ray_d, tile, half, lane);
     bool alive0 = rp.valid0, alive1 = rp.valid1;
     v2f T = splat(1.f), D = splat(0.f), T_fin = splat(0.f), D_fin = splat(0.f), gT = splat(0.f), gD = splat(0.f);
-    v2f Rem[kNhtRay], gC[kNhtRay];
+    v2f gC[kNhtRay], Q = splat(0.f);   // Q = sum_i (C_fin_i - partial sums_i) gC_i
 #pragma unroll
-    for (int i = 0; i < kNhtRay; ++i) { Rem[i] = splat(0.f); gC[i] = splat(0.f); }
+    for (int i = 0; i < kNhtRay; ++i) gC[i] = splat(0.f);
     constexpr size_t stride = kNhtRay + 1;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         if (!(p ? alive1 : alive0)) continue;
         const size_t pix = (size_t)(p ? rp.py1 : rp.py0) * P.W + rp.px;
-        float opa, gop;
+        float opa, gop, g[kNhtRay];
+        if (g_in.fd) {
+            const float* gq = g_in.fd + pix * stride;
+#pragma unroll
+            for (int i = 0; i < kNhtRay; ++i) g[i] = gq[i];
+            gop = gq[kNhtRay];
+        } else {
+#pragma unroll
+            for (int i = 0; i < kNhtRay; ++i) g[i] = g_in.feat ? g_in.feat[pix * kNhtRay + i] : 0.f;
+            gop = g_in.opa ? g_in.opa[pix] : 0.f;
+        }
+        float q = 0.f;
         if (P.out_half) {
             const __half* f = reinterpret_cast<const __half*>(fd) + pix * stride;
 #pragma unroll
-            for (int i = 0; i < kNhtRay; ++i) { if (p) Rem[i].y = __half2float(f[i]); else Rem[i].x = __half2float(f[i]); }
+            for (int i = 0; i < kNhtRay; ++i) q = fmaf(__half2float(f[i]), g[i], q);
             opa = __half2float(f[kNhtRay]);
         } else {
             const float* f = fd + pix * stride;
 #pragma unroll
-            for (int i = 0; i < kNhtRay; ++i) { if (p) Rem[i].y = f[i]; else Rem[i].x = f[i]; }
+            for (int i = 0; i < kNhtRay; ++i) q = fmaf(f[i], g[i], q);
             opa = f[kNhtRay];
         }
-        if (g_in.fd) {
-            const float* gq = g_in.fd + pix * stride;
 #pragma unroll
-            for (int i = 0; i < kNhtRay; ++i) { if (p) gC[i].y = gq[i]; else gC[i].x = gq[i]; }
-            gop = gq[kNhtRay];
-        } else {
-            if (g_in.feat) {
-                const float* gq = g_in.feat + pix * kNhtRay;
-#pragma unroll
-                for (int i = 0; i < kNhtRay; ++i) { if (p) gC[i].y = gq[i]; else gC[i].x = gq[i]; }
-            }
-            gop = g_in.opa ? g_in.opa[pix] : 0.f;
-        }
+        for (int i = 0; i < kNhtRay; ++i) { if (p) gC[i].y = g[i]; else gC[i].x = g[i]; }
+        if (p) Q.y = q; else Q.x = q;
         if (p) { T_fin.y = 1.f - opa; gT.y = -gop; } else { T_fin.x = 1.f - opa; gT.x = -gop; }
         if (HAS_GDIST) {
             if (p) { D_fin.y = dist[pix]; gD.y = g_dist[pix]; } else { D_fin.x = dist[pix]; gD.x = g_dist[pix]; }
@@ -515,16 +519,15 @@ void gut_render_nhtp_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, E
 #pragma unroll
         for (int q = 0; q < 12; ++q) {
             const float4 c = in[64 * (q + 1)];
-            Rem[2 * q] -= v2f{c.x, c.y};
-            Rem[2 * q + 1] -= v2f{c.z, c.w};
+            Q = pfma(-v2f{c.x, c.y}, gC[2 * q], pfma(-v2f{c.z, c.w}, gC[2 * q + 1], Q));
         }
         alive0 = alive0 && !(T.x < P.min_transmittance);
         alive1 = alive1 && !(T.y < P.min_transmittance);
     }
     if (rp.uniform_origin)
         nht_bwd_sweep<DEG, HAS_GDIST, true>(P, rp, seg_begin, seg_end, lane, half, lists, density12, features, slots, g_features, s_rec, s_feat, s_acc,
-                                            s_tr, T, D, Rem, gC, T_fin, D_fin, gT, gD, alive0, alive1);
+                                            s_tr, T, D, Q, gC, T_fin, D_fin, gT, gD, alive0, alive1);
     else
         nht_bwd_sweep<DEG, HAS_GDIST, false>(P, rp, seg_begin, seg_end, lane, half, lists, density12, features, slots, g_features, s_rec, s_feat, s_acc,
-                                             s_tr, T, D, Rem, gC, T_fin, D_fin, gT, gD, alive0, alive1);
+                                             s_tr, T, D, Q, gC, T_fin, D_fin, gT, gD, alive0, alive1);
 }

@@ -302,6 +302,16 @@ class _NhtAutograd(torch.autograd.Function):
     def backward(ctx, g_feat, g_opa, g_dist, _g_cnt, _g_vis):
         ray_ori, ray_dir, fd, dist, particle_density, feats_k = ctx.saved_tensors
         H, W, nr = fd.shape[0], fd.shape[1], fd.shape[2] - 1
+        c = ctx.native.cfg
+        if (ctx.exchange is None and c.particle_feature_dim == 48 and c.interp_point_feature_dim == 12 and c.feature_interpolation_support == 1
+                and c.feature_activation_type == 2 and c.feature_activation_num_frequencies == 1 and not os.environ.get("GRUT_NHT_GENERIC")):
+            # the default feature model runs on the pixel-pair sweeps, which take the upstream gradients as autograd delivers them and write
+            # the model's four gradient tensors directly: no concatenation before, no unpack pass after
+            g_pos, g_dns, g_rot, g_scl, g_features = ctx.native.trace_bwd_unpacked(
+                ctx.frame, particle_density, feats_k, ray_ori, ray_dir, fd,
+                None if g_feat is None else g_feat.reshape(H, W, nr).float().contiguous(), None if g_opa is None else g_opa.reshape(H, W, 1).float().contiguous(),
+                dist, None if g_dist is None else g_dist.contiguous())
+            return None, None, None, None, g_pos, g_rot, g_scl, g_dns, g_features, None
         g_feat = fd.new_zeros((H, W, nr), dtype=torch.float32) if g_feat is None else g_feat.reshape(H, W, nr).float()
         g_opa = fd.new_zeros((H, W, 1), dtype=torch.float32) if g_opa is None else g_opa.reshape(H, W, 1).float()
         g_fd = torch.cat([g_feat, g_opa], dim=-1).contiguous()
