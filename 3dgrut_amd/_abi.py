@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgrut_amd.so")
 
@@ -97,6 +97,7 @@ class GrtStats(C.Structure):
         ("candidates", C.c_uint64), ("processed_hits", C.c_uint64), ("scene_aabb", C.c_float * 6),
         ("list_entries", C.c_uint64), ("packet_tests", C.c_uint64), ("list_batches", C.c_uint64),
         ("bwd_rederived_rays", C.c_uint32), ("bwd_premise_rays", C.c_uint32),
+        ("bwd_atomic_instructions", C.c_uint64), ("bwd_atomic_words", C.c_uint64),
     ]
 
 

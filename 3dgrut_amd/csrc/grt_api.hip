@@ -531,6 +531,20 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
                 lists.ranges ? "yes" : "no");
     }
     hipStream_t rederive = s;
+    // whatever happens after the fork, the caller's stream must wait for the side stream again before this call returns (the
+    // re-derivation may still be adding to the gradient buffers): the guard joins on every exit path
+    struct SideJoin {
+        GrtHandle* h;
+        hipStream_t s;
+        bool armed;
+        int join() {
+            armed = false;
+            GRUT_HIP(hipEventRecord(h->side_join, h->side_stream));
+            GRUT_HIP(hipStreamWaitEvent(s, h->side_join, 0));
+            return GRUT_OK;
+        }
+        ~SideJoin() { if (armed) (void)join(); }
+    } side{h, s, false};
     if (log.pool) {   // fork: the re-derivation of the flagged rays next to the replay (both only ADD to the gradient buffers)
         if (!h->side_stream) {
             GRUT_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
@@ -538,15 +552,13 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
             GRUT_HIP(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
         }
         GRUT_HIP(hipEventRecord(h->side_fork, s));
+        side.armed = true;
         GRUT_HIP(hipStreamWaitEvent(h->side_stream, h->side_fork, 0));
         rederive = h->side_stream;
     }
     grt_launch_trace_bwd(s, rederive, P, bvh_view(h), particle_density, particle_sph, ray_origin, ray_direction, features, density, hit_distance,
                          grad_features, grad_density, grad_hit_distance, grad_particle_density, grad_particle_sph, log, lists);
-    if (log.pool) {   // join
-        GRUT_HIP(hipEventRecord(h->side_join, h->side_stream));
-        GRUT_HIP(hipStreamWaitEvent(s, h->side_join, 0));
-    }
+    if (log.pool) GRUT_CHECK(side.join());
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
     return GRUT_OK;
@@ -683,17 +695,14 @@ int grt_stats(GrtHandle* h, GrtStats* stats) {
     stats->list_entries = h->list_entries;
     stats->packet_tests = h->work_host[9];
     stats->list_batches = h->work_host[12];
-    if (h->log_valid && h->log.pool) {   // (synchronises: a diagnostics call)
-        const size_t rays = (size_t)h->log_W * h->log_H;
-        std::vector<uint32_t> flags(rays);
-        uint32_t st[4] = {0, 0, 0, 0};
+    if (h->log_valid && h->log.pool) {   // the replay kernels' own counters: one 32-byte read-back (synchronises: a diagnostics call)
+        uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         GRUT_HIP(hipDeviceSynchronize());
-        GRUT_HIP(hipMemcpy(flags.data(), h->log.ray_flags, rays * 4, hipMemcpyDeviceToHost));
-        GRUT_HIP(hipMemcpy(st, h->log.state, 16, hipMemcpyDeviceToHost));
-        uint32_t n = 0;
-        for (uint32_t v : flags) n += v >> 31;
-        stats->bwd_rederived_rays = n;
+        GRUT_HIP(hipMemcpy(st, h->log.state, 32, hipMemcpyDeviceToHost));
         stats->bwd_premise_rays = st[2];
+        stats->bwd_rederived_rays = st[3];
+        stats->bwd_atomic_instructions = st[4];
+        stats->bwd_atomic_words = (uint64_t)st[5] * 16u;
     }
     if (h->built && h->N > 0) {
         if (!h->scene_host_valid) {  // synchronises with the build stream

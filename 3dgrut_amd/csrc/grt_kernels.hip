@@ -1626,6 +1626,16 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
 constexpr int kTermStride = 15;    // per lane: 11 geometry terms + 3 colour weights, padded to an odd stride (LDS banks)
 constexpr int kBasisStride = 17;
 
+// Per-wave tail of the replay kernels: GrtHitLog::state[3] += rays of this wave whose rounds are re-derived, [4] += atomic instructions issued,
+// [5] += float words they carried, in units of 16 (what bench.py prices against scripts/atomic_calib.hip; GrtStats reads them back).
+__device__ __forceinline__ void replay_bookkeeping(const GrtHitLog& log, bool rederived, uint32_t at_instr, uint32_t at_words, int lane) {
+    const unsigned long long red = __ballot(rederived);
+    if (lane == 0) {
+        if (red) atomicAdd(&log.state[3], (uint32_t)__popcll(red));
+        if (at_instr) { atomicAdd(&log.state[4], at_instr); atomicAdd(&log.state[5], (at_words + 8u) >> 4); }
+    }
+}
+
 template <int DEG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
@@ -1655,6 +1665,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     f3 rad = mk3(0.f, 0.f, 0.f);
     float T = 1.f, depth = 0.f;
     const bool replayed = in_image && !(log.ray_flags[pix] & kGrtRederiveRay);   // (else: the exact rounds of grt_trace_bwd_kernel serve this ray)
+    uint32_t at_instr = 0u, at_words = 0u;
     // the scatter's lane roles: word j of a hit's gradient — SH words first (their row is 3 * ncoef floats), then the 11 packed terms
     const bool sh_lane = lane < 48;
     const int coef = lane / 3, chn = lane - 3 * coef;
@@ -1784,7 +1795,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                     same &= same - 1;
                     v = fmaf(s_terms[s2 * kTermStride + term_word], sh_lane ? s_basis[s2 * kBasisStride + basis_word] : 1.f, v);
                 }
-                if (word_used && v != 0.f) atomicAdd(row_base + (size_t)pid * row_stride, v);
+                const bool send = word_used && v != 0.f;
+                if (send) atomicAdd(row_base + (size_t)pid * row_stride, v);
+                const unsigned long long sent = __ballot(send);   // (scalar bookkeeping: the atomic instructions and words this wave issues)
+                at_instr += sent != 0ull;
+                at_words += (uint32_t)__popcll(sent);
             }
             __syncthreads();
         }
@@ -1793,6 +1808,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // rays whose ghost premise failed (see GhostLog): their gradient may miss a hit the reference's backward would have been offered
     const unsigned long long broken = __ballot(premise_broken);
     if (broken && lane == 0) atomicAdd(&log.state[2], (uint32_t)__popcll(broken));
+    replay_bookkeeping(log, in_image && !replayed, at_instr, at_words, lane);
 }
 
 // The replay backward for neural harmonic features (referenceSlangBwdOptix.cu:70-185): the log walk and the backward program's trace
@@ -1818,6 +1834,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const NhtTetra tet = nht_tetra();
     NhtBwdRay st = nht_bwd_ray_init(P, in_image, pix, in_feat, in_dns, in_hit2, g_feat, g_dns, g_hit);
     const bool replayed = in_image && !(log.ray_flags[pix] & kGrtRederiveRay);
+    uint32_t at_instr = 0u, at_words = 0u;
     // the scatter's lane roles
     const int K = P.nht_k, ipd = P.nht_ipd;
     const bool row_lane = lane < K;
@@ -1885,7 +1902,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const float* tw = s_terms + s2 * kNhtTermStride;
                     v += row_lane ? tw[11 + kq] * tw[15 + nq] : tw[word_used ? lane - K : 0];
                 }
-                if (word_used && v != 0.f) atomicAdd(row_base + (size_t)pid * row_stride, v);
+                const bool send = word_used && v != 0.f;
+                if (send) atomicAdd(row_base + (size_t)pid * row_stride, v);
+                const unsigned long long sent = __ballot(send);
+                at_instr += sent != 0ull;
+                at_words += (uint32_t)__popcll(sent);
             }
             __syncthreads();
         }
@@ -1893,6 +1914,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (P.bwd_sig && replayed) { P.bwd_sig[pix] = dbg_sig; P.bwd_cnt[pix] = dbg_n; }
     const unsigned long long broken = __ballot(premise_broken);
     if (broken && lane == 0) atomicAdd(&log.state[2], (uint32_t)__popcll(broken));
+    replay_bookkeeping(log, in_image && !replayed, at_instr, at_words, lane);
 }
 
 // ---------------------------------------------------------------------------------------------

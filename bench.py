@@ -138,26 +138,48 @@ def grt_roofline(work, P, stages):
     return r
 
 
-def grt_backward_roofline(work, P, stages):
-    """Replay backward.  What binds it is the atomic units, not HBM or VALU (0.92 G VALU instructions, 22 % of the issue
-    time): every differentiated hit adds 11 + 48 float words to its particle's gradient rows.  Algorithmic bytes per the contract: per
-    processed hit 240 B of parameters read (48 B particle + 192 B SH) + 48 B proxy record (the round-structure test) + 236 B of gradient
-    words (read-modify-write at the memory side: counted once) + 4 B of log; per ray 64 B.  `atomic_words_per_s` is the rate the kernel
-    actually lives by."""
+def atomic_calibration():
+    """profiles/rNN_atomic_calib.json of the latest round that has one (scripts/atomic_calib.hip run on an MI355X): float words per second
+    of the replay backward's own atomic-instruction shape ("rows59": 59 consecutive words of one row per instruction, 256 MB table)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_atomic_calib.json")), reverse=True):
+        try:
+            c = json.load(open(path))
+            return {"file": os.path.relpath(path, ROOT), "rows59_words_per_s": float(c["rows59"]["words_per_s"]),
+                    "rows59_instructions_per_s": float(c["rows59"]["instructions_per_s"]), "rows59_hot_words_per_s": float(c["rows59_hot"]["words_per_s"])}
+        except Exception:
+            continue
+    return None
+
+
+def grt_backward_roofline(work, P, stages, atomics=None):
+    """Replay backward.  What binds it is the L2's atomic units, not HBM or VALU (22 % of the VALU issue time; the float words
+    are merged in the L2 and never reach HBM one by one - the PMC passes see a third of the "algorithmic" bytes).  So it is priced against
+    the unit that binds it: `achieved` = float words its atomic instructions carry per second (counted on the device by the kernel itself,
+    GrtStats::bwd_atomic_words) against `peak` = the rate scripts/atomic_calib.hip measures on this chip for the same instruction shape
+    (one instruction = up to 59 consecutive words of one particle's rows).  `frac_traffic` keeps the HBM view beside it: PMC bytes / time /
+    8 TB/s.  `algorithmic_words` = 59 per differentiated hit, what the reference issues as 59 separate atomics; same-slot merging (lanes of
+    a wave that meet the same particle leave as one instruction) is why fewer are issued."""
     if not work or "backward_render" not in stages:
         return None
     hits = work["processed_hits"]
-    byts = hits * (240 + 48 + 236 + 4) + P * 64
     ms = stages["backward_render"]
-    achieved = byts / (ms * 1e-3) / 1e9
     traffic = None
     try:
         traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("c3_grt_1m_800", {}).get("replay_bwd")
     except Exception:
         pass
-    return {"bound": "hbm", "kernel": "grt_replay_bwd", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "algorithmic_bytes": byts, "kernel_ms": ms, "atomic_words": hits * 59, "atomic_words_per_s": hits * 59 / (ms * 1e-3),
-            "note": "bound by float atomics (59 words per differentiated hit), see DESIGN.md §5"}
+    words = int(atomics["words"]) if atomics and atomics.get("words") else hits * 59
+    cal = atomic_calibration()
+    achieved = words / (ms * 1e-3)
+    r = {"bound": "l2_atomic", "kernel": "grt_replay_bwd", "achieved": achieved, "peak": cal["rows59_words_per_s"] if cal else None, "unit": "float words/s",
+         "frac": achieved / cal["rows59_words_per_s"] if cal else None, "calibration": cal, "kernel_ms": ms,
+         "atomic_words_issued": words, "atomic_instructions_issued": int(atomics["instructions"]) if atomics else None,
+         "algorithmic_words": hits * 59, "traffic": traffic,
+         "frac_traffic": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+         "note": "bound by the L2 atomic units: words/s against the calibrated rate of the same instruction shape (scripts/atomic_calib.hip); "
+                 "kernel_ms is the whole backward stage (replay + the re-derivation launch on the side stream)"}
+    return r
 
 
 def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
@@ -210,7 +232,8 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
         del os.environ["GRUT_GRT_COUNT"]
         st = tracer.tracer_wrapper.stats()
         work = {"wave_node_visits": int(st.nodes_visited), "leaf_tests": int(st.candidates), "processed_hits": int(st.processed_hits),
-                "list_entries": int(st.list_entries), "packet_tests": int(st.packet_tests), "list_batches": int(st.list_batches)}
+                "list_entries": int(st.list_entries), "packet_tests": int(st.packet_tests), "list_batches": int(st.list_batches),
+                "bwd_atomic_instructions": int(st.bwd_atomic_instructions), "bwd_atomic_words": int(st.bwd_atomic_words)}
         step()  # back to the uninstrumented kernels before timing
         tracer.timings
         torch.cuda.synchronize()
@@ -239,7 +262,7 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"3DGRT BVH build + fwd + bwd, {n} Gaussians (cloud B trained-like, seed 42), {W}x{H}, one view per GPU, "
                                    f"SH degree 3, k = 16 hits per trace", "name": name, "parallelism": f"view-dp{world}"},
-            "roofline": grt_roofline(work, P, stages), "roofline_backward": grt_backward_roofline(work, P, stages), "stages_ms": stages, "work": work}
+            "roofline": grt_roofline(work, P, stages), "roofline_backward": grt_backward_roofline(work, P, stages, {"words": work.get("bwd_atomic_words"), "instructions": work.get("bwd_atomic_instructions")} if work else None), "stages_ms": stages, "work": work}
         if emit:
             print(json.dumps(result), flush=True)
     if world > 1 and emit:
@@ -363,6 +386,26 @@ def bench_nht(args, dev, n, W, H, ms, emit=True):
     if emit:
         print(json.dumps(result), flush=True)
     return result
+
+
+XGMI_LINK_GBS = 153.0        # per link and direction (MI355X_MICROARCH.md); 7 links per GPU, point to point
+RING_LINK_EFFICIENCY = 0.65   # assumed share of a link a RCCL ring sustains (no measurement on this pool yet: the driver's SCALE run is the first)
+
+
+def predicted_exchange(kind, world, n, touched_rows=None):
+    """What the exchange step should cost on xGMI: a ring collective is bound by ONE link, so time = bytes a rank forwards / (link rate x
+    assumed efficiency).  Printed next to the measured device time so that the first RCCL run can be read against a number."""
+    w = max(world, 1)
+    rows = n if touched_rows is None else int(touched_rows)
+    if kind == "allreduce":                       # five tensors, [N,59] floats
+        ring = 2.0 * (w - 1) / w * 236.0 * n
+    elif kind == "sharded":                       # reduce-scatter [N,12] + all-to-all factors + all-gather [S,60]
+        ring = (w - 1) / w * (48.0 + 12.0 + 240.0) * n
+    else:                                         # factored / visible: all-reduce [rows,12] + all-gather of [rows+1,3] from every other rank
+        ring = 2.0 * (w - 1) / w * 48.0 * rows + (w - 1) * 12.0 * (rows + 1) + (n if kind == "visible" else 0)
+    rate = XGMI_LINK_GBS * RING_LINK_EFFICIENCY
+    return {"ring_bytes_per_rank": int(ring), "assumed_link_GBps": rate, "ms": ring / rate / 1e6,
+            "model": "bytes a rank forwards over its ring link / (153 GB/s x 0.65)"}
 
 
 def self_launch(n):
@@ -520,7 +563,8 @@ def main():
         per_rank[rank] = ms if ms is not None else -1.0
         dist.all_reduce(per_rank)   # (a gather written as a sum: works on every backend)
         exchange = {"kind": exchange_kind, "ms_per_step_per_rank": [float(x) for x in per_rank.tolist()], "payload_bytes_per_rank": int(payload),
-                    "note": "device time between issuing the collectives and their completion on the compute stream (RCCL over xGMI)"}
+                    "note": "device time between issuing the collectives and their completion on the compute stream (RCCL over xGMI)",
+                    "predicted": predicted_exchange(exchange_kind, world, n, getattr(tracer.gradient_exchange, "last_rows", None))}
     if rank == 0:
         P = W * H
         # every stage from the all-stage pass; the dominant kernel from the timed region itself

@@ -333,8 +333,10 @@ typedef struct GrtStats {
     uint64_t list_entries;      /* last forward: entries of the packet lists (0: the tree walk served the frame — rays with different origins) */
     uint64_t packet_tests;      /* only in instrumented launches: candidate tests of whole packets (list entries / leaves tested by a wave) */
     uint64_t list_batches;      /* only in instrumented launches: 64-entry batches of packet lists fetched by the trace rounds (one 64-byte record per entry) */
-    uint32_t bwd_rederived_rays;   /* last logged forward: rays whose backward rounds are re-derived instead of replayed (a round met more ghosts than a log chunk holds) */
+    uint32_t bwd_rederived_rays;   /* last replayed backward: rays whose rounds were re-derived instead of replayed (a round met more ghosts than a log chunk holds) */
     uint32_t bwd_premise_rays;     /* last replayed backward: rays for which the ghost filter's premise failed (DESIGN.md "3DGRT backward"; expected 0) */
+    uint64_t bwd_atomic_instructions; /* last replayed backward: atomic-add instructions issued (one per differentiated hit or same-slot group of hits) */
+    uint64_t bwd_atomic_words;     /* ... and the non-zero float words they carried (to 16): what scripts/atomic_calib.hip's rate prices */
 } GrtStats;
 
 typedef struct GrtHandle GrtHandle;

@@ -51,6 +51,32 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["factored", "visible", "allreduce"])
+def test_bench_multi_rank_line_over_gloo_on_one_gpu(exchange):
+    """The multi-rank bench path end to end as the driver starts it (`python bench.py --gpus 2` launches its own ranks), with gloo standing
+    in for RCCL on the one-GPU test box (GRUT_BENCH_BACKEND=gloo: both ranks share device 0): the JSON line must carry n_gpus = 2, the
+    exchange block with a measured and a predicted time per rank, and the roofline block - so that the first real RCCL run only swaps the
+    transport under a path that has already run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GRUT_BENCH_BACKEND="gloo", GRUT_BENCH_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c1_100k_400",
+                        "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["config"]["parallelism"].startswith("view-dp2")
+    ex = line["exchange"]
+    assert ex["kind"] == exchange and len(ex["ms_per_step_per_rank"]) == 2 and all(m > 0 for m in ex["ms_per_step_per_rank"])
+    assert ex["payload_bytes_per_rank"] > 0 and ex["predicted"]["ms"] > 0 and ex["predicted"]["ring_bytes_per_rank"] > 0
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    # two ranks render two views: the whole-job rate counts both
+    assert abs(line["value"] - 2 * 400 * 400 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+
+
 def test_factored_exchange_world2_on_one_gpu():
     world = 2
     mgr = mp.Manager()
