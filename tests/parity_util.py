@@ -36,16 +36,22 @@ camera = importlib.import_module("3dgrut_amd.camera")
 GRAD_SLICES = {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}
 
 
-def make_frame_inputs(n, w, h, median_scale, seed=42, view=0, n_views=8):
+def make_frame_inputs(n, w, h, median_scale, seed=42, view=0, n_views=8, camera_model="pinhole"):
     d12, sph = syn.cloud_trained_like(n, seed=seed, median_scale=median_scale)
-    K = syn.pinhole_intrinsics(w, h)
-    ro, rd = syn.pinhole_rays(w, h, K)
-    batch = dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(view, n_views=n_views)[None], intrinsics=K)
+    if camera_model == "fisheye":   # OpenCV fisheye with distortion driving the binning, the exact equidistant ray field for the compositing
+        Kf = syn.fisheye_intrinsics(w, h, fov_deg=120.0)
+        ro, rd = syn.fisheye_rays(w, h, Kf)
+        Kf = dict(Kf, radial_coeffs=np.array([0.02, -0.01, 0.003, 0.0], np.float32))
+        batch = dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(view, n_views=n_views)[None], intrinsics_OpenCVFisheyeCameraModelParameters=Kf)
+    else:
+        K = syn.pinhole_intrinsics(w, h)
+        ro, rd = syn.pinhole_rays(w, h, K)
+        batch = dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(view, n_views=n_views)[None], intrinsics=K)
     cam, ps, pe = camera.camera_from_batch(batch)
     return dict(d12=d12, sph=sph, batch=batch, cam=cam, ps=ps, pe=pe, rays=(ro, rd), W=w, H=h, N=n)
 
 
-def hip_forward(inp, tracer=None, device_pose=False):
+def hip_forward(inp, tracer=None, device_pose=False, render=None):
     """One train-mode forward through the plugin; returns images as numpy plus the binning products of that forward.
 
     device_pose=False: the camera-to-world matrix is handed over as a HOST tensor and the plugin derives the sensor pose exactly as the
@@ -55,7 +61,10 @@ def hip_forward(inp, tracer=None, device_pose=False):
     bits, so both parametrisations meet the same integer-exact stage A."""
     import torch
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
-    tracer = tracer or gt.Tracer({"render": {"enable_hitcounts": True, "splat": {}}})
+    if tracer is None:
+        render = dict(render or {})
+        conf = {"render": dict({k: v for k, v in render.items() if k != "splat"}, enable_hitcounts=True, splat=dict(render.get("splat", {})))}
+        tracer = gt.Tracer(conf)
     g = syn.SimpleGaussians(inp["d12"], inp["sph"])
     batch = torch_batch(inp["batch"], "cuda")
     if not device_pose:
@@ -134,56 +143,67 @@ def pixel_errors(fd, dist, ref_fd, ref_dist):
     return d_img, d_dist
 
 
-def _rounding_bound(alpha32, alpha64, hit_t, accept, min_T, end_shift, c_max, t_max):
-    """First-order bound of what the fp32 rounding of the per-hit alphas can move a pixel by: with S = sum_k |alpha32_k - alpha64_k| T_k
-    over the composited hits (T_k the transmittance in front of hit k), |d opacity| <= S, |d rgb| <= 2 c_max S, |d depth| <= 2 t_max S
-    (d out / d alpha_k = T_k (x_k - mean of what lies behind), |x| <= x_max).  alpha = response * density with response =
-    exp(-|v x u|^2 / |v|^2 ...) of canonical-frame vectors of length 1e2..1e3: its fp32 evaluation carries up to ~1e-3 relative noise
-    for small distant particles in ANY evaluation order — the reference's CUDA, the float oracle and the HIP kernels each draw their
-    own sample of it, the double oracle shows how large it is for the pixel at hand."""
-    T, S = 1.0, 0.0
-    skip = end_shift > 0
-    for i in np.flatnonzero(accept & (alpha64 > 0)):
-        a = float(alpha64[i])
-        S += abs(float(alpha32[i]) - a) * T
-        T *= 1.0 - a
-        if T < min_T:
-            if skip and T > (1.0 - 1e-3) * min_T:
-                skip = False
-                continue
-            break
-        if end_shift < 0 and T < (1.0 + 1e-3) * min_T:
-            break
-    return 2.0 * c_max * S, S, 2.0 * t_max * S
+def _composite(alpha, hit_t, colour, accept, min_T, end_shift=0, K=0, alpha_ref=None):
+    """The compositing loop (gutKBufferRenderer.cuh:273-352) over one pixel's traced entries with the given accept decisions: K = 0
+    composites in list order; K > 0 keeps the K nearest pending hits by hit distance and composites the nearest when the buffer is full
+    (HitParticleKBufferT, :62-122), draining what is left at the end of the list.  end_shift toggles the OTHER discontinuity, the end of
+    the ray at T < min_transmittance, when the transmittance is within 1e-3 (relative) of the threshold there - T is a product of ~100
+    fp32 factors: +1 = the first trigger is ignored (one more hit is composited), -1 = the ray ends at the first hit that leaves T that
+    close above the threshold.
 
-
-def _composite(alpha, hit_t, colour, accept, min_T, end_shift=0):
-    """The K = 0 compositing loop (gutKBufferRenderer.cuh:273-352) over one pixel's traced entries with the given accept decisions.
-    end_shift toggles the OTHER discontinuity, the end of the ray at T < min_transmittance, when the transmittance is within
-    1e-3 (relative) of the threshold there — T is a product of ~100 fp32 factors: +1 = the first trigger is ignored (one more hit is
-    composited), -1 = the ray ends at the first hit that leaves T that close above the threshold."""
-    T, D, cnt = 1.0, 0.0, 0
+    alpha_ref (the float64 alphas of the same entries): also returns S = sum_k |alpha_k - alpha_ref_k| T_k over the composited hits, the
+    first-order bound of what the fp32 rounding of the per-hit alphas can move the pixel by (|d opacity| <= S, |d rgb| <= 2 c_max S,
+    |d depth| <= 2 t_max S: d out / d alpha_k = T_k (x_k - mean of what lies behind)).  alpha = response * density with response =
+    exp(-|v x u|^2 / |v|^2 ...) of canonical-frame vectors of length 1e2..1e3: its fp32 evaluation carries up to ~1e-3 relative noise for
+    small distant particles in ANY evaluation order - the reference's CUDA, the float oracle and the HIP kernels each draw their own
+    sample of it, the double oracle shows how large it is for the pixel at hand."""
+    state = dict(T=1.0, D=0.0, cnt=0, S=0.0, alive=True, skip=end_shift > 0)
     C = np.zeros(3)
-    skip = end_shift > 0
-    for i in np.flatnonzero(accept & (alpha > 0)):
+
+    def integrate(i):
         a = float(alpha[i])
-        w = a * T
-        D += float(hit_t[i]) * w
-        T *= 1.0 - a
+        w = a * state["T"]
+        if alpha_ref is not None:
+            state["S"] += abs(a - float(alpha_ref[i])) * state["T"]
+        state["D"] += float(hit_t[i]) * w
+        state["T"] *= 1.0 - a
         if w > 0:
-            C += w * colour[i]
-            cnt += 1
+            C[:] += w * colour[i]
+            state["cnt"] += 1
+        T = state["T"]
         if T < min_T:
-            if skip and T > (1.0 - 1e-3) * min_T:
-                skip = False
-                continue
-            break
-        if end_shift < 0 and T < (1.0 + 1e-3) * min_T:
-            break
-    return C, 1.0 - T, D, cnt
+            if state["skip"] and T > (1.0 - 1e-3) * min_T:
+                state["skip"] = False
+                return
+            state["alive"] = False
+        elif end_shift < 0 and T < (1.0 + 1e-3) * min_T:
+            state["alive"] = False
+
+    if K == 0:
+        for i in np.flatnonzero(accept & (alpha > 0)):
+            integrate(i)
+            if not state["alive"]:
+                break
+    else:
+        buf = []   # pending hits, ascending in hit distance (ties: the later one goes behind, like the reference's strict `>`)
+        for i in np.flatnonzero(accept & (alpha > 0)):
+            if len(buf) == K:
+                integrate(buf.pop(0))
+                if not state["alive"]:
+                    break
+            pos = len(buf)
+            while pos > 0 and not (hit_t[i] > hit_t[buf[pos - 1]]):
+                pos -= 1
+            buf.insert(pos, i)
+        if state["alive"]:
+            for i in buf:
+                integrate(i)
+                if not state["alive"]:
+                    break
+    return C, 1.0 - state["T"], state["D"], state["cnt"], state["S"]
 
 
-def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dist, margin=1e-3, tol=1e-4):
+def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dist, margin=1e-3, tol=1e-4, tol_half=None):
     """For each listed pixel (flat index), finds the smallest set of accept / reject decisions the oracle took within `margin`
     (relative) of their threshold that, taken the other way, reproduces the GPU's pixel: same hit count, colour, opacity AND hit
     distance within `tol` (absolute).  Decisions that close to a threshold are decided by rounding, so such a pixel is an IDENTIFIED
@@ -192,11 +212,12 @@ def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dis
 
     A pixel whose decisions all agree (or agree after the toggles) but whose VALUE is beyond `tol` of the float evaluation is a
     member of the ROUNDING class: it must then lie within `tol` + 3 x the propagated fp32 rounding of its own alphas
-    (_rounding_bound) of the DOUBLE evaluation of the same decisions.
+    (_composite's S) of the DOUBLE evaluation of the same decisions.
 
     Returns (toggles per pixel (-1: not reproducible), rounding-class flag per pixel, error / bound ratio per pixel)."""
     import itertools
     min_T = float(cfg.min_transmittance)
+    K = int(cfg.k_buffer_size)
     fd = hip_fd.reshape(-1, 4)
     cnt = hip_cnt.reshape(-1)
     dist = hip_dist.reshape(-1)
@@ -217,25 +238,58 @@ def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dis
         c_max = float(colour.max()) if colour.size else 1.0
         t_max = float(hit_t64.max()) if hit_t64.size else 1.0
 
-        def matches(acc, end_shift):
+        # sorted mode: the k-buffer orders hits by their fp32 hit distance - two hits whose distances agree to rounding (canonical-frame
+        # vectors of length 1e2..1e3: ~1e-5 relative between any two evaluation orders) may pop in either order, and with both alphas
+        # large the pixel moves by several per cent.  Such a pair is a borderline decision like an accept test at its threshold: the toggle
+        # exchanges the two distances.  (K = 0 composites in list order: no such decision exists there.)
+        ties = []
+        if K > 0:
+            live = np.flatnonzero(alpha > 0)
+            order = live[np.argsort(hit_t[live], kind="stable")]
+            for a_, b_ in zip(order[:-1], order[1:]):
+                if abs(hit_t[a_] - hit_t[b_]) <= 2e-5 * max(1.0, abs(hit_t[a_])):
+                    ties.append((int(a_), int(b_)))
+        toggles_all = [("acc", int(i)) for i in near] + [("swap",) + t for t in ties]
+
+        def matches(acc, end_shift, swaps=()):
             """0: no; 1: the float evaluation of these decisions is within tol; 2: the double evaluation is, up to the propagated rounding"""
-            C, opa, D, c = _composite(alpha, hit_t, colour, acc, min_T, end_shift)
-            if c == tcnt and np.abs(C - target[:3]).max() < tol and abs(opa - target[3]) < tol and abs(D - tdist) < tol:
+            ht, ht64 = hit_t, hit_t64
+            if swaps:
+                ht, ht64 = hit_t.copy(), hit_t64.copy()
+                for a_, b_ in swaps:
+                    ht[a_], ht[b_] = ht[b_], ht[a_]
+                    ht64[a_], ht64[b_] = ht64[b_], ht64[a_]
+            return _matches(acc, end_shift, ht, ht64)
+
+        def _matches(acc, end_shift, hit_t, hit_t64):
+            C, opa, D, c, _ = _composite(alpha, hit_t, colour, acc, min_T, end_shift, K)
+            # (feature_output_half: the image is the fp32 result rounded to half - half an ulp of the value on top of the tolerance)
+            t_rgb = tol + (0.0 if tol_half is None else float(tol_half(np.abs(C).max())))
+            t_opa = tol + (0.0 if tol_half is None else float(tol_half(abs(opa))))
+            if c == tcnt and np.abs(C - target[:3]).max() < t_rgb and abs(opa - target[3]) < t_opa and abs(D - tdist) < tol:
                 return 1, 0.0
-            C, opa, D, c = _composite(alpha64, hit_t64, colour, acc, min_T, end_shift)
+            C, opa, D, c, S = _composite(alpha64, hit_t64, colour, acc, min_T, end_shift, K, alpha_ref=alpha)
             if c != tcnt:
                 return 0, 0.0
-            b_rgb, b_opa, b_d = _rounding_bound(alpha, alpha64, hit_t64, acc, min_T, end_shift, c_max, t_max)
-            r = max(np.abs(C - target[:3]).max() / (tol + 3 * b_rgb), abs(opa - target[3]) / (tol + 3 * b_opa), abs(D - tdist) / (tol + 3 * b_d))
+            b_rgb, b_opa, b_d = 2.0 * c_max * S, S, 2.0 * t_max * S
+            r = max(np.abs(C - target[:3]).max() / (t_rgb + 3 * b_rgb), abs(opa - target[3]) / (t_opa + 3 * b_opa), abs(D - tdist) / (tol + 3 * b_d))
             return (2, float(r)) if r <= 1.0 else (0, float(r))
 
         found = -1
         for n_toggle in (0, 1, 2, 3):
-            for combo in itertools.combinations(near, n_toggle):
+            for combo in itertools.combinations(toggles_all, n_toggle):
                 acc = accept0.copy()
-                acc[list(combo)] = ~acc[list(combo)]
+                flip = [t[1] for t in combo if t[0] == "acc"]
+                acc[flip] = ~acc[flip]
+                swaps = [t[1:] for t in combo if t[0] == "swap"]
                 for extra, end_shift in ((0, 0), (1, 1), (1, -1)):
-                    how, r = matches(acc, end_shift)
+                    how, r = matches(acc, end_shift, swaps)
+                    if how == 2 and K > 0:
+                        # the double evaluation reproduces the pixel: is it its ORDER of the hits (ties of the fp32 distances resolved as the
+                        # float64 distances resolve them), with the fp32 values?  Then this is an order tie - a flip - not a rounding-class pixel
+                        C, opa, D, c, _ = _composite(alpha, hit_t64, colour, acc, min_T, end_shift, K)
+                        if c == tcnt and np.abs(C - target[:3]).max() < tol and abs(opa - target[3]) < tol and abs(D - tdist) < tol:
+                            how, extra = 1, extra + 1
                     if how:
                         found = n_toggle + extra
                         rounding[k] = how == 2
@@ -243,21 +297,36 @@ def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dis
                         break
                 if found >= 0:
                     break
-            if found >= 0 or len(near) < n_toggle + 1:
+            if found >= 0 or len(toggles_all) < n_toggle + 1:
                 break
         out[k] = found
     return out, rounding, ratio
 
 
-def gut_full_parity(n, w, h, median_scale, seed=42, view=0, log=None, with_backward=True, end_to_end=True, device_pose=False):
-    """Runs stages A-C (module docstring) and returns a flat dict of the measured statistics."""
+def _half_ulp(x):
+    """half an ulp of IEEE half at |x| (the rounding of FEATURE_OUTPUT_HALF)"""
+    return 0.5 * np.spacing(np.abs(np.asarray(x, np.float32)).astype(np.float16)).astype(np.float32)
+
+
+def gut_full_parity(n, w, h, median_scale, seed=42, view=0, log=None, with_backward=True, end_to_end=True, device_pose=False, variant=None):
+    """Runs stages A-C (module docstring) and returns a flat dict of the measured statistics.
+
+    variant (non-default configurations at the same size, same staged method): dict with any of
+      camera_model = "fisheye"            OpenCV fisheye with distortion (binning) + equidistant rays
+      render       = {...}                the plugin's conf.render keys (particle_kernel_degree, splat.k_buffer_size, particle_feature_half ...)
+      oracle_cfg   = {...}                the same switches as GutConfig fields of the oracle
+      half         = True                 fp16 feature I/O: the oracle reads the rounded coefficients and its image is rounded to half"""
     t_all = time.time()
-    inp = make_frame_inputs(n, w, h, median_scale, seed=seed, view=view)
-    cfg = oracle.default_gut_config()
-    hip = hip_forward(inp, device_pose=device_pose)
+    variant = variant or {}
+    half = bool(variant.get("half"))
+    inp = make_frame_inputs(n, w, h, median_scale, seed=seed, view=view, camera_model=variant.get("camera_model", "pinhole"))
+    cfg = oracle.default_gut_config(**variant.get("oracle_cfg", {}))
+    hip = hip_forward(inp, device_pose=device_pose, render=variant.get("render"))
+    if half:
+        inp = dict(inp, sph=oracle.round_to_half(inp["sph"]))
     t0 = time.time()
     proj = oracle.gut_project(cfg, inp["cam"], inp["ps"], inp["pe"], 3, inp["d12"], inp["sph"])
-    stats = dict(N=n, W=w, H=h, P=w * h, pose="device" if device_pose else "host")
+    stats = dict(N=n, W=w, H=h, P=w * h, pose="device" if device_pose else "host", variant={k: v for k, v in variant.items()})
     gx = (w + 15) // 16
     # ---- stage A -------------------------------------------------------------------------------------------------------
     own = oracle.gut_forward(cfg, inp["cam"], inp["ps"], inp["pe"], 3, inp["d12"], inp["sph"], *inp["rays"], proj=proj) if end_to_end else None
@@ -271,34 +340,43 @@ def gut_full_parity(n, w, h, median_scale, seed=42, view=0, log=None, with_backw
     proj_shared = dict(proj, rgb=hip["rgb"].astype(np.float32), tiles_count=hip["tiles_count"])
     shared = oracle.gut_forward(cfg, inp["cam"], inp["ps"], inp["pe"], 3, inp["d12"], inp["sph"], *inp["rays"], proj=proj_shared,
                                 lists=(hip["sorted_idx"], hip["tile_ranges"]))
+    if half:   # FEATURE_OUTPUT_HALF: the image is the fp32 image rounded once (rayPayload.cuh:176-186); the backward reads the rounded finals
+        unrounded = shared["feat_density"]
+        shared = dict(shared, feat_density=oracle.round_to_half(unrounded))
     d_img, d_dist = pixel_errors(hip["fd"], hip["dist"], shared["feat_density"], shared["hit_distance"])
     X = hip["cnt"] != shared["hit_count"][..., 0]                     # identified flips: the hit count differs on identical candidates
-    bad = (d_img > 1e-4) | (d_dist > 1e-4)
+    tol_img = 1e-4 + (_half_ulp(np.abs(shared["feat_density"]).max(-1)) * 2.0 if half else 0.0)   # (a value next to a rounding boundary lands one half-ulp step away)
+    bad = (d_img > tol_img) | (d_dist > 1e-4)
     # every pixel of X, and every pixel beyond tolerance, must be REPRODUCED by the oracle with at most three of its own borderline
     # decisions (within 1e-3 of a threshold) taken the other way: then it is known which particles flipped
     exempt = np.flatnonzero((X | bad).reshape(-1))
-    toggles, rounding, ratio = identify_flips(cfg, inp["cam"], shared, proj_shared["rgb"], exempt, hip["fd"], hip["cnt"], hip["dist"])
+    toggles, rounding, ratio = identify_flips(cfg, inp["cam"], shared, proj_shared["rgb"], exempt, hip["fd"], hip["cnt"], hip["dist"],
+                                              tol_half=(lambda v: 2.0 * _half_ulp(v)) if half else None)
     # the exempted pixels are of two classes: FLIPS (an identified accept / termination decision fell the other way) and ROUNDING (every
     # decision agrees, the value is beyond 1e-4 of the float oracle but within 1e-4 + 3 x the propagated fp32 alpha rounding of that
-    # very pixel of the double oracle, _rounding_bound)
+    # very pixel of the double oracle, _composite's S)
     d_img_f, d_dist_f = d_img.reshape(-1), d_dist.reshape(-1)
+    pure = rounding & (toggles == 0)   # value-only differences: every decision of the oracle stands (a pixel that needs a toggle AND the rounding
+    #                                    allowance is counted with the flips: its distance from the UNtoggled oracle frame is a flip's)
     stats.update(B_flip_pixels=int(X.sum()), B_flip_frac=float(X.mean()), B_bad_pixels=int(bad.sum()),
                  B_bad_outside_flips=int((bad & ~X).sum()), B_exempt_pixels=int(exempt.size), B_exempt_frac=float(exempt.size / X.size),
                  B_exempt_unidentified=int((toggles < 0).sum()), B_exempt_by_toggles={int(t): int((toggles == t).sum()) for t in np.unique(toggles)},
-                 B_rounding_class_pixels=int(rounding.sum()),
-                 B_rounding_class_max_rgb_err=float(d_img_f[exempt][rounding].max()) if rounding.any() else 0.0,
-                 B_rounding_class_max_dist_err=float(d_dist_f[exempt][rounding].max()) if rounding.any() else 0.0,
+                 B_rounding_class_pixels=int(pure.sum()), B_rounding_after_toggles=int((rounding & ~pure).sum()),
+                 B_rounding_class_max_rgb_err=float(d_img_f[exempt][pure].max()) if pure.any() else 0.0,
+                 B_rounding_class_max_dist_err=float(d_dist_f[exempt][pure].max()) if pure.any() else 0.0,
                  B_rounding_class_max_ratio_to_bound=float(ratio[rounding].max()) if rounding.any() else 0.0,
                  B_max_rgb_err_outside_flips=float(d_img[~X].max()), B_max_dist_err_outside_flips=float(d_dist[~X].max()),
                  B_max_rgb_err_in_flips=float(d_img[X].max()) if X.any() else 0.0,
                  B_hit_count_l1_in_flips=float(np.abs(hip["cnt"] - shared["hit_count"][..., 0])[X].mean()) if X.any() else 0.0)
     # ---- end to end: the oracle with its own binning ---------------------------------------------------------------------
     if own is not None:
+        if half:
+            own = dict(own, feat_density=oracle.round_to_half(own["feat_density"]))
         e_img, e_dist = pixel_errors(hip["fd"], hip["dist"], own["feat_density"], own["hit_distance"])
         ty, tx = np.meshgrid(np.arange(h) // 16, np.arange(w) // 16, indexing="ij")
         in_diff_tile = tile_differs[ty * gx + tx]
         Xe = hip["cnt"] != own["hit_count"][..., 0]
-        ebad = (e_img > 1e-4) | (e_dist > 1e-4)
+        ebad = (e_img > tol_img) | (e_dist > 1e-4)
         stats.update(E_bad_pixels=int(ebad.sum()), E_bad_frac=float(ebad.mean()), E_flip_pixels=int(Xe.sum()),
                      E_pixels_in_differing_tiles=int(in_diff_tile.sum()),
                      E_bad_unexplained=int((ebad & ~Xe & ~in_diff_tile).sum()),
@@ -332,6 +410,69 @@ def gut_full_parity(n, w, h, median_scale, seed=42, view=0, log=None, with_backw
     return stats
 
 
+def gut_full_parity_nht(n, w, h, median_scale, seed=42, view=0, log=None, device_pose=True):
+    """Neural harmonic features (the reference's default model: 48 = 4 x 12 floats, sincos) at BASELINE size, same stages: A the binning
+    as integers (it does not depend on the feature model); B the oracle's orc_gut_render_nht_fwd composites the GPU's lists - pixels whose
+    HIT COUNT differs are the flips (an accept / termination decision fell the other way; bounded at 0.2 %), every other pixel must agree
+    to 1e-4 up to the rounding class (value-only differences of the fp32 alphas, bounded in number and size like the SH frames'); C the
+    gradients w.r.t. particle rows and the feature buffer with the upstream gradient zeroed on the exempted pixels, 1e-3."""
+    import torch
+    t_all = time.time()
+    inp = make_frame_inputs(n, w, h, median_scale, seed=seed, view=view)
+    feats = np.random.default_rng(seed + 1).uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)   # configs/base_gs.yaml:97-99 init range
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    model = {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1}, "interpolation_type": "barycentric"}}
+    tracer = gt.Tracer({"render": {"enable_hitcounts": True, "splat": {}}, "model": model})
+    hip = hip_forward(dict(inp, sph=feats), tracer=tracer, device_pose=device_pose)
+    cfg = oracle.default_gut_config()
+    stats = dict(N=n, W=w, H=h, P=w * h, pose="device" if device_pose else "host", variant="nht")
+    proj = oracle.gut_project(cfg, inp["cam"], inp["ps"], inp["pe"], 3, inp["d12"], inp["sph"])
+    bins = oracle.gut_bin(cfg, w, h, proj)
+    proj_cmp = dict(proj, rgb=hip["rgb"])   # (no per-particle radiance in this mode: nothing to compare there)
+    a, _ = compare_binning(hip, proj_cmp, bins, (w + 15) // 16)
+    stats.update({f"A_{k}": v for k, v in a.items()})
+    shared = oracle.gut_forward_nht(cfg, inp["cam"], inp["ps"], inp["pe"], inp["d12"], feats, *inp["rays"], lists=(hip["sorted_idx"], hip["tile_ranges"]))
+    fd = hip["fd"]
+    d_img = np.abs(fd - shared["feat_density"]).max(-1)
+    d_dist = np.abs(hip["dist"] - shared["hit_distance"])[..., 0]
+    X = hip["cnt"] != shared["hit_count"][..., 0]
+    bad = (d_img > 1e-4) | (d_dist > 1e-4)
+    stats.update(B_flip_pixels=int(X.sum()), B_flip_frac=float(X.mean()), B_bad_pixels=int(bad.sum()), B_bad_outside_flips=int((bad & ~X).sum()),
+                 B_max_err_outside_flips=float(d_img[~X].max()), B_max_dist_err_outside_flips=float(d_dist[~X].max()),
+                 B_feature_abs_max=float(np.abs(shared["feat_density"][..., :24]).max()))
+    g_fd = np.random.default_rng(seed + 2).normal(size=(h, w, 25)).astype(np.float32)
+    g_fd[X | bad] = 0.0
+    g = hip["gaussians"]
+    g.zero_grad()
+    t = torch.as_tensor(g_fd, device="cuda")[None]
+    out = hip["out"]
+    torch.autograd.backward([out["pred_features"], out["pred_opacity"]], [t[..., :24].contiguous(), t[..., 24:].contiguous()])
+    torch.cuda.synchronize()
+    gd, gf = g.grads_packed()
+    rd, rf = oracle.gut_backward_nht(cfg, inp["cam"], inp["ps"], inp["pe"], inp["d12"], feats, *inp["rays"], shared, g_fd)
+    for k, sl in GRAD_SLICES.items():
+        stats[f"C_grad_{k}_rel_err"] = rel_err(gd[:, sl], rd[:, sl])
+    stats["C_grad_features_rel_err"] = rel_err(gf, rf)
+    stats["C_grad_nonzero_particles"] = int((np.abs(rd[:, :11]).max(1) > 0).sum())
+    stats["t_total_s"] = time.time() - t_all
+    if log:
+        for k, v in stats.items():
+            log(f"  {k:38s} {v}")
+    return stats
+
+
+def assert_gut_full_parity_nht(stats):
+    P, N, tiles = stats["P"], stats["N"], stats["A_tiles_total"]
+    assert stats["A_depth_bits_differ"] == 0 and stats["A_tiles_same_set_other_order"] == 0, stats
+    assert stats["A_particles_tile_count_differs"] <= max(2, 1e-4 * N) and stats["A_tiles_list_differs"] <= max(2, 2e-2 * tiles), stats
+    assert stats["B_flip_frac"] <= 2e-3, stats
+    assert stats["B_bad_outside_flips"] <= max(8, 2e-4 * P) and stats["B_max_err_outside_flips"] < 2e-2 and stats["B_max_dist_err_outside_flips"] < 5e-3, stats
+    assert stats["B_feature_abs_max"] > 0.3
+    for k in list(GRAD_SLICES) + ["features"]:
+        assert stats[f"C_grad_{k}_rel_err"] < 1e-3, (k, stats)
+    assert stats["C_grad_nonzero_particles"] > 1000
+
+
 def record_full_parity(name, stats):
     """Appends one configuration's measured statistics (exemption classes included) to gpurun_out/full_parity.json, which travels back
     from the GPU box; the round's copy is committed as profiles/rNN_full_parity.json."""
@@ -346,7 +487,7 @@ def record_full_parity(name, stats):
     json.dump(allstats, open(path, "w"), indent=1, default=str)
 
 
-def assert_gut_full_parity(stats, max_flip_frac=2e-3):
+def assert_gut_full_parity(stats, max_flip_frac=2e-3, max_rounding_frac=2e-4):
     """The bar of tests/test_full_size_gpu.py (BASELINE.json: RGB / depth 1e-4 abs, gradients 1e-3 relative)."""
     P, N, tiles = stats["P"], stats["N"], stats["A_tiles_total"]
     # A: binning — integer work
@@ -360,7 +501,7 @@ def assert_gut_full_parity(stats, max_flip_frac=2e-3):
     # B: compositing on identical candidates
     assert stats["B_exempt_frac"] <= max_flip_frac, stats
     assert stats["B_exempt_unidentified"] == 0, f"pixels beyond tolerance that no set of borderline decisions explains: {stats}"
-    assert stats["B_rounding_class_pixels"] <= max(8, 2e-4 * P), stats     # value-only differences: a few dozen pixels per frame
+    assert stats["B_rounding_class_pixels"] <= max(8, max_rounding_frac * P), stats     # value-only differences: a few dozen pixels per frame
     assert stats["B_rounding_class_max_rgb_err"] < 2e-2 and stats["B_rounding_class_max_dist_err"] < 5e-3, stats
     # end to end
     if "E_bad_unexplained" in stats:
