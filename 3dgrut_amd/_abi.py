@@ -143,7 +143,7 @@ class GutGradIO(C.Structure):
 
 # every symbol include/grut_amd.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
-    "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_backward_unpacked", "gut_backward_factored", "grut_sph_grad_from_views", "gut_timings", "gut_stats",
+    "gut_create", "gut_destroy", "gut_forward", "gut_backward", "gut_backward_unpacked", "gut_backward_factored", "gut_backward_factored_chunked", "grut_sph_grad_from_views", "gut_timings", "gut_stats",
     "gut_profile_enable", "gut_profile_select", "gut_profile_read",
     "gut_debug_fetch", "gut_debug_fetch_work", "grut_debug_pose_from_c2w", "grut_debug_frame_poses", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
@@ -156,6 +156,7 @@ EXPORTED_SYMBOLS = [
 _lib = None
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint64)   # GrutAllocFn / GrutFreeFn of include/grut_amd.h
 FREE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+CHUNK_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32)   # GrutChunkFn: (user, chunk, first particle, particles)
 
 
 def _declare(lib):
@@ -170,6 +171,8 @@ def _declare(lib):
     lib.gut_backward.restype = C.c_int
     lib.gut_backward_factored.argtypes = [C.c_void_p, vp, C.POINTER(GutFrame)] + [fp] * 10
     lib.gut_backward_factored.restype = C.c_int
+    lib.gut_backward_factored_chunked.argtypes = [C.c_void_p, vp, C.POINTER(GutFrame)] + [fp] * 10 + [C.c_uint32, CHUNK_FN, C.c_void_p]
+    lib.gut_backward_factored_chunked.restype = C.c_int
     lib.gut_backward_unpacked.argtypes = [C.c_void_p, vp, C.POINTER(GutFrame)] + [fp] * 7 + [C.POINTER(GutGradIO), fp]
     lib.gut_backward_unpacked.restype = C.c_int
     lib.grut_sph_grad_from_views.argtypes = [vp, C.c_uint32, C.c_uint32, fp, fp, C.c_uint32, C.c_int32, C.c_int32, C.c_float, fp]
@@ -333,16 +336,19 @@ def pack_particles(mog_pos, mog_dns, mog_rot, mog_scl):
     return out
 
 
-def sph_grad_from_views(view_factors, positions, n_active_features, sph_degree, scale=1.0):
+def sph_grad_from_views(view_factors, positions, n_active_features, sph_degree, scale=1.0, out=None):
     """Sum over views of the SH-coefficient gradients from the gathered view factors of gut_backward_factored:
-    view_factors [V, N+1, 3] (row N of each view = its sensor position), positions [N, 3] or packed [N, 12] rows."""
+    view_factors [V, N+1, 3] (row N of each view = its sensor position), positions [N, 3] or packed [N, 12] rows.
+    out: a contiguous [N, 3 (deg+1)^2] float32 block to write (a row range of a larger tensor: the pipelined exchange)."""
     import torch
     lib = load_library()
     view_factors = view_factors.contiguous()
     positions = positions.contiguous()
     v, n = int(view_factors.shape[0]), int(view_factors.shape[1]) - 1
     assert view_factors.shape[2] == 3 and positions.shape[0] == n and positions.shape[1] in (3, 12)
-    out = torch.empty((n, 3 * (sph_degree + 1) ** 2), dtype=torch.float32, device=view_factors.device)
+    if out is None:
+        out = torch.empty((n, 3 * (sph_degree + 1) ** 2), dtype=torch.float32, device=view_factors.device)
+    assert out.is_contiguous() and tuple(out.shape) == (n, 3 * (sph_degree + 1) ** 2) and out.dtype == torch.float32
     stream = C.c_void_p(torch.cuda.current_stream(view_factors.device).cuda_stream)
     check(lib.grut_sph_grad_from_views(stream, n, v, C.c_void_p(view_factors.data_ptr()), C.c_void_p(positions.data_ptr()), int(positions.shape[1]),
                                        int(n_active_features), int(sph_degree), float(scale), C.c_void_p(out.data_ptr())), "grut_sph_grad_from_views")

@@ -477,7 +477,8 @@ int gut_forward(GutHandle* h, void* stream_, const GutFrame* frame, const float*
 static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, const float* particle_density, const void* particle_sph_,
                          const float* ray_origin, const float* ray_direction, const void* feat_density_, const float* grad_feat_density,
                          const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_particle_sph,
-                         float* grad_radiance, const GutGradIO* io = nullptr) {
+                         float* grad_radiance, const GutGradIO* io = nullptr, uint32_t num_chunks = 1, GrutChunkFn on_chunk = nullptr,
+                         void* chunk_user = nullptr) {
     const float* particle_sph = reinterpret_cast<const float*>(particle_sph_);       // (fp32, or half with particle_feature_half)
     const float* feat_density = reinterpret_cast<const float*>(feat_density_);       // (fp32, or half with feature_output_half)
     GRUT_REQUIRE(h && frame, "gut_backward: null handle/frame");
@@ -608,8 +609,22 @@ static int backward_impl(GutHandle* h, void* stream_, const GutFrame* frame, con
     }
     GRUT_CHECK(h->stage_begin(GUT_STAGE_PROJECT_BWD, s, slot));
     GRUT_CHECK(h->g_rgb.ensure((size_t)P.N * 12, 1.25f));  // per-particle radiance gradient between gather and SH backward
-    launch_grad_finalize(s, P, proj, particle_density, particle_sph, slots, has_gdist, I > 0, h->g_rgb.as<float>(), g_out,
-                         grad_particle_sph, grad_radiance);
+    if (num_chunks <= 1 || !on_chunk) {
+        launch_grad_finalize(s, P, proj, particle_density, particle_sph, slots, has_gdist, I > 0, h->g_rgb.as<float>(), g_out,
+                             grad_particle_sph, grad_radiance);
+    } else {
+        // pipelined exchange: the finalisation runs chunk by chunk over the particle range (chunks start at multiples of 128: the
+        // projection backward's workgroup) and the caller is told after each chunk's launches - it issues that chunk's collectives, which
+        // then run under the next chunk's kernels
+        const uint32_t per = ((P.N + num_chunks - 1) / num_chunks + 127u) & ~127u;
+        uint32_t c = 0;
+        for (uint32_t first = 0; first < P.N; first += per, ++c) {
+            const uint32_t end = first + per < P.N ? first + per : P.N;
+            launch_grad_finalize(s, P, proj, particle_density, particle_sph, slots, has_gdist, I > 0, h->g_rgb.as<float>(), g_out,
+                                 grad_particle_sph, grad_radiance, first, end);
+            on_chunk(chunk_user, c, first, end - first);
+        }
+    }
     GRUT_CHECK(h->stage_end(GUT_STAGE_PROJECT_BWD, s, slot));
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->bwd_timer.end(s));
@@ -637,6 +652,16 @@ int gut_backward_factored(GutHandle* h, void* stream, const GutFrame* frame, con
     GRUT_REQUIRE(grad_radiance, "gut_backward_factored: null buffer");
     return backward_impl(h, stream, frame, particle_density, particle_sph, ray_origin, ray_direction, feat_density, grad_feat_density, hit_distance,
                          grad_hit_distance, grad_particle_density, nullptr, grad_radiance);
+}
+
+int gut_backward_factored_chunked(GutHandle* h, void* stream, const GutFrame* frame, const float* particle_density, const void* particle_sph,
+                                  const float* ray_origin, const float* ray_direction, const void* feat_density, const float* grad_feat_density,
+                                  const float* hit_distance, const float* grad_hit_distance, float* grad_particle_density, float* grad_radiance,
+                                  uint32_t num_chunks, GrutChunkFn on_chunk, void* user) {
+    GRUT_REQUIRE(grad_radiance && on_chunk && num_chunks >= 1, "gut_backward_factored_chunked: null buffer / callback");
+    GRUT_REQUIRE(!h || h->cfg.k_buffer_size == 0, "gut_backward_factored_chunked: the sorted mode finalises in one piece");
+    return backward_impl(h, stream, frame, particle_density, particle_sph, ray_origin, ray_direction, feat_density, grad_feat_density, hit_distance,
+                         grad_hit_distance, grad_particle_density, nullptr, grad_radiance, nullptr, num_chunks < 2 ? 2 : num_chunks, on_chunk, user);
 }
 
 int grut_sph_grad_from_views(void* stream, uint32_t num_particles, uint32_t num_views, const float* view_factors, const float* positions,

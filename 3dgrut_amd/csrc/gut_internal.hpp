@@ -147,10 +147,10 @@ void launch_render_k_bwd(hipStream_t s, const GutParams& P, const uint32_t* rang
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd,
                          const float* dist, const float* g_dist, float* g_density12, float* g_rgb);
 void launch_project_bwd(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
-                        const float* g_rgb, const GutGradOut& g_out, float* g_sph, float* g_radiance);
+                        const float* g_rgb, const GutGradOut& g_out, float* g_sph, float* g_radiance, uint32_t first = 0u, uint32_t end = 0xFFFFFFFFu);
 void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
                           const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, const GutGradOut& g_out, float* g_sph,
-                          float* g_radiance);
+                          float* g_radiance, uint32_t first = 0u, uint32_t end = 0xFFFFFFFFu);
 void launch_sph_grad_from_views(hipStream_t s, uint32_t N, uint32_t n_views, const float* factors, const float* positions, uint32_t pos_stride,
                                 int n_active, int ncoef, float scale, float* g_sph);
 

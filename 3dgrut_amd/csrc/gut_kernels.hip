@@ -703,10 +703,11 @@ __device__ __forceinline__ float xor_sum_quads(float v) {  // sum over the 16 qu
 template <int STRIDE, bool NHT = false>
 __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutProjected proj, const float4* __restrict__ density12,
                                                               GutGradSlots slots, int have_partials, GutGradOut g_out,
-                                                              float* __restrict__ g_rgb) {
+                                                              float* __restrict__ g_rgb, uint32_t first, uint32_t end) {
+    // particles [first, end): the whole scene, or one chunk of the pipelined gradient exchange (gut_backward_factored_chunked)
     const int lane = threadIdx.x & 63, c = threadIdx.x & 3;
-    const uint32_t i = blockIdx.x * 64u + (threadIdx.x >> 2);
-    const uint32_t count = (i < P.N) ? proj.tiles_count[i] : 0u;
+    const uint32_t i = first + blockIdx.x * 64u + (threadIdx.x >> 2);
+    const uint32_t count = (i < end) ? proj.tiles_count[i] : 0u;
     const bool has = count != 0;
     QuadAcc<STRIDE> acc;
     acc.clear();
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     r[8] = quad_bcast<2>(acc.a.x); r[9] = quad_bcast<2>(acc.a.y); r[10] = quad_bcast<2>(acc.a.z); r[11] = quad_bcast<2>(acc.a.w);
     r[12] = quad_bcast<3>(acc.a.x); r[13] = quad_bcast<3>(acc.a.y); r[14] = quad_bcast<3>(acc.a.z); r[15] = quad_bcast<3>(acc.a.w);
     r[16] = quad_bcast<0>(acc.x.x); r[17] = quad_bcast<0>(acc.x.y); r[18] = quad_bcast<0>(acc.x.z); r[19] = 0.f;
-    if (i >= P.N) return;
+    if (i >= end) return;
     float4* gd = reinterpret_cast<float4*>(g_out.packed + 12 * (size_t)i);
     if (!has) {
         if (g_out.packed) {
@@ -844,18 +845,18 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
                                                               const float4* __restrict__ density12, const float* __restrict__ sph,
                                                               const float* __restrict__ rgb, const float* __restrict__ g_rgb,
                                                               GutGradOut g_out, float* __restrict__ g_sph,
-                                                              float* __restrict__ g_radiance) {
+                                                              float* __restrict__ g_radiance, uint32_t first, uint32_t end) {
     __shared__ float s_rows[2][64 * kShStride];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t wave_base = blockIdx.x * 128u + (uint32_t)wave * 64u;
+    const uint32_t wave_base = first + blockIdx.x * 128u + (uint32_t)wave * 64u;   // particles [first, end), first a multiple of 128
     const uint32_t i = wave_base + lane;
     const int rowlen = 3 * P.ncoef;
     const int nact = min((P.n_active + 1) * (P.n_active + 1), P.ncoef);
     float* rows = s_rows[wave];
     const FramePoses& FP = frame_poses(P);
-    const bool has = (i < P.N) && (tiles_count[i] != 0);
+    const bool has = (i < end) && (tiles_count[i] != 0);
     const unsigned long long has_mask = __ballot(has);
-    const int nrows = (int)min(64u, P.N > wave_base ? P.N - wave_base : 0u);
+    const int nrows = (int)min(64u, end > wave_base ? end - wave_base : 0u);
     // stage in.  48-float rows: the wave's rows are one contiguous, 16-byte aligned block, copied as independent float4
     // requests (12 per lane in flight); rows of particles without tiles ride along.  Other row lengths: one row per step.
     if (P.sph_half) {
@@ -923,11 +924,11 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
         if (FACTORED) { g_radiance[3 * (size_t)i] = g.x; g_radiance[3 * (size_t)i + 1] = g.y; g_radiance[3 * (size_t)i + 2] = g.z; }
     } else if (!FACTORED) {
         for (int k = 0; k < rowlen; ++k) myrow[k] = 0.f;
-    } else if (i < P.N) {
+    } else if (i < end) {
         g_radiance[3 * (size_t)i] = 0.f; g_radiance[3 * (size_t)i + 1] = 0.f; g_radiance[3 * (size_t)i + 2] = 0.f;
     }
     if (FACTORED) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {   // the view's sensor position rides along as row N
+        if (first == 0u && blockIdx.x == 0 && threadIdx.x == 0) {   // the view's sensor position rides along as row N
             g_radiance[3 * (size_t)P.N] = FP.s2w_t[0]; g_radiance[3 * (size_t)P.N + 1] = FP.s2w_t[1]; g_radiance[3 * (size_t)P.N + 2] = FP.s2w_t[2];
         }
         return;
@@ -1069,13 +1070,15 @@ void launch_tile_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev, uint32
 
 // exactly one of g_sph (expanded SH gradient) and g_radiance (view factor, see gut_project_bwd_kernel<true>) is non-null
 void launch_project_bwd(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
-                        const float* g_rgb, const GutGradOut& g_out, float* g_sph, float* g_radiance) {
+                        const float* g_rgb, const GutGradOut& g_out, float* g_sph, float* g_radiance, uint32_t first, uint32_t end) {
+    if (end > P.N) end = P.N;
+    if (end <= first) return;
     if (g_radiance)
-        hipLaunchKernelGGL(gut_project_bwd_kernel<true>, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
-                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_out, g_sph, g_radiance);
+        hipLaunchKernelGGL(gut_project_bwd_kernel<true>, dim3(div_up(end - first, 128)), dim3(128), 0, s, P, proj.tiles_count,
+                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_out, g_sph, g_radiance, first, end);
     else
-        hipLaunchKernelGGL(gut_project_bwd_kernel<false>, dim3(div_up(P.N, 128)), dim3(128), 0, s, P, proj.tiles_count,
-                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_out, g_sph, g_radiance);
+        hipLaunchKernelGGL(gut_project_bwd_kernel<false>, dim3(div_up(end - first, 128)), dim3(128), 0, s, P, proj.tiles_count,
+                           reinterpret_cast<const float4*>(density12), sph, proj.rgb, g_rgb, g_out, g_sph, g_radiance, first, end);
 }
 void launch_sph_grad_from_views(hipStream_t s, uint32_t N, uint32_t n_views, const float* factors, const float* positions, uint32_t pos_stride,
                                 int n_active, int ncoef, float scale, float* g_sph) {
@@ -1086,19 +1089,22 @@ void launch_sph_grad_from_views(hipStream_t s, uint32_t N, uint32_t n_views, con
 void launch_grad_finalize_nht(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const GutGradSlots& slots,
                               bool have_partials, const GutGradOut& g_out) {
     hipLaunchKernelGGL((gut_grad_gather_kernel<16, true>), dim3(div_up(P.N, 64)), dim3(256), 0, s, P, proj, reinterpret_cast<const float4*>(density12),
-                       slots, have_partials ? 1 : 0, g_out, static_cast<float*>(nullptr));
+                       slots, have_partials ? 1 : 0, g_out, static_cast<float*>(nullptr), 0u, P.N);
 }
 void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected& proj, const float* density12, const float* sph,
                           const GutGradSlots& slots, bool has_gdist, bool have_partials, float* g_rgb, const GutGradOut& g_out, float* g_sph,
-                          float* g_radiance) {
-    const dim3 grid(div_up(P.N, 64)), block(256);  // four lanes per particle
+                          float* g_radiance, uint32_t first, uint32_t end) {
+    // particles [first, end) (first a multiple of 128): everything, or one chunk of the pipelined exchange
+    if (end > P.N) end = P.N;
+    if (end <= first) return;
+    const dim3 grid(div_up(end - first, 64)), block(256);  // four lanes per particle
     if (has_gdist)
         hipLaunchKernelGGL(gut_grad_gather_kernel<20>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
-                           have_partials ? 1 : 0, g_out, g_rgb);
+                           have_partials ? 1 : 0, g_out, g_rgb, first, end);
     else
         hipLaunchKernelGGL(gut_grad_gather_kernel<16>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
-                           have_partials ? 1 : 0, g_out, g_rgb);
-    launch_project_bwd(s, P, proj, density12, sph, g_rgb, g_out, g_sph, g_radiance);
+                           have_partials ? 1 : 0, g_out, g_rgb, first, end);
+    launch_project_bwd(s, P, proj, density12, sph, g_rgb, g_out, g_sph, g_radiance, first, end);
 }
 
 }  // namespace grut

@@ -98,9 +98,12 @@ class FactoredGradientExchange:
     At 8 ranks a ring moves 2*(7/8)*236 = 413 B per particle for the plain all-reduce, 2*(7/8)*48 + (7/8)*8*12 = 168 B this
     way.  Views are added in rank order on every rank, so replicas stay bitwise identical, like after an all-reduce."""
 
-    def __init__(self, average: bool = True, group=None, local_gradient_hook=None, timed: bool = False):
+    def __init__(self, average: bool = True, group=None, local_gradient_hook=None, timed: bool = False, chunks: int = 1):
         self.average = average  # mean over views, like GradientExchange and the module docstring (keeps the single-view loss scale)
         self.group = group
+        # > 1: the plugin finalises its gradients in this many particle ranges and the collectives of range i are issued under the
+        # kernels of range i + 1 (reduce_packed_pipelined); 1: one exchange after the whole backward (reduce_packed)
+        self.chunks = int(chunks)
         self.timer = _ExchangeTimer() if timed else None
         # called with this view's packed gradient [N,12] (columns 0..2 = dL/d position) BEFORE it is reduced: the place to take
         # the densification statistics, which must come from the local view (local_densify_stats)
@@ -126,6 +129,76 @@ class FactoredGradientExchange:
         if self.timer:
             self.timer.end(payload)
         return g_density, _abi.sph_grad_from_views(factors, positions, n_active_features, sph_degree, scale)
+
+    # ---- pipelined form -----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def begin_chunk(self, g_density_rows, g_radiance_rows):
+        """Issues the two collectives of one particle range WITHOUT waiting: all-reduce of the packed rows in place, gather of the view
+        factors of the rows.  Returns the handle finish_chunk takes.  (RCCL: asynchronous on its own stream, ordered after what the
+        compute stream holds at this point - the range's finalisation kernels; gloo: the calls complete before they return.)"""
+        world = self._world()
+        nccl = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
+        w_geo = dist.all_reduce(g_density_rows, op=op, group=self.group, async_op=True)
+        rows = g_radiance_rows.contiguous()
+        gathered = torch.empty((world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
+        if nccl:
+            w_fac = dist.all_gather_into_tensor(gathered, rows, group=self.group, async_op=True)
+        else:
+            gathered.zero_()
+            gathered[dist.get_rank(self.group)].copy_(rows)
+            w_fac = dist.all_reduce(gathered, group=self.group, async_op=True)
+        return (g_density_rows, gathered, w_geo, w_fac, nccl)
+
+    @torch.no_grad()
+    def finish_chunk(self, handle):
+        """-> the gathered view factors [world, rows, 3] of the range; its packed rows are reduced in place."""
+        g_rows, gathered, w_geo, w_fac, nccl = handle
+        w_geo.wait()
+        w_fac.wait()
+        if self.average and not nccl:
+            g_rows.div_(float(self._world()))
+        return gathered
+
+    @torch.no_grad()
+    def reduce_packed_pipelined(self, run_chunked_backward, positions, n_active_features, sph_degree):
+        """run_chunked_backward(num_chunks, on_chunk) -> (g_density [N,12], g_radiance [N+1,3]) runs the plugin's chunked backward
+        (gut_backward_factored_chunked), calling on_chunk(chunk, first, count, g_density, g_radiance) after each particle range.
+        Range i's collectives are issued inside that call-back, i.e. before range i + 1's kernels are even launched, and are waited
+        for only after the last range: on RCCL they overlap the remaining finalisation; the SH rebuild then proceeds range by range,
+        each as soon as ITS factors have arrived.  Same values as reduce_packed, row for row (an all-reduce adds element-wise; views are
+        added in rank order)."""
+        from . import _abi
+        world = self._world()
+        scale = 1.0 / world if self.average else 1.0
+        pending = []
+        payload = [0]
+
+        def on_chunk(chunk, first, count, g_density, g_radiance):
+            rows_d, rows_r = g_density[first:first + count], g_radiance[first:first + count]
+            if self.local_gradient_hook is not None:
+                self.local_gradient_hook(rows_d, first)   # (rows of the range, index of its first particle)
+            if world > 1:
+                if self.timer and not pending:
+                    self.timer.begin(g_density.device)
+                pending.append((first, count, self.begin_chunk(rows_d, rows_r)))
+                payload[0] += rows_d.numel() * 4 + rows_r.numel() * 4
+
+        g_density, g_radiance = run_chunked_backward(self.chunks, on_chunk)
+        n = g_density.shape[0]
+        g_sph = torch.empty((n, 3 * (sph_degree + 1) ** 2), dtype=torch.float32, device=g_density.device)
+        if world == 1:
+            _abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active_features, sph_degree, 1.0, out=g_sph)
+            return g_density, g_sph
+        nccl = dist.get_backend(self.group) == "nccl"
+        sensors = _all_gather_rows(g_radiance[n].contiguous(), self.group, nccl)     # [world, 3]: every view's sensor position
+        for first, count, handle in pending:
+            gathered = self.finish_chunk(handle)
+            factors = torch.cat([gathered, sensors[:, None, :]], dim=1)            # [world, count + 1, 3]
+            _abi.sph_grad_from_views(factors, positions[first:first + count], n_active_features, sph_degree, scale, out=g_sph[first:first + count])
+        if self.timer:
+            self.timer.end(payload[0])
+        return g_density, g_sph
 
     @torch.no_grad()
     def reduce_dense(self, g_density, *others):

@@ -262,6 +262,29 @@ class _GutNative:
                                                   _ptr(g_density), _ptr(g_radiance)), "gut_backward_factored")
         return g_density, g_radiance
 
+    def trace_bwd_factored_chunked(self, frame, particle_density, particle_sph, ray_ori, ray_dir, fd, g_fd, dist, g_dist, num_chunks, on_chunk):
+        """gut_backward_factored_chunked: as trace_bwd_factored, but the finalisation runs in `num_chunks` particle ranges and
+        on_chunk(chunk, first, count, g_density, g_radiance) is called after each range's kernels are enqueued (rows [first, first + count)
+        of both tensors are complete in stream order)."""
+        dev = ray_ori.device
+        g_density = torch.empty_like(particle_density)
+        g_radiance = torch.empty((particle_density.shape[0] + 1, 3), dtype=torch.float32, device=dev)
+        errors = []
+
+        def _cb(_user, chunk, first, count):
+            try:
+                on_chunk(int(chunk), int(first), int(count), g_density, g_radiance)
+            except BaseException as e:   # an exception must not unwind through the C frames
+                errors.append(e)
+        cb = _abi.CHUNK_FN(_cb)
+        rc = self.lib.gut_backward_factored_chunked(self.handle, _stream_ptr(dev), C.byref(frame), _ptr(particle_density), _ptr(particle_sph),
+                                                    _ptr(ray_ori), _ptr(ray_dir), _ptr(fd), _ptr(g_fd), _ptr(dist), _ptr(g_dist),
+                                                    _ptr(g_density), _ptr(g_radiance), int(num_chunks), cb, None)
+        if errors:
+            raise errors[0]
+        _abi.check(rc, "gut_backward_factored_chunked")
+        return g_density, g_radiance
+
     def collect_times(self):
         if not self.cfg.enable_kernel_timings:
             return {}
@@ -373,10 +396,17 @@ class Tracer:
             else:
                 # view-sharded data parallelism (3dgrut_amd/dp.py): the packed gradient is all-reduced and the SH gradient is
                 # rebuilt from the gathered per-view factors, before anything is unpacked
-                g_density, g_radiance = ctx.native.trace_bwd_factored(ctx.frame, particle_density, particle_features, ray_ori, ray_dir,
-                                                                      fd, g_fd, dist, g_dist)
-                g_density, g_sph = ctx.exchange.reduce_packed(g_density, g_radiance, particle_density, int(ctx.frame.n_active_features),
-                                                              int(ctx.native.cfg.particle_radiance_sph_degree))
+                if getattr(ctx.exchange, "chunks", 1) > 1 and int(ctx.native.cfg.k_buffer_size) == 0:
+                    # pipelined: the collectives of particle range i are issued while the finalisation kernels of range i + 1 run
+                    g_density, g_sph = ctx.exchange.reduce_packed_pipelined(
+                        lambda n, cb: ctx.native.trace_bwd_factored_chunked(ctx.frame, particle_density, particle_features, ray_ori, ray_dir, fd, g_fd,
+                                                                            dist, g_dist, n, cb),
+                        particle_density, int(ctx.frame.n_active_features), int(ctx.native.cfg.particle_radiance_sph_degree))
+                else:
+                    g_density, g_radiance = ctx.native.trace_bwd_factored(ctx.frame, particle_density, particle_features, ray_ori, ray_dir,
+                                                                          fd, g_fd, dist, g_dist)
+                    g_density, g_sph = ctx.exchange.reduce_packed(g_density, g_radiance, particle_density, int(ctx.frame.n_active_features),
+                                                                  int(ctx.native.cfg.particle_radiance_sph_degree))
             # views into the packed gradient, as the reference returns them (tracer.py:268-285): no copies
             if ctx.raw is not None:   # chain rule to the raw parameters, four contiguous tensors in one pass
                 g_pos, g_dns, g_rot, g_scl = _abi.activate_pack_backward(*ctx.raw, g_density)

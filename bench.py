@@ -493,10 +493,14 @@ def main():
     dp = importlib.import_module("3dgrut_amd.dp")
     exch = None
     exchange_kind = "none"
+    chunks = int(os.environ.get("GRUT_BENCH_EXCHANGE_CHUNKS", "1"))   # > 1: pipelined (collectives of particle range i under the kernels of range i + 1)
+    auto_exchange = False
     if world > 1:
-        exchange_kind = os.environ.get("GRUT_BENCH_EXCHANGE", "factored")
+        exchange_kind = os.environ.get("GRUT_BENCH_EXCHANGE", "auto")
+        if exchange_kind == "auto":   # factored, unless the union of the step's views leaves more than a quarter of the scene untouched (decided after the first warm-up step)
+            exchange_kind, auto_exchange = "factored", True
         if exchange_kind == "factored":
-            tracer.gradient_exchange = dp.FactoredGradientExchange(average=False, timed=True)
+            tracer.gradient_exchange = dp.FactoredGradientExchange(average=False, timed=True, chunks=chunks)
         elif exchange_kind == "visible":    # the factored exchange on the rows some view touched (OR-reduced masks -> index list)
             tracer.gradient_exchange = dp.VisibleRowsExchange(average=False, timed=True)
         elif exchange_kind == "sharded":    # reduce-scatter + all-to-all + shard-local SH rebuild + all-gather
@@ -513,8 +517,17 @@ def main():
         if exch is not None:  # in-place all-reduce of the Gaussian gradients ([N,59] fp32 in five tensors)
             exch.reduce()
 
-    for _ in range(args.warmup):
+    untouched = None
+    for it in range(args.warmup):
         step()
+        if it == 0 and auto_exchange:
+            # rows no view of this step touched: OR of the ranks' visibility masks (one byte per particle over the links, once)
+            seen = tracer.render(g, batch, train=False)["mog_visibility"].reshape(-1).bool().to(torch.uint8)
+            dist.all_reduce(seen, op=dist.ReduceOp.MAX)
+            untouched = 1.0 - float(seen.float().mean())
+            if untouched > 0.25:
+                exchange_kind = "visible"
+                tracer.gradient_exchange = dp.VisibleRowsExchange(average=False, timed=True)
     # one instrumented frame outside the timed region: the sweeps count the tile entries they evaluate / accept (roofline.touched_bytes)
     abi.check(nat.lib.gut_profile_enable(nat.handle, 2), "gut_profile_enable")
     step()
@@ -564,7 +577,8 @@ def main():
         dist.all_reduce(per_rank)   # (a gather written as a sum: works on every backend)
         exchange = {"kind": exchange_kind, "ms_per_step_per_rank": [float(x) for x in per_rank.tolist()], "payload_bytes_per_rank": int(payload),
                     "note": "device time between issuing the collectives and their completion on the compute stream (RCCL over xGMI)",
-                    "predicted": predicted_exchange(exchange_kind, world, n, getattr(tracer.gradient_exchange, "last_rows", None))}
+                    "predicted": predicted_exchange(exchange_kind, world, n, getattr(tracer.gradient_exchange, "last_rows", None)),
+                    "chunks": chunks if exchange_kind == "factored" else 1, "untouched_fraction": untouched}
     if rank == 0:
         P = W * H
         # every stage from the all-stage pass; the dominant kernel from the timed region itself

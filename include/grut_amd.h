@@ -230,6 +230,20 @@ int gut_backward_factored(GutHandle* handle, void* stream, const GutFrame* frame
                           const void* feat_density, const float* grad_feat_density,
                           const float* hit_distance, const float* grad_hit_distance,
                           float* grad_particle_density, float* grad_radiance);
+
+/* gut_backward_factored with the gradient finalisation cut into `num_chunks` particle ranges (starting at multiples of 128): after the
+ * launches of each chunk the library calls on_chunk(user, chunk, first_particle, num_particles) ON THE CALLING THREAD; rows [first, first +
+ * num) of grad_particle_density and grad_radiance are then complete in stream order, and the caller may enqueue that chunk's collectives
+ * (3dgrut_amd/dp.py: all-reduce of the packed rows, all-gather of the view factors), which run under the next chunk's kernels.  Row N of
+ * grad_radiance (the sensor position) is written with the first chunk.  Results are bit for bit gut_backward_factored's. */
+typedef void (*GrutChunkFn)(void* user, uint32_t chunk, uint32_t first_particle, uint32_t num_particles);
+int gut_backward_factored_chunked(GutHandle* handle, void* stream, const GutFrame* frame,
+                                  const float* particle_density, const void* particle_sph,
+                                  const float* ray_origin, const float* ray_direction,
+                                  const void* feat_density, const float* grad_feat_density,
+                                  const float* hit_distance, const float* grad_hit_distance,
+                                  float* grad_particle_density, float* grad_radiance,
+                                  uint32_t num_chunks, GrutChunkFn on_chunk, void* user);
 int grut_sph_grad_from_views(void* stream, uint32_t num_particles, uint32_t num_views, const float* view_factors,
                              const float* positions, uint32_t position_stride, int32_t n_active_features, int32_t sph_degree,
                              float scale, float* grad_particle_sph);

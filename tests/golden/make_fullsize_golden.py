@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""tests/golden/fullsize_*.npz: the REFERENCE's own compiled programs run at BASELINE.json's sizes, on a sample.
+
+    make -C oracle ref && python tests/golden/make_fullsize_golden.py [gut_c4 gut_c2 grt_c3]
+
+Until round 4 the compiled reference code (oracle/_ref: the 3DGUT kernels over the thread-block emulation, the 3DGRT OptiX programs over
+the emulated traversal) only ever saw the small golden scenes; at 1 M Gaussians the HIP path was compared with the C oracle alone.  This
+script closes the loop at full size, where the reference code can afford it:
+
+  fullsize_gut_{c4_1m_1080p, c2_1m_800}.npz   projectOnTiles over ALL N particles (a 4096-particle sample of its outputs is stored: tile
+      counts, depth bits, projected centre, conic, extent, radiance), the reference's binning of all of them (expand, stable sort, ranges;
+      stored: the entry count and the sorted lists of the sampled tiles), then `render` on a crop of 2 x 24 tiles (32 x 384 pixels) and
+      `renderBackward` on its first tile row with a random upstream gradient (stored: images, hit counts, and the gradient rows of the
+      particles it touches).
+  fullsize_grt_c3_1m_800.npz   referenceOptix.cu / referenceBwdOptix.cu on 1536 rays of the 800 x 800 frame (every ray is offered every
+      one of the 1 M instances by the emulated traversal), proxies by the reference's instance kernel: images, hit counts, last-hit
+      distances, gradient rows of the touched particles.
+
+tests/test_full_size_gpu.py compares the HIP frames with these files directly ("HIP = reference code" on the sample; "HIP = oracle" on
+every pixel is the staged parity of the same file).  Inputs are regenerated from seeds by 3dgrut_amd.synthetic; nothing but the sample is stored.
+"""
+import ctypes as C
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
+REF = os.path.join(ROOT, "oracle", "_ref")
+F = np.float32
+syn = importlib.import_module("3dgrut_amd.synthetic")
+camera = importlib.import_module("3dgrut_amd.camera")
+
+GUT_FRAMES = {"c4_1m_1080p": (1_000_000, 1920, 1080, 0.01), "c2_1m_800": (1_000_000, 800, 800, 0.01)}
+GUT_CROP = dict(tile_row=30, tile_col=48, rows=2, cols=24)          # (in 16-pixel tiles; the dense middle of the frame)
+GUT_CROP_C2 = dict(tile_row=22, tile_col=14, rows=2, cols=24)
+GRT_FRAME = (1_000_000, 800, 800, 0.01)
+GRT_RAYS = (32, 48)                                                 # 1536 rays on a regular sub-grid of the frame
+PARTICLE_SAMPLE = 4096
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def frame_inputs(n, w, h, ms, seed=42, view=0):
+    d12, sph = syn.cloud_trained_like(n, seed=seed, median_scale=ms)
+    K = syn.pinhole_intrinsics(w, h)
+    ro, rd = syn.pinhole_rays(w, h, K)
+    batch = dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(view, n_views=8)[None], intrinsics=K)
+    cam, ps, pe = camera.camera_from_batch(batch)
+    return dict(d12=np.ascontiguousarray(d12, F), sph=np.ascontiguousarray(sph, F), batch=batch, cam=cam, ps=np.asarray(ps, F), pe=np.asarray(pe, F),
+                rays=(ro, rd), W=w, H=h, N=n)
+
+
+def crop_upstream(h, w, seed=29):
+    r = np.random.default_rng(seed)
+    return r.normal(size=(h, w, 4)).astype(F), np.zeros((h, w, 1), F)
+
+
+def make_gut(name):
+    import make_golden as mg
+    n, W, H, ms = GUT_FRAMES[name]
+    crop = GUT_CROP if name.startswith("c4") else GUT_CROP_C2
+    inp = frame_inputs(n, W, H, ms)
+    lib = C.CDLL(os.path.join(REF, "libref_gut_render_deg2_k0.so"))
+    plib = C.CDLL(os.path.join(REF, "libref_projector.so"))
+    cam, ps, pe, d12, sph = inp["cam"], inp["ps"], inp["pe"], inp["d12"], inp["sph"]
+    prm = mg.camera_prm(cam)
+    t0 = time.time()
+    o = dict(tiles_count=np.zeros(n, np.uint32), proj_pos=np.zeros((n, 2), F), conic_opacity=np.zeros((n, 4), F), extent=np.zeros((n, 2), F),
+             depth=np.zeros(n, F), features=np.zeros((n, 3), F), visibility=np.zeros(n, np.int32))
+    lib.ref_gut_project(int(cam.model), int(cam.shutter), W, H, _p(prm), _p(ps), _p(pe), C.c_uint32(n), _p(d12), _p(sph), 3, _p(o["tiles_count"]),
+                        _p(o["proj_pos"]), _p(o["conic_opacity"]), _p(o["extent"]), _p(o["depth"]), _p(o["features"]), _p(o["visibility"]))
+    print(f"{name}: projectOnTiles over {n} particles in {time.time() - t0:.1f} s; visible {int((o['tiles_count'] > 0).sum())}", flush=True)
+    offsets = np.cumsum(o["tiles_count"], dtype=np.uint64).astype(np.uint32)
+    total = int(offsets[-1])
+    keys, idx = np.zeros(total, np.uint64), np.zeros(total, np.uint32)
+    plib.ref_expand_particles(W, H, C.c_uint32(n), _p(offsets), _p(o["proj_pos"]), _p(o["conic_opacity"]), _p(o["extent"]), _p(o["depth"]), _p(keys), _p(idx))
+    order = np.argsort(keys, kind="stable")
+    sorted_idx = np.ascontiguousarray(idx[order])
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    tile_of = (keys[order] >> np.uint64(32)).astype(np.int64)
+    ranges = np.stack([np.searchsorted(tile_of, np.arange(gx * gy), "left"), np.searchsorted(tile_of, np.arange(gx * gy), "right")], 1).astype(np.uint32)
+    print(f"{name}: {total} tile entries", flush=True)
+    # the crop as its own small frame: its tiles' ranges re-indexed on a cols-wide grid, its pixels' rays
+    r0, c0, nr, nc = crop["tile_row"], crop["tile_col"], crop["rows"], crop["cols"]
+    tiles = np.array([(r0 + ty) * gx + (c0 + tx) for ty in range(nr) for tx in range(nc)])
+    sub_ranges = np.ascontiguousarray(ranges[tiles])
+    sub_ranges[sub_ranges[:, 0] == sub_ranges[:, 1]] = 0
+    y0, x0, ch, cw = 16 * r0, 16 * c0, 16 * nr, 16 * nc
+    ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)[y0:y0 + ch, x0:x0 + cw]) for a in inp["rays"])
+    lo, hi = np.full(3, -1e6, F), np.full(3, 1e6, F)
+    fd, dist, cnt = np.zeros((ch, cw, 4), F), np.full((ch, cw, 1), 1e6, F), np.zeros((ch, cw, 1), F)
+    t0 = time.time()
+    lib.ref_gut_render_fwd(cw, ch, _p(ps), _p(pe), _p(lo), _p(hi), C.c_uint32(n), _p(d12), _p(sph), 3, _p(sub_ranges), _p(sorted_idx), _p(o["features"]),
+                           _p(ro), _p(rd), _p(fd), _p(dist), _p(cnt))
+    print(f"{name}: render on the {ch}x{cw} crop in {time.time() - t0:.1f} s; hits per pixel {cnt.mean():.1f}, opacity {fd[..., 3].mean():.3f}", flush=True)
+    # backward on the first tile row of the crop
+    bh = 16
+    gfd, gdist = crop_upstream(bh, cw)
+    gd, gfeat, gsph = np.zeros((n, 12), F), np.zeros((n, 3), F), np.zeros_like(sph)
+    t0 = time.time()
+    lib.ref_gut_render_bwd(cw, bh, _p(ps), _p(pe), _p(lo), _p(hi), C.c_uint32(n), _p(d12), _p(sph), 3, _p(np.ascontiguousarray(sub_ranges[:nc])), _p(sorted_idx),
+                           _p(o["features"]), _p(np.ascontiguousarray(ro[:bh])), _p(np.ascontiguousarray(rd[:bh])), _p(np.ascontiguousarray(fd[:bh])), _p(gfd),
+                           _p(np.ascontiguousarray(dist[:bh])), _p(gdist), _p(gd), _p(gsph), _p(gfeat))
+    touched = np.flatnonzero((np.abs(gd).max(1) > 0) | (np.abs(gfeat).max(1) > 0))
+    print(f"{name}: renderBackward on {bh}x{cw} in {time.time() - t0:.1f} s; {len(touched)} particles touched", flush=True)
+    sample = np.sort(np.random.default_rng(1).choice(n, PARTICLE_SAMPLE, replace=False))
+    lists = np.concatenate([sorted_idx[a:b] for a, b in ranges[tiles]]) if len(tiles) else np.zeros(0, np.uint32)
+    np.savez_compressed(os.path.join(HERE, f"fullsize_gut_{name}.npz"), n=n, W=W, H=H, median_scale=ms, crop=np.array([r0, c0, nr, nc]), num_entries=total,
+                        sample=sample.astype(np.uint32), **{f"sample_{k}": v[sample] for k, v in o.items()},
+                        crop_list_lengths=(ranges[tiles, 1] - ranges[tiles, 0]).astype(np.uint32), crop_lists=lists,
+                        feat_density=fd, hit_distance=dist, hit_count=cnt, bwd_rows=bh, g_fd=gfd, touched=touched.astype(np.uint32),
+                        grad_density=gd[touched], grad_features=gfeat[touched])
+    print(f"wrote fullsize_gut_{name}.npz", flush=True)
+
+
+def make_grt():
+    import make_golden as mg
+    n, W, H, ms = GRT_FRAME
+    inp = frame_inputs(n, W, H, ms)
+    px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    fw = C.CDLL(os.path.join(REF, "libref_grt_trace_deg4.so"))
+    bw = C.CDLL(os.path.join(REF, "libref_grt_trace_bwd_deg4.so"))
+    d12, sph = inp["d12"], inp["sph"]
+    pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]), np.ascontiguousarray(d12[:, 3]))
+    aabb, tf = np.zeros((n, 6), F), np.zeros((n, 12), F)
+    px.ref_enclosing_proxies(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(mg.MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(aabb), _p(tf))
+    box = np.concatenate([aabb[:, :3].min(0), aabb[:, 3:].max(0)]).astype(F)
+    r2w = np.ascontiguousarray(np.asarray(inp["batch"]["T_to_world"][0], F)[:3, :4])
+    sh, sw = GRT_RAYS
+    ys = (np.arange(sh) * (H // sh) + H // (2 * sh)).astype(np.int64)
+    xs = (np.arange(sw) * (W // sw) + W // (2 * sw)).astype(np.int64)
+    ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)[np.ix_(ys, xs)]) for a in inp["rays"])
+    feat, den, hit, nrm = np.zeros((sh, sw, 3), F), np.zeros((sh, sw, 1), F), np.zeros((sh, sw, 2), F), np.zeros((sh, sw, 3), F)
+    cnt, vis = np.zeros((sh, sw, 1), F), np.zeros(n, np.int32)
+    common = (C.c_uint(n), _p(tf), _p(d12), _p(sph), sw, sh, _p(r2w), _p(ro), _p(rd), _p(box), C.c_float(mg.MIN_T_GRT), C.c_float(mg.MIN_RESPONSE),
+              C.c_float(mg.MIN_ALPHA), C.c_uint(3))
+    fw.ref_grt_set_box_test_uses_shrunk_tmax(0)
+    t0 = time.time()
+    fw.ref_grt_trace_fwd(*common, _p(feat), _p(den), _p(hit), _p(nrm), _p(cnt), _p(vis))
+    print(f"grt c3: forward programs on {sh * sw} rays x {n} instances in {time.time() - t0:.1f} s; hits per ray {cnt.mean():.1f}", flush=True)
+    g_rad, g_dns, g_hit = mg.grt_trace_upstream(sh, sw)
+    gd, gs = np.zeros((n, 12), F), np.zeros((n, 48), F)
+    t0 = time.time()
+    bw.ref_grt_trace_bwd(*common, _p(feat), _p(den), _p(hit), _p(g_rad), _p(g_dns), _p(g_hit), _p(gd), _p(gs))
+    touched = np.flatnonzero((np.abs(gd).max(1) > 0) | (np.abs(gs).max(1) > 0))
+    print(f"grt c3: backward programs in {time.time() - t0:.1f} s; {len(touched)} particles touched", flush=True)
+    np.savez_compressed(os.path.join(HERE, "fullsize_grt_c3_1m_800.npz"), n=n, W=W, H=H, median_scale=ms, ys=ys, xs=xs, features=feat, density=den,
+                        hit_distance=hit, hits_count=cnt, visible=np.flatnonzero(vis).astype(np.uint32), touched=touched.astype(np.uint32),
+                        grad_density=gd[touched], grad_sph=gs[touched])
+    print("wrote fullsize_grt_c3_1m_800.npz", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gut_c4", "gut_c2", "grt_c3"]
+    if "gut_c4" in which:
+        make_gut("c4_1m_1080p")
+    if "gut_c2" in which:
+        make_gut("c2_1m_800")
+    if "grt_c3" in which:
+        make_grt()

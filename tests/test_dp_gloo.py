@@ -118,3 +118,50 @@ def test_exchange_variants_world2():
         np.testing.assert_array_equal(r[k]["sh_fac"][:, :hi - lo], facs[:, lo:hi])
         np.testing.assert_array_equal(r[k]["sh_fac"][:, s], facs[:, n])
         np.testing.assert_allclose(r[k]["sh_full"], mean_geo, rtol=1e-6, atol=1e-7)
+
+
+def _pipelined_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module("3dgrut_amd.dp")
+    n = 1000
+    g = torch.Generator().manual_seed(11 + rank)
+    geo = torch.randn(n, 12, generator=g)
+    fac = torch.randn(n + 1, 3, generator=g)
+    ref_geo, ref_fac, _ = dp.FactoredGradientExchange(average=True).exchange(geo.clone(), fac.clone())
+    # the plugin's chunked backward, emulated: ranges at multiples of 128 become complete one after the other and the call-back issues
+    # their collectives at once; everything is waited for only after the last range (the order reduce_packed_pipelined uses)
+    ex = dp.FactoredGradientExchange(average=True, chunks=4)
+    g_density, g_radiance = geo.clone(), fac.clone()
+    per = ((n + ex.chunks - 1) // ex.chunks + 127) & ~127
+    order, pending = [], []
+    for first in range(0, n, per):
+        count = min(per, n - first)
+        order.append(("issue", first))
+        pending.append((first, count, ex.begin_chunk(g_density[first:first + count], g_radiance[first:first + count])))
+    gathered = torch.empty((world, n, 3))
+    for first, count, h in pending:
+        order.append(("finish", first))
+        gathered[:, first:first + count] = ex.finish_chunk(h)
+    out[rank] = dict(ref_geo=ref_geo.numpy(), ref_fac=ref_fac.numpy(), geo=g_density.numpy(), fac=gathered.numpy(), order=order, per=per)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_exchange_equals_the_one_piece_exchange_world2():
+    """dp.FactoredGradientExchange(chunks = 4): the collectives of particle range i are issued as soon as the range is final (under the
+    kernels of range i + 1 on the GPU) and waited for at the end.  Every range's all-reduce / gather must deliver exactly the rows the
+    one-piece exchange delivers - bit for bit, on both replicas - whatever the number of ranges in flight."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_pipelined_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = [out[0], out[1]]
+    assert r[0]["per"] == 256 and [o for o in r[0]["order"] if o[0] == "issue"] == [("issue", f) for f in (0, 256, 512, 768)]
+    assert r[0]["order"][:4] == [("issue", f) for f in (0, 256, 512, 768)], "all ranges are issued before the first is waited for"
+    for k in range(world):
+        np.testing.assert_array_equal(r[k]["geo"], r[k]["ref_geo"])
+        np.testing.assert_array_equal(r[k]["fac"], r[k]["ref_fac"][:, :1000])
+    np.testing.assert_array_equal(r[0]["geo"], r[1]["geo"])
+    np.testing.assert_array_equal(r[0]["fac"], r[1]["fac"])

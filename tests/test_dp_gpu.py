@@ -40,18 +40,33 @@ def _backward(view, exchange):
     return g.grads_packed()
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, chunks=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dp = importlib.import_module("3dgrut_amd.dp")
-    out[rank] = _backward(2 * rank + 1, dp.FactoredGradientExchange(average=True))
+    out[rank] = _backward(2 * rank + 1, dp.FactoredGradientExchange(average=True, chunks=chunks))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["factored", "visible", "allreduce"])
+def test_pipelined_exchange_world2_on_one_gpu():
+    """gut_backward_factored_chunked + dp.reduce_packed_pipelined (the gradient finalisation in 5 particle ranges, each range's collectives
+    issued from the library's call-back before the next range's kernels are launched): the same gradients as the one-piece exchange, bit for
+    bit (an all-reduce of two ranks adds two numbers: no order to differ in), on both replicas."""
+    world = 2
+    mgr = mp.Manager()
+    one, piped = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), one), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), piped, 5), nprocs=world, join=True)
+    for k in range(world):
+        assert np.array_equal(one[k][0], piped[k][0]) and np.array_equal(one[k][1], piped[k][1])
+    assert np.array_equal(piped[0][0], piped[1][0]) and np.array_equal(piped[0][1], piped[1][1])
+    assert float(np.abs(piped[0][1]).max()) > 0
+
+
+@pytest.mark.parametrize("exchange", ["auto", "factored+chunks", "visible", "allreduce"])
 def test_bench_multi_rank_line_over_gloo_on_one_gpu(exchange):
     """The multi-rank bench path end to end as the driver starts it (`python bench.py --gpus 2` launches its own ranks), with gloo standing
     in for RCCL on the one-GPU test box (GRUT_BENCH_BACKEND=gloo: both ranks share device 0): the JSON line must carry n_gpus = 2, the
@@ -61,7 +76,9 @@ def test_bench_multi_rank_line_over_gloo_on_one_gpu(exchange):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, GRUT_BENCH_BACKEND="gloo", GRUT_BENCH_EXCHANGE=exchange, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, GRUT_BENCH_BACKEND="gloo", GRUT_BENCH_EXCHANGE=exchange.split("+")[0], HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if "chunks" in exchange:
+        env["GRUT_BENCH_EXCHANGE_CHUNKS"] = "4"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", "c1_100k_400",
                         "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -70,7 +87,9 @@ def test_bench_multi_rank_line_over_gloo_on_one_gpu(exchange):
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["scaling"] == "weak" and line["value"] > 0
     assert line["config"]["parallelism"].startswith("view-dp2")
     ex = line["exchange"]
-    assert ex["kind"] == exchange and len(ex["ms_per_step_per_rank"]) == 2 and all(m > 0 for m in ex["ms_per_step_per_rank"])
+    want = {"auto": ("factored", "visible"), "factored+chunks": ("factored",)}.get(exchange, (exchange,))
+    assert ex["kind"] in want and len(ex["ms_per_step_per_rank"]) == 2 and all(m > 0 for m in ex["ms_per_step_per_rank"])
+    assert ex["chunks"] == (4 if "chunks" in exchange else 1) and (exchange != "auto" or 0.0 <= ex["untouched_fraction"] <= 1.0)
     assert ex["payload_bytes_per_rank"] > 0 and ex["predicted"]["ms"] > 0 and ex["predicted"]["ring_bytes_per_rank"] > 0
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
     # two ranks render two views: the whole-job rate counts both
