@@ -1329,7 +1329,49 @@ __device__ __forceinline__ void nht_activation(const GrtTraceParams& P, const fl
         f = grt_nht_sin(ang); df = fr * grt_nht_cos(ang);
     }
 }
-template <int DEG>
+// ---- the default feature model with compile-time shapes (configs/base_gs.yaml:96-103: 48 = 4 vertices x 12 floats, sincos, one frequency
+// -> 24 ray features): the particle's row is fetched ONCE as twelve 16-byte loads and everything else stays in registers.  The generic
+// functions above index the row word by word from memory inside run-time loops (96 scattered loads and a 32 x 16 select cascade per hit).
+constexpr int kGrtNhtFastIpd = 12, kGrtNhtFastRay = 24, kGrtNhtFastK = 48;
+__device__ __forceinline__ bool grt_nht_fast_shape(const GrtTraceParams& P) {
+    return P.nht_k == kGrtNhtFastK && P.nht_ipd == kGrtNhtFastIpd && P.nht_support == 1 && P.nht_act == 2 && P.nht_nf == 1;
+}
+__device__ __forceinline__ void nht_load_row48(const GrtTraceParams& P, const float* __restrict__ features, uint32_t id, float (&F)[kGrtNhtFastK]) {
+    if (P.sph_half) {
+        const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(features) + (size_t)id * kGrtNhtFastK);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const uint4 w = src[q];
+            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const __half2 h2 = *reinterpret_cast<const __half2*>(&ws[k]);
+                F[8 * q + 2 * k] = __low2float(h2);
+                F[8 * q + 2 * k + 1] = __high2float(h2);
+            }
+        }
+    } else {
+        const float4* src = reinterpret_cast<const float4*>(features + (size_t)id * kGrtNhtFastK);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const float4 w = src[q];
+            F[4 * q] = w.x; F[4 * q + 1] = w.y; F[4 * q + 2] = w.z; F[4 * q + 3] = w.w;
+        }
+    }
+}
+__device__ __forceinline__ void nht_fast_sincos(const float (&F)[kGrtNhtFastK], const float (&wq)[4], float (&sn)[kGrtNhtFastIpd], float (&cs)[kGrtNhtFastIpd]) {
+#pragma unroll
+    for (int m = 0; m < kGrtNhtFastIpd; ++m) {
+        float base = F[m] * wq[0];
+        base = fmaf(wq[1], F[kGrtNhtFastIpd + m], base);
+        base = fmaf(wq[2], F[2 * kGrtNhtFastIpd + m], base);
+        base = fmaf(wq[3], F[3 * kGrtNhtFastIpd + m], base);
+        sn[m] = grt_nht_sin(base);
+        cs[m] = grt_nht_cos(base);
+    }
+}
+
+template <int DEG, bool FAST = false>
 __global__ __launch_bounds__(64) void grt_nht_fwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ features,
                                                          const float* __restrict__ ray_o, const float* __restrict__ ray_d, float* __restrict__ out_feat,
                                                          GrtHitLog log) {
@@ -1361,7 +1403,18 @@ __global__ __launch_bounds__(64) void grt_nht_fwd_kernel(GrtTraceParams P, const
                 if (g.accept) {
                     const float weight = g.galpha * T;
                     T *= (1.f - g.galpha);
-                    if (weight > 0.f) {
+                    if (FAST && weight > 0.f) {
+                        const float pdot = -dot(g.grd, g.gro);
+                        float wq[4], F[kGrtNhtFastK], sn[kGrtNhtFastIpd], cs[kGrtNhtFastIpd];
+                        nht_weights(P, tet, g.gro + g.grd * pdot, wq);
+                        nht_load_row48(P, features, id, F);
+                        nht_fast_sincos(F, wq, sn, cs);
+#pragma unroll
+                        for (int m = 0; m < kGrtNhtFastIpd; ++m) {
+                            acc[2 * m] = fmaf(sn[m], weight, acc[2 * m]);
+                            acc[2 * m + 1] = fmaf(cs[m], weight, acc[2 * m + 1]);
+                        }
+                    } else if (weight > 0.f) {
                         const float pdot = -dot(g.grd, g.gro);
                         float wq[4], base[kGrtNhtMaxIpd];
                         nht_weights(P, tet, g.gro + g.grd * pdot, wq);
@@ -1396,6 +1449,9 @@ __global__ __launch_bounds__(64) void grt_nht_fwd_kernel(GrtTraceParams P, const
 struct NhtBwdRay {
     float Cb[kGrtNhtMaxRay], gC[kGrtNhtMaxRay];   // "behind" features (start at the forward's result) and their running upstream gradient
     float Tb, gT, Db, gD;
+    // fast shape (nht_hit_bwd_fast): every gC_i is scaled by the same (1 - alpha) per hit, so gC stays the UPSTREAM gradient and G carries
+    // the common factor; the 24 "behind" features enter only through S = sum_i Cb_i gC_i, un-blended as one scalar
+    float S, G;
 };
 template <int DEG>
 __device__ __forceinline__ bool nht_hit_bwd(const GrtTraceParams& P, const RayW& r, const Particle& p, const HitGeom& g, const float* __restrict__ features,
@@ -1479,6 +1535,84 @@ __device__ __forceinline__ bool nht_hit_bwd(const GrtTraceParams& P, const RayW&
     gd[8] = sclGrd.x; gd[9] = sclGrd.y; gd[10] = sclGrd.z;
     return contributes;
 }
+template <int DEG>
+__device__ __forceinline__ bool nht_hit_bwd_fast(const GrtTraceParams& P, const RayW& r, const Particle& p, const HitGeom& g, const float* __restrict__ features,
+                                                 uint32_t id, const NhtTetra& tet, NhtBwdRay& st, float (&gd)[11], float (&wq)[4], float (&gbase)[kGrtNhtMaxIpd]) {
+#pragma unroll
+    for (int m = 0; m < kGrtNhtMaxIpd; ++m) gbase[m] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) gd[k] = 0.f;
+    wq[0] = 1.f; wq[1] = wq[2] = wq[3] = 0.f;
+    if (!g.accept) return false;
+    const float alpha = g.galpha;
+    const float pdot = -dot(g.grd, g.gro);
+    const f3 grdd = g.grd * pdot;
+    const f3 grds = p.scl * grdd;
+    const float gsq = dot(grds, grds);
+    const float hitT = sqrtf(gsq);
+    nht_weights(P, tet, g.gro + grdd, wq);
+    const float w = 1.f / (1.f - alpha);
+    const bool contributes = alpha > 0.f;
+    float dalpha = 0.f;
+    f3 dP = mk3(0.f, 0.f, 0.f);
+    if (contributes) {
+        float F[kGrtNhtFastK], sn[kGrtNhtFastIpd], cs[kGrtNhtFastIpd];
+        nht_load_row48(P, features, id, F);
+        nht_fast_sincos(F, wq, sn, cs);
+        float fg = 0.f;
+#pragma unroll
+        for (int m = 0; m < kGrtNhtFastIpd; ++m) fg = fmaf(sn[m], st.gC[2 * m], fmaf(cs[m], st.gC[2 * m + 1], fg));
+        st.S = (st.S - alpha * fg) * w;
+        dalpha = st.G * (fg - st.S);
+        const float ag = alpha * st.G;
+        float dw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < kGrtNhtFastIpd; ++m) {
+            gbase[m] = ag * (cs[m] * st.gC[2 * m] - sn[m] * st.gC[2 * m + 1]);
+            dw[0] = fmaf(F[m], gbase[m], dw[0]); dw[1] = fmaf(F[kGrtNhtFastIpd + m], gbase[m], dw[1]);
+            dw[2] = fmaf(F[2 * kGrtNhtFastIpd + m], gbase[m], dw[2]); dw[3] = fmaf(F[3 * kGrtNhtFastIpd + m], gbase[m], dw[3]);
+        }
+        st.G *= (1.f - alpha);
+        dP = tet.gw0 * dw[0] + tet.gw1 * dw[1] + tet.gw2 * dw[2] + tet.gw3 * dw[3];
+    }
+    st.Tb *= w;
+    st.Db = (st.Db - hitT * alpha) * w;
+    dalpha += (hitT - st.Db) * st.gD - st.Tb * st.gT;
+    const float ddepth = alpha * st.gD;
+    st.gD *= (1.f - alpha);
+    st.gT *= (1.f - alpha);
+    float dres = 0.f, ddens = 0.f;
+    if (g.gres * p.density < P.max_alpha) { dres = p.density * dalpha; ddens = g.gres * dalpha; }
+    const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, dres);
+    const f3 grdsGrd = gsq > 0.f ? grds * (ddepth / hitT) : mk3(0.f, 0.f, 0.f);
+    const f3 gsclHit = grdd * grdsGrd;
+    const float sdot = dot(grdsGrd * p.scl, g.grd);
+    const float gdP = dot(g.grd, dP);
+    const f3 grdHit = p.scl * grdsGrd * pdot - g.gro * sdot + dP * pdot - g.gro * gdP;
+    const f3 groHit = g.grd * (-sdot) + dP - g.grd * gdP;
+    const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
+    const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x, gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
+    const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z, gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
+    const f3 groTot = groGrd + groHit;
+    const f3 is2 = g.giscl * g.giscl;
+    const f3 gsclGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;
+    const f3 gposcrGrd = g.giscl * groTot;
+    const f3 gposcGrd = mul_cols(p.rotT, gposcrGrd);
+    const float4 gq1 = matmul_bw_quat(g.gposc, gposcrGrd, p.quat);
+    const f3 dn = grdGrd + grdHit;
+    const float l2 = dot(g.grdu, g.grdu);
+    f3 grduGrd = mk3(0.f, 0.f, 0.f);
+    if (l2 > 0.f) {
+        const float il = 1.f / sqrtf(l2);
+        grduGrd = dn * il - g.grdu * (il * il * il * dot(dn, g.grdu));
+    }
+    const f3 sclGrd = gsclHit + gsclGro + mk3(-g.rdr.x * is2.x, -g.rdr.y * is2.y, -g.rdr.z * is2.z) * grduGrd;
+    const float4 gq2 = matmul_bw_quat(r.d, g.giscl * grduGrd, p.quat);
+    gd[0] = -gposcGrd.x; gd[1] = -gposcGrd.y; gd[2] = -gposcGrd.z; gd[3] = ddens;
+    gd[4] = gq1.x + gq2.x; gd[5] = gq1.y + gq2.y; gd[6] = gq1.z + gq2.z; gd[7] = gq1.w + gq2.w;
+    gd[8] = sclGrd.x; gd[9] = sclGrd.y; gd[10] = sclGrd.z;
+    return contributes;
+}
 __device__ __forceinline__ NhtBwdRay nht_bwd_ray_init(const GrtTraceParams& P, bool use, size_t pix, const float* __restrict__ in_feat,
                                                       const float* __restrict__ in_dns, const float* __restrict__ in_hit2,
                                                       const float* __restrict__ g_feat, const float* __restrict__ g_dns, const float* __restrict__ g_hit) {
@@ -1492,6 +1626,9 @@ __device__ __forceinline__ NhtBwdRay nht_bwd_ray_init(const GrtTraceParams& P, b
     }
     st.Tb = 1.f - in_dns[pix]; st.gT = -g_dns[pix];
     st.Db = in_hit2[2 * pix]; st.gD = g_hit ? g_hit[pix] : 0.f;
+    st.S = 0.f; st.G = 1.f;
+#pragma unroll
+    for (int i = 0; i < kGrtNhtMaxRay; ++i) st.S = fmaf(st.Cb[i], st.gC[i], st.S);
     return st;
 }
 // lane-level version for the traversal backward (the rays the replay does not serve): the reference's per-hit atomics
@@ -1816,7 +1953,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // transposed atomics: lane j < K carries word j of the particle's feature-row gradient (= barycentric weight x d L / d base feature,
 // both left in LDS by the hit's lane), lanes K .. K + 10 its 11 geometric terms.  (K + 11 <= 64.)
 constexpr int kNhtTermStride = 33;   // per lane: 11 geometric terms + 4 barycentric weights + 16 base-feature gradients, odd stride
-template <int DEG>
+template <int DEG, bool FAST = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void grt_replay_nht_bwd_kernel(
     GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ features, const float* __restrict__ ray_o,
     const float* __restrict__ ray_d, const float* __restrict__ in_feat, const float* __restrict__ in_dns, const float* __restrict__ in_hit2,
@@ -1876,7 +2013,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const Particle p = load_particle(density12, id);
                     const HitGeom g = hit_geometry<DEG>(P, p, r);
                     float gd[11], wq[4], gbase[kGrtNhtMaxIpd];
-                    contributes = nht_hit_bwd<DEG>(P, r, p, g, features, id, tet, st, gd, wq, gbase);
+                    contributes = FAST ? nht_hit_bwd_fast<DEG>(P, r, p, g, features, id, tet, st, gd, wq, gbase)
+                                       : nht_hit_bwd<DEG>(P, r, p, g, features, id, tet, st, gd, wq, gbase);
                     if (contributes) {
                         float* const tw = s_terms + lane * kNhtTermStride;
 #pragma unroll
@@ -3152,8 +3290,14 @@ void grt_launch_list_ranges(hipStream_t s, uint32_t n, const uint32_t* n_dev, ui
 void grt_launch_nht_fwd(hipStream_t s, const GrtTraceParams& P, const float* density12, const float* features, const float* ray_o, const float* ray_d,
                         float* out_feat, const GrtHitLog& log) {
     const dim3 grid(pixel_block_grid(P.W, P.H));
-    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_nht_fwd_kernel<D_>), grid, dim3(64), 0, s, P, reinterpret_cast<const float4*>(density12), features,
-                                                     ray_o, ray_d, out_feat, log));
+    const bool fast = P.nht_k == 48 && P.nht_ipd == 12 && P.nht_support == 1 && P.nht_act == 2 && P.nht_nf == 1 && !getenv("GRUT_NHT_GENERIC");
+    if (fast) {
+        GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_nht_fwd_kernel<D_, true>), grid, dim3(64), 0, s, P, reinterpret_cast<const float4*>(density12), features,
+                                                         ray_o, ray_d, out_feat, log));
+    } else {
+        GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_nht_fwd_kernel<D_>), grid, dim3(64), 0, s, P, reinterpret_cast<const float4*>(density12), features,
+                                                         ray_o, ray_d, out_feat, log));
+    }
 }
 
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,
@@ -3194,7 +3338,12 @@ void grt_launch_trace_bwd(hipStream_t s, hipStream_t s_rederive, const GrtTraceP
                                                      g_hit, g_density12, g_sph, log.pool ? log.state : nullptr, log.pool ? log.ray_flags : nullptr, lists))
     if (P.nht) {   // neural harmonic features: the Slang backward pipeline (sph / g_sph = feature buffer and its gradient, rad / g_rad = [H,W,ray_dim])
         if (lists.ranges) { GRT_BWD_LAUNCH_NHT(true); } else { GRT_BWD_LAUNCH_NHT(false); }
-        if (log.pool) {
+        const bool fast = P.nht_k == 48 && P.nht_ipd == 12 && P.nht_support == 1 && P.nht_act == 2 && P.nht_nf == 1 && !getenv("GRUT_NHT_GENERIC");
+        if (log.pool && fast) {
+            GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_replay_nht_bwd_kernel<D_, true>), grid, dim3(64), 0, s, P,
+                                                             reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad,
+                                                             g_dns, g_hit, g_density12, g_sph, log, bvh.inst, bvh.scene));
+        } else if (log.pool) {
             GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_replay_nht_bwd_kernel<D_>), grid, dim3(64), 0, s, P,
                                                              reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, rad, dns, hit2, g_rad,
                                                              g_dns, g_hit, g_density12, g_sph, log, bvh.inst, bvh.scene));
