@@ -80,6 +80,7 @@ class GrtConfig(C.Structure):
         ("max_hits_per_trace", C.c_int32), ("particle_feature_half", C.c_int32), ("feature_output_half", C.c_int32),
         ("feature_transform_type", C.c_int32), ("particle_feature_dim", C.c_int32), ("interp_point_feature_dim", C.c_int32),
         ("feature_interpolation_support", C.c_int32), ("feature_activation_type", C.c_int32), ("feature_activation_num_frequencies", C.c_int32),
+        ("primitive_type", C.c_int32),
     ]
 
 
@@ -109,6 +110,8 @@ class GrutAdamGroup(C.Structure):
 
 
 VIS_NONE, VIS_BOOL_U8, VIS_INT32, VIS_FLOAT_BITS = range(4)
+# GrtConfig::primitive_type (render.primitive_type, optixTracer.cpp:176-201)
+GRT_PRIMITIVES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4}
 
 
 class GrtTexture(C.Structure):

@@ -66,6 +66,10 @@ struct GrtHandle {
 
 static int grt_validate(const GrtConfig& c) {
     GRUT_REQUIRE(c.particle_radiance_sph_degree >= 0 && c.particle_radiance_sph_degree <= 3, "sph degree must be in [0,3]");
+    if (c.primitive_type < GRUT_PRIM_INSTANCES || c.primitive_type > GRUT_PRIM_DIAMOND) {
+        set_last_error("primitive_type %d: instances (0), icosahedron (1), octahedron (2), tetrahedron (3), diamond (4) are provided", c.primitive_type);
+        return GRUT_ERR_UNSUPPORTED;
+    }
     const int d = c.particle_kernel_degree;
     GRUT_REQUIRE(d == 0 || d == 1 || d == 2 || d == 3 || d == 4 || d == 5 || d == 8, "unsupported particle_kernel_degree %d", d);
     if (c.feature_transform_type != 0) {
@@ -92,6 +96,7 @@ static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
     GrtTraceParams P;
     memset(&P, 0, sizeof(P));
     P.degree = h->cfg.particle_kernel_degree;
+    P.prim = h->cfg.primitive_type;
     P.ncoef = (h->cfg.particle_radiance_sph_degree + 1) * (h->cfg.particle_radiance_sph_degree + 1);
     P.sph_degree = f.sph_degree < h->cfg.particle_radiance_sph_degree ? f.sph_degree : h->cfg.particle_radiance_sph_degree;
     if (P.sph_degree < 0) P.sph_degree = 0;
@@ -235,6 +240,7 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     GrtBuildParams P;
     P.N = N;
     P.degree = h->cfg.particle_kernel_degree;
+    P.prim = h->cfg.primitive_type;
     P.clamping = h->cfg.particle_kernel_density_clamping;
     P.min_response = h->cfg.particle_kernel_min_response;
     uint32_t* scene_enc = h->scene_enc.as<uint32_t>();
@@ -270,7 +276,8 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
     GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     h->list_entries = 0;
     h->log_lists = lists;   // the list scratch is about to be overwritten: a pending backward of an older forward walks the tree
-    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0) {
+    // (triangle-mesh proxies: the lists' per-packet distance bounds are derived for the instance path's hit distance - the tree walk serves them)
+    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && h->cfg.primitive_type == GRUT_PRIM_INSTANCES) {
         const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
         if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
         GRUT_CHECK(h->l_flags.ensure(64));

@@ -28,6 +28,7 @@ struct GrtBuildParams {
     uint32_t N;
     int degree, clamping;
     float min_response;
+    int prim;   // GrtConfig::primitive_type: the proxies' world boxes enclose the polyhedron, not the unit cube
 };
 
 struct GrtBvh {
@@ -41,6 +42,7 @@ struct GrtTraceParams {
     int degree, sph_degree, ncoef, normals, hitcounts;
     float min_response, min_alpha, max_alpha, min_transmittance;
     int W, H;
+    int prim;                 // GrtConfig::primitive_type (GRUT_PRIM_*): which candidate test a (ray, particle) pair takes
     float ray_to_world[12];
     const float* ray_to_world_dev;   // optional: the same matrix in device memory (GrtFrame::device_ray_to_world), used instead when set
     uint32_t dbg_cap;

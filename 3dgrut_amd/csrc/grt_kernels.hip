@@ -61,6 +61,8 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+#include "grt_polyhedra.inl"
+
 constexpr int kSceneReplicas = 64, kSceneReplicaStride = 32;   // one 128-byte line per replica of the encoded scene box
 
 // computeGaussianEnclosingInstancesKernel (particlePrimitives.cu:543-610), emitted as the inverse instance map
@@ -82,14 +84,16 @@ __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const 
         o[9] = cx; o[10] = cy; o[11] = cz;
         // world half extents of the oriented box, padded by a hair so that rounding can never make the ray miss the
         // AABB of a box it touches (culling must stay conservative; candidates are decided in the proxy's own frame)
-        float hx = fabsf(rt.r0.x) * k0 + fabsf(rt.r1.x) * k1 + fabsf(rt.r2.x) * k2;
-        float hy = fabsf(rt.r0.y) * k0 + fabsf(rt.r1.y) * k1 + fabsf(rt.r2.y) * k2;
-        float hz = fabsf(rt.r0.z) * k0 + fabsf(rt.r1.z) * k1 + fabsf(rt.r2.z) * k2;
+        // (triangle-mesh proxies: the polyhedron's vertices reach ext_k along axis k of the proxy's frame instead of 1)
+        const float e0 = k0 * kGrtPolyhedra[P.prim].ext[0], e1 = k1 * kGrtPolyhedra[P.prim].ext[1], e2 = k2 * kGrtPolyhedra[P.prim].ext[2];
+        float hx = fabsf(rt.r0.x) * e0 + fabsf(rt.r1.x) * e1 + fabsf(rt.r2.x) * e2;
+        float hy = fabsf(rt.r0.y) * e0 + fabsf(rt.r1.y) * e1 + fabsf(rt.r2.y) * e2;
+        float hz = fabsf(rt.r0.z) * e0 + fabsf(rt.r1.z) * e1 + fabsf(rt.r2.z) * e2;
         hx += 1e-4f * hx + 1e-6f * (fabsf(cx) + 1.f); hy += 1e-4f * hy + 1e-6f * (fabsf(cy) + 1.f); hz += 1e-4f * hz + 1e-6f * (fabsf(cz) + 1.f);
         lo[0] = cx - hx; lo[1] = cy - hy; lo[2] = cz - hz; hi[0] = cx + hx; hi[1] = cy + hy; hi[2] = cz + hz;
         float* b = aabb + 6 * (size_t)i;
         b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
-        slack[i] = 1.41421356237f * 1.0001f * fmaxf(k0, fmaxf(k1, k2));
+        slack[i] = 1.41421356237f * 1.0001f * fmaxf(e0, fmaxf(e1, e2));
     }
     // scene box: one set of atomics per wave, spread over kSceneReplicas cache lines (15 k waves hammering six words of
     // ONE line serialised in L2 and cost 1 ms of this kernel's 1.07 ms); the Morton kernel folds the replicas
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(256) void grt_refit_pass_kernel(uint32_t N, uint32_
 // ---------------------------------------------------------------------------------------------
 struct RayW {
     f3 o, d, inv;
+    int prim;   // GrtTraceParams::prim rides with the ray: the candidate test is the one place that depends on it
 };
 __device__ __forceinline__ float safe_rcp(float v) {
     return fabsf(v) > 1e-30f ? 1.0f / v : copysignf(1.0e30f, v);
@@ -275,6 +280,7 @@ __device__ __forceinline__ RayW make_ray(const GrtTraceParams& P, const float* _
         r.d = mk3(m[0] * sd.x + m[1] * sd.y + m[2] * sd.z, m[4] * sd.x + m[5] * sd.y + m[6] * sd.z, m[8] * sd.x + m[9] * sd.y + m[10] * sd.z);
     }
     r.inv = mk3(safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z));
+    r.prim = P.prim;
     return r;
 }
 // referenceOptix.cu:33-39 intersectAABB
@@ -346,6 +352,31 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     const float pox = po.x, poy = po.y, poz = po.z;
     const float pdx = fmaf(a.z, r.d.z, fmaf(a.y, r.d.y, a.x * r.d.x)), pdy = fmaf(b.y, r.d.z, fmaf(b.x, r.d.y, a.w * r.d.x)),
                 pdz = fmaf(e.x, r.d.z, fmaf(b.w, r.d.y, b.z * r.d.x));
+    if (r.prim != GRUT_PRIM_INSTANCES) {
+        // triangle-mesh proxies (icosahedron ...): the distance at which the ray ENTERS the fixed convex polyhedron of the proxy's frame -
+        // what OptiX reports for the one front-facing triangle of the reference's mesh the ray passes (back faces culled; a ray that starts
+        // inside is not offered the particle).  Clip against the face planes n . x <= h: entering planes (n . d < 0) raise the entry
+        // distance, leaving planes lower the exit distance; parallel and outside = miss.  Same operations, same order in the CPU checker.
+        const GrtPolyhedron& ph = kGrtPolyhedra[r.prim];
+        float tin = -3.0e38f, tout = 3.0e38f;
+        bool miss = false;
+        for (int f = 0; f < ph.num_planes; ++f) {
+            const float nx = ph.planes[f][0], ny = ph.planes[f][1], nz = ph.planes[f][2], hh = ph.planes[f][3];
+            const float dn = fmaf(nz, pdz, fmaf(ny, pdy, nx * pdx));
+            const float on = hh - fmaf(nz, poz, fmaf(ny, poy, nx * pox));
+            const float tf = on / dn;
+            if (dn < 0.f) tin = fmaxf(tin, tf);
+            else if (dn > 0.f) tout = fminf(tout, tf);
+            else if (on < 0.f) miss = true;
+        }
+        c.t = tin;
+        c.box = !miss && (tin <= tout) && (tin > -3.0e38f);
+        const bool want = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
+        c.tnear = tin; c.tfar = 3.0e38f;   // the reported distance IS the geometric hit: eligibility is t in (tmin, tmax) alone
+        c.why = c.box ? 1 : 2;
+        c.ok = c.box && want;
+        return c;
+    }
     // intersectInstanceParticle: hit distance = closest approach in the proxy's frame
     const float numerator = -fmaf(poz, pdz, fmaf(poy, pdy, pox * pdx));
     const float dd = fmaf(pdz, pdz, fmaf(pdy, pdy, pdx * pdx));

@@ -46,9 +46,12 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
         raise NotImplementedError(f"3dgrut_amd: render.backward_pipeline_type={bwd_pipeline!r} is not supported "
                                   f"(only {tuple(p + 'Bwd' for p in allowed)})")
     prim = _conf_get(render, "primitive_type", "instances")
-    if prim not in _SUPPORTED_PRIMITIVES:
-        raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (only {_SUPPORTED_PRIMITIVES}: "
-                                  "the software BVH bounds each particle by its oriented proxy box)")
+    if prim not in _abi.GRT_PRIMITIVES:
+        raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (provided: {tuple(_abi.GRT_PRIMITIVES)}; "
+                                  "trihexa / trisurfel / sphere / custom proxies are not)")
+    if prim != "instances" and nht:
+        raise NotImplementedError("3dgrut_amd: neural harmonic features are provided with primitive_type=instances only")
+    cfg.primitive_type = _abi.GRT_PRIMITIVES[prim]
     # fp16 feature I/O (setup_3dgrt.py:41-44): run-time switches here, compile-time macros in the reference
     cfg.particle_feature_half = int(bool(_conf_get(render, "particle_feature_half", False)))
     cfg.feature_output_half = int(bool(_conf_get(render, "feature_output_half", False)))

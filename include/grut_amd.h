@@ -321,7 +321,14 @@ typedef struct GrtConfig {
     int32_t feature_interpolation_support;
     int32_t feature_activation_type;
     int32_t feature_activation_num_frequencies;
+    /* render.primitive_type (optixTracer.cpp:176-201): the proxy geometry a particle is traced through.  GRUT_PRIM_INSTANCES: the unit cube
+     * under the particle's instance transform, hit distance = the point of maximum response (intersectInstanceParticle).  The closed convex
+     * triangle meshes of particlePrimitives.cu:63-496: the ray is offered the particle at the distance at which it ENTERS the proxy (OptiX
+     * triangles with back faces culled, referenceOptix.cu:62), rays that start inside are not offered it.  Other meshes (trihexa, trisurfel),
+     * `sphere` and `custom` are GRUT_ERR_UNSUPPORTED. */
+    int32_t primitive_type;
 } GrtConfig;
+enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON = 2, GRUT_PRIM_TETRAHEDRON = 3, GRUT_PRIM_DIAMOND = 4 };
 
 typedef struct GrtFrame {
     uint32_t frame_id;

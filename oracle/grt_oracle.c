@@ -37,6 +37,14 @@ real orc_grt_kernel_scale(real density, real min_response, int clamping, real de
     return r_pow(r_log(mr) / a, 1 / degree);
 }
 
+/* render.primitive_type (GrtConfig::primitive_type; optixTracer.cpp:176-201).  0 = instances; 1..4 = the closed convex triangle meshes of
+ * particlePrimitives.cu:63-496, which OptiX traverses as built-in triangles with back faces culled (referenceOptix.cu:62): the particle is
+ * offered at the distance at which the ray ENTERS its proxy, i.e. - in the proxy's own frame - the fixed polyhedron of orc_polyhedra.h.
+ * A process-wide setting of this test library (the entry points that take a GrtConfig set it from cfg->primitive_type). */
+#include "orc_polyhedra.h"
+static int g_prim = 0;
+void orc_grt_set_primitive(int prim) { g_prim = prim; }
+
 /* computeGaussianEnclosingInstancesKernel, particlePrimitives.cu:543-610: instance transform [R diag(kscl) | mu] over a
  * unit box.  Emitted here as the INVERSE map (what traversal needs): inst = {W rows (9), mu (3)}, W = diag(1/kscl) R^T,
  * so that the object-space ray is o' = W (o - mu), d' = W d.  Also the world AABB of the box, the pruning slack
@@ -56,12 +64,14 @@ int orc_grt_proxies(const GrtConfig* cfg, uint32_t N, const real* positions, con
         }
         o[9] = positions[3 * i]; o[10] = positions[3 * i + 1]; o[11] = positions[3 * i + 2];
         /* world half extent_c = sum_r |R_cr| kscl_r with R_cr = rotT.r[r].c */
-        const real hx = r_fabs(rotT.r[0].x) * kscl[0] + r_fabs(rotT.r[1].x) * kscl[1] + r_fabs(rotT.r[2].x) * kscl[2];
-        const real hy = r_fabs(rotT.r[0].y) * kscl[0] + r_fabs(rotT.r[1].y) * kscl[1] + r_fabs(rotT.r[2].y) * kscl[2];
-        const real hz = r_fabs(rotT.r[0].z) * kscl[0] + r_fabs(rotT.r[1].z) * kscl[1] + r_fabs(rotT.r[2].z) * kscl[2];
+        const orc_polyhedron* ph = &orc_polyhedra[cfg->primitive_type];   /* (instances: ext = 1) */
+        const real ex[3] = {kscl[0] * (real)ph->ext[0], kscl[1] * (real)ph->ext[1], kscl[2] * (real)ph->ext[2]};
+        const real hx = r_fabs(rotT.r[0].x) * ex[0] + r_fabs(rotT.r[1].x) * ex[1] + r_fabs(rotT.r[2].x) * ex[2];
+        const real hy = r_fabs(rotT.r[0].y) * ex[0] + r_fabs(rotT.r[1].y) * ex[1] + r_fabs(rotT.r[2].y) * ex[2];
+        const real hz = r_fabs(rotT.r[0].z) * ex[0] + r_fabs(rotT.r[1].z) * ex[1] + r_fabs(rotT.r[2].z) * ex[2];
         real* b = aabb6 + 6 * (size_t)i;
         b[0] = o[9] - hx; b[1] = o[10] - hy; b[2] = o[11] - hz; b[3] = o[9] + hx; b[4] = o[10] + hy; b[5] = o[11] + hz;
-        slack[i] = R_(1.41421356237) * r_max(kscl[0], r_max(kscl[1], kscl[2]));
+        slack[i] = R_(1.41421356237) * r_max(ex[0], r_max(ex[1], ex[2]));
         for (int k = 0; k < 3; ++k) { scene6[k] = r_min(scene6[k], b[k]); scene6[3 + k] = r_max(scene6[3 + k], b[3 + k]); }
     }
     return 0;
@@ -78,6 +88,7 @@ int orc_grt_proxies(const GrtConfig* cfg, uint32_t N, const real* positions, con
  * |normalize(pd) x po|^2 / |pd|^2 < 9). */
 typedef struct { real t, tnear, tfar; int ok; } grt_cand;
 
+
 static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist) {
     grt_cand c; c.ok = 0; c.t = 0; c.tnear = 0; c.tfar = 0;
     const v3 dl = v3_make(o.x - inst[9], o.y - inst[10], o.z - inst[11]);
@@ -85,6 +96,23 @@ static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist) {
                           inst[6] * dl.x + inst[7] * dl.y + inst[8] * dl.z);
     const v3 pd = v3_make(r_fma(inst[2], d.z, r_fma(inst[1], d.y, inst[0] * d.x)), r_fma(inst[5], d.z, r_fma(inst[4], d.y, inst[3] * d.x)),
                           r_fma(inst[8], d.z, r_fma(inst[7], d.y, inst[6] * d.x)));
+    if (g_prim != 0) {   /* triangle-mesh proxy: clip against the polyhedron's face planes, operation by operation as candidate_abe (grt_kernels.hip) */
+        const orc_polyhedron* ph = &orc_polyhedra[g_prim];
+        real tin = R_(-3.0e38), tout = R_(3.0e38);
+        int miss = 0;
+        for (int f = 0; f < ph->num_planes; ++f) {
+            const real nx = (real)ph->planes[f][0], ny = (real)ph->planes[f][1], nz = (real)ph->planes[f][2], hh = (real)ph->planes[f][3];
+            const real dn = r_fma(nz, pd.z, r_fma(ny, pd.y, nx * pd.x));
+            const real on = hh - r_fma(nz, po.z, r_fma(ny, po.y, nx * po.x));
+            const real tf = on / dn;
+            if (dn < 0) tin = r_fmax(tin, tf);
+            else if (dn > 0) tout = r_fmin(tout, tf);
+            else if (on < 0) miss = 1;
+        }
+        c.t = tin; c.tnear = tin; c.tfar = R_(3.0e38);
+        c.ok = !miss && (tin <= tout) && (tin > R_(-3.0e38));
+        return c;
+    }
     /* slab test of the unit box */
     const real ix = 1 / pd.x, iy = 1 / pd.y, iz = 1 / pd.z;
     const real ax0 = (-1 - po.x) * ix, ax1 = (1 - po.x) * ix;
@@ -332,6 +360,7 @@ int orc_grt_trace_fwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
                       const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
                       const real* ray_d, real* out_rad, real* out_dns, real* out_hit2, real* out_nrm, real* out_cnt,
                       int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap) {
+    orc_grt_set_primitive(cfg->primitive_type);
     const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
     if (K > GRT_MAX_K) return -1;
     const int ncoef = (cfg->particle_radiance_sph_degree + 1) * (cfg->particle_radiance_sph_degree + 1);
@@ -387,6 +416,7 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
                       const real* ray_d, const real* rad, const real* dns, const real* hit2, const real* g_rad, const real* g_dns,
                       const real* g_hit, real* g_density12, real* g_sph, uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap,
                       uint8_t* round_shift) {
+    orc_grt_set_primitive(cfg->primitive_type);
     const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
     if (K > GRT_MAX_K) return -1;
     const int ncoef = (cfg->particle_radiance_sph_degree + 1) * (cfg->particle_radiance_sph_degree + 1);
@@ -493,6 +523,7 @@ int orc_grt_trace_nht_fwd(const GrtConfig* cfg, const int* nht, uint32_t N, cons
                           const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
                           const real* ray_d, real* out_feat, real* out_dns, real* out_hit2, real* out_cnt, int32_t* visibility,
                           uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap) {
+    orc_grt_set_primitive(cfg->primitive_type);
     const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
     const int nr = orc_nht_ray_dim(nht), KF = nht[0];
     if (K > GRT_MAX_K || nr > ORC_NHT_MAX_DIM || nht[1] > ORC_NHT_MAX_DIM) return -1;
@@ -566,6 +597,7 @@ int orc_grt_trace_nht_bwd(const GrtConfig* cfg, const int* nht, uint32_t N, cons
                           const real* inst12, const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o,
                           const real* ray_d, const real* feat, const real* dns, const real* hit2, const real* g_feat, const real* g_dns,
                           const real* g_hit, real* g_density12, real* g_features) {
+    orc_grt_set_primitive(cfg->primitive_type);
     (void)min_T;
     const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
     const int nr = orc_nht_ray_dim(nht), KF = nht[0];
@@ -1039,6 +1071,7 @@ int orc_grt_hybrid_trace(const GrtConfig* cfg, uint32_t N, const real* density12
                          const real* ray_d, const real* ray_max_t, const orc_mesh* mesh, uint32_t opts, uint32_t max_pbr_bounces,
                          uint32_t frame_number, const uint32_t* pixel_xy, uint32_t launch_width, real* out_rgba, real* out_last_ray,
                          uint32_t* out_bounces) {
+    orc_grt_set_primitive(cfg->primitive_type);
     const uint32_t nrays = width * height;
     const uint32_t seed_width = launch_width ? launch_width : width;
 #pragma omp parallel

@@ -22,6 +22,10 @@ struct Scene {
     float trace_tmax = 0.f;
     uint32_t n = 0;
     std::vector<float> inv;   // [n][12]: rows of the inverse linear part, then the translation of the instance transform
+    // triangle-mesh proxies (render.primitive_type icosahedron ...: one triangle GAS over all particles' meshes, optixTracer.cpp:836-845)
+    uint32_t num_triangles = 0;
+    const float* vertices = nullptr;   // [V,3] world space, as the reference's mesh kernel wrote them
+    const int32_t* triangles = nullptr;
 } g_scene;
 }  // namespace
 
@@ -46,6 +50,35 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
     g_optix.worldOrigin = o; g_optix.worldDirection = d;
     g_optix.tmin = tmin; g_optix.tmax = tmax;
     g_scene.trace_tmax = tmax;
+#ifdef SHIM_OPTIX_TRIANGLE_PROXIES
+    // Built-in triangles with OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES (referenceOptix.cu:62): every FRONT-facing triangle (counter-clockwise
+    // seen from the ray origin, OptiX's default) the ray crosses within its CURRENT interval is reported to the any-hit program, in
+    // index order (OptiX leaves the order open; the payload ends up with the 16 nearest either way, up to ties).  Moeller-Trumbore in
+    // world space, separately rounded fp32 operations.
+    for (uint32_t f = 0; f < g_scene.num_triangles; ++f) {
+        const int32_t* tri = g_scene.triangles + 3 * (size_t)f;
+        const float* pa = g_scene.vertices + 3 * (size_t)tri[0];
+        const float* pb = g_scene.vertices + 3 * (size_t)tri[1];
+        const float* pc = g_scene.vertices + 3 * (size_t)tri[2];
+        const float e1x = pb[0] - pa[0], e1y = pb[1] - pa[1], e1z = pb[2] - pa[2], e2x = pc[0] - pa[0], e2y = pc[1] - pa[1], e2z = pc[2] - pa[2];
+        const float px = d.y * e2z - d.z * e2y, py = d.z * e2x - d.x * e2z, pz = d.x * e2y - d.y * e2x;
+        const float det = e1x * px + e1y * py + e1z * pz;     // = d . (e2 x e1) = -(d . n): positive for a front face
+        if (!(det > 0.f)) continue;                            // back-facing or parallel: culled
+        const float tx = o.x - pa[0], ty = o.y - pa[1], tz = o.z - pa[2];
+        const float u = (tx * px + ty * py + tz * pz) / det;
+        if (!(u >= 0.f && u <= 1.f)) continue;
+        const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+        const float v = (d.x * qx + d.y * qy + d.z * qz) / det;
+        if (!(v >= 0.f && u + v <= 1.f)) continue;
+        const float t = (e2x * qx + e2y * qy + e2z * qz) / det;
+        // the ray interval is OPEN for built-in triangles: the raygen programs re-trace from tmin = (last hit distance + 1e-9), which is
+        // the last hit distance itself in fp32 - a hit AT tmin reported again would never let the round loop advance
+        if (!(t > g_optix.tmin && t < g_optix.tmax)) continue;
+        g_optix.primitive = f;
+        optixReportIntersection(t, 0);
+    }
+    return;
+#endif
     for (uint32_t i = 0; i < g_scene.n; ++i) {
         const float* m = &g_scene.inv[12 * (size_t)i];
         const float dx = o.x - m[9], dy = o.y - m[10], dz = o.z - m[11];
@@ -112,6 +145,10 @@ static void set_common_params(int width, int height, const float* ray_to_world, 
     params.frameBounds = uint2{(unsigned)width - 1, (unsigned)height - 1};
     params.frameNumber = 0;
     params.gPrimNumTri = 0;
+}
+static void set_scene_triangles(uint32_t num_triangles, uint32_t triangles_per_particle, const float* vertices, const int32_t* triangles) {
+    g_scene.num_triangles = num_triangles; g_scene.vertices = vertices; g_scene.triangles = triangles;
+    params.gPrimNumTri = triangles_per_particle;
 }
 
 static void launch_raygen(int width, int height) {

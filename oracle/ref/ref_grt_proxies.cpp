@@ -33,4 +33,25 @@ void ref_enclosing_proxies(unsigned n, const float* pos, const float* rot, const
     delete[] boxes;
     delete[] inst;
 }
+
+// the triangle-mesh proxies: prim 1 icosahedron, 2 octahedron, 3 tetrahedron, 4 diamond (GRUT_PRIM_*) -> vertices [n * V, 3] in world space,
+// triangles [n * T, 3] (indices into all vertices), written by the reference's own mesh kernel of that type.  Returns T (V through *num_vertices).
+unsigned ref_enclosing_mesh(int prim, unsigned n, const float* pos, const float* rot, const float* scl, const float* dns, float min_response, unsigned opts,
+                            float degree, float* vertices, int* triangles, unsigned* num_vertices) {
+    blockDim.x = 1; threadIdx.x = 0;
+    for (unsigned i = 0; i < n; ++i) {
+        blockIdx.x = i;
+        switch (prim) {
+        case 1: computeGaussianEnclosingIcosaHedronKernel(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices, (int3*)triangles); break;
+        case 2: computeGaussianEnclosingOctaHedronKernel(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices, (int3*)triangles); break;
+        case 3: computeGaussianEnclosingTetraHedronKernel(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices, (int3*)triangles); break;
+        case 4: computeGaussianEnclosingDiamondKernel(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices, (int3*)triangles); break;
+        default: return 0;
+        }
+    }
+    const unsigned nv[5] = {0, icosaHedronNumVrt, octaHedronNumVrt, tetraHedronNumVrt, diamondNumVrt};
+    const unsigned nt[5] = {0, icosaHedronNumTri, octaHedronNumTri, tetraHedronNumTri, diamondNumTri};
+    *num_vertices = nv[prim];
+    return nt[prim];
+}
 }

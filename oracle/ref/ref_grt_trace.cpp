@@ -23,7 +23,12 @@
 #define PARTICLE_FEATURE_DIM 48
 #define RAY_FEATURE_DIM 3
 #define FEATURE_TRANSFORM_TYPE 0
+#ifdef REF_PRIMITIVE   // a triangle-mesh proxy: -DREF_PRIMITIVE=MOGTracingIcosaHedron ... (optixTracer.cpp:176-201)
+#define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::REF_PRIMITIVE
+#define SHIM_OPTIX_TRIANGLE_PROXIES
+#else
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingInstances
+#endif
 #define PARTICLE_PRIMITIVE_CLAMPED 1
 #define ENABLE_NORMALS
 #define ENABLE_HIT_COUNTS
@@ -50,5 +55,18 @@ void ref_grt_trace_fwd(uint32_t n, const float* transforms, const float* density
                       sph_degree, features, density, hit_distance2, normals, hits_count, visibility);
     launch_raygen(width, height);
 }
+
+#ifdef REF_PRIMITIVE
+// the same programs over the particles' triangle meshes (vertices / triangles as the reference's mesh kernel wrote them, ref_grt_proxies.cpp)
+void ref_grt_trace_fwd_mesh(uint32_t n, uint32_t triangles_per_particle, const float* vertices, const int32_t* triangles, const float* density12,
+                            const float* sph48, int width, int height, const float* ray_to_world, const float* ray_o, const float* ray_d,
+                            const float* scene_aabb6, float min_transmittance, float min_response, float min_alpha, unsigned sph_degree, float* features,
+                            float* density, float* hit_distance2, float* normals, float* hits_count, int32_t* visibility) {
+    set_common_params(width, height, ray_to_world, ray_o, ray_d, density12, sph48, scene_aabb6, min_transmittance, min_response, min_alpha,
+                      sph_degree, features, density, hit_distance2, normals, hits_count, visibility);
+    set_scene_triangles(n * triangles_per_particle, triangles_per_particle, vertices, triangles);
+    launch_raygen(width, height);
+}
+#endif
 
 }  // extern "C"

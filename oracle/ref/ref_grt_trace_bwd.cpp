@@ -23,7 +23,12 @@
 #define PARTICLE_FEATURE_DIM 48
 #define RAY_FEATURE_DIM 3
 #define FEATURE_TRANSFORM_TYPE 0
+#ifdef REF_PRIMITIVE   // a triangle-mesh proxy: -DREF_PRIMITIVE=MOGTracingIcosaHedron ... (optixTracer.cpp:176-201)
+#define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::REF_PRIMITIVE
+#define SHIM_OPTIX_TRIANGLE_PROXIES
+#else
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingInstances
+#endif
 #define PARTICLE_PRIMITIVE_CLAMPED 1
 #define ENABLE_NORMALS
 #define ENABLE_HIT_COUNTS
@@ -38,19 +43,17 @@ extern "C" {
 
 void ref_grt_set_box_test_uses_shrunk_tmax(int on) { g_scene.box_test_uses_shrunk_tmax = on != 0; }
 
-// forward results (features / density / hit_distance2) and upstream gradients in, particle gradients out ([n,12], [n,48],
-// zero-filled by the caller like optixTracer.cpp:1010-1031 does)
-void ref_grt_trace_bwd(uint32_t n, const float* transforms, const float* density12, const float* sph48, int width, int height,
-                       const float* ray_to_world, const float* ray_o, const float* ray_d, const float* scene_aabb6, float min_transmittance,
-                       float min_response, float min_alpha, unsigned sph_degree, const float* features, const float* density,
-                       const float* hit_distance2, const float* g_features, const float* g_density, const float* g_hit_distance,
-                       float* g_density12, float* g_sph48) {
-    set_scene(n, transforms);
+static void bwd_params_and_launch(uint32_t n, const float* density12, const float* sph48, int width, int height, const float* ray_to_world, const float* ray_o,
+                                  const float* ray_d, const float* scene_aabb6, float min_transmittance, float min_response, float min_alpha, unsigned sph_degree,
+                                  const float* features, const float* density, const float* hit_distance2, const float* g_features, const float* g_density,
+                                  const float* g_hit_distance, float* g_density12, float* g_sph48, uint32_t triangles_per_particle, const float* vertices,
+                                  const int32_t* triangles) {
     std::vector<float> dummy3((size_t)width * height * 3, 0.f), dummy1((size_t)width * height, 0.f);
     std::vector<int32_t> vis(n, 0);
     set_common_params(width, height, ray_to_world, ray_o, ray_d, density12, sph48, scene_aabb6, min_transmittance, min_response, min_alpha,
                       sph_degree, const_cast<float*>(features), const_cast<float*>(density), const_cast<float*>(hit_distance2), dummy3.data(),
                       dummy1.data(), vis.data());
+    if (vertices) set_scene_triangles(n * triangles_per_particle, triangles_per_particle, vertices, triangles);
     const int32_t sz3[4] = {1, height, width, 3}, st3[4] = {height * width * 3, width * 3, 3, 1};
     const int32_t sz1[4] = {1, height, width, 1}, st1[4] = {height * width, width, 1, 1};
     fill_accessor(params.rayFeaturesGrad, const_cast<float*>(g_features), sz3, st3);
@@ -61,5 +64,29 @@ void ref_grt_trace_bwd(uint32_t n, const float* transforms, const float* density
     params.particleFeaturesGrad = g_sph48;
     launch_raygen(width, height);
 }
+
+// forward results (features / density / hit_distance2) and upstream gradients in, particle gradients out ([n,12], [n,48],
+// zero-filled by the caller like optixTracer.cpp:1010-1031 does)
+void ref_grt_trace_bwd(uint32_t n, const float* transforms, const float* density12, const float* sph48, int width, int height,
+                       const float* ray_to_world, const float* ray_o, const float* ray_d, const float* scene_aabb6, float min_transmittance,
+                       float min_response, float min_alpha, unsigned sph_degree, const float* features, const float* density,
+                       const float* hit_distance2, const float* g_features, const float* g_density, const float* g_hit_distance,
+                       float* g_density12, float* g_sph48) {
+    set_scene(n, transforms);
+    bwd_params_and_launch(n, density12, sph48, width, height, ray_to_world, ray_o, ray_d, scene_aabb6, min_transmittance, min_response, min_alpha, sph_degree,
+                          features, density, hit_distance2, g_features, g_density, g_hit_distance, g_density12, g_sph48, 0, nullptr, nullptr);
+}
+
+#ifdef REF_PRIMITIVE
+void ref_grt_trace_bwd_mesh(uint32_t n, uint32_t triangles_per_particle, const float* vertices, const int32_t* triangles, const float* density12,
+                            const float* sph48, int width, int height, const float* ray_to_world, const float* ray_o, const float* ray_d,
+                            const float* scene_aabb6, float min_transmittance, float min_response, float min_alpha, unsigned sph_degree,
+                            const float* features, const float* density, const float* hit_distance2, const float* g_features, const float* g_density,
+                            const float* g_hit_distance, float* g_density12, float* g_sph48) {
+    bwd_params_and_launch(n, density12, sph48, width, height, ray_to_world, ray_o, ray_d, scene_aabb6, min_transmittance, min_response, min_alpha, sph_degree,
+                          features, density, hit_distance2, g_features, g_density, g_hit_distance, g_density12, g_sph48, triangles_per_particle, vertices,
+                          triangles);
+}
+#endif
 
 }  // extern "C"

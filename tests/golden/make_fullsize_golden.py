@@ -153,9 +153,15 @@ def make_grt():
     bw.ref_grt_trace_bwd(*common, _p(feat), _p(den), _p(hit), _p(g_rad), _p(g_dns), _p(g_hit), _p(gd), _p(gs))
     touched = np.flatnonzero((np.abs(gd).max(1) > 0) | (np.abs(gs).max(1) > 0))
     print(f"grt c3: backward programs in {time.time() - t0:.1f} s; {len(touched)} particles touched", flush=True)
+    # gradient rows: of the ~33 k touched particles the 1500 with the largest gradients (they set the norm the comparison is relative to)
+    # and 2500 random others are stored (rows = positions in `touched`); the full `touched` list stays (nothing else may carry a gradient)
+    mag = np.abs(gd[touched][:, :11]).max(1)
+    big = np.argsort(mag)[-1500:]
+    rest = np.setdiff1d(np.arange(len(touched)), big)
+    sel = np.sort(np.concatenate([big, np.random.default_rng(3).choice(rest, min(2500, len(rest)), replace=False)]))
     np.savez_compressed(os.path.join(HERE, "fullsize_grt_c3_1m_800.npz"), n=n, W=W, H=H, median_scale=ms, ys=ys, xs=xs, features=feat, density=den,
                         hit_distance=hit, hits_count=cnt, visible=np.flatnonzero(vis).astype(np.uint32), touched=touched.astype(np.uint32),
-                        grad_density=gd[touched], grad_sph=gs[touched])
+                        grad_rows=sel.astype(np.uint32), grad_density=gd[touched][sel], grad_sph=gs[touched][sel])
     print("wrote fullsize_grt_c3_1m_800.npz", flush=True)
 
 

@@ -337,6 +337,52 @@ def make_grt_trace():
     print("wrote grt_trace.npz; hits per ray:", [float(out[f"s{k}_hits_count"].mean()) for k in range(len(GRT_TRACE_SCENES))])
 
 
+MESH_PRIMITIVES = {"icosahedron": (1, "IcosaHedron"), "octahedron": (2, "OctraHedron"), "tetrahedron": (3, "TetraHedron"), "diamond": (4, "Diamond")}
+
+
+def make_grt_trace_mesh():
+    """tests/golden/grt_trace_mesh.npz: the reference's 3DGRT forward / backward programs compiled for the TRIANGLE-MESH proxies
+    (render.primitive_type icosahedron - the paper's configuration, configs/paper/3dgrt/base_ours_reference.yaml:16 - octahedron,
+    tetrahedron, diamond) over the emulated OptiX: the particles' meshes come from the reference's own mesh kernels
+    (particlePrimitives.cu:63-496 through oracle/ref/ref_grt_proxies.cpp), the traversal offers every front-facing triangle the ray crosses
+    (oracle/ref/ref_grt_emul.inl).  Scene 0 of GRT_TRACE_SCENES for every primitive, scene 1 for the icosahedron too."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import make_scene
+    px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    px.ref_enclosing_mesh.restype = C.c_uint
+    out = {}
+    for name, (code, tag) in MESH_PRIMITIVES.items():
+        fw = C.CDLL(os.path.join(REF, f"libref_grt_trace_{tag}_deg4.so"))
+        bw = C.CDLL(os.path.join(REF, f"libref_grt_trace_bwd_{tag}_deg4.so"))
+        for k, kw in enumerate(GRT_TRACE_SCENES[:2 if name == "icosahedron" else 1]):
+            sc = make_scene(**kw)
+            d12, sph = np.ascontiguousarray(sc["density12"]), np.ascontiguousarray(sc["sph"])
+            n, H, W = len(d12), kw["height"], kw["width"]
+            pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
+                                  np.ascontiguousarray(d12[:, 3]))
+            verts, tris, nv = np.zeros((n * 12, 3), F), np.zeros((n * 20, 3), np.int32), C.c_uint(0)
+            nt = px.ref_enclosing_mesh(code, C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(verts), _p(tris),
+                                       C.byref(nv))
+            verts, tris = np.ascontiguousarray(verts[:n * nv.value]), np.ascontiguousarray(tris[:n * nt])
+            box = np.concatenate([verts.min(0), verts.max(0)]).astype(F)
+            r2w = np.ascontiguousarray(np.asarray(sc["batch"]["T_to_world"][0], F)[:3, :4])
+            ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)) for a in sc["rays"])
+            feat, den, hit, nrm = np.zeros((H, W, 3), F), np.zeros((H, W, 1), F), np.zeros((H, W, 2), F), np.zeros((H, W, 3), F)
+            cnt, vis = np.zeros((H, W, 1), F), np.zeros(n, np.int32)
+            common = (C.c_uint(n), C.c_uint(nt), _p(verts), _p(tris), _p(d12), _p(sph), W, H, _p(r2w), _p(ro), _p(rd), _p(box), C.c_float(MIN_T_GRT),
+                      C.c_float(MIN_RESPONSE), C.c_float(MIN_ALPHA), C.c_uint(3))
+            fw.ref_grt_trace_fwd_mesh(*common, _p(feat), _p(den), _p(hit), _p(nrm), _p(cnt), _p(vis))
+            g_rad, g_dns, g_hit = grt_trace_upstream(H, W)
+            gd, gs = np.zeros((n, 12), F), np.zeros((n, 48), F)
+            bw.ref_grt_trace_bwd_mesh(*common, _p(feat), _p(den), _p(hit), _p(g_rad), _p(g_dns), _p(g_hit), _p(gd), _p(gs))
+            for key, a in dict(features=feat, density=den, hit_distance=hit, hits_count=cnt, visibility=vis, grad_density=gd, grad_sph=gs, scene_box=box).items():
+                out[f"{name}_s{k}_{key}"] = a
+            print(f"{name} scene {k}: {nt} triangles per particle, hits per ray {cnt.mean():.1f} (max {cnt.max():.0f}), opacity {den.mean():.3f}")
+    np.savez_compressed(os.path.join(HERE, "grt_trace_mesh.npz"), **out)
+    print("wrote grt_trace_mesh.npz")
+
+
 def make_grt_trace_nht():
     """tests/golden/grt_trace_nht.npz: the reference's SLANG forward pipeline (referenceSlangOptix.cu: raygen round loop, intersection, any-hit
     k-buffer) in the neural-harmonic-features configuration, on the host over the emulated OptiX (oracle/ref/ref_grt_trace_slang.cpp), on the
@@ -709,7 +755,7 @@ def make_playground():
 if __name__ == "__main__":
     import sys
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
-    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "gut_render", "playground", "gut_nht", "grt_trace_nht", "grt_trace_slang_sh"]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "grt_trace_mesh", "gut_render", "playground", "gut_nht", "grt_trace_nht", "grt_trace_slang_sh"]
     if "--adam-only" in sys.argv:
         which = ["adam"]
     if "per_hit" in which:
@@ -725,6 +771,8 @@ if __name__ == "__main__":
         make_grt_proxies()
     if "grt_trace" in which:
         make_grt_trace()
+    if "grt_trace_mesh" in which:
+        make_grt_trace_mesh()
     if "gut_render" in which:
         make_gut_render()
     if "playground" in which:
