@@ -40,6 +40,8 @@ WORKLOADS = {
     # model.feature_type = nht at the headline size
     "c4_nht_1m_1080p": (1_000_000, 1920, 1080, 0.01),
     "c3_grt_nht_1m_800": (1_000_000, 800, 800, 0.01),
+    # render.primitive_type = icosahedron (the reference paper's 3DGRT configuration, configs/paper/3dgrt/base_ours_reference.yaml:16): tree walk
+    "c3_grt_icosa_1m_800": (1_000_000, 800, 800, 0.01),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -201,7 +203,7 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
                              "model": {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1},
                                                                                "interpolation_type": "barycentric"}}})
     else:
-        tracer = grt.Tracer({"render": {"enable_kernel_timings": True}})
+        tracer = grt.Tracer({"render": dict({"enable_kernel_timings": True}, **({"primitive_type": "icosahedron"} if "icosa" in name else {}))})
     g = syn.SimpleGaussians(d12, sph, device=dev)
     g_fd_np, _ = syn.upstream_grads(W, H)
     g_fd = torch.as_tensor(g_fd_np, device=dev)
