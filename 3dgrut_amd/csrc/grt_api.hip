@@ -276,8 +276,9 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
     GrtLists lists = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     h->list_entries = 0;
     h->log_lists = lists;   // the list scratch is about to be overwritten: a pending backward of an older forward walks the tree
-    // (triangle-mesh proxies: the lists' per-packet distance bounds are derived for the instance path's hit distance - the tree walk serves them)
-    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && h->cfg.primitive_type == GRUT_PRIM_INSTANCES) {
+    // (triangle-mesh proxies bin by the box of the polyhedron's vertices and start from bounding-sphere distance intervals, which the packets'
+    // first tests refine to exact ones like the instance path's; GRUT_GRT_NO_MESH_LISTS=1 keeps them on the tree walk)
+    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && (h->cfg.primitive_type == GRUT_PRIM_INSTANCES || !getenv("GRUT_GRT_NO_MESH_LISTS"))) {
         const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
         if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
         GRUT_CHECK(h->l_flags.ensure(64));

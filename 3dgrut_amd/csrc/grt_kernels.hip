@@ -675,7 +675,7 @@ struct ListEntry {
 };
 // one entry per lane: the particle's records are gathered and its packet-specific bounds computed on the spot (one lane per entry:
 // a few dozen operations per 64 entries of wave time)
-__device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const GrtCone& cone, float dmin, float dmax, uint32_t e, uint32_t end) {
+__device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const GrtCone& cone, float dmin, float dmax, uint32_t e, uint32_t end, int prim = GRUT_PRIM_INSTANCES) {
     ListEntry x;
     x.a = x.b = x.e = make_float4(0.f, 0.f, 0.f, 0.f);
     x.id = 0xFFFFFFFFu; x.lo = 3.0e38f; x.hi = -3.0e38f; x.key = 3.0e38f;   // dead for every ray, beyond every bound
@@ -695,6 +695,16 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
             if (word & kGrtEntryRefined) {   // the packet's own rays have been through this entry (see list_round)
                 const unsigned long long raw = __hip_atomic_load(reinterpret_cast<unsigned long long*>(L.bounds + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 x.lo = __uint_as_float((uint32_t)raw); x.hi = __uint_as_float((uint32_t)(raw >> 32));
+            } else if (prim != GRUT_PRIM_INSTANCES) {
+                // mesh proxies: until the packet's first test refines it, the entry distance lies within the bounding sphere of the
+                // polyhedron's box around the centre's distance (the key is that sphere's near end over the frame's direction lengths)
+                const GrtPolyhedron& ph = kGrtPolyhedra[prim];
+                const float k0 = ph.ext[0] * ph.ext[0] / (x.a.x * x.a.x + x.a.y * x.a.y + x.a.z * x.a.z),
+                            k1 = ph.ext[1] * ph.ext[1] / (x.a.w * x.a.w + x.b.x * x.b.x + x.b.y * x.b.y),
+                            k2 = ph.ext[2] * ph.ext[2] / (x.b.z * x.b.z + x.b.w * x.b.w + x.e.x * x.e.x);
+                x.lo = vk.w;
+                x.hi = ((sqrtf(dot(v, v)) * (1.f + 2e-6f) + sqrtf(k0 + k1 + k2) * 1.00002f) / dmin) * (1.f + 2e-6f) + 1e-30f;
+                x.fresh = true;
             } else {
                 packet_bounds(cone, v, dot(v, v), x.a, x.b, x.e.x, vk.w, 3.0e38f, dmin, dmax, x.lo, x.hi);
                 x.fresh = true;
@@ -743,7 +753,7 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
         if (pass == 1 && !(deferred && wmax_bound > mark)) break;
         bool seen_live = pass == 1;   // (the scan start only moves in the first pass)
         uint32_t base = start & ~63u;
-        ListEntry nxt = load_list_entry(L, cone, dmin, dmax, base + lane, le);
+        ListEntry nxt = load_list_entry(L, cone, dmin, dmax, base + lane, le, r.prim);
         if (COUNT && lane == 0) tc.batch_loads++;
         while (base < le) {
             s_ent[lane * 3 + 0] = nxt.a; s_ent[lane * 3 + 1] = nxt.b; s_ent[lane * 3 + 2] = nxt.e;
@@ -752,7 +762,7 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
             const unsigned long long fresh = REFINE ? __ballot(nxt.fresh) : 0ull;
             __syncthreads();   // single-wave workgroup: orders the LDS hand-off
             const uint32_t bend = min(le, base + 64u);
-            nxt = load_list_entry(L, cone, dmin, dmax, bend + lane, le);   // the following batch travels while this one is tested
+            nxt = load_list_entry(L, cone, dmin, dmax, bend + lane, le, r.prim);   // the following batch travels while this one is tested
             if (COUNT && lane == 0 && bend < le) tc.batch_loads++;
             const bool mine = (base + (uint32_t)lane >= start) && (base + (uint32_t)lane < bend);
             const unsigned long long beyond = __ballot(mine && my_key > wmax_bound);           // a suffix of the batch (keys ascend)
@@ -2874,14 +2884,23 @@ __device__ __forceinline__ bool packet_hit(const GrtCone& k, const GrtPyramid& p
 // bounds: the hit "distance" t of a candidate is the ray parameter of the point closest to the centre in the proxy's metric; that point
 // lies within sqrt(3) max(kscl) of the centre whenever the ray touches the proxy box (the box holds a point of the ray at metric distance
 // <= sqrt 3 and the closest one is no farther), so |o + t d - mu| <= Rt and (|v| - Rt) / |d| <= t <= (|v| + Rt) / |d|
-__device__ __forceinline__ BinParticle bin_particle(const float4& a, const float4& b, const float4& e, f3 o, float dmin, float dmax) {
+__device__ __forceinline__ BinParticle bin_particle(const float4& a, const float4& b, const float4& e, f3 o, float dmin, float dmax, int prim) {
     BinParticle q;
-    const float k0 = 1.f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), k1 = 1.f / sqrtf(a.w * a.w + b.x * b.x + b.y * b.y),
-                k2 = 1.f / sqrtf(b.z * b.z + b.w * b.w + e.x * e.x);   // rows of W = R^T / kscl
-    q.Rs = sqrtf(k0 * k0 + k1 * k1 + k2 * k2) * 1.00001f;
+    float k0 = 1.f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), k1 = 1.f / sqrtf(a.w * a.w + b.x * b.x + b.y * b.y),
+          k2 = 1.f / sqrtf(b.z * b.z + b.w * b.w + e.x * e.x);   // rows of W = R^T / kscl
     // half axis i = (row i of W) / |row i|^2: W h_i = e_i, the box is |W (x - mu)|_inf <= 1
     q.h0 = mk3(a.x, a.y, a.z) * (k0 * k0); q.h1 = mk3(a.w, b.x, b.y) * (k1 * k1); q.h2 = mk3(b.z, b.w, e.x) * (k2 * k2);
-    const float Rt = 1.7320509f * fmaxf(k0, fmaxf(k1, k2)) * 1.00001f;
+    float Rt = 1.7320509f * fmaxf(k0, fmaxf(k1, k2)) * 1.00001f;
+    if (prim != GRUT_PRIM_INSTANCES) {
+        // triangle-mesh proxies: the box of the polyhedron's vertices (half extents ext_i along the proxy's axes) stands in for the unit
+        // cube in every separation test, and the reported distance is the ENTRY into the polyhedron - a point of that box: within its
+        // bounding sphere of the centre's distance along any ray
+        const GrtPolyhedron& ph = kGrtPolyhedra[prim];
+        k0 *= ph.ext[0]; k1 *= ph.ext[1]; k2 *= ph.ext[2];
+        q.h0 = q.h0 * ph.ext[0]; q.h1 = q.h1 * ph.ext[1]; q.h2 = q.h2 * ph.ext[2];
+        Rt = sqrtf(k0 * k0 + k1 * k1 + k2 * k2) * 1.00002f;
+    }
+    q.Rs = sqrtf(k0 * k0 + k1 * k1 + k2 * k2) * 1.00001f;
     q.v = mk3(e.y - o.x, e.z - o.y, e.w - o.z);
     q.L2 = dot(q.v, q.v);
     const float L = sqrtf(q.L2);
@@ -3159,7 +3178,7 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
         const float4* rec = reinterpret_cast<const float4*>(bvh.inst) + 3 * (size_t)i;
         a = rec[0]; b = rec[1]; e = rec[2];
     }
-    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
+    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim);
     const BinOut cache = {nullptr, nullptr, pairs, pair_n};
     const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H);
     const GrtGrid G = grt_block_grid(block_cones, gx * gy, gx);
@@ -3238,7 +3257,7 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
         }
         const bool again = have && np == kGridWaveTested;
         if (__any(again)) {
-            const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
+            const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim);
             GridParticle g = grid_particle(G, gx, gy, again, q, P.bin_lane_area);
             if (!again) g.kind = 0;
             uint32_t n = 0u;
@@ -3250,7 +3269,7 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
     const bool cached = have && np <= (uint32_t)kBinCachedPairs;
     emit_cached_pairs(P, lane, cached, p, np, off, end, out);
     // (what the cache did not hold: tested again; pads whatever the masks left unwritten, which is not expected)
-    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax);
+    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim);
     const bool again = have && !cached;
     if (__any(again)) bin_pairs<true>(P, block_cones, super_cones, lane, again, q, p, off, again ? end : off, out);
     if (cached) {

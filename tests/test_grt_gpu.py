@@ -286,7 +286,7 @@ def test_mesh_proxies_match_reference_programs_golden(prim):
         g_rad, g_dns, g_hit = make_golden.grt_trace_upstream(H, W)
         gpu = _render(scene, g_rad, g_dns, g_hit, primitive_type=prim)
         out = gpu["out"]
-        assert int(gpu["tracer"].tracer_wrapper.stats().list_entries) == 0     # (the tree walk serves the mesh proxies)
+        assert int(gpu["tracer"].tracer_wrapper.stats().list_entries) > 0      # (one ray origin: the packet lists serve the mesh proxies too)
         cnt = out["hits_count"][0].detach().cpu().numpy()
         flips = (cnt != g[f"{prim}_s{k}_hits_count"])[..., 0]
         assert flips.mean() <= 0.01, f"scene {k}: {int(flips.sum())} rays with a different number of accepted hits"
@@ -334,6 +334,19 @@ def test_mesh_proxies_hit_order_equals_oracle(prim):
     assert rel_err(gd[:, :11], rd[:, :11]) < 1e-3 and rel_err(gs, rs) < 1e-3
 
 
+@pytest.mark.parametrize("prim", ["icosahedron", "octahedron", "tetrahedron", "diamond"])
+def test_mesh_proxy_packet_lists_equal_the_tree_walk(monkeypatch, prim):
+    """The packet lists with the mesh proxies: binning by the box of the polyhedron's vertices, entry-distance intervals from the bounding
+    sphere until a packet's first test refines them - every output and every ray's sequence of processed particles must equal the tree
+    walk's, bit for bit (large and tiny particles, partial packets at the border)."""
+    scene = _scene(20000, 100, 60, 0.03)
+    (a, n_lists), (b, n_walk) = _hits_with(scene, monkeypatch, False, primitive_type=prim), _hits_with(scene, monkeypatch, True, primitive_type=prim)
+    assert n_lists > 0 and n_walk == 0
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert a[-1].max() > 10    # processed hits per ray
+
+
 def test_unsupported_primitives_are_refused():
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     for prim in ("trihexa", "trisurfel", "sphere", "custom"):
@@ -342,13 +355,13 @@ def test_unsupported_primitives_are_refused():
 
 
 # ---- packet lists (frames with one ray origin) against the tree walk -------------------------------------------------------
-def _hits_with(scene, monkeypatch, no_lists, rays_ori=None, rays_dir=None):
+def _hits_with(scene, monkeypatch, no_lists, rays_ori=None, rays_dir=None, **render_kw):
     import torch
     if no_lists:
         monkeypatch.setenv("GRUT_GRT_NO_LISTS", "1")
     else:
         monkeypatch.delenv("GRUT_GRT_NO_LISTS", raising=False)
-    tr = _tracer()
+    tr = _tracer(**render_kw)
     g = syn.SimpleGaussians(scene["density12"], scene["sph"])
     tr.build_acc(g, rebuild=True)
     nat = tr.tracer_wrapper
