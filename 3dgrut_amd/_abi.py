@@ -151,7 +151,7 @@ EXPORTED_SYMBOLS = [
     "gut_debug_fetch", "gut_debug_fetch_work", "grut_debug_pose_from_c2w", "grut_debug_frame_poses", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats", "grt_debug_fetch_work",
-    "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_debug_backward_signature", "grt_build_mesh_bvh", "grt_trace_hybrid",
+    "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_debug_fetch_lists", "grt_debug_backward_signature", "grt_build_mesh_bvh", "grt_trace_hybrid",
     "grut_selective_adam_update", "grut_pack_particles", "grut_unpack_particle_grads", "grut_activate_pack", "grut_activate_pack_backward",
     "grut_last_error", "grut_abi_version", "grut_set_allocator", "gut_trim", "grt_trim",
 ]
@@ -207,6 +207,8 @@ def _declare(lib):
     lib.grut_inclusive_scan_u32.restype = C.c_int
     lib.grut_scan_scratch_bytes.argtypes = [C.c_uint32]
     lib.grut_scan_scratch_bytes.restype = C.c_uint64
+    lib.grt_debug_fetch_lists.argtypes = [C.c_void_p, vp, up, up, C.c_uint64]
+    lib.grt_debug_fetch_lists.restype = C.c_int
     lib.grt_create.argtypes = [C.POINTER(GrtConfig), C.POINTER(C.c_void_p)]
     lib.grt_create.restype = C.c_int
     lib.grt_destroy.argtypes = [C.c_void_p]

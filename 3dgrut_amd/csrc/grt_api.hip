@@ -730,4 +730,20 @@ int grt_debug_fetch_instances(GrtHandle* h, void* stream_, float* instances) {
     return GRUT_OK;
 }
 
+// copies the packet lists of the last forward (GrtStats::list_entries > 0) to caller DEVICE buffers: ranges [blocks, 2] u32 ([first, last) of each
+// 8x8 ray packet, row-major block index) and entries [list_entries] u32 (particle ids; the top bit is the library's "refined" flag)
+int grt_debug_fetch_lists(GrtHandle* h, void* stream_, uint32_t* ranges, uint32_t* entries, uint64_t entry_capacity) {
+    GRUT_REQUIRE(h && ranges && entries, "grt_debug_fetch_lists: null argument");
+    if (!h->log_lists.ranges || h->list_entries == 0 || h->list_entries > entry_capacity) {
+        set_last_error("grt_debug_fetch_lists: no packet lists kept (a training forward of a one-origin frame keeps them) or capacity %llu < %llu entries",
+                       (unsigned long long)entry_capacity, (unsigned long long)h->list_entries);
+        return GRUT_ERR_NOT_READY;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    const uint32_t blocks = div_up((uint32_t)h->log_W, 8) * div_up((uint32_t)h->log_H, 8);
+    GRUT_HIP(hipMemcpyAsync(ranges, h->log_lists.ranges, (size_t)blocks * 8, hipMemcpyDeviceToDevice, s));
+    GRUT_HIP(hipMemcpyAsync(entries, h->log_lists.entries, (size_t)h->list_entries * 4, hipMemcpyDeviceToDevice, s));
+    return GRUT_OK;
+}
+
 }  // extern "C"

@@ -170,6 +170,15 @@ class _GrtNative:
         _abi.check(self.lib.grt_debug_backward_signature(self.handle, _ptr(sig), _ptr(cnt)), "grt_debug_backward_signature")
         return sig, cnt
 
+    def fetch_lists(self, width, height, device):
+        """(ranges [blocks,2], entries [I]) int32 tensors holding the packet lists of the last train-mode forward (grt_debug_fetch_lists)."""
+        n = int(self.stats().list_entries)
+        blocks = ((width + 7) // 8) * ((height + 7) // 8)
+        ranges = torch.zeros((blocks, 2), dtype=torch.int32, device=device)
+        entries = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+        _abi.check(self.lib.grt_debug_fetch_lists(self.handle, _stream_ptr(device), _ptr(ranges), _ptr(entries), n), "grt_debug_fetch_lists")
+        return ranges, entries[:n]
+
     def instances(self, n, device):
         out = torch.zeros((n, 12), dtype=torch.float32, device=device)
         _abi.check(self.lib.grt_debug_fetch_instances(self.handle, _stream_ptr(device), _ptr(out)), "grt_debug_fetch_instances")

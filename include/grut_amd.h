@@ -462,6 +462,10 @@ int grt_debug_forward_hits(GrtHandle* handle, void* stream, const GrtFrame* fram
 int grt_debug_backward_signature(GrtHandle* handle, unsigned long long* ray_signature, uint32_t* ray_hit_count);
 /* proxy instance records of the last build: [N,12] f32 = rows of W = diag(1/kscl) R^T, then mu (object ray: o' = W (o - mu)) */
 int grt_debug_fetch_instances(GrtHandle* handle, void* stream, float* instances);
+/* The per-packet candidate lists of the last train-mode forward (GrtStats::list_entries of them) to caller DEVICE buffers: ranges [blocks,2]
+ * ([first, last) of each 8x8 ray packet, row-major), entries [list_entries] particle ids (top bit: internal flag).  GRUT_ERR_NOT_READY when
+ * the tree walk served the frame or the capacity is too small.  The parity tests hand them to the CPU checker as a candidate prefilter. */
+int grt_debug_fetch_lists(GrtHandle* handle, void* stream, uint32_t* ranges, uint32_t* entries, uint64_t entry_capacity);
 
 int grt_timings(GrtHandle* handle, float* forward_ms, float* backward_ms, float* build_ms);
 int grt_stats(GrtHandle* handle, GrtStats* stats);

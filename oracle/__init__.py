@@ -269,6 +269,24 @@ def grt_proxies(cfg, positions, rotations, scales, densities, dtype=np.float32):
     return dict(inst=inst, aabb=aabb, slack=slack, scene=scene)
 
 
+_prefilter_keepalive = {}
+
+
+def grt_set_candidate_prefilter(ranges=None, entries=None, ray_packet=None):
+    """Restricts every ray's all-pairs candidate scan to the particles of its packet's list (orc_grt_set_candidate_prefilter; both builds).
+    ranges [blocks,2] u32, entries [I] u32, ray_packet [nrays] u32 = packet index of each ray of the NEXT grt_forward / backward calls.
+    Call without arguments to clear."""
+    for dtype in (np.float32, np.float64):
+        l = lib(dtype)
+        if ranges is None:
+            l.orc_grt_set_candidate_prefilter(None, None, None)
+            _prefilter_keepalive.clear()
+        else:
+            r, e, p = (np.ascontiguousarray(a, np.uint32) for a in (ranges, entries, ray_packet))
+            _prefilter_keepalive[dtype] = (r, e, p)
+            l.orc_grt_set_candidate_prefilter(_p(r), _p(e), _p(p))
+
+
 def grt_forward(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, ray_o, ray_d, inst=None, scene=None, dbg_cap=0,
                 dtype=np.float32):
     """OptixTracer::trace semantics.  ray_to_world: [3,4]; rays: [H,W,3] in ray space.  `inst` / `scene` may be supplied

@@ -335,8 +335,30 @@ static int hit_cmp(const void* a, const void* b) {
     return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
 }
 /* all candidates of one ray, sorted by (t, id); brute force over the particles */
-static uint32_t ray_candidates(uint32_t N, const real* inst12, v3 o, v3 d, grt_hit* out) {
+/* Optional prefilter (test infrastructure for the 1 M-particle frames): the per-packet candidate lists the GPU built for its own forward -
+ * `ranges[packet][2]` into `entries` (particle ids; the top bit is a flag of the GPU's, 0xFFFFFFFF pads), `ray_packet[ray]` = the 8x8 packet
+ * of each ray.  A list holds every particle whose proxy box some ray of the packet can touch (conservative by construction), so
+ * restricting the all-pairs scan to it must not change any ray's candidate set: tests/parity_util.grt_full_parity checks exactly that on the
+ * rays it also runs through all pairs, then uses the prefilter to compare 15 x more rays. */
+static const uint32_t *g_pre_ranges = NULL, *g_pre_entries = NULL, *g_pre_ray_packet = NULL;
+void orc_grt_set_candidate_prefilter(const uint32_t* ranges, const uint32_t* entries, const uint32_t* ray_packet) {
+    g_pre_ranges = ranges; g_pre_entries = entries; g_pre_ray_packet = ray_packet;
+}
+static uint32_t ray_candidates(uint32_t N, const real* inst12, v3 o, v3 d, grt_hit* out, uint32_t ray) {
     uint32_t n = 0;
+    if (g_pre_ranges && ray != 0xFFFFFFFFu) {
+        const uint32_t p = g_pre_ray_packet[ray];
+        for (uint32_t e = g_pre_ranges[2 * p]; e < g_pre_ranges[2 * p + 1]; ++e) {
+            uint32_t i = g_pre_entries[e];
+            if (i == 0xFFFFFFFFu) continue;
+            i &= 0x7FFFFFFFu;
+            if (i >= N) continue;
+            const grt_cand c = candidate(inst12 + 12 * (size_t)i, o, d, R_(9.0));
+            if (c.ok) { out[n].t = c.t; out[n].id = i; out[n].tnear = c.tnear; out[n].tfar = c.tfar; n++; }
+        }
+        qsort(out, n, sizeof(grt_hit), hit_cmp);
+        return n;
+    }
     for (uint32_t i = 0; i < N; ++i) {
         const grt_cand c = candidate(inst12 + 12 * (size_t)i, o, d, R_(9.0)); /* hitMaxParticleSquaredDistance, pipelineParameters.h:71 */
         if (c.ok) { out[n].t = c.t; out[n].id = i; out[n].tnear = c.tnear; out[n].tfar = c.tfar; n++; }
@@ -377,7 +399,7 @@ int orc_grt_trace_fwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
             real tEnter, tExit;
             scene_interval(scene6, o, d, &tEnter, &tExit);
             real tLast = r_max(0, tEnter - eps);
-            const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+            const uint32_t n = ray_candidates(N, inst12, o, d, cands, r);
             uint32_t ndbg = 0;
             grt_hit buf[GRT_MAX_K];
             while ((tLast <= tExit) && (s.T > min_T)) {
@@ -445,7 +467,7 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
             scene_interval(scene6, o, d, &tEnter, &tExit);
             real startT = r_max(0, tEnter - eps);
             const real endT = r_min(maxHit, tExit) + eps;
-            const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+            const uint32_t n = ray_candidates(N, inst12, o, d, cands, r);
             grt_hit buf[GRT_MAX_K];
             uint32_t ndbg = 0;
             while (startT < endT) {
@@ -541,7 +563,7 @@ int orc_grt_trace_nht_fwd(const GrtConfig* cfg, const int* nht, uint32_t N, cons
             real tEnter, tExit;
             scene_interval(scene6, o, d, &tEnter, &tExit);
             real tLast = r_max(0, tEnter - eps);
-            const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+            const uint32_t n = ray_candidates(N, inst12, o, d, cands, r);
             uint32_t ndbg = 0;
             grt_hit buf[GRT_MAX_K];
             while ((tLast <= tExit) && (T > min_T)) {
@@ -621,7 +643,7 @@ int orc_grt_trace_nht_bwd(const GrtConfig* cfg, const int* nht, uint32_t N, cons
             scene_interval(scene6, o, d, &tEnter, &tExit);
             real startT = r_max(0, tEnter - eps);
             const real endT = r_min(maxHit, tExit) + eps;
-            const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+            const uint32_t n = ray_candidates(N, inst12, o, d, cands, r);
             grt_hit buf[GRT_MAX_K];
             while (startT < endT) {
                 const int k = trace_round(cands, n, startT + eps, endT, K, buf);
@@ -726,7 +748,7 @@ int orc_grt_ray_candidates(uint32_t N, const real* inst12, const real* ray_to_wo
     const v3 o = xform_point(ray_to_world12, v3_make(ray_o3[0], ray_o3[1], ray_o3[2]));
     const v3 d = xform_dir(ray_to_world12, v3_make(ray_d3[0], ray_d3[1], ray_d3[2]));
     grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
-    const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+    const uint32_t n = ray_candidates(N, inst12, o, d, cands, 0xFFFFFFFFu /* no prefilter: a ray outside the frame's packets */);
     uint32_t k = 0;
     for (; k < n && k < cap; ++k) { out_id[k] = cands[k].id; out_t[k] = cands[k].t; out_tnear[k] = cands[k].tnear; out_tfar[k] = cands[k].tfar; }
     free(cands);
@@ -821,7 +843,7 @@ static void trace_segment(const GrtConfig* cfg, uint32_t N, const real* density1
     t0 = r_max(t0, tmin); t1 = r_min(t1, tmax);
     real tLast = r_max(0, t0 - eps);
     grt_ray_state s; s.T = *T; s.rad = *rad; s.depth = 0; s.normal = v3_make(0, 0, 0);
-    const uint32_t n = ray_candidates(N, inst12, o, d, cands);
+    const uint32_t n = ray_candidates(N, inst12, o, d, cands, 0xFFFFFFFFu /* no prefilter: a ray outside the frame's packets */);
     grt_hit buf[GRT_MAX_K];
     while ((tLast <= t1) && (s.T > min_T)) {
         const int k = trace_round(cands, n, tLast + eps, t1 + eps, K, buf);

@@ -520,7 +520,7 @@ def assert_gut_full_parity(stats, max_flip_frac=2e-3, max_rounding_frac=2e-4):
 # ---------------------------------------------------------------------------------------------------------------------
 # 3DGRT at BASELINE config 3's sizes
 # ---------------------------------------------------------------------------------------------------------------------
-def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_cap=192, with_backward=True, log=None):
+def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_cap=192, with_backward=True, log=None, wide_stride=0):
     """HIP 3DGRT against the oracle on every `ray_stride`-th ray of the frame (the oracle tests every particle against every
     ray: stride 1 at 100 k particles / 400x400, a >= 4 k-ray subsample at 1 M particles / 800x800).
 
@@ -599,6 +599,39 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
     stats["T_max_rgb_err_in_flips"] = float(e_rgb[F].max()) if F.any() else 0.0
     if ray_stride == 1:
         stats["T_visibility_differs"] = int((vis != (ora["visibility"] != 0)).sum())
+    # ---- stage W: a much wider ray sample, the oracle's all-pairs scan restricted to each ray's PACKET LIST as the GPU built it ----------
+    # (a list holds every particle whose proxy box some ray of the packet can touch; that the restriction changes nothing is CHECKED on the
+    # rays of stage T, which went through all pairs: every output of the oracle must be bit-identical with and without it)
+    if wide_stride:
+        out = tr.render(g, batch, train=True)          # a train-mode forward keeps its lists
+        torch.cuda.synchronize()
+        ranges_t, entries_t = nat.fetch_lists(w, h, "cuda")
+        ranges, entries = ranges_t.cpu().numpy().view(np.uint32), entries_t.cpu().numpy().view(np.uint32)
+        gxp = (w + 7) // 8
+        packet_of = lambda pix: ((pix // w) // 8) * gxp + (pix % w) // 8
+        t0 = time.time()
+        oracle.grt_set_candidate_prefilter(ranges, entries, packet_of(sel).astype(np.uint32))
+        chk = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro_s, rd_s, inst=inst, scene=scene_aabb, dbg_cap=hit_cap)
+        stats["W_prefilter_changes_rays"] = int(((chk["hit_ids"] != ora["hit_ids"]).any(1) | (chk["hit_num"] != ora["hit_num"])
+                                                 | (chk["features"].reshape(-1, 3) != ora["features"].reshape(-1, 3)).any(1)
+                                                 | (chk["hit_distance"].reshape(-1, 2) != ora["hit_distance"].reshape(-1, 2)).any(1)).sum())
+        sel2 = np.arange(wide_stride // 2, w * h, wide_stride)
+        ro2, rd2 = ro.reshape(-1, 3)[sel2][None], rd.reshape(-1, 3)[sel2][None]
+        oracle.grt_set_candidate_prefilter(ranges, entries, packet_of(sel2).astype(np.uint32))
+        wide = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro2, rd2, inst=inst, scene=scene_aabb, dbg_cap=hit_cap)
+        oracle.grt_set_candidate_prefilter()
+        stats["t_oracle_wide_s"] = time.time() - t0
+        w_num = wide["hit_num"].astype(np.int64)
+        kk = np.minimum(np.minimum(num[sel2], w_num), hit_cap)
+        live2 = np.arange(hit_cap)[None, :] < kk[:, None]
+        F2 = (num[sel2] != w_num) | (cnt.reshape(-1)[sel2] != wide["hit_count"].reshape(-1))
+        stats.update(W_rays_compared=int(sel2.size), W_list_entries=int(entries.size),
+                     W_rays_hit_number_differs=int((num[sel2] != w_num).sum()),
+                     W_rays_order_differs=int(((ids[sel2] != wide["hit_ids"]) & live2).any(1).sum()),
+                     W_processed_hits_compared=int(kk.sum()), W_flip_rays=int(F2.sum()),
+                     W_max_rgb_err_outside_flips=float(np.abs(feat.reshape(-1, 3)[sel2] - wide["features"].reshape(-1, 3)).max(-1)[~F2].max()),
+                     W_max_opacity_err_outside_flips=float(np.abs(dns.reshape(-1)[sel2] - wide["density"].reshape(-1))[~F2].max()),
+                     W_max_last_hit_t_abs_err_outside_flips=float(np.abs(hit.reshape(-1, 2)[sel2] - wide["hit_distance"].reshape(-1, 2))[~F2, 1].max()))
     # ---- stage G: gradients of the whole frame, upstream gradient zeroed on the flipped rays --------------------------------
     if with_backward and ray_stride == 1:
         t0 = time.time()
@@ -658,6 +691,12 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
 
 def assert_grt_full_parity(stats):
     assert stats["P_instance_rel_err"] < 5e-6, stats
+    if "W_rays_compared" in stats:   # the wide sample through the packet-list prefilter
+        assert stats["W_prefilter_changes_rays"] == 0, "restricting the oracle's scan to the GPU's packet lists changed a ray"
+        assert stats["W_rays_compared"] >= 64000 and stats["W_rays_order_differs"] == 0, stats
+        assert stats["W_flip_rays"] <= max(8, 2e-3 * stats["W_rays_compared"]), stats
+        assert stats["W_max_rgb_err_outside_flips"] < 1e-4 and stats["W_max_opacity_err_outside_flips"] < 1e-4, stats
+        assert stats["W_max_last_hit_t_abs_err_outside_flips"] == 0.0, stats   # the last hit distance is one of the identical candidates' t
     assert stats["T_rays_compared"] >= 4000
     assert stats["T_rays_order_differs"] == 0, stats                                   # BVH hit ordering bit-exact
     assert stats["T_processed_hits_compared"] > 10 * stats["T_rays_compared"]

@@ -72,8 +72,11 @@ def test_gut_nht_frame_matches_oracle_at_baseline_size():
 def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, ray_stride):
     """3DGRT (LBVH + software traversal) against the oracle: the per-ray order of processed particles bit-exact, images within
     1e-4, gradients within 1e-3 relative (full frame at 100 k particles; a 4 k-ray subsample of the 1 M / 800x800 frame)."""
-    stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print)
+    # 1 M particles: every 149th ray through all pairs (4296 rays), then every 9th ray (71 k) with the oracle's scan restricted to the
+    # packet lists the GPU built - checked to change nothing on the 4296
+    stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print, wide_stride=9 if ray_stride > 1 else 0)
     pu.assert_grt_full_parity(stats)
+    pu.record_full_parity(name, stats)
 
 
 def _trimmed(got, ref, n_drop):
