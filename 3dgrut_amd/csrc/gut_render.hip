@@ -231,6 +231,87 @@ __device__ __forceinline__ void stage_entry(const GutParams& P, const RawEntry& 
     rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4; rec[5] = r5;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Half-tile culling of staged entries (round 4).  A tile's list is binned for the 16x16 tile by the reference's 2-D test; the wave owns
+// 16x8 of it, and 36 % of the entries a wave evaluates on the bench frame are accepted by none of its 128 pixels - each
+// of them costs the pair geometry.  The accept test is a LINE - sphere test in the particle's canonical frame (|v x u|^2 < gmax |v|^2:
+// the line through u along v passes the origin closer than r = sqrt(gmax)), so an entry whose sphere misses every line of the wave can
+// be dropped when it is staged, and no result changes.  The lines of a wave are bounded, for ANY camera model, by the pyramid of its
+// own rays: in a frame (a, e1, e2) around the first valid ray every ray is a + x e1 + y e2 up to scale, and the wave reduces
+// [x0, x1] x [y0, y1] once.  M maps the pyramid's four faces to planes through u spanned by (M c, M e2) / (M c, M e1) with c a corner
+// direction; det[M c, M e1, M e2] = det M > 0 fixes which side is out.  The lines also extend BEHIND the apex; that mirror pyramid lies
+// behind the plane through u with normal M e1 x M e2 (the image of the camera plane normal to a), so the entry is dropped only if its
+// sphere is wholly in front of that plane and wholly outside one face.  All comparisons carry r' = 1.001 r + 1e-5 |u| (the accept test
+// and these triple products both cancel to ~1e-7 |u|).
+// ---------------------------------------------------------------------------------------------
+struct WavePyramid {
+    bool on;          // wave-uniform: the bound exists (>= 1 valid ray, every ray within 60 degrees of the first)
+    f3 c00, e1, e2;   // corner direction a + x0 e1 + y0 e2 and the frame's tangents
+    float dx, dy;     // x1 - x0, y1 - y0
+};
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float uniform(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ WavePyramid wave_pyramid(const RayPair& rp) {
+    WavePyramid w;
+    w.on = false;
+    w.c00 = w.e1 = w.e2 = mk3(0.f, 0.f, 0.f);
+    w.dx = w.dy = 0.f;
+    const unsigned long long m0 = __ballot(rp.valid0), m1 = __ballot(rp.valid1);
+    if (!(m0 | m1)) return w;
+    f3 a;
+    if (m0) { const int src = __ffsll((long long)m0) - 1; a = mk3(__shfl(rp.d.x.x, src, 64), __shfl(rp.d.y.x, src, 64), __shfl(rp.d.z.x, src, 64)); }
+    else { const int src = __ffsll((long long)m1) - 1; a = mk3(__shfl(rp.d.x.y, src, 64), __shfl(rp.d.y.y, src, 64), __shfl(rp.d.z.y, src, 64)); }
+    a = a * __builtin_amdgcn_rsqf(dot(a, a));
+    a = mk3(uniform(a.x), uniform(a.y), uniform(a.z));
+    // any unit tangent pair: e1 = a x (the axis a is least aligned with), e2 = a x e1
+    const float ax = fabsf(a.x), ay = fabsf(a.y), az = fabsf(a.z);
+    const f3 k = (ax <= ay && ax <= az) ? mk3(1.f, 0.f, 0.f) : (ay <= az ? mk3(0.f, 1.f, 0.f) : mk3(0.f, 0.f, 1.f));
+    f3 e1 = cross(a, k);
+    e1 = e1 * __builtin_amdgcn_rsqf(dot(e1, e1));
+    const f3 e2 = cross(a, e1);
+    const f3 d0 = mk3(rp.d.x.x, rp.d.y.x, rp.d.z.x), d1 = mk3(rp.d.x.y, rp.d.y.y, rp.d.z.y);
+    const float q0 = dot(d0, a), q1 = dot(d1, a);
+    const float l0 = __builtin_amdgcn_sqrtf(dot(d0, d0)), l1 = __builtin_amdgcn_sqrtf(dot(d1, d1));
+    const bool ok0 = !rp.valid0 || q0 > 0.5f * l0, ok1 = !rp.valid1 || q1 > 0.5f * l1;
+    if (!__all(ok0 && ok1)) return w;
+    const float big = 3.0e38f;
+    const float i0 = 1.f / q0, i1 = 1.f / q1;
+    const float x_0 = dot(d0, e1) * i0, y_0 = dot(d0, e2) * i0, x_1 = dot(d1, e1) * i1, y_1 = dot(d1, e2) * i1;
+    const float xlo = wave_min(fminf(rp.valid0 ? x_0 : big, rp.valid1 ? x_1 : big)), xhi = -wave_min(fminf(rp.valid0 ? -x_0 : big, rp.valid1 ? -x_1 : big));
+    const float ylo = wave_min(fminf(rp.valid0 ? y_0 : big, rp.valid1 ? y_1 : big)), yhi = -wave_min(fminf(rp.valid0 ? -y_0 : big, rp.valid1 ? -y_1 : big));
+    const float pad = 1e-6f;   // tangent units (a pixel is ~1e-3): the rounding of x, y themselves
+    const float x0 = uniform(xlo) - pad, x1 = uniform(xhi) + pad, y0 = uniform(ylo) - pad, y1 = uniform(yhi) + pad;
+    w.on = true;
+    w.c00 = a + e1 * x0 + e2 * y0;
+    w.e1 = mk3(uniform(e1.x), uniform(e1.y), uniform(e1.z));
+    w.e2 = mk3(uniform(e2.x), uniform(e2.y), uniform(e2.z));
+    w.c00 = mk3(uniform(w.c00.x), uniform(w.c00.y), uniform(w.c00.z));
+    w.dx = x1 - x0;
+    w.dy = y1 - y0;
+    return w;
+}
+// does the staged record's sphere miss every line of the wave?  (rec as stage_entry builds it, uniform-origin form: r5.xyz = u)
+__device__ __forceinline__ bool pyramid_misses(const WavePyramid& w, float4 r0, float4 r1, float4 r2, float gmax, float4 r5) {
+    const f3 m0 = mk3(r0.x, r0.y, r0.z), m1 = mk3(r1.x, r1.y, r1.z), m2 = mk3(r2.x, r2.y, r2.z);
+    const f3 u = mk3(r5.x, r5.y, r5.z);
+    const f3 v00 = mk3(dot(m0, w.c00), dot(m1, w.c00), dot(m2, w.c00));
+    const f3 f1 = mk3(dot(m0, w.e1), dot(m1, w.e1), dot(m2, w.e1)), f2 = mk3(dot(m0, w.e2), dot(m1, w.e2), dot(m2, w.e2));
+    const f3 v10 = v00 + f1 * w.dx, v01 = v00 + f2 * w.dy;
+    const float rr = 1.001f * __builtin_amdgcn_sqrtf(gmax) + 1e-5f * __builtin_amdgcn_sqrtf(dot(u, u));
+    const float r2lim = rr * rr;
+    // signed distance of the sphere's centre (the origin) OUT of the face, times |n|:  s = -(u . n_out)
+    const f3 nx0 = cross(v00, f2), nx1 = cross(v10, f2), ny0 = cross(v00, f1), ny1 = cross(v01, f1), wf = cross(f1, f2);
+    const float sx0 = -dot(u, nx0), sx1 = dot(u, nx1), sy0 = dot(u, ny0), sy1 = -dot(u, ny1), sf = -dot(u, wf);
+    const bool front = sf > 0.f && sf * sf > r2lim * dot(wf, wf);
+    const bool out = (sx0 > 0.f && sx0 * sx0 > r2lim * dot(nx0, nx0)) || (sx1 > 0.f && sx1 * sx1 > r2lim * dot(nx1, nx1)) ||
+                     (sy0 > 0.f && sy0 * sy0 > r2lim * dot(ny0, ny0)) || (sy1 > 0.f && sy1 * sy1 > r2lim * dot(ny1, ny1));
+    return front && out;
+}
+
 // canonical-frame ray of the pixel pair against one staged entry, and the accept test
 struct PairGeom {
     p3 u, v;        // canonical origin, canonical (un-normalised) direction
@@ -302,8 +383,12 @@ __device__ __forceinline__ void write_split_outputs(const GutParams& P, size_t p
 // Rounds are aligned to multiples of 64 in the global sorted list, so every segment boundary (multiple of
 // kGutSegment) is a round start, where the running state is checkpointed for the gradient sweep.
 // ---------------------------------------------------------------------------------------------
+#ifndef GRUT_FWD_HALF_TILE_CULL
+#define GRUT_FWD_HALF_TILE_CULL 1   // staged entries whose sphere misses the wave's ray pyramid are dropped (see WavePyramid)
+#endif
 struct FwdState {
     v2f T, D, Cr, Cg, Cb, cnt;
+    unsigned long long t_stage;   // instrumented build: ticks spent staging rounds
 };
 template <int DEG, bool CKPT, bool UNI, bool COUNT = false>
 __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPair& rp, uint2 range, uint32_t half, int lane,
@@ -312,9 +397,14 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
                                                  FwdState& st) {
     bool alive0 = rp.valid0, alive1 = rp.valid1;
     v2f T = splat(1.f), D = splat(0.f), Cr = splat(0.f), Cg = splat(0.f), Cb = splat(0.f), cnt = splat(0.f);
-    uint32_t n_eval = 0u, n_acc = 0u;   // wave-uniform work counters (scalar registers), reported when P.work is set
+    uint32_t n_eval = 0u, n_acc = 0u, n_rounds = 0u;   // wave-uniform work counters (scalar registers), reported when P.work is set
+    const unsigned long long t_sweep = COUNT ? wall_clock64() : 0ull;
+    unsigned long long t_first = 0ull, t_stage = 0ull;
     uint32_t b = range.x;
     RawEntry next = load_entry<false>(b + lane, min(range.y, (b & ~63u) + 64u), lists, density12, rgb);
+    constexpr bool CULL = GRUT_FWD_HALF_TILE_CULL != 0;
+    WavePyramid pyr;
+    if (UNI && CULL) pyr = wave_pyramid(rp);
     while (b < range.y) {
         if (!__any(alive0 || alive1)) break;
         const uint32_t bend = min(range.y, (b & ~63u) + 64u);
@@ -327,11 +417,29 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
             ck.d[slot + 1] = D.y;
             if (lane == 0) ck.reached[(size_t)(b / kGutSegment) * 2 + half] = 1;
         }
-        stage_entry<DEG, false>(P, next, UNI, rp.origin, &s_rec[lane * kRecQuads]);
+        int n = (int)(bend - b);
+        if (COUNT) ++n_rounds;
+        const unsigned long long t_round = COUNT ? wall_clock64() : 0ull;
+        if (UNI && CULL) {
+            // stage to a private record, drop it if its sphere misses the wave's pyramid, pack the survivors (order kept)
+            float4 q[kRecQuads];
+            stage_entry<DEG, false>(P, next, true, rp.origin, q);
+            const bool keep = lane < n && next.idx != 0xFFFFFFFFu && !(pyr.on && pyramid_misses(pyr, q[0], q[1], q[2], q[4].w, q[5]));
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                float4* dst = &s_rec[__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u)) * kRecQuads];
+#pragma unroll
+                for (int k = 0; k < kRecQuads; ++k) dst[k] = q[k];
+            }
+            n = __popcll(km);
+        } else {
+            stage_entry<DEG, false>(P, next, UNI, rp.origin, &s_rec[lane * kRecQuads]);
+        }
         __syncthreads();  // single-wave workgroup: orders the LDS hand-off
+        if (COUNT && n_rounds == 1u) t_first = wall_clock64() - t_sweep;
+        if (COUNT) t_stage += wall_clock64() - t_round;
         // fetch the following round while this one is being composited
         next = load_entry<false>(bend + lane, min(range.y, bend + 64u), lists, density12, rgb);
-        const int n = (int)(bend - b);
         for (int j = 0; j < n; ++j) {
             if (!__any(alive0 || alive1)) break;   // the rest of the round is behind every pixel's termination
             const float4* rec = &s_rec[j * kRecQuads];
@@ -367,10 +475,14 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         __syncthreads();
         b = bend;
     }
-    st = FwdState{T, D, Cr, Cg, Cb, cnt};
+    st = FwdState{T, D, Cr, Cg, Cb, cnt, 0ull};
     if (COUNT && P.work && lane == 0) {   // per-wave words, summed on the host (atomics on two shared counters would serialise the waves' exits)
         P.work[16 + 4 * (size_t)blockIdx.x + 2] = ((unsigned long long)n_acc << 32) | n_eval;
-        P.work[16 + 4 * (size_t)blockIdx.x + 3] = range.y - range.x;
+        st.t_stage = t_stage;
+        // [0, 24) list length, [24, 34) staged rounds, [34, 49) first round staged, [49, 64) sweep over - both in 10 ns ticks since the sweep began
+        const unsigned long long t_done = wall_clock64() - t_sweep;
+        P.work[16 + 4 * (size_t)blockIdx.x + 3] = (unsigned long long)min(range.y - range.x, 0xFFFFFFu) | ((unsigned long long)min(n_rounds, 1023u) << 24) |
+                                                  (min(t_first, 32767ull) << 34) | (min(t_done, 32767ull) << 49);
     }
 }
 
@@ -399,13 +511,15 @@ void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryL
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;   // constant-rate (100 MHz) counter shared by the whole chip
     const RayPair rp = init_ray_pair(P, ray_o, ray_d, tile, half, lane);
     const uint2 range = ranges[tile];
+    const unsigned long long t_rays = COUNT ? wall_clock64() : 0ull;
     FwdState st;
     // two copies of the sweep: the shared-origin one keeps the canonical origin out of the per-pixel math
     if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
     else render_fwd_sweep<DEG, CKPT, false, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
     if (COUNT && P.work && lane == 0) {   // diagnostics: this wave's lifetime (shader-clock ticks) and start time, for the balance analysis
         const unsigned long long t_end = wall_clock64();
-        P.work[16 + 4 * (size_t)blockIdx.x] = t_end - t_begin;
+        // lifetime | rays ready << 32 | time spent staging << 48 (10 ns ticks)
+        P.work[16 + 4 * (size_t)blockIdx.x] = (t_end - t_begin) | (min(t_rays - t_begin, 0xFFFFull) << 32) | (min(st.t_stage, 0xFFFFull) << 48);
         P.work[16 + 4 * (size_t)blockIdx.x + 1] = t_begin;
     }
     // every pixel of the image is written (the caller does not pre-fill): rays that miss the scene box get the reference's

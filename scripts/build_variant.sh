@@ -9,7 +9,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp-contr
 [ "$src" = "grt_kernels.hip" ] && FLAGS="$FLAGS -ffp-contract=on"
 /opt/rocm/bin/hipcc -x hip $FLAGS "$@" -c "$src" -o "../../variants/${name}_${src%.hip}.o"
 objs=""
-for f in scan_sort gut_kernels gut_render gut_api grt_kernels grt_api optim; do
+for f in scan_sort gut_kernels gut_poses gut_render gut_api grt_kernels grt_api optim; do
   if [ "$f.hip" = "$src" ]; then objs="$objs ../../variants/${name}_${f}.o"; else objs="$objs $f.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o "../../variants/libgrut_amd_${name}.so"
