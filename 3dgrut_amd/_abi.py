@@ -111,7 +111,7 @@ class GrutAdamGroup(C.Structure):
 
 VIS_NONE, VIS_BOOL_U8, VIS_INT32, VIS_FLOAT_BITS = range(4)
 # GrtConfig::primitive_type (render.primitive_type, optixTracer.cpp:176-201)
-GRT_PRIMITIVES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4}
+GRT_PRIMITIVES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4, "custom": 5}
 
 
 class GrtTexture(C.Structure):
@@ -151,7 +151,7 @@ EXPORTED_SYMBOLS = [
     "gut_debug_fetch", "gut_debug_fetch_work", "grut_debug_pose_from_c2w", "grut_debug_frame_poses", "grut_sort_pairs_u32", "grut_sort_scratch_bytes", "grut_inclusive_scan_u32",
     "grut_scan_scratch_bytes",
     "grt_create", "grt_destroy", "grt_build_bvh", "grt_forward", "grt_backward", "grt_timings", "grt_stats", "grt_debug_fetch_work",
-    "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_debug_fetch_lists", "grt_debug_backward_signature", "grt_build_mesh_bvh", "grt_trace_hybrid",
+    "grt_debug_forward_hits", "grt_debug_fetch_instances", "grt_debug_fetch_custom_boxes", "grt_debug_fetch_lists", "grt_debug_backward_signature", "grt_build_mesh_bvh", "grt_trace_hybrid",
     "grut_selective_adam_update", "grut_pack_particles", "grut_unpack_particle_grads", "grut_activate_pack", "grut_activate_pack_backward",
     "grut_last_error", "grut_abi_version", "grut_set_allocator", "gut_trim", "grt_trim",
 ]
@@ -223,6 +223,8 @@ def _declare(lib):
     lib.grt_debug_forward_hits.restype = C.c_int
     lib.grt_debug_fetch_instances.argtypes = [C.c_void_p, vp, fp]
     lib.grt_debug_fetch_instances.restype = C.c_int
+    lib.grt_debug_fetch_custom_boxes.argtypes = [C.c_void_p, vp, fp]
+    lib.grt_debug_fetch_custom_boxes.restype = C.c_int
     lib.grt_debug_backward_signature.argtypes = [C.c_void_p, up, up]
     lib.grt_debug_backward_signature.restype = C.c_int
     lib.grt_build_mesh_bvh.argtypes = [C.c_void_p, vp, C.c_uint32, fp, C.c_uint32, ip, C.c_int, C.c_int]

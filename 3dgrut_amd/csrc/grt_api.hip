@@ -14,6 +14,7 @@ struct GrtHandle {
     uint32_t N = 0;
     bool built = false;
     hipStream_t build_stream = nullptr;
+    DeviceBuffer box8;   // GRUT_PRIM_CUSTOM: the particles' exact world boxes + kernelScale^2 (grt_proxy_kernel)
     DeviceBuffer inst, aabb, slack, scene_enc, scene, codes, ids, codes_tmp, ids_tmp, sort_scratch, nodes,
         counters, dbg_ids, dbg_count;
     uint32_t* sorted_ids = nullptr;
@@ -66,8 +67,8 @@ struct GrtHandle {
 
 static int grt_validate(const GrtConfig& c) {
     GRUT_REQUIRE(c.particle_radiance_sph_degree >= 0 && c.particle_radiance_sph_degree <= 3, "sph degree must be in [0,3]");
-    if (c.primitive_type < GRUT_PRIM_INSTANCES || c.primitive_type > GRUT_PRIM_DIAMOND) {
-        set_last_error("primitive_type %d: instances (0), icosahedron (1), octahedron (2), tetrahedron (3), diamond (4) are provided", c.primitive_type);
+    if (c.primitive_type < GRUT_PRIM_INSTANCES || c.primitive_type > GRUT_PRIM_CUSTOM) {
+        set_last_error("primitive_type %d: instances (0), icosahedron (1), octahedron (2), tetrahedron (3), diamond (4), custom (5) are provided", c.primitive_type);
         return GRUT_ERR_UNSUPPORTED;
     }
     const int d = c.particle_kernel_degree;
@@ -97,6 +98,7 @@ static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
     memset(&P, 0, sizeof(P));
     P.degree = h->cfg.particle_kernel_degree;
     P.prim = h->cfg.primitive_type;
+    P.box8 = h->cfg.primitive_type == GRUT_PRIM_CUSTOM ? h->box8.as<float>() : nullptr;
     P.ncoef = (h->cfg.particle_radiance_sph_degree + 1) * (h->cfg.particle_radiance_sph_degree + 1);
     P.sph_degree = f.sph_degree < h->cfg.particle_radiance_sph_degree ? f.sph_degree : h->cfg.particle_radiance_sph_degree;
     if (P.sph_degree < 0) P.sph_degree = 0;
@@ -160,7 +162,7 @@ int grt_create(const GrtConfig* config, GrtHandle** handle) {
 }
 
 static void release_scratch(GrtHandle* h) {
-    DeviceBuffer* bufs[] = {&h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
+    DeviceBuffer* bufs[] = {&h->box8, &h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
                             &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
                             &h->work_counters, &h->l_flags, &h->l_starts, &h->l_bounds, &h->l_pair_cache, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits,
                             &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets, &h->l_scan_scratch, &h->l_sort_scratch,
@@ -227,6 +229,7 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     GRUT_CHECK(h->inst.ensure(n * 48, 1.25f));
     GRUT_CHECK(h->aabb.ensure(n * 24, 1.25f));
     GRUT_CHECK(h->slack.ensure(n * 4, 1.25f));
+    if (h->cfg.primitive_type == GRUT_PRIM_CUSTOM) GRUT_CHECK(h->box8.ensure(n * 32, 1.25f));
     GRUT_CHECK(h->scene_enc.ensure(grt_scene_enc_bytes()));
     GRUT_CHECK(h->scene.ensure(64));
     GRUT_CHECK(h->codes.ensure(n * 4, 1.25f));
@@ -244,7 +247,8 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     P.clamping = h->cfg.particle_kernel_density_clamping;
     P.min_response = h->cfg.particle_kernel_min_response;
     uint32_t* scene_enc = h->scene_enc.as<uint32_t>();
-    grt_launch_proxies(s, P, positions, rotations, scales, densities, h->inst.as<float>(), h->aabb.as<float>(), h->slack.as<float>(), scene_enc);
+    grt_launch_proxies(s, P, positions, rotations, scales, densities, h->inst.as<float>(), h->aabb.as<float>(), h->slack.as<float>(), scene_enc,
+                       h->cfg.primitive_type == GRUT_PRIM_CUSTOM ? h->box8.as<float>() : nullptr);
     // refit-only updates keep the sorted order of the last full build, so the code / id buffers must stay untouched
     grt_launch_morton(s, N, h->aabb.as<float>(), scene_enc, h->scene.as<float>(), rebuild ? h->codes.as<uint32_t>() : nullptr,
                       rebuild ? h->ids.as<uint32_t>() : nullptr);
@@ -278,7 +282,10 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
     h->log_lists = lists;   // the list scratch is about to be overwritten: a pending backward of an older forward walks the tree
     // (triangle-mesh proxies bin by the box of the polyhedron's vertices and start from bounding-sphere distance intervals, which the packets'
     // first tests refine to exact ones like the instance path's; GRUT_GRT_NO_MESH_LISTS=1 keeps them on the tree walk)
-    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && (h->cfg.primitive_type == GRUT_PRIM_INSTANCES || !getenv("GRUT_GRT_NO_MESH_LISTS"))) {
+    // (custom primitives: the candidates are the rays of the particle's WORLD box, which the packet binning - bounds of the oriented proxy - does
+    // not cover: tree walk)
+    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && h->cfg.primitive_type != GRUT_PRIM_CUSTOM &&
+        (h->cfg.primitive_type == GRUT_PRIM_INSTANCES || !getenv("GRUT_GRT_NO_MESH_LISTS"))) {
         const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
         if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
         GRUT_CHECK(h->l_flags.ensure(64));
@@ -727,6 +734,14 @@ int grt_stats(GrtHandle* h, GrtStats* stats) {
 int grt_debug_fetch_instances(GrtHandle* h, void* stream_, float* instances) {
     GRUT_REQUIRE(h && h->built && instances, "grt_debug_fetch_instances: no BVH / null buffer");
     if (h->N) GRUT_HIP(hipMemcpyAsync(instances, h->inst.ptr, (size_t)h->N * 48, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream_)));
+    return GRUT_OK;
+}
+
+// GRUT_PRIM_CUSTOM: the particles' world boxes + kernelScale^2 ([N,8]) of the last build to a caller DEVICE buffer
+int grt_debug_fetch_custom_boxes(GrtHandle* h, void* stream_, float* box8) {
+    GRUT_REQUIRE(h && h->built && box8, "grt_debug_fetch_custom_boxes: no BVH / null buffer");
+    if (h->cfg.primitive_type != GRUT_PRIM_CUSTOM) { set_last_error("grt_debug_fetch_custom_boxes: primitive_type is not custom"); return GRUT_ERR_NOT_READY; }
+    if (h->N) GRUT_HIP(hipMemcpyAsync(box8, h->box8.ptr, (size_t)h->N * 32, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream_)));
     return GRUT_OK;
 }
 

@@ -43,6 +43,7 @@ struct GrtTraceParams {
     float min_response, min_alpha, max_alpha, min_transmittance;
     int W, H;
     int prim;                 // GrtConfig::primitive_type (GRUT_PRIM_*): which candidate test a (ray, particle) pair takes
+    const float* box8;        // GRUT_PRIM_CUSTOM: [N,8] {world box, kernelScale^2, 0} of the proxy kernel (null otherwise)
     float ray_to_world[12];
     const float* ray_to_world_dev;   // optional: the same matrix in device memory (GrtFrame::device_ray_to_world), used instead when set
     uint32_t dbg_cap;
@@ -164,7 +165,7 @@ struct GrtHybridParams {
 
 // build stages
 void grt_launch_proxies(hipStream_t s, const GrtBuildParams& P, const float* pos, const float* rot, const float* scl, const float* dns,
-                        float* inst, float* aabb, float* slack, uint32_t* scene_enc);
+                        float* inst, float* aabb, float* slack, uint32_t* scene_enc, float* box8);
 void grt_launch_morton(hipStream_t s, uint32_t N, const float* aabb, const uint32_t* scene_enc, float* scene, uint32_t* codes, uint32_t* ids);
 void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_codes, const uint32_t* sorted_ids, GrtNode* nodes);
 void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float* slack, GrtNode* nodes, uint8_t* done);

@@ -69,7 +69,7 @@ constexpr int kSceneReplicas = 64, kSceneReplicaStride = 32;   // one 128-byte l
 __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const float* __restrict__ pos, const float* __restrict__ rot,
                                                         const float* __restrict__ scl, const float* __restrict__ dns,
                                                         float* __restrict__ inst, float* __restrict__ aabb, float* __restrict__ slack,
-                                                        uint32_t* __restrict__ scene_enc) {
+                                                        uint32_t* __restrict__ scene_enc, float* __restrict__ box8) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     if (i < P.N) {
@@ -89,11 +89,26 @@ __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const 
         float hx = fabsf(rt.r0.x) * e0 + fabsf(rt.r1.x) * e1 + fabsf(rt.r2.x) * e2;
         float hy = fabsf(rt.r0.y) * e0 + fabsf(rt.r1.y) * e1 + fabsf(rt.r2.y) * e2;
         float hz = fabsf(rt.r0.z) * e0 + fabsf(rt.r1.z) * e1 + fabsf(rt.r2.z) * e2;
+        if (P.prim == GRUT_PRIM_CUSTOM) {
+            // computeGaussianEnclosingAABBKernel (particlePrimitives.cu:498-541): min / max over the 8 corners R (c * kscl) + mu, c = +-1 - the
+            // extreme corner of an axis has all three products of one sign, so the bound is mu -+ ((|R_c0| k0 + |R_c1| k1) + |R_c2| k2) in the
+            // kernel's own (uncontracted, left-to-right) summation order.  THIS box decides which rays the particle is offered to
+            // (candidate_abe); the padded copy below only steers the hierarchy.
+#pragma clang fp contract(off)
+            const float ux = (fabsf(rt.r0.x) * k0 + fabsf(rt.r1.x) * k1) + fabsf(rt.r2.x) * k2;
+            const float uy = (fabsf(rt.r0.y) * k0 + fabsf(rt.r1.y) * k1) + fabsf(rt.r2.y) * k2;
+            const float uz = (fabsf(rt.r0.z) * k0 + fabsf(rt.r1.z) * k1) + fabsf(rt.r2.z) * k2;
+            float* bx = box8 + 8 * (size_t)i;
+            bx[0] = cx - ux; bx[1] = cy - uy; bx[2] = cz - uz; bx[3] = cx + ux; bx[4] = cy + uy; bx[5] = cz + uz;
+            bx[6] = ks * ks; bx[7] = 0.f;
+        }
         hx += 1e-4f * hx + 1e-6f * (fabsf(cx) + 1.f); hy += 1e-4f * hy + 1e-6f * (fabsf(cy) + 1.f); hz += 1e-4f * hz + 1e-6f * (fabsf(cz) + 1.f);
         lo[0] = cx - hx; lo[1] = cy - hy; lo[2] = cz - hz; hi[0] = cx + hx; hi[1] = cy + hy; hi[2] = cz + hz;
         float* b = aabb + 6 * (size_t)i;
         b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
-        slack[i] = 1.41421356237f * 1.0001f * fmaxf(e0, fmaxf(e1, e2));
+        // how far the hit distance can precede the ray's entry into the (padded) box: sqrt(2) max kscl for the cube; for the custom
+        // primitives' WORLD box (the cube's bounding box: the closest approach to the centre of a line through it lies within the half diagonal)
+        slack[i] = P.prim == GRUT_PRIM_CUSTOM ? 1.0001f * sqrtf(hx * hx + hy * hy + hz * hz) : 1.41421356237f * 1.0001f * fmaxf(e0, fmaxf(e1, e2));
     }
     // scene box: one set of atomics per wave, spread over kSceneReplicas cache lines (15 k waves hammering six words of
     // ONE line serialised in L2 and cost 1 ms of this kernel's 1.07 ms); the Morton kernel folds the replicas
@@ -258,6 +273,7 @@ __global__ __launch_bounds__(256) void grt_refit_pass_kernel(uint32_t N, uint32_
 struct RayW {
     f3 o, d, inv;
     int prim;   // GrtTraceParams::prim rides with the ray: the candidate test is the one place that depends on it
+    const float* box8;   // GRUT_PRIM_CUSTOM: per particle {world box min, max (as the reference's AABB kernel computes it), kernelScale^2, 0}
 };
 __device__ __forceinline__ float safe_rcp(float v) {
     return fabsf(v) > 1e-30f ? 1.0f / v : copysignf(1.0e30f, v);
@@ -281,6 +297,7 @@ __device__ __forceinline__ RayW make_ray(const GrtTraceParams& P, const float* _
     }
     r.inv = mk3(safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z));
     r.prim = P.prim;
+    r.box8 = P.box8;
     return r;
 }
 // referenceOptix.cu:33-39 intersectAABB
@@ -352,7 +369,7 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     const float pox = po.x, poy = po.y, poz = po.z;
     const float pdx = fmaf(a.z, r.d.z, fmaf(a.y, r.d.y, a.x * r.d.x)), pdy = fmaf(b.y, r.d.z, fmaf(b.x, r.d.y, a.w * r.d.x)),
                 pdz = fmaf(e.x, r.d.z, fmaf(b.w, r.d.y, b.z * r.d.x));
-    if (r.prim != GRUT_PRIM_INSTANCES) {
+    if (r.prim >= GRUT_PRIM_ICOSAHEDRON && r.prim <= GRUT_PRIM_DIAMOND) {
         // triangle-mesh proxies (icosahedron ...): the distance at which the ray ENTERS the fixed convex polyhedron of the proxy's frame -
         // what OptiX reports for the one front-facing triangle of the reference's mesh the ray passes (back faces culled; a ray that starts
         // inside is not offered the particle).  Clip against the face planes n . x <= h: entering planes (n . d < 0) raise the entry
@@ -383,6 +400,24 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     c.t = numerator / dd;
     const bool wanted = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
     if (!wanted && !always_box) return c;
+    if (r.prim == GRUT_PRIM_CUSTOM) {
+        // custom primitives (render.primitive_type custom; optixTracer.cpp:638-655, intersectCustomParticle gaussianParticles.cuh:407-441): the
+        // intersection program runs for rays that overlap the particle's WORLD box, reports the point of maximum response - the same point
+        // as the instances' (the proxy frame differs from the program's scale frame by the scalar kernelScale, which cancels in the
+        // distance) - and accepts it within 3 sigma of the SCALE frame: |pd x po|^2 ks^2 < 9 |pd|^2 in proxy-frame quantities.
+        const float* bx = r.box8 + 8 * (size_t)id;
+        const float ax0 = (bx[0] - r.o.x) * r.inv.x, ax1 = (bx[3] - r.o.x) * r.inv.x, ay0 = (bx[1] - r.o.y) * r.inv.y, ay1 = (bx[4] - r.o.y) * r.inv.y;
+        const float az0 = (bx[2] - r.o.z) * r.inv.z, az1 = (bx[5] - r.o.z) * r.inv.z;
+        const float tnear = max3f(fminf(ax0, ax1), fminf(ay0, ay1), fminf(az0, az1));
+        const float tfar = min3f(fmaxf(ax0, ax1), fmaxf(ay0, ay1), fmaxf(az0, az1));
+        if (wanted) c.why = 2;
+        if (!(tnear <= tfar)) return c;
+        if (wanted) { c.why = 3; c.tnear = tnear; c.tfar = tfar; }
+        const float crx = fmaf(pdy, poz, -(pdz * poy)), cry = fmaf(pdz, pox, -(pdx * poz)), crz = fmaf(pdx, poy, -(pdy * pox));
+        c.box = fmaf(crz, crz, fmaf(cry, cry, crx * crx)) * bx[6] < 9.0f * dd;
+        c.ok = c.box && wanted;
+        return c;
+    }
     // slab test of the unit box: one reciprocal per axis, IEEE minNum / maxNum
     const float ix = 1.f / pdx, iy = 1.f / pdy, iz = 1.f / pdz;
     const float ax0 = (-1.f - pox) * ix, ax1 = (1.f - pox) * ix, ay0 = (-1.f - poy) * iy, ay1 = (1.f - poy) * iy, az0 = (-1.f - poz) * iz, az1 = (1.f - poz) * iz;
@@ -1078,7 +1113,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
 #pragma unroll
             for (int g = 0; g < kGrtMaxGhosts; ++g) {
                 const bool have = g_id[g] != 0xFFFFFFFFu;
-                g_t[g] = have ? candidate(bvh.inst + 12 * (size_t)g_id[g], r).t : 3.0e38f;   // (the very value the round computed: same arithmetic, same inputs)
+                g_t[g] = have ? candidate(bvh.inst + 12 * (size_t)g_id[g], r, 3.0e38f).t : 3.0e38f;   // (the very value the round computed: same arithmetic, same inputs)
                 // beyond the 16th candidate of a full round: not this round's business (the next round meets it again)
                 if (have && full && !hit_less(g_t[g], g_id[g], t16, id16)) { g_id[g] = 0xFFFFFFFFu; g_t[g] = 3.0e38f; }
                 ng += g_id[g] != 0xFFFFFFFFu ? 1u : 0u;
@@ -1883,7 +1918,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 const bool ghost = (id & kGrtGhostBit) != 0u;
                 id &= ~kGrtGhostBit;
                 // is this candidate offered to the backward's running trace?  (same arithmetic as the traces themselves: candidate())
-                const Cand cd = candidate(inst + 12 * (size_t)id, r);
+                const Cand cd = candidate(inst + 12 * (size_t)id, r, -3.0e38f, 3.0e38f, id);
                 if (!ghost) fw_last = fmaxf(fw_last, cd.t);
                 const float tmin = bw_start + eps;
                 if (cd.ok && (cd.t > tmin) && (cd.t < endT) && (cd.tfar >= tmin) && (cd.tnear <= endT)) {
@@ -2044,7 +2079,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             if (id != 0xFFFFFFFFu) {
                 const bool ghost = (id & kGrtGhostBit) != 0u;
                 id &= ~kGrtGhostBit;
-                const Cand cd = candidate(inst + 12 * (size_t)id, r);
+                const Cand cd = candidate(inst + 12 * (size_t)id, r, -3.0e38f, 3.0e38f, id);
                 if (!ghost) fw_last = fmaxf(fw_last, cd.t);
                 const float tmin = bw_start + eps;
                 if (cd.ok && (cd.t > tmin) && (cd.t < endT) && (cd.tfar >= tmin) && (cd.tnear <= endT)) {
@@ -2631,9 +2666,9 @@ __global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh
 // launchers
 // ---------------------------------------------------------------------------------------------
 void grt_launch_proxies(hipStream_t s, const GrtBuildParams& P, const float* pos, const float* rot, const float* scl, const float* dns,
-                        float* inst, float* aabb, float* slack, uint32_t* scene_enc) {
+                        float* inst, float* aabb, float* slack, uint32_t* scene_enc, float* box8) {
     hipLaunchKernelGGL(grt_scene_init_kernel, dim3(1), dim3(64), 0, s, scene_enc);
-    hipLaunchKernelGGL(grt_proxy_kernel, dim3(div_up(P.N, 256)), dim3(256), 0, s, P, pos, rot, scl, dns, inst, aabb, slack, scene_enc);
+    hipLaunchKernelGGL(grt_proxy_kernel, dim3(div_up(P.N, 256)), dim3(256), 0, s, P, pos, rot, scl, dns, inst, aabb, slack, scene_enc, box8);
 }
 size_t grt_scene_enc_bytes() { return (size_t)kSceneReplicas * kSceneReplicaStride * sizeof(uint32_t); }
 void grt_launch_morton(hipStream_t s, uint32_t N, const float* aabb, const uint32_t* scene_enc, float* scene, uint32_t* codes, uint32_t* ids) {

@@ -48,7 +48,7 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
     prim = _conf_get(render, "primitive_type", "instances")
     if prim not in _abi.GRT_PRIMITIVES:
         raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (provided: {tuple(_abi.GRT_PRIMITIVES)}; "
-                                  "trihexa / trisurfel / sphere / custom proxies are not)")
+                                  "trihexa / trisurfel / sphere proxies are not)")
     if prim != "instances" and nht:
         raise NotImplementedError("3dgrut_amd: neural harmonic features are provided with primitive_type=instances only")
     cfg.primitive_type = _abi.GRT_PRIMITIVES[prim]
@@ -182,6 +182,13 @@ class _GrtNative:
     def instances(self, n, device):
         out = torch.zeros((n, 12), dtype=torch.float32, device=device)
         _abi.check(self.lib.grt_debug_fetch_instances(self.handle, _stream_ptr(device), _ptr(out)), "grt_debug_fetch_instances")
+        return out
+
+
+    def custom_boxes(self, n, device):
+        """primitive_type custom: [n,8] world boxes + kernelScale^2 of the last build (grt_debug_fetch_custom_boxes)."""
+        out = torch.zeros((n, 8), dtype=torch.float32, device=device)
+        _abi.check(self.lib.grt_debug_fetch_custom_boxes(self.handle, _stream_ptr(device), _ptr(out)), "grt_debug_fetch_custom_boxes")
         return out
 
 

@@ -324,11 +324,13 @@ typedef struct GrtConfig {
     /* render.primitive_type (optixTracer.cpp:176-201): the proxy geometry a particle is traced through.  GRUT_PRIM_INSTANCES: the unit cube
      * under the particle's instance transform, hit distance = the point of maximum response (intersectInstanceParticle).  The closed convex
      * triangle meshes of particlePrimitives.cu:63-496: the ray is offered the particle at the distance at which it ENTERS the proxy (OptiX
-     * triangles with back faces culled, referenceOptix.cu:62), rays that start inside are not offered it.  Other meshes (trihexa, trisurfel),
-     * `sphere` and `custom` are GRUT_ERR_UNSUPPORTED. */
+     * triangles with back faces culled, referenceOptix.cu:62), rays that start inside are not offered it.  GRUT_PRIM_CUSTOM: custom primitives over
+     * the particles' WORLD boxes (computeGaussianEnclosingAABBKernel) with the world-space intersection program intersectCustomParticle
+     * (gaussianParticles.cuh:407-441): the instances' hit point, offered to the rays that cross the world box, accepted within 3 sigma.
+     * The open meshes (trihexa, trisurfel) and `sphere` are GRUT_ERR_UNSUPPORTED. */
     int32_t primitive_type;
 } GrtConfig;
-enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON = 2, GRUT_PRIM_TETRAHEDRON = 3, GRUT_PRIM_DIAMOND = 4 };
+enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON = 2, GRUT_PRIM_TETRAHEDRON = 3, GRUT_PRIM_DIAMOND = 4, GRUT_PRIM_CUSTOM = 5 };
 
 typedef struct GrtFrame {
     uint32_t frame_id;
@@ -462,6 +464,9 @@ int grt_debug_forward_hits(GrtHandle* handle, void* stream, const GrtFrame* fram
 int grt_debug_backward_signature(GrtHandle* handle, unsigned long long* ray_signature, uint32_t* ray_hit_count);
 /* proxy instance records of the last build: [N,12] f32 = rows of W = diag(1/kscl) R^T, then mu (object ray: o' = W (o - mu)) */
 int grt_debug_fetch_instances(GrtHandle* handle, void* stream, float* instances);
+/* GRUT_PRIM_CUSTOM: [N,8] f32 = the particle's world box (min xyz, max xyz; computeGaussianEnclosingAABBKernel, particlePrimitives.cu:498-541),
+ * kernelScale^2, 0 - what the candidate test of the custom primitives reads.  GRUT_ERR_NOT_READY for another primitive type. */
+int grt_debug_fetch_custom_boxes(GrtHandle* handle, void* stream, float* box8);
 /* The per-packet candidate lists of the last train-mode forward (GrtStats::list_entries of them) to caller DEVICE buffers: ranges [blocks,2]
  * ([first, last) of each 8x8 ray packet, row-major), entries [list_entries] particle ids (top bit: internal flag).  GRUT_ERR_NOT_READY when
  * the tree walk served the frame or the capacity is too small.  The parity tests hand them to the CPU checker as a candidate prefilter. */

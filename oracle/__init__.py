@@ -269,6 +269,31 @@ def grt_proxies(cfg, positions, rotations, scales, densities, dtype=np.float32):
     return dict(inst=inst, aabb=aabb, slack=slack, scene=scene)
 
 
+_custom_keepalive = {}
+
+
+def grt_set_custom_boxes(box8, dtype=np.float32):
+    """Registers caller-supplied boxes (e.g. the ones the GPU built: grt_debug_fetch_custom_boxes) for the next traces of this build."""
+    b = _c(box8, dtype)
+    _custom_keepalive[dtype] = b
+    lib(dtype).orc_grt_set_custom_boxes(_p(b))
+    return b
+
+
+def grt_custom_boxes(cfg, density12, dtype=np.float32):
+    """render.primitive_type custom: [N,8] {world box min, max, kernelScale^2, 0} (orc_grt_custom_boxes), registered with the library for the
+    next traces (orc_grt_set_custom_boxes) and kept alive here."""
+    l = lib(dtype)
+    d12 = _c(density12, dtype)
+    pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
+                          np.ascontiguousarray(d12[:, 3]))
+    box8 = np.zeros((d12.shape[0], 8), dtype)
+    l.orc_grt_custom_boxes(C.byref(cfg), C.c_uint32(d12.shape[0]), _p(pos), _p(rot), _p(scl), _p(dns), _p(box8))
+    _custom_keepalive[dtype] = box8
+    l.orc_grt_set_custom_boxes(_p(box8))
+    return box8
+
+
 _prefilter_keepalive = {}
 
 
@@ -288,7 +313,7 @@ def grt_set_candidate_prefilter(ranges=None, entries=None, ray_packet=None):
 
 
 def grt_forward(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, ray_o, ray_d, inst=None, scene=None, dbg_cap=0,
-                dtype=np.float32):
+                dtype=np.float32, box8=None):
     """OptixTracer::trace semantics.  ray_to_world: [3,4]; rays: [H,W,3] in ray space.  `inst` / `scene` may be supplied
     (e.g. the proxies the GPU built) so that hit order can be compared bit-exactly."""
     l, R = lib(dtype), _real(dtype)
@@ -298,6 +323,8 @@ def grt_forward(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, r
         pr = grt_proxies(cfg, d12[:, 0:3], d12[:, 4:8], d12[:, 8:11], d12[:, 3], dtype)
         inst, scene = pr["inst"], pr["scene"]
     inst, scene = _c(inst, dtype), _c(scene, dtype)
+    if cfg.primitive_type == 5:   # custom primitives: the world boxes (the GPU's, when given - like `inst`)
+        box8 = grt_custom_boxes(cfg, d12, dtype) if box8 is None else grt_set_custom_boxes(box8, dtype)
     ro, rd = _c(ray_o, dtype), _c(ray_d, dtype)
     H, W = ro.shape[-3], ro.shape[-2]
     n = H * W
@@ -311,7 +338,7 @@ def grt_forward(cfg, density12, sph, sph_deg, min_transmittance, ray_to_world, r
                             _p(out["normals"]), _p(out["hit_count"]), _p(out["visibility"]),
                             _p(dbg_ids) if dbg_cap else None, _p(dbg_cnt), C.c_uint32(dbg_cap))
     assert r == 0
-    out.update(hit_ids=dbg_ids, hit_num=dbg_cnt, inst=inst, scene=scene, density12=d12, sph=s, rays=(ro, rd), ray_to_world=m)
+    out.update(hit_ids=dbg_ids, hit_num=dbg_cnt, inst=inst, scene=scene, density12=d12, sph=s, rays=(ro, rd), ray_to_world=m, box8=box8)
     return out
 
 
@@ -374,6 +401,8 @@ def grt_backward(cfg, sph_deg, min_transmittance, fwd, g_features, g_density, g_
     ro, rd = fwd["rays"]
     n = ro.shape[-3] * ro.shape[-2]
     gd, gs = np.zeros((N, 12), dtype), np.zeros_like(s)
+    if cfg.primitive_type == 5:
+        grt_set_custom_boxes(fwd["box8"], dtype)
     dbg_ids = np.full((n, max(dbg_cap, 1)), 0xFFFFFFFF, np.uint32)
     dbg_cnt = np.zeros(n, np.uint32)
     r = l.orc_grt_trace_bwd(C.byref(cfg), C.c_uint32(N), _p(d12), _p(s), C.c_int(sph_deg), R(min_transmittance), _p(fwd["inst"]),

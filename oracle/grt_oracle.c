@@ -44,6 +44,10 @@ real orc_grt_kernel_scale(real density, real min_response, int clamping, real de
 #include "orc_polyhedra.h"
 static int g_prim = 0;
 void orc_grt_set_primitive(int prim) { g_prim = prim; }
+/* GRUT_PRIM_CUSTOM (render.primitive_type custom): per particle {world box min, max, kernelScale^2, 0} - orc_grt_custom_boxes fills it, the
+ * caller keeps it alive and registers it here before tracing (process-wide, like the primitive type). */
+static const real* g_box8 = NULL;
+void orc_grt_set_custom_boxes(const real* box8) { g_box8 = box8; }
 
 /* computeGaussianEnclosingInstancesKernel, particlePrimitives.cu:543-610: instance transform [R diag(kscl) | mu] over a
  * unit box.  Emitted here as the INVERSE map (what traversal needs): inst = {W rows (9), mu (3)}, W = diag(1/kscl) R^T,
@@ -77,6 +81,28 @@ int orc_grt_proxies(const GrtConfig* cfg, uint32_t N, const real* positions, con
     return 0;
 }
 
+/* computeGaussianEnclosingAABBKernel, particlePrimitives.cu:498-541: the bounding box of the 8 corners R (c * kscl) + mu, c = +-1.  The
+ * extreme corner of an axis has all three products of one sign: mu -+ ((|R_c0| k0 + |R_c1| k1) + |R_c2| k2), in the kernel's own
+ * left-to-right summation (the same expression as grt_proxy_kernel's). */
+int orc_grt_custom_boxes(const GrtConfig* cfg, uint32_t N, const real* positions, const real* rotations, const real* scales, const real* densities,
+                         real* box8) {
+    for (uint32_t i = 0; i < N; ++i) {
+        const v4 q = {rotations[4 * i], rotations[4 * i + 1], rotations[4 * i + 2], rotations[4 * i + 3]};
+        const m33 rotT = quat_wxyz_to_rotT(q);
+        const real ks = orc_grt_kernel_scale(densities[i], (real)cfg->particle_kernel_min_response, cfg->particle_kernel_density_clamping,
+                                             (real)cfg->particle_kernel_degree);
+        const real k0 = ks * scales[3 * i], k1 = ks * scales[3 * i + 1], k2 = ks * scales[3 * i + 2];
+        const real ux = (r_fabs(rotT.r[0].x) * k0 + r_fabs(rotT.r[1].x) * k1) + r_fabs(rotT.r[2].x) * k2;
+        const real uy = (r_fabs(rotT.r[0].y) * k0 + r_fabs(rotT.r[1].y) * k1) + r_fabs(rotT.r[2].y) * k2;
+        const real uz = (r_fabs(rotT.r[0].z) * k0 + r_fabs(rotT.r[1].z) * k1) + r_fabs(rotT.r[2].z) * k2;
+        real* b = box8 + 8 * (size_t)i;
+        b[0] = positions[3 * i] - ux; b[1] = positions[3 * i + 1] - uy; b[2] = positions[3 * i + 2] - uz;
+        b[3] = positions[3 * i] + ux; b[4] = positions[3 * i + 1] + uy; b[5] = positions[3 * i + 2] + uz;
+        b[6] = ks * ks; b[7] = 0;
+    }
+    return 0;
+}
+
 /* ---- candidate test -------------------------------------------------------------------------
  * Instance traversal: transform the ray with the instance's inverse map, slab-test the unit box [-1,1]^3 over the
  * current interval, then intersectInstanceParticle (gaussianParticles.cuh:449-466).  All in one arithmetic type.
@@ -89,14 +115,15 @@ int orc_grt_proxies(const GrtConfig* cfg, uint32_t N, const real* positions, con
 typedef struct { real t, tnear, tfar; int ok; } grt_cand;
 
 
-static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist) {
+static real safe_rcp(real v) { return r_fabs(v) > R_(1e-30) ? 1 / v : (v < 0 || (v == 0 && 1 / v < 0) ? R_(-1.0e30) : R_(1.0e30)); }   /* grt_kernels.hip: safe_rcp */
+static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist, uint32_t id) {
     grt_cand c; c.ok = 0; c.t = 0; c.tnear = 0; c.tfar = 0;
     const v3 dl = v3_make(o.x - inst[9], o.y - inst[10], o.z - inst[11]);
     const v3 po = v3_make(inst[0] * dl.x + inst[1] * dl.y + inst[2] * dl.z, inst[3] * dl.x + inst[4] * dl.y + inst[5] * dl.z,
                           inst[6] * dl.x + inst[7] * dl.y + inst[8] * dl.z);
     const v3 pd = v3_make(r_fma(inst[2], d.z, r_fma(inst[1], d.y, inst[0] * d.x)), r_fma(inst[5], d.z, r_fma(inst[4], d.y, inst[3] * d.x)),
                           r_fma(inst[8], d.z, r_fma(inst[7], d.y, inst[6] * d.x)));
-    if (g_prim != 0) {   /* triangle-mesh proxy: clip against the polyhedron's face planes, operation by operation as candidate_abe (grt_kernels.hip) */
+    if (g_prim >= 1 && g_prim <= 4) {   /* triangle-mesh proxy: clip against the polyhedron's face planes, operation by operation as candidate_abe (grt_kernels.hip) */
         const orc_polyhedron* ph = &orc_polyhedra[g_prim];
         real tin = R_(-3.0e38), tout = R_(3.0e38);
         int miss = 0;
@@ -111,6 +138,22 @@ static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist) {
         }
         c.t = tin; c.tnear = tin; c.tfar = R_(3.0e38);
         c.ok = !miss && (tin <= tout) && (tin > R_(-3.0e38));
+        return c;
+    }
+    if (g_prim == 5) {   /* custom primitives: world box + the world-space intersection program (gaussianParticles.cuh:407-441); see candidate_abe */
+        const real* bx = g_box8 + 8 * (size_t)id;
+        const real jx = safe_rcp(d.x), jy = safe_rcp(d.y), jz = safe_rcp(d.z);
+        const real ax0 = (bx[0] - o.x) * jx, ax1 = (bx[3] - o.x) * jx, ay0 = (bx[1] - o.y) * jy, ay1 = (bx[4] - o.y) * jy;
+        const real az0 = (bx[2] - o.z) * jz, az1 = (bx[5] - o.z) * jz;
+        const real tnear = r_fmax(r_fmax(r_fmin(ax0, ax1), r_fmin(ay0, ay1)), r_fmin(az0, az1));
+        const real tfar  = r_fmin(r_fmin(r_fmax(ax0, ax1), r_fmax(ay0, ay1)), r_fmax(az0, az1));
+        if (!(tnear <= tfar)) return c;
+        c.tnear = tnear; c.tfar = tfar;
+        const real numerator = -r_fma(po.z, pd.z, r_fma(po.y, pd.y, po.x * pd.x));
+        const real dd = r_fma(pd.z, pd.z, r_fma(pd.y, pd.y, pd.x * pd.x));
+        c.t = numerator / dd;
+        const v3 cr = v3_make(r_fma(pd.y, po.z, -(pd.z * po.y)), r_fma(pd.z, po.x, -(pd.x * po.z)), r_fma(pd.x, po.y, -(pd.y * po.x)));
+        c.ok = (r_fma(cr.z, cr.z, r_fma(cr.y, cr.y, cr.x * cr.x)) * bx[6] < max_sqdist * dd);
         return c;
     }
     /* slab test of the unit box */
@@ -353,14 +396,14 @@ static uint32_t ray_candidates(uint32_t N, const real* inst12, v3 o, v3 d, grt_h
             if (i == 0xFFFFFFFFu) continue;
             i &= 0x7FFFFFFFu;
             if (i >= N) continue;
-            const grt_cand c = candidate(inst12 + 12 * (size_t)i, o, d, R_(9.0));
+            const grt_cand c = candidate(inst12 + 12 * (size_t)i, o, d, R_(9.0), i);
             if (c.ok) { out[n].t = c.t; out[n].id = i; out[n].tnear = c.tnear; out[n].tfar = c.tfar; n++; }
         }
         qsort(out, n, sizeof(grt_hit), hit_cmp);
         return n;
     }
     for (uint32_t i = 0; i < N; ++i) {
-        const grt_cand c = candidate(inst12 + 12 * (size_t)i, o, d, R_(9.0)); /* hitMaxParticleSquaredDistance, pipelineParameters.h:71 */
+        const grt_cand c = candidate(inst12 + 12 * (size_t)i, o, d, R_(9.0), i); /* hitMaxParticleSquaredDistance, pipelineParameters.h:71 */
         if (c.ok) { out[n].t = c.t; out[n].id = i; out[n].tnear = c.tnear; out[n].tfar = c.tfar; n++; }
     }
     qsort(out, n, sizeof(grt_hit), hit_cmp);

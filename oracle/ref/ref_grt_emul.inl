@@ -26,6 +26,9 @@ struct Scene {
     uint32_t num_triangles = 0;
     const float* vertices = nullptr;   // [V,3] world space, as the reference's mesh kernel wrote them
     const int32_t* triangles = nullptr;
+    // custom primitives (render.primitive_type custom: one custom-primitive GAS over the particles' world boxes, optixTracer.cpp:638-655, 810-817)
+    uint32_t num_boxes = 0;
+    const float* boxes = nullptr;      // [n,6] min xyz, max xyz, as computeGaussianEnclosingAABBKernel wrote them
 } g_scene;
 }  // namespace
 
@@ -76,6 +79,23 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
         if (!(t > g_optix.tmin && t < g_optix.tmax)) continue;
         g_optix.primitive = f;
         optixReportIntersection(t, 0);
+    }
+    return;
+#endif
+#ifdef SHIM_OPTIX_CUSTOM_PROXIES
+    // Custom primitives: the intersection program (intersectCustomParticle, world-space ray) runs for every particle whose WORLD box the
+    // ray overlaps within its interval - the same slab test and the same far-end convention as for the instances' unit boxes below.
+    // (OptiX may also call the program for a ray that misses the box narrowly; the emulation's boxes are exact.)
+    for (uint32_t i = 0; i < g_scene.num_boxes; ++i) {
+        const float* bx = g_scene.boxes + 6 * (size_t)i;
+        const float ax0 = (bx[0] - o.x) / d.x, ax1 = (bx[3] - o.x) / d.x, ay0 = (bx[1] - o.y) / d.y, ay1 = (bx[4] - o.y) / d.y;
+        const float az0 = (bx[2] - o.z) / d.z, az1 = (bx[5] - o.z) / d.z;
+        const float tn = fmaxf(fmaxf(fminf(ax0, ax1), fminf(ay0, ay1)), fminf(az0, az1));
+        const float tf = fminf(fminf(fmaxf(ax0, ax1), fmaxf(ay0, ay1)), fmaxf(az0, az1));
+        const float far_end = g_scene.box_test_uses_shrunk_tmax ? g_optix.tmax : g_scene.trace_tmax;
+        if (!(tn <= tf) || !(tf >= g_optix.tmin) || !(tn <= far_end)) continue;
+        g_optix.primitive = i;
+        __intersection__is();
     }
     return;
 #endif
@@ -150,6 +170,8 @@ static void set_scene_triangles(uint32_t num_triangles, uint32_t triangles_per_p
     g_scene.num_triangles = num_triangles; g_scene.vertices = vertices; g_scene.triangles = triangles;
     params.gPrimNumTri = triangles_per_particle;
 }
+
+static void set_scene_boxes(uint32_t n, const float* boxes) { g_scene.num_boxes = n; g_scene.boxes = boxes; }
 
 static void launch_raygen(int width, int height) {
     for (int y = 0; y < height; ++y)

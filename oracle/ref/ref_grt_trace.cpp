@@ -26,6 +26,9 @@
 #ifdef REF_PRIMITIVE   // a triangle-mesh proxy: -DREF_PRIMITIVE=MOGTracingIcosaHedron ... (optixTracer.cpp:176-201)
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::REF_PRIMITIVE
 #define SHIM_OPTIX_TRIANGLE_PROXIES
+#elif defined(REF_CUSTOM)   // render.primitive_type custom: world boxes + intersectCustomParticle (optixTracer.cpp:197-198)
+#define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingCustom
+#define SHIM_OPTIX_CUSTOM_PROXIES
 #else
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingInstances
 #endif
@@ -65,6 +68,18 @@ void ref_grt_trace_fwd_mesh(uint32_t n, uint32_t triangles_per_particle, const f
     set_common_params(width, height, ray_to_world, ray_o, ray_d, density12, sph48, scene_aabb6, min_transmittance, min_response, min_alpha,
                       sph_degree, features, density, hit_distance2, normals, hits_count, visibility);
     set_scene_triangles(n * triangles_per_particle, triangles_per_particle, vertices, triangles);
+    launch_raygen(width, height);
+}
+#endif
+
+#ifdef REF_CUSTOM
+// the same programs over the particles' world boxes (boxes [n,6] as the reference's AABB kernel wrote them, ref_grt_proxies.cpp)
+void ref_grt_trace_fwd_custom(uint32_t n, const float* boxes, const float* density12, const float* sph48, int width, int height, const float* ray_to_world,
+                              const float* ray_o, const float* ray_d, const float* scene_aabb6, float min_transmittance, float min_response, float min_alpha,
+                              unsigned sph_degree, float* features, float* density, float* hit_distance2, float* normals, float* hits_count, int32_t* visibility) {
+    set_common_params(width, height, ray_to_world, ray_o, ray_d, density12, sph48, scene_aabb6, min_transmittance, min_response, min_alpha,
+                      sph_degree, features, density, hit_distance2, normals, hits_count, visibility);
+    set_scene_boxes(n, boxes);
     launch_raygen(width, height);
 }
 #endif

@@ -26,6 +26,9 @@
 #ifdef REF_PRIMITIVE   // a triangle-mesh proxy: -DREF_PRIMITIVE=MOGTracingIcosaHedron ... (optixTracer.cpp:176-201)
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::REF_PRIMITIVE
 #define SHIM_OPTIX_TRIANGLE_PROXIES
+#elif defined(REF_CUSTOM)   // render.primitive_type custom: world boxes + intersectCustomParticle (optixTracer.cpp:197-198)
+#define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingCustom
+#define SHIM_OPTIX_CUSTOM_PROXIES
 #else
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingInstances
 #endif
@@ -86,6 +89,17 @@ void ref_grt_trace_bwd_mesh(uint32_t n, uint32_t triangles_per_particle, const f
     bwd_params_and_launch(n, density12, sph48, width, height, ray_to_world, ray_o, ray_d, scene_aabb6, min_transmittance, min_response, min_alpha, sph_degree,
                           features, density, hit_distance2, g_features, g_density, g_hit_distance, g_density12, g_sph48, triangles_per_particle, vertices,
                           triangles);
+}
+#endif
+
+#ifdef REF_CUSTOM
+void ref_grt_trace_bwd_custom(uint32_t n, const float* boxes, const float* density12, const float* sph48, int width, int height, const float* ray_to_world,
+                              const float* ray_o, const float* ray_d, const float* scene_aabb6, float min_transmittance, float min_response, float min_alpha,
+                              unsigned sph_degree, const float* features, const float* density, const float* hit_distance2, const float* g_features,
+                              const float* g_density, const float* g_hit_distance, float* g_density12, float* g_sph48) {
+    set_scene_boxes(n, boxes);
+    bwd_params_and_launch(n, density12, sph48, width, height, ray_to_world, ray_o, ray_d, scene_aabb6, min_transmittance, min_response, min_alpha, sph_degree,
+                          features, density, hit_distance2, g_features, g_density, g_hit_distance, g_density12, g_sph48, 0, nullptr, nullptr);
 }
 #endif
 

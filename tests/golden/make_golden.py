@@ -379,6 +379,32 @@ def make_grt_trace_mesh():
             for key, a in dict(features=feat, density=den, hit_distance=hit, hits_count=cnt, visibility=vis, grad_density=gd, grad_sph=gs, scene_box=box).items():
                 out[f"{name}_s{k}_{key}"] = a
             print(f"{name} scene {k}: {nt} triangles per particle, hits per ray {cnt.mean():.1f} (max {cnt.max():.0f}), opacity {den.mean():.3f}")
+    # render.primitive_type custom: the particles' world boxes (computeGaussianEnclosingAABBKernel) as custom primitives, the world-space
+    # intersection program intersectCustomParticle (gaussianParticles.cuh:407-441) - both scenes
+    fw = C.CDLL(os.path.join(REF, "libref_grt_trace_Custom_deg4.so"))
+    bw = C.CDLL(os.path.join(REF, "libref_grt_trace_bwd_Custom_deg4.so"))
+    for k, kw in enumerate(GRT_TRACE_SCENES):
+        sc = make_scene(**kw)
+        d12, sph = np.ascontiguousarray(sc["density12"]), np.ascontiguousarray(sc["sph"])
+        n, H, W = len(d12), kw["height"], kw["width"]
+        pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
+                              np.ascontiguousarray(d12[:, 3]))
+        aabb, tf = np.zeros((n, 6), F), np.zeros((n, 12), F)
+        px.ref_enclosing_proxies(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(aabb), _p(tf))
+        box = np.concatenate([aabb[:, :3].min(0), aabb[:, 3:].max(0)]).astype(F)
+        r2w = np.ascontiguousarray(np.asarray(sc["batch"]["T_to_world"][0], F)[:3, :4])
+        ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)) for a in sc["rays"])
+        feat, den, hit, nrm = np.zeros((H, W, 3), F), np.zeros((H, W, 1), F), np.zeros((H, W, 2), F), np.zeros((H, W, 3), F)
+        cnt, vis = np.zeros((H, W, 1), F), np.zeros(n, np.int32)
+        common = (C.c_uint(n), _p(aabb), _p(d12), _p(sph), W, H, _p(r2w), _p(ro), _p(rd), _p(box), C.c_float(MIN_T_GRT), C.c_float(MIN_RESPONSE),
+                  C.c_float(MIN_ALPHA), C.c_uint(3))
+        fw.ref_grt_trace_fwd_custom(*common, _p(feat), _p(den), _p(hit), _p(nrm), _p(cnt), _p(vis))
+        g_rad, g_dns, g_hit = grt_trace_upstream(H, W)
+        gd, gs = np.zeros((n, 12), F), np.zeros((n, 48), F)
+        bw.ref_grt_trace_bwd_custom(*common, _p(feat), _p(den), _p(hit), _p(g_rad), _p(g_dns), _p(g_hit), _p(gd), _p(gs))
+        for key, a in dict(features=feat, density=den, hit_distance=hit, hits_count=cnt, visibility=vis, grad_density=gd, grad_sph=gs, scene_box=box, boxes=aabb).items():
+            out[f"custom_s{k}_{key}"] = a
+        print(f"custom scene {k}: hits per ray {cnt.mean():.1f} (max {cnt.max():.0f}), opacity {den.mean():.3f}")
     np.savez_compressed(os.path.join(HERE, "grt_trace_mesh.npz"), **out)
     print("wrote grt_trace_mesh.npz")
 

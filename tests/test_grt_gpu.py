@@ -347,9 +347,80 @@ def test_mesh_proxy_packet_lists_equal_the_tree_walk(monkeypatch, prim):
     assert a[-1].max() > 10    # processed hits per ray
 
 
+def test_custom_primitives_match_reference_programs_golden():
+    """render.primitive_type = custom DIRECTLY against tests/golden/grt_trace_mesh.npz `custom_*` = the reference's forward / backward
+    programs compiled with PARTICLE_PRIMITIVE_TYPE = MOGTracingCustom over the emulated OptiX's custom-primitive boxes (the reference's AABB
+    kernel) - both scenes.  The HIP path: the instances' hit point, offered to the rays that cross the particle's WORLD box, within 3 sigma
+    (candidate_abe); tree walk (the packet lists bound the oriented proxy, not its world box)."""
+    import os
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    g = np.load(os.path.join(here, "golden", "grt_trace_mesh.npz"))
+    for k, kw in enumerate(make_golden.GRT_TRACE_SCENES):
+        scene = make_scene(**kw)
+        H, W = kw["height"], kw["width"]
+        g_rad, g_dns, g_hit = make_golden.grt_trace_upstream(H, W)
+        gpu = _render(scene, g_rad, g_dns, g_hit, primitive_type="custom")
+        out = gpu["out"]
+        assert int(gpu["tracer"].tracer_wrapper.stats().list_entries) == 0
+        cnt = out["hits_count"][0].detach().cpu().numpy()
+        flips = (cnt != g[f"custom_s{k}_hits_count"])[..., 0]
+        assert flips.mean() <= 0.01, f"scene {k}: {int(flips.sum())} rays with a different number of accepted hits"
+        e = np.abs(out["pred_features"][0].detach().cpu().numpy() - g[f"custom_s{k}_features"]).max(-1)
+        hd = g[f"custom_s{k}_hit_distance"]
+        e_d = np.abs(out["pred_dist"][0].detach().cpu().numpy() - hd[..., :1])[..., 0]
+        tied = ~flips & ((e > 1e-4) | (e_d > 1e-4 * max(1.0, np.abs(hd).max())))
+        assert tied.mean() <= 0.02 and (not tied.any() or e[tied].max() < 5e-2)
+        ok = ~flips & ~tied
+        assert np.abs(out["pred_opacity"][0].detach().cpu().numpy() - g[f"custom_s{k}_density"])[ok].max() < 1e-4
+        vis = out["mog_visibility"].view(-1).view(torch.int32).cpu().numpy() != 0
+        ndrop = 3 * int((flips | tied).sum())
+        assert (vis != (g[f"custom_s{k}_visibility"] != 0)).sum() <= ndrop
+        gd, gs = gpu["grads"]
+        rd, rs = g[f"custom_s{k}_grad_density"], g[f"custom_s{k}_grad_sph"]
+        per = np.sort(np.abs(gd[:, :11].astype(np.float64) - rd[:, :11]).max(1))[: max(1, len(gd) - ndrop)]
+        assert per.max() / np.abs(rd[:, :11]).max() < 1e-3
+        per = np.sort(np.abs(gs.astype(np.float64) - rs).max(1))[: max(1, len(gs) - ndrop)]
+        assert per.max() / np.abs(rs).max() < 1e-3
+
+
+def test_custom_primitives_hit_order_equals_oracle():
+    """A larger scene through the debug hit lists: every ray's SEQUENCE of processed particles against the oracle given the GPU-built proxy
+    records (world-box slab test and 3-sigma test: the same operations in the same order on both sides), images, default (replayed)
+    backward against the oracle's backward program."""
+    scene = _scene(4000, 64, 48, 0.06)
+    tr, (feat, dns, hit, nrm, cnt, vis, ids, num), inst, scene_aabb = _gpu_hits(scene, primitive_type="custom")
+    cfg = oracle.default_grt_config(primitive_type=5)
+    box8 = tr.tracer_wrapper.custom_boxes(len(scene["density12"]), "cuda").cpu().numpy()
+    assert np.abs(box8 - oracle.grt_custom_boxes(cfg, scene["density12"])).max() <= 2e-6 * np.abs(box8).max()   # (kernelScale: device logf / sqrtf)
+    ora = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=scene_aabb, dbg_cap=256, box8=box8)
+    num = num.astype(np.int64)
+    assert np.array_equal(num, ora["hit_num"].astype(np.int64)), f"{(num != ora['hit_num']).sum()} rays with a different number of processed hits"
+    k = np.minimum(num, 256)
+    got, ref = ids.view(np.uint32), ora["hit_ids"]
+    for r in range(scene["H"] * scene["W"]):
+        assert np.array_equal(got[r, :k[r]], ref[r, :k[r]]), f"ray {r}: order differs"
+    assert num.max() > 20
+    assert np.abs(feat[0] - ora["features"]).max() < 1e-4 and np.abs(dns[0] - ora["density"]).max() < 1e-4 and np.array_equal(cnt[0], ora["hit_count"])
+    # another candidate set than the instances of the same scene (world box instead of the oriented cube, the plain 3-sigma test instead of
+    # intersectInstanceParticle's)
+    _, (_, _, _, _, _, _, _, num_inst), _, _ = _gpu_hits(scene)
+    assert num.sum() != num_inst.astype(np.int64).sum()
+    rng = np.random.default_rng(4)
+    g_rad = rng.normal(size=(scene["H"], scene["W"], 3)).astype(np.float32)
+    g_dns = rng.normal(size=(scene["H"], scene["W"], 1)).astype(np.float32)
+    gpu = _render(scene, g_rad, g_dns, None, primitive_type="custom")
+    rd, rs = oracle.grt_backward(cfg, 3, 1e-3, ora, g_rad, g_dns, np.zeros_like(g_dns))
+    gd, gs = gpu["grads"]
+    assert rel_err(gd[:, :11], rd[:, :11]) < 1e-3 and rel_err(gs, rs) < 1e-3
+
+
 def test_unsupported_primitives_are_refused():
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
-    for prim in ("trihexa", "trisurfel", "sphere", "custom"):
+    for prim in ("trihexa", "trisurfel", "sphere"):
         with pytest.raises(NotImplementedError, match="primitive_type"):
             grt.Tracer({"render": {"primitive_type": prim}})
 

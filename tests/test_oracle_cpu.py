@@ -495,6 +495,50 @@ def test_grt_mesh_proxies_match_reference_programs_golden(prim):
     assert (prox["scene"][3:] - prox["scene"][:3] <= (box[3:] - box[:3]) * 1.8).all()
 
 
+def test_grt_custom_primitives_match_reference_programs_golden():
+    """render.primitive_type = custom: the oracle (world boxes of computeGaussianEnclosingAABBKernel + the maximum-response point within
+    3 sigma, orc_grt_custom_boxes / candidate) against tests/golden/grt_trace_mesh.npz `custom_*` = the reference's programs compiled with
+    PARTICLE_PRIMITIVE_TYPE = MOGTracingCustom (intersectCustomParticle in world space) over the emulated OptiX's custom-primitive boxes.
+    The reference's program evaluates the hit distance in the particle's scale frame, the oracle in the proxy frame (the same point; other
+    roundings): two hits that tie to rounding may swap."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = np.load(os.path.join(HERE, "golden", "grt_trace_mesh.npz"))
+    cfg = oracle.default_grt_config(primitive_type=5)
+    for k, kw in enumerate(make_golden.GRT_TRACE_SCENES):
+        sc = make_scene(**kw)
+        H, W = kw["height"], kw["width"]
+        o = oracle.grt_forward(cfg, sc["density12"], sc["sph"], 3, 1e-3, sc["batch"]["T_to_world"][0], *sc["rays"])
+        # the boxes are the reference kernel's, to the last bit but for the kernel-scale's own rounding
+        box8 = oracle.grt_custom_boxes(cfg, sc["density12"])
+        ref_box = g[f"custom_s{k}_boxes"]
+        assert np.abs(box8[:, :6] - ref_box).max() <= 4e-7 * np.abs(ref_box).max(), f"scene {k}: world boxes"
+        ref_cnt = g[f"custom_s{k}_hits_count"]
+        flips = (o["hit_count"] != ref_cnt)[..., 0]
+        assert flips.mean() <= 0.01 and ref_cnt.max() >= 20, f"custom scene {k}: {int(flips.sum())} rays with another number of accepted hits"
+        ok = ~flips
+        e = np.abs(o["features"] - g[f"custom_s{k}_features"]).max(-1)
+        hd = g[f"custom_s{k}_hit_distance"]
+        e_depth = np.abs(o["hit_distance"] - hd)[..., 0]
+        tied = ok & ((e > 1e-5) | (e_depth > 2e-5 * max(1.0, np.abs(hd).max())))
+        assert tied.mean() <= 0.02 and (not tied.any() or (e[tied].max() < 2e-2 and e_depth[tied].max() < 2e-2)), f"custom scene {k}: {int(tied.sum())} rays differ with the same hit count"
+        ok = ok & ~tied
+        assert np.abs(o["density"] - g[f"custom_s{k}_density"])[ok].max() < 1e-5
+        assert np.abs(o["hit_distance"] - hd)[..., 1][ok].max() <= 1e-5 * max(1.0, np.abs(hd).max())
+        assert ((o["visibility"] != 0) != (g[f"custom_s{k}_visibility"] != 0)).sum() <= 3 * int((flips | tied).sum())
+        # not the instances' result: the world box contains the oriented cube, so more rays are offered the particle
+        inst_cnt = np.load(os.path.join(HERE, "golden", "grt_trace.npz"))[f"s{k}_hits_count"]
+        assert ref_cnt.sum() > inst_cnt.sum()
+        g_rad, g_dns, g_hit = make_golden.grt_trace_upstream(H, W)
+        gd, gs = oracle.grt_backward(cfg, 3, 1e-3, o, g_rad, g_dns, g_hit)
+        rd, rs = g[f"custom_s{k}_grad_density"], g[f"custom_s{k}_grad_sph"]
+        ndrop = 3 * int((flips | tied).sum())
+        per = np.sort(np.abs(gd[:, :11].astype(np.float64) - rd[:, :11]).max(1))[: max(1, len(gd) - ndrop)]
+        assert per.max() / np.abs(rd[:, :11]).max() < 2e-4, f"custom scene {k}: particle gradients"
+        per = np.sort(np.abs(gs.astype(np.float64) - rs).max(1))[: max(1, len(gs) - ndrop)]
+        assert per.max() / np.abs(rs).max() < 2e-4, f"custom scene {k}: SH gradients"
+
+
 def test_gut_frame_matches_reference_kernels_golden():
     """The oracle's whole 3DGUT frame against tests/golden/gut_render.npz = the reference's own projectOnTiles / render /
     renderBackward kernels run on the host (oracle/ref/ref_gut_render.cpp: the real particle class, GUTKBufferRenderer's tile
