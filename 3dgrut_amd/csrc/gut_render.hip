@@ -390,7 +390,7 @@ struct FwdState {
     v2f T, D, Cr, Cg, Cb, cnt;
     unsigned long long t_stage;   // instrumented build: ticks spent staging rounds
 };
-template <int DEG, bool CKPT, bool UNI, bool COUNT = false>
+template <int DEG, bool CKPT, bool UNI, bool COUNT = false, bool ILP2 = false>
 __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPair& rp, uint2 range, uint32_t half, int lane,
                                                  const EntryLists& lists, const float4* __restrict__ density12,
                                                  const float* __restrict__ rgb, const GutCheckpoints& ck, float4* __restrict__ s_rec,
@@ -440,6 +440,55 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         if (COUNT) t_stage += wall_clock64() - t_round;
         // fetch the following round while this one is being composited
         next = load_entry<false>(bend + lane, min(range.y, bend + 64u), lists, density12, rgb);
+        if (ILP2) {
+            // latency form (launches whose waves are all resident at once: the longest wave IS the kernel, and a lone wave spends an entry's
+            // ~1300 cycles waiting on its own dependency chain): two entries' geometry and responses are evaluated side by side, then
+            // applied in order - an entry with alpha = 0 is an exact no-op on (T, D, C, cnt), and a pixel the first entry killed takes
+            // alpha = 0 from the second, so every pixel sees the same operations in the same order as in the plain loop
+            for (int j = 0; j < n; j += 2) {
+                if (!__any(alive0 || alive1)) break;
+                const bool two = j + 1 < n;
+                const float4* recA = &s_rec[j * kRecQuads];
+                const float4* recB = &s_rec[(two ? j + 1 : j) * kRecQuads];
+                const float4 a3 = recA[3], a4 = recA[4], b3 = recB[3], b4 = recB[4];   // (requested with the geometry rows: one LDS round trip per pair)
+                const PairGeom gA = pair_geometry<UNI>(rp, recA), gB = pair_geometry<UNI>(rp, recB);
+                const bool cA0 = gA.acc0 && alive0, cA1 = gA.acc1 && alive1, cB0 = two && gB.acc0 && alive0, cB1 = two && gB.acc1 && alive1;
+                if (COUNT) n_eval += two ? 2u : 1u;
+                if (!__any(cA0 || cA1 || cB0 || cB1)) continue;
+                if (COUNT) n_acc += (__any(cA0 || cA1) ? 1u : 0u) + (__any(cB0 || cB1) ? 1u : 0u);
+                const v2f ilA = prcp(gA.l2), ilB = prcp(gB.l2);
+                const v2f adA = pair_response<DEG>(gA.cc * ilA) * a3.w, adB = pair_response<DEG>(gB.cc * ilB) * b3.w;
+                const v2f vuA = pdot(gA.v, gA.u), vuB = pdot(gB.v, gB.u);
+                const p3 svA = p3{a3.x * gA.v.x, a3.y * gA.v.y, a3.z * gA.v.z}, svB = p3{b3.x * gB.v.x, b3.y * gB.v.y, b3.z * gB.v.z};
+                const v2f ssA = pdot(svA, svA) * (vuA * vuA), ssB = pdot(svB, svB) * (vuB * vuB);
+                const v2f hitA = v2f{__builtin_amdgcn_sqrtf(ssA.x), __builtin_amdgcn_sqrtf(ssA.y)} * ilA;
+                const v2f hitB = v2f{__builtin_amdgcn_sqrtf(ssB.x), __builtin_amdgcn_sqrtf(ssB.y)} * ilB;
+                {
+                    const bool h0 = cA0 && (hitA.x > rp.tmin.x) && (hitA.x < rp.tmax.x), h1 = cA1 && (hitA.y > rp.tmin.y) && (hitA.y < rp.tmax.y);
+                    const v2f alpha = psel(h0, h1, v2f{fminf(P.max_alpha, adA.x), fminf(P.max_alpha, adA.y)}, splat(0.f));
+                    const v2f hT = psel(h0, h1, hitA, splat(0.f));
+                    const v2f w = alpha * T;
+                    D = pfma(hT, w, D);
+                    T = T * (1.f - alpha);
+                    Cr = pfma(a4.x, w, Cr); Cg = pfma(a4.y, w, Cg); Cb = pfma(a4.z, w, Cb);
+                    cnt += psel(w.x > 0.f, w.y > 0.f, splat(1.f), splat(0.f));
+                    alive0 = alive0 && !(T.x < P.min_transmittance);
+                    alive1 = alive1 && !(T.y < P.min_transmittance);
+                }
+                {
+                    const bool h0 = cB0 && alive0 && (hitB.x > rp.tmin.x) && (hitB.x < rp.tmax.x), h1 = cB1 && alive1 && (hitB.y > rp.tmin.y) && (hitB.y < rp.tmax.y);
+                    const v2f alpha = psel(h0, h1, v2f{fminf(P.max_alpha, adB.x), fminf(P.max_alpha, adB.y)}, splat(0.f));
+                    const v2f hT = psel(h0, h1, hitB, splat(0.f));
+                    const v2f w = alpha * T;
+                    D = pfma(hT, w, D);
+                    T = T * (1.f - alpha);
+                    Cr = pfma(b4.x, w, Cr); Cg = pfma(b4.y, w, Cg); Cb = pfma(b4.z, w, Cb);
+                    cnt += psel(w.x > 0.f, w.y > 0.f, splat(1.f), splat(0.f));
+                    alive0 = alive0 && !(T.x < P.min_transmittance);
+                    alive1 = alive1 && !(T.y < P.min_transmittance);
+                }
+            }
+        } else
         for (int j = 0; j < n; ++j) {
             if (!__any(alive0 || alive1)) break;   // the rest of the round is behind every pixel's termination
             const float4* rec = &s_rec[j * kRecQuads];
@@ -486,13 +535,16 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
     }
 }
 
+#ifndef GRUT_FWD_ILP2_WAVES
+#define GRUT_FWD_ILP2_WAVES 5   // the latency form (two entries side by side): 96 VGPRs
+#endif
 #ifndef GRUT_FWD_WAVES
 #define GRUT_FWD_WAVES 6   // held to 80 VGPRs (12 B of scratch): r02v 0.485 -> 0.472 ms; 0 = the allocator's own choice (90 VGPRs, 5 waves): 4 waves 0.508
 #endif
-template <int DEG, bool CKPT, bool COUNT = false>
+template <int DEG, bool CKPT, bool COUNT = false, bool ILP2 = false>
 __global__ __launch_bounds__(64)
 #if GRUT_FWD_WAVES > 0
-__attribute__((amdgpu_waves_per_eu(GRUT_FWD_WAVES, GRUT_FWD_WAVES)))
+__attribute__((amdgpu_waves_per_eu(ILP2 ? GRUT_FWD_ILP2_WAVES : GRUT_FWD_WAVES, ILP2 ? GRUT_FWD_ILP2_WAVES : GRUT_FWD_WAVES)))
 #endif
 void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
@@ -514,8 +566,8 @@ void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryL
     const unsigned long long t_rays = COUNT ? wall_clock64() : 0ull;
     FwdState st;
     // two copies of the sweep: the shared-origin one keeps the canonical origin out of the per-pixel math
-    if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
-    else render_fwd_sweep<DEG, CKPT, false, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
+    if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true, COUNT, ILP2>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
+    else render_fwd_sweep<DEG, CKPT, false, COUNT, false>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
     if (COUNT && P.work && lane == 0) {   // diagnostics: this wave's lifetime (shader-clock ticks) and start time, for the balance analysis
         const unsigned long long t_end = wall_clock64();
         // lifetime | rays ready << 32 | time spent staging << 48 (10 ns ticks)
@@ -1256,6 +1308,14 @@ void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
     const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
     if (P.work && P.degree == 2 && write_checkpoints) {   // instrumented frame (gut_profile_enable level 2): the counting build of the default kernel
         hipLaunchKernelGGL((gut_render_fwd_kernel<2, true, true>), dim3(half_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
+                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d, reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck);
+        return;
+    }
+    // latency form: when every wave of the launch is resident at once (<= 5 per SIMD x 1024 SIMDs) the longest wave is the kernel
+    static const int ilp2_env = getenv("GRUT_FWD_ILP2") ? atoi(getenv("GRUT_FWD_ILP2")) : -1;   // development switch: 0 / 1 force, default by size
+    const bool ilp2 = ilp2_env >= 0 ? ilp2_env != 0 : half_grid(P) <= 5120u;
+    if (write_checkpoints && ilp2 && P.degree == 2) {
+        hipLaunchKernelGGL((gut_render_fwd_kernel<2, true, false, true>), dim3(half_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
                            reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d, reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck);
         return;
     }
