@@ -400,7 +400,9 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     c.t = numerator / dd;
     const bool wanted = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
     if (!wanted && !always_box) return c;
-    if (r.prim == GRUT_PRIM_CUSTOM) {
+    // (not in the packet lists' test, REL: custom primitives walk the tree - the list kernels keep their register allocation; inlined
+    // there, the branch cost the forward 3 %)
+    if (!REL && r.prim == GRUT_PRIM_CUSTOM) {
         // custom primitives (render.primitive_type custom; optixTracer.cpp:638-655, intersectCustomParticle gaussianParticles.cuh:407-441): the
         // intersection program runs for rays that overlap the particle's WORLD box, reports the point of maximum response - the same point
         // as the instances' (the proxy frame differs from the program's scale frame by the scalar kernelScale, which cancels in the
