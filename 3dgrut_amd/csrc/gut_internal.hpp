@@ -91,7 +91,12 @@ __device__ __forceinline__ float4 load_grad_in(const GutGradIn& g, size_t pix) {
 #endif
 
 // the gradient sweep runs a long tile list as independent segments of this many sorted entries
-constexpr uint32_t kGutSegment = 256;
+#ifndef GRUT_GUT_SEGMENT
+#define GRUT_GUT_SEGMENT 64    // round 4: 256 -> 64 (the forward's batch): gradient-sweep tasks a quarter as long - 1080p step 2.040 -> 2.016 ms, 800x800
+                               // 1.84 -> 1.75, 400x400 0.81 -> 0.70, 3 M Gaussians 3.25 -> 3.17 (A/B on one box; 128: in between); 80 B of
+                               // checkpoint space per tile entry
+#endif
+constexpr uint32_t kGutSegment = GRUT_GUT_SEGMENT;
 
 // Per-pixel compositing state saved by the forward sweep every kGutSegment sorted entries (at the global sorted
 // index b * kGutSegment, for the tile whose list contains it), so that the gradient sweep can start any segment of

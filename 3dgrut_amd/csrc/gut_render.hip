@@ -1751,7 +1751,9 @@ bool nht_fast_path(const GutParams& P) {
     const bool generic = getenv("GRUT_NHT_GENERIC") != nullptr;   // (development / test switch, read per call: the strip kernels for every shape)
     return P.nht && !generic && P.nht_k == kNhtK && P.nht_ipd == kNhtIpd && P.nht_support == 1 && P.nht_act == 2 && P.nht_nf == 1 && P.k_buffer == 0;
 }
-uint64_t nht_checkpoint_bytes(uint32_t num_boundaries) { return (uint64_t)num_boundaries * 2u * kNhtCkQuads * 64u * sizeof(float4); }
+uint64_t nht_checkpoint_bytes(uint32_t num_boundaries) {   // (num_boundaries counts kGutSegment boundaries; the feature sweeps use every kNhtSegment-th entry)
+    return ((uint64_t)nht_boundaries(num_boundaries) + 1u) * 2u * kNhtCkQuads * 64u * sizeof(float4);
+}
 void launch_render_nhtp_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                             const float* density12, const float* features, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                             float* out_cnt, void* ck_nht, const GutCheckpoints& ck, bool write_checkpoints) {
@@ -1770,7 +1772,7 @@ void launch_render_nhtp_bwd(hipStream_t s, const GutParams& P, const uint32_t* r
                             const float* features, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd, const float* g_feat,
                             const float* g_opa, const float* dist, const float* g_dist, const GutGradSlots& slots, float* g_features,
                             const void* ck_nht, const GutCheckpoints& ck) {
-    const dim3 grid(segment_grid(P, ck.num_boundaries));
+    const dim3 grid(segment_grid(P, nht_boundaries(ck.num_boundaries)));
     const EntryLists lists = entry_lists(P, sorted_pos, slots.pos_particle);
     const NhtGradIn g_in{g_fd, g_feat, g_opa};
     if (g_dist) {

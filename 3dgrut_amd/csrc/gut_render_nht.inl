@@ -17,6 +17,10 @@
 //   * geometric gradients leave through the entry's slot (16 words: B, d density, M, direct scale terms; contracted once per particle
 //     by gut_grad_gather_kernel) - no atomics; the 48 feature-row words are summed over the wave through the LDS transposition and
 //     leave as ONE 48-lane atomic instruction per (half tile, entry) on consecutive words of the particle's row.
+constexpr uint32_t kNhtSegment = 256;              // the feature sweeps' checkpoint interval: a multiple of kGutSegment (their checkpoints are 26 KB per
+                                                   // segment and half tile; the SH sweeps' 64-entry segments measured no faster here)
+static_assert(kNhtSegment % kGutSegment == 0, "feature checkpoints sit on SH segment boundaries");
+__host__ __device__ inline uint32_t nht_boundaries(uint32_t num_boundaries) { return (num_boundaries + kNhtSegment / kGutSegment - 1u) / (kNhtSegment / kGutSegment); }
 constexpr uint32_t kNhtBatch = 32;                 // staged entries per round (LDS: 32 x (96 + 192) B per wave)
 constexpr int kNhtIpd = 12, kNhtRay = 24, kNhtK = 48;
 constexpr int kNhtCkQuads = 13;                    // checkpoint of a lane: {T, D} + 24 partial sums, for two pixels = 13 float4
@@ -101,8 +105,8 @@ __device__ __forceinline__ void nht_fwd_sweep(const GutParams& P, const RayPair&
     while (b < range.y) {
         if (!__any(alive0 || alive1)) break;
         const uint32_t bend = min(range.y, (b & ~(kNhtBatch - 1u)) + kNhtBatch);
-        if (CKPT && b > range.x && (b % kGutSegment) == 0) {
-            float4* out = ck_nht + ((size_t)(b / kGutSegment) * 2 + half) * (kNhtCkQuads * 64) + lane;
+        if (CKPT && b > range.x && (b % kNhtSegment) == 0) {
+            float4* out = ck_nht + ((size_t)(b / kNhtSegment) * 2 + half) * (kNhtCkQuads * 64) + lane;
             out[0] = make_float4(alive0 ? T.x : 0.f, alive1 ? T.y : 0.f, D.x, D.y);   // dead pixels restart dead
 #pragma unroll
             for (int q = 0; q < 12; ++q) out[64 * (q + 1)] = make_float4(acc[2 * q].x, acc[2 * q].y, acc[2 * q + 1].x, acc[2 * q + 1].y);
@@ -448,7 +452,9 @@ void gut_render_nhtp_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, E
     __shared__ float s_tr[16 * 65];
     __shared__ float s_acc[kNhtBatch * 16];
     // task = (virtual tile, half), as gut_render_bwd_kernel: the segments that start at a checkpoint first, then the tiles' first segments
-    const uint32_t num_tiles = (uint32_t)(P.gx * P.gy), bnd_pad = (ck.num_boundaries + 7u) & ~7u;
+    // (the feature sweeps checkpoint every kNhtSegment entries: every kNhtSegment / kGutSegment-th boundary of the frame's tables)
+    constexpr uint32_t kStep = kNhtSegment / kGutSegment;
+    const uint32_t num_tiles = (uint32_t)(P.gx * P.gy), bnd_pad = (nht_boundaries(ck.num_boundaries) + 7u) & ~7u;
     uint32_t vtile, half;
     half_mapping(blockIdx.x, vtile, half);
     uint32_t tile, seg_begin, boundary = 0;
@@ -458,7 +464,7 @@ void gut_render_nhtp_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, E
         if (tile >= num_tiles) return;
         seg_begin = ranges[tile].x;
     } else {
-        boundary = vtile;
+        boundary = vtile * kStep;
         if (boundary == 0 || boundary >= ck.num_boundaries) return;
         if (!ck.reached[(size_t)boundary * 2 + half]) return;
         tile = ck.boundary_tile[boundary];
@@ -468,7 +474,7 @@ void gut_render_nhtp_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, E
         from_checkpoint = true;
     }
     const int lane = threadIdx.x;
-    const uint32_t seg_end = min(ranges[tile].y, (seg_begin / kGutSegment + 1u) * kGutSegment);
+    const uint32_t seg_end = min(ranges[tile].y, (seg_begin / kNhtSegment + 1u) * kNhtSegment);
     const RayPair rp = init_ray_pair(P, ray_o, ray_d, tile, half, lane);
     bool alive0 = rp.valid0, alive1 = rp.valid1;
     v2f T = splat(1.f), D = splat(0.f), T_fin = splat(0.f), D_fin = splat(0.f), gT = splat(0.f), gD = splat(0.f);
@@ -512,7 +518,7 @@ void gut_render_nhtp_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, E
         }
     }
     if (from_checkpoint) {
-        const float4* in = ck_nht + ((size_t)boundary * 2 + half) * (kNhtCkQuads * 64) + lane;
+        const float4* in = ck_nht + ((size_t)(boundary / kStep) * 2 + half) * (kNhtCkQuads * 64) + lane;
         const float4 c0 = in[0];
         T = v2f{c0.x, c0.y};
         if (HAS_GDIST) D = v2f{c0.z, c0.w};
