@@ -255,16 +255,17 @@ __device__ __forceinline__ float wave_min(float v) {
     return v;
 }
 __device__ __forceinline__ float uniform(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
-__device__ __forceinline__ WavePyramid wave_pyramid(const RayPair& rp) {
+// (up to two rays per lane: the pixel pair of the half-tile waves, one ray of the quarter-tile waves with valid1 = false)
+__device__ __forceinline__ WavePyramid wave_pyramid(bool valid0, f3 d0, bool valid1, f3 d1) {
     WavePyramid w;
     w.on = false;
     w.c00 = w.e1 = w.e2 = mk3(0.f, 0.f, 0.f);
     w.dx = w.dy = 0.f;
-    const unsigned long long m0 = __ballot(rp.valid0), m1 = __ballot(rp.valid1);
+    const unsigned long long m0 = __ballot(valid0), m1 = __ballot(valid1);
     if (!(m0 | m1)) return w;
     f3 a;
-    if (m0) { const int src = __ffsll((long long)m0) - 1; a = mk3(__shfl(rp.d.x.x, src, 64), __shfl(rp.d.y.x, src, 64), __shfl(rp.d.z.x, src, 64)); }
-    else { const int src = __ffsll((long long)m1) - 1; a = mk3(__shfl(rp.d.x.y, src, 64), __shfl(rp.d.y.y, src, 64), __shfl(rp.d.z.y, src, 64)); }
+    if (m0) { const int src = __ffsll((long long)m0) - 1; a = mk3(__shfl(d0.x, src, 64), __shfl(d0.y, src, 64), __shfl(d0.z, src, 64)); }
+    else { const int src = __ffsll((long long)m1) - 1; a = mk3(__shfl(d1.x, src, 64), __shfl(d1.y, src, 64), __shfl(d1.z, src, 64)); }
     a = a * __builtin_amdgcn_rsqf(dot(a, a));
     a = mk3(uniform(a.x), uniform(a.y), uniform(a.z));
     // any unit tangent pair: e1 = a x (the axis a is least aligned with), e2 = a x e1
@@ -273,16 +274,15 @@ __device__ __forceinline__ WavePyramid wave_pyramid(const RayPair& rp) {
     f3 e1 = cross(a, k);
     e1 = e1 * __builtin_amdgcn_rsqf(dot(e1, e1));
     const f3 e2 = cross(a, e1);
-    const f3 d0 = mk3(rp.d.x.x, rp.d.y.x, rp.d.z.x), d1 = mk3(rp.d.x.y, rp.d.y.y, rp.d.z.y);
     const float q0 = dot(d0, a), q1 = dot(d1, a);
     const float l0 = __builtin_amdgcn_sqrtf(dot(d0, d0)), l1 = __builtin_amdgcn_sqrtf(dot(d1, d1));
-    const bool ok0 = !rp.valid0 || q0 > 0.5f * l0, ok1 = !rp.valid1 || q1 > 0.5f * l1;
+    const bool ok0 = !valid0 || q0 > 0.5f * l0, ok1 = !valid1 || q1 > 0.5f * l1;
     if (!__all(ok0 && ok1)) return w;
     const float big = 3.0e38f;
     const float i0 = 1.f / q0, i1 = 1.f / q1;
     const float x_0 = dot(d0, e1) * i0, y_0 = dot(d0, e2) * i0, x_1 = dot(d1, e1) * i1, y_1 = dot(d1, e2) * i1;
-    const float xlo = wave_min(fminf(rp.valid0 ? x_0 : big, rp.valid1 ? x_1 : big)), xhi = -wave_min(fminf(rp.valid0 ? -x_0 : big, rp.valid1 ? -x_1 : big));
-    const float ylo = wave_min(fminf(rp.valid0 ? y_0 : big, rp.valid1 ? y_1 : big)), yhi = -wave_min(fminf(rp.valid0 ? -y_0 : big, rp.valid1 ? -y_1 : big));
+    const float xlo = wave_min(fminf(valid0 ? x_0 : big, valid1 ? x_1 : big)), xhi = -wave_min(fminf(valid0 ? -x_0 : big, valid1 ? -x_1 : big));
+    const float ylo = wave_min(fminf(valid0 ? y_0 : big, valid1 ? y_1 : big)), yhi = -wave_min(fminf(valid0 ? -y_0 : big, valid1 ? -y_1 : big));
     const float pad = 1e-6f;   // tangent units (a pixel is ~1e-3): the rounding of x, y themselves
     const float x0 = uniform(xlo) - pad, x1 = uniform(xhi) + pad, y0 = uniform(ylo) - pad, y1 = uniform(yhi) + pad;
     w.on = true;
@@ -293,6 +293,9 @@ __device__ __forceinline__ WavePyramid wave_pyramid(const RayPair& rp) {
     w.dx = x1 - x0;
     w.dy = y1 - y0;
     return w;
+}
+__device__ __forceinline__ WavePyramid wave_pyramid(const RayPair& rp) {
+    return wave_pyramid(rp.valid0, mk3(rp.d.x.x, rp.d.y.x, rp.d.z.x), rp.valid1, mk3(rp.d.x.y, rp.d.y.y, rp.d.z.y));
 }
 // does the staged record's sphere miss every line of the wave?  (rec as stage_entry builds it, uniform-origin form: r5.xyz = u)
 __device__ __forceinline__ bool pyramid_misses(const WavePyramid& w, float4 r0, float4 r1, float4 r2, float gmax, float4 r5) {
@@ -390,7 +393,7 @@ struct FwdState {
     v2f T, D, Cr, Cg, Cb, cnt;
     unsigned long long t_stage;   // instrumented build: ticks spent staging rounds
 };
-template <int DEG, bool CKPT, bool UNI, bool COUNT = false, bool ILP2 = false>
+template <int DEG, bool CKPT, bool UNI, bool COUNT = false>
 __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPair& rp, uint2 range, uint32_t half, int lane,
                                                  const EntryLists& lists, const float4* __restrict__ density12,
                                                  const float* __restrict__ rgb, const GutCheckpoints& ck, float4* __restrict__ s_rec,
@@ -415,7 +418,7 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
             ck.tc[slot + 1] = make_float4(alive1 ? T.y : 0.f, Cr.y, Cg.y, Cb.y);
             ck.d[slot] = D.x;
             ck.d[slot + 1] = D.y;
-            if (lane == 0) ck.reached[(size_t)(b / kGutSegment) * 2 + half] = 1;
+            if (lane == 0) ck.reached[(size_t)(b / kGutSegment) * 2 + half] = 3;   // (one bit per quarter of the half tile: both arrive together here)
         }
         int n = (int)(bend - b);
         if (COUNT) ++n_rounds;
@@ -440,55 +443,6 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         if (COUNT) t_stage += wall_clock64() - t_round;
         // fetch the following round while this one is being composited
         next = load_entry<false>(bend + lane, min(range.y, bend + 64u), lists, density12, rgb);
-        if (ILP2) {
-            // latency form (launches whose waves are all resident at once: the longest wave IS the kernel, and a lone wave spends an entry's
-            // ~1300 cycles waiting on its own dependency chain): two entries' geometry and responses are evaluated side by side, then
-            // applied in order - an entry with alpha = 0 is an exact no-op on (T, D, C, cnt), and a pixel the first entry killed takes
-            // alpha = 0 from the second, so every pixel sees the same operations in the same order as in the plain loop
-            for (int j = 0; j < n; j += 2) {
-                if (!__any(alive0 || alive1)) break;
-                const bool two = j + 1 < n;
-                const float4* recA = &s_rec[j * kRecQuads];
-                const float4* recB = &s_rec[(two ? j + 1 : j) * kRecQuads];
-                const float4 a3 = recA[3], a4 = recA[4], b3 = recB[3], b4 = recB[4];   // (requested with the geometry rows: one LDS round trip per pair)
-                const PairGeom gA = pair_geometry<UNI>(rp, recA), gB = pair_geometry<UNI>(rp, recB);
-                const bool cA0 = gA.acc0 && alive0, cA1 = gA.acc1 && alive1, cB0 = two && gB.acc0 && alive0, cB1 = two && gB.acc1 && alive1;
-                if (COUNT) n_eval += two ? 2u : 1u;
-                if (!__any(cA0 || cA1 || cB0 || cB1)) continue;
-                if (COUNT) n_acc += (__any(cA0 || cA1) ? 1u : 0u) + (__any(cB0 || cB1) ? 1u : 0u);
-                const v2f ilA = prcp(gA.l2), ilB = prcp(gB.l2);
-                const v2f adA = pair_response<DEG>(gA.cc * ilA) * a3.w, adB = pair_response<DEG>(gB.cc * ilB) * b3.w;
-                const v2f vuA = pdot(gA.v, gA.u), vuB = pdot(gB.v, gB.u);
-                const p3 svA = p3{a3.x * gA.v.x, a3.y * gA.v.y, a3.z * gA.v.z}, svB = p3{b3.x * gB.v.x, b3.y * gB.v.y, b3.z * gB.v.z};
-                const v2f ssA = pdot(svA, svA) * (vuA * vuA), ssB = pdot(svB, svB) * (vuB * vuB);
-                const v2f hitA = v2f{__builtin_amdgcn_sqrtf(ssA.x), __builtin_amdgcn_sqrtf(ssA.y)} * ilA;
-                const v2f hitB = v2f{__builtin_amdgcn_sqrtf(ssB.x), __builtin_amdgcn_sqrtf(ssB.y)} * ilB;
-                {
-                    const bool h0 = cA0 && (hitA.x > rp.tmin.x) && (hitA.x < rp.tmax.x), h1 = cA1 && (hitA.y > rp.tmin.y) && (hitA.y < rp.tmax.y);
-                    const v2f alpha = psel(h0, h1, v2f{fminf(P.max_alpha, adA.x), fminf(P.max_alpha, adA.y)}, splat(0.f));
-                    const v2f hT = psel(h0, h1, hitA, splat(0.f));
-                    const v2f w = alpha * T;
-                    D = pfma(hT, w, D);
-                    T = T * (1.f - alpha);
-                    Cr = pfma(a4.x, w, Cr); Cg = pfma(a4.y, w, Cg); Cb = pfma(a4.z, w, Cb);
-                    cnt += psel(w.x > 0.f, w.y > 0.f, splat(1.f), splat(0.f));
-                    alive0 = alive0 && !(T.x < P.min_transmittance);
-                    alive1 = alive1 && !(T.y < P.min_transmittance);
-                }
-                {
-                    const bool h0 = cB0 && alive0 && (hitB.x > rp.tmin.x) && (hitB.x < rp.tmax.x), h1 = cB1 && alive1 && (hitB.y > rp.tmin.y) && (hitB.y < rp.tmax.y);
-                    const v2f alpha = psel(h0, h1, v2f{fminf(P.max_alpha, adB.x), fminf(P.max_alpha, adB.y)}, splat(0.f));
-                    const v2f hT = psel(h0, h1, hitB, splat(0.f));
-                    const v2f w = alpha * T;
-                    D = pfma(hT, w, D);
-                    T = T * (1.f - alpha);
-                    Cr = pfma(b4.x, w, Cr); Cg = pfma(b4.y, w, Cg); Cb = pfma(b4.z, w, Cb);
-                    cnt += psel(w.x > 0.f, w.y > 0.f, splat(1.f), splat(0.f));
-                    alive0 = alive0 && !(T.x < P.min_transmittance);
-                    alive1 = alive1 && !(T.y < P.min_transmittance);
-                }
-            }
-        } else
         for (int j = 0; j < n; ++j) {
             if (!__any(alive0 || alive1)) break;   // the rest of the round is behind every pixel's termination
             const float4* rec = &s_rec[j * kRecQuads];
@@ -535,16 +489,13 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
     }
 }
 
-#ifndef GRUT_FWD_ILP2_WAVES
-#define GRUT_FWD_ILP2_WAVES 5   // the latency form (two entries side by side): 96 VGPRs
-#endif
 #ifndef GRUT_FWD_WAVES
 #define GRUT_FWD_WAVES 6   // held to 80 VGPRs (12 B of scratch): r02v 0.485 -> 0.472 ms; 0 = the allocator's own choice (90 VGPRs, 5 waves): 4 waves 0.508
 #endif
-template <int DEG, bool CKPT, bool COUNT = false, bool ILP2 = false>
+template <int DEG, bool CKPT, bool COUNT = false>
 __global__ __launch_bounds__(64)
 #if GRUT_FWD_WAVES > 0
-__attribute__((amdgpu_waves_per_eu(ILP2 ? GRUT_FWD_ILP2_WAVES : GRUT_FWD_WAVES, ILP2 ? GRUT_FWD_ILP2_WAVES : GRUT_FWD_WAVES)))
+__attribute__((amdgpu_waves_per_eu(GRUT_FWD_WAVES, GRUT_FWD_WAVES)))
 #endif
 void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                             const float4* __restrict__ density12, const float* __restrict__ rgb,
@@ -566,8 +517,8 @@ void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryL
     const unsigned long long t_rays = COUNT ? wall_clock64() : 0ull;
     FwdState st;
     // two copies of the sweep: the shared-origin one keeps the canonical origin out of the per-pixel math
-    if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true, COUNT, ILP2>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
-    else render_fwd_sweep<DEG, CKPT, false, COUNT, false>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
+    if (rp.uniform_origin) render_fwd_sweep<DEG, CKPT, true, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
+    else render_fwd_sweep<DEG, CKPT, false, COUNT>(P, rp, range, half, lane, lists, density12, rgb, ck, s_rec, st);
     if (COUNT && P.work && lane == 0) {   // diagnostics: this wave's lifetime (shader-clock ticks) and start time, for the balance analysis
         const unsigned long long t_end = wall_clock64();
         // lifetime | rays ready << 32 | time spent staging << 48 (10 ns ticks)
@@ -591,6 +542,144 @@ void gut_render_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryL
         write_split_outputs(P, pix, o);
         out_dist[pix] = rp.valid1 ? st.D.y : 1e6f;
         if (P.hitcounts) out_cnt[pix] = rp.valid1 ? st.cnt.y : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7q: the forward for launches that fit the chip at once (round 4).  When every wave of the launch is resident from the start
+// (BASELINE configs 1 and 2: 1 250 / 5 000 half tiles for 6 144 slots) the longest wave IS the kernel, and a lone wave pays ~8 cycles per
+// dependent instruction whatever its lane count: what shortens it is fewer instructions per entry.  One pixel per lane - a QUARTER tile
+// (16 x 4 pixels) per wave, the .x pixels (quarter 0) or the .y pixels (quarter 1) of the half-tile wave's lanes - runs the same entry in
+// ~0.6x the instructions (plain instead of packed arithmetic), walks the same list only as far as ITS 64 pixels need, and culls staged
+// entries against a pyramid half as high.  Every expression below is the pair sweep's, component by component (same fused
+// multiply-adds, same order): for frames with one ray origin - every frame of the static cameras - images, hit counts, checkpoints and
+// with them all gradients are bit-identical to the half-tile kernel's; with per-pixel ray origins the two builds differ by an ulp per hit
+// somewhere the source does not show (1.2e-7 median on the image; tests/test_gut_gpu.py::test_quarter_tile_forward_equals_the_half_tile_forward).  Checkpoints keep the pair layout
+// (slot + quarter); `reached` carries one bit per quarter, set atomically, and the gradient sweep starts the pixels of a quarter that
+// did not arrive dead.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float qdot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+template <int DEG>
+__device__ __forceinline__ float response1(float g) {
+    constexpr float kLog2e = 1.4426950408889634f;
+    if constexpr (DEG == 2) return __builtin_amdgcn_exp2f(g * (-0.5f * kLog2e));
+    else if constexpr (DEG == 4) return __builtin_amdgcn_exp2f((g * g) * (-0.0555555555556f * kLog2e));
+    else return particle_response<DEG>(g);
+}
+template <int DEG, bool CKPT, bool UNI>
+__device__ __forceinline__ void render_fwd_sweep_quarter(const GutParams& P, const Ray& ry, f3 origin, uint2 range, uint32_t half, uint32_t quarter, int lane,
+                                                         const EntryLists& lists, const float4* __restrict__ density12, const float* __restrict__ rgb,
+                                                         const GutCheckpoints& ck, float4* __restrict__ s_rec, float (&st)[6]) {
+    bool alive = ry.valid;
+    float T = 1.f, D = 0.f, Cr = 0.f, Cg = 0.f, Cb = 0.f, cnt = 0.f;
+    uint32_t b = range.x;
+    RawEntry next = load_entry<false>(b + lane, min(range.y, (b & ~63u) + 64u), lists, density12, rgb);
+    WavePyramid pyr;
+    if (UNI) pyr = wave_pyramid(ry.valid, ry.d, false, ry.d);
+    while (b < range.y) {
+        if (!__any(alive)) break;
+        const uint32_t bend = min(range.y, (b & ~63u) + 64u);
+        if (CKPT && b > range.x && (b % kGutSegment) == 0) {
+            const size_t idx = (size_t)(b / kGutSegment) * 2 + half;
+            const size_t slot = (idx * 64 + lane) * 2 + quarter;
+            ck.tc[slot] = make_float4(alive ? T : 0.f, Cr, Cg, Cb);   // dead pixels restart dead
+            ck.d[slot] = D;
+            if (lane == 0) atomicOr(reinterpret_cast<uint32_t*>(ck.reached) + (idx >> 2), (1u << quarter) << (8u * (uint32_t)(idx & 3)));
+        }
+        int n = (int)(bend - b);
+        if (UNI) {
+            float4 q[kRecQuads];
+            stage_entry<DEG, false>(P, next, true, origin, q);
+            const bool keep = lane < n && next.idx != 0xFFFFFFFFu && !(pyr.on && pyramid_misses(pyr, q[0], q[1], q[2], q[4].w, q[5]));
+            const unsigned long long km = __ballot(keep);
+            if (keep) {
+                float4* dst = &s_rec[__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u)) * kRecQuads];
+#pragma unroll
+                for (int k = 0; k < kRecQuads; ++k) dst[k] = q[k];
+            }
+            n = __popcll(km);
+        } else {
+            stage_entry<DEG, false>(P, next, false, origin, &s_rec[lane * kRecQuads]);
+        }
+        __syncthreads();
+        next = load_entry<false>(bend + lane, min(range.y, bend + 64u), lists, density12, rgb);
+        for (int j = 0; j < n; ++j) {
+            if (!__any(alive)) break;
+            const float4* rec = &s_rec[j * kRecQuads];
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            const f3 m0 = mk3(r0.x, r0.y, r0.z), m1 = mk3(r1.x, r1.y, r1.z), m2 = mk3(r2.x, r2.y, r2.z);
+            const f3 v = mk3(qdot(m0, ry.d), qdot(m1, ry.d), qdot(m2, ry.d));
+            f3 u;
+            if (UNI) { const float4 r5 = rec[5]; u = mk3(r5.x, r5.y, r5.z); }
+            else { const f3 dl = mk3(ry.o.x - r0.w, ry.o.y - r1.w, ry.o.z - r2.w); u = mk3(qdot(m0, dl), qdot(m1, dl), qdot(m2, dl)); }
+            const float l2 = qdot(v, v);
+            const f3 c = mk3(fmaf(v.y, u.z, -(v.z * u.y)), fmaf(v.z, u.x, -(v.x * u.z)), fmaf(v.x, u.y, -(v.y * u.x)));
+            const float cc = qdot(c, c);
+            const float4 r4 = rec[4];
+            const bool acc = cc < r4.w * l2;
+            const bool ca = acc && alive;
+            if (!__any(ca)) continue;
+            const float4 r3 = rec[3];
+            const float il2 = __builtin_amdgcn_rcpf(l2);
+            const float gray = cc * il2;
+            const float resp = response1<DEG>(gray);
+            const float ad = resp * r3.w;
+            const float vu = qdot(v, u);
+            const f3 sv = mk3(r3.x * v.x, r3.y * v.y, r3.z * v.z);
+            const float ss = qdot(sv, sv) * (vu * vu);
+            const float hitT = __builtin_amdgcn_sqrtf(ss) * il2;
+            const bool h = ca && (hitT > ry.tmin) && (hitT < ry.tmax);
+            const float alpha = h ? fminf(P.max_alpha, ad) : 0.f;
+            const float hT = h ? hitT : 0.f;
+            const float w = alpha * T;
+            D = fmaf(hT, w, D);
+            T = T * (1.f - alpha);
+            Cr = fmaf(r4.x, w, Cr);
+            Cg = fmaf(r4.y, w, Cg);
+            Cb = fmaf(r4.z, w, Cb);
+            cnt += w > 0.f ? 1.f : 0.f;
+            alive = alive && !(T < P.min_transmittance);
+        }
+        __syncthreads();
+        b = bend;
+    }
+    st[0] = T; st[1] = D; st[2] = Cr; st[3] = Cg; st[4] = Cb; st[5] = cnt;
+}
+// block -> (virtual tile, half, quarter): the four waves of a tile on one XCD, like half_mapping
+template <int DEG, bool CKPT>
+__global__ __launch_bounds__(64) void gut_render_fwd_quarter_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+                                                                    const float4* __restrict__ density12, const float* __restrict__ rgb,
+                                                                    const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                                    float4* __restrict__ out_fd, float* __restrict__ out_dist,
+                                                                    float* __restrict__ out_cnt, GutCheckpoints ck) {
+    __shared__ float4 s_rec[64 * kRecQuads];
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    uint32_t tile = ((slot >> 2) << 3) + xcd;
+    const uint32_t half = (slot >> 1) & 1u, quarter = slot & 1u;
+    if (tile >= (uint32_t)(P.gx * P.gy)) return;
+    if (GRUT_FWD_TILE_STRIDE > 1) tile = stride_permute(tile, (uint32_t)(P.gx * P.gy), GRUT_FWD_TILE_STRIDE);
+    const int lane = threadIdx.x;
+    const int px = (int)(tile % P.gx) * 16 + (lane & 15), py = (int)(tile / P.gx) * 16 + (int)half * 8 + (int)quarter * 4 + (lane >> 4);
+    const Ray ry = init_ray(P, ray_o, ray_d, px, py);
+    // wave-uniform origin?  (as init_ray_pair)
+    const unsigned long long m = __ballot(ry.valid);
+    f3 cand = mk3(0.f, 0.f, 0.f);
+    if (m) {
+        const int src = __ffsll((long long)m) - 1;
+        cand = mk3(__shfl(ry.o.x, src, 64), __shfl(ry.o.y, src, 64), __shfl(ry.o.z, src, 64));
+    }
+    const bool uniform_origin = __all(!ry.valid || (ry.o.x == cand.x && ry.o.y == cand.y && ry.o.z == cand.z));
+    const uint2 range = ranges[tile];
+    float st[6];
+    if (uniform_origin) render_fwd_sweep_quarter<DEG, CKPT, true>(P, ry, cand, range, half, quarter, lane, lists, density12, rgb, ck, s_rec, st);
+    else render_fwd_sweep_quarter<DEG, CKPT, false>(P, ry, cand, range, half, quarter, lane, lists, density12, rgb, ck, s_rec, st);
+    if (ry.inside) {
+        const size_t pix = (size_t)py * P.W + px;
+        const float4 o = ry.valid ? make_float4(st[2], st[3], st[4], 1.f - st[0]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        store_fd(P, out_fd, pix, o);
+        write_split_outputs(P, pix, o);
+        out_dist[pix] = ry.valid ? st[1] : 1e6f;
+        if (P.hitcounts) out_cnt[pix] = ry.valid ? st[5] : 0.f;
     }
 }
 
@@ -867,7 +956,7 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
     half_mapping(blockIdx.x, vtile, half);
     uint32_t tile, seg_begin;
     bool from_checkpoint = false;
-    uint32_t boundary = 0;
+    uint32_t boundary = 0, reached_bits = 3u;   // bit q: quarter q of the half tile (pixel .x / .y of the lanes) arrived at the boundary alive
 #ifndef GRUT_BWD_TASK_STRIDE
 #define GRUT_BWD_TASK_STRIDE 0   // (a strided order of the gradient sweep's tasks was measured slower: 0.854-0.863 vs 0.839 ms)
 #endif
@@ -878,7 +967,8 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
     } else {
         boundary = GRUT_BWD_TASK_STRIDE > 1 ? stride_permute(vtile, bnd_pad, GRUT_BWD_TASK_STRIDE) : vtile;
         if (boundary == 0 || boundary >= ck.num_boundaries) return;
-        if (!ck.reached[(size_t)boundary * 2 + half]) return;        // the forward sweep never got here alive
+        reached_bits = ck.reached[(size_t)boundary * 2 + half];
+        if (!reached_bits) return;                                   // the forward sweep never got here alive
         tile = ck.boundary_tile[boundary];
         if (tile >= num_tiles) return;
         seg_begin = boundary * kGutSegment;
@@ -910,9 +1000,11 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
     }
     if (from_checkpoint) {
         const size_t slot = (((size_t)boundary * 2 + half) * 64 + lane) * 2;
-        const float4 c0 = ck.tc[slot], c1 = ck.tc[slot + 1];
+        // (a quarter-tile forward wave that was done before this boundary left no checkpoint: its pixels restart dead)
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 c0 = (reached_bits & 1u) ? ck.tc[slot] : zero4, c1 = (reached_bits & 2u) ? ck.tc[slot + 1] : zero4;
         T = v2f{c0.x, c1.x}; Cr = v2f{c0.y, c1.y}; Cg = v2f{c0.z, c1.z}; Cb = v2f{c0.w, c1.w};
-        if (HAS_GDIST) D = v2f{ck.d[slot], ck.d[slot + 1]};
+        if (HAS_GDIST) D = v2f{(reached_bits & 1u) ? ck.d[slot] : 0.f, (reached_bits & 2u) ? ck.d[slot + 1] : 0.f};
         alive0 = alive0 && !(T.x < P.min_transmittance);
         alive1 = alive1 && !(T.y < P.min_transmittance);
     }
@@ -1311,12 +1403,21 @@ void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
                            reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d, reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck);
         return;
     }
-    // latency form: when every wave of the launch is resident at once (<= 5 per SIMD x 1024 SIMDs) the longest wave is the kernel
-    static const int ilp2_env = getenv("GRUT_FWD_ILP2") ? atoi(getenv("GRUT_FWD_ILP2")) : -1;   // development switch: 0 / 1 force, default by size
-    const bool ilp2 = ilp2_env >= 0 ? ilp2_env != 0 : half_grid(P) <= 5120u;
-    if (write_checkpoints && ilp2 && P.degree == 2) {
-        hipLaunchKernelGGL((gut_render_fwd_kernel<2, true, false, true>), dim3(half_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
-                           reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d, reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck);
+    // when every wave of the launch is resident at once (<= 5 half-tile waves per SIMD x 1024 SIMDs) the longest wave is the kernel: quarter tiles
+    const char* quarter_str = getenv("GRUT_FWD_QUARTER");   // development / test switch (read per call): 0 / 1 force, default by size
+    const int quarter_env = quarter_str ? atoi(quarter_str) : -1;
+    const bool quarter = quarter_env >= 0 ? quarter_env != 0 : half_grid(P) <= 5120u;
+    if (quarter && !(P.work && P.degree == 2 && write_checkpoints)) {
+        const dim3 grid(half_grid(P) * 2u);
+        if (write_checkpoints) {
+            GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_fwd_quarter_kernel<D_, true>), grid, dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges),
+                                                              lists, reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                              reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck));
+        } else {
+            GRUT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((gut_render_fwd_quarter_kernel<D_, false>), grid, dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges),
+                                                              lists, reinterpret_cast<const float4*>(density12), rgb, ray_o, ray_d,
+                                                              reinterpret_cast<float4*>(out_fd), out_dist, out_cnt, ck));
+        }
         return;
     }
     if (write_checkpoints) {

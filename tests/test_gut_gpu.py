@@ -908,6 +908,42 @@ def test_nht_pixel_pair_sweeps_equal_the_generic_kernels(depth_grad, monkeypatch
     assert _trimmed_rel_err(gf_f, gf_g, 3 * nflip) < 2e-4 and float(np.abs(gf_g).max()) > 0
 
 
+@pytest.mark.parametrize("depth_grad,rolling", [(False, False), (True, False), (False, True)])
+def test_quarter_tile_forward_equals_the_half_tile_forward(depth_grad, rolling, monkeypatch):
+    """Launches that fit the chip at once (BASELINE configs 1 and 2) run the forward with one pixel per lane, a quarter tile per wave
+    (csrc/gut_render.hip: gut_render_fwd_quarter_kernel) - the pair sweep's expressions component by component.  The same dense frame (tile
+    lists of many 64-entry segments: most gradient-sweep tasks start from a checkpoint, some from a boundary only ONE quarter of the half
+    tile reached alive) through both forwards: images, distances, hit counts and - through the checkpoints - every gradient must be
+    bit-identical, with and without a depth gradient.  With per-pixel ray origins (the sweeps' non-uniform-origin form) the two compiled
+    sweeps differ by an ulp per hit (median 1.2e-7 on the image): rounding-level agreement is asserted there."""
+    import torch
+    scene = make_scene(n=30000, width=160, height=96, median_scale=0.06, max_density=0.35)
+    rng = np.random.default_rng(12)
+    if rolling:   # every pixel its own ray origin (what a moving sensor's rays look like): the sweeps' non-uniform-origin form
+        scene["batch"]["rays_ori"] = (scene["batch"]["rays_ori"] + 2e-3 * rng.normal(size=scene["batch"]["rays_ori"].shape)).astype(np.float32)
+    g_fd = rng.normal(size=(96, 160, 4)).astype(np.float32)
+    g_dist = rng.normal(size=(96, 160, 1)).astype(np.float32) if depth_grad else None
+
+    def run(quarter):
+        monkeypatch.setenv("GRUT_FWD_QUARTER", "1" if quarter else "0")
+        r = _run_gpu(scene, g_fd, g_dist, enable_hitcounts=True)
+        o = r["out"]
+        return [o[k].detach().cpu().numpy() for k in ("pred_features", "pred_opacity", "pred_dist", "hits_count")] + list(r["grads"]), r["tracer"].tracer_wrapper.stats()
+    (a, st), (b, _) = run(True), run(False)
+    assert int(st.num_intersections) > 64 * 4 * int(st.num_tiles), "the frame should hold tile lists of several segments"
+    if not rolling:
+        for x, y, name in zip(a, b, ("features", "opacity", "distance", "hit count", "grad density12", "grad sph")):
+            assert np.array_equal(x, y), f"{name}: {int((x != y).sum())} values differ"
+    else:
+        flips = (a[3] != b[3])[0, ..., 0]
+        assert flips.mean() <= 1e-3
+        for x, y, name in zip(a[:3], b[:3], ("features", "opacity", "distance")):
+            assert np.abs(x - y)[0][~flips].max() < 5e-6, name
+        nflip = int(flips.sum())
+        assert _trimmed_rel_err(a[4][:, :11], b[4][:, :11], 3 * nflip) < 1e-4 and _trimmed_rel_err(a[5], b[5], 3 * nflip) < 1e-4
+    assert float(np.abs(a[4]).max()) > 0
+
+
 def test_nht_refuses_what_it_does_not_provide():
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
     with pytest.raises(RuntimeError, match="k_buffer_size must be 0"):
