@@ -14,6 +14,7 @@ struct GrtHandle {
     uint32_t N = 0;
     bool built = false;
     hipStream_t build_stream = nullptr;
+    DeviceBuffer refit_todo;   // the nodes the level-synchronous refit launches leave to grt_refit_finish_kernel
     DeviceBuffer box8;   // GRUT_PRIM_CUSTOM: the particles' exact world boxes + kernelScale^2 (grt_proxy_kernel)
     DeviceBuffer inst, aabb, slack, scene_enc, scene, codes, ids, codes_tmp, ids_tmp, sort_scratch, nodes,
         counters, dbg_ids, dbg_count;
@@ -162,7 +163,7 @@ int grt_create(const GrtConfig* config, GrtHandle** handle) {
 }
 
 static void release_scratch(GrtHandle* h) {
-    DeviceBuffer* bufs[] = {&h->box8, &h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
+    DeviceBuffer* bufs[] = {&h->refit_todo, &h->box8, &h->inst, &h->aabb, &h->slack, &h->scene_enc, &h->scene, &h->codes, &h->ids, &h->codes_tmp, &h->ids_tmp,
                             &h->sort_scratch, &h->nodes, &h->counters, &h->dbg_ids, &h->dbg_count,
                             &h->work_counters, &h->l_flags, &h->l_starts, &h->l_bounds, &h->l_pair_cache, &h->l_block_cones, &h->l_super_cones, &h->l_inst_rel, &h->l_key_bits,
                             &h->l_counts, &h->l_pidx, &h->l_key_tmp, &h->l_pidx_tmp, &h->l_offsets, &h->l_scan_scratch, &h->l_sort_scratch,
@@ -262,7 +263,8 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     }
     // the refit re-derives every box from the fresh proxies; on rebuild = 0 the sorted order of the last build is reused
     GRUT_HIP(hipMemsetAsync(h->counters.ptr, 0, n, s));   // per-node "done in pass" bytes
-    grt_launch_refit(s, N, h->aabb.as<float>(), h->slack.as<float>(), h->nodes.as<GrtNode>(), h->counters.as<uint8_t>());
+    GRUT_CHECK(h->refit_todo.ensure((n + 1) * 4, 1.25f));
+    grt_launch_refit(s, N, h->aabb.as<float>(), h->slack.as<float>(), h->nodes.as<GrtNode>(), h->counters.as<uint8_t>(), h->refit_todo.as<uint32_t>());
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.end(s));
     h->N = N;

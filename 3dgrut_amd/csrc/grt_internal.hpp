@@ -168,7 +168,7 @@ void grt_launch_proxies(hipStream_t s, const GrtBuildParams& P, const float* pos
                         float* inst, float* aabb, float* slack, uint32_t* scene_enc, float* box8);
 void grt_launch_morton(hipStream_t s, uint32_t N, const float* aabb, const uint32_t* scene_enc, float* scene, uint32_t* codes, uint32_t* ids);
 void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_codes, const uint32_t* sorted_ids, GrtNode* nodes);
-void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float* slack, GrtNode* nodes, uint8_t* done);
+void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float* slack, GrtNode* nodes, uint8_t* done, uint32_t* todo = nullptr);
 size_t grt_scene_enc_bytes();
 // trace
 void grt_launch_trace_fwd(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* density12, const float* sph,

@@ -240,8 +240,10 @@ __device__ __forceinline__ void child_box(const GrtNode* __restrict__ nodes, con
         sl = fmaxf(q3.z, q3.w);
     }
 }
+// `todo` (last regular pass only): the nodes this pass could not finish either are listed ([0] = count, then the nodes) for
+// grt_refit_finish_kernel
 __global__ __launch_bounds__(256) void grt_refit_pass_kernel(uint32_t N, uint32_t pass, const float* __restrict__ aabb,
-                                                             const float* __restrict__ slack, GrtNode* nodes, uint8_t* done) {
+                                                             const float* __restrict__ slack, GrtNode* nodes, uint8_t* done, uint32_t* todo) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float lo[3], hi[3], sl;
     if (N == 1) {  // single particle: the root has one leaf and one empty slot
@@ -259,12 +261,76 @@ __global__ __launch_bounds__(256) void grt_refit_pass_kernel(uint32_t N, uint32_
     const uint32_t c0 = nodes[i].c[0], c1 = nodes[i].c[1];
     const bool r0 = (c0 & kGrtLeafBit) || (done[c0] != 0 && done[c0] <= pass);
     const bool r1 = (c1 & kGrtLeafBit) || (done[c1] != 0 && done[c1] <= pass);
-    if (!(r0 && r1)) return;
+    if (!(r0 && r1)) {
+        if (todo) todo[1u + atomicAdd(&todo[0], 1u)] = i;
+        return;
+    }
     child_box(nodes, aabb, slack, c0, lo, hi, sl);
     write_child(&nodes[i], 0, lo, hi, sl);
     child_box(nodes, aabb, slack, c1, lo, hi, sl);
     write_child(&nodes[i], 1, lo, hi, sl);
     done[i] = (uint8_t)(pass + 1);
+}
+// The top of the tree in ONE launch.  After kGrtRefitPasses level-synchronous launches only the nodes higher than that are open - a few
+// hundred of a million - but the tree may be up to 62 levels deep and every further launch costs ~6 us of dependent launch latency whether it
+// finds work or not (60 fixed launches: 0.37 of the 0.51 ms build).  One workgroup finishes the listed nodes pass by pass between workgroup
+// barriers.  What an earlier pass of THIS launch wrote is read around the L1 (agent-scope atomic loads: another wave of the CU may hold the
+// line of the neighbouring node), and published with a fence before the barrier; the "finished by an EARLIER pass" rule is the launches' own.
+constexpr uint32_t kGrtRefitPasses = 20;   // (12: the finisher takes 0.37 ms for the longer list; 20: 0.05 ms)
+__device__ __forceinline__ float coherent_load(const float* p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void child_box_coherent(const GrtNode* nodes, const float* __restrict__ aabb, const float* __restrict__ slack, uint32_t c,
+                                                   float lo[3], float hi[3], float& sl) {
+    if (c & kGrtLeafBit) { child_box(nodes, aabb, slack, c, lo, hi, sl); return; }
+    const GrtNode* n = &nodes[c];
+    lo[0] = fminf(coherent_load(&n->lox[0]), coherent_load(&n->lox[1])); lo[1] = fminf(coherent_load(&n->loy[0]), coherent_load(&n->loy[1]));
+    lo[2] = fminf(coherent_load(&n->loz[0]), coherent_load(&n->loz[1]));
+    hi[0] = fmaxf(coherent_load(&n->hix[0]), coherent_load(&n->hix[1])); hi[1] = fmaxf(coherent_load(&n->hiy[0]), coherent_load(&n->hiy[1]));
+    hi[2] = fmaxf(coherent_load(&n->hiz[0]), coherent_load(&n->hiz[1]));
+    sl = fmaxf(coherent_load(&n->slack[0]), coherent_load(&n->slack[1]));
+}
+__global__ __launch_bounds__(1024) void grt_refit_finish_kernel(uint32_t N, uint32_t first_pass, const float* __restrict__ aabb,
+                                                                const float* __restrict__ slack, GrtNode* nodes, uint8_t* done, const uint32_t* todo) {
+    const uint32_t n = todo[0];
+    // up to kOwn listed nodes per thread live in registers (node, children, open?): a pass is then two dependent round trips to the L2
+    // (the children's pass marks, their boxes) and a barrier; longer lists take the same loop from memory
+    constexpr int kOwn = 4;
+    uint32_t own[kOwn], ch0[kOwn], ch1[kOwn];
+    bool is_open[kOwn];
+#pragma unroll
+    for (int q = 0; q < kOwn; ++q) {
+        const uint32_t k = threadIdx.x + (uint32_t)q * blockDim.x;
+        is_open[q] = k < n;
+        own[q] = is_open[q] ? todo[1u + k] : 0u;
+        ch0[q] = is_open[q] ? nodes[own[q]].c[0] : 0u;   // (written by the hierarchy kernel: an earlier launch)
+        ch1[q] = is_open[q] ? nodes[own[q]].c[1] : 0u;
+    }
+    auto try_node = [&](uint32_t i, uint32_t c0, uint32_t c1, uint32_t pass) -> bool {
+        const uint8_t d0 = (c0 & kGrtLeafBit) ? 1 : __hip_atomic_load(done + c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint8_t d1 = (c1 & kGrtLeafBit) ? 1 : __hip_atomic_load(done + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(d0 != 0 && d0 <= pass && d1 != 0 && d1 <= pass)) return false;
+        float lo[3], hi[3], sl;
+        child_box_coherent(nodes, aabb, slack, c0, lo, hi, sl);
+        write_child(&nodes[i], 0, lo, hi, sl);
+        child_box_coherent(nodes, aabb, slack, c1, lo, hi, sl);
+        write_child(&nodes[i], 1, lo, hi, sl);
+        __hip_atomic_store(done + i, (uint8_t)(pass + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return true;
+    };
+    for (uint32_t pass = first_pass; pass < (uint32_t)kGrtMaxDepth; ++pass) {
+        int open = 0;
+#pragma unroll
+        for (int q = 0; q < kOwn; ++q)
+            if (is_open[q]) { is_open[q] = !try_node(own[q], ch0[q], ch1[q], pass); open |= is_open[q] ? 1 : 0; }
+        for (uint32_t k = threadIdx.x + (uint32_t)kOwn * blockDim.x; k < n; k += blockDim.x) {
+            const uint32_t i = todo[1u + k];
+            if (__hip_atomic_load(done + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) continue;
+            if (!try_node(i, nodes[i].c[0], nodes[i].c[1], pass)) open = 1;
+        }
+        __threadfence();
+        if (!__syncthreads_or(open)) break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2679,11 +2745,15 @@ void grt_launch_morton(hipStream_t s, uint32_t N, const float* aabb, const uint3
 void grt_launch_hierarchy(hipStream_t s, uint32_t N, const uint32_t* sorted_codes, const uint32_t* sorted_ids, GrtNode* nodes) {
     if (N > 1) hipLaunchKernelGGL(grt_hierarchy_kernel, dim3(div_up(N - 1, 256)), dim3(256), 0, s, N, sorted_codes, sorted_ids, nodes);
 }
-void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float* slack, GrtNode* nodes, uint8_t* done) {
-    // a radix tree over 30-bit keys + 32 index bits (duplicates) is at most 62 levels deep; finished passes cost a few us
-    const uint32_t passes = N <= 2 ? 1u : (uint32_t)kGrtMaxDepth - 2u;
+void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float* slack, GrtNode* nodes, uint8_t* done, uint32_t* todo) {
+    // a radix tree over 30-bit keys + 32 index bits (duplicates) is at most 62 levels deep: kGrtRefitPasses level-synchronous launches over all
+    // nodes, then the few nodes above that in one workgroup (`todo`: N + 1 words, [0] zeroed here)
+    const uint32_t passes = N <= 2 ? 1u : (todo ? kGrtRefitPasses : (uint32_t)kGrtMaxDepth - 2u);
+    if (todo && N > 2) hipMemsetAsync(todo, 0, 4, s);
     for (uint32_t p = 0; p < passes; ++p)
-        hipLaunchKernelGGL(grt_refit_pass_kernel, dim3(div_up(N > 1 ? N - 1 : 1u, 256)), dim3(256), 0, s, N, p, aabb, slack, nodes, done);
+        hipLaunchKernelGGL(grt_refit_pass_kernel, dim3(div_up(N > 1 ? N - 1 : 1u, 256)), dim3(256), 0, s, N, p, aabb, slack, nodes, done,
+                           (todo && N > 2 && p + 1 == passes) ? todo : nullptr);
+    if (todo && N > 2) hipLaunchKernelGGL(grt_refit_finish_kernel, dim3(1), dim3(1024), 0, s, N, passes, aabb, slack, nodes, done, todo);
 }
 
 #define GRT_DISPATCH_DEGREE(DEG, ...)                          \
