@@ -950,7 +950,9 @@ __global__ __launch_bounds__(64) void gut_render_bwd_kernel(
     // is made of the short first segments of each tile list, virtual tiles [bndPad, bndPad + tiles).  Only a quarter of the
     // launched workgroups find work on the bench frame (the forward reached 26 k of the ~106 k possible tasks alive); compacting
     // them into a task list first (persistent workers, or one workgroup per real task) was measured and is NOT faster: the empty
-    // workgroups retire in the shadow of the running ones (DESIGN.md "Gradient sweep: task dispatch").
+    // workgroups retire in the shadow of the running ones (DESIGN.md "Gradient sweep: task dispatch").  Measured again in round 4 with 64-entry
+    // segments (376 k workgroups for ~100 k tasks; launching them all EMPTY takes 82 us): a compacted task list built by a small kernel, the grid
+    // sized from the previous frame's count - gradient sweep 0.825-0.829 ms against 0.810-0.816 ms with the direct mapping.  Not kept.
     const uint32_t num_tiles = (uint32_t)(P.gx * P.gy), bnd_pad = (ck.num_boundaries + 7u) & ~7u;
     uint32_t vtile, half;
     half_mapping(blockIdx.x, vtile, half);
