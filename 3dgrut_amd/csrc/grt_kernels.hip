@@ -1918,7 +1918,10 @@ __device__ __forceinline__ void replay_bookkeeping(const GrtHitLog& log, bool re
 }
 
 template <int DEG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
+#ifndef GRT_REPLAY_WAVES
+#define GRT_REPLAY_WAVES 3   // round 4: 4 -> 3 waves per SIMD (168 registers, no scratch; at 4 the kernel kept 84 B per lane in scratch): backward 4.2-4.4 -> 3.76 ms; 2: 3.85, 5: 6.3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_REPLAY_WAVES, GRT_REPLAY_WAVES))) void grt_replay_bwd_kernel(GrtTraceParams P, const float4* __restrict__ density12, const float* __restrict__ sph,
                                                             const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                             const float* __restrict__ in_rad, const float* __restrict__ in_dns,
                                                             const float* __restrict__ in_hit2, const float* __restrict__ g_rad,
@@ -2585,7 +2588,14 @@ __device__ __forceinline__ f3 pg_background(const GrtMeshView& m, f3 d) {   // g
 }
 
 template <int DEG>
-__global__ __launch_bounds__(64) void grt_hybrid_kernel(GrtTraceParams P, GrtBvh bvh, GrtMeshView mesh, GrtHybridParams hp,
+#ifndef GRT_HYBRID_WAVES
+#define GRT_HYBRID_WAVES 0   // 0: the allocator's own choice (219 registers, 2 waves per SIMD)
+#endif
+__global__ __launch_bounds__(64)
+#if GRT_HYBRID_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(GRT_HYBRID_WAVES, GRT_HYBRID_WAVES)))
+#endif
+void grt_hybrid_kernel(GrtTraceParams P, GrtBvh bvh, GrtMeshView mesh, GrtHybridParams hp,
                                                         const float4* __restrict__ density12, const float* __restrict__ sph,
                                                         const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                         const float* __restrict__ ray_max_t, float* __restrict__ out_rgb,
