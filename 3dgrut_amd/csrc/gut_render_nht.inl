@@ -167,7 +167,10 @@ __device__ __forceinline__ void nht_fwd_sweep(const GutParams& P, const RayPair&
 }
 
 template <int DEG, bool CKPT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef GRUT_NHT_FWD_WAVES
+#define GRUT_NHT_FWD_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRUT_NHT_FWD_WAVES, GRUT_NHT_FWD_WAVES)))
 void gut_render_nhtp_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists, const float4* __restrict__ density12,
                                 const float* __restrict__ features, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                 float* __restrict__ out_fd, float* __restrict__ out_dist, float* __restrict__ out_cnt, float4* __restrict__ ck_nht,
