@@ -443,7 +443,20 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
         const GrtPolyhedron& ph = kGrtPolyhedra[r.prim];
         float tin = -3.0e38f, tout = 3.0e38f;
         bool miss = false;
-        for (int f = 0; f < ph.num_planes; ++f) {
+        // antipodal pairs (n, h) / (-n, h) - all of the icosahedron's and the octahedron's faces: n . d and n . o of the second plane are the
+        // first's negated, bit for bit (every operand of its fused multiply-adds is negated), so one pair of dot products serves two planes
+        // and the values equal the plane-by-plane loop's (which the CPU checker runs over the same table)
+        for (int p = 0; p < ph.num_pairs; ++p) {
+            const float nx = ph.planes[2 * p][0], ny = ph.planes[2 * p][1], nz = ph.planes[2 * p][2], hh = ph.planes[2 * p][3];
+            const float dn = fmaf(nz, pdz, fmaf(ny, pdy, nx * pdx));
+            const float dt = fmaf(nz, poz, fmaf(ny, poy, nx * pox));
+            const float on_a = hh - dt, on_b = hh + dt;
+            const float tf_a = on_a / dn, tf_b = on_b / (-dn);
+            if (dn < 0.f) { tin = fmaxf(tin, tf_a); tout = fminf(tout, tf_b); }
+            else if (dn > 0.f) { tout = fminf(tout, tf_a); tin = fmaxf(tin, tf_b); }
+            else if (on_a < 0.f || on_b < 0.f) miss = true;
+        }
+        for (int f = 2 * ph.num_pairs; f < ph.num_planes; ++f) {
             const float nx = ph.planes[f][0], ny = ph.planes[f][1], nz = ph.planes[f][2], hh = ph.planes[f][3];
             const float dn = fmaf(nz, pdz, fmaf(ny, pdy, nx * pdx));
             const float on = hh - fmaf(nz, poz, fmaf(ny, poy, nx * pox));
