@@ -668,14 +668,16 @@ def main():
                                                                         "roofline", "roofline_backward", "work")}}
             # BASELINE config 2 (1 M Gaussians, 800x800: one wave per half tile leaves the chip short of waves), same code
             # path as the headline, run as its own process so that nothing of this one's state is shared
+            # ... and BASELINE config 1 (100 k Gaussians, 400x400), the smallest launch: both run the quarter-tile forward
             import subprocess
-            try:
-                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c2_1m_800", "--no-cpu-baseline", "--no-secondary",
-                                      "--steps", str(args.steps), "--warmup", str(args.warmup)], capture_output=True, text=True, timeout=300).stdout
-                c2 = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
-                result["secondary"]["c2_1m_800"] = {k: c2[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "stages_ms", "work")}
-            except Exception as e:   # the headline line must not depend on it
-                result["secondary"]["c2_1m_800"] = {"error": repr(e)[:200]}
+            for small in ("c2_1m_800", "c1_100k_400"):
+                try:
+                    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", small, "--no-cpu-baseline", "--no-secondary",
+                                          "--steps", str(args.steps), "--warmup", str(args.warmup)], capture_output=True, text=True, timeout=300).stdout
+                    c2 = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+                    result["secondary"][small] = {k: c2[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "stages_ms", "work")}
+                except Exception as e:   # the headline line must not depend on it
+                    result["secondary"][small] = {"error": repr(e)[:200]}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
