@@ -123,7 +123,7 @@ static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist, uint32_
                           inst[6] * dl.x + inst[7] * dl.y + inst[8] * dl.z);
     const v3 pd = v3_make(r_fma(inst[2], d.z, r_fma(inst[1], d.y, inst[0] * d.x)), r_fma(inst[5], d.z, r_fma(inst[4], d.y, inst[3] * d.x)),
                           r_fma(inst[8], d.z, r_fma(inst[7], d.y, inst[6] * d.x)));
-    if (g_prim >= 1 && g_prim <= 4) {   /* triangle-mesh proxy: clip against the polyhedron's face planes, operation by operation as candidate_abe (grt_kernels.hip) */
+    if (g_prim >= 1 && g_prim <= 4) {   /* closed triangle-mesh proxy: clip against the polyhedron's face planes, operation by operation as candidate_abe (grt_kernels.hip) */
         const orc_polyhedron* ph = &orc_polyhedra[g_prim];
         real tin = R_(-3.0e38), tout = R_(3.0e38);
         int miss = 0;
@@ -138,6 +138,15 @@ static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist, uint32_
         }
         c.t = tin; c.tnear = tin; c.tfar = R_(3.0e38);
         c.ok = !miss && (tin <= tout) && (tin > R_(-3.0e38));
+        return c;
+    }
+    if (g_prim == 6) {   /* trisurfel (particlePrimitives.cu:155-205): the rhombus |x| + |y| <= sqrt 2 in the proxy's z = 0 plane, two triangles traced
+                          * WITHOUT face culling (referenceOptix.cu:62: SurfelPrimitive -> OPTIX_RAY_FLAG_NONE); the reported distance is the plane's */
+        if (pd.z == 0) return c;
+        const real t = -po.z / pd.z;
+        const real hx = r_fma(t, pd.x, po.x), hy = r_fma(t, pd.y, po.y);
+        c.t = t; c.tnear = t; c.tfar = R_(3.0e38);
+        c.ok = (r_fabs(hx) + r_fabs(hy) <= R_(1.4142135381698608));
         return c;
     }
     if (g_prim == 5) {   /* custom primitives: world box + the world-space intersection program (gaussianParticles.cuh:407-441); see candidate_abe */
@@ -197,14 +206,15 @@ static int process_hit(const GrtConfig* cfg, v3 ro, v3 rd, const real* pd, const
     const v3 rdr = v3_mul_rows(rd, &p.rotT);
     const v3 grdu = v3_mul(giscl, rdr);
     const v3 grd = v3_safe_normalize(grdu);
-    const v3 gcrod = v3_cross(grd, gro);
+    const int surfel = cfg->primitive_type == 6;   /* PipelineParameters::SurfelPrimitive: the hit is the ray's crossing of the particle's z = 0 plane */
+    const v3 gcrod = surfel ? v3_add(gro, v3_make(grd.x * -gro.z / grd.z, grd.y * -gro.z / grd.z, grd.z * -gro.z / grd.z)) : v3_cross(grd, gro);
     const real gray = v3_dot(gcrod, gcrod);
     const real gres = particle_response(cfg->particle_kernel_degree, gray);
     const real galpha = r_min((real)cfg->particle_kernel_max_alpha, gres * p.density);
     const int accept = (gres > (real)cfg->particle_kernel_min_response) && (galpha > (real)cfg->particle_kernel_min_alpha);
     if (accept) {
         const real weight = galpha * s->T;
-        const real pdot = v3_dot(grd, v3_scale(gro, -1));
+        const real pdot = surfel ? -gro.z / grd.z : v3_dot(grd, v3_scale(gro, -1));
         const v3 grds = v3_mul(p.scl, v3_scale(grd, pdot));
         const real hitT = r_sqrt(v3_dot(grds, grds));
         const v3 grad = v3_max0(sh_radiance_unclamped(sph_deg, sph, rd));
@@ -213,9 +223,13 @@ static int process_hit(const GrtConfig* cfg, v3 ro, v3 rd, const real* pd, const
         s->depth += hitT * weight;
         if (with_normal) { /* :398-402 */
             const v3 psr = m33_mul_cols(&p.rotT, p.scl);
-            const v3 q = v3_add(gro, v3_scale(grd, pdot - r_sqrt(9 - gray)));
-            const v3 n = v3_safe_normalize(v3_mul(q, psr));
-            s->normal = v3_add(s->normal, v3_scale(n, weight));
+            if (surfel) {
+                s->normal = v3_add(s->normal, v3_scale(v3_make(0, 0, (grd.z > 0 ? 1 : -1) * psr.z), weight));
+            } else {
+                const v3 q = v3_add(gro, v3_scale(grd, pdot - r_sqrt(9 - gray)));
+                const v3 n = v3_safe_normalize(v3_mul(q, psr));
+                s->normal = v3_add(s->normal, v3_scale(n, weight));
+            }
         }
     }
     return accept;
@@ -239,13 +253,14 @@ static void process_hit_bwd(const GrtConfig* cfg, v3 ro, v3 rd, const real* pd, 
     const v3 rdr = v3_mul_rows(rd, &p.rotT);
     const v3 grdu = v3_mul(giscl, rdr);
     const v3 grd = v3_safe_normalize(grdu);
-    const v3 gcrod = v3_cross(grd, gro);
+    const int surfel = cfg->primitive_type == 6;   /* the SurfelPrimitive branches of gaussianParticles.cuh:512-521, :558-565, :628-659 */
+    const v3 gcrod = surfel ? v3_add(gro, v3_make(grd.x * -gro.z / grd.z, grd.y * -gro.z / grd.z, grd.z * -gro.z / grd.z)) : v3_cross(grd, gro);
     const real gray = v3_dot(gcrod, gcrod);
     const real gres = particle_response(cfg->particle_kernel_degree, gray);
     const real galpha = r_min((real)cfg->particle_kernel_max_alpha, gres * p.density);
     if (!((gres > (real)cfg->particle_kernel_min_response) && (galpha > (real)cfg->particle_kernel_min_alpha))) return;
 
-    const real pdot = v3_dot(grd, v3_scale(gro, -1));
+    const real pdot = surfel ? -gro.z / grd.z : v3_dot(grd, v3_scale(gro, -1));
     const v3 grdd = v3_scale(grd, pdot);
     const v3 grds = v3_mul(gscl, grdd);
     const real gsq = v3_dot(grds, grds);
@@ -260,8 +275,14 @@ static void process_hit_bwd(const GrtConfig* cfg, v3 ro, v3 rd, const real* pd, 
     const v3 grdsRayHitGrd = gsq > 0 ? v3_scale(grds, (2 * weight) / (2 * gdist) * r->depth_grad) : v3_make(0, 0, 0);
     const v3 gsclRayHitGrd = v3_mul(grdd, grdsRayHitGrd);
     const real grdScaledDot = v3_dot(v3_mul(grdsRayHitGrd, gscl), grd);
-    const v3 grdRayHitGrd = v3_sub(v3_scale(v3_mul(gscl, grdsRayHitGrd), pdot), v3_scale(gro, grdScaledDot));
-    const v3 groRayHitGrd = v3_scale(grd, -grdScaledDot);
+    v3 grdRayHitGrd, groRayHitGrd;
+    if (surfel) {   /* :558-561 */
+        grdRayHitGrd = v3_sub(v3_scale(v3_mul(gscl, grdsRayHitGrd), pdot), v3_make(0, 0, (pdot / grd.z) * grdScaledDot));
+        groRayHitGrd = v3_make(0, 0, -grdScaledDot / grd.z);
+    } else {
+        grdRayHitGrd = v3_sub(v3_scale(v3_mul(gscl, grdsRayHitGrd), pdot), v3_scale(gro, grdScaledDot));
+        groRayHitGrd = v3_scale(grd, -grdScaledDot);
+    }
 
     const real resTrm = galpha < R_(0.999999) ? r->T_fin / (1 - galpha) : T;
     const real galphaRayDnsGrd = resTrm * -r->T_grad;
@@ -287,9 +308,21 @@ static void process_hit_bwd(const GrtConfig* cfg, v3 ro, v3 rd, const real* pd, 
     const real gresGrd = p.density * common;
     const real grayGrd = particle_response_grd(cfg->particle_kernel_degree, gray, gres, gresGrd);
 
-    const v3 gcrodGrd = v3_scale(gcrod, 2 * grayGrd);
-    const v3 grdGrd = v3_make(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
-    const v3 groGrd = v3_make(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+    v3 grdGrd, groGrd;
+    if (surfel) {   /* :628-659: grayDist = |gro + grd ghitT|^2, ghitT = -gro.z / grd.z */
+        const real ghitT = -gro.z / grd.z;
+        const v3 ghitPos = v3_add(gro, v3_scale(grd, ghitT));
+        const v3 ghitPosGrd = v3_scale(ghitPos, 2 * grayGrd);
+        groGrd = ghitPosGrd;
+        grdGrd = v3_scale(ghitPosGrd, ghitT);
+        const real ghitTGrd = grd.x * ghitPosGrd.x + grd.y * ghitPosGrd.y + grd.z * ghitPosGrd.z;
+        groGrd.z += -ghitTGrd / grd.z;
+        grdGrd.z += (gro.z * ghitTGrd) / (grd.z * grd.z);
+    } else {
+        const v3 gcrodGrd = v3_scale(gcrod, 2 * grayGrd);
+        grdGrd = v3_make(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
+        groGrd = v3_make(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+    }
     const v3 groTot = v3_add(groGrd, groRayHitGrd);
     const v3 gsclGrdGro = v3_mul(v3_make(-gposcr.x / (gscl.x * gscl.x), -gposcr.y / (gscl.y * gscl.y), -gposcr.z / (gscl.z * gscl.z)), groTot);
     const v3 gposcrGrd = v3_mul(giscl, groTot);

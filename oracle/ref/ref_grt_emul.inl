@@ -42,7 +42,7 @@ bool optixReportIntersection(float t, unsigned) {
     return true;               // accepted: the ray now ends at t
 }
 
-void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tmax, float, OptixVisibilityMask, unsigned, unsigned, unsigned,
+void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tmax, float, OptixVisibilityMask, unsigned ray_flags, unsigned, unsigned,
                 unsigned, uint32_t& p0, uint32_t& p1, uint32_t& p2, uint32_t& p3, uint32_t& p4, uint32_t& p5, uint32_t& p6, uint32_t& p7,
                 uint32_t& p8, uint32_t& p9, uint32_t& p10, uint32_t& p11, uint32_t& p12, uint32_t& p13, uint32_t& p14, uint32_t& p15,
                 uint32_t& p16, uint32_t& p17, uint32_t& p18, uint32_t& p19, uint32_t& p20, uint32_t& p21, uint32_t& p22, uint32_t& p23,
@@ -66,7 +66,9 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
         const float e1x = pb[0] - pa[0], e1y = pb[1] - pa[1], e1z = pb[2] - pa[2], e2x = pc[0] - pa[0], e2y = pc[1] - pa[1], e2z = pc[2] - pa[2];
         const float px = d.y * e2z - d.z * e2y, py = d.z * e2x - d.x * e2z, pz = d.x * e2y - d.y * e2x;
         const float det = e1x * px + e1y * py + e1z * pz;     // = d . (e2 x e1) = -(d . n): positive for a front face
-        if (!(det > 0.f)) continue;                            // back-facing or parallel: culled
+        // back faces are culled when the trace asks for it (OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES: every closed mesh; the trisurfel
+        // pipelines trace with OPTIX_RAY_FLAG_NONE, referenceOptix.cu:62); parallel rays hit nothing
+        if ((ray_flags & OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES) ? !(det > 0.f) : !(det != 0.f)) continue;
         const float tx = o.x - pa[0], ty = o.y - pa[1], tz = o.z - pa[2];
         const float u = (tx * px + ty * py + tz * pz) / det;
         if (!(u >= 0.f && u <= 1.f)) continue;

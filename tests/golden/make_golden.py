@@ -337,7 +337,10 @@ def make_grt_trace():
     print("wrote grt_trace.npz; hits per ray:", [float(out[f"s{k}_hits_count"].mean()) for k in range(len(GRT_TRACE_SCENES))])
 
 
-MESH_PRIMITIVES = {"icosahedron": (1, "IcosaHedron"), "octahedron": (2, "OctraHedron"), "tetrahedron": (3, "TetraHedron"), "diamond": (4, "Diamond")}
+MESH_PRIMITIVES = {"icosahedron": (1, "IcosaHedron"), "octahedron": (2, "OctraHedron"), "tetrahedron": (3, "TetraHedron"), "diamond": (4, "Diamond"),
+                   # checker-only so far (the HIP plugin refuses it): the open two-triangle surfel proxy, traced WITHOUT face culling, with the surfel
+                   # branches of processHit / processHitBwd (PipelineParameters::SurfelPrimitive)
+                   "trisurfel": (6, "TriSurfel")}
 
 
 def make_grt_trace_mesh():
