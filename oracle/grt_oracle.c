@@ -420,8 +420,41 @@ static const uint32_t *g_pre_ranges = NULL, *g_pre_entries = NULL, *g_pre_ray_pa
 void orc_grt_set_candidate_prefilter(const uint32_t* ranges, const uint32_t* entries, const uint32_t* ray_packet) {
     g_pre_ranges = ranges; g_pre_entries = entries; g_pre_ray_packet = ray_packet;
 }
+/* trihexa (particlePrimitives.cu:107-153; checker only): three rhombi |a| + |b| <= sqrt 2 in the proxy's coordinate planes, traced as triangles with
+ * back faces culled.  The windings make the x = 0 rhombus face +x, the y = 0 rhombus +y, and the two triangles of the z = 0 rhombus face opposite
+ * ways (the x >= 0 half +z, the x <= 0 half -z): a ray is offered the particle once per front-facing piece it crosses - up to three times, at
+ * three distances - and the any-hit / processHit programs treat every offer as a hit of the particle. */
+static uint32_t trihexa_candidates(const real* inst, v3 o, v3 d, uint32_t id, grt_hit* out) {
+    const v3 dl = v3_make(o.x - inst[9], o.y - inst[10], o.z - inst[11]);
+    const v3 po = v3_make(inst[0] * dl.x + inst[1] * dl.y + inst[2] * dl.z, inst[3] * dl.x + inst[4] * dl.y + inst[5] * dl.z,
+                          inst[6] * dl.x + inst[7] * dl.y + inst[8] * dl.z);
+    const v3 pd = v3_make(r_fma(inst[2], d.z, r_fma(inst[1], d.y, inst[0] * d.x)), r_fma(inst[5], d.z, r_fma(inst[4], d.y, inst[3] * d.x)),
+                          r_fma(inst[8], d.z, r_fma(inst[7], d.y, inst[6] * d.x)));
+    const real D = R_(1.4142135381698608);
+    uint32_t n = 0;
+    if (pd.x < 0) {   /* the x = 0 rhombus, seen from +x */
+        const real t = -po.x / pd.x, hy = r_fma(t, pd.y, po.y), hz = r_fma(t, pd.z, po.z);
+        if (r_fabs(hy) + r_fabs(hz) <= D) { out[n].t = t; out[n].id = id; out[n].tnear = t; out[n].tfar = R_(3.0e38); n++; }
+    }
+    if (pd.y < 0) {   /* the y = 0 rhombus, seen from +y */
+        const real t = -po.y / pd.y, hx = r_fma(t, pd.x, po.x), hz = r_fma(t, pd.z, po.z);
+        if (r_fabs(hx) + r_fabs(hz) <= D) { out[n].t = t; out[n].id = id; out[n].tnear = t; out[n].tfar = R_(3.0e38); n++; }
+    }
+    if (pd.z != 0) {  /* the z = 0 rhombus: its x >= 0 half seen from +z, its x <= 0 half from -z */
+        const real t = -po.z / pd.z, hx = r_fma(t, pd.x, po.x), hy = r_fma(t, pd.y, po.y);
+        if (r_fabs(hx) + r_fabs(hy) <= D && ((hx > 0 && pd.z < 0) || (hx < 0 && pd.z > 0))) {
+            out[n].t = t; out[n].id = id; out[n].tnear = t; out[n].tfar = R_(3.0e38); n++;
+        }
+    }
+    return n;
+}
 static uint32_t ray_candidates(uint32_t N, const real* inst12, v3 o, v3 d, grt_hit* out, uint32_t ray) {
     uint32_t n = 0;
+    if (g_prim == 7) {   /* (up to three offers per particle: the callers' buffers hold 3 N + 3 entries) */
+        for (uint32_t i = 0; i < N; ++i) n += trihexa_candidates(inst12 + 12 * (size_t)i, o, d, i, out + n);
+        qsort(out, n, sizeof(grt_hit), hit_cmp);
+        return n;
+    }
     if (g_pre_ranges && ray != 0xFFFFFFFFu) {
         const uint32_t p = g_pre_ray_packet[ray];
         for (uint32_t e = g_pre_ranges[2 * p]; e < g_pre_ranges[2 * p + 1]; ++e) {
@@ -465,7 +498,7 @@ int orc_grt_trace_fwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
     const real eps = R_(1e-9);
 #pragma omp parallel
     {
-        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (3 * (size_t)N + 3))   /* (trihexa: up to three offers per particle) */;
 #pragma omp for schedule(dynamic, 8)
         for (uint32_t r = 0; r < nrays; ++r) {
             const v3 o = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
@@ -525,7 +558,7 @@ int orc_grt_trace_bwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
     double* acc_s = (double*)calloc((size_t)N * 3 * ncoef + 1, sizeof(double));
 #pragma omp parallel
     {
-        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (3 * (size_t)N + 3))   /* (trihexa: up to three offers per particle) */;
 #pragma omp for schedule(dynamic, 8)
         for (uint32_t r = 0; r < nrays; ++r) {
             const v3 o = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
@@ -629,7 +662,7 @@ int orc_grt_trace_nht_fwd(const GrtConfig* cfg, const int* nht, uint32_t N, cons
     const orc_nht_tet tet = orc_nht_tetra();
 #pragma omp parallel
     {
-        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (3 * (size_t)N + 3))   /* (trihexa: up to three offers per particle) */;
 #pragma omp for schedule(dynamic, 8)
         for (uint32_t r = 0; r < nrays; ++r) {
             const v3 o = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
@@ -706,7 +739,7 @@ int orc_grt_trace_nht_bwd(const GrtConfig* cfg, const int* nht, uint32_t N, cons
     double* acc_f = (double*)calloc((size_t)N * KF + 1, sizeof(double));
 #pragma omp parallel
     {
-        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (3 * (size_t)N + 3))   /* (trihexa: up to three offers per particle) */;
 #pragma omp for schedule(dynamic, 8)
         for (uint32_t r = 0; r < nrays; ++r) {
             const v3 o = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
@@ -823,7 +856,7 @@ int orc_grt_ray_candidates(uint32_t N, const real* inst12, const real* ray_to_wo
                            uint32_t* out_id, real* out_t, real* out_tnear, real* out_tfar) {
     const v3 o = xform_point(ray_to_world12, v3_make(ray_o3[0], ray_o3[1], ray_o3[2]));
     const v3 d = xform_dir(ray_to_world12, v3_make(ray_d3[0], ray_d3[1], ray_d3[2]));
-    grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+    grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (3 * (size_t)N + 3))   /* (trihexa: up to three offers per particle) */;
     const uint32_t n = ray_candidates(N, inst12, o, d, cands, 0xFFFFFFFFu /* no prefilter: a ray outside the frame's packets */);
     uint32_t k = 0;
     for (; k < n && k < cap; ++k) { out_id[k] = cands[k].id; out_t[k] = cands[k].t; out_tnear[k] = cands[k].tnear; out_tfar[k] = cands[k].tfar; }
@@ -1174,7 +1207,7 @@ int orc_grt_hybrid_trace(const GrtConfig* cfg, uint32_t N, const real* density12
     const uint32_t seed_width = launch_width ? launch_width : width;
 #pragma omp parallel
     {
-        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (N ? N : 1));
+        grt_hit* cands = (grt_hit*)malloc(sizeof(grt_hit) * (3 * (size_t)N + 3))   /* (trihexa: up to three offers per particle) */;
 #pragma omp for schedule(dynamic, 8)
         for (uint32_t r = 0; r < nrays; ++r) {
             const uint32_t px = pixel_xy ? pixel_xy[2 * r] : r % width, py = pixel_xy ? pixel_xy[2 * r + 1] : r / width;

@@ -35,7 +35,7 @@ void ref_enclosing_proxies(unsigned n, const float* pos, const float* rot, const
     delete[] inst;
 }
 
-// the triangle-mesh proxies: prim 1 icosahedron, 2 octahedron, 3 tetrahedron, 4 diamond (GRUT_PRIM_*), 6 trisurfel (checker only) -> vertices [n * V, 3] in world space,
+// the triangle-mesh proxies: prim 1 icosahedron, 2 octahedron, 3 tetrahedron, 4 diamond (GRUT_PRIM_*), 6 trisurfel, 7 trihexa (checker only) -> vertices [n * V, 3] in world space,
 // triangles [n * T, 3] (indices into all vertices), written by the reference's own mesh kernel of that type.  Returns T (V through *num_vertices).
 unsigned ref_enclosing_mesh(int prim, unsigned n, const float* pos, const float* rot, const float* scl, const float* dns, float min_response, unsigned opts,
                             float degree, float* vertices, int* triangles, unsigned* num_vertices) {
@@ -48,12 +48,13 @@ unsigned ref_enclosing_mesh(int prim, unsigned n, const float* pos, const float*
         case 2: computeGaussianEnclosingOctaHedronKernel(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices, (int3*)triangles); break;
         case 3: computeGaussianEnclosingTetraHedronKernel(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices, (int3*)triangles); break;
         case 4: computeGaussianEnclosingDiamondKernel(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices, (int3*)triangles); break;
+        case 7: computeGaussianEnclosingTriHexaKernel(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices, (int3*)triangles); break;
         case 6: computeGaussianEnclosingTriSurfelKernel<false>(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices, (int3*)triangles, normal_density.data()); break;
         default: return 0;
         }
     }
-    const unsigned nv[7] = {0, icosaHedronNumVrt, octaHedronNumVrt, tetraHedronNumVrt, diamondNumVrt, 0, triSurfelNumVrt};
-    const unsigned nt[7] = {0, icosaHedronNumTri, octaHedronNumTri, tetraHedronNumTri, diamondNumTri, 0, triSurfelNumTri};
+    const unsigned nv[8] = {0, icosaHedronNumVrt, octaHedronNumVrt, tetraHedronNumVrt, diamondNumVrt, 0, triSurfelNumVrt, triHexaNumVrt};
+    const unsigned nt[8] = {0, icosaHedronNumTri, octaHedronNumTri, tetraHedronNumTri, diamondNumTri, 0, triSurfelNumTri, triHexaNumTri};
     *num_vertices = nv[prim];
     return nt[prim];
 }

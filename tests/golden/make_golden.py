@@ -340,7 +340,9 @@ def make_grt_trace():
 MESH_PRIMITIVES = {"icosahedron": (1, "IcosaHedron"), "octahedron": (2, "OctraHedron"), "tetrahedron": (3, "TetraHedron"), "diamond": (4, "Diamond"),
                    # checker-only so far (the HIP plugin refuses it): the open two-triangle surfel proxy, traced WITHOUT face culling, with the surfel
                    # branches of processHit / processHitBwd (PipelineParameters::SurfelPrimitive)
-                   "trisurfel": (6, "TriSurfel")}
+                   "trisurfel": (6, "TriSurfel"),
+                   # ... and the three back-face-culled rhombi in the proxy's coordinate planes: a ray is offered the SAME particle up to three times
+                   "trihexa": (7, "TriHexa")}
 
 
 def make_grt_trace_mesh():

@@ -534,6 +534,44 @@ def test_grt_trisurfel_checker_matches_reference_programs_golden():
     assert per.max() / np.abs(rs).max() < 2e-4, "SH gradients"
 
 
+def test_grt_trihexa_checker_matches_reference_programs_golden():
+    """render.primitive_type = trihexa - refused by the HIP plugin; the CHECKER for it: the reference's programs compiled with
+    PARTICLE_PRIMITIVE_TYPE = MOGTracingTriHexa over the emulated OptiX walking the six triangles per particle of the reference's trihexa
+    kernel (back faces culled), against the oracle's three rhombi in the proxy's coordinate planes with the windings' facing (the z = 0 rhombus
+    has two halves facing opposite ways).  A ray is offered the same particle up to three times; every offer is processed as a hit."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = np.load(os.path.join(HERE, "golden", "grt_trace_mesh.npz"))
+    cfg = oracle.default_grt_config(primitive_type=7)
+    kw = make_golden.GRT_TRACE_SCENES[0]
+    sc = make_scene(**kw)
+    H, W = kw["height"], kw["width"]
+    o = oracle.grt_forward(cfg, sc["density12"], sc["sph"], 3, 1e-3, sc["batch"]["T_to_world"][0], *sc["rays"], dbg_cap=128)
+    ref_cnt = g["trihexa_s0_hits_count"]
+    flips = (o["hit_count"] != ref_cnt)[..., 0]
+    assert flips.mean() <= 0.02 and ref_cnt.max() >= 20, f"{int(flips.sum())} rays with another number of accepted hits"
+    # the quirk is real: some ray processes one particle more than once
+    ids, num = o["hit_ids"], o["hit_num"]
+    assert any(len(set(ids[r, :min(int(num[r]), 128)].tolist())) < min(int(num[r]), 128) for r in range(H * W))
+    ok = ~flips
+    e = np.abs(o["features"] - g["trihexa_s0_features"]).max(-1)
+    hd = g["trihexa_s0_hit_distance"]
+    e_depth = np.abs(o["hit_distance"] - hd)[..., 0]
+    tied = ok & ((e > 1e-5) | (e_depth > 2e-5 * max(1.0, np.abs(hd).max())))
+    assert tied.mean() <= 0.02 and (not tied.any() or (e[tied].max() < 2e-2 and e_depth[tied].max() < 2e-2)), f"{int(tied.sum())} rays differ with the same hit count"
+    ok = ok & ~tied
+    assert np.abs(o["density"] - g["trihexa_s0_density"])[ok].max() < 1e-5
+    assert np.abs(o["hit_distance"] - hd)[..., 1][ok].max() <= 1e-3 and np.median(np.abs(o["hit_distance"] - hd)[..., 1][ok]) <= 2e-6
+    g_rad, g_dns, g_hit = make_golden.grt_trace_upstream(H, W)
+    gd, gs = oracle.grt_backward(cfg, 3, 1e-3, o, g_rad, g_dns, g_hit)
+    rd, rs = g["trihexa_s0_grad_density"], g["trihexa_s0_grad_sph"]
+    ndrop = 3 * int((flips | tied).sum())
+    per = np.sort(np.abs(gd[:, :11].astype(np.float64) - rd[:, :11]).max(1))[: max(1, len(gd) - ndrop)]
+    assert per.max() / np.abs(rd[:, :11]).max() < 2e-4, f"particle gradients {per.max() / np.abs(rd[:, :11]).max():.2e}"
+    per = np.sort(np.abs(gs.astype(np.float64) - rs).max(1))[: max(1, len(gs) - ndrop)]
+    assert per.max() / np.abs(rs).max() < 2e-4, "SH gradients"
+
+
 def test_grt_custom_primitives_match_reference_programs_golden():
     """render.primitive_type = custom: the oracle (world boxes of computeGaussianEnclosingAABBKernel + the maximum-response point within
     3 sigma, orc_grt_custom_boxes / candidate) against tests/golden/grt_trace_mesh.npz `custom_*` = the reference's programs compiled with
