@@ -47,6 +47,9 @@ struct Ray {
     bool inside;   // pixel lies in the image (a ray that misses the scene box is inside but not valid)
 };
 __device__ __forceinline__ void swapf(float& a, float& b) { const float t = a; a = b; b = t; }
+// (a.x b.x + a.y b.y) + a.z b.z with every product and sum rounded on its own (the checker's v3_dot under -ffp-contract=off)
+__device__ __forceinline__ float rn_dot3(float ax, float ay, float az, f3 b) { return add_rn(add_rn(mul_rn(ax, b.x), mul_rn(ay, b.y)), mul_rn(az, b.z)); }
+__device__ __forceinline__ float rn_dot3(f3 a, f3 b) { return rn_dot3(a.x, a.y, a.z, b); }
 __device__ __forceinline__ Ray init_ray(const GutParams& P, const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                         int px, int py) {
     Ray r;
@@ -62,9 +65,11 @@ __device__ __forceinline__ Ray init_ray(const GutParams& P, const float* __restr
     const f3 sd = mk3(ray_d[3 * pix], ray_d[3 * pix + 1], ray_d[3 * pix + 2]);
     const FramePoses& FP = frame_poses(P);
     const float* R = FP.s2w_R;
-    r.o = apply_rows(R, FP.s2w_t, so);
-    r.d = mk3(fmaf(R[0], sd.x, fmaf(R[1], sd.y, R[2] * sd.z)), fmaf(R[3], sd.x, fmaf(R[4], sd.y, R[5] * sd.z)),
-              fmaf(R[6], sd.x, fmaf(R[7], sd.y, R[8] * sd.z)));
+    // world-space ray = pose . (o, d) (rayPayload.cuh:75-108) in the checker's operation order - rows dotted left to right, separately
+    // rounded, then the translation: the sorted mode orders hits by distances computed from these bits (oracle_order_hit_t)
+    r.o = mk3(add_rn(rn_dot3(R[0], R[1], R[2], so), FP.s2w_t[0]), add_rn(rn_dot3(R[3], R[4], R[5], so), FP.s2w_t[1]),
+              add_rn(rn_dot3(R[6], R[7], R[8], so), FP.s2w_t[2]));
+    r.d = mk3(rn_dot3(R[0], R[1], R[2], sd), rn_dot3(R[3], R[4], R[5], sd), rn_dot3(R[6], R[7], R[8], sd));
     const float lo = -1e6f, hi = 1e6f, big = 3.4028234663852886e+38f;
     float tmin = (lo - r.o.x) / r.d.x, tmax = (hi - r.o.x) / r.d.x;
     if (tmin > tmax) swapf(tmin, tmax);
@@ -1069,6 +1074,30 @@ __device__ __forceinline__ float response_grd_rt(int deg, float g, float gres, f
     }
 }
 
+// Sorted mode: the k-buffer ORDERS a ray's hits by their fp32 hit distance, so two implementations agree on the order only if they agree on
+// the distance's bits.  The hit distance of an accepted hit is therefore evaluated in the CHECKER's operation order (oracle/gut_oracle.c
+// density_hit_ex, itself the source order of gaussianParticles.slang:96-110, 181-190): every product and sum rounded on its own, correctly
+// rounded 1/x and sqrt - ~70 instructions per ACCEPTED hit on top of the accept test, which keeps the fast pre-transformed form (its flips
+// are identified per pixel by the parity tests; an order tie could not be).  rt* = rows of R^T from the quaternion, gis = 1 / scale.
+__device__ __forceinline__ float sub_rn(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void rn_rotT(float r, float x, float y, float z, f3& r0, f3& r1, f3& r2) {   // quat_wxyz_to_rotT, uncontracted
+    const float xx = mul_rn(x, x), yy = mul_rn(y, y), zz = mul_rn(z, z), xy = mul_rn(x, y), xz = mul_rn(x, z), yz = mul_rn(y, z);
+    const float rx = mul_rn(r, x), ry = mul_rn(r, y), rz = mul_rn(r, z);
+    r0 = mk3(sub_rn(1.f, mul_rn(2.f, add_rn(yy, zz))), mul_rn(2.f, add_rn(xy, rz)), mul_rn(2.f, sub_rn(xz, ry)));
+    r1 = mk3(mul_rn(2.f, sub_rn(xy, rz)), sub_rn(1.f, mul_rn(2.f, add_rn(xx, zz))), mul_rn(2.f, add_rn(yz, rx)));
+    r2 = mk3(mul_rn(2.f, add_rn(xz, ry)), mul_rn(2.f, sub_rn(yz, rx)), sub_rn(1.f, mul_rn(2.f, add_rn(xx, yy))));
+}
+__device__ __forceinline__ float oracle_order_hit_t(const Ray& ray, f3 pos, f3 scl, f3 rt0, f3 rt1, f3 rt2, f3 gis) {
+    const f3 gposc = mk3(sub_rn(ray.o.x, pos.x), sub_rn(ray.o.y, pos.y), sub_rn(ray.o.z, pos.z));
+    const f3 gro = mk3(mul_rn(gis.x, rn_dot3(rt0, gposc)), mul_rn(gis.y, rn_dot3(rt1, gposc)), mul_rn(gis.z, rn_dot3(rt2, gposc)));
+    const f3 grdu = mk3(mul_rn(gis.x, rn_dot3(rt0, ray.d)), mul_rn(gis.y, rn_dot3(rt1, ray.d)), mul_rn(gis.z, rn_dot3(rt2, ray.d)));
+    const float inv = 1.f / sqrtf(rn_dot3(grdu, grdu));            // (IEEE division and square root: the file is not built with fast-math)
+    const f3 grd = mk3(mul_rn(grdu.x, inv), mul_rn(grdu.y, inv), mul_rn(grdu.z, inv));
+    const float along = rn_dot3(grd, mk3(-gro.x, -gro.y, -gro.z));
+    const f3 grds = mk3(mul_rn(scl.x, mul_rn(grd.x, along)), mul_rn(scl.y, mul_rn(grd.y, along)), mul_rn(scl.z, mul_rn(grd.z, along)));
+    return sqrtf(rn_dot3(grds, grds));
+}
+
 template <int K>
 struct KBuffer {   // ascending in hitT: slot 0 = nearest pending hit, empty slots hold hitT = -1 at the front
     float hitT[K], alpha[K];
@@ -1226,7 +1255,8 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
                                                   float4* __restrict__ out_fd, float* __restrict__ out_dist, float* __restrict__ out_cnt,
                                                   const float4* __restrict__ g_fd, const float* __restrict__ g_dist,
                                                   float* __restrict__ g_density12, float* __restrict__ g_rgb) {
-    __shared__ float4 s_rec[64 * 5];
+    constexpr int kQ = 8;   // quads per staged entry: 0-2 M rows | pos, 3 scale | density, 4 particle | accept limit, 5-7 rows of R^T | 1 / scale
+    __shared__ float4 s_rec[64 * kQ];
     // strip -> (tile, strip-in-tile) with all four strips of a tile on one XCD
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t tile = ((slot >> 2) << 3) + xcd, strip = slot & 3u;
@@ -1255,7 +1285,15 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
             const RawEntry e = load_entry(b + lane, range.y, lists, density12, rgb);
             float4 r0 = make_float4(1.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 1.f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
             float4 r3 = make_float4(1.f, 1.f, 1.f, 0.f), r4 = make_float4(__uint_as_float(0xFFFFFFFFu), 0.f, 0.f, 0.f);
+            float4 r5 = r0, r6 = r1, r7 = r2;
             if (e.idx != 0xFFFFFFFFu) {
+                {   // the hit-distance inputs in the checker's operation order (oracle_order_hit_t)
+                    f3 t0, t1, t2;
+                    rn_rotT(e.q.x, e.q.y, e.q.z, e.q.w, t0, t1, t2);
+                    r5 = make_float4(t0.x, t0.y, t0.z, 1.f / e.s.x);
+                    r6 = make_float4(t1.x, t1.y, t1.z, 1.f / e.s.y);
+                    r7 = make_float4(t2.x, t2.y, t2.z, 1.f / e.s.z);
+                }
                 const m3 rt = quat_wxyz_to_rotT(e.q.x, e.q.y, e.q.z, e.q.w);
                 const float ix = __builtin_amdgcn_rcpf(e.s.x), iy = __builtin_amdgcn_rcpf(e.s.y), iz = __builtin_amdgcn_rcpf(e.s.z);
                 r0 = make_float4(rt.r0.x * ix, rt.r0.y * ix, rt.r0.z * ix, e.a.x);
@@ -1267,14 +1305,14 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
                 const float need = fmaxf(P.min_response, P.min_alpha / e.a.w);
                 r4.y = (P.max_alpha > P.min_alpha && e.a.w > 0.f) ? gray_limit_rt(P.degree, need) : 0.f;
             }
-            float4* rec = &s_rec[lane * 5];
-            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4;
+            float4* rec = &s_rec[lane * kQ];
+            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4; rec[5] = r5; rec[6] = r6; rec[7] = r7;
         }
         __syncthreads();
         const int n = (int)min(64u, range.y - b);
         for (int j = 0; j < n; ++j) {
             if (!__any(alive)) break;
-            const float4* rec = &s_rec[j * 5];
+            const float4* rec = &s_rec[j * kQ];
             const uint32_t idx = __float_as_uint(rec[4].x);
             if (idx == 0xFFFFFFFFu) break;   // padding closes the list (gutKBufferRenderer.cuh:312-315)
             bool pop = false;
@@ -1292,10 +1330,10 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
                     const float il2 = __builtin_amdgcn_rcpf(l2);
                     const float resp = response_rt(P.degree, cc * il2);
                     const float alpha = fminf(P.max_alpha, resp * q3.w);
-                    // hit distance |S n (n.-u)| = |v.u| |S v| / |v|^2  (as in render_fwd_sweep)
-                    const float vu = dot(grdu, gro);
-                    const f3 sv = mk3(q3.x, q3.y, q3.z) * grdu;
-                    const float hitT = __builtin_amdgcn_sqrtf(dot(sv, sv) * (vu * vu)) * il2;
+                    // hit distance |S n (n.-u)| (gaussianParticles.slang:181-190), bits = the checker's: it is the k-buffer's sort key
+                    const float4 q5 = rec[5], q6 = rec[6], q7 = rec[7];
+                    const float hitT = oracle_order_hit_t(ray, mk3(q0.w, q1.w, q2.w), mk3(q3.x, q3.y, q3.z), mk3(q5.x, q5.y, q5.z), mk3(q6.x, q6.y, q6.z),
+                                                          mk3(q7.x, q7.y, q7.z), mk3(q5.w, q6.w, q7.w));
                     if ((hitT > ray.tmin) && (hitT < ray.tmax)) {
                         if (kb.num == K) {   // full: the nearest pending hit is composited (below), the new one takes its slot
                             pop = true; pop_t = kb.hitT[0]; pop_a = kb.alpha[0]; pop_i = kb.idx[0];

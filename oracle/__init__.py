@@ -501,6 +501,23 @@ def gut_pixel_trace(cfg, cam, fwd, pixel, cap=4096, dtype=np.float32):
     return dict(idx=idx[:n], alpha=alpha[:n], hit_t=hit_t[:n], margin=margin[:n])
 
 
+def gut_pixel_trace_nht(cfg, cam, fwd, pixel, cap=4096, dtype=np.float32, nht=None):
+    """gut_pixel_trace for the neural-harmonic-features path (orc_gut_pixel_trace_nht): additionally `colour` [n, ray_dim], the feature values
+    every entry's hit would blend.  fwd: dict with poses, rays, density12, nht_features, bins (sorted_idx, tile_ranges)."""
+    nht = dict(NHT_DEFAULT, **(nht or {}))
+    l = lib(dtype)
+    nr = nht_ray_feature_dim(nht)
+    prm = np.array([nht["particle_feature_dim"], nht["interp_point_dim"], nht["support"], nht["activation"], nht["num_frequencies"]], np.int32)
+    idx = np.zeros(cap, np.uint32)
+    alpha, hit_t, margin, feat = np.zeros(cap, dtype), np.zeros(cap, dtype), np.zeros(cap, dtype), np.zeros((cap, nr), dtype)
+    ps, pe = fwd["poses"]
+    ro, rd = fwd["rays"]
+    n = l.orc_gut_pixel_trace_nht(C.byref(cfg), _p(prm), C.c_int(cam.width), C.c_int(cam.height), _p(_c(ps, dtype)), _p(_c(pe, dtype)), _p(_c(fwd["density12"], dtype)),
+                                  _p(_c(fwd["nht_features"], dtype)), _p(fwd["bins"]["sorted_idx"]), _p(fwd["bins"]["tile_ranges"]), _p(_c(ro, dtype)), _p(_c(rd, dtype)),
+                                  C.c_uint32(int(pixel)), C.c_uint32(cap), _p(idx), _p(alpha), _p(hit_t), _p(margin), _p(feat))
+    return dict(idx=idx[:n], alpha=alpha[:n], hit_t=hit_t[:n], margin=margin[:n], colour=feat[:n])
+
+
 class _OrcTexture(C.Structure):
     _fields_ = [("data", C.c_void_p), ("height", C.c_int32), ("width", C.c_int32), ("channels", C.c_int32)]
 

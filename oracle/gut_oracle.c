@@ -868,6 +868,48 @@ int orc_gut_render_nht_fwd(const GutConfig* cfg, const int* nht, int width, int 
     return 0;
 }
 
+/* orc_gut_pixel_trace for the feature path: additionally the nr feature values each entry's hit would blend (interpolated at ITS
+ * canonical intersection - per ray, so they cannot come from a per-particle table like the SH radiance), out_feat [cap, nr]. */
+int orc_gut_pixel_trace_nht(const GutConfig* cfg, const int* nht, int width, int height, const real* pose_start7, const real* pose_end7,
+                            const real* density12, const real* features, const uint32_t* sorted_idx, const uint32_t* tile_ranges, const real* ray_o,
+                            const real* ray_d, uint32_t pix, uint32_t cap, uint32_t* out_idx, real* out_alpha, real* out_hitT, real* out_margin,
+                            real* out_feat) {
+    const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
+    const int gx = tile_grid_dim(width);
+    const int nr = nht_ray_dim(nht);
+    const int x = (int)pix % width, y = (int)pix / width;
+    const orc_ray ray = init_ray(&fp, ray_o + 3 * (size_t)pix, ray_d + 3 * (size_t)pix);
+    if (!ray.valid || nr > ORC_NHT_MAX_RAY_DIM) return 0;
+    const uint32_t tile = (uint32_t)((y / ORC_TILE) * gx + (x / ORC_TILE));
+    uint32_t n = 0;
+    for (uint32_t e = tile_ranges[2 * tile]; e < tile_ranges[2 * tile + 1] && n < cap; ++e) {
+        const uint32_t idx = sorted_idx[e];
+        if (idx == ORC_INVALID_IDX) break;
+        const orc_particle p = load_particle(density12 + 12 * (size_t)idx);
+        /* as orc_gut_render_nht_fwd, every entry kept */
+        const v3 giscl = v3_make(1 / p.scl.x, 1 / p.scl.y, 1 / p.scl.z);
+        const v3 gro = v3_mul(giscl, v3_mul_rows(v3_sub(ray.o, p.pos), &p.rotT));
+        const v3 grdu = v3_mul(giscl, v3_mul_rows(ray.d, &p.rotT));
+        const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
+        const v3 gcrod = v3_cross(grd, gro);
+        const real resp = particle_response(cfg->particle_kernel_degree, v3_dot(gcrod, gcrod));
+        const real alpha = r_min((real)cfg->particle_kernel_max_alpha, resp * p.density);
+        const v3 cg = v3_scale(grd, v3_dot(grd, v3_scale(gro, -1)));
+        const v3 P = v3_add(gro, cg);
+        const v3 grds = v3_mul(p.scl, cg);
+        const real hitT = r_sqrt(v3_dot(grds, grds));
+        real f[ORC_NHT_MAX_RAY_DIM];
+        nht_features_at(nht, features + (size_t)nht[0] * idx, P, f);
+        out_idx[n] = idx;
+        out_alpha[n] = (hitT > ray.tmin && hitT < ray.tmax) ? alpha : 0;
+        out_hitT[n] = hitT;
+        out_margin[n] = r_min(resp / (real)cfg->particle_kernel_min_response, resp * p.density / (real)cfg->particle_kernel_min_alpha) - 1;
+        for (int i = 0; i < nr; ++i) out_feat[(size_t)n * nr + i] = f[i];
+        n++;
+    }
+    return (int)n;
+}
+
 static size_t list_particle_bound(int width, int height, const uint32_t* sorted_idx, const uint32_t* tile_ranges);
 /* --------------------------------------------------------------------------------------
  * render backward with neural harmonic features (K = 0): evalBackwardNoKBuffer's PerRayParticleFeatures branch

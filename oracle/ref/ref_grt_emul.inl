@@ -29,7 +29,17 @@ struct Scene {
     // custom primitives (render.primitive_type custom: one custom-primitive GAS over the particles' world boxes, optixTracer.cpp:638-655, 810-817)
     uint32_t num_boxes = 0;
     const float* boxes = nullptr;      // [n,6] min xyz, max xyz, as computeGaussianEnclosingAABBKernel wrote them
+    // Optional per-ray candidate subsets (ref_grt_set_ray_candidates): ray r is offered only the particles cand[cand_begin[r] .. cand_begin[r+1])
+    // (ascending, so the index order of the full loops is kept).  The caller guarantees a CONSERVATIVE superset - every particle whose proxy
+    // the ray's line can touch at all (tests/golden/make_fullsize_golden.py: bounding spheres in float64 with a margin) - so the programs
+    // see exactly the reports the full loop would give them; it only makes 1 M-particle frames affordable for more than a handful of rays.
+    const uint32_t* cand_begin = nullptr;
+    const uint32_t* cand = nullptr;
+    uint32_t cur_ray = 0;
 } g_scene;
+// first / one-past-last position of the current ray's primitives in its candidate list, or the whole range [0, n)
+static inline uint32_t cand_count(uint32_t n) { return g_scene.cand_begin ? g_scene.cand_begin[g_scene.cur_ray + 1] - g_scene.cand_begin[g_scene.cur_ray] : n; }
+static inline uint32_t cand_at(uint32_t k) { return g_scene.cand_begin ? g_scene.cand[g_scene.cand_begin[g_scene.cur_ray] + k] : k; }
 }  // namespace
 
 bool optixReportIntersection(float t, unsigned) {
@@ -58,7 +68,10 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
     // seen from the ray origin, OptiX's default) the ray crosses within its CURRENT interval is reported to the any-hit program, in
     // index order (OptiX leaves the order open; the payload ends up with the 16 nearest either way, up to ties).  Moeller-Trumbore in
     // world space, separately rounded fp32 operations.
-    for (uint32_t f = 0; f < g_scene.num_triangles; ++f) {
+    const uint32_t tpp = params.gPrimNumTri ? params.gPrimNumTri : 1u;   // a candidate subset names PARTICLES: all tpp triangles of each, in index order
+    const uint32_t n_units = g_scene.cand_begin ? cand_count(0) * tpp : g_scene.num_triangles;
+    for (uint32_t k = 0; k < n_units; ++k) {
+        const uint32_t f = g_scene.cand_begin ? cand_at(k / tpp) * tpp + k % tpp : k;
         const int32_t* tri = g_scene.triangles + 3 * (size_t)f;
         const float* pa = g_scene.vertices + 3 * (size_t)tri[0];
         const float* pb = g_scene.vertices + 3 * (size_t)tri[1];
@@ -88,7 +101,8 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
     // Custom primitives: the intersection program (intersectCustomParticle, world-space ray) runs for every particle whose WORLD box the
     // ray overlaps within its interval - the same slab test and the same far-end convention as for the instances' unit boxes below.
     // (OptiX may also call the program for a ray that misses the box narrowly; the emulation's boxes are exact.)
-    for (uint32_t i = 0; i < g_scene.num_boxes; ++i) {
+    for (uint32_t k = 0, nk = cand_count(g_scene.num_boxes); k < nk; ++k) {
+        const uint32_t i = cand_at(k);
         const float* bx = g_scene.boxes + 6 * (size_t)i;
         const float ax0 = (bx[0] - o.x) / d.x, ax1 = (bx[3] - o.x) / d.x, ay0 = (bx[1] - o.y) / d.y, ay1 = (bx[4] - o.y) / d.y;
         const float az0 = (bx[2] - o.z) / d.z, az1 = (bx[5] - o.z) / d.z;
@@ -101,7 +115,8 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
     }
     return;
 #endif
-    for (uint32_t i = 0; i < g_scene.n; ++i) {
+    for (uint32_t k = 0, nk = cand_count(g_scene.n); k < nk; ++k) {
+        const uint32_t i = cand_at(k);
         const float* m = &g_scene.inv[12 * (size_t)i];
         const float dx = o.x - m[9], dy = o.y - m[10], dz = o.z - m[11];
         const float3 oo = make_float3(m[0] * dx + m[1] * dy + m[2] * dz, m[3] * dx + m[4] * dy + m[5] * dz, m[6] * dx + m[7] * dy + m[8] * dz);
@@ -179,6 +194,10 @@ static void launch_raygen(int width, int height) {
     for (int y = 0; y < height; ++y)
         for (int x = 0; x < width; ++x) {
             g_optix.launchIndex = uint3{(unsigned)x, (unsigned)y, 0u};
+            g_scene.cur_ray = (uint32_t)(y * width + x);
             __raygen__rg();
         }
 }
+
+// per-ray candidate subsets for the NEXT launches of this library: offsets [rays + 1], particles [offsets[rays]] ascending per ray; nulls clear
+extern "C" void ref_grt_set_ray_candidates(const uint32_t* offsets, const uint32_t* particles) { g_scene.cand_begin = offsets; g_scene.cand = particles; }

@@ -165,8 +165,123 @@ def make_grt():
     print("wrote fullsize_grt_c3_1m_800.npz", flush=True)
 
 
+GRT_PRIM_RAYS = (64, 96)       # 6144 rays on a regular sub-grid: affordable through the per-ray candidate subsets below
+
+
+def ray_candidates(centres, radii, origin, dirs, chunk=4000):
+    """Per ray, the particles whose bounding sphere (centre, radius) the ray's LINE reaches - float64, radius widened by 1e-4 relative +
+    1e-6: a conservative superset of everything the emulated traversal could report to the programs for that ray.  Returns the CSR pair
+    (offsets [rays + 1], particles ascending per ray) of ref_grt_set_ray_candidates (oracle/ref/ref_grt_emul.inl)."""
+    c = np.asarray(centres, np.float64) - np.asarray(origin, np.float64)[None]
+    rr = (np.asarray(radii, np.float64) * (1.0 + 1e-4) + 1e-6) ** 2
+    d = np.asarray(dirs, np.float64)
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    rays_l, parts_l = [], []
+    for a in range(0, len(c), chunk):
+        cc = c[a:a + chunk]
+        proj = cc @ d.T
+        d2 = (cc * cc).sum(1)[:, None] - proj * proj
+        pi, ri = np.nonzero(d2 <= rr[a:a + chunk, None])
+        rays_l.append(ri.astype(np.uint32))
+        parts_l.append((pi + a).astype(np.uint32))
+    rays, parts = np.concatenate(rays_l), np.concatenate(parts_l)
+    order = np.lexsort((parts, rays))
+    rays, parts = rays[order], np.ascontiguousarray(parts[order])
+    offsets = np.zeros(len(d) + 1, np.uint32)
+    offsets[1:] = np.cumsum(np.bincount(rays, minlength=len(d)))
+    return offsets, parts
+
+
+def make_grt_prim(prim):
+    """fullsize_grt_<prim>_c3_1m_800.npz: the reference's forward / backward programs built for `prim` (icosahedron: the paper's own 3DGRT
+    configuration, configs/paper/3dgrt/base_ours_reference.yaml:16; custom: world boxes + intersectCustomParticle) on GRT_PRIM_RAYS rays of
+    BASELINE config 3's frame, proxies by the reference's own mesh / AABB kernels over all 1 M particles.  Each ray is offered the particles
+    whose proxy's bounding sphere its line reaches (ray_candidates) instead of all 1 M - a superset of what can report a hit."""
+    import make_golden as mg
+    n, W, H, ms = GRT_FRAME
+    inp = frame_inputs(n, W, H, ms)
+    px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    px.ref_enclosing_mesh.restype = C.c_uint
+    d12, sph = inp["d12"], inp["sph"]
+    pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]), np.ascontiguousarray(d12[:, 3]))
+    r2w = np.ascontiguousarray(np.asarray(inp["batch"]["T_to_world"][0], F)[:3, :4])
+    sh, sw = GRT_PRIM_RAYS
+    ys = (np.arange(sh) * (H // sh) + H // (2 * sh)).astype(np.int64)
+    xs = (np.arange(sw) * (W // sw) + W // (2 * sw)).astype(np.int64)
+    ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)[np.ix_(ys, xs)]) for a in inp["rays"])
+    assert np.all(ro.reshape(-1, 3) == ro.reshape(-1, 3)[0])          # one origin (pinhole)
+    o_w = r2w[:, :3].astype(np.float64) @ ro.reshape(-1, 3)[0].astype(np.float64) + r2w[:, 3]
+    d_w = rd.reshape(-1, 3).astype(np.float64) @ r2w[:, :3].astype(np.float64).T
+    t0 = time.time()
+    if prim == "custom":
+        tag, fn = "Custom", "custom"
+        aabb, tf = np.zeros((n, 6), F), np.zeros((n, 12), F)
+        px.ref_enclosing_proxies(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(mg.MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(aabb), _p(tf))
+        box = np.concatenate([aabb[:, :3].min(0), aabb[:, 3:].max(0)]).astype(F)
+        centres = 0.5 * (aabb[:, :3].astype(np.float64) + aabb[:, 3:])
+        radii = 0.5 * np.linalg.norm(aabb[:, 3:].astype(np.float64) - aabb[:, :3], axis=1)
+        scene_args = (C.c_uint(n), _p(aabb))
+    else:
+        (code, tag), fn = mg.MESH_PRIMITIVES[prim], "mesh"
+        verts, tris, nv = np.zeros((n * 12, 3), F), np.zeros((n * 20, 3), np.int32), C.c_uint(0)
+        nt = px.ref_enclosing_mesh(code, C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(mg.MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(verts), _p(tris),
+                                   C.byref(nv))
+        verts, tris = np.ascontiguousarray(verts[:n * nv.value]), np.ascontiguousarray(tris[:n * nt])
+        box = np.concatenate([verts.min(0), verts.max(0)]).astype(F)
+        centres = pos.astype(np.float64)
+        radii = np.linalg.norm(verts.reshape(n, nv.value, 3).astype(np.float64) - centres[:, None], axis=2).max(1)
+        scene_args = (C.c_uint(n), C.c_uint(nt), _p(verts), _p(tris))
+    offsets, cand = ray_candidates(centres, radii, o_w, d_w)
+    print(f"grt {prim}: proxies + candidate subsets in {time.time() - t0:.1f} s; {len(cand) / (sh * sw):.0f} candidate particles per ray", flush=True)
+    fw = C.CDLL(os.path.join(REF, f"libref_grt_trace_{tag}_deg4.so"))
+    bw = C.CDLL(os.path.join(REF, f"libref_grt_trace_bwd_{tag}_deg4.so"))
+    feat, den, hit, nrm = np.zeros((sh, sw, 3), F), np.zeros((sh, sw, 1), F), np.zeros((sh, sw, 2), F), np.zeros((sh, sw, 3), F)
+    cnt, vis = np.zeros((sh, sw, 1), F), np.zeros(n, np.int32)
+    common = scene_args + (_p(d12), _p(sph), sw, sh, _p(r2w), _p(ro), _p(rd), _p(box), C.c_float(mg.MIN_T_GRT), C.c_float(mg.MIN_RESPONSE),
+                           C.c_float(mg.MIN_ALPHA), C.c_uint(3))
+    if prim == "custom":
+        fw.ref_grt_set_box_test_uses_shrunk_tmax(0)
+    fw.ref_grt_set_ray_candidates(_p(offsets), _p(cand))
+    bw.ref_grt_set_ray_candidates(_p(offsets), _p(cand))
+    t0 = time.time()
+    getattr(fw, f"ref_grt_trace_fwd_{fn}")(*common, _p(feat), _p(den), _p(hit), _p(nrm), _p(cnt), _p(vis))
+    print(f"grt {prim}: forward programs on {sh * sw} rays in {time.time() - t0:.1f} s; hits per ray {cnt.mean():.1f}", flush=True)
+    g_rad, g_dns, g_hit = mg.grt_trace_upstream(sh, sw)
+    gd, gs = np.zeros((n, 12), F), np.zeros((n, 48), F)
+    t0 = time.time()
+    getattr(bw, f"ref_grt_trace_bwd_{fn}")(*common, _p(feat), _p(den), _p(hit), _p(g_rad), _p(g_dns), _p(g_hit), _p(gd), _p(gs))
+    touched = np.flatnonzero((np.abs(gd).max(1) > 0) | (np.abs(gs).max(1) > 0))
+    print(f"grt {prim}: backward programs in {time.time() - t0:.1f} s; {len(touched)} particles touched", flush=True)
+    # the superset property of the candidate subsets, checked where it is affordable: a sub-sample of the rays again with EVERY particle offered
+    sub = np.arange(0, sh * sw, 128 if fn == "mesh" else 16)
+    fw.ref_grt_set_ray_candidates(None, None)
+    f2, d2, h2, n2 = np.zeros((1, len(sub), 3), F), np.zeros((1, len(sub), 1), F), np.zeros((1, len(sub), 2), F), np.zeros((1, len(sub), 3), F)
+    c2, v2 = np.zeros((1, len(sub), 1), F), np.zeros(n, np.int32)
+    ro2, rd2 = np.ascontiguousarray(ro.reshape(-1, 3)[sub][None]), np.ascontiguousarray(rd.reshape(-1, 3)[sub][None])
+    common2 = scene_args + (_p(d12), _p(sph), len(sub), 1, _p(r2w), _p(ro2), _p(rd2), _p(box), C.c_float(mg.MIN_T_GRT), C.c_float(mg.MIN_RESPONSE),
+                            C.c_float(mg.MIN_ALPHA), C.c_uint(3))
+    t0 = time.time()
+    getattr(fw, f"ref_grt_trace_fwd_{fn}")(*common2, _p(f2), _p(d2), _p(h2), _p(n2), _p(c2), _p(v2))
+    same = (np.array_equal(f2[0], feat.reshape(-1, 3)[sub]) and np.array_equal(d2[0], den.reshape(-1, 1)[sub]) and np.array_equal(h2[0], hit.reshape(-1, 2)[sub])
+            and np.array_equal(c2[0], cnt.reshape(-1, 1)[sub]))
+    print(f"grt {prim}: {len(sub)} rays again with all {n} particles offered in {time.time() - t0:.1f} s: bit-identical = {same}", flush=True)
+    assert same, "the candidate subsets changed a ray"
+    mag = np.abs(gd[touched][:, :11]).max(1)
+    big = np.argsort(mag)[-3000:]
+    rest = np.setdiff1d(np.arange(len(touched)), big)
+    sel = np.sort(np.concatenate([big, np.random.default_rng(3).choice(rest, min(5000, len(rest)), replace=False)]))
+    np.savez_compressed(os.path.join(HERE, f"fullsize_grt_{prim}_c3_1m_800.npz"), n=n, W=W, H=H, median_scale=ms, ys=ys, xs=xs, features=feat, density=den,
+                        hit_distance=hit, hits_count=cnt, visible=np.flatnonzero(vis).astype(np.uint32), touched=touched.astype(np.uint32),
+                        grad_rows=sel.astype(np.uint32), grad_density=gd[touched][sel], grad_sph=gs[touched][sel],
+                        candidates_per_ray=np.float32(len(cand) / (sh * sw)), superset_check_rays=np.int32(len(sub)))
+    print(f"wrote fullsize_grt_{prim}_c3_1m_800.npz", flush=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gut_c4", "gut_c2", "grt_c3"]
+    which = sys.argv[1:] or ["gut_c4", "gut_c2", "grt_c3", "grt_icosahedron", "grt_custom"]
+    for w_ in which:
+        if w_.startswith("grt_") and w_ != "grt_c3":
+            make_grt_prim(w_[4:])
     if "gut_c4" in which:
         make_gut("c4_1m_1080p")
     if "gut_c2" in which:

@@ -158,7 +158,7 @@ def _composite(alpha, hit_t, colour, accept, min_T, end_shift=0, K=0, alpha_ref=
     small distant particles in ANY evaluation order - the reference's CUDA, the float oracle and the HIP kernels each draw their own
     sample of it, the double oracle shows how large it is for the pixel at hand."""
     state = dict(T=1.0, D=0.0, cnt=0, S=0.0, alive=True, skip=end_shift > 0)
-    C = np.zeros(3)
+    C = np.zeros(colour.shape[1] if colour.ndim == 2 else 3)
 
     def integrate(i):
         a = float(alpha[i])
@@ -203,7 +203,7 @@ def _composite(alpha, hit_t, colour, accept, min_T, end_shift=0, K=0, alpha_ref=
     return C, 1.0 - state["T"], state["D"], state["cnt"], state["S"]
 
 
-def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dist, margin=1e-3, tol=1e-4, tol_half=None):
+def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dist, margin=1e-3, tol=1e-4, tol_half=None, trace_fn=None):
     """For each listed pixel (flat index), finds the smallest set of accept / reject decisions the oracle took within `margin`
     (relative) of their threshold that, taken the other way, reproduces the GPU's pixel: same hit count, colour, opacity AND hit
     distance within `tol` (absolute).  Decisions that close to a threshold are decided by rounding, so such a pixel is an IDENTIFIED
@@ -214,28 +214,31 @@ def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dis
     member of the ROUNDING class: it must then lie within `tol` + 3 x the propagated fp32 rounding of its own alphas
     (_composite's S) of the DOUBLE evaluation of the same decisions.
 
+    trace_fn (feature path): callable (pixel, dtype) -> the pixel's trace incl. `colour` [n, channels], the values each entry's hit blends
+    (per ray there, not a per-particle table); hip_fd then has channels + 1 columns, the opacity last.
+
     Returns (toggles per pixel (-1: not reproducible), rounding-class flag per pixel, error / bound ratio per pixel)."""
     import itertools
     min_T = float(cfg.min_transmittance)
     K = int(cfg.k_buffer_size)
-    fd = hip_fd.reshape(-1, 4)
+    fd = hip_fd.reshape(-1, hip_fd.shape[-1])
     cnt = hip_cnt.reshape(-1)
     dist = hip_dist.reshape(-1)
     out = np.full(len(pixels), -1, np.int32)
     rounding = np.zeros(len(pixels), bool)
     ratio = np.zeros(len(pixels))
-    fwd64 = dict(fwd, density12=fwd["density12"].astype(np.float64), rays=tuple(r.astype(np.float64) for r in fwd["rays"]),
-                 poses=tuple(p.astype(np.float64) for p in fwd["poses"]))
+    fwd64 = None if trace_fn else dict(fwd, density12=fwd["density12"].astype(np.float64), rays=tuple(r.astype(np.float64) for r in fwd["rays"]),
+                                       poses=tuple(p.astype(np.float64) for p in fwd["poses"]))
     for k, pix in enumerate(pixels):
-        tr = oracle.gut_pixel_trace(cfg, cam, fwd, pix)
-        tr64 = oracle.gut_pixel_trace(cfg, cam, fwd64, pix, dtype=np.float64)
+        tr = trace_fn(pix, np.float32) if trace_fn else oracle.gut_pixel_trace(cfg, cam, fwd, pix)
+        tr64 = trace_fn(pix, np.float64) if trace_fn else oracle.gut_pixel_trace(cfg, cam, fwd64, pix, dtype=np.float64)
         alpha, hit_t, m = tr["alpha"].astype(np.float64), tr["hit_t"].astype(np.float64), tr["margin"].astype(np.float64)
         alpha64, hit_t64 = tr64["alpha"], tr64["hit_t"]
-        colour = np.maximum(particle_rgb[tr["idx"]].astype(np.float64), 0.0)
+        colour = tr["colour"].astype(np.float64) if trace_fn else np.maximum(particle_rgb[tr["idx"]].astype(np.float64), 0.0)
         accept0 = m > 0
         near = np.flatnonzero((np.abs(m) < margin) & (alpha > 0))
         target, tcnt, tdist = fd[pix], int(cnt[pix]), float(dist[pix])
-        c_max = float(colour.max()) if colour.size else 1.0
+        c_max = float(np.abs(colour).max()) if colour.size else 1.0
         t_max = float(hit_t64.max()) if hit_t64.size else 1.0
 
         # sorted mode: the k-buffer orders hits by their fp32 hit distance - two hits whose distances agree to rounding (canonical-frame
@@ -266,13 +269,13 @@ def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dis
             # (feature_output_half: the image is the fp32 result rounded to half - half an ulp of the value on top of the tolerance)
             t_rgb = tol + (0.0 if tol_half is None else float(tol_half(np.abs(C).max())))
             t_opa = tol + (0.0 if tol_half is None else float(tol_half(abs(opa))))
-            if c == tcnt and np.abs(C - target[:3]).max() < t_rgb and abs(opa - target[3]) < t_opa and abs(D - tdist) < tol:
+            if c == tcnt and np.abs(C - target[:-1]).max() < t_rgb and abs(opa - target[-1]) < t_opa and abs(D - tdist) < tol:
                 return 1, 0.0
             C, opa, D, c, S = _composite(alpha64, hit_t64, colour, acc, min_T, end_shift, K, alpha_ref=alpha)
             if c != tcnt:
                 return 0, 0.0
             b_rgb, b_opa, b_d = 2.0 * c_max * S, S, 2.0 * t_max * S
-            r = max(np.abs(C - target[:3]).max() / (t_rgb + 3 * b_rgb), abs(opa - target[3]) / (t_opa + 3 * b_opa), abs(D - tdist) / (tol + 3 * b_d))
+            r = max(np.abs(C - target[:-1]).max() / (t_rgb + 3 * b_rgb), abs(opa - target[-1]) / (t_opa + 3 * b_opa), abs(D - tdist) / (tol + 3 * b_d))
             return (2, float(r)) if r <= 1.0 else (0, float(r))
 
         found = -1
@@ -288,7 +291,7 @@ def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dis
                         # the double evaluation reproduces the pixel: is it its ORDER of the hits (ties of the fp32 distances resolved as the
                         # float64 distances resolve them), with the fp32 values?  Then this is an order tie - a flip - not a rounding-class pixel
                         C, opa, D, c, _ = _composite(alpha, hit_t64, colour, acc, min_T, end_shift, K)
-                        if c == tcnt and np.abs(C - target[:3]).max() < tol and abs(opa - target[3]) < tol and abs(D - tdist) < tol:
+                        if c == tcnt and np.abs(C - target[:-1]).max() < tol and abs(opa - target[-1]) < tol and abs(D - tdist) < tol:
                             how, extra = 1, extra + 1
                     if how:
                         found = n_toggle + extra
@@ -440,6 +443,23 @@ def gut_full_parity_nht(n, w, h, median_scale, seed=42, view=0, log=None, device
     stats.update(B_flip_pixels=int(X.sum()), B_flip_frac=float(X.mean()), B_bad_pixels=int(bad.sum()), B_bad_outside_flips=int((bad & ~X).sum()),
                  B_max_err_outside_flips=float(d_img[~X].max()), B_max_dist_err_outside_flips=float(d_dist[~X].max()),
                  B_feature_abs_max=float(np.abs(shared["feat_density"][..., :24]).max()))
+    # every exempted pixel identified, as on the SH frames (identify_flips): the oracle's own trace of the pixel - per entry the alpha, the
+    # hit distance, the accept margin and the 24 feature values its hit would blend - reproduces the GPU's pixel with at most three
+    # borderline decisions taken the other way, or is a member of the bounded rounding class
+    exempt = np.flatnonzero((X | bad).reshape(-1))
+    t0 = time.time()
+    rays = tuple(np.ascontiguousarray(r.reshape(h, w, 3)) for r in inp["rays"])
+    trace_in = dict(poses=(inp["ps"], inp["pe"]), rays=rays, density12=inp["d12"], nht_features=feats,
+                    bins=dict(sorted_idx=shared["sorted_idx"], tile_ranges=shared["tile_ranges"]))
+    toggles, rounding, ratio = identify_flips(cfg, inp["cam"], trace_in, None, exempt, fd, hip["cnt"], hip["dist"],
+                                              trace_fn=lambda pix, dt: oracle.gut_pixel_trace_nht(cfg, inp["cam"], trace_in, pix, dtype=dt))
+    pure = rounding & (toggles == 0)
+    d_img_f, d_dist_f = d_img.reshape(-1), d_dist.reshape(-1)
+    stats.update(B_exempt_pixels=int(exempt.size), B_exempt_frac=float(exempt.size / X.size), B_exempt_unidentified=int((toggles < 0).sum()),
+                 B_exempt_by_toggles={int(t): int((toggles == t).sum()) for t in np.unique(toggles)}, B_rounding_class_pixels=int(pure.sum()),
+                 B_rounding_class_max_err=float(d_img_f[exempt][pure].max()) if pure.any() else 0.0,
+                 B_rounding_class_max_dist_err=float(d_dist_f[exempt][pure].max()) if pure.any() else 0.0,
+                 B_rounding_class_max_ratio_to_bound=float(ratio[rounding].max()) if rounding.any() else 0.0, t_identify_s=time.time() - t0)
     g_fd = np.random.default_rng(seed + 2).normal(size=(h, w, 25)).astype(np.float32)
     g_fd[X | bad] = 0.0
     g = hip["gaussians"]
@@ -465,8 +485,10 @@ def assert_gut_full_parity_nht(stats):
     P, N, tiles = stats["P"], stats["N"], stats["A_tiles_total"]
     assert stats["A_depth_bits_differ"] == 0 and stats["A_tiles_same_set_other_order"] == 0, stats
     assert stats["A_particles_tile_count_differs"] <= max(2, 1e-4 * N) and stats["A_tiles_list_differs"] <= max(2, 2e-2 * tiles), stats
-    assert stats["B_flip_frac"] <= 2e-3, stats
-    assert stats["B_bad_outside_flips"] <= max(8, 2e-4 * P) and stats["B_max_err_outside_flips"] < 2e-2 and stats["B_max_dist_err_outside_flips"] < 5e-3, stats
+    assert stats["B_exempt_frac"] <= 2e-3, stats
+    assert stats["B_exempt_unidentified"] == 0, f"pixels beyond tolerance that no set of borderline decisions explains: {stats}"
+    assert stats["B_rounding_class_pixels"] <= max(8, 2e-4 * P), stats
+    assert stats["B_rounding_class_max_err"] < 2e-2 and stats["B_rounding_class_max_dist_err"] < 5e-3, stats
     assert stats["B_feature_abs_max"] > 0.3
     for k in list(GRAD_SLICES) + ["features"]:
         assert stats[f"C_grad_{k}_rel_err"] < 1e-3, (k, stats)
@@ -512,8 +534,10 @@ def assert_gut_full_parity(stats, max_flip_frac=2e-3, max_rounding_frac=2e-4):
         for k in list(GRAD_SLICES) + ["sph"]:
             assert stats[f"C_grad_{k}_rel_err"] < 1e-3, (k, stats)
             if f"E_grad_{k}_rel_err_unmasked" in stats:
-                # every flip moves its particle's gradient by about one hit's worth: a sanity bound, not a parity bar
-                assert stats[f"E_grad_{k}_rel_err_unmasked"] < 0.1, (k, stats)
+                # NOT masked: the whole frame against the oracle's own frame, threshold flips included - every flip moves its particle's
+                # gradient by about one hit's worth.  Measured <= 4.5e-3 (rotation, 1 M @ 1080p; profiles/rNN_full_parity.json keeps the
+                # per-round numbers); the fence is 1e-2, one decade above BASELINE's bar for identical hit sequences (stage C)
+                assert stats[f"E_grad_{k}_rel_err_unmasked"] < 1e-2, (k, stats)
         assert stats["C_grad_nonzero_particles"] > 0.05 * stats["A_particles_visible_oracle"]   # (the particles in front of the terminations)
 
 

@@ -52,10 +52,13 @@ def test_gut_non_default_configurations_meet_the_staged_method_at_baseline_size(
     mode's k-buffer order included: parity_util._composite), masked gradients to 1e-3 - instead of the trimmed error on 30 k-particle
     scenes these configurations had in round 3."""
     stats = pu.gut_full_parity(N, W, H, 0.01, log=print, device_pose=True, end_to_end=False, variant=VARIANTS[variant])
-    # sorted mode: besides accept / termination flips, pairs of hits whose fp32 hit distances tie to rounding pop in either order
-    # (identified like the other borderline decisions; ~0.3 % of the pixels of this frame hold such a pair among their ~130 hits)
-    # (and the value-only class is twice the unsorted frame's: 827 pixels, all below 4.1e-4 rgb / 1.8e-4 depth, profiles/r04_full_parity.json)
-    pu.assert_gut_full_parity(stats, max_flip_frac=6e-3 if variant == "k16" else 2e-3, max_rounding_frac=6e-4 if variant == "k16" else 2e-4)
+    # sorted mode: the k-buffer orders hits by their fp32 hit distance.  Until round 4 the kernels and the checker evaluated that distance
+    # in different operation orders, pairs of hits that tie to rounding popped in either order and 0.34 % of the frame needed an exemption
+    # of its own.  Now the kernels evaluate it in the checker's order (csrc/gut_render.hip: oracle_order_hit_t): same bits, same order, the
+    # DEFAULT limits - and nothing beyond 1e-2 outside the identified accept / termination flips.
+    pu.assert_gut_full_parity(stats)
+    if variant == "k16":
+        assert stats["B_max_rgb_err_outside_flips"] < 1e-2, stats
     pu.record_full_parity(f"c4_1m_1080p_{variant}", stats)
 
 

@@ -836,6 +836,53 @@ def test_nht_forward_matches_reference_kernels_golden(k):
     assert np.abs(full["feat_density"] - ref).max() < 2e-5
 
 
+def test_nht_pixel_trace_recomposites_the_frame_and_identifies_a_toggled_decision():
+    """The flip identification of the full-size NHT parity (parity_util.identify_flips with orc_gut_pixel_trace_nht): compositing a pixel's
+    trace reproduces orc_gut_render_nht_fwd's pixel; a pixel whose most borderline accepted hit is REMOVED from the target is identified by
+    exactly one toggle once the margin admits that hit, and is unidentifiable when it does not."""
+    from scenes import make_scene
+    import parity_util as pu
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gut_nht.npz"))
+    sc = make_scene(**mg.GUT_RENDER_SCENES[0])
+    feats = g["s0_features"]
+    cfg = oracle.default_gut_config()
+    fwd = oracle.gut_forward_nht(cfg, sc["cam"], sc["pose_start"], sc["pose_end"], sc["density12"], feats, *sc["rays"])
+    H, W = sc["H"], sc["W"]
+    rays = tuple(np.ascontiguousarray(np.asarray(r, np.float32).reshape(H, W, 3)) for r in sc["rays"])
+    tin = dict(poses=(sc["pose_start"], sc["pose_end"]), rays=rays, density12=sc["density12"], nht_features=feats,
+               bins=dict(sorted_idx=fwd["sorted_idx"], tile_ranges=fwd["tile_ranges"]))
+    trace = lambda pix, dt: oracle.gut_pixel_trace_nht(cfg, sc["cam"], tin, pix, dtype=dt)
+    fd, cnt, dist = fwd["feat_density"].copy(), fwd["hit_count"][..., 0].copy(), fwd["hit_distance"].copy()
+    pixels = np.flatnonzero(cnt.reshape(-1) > 3)[::37][:12]
+    assert len(pixels) >= 8
+    for pix in pixels:
+        tr = trace(pix, np.float32)
+        C_, opa, D, c, _ = pu._composite(tr["alpha"].astype(np.float64), tr["hit_t"].astype(np.float64), tr["colour"].astype(np.float64), tr["margin"] > 0,
+                                         float(cfg.min_transmittance))
+        assert c == int(cnt.reshape(-1)[pix])
+        assert np.abs(C_ - fd.reshape(-1, 25)[pix, :24]).max() < 2e-5 and abs(opa - fd.reshape(-1, 25)[pix, 24]) < 2e-5 and abs(D - dist.reshape(-1)[pix]) < 2e-5
+    toggles, rounding, _ = pu.identify_flips(cfg, sc["cam"], tin, None, pixels, fd, cnt, dist, trace_fn=trace)
+    assert (toggles == 0).all() and not rounding.any()
+    # remove each pixel's most borderline accepted hit from the TARGET
+    margins = []
+    for pix in pixels:
+        tr = trace(pix, np.float32)
+        acc = (tr["margin"] > 0) & (tr["alpha"] > 0)
+        j = np.flatnonzero(acc)[np.argmin(tr["margin"][acc])]
+        acc2 = tr["margin"] > 0
+        acc2[j] = False
+        C_, opa, D, c, _ = pu._composite(tr["alpha"].astype(np.float64), tr["hit_t"].astype(np.float64), tr["colour"].astype(np.float64), acc2,
+                                         float(cfg.min_transmittance))
+        fd.reshape(-1, 25)[pix, :24], fd.reshape(-1, 25)[pix, 24], dist.reshape(-1)[pix], cnt.reshape(-1)[pix] = C_, opa, D, c
+        margins.append(float(tr["margin"][j]))
+    wide, _, _ = pu.identify_flips(cfg, sc["cam"], tin, None, pixels, fd, cnt, dist, margin=max(margins) * 1.01, trace_fn=trace)
+    assert (wide >= 1).all() and (wide <= 2).all(), wide                     # (one toggle; a second only where the end of the ray moved with it)
+    narrow, _, _ = pu.identify_flips(cfg, sc["cam"], tin, None, pixels, fd, cnt, dist, margin=min(margins) * 0.5, trace_fn=trace)
+    assert (narrow == -1).all(), narrow
+
+
 @pytest.mark.parametrize("name", ["nht", "nht_depth"])
 def test_nht_backward_matches_autograd_of_the_restated_reference_forward(name):
     """The nht backward is Slang autodiff output in the reference (not in the checkout): the oracle's reverse mode against float64
