@@ -690,6 +690,11 @@ template <int J>
 __device__ __forceinline__ float quad_bcast(float v) {  // value of lane J of the caller's quad
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false));
 }
+template <int X>
+__device__ __forceinline__ float quad_bcast_xor(float v) {  // value of lane (own ^ X) of the caller's quad, X = 1 or 2
+    constexpr int perm = X == 1 ? (1 | (0 << 2) | (3 << 4) | (2 << 6)) : (2 | (3 << 2) | (0 << 4) | (1 << 6));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), perm, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float xor_sum_quads(float v) {  // sum over the 16 quads of a wave, same column: lanes c, c+4, ...
     v += __shfl_xor(v, 4, 64);
     v += __shfl_xor(v, 8, 64);
@@ -700,10 +705,18 @@ __device__ __forceinline__ float xor_sum_quads(float v) {  // sum over the 16 qu
 
 // NHT (neural harmonic features, gut_render_nht.inl): slot words 13..15 carry the direct hit-distance scale terms instead of a radiance
 // gradient, and nothing is handed on to the SH backward.
-template <int STRIDE, bool NHT = false>
+// FUSE_SH (round 5; fp32 rows of 48 coefficients, the expanded - not factored - SH gradient): the projection backward runs in the same
+// kernel.  The quad that gathered a particle splits its 16 SH coefficients four ways: lane c owns coefficients 4c .. 4c+3 = floats
+// [12 c, 12 c + 12) of the row, which are three consecutive 16-byte words - so the wave's 16 rows are read and their gradient rows written
+// as 3 float4 per lane at float4 index 3 lane + {0, 1, 2}, straight from / to global memory (no LDS transpose), requested at the top of the
+// kernel so that their round trip lies under the flag -> row chain.  Rows of particles without tiles are not read (a third of them) and
+// their gradient rows are written as zeros.  Saves a launch, the g_rgb round trip, the second read of the particle rows and the
+// read-modify-write of the position gradient.
+template <int STRIDE, bool NHT = false, bool FUSE_SH = false>
 __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutProjected proj, const float4* __restrict__ density12,
                                                               GutGradSlots slots, int have_partials, GutGradOut g_out,
-                                                              float* __restrict__ g_rgb, uint32_t first, uint32_t end) {
+                                                              float* __restrict__ g_rgb, uint32_t first, uint32_t end,
+                                                              const float* __restrict__ sph = nullptr, float* __restrict__ g_sph = nullptr) {
     // particles [first, end): the whole scene, or one chunk of the pipelined gradient exchange (gut_backward_factored_chunked)
     const int lane = threadIdx.x & 63, c = threadIdx.x & 3;
     const uint32_t i = first + blockIdx.x * 64u + (threadIdx.x >> 2);
@@ -716,6 +729,14 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     // flag -> row chain below instead of following it
     float4 q = make_float4(1.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 0.f);
     if (has) { q = density12[3 * (size_t)i + 1]; sc = density12[3 * (size_t)i + 2]; }
+    float4 sh0 = make_float4(0.f, 0.f, 0.f, 0.f), sh1 = sh0, sh2 = sh0, pa = sh0;
+    f3 rad = mk3(0.f, 0.f, 0.f);
+    if (FUSE_SH && has) {
+        const float4* row = reinterpret_cast<const float4*>(sph + 48 * (size_t)i) + 3 * c;
+        sh0 = row[0]; sh1 = row[1]; sh2 = row[2];
+        pa = density12[3 * (size_t)i];
+        rad = mk3(proj.rgb[3 * (size_t)i], proj.rgb[3 * (size_t)i + 1], proj.rgb[3 * (size_t)i + 2]);
+    }
     if (have_partials) {
         if (has && count <= kGatherSmall) {
             // Set flags are rare (most tile entries lie behind the rays' termination) and every load here is a dependent
@@ -790,6 +811,10 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     r[16] = quad_bcast<0>(acc.x.x); r[17] = quad_bcast<0>(acc.x.y); r[18] = quad_bcast<0>(acc.x.z); r[19] = 0.f;
     if (i >= end) return;
     float4* gd = reinterpret_cast<float4*>(g_out.packed + 12 * (size_t)i);
+    if (FUSE_SH && !has) {
+        float4* out = reinterpret_cast<float4*>(g_sph + 48 * (size_t)i) + 3 * c;
+        out[0] = out[1] = out[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (!has) {
         if (g_out.packed) {
             if (c < 3) gd[c] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -816,6 +841,70 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     if (STRIDE > 16) { gsx += r[16]; gsy += r[17]; gsz += r[18]; }
     if (NHT) { gsx += r[13]; gsy += r[14]; gsz += r[15]; }
     const float4 dq = quat_contract(m, make_float4(2.f * q.x, 2.f * q.y, 2.f * q.z, 2.f * q.w));
+    f3 gpos_out = gpos;
+    if (FUSE_SH) {   // GUTProjector::evalBackward (gutProjector.cuh:390-430): dRGB -> dSH through the clamp, d direction -> d position
+        const FramePoses& FP = frame_poses(P);
+        const int nact = min((P.n_active + 1) * (P.n_active + 1), P.ncoef);
+        const f3 v = mk3(pa.x, pa.y, pa.z) - mk3(FP.s2w_t[0], FP.s2w_t[1], FP.s2w_t[2]);
+        const float ilen = 1.f / sqrtf(dot(v, v));
+        const f3 dir = v * ilen;
+        f3 g = mk3(r[13], r[14], r[15]);
+        if (!(rad.x > 0.f)) g.x = 0.f;     // clamp mask on the unclamped radiance stored by the forward projection
+        if (!(rad.y > 0.f)) g.y = 0.f;
+        if (!(rad.z > 0.f)) g.z = 0.f;
+        const float rowv[12] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w, sh2.x, sh2.y, sh2.z, sh2.w};
+        float o[12];
+        f3 gdir = mk3(0.f, 0.f, 0.f);
+        // the lane's four coefficients k = 4 c + j: one branch per c with static indices (a select over c is turned into a dynamically
+        // indexed array by the compiler - 208 B of scratch); each branch keeps only its own four basis functions alive
+        auto part = [&](auto group) {
+            constexpr int G = decltype(group)::value;
+            float basis[16];
+            f3 dbasis[16];
+            sh_basis(P.n_active, dir, basis);
+            sh_basis_grad(P.n_active, dir, dbasis);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool on = 4 * G + j < nact;
+                const float sk = on ? g.x * rowv[3 * j] + g.y * rowv[3 * j + 1] + g.z * rowv[3 * j + 2] : 0.f;
+                gdir = gdir + dbasis[4 * G + j] * sk;
+                const float bk = on ? basis[4 * G + j] : 0.f;
+                o[3 * j] = bk * g.x; o[3 * j + 1] = bk * g.y; o[3 * j + 2] = bk * g.z;
+            }
+        };
+        switch (c) {
+        case 0: part(std::integral_constant<int, 0>{}); break;
+        case 1: part(std::integral_constant<int, 1>{}); break;
+        case 2: part(std::integral_constant<int, 2>{}); break;
+        default: part(std::integral_constant<int, 3>{}); break;
+        }
+        // sum of the four lanes' parts (quad butterflies)
+        gdir.x += quad_bcast_xor<1>(gdir.x); gdir.y += quad_bcast_xor<1>(gdir.y); gdir.z += quad_bcast_xor<1>(gdir.z);
+        gdir.x += quad_bcast_xor<2>(gdir.x); gdir.y += quad_bcast_xor<2>(gdir.y); gdir.z += quad_bcast_xor<2>(gdir.z);
+        const float ng = dot(dir, gdir);
+        const f3 gsh = (gdir - dir * ng) * ilen;
+        gpos_out = mk3(add_rn(gpos.x, gsh.x), add_rn(gpos.y, gsh.y), add_rn(gpos.z, gsh.z));
+        float4* out = reinterpret_cast<float4*>(g_sph + 48 * (size_t)i) + 3 * c;
+        out[0] = make_float4(o[0], o[1], o[2], o[3]);
+        out[1] = make_float4(o[4], o[5], o[6], o[7]);
+        out[2] = make_float4(o[8], o[9], o[10], o[11]);
+    }
+    if (FUSE_SH) {
+        if (c == 0) {
+            if (g_out.packed) gd[0] = make_float4(gpos_out.x, gpos_out.y, gpos_out.z, r[3]);
+            else {
+                g_out.pos[3 * (size_t)i] = gpos_out.x; g_out.pos[3 * (size_t)i + 1] = gpos_out.y; g_out.pos[3 * (size_t)i + 2] = gpos_out.z;
+                g_out.dns[i] = r[3];
+            }
+        } else if (c == 1) {
+            if (g_out.packed) gd[1] = dq;
+            else reinterpret_cast<float4*>(g_out.rot)[i] = dq;
+        } else if (c == 2) {
+            if (g_out.packed) gd[2] = make_float4(gsx, gsy, gsz, 0.f);
+            else { g_out.scl[3 * (size_t)i] = gsx; g_out.scl[3 * (size_t)i + 1] = gsy; g_out.scl[3 * (size_t)i + 2] = gsz; }
+        }
+        return;
+    }
     if (c == 0) {
         if (g_out.packed) gd[0] = make_float4(gpos.x, gpos.y, gpos.z, r[3]);
         else {
@@ -1098,6 +1187,16 @@ void launch_grad_finalize(hipStream_t s, const GutParams& P, const GutProjected&
     if (end > P.N) end = P.N;
     if (end <= first) return;
     const dim3 grid(div_up(end - first, 64)), block(256);  // four lanes per particle
+    static const bool unfused = [] { const char* e = getenv("GRUT_GUT_UNFUSED_FINALIZE"); return e && e[0] == '1'; }();   // (A/B measurements)
+    if (!unfused && !g_radiance && g_sph && P.ncoef == 16 && !P.sph_half) {   // one kernel: gather + projection backward
+        if (has_gdist)
+            hipLaunchKernelGGL((gut_grad_gather_kernel<20, false, true>), grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
+                               have_partials ? 1 : 0, g_out, g_rgb, first, end, sph, g_sph);
+        else
+            hipLaunchKernelGGL((gut_grad_gather_kernel<16, false, true>), grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
+                               have_partials ? 1 : 0, g_out, g_rgb, first, end, sph, g_sph);
+        return;
+    }
     if (has_gdist)
         hipLaunchKernelGGL(gut_grad_gather_kernel<20>, grid, block, 0, s, P, proj, reinterpret_cast<const float4*>(density12), slots,
                            have_partials ? 1 : 0, g_out, g_rgb, first, end);

@@ -1075,7 +1075,7 @@ __device__ __forceinline__ float response_grd_rt(int deg, float g, float gres, f
 }
 
 // Sorted mode: the k-buffer ORDERS a ray's hits by their fp32 hit distance, so two implementations agree on the order only if they agree on
-// the distance's bits.  The hit distance of an accepted hit is therefore evaluated in the CHECKER's operation order (oracle/gut_oracle.c
+// the distance's bits.  The hit distance of an accepted hit is therefore evaluated in the CHECKER's operation order (the checker's gut_oracle.c:
 // density_hit_ex, itself the source order of gaussianParticles.slang:96-110, 181-190): every product and sum rounded on its own, correctly
 // rounded 1/x and sqrt - ~70 instructions per ACCEPTED hit on top of the accept test, which keeps the fast pre-transformed form (its flips
 // are identified per pixel by the parity tests; an order tie could not be).  rt* = rows of R^T from the quaternion, gis = 1 / scale.

@@ -328,6 +328,162 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// One-sweep passes (round 5): ONE kernel per digit instead of three.  The digit totals of ALL passes come from one read of the keys
+// (radix_global_hist_kernel); a pass's workgroups then take their tiles in ticket order, rank them as above, publish the tile's digit
+// counts and obtain the counts of the tiles in front of them by a decoupled look-back over per-(tile, digit) status words
+// (flag in the top two bits: 1 = this tile's count, 2 = count of this tile and every tile before it).  A tile publishes its own count
+// BEFORE it looks back, and tiles are handed out by an atomic ticket, so every tile a workgroup waits for is resident and never waits
+// for anything itself: no dependence on dispatch order.  The status words carry their own payload (relaxed agent-scope atomics; the
+// eight XCDs' L2s are not coherent with each other, so plain loads could spin on a stale line).
+// Per pass this removes the histogram kernel (a second read of the keys), the row scan and two dependent launches.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kFlagAgg = 1u << 30, kFlagPrefix = 2u << 30, kCountMask = (1u << 30) - 1u;
+constexpr int kMaxPasses = 4;
+
+__global__ __launch_bounds__(kSortThreads) void radix_global_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev,
+                                                                         int begin_bit, int width, int passes, int end_bit,
+                                                                         uint32_t* __restrict__ hist /* [kMaxPasses][kRadix], zeroed */) {
+    __shared__ uint32_t s_hist[kMaxPasses][kRadix];
+    const uint32_t ne = eff_count(n, n_dev);
+    for (int p = 0; p < kMaxPasses; ++p) s_hist[p][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kSortThreads * 4;
+    for (uint32_t i = (blockIdx.x * kSortThreads + threadIdx.x) * 4; i < ne; i += stride) {
+        uint32_t k[4];
+        if (i + 4 <= ne) {
+            const uint4 v = *reinterpret_cast<const uint4*>(keys + i);
+            k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+        } else {
+            for (int j = 0; j < 4; ++j) k[j] = i + j < ne ? keys[i + j] : 0xFFFFFFFFu;
+        }
+        const int cnt = (int)min(4u, ne - i);
+        for (int j = 0; j < cnt; ++j)
+            for (int p = 0; p < passes; ++p) {
+                const int bit = begin_bit + p * width;
+                const int nbits = (end_bit - bit) < width ? (end_bit - bit) : width;
+                atomicAdd(&s_hist[p][(k[j] >> bit) & ((1u << nbits) - 1u)], 1u);
+            }
+    }
+    __syncthreads();
+    for (int p = 0; p < passes; ++p) {
+        const uint32_t c = s_hist[p][threadIdx.x];
+        if (c) atomicAdd(&hist[p * kRadix + threadIdx.x], c);
+    }
+}
+
+template <int kSortRounds>
+__global__ __launch_bounds__(kSortThreads) void radix_onesweep_kernel(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint32_t n,
+                                                                      const uint32_t* __restrict__ n_dev, int shift, uint32_t mask,
+                                                                      const uint32_t* __restrict__ digit_totals /* [kRadix] of this pass */,
+                                                                      uint32_t* __restrict__ status /* [tiles][kRadix], zeroed */, uint32_t* __restrict__ ticket,
+                                                                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    constexpr int kSortTile = kSortThreads * kSortRounds, kSortWaveKeys = 64 * kSortRounds;
+    __shared__ uint32_t s_cnt[4][kRadix];
+    __shared__ uint32_t s_tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t ne = eff_count(n, n_dev);
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * kSortTile;
+    if (base >= ne) return;
+
+    uint32_t key[kSortRounds], val[kSortRounds], rank[kSortRounds];
+    const uint32_t wbase = base + wave * kSortWaveKeys;
+    volatile uint32_t* cnt = s_cnt[wave];
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        const bool valid = i < ne;
+        key[r] = valid ? keys_in[i] : 0xFFFFFFFFu;
+        val[r] = valid ? (vals_in ? vals_in[i] : i) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        const bool valid = i < ne;
+        const uint32_t d = (key[r] >> shift) & mask;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t count  = (uint32_t)__popcll(m);
+        uint32_t old = 0;
+        if (valid) old = cnt[d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) cnt[d] = old + count;
+        __builtin_amdgcn_wave_barrier();
+        rank[r] = old + before;
+    }
+    __syncthreads();
+    __shared__ uint32_t s_keys[kSortTile], s_vals[kSortTile];
+    __shared__ uint32_t s_dstart[kRadix];
+    __shared__ uint32_t s_gdelta[kRadix];
+    __shared__ uint32_t s_wave_tot[4];
+    {
+        const uint32_t d = threadIdx.x;
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint32_t c = s_cnt[w][d];
+            s_cnt[w][d] = run;
+            run += c;
+        }
+        // publish this tile's count of digit d, then collect the counts of the tiles in front
+        uint32_t before_tiles = 0;
+        if (d <= mask) {
+            uint32_t* mine = status + (size_t)tile * kRadix + d;
+            __hip_atomic_store(mine, (tile == 0 ? kFlagPrefix : kFlagAgg) | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tile > 0) {
+                uint32_t t = tile - 1;
+                while (true) {
+                    const uint32_t w = __hip_atomic_load(status + (size_t)t * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((w >> 30) == 0u) { __builtin_amdgcn_s_sleep(1); continue; }
+                    before_tiles += w & kCountMask;
+                    if (w & kFlagPrefix) break;
+                    --t;   // (tile 0 publishes a prefix: the walk ends there at the latest)
+                }
+                __hip_atomic_store(mine, kFlagPrefix | (before_tiles + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        uint32_t total;
+        const uint32_t excl = block_excl_scan_256(run, &total, s_wave_tot);
+        const uint32_t digit_base = block_excl_scan_256(digit_totals[d], &total, s_wave_tot);  // keys with a smaller digit, all tiles
+        s_dstart[d] = excl;
+        s_gdelta[d] = digit_base + before_tiles - excl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t i = wbase + r * 64 + lane;
+        if (i < ne) {
+            const uint32_t d = (key[r] >> shift) & mask;
+            const uint32_t pos = s_dstart[d] + s_cnt[wave][d] + rank[r];
+            s_keys[pos] = key[r];
+            s_vals[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t nvalid = min((uint32_t)kSortTile, ne - base);
+#pragma unroll
+    for (int r = 0; r < kSortRounds; ++r) {
+        const uint32_t idx = r * kSortThreads + threadIdx.x;
+        if (idx < nvalid) {
+            const uint32_t k = s_keys[idx];
+            const uint32_t dst = s_gdelta[(k >> shift) & mask] + idx;
+            keys_out[dst] = k;
+            vals_out[dst] = s_vals[idx];
+        }
+    }
+}
+
 }  // namespace
 
 size_t scan_scratch_bytes(uint32_t n) { return (size_t)(div_up(n, kScanTile) + 1) * sizeof(uint32_t); }
@@ -337,10 +493,19 @@ int inclusive_scan_u32(hipStream_t s, uint32_t n, const uint32_t* in, const uint
     return scan_impl(s, n, in, gather, out, false, scratch, scratch_bytes);
 }
 
+// one-sweep layout of the scratch: [kMaxPasses][kRadix] digit totals | kMaxPasses tickets (+ padding to 64 words) | [passes][tiles][kRadix] status words
+constexpr size_t kOnesweepHead = (size_t)kMaxPasses * kRadix + 64;
 size_t sort_scratch_bytes(uint32_t n) {
     const uint32_t nb = div_up(n, (uint32_t)(kSortThreads * kSortRoundsSmall));   // (the smaller tile: an upper bound for either layout)
     const size_t hist = (size_t)kRadix * nb * sizeof(uint32_t);
-    return hist + kRadix * sizeof(uint32_t) + 256;  // per-block digit counts + digit totals
+    const size_t legacy = hist + kRadix * sizeof(uint32_t) + 256;  // per-block digit counts + digit totals
+    const size_t onesweep = (kOnesweepHead + (size_t)kMaxPasses * nb * kRadix) * sizeof(uint32_t);
+    return legacy > onesweep ? legacy : onesweep;
+}
+
+static bool sort_legacy() {   // GRUT_SORT_LEGACY=1: the three-kernel passes (A/B measurements)
+    static const bool v = [] { const char* e = getenv("GRUT_SORT_LEGACY"); return e && e[0] == '1'; }();
+    return v;
 }
 
 int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_bit, int end_bit,
@@ -355,6 +520,33 @@ int sort_pairs_u32(hipStream_t s, uint32_t n, const uint32_t* n_dev, int begin_b
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch);
     uint32_t* totals = hist + (size_t)kRadix * nb;
     uint32_t *ki = keys, *vi = vals, *ko = keys_tmp, *vo = vals_tmp;
+    {
+        const int total_bits = end_bit - begin_bit, passes = (total_bits + 7) / 8, width = (total_bits + passes - 1) / passes;
+        if (!sort_legacy() && passes <= kMaxPasses) {
+            uint32_t* head = reinterpret_cast<uint32_t*>(scratch);
+            uint32_t* tickets = head + (size_t)kMaxPasses * kRadix;
+            uint32_t* status = head + kOnesweepHead;
+            GRUT_HIP(hipMemsetAsync(head, 0, (kOnesweepHead + (size_t)passes * nb * kRadix) * sizeof(uint32_t), s));
+            const uint32_t hist_blocks = nb < 1024u ? nb : 1024u;
+            hipLaunchKernelGGL(radix_global_hist_kernel, dim3(hist_blocks), dim3(kSortThreads), 0, s, ki, n, n_dev, begin_bit, width, passes, end_bit, head);
+            int p = 0;
+            for (int bit = begin_bit; bit < end_bit; bit += width, ++p) {
+                const int nbits = (end_bit - bit) < width ? (end_bit - bit) : width;
+                const uint32_t mask = (1u << nbits) - 1u;
+                const uint32_t* vin = (vals_iota && bit == begin_bit) ? nullptr : vi;
+                uint32_t* st = status + (size_t)p * nb * kRadix;
+                if (small) hipLaunchKernelGGL(radix_onesweep_kernel<kSortRoundsSmall>, dim3(nb), dim3(kSortThreads), 0, s, ki, vin, n, n_dev, bit, mask, head + p * kRadix, st, tickets + p, ko, vo);
+                else hipLaunchKernelGGL(radix_onesweep_kernel<kSortRoundsLarge>, dim3(nb), dim3(kSortThreads), 0, s, ki, vin, n, n_dev, bit, mask, head + p * kRadix, st, tickets + p, ko, vo);
+                uint32_t* t;
+                t = ki; ki = ko; ko = t;
+                t = vi; vi = vo; vo = t;
+            }
+            GRUT_HIP(hipGetLastError());
+            *out_keys = ki;
+            *out_vals = vi;
+            return GRUT_OK;
+        }
+    }
     // digits of equal width: 13 tile bits are sorted as 7 + 6, not 8 + 5 — the row scan works on 128 + 64 rows instead of 256 + 256
     const int total_bits = end_bit - begin_bit, passes = (total_bits + 7) / 8, width = (total_bits + passes - 1) / passes;
     for (int bit = begin_bit; bit < end_bit; bit += width) {

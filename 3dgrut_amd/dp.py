@@ -105,9 +105,31 @@ class FactoredGradientExchange:
         # kernels of range i + 1 (reduce_packed_pipelined); 1: one exchange after the whole backward (reduce_packed)
         self.chunks = int(chunks)
         self.timer = _ExchangeTimer() if timed else None
-        # called with this view's packed gradient [N,12] (columns 0..2 = dL/d position) BEFORE it is reduced: the place to take
-        # the densification statistics, which must come from the local view (local_densify_stats)
+        # local_gradient_hook(rows, first): this view's packed gradient rows [n,12] (columns 0..2 = dL/d position) of the particles
+        # [first, first + n) BEFORE they are reduced - the place to take the densification statistics, which must come from the local
+        # view (local_densify_stats).  ONE signature on every path: the unchunked exchanges call it once with (all N rows, 0), the
+        # pipelined one once per particle range.  A hook that takes a single argument is still accepted (it is then called with the
+        # rows only - fine for statistics that do not need the particle index).
         self.local_gradient_hook = local_gradient_hook
+        if self.chunks > 1 and type(self) is not FactoredGradientExchange and not getattr(type(self), "PIPELINED", False):
+            raise ValueError(f"{type(self).__name__} has no pipelined form: chunks must be 1 (the base FactoredGradientExchange pipelines)")
+
+    def _call_hook(self, rows, first=0):
+        hook = self.local_gradient_hook
+        if hook is None:
+            return
+        if getattr(self, "_hook_arity", None) is None:
+            import inspect
+            try:
+                params = [p for p in inspect.signature(hook).parameters.values()
+                          if p.kind in (p.POSITIONAL_ONLY, p.POSITIONAL_OR_KEYWORD, p.VAR_POSITIONAL)]
+                self._hook_arity = 2 if (len(params) >= 2 or any(p.kind == p.VAR_POSITIONAL for p in params)) else 1
+            except (TypeError, ValueError):
+                self._hook_arity = 2
+        if self._hook_arity == 2:
+            hook(rows, first)
+        else:
+            hook(rows)
 
     def _world(self):
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -119,8 +141,7 @@ class FactoredGradientExchange:
         from . import _abi
         world = self._world()
         scale = 1.0 / world if self.average else 1.0
-        if self.local_gradient_hook is not None:
-            self.local_gradient_hook(g_density)
+        self._call_hook(g_density, 0)
         if world == 1:
             return g_density, _abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active_features, sph_degree, 1.0)
         if self.timer:
@@ -176,8 +197,7 @@ class FactoredGradientExchange:
 
         def on_chunk(chunk, first, count, g_density, g_radiance):
             rows_d, rows_r = g_density[first:first + count], g_radiance[first:first + count]
-            if self.local_gradient_hook is not None:
-                self.local_gradient_hook(rows_d, first)   # (rows of the range, index of its first particle)
+            self._call_hook(rows_d, first)   # (rows of the range, index of its first particle)
             if world > 1:
                 if self.timer and not pending:
                     self.timer.begin(g_density.device)
@@ -206,8 +226,7 @@ class FactoredGradientExchange:
         features: the [N,48] feature-row gradient is a sum over hits of hit-dependent weights, gut_tracer._NhtAutograd).  The packed
         gradient goes first (the local hook sees it before the reduction).  Returns the tensors."""
         world = self._world()
-        if self.local_gradient_hook is not None:
-            self.local_gradient_hook(g_density)
+        self._call_hook(g_density, 0)
         tensors = [g_density, *others]
         if world == 1:
             return tensors
@@ -360,8 +379,7 @@ class ShardedGradientExchange(FactoredGradientExchange):
     def reduce_packed(self, g_density, g_radiance, positions, n_active_features, sph_degree):
         from . import _abi
         world = self._world()
-        if self.local_gradient_hook is not None:
-            self.local_gradient_hook(g_density)
+        self._call_hook(g_density, 0)
         if world == 1:
             return g_density, _abi.sph_grad_from_views(g_radiance.unsqueeze(0), positions, n_active_features, sph_degree, 1.0)
         n = g_density.shape[0]
@@ -372,6 +390,98 @@ class ShardedGradientExchange(FactoredGradientExchange):
         if self.timer:
             self.timer.end(self._payload + both.shape[1] * 4 * ((n + world - 1) // world))
         return both[:, :12].contiguous(), both[:, 12:].contiguous()
+
+
+class HalfFactorsExchange(FactoredGradientExchange):
+    """The factored exchange with the view factors on the links as IEEE half (6 B instead of 12 B per particle and view; at 8 ranks
+    2*(7/8)*48 + (7/8)*8*6 = 126 B per particle instead of 168).  A view's radiance gradients are far below half's range (~1e-7 on a
+    2 M-pixel frame), so each view scales its factors by the power of two that brings its largest magnitude to 2^14 and the exponent
+    rides in the sensor row; every rank - the sender included - rebuilds the SH gradient from the ROUNDED factors, so replicas stay
+    bitwise identical.  Costs 11 bits of the radiance gradient (<= 4.9e-4 of a view's largest factor): opt-in
+    (GRUT_BENCH_EXCHANGE=half), not the default."""
+
+    @torch.no_grad()
+    def exchange(self, g_density, g_radiance):
+        world = self._world()
+        nccl = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if (self.average and nccl) else dist.ReduceOp.SUM
+        w_geo = dist.all_reduce(g_density, op=op, group=self.group, async_op=True)
+        n = g_radiance.shape[0] - 1
+        peak = g_radiance[:n].abs().max().clamp_min(1e-38)
+        expo = torch.floor(torch.log2(peak))                    # largest magnitude in [2^e, 2^(e+1))
+        scale = torch.exp2(14.0 - expo)                         # -> [2^14, 2^15): inside half's range, no overflow
+        halves = (g_radiance[:n] * scale).to(torch.float16)
+        head = torch.cat([g_radiance[n], scale.reshape(1)])     # sensor position + the scale, fp32
+        heads = _all_gather_rows(head.contiguous(), self.group, nccl)                        # [world, 4]
+        if nccl:
+            gathered = _all_gather_rows(halves, self.group, True)                            # [world, n, 3] half
+        else:   # gloo reduces neither half nor int16: the bit patterns travel widened to int32 (one non-zero contribution per element: the sum is a copy)
+            gathered = _all_gather_rows(halves.view(torch.int16).to(torch.int32), self.group, False).to(torch.int16).view(torch.float16)
+        w_geo.wait()
+        if self.average and not nccl:
+            g_density.div_(float(world))
+        factors = torch.empty((world, n + 1, 3), dtype=torch.float32, device=g_radiance.device)
+        factors[:, :n] = gathered.float() / heads[:, 3].reshape(world, 1, 1)
+        factors[:, n] = heads[:, :3]
+        return g_density, factors, g_density.numel() * 4 + halves.numel() * 2 + 16
+
+
+def _p2p_exchange(sends, recvs, group):
+    """One batch of point-to-point transfers: sends / recvs = [(tensor, peer)].  Over RCCL the batch is one group call whose transfers
+    run concurrently on the direct xGMI links between the pairs; over gloo (CPU tests) the same calls complete one after the other."""
+    ops = [dist.P2POp(dist.isend, t, peer, group=group) for t, peer in sends] + [dist.P2POp(dist.irecv, t, peer, group=group) for t, peer in recvs]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+class AllLinksExchange(FactoredGradientExchange):
+    """The factored exchange as DIRECT transfers between every pair of ranks instead of ring collectives (GRUT_BENCH_EXCHANGE=alllinks).
+    An MI355X node is a full mesh: 7 xGMI links per GPU, one to each peer.  A ring all-reduce / all-gather keeps one link per direction
+    busy and forwards everything world - 1 times; here
+      * packed gradient [N,12]: rank r owns the rows [r S, (r+1) S).  Every rank sends slice j of its local gradient straight to rank
+        j (7 transfers on 7 links at once), the owner adds the views IN RANK ORDER (its own included: every owner, hence every replica,
+        produces the same bits), scales, and sends its reduced slice straight to every peer;
+      * view factors [N+1,3]: every rank sends its factors straight to every peer.
+    Bytes per rank are those of the ring forms - 2*(7/8)*48 + 7*12 B per particle sent - but spread over 7 links, so the exposed time
+    is the ring's divided by up to 7 (bench.py: exchange.predicted.all_links_ms next to .one_ring_ms).  Values: the same sums as the
+    ring forms up to the order of the additions; replicas bitwise identical."""
+
+    @torch.no_grad()
+    def exchange(self, g_density, g_radiance):
+        world = self._world()
+        rank = dist.get_rank(self.group)
+        n, cols = g_density.shape
+        s = (n + world - 1) // world
+        lo = [min(n, r * s) for r in range(world)]
+        hi = [min(n, (r + 1) * s) for r in range(world)]
+        peers = [r for r in range(world) if r != rank]
+        mine = hi[rank] - lo[rank]
+        # (1) slices to their owners + factors to everyone, one batch
+        inbox = {r: torch.empty((mine, cols), dtype=g_density.dtype, device=g_density.device) for r in peers}
+        factors = torch.empty((world,) + tuple(g_radiance.shape), dtype=g_radiance.dtype, device=g_radiance.device)
+        factors[rank].copy_(g_radiance)
+        fac_src = g_radiance.contiguous()
+        sends = [(g_density[lo[r]:hi[r]].contiguous(), r) for r in peers if hi[r] > lo[r]] + [(fac_src, r) for r in peers]
+        recvs = [(inbox[r], r) for r in peers if mine > 0] + [(factors[r], r) for r in peers]
+        _p2p_exchange(sends, recvs, self.group)
+        # (2) the owner's sum, views in rank order
+        if mine > 0:
+            total = None
+            for r in range(world):
+                part = g_density[lo[rank]:hi[rank]] if r == rank else inbox[r]
+                total = part.clone() if total is None else total.add_(part)
+            if self.average:
+                total.div_(float(world))
+            g_density[lo[rank]:hi[rank]].copy_(total)
+        # (3) reduced slices to everyone
+        outs = {r: torch.empty((hi[r] - lo[r], cols), dtype=g_density.dtype, device=g_density.device) for r in peers if hi[r] > lo[r]}
+        own = g_density[lo[rank]:hi[rank]].contiguous()
+        _p2p_exchange([(own, r) for r in peers if mine > 0], [(outs[r], r) for r in outs], self.group)
+        for r, t in outs.items():
+            g_density[lo[r]:hi[r]].copy_(t)
+        sent = sum((hi[r] - lo[r]) * cols * 4 for r in peers) + len(peers) * (g_radiance.numel() * 4 + mine * cols * 4)
+        return g_density, factors, sent
 
 
 @torch.no_grad()

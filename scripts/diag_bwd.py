@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.inse
 import torch, oracle
 from scenes import make_scene, rel_err
 import test_gut_gpu as T
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 jitter = float(sys.argv[1]) if len(sys.argv) > 1 else 0.02
 scene = make_scene(n=3000, width=80, height=48, median_scale=0.06)
 ro, rd = scene["rays"]

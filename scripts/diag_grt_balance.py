@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ["GRUT_GRT_COUNT"] = "1"
 import torch
 from scenes import torch_batch
-syn = importlib.import_module("3dgrut_amd.synthetic"); grt = importlib.import_module("3dgrut_amd.grt_tracer"); abi = importlib.import_module("3dgrut_amd._abi")
+syn = importlib.import_module("workloads.synthetic"); grt = importlib.import_module("3dgrut_amd.grt_tracer"); abi = importlib.import_module("3dgrut_amd._abi")
 n, W, H = 1_000_000, 800, 800
 d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=0.01)
 K = syn.pinhole_intrinsics(W, H); ro, rd = syn.pinhole_rays(W, H, K)

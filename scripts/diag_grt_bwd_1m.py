@@ -7,7 +7,7 @@ import torch
 import oracle
 import parity_util as pu
 from scenes import rel_err, torch_batch
-syn = importlib.import_module("3dgrut_amd.synthetic"); grt = importlib.import_module("3dgrut_amd.grt_tracer")
+syn = importlib.import_module("workloads.synthetic"); grt = importlib.import_module("3dgrut_amd.grt_tracer")
 n, w, h, ms = 1_000_000, 800, 800, 0.01
 stride = int(sys.argv[1]) if len(sys.argv) > 1 else 149
 inp = pu.make_frame_inputs(n, w, h, ms)

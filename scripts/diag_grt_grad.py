@@ -14,7 +14,7 @@ import parity_util as pu  # noqa: E402
 from scenes import torch_batch  # noqa: E402
 import torch  # noqa: E402
 
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 grt = importlib.import_module("3dgrut_amd.grt_tracer")
 n, w, h, cap = 100_000, 400, 400, 192
 inp = pu.make_frame_inputs(n, w, h, 0.01)

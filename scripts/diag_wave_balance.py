@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from scenes import torch_batch
-syn = importlib.import_module("3dgrut_amd.synthetic"); gt = importlib.import_module("3dgrut_amd.gut_tracer"); abi = importlib.import_module("3dgrut_amd._abi")
+syn = importlib.import_module("workloads.synthetic"); gt = importlib.import_module("3dgrut_amd.gut_tracer"); abi = importlib.import_module("3dgrut_amd._abi")
 n, W, H = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (1_000_000, 1920, 1080)
 d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=0.01)
 K = syn.pinhole_intrinsics(W, H); ro, rd = syn.pinhole_rays(W, H, K)

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from scenes import torch_batch  # noqa: E402
 
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 gt = importlib.import_module("3dgrut_amd.gut_tracer")
 
 n, W, H = 1_000_000, 1920, 1080

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 camera = importlib.import_module("3dgrut_amd.camera")
 n, W, H = (int(a) for a in (sys.argv[1:4] + ["1000000", "1920", "1080"][len(sys.argv) - 1:]))
 F = np.float32

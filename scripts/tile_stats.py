@@ -3,7 +3,7 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..")); sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 import torch
 from scenes import torch_batch
-syn = importlib.import_module("3dgrut_amd.synthetic"); gt = importlib.import_module("3dgrut_amd.gut_tracer")
+syn = importlib.import_module("workloads.synthetic"); gt = importlib.import_module("3dgrut_amd.gut_tracer")
 n, W, H = 1_000_000, 1920, 1080
 d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=0.01)
 K = syn.pinhole_intrinsics(W, H); ro, rd = syn.pinhole_rays(W, H, K)

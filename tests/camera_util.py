@@ -5,7 +5,7 @@ import numpy as np
 
 import oracle
 
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 camera = importlib.import_module("3dgrut_amd.camera")
 
 

@@ -17,7 +17,7 @@ script closes the loop at full size, where the reference code can afford it:
       distances, gradient rows of the touched particles.
 
 tests/test_full_size_gpu.py compares the HIP frames with these files directly ("HIP = reference code" on the sample; "HIP = oracle" on
-every pixel is the staged parity of the same file).  Inputs are regenerated from seeds by 3dgrut_amd.synthetic; nothing but the sample is stored.
+every pixel is the staged parity of the same file).  Inputs are regenerated from seeds by workloads.synthetic; nothing but the sample is stored.
 """
 import ctypes as C
 import importlib
@@ -34,7 +34,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, HERE)
 REF = os.path.join(ROOT, "oracle", "_ref")
 F = np.float32
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 camera = importlib.import_module("3dgrut_amd.camera")
 
 GUT_FRAMES = {"c4_1m_1080p": (1_000_000, 1920, 1080, 0.01), "c2_1m_800": (1_000_000, 800, 800, 0.01)}

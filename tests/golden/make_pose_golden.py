@@ -60,7 +60,7 @@ def main():
     ref = import_reference_tracer()
     sys.path.insert(0, ROOT)
     import importlib
-    syn = importlib.import_module("3dgrut_amd.synthetic")
+    syn = importlib.import_module("workloads.synthetic")
     poses = np.concatenate([random_poses(1024, 7), np.stack([syn.orbit_pose(v, n_views=8) for v in range(8)]).astype(np.float32),
                             np.eye(4, dtype=np.float32)[None]])
     ends = np.roll(poses, 1, axis=0)

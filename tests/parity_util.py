@@ -30,7 +30,7 @@ from scenes import rel_err, torch_batch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 camera = importlib.import_module("3dgrut_amd.camera")
 
 GRAD_SLICES = {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}
@@ -544,19 +544,28 @@ def assert_gut_full_parity(stats, max_flip_frac=2e-3, max_rounding_frac=2e-4):
 # ---------------------------------------------------------------------------------------------------------------------
 # 3DGRT at BASELINE config 3's sizes
 # ---------------------------------------------------------------------------------------------------------------------
-def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_cap=192, with_backward=True, log=None, wide_stride=0):
+GRT_PRIMITIVE_CODES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4, "custom": 5}
+
+
+def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_cap=192, with_backward=True, log=None, wide_stride=0,
+                    primitive_type="instances"):
     """HIP 3DGRT against the oracle on every `ray_stride`-th ray of the frame (the oracle tests every particle against every
     ray: stride 1 at 100 k particles / 400x400, a >= 4 k-ray subsample at 1 M particles / 800x800).
 
     The oracle is fed the proxy records the GPU built (`inst`, scene box), so the per-ray ORDER of processed particles can be
     compared bit for bit; the proxies themselves are compared separately (stage P).  Gradients (stride 1 only) are compared
-    against the oracle's backward of the same frame."""
+    against the oracle's backward of the same frame.
+
+    primitive_type: render.primitive_type of the plugin and the oracle's candidate test - "icosahedron" is the reference paper's own 3DGRT
+    configuration (configs/paper/3dgrt/base_ours_reference.yaml:16; entry distance into the proxy polyhedron), "custom" the world boxes with
+    intersectCustomParticle (the oracle gets the GPU's boxes like it gets the GPU's instance records)."""
     import torch
     t_all = time.time()
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     inp = make_frame_inputs(n, w, h, median_scale, seed=seed, view=view)
     d12, sph = inp["d12"], inp["sph"]
-    tr = grt.Tracer({"render": {"enable_hitcounts": True}})
+    render_conf = {"enable_hitcounts": True, "primitive_type": primitive_type}
+    tr = grt.Tracer({"render": dict(render_conf)})
     g = syn.SimpleGaussians(d12, sph)
     tr.build_acc(g, rebuild=True)
     nat = tr.tracer_wrapper
@@ -572,8 +581,9 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
     feat, dns, hit, cnt = (t[0].cpu().numpy() for t in (feat, dns, hit, cnt))
     vis = vis.view(torch.int32).reshape(-1).cpu().numpy() != 0
     ids, num = ids.cpu().numpy().view(np.uint32), num.cpu().numpy().astype(np.int64)
-    stats = dict(N=n, W=w, H=h, P=w * h)
-    cfg = oracle.default_grt_config()
+    stats = dict(N=n, W=w, H=h, P=w * h, primitive_type=primitive_type)
+    cfg = oracle.default_grt_config(primitive_type=GRT_PRIMITIVE_CODES[primitive_type])
+    box_kw = dict(box8=nat.custom_boxes(n, "cuda").cpu().numpy()) if primitive_type == "custom" else {}
     # ---- stage P: proxies ----------------------------------------------------------------------------------------------
     pr = oracle.grt_proxies(cfg, d12[:, 0:3], d12[:, 4:8], d12[:, 8:11], d12[:, 3])
     stats["P_instance_rel_err"] = rel_err(inst, pr["inst"])
@@ -583,7 +593,7 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
     ro_s, rd_s = ro.reshape(-1, 3)[sel][None], rd.reshape(-1, 3)[sel][None]
     T = inp["batch"]["T_to_world"][0]
     t0 = time.time()
-    ora = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro_s, rd_s, inst=inst, scene=scene_aabb, dbg_cap=hit_cap)
+    ora = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro_s, rd_s, inst=inst, scene=scene_aabb, dbg_cap=hit_cap, **box_kw)
     stats["t_oracle_forward_s"] = time.time() - t0
     o_num = ora["hit_num"].astype(np.int64)
     stats["T_rays_compared"] = int(sel.size)
@@ -611,7 +621,7 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
     # BASELINE's bar for the depth is 1e-4 ABSOLUTE on values of ~4: the same rays through the oracle's DOUBLE build tell how far an
     # fp32 evaluation of these very hit sequences is from the exact value (the rounding of the per-hit alphas, see _rounding_bound) —
     # the HIP frame must not be farther from the double oracle than the float oracle is
-    ora64 = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro_s, rd_s, inst=inst, scene=scene_aabb, dtype=np.float64)
+    ora64 = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro_s, rd_s, inst=inst, scene=scene_aabb, dtype=np.float64, **box_kw)
     same = ~F & (ora64["hit_count"].reshape(-1) == ora["hit_count"].reshape(-1))
     d_h32 = np.abs(h_s[:, 0] - o_hit[:, 0])[same]
     d_h64 = np.abs(h_s[:, 0] - ora64["hit_distance"].reshape(-1, 2)[:, 0])[same]
@@ -635,14 +645,14 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
         packet_of = lambda pix: ((pix // w) // 8) * gxp + (pix % w) // 8
         t0 = time.time()
         oracle.grt_set_candidate_prefilter(ranges, entries, packet_of(sel).astype(np.uint32))
-        chk = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro_s, rd_s, inst=inst, scene=scene_aabb, dbg_cap=hit_cap)
+        chk = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro_s, rd_s, inst=inst, scene=scene_aabb, dbg_cap=hit_cap, **box_kw)
         stats["W_prefilter_changes_rays"] = int(((chk["hit_ids"] != ora["hit_ids"]).any(1) | (chk["hit_num"] != ora["hit_num"])
                                                  | (chk["features"].reshape(-1, 3) != ora["features"].reshape(-1, 3)).any(1)
                                                  | (chk["hit_distance"].reshape(-1, 2) != ora["hit_distance"].reshape(-1, 2)).any(1)).sum())
         sel2 = np.arange(wide_stride // 2, w * h, wide_stride)
         ro2, rd2 = ro.reshape(-1, 3)[sel2][None], rd.reshape(-1, 3)[sel2][None]
         oracle.grt_set_candidate_prefilter(ranges, entries, packet_of(sel2).astype(np.uint32))
-        wide = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro2, rd2, inst=inst, scene=scene_aabb, dbg_cap=hit_cap)
+        wide = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro2, rd2, inst=inst, scene=scene_aabb, dbg_cap=hit_cap, **box_kw)
         oracle.grt_set_candidate_prefilter()
         stats["t_oracle_wide_s"] = time.time() - t0
         w_num = wide["hit_num"].astype(np.int64)
@@ -682,7 +692,7 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
             return g.grads_packed()
 
         # (1) the reference's backward program exactly: the plugin traverses again (render.backward_hit_replay = false)
-        tr_exact = grt.Tracer({"render": {"enable_hitcounts": True, "backward_hit_replay": False}})
+        tr_exact = grt.Tracer({"render": dict(render_conf, backward_hit_replay=False)})
         tr_exact.build_acc(g, rebuild=True)
         gd, gs = hip_grads(tr_exact, g_rad, g_dns)
         for kname, sl in GRAD_SLICES.items():

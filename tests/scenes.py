@@ -1,79 +1,3 @@
-"""Seeded test scenes shared by the CPU (oracle) and GPU (parity) tests."""
-import importlib
-
-import numpy as np
-
-syn = importlib.import_module("3dgrut_amd.synthetic")
-camera = importlib.import_module("3dgrut_amd.camera")
-
-
-def make_scene(n=2000, width=64, height=64, median_scale=0.05, seed=3, view=0, kind="trained", max_density=0.99,
-               sph_degree=3):
-    if kind == "trained":
-        d12, sph = syn.cloud_trained_like(n, seed=seed, median_scale=median_scale, max_density=max_density, sph_degree=sph_degree)
-    else:
-        d12, sph = syn.cloud_random_init(n, seed=seed, sph_degree=sph_degree)
-    K = syn.pinhole_intrinsics(width, height)
-    ro, rd = syn.pinhole_rays(width, height, K)
-    batch = dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(view)[None], intrinsics=K)
-    cam, ps, pe = camera.camera_from_batch(batch)
-    return dict(density12=d12, sph=sph, batch=batch, cam=cam, pose_start=ps, pose_end=pe, rays=(ro, rd), W=width, H=height)
-
-
-def make_camera_scene(kind, n=4000, w=96, h=64):
-    """Scenes for the non-trivial camera models of cameraProjections.cuh: rays are generated by numerically inverting
-    nothing — the projection only drives binning (which particles land in which tile); compositing uses the rays given.
-    So any consistent ray field works; the fisheye one is the exact inverse, the others reuse pinhole rays."""
-    scene = make_scene(n=n, width=w, height=h, median_scale=0.06)
-    b = scene["batch"]
-    K = b.pop("intrinsics")
-    fx, fy, cx, cy = K
-    if kind == "fisheye":
-        Kf = syn.fisheye_intrinsics(w, h, fov_deg=120.0)
-        Kf["radial_coeffs"] = np.array([0.02, -0.01, 0.003, 0.0], np.float32)
-        b["intrinsics_OpenCVFisheyeCameraModelParameters"] = Kf
-        Kz = dict(Kf, radial_coeffs=np.zeros(4, np.float32))
-        ro, rd = syn.fisheye_rays(w, h, Kz)
-        b["rays_ori"], b["rays_dir"] = ro, rd
-        scene["rays"] = (ro, rd)
-    elif kind == "pinhole_rs":
-        b["intrinsics_OpenCVPinholeCameraModelParameters"] = dict(
-            resolution=np.array([w, h], np.uint32), shutter_type="ROLLING_TOP_TO_BOTTOM", principal_point=np.array([cx, cy], np.float32),
-            focal_length=np.array([fx, fy], np.float32), radial_coeffs=np.array([0.05, -0.02, 0.0, 0.01, 0.0, 0.0], np.float32),
-            tangential_coeffs=np.array([0.002, -0.001], np.float32), thin_prism_coeffs=np.array([0.001, 0.0, -0.001, 0.0], np.float32))
-        end = b["T_to_world"][0].copy()
-        end[:3, 3] += np.array([0.05, -0.03, 0.02], np.float32)   # camera moves during the exposure
-        b["T_to_world_end"] = end[None]
-    elif kind == "ftheta":
-        # equidistant model expressed as an f-theta polynomial: angle = pixeldist / f
-        f = fx
-        b["intrinsics_FThetaCameraModelParameters"] = dict(
-            resolution=np.array([w, h], np.uint32), shutter_type="ROLLING_LEFT_TO_RIGHT", principal_point=np.array([cx, cy], np.float32),
-            reference_poly="PIXELDIST_TO_ANGLE", pixeldist_to_angle_poly=np.array([0.0, 1.0 / f, 0.0, 1e-9, 0.0, 0.0], np.float32),
-            angle_to_pixeldist_poly=np.array([0.0, f, 0.0, 0.0, 0.0, 0.0], np.float32), max_angle=1.2,
-            linear_cde=np.array([1.0, 0.0, 0.0], np.float32))
-        end = b["T_to_world"][0].copy()
-        end[:3, 3] += np.array([-0.04, 0.02, 0.0], np.float32)
-        b["T_to_world_end"] = end[None]
-    scene["cam"], scene["pose_start"], scene["pose_end"] = camera.camera_from_batch(b)
-    return scene
-
-
-def torch_batch(batch, device):
-    import torch
-    from types import SimpleNamespace
-    return SimpleNamespace(
-        rays_ori=torch.as_tensor(batch["rays_ori"], device=device),
-        rays_dir=torch.as_tensor(batch["rays_dir"], device=device),
-        T_to_world=torch.as_tensor(batch["T_to_world"], device=device),
-        T_to_world_end=None, rays_in_world_space=False,
-        intrinsics=batch.get("intrinsics"),
-        intrinsics_OpenCVPinholeCameraModelParameters=batch.get("intrinsics_OpenCVPinholeCameraModelParameters"),
-        intrinsics_OpenCVFisheyeCameraModelParameters=batch.get("intrinsics_OpenCVFisheyeCameraModelParameters"),
-        intrinsics_FThetaCameraModelParameters=batch.get("intrinsics_FThetaCameraModelParameters"))
-
-
-def rel_err(a, b):
-    """||a-b||inf / (||b||inf + eps): the per-tensor gradient metric of SURVEY.md §8d."""
-    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+"""Seeded test scenes: moved to workloads/scenes.py (bench.py and smoke() use them too); re-exported for the tests."""
+from workloads.scenes import *  # noqa: F401,F403
+from workloads.scenes import make_camera_scene, make_scene, rel_err, torch_batch  # noqa: F401

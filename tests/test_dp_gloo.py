@@ -85,6 +85,27 @@ def _variant_worker(rank, world, port, out):
     res["shard"] = (s, lo, hi)
     res["sh_geo"], res["sh_fac"] = mine.numpy(), factors.numpy()
     res["sh_full"] = sh.all_gather_rows(mine[:hi - lo], n).numpy()
+    # round 5: view factors as scaled halves; direct pairwise transfers instead of ring collectives
+    hf_geo, hf_fac, hf_bytes = dp.HalfFactorsExchange(average=True).exchange(geo.clone(), fac.clone() * 1e-7)   # (gradients of a 2 M-pixel frame: ~1e-7)
+    res["hf_geo"], res["hf_fac"], res["hf_bytes"] = hf_geo.numpy(), hf_fac.numpy(), hf_bytes
+    al_geo, al_fac, al_bytes = dp.AllLinksExchange(average=True).exchange(geo.clone(), fac.clone())
+    res["al_geo"], res["al_fac"], res["al_bytes"] = al_geo.numpy(), al_fac.numpy(), al_bytes
+    # fewer particles than ranks x (ranks - 1): the last rank owns the empty range [n, n) (ShardedGradientExchange.shard_rows clamps)
+    tiny_geo, tiny_fac = geo[:1].clone(), torch.cat([fac[:1], fac[n:]]).clone()
+    res["tiny_in"] = (tiny_geo.numpy().copy(), tiny_fac.numpy().copy())
+    res["tiny_shard"] = sh.shard_rows(1)
+    t_mine, t_factors, _ = sh.exchange_shard(tiny_geo.clone(), tiny_fac.clone())
+    res["tiny_mine"], res["tiny_factors"] = t_mine.numpy(), t_factors.numpy()
+    s1, lo1, hi1 = sh.shard_rows(1)
+    res["tiny_full"] = sh.all_gather_rows(t_mine[:hi1 - lo1], 1).numpy()
+    al1_geo, al1_fac, _ = dp.AllLinksExchange(average=True).exchange(tiny_geo.clone(), tiny_fac.clone())
+    res["tiny_al_geo"], res["tiny_al_fac"] = al1_geo.numpy(), al1_fac.numpy()
+    for cls in (dp.VisibleRowsExchange, dp.ShardedGradientExchange, dp.HalfFactorsExchange, dp.AllLinksExchange):
+        try:
+            cls(chunks=4)
+            res["chunks_rejected"] = False
+        except ValueError:
+            res.setdefault("chunks_rejected", True)
     out[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -118,6 +139,31 @@ def test_exchange_variants_world2():
         np.testing.assert_array_equal(r[k]["sh_fac"][:, :hi - lo], facs[:, lo:hi])
         np.testing.assert_array_equal(r[k]["sh_fac"][:, s], facs[:, n])
         np.testing.assert_allclose(r[k]["sh_full"], mean_geo, rtol=1e-6, atol=1e-7)
+        # half factors: the packed gradient as before; every view's factors within half precision of ITS largest magnitude, sensor rows exact
+        np.testing.assert_allclose(r[k]["hf_geo"], mean_geo, rtol=1e-6, atol=1e-7)
+        for v in range(world):
+            want = facs[v, :n] * 1e-7
+            assert np.abs(r[k]["hf_fac"][v, :n] - want).max() <= 4.9e-4 * np.abs(want).max()
+            assert np.abs(r[k]["hf_fac"][v, :n]).max() > 0.5 * np.abs(want).max()
+        np.testing.assert_allclose(r[k]["hf_fac"][:, n], facs[:, n] * 1e-7, rtol=1e-6)
+        assert r[k]["hf_bytes"] == n * 48 + n * 6 + 16
+        # direct transfers: same sums (up to the order of two additions: exact here), same factors
+        np.testing.assert_allclose(r[k]["al_geo"], mean_geo, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(r[k]["al_fac"], facs)
+        # one particle on two ranks
+        assert r[k]["tiny_shard"] == ((1, 0, 1) if k == 0 else (1, 1, 1))
+        tiny_mean = (r[0]["tiny_in"][0] + r[1]["tiny_in"][0]) / 2
+        if k == 0:
+            np.testing.assert_allclose(r[k]["tiny_mine"][:1], tiny_mean, rtol=1e-6, atol=1e-7)
+            np.testing.assert_array_equal(r[k]["tiny_factors"][:, 0], np.stack([r[0]["tiny_in"][1][0], r[1]["tiny_in"][1][0]]))
+        np.testing.assert_array_equal(r[k]["tiny_factors"][:, 1], np.stack([r[0]["tiny_in"][1][1], r[1]["tiny_in"][1][1]]))   # sensor rows
+        np.testing.assert_allclose(r[k]["tiny_full"], tiny_mean, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(r[k]["tiny_al_geo"], tiny_mean, rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(r[k]["tiny_al_fac"], np.stack([r[0]["tiny_in"][1], r[1]["tiny_in"][1]]))
+        assert r[k]["chunks_rejected"] is True
+    # replicas are bitwise identical for every variant
+    for key in ("hf_geo", "hf_fac", "al_geo", "al_fac", "tiny_full", "tiny_al_geo"):
+        np.testing.assert_array_equal(r[0][key], r[1][key])
 
 
 def _pipelined_worker(rank, world, port, out):
@@ -165,3 +211,35 @@ def test_pipelined_exchange_equals_the_one_piece_exchange_world2():
         np.testing.assert_array_equal(r[k]["fac"], r[k]["ref_fac"][:, :1000])
     np.testing.assert_array_equal(r[0]["geo"], r[1]["geo"])
     np.testing.assert_array_equal(r[0]["fac"], r[1]["fac"])
+
+
+def test_local_gradient_hook_has_one_signature_on_every_path(monkeypatch):
+    """the pipelined exchange called the hook with (rows, first), the one-piece exchanges with (rows) - a documented
+    one-argument hook raised as soon as chunks > 1.  Now every path calls hook(rows, first); one-argument hooks are still accepted."""
+    dp = importlib.import_module("3dgrut_amd.dp")
+    abi = importlib.import_module("3dgrut_amd._abi")
+    monkeypatch.setattr(abi, "sph_grad_from_views", lambda factors, positions, n_active, deg, scale, out=None:
+                        (out if out is not None else torch.zeros(factors.shape[1] - 1, 3 * (deg + 1) ** 2)))
+    n = 1000
+    geo, fac, pos = torch.randn(n, 12), torch.randn(n + 1, 3), torch.randn(n, 3)
+
+    def chunked_backward(num_chunks, on_chunk):
+        per = ((n + num_chunks - 1) // num_chunks + 127) & ~127
+        for k, first in enumerate(range(0, n, per)):
+            on_chunk(k, first, min(per, n - first), geo, fac)
+        return geo, fac
+
+    for chunks in (1, 4):
+        two, one = [], []
+        ex2 = dp.FactoredGradientExchange(local_gradient_hook=lambda rows, first: two.append((first, rows.shape[0])), chunks=chunks)
+        ex1 = dp.FactoredGradientExchange(local_gradient_hook=lambda rows: one.append(rows.shape[0]), chunks=chunks)
+        for ex in (ex2, ex1):
+            if chunks == 1:
+                ex.reduce_packed(geo, fac, pos, 3, 3)
+                ex.reduce_dense(geo)
+            else:
+                ex.reduce_packed_pipelined(chunked_backward, pos, 3, 3)
+        if chunks == 1:
+            assert two == [(0, n), (0, n)] and one == [n, n]
+        else:
+            assert two == [(0, 256), (256, 256), (512, 256), (768, 232)] and one == [256, 256, 256, 232]

@@ -26,7 +26,7 @@ def _free_port():
 
 
 def _backward(view, exchange):
-    syn = importlib.import_module("3dgrut_amd.synthetic")
+    syn = importlib.import_module("workloads.synthetic")
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
     scene = make_scene(view=view, **SCENE)
     tr = gt.Tracer({"render": {"splat": {}}})
@@ -143,7 +143,7 @@ def _train_worker(rank, world, port, teacher, out):
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dp = importlib.import_module("3dgrut_amd.dp")
-    syn = importlib.import_module("3dgrut_amd.synthetic")
+    syn = importlib.import_module("workloads.synthetic")
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
     opt_mod = importlib.import_module("3dgrut_amd.optimizers")
     tracer = gt.Tracer({"render": {"splat": {}}})
@@ -194,7 +194,7 @@ def _rccl_rank(rank, world, port, out):
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     dp = importlib.import_module("3dgrut_amd.dp")
-    syn = importlib.import_module("3dgrut_amd.synthetic")
+    syn = importlib.import_module("workloads.synthetic")
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
     res = {}
     for kind in ("factored", "allreduce"):

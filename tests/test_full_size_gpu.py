@@ -70,14 +70,21 @@ def test_gut_nht_frame_matches_oracle_at_baseline_size():
     pu.record_full_parity("c4_1m_1080p_nht", stats)
 
 
-@pytest.mark.parametrize("name,n,w,h,median_scale,ray_stride", [("c3_grt_100k_400", 100_000, 400, 400, 0.01, 1),
-                                                                ("c3_grt_1m_800", 1_000_000, 800, 800, 0.01, 149)])
-def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, ray_stride):
+@pytest.mark.parametrize("name,n,w,h,median_scale,ray_stride,prim", [
+    ("c3_grt_100k_400", 100_000, 400, 400, 0.01, 1, "instances"), ("c3_grt_1m_800", 1_000_000, 800, 800, 0.01, 149, "instances"),
+    # the reference paper's own 3DGRT configuration (configs/paper/3dgrt/base_ours_reference.yaml:16) and the custom-primitive proxies at
+    # BASELINE config 3's size, through the same stages (round 5; until then they were compared on <= 20 k-particle scenes only)
+    ("c3_grt_icosahedron_100k_400", 100_000, 400, 400, 0.01, 1, "icosahedron"), ("c3_grt_icosahedron_1m_800", 1_000_000, 800, 800, 0.01, 149, "icosahedron"),
+    ("c3_grt_custom_1m_800", 1_000_000, 800, 800, 0.01, 149, "custom")])
+def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, ray_stride, prim):
     """3DGRT (LBVH + software traversal) against the oracle: the per-ray order of processed particles bit-exact, images within
     1e-4, gradients within 1e-3 relative (full frame at 100 k particles; a 4 k-ray subsample of the 1 M / 800x800 frame)."""
     # 1 M particles: every 149th ray through all pairs (4296 rays), then every 9th ray (71 k) with the oracle's scan restricted to the
     # packet lists the GPU built - checked to change nothing on the 4296
-    stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print, wide_stride=9 if ray_stride > 1 else 0)
+    grt = importlib.import_module("3dgrut_amd.grt_tracer")
+    has_lists = prim != "custom" or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
+    stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print, wide_stride=9 if ray_stride > 1 and has_lists else 0,
+                               primitive_type=prim)
     pu.assert_grt_full_parity(stats)
     pu.record_full_parity(name, stats)
 
@@ -145,26 +152,30 @@ def test_gut_frame_equals_the_reference_kernels_on_a_sample_at_baseline_size(nam
     assert len(untouched) <= 3 * nflip, "particles with a gradient that the reference's backward never touched"
 
 
-def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_size():
+@pytest.mark.parametrize("prim", ["instances", "icosahedron", "custom"])
+def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_size(prim):
     """BASELINE config 3's frame (1 M Gaussians, 800 x 800) against the reference's OWN 3DGRT programs - referenceOptix.cu and
     referenceBwdOptix.cu compiled on the host over the emulated traversal, every ray offered every one of the 1 M instances
     (tests/golden/fullsize_grt_c3_1m_800.npz, 1536 rays on a regular sub-grid): accepted-hit counts, images, last-hit distances, and the
-    gradient rows of the particles those rays' backward touches, with the upstream gradient confined to the sampled rays."""
+    gradient rows of the particles those rays' backward touches, with the upstream gradient confined to the sampled rays.
+    icosahedron (the paper's configuration) / custom: the programs built for that primitive over the reference's own meshes / world boxes
+    of all 1 M particles, 6144 rays, each ray offered a conservative superset of the particles it can touch
+    (tests/golden/fullsize_grt_<prim>_c3_1m_800.npz, make_fullsize_golden.py: make_grt_prim)."""
     import os
     import sys
     import torch
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, os.path.join(here, "golden"))
     import make_golden as mg
-    g = np.load(os.path.join(here, "golden", "fullsize_grt_c3_1m_800.npz"))
+    g = np.load(os.path.join(here, "golden", "fullsize_grt_c3_1m_800.npz" if prim == "instances" else f"fullsize_grt_{prim}_c3_1m_800.npz"))
     n, w, h, ms = int(g["n"]), int(g["W"]), int(g["H"]), float(g["median_scale"])
-    syn = importlib.import_module("3dgrut_amd.synthetic")
+    syn = importlib.import_module("workloads.synthetic")
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=ms)
     K = syn.pinhole_intrinsics(w, h)
     ro, rd = syn.pinhole_rays(w, h, K)
     batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(0, n_views=8)[None], intrinsics=K), "cuda")
-    tracer = grt.Tracer({"render": {"enable_hitcounts": True}})
+    tracer = grt.Tracer({"render": {"enable_hitcounts": True, "primitive_type": prim}})
     gs = syn.SimpleGaussians(d12, sph)
     tracer.build_acc(gs, rebuild=True)
     out = tracer.render(gs, batch, train=True)
@@ -183,7 +194,10 @@ def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_siz
     e_o = np.abs(pick(out["pred_opacity"]) - g["density"])[..., 0]
     e_d = np.abs(pick(out["pred_dist"]) - g["hit_distance"][..., :1])[..., 0]
     tied = ok & ((e_f > 1e-4) | (e_o > 1e-4) | (e_d > 1e-4 * max(1.0, float(np.abs(g["hit_distance"]).max()))))
-    print(f"{int(tied.sum())} rays with the same count beyond 1e-4 (order ties): max colour difference {float(e_f[tied].max()) if tied.any() else 0.0:.2e}")
+    print(f"{prim}: {int(tied.sum())} of {tied.size} rays with the same count beyond 1e-4 (order ties): max colour difference {float(e_f[tied].max()) if tied.any() else 0.0:.2e}")
+    pu.record_full_parity(f"ref_programs_{prim}_c3_1m_800", dict(rays=int(flips.size), count_flips=int(flips.sum()), order_ties=int(tied.sum()),
+                                                                 max_rgb_err_in_ties=float(e_f[tied].max()) if tied.any() else 0.0,
+                                                                 max_rgb_err_elsewhere=float(e_f[ok & ~tied].max()), hits_per_ray=float(g["hits_count"].mean())))
     assert tied.mean() <= 5e-3 and (not tied.any() or (e_f[tied].max() < 5e-2 and e_o[tied].max() < 5e-2))
     ok = ok & ~tied
     # backward: the upstream gradient lives on the sampled rays only
@@ -211,7 +225,7 @@ def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_siz
 @pytest.fixture(scope="module")
 def frame():
     import torch
-    syn = importlib.import_module("3dgrut_amd.synthetic")
+    syn = importlib.import_module("workloads.synthetic")
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
     d12, sph = syn.cloud_trained_like(N, seed=42, median_scale=0.01)
     K = syn.pinhole_intrinsics(W, H)
@@ -296,7 +310,7 @@ def test_grt_full_size_forward_is_reproducible_and_backward_is_stable():
     and compositing do not depend on the traversal order), the per-particle visibility is exactly "took part in a processed hit
     of some ray", and the gradients — float atomics, hence order-dependent — agree run to run within rounding."""
     import torch
-    syn = importlib.import_module("3dgrut_amd.synthetic")
+    syn = importlib.import_module("workloads.synthetic")
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     n, w, h = 1_000_000, 800, 800
     d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=0.01)
@@ -339,7 +353,7 @@ def test_grt_default_backward_equals_the_rederived_backward_at_full_size():
     oracle can afford every ray).  At this size 70 % of the rays lose a hit to the endT clip of the backward's traces and 8 % of them
     process another hit SET than the forward (oracle statistics); all of it must come out the same."""
     import torch
-    syn = importlib.import_module("3dgrut_amd.synthetic")
+    syn = importlib.import_module("workloads.synthetic")
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     n, w, h = 1_000_000, 800, 800
     d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=0.01)
@@ -378,7 +392,7 @@ def test_device_pose_path_is_the_host_pose_path_bit_for_bit_at_full_size():
     arithmetic on the GPU with contraction off, so the two paths must render THE SAME BITS on the bench frame: depth keys, lists,
     images, hit counts and every gradient (round 3 inverted in fp32 on the device: 0.2 % of the pixels moved)."""
     import torch
-    syn = importlib.import_module("3dgrut_amd.synthetic")
+    syn = importlib.import_module("workloads.synthetic")
     inp = pu.make_frame_inputs(N, W, H, 0.01)
     g_fd_np, _ = syn.upstream_grads(W, H)
     g_fd = g_fd_np * (W * H)

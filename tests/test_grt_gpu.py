@@ -10,7 +10,7 @@ import oracle
 from scenes import make_scene, rel_err, torch_batch
 
 pytestmark = pytest.mark.gpu
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 
 
 def _tracer(**render_kw):

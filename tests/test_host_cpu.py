@@ -12,7 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 camera = importlib.import_module("3dgrut_amd.camera")
 abi = importlib.import_module("3dgrut_amd._abi")
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 
 
 def _rot_from_xyzw(q):

@@ -19,7 +19,7 @@ import oracle
 import playground_scenes as ps
 
 pytestmark = pytest.mark.gpu
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "playground.npz")
 
 

@@ -11,7 +11,7 @@ from oracle import adam_oracle
 from scenes import make_scene, torch_batch
 
 pytestmark = pytest.mark.gpu
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 HERE = os.path.dirname(os.path.abspath(__file__))
 TOL = 2e-6  # fp32 with fused multiply-adds against the unfused oracle
 
@@ -157,7 +157,7 @@ def test_training_recovers_a_teacher_scene(method):
     assert psnr_after > psnr_before + 6.0, (psnr_before, psnr_after)
 
 
-train_surrogate = importlib.import_module("3dgrut_amd.surrogate").train_surrogate
+train_surrogate = importlib.import_module("workloads.surrogate").train_surrogate
 
 
 @pytest.mark.parametrize("method", ["3dgut", "3dgrt"])

@@ -17,7 +17,7 @@ import oracle
 from scenes import make_scene, rel_err
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-syn = importlib.import_module("3dgrut_amd.synthetic")
+syn = importlib.import_module("workloads.synthetic")
 
 
 def _golden(degree):

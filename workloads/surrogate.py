@@ -39,7 +39,7 @@ def train_surrogate(method, n=100_000, w=400, h=400, views=8, steps=500, median_
     d12_0[:, 3] = np.clip(d12_0[:, 3] * np.exp(rng.normal(size=n) * 0.3).astype(np.float32), 0.01, 0.98)
     sph_0[:, :3] += rng.normal(size=(n, 3)).astype(np.float32) * 0.4
     sph_0[:, 3:] = 0
-    mod = importlib.import_module(".gut_tracer" if method == "3dgut" else ".grt_tracer", __package__)
+    mod = importlib.import_module("3dgrut_amd.gut_tracer" if method == "3dgut" else "3dgrut_amd.grt_tracer")
     tracer = mod.Tracer({"render": {"splat": {}}} if method == "3dgut" else {"render": {}})
     batches = [torch_batch(b, "cuda") for b in batches_np]
 
@@ -51,7 +51,7 @@ def train_surrogate(method, n=100_000, w=400, h=400, views=8, steps=500, median_
 
     target = hip_images(d12, sph) if teacher_images is None else torch.as_tensor(teacher_images, device="cuda")
     g = syn.ActivatedGaussians(d12_0, sph_0)
-    opt_mod = importlib.import_module(".optimizers", __package__)
+    opt_mod = importlib.import_module("3dgrut_amd.optimizers")
     lrs = [1.6e-4, 5e-2, 1e-3, 5e-3, 2.5e-3, 2.5e-3 / 20]   # configs/base_gs.yaml (optimizer.params.*.lr)
     opt = opt_mod.SelectiveAdam([{"params": [p], "lr": lr} for p, lr in zip(g.parameters(), lrs)], eps=1e-15)
     for it in range(steps):
