@@ -82,6 +82,78 @@ __device__ __forceinline__ void sh_basis_grad(int deg, f3 d, f3 g[16]) {
     }
 }
 
+// The backward's copies of the two functions above with every rounding pinned in the source (opaque products, explicit fused multiply-adds).
+// Three kernels evaluate the basis for the gradient - the fused gather (a quad's lanes keep four functions each), the projection backward
+// (all sixteen) and the rebuild from gathered view factors - and the data-parallel contract is that they agree BIT FOR BIT (a replica that
+// rebuilds the SH gradient from factors must hold what a single GPU holds).  Left to the compiler, a product such as 3 x^2 is contracted into
+// the neighbouring subtraction when it has one use and kept when it has several, i.e. differently in a kernel that needs four functions
+// than in one that needs sixteen (round 5: tests/test_gut_gpu.py::test_factored_backward_rebuilds_the_sph_gradient[3-2]).
+__device__ __forceinline__ void sh_basis_pinned(int deg, f3 d, float b[16]) {
+    GRUT_SH_CONSTANTS;
+    const float x = d.x, y = d.y, z = d.z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) b[i] = 0.f;
+    b[0] = kC0;
+    if (deg > 0) {
+        b[1] = -kC1 * y; b[2] = kC1 * z; b[3] = -kC1 * x;
+        if (deg > 1) {
+            const float xx = mul_rn(x, x), yy = mul_rn(y, y), zz = mul_rn(z, z), xy = mul_rn(x, y), yz = mul_rn(y, z), xz = mul_rn(x, z);
+            const float t6 = add_rn(fmaf(2.f, zz, -xx), -yy), d8 = add_rn(xx, -yy);
+            b[4] = kC2[0] * xy; b[5] = kC2[1] * yz; b[6] = kC2[2] * t6; b[7] = kC2[3] * xz; b[8] = kC2[4] * d8;
+            if (deg > 2) {
+                const float t11 = add_rn(fmaf(4.f, zz, -xx), -yy);
+                b[9]  = kC3[0] * y * fmaf(3.f, xx, -yy);
+                b[10] = kC3[1] * xy * z;
+                b[11] = kC3[2] * y * t11;
+                b[12] = kC3[3] * z * fmaf(-3.f, yy, fmaf(-3.f, xx, mul_rn(2.f, zz)));
+                b[13] = kC3[4] * x * t11;
+                b[14] = kC3[5] * z * d8;
+                b[15] = kC3[6] * x * fmaf(-3.f, yy, xx);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void sh_basis_grad_pinned(int deg, f3 d, f3 g[16]) {
+    GRUT_SH_CONSTANTS;
+    const float x = d.x, y = d.y, z = d.z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[i] = mk3(0.f, 0.f, 0.f);
+    if (deg > 0) {
+        g[1] = mk3(0.f, -kC1, 0.f); g[2] = mk3(0.f, 0.f, kC1); g[3] = mk3(-kC1, 0.f, 0.f);
+        if (deg > 1) {
+            const float xx = mul_rn(x, x), yy = mul_rn(y, y), zz = mul_rn(z, z), xy = mul_rn(x, y), yz = mul_rn(y, z), xz = mul_rn(x, z);
+            g[4] = kC2[0] * mk3(y, x, 0.f);
+            g[5] = kC2[1] * mk3(0.f, z, y);
+            g[6] = kC2[2] * mk3(-2.f * x, -2.f * y, 4.f * z);
+            g[7] = kC2[3] * mk3(z, 0.f, x);
+            g[8] = kC2[4] * mk3(2.f * x, -2.f * y, 0.f);
+            if (deg > 2) {
+                const float t9 = fmaf(3.f, xx, -mul_rn(3.f, yy));
+                g[9]  = kC3[0] * mk3(6.f * xy, t9, 0.f);
+                g[10] = kC3[1] * mk3(yz, xz, xy);
+                g[11] = kC3[2] * mk3(-2.f * xy, fmaf(-3.f, yy, fmaf(4.f, zz, -xx)), 8.f * yz);
+                g[12] = kC3[3] * mk3(-6.f * xz, -6.f * yz, fmaf(-3.f, yy, fmaf(-3.f, xx, mul_rn(6.f, zz))));
+                g[13] = kC3[4] * mk3(add_rn(fmaf(-3.f, xx, mul_rn(4.f, zz)), -yy), -2.f * xy, 8.f * xz);
+                g[14] = kC3[5] * mk3(2.f * xz, -2.f * yz, add_rn(xx, -yy));
+                g[15] = kC3[6] * mk3(t9, -6.f * xy, 0.f);
+            }
+        }
+    }
+}
+// the rest of the projection backward's chain, shared by the same kernels for the same reason
+__device__ __forceinline__ f3 sh_view_direction(f3 p, f3 cam, float& ilen) {
+    const f3 v = mk3(add_rn(p.x, -cam.x), add_rn(p.y, -cam.y), add_rn(p.z, -cam.z));
+    ilen = 1.f / sqrtf(fmaf(v.z, v.z, fmaf(v.y, v.y, mul_rn(v.x, v.x))));
+    return mk3(mul_rn(v.x, ilen), mul_rn(v.y, ilen), mul_rn(v.z, ilen));
+}
+__device__ __forceinline__ float sh_row_dot(f3 g, float m0, float m1, float m2) { return fmaf(g.z, m2, fmaf(g.y, m1, mul_rn(g.x, m0))); }
+__device__ __forceinline__ f3 sh_axpy(f3 acc, f3 db, float s) { return mk3(fmaf(db.x, s, acc.x), fmaf(db.y, s, acc.y), fmaf(db.z, s, acc.z)); }
+__device__ __forceinline__ f3 sh_sum(f3 a, f3 b) { return mk3(add_rn(a.x, b.x), add_rn(a.y, b.y), add_rn(a.z, b.z)); }
+__device__ __forceinline__ f3 sh_position_gradient(f3 dir, float ilen, f3 gdir) {   // safe_normalize backward
+    const float ng = fmaf(dir.z, gdir.z, fmaf(dir.y, gdir.y, mul_rn(dir.x, gdir.x)));
+    return mk3(mul_rn(fmaf(-dir.x, ng, gdir.x), ilen), mul_rn(fmaf(-dir.y, ng, gdir.y), ilen), mul_rn(fmaf(-dir.z, ng, gdir.z), ilen));
+}
+
 // ---------------------------------------------------------------------------------------------
 // tile-space helpers (gutProjector.cuh:32-116)
 // ---------------------------------------------------------------------------------------------
@@ -845,9 +917,8 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
     if (FUSE_SH) {   // GUTProjector::evalBackward (gutProjector.cuh:390-430): dRGB -> dSH through the clamp, d direction -> d position
         const FramePoses& FP = frame_poses(P);
         const int nact = min((P.n_active + 1) * (P.n_active + 1), P.ncoef);
-        const f3 v = mk3(pa.x, pa.y, pa.z) - mk3(FP.s2w_t[0], FP.s2w_t[1], FP.s2w_t[2]);
-        const float ilen = 1.f / sqrtf(dot(v, v));
-        const f3 dir = v * ilen;
+        float ilen;
+        const f3 dir = sh_view_direction(mk3(pa.x, pa.y, pa.z), mk3(FP.s2w_t[0], FP.s2w_t[1], FP.s2w_t[2]), ilen);
         f3 g = mk3(r[13], r[14], r[15]);
         if (!(rad.x > 0.f)) g.x = 0.f;     // clamp mask on the unclamped radiance stored by the forward projection
         if (!(rad.y > 0.f)) g.y = 0.f;
@@ -861,15 +932,17 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
             constexpr int G = decltype(group)::value;
             float basis[16];
             f3 dbasis[16];
-            sh_basis(P.n_active, dir, basis);
-            sh_basis_grad(P.n_active, dir, dbasis);
+            sh_basis_pinned(P.n_active, dir, basis);
+            sh_basis_grad_pinned(P.n_active, dir, dbasis);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const bool on = 4 * G + j < nact;
-                const float sk = on ? g.x * rowv[3 * j] + g.y * rowv[3 * j + 1] + g.z * rowv[3 * j + 2] : 0.f;
-                gdir = gdir + dbasis[4 * G + j] * sk;
-                const float bk = on ? basis[4 * G + j] : 0.f;
-                o[3 * j] = bk * g.x; o[3 * j + 1] = bk * g.y; o[3 * j + 2] = bk * g.z;
+                o[3 * j] = o[3 * j + 1] = o[3 * j + 2] = 0.f;
+                if (on) {   // (inactive degrees: their basis functions are not evaluated - nothing of them may enter a sum)
+                    const float s = sh_row_dot(g, rowv[3 * j], rowv[3 * j + 1], rowv[3 * j + 2]);
+                    gdir = sh_axpy(gdir, dbasis[4 * G + j], s);
+                    o[3 * j] = mul_rn(basis[4 * G + j], g.x); o[3 * j + 1] = mul_rn(basis[4 * G + j], g.y); o[3 * j + 2] = mul_rn(basis[4 * G + j], g.z);
+                }
             }
         };
         switch (c) {
@@ -879,10 +952,9 @@ __global__ __launch_bounds__(256) void gut_grad_gather_kernel(GutParams P, GutPr
         default: part(std::integral_constant<int, 3>{}); break;
         }
         // sum of the four lanes' parts (quad butterflies)
-        gdir.x += quad_bcast_xor<1>(gdir.x); gdir.y += quad_bcast_xor<1>(gdir.y); gdir.z += quad_bcast_xor<1>(gdir.z);
-        gdir.x += quad_bcast_xor<2>(gdir.x); gdir.y += quad_bcast_xor<2>(gdir.y); gdir.z += quad_bcast_xor<2>(gdir.z);
-        const float ng = dot(dir, gdir);
-        const f3 gsh = (gdir - dir * ng) * ilen;
+        gdir = sh_sum(gdir, mk3(quad_bcast_xor<1>(gdir.x), quad_bcast_xor<1>(gdir.y), quad_bcast_xor<1>(gdir.z)));   // (p0 + p1), (p2 + p3)
+        gdir = sh_sum(gdir, mk3(quad_bcast_xor<2>(gdir.x), quad_bcast_xor<2>(gdir.y), quad_bcast_xor<2>(gdir.z)));   // their sum
+        const f3 gsh = sh_position_gradient(dir, ilen, gdir);
         gpos_out = mk3(add_rn(gpos.x, gsh.x), add_rn(gpos.y, gsh.y), add_rn(gpos.z, gsh.z));
         float4* out = reinterpret_cast<float4*>(g_sph + 48 * (size_t)i) + 3 * c;
         out[0] = make_float4(o[0], o[1], o[2], o[3]);
@@ -980,10 +1052,8 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
     float* myrow = rows + lane * kShStride;
     if (has) {
         const float4 a = density12[3 * (size_t)i];
-        const f3 v = mk3(a.x, a.y, a.z) - mk3(FP.s2w_t[0], FP.s2w_t[1], FP.s2w_t[2]);
-        const float len = sqrtf(dot(v, v));
-        const float ilen = 1.f / len;
-        const f3 dir = v * ilen;
+        float ilen;
+        const f3 dir = sh_view_direction(mk3(a.x, a.y, a.z), mk3(FP.s2w_t[0], FP.s2w_t[1], FP.s2w_t[2]), ilen);
         f3 g = mk3(g_rgb[3 * (size_t)i], g_rgb[3 * (size_t)i + 1], g_rgb[3 * (size_t)i + 2]);
         // clamp mask on the unclamped radiance stored by the forward projection
         if (!(rgb[3 * (size_t)i] > 0.f)) g.x = 0.f;
@@ -991,21 +1061,29 @@ __global__ __launch_bounds__(128) void gut_project_bwd_kernel(GutParams P, const
         if (!(rgb[3 * (size_t)i + 2] > 0.f)) g.z = 0.f;
         float basis[16];
         f3 dbasis[16];
-        sh_basis(P.n_active, dir, basis);
-        sh_basis_grad(P.n_active, dir, dbasis);
-        f3 gdir = mk3(0.f, 0.f, 0.f);
+        sh_basis_pinned(P.n_active, dir, basis);
+        sh_basis_grad_pinned(P.n_active, dir, dbasis);
+        // summed in four groups of four coefficients, then (p0 + p1) + (p2 + p3): the order of the fused gather kernel, whose quads split
+        // the coefficients four ways (FUSE_SH above) - every path to the position gradient gives the same bits
+        f3 part[4];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (k < nact) {
-                const float s = g.x * myrow[3 * k] + g.y * myrow[3 * k + 1] + g.z * myrow[3 * k + 2];
-                gdir = gdir + dbasis[k] * s;
-                if (!FACTORED) { myrow[3 * k] = basis[k] * g.x; myrow[3 * k + 1] = basis[k] * g.y; myrow[3 * k + 2] = basis[k] * g.z; }
+        for (int G = 0; G < 4; ++G) {
+            f3 gdir = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 4 * G + j;
+                if (k < nact) {
+                    const float s = sh_row_dot(g, myrow[3 * k], myrow[3 * k + 1], myrow[3 * k + 2]);
+                    gdir = sh_axpy(gdir, dbasis[k], s);
+                    if (!FACTORED) { myrow[3 * k] = mul_rn(basis[k], g.x); myrow[3 * k + 1] = mul_rn(basis[k], g.y); myrow[3 * k + 2] = mul_rn(basis[k], g.z); }
+                }
             }
+            part[G] = gdir;
         }
+        const f3 gdir = sh_sum(sh_sum(part[0], part[1]), sh_sum(part[2], part[3]));
         if (!FACTORED)
             for (int k = 3 * nact; k < rowlen; ++k) myrow[k] = 0.f;
-        const float ng = dot(dir, gdir);
-        const f3 gpos = (gdir - dir * ng) * ilen;
+        const f3 gpos = sh_position_gradient(dir, ilen, gdir);
         float* gp = g_out.packed ? g_out.packed + 12 * (size_t)i : g_out.pos + 3 * (size_t)i;
         gp[0] += gpos.x;
         gp[1] += gpos.y;
@@ -1066,13 +1144,13 @@ __global__ __launch_bounds__(128) void sph_grad_from_views_kernel(uint32_t N, ui
             const float* view = factors + (size_t)v * 3 * ((size_t)N + 1);
             const f3 g = mk3(view[3 * (size_t)i], view[3 * (size_t)i + 1], view[3 * (size_t)i + 2]);
             if (g.x == 0.f && g.y == 0.f && g.z == 0.f) continue;   // invisible or fully clamped in this view
-            const f3 d = mu - mk3(view[3 * (size_t)N], view[3 * (size_t)N + 1], view[3 * (size_t)N + 2]);
-            const f3 dir = d * (1.f / sqrtf(dot(d, d)));
+            float ilen;
+            const f3 dir = sh_view_direction(mu, mk3(view[3 * (size_t)N], view[3 * (size_t)N + 1], view[3 * (size_t)N + 2]), ilen);
             float basis[16];
-            sh_basis(n_active, dir, basis);
+            sh_basis_pinned(n_active, dir, basis);
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k < nact) { acc[3 * k] += basis[k] * g.x; acc[3 * k + 1] += basis[k] * g.y; acc[3 * k + 2] += basis[k] * g.z; }
+            for (int k = 0; k < 16; ++k)   // (product rounded on its own, then added: one view gives the single-GPU kernels' bits)
+                if (k < nact) { acc[3 * k] = add_rn(acc[3 * k], mul_rn(basis[k], g.x)); acc[3 * k + 1] = add_rn(acc[3 * k + 1], mul_rn(basis[k], g.y)); acc[3 * k + 2] = add_rn(acc[3 * k + 2], mul_rn(basis[k], g.z)); }
         }
 #pragma unroll
         for (int k = 0; k < 48; ++k)

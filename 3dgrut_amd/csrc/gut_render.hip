@@ -348,6 +348,64 @@ __device__ __forceinline__ PairGeom pair_geometry(const RayPair& rp, const float
     return g;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Experiment (round 5, -DGRUT_FWD_MFMA=1): the canonical direction v = M d of the pair geometry on the matrix pipe.
+// v_mfma_f32_4x4x1_16b_f32 multiplies, in each of 16 blocks of four lanes, a 4 x 1 column (A: one value per lane, row = lane & 3) with a
+// 1 x 4 row (B: one value per lane, column = lane & 3) and adds the 4 x 4 product to the accumulator (register r of a lane = row r of its
+// column).  With A = a coefficient of M of staged entry (group + (lane & 3)) and B = the lane's own ray direction component, register r
+// of every lane receives coefficient(entry group + r) x d(own pixel): three chained instructions (z, y, x - the order of pdot) give one
+// component of v for FOUR entries; fp32 MFMA is an exact fmaf chain on gfx950, so the bits are pdot's.  18 instructions per group of four
+// entries and pixel pair replace 4 x 9 packed multiply-adds on the VALU pipe; the accumulators of the next group are issued before the
+// current group is composited.
+// ---------------------------------------------------------------------------------------------
+#ifndef GRUT_FWD_MFMA
+#define GRUT_FWD_MFMA 0
+#endif
+typedef float v4f __attribute__((ext_vector_type(4)));
+struct GroupV {
+    v4f x0, x1, y0, y1, z0, z1;   // component of v, pixel of the pair; register r = entry group + r
+};
+__device__ __forceinline__ GroupV group_directions(const RayPair& rp, const float4* __restrict__ s_rec, int jg, int lane) {
+    const float4* rec = &s_rec[(jg + (lane & 3)) * kRecQuads];
+    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+    const v4f zero = {0.f, 0.f, 0.f, 0.f};
+    GroupV g;
+    g.x0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.z, rp.d.z.x, zero, 0, 0, 0);
+    g.x1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.z, rp.d.z.y, zero, 0, 0, 0);
+    g.y0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.z, rp.d.z.x, zero, 0, 0, 0);
+    g.y1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.z, rp.d.z.y, zero, 0, 0, 0);
+    g.z0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r2.z, rp.d.z.x, zero, 0, 0, 0);
+    g.z1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r2.z, rp.d.z.y, zero, 0, 0, 0);
+    g.x0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.y, rp.d.y.x, g.x0, 0, 0, 0);
+    g.x1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.y, rp.d.y.y, g.x1, 0, 0, 0);
+    g.y0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.y, rp.d.y.x, g.y0, 0, 0, 0);
+    g.y1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.y, rp.d.y.y, g.y1, 0, 0, 0);
+    g.z0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r2.y, rp.d.y.x, g.z0, 0, 0, 0);
+    g.z1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r2.y, rp.d.y.y, g.z1, 0, 0, 0);
+    g.x0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.x, rp.d.x.x, g.x0, 0, 0, 0);
+    g.x1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.x, rp.d.x.y, g.x1, 0, 0, 0);
+    g.y0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.x, rp.d.x.x, g.y0, 0, 0, 0);
+    g.y1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.x, rp.d.x.y, g.y1, 0, 0, 0);
+    g.z0 = __builtin_amdgcn_mfma_f32_4x4x1f32(r2.x, rp.d.x.x, g.z0, 0, 0, 0);
+    g.z1 = __builtin_amdgcn_mfma_f32_4x4x1f32(r2.x, rp.d.x.y, g.z1, 0, 0, 0);
+    return g;
+}
+// the rest of pair_geometry<true> for a direction that is already there
+__device__ __forceinline__ PairGeom pair_geometry_given_v(p3 v, const float4* __restrict__ rec) {
+    PairGeom g;
+    g.v = v;
+    const float4 r5 = rec[5];
+    g.u = p3{splat(r5.x), splat(r5.y), splat(r5.z)};
+    g.l2 = pdot(g.v, g.v);
+    const p3 c = pcross(g.v, g.u);
+    g.cc = pdot(c, c);
+    const v2f lim = rec[4].w * g.l2;
+    g.acc0 = g.cc.x < lim.x;
+    g.acc1 = g.cc.y < lim.y;
+    return g;
+}
+
 // particle_response<DEG> for a pixel pair (one v_exp_f32 per pixel, the polynomial part packed)
 template <int DEG>
 __device__ __forceinline__ v2f pair_response(v2f g) {
@@ -448,6 +506,57 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         if (COUNT) t_stage += wall_clock64() - t_round;
         // fetch the following round while this one is being composited
         next = load_entry<false>(bend + lane, min(range.y, bend + 64u), lists, density12, rgb);
+#if GRUT_FWD_MFMA
+        if constexpr (UNI) {
+#if GRUT_FWD_MFMA == 1
+            GroupV gn = group_directions(rp, s_rec, 0, lane);
+#endif
+            bool stop = false;
+            for (int jg = 0; jg < n && !stop; jg += 4) {
+#if GRUT_FWD_MFMA == 1
+                const GroupV gv = gn;
+                if (jg + 4 < n) gn = group_directions(rp, s_rec, jg + 4, lane);   // in flight on the matrix pipe while this group is composited
+#else
+                const GroupV gv = group_directions(rp, s_rec, jg, lane);           // (2: no group ahead - 24 registers fewer; the other waves of the SIMD cover the latency)
+#endif
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jg + r;
+                    if (j >= n) break;
+                    if (!__any(alive0 || alive1)) { stop = true; break; }
+                    const float4* rec = &s_rec[j * kRecQuads];
+                    const PairGeom g = pair_geometry_given_v(p3{v2f{gv.x0[r], gv.x1[r]}, v2f{gv.y0[r], gv.y1[r]}, v2f{gv.z0[r], gv.z1[r]}}, rec);
+                    const bool c0 = g.acc0 && alive0, c1 = g.acc1 && alive1;
+                    if (COUNT) ++n_eval;
+                    if (!__any(c0 || c1)) continue;
+                    if (COUNT) ++n_acc;
+                    const float4 r3 = rec[3], r4 = rec[4];
+                    const v2f il2 = prcp(g.l2);
+                    const v2f gray = g.cc * il2;
+                    const v2f resp = pair_response<DEG>(gray);
+                    const v2f ad = resp * r3.w;
+                    // hit distance |S n (n.-u)| = |v.u| |S v| / |v|^2   (gaussianParticles.slang:181-190)
+                    const v2f vu = pdot(g.v, g.u);
+                    const p3 sv = p3{r3.x * g.v.x, r3.y * g.v.y, r3.z * g.v.z};
+                    const v2f ss = pdot(sv, sv) * (vu * vu);
+                    const v2f hitT = v2f{__builtin_amdgcn_sqrtf(ss.x), __builtin_amdgcn_sqrtf(ss.y)} * il2;
+                    const bool h0 = c0 && (hitT.x > rp.tmin.x) && (hitT.x < rp.tmax.x);
+                    const bool h1 = c1 && (hitT.y > rp.tmin.y) && (hitT.y < rp.tmax.y);
+                    const v2f alpha = psel(h0, h1, v2f{fminf(P.max_alpha, ad.x), fminf(P.max_alpha, ad.y)}, splat(0.f));
+                    const v2f hT = psel(h0, h1, hitT, splat(0.f));
+                    const v2f w = alpha * T;
+                    D = pfma(hT, w, D);
+                    T = T * (1.f - alpha);
+                    Cr = pfma(r4.x, w, Cr);
+                    Cg = pfma(r4.y, w, Cg);
+                    Cb = pfma(r4.z, w, Cb);
+                    cnt += psel(w.x > 0.f, w.y > 0.f, splat(1.f), splat(0.f));
+                    alive0 = alive0 && !(T.x < P.min_transmittance);
+                    alive1 = alive1 && !(T.y < P.min_transmittance);
+                }
+            }
+        } else
+#endif
         for (int j = 0; j < n; ++j) {
             if (!__any(alive0 || alive1)) break;   // the rest of the round is behind every pixel's termination
             const float4* rec = &s_rec[j * kRecQuads];

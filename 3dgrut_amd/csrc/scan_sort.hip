@@ -341,6 +341,10 @@ __global__ __launch_bounds__(kSortThreads) void radix_scatter_kernel(const uint3
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kFlagAgg = 1u << 30, kFlagPrefix = 2u << 30, kCountMask = (1u << 30) - 1u;
 constexpr int kMaxPasses = 4;
+#ifndef GRUT_SORT_LOOKBACK
+#define GRUT_SORT_LOOKBACK 8
+#endif
+constexpr int kLookback = GRUT_SORT_LOOKBACK;
 
 __global__ __launch_bounds__(kSortThreads) void radix_global_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ n_dev,
                                                                          int begin_bit, int width, int passes, int end_bit,
@@ -442,13 +446,29 @@ __global__ __launch_bounds__(kSortThreads) void radix_onesweep_kernel(const uint
             uint32_t* mine = status + (size_t)tile * kRadix + d;
             __hip_atomic_store(mine, (tile == 0 ? kFlagPrefix : kFlagAgg) | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (tile > 0) {
-                uint32_t t = tile - 1;
-                while (true) {
-                    const uint32_t w = __hip_atomic_load(status + (size_t)t * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((w >> 30) == 0u) { __builtin_amdgcn_s_sleep(1); continue; }
-                    before_tiles += w & kCountMask;
-                    if (w & kFlagPrefix) break;
-                    --t;   // (tile 0 publishes a prefix: the walk ends there at the latest)
+                // a window of kLookback predecessors per round trip (independent loads), consumed nearest first: the walk's dependent
+                // chain is what a pass waits for when a thousand tiles finish ranking together (one status word at a time: 92 us per
+                // 11.5 M-pair pass, no faster than the three-kernel pass it replaces)
+                int t = (int)tile - 1;
+                bool done = false;
+                while (!done) {
+                    uint32_t w[kLookback];
+#pragma unroll
+                    for (int k = 0; k < kLookback; ++k)
+                        w[k] = t - k >= 0 ? __hip_atomic_load(status + (size_t)(t - k) * kRadix + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kFlagPrefix;
+                    int used = 0;
+#pragma unroll
+                    for (int k = 0; k < kLookback; ++k) {
+                        if (!done && used == k) {
+                            if ((w[k] >> 30) != 0u) {
+                                before_tiles += w[k] & kCountMask;
+                                ++used;
+                                done = (w[k] & kFlagPrefix) != 0u;   // (tile 0 publishes a prefix: the walk ends there at the latest)
+                            }
+                        }
+                    }
+                    t -= used;
+                    if (!done && used == 0) __builtin_amdgcn_s_sleep(1);
                 }
                 __hip_atomic_store(mine, kFlagPrefix | (before_tiles + run), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -503,8 +523,13 @@ size_t sort_scratch_bytes(uint32_t n) {
     return legacy > onesweep ? legacy : onesweep;
 }
 
-static bool sort_legacy() {   // GRUT_SORT_LEGACY=1: the three-kernel passes (A/B measurements)
-    static const bool v = [] { const char* e = getenv("GRUT_SORT_LEGACY"); return e && e[0] == '1'; }();
+// Measured (round 5, one box, 1 M Gaussians @ 1080p, profiles/r05_sort_variants.txt): the one-sweep pass of the 11.5 M tile entries takes 92 us -
+// what histogram + row scan + scatter of the three-kernel pass take together - and the 1 M-key depth passes 25 us each against 22; with the
+// shared histogram kernel (22 us) and the status memset in front the frame is 0.06-0.08 ms SLOWER (2.07-2.09 against 2.00 ms), whatever the
+// look-back window (1 / 4 / 8 / 16 status words per round trip: 2.090 / 2.065 / 2.065-2.088 / 2.084 ms): the pass is not waiting for its
+// look-back.  The three-kernel passes stay the default; GRUT_SORT_ONESWEEP=1 selects these.
+static bool sort_legacy() {
+    static const bool v = [] { const char* e = getenv("GRUT_SORT_ONESWEEP"); return !(e && e[0] == '1'); }();
     return v;
 }
 

@@ -306,6 +306,22 @@ def identify_flips(cfg, cam, fwd, particle_rgb, pixels, hip_fd, hip_cnt, hip_dis
     return out, rounding, ratio
 
 
+def _pixel_diag(exempt, toggles, rounding, ratio, X, d_img, hip, shared, cap=48):
+    """The pixels a verdict hangs on, for analysis off the GPU box (the frame is seeded: the oracle's trace of a pixel can be repeated on
+    any host): unidentified pixels, and pixels with EQUAL hit counts beyond 1e-2 - flat index, the GPU's values, the oracle's, and what
+    identify_flips concluded."""
+    Xf, df = X.reshape(-1), d_img.reshape(-1)
+    fd, ofd = hip["fd"].reshape(-1, hip["fd"].shape[-1]), shared["feat_density"].reshape(-1, shared["feat_density"].shape[-1])
+    rows = []
+    for k, pix in enumerate(exempt):
+        if toggles[k] < 0 or (not Xf[pix] and df[pix] > 1e-2):
+            rows.append(dict(pix=int(pix), toggles=int(toggles[k]), rounding=bool(rounding[k]), ratio=float(ratio[k]), flip=bool(Xf[pix]),
+                             err=float(df[pix]), hip_cnt=float(hip["cnt"].reshape(-1)[pix]), ora_cnt=float(shared["hit_count"].reshape(-1)[pix]),
+                             hip_dist=float(hip["dist"].reshape(-1)[pix]), ora_dist=float(shared["hit_distance"].reshape(-1)[pix]),
+                             hip_fd=[float(v) for v in fd[pix][:4]] + [float(fd[pix][-1])], ora_fd=[float(v) for v in ofd[pix][:4]] + [float(ofd[pix][-1])]))
+    return rows[:cap]
+
+
 def _half_ulp(x):
     """half an ulp of IEEE half at |x| (the rounding of FEATURE_OUTPUT_HALF)"""
     return 0.5 * np.spacing(np.abs(np.asarray(x, np.float32)).astype(np.float16)).astype(np.float32)
@@ -371,6 +387,7 @@ def gut_full_parity(n, w, h, median_scale, seed=42, view=0, log=None, with_backw
                  B_max_rgb_err_outside_flips=float(d_img[~X].max()), B_max_dist_err_outside_flips=float(d_dist[~X].max()),
                  B_max_rgb_err_in_flips=float(d_img[X].max()) if X.any() else 0.0,
                  B_hit_count_l1_in_flips=float(np.abs(hip["cnt"] - shared["hit_count"][..., 0])[X].mean()) if X.any() else 0.0)
+    stats["B_diag"] = _pixel_diag(exempt, toggles, rounding, ratio, X, d_img, hip, shared)
     # ---- end to end: the oracle with its own binning ---------------------------------------------------------------------
     if own is not None:
         if half:
@@ -460,6 +477,7 @@ def gut_full_parity_nht(n, w, h, median_scale, seed=42, view=0, log=None, device
                  B_rounding_class_max_err=float(d_img_f[exempt][pure].max()) if pure.any() else 0.0,
                  B_rounding_class_max_dist_err=float(d_dist_f[exempt][pure].max()) if pure.any() else 0.0,
                  B_rounding_class_max_ratio_to_bound=float(ratio[rounding].max()) if rounding.any() else 0.0, t_identify_s=time.time() - t0)
+    stats["B_diag"] = _pixel_diag(exempt, toggles, rounding, ratio, X, d_img, hip, shared)
     g_fd = np.random.default_rng(seed + 2).normal(size=(h, w, 25)).astype(np.float32)
     g_fd[X | bad] = 0.0
     g = hip["gaussians"]
@@ -604,6 +622,9 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
     stats["T_rays_order_differs"] = int(((ids[sel] != ora["hit_ids"]) & live).any(1).sum())
     stats["T_processed_hits_compared"] = int(k.sum())
     stats["T_max_hits_per_ray"] = int(o_num.max())
+    differs = np.flatnonzero(((ids[sel] != ora["hit_ids"]) & live).any(1) | (num[sel] != o_num))
+    stats["T_diag"] = [dict(ray=int(sel[j]), hip_num=int(num[sel][j]), ora_num=int(o_num[j]), hip_ids=[int(v) for v in ids[sel][j][:min(int(num[sel][j]), hit_cap)]],
+                            ora_ids=[int(v) for v in ora["hit_ids"][j][:min(int(o_num[j]), hit_cap)]]) for j in differs[:16]]
     f_s, d_s, h_s, c_s = feat.reshape(-1, 3)[sel], dns.reshape(-1)[sel], hit.reshape(-1, 2)[sel], cnt.reshape(-1)[sel]
     # identified flips: rays whose number of processed or of accepted hits differs (alpha / response / transmittance thresholds of
     # processHit evaluated with different rounding on identical, identically ordered candidates)
