@@ -106,9 +106,21 @@ __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const 
         lo[0] = cx - hx; lo[1] = cy - hy; lo[2] = cz - hz; hi[0] = cx + hx; hi[1] = cy + hy; hi[2] = cz + hz;
         float* b = aabb + 6 * (size_t)i;
         b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2]; b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
-        // how far the hit distance can precede the ray's entry into the (padded) box: sqrt(2) max kscl for the cube; for the custom
-        // primitives' WORLD box (the cube's bounding box: the closest approach to the centre of a line through it lies within the half diagonal)
-        slack[i] = P.prim == GRUT_PRIM_CUSTOM ? 1.0001f * sqrtf(hx * hx + hy * hy + hz * hz) : 1.41421356237f * 1.0001f * fmaxf(e0, fmaxf(e1, e2));
+        // how far the hit distance can precede the ray's entry into the (padded) box: sqrt(2) max kscl for the cube.  Custom primitives: the
+        // reported distance t* minimises |W (o + t d - mu)| - the closest approach in the particle's SCALED frame, not in world space - and the
+        // ray only has to touch the WORLD box.  With p = o + t_p d any point of the ray inside that box, y(t) = W (p - mu) + (t - t_p) W d
+        // and y(t*) perpendicular to W d:  |t* - t_p| <= |W (p - mu)| / |W d| <= kmax sqrt(s0^2 + s1^2 + s2^2),  s_i = sum_j |W_ij| h_j
+        // (|p - mu|_j <= h_j, |W d| >= 1 / kmax for a unit direction).  Until round 5 this was the box's half diagonal - the bound of the
+        // EUCLIDEAN closest approach, too small by up to the particle's anisotropy: found by the 1 M-particle parity run (one ray in 4 296
+        // lost a particle whose t* preceded its box by 1.14 half diagonals; tests/test_grt_custom_slack_cpu.py checks the bound as mathematics)
+        if (P.prim == GRUT_PRIM_CUSTOM) {
+            const float s0 = (fabsf(rt.r0.x) * hx + fabsf(rt.r0.y) * hy + fabsf(rt.r0.z) * hz) / k0;
+            const float s1 = (fabsf(rt.r1.x) * hx + fabsf(rt.r1.y) * hy + fabsf(rt.r1.z) * hz) / k1;
+            const float s2 = (fabsf(rt.r2.x) * hx + fabsf(rt.r2.y) * hy + fabsf(rt.r2.z) * hz) / k2;
+            slack[i] = 1.0001f * fmaxf(k0, fmaxf(k1, k2)) * sqrtf(s0 * s0 + s1 * s1 + s2 * s2);
+        } else {
+            slack[i] = 1.41421356237f * 1.0001f * fmaxf(e0, fmaxf(e1, e2));
+        }
     }
     // scene box: one set of atomics per wave, spread over kSceneReplicas cache lines (15 k waves hammering six words of
     // ONE line serialised in L2 and cost 1 ms of this kernel's 1.07 ms); the Morton kernel folds the replicas
@@ -1427,8 +1439,8 @@ __device__ __forceinline__ void process_hit_bwd(const GrtTraceParams& P, const R
 // integrates ray_dim features per ray: the trace kernel's register budget (128, four waves per SIMD) has no room for 24 accumulators.
 // ---------------------------------------------------------------------------------------------
 constexpr int kGrtNhtMaxRay = 32, kGrtNhtMaxIpd = 16;
-__device__ __forceinline__ float grt_nht_sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189535f); }
-__device__ __forceinline__ float grt_nht_cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
+__device__ __forceinline__ float grt_nht_sin(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189535f)); }
+__device__ __forceinline__ float grt_nht_cos(float x) { return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x * 0.15915494309189535f)); }
 struct NhtTetra {
     f3 v0, e1, e2, e3, c23, gw0, gw1, gw2, gw3;
     float inv_det;

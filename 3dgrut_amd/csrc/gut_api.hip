@@ -196,8 +196,13 @@ static int ensure_intersection_scratch(GutHandle* h, uint32_t I, uint32_t tiles)
     GRUT_CHECK(h->tile_sort_scratch.ensure(sort_scratch_bytes((uint32_t)n), 1.3f));
     GRUT_CHECK(h->ranges.ensure((size_t)tiles * 8 + 8));
     const size_t nb = (size_t)I / kGutSegment + 1;
-    GRUT_CHECK(h->ck_tc.ensure(nb * 4 * 64 * 16, 1.3f));
-    GRUT_CHECK(h->ck_d.ensure(nb * 4 * 64 * 4, 1.3f));
+    // {T, C} + D per segment boundary, half tile and pixel: 80 B of space per tile entry with 64-entry segments, touched only where a forward
+    // wave arrives alive.  Only the unsorted SH sweeps read them: the feature sweeps keep their own table (ck_nht below), the sorted mode
+    // and the strip kernels have no checkpoints - those configurations do not pay for the space (several GB at tens of millions of entries)
+    if (!h->params.nht && h->params.k_buffer == 0) {
+        GRUT_CHECK(h->ck_tc.ensure(nb * 4 * 64 * 16, 1.3f));
+        GRUT_CHECK(h->ck_d.ensure(nb * 4 * 64 * 4, 1.3f));
+    }
     GRUT_CHECK(h->ck_reached.ensure(nb * 4, 1.3f));
     GRUT_CHECK(h->ck_boundary_tile.ensure(nb * 4, 1.3f));
     h->checkpoints.tc = h->ck_tc.as<float4>();

@@ -1555,7 +1555,14 @@ void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges
     // when every wave of the launch is resident at once (<= 5 half-tile waves per SIMD x 1024 SIMDs) the longest wave is the kernel: quarter tiles
     const char* quarter_str = getenv("GRUT_FWD_QUARTER");   // development / test switch (read per call): 0 / 1 force, default by size
     const int quarter_env = quarter_str ? atoi(quarter_str) : -1;
-    const bool quarter = quarter_env >= 0 ? quarter_env != 0 : half_grid(P) <= 5120u;
+    // (5 waves x 4 SIMDs per compute unit, from the device's own CU count: 5120 on the 256 CUs of an MI355X)
+    static const uint32_t resident_limit = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 5120u;
+        return 20u * (uint32_t)prop.multiProcessorCount;
+    }();
+    const bool quarter = quarter_env >= 0 ? quarter_env != 0 : half_grid(P) <= resident_limit;
     if (quarter && !(P.work && P.degree == 2 && write_checkpoints)) {
         const dim3 grid(half_grid(P) * 2u);
         if (write_checkpoints) {
@@ -1619,8 +1626,8 @@ constexpr int kNhtMaxRay = 32, kNhtMaxIpd = 16;
 // sin / cos of the activation on the hardware's v_sin_f32 / v_cos_f32 (argument in revolutions; absolute error ~1e-6 for the |angle| < 256
 // this model produces — features are initialised in [-pi/2, pi/2] and multiplied by at most the frequency index): the library sinf / cosf
 // cost ~40 instructions each, 48 of them per hit and pixel made up five sixths of the first version's forward
-__device__ __forceinline__ float nht_sin(float x) { return __builtin_amdgcn_sinf(x * 0.15915494309189535f); }
-__device__ __forceinline__ float nht_cos(float x) { return __builtin_amdgcn_cosf(x * 0.15915494309189535f); }
+__device__ __forceinline__ float nht_sin(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189535f)); }
+__device__ __forceinline__ float nht_cos(float x) { return __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(x * 0.15915494309189535f)); }
 __global__ __launch_bounds__(64) void gut_render_nht_fwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                                 const float4* __restrict__ density12, const float* __restrict__ features,
                                                                 const float* __restrict__ ray_o, const float* __restrict__ ray_d,

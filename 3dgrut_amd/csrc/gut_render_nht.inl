@@ -44,8 +44,10 @@ __device__ __forceinline__ NhtTet nht_tet() {
     return t;
 }
 __device__ __forceinline__ v2f nht_weight(f3 gw, float c, const p3& a) { return pfma(gw.x, a.x, pfma(gw.y, a.y, pfma(gw.z, a.z, splat(c)))); }
-__device__ __forceinline__ v2f nht_sin2(v2f rev) { return v2f{__builtin_amdgcn_sinf(rev.x), __builtin_amdgcn_sinf(rev.y)}; }
-__device__ __forceinline__ v2f nht_cos2(v2f rev) { return v2f{__builtin_amdgcn_cosf(rev.x), __builtin_amdgcn_cosf(rev.y)}; }
+// (v_sin_f32 / v_cos_f32 take revolutions and return 0 outside [-256, 256]: the argument is reduced with v_fract_f32 first - exact, one
+// instruction - so features that drift far from their initial [-pi/2, pi/2] during training keep their activation)
+__device__ __forceinline__ v2f nht_sin2(v2f rev) { return v2f{__builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev.x)), __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(rev.y))}; }
+__device__ __forceinline__ v2f nht_cos2(v2f rev) { return v2f{__builtin_amdgcn_cosf(__builtin_amdgcn_fractf(rev.x)), __builtin_amdgcn_cosf(__builtin_amdgcn_fractf(rev.y))}; }
 constexpr float kInvTwoPi = 0.15915494309189535f;
 
 // Stages the feature rows of a round's entries: lane l takes the vertex pair (l & 1) of entry l >> 1 - 24 consecutive floats - and

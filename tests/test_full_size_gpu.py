@@ -55,11 +55,12 @@ def test_gut_non_default_configurations_meet_the_staged_method_at_baseline_size(
     # sorted mode: the k-buffer orders hits by their fp32 hit distance.  Until round 4 the kernels and the checker evaluated that distance
     # in different operation orders, pairs of hits that tie to rounding popped in either order and 0.34 % of the frame needed an exemption
     # of its own.  Now the kernels evaluate it in the checker's order (csrc/gut_render.hip: oracle_order_hit_t): same bits, same order, the
-    # DEFAULT limits - and nothing beyond 1e-2 outside the identified accept / termination flips.
+    # DEFAULT limits (measured round 5: 0.055 % exempt, every pixel identified, no order swap among the toggles) - and nothing beyond 1e-2
+    # outside the identified accept / termination flips.
     pu.record_full_parity(f"c4_1m_1080p_{variant}", stats)
     pu.assert_gut_full_parity(stats)
-    if variant == "k16":
-        assert stats["B_max_rgb_err_outside_flips"] < 1e-2, stats
+    if variant == "k16":   # (outside the pixels where a decision was IDENTIFIED as taken the other way; an order tie is not among the decisions any more)
+        assert stats["B_max_rgb_err_outside_identified_flips"] < 1e-2, stats
 
 
 def test_gut_nht_frame_matches_oracle_at_baseline_size():

@@ -814,6 +814,35 @@ def test_nht_forward_matches_oracle(model_kw, half):
     assert np.abs(got[..., :nr]).max() > 0.3
 
 
+def test_nht_activation_survives_features_far_outside_the_initial_range():
+    """v_sin_f32 / v_cos_f32 return 0 for arguments beyond 256 revolutions; features that drift there during training would silently lose
+    their activation on the pixel-pair sweeps (they are initialised in [-pi/2, pi/2], nothing bounds them).  The argument is reduced first
+    (csrc/gut_render_nht.inl: v_fract_f32).  Features of +-2000..2600 rad = 320..410 revolutions: the image must follow the oracle's libm
+    sincos - loosely, 5e-3 absolute: one ulp of an fp32 angle of 2600 is 2.4e-4 rad before any kernel sees it - and must not be the
+    all-zero activation.  Both kernel families (pixel-pair fast path and the generic strip kernels) are held to it."""
+    scene = make_scene(n=3000, width=96, height=64, median_scale=0.06)
+    rng = np.random.default_rng(5)
+    feats = (rng.uniform(2000.0, 2600.0, size=(3000, 48)) * rng.choice([-1.0, 1.0], size=(3000, 48))).astype(np.float32)
+    nf = NHT_MODEL["nht_features"]
+    nht = dict(particle_feature_dim=48, interp_point_dim=12, support=1, activation=2, num_frequencies=nf["activation"]["num_frequencies"])
+    ora = oracle.gut_forward_nht(oracle.default_gut_config(), scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats,
+                                 *scene["rays"], nht=nht)
+    nr = oracle.nht_ray_feature_dim(nht)
+    assert np.abs(ora["feat_density"][..., :nr]).max() > 0.3
+    for generic in (False, True):
+        if generic:
+            os.environ["GRUT_NHT_GENERIC"] = "1"
+        try:
+            _, out = _nht_render(scene, feats, NHT_MODEL)
+        finally:
+            os.environ.pop("GRUT_NHT_GENERIC", None)
+        got = np.concatenate([out["pred_features"][0].cpu().numpy(), out["pred_opacity"][0].cpu().numpy()], -1)
+        flips = (out["hits_count"][0].cpu().numpy() != ora["hit_count"])[..., 0]
+        err = np.abs(got - ora["feat_density"]).max(-1)
+        assert flips.mean() <= 2e-3 and (err[~flips] > 5e-3).mean() <= 1e-3, (generic, float(err[~flips].max()), int(flips.sum()))
+        assert np.abs(got[..., :nr]).max() > 0.3, "the activation vanished"
+
+
 @pytest.mark.parametrize("name", ["nht", "nht_depth"])
 def test_nht_gradients_match_autograd_golden(name):
     """The nht backward (Slang autodiff output in the reference) against float64 torch.autograd of the restated forward
