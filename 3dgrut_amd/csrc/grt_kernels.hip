@@ -485,6 +485,20 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
         c.ok = c.box && want;
         return c;
     }
+    if (r.prim == GRUT_PRIM_TRISURFEL) {
+        // trisurfel (particlePrimitives.cu:155-205): two triangles = the rhombus |x| + |y| <= sqrt 2 of the proxy's z = 0 plane, traced WITHOUT
+        // face culling (referenceOptix.cu:62: SurfelPrimitive -> OPTIX_RAY_FLAG_NONE): the reported distance is the plane crossing's.  Same
+        // operations, same order in the CPU checker (oracle/grt_oracle.c: candidate, g_prim 6).
+        if (pdz == 0.f) { c.why = 2; return c; }
+        const float t = -poz / pdz;
+        const float hx = fmaf(t, pdx, pox), hy = fmaf(t, pdy, poy);
+        c.t = t; c.tnear = t; c.tfar = 3.0e38f;
+        c.box = fabsf(hx) + fabsf(hy) <= 1.4142135381698608f;
+        const bool want = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
+        c.why = c.box ? 1 : 2;
+        c.ok = c.box && want;
+        return c;
+    }
     // intersectInstanceParticle: hit distance = closest approach in the proxy's frame
     const float numerator = -fmaf(poz, pdz, fmaf(poy, pdy, pox * pdx));
     const float dd = fmaf(pdz, pdz, fmaf(pdy, pdy, pdx * pdx));
@@ -1087,12 +1101,51 @@ __device__ __forceinline__ HitGeom hit_geometry(const GrtTraceParams& P, const P
     g.grdu = g.giscl * g.rdr;
     const float l2 = dot(g.grdu, g.grdu);
     g.grd = l2 > 0.f ? g.grdu * (1.f / sqrtf(l2)) : g.grdu;
-    g.gcrod = cross(g.grd, g.gro);
+    if (P.prim == GRUT_PRIM_TRISURFEL) {
+        // PipelineParameters::SurfelPrimitive (gaussianParticles.cuh:371-400): the response is evaluated where the ray crosses the particle's
+        // z = 0 plane, gro + grd ghitT with ghitT = -gro.z / grd.z (component by component as the checker: (grd_k * -gro.z) / grd.z)
+        const float nz = -g.gro.z;
+        g.gcrod = mk3(g.gro.x + (g.grd.x * nz) / g.grd.z, g.gro.y + (g.grd.y * nz) / g.grd.z, g.gro.z + (g.grd.z * nz) / g.grd.z);
+    } else {
+        g.gcrod = cross(g.grd, g.gro);
+    }
     g.gray = dot(g.gcrod, g.gcrod);
     g.gres = particle_response<DEG>(g.gray);
     g.galpha = fminf(P.max_alpha, g.gres * p.density);
     g.accept = (g.gres > P.min_response) && (g.galpha > P.min_alpha);
     return g;
+}
+
+// The two places where processHitBwd depends on the primitive (gaussianParticles.cuh:558-565 and :628-659), shared by the traversal
+// backward and the log replay.  `surfel` is wave-uniform (GrtTraceParams::prim).
+// d hitT -> d grd, d gro: the volumetric primitives measure the distance to the point of maximum response (pdot = -grd . gro), the
+// surfel to the crossing of its z = 0 plane (pdot = -gro.z / grd.z, which depends on the z components only).  lead = gscl grdsRayHitGrd pdot.
+__device__ __forceinline__ void surfel_hit_distance_grads(bool surfel, const HitGeom& g, f3 lead, float pdot, float grdScaledDot, f3& grdRayHitGrd,
+                                                          f3& groRayHitGrd) {
+    if (surfel) {
+        grdRayHitGrd = lead - mk3(0.f, 0.f, (pdot / g.grd.z) * grdScaledDot);
+        groRayHitGrd = mk3(0.f, 0.f, -grdScaledDot / g.grd.z);
+    } else {
+        grdRayHitGrd = lead - g.gro * grdScaledDot;
+        groRayHitGrd = g.grd * (-grdScaledDot);
+    }
+}
+// d grayDist -> d grd, d gro: |grd x gro|^2 for the volumetric primitives, |gro + grd ghitT|^2 with ghitT = -gro.z / grd.z for the surfel
+__device__ __forceinline__ void gray_distance_grads(bool surfel, const HitGeom& g, float grayGrd, f3& grdGrd, f3& groGrd) {
+    if (surfel) {
+        const float ghitT = -g.gro.z / g.grd.z;
+        const f3 ghitPos = g.gro + g.grd * ghitT;
+        const f3 ghitPosGrd = ghitPos * (2.f * grayGrd);
+        groGrd = ghitPosGrd;
+        grdGrd = ghitPosGrd * ghitT;
+        const float ghitTGrd = g.grd.x * ghitPosGrd.x + g.grd.y * ghitPosGrd.y + g.grd.z * ghitPosGrd.z;
+        groGrd.z += -ghitTGrd / g.grd.z;
+        grdGrd.z += (g.gro.z * ghitTGrd) / (g.grd.z * g.grd.z);
+    } else {
+        const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
+        grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x, gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
+        groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z, gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1260,7 +1313,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                 const HitGeom g = hit_geometry<DEG>(P, p, r);
                 if (g.accept) {
                     const float weight = g.galpha * T;
-                    const float pdot = -dot(g.grd, g.gro);
+                    const bool surfel = P.prim == GRUT_PRIM_TRISURFEL;
+                    const float pdot = surfel ? -g.gro.z / g.grd.z : -dot(g.grd, g.gro);
                     const f3 grds = p.scl * g.grd * pdot;
                     const float hitT = sqrtf(dot(grds, grds));
                     const f3 u = P.nht ? mk3(0.f, 0.f, 0.f) : sh_radiance(P, sph, id, basis);   // (nht: the features come from the log, grt_nht_fwd_kernel)
@@ -1270,10 +1324,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                     depth = fmaf(hitT, weight, depth);
                     if (P.normals) {  // gaussianParticles.cuh:398-402
                         const f3 psr = mul_cols(p.rotT, p.scl);
-                        const f3 q = (g.gro + g.grd * (pdot - sqrtf(9.f - g.gray))) * psr;
-                        const float l2 = dot(q, q);
-                        const f3 n = l2 > 0.f ? q * (1.f / sqrtf(l2)) : q;
-                        nrm = nrm + n * weight;
+                        if (surfel) {   // the surfel's own normal, towards the side the ray comes from (:398-400)
+                            nrm = nrm + mk3(0.f, 0.f, (g.grd.z > 0.f ? 1.f : -1.f) * psr.z) * weight;
+                        } else {
+                            const f3 q = (g.gro + g.grd * (pdot - sqrtf(9.f - g.gray))) * psr;
+                            const float l2 = dot(q, q);
+                            const f3 n = l2 > 0.f ? q * (1.f / sqrtf(l2)) : q;
+                            nrm = nrm + n * weight;
+                        }
                     }
                     visibility[id] = 1;  // benign race: every writer stores the same value (referenceOptix.cu:158-161)
                     cnt += 1.f;
@@ -1354,7 +1412,8 @@ __device__ __forceinline__ void process_hit_bwd(const GrtTraceParams& P, const R
     const HitGeom g = hit_geometry<DEG>(P, p, r);
     if (g.accept) {
         const f3 gscl = p.scl;
-        const float pdot = -dot(g.grd, g.gro);
+        const bool surfel = P.prim == GRUT_PRIM_TRISURFEL;
+        const float pdot = surfel ? -g.gro.z / g.grd.z : -dot(g.grd, g.gro);
         const f3 grdd = g.grd * pdot;
         const f3 grds = gscl * grdd;
         const float gsq = dot(grds, grds);
@@ -1367,8 +1426,8 @@ __device__ __forceinline__ void process_hit_bwd(const GrtTraceParams& P, const R
         const f3 grdsRayHitGrd = gsq > 0.f ? grds * ((2.f * weight) / (2.f * gdist) * depth_grad) : mk3(0.f, 0.f, 0.f);
         const f3 gsclRayHitGrd = grdd * grdsRayHitGrd;
         const float grdScaledDot = dot(grdsRayHitGrd * gscl, g.grd);
-        const f3 grdRayHitGrd = gscl * grdsRayHitGrd * pdot - g.gro * grdScaledDot;
-        const f3 groRayHitGrd = g.grd * (-grdScaledDot);
+        f3 grdRayHitGrd, groRayHitGrd;
+        surfel_hit_distance_grads(surfel, g, gscl * grdsRayHitGrd * pdot, pdot, grdScaledDot, grdRayHitGrd, groRayHitGrd);
         const float resTrm = g.galpha < 0.999999f ? T_fin / (1.f - g.galpha) : T;
         const float galphaRayDnsGrd = resTrm * -T_grad;
 
@@ -1397,11 +1456,8 @@ __device__ __forceinline__ void process_hit_bwd(const GrtTraceParams& P, const R
         atomicAdd(gd + 3, g.gres * common);
         const float gresGrd = p.density * common;
         const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, gresGrd);
-        const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
-        const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x,
-                              gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
-        const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z,
-                              gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
+        f3 grdGrd, groGrd;
+        gray_distance_grads(surfel, g, grayGrd, grdGrd, groGrd);
         const f3 groTot = groGrd + groRayHitGrd;
         const f3 is2 = g.giscl * g.giscl;
         const f3 gsclGrdGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;
@@ -2024,7 +2080,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_REPLAY_W
                     const Particle p = load_particle(density12, id);
                     const HitGeom g = hit_geometry<DEG>(P, p, r);
                     if (g.accept) {
-                        const float pdot = -dot(g.grd, g.gro);
+                        const bool surfel = P.prim == GRUT_PRIM_TRISURFEL;
+                        const float pdot = surfel ? -g.gro.z / g.grd.z : -dot(g.grd, g.gro);
                         const f3 grdd = g.grd * pdot;
                         const f3 grds = p.scl * grdd;
                         const float gsq = dot(grds, grds);
@@ -2058,15 +2115,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_REPLAY_W
                         const f3 grdsRayHitGrd = gsq > 0.f ? grds * (wd / gdist) : mk3(0.f, 0.f, 0.f);
                         const f3 gsclRayHitGrd = grdd * grdsRayHitGrd;
                         const float grdScaledDot = dot(grdsRayHitGrd * gscl, g.grd);
-                        const f3 grdRayHitGrd = gscl * grdsRayHitGrd * pdot - g.gro * grdScaledDot;
-                        const f3 groRayHitGrd = g.grd * (-grdScaledDot);
+                        f3 grdRayHitGrd, groRayHitGrd;
+                        surfel_hit_distance_grads(surfel, g, gscl * grdsRayHitGrd * pdot, pdot, grdScaledDot, grdRayHitGrd, groRayHitGrd);
                         const float gresGrd = p.density * common;
                         const float grayGrd = particle_response_grd<DEG>(g.gray, g.gres, gresGrd);
-                        const f3 gcrodGrd = g.gcrod * (2.f * grayGrd);
-                        const f3 grdGrd = mk3(gcrodGrd.z * g.gro.y - gcrodGrd.y * g.gro.z, gcrodGrd.x * g.gro.z - gcrodGrd.z * g.gro.x,
-                                              gcrodGrd.y * g.gro.x - gcrodGrd.x * g.gro.y);
-                        const f3 groGrd = mk3(gcrodGrd.y * g.grd.z - gcrodGrd.z * g.grd.y, gcrodGrd.z * g.grd.x - gcrodGrd.x * g.grd.z,
-                                              gcrodGrd.x * g.grd.y - gcrodGrd.y * g.grd.x);
+                        f3 grdGrd, groGrd;
+                        gray_distance_grads(surfel, g, grayGrd, grdGrd, groGrd);
                         const f3 groTot = groGrd + groRayHitGrd;
                         const f3 is2 = g.giscl * g.giscl;
                         const f3 gsclGrdGro = mk3(-g.gposcr.x * is2.x, -g.gposcr.y * is2.y, -g.gposcr.z * is2.z) * groTot;

@@ -48,7 +48,7 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
     prim = _conf_get(render, "primitive_type", "instances")
     if prim not in _abi.GRT_PRIMITIVES:
         raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (provided: {tuple(_abi.GRT_PRIMITIVES)}; "
-                                  "trihexa / trisurfel / sphere proxies are not)")
+                                  "trihexa / sphere proxies are not)")
     if prim != "instances" and nht:
         raise NotImplementedError("3dgrut_amd: neural harmonic features are provided with primitive_type=instances only")
     cfg.primitive_type = _abi.GRT_PRIMITIVES[prim]

@@ -330,7 +330,11 @@ typedef struct GrtConfig {
      * The open meshes (trihexa, trisurfel) and `sphere` are GRUT_ERR_UNSUPPORTED. */
     int32_t primitive_type;
 } GrtConfig;
-enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON = 2, GRUT_PRIM_TETRAHEDRON = 3, GRUT_PRIM_DIAMOND = 4, GRUT_PRIM_CUSTOM = 5 };
+enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON = 2, GRUT_PRIM_TETRAHEDRON = 3, GRUT_PRIM_DIAMOND = 4, GRUT_PRIM_CUSTOM = 5,
+       /* trisurfel (particlePrimitives.cu:155-205): two triangles per particle = the rhombus |x| + |y| <= sqrt 2 of the proxy's z = 0 plane, traced
+        * WITHOUT face culling (referenceOptix.cu:62); the hit is the ray's crossing of that plane and the per-hit math takes its
+        * SurfelPrimitive branches (gaussianParticles.cuh:371-400, 512-521, 558-565, 628-659).  Tree walk (no packet lists). */
+       GRUT_PRIM_TRISURFEL = 6 };
 
 typedef struct GrtFrame {
     uint32_t frame_id;

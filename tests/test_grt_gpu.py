@@ -183,7 +183,7 @@ def test_refit_update_matches_full_rebuild():
 def test_errors_are_loud():
     gt = importlib.import_module("3dgrut_amd.grt_tracer")
     with pytest.raises(NotImplementedError):
-        gt.Tracer({"render": {"primitive_type": "trisurfel"}})
+        gt.Tracer({"render": {"primitive_type": "trihexa"}})
     tr = _tracer()
     scene = _scene(10, 8, 8, 0.2)
     g = syn.SimpleGaussians(scene["density12"], scene["sph"])
@@ -418,9 +418,81 @@ def test_custom_primitives_hit_order_equals_oracle():
     assert rel_err(gd[:, :11], rd[:, :11]) < 1e-3 and rel_err(gs, rs) < 1e-3
 
 
+def test_trisurfel_matches_reference_programs_golden():
+    """render.primitive_type = trisurfel (round 5) DIRECTLY against tests/golden/grt_trace_mesh.npz: trisurfel_* = the reference's forward /
+    backward programs compiled with PARTICLE_PRIMITIVE_TYPE = MOGTracingTriSurfel (the SurfelPrimitive branches of processHit / processHitBwd,
+    no face culling) over the emulated OptiX walking the two triangles per particle the reference's trisurfel kernel wrote - with the
+    hit-distance gradient flowing (the surfel's own d hitT chain) and through both backward paths (log replay, traversal)."""
+    import os
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    g = np.load(os.path.join(here, "golden", "grt_trace_mesh.npz"))
+    kw = make_golden.GRT_TRACE_SCENES[0]
+    scene = make_scene(**kw)
+    H, W = kw["height"], kw["width"]
+    g_rad, g_dns, g_hit = make_golden.grt_trace_upstream(H, W)
+    inst_img = np.load(os.path.join(here, "golden", "grt_trace.npz"))["s0_features"]
+    for replay in (True, False):
+        gpu = _render(scene, g_rad, g_dns, g_hit, primitive_type="trisurfel", backward_hit_replay=replay)
+        out = gpu["out"]
+        assert int(gpu["tracer"].tracer_wrapper.stats().list_entries) == 0      # (tree walk: the packet lists do not serve the flat proxies)
+        cnt = out["hits_count"][0].detach().cpu().numpy()
+        flips = (cnt != g["trisurfel_s0_hits_count"])[..., 0]
+        assert flips.mean() <= 0.02 and cnt.max() >= 20, f"{int(flips.sum())} rays with a different number of accepted hits"
+        feat = out["pred_features"][0].detach().cpu().numpy()
+        e = np.abs(feat - g["trisurfel_s0_features"]).max(-1)
+        hd = g["trisurfel_s0_hit_distance"]
+        e_d = np.abs(out["pred_dist"][0].detach().cpu().numpy() - hd[..., :1])[..., 0]
+        tied = ~flips & ((e > 1e-4) | (e_d > 1e-4 * max(1.0, np.abs(hd).max())))
+        assert tied.mean() <= 0.02 and (not tied.any() or e[tied].max() < 5e-2), f"{int(tied.sum())} rays differ with the same hit count"
+        ok = ~flips & ~tied
+        assert np.abs(out["pred_opacity"][0].detach().cpu().numpy() - g["trisurfel_s0_density"])[ok].max() < 1e-4
+        assert np.abs(feat - inst_img).max() > 1e-2       # not the instances' image: the response is evaluated at the plane crossing
+        vis = out["mog_visibility"].view(-1).view(torch.int32).cpu().numpy() != 0
+        ndrop = 3 * int((flips | tied).sum())
+        assert (vis != (g["trisurfel_s0_visibility"] != 0)).sum() <= ndrop
+        gd, gs = gpu["grads"]
+        rd, rs = g["trisurfel_s0_grad_density"], g["trisurfel_s0_grad_sph"]
+        per = np.sort(np.abs(gd[:, :11].astype(np.float64) - rd[:, :11]).max(1))[: max(1, len(gd) - ndrop)]
+        assert per.max() / np.abs(rd[:, :11]).max() < 1e-3, (replay, per.max() / np.abs(rd[:, :11]).max())
+        per = np.sort(np.abs(gs.astype(np.float64) - rs).max(1))[: max(1, len(gs) - ndrop)]
+        assert per.max() / np.abs(rs).max() < 1e-3, replay
+
+
+def test_trisurfel_hit_order_equals_oracle_and_gradients_follow():
+    """A larger scene through the debug hit lists: every ray's SEQUENCE of processed particles (plane-crossing distance, (t, id) ties) against
+    the oracle given the GPU-built proxy records - the candidate test is the checker's arithmetic operation by operation - then images,
+    accumulated normals (the surfel's own, gaussianParticles.cuh:398-400) and the gradients of both backward paths."""
+    scene = _scene(4000, 64, 48, 0.06)
+    tr, (feat, dns, hit, nrm, cnt, vis, ids, num), inst, scene_aabb = _gpu_hits(scene, primitive_type="trisurfel", enable_normals=True)
+    cfg = oracle.default_grt_config(primitive_type=6, enable_normals=1)
+    ora = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=scene_aabb, dbg_cap=256)
+    num = num.astype(np.int64)
+    assert np.array_equal(num, ora["hit_num"].astype(np.int64)), f"{(num != ora['hit_num']).sum()} rays with a different number of processed hits"
+    k = np.minimum(num, 256)
+    got, ref = ids.view(np.uint32), ora["hit_ids"]
+    for r in range(scene["H"] * scene["W"]):
+        assert np.array_equal(got[r, :k[r]], ref[r, :k[r]]), f"ray {r}: order differs"
+    assert num.max() > 20
+    assert np.abs(feat[0] - ora["features"]).max() < 1e-4 and np.abs(dns[0] - ora["density"]).max() < 1e-4 and np.array_equal(cnt[0], ora["hit_count"])
+    assert np.abs(nrm[0] - ora["normals"]).max() < 1e-4 and np.abs(ora["normals"]).max() > 0.05
+    rng = np.random.default_rng(4)
+    g_rad = rng.normal(size=(scene["H"], scene["W"], 3)).astype(np.float32)
+    g_dns = rng.normal(size=(scene["H"], scene["W"], 1)).astype(np.float32)
+    g_hit = rng.normal(size=(scene["H"], scene["W"], 1)).astype(np.float32)
+    rd, rs = oracle.grt_backward(cfg, 3, 1e-3, ora, g_rad, g_dns, g_hit)
+    for replay in (True, False):
+        gpu = _render(scene, g_rad, g_dns, g_hit, primitive_type="trisurfel", backward_hit_replay=replay)
+        gd, gs = gpu["grads"]
+        assert rel_err(gd[:, :11], rd[:, :11]) < 1e-3 and rel_err(gs, rs) < 1e-3, replay
+
+
 def test_unsupported_primitives_are_refused():
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
-    for prim in ("trihexa", "trisurfel", "sphere"):
+    for prim in ("trihexa", "sphere"):
         with pytest.raises(NotImplementedError, match="primitive_type"):
             grt.Tracer({"render": {"primitive_type": prim}})
 
