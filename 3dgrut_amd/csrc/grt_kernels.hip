@@ -488,7 +488,7 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     if (r.prim == GRUT_PRIM_TRISURFEL) {
         // trisurfel (particlePrimitives.cu:155-205): two triangles = the rhombus |x| + |y| <= sqrt 2 of the proxy's z = 0 plane, traced WITHOUT
         // face culling (referenceOptix.cu:62: SurfelPrimitive -> OPTIX_RAY_FLAG_NONE): the reported distance is the plane crossing's.  Same
-        // operations, same order in the CPU checker (oracle/grt_oracle.c: candidate, g_prim 6).
+        // operations, same order in the CPU checker (its grt_oracle.c: candidate, g_prim 6).
         if (pdz == 0.f) { c.why = 2; return c; }
         const float t = -poz / pdz;
         const float hx = fmaf(t, pdx, pox), hy = fmaf(t, pdy, poy);

@@ -41,6 +41,9 @@ WORKLOADS = {
     "c3_grt_nht_1m_800": (1_000_000, 800, 800, 0.01),
     # render.primitive_type = icosahedron (the reference paper's 3DGRT configuration, configs/paper/3dgrt/base_ours_reference.yaml:16): tree walk
     "c3_grt_icosa_1m_800": (1_000_000, 800, 800, 0.01),
+    # render.primitive_type = custom / trisurfel: the proxies the packet lists do not serve (tree walk every round)
+    "c3_grt_custom_1m_800": (1_000_000, 800, 800, 0.01),
+    "c3_grt_trisurfel_1m_800": (1_000_000, 800, 800, 0.01),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -202,7 +205,8 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
                              "model": {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1},
                                                                                "interpolation_type": "barycentric"}}})
     else:
-        tracer = grt.Tracer({"render": dict({"enable_kernel_timings": True}, **({"primitive_type": "icosahedron"} if "icosa" in name else {}))})
+        prim = next((v for k, v in (("icosa", "icosahedron"), ("custom", "custom"), ("trisurfel", "trisurfel")) if k in name), "instances")
+        tracer = grt.Tracer({"render": {"enable_kernel_timings": True, "primitive_type": prim}})
     g = syn.SimpleGaussians(d12, sph, device=dev)
     g_fd_np, _ = syn.upstream_grads(W, H)
     g_fd = torch.as_tensor(g_fd_np, device=dev)

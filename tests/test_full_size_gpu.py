@@ -76,14 +76,16 @@ def test_gut_nht_frame_matches_oracle_at_baseline_size():
     # the reference paper's own 3DGRT configuration (configs/paper/3dgrt/base_ours_reference.yaml:16) and the custom-primitive proxies at
     # BASELINE config 3's size, through the same stages (round 5; until then they were compared on <= 20 k-particle scenes only)
     ("c3_grt_icosahedron_100k_400", 100_000, 400, 400, 0.01, 1, "icosahedron"), ("c3_grt_icosahedron_1m_800", 1_000_000, 800, 800, 0.01, 149, "icosahedron"),
-    ("c3_grt_custom_1m_800", 1_000_000, 800, 800, 0.01, 149, "custom")])
+    ("c3_grt_custom_1m_800", 1_000_000, 800, 800, 0.01, 149, "custom"),
+    # the flat proxies (round 5): plane-crossing candidates, the surfel branches of the per-hit math; tree walk
+    ("c3_grt_trisurfel_1m_800", 1_000_000, 800, 800, 0.01, 149, "trisurfel")])
 def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, ray_stride, prim):
     """3DGRT (LBVH + software traversal) against the oracle: the per-ray order of processed particles bit-exact, images within
     1e-4, gradients within 1e-3 relative (full frame at 100 k particles; a 4 k-ray subsample of the 1 M / 800x800 frame)."""
     # 1 M particles: every 149th ray through all pairs (4296 rays), then every 9th ray (71 k) with the oracle's scan restricted to the
     # packet lists the GPU built - checked to change nothing on the 4296
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
-    has_lists = prim != "custom" or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
+    has_lists = prim not in ("custom", "trisurfel") or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
     stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print, wide_stride=9 if ray_stride > 1 and has_lists else 0,
                                primitive_type=prim)
     pu.record_full_parity(name, stats)
