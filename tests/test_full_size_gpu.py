@@ -155,13 +155,13 @@ def test_gut_frame_equals_the_reference_kernels_on_a_sample_at_baseline_size(nam
     assert len(untouched) <= 3 * nflip, "particles with a gradient that the reference's backward never touched"
 
 
-@pytest.mark.parametrize("prim", ["instances", "icosahedron", "custom"])
+@pytest.mark.parametrize("prim", ["instances", "icosahedron", "custom", "trisurfel"])
 def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_size(prim):
     """BASELINE config 3's frame (1 M Gaussians, 800 x 800) against the reference's OWN 3DGRT programs - referenceOptix.cu and
     referenceBwdOptix.cu compiled on the host over the emulated traversal, every ray offered every one of the 1 M instances
     (tests/golden/fullsize_grt_c3_1m_800.npz, 1536 rays on a regular sub-grid): accepted-hit counts, images, last-hit distances, and the
     gradient rows of the particles those rays' backward touches, with the upstream gradient confined to the sampled rays.
-    icosahedron (the paper's configuration) / custom: the programs built for that primitive over the reference's own meshes / world boxes
+    icosahedron (the paper's configuration) / custom / trisurfel: the programs built for that primitive over the reference's own meshes / world boxes
     of all 1 M particles, 6144 rays, each ray offered a conservative superset of the particles it can touch
     (tests/golden/fullsize_grt_<prim>_c3_1m_800.npz, make_fullsize_golden.py: make_grt_prim)."""
     import os

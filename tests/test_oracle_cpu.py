@@ -496,8 +496,8 @@ def test_grt_mesh_proxies_match_reference_programs_golden(prim):
 
 
 def test_grt_trisurfel_checker_matches_reference_programs_golden():
-    """render.primitive_type = trisurfel - NOT provided by the HIP plugin yet (it refuses the name); this pins the CHECKER for it, so that the
-    kernels have something to be compared with: the reference's forward / backward programs compiled with PARTICLE_PRIMITIVE_TYPE =
+    """render.primitive_type = trisurfel (provided by the HIP plugin since round 5: tests/test_grt_gpu.py::test_trisurfel_*); this pins the
+    CHECKER for it: the reference's forward / backward programs compiled with PARTICLE_PRIMITIVE_TYPE =
     MOGTracingTriSurfel (the surfel branches of processHit / processHitBwd, no face culling) over the emulated OptiX walking the two triangles
     per particle the reference's trisurfel kernel wrote, against the oracle (rhombus |x| + |y| <= sqrt 2 in the proxy's z = 0 plane, plane
     crossing as the hit, orc_grt: g_prim 6)."""
