@@ -190,9 +190,10 @@ def test_grt_configuration_defaults_and_unsupported_pipelines():
     # the Slang pipelines' names are accepted (same function, same kernels); other pipelines and proxies are refused
     grt.grt_config_from_conf({"render": {"pipeline_type": "referenceSlang", "backward_pipeline_type": "referenceSlangBwd"}})
     grt.grt_config_from_conf({"render": {"pipeline_type": "reference", "backward_pipeline_type": "referenceBwd"}})
-    # the closed triangle-mesh proxies of particlePrimitives.cu (icosahedron = the paper's configuration) and the custom primitives are provided
-    assert [grt.grt_config_from_conf({"render": {"primitive_type": p}}).primitive_type for p in ("instances", "icosahedron", "octahedron", "tetrahedron", "diamond", "custom")] == [0, 1, 2, 3, 4, 5]
-    for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "trisurfel"}, {"primitive_type": "sphere"}, {"backward_pipeline_type": "referenceB2FSlangBwd"},
+    # the closed triangle-mesh proxies of particlePrimitives.cu (icosahedron = the paper's configuration), the custom primitives and the flat trisurfel proxies are provided
+    assert [grt.grt_config_from_conf({"render": {"primitive_type": p}}).primitive_type
+            for p in ("instances", "icosahedron", "octahedron", "tetrahedron", "diamond", "custom", "trisurfel")] == [0, 1, 2, 3, 4, 5, 6]
+    for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "trihexa"}, {"primitive_type": "sphere"}, {"backward_pipeline_type": "referenceB2FSlangBwd"},
                 {"pipeline_type": "barycentricSurfels"}):
         with pytest.raises(NotImplementedError):
             grt.grt_config_from_conf({"render": bad})
