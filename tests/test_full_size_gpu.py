@@ -75,7 +75,8 @@ def test_gut_nht_frame_matches_oracle_at_baseline_size():
     ("c3_grt_100k_400", 100_000, 400, 400, 0.01, 1, "instances"), ("c3_grt_1m_800", 1_000_000, 800, 800, 0.01, 149, "instances"),
     # the reference paper's own 3DGRT configuration (configs/paper/3dgrt/base_ours_reference.yaml:16) and the custom-primitive proxies at
     # BASELINE config 3's size, through the same stages (round 5; until then they were compared on <= 20 k-particle scenes only)
-    ("c3_grt_icosahedron_100k_400", 100_000, 400, 400, 0.01, 1, "icosahedron"), ("c3_grt_icosahedron_1m_800", 1_000_000, 800, 800, 0.01, 149, "icosahedron"),
+    # (every ray with gradients at 100 k particles on 200 x 200 rays: the checker's 20-plane clip of all pairs took 352 s of the suite's 726 s at 400 x 400)
+    ("c3_grt_icosahedron_100k_200", 100_000, 200, 200, 0.01, 1, "icosahedron"), ("c3_grt_icosahedron_1m_800", 1_000_000, 800, 800, 0.01, 149, "icosahedron"),
     ("c3_grt_custom_1m_800", 1_000_000, 800, 800, 0.01, 149, "custom"),
     # the flat proxies (round 5): plane-crossing candidates, the surfel branches of the per-hit math; tree walk
     ("c3_grt_trisurfel_1m_800", 1_000_000, 800, 800, 0.01, 149, "trisurfel")])
