@@ -535,6 +535,20 @@ def main():
             exch.reduce()
 
     untouched = None
+    exchange_fallback = None
+    if world > 1 and exchange_kind == "factored" and chunks > 1:
+        # The pipelined exchange has run over gloo only (tests/test_dp_gloo.py, tests/test_dp_gpu.py): no multi-GPU box in five rounds.  Its
+        # first step over RCCL runs under a net - a failure is the same exception on every rank (same code, same shapes), so all ranks fall
+        # back together to the one-piece exchange, say so in the line, and the scaling curve is still measured.
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            exchange_fallback = f"pipelined exchange failed on its first step ({type(e).__name__}: {e}); one-piece exchange used"
+            if rank == 0:
+                print(f"[bench] {exchange_fallback}", file=sys.stderr, flush=True)
+            chunks = 1
+            tracer.gradient_exchange = dp.FactoredGradientExchange(average=False, timed=True, chunks=1)
     for it in range(args.warmup):
         step()
         if it == 0 and auto_exchange:
@@ -596,6 +610,8 @@ def main():
                     "note": "device time between issuing the collectives and their completion on the compute stream (RCCL over xGMI)",
                     "predicted": predicted_exchange(exchange_kind, world, n, getattr(tracer.gradient_exchange, "last_rows", None)),
                     "chunks": chunks if exchange_kind == "factored" else 1, "untouched_fraction": untouched}
+        if exchange_fallback:
+            exchange["fallback"] = exchange_fallback
     if rank == 0:
         P = W * H
         # every stage from the all-stage pass; the dominant kernel from the timed region itself
