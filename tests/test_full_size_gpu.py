@@ -86,7 +86,7 @@ def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, 
     # 1 M particles: every 149th ray through all pairs (4296 rays), then every 9th ray (71 k) with the oracle's scan restricted to the
     # packet lists the GPU built - checked to change nothing on the 4296
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
-    has_lists = prim not in ("custom", "trisurfel") or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
+    has_lists = prim != "custom" or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
     stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print, wide_stride=9 if ray_stride > 1 and has_lists else 0,
                                primitive_type=prim)
     pu.record_full_parity(name, stats)
