@@ -695,18 +695,43 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
         ro2, rd2 = ro.reshape(-1, 3)[sel2][None], rd.reshape(-1, 3)[sel2][None]
         oracle.grt_set_candidate_prefilter(ranges, entries, packet_of(sel2).astype(np.uint32))
         wide = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro2, rd2, inst=inst, scene=scene_aabb, dbg_cap=hit_cap, **box_kw)
-        oracle.grt_set_candidate_prefilter()
-        stats["t_oracle_wide_s"] = time.time() - t0
         w_num = wide["hit_num"].astype(np.int64)
         kk = np.minimum(np.minimum(num[sel2], w_num), hit_cap)
         live2 = np.arange(hit_cap)[None, :] < kk[:, None]
         F2 = (num[sel2] != w_num) | (cnt.reshape(-1)[sel2] != wide["hit_count"].reshape(-1))
+        e_rgb2 = np.abs(feat.reshape(-1, 3)[sel2] - wide["features"].reshape(-1, 3)).max(-1)
+        e_opa2 = np.abs(dns.reshape(-1)[sel2] - wide["density"].reshape(-1))
+        # ROUNDING class (as on the 3DGUT frames): same sequence, same decisions, value beyond 1e-4 of the float checker.  The surfel's response
+        # is evaluated at gro + grd (-gro.z / grd.z): for rays that graze a surfel's plane the quotient amplifies the last bits of grd.z, and the
+        # float checker itself sits that far from the exact value - such a ray must be no farther from the DOUBLE checker (same rays, same
+        # prefilter) than twice the float checker's own distance + 1e-4, and the class is bounded in number
+        over = np.flatnonzero(~F2 & ((e_rgb2 > 1e-4) | (e_opa2 > 1e-4)))
+        stats["W_rounding_rays"], stats["W_rounding_unexplained"] = int(over.size), 0
+        if 0 < over.size <= 512:
+            oracle.grt_set_candidate_prefilter(ranges, entries, packet_of(sel2[over]).astype(np.uint32))
+            ro3, rd3 = np.ascontiguousarray(ro2[:, over]), np.ascontiguousarray(rd2[:, over])
+            w64 = oracle.grt_forward(cfg, d12, sph, 3, tr._min_transmittance, T, ro3, rd3, inst=inst, scene=scene_aabb, dtype=np.float64, **box_kw)
+            f64, o64 = w64["features"].reshape(-1, 3), w64["density"].reshape(-1)
+            hip_f, hip_o = feat.reshape(-1, 3)[sel2][over], dns.reshape(-1)[sel2][over]
+            ora_f, ora_o = wide["features"].reshape(-1, 3)[over], wide["density"].reshape(-1)[over]
+            d_hip = np.maximum(np.abs(hip_f - f64).max(-1), np.abs(hip_o - o64))
+            d_ora = np.maximum(np.abs(ora_f - f64).max(-1), np.abs(ora_o - o64))
+            same64 = w64["hit_count"].reshape(-1) == wide["hit_count"].reshape(-1)[over]      # (the double checker took the same decisions)
+            explained = same64 & (d_hip <= 2.0 * d_ora + 1e-4)
+            stats["W_rounding_unexplained"] = int((~explained).sum())
+            stats["W_rounding_max_hip_vs_f64"], stats["W_rounding_max_f32_vs_f64"] = float(d_hip.max()), float(d_ora.max())
+            keep = np.ones(sel2.size, bool)
+            keep[over[explained]] = False
+        else:
+            keep = np.ones(sel2.size, bool)
+        oracle.grt_set_candidate_prefilter()
+        stats["t_oracle_wide_s"] = time.time() - t0
         stats.update(W_rays_compared=int(sel2.size), W_list_entries=int(entries.size),
                      W_rays_hit_number_differs=int((num[sel2] != w_num).sum()),
                      W_rays_order_differs=int(((ids[sel2] != wide["hit_ids"]) & live2).any(1).sum()),
                      W_processed_hits_compared=int(kk.sum()), W_flip_rays=int(F2.sum()),
-                     W_max_rgb_err_outside_flips=float(np.abs(feat.reshape(-1, 3)[sel2] - wide["features"].reshape(-1, 3)).max(-1)[~F2].max()),
-                     W_max_opacity_err_outside_flips=float(np.abs(dns.reshape(-1)[sel2] - wide["density"].reshape(-1))[~F2].max()),
+                     W_max_rgb_err_outside_flips=float(e_rgb2[~F2 & keep].max()),
+                     W_max_opacity_err_outside_flips=float(e_opa2[~F2 & keep].max()),
                      W_max_last_hit_t_abs_err_outside_flips=float(np.abs(hit.reshape(-1, 2)[sel2] - wide["hit_distance"].reshape(-1, 2))[~F2, 1].max()))
     # ---- stage G: gradients of the whole frame, upstream gradient zeroed on the flipped rays --------------------------------
     if with_backward and ray_stride == 1:
@@ -771,6 +796,7 @@ def assert_grt_full_parity(stats):
         assert stats["W_prefilter_changes_rays"] == 0, "restricting the oracle's scan to the GPU's packet lists changed a ray"
         assert stats["W_rays_compared"] >= 64000 and stats["W_rays_order_differs"] == 0, stats
         assert stats["W_flip_rays"] <= max(8, 2e-3 * stats["W_rays_compared"]), stats
+        assert stats["W_rounding_rays"] <= max(8, 2e-4 * stats["W_rays_compared"]) and stats["W_rounding_unexplained"] == 0, stats
         assert stats["W_max_rgb_err_outside_flips"] < 1e-4 and stats["W_max_opacity_err_outside_flips"] < 1e-4, stats
         assert stats["W_max_last_hit_t_abs_err_outside_flips"] == 0.0, stats   # the last hit distance is one of the identical candidates' t
     assert stats["T_rays_compared"] >= 4000
