@@ -41,7 +41,7 @@ WORKLOADS = {
     "c3_grt_nht_1m_800": (1_000_000, 800, 800, 0.01),
     # render.primitive_type = icosahedron (the reference paper's 3DGRT configuration, configs/paper/3dgrt/base_ours_reference.yaml:16): tree walk
     "c3_grt_icosa_1m_800": (1_000_000, 800, 800, 0.01),
-    # render.primitive_type = custom / trisurfel: the proxies the packet lists do not serve (tree walk every round)
+    # render.primitive_type = custom (world boxes: tree walk every round) / trisurfel (flat proxies, on the packet lists)
     "c3_grt_custom_1m_800": (1_000_000, 800, 800, 0.01),
     "c3_grt_trisurfel_1m_800": (1_000_000, 800, 800, 0.01),
 }

@@ -333,7 +333,7 @@ typedef struct GrtConfig {
 enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON = 2, GRUT_PRIM_TETRAHEDRON = 3, GRUT_PRIM_DIAMOND = 4, GRUT_PRIM_CUSTOM = 5,
        /* trisurfel (particlePrimitives.cu:155-205): two triangles per particle = the rhombus |x| + |y| <= sqrt 2 of the proxy's z = 0 plane, traced
         * WITHOUT face culling (referenceOptix.cu:62); the hit is the ray's crossing of that plane and the per-hit math takes its
-        * SurfelPrimitive branches (gaussianParticles.cuh:371-400, 512-521, 558-565, 628-659).  Tree walk (no packet lists). */
+        * SurfelPrimitive branches (gaussianParticles.cuh:371-400, 512-521, 558-565, 628-659). */
        GRUT_PRIM_TRISURFEL = 6 };
 
 typedef struct GrtFrame {
