@@ -112,12 +112,19 @@ __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const 
         // and y(t*) perpendicular to W d:  |t* - t_p| <= |W (p - mu)| / |W d| <= kmax sqrt(s0^2 + s1^2 + s2^2),  s_i = sum_j |W_ij| h_j
         // (|p - mu|_j <= h_j, |W d| >= 1 / kmax for a unit direction).  Until round 5 this was the box's half diagonal - the bound of the
         // EUCLIDEAN closest approach, too small by up to the particle's anisotropy: found by the 1 M-particle parity run (one ray in 4 296
-        // lost a particle whose t* preceded its box by 1.14 half diagonals; tests/test_grt_custom_slack_cpu.py checks the bound as mathematics)
+        // lost a particle whose t* preceded its box by 1.14 half diagonals; tests/test_grt_custom_slack_cpu.py checks both bounds as mathematics)
         if (P.prim == GRUT_PRIM_CUSTOM) {
             const float s0 = (fabsf(rt.r0.x) * hx + fabsf(rt.r0.y) * hy + fabsf(rt.r0.z) * hz) / k0;
             const float s1 = (fabsf(rt.r1.x) * hx + fabsf(rt.r1.y) * hy + fabsf(rt.r1.z) * hz) / k1;
             const float s2 = (fabsf(rt.r2.x) * hx + fabsf(rt.r2.y) * hy + fabsf(rt.r2.z) * hz) / k2;
-            slack[i] = 1.0001f * fmaxf(k0, fmaxf(k1, k2)) * sqrtf(s0 * s0 + s1 * s1 + s2 * s2);
+            const float kmax = fmaxf(k0, fmaxf(k1, k2));
+            // ... and a second bound for the candidates that can be ACCEPTED - the only ones pruning must not lose: the program accepts
+            // |W (x* - mu)| ks < 3, i.e. |x* - mu| < 3 kmax / ks = 3 max scl, and p lies within the box's half diagonal of mu:
+            // |t* - t_p| = |x* - p| <= 3 max scl + half diagonal.  For needles (kmax / kmin in the hundreds) this is a few kmax where the
+            // first bound is hundreds of kmax; the smaller of the two is used.
+            const float by_metric = kmax * sqrtf(s0 * s0 + s1 * s1 + s2 * s2);
+            const float by_accept = 3.f * (kmax / ks) + sqrtf(hx * hx + hy * hy + hz * hz);
+            slack[i] = 1.0001f * fminf(by_metric, by_accept);
         } else {
             slack[i] = 1.41421356237f * 1.0001f * fmaxf(e0, fmaxf(e1, e2));
         }
