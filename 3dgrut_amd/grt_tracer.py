@@ -49,8 +49,11 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
     if prim not in _abi.GRT_PRIMITIVES:
         raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (provided: {tuple(_abi.GRT_PRIMITIVES)}; "
                                   "trihexa / sphere proxies are not)")
-    if prim != "instances" and nht:
-        raise NotImplementedError("3dgrut_amd: neural harmonic features are provided with primitive_type=instances only")
+    if nht and prim not in ("instances", "icosahedron", "octahedron", "tetrahedron", "diamond"):
+        # (the feature path walks the trace kernel's hit log and evaluates the features at each hit's canonical intersection: it does not care
+        # which candidate test ordered the log - instances and the closed mesh proxies; the surfel / world-box per-hit variants are not built)
+        raise NotImplementedError("3dgrut_amd: neural harmonic features are provided with primitive_type instances / icosahedron / octahedron / "
+                                  "tetrahedron / diamond only")
     cfg.primitive_type = _abi.GRT_PRIMITIVES[prim]
     # fp16 feature I/O (setup_3dgrt.py:41-44): run-time switches here, compile-time macros in the reference
     cfg.particle_feature_half = int(bool(_conf_get(render, "particle_feature_half", False)))

@@ -448,6 +448,45 @@ def make_grt_trace_nht():
     print("wrote grt_trace_nht.npz")
 
 
+def make_grt_trace_nht_mesh():
+    """tests/golden/grt_trace_nht_mesh.npz: the SLANG forward pipeline with neural harmonic features compiled for the ICOSAHEDRON proxies
+    (oracle/_ref/libref_grt_trace_slang_IcosaHedron_deg4.so: referenceSlangOptix.cu with PARTICLE_PRIMITIVE_TYPE = MOGTracingIcosaHedron over
+    the emulated OptiX's built-in triangles, back faces culled), meshes from the reference's own mesh kernel - model.feature_type nht together
+    with render.primitive_type icosahedron (round 5).  Scene 0 of GRT_TRACE_SCENES."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import make_scene
+    px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    px.ref_enclosing_mesh.restype = C.c_uint
+    fw = C.CDLL(os.path.join(REF, "libref_grt_trace_slang_IcosaHedron_deg4.so"))
+    assert fw.ref_grt_slang_ray_feature_dim() == 24
+    out = {}
+    code, _ = MESH_PRIMITIVES["icosahedron"]
+    for k, kw in enumerate(GRT_TRACE_SCENES[:1]):
+        sc = make_scene(**kw)
+        d12 = np.ascontiguousarray(sc["density12"])
+        n, H, W = len(d12), kw["height"], kw["width"]
+        feats = nht_features(n, seed=55 + k)
+        pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
+                              np.ascontiguousarray(d12[:, 3]))
+        verts, tris, nv = np.zeros((n * 12, 3), F), np.zeros((n * 20, 3), np.int32), C.c_uint(0)
+        nt = px.ref_enclosing_mesh(code, C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(verts), _p(tris),
+                                   C.byref(nv))
+        verts, tris = np.ascontiguousarray(verts[:n * nv.value]), np.ascontiguousarray(tris[:n * nt])
+        box = np.concatenate([verts.min(0), verts.max(0)]).astype(F)
+        r2w = np.ascontiguousarray(np.asarray(sc["batch"]["T_to_world"][0], F)[:3, :4])
+        ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)) for a in sc["rays"])
+        feat, den, hit = np.zeros((H, W, 24), F), np.zeros((H, W, 1), F), np.zeros((H, W, 2), F)
+        cnt, vis = np.zeros((H, W, 1), F), np.zeros(n, np.int32)
+        fw.ref_grt_trace_slang_fwd_mesh(C.c_uint(n), C.c_uint(nt), _p(verts), _p(tris), _p(d12), _p(feats), W, H, _p(r2w), _p(ro), _p(rd), _p(box),
+                                        C.c_float(MIN_T_GRT), C.c_float(MIN_RESPONSE), C.c_float(MIN_ALPHA), _p(feat), _p(den), _p(hit), _p(cnt), _p(vis))
+        for name, a in dict(nht_features=feats, features=feat, density=den, hit_distance=hit, hits_count=cnt, visibility=vis, scene_box=box).items():
+            out[f"icosahedron_s{k}_{name}"] = a
+        print(f"grt nht icosahedron scene {k}: hits per ray {cnt.mean():.1f}, |features| mean {np.abs(feat).mean():.3f}")
+    np.savez_compressed(os.path.join(HERE, "grt_trace_nht_mesh.npz"), **out)
+    print("wrote grt_trace_nht_mesh.npz")
+
+
 def make_grt_trace_slang_sh():
     """tests/golden/grt_trace_slang_sh.npz: the reference's SLANG forward pipeline (referenceSlangOptix.cu) with SH radiance — the
     configuration render.pipeline_type = referenceSlang of a model.feature_type = sh run — on the scenes of grt_trace.npz, so that the two
@@ -786,7 +825,7 @@ def make_playground():
 if __name__ == "__main__":
     import sys
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
-    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "grt_trace_mesh", "gut_render", "playground", "gut_nht", "grt_trace_nht", "grt_trace_slang_sh"]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "grt_trace_mesh", "gut_render", "playground", "gut_nht", "grt_trace_nht", "grt_trace_nht_mesh", "grt_trace_slang_sh"]
     if "--adam-only" in sys.argv:
         which = ["adam"]
     if "per_hit" in which:
@@ -812,5 +851,7 @@ if __name__ == "__main__":
         make_gut_nht()
     if "grt_trace_nht" in which:
         make_grt_trace_nht()
+    if "grt_trace_nht_mesh" in which:
+        make_grt_trace_nht_mesh()
     if "grt_trace_slang_sh" in which:
         make_grt_trace_slang_sh()

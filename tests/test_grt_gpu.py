@@ -854,6 +854,71 @@ def test_nht_backward_matches_oracle(replay, half):
     assert trimmed(gf, rf, 3 * n_flip) < 1e-3 and gf.shape == (n, 48) and np.abs(rf).max() > 0
 
 
+def test_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden_and_the_oracle():
+    """model.feature_type = nht with render.primitive_type = icosahedron (round 5; refused until then): the forward DIRECTLY against
+    tests/golden/grt_trace_nht_mesh.npz = the reference's Slang forward programs compiled for MOGTracingIcosaHedron over the emulated OptiX's
+    triangles (tests/test_oracle_cpu.py pins the oracle on the same file), then forward and both backward paths against the oracle given the
+    GPU-built proxy records."""
+    import os
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    gold = np.load(os.path.join(here, "golden", "grt_trace_nht_mesh.npz"))
+    kw = make_golden.GRT_TRACE_SCENES[0]
+    scene = make_scene(**kw)
+    feats = gold["icosahedron_s0_nht_features"]
+    tr = _nht_tracer(primitive_type="icosahedron")
+    g = syn.SimpleGaussians(scene["density12"], feats, requires_grad=False)
+    tr.build_acc(g, rebuild=True)
+    with torch.no_grad():
+        out = tr.render(g, torch_batch(scene["batch"], "cuda"))
+    cnt = out["hits_count"][0].cpu().numpy()
+    flips = (cnt != gold["icosahedron_s0_hits_count"])[..., 0]
+    assert flips.mean() <= 0.01, f"{int(flips.sum())} rays with a different number of accepted hits"
+    e = np.abs(out["pred_features"][0].cpu().numpy() - gold["icosahedron_s0_features"]).max(-1)
+    tied = ~flips & (e > 1e-4)
+    assert tied.mean() <= 0.02 and (not tied.any() or e[tied].max() < 5e-2), (int(tied.sum()), float(e.max()))
+    ok = ~flips & ~tied
+    assert np.abs(out["pred_opacity"][0].cpu().numpy() - gold["icosahedron_s0_density"])[ok].max() < 1e-4
+    assert np.abs(gold["icosahedron_s0_features"]).max() > 0.5 and cnt.max() >= 15
+    # against the oracle on a second scene, with gradients through both backward paths
+    n, w, h = 2500, 56, 40
+    scene = _scene(n, w, h, 0.07)
+    feats = np.random.default_rng(21).uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)
+    cfg = oracle.default_grt_config(primitive_type=1)
+    rng = np.random.default_rng(4)
+    g_f = rng.normal(size=(h, w, 24)).astype(np.float32)
+    g_d = rng.normal(size=(h, w, 1)).astype(np.float32)
+    g_h = (rng.normal(size=(h, w, 1)) * 0.1).astype(np.float32)
+    for replay in (True, False):
+        tr = _nht_tracer(primitive_type="icosahedron", backward_hit_replay=replay)
+        g = syn.SimpleGaussians(scene["density12"], feats)
+        tr.build_acc(g, rebuild=True)
+        out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)
+        loss = (out["pred_features"][0] * torch.as_tensor(g_f, device="cuda")).sum() + (out["pred_opacity"][0] * torch.as_tensor(g_d, device="cuda")).sum() + \
+               (out["pred_dist"][0] * torch.as_tensor(g_h, device="cuda")).sum()
+        loss.backward()
+        gd, gf = g.grads_packed()
+        nat = tr.tracer_wrapper
+        inst = nat.instances(n, "cuda").cpu().numpy()
+        aabb = np.array(list(nat.stats().scene_aabb), np.float32)
+        ora = oracle.grt_forward_nht(cfg, scene["density12"], feats, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=aabb)
+        f = out["pred_features"][0].detach().cpu().numpy()
+        flips = (out["hits_count"][0].detach().cpu().numpy() != ora["hit_count"])[..., 0]
+        bad = (np.abs(f - ora["features"]) > 1e-4).any(-1) | (np.abs(out["pred_opacity"][0].detach().cpu().numpy() - ora["density"])[..., 0] > 1e-4)
+        assert flips.mean() <= 5e-3 and (bad & ~flips).mean() <= 2e-3, (replay, int(bad.sum()), int(flips.sum()))
+        rd, rf = oracle.grt_backward_nht(cfg, 1e-3, ora, g_f, g_d, g_h.reshape(-1))
+        n_flip = int(flips.sum())
+
+        def trimmed(a, b, drop):
+            err = np.abs(np.asarray(a, np.float64) - b).reshape(a.shape[0], -1).max(1)
+            err = np.sort(err)[: max(1, len(err) - drop)]
+            return float(err.max() / (np.abs(b).max() + 1e-12))
+        assert trimmed(gd[:, :11], rd[:, :11], 3 * n_flip) < 1e-3 and trimmed(gf, rf, 3 * n_flip) < 1e-3, (replay, trimmed(gd[:, :11], rd[:, :11], 3 * n_flip), trimmed(gf, rf, 3 * n_flip))
+
+
 def test_nht_forward_matches_reference_slang_programs_golden():
     """The HIP 3DGRT path with neural harmonic features DIRECTLY against tests/golden/grt_trace_nht.npz — the reference's Slang forward
     pipeline (referenceSlangOptix.cu) run on the host over the emulated traversal: accepted-hit counts, visibility, 24 ray features."""

@@ -997,6 +997,34 @@ def test_grt_nht_forward_matches_reference_slang_programs_golden():
         assert g[f"s{k}_hits_count"].max() >= 20 and np.abs(g[f"s{k}_features"]).max() > 0.5
 
 
+def test_grt_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden():
+    """model.feature_type = nht together with render.primitive_type = icosahedron (round 5): orc_grt_trace_nht_fwd with the polyhedron clip as
+    candidate test against tests/golden/grt_trace_nht_mesh.npz = the reference's Slang forward programs compiled for MOGTracingIcosaHedron
+    over the emulated OptiX's built-in triangles (meshes from the reference's mesh kernel, back faces culled).  Like the SH meshes
+    (test_grt_mesh_proxies_...): two roundings of the same entry distance - ideal polyhedron in the proxy frame vs float32 world
+    vertices - may swap tied hits on a few rays."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = np.load(os.path.join(HERE, "golden", "grt_trace_nht_mesh.npz"))
+    cfg = oracle.default_grt_config(primitive_type=1)
+    kw = make_golden.GRT_TRACE_SCENES[0]
+    sc = make_scene(**kw)
+    o = oracle.grt_forward_nht(cfg, sc["density12"], g["icosahedron_s0_nht_features"], 1e-3, sc["batch"]["T_to_world"][0], *sc["rays"])
+    flips = (o["hit_count"] != g["icosahedron_s0_hits_count"])[..., 0]
+    assert flips.mean() <= 0.01, f"{int(flips.sum())} rays with another number of accepted hits"
+    e = np.abs(o["features"] - g["icosahedron_s0_features"]).max(-1)
+    tied = ~flips & (e > 1e-5)
+    assert tied.mean() <= 0.02 and (not tied.any() or e[tied].max() < 5e-2), (int(tied.sum()), float(e[tied].max()) if tied.any() else 0.0)
+    ok = ~flips & ~tied
+    assert np.abs(o["density"] - g["icosahedron_s0_density"])[ok].max() < 1e-5
+    hd = g["icosahedron_s0_hit_distance"]
+    assert np.abs(o["hit_distance"] - hd)[ok].max() <= 2e-5 * max(1.0, np.abs(hd).max())
+    assert (o["visibility"] != 0).sum() > 0 and ((o["visibility"] != 0) != (g["icosahedron_s0_visibility"] != 0)).sum() <= 3 * int((flips | tied).sum())
+    # not the instances' frame: the particle is offered at the distance the ray ENTERS its icosahedron
+    inst = np.load(os.path.join(HERE, "golden", "grt_trace_nht.npz"))
+    assert np.abs(g["icosahedron_s0_features"] - inst["s0_features"]).max() > 1e-2 and g["icosahedron_s0_hits_count"].max() >= 15
+
+
 def test_slang_forward_with_sh_radiance_is_the_reference_forward():
     """render.pipeline_type = referenceSlang with model.feature_type = sh is served by the kernels of the `reference` pipeline
     (3dgrut_amd/grt_tracer.py): the two reference programs integrate the same function.  Pinned here program against program —
