@@ -1357,6 +1357,42 @@ __device__ __forceinline__ void k_bwd_flush(bool have, uint32_t idx, const float
     }
 }
 
+// Round 5: the same sums through LDS instead of the DPP reduce-scatter (GRUT_K_FLUSH_LDS, default on).  A step's popping lanes hold
+// DIFFERENT particles more often than not (a pop is an OLD pending hit; neighbouring pixels' buffers drift apart), so the loop above runs
+// once per distinct particle at ~100 instructions each (16 selects + the 30-step reduce-scatter + the atomics).  Here every popping lane
+// parks its 14 terms in LDS (stride 15: conflict-free both ways) and lanes 0..13 ARE the 14 words of a particle's gradient: per distinct
+// particle the members' words are added from LDS (one read + one add per member) and leave as ONE atomic instruction - the hit-major
+// transposition of the 3DGRT replay backward (grt_replay_bwd_kernel).
+#ifndef GRUT_K_FLUSH_LDS
+#define GRUT_K_FLUSH_LDS 1
+#endif
+constexpr int kKTermStride = 15;
+__device__ __forceinline__ void k_bwd_flush_lds(bool have, uint32_t idx, const float (&terms)[16], int lane, float* __restrict__ s_terms,
+                                                float* __restrict__ g_density12, float* __restrict__ g_rgb) {
+    if (have) {
+#pragma unroll
+        for (int k = 0; k < 14; ++k) s_terms[lane * kKTermStride + k] = terms[k];
+    }
+    __syncthreads();   // single-wave workgroup: orders the LDS hand-off
+    unsigned long long m = __ballot(have);
+    float* const row = lane < 11 ? g_density12 + lane : g_rgb + (lane < 14 ? lane - 11 : 0);
+    const uint32_t stride = lane < 11 ? 12u : 3u;
+    while (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)idx, leader);
+        unsigned long long same = __ballot(have && idx == pid);
+        m &= ~same;
+        float v = 0.f;
+        while (same) {
+            const int s2 = __ffsll((long long)same) - 1;
+            same &= same - 1;
+            v += s_terms[s2 * kKTermStride + (lane < 14 ? lane : 0)];
+        }
+        if (lane < 14 && v != 0.f) atomicAdd(row + (size_t)pid * stride, v);
+    }
+    __syncthreads();   // the next step overwrites s_terms
+}
+
 template <int K, bool BWD>
 __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint2* __restrict__ ranges, const EntryLists& lists,
                                                   const float4* __restrict__ density12, const float* __restrict__ rgb,
@@ -1366,6 +1402,7 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
                                                   float* __restrict__ g_density12, float* __restrict__ g_rgb) {
     constexpr int kQ = 8;   // quads per staged entry: 0-2 M rows | pos, 3 scale | density, 4 particle | accept limit, 5-7 rows of R^T | 1 / scale
     __shared__ float4 s_rec[64 * kQ];
+    __shared__ float s_kterms[(BWD && GRUT_K_FLUSH_LDS) ? 64 * kKTermStride : 1];
     // strip -> (tile, strip-in-tile) with all four strips of a tile on one XCD
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t tile = ((slot >> 2) << 3) + xcd, strip = slot & 3u;
@@ -1458,7 +1495,8 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
                 if (__any(pop)) {   // wave-level: gradients of lanes that popped the same particle are summed before the atomics
                     float terms[16];
                     const bool have = pop && k_bwd_terms(P, ray, density12, rgb, pop_t, pop_a, pop_i, bs, alive, terms);
-                    k_bwd_flush(have, pop_i, terms, lane, g_density12, g_rgb);
+                    if (GRUT_K_FLUSH_LDS) k_bwd_flush_lds(have, pop_i, terms, lane, s_kterms, g_density12, g_rgb);
+                    else k_bwd_flush(have, pop_i, terms, lane, g_density12, g_rgb);
                 }
             } else if (pop) {
                 k_process_fwd(P, rgb, pop_t, pop_a, pop_i, fs, alive);
@@ -1481,7 +1519,8 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
             if (__any(act)) {
                 float terms[16];
                 const bool have = act && k_bwd_terms(P, ray, density12, rgb, t0, a0, i0, bs, alive, terms);
-                k_bwd_flush(have, i0, terms, lane, g_density12, g_rgb);
+                if (GRUT_K_FLUSH_LDS) k_bwd_flush_lds(have, i0, terms, lane, s_kterms, g_density12, g_rgb);
+                else k_bwd_flush(have, i0, terms, lane, g_density12, g_rgb);
             }
         } else if (act) {
             k_process_fwd(P, rgb, t0, a0, i0, fs, alive);
@@ -1506,8 +1545,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void gu
     float* __restrict__ out_cnt) {
     gut_render_k_body<K, false>(P, ranges, lists, density12, rgb, ray_o, ray_d, out_fd, out_dist, out_cnt, nullptr, nullptr, nullptr, nullptr);
 }
+#ifndef GRUT_K_BWD_WAVES
+#define GRUT_K_BWD_WAVES 0   // 0: the allocator's choice (209 VGPRs with the LDS flush, two waves per SIMD)
+#endif
 template <int K>
-__global__ __launch_bounds__(64) void gut_render_k_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+__global__ __launch_bounds__(64)
+#if GRUT_K_BWD_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(GRUT_K_BWD_WAVES, GRUT_K_BWD_WAVES)))
+#endif
+void gut_render_k_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                               const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                               const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                               float4* __restrict__ fd, float* __restrict__ dist, const float4* __restrict__ g_fd,
