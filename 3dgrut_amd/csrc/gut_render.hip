@@ -1366,6 +1366,10 @@ __device__ __forceinline__ void k_bwd_flush(bool have, uint32_t idx, const float
 #ifndef GRUT_K_FLUSH_LDS
 #define GRUT_K_FLUSH_LDS 1
 #endif
+#ifndef GRUT_K_FLUSH_MINK
+#define GRUT_K_FLUSH_MINK 8    // smallest K that takes the LDS flush and the three-waves allocation that goes with it (K = 4 runs three waves
+                               // on the DPP reduce-scatter already; measured at 1 M / 1080p, step: K = 16 11.89 -> 10.90 ms, K = 8 8.89 -> 8.41 ms)
+#endif
 constexpr int kKTermStride = 15;
 __device__ __forceinline__ void k_bwd_flush_lds(bool have, uint32_t idx, const float (&terms)[16], int lane, float* __restrict__ s_terms,
                                                 float* __restrict__ g_density12, float* __restrict__ g_rgb) {
@@ -1390,7 +1394,8 @@ __device__ __forceinline__ void k_bwd_flush_lds(bool have, uint32_t idx, const f
         }
         if (lane < 14 && v != 0.f) atomicAdd(row + (size_t)pid * stride, v);
     }
-    __syncthreads();   // the next step overwrites s_terms
+    __syncthreads();   // the next step overwrites s_terms.  (Two buffers used alternately - one barrier per step - were measured SLOWER: 15.9 KB of
+                       // LDS per wave leave room for 10 waves per CU, i.e. two per SIMD again: backward 9.5 instead of 7.6 ms.)
 }
 
 template <int K, bool BWD>
@@ -1402,7 +1407,8 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
                                                   float* __restrict__ g_density12, float* __restrict__ g_rgb) {
     constexpr int kQ = 8;   // quads per staged entry: 0-2 M rows | pos, 3 scale | density, 4 particle | accept limit, 5-7 rows of R^T | 1 / scale
     __shared__ float4 s_rec[64 * kQ];
-    __shared__ float s_kterms[(BWD && GRUT_K_FLUSH_LDS) ? 64 * kKTermStride : 1];
+    constexpr bool kLdsFlush = BWD && GRUT_K_FLUSH_LDS && K >= GRUT_K_FLUSH_MINK;
+    __shared__ float s_kterms[kLdsFlush ? 64 * kKTermStride : 1];
     // strip -> (tile, strip-in-tile) with all four strips of a tile on one XCD
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t tile = ((slot >> 2) << 3) + xcd, strip = slot & 3u;
@@ -1495,7 +1501,7 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
                 if (__any(pop)) {   // wave-level: gradients of lanes that popped the same particle are summed before the atomics
                     float terms[16];
                     const bool have = pop && k_bwd_terms(P, ray, density12, rgb, pop_t, pop_a, pop_i, bs, alive, terms);
-                    if (GRUT_K_FLUSH_LDS) k_bwd_flush_lds(have, pop_i, terms, lane, s_kterms, g_density12, g_rgb);
+                    if (kLdsFlush) k_bwd_flush_lds(have, pop_i, terms, lane, s_kterms, g_density12, g_rgb);
                     else k_bwd_flush(have, pop_i, terms, lane, g_density12, g_rgb);
                 }
             } else if (pop) {
@@ -1519,7 +1525,7 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
             if (__any(act)) {
                 float terms[16];
                 const bool have = act && k_bwd_terms(P, ray, density12, rgb, t0, a0, i0, bs, alive, terms);
-                if (GRUT_K_FLUSH_LDS) k_bwd_flush_lds(have, i0, terms, lane, s_kterms, g_density12, g_rgb);
+                if (kLdsFlush) k_bwd_flush_lds(have, i0, terms, lane, s_kterms, g_density12, g_rgb);
                 else k_bwd_flush(have, i0, terms, lane, g_density12, g_rgb);
             }
         } else if (act) {
@@ -1545,14 +1551,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void gu
     float* __restrict__ out_cnt) {
     gut_render_k_body<K, false>(P, ranges, lists, density12, rgb, ray_o, ray_d, out_fd, out_dist, out_cnt, nullptr, nullptr, nullptr, nullptr);
 }
+// K = 16 with the LDS flush: 209 VGPRs where the DPP reduce-scatter needed 231 - held to 168 (116 B of scratch) the kernel runs three waves
+// per SIMD: backward 8.59 -> 7.60 ms (A/B on one box; the LDS flush at two waves: 8.98, the DPP flush at three: 9.6 in round 2).  K = 8: 177 ->
+// 161 VGPRs, three waves without scratch, backward 6.53 -> 6.06 ms.
 #ifndef GRUT_K_BWD_WAVES
-#define GRUT_K_BWD_WAVES 0   // 0: the allocator's choice (209 VGPRs with the LDS flush, two waves per SIMD)
+#define GRUT_K_BWD_WAVES 3
 #endif
 template <int K>
 __global__ __launch_bounds__(64)
-#if GRUT_K_BWD_WAVES > 0
-__attribute__((amdgpu_waves_per_eu(GRUT_K_BWD_WAVES, GRUT_K_BWD_WAVES)))
-#endif
+__attribute__((amdgpu_waves_per_eu((K >= GRUT_K_FLUSH_MINK && GRUT_K_FLUSH_LDS) ? GRUT_K_BWD_WAVES : 1, (K >= GRUT_K_FLUSH_MINK && GRUT_K_FLUSH_LDS) ? GRUT_K_BWD_WAVES : 8)))
 void gut_render_k_bwd_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                               const float4* __restrict__ density12, const float* __restrict__ rgb,
                                                               const float* __restrict__ ray_o, const float* __restrict__ ray_d,
