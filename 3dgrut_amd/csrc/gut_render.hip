@@ -1544,8 +1544,11 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
 
 // The forward fits three waves per SIMD when told to (1.96 vs 2.5 ms at K = 16); the backward needs its 231 registers
 // (8.0 ms at two waves, 9.6 at three, 13.3 at four).
+#ifndef GRUT_K_FWD_WAVES
+#define GRUT_K_FWD_WAVES 3   // (measured again in round 5 with the exact-order hit distance: forward 3.07 / 2.61 / 3.08 ms at 2 / 3 / 4 waves)
+#endif
 template <int K>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void gut_render_k_fwd_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRUT_K_FWD_WAVES))) void gut_render_k_fwd_kernel(
     GutParams P, const uint2* __restrict__ ranges, EntryLists lists, const float4* __restrict__ density12, const float* __restrict__ rgb,
     const float* __restrict__ ray_o, const float* __restrict__ ray_d, float4* __restrict__ out_fd, float* __restrict__ out_dist,
     float* __restrict__ out_cnt) {
