@@ -16,6 +16,7 @@ struct GrtHandle {
     hipStream_t build_stream = nullptr;
     DeviceBuffer refit_todo;   // the nodes the level-synchronous refit launches leave to grt_refit_finish_kernel
     DeviceBuffer box8;   // GRUT_PRIM_CUSTOM: the particles' exact world boxes + kernelScale^2 (grt_proxy_kernel)
+    uint32_t NP = 0;     // proxies of the last build (= N; 3 N for GRUT_PRIM_TRIHEXA)
     DeviceBuffer inst, aabb, slack, scene_enc, scene, codes, ids, codes_tmp, ids_tmp, sort_scratch, nodes,
         counters, dbg_ids, dbg_count;
     uint32_t* sorted_ids = nullptr;
@@ -68,8 +69,8 @@ struct GrtHandle {
 
 static int grt_validate(const GrtConfig& c) {
     GRUT_REQUIRE(c.particle_radiance_sph_degree >= 0 && c.particle_radiance_sph_degree <= 3, "sph degree must be in [0,3]");
-    if (c.primitive_type < GRUT_PRIM_INSTANCES || c.primitive_type > GRUT_PRIM_TRISURFEL) {
-        set_last_error("primitive_type %d: instances (0), icosahedron (1), octahedron (2), tetrahedron (3), diamond (4), custom (5), trisurfel (6) are provided", c.primitive_type);
+    if (c.primitive_type < GRUT_PRIM_INSTANCES || c.primitive_type > GRUT_PRIM_TRIHEXA) {
+        set_last_error("primitive_type %d: instances (0), icosahedron (1), octahedron (2), tetrahedron (3), diamond (4), custom (5), trisurfel (6), trihexa (7) are provided", c.primitive_type);
         return GRUT_ERR_UNSUPPORTED;
     }
     const int d = c.particle_kernel_degree;
@@ -136,7 +137,7 @@ static GrtBvh bvh_view(const GrtHandle* h) {
     b.nodes = h->nodes.as<GrtNode>();
     b.inst = h->inst.as<float>();
     b.scene = h->scene.as<float>();
-    b.N = h->N;
+    b.N = h->NP;   // leaves of the tree = proxies (three per particle for GRUT_PRIM_TRIHEXA)
     return b;
 }
 
@@ -182,6 +183,7 @@ int grt_trim(GrtHandle* h) {
     h->built = false;
     h->mesh_built = false;
     h->N = 0;
+    h->NP = 0;
     h->log_valid = false;
     h->log_event_pending = false;
     h->scene_host_valid = false;
@@ -219,14 +221,18 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     ScratchStreamScope scratch_scope(s);
     if (N == 0) {
         h->N = 0;
+        h->NP = 0;
         h->built = true;
         return GRUT_OK;
     }
     GRUT_REQUIRE(positions && rotations && scales && densities, "grt_build_bvh: null buffer");
-    GRUT_REQUIRE(N <= 0x1FFFFFFEu, "grt_build_bvh: %u particles (the hit buffers keep 29 bits of particle index)", N);
+    // proxies: one per particle, three (one per rhombus) for GRUT_PRIM_TRIHEXA - the tree, the hit buffers and the log are keyed by PROXY
+    const uint32_t per = h->cfg.primitive_type == GRUT_PRIM_TRIHEXA ? 3u : 1u;
+    GRUT_REQUIRE((uint64_t)N * per <= 0x1FFFFFFEu, "grt_build_bvh: %u particles (the hit buffers keep 29 bits of proxy index)", N);
     if (!rebuild && (!h->built || h->N != N)) rebuild = 1;  // "cannot refit GAS with a different number of gaussian" (optixTracer.cpp:629-632)
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.begin(s));
-    const size_t n = N;
+    const uint32_t NP = N * per;
+    const size_t n = NP;
     GRUT_CHECK(h->inst.ensure(n * 48, 1.25f));
     GRUT_CHECK(h->aabb.ensure(n * 24, 1.25f));
     GRUT_CHECK(h->slack.ensure(n * 4, 1.25f));
@@ -242,7 +248,7 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     GRUT_CHECK(h->counters.ensure(n * 4, 1.25f));
 
     GrtBuildParams P;
-    P.N = N;
+    P.N = NP;
     P.degree = h->cfg.particle_kernel_degree;
     P.prim = h->cfg.primitive_type;
     P.clamping = h->cfg.particle_kernel_density_clamping;
@@ -251,23 +257,24 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     grt_launch_proxies(s, P, positions, rotations, scales, densities, h->inst.as<float>(), h->aabb.as<float>(), h->slack.as<float>(), scene_enc,
                        h->cfg.primitive_type == GRUT_PRIM_CUSTOM ? h->box8.as<float>() : nullptr);
     // refit-only updates keep the sorted order of the last full build, so the code / id buffers must stay untouched
-    grt_launch_morton(s, N, h->aabb.as<float>(), scene_enc, h->scene.as<float>(), rebuild ? h->codes.as<uint32_t>() : nullptr,
+    grt_launch_morton(s, NP, h->aabb.as<float>(), scene_enc, h->scene.as<float>(), rebuild ? h->codes.as<uint32_t>() : nullptr,
                       rebuild ? h->ids.as<uint32_t>() : nullptr);
     if (rebuild) {
         uint32_t *sc = nullptr, *si = nullptr;
-        GRUT_CHECK(sort_pairs_u32(s, N, nullptr, 0, 30, h->codes.as<uint32_t>(), h->ids.as<uint32_t>(), h->codes_tmp.as<uint32_t>(),
+        GRUT_CHECK(sort_pairs_u32(s, NP, nullptr, 0, 30, h->codes.as<uint32_t>(), h->ids.as<uint32_t>(), h->codes_tmp.as<uint32_t>(),
                                   h->ids_tmp.as<uint32_t>(), h->sort_scratch.ptr, h->sort_scratch.bytes, &sc, &si));
         h->sorted_codes = sc;
         h->sorted_ids = si;
-        grt_launch_hierarchy(s, N, sc, si, h->nodes.as<GrtNode>());
+        grt_launch_hierarchy(s, NP, sc, si, h->nodes.as<GrtNode>());
     }
     // the refit re-derives every box from the fresh proxies; on rebuild = 0 the sorted order of the last build is reused
     GRUT_HIP(hipMemsetAsync(h->counters.ptr, 0, n, s));   // per-node "done in pass" bytes
     GRUT_CHECK(h->refit_todo.ensure((n + 1) * 4, 1.25f));
-    grt_launch_refit(s, N, h->aabb.as<float>(), h->slack.as<float>(), h->nodes.as<GrtNode>(), h->counters.as<uint8_t>(), h->refit_todo.as<uint32_t>());
+    grt_launch_refit(s, NP, h->aabb.as<float>(), h->slack.as<float>(), h->nodes.as<GrtNode>(), h->counters.as<uint8_t>(), h->refit_todo.as<uint32_t>());
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.end(s));
     h->N = N;
+    h->NP = NP;
     h->built = true;
     h->build_stream = s;
     h->scene_host_valid = false;
@@ -286,7 +293,7 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
     // first tests refine to exact ones like the instance path's; GRUT_GRT_NO_MESH_LISTS=1 keeps them on the tree walk)
     // (custom primitives: the candidates are the rays of the particle's WORLD box, which the packet binning - bounds of the oriented proxy - does
     // not cover: tree walk)
-    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && h->cfg.primitive_type != GRUT_PRIM_CUSTOM && !(h->cfg.primitive_type == GRUT_PRIM_TRISURFEL && getenv("GRUT_GRT_TRISURFEL_WALK")) &&
+    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && h->cfg.primitive_type != GRUT_PRIM_CUSTOM && h->cfg.primitive_type != GRUT_PRIM_TRIHEXA && !(h->cfg.primitive_type == GRUT_PRIM_TRISURFEL && getenv("GRUT_GRT_TRISURFEL_WALK")) &&
         (h->cfg.primitive_type == GRUT_PRIM_INSTANCES || !getenv("GRUT_GRT_NO_MESH_LISTS"))) {
         const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
         if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
@@ -705,7 +712,7 @@ int grt_stats(GrtHandle* h, GrtStats* stats) {
     GRUT_REQUIRE(h && stats, "grt_stats: null argument");
     memset(stats, 0, sizeof(*stats));
     stats->num_particles = h->N;
-    stats->num_nodes = h->N > 1 ? h->N - 1 : (h->N ? 1 : 0);
+    stats->num_nodes = h->NP > 1 ? h->NP - 1 : (h->NP ? 1 : 0);
     stats->nodes_visited = h->work_host[0];
     stats->candidates = h->work_host[1];
     stats->processed_hits = h->work_host[2];
@@ -735,7 +742,9 @@ int grt_stats(GrtHandle* h, GrtStats* stats) {
 // copies the proxy instance records (inverse maps {W rows, mu}, [N,12]) of the last build to a caller DEVICE buffer
 int grt_debug_fetch_instances(GrtHandle* h, void* stream_, float* instances) {
     GRUT_REQUIRE(h && h->built && instances, "grt_debug_fetch_instances: no BVH / null buffer");
-    if (h->N) GRUT_HIP(hipMemcpyAsync(instances, h->inst.ptr, (size_t)h->N * 48, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream_)));
+    // (GRUT_PRIM_TRIHEXA keeps three identical records per particle, one per rhombus: the caller gets one)
+    const size_t per = h->N ? h->NP / h->N : 1;
+    if (h->N) GRUT_HIP(hipMemcpy2DAsync(instances, 48, h->inst.ptr, 48 * per, 48, h->N, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream_)));
     return GRUT_OK;
 }
 

@@ -70,13 +70,18 @@ __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const 
                                                         const float* __restrict__ scl, const float* __restrict__ dns,
                                                         float* __restrict__ inst, float* __restrict__ aabb, float* __restrict__ slack,
                                                         uint32_t* __restrict__ scene_enc, float* __restrict__ box8) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // proxy
     float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     if (i < P.N) {
-        const m3 rt = quat_wxyz_to_rotT(rot[4 * (size_t)i], rot[4 * (size_t)i + 1], rot[4 * (size_t)i + 2], rot[4 * (size_t)i + 3]);
-        const float ks = kernel_scale(dns[i], P.min_response, P.clamping, (float)P.degree);
-        const float k0 = ks * scl[3 * (size_t)i], k1 = ks * scl[3 * (size_t)i + 1], k2 = ks * scl[3 * (size_t)i + 2];
-        const float cx = pos[3 * (size_t)i], cy = pos[3 * (size_t)i + 1], cz = pos[3 * (size_t)i + 2];
+        // GRUT_PRIM_TRIHEXA: proxy 3 p + j is the rhombus of particle p in the proxy frame's plane j (x = 0, y = 0, z = 0); its record is
+        // the particle's (the candidate test reads the plane from the proxy index)
+        const bool hexa = P.prim == GRUT_PRIM_TRIHEXA;
+        const size_t pi = hexa ? i / 3u : i;
+        const int plane = hexa ? (int)(i - 3u * (uint32_t)pi) : -1;
+        const m3 rt = quat_wxyz_to_rotT(rot[4 * pi], rot[4 * pi + 1], rot[4 * pi + 2], rot[4 * pi + 3]);
+        const float ks = kernel_scale(dns[pi], P.min_response, P.clamping, (float)P.degree);
+        const float k0 = ks * scl[3 * pi], k1 = ks * scl[3 * pi + 1], k2 = ks * scl[3 * pi + 2];
+        const float cx = pos[3 * pi], cy = pos[3 * pi + 1], cz = pos[3 * pi + 2];
         float* o = inst + 12 * (size_t)i;
         o[0] = rt.r0.x / k0; o[1] = rt.r0.y / k0; o[2] = rt.r0.z / k0;
         o[3] = rt.r1.x / k1; o[4] = rt.r1.y / k1; o[5] = rt.r1.z / k1;
@@ -85,7 +90,12 @@ __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const 
         // world half extents of the oriented box, padded by a hair so that rounding can never make the ray miss the
         // AABB of a box it touches (culling must stay conservative; candidates are decided in the proxy's own frame)
         // (triangle-mesh proxies: the polyhedron's vertices reach ext_k along axis k of the proxy's frame instead of 1)
-        const float e0 = k0 * kGrtPolyhedra[P.prim].ext[0], e1 = k1 * kGrtPolyhedra[P.prim].ext[1], e2 = k2 * kGrtPolyhedra[P.prim].ext[2];
+        float e0, e1, e2;
+        if (hexa) {   // a rhombus (+-sqrt 2 along the two axes of its plane, flat along the third)
+            e0 = plane == 0 ? 0.f : 1.4142135381698608f * k0; e1 = plane == 1 ? 0.f : 1.4142135381698608f * k1; e2 = plane == 2 ? 0.f : 1.4142135381698608f * k2;
+        } else {
+            e0 = k0 * kGrtPolyhedra[P.prim].ext[0]; e1 = k1 * kGrtPolyhedra[P.prim].ext[1]; e2 = k2 * kGrtPolyhedra[P.prim].ext[2];
+        }
         float hx = fabsf(rt.r0.x) * e0 + fabsf(rt.r1.x) * e1 + fabsf(rt.r2.x) * e2;
         float hy = fabsf(rt.r0.y) * e0 + fabsf(rt.r1.y) * e1 + fabsf(rt.r2.y) * e2;
         float hz = fabsf(rt.r0.z) * e0 + fabsf(rt.r1.z) * e1 + fabsf(rt.r2.z) * e2;
@@ -488,6 +498,27 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
         c.box = !miss && (tin <= tout) && (tin > -3.0e38f);
         const bool want = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
         c.tnear = tin; c.tfar = 3.0e38f;   // the reported distance IS the geometric hit: eligibility is t in (tmin, tmax) alone
+        c.why = c.box ? 1 : 2;
+        c.ok = c.box && want;
+        return c;
+    }
+    if (r.prim == GRUT_PRIM_TRIHEXA) {
+        // trihexa (particlePrimitives.cu:107-153): proxy `id` is the rhombus |a| + |b| <= sqrt 2 of particle id / 3 in the proxy frame's plane
+        // id % 3, traced as triangles with back faces culled: the windings make the x = 0 rhombus face +x, the y = 0 rhombus +y, and the two
+        // triangles of the z = 0 rhombus face opposite ways (its x >= 0 half +z, its x <= 0 half -z).  Same operations, same order as the CPU
+        // checker's trihexa_candidates.
+        const uint32_t plane = id % 3u;
+        const float pn = plane == 0u ? pdx : (plane == 1u ? pdy : pdz), on = plane == 0u ? pox : (plane == 1u ? poy : poz);
+        const bool facing = plane == 2u ? (pn != 0.f) : (pn < 0.f);
+        if (!facing) { c.why = 2; return c; }
+        const float t = -on / pn;
+        // the two in-plane coordinates of the crossing: (y, z) / (x, z) / (x, y)
+        const float a0 = plane == 0u ? fmaf(t, pdy, poy) : fmaf(t, pdx, pox);
+        const float a1 = plane == 2u ? fmaf(t, pdy, poy) : fmaf(t, pdz, poz);
+        c.t = t; c.tnear = t; c.tfar = 3.0e38f;
+        c.box = fabsf(a0) + fabsf(a1) <= 1.4142135381698608f;
+        if (plane == 2u) c.box = c.box && ((a0 > 0.f && pdz < 0.f) || (a0 < 0.f && pdz > 0.f));
+        const bool want = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
         c.why = c.box ? 1 : 2;
         c.ok = c.box && want;
         return c;
@@ -1092,6 +1123,9 @@ __device__ __forceinline__ f3 sh_radiance(const GrtTraceParams& P, const float* 
     return rad + mk3(0.5f, 0.5f, 0.5f);
 }
 
+// the particle behind a proxy index (hit buffers, the log and the tree are keyed by proxy; GRUT_PRIM_TRIHEXA has three proxies per particle)
+__device__ __forceinline__ uint32_t particle_of(const GrtTraceParams& P, uint32_t proxy) { return P.prim == GRUT_PRIM_TRIHEXA ? proxy / 3u : proxy; }
+
 struct HitGeom {
     f3 gposc, gposcr, gro, rdr, grdu, grd, gcrod, giscl;
     float gray, gres, galpha;
@@ -1316,7 +1350,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
             const bool process = running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
             if (!__any(process)) break;  // ascending list: nothing further for any lane
             if (process) {
-                const Particle p = load_particle(density12, id);
+                const uint32_t pid = particle_of(P, id);
+                const Particle p = load_particle(density12, pid);
                 const HitGeom g = hit_geometry<DEG>(P, p, r);
                 if (g.accept) {
                     const float weight = g.galpha * T;
@@ -1324,7 +1359,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                     const float pdot = surfel ? -g.gro.z / g.grd.z : -dot(g.grd, g.gro);
                     const f3 grds = p.scl * g.grd * pdot;
                     const float hitT = sqrtf(dot(grds, grds));
-                    const f3 u = P.nht ? mk3(0.f, 0.f, 0.f) : sh_radiance(P, sph, id, basis);   // (nht: the features come from the log, grt_nht_fwd_kernel)
+                    const f3 u = P.nht ? mk3(0.f, 0.f, 0.f) : sh_radiance(P, sph, pid, basis);   // (nht: the features come from the log, grt_nht_fwd_kernel)
                     const f3 c = mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f));
                     rad = rad + c * weight;
                     T *= (1.f - g.galpha);
@@ -1340,13 +1375,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                             nrm = nrm + n * weight;
                         }
                     }
-                    visibility[id] = 1;  // benign race: every writer stores the same value (referenceOptix.cu:158-161)
+                    visibility[pid] = 1;  // benign race: every writer stores the same value (referenceOptix.cu:158-161)
                     cnt += 1.f;
                 }
                 tLast = fmaxf(tLast, hit_t);
                 if (LOG) last_id = id;
                 if (COUNT) tc.processed++;
-                if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = id;
+                if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = particle_of(P, id);
                 ndbg++;
             }
         }
@@ -1967,7 +2002,7 @@ __global__ __launch_bounds__(64) void grt_trace_bwd_kernel(GrtTraceParams P, Grt
             if (!__any(process)) break;  // ascending list: nothing further for any lane
             if (process) {
                 if constexpr (NHT) process_hit_bwd_nht<DEG>(P, r, id, density12, sph, tet, nht_state, g_density12, g_sph);
-                else process_hit_bwd<DEG>(P, r, basis, nact, id, density12, sph, ray_state, g_density12, g_sph);
+                else process_hit_bwd<DEG>(P, r, basis, nact, particle_of(P, id), density12, sph, ray_state, g_density12, g_sph);
                 startT = fmaxf(startT, s_hit_t[i * 64 + lane]);
                 dbg_n++; dbg_sig += (unsigned long long)id * 0x9E3779B97F4A7C15ull + 1ull;
             }
@@ -2084,6 +2119,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_REPLAY_W
                     bw_max = fmaxf(bw_max, cd.t);
                     if (++bw_cnt == (uint32_t)kGrtMaxHits) { bw_start = bw_max; bw_cnt = 0u; }   // the trace is full: the next one starts behind its last hit
                     dbg_n++; dbg_sig += (unsigned long long)id * 0x9E3779B97F4A7C15ull + 1ull;
+                    id = particle_of(P, id);   // from here on: the particle (its rows are the atomics' targets, lanes merge by particle)
                     const Particle p = load_particle(density12, id);
                     const HitGeom g = hit_geometry<DEG>(P, p, r);
                     if (g.accept) {

@@ -334,7 +334,12 @@ enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON 
        /* trisurfel (particlePrimitives.cu:155-205): two triangles per particle = the rhombus |x| + |y| <= sqrt 2 of the proxy's z = 0 plane, traced
         * WITHOUT face culling (referenceOptix.cu:62); the hit is the ray's crossing of that plane and the per-hit math takes its
         * SurfelPrimitive branches (gaussianParticles.cuh:371-400, 512-521, 558-565, 628-659). */
-       GRUT_PRIM_TRISURFEL = 6 };
+       GRUT_PRIM_TRISURFEL = 6,
+       /* trihexa (particlePrimitives.cu:107-153): three rhombi in the proxy's coordinate planes, six triangles, back faces culled - the windings
+        * make the x = 0 / y = 0 rhombi face +x / +y and the two halves of the z = 0 rhombus face opposite ways, so a ray is offered the SAME
+        * particle up to three times at three distances and the programs process every offer as a hit of the particle.  Here every rhombus is a
+        * proxy of its own (3 N leaves, proxy 3 i + j = plane j of particle i).  Tree walk. */
+       GRUT_PRIM_TRIHEXA = 7 };
 
 typedef struct GrtFrame {
     uint32_t frame_id;

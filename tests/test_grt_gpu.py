@@ -183,7 +183,7 @@ def test_refit_update_matches_full_rebuild():
 def test_errors_are_loud():
     gt = importlib.import_module("3dgrut_amd.grt_tracer")
     with pytest.raises(NotImplementedError):
-        gt.Tracer({"render": {"primitive_type": "trihexa"}})
+        gt.Tracer({"render": {"primitive_type": "sphere"}})
     tr = _tracer()
     scene = _scene(10, 8, 8, 0.2)
     g = syn.SimpleGaussians(scene["density12"], scene["sph"])
@@ -498,9 +498,80 @@ def test_trisurfel_hit_order_equals_oracle_and_gradients_follow():
     assert all(max(m[f"grad_replay_{r}"]) < 1e-3 for r in (True, False)), m
 
 
+def test_trihexa_matches_reference_programs_golden_and_the_oracle():
+    """render.primitive_type = trihexa (round 5): three rhombi per particle, back faces culled, a ray is offered the SAME particle up to
+    three times.  Every rhombus is a proxy of its own here (3 N leaves).  (i) DIRECTLY against tests/golden/grt_trace_mesh.npz: trihexa_* =
+    the reference's forward / backward programs compiled for MOGTracingTriHexa over the emulated OptiX walking the six triangles per
+    particle of the reference's trihexa kernel, both backward paths; (ii) every ray's SEQUENCE of processed particles - repeats included -
+    against the oracle given the GPU-built proxy records, then images and the gradients of both backward paths."""
+    import os
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    g = np.load(os.path.join(here, "golden", "grt_trace_mesh.npz"))
+    kw = make_golden.GRT_TRACE_SCENES[0]
+    scene = make_scene(**kw)
+    H, W = kw["height"], kw["width"]
+    g_rad, g_dns, g_hit = make_golden.grt_trace_upstream(H, W)
+    for replay in (True, False):
+        gpu = _render(scene, g_rad, g_dns, g_hit, primitive_type="trihexa", backward_hit_replay=replay)
+        out = gpu["out"]
+        assert int(gpu["tracer"].tracer_wrapper.stats().list_entries) == 0      # tree walk
+        cnt = out["hits_count"][0].detach().cpu().numpy()
+        flips = (cnt != g["trihexa_s0_hits_count"])[..., 0]
+        assert flips.mean() <= 0.02 and cnt.max() >= 20, f"{int(flips.sum())} rays with a different number of accepted hits"
+        e = np.abs(out["pred_features"][0].detach().cpu().numpy() - g["trihexa_s0_features"]).max(-1)
+        hd = g["trihexa_s0_hit_distance"]
+        e_d = np.abs(out["pred_dist"][0].detach().cpu().numpy() - hd[..., :1])[..., 0]
+        tied = ~flips & ((e > 1e-4) | (e_d > 1e-4 * max(1.0, np.abs(hd).max())))
+        assert tied.mean() <= 0.02 and (not tied.any() or e[tied].max() < 5e-2), f"{int(tied.sum())} rays differ with the same hit count"
+        ok = ~flips & ~tied
+        assert np.abs(out["pred_opacity"][0].detach().cpu().numpy() - g["trihexa_s0_density"])[ok].max() < 1e-4
+        vis = out["mog_visibility"].view(-1).view(torch.int32).cpu().numpy() != 0
+        ndrop = 3 * int((flips | tied).sum())
+        assert (vis != (g["trihexa_s0_visibility"] != 0)).sum() <= ndrop
+        gd, gs = gpu["grads"]
+        rd, rs = g["trihexa_s0_grad_density"], g["trihexa_s0_grad_sph"]
+        per = np.sort(np.abs(gd[:, :11].astype(np.float64) - rd[:, :11]).max(1))[: max(1, len(gd) - ndrop)]
+        assert per.max() / np.abs(rd[:, :11]).max() < 1e-3, (replay, per.max() / np.abs(rd[:, :11]).max())
+        per = np.sort(np.abs(gs.astype(np.float64) - rs).max(1))[: max(1, len(gs) - ndrop)]
+        assert per.max() / np.abs(rs).max() < 1e-3, replay
+    # (ii) the sequences
+    scene = _scene(4000, 64, 48, 0.06)
+    tr, (feat, dns, hit, nrm, cnt, vis, ids, num), inst, scene_aabb = _gpu_hits(scene, primitive_type="trihexa")
+    assert inst.shape == (4000, 12)                                  # (one record per particle, not per rhombus)
+    cfg = oracle.default_grt_config(primitive_type=7)
+    ora = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=scene_aabb, dbg_cap=256)
+    num = num.astype(np.int64)
+    assert np.array_equal(num, ora["hit_num"].astype(np.int64)), f"{(num != ora['hit_num']).sum()} rays with a different number of processed hits"
+    k = np.minimum(num, 256)
+    got, ref = ids.view(np.uint32), ora["hit_ids"]
+    repeats = 0
+    for r in range(scene["H"] * scene["W"]):
+        assert np.array_equal(got[r, :k[r]], ref[r, :k[r]]), f"ray {r}: order differs"
+        repeats += int(k[r] - len(np.unique(got[r, :k[r]])))
+    assert num.max() > 20 and repeats > 0, "no ray was offered a particle twice"
+    flips = (cnt[0] != ora["hit_count"])[..., 0]
+    m = dict(flips=int(flips.sum()), feat=float(np.abs(feat[0] - ora["features"]).max()), dns=float(np.abs(dns[0] - ora["density"]).max()))
+    rng = np.random.default_rng(4)
+    g_rad = rng.normal(size=(scene["H"], scene["W"], 3)).astype(np.float32)
+    g_dns = rng.normal(size=(scene["H"], scene["W"], 1)).astype(np.float32)
+    for a in (g_rad, g_dns):
+        a[flips] = 0.0
+    rd, rs = oracle.grt_backward(cfg, 3, 1e-3, ora, g_rad, g_dns, np.zeros_like(g_dns))
+    for replay in (True, False):
+        gpu = _render(scene, g_rad, g_dns, None, primitive_type="trihexa", backward_hit_replay=replay)
+        gd, gs = gpu["grads"]
+        m[f"grad_replay_{replay}"] = (rel_err(gd[:, :11], rd[:, :11]), rel_err(gs, rs))
+    assert m["flips"] <= max(2, 2e-3 * flips.size) and m["feat"] < 1e-4 and m["dns"] < 1e-4, m
+    assert all(max(m[f"grad_replay_{r}"]) < 1e-3 for r in (True, False)), m
+
+
 def test_unsupported_primitives_are_refused():
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
-    for prim in ("trihexa", "sphere"):
+    for prim in ("sphere", "dodecahedron"):
         with pytest.raises(NotImplementedError, match="primitive_type"):
             grt.Tracer({"render": {"primitive_type": prim}})
 
