@@ -278,7 +278,7 @@ def make_grt_prim(prim):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gut_c4", "gut_c2", "grt_c3", "grt_icosahedron", "grt_custom", "grt_trisurfel"]
+    which = sys.argv[1:] or ["gut_c4", "gut_c2", "grt_c3", "grt_icosahedron", "grt_custom", "grt_trisurfel", "grt_trihexa"]
     for w_ in which:
         if w_.startswith("grt_") and w_ != "grt_c3":
             make_grt_prim(w_[4:])

@@ -583,7 +583,7 @@ def assert_gut_full_parity(stats, max_flip_frac=2e-3, max_rounding_frac=2e-4):
 # ---------------------------------------------------------------------------------------------------------------------
 # 3DGRT at BASELINE config 3's sizes
 # ---------------------------------------------------------------------------------------------------------------------
-GRT_PRIMITIVE_CODES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4, "custom": 5, "trisurfel": 6}
+GRT_PRIMITIVE_CODES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4, "custom": 5, "trisurfel": 6, "trihexa": 7}
 
 
 def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_cap=192, with_backward=True, log=None, wide_stride=0,

@@ -79,14 +79,16 @@ def test_gut_nht_frame_matches_oracle_at_baseline_size():
     ("c3_grt_icosahedron_100k_200", 100_000, 200, 200, 0.01, 1, "icosahedron"), ("c3_grt_icosahedron_1m_800", 1_000_000, 800, 800, 0.01, 149, "icosahedron"),
     ("c3_grt_custom_1m_800", 1_000_000, 800, 800, 0.01, 149, "custom"),
     # the flat proxies (round 5): plane-crossing candidates, the surfel branches of the per-hit math; tree walk
-    ("c3_grt_trisurfel_1m_800", 1_000_000, 800, 800, 0.01, 149, "trisurfel")])
+    ("c3_grt_trisurfel_1m_800", 1_000_000, 800, 800, 0.01, 149, "trisurfel"),
+    # three offers per particle (every rhombus a proxy of its own), tree walk
+    ("c3_grt_trihexa_1m_800", 1_000_000, 800, 800, 0.01, 149, "trihexa")])
 def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, ray_stride, prim):
     """3DGRT (LBVH + software traversal) against the oracle: the per-ray order of processed particles bit-exact, images within
     1e-4, gradients within 1e-3 relative (full frame at 100 k particles; a 4 k-ray subsample of the 1 M / 800x800 frame)."""
     # 1 M particles: every 149th ray through all pairs (4296 rays), then every 9th ray (71 k) with the oracle's scan restricted to the
     # packet lists the GPU built - checked to change nothing on the 4296
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
-    has_lists = prim != "custom" or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
+    has_lists = prim not in ("custom", "trihexa") or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
     stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print, wide_stride=9 if ray_stride > 1 and has_lists else 0,
                                primitive_type=prim)
     pu.record_full_parity(name, stats)
@@ -156,13 +158,13 @@ def test_gut_frame_equals_the_reference_kernels_on_a_sample_at_baseline_size(nam
     assert len(untouched) <= 3 * nflip, "particles with a gradient that the reference's backward never touched"
 
 
-@pytest.mark.parametrize("prim", ["instances", "icosahedron", "custom", "trisurfel"])
+@pytest.mark.parametrize("prim", ["instances", "icosahedron", "custom", "trisurfel", "trihexa"])
 def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_size(prim):
     """BASELINE config 3's frame (1 M Gaussians, 800 x 800) against the reference's OWN 3DGRT programs - referenceOptix.cu and
     referenceBwdOptix.cu compiled on the host over the emulated traversal, every ray offered every one of the 1 M instances
     (tests/golden/fullsize_grt_c3_1m_800.npz, 1536 rays on a regular sub-grid): accepted-hit counts, images, last-hit distances, and the
     gradient rows of the particles those rays' backward touches, with the upstream gradient confined to the sampled rays.
-    icosahedron (the paper's configuration) / custom / trisurfel: the programs built for that primitive over the reference's own meshes / world boxes
+    icosahedron (the paper's configuration) / custom / trisurfel / trihexa: the programs built for that primitive over the reference's own meshes / world boxes
     of all 1 M particles, 6144 rays, each ray offered a conservative superset of the particles it can touch
     (tests/golden/fullsize_grt_<prim>_c3_1m_800.npz, make_fullsize_golden.py: make_grt_prim)."""
     import os

@@ -535,7 +535,7 @@ def test_grt_trisurfel_checker_matches_reference_programs_golden():
 
 
 def test_grt_trihexa_checker_matches_reference_programs_golden():
-    """render.primitive_type = trihexa - refused by the HIP plugin; the CHECKER for it: the reference's programs compiled with
+    """render.primitive_type = trihexa (provided by the HIP plugin since round 5: tests/test_grt_gpu.py::test_trihexa_*); the CHECKER for it: the reference's programs compiled with
     PARTICLE_PRIMITIVE_TYPE = MOGTracingTriHexa over the emulated OptiX walking the six triangles per particle of the reference's trihexa
     kernel (back faces culled), against the oracle's three rhombi in the proxy's coordinate planes with the windings' facing (the z = 0 rhombus
     has two halves facing opposite ways).  A ray is offered the same particle up to three times; every offer is processed as a hit."""
