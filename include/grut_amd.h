@@ -327,7 +327,7 @@ typedef struct GrtConfig {
      * triangles with back faces culled, referenceOptix.cu:62), rays that start inside are not offered it.  GRUT_PRIM_CUSTOM: custom primitives over
      * the particles' WORLD boxes (computeGaussianEnclosingAABBKernel) with the world-space intersection program intersectCustomParticle
      * (gaussianParticles.cuh:407-441): the instances' hit point, offered to the rays that cross the world box, accepted within 3 sigma.
-     * The open meshes (trihexa, trisurfel) and `sphere` are GRUT_ERR_UNSUPPORTED. */
+     * The open meshes GRUT_PRIM_TRISURFEL / GRUT_PRIM_TRIHEXA: below.  `sphere` (OptiX's built-in sphere intersector) is GRUT_ERR_UNSUPPORTED. */
     int32_t primitive_type;
 } GrtConfig;
 enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON = 2, GRUT_PRIM_TETRAHEDRON = 3, GRUT_PRIM_DIAMOND = 4, GRUT_PRIM_CUSTOM = 5,
