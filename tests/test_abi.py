@@ -46,3 +46,20 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text and "oracle/" not in text, f
+
+
+def test_primitive_codes_match_the_header_and_the_checker():
+    """render.primitive_type names -> GRUT_PRIM_* codes: the plugin's table (3dgrut_amd/_abi.py), the C header's enum and the CPU checker's
+    GrtConfig.primitive_type (oracle/grt_oracle.c: g_prim) must be one numbering - a shifted code would trace another proxy silently."""
+    abi = importlib.import_module("3dgrut_amd._abi")
+    header = open(os.path.join(ROOT, "include", "grut_amd.h")).read()
+    enum = {name.lower(): int(val) for name, val in re.findall(r"GRUT_PRIM_([A-Z]+)\s*=\s*(\d+)", header)}
+    assert enum == abi.GRT_PRIMITIVES, (enum, abi.GRT_PRIMITIVES)
+    assert sorted(enum.values()) == list(range(len(enum)))
+    checker = open(os.path.join(ROOT, "oracle", "grt_oracle.c")).read()
+    for name in ("custom", "trisurfel", "trihexa"):        # the codes the checker branches on by number
+        assert re.search(rf"g_prim == {enum[name]}\b", checker), name
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import parity_util
+    assert parity_util.GRT_PRIMITIVE_CODES == enum
