@@ -61,6 +61,18 @@ struct GrtHandle {
     // next to the replay instead of behind it
     hipStream_t side_stream = nullptr;
     hipEvent_t side_fork = nullptr, side_join = nullptr;
+    // The TREE of the Gaussian BVH (Morton sort, hierarchy, refit: ~25 small dependent launches, 0.35 ms at 1 M particles) is built on a stream
+    // of its own behind the proxy + Morton kernels: frames with one ray origin are served by the packet lists, which need the proxies and the
+    // scene box only, so the list build and the trace start while the tree is still being linked; whatever walks the tree (frames without
+    // lists, the hybrid tracer, a backward without the forward's lists) makes its stream wait for `tree_done` first, and so does the next
+    // build before it touches the buffers the refit reads.  GRUT_GRT_SYNC_BUILD=1: everything on the caller's stream, as before.
+    hipStream_t tree_stream = nullptr;
+    hipEvent_t tree_fork = nullptr, tree_done = nullptr;
+    bool tree_async = false;   // the last build left its tree stages on tree_stream
+    int wait_tree(hipStream_t s) {
+        if (tree_async) GRUT_HIP(hipStreamWaitEvent(s, tree_done, 0));
+        return GRUT_OK;
+    }
     unsigned long long* dbg_bwd_sig = nullptr;   // grt_debug_backward_signature: caller DEVICE buffers the next backward fills
     uint32_t* dbg_bwd_cnt = nullptr;
     DeviceBuffer work_counters;  // instrumented launches (GRUT_GRT_COUNT=1): nodes, leaf tests, processed hits, rounds, inserts
@@ -78,6 +90,9 @@ static int grt_validate(const GrtConfig& c) {
     if (c.feature_transform_type != 0) {
         GRUT_REQUIRE(c.feature_transform_type == 1, "feature_transform_type %d: 0 (SH) or 1 (neural harmonic features)", c.feature_transform_type);
         GRUT_REQUIRE(!c.enable_normals, "neural harmonic features: enable_normals must be off");
+        // (the feature kernels index the feature rows by the log's proxy id and blend at the volumetric intersection: closed proxies only —
+        // the plugin's grt_config_from_conf refuses the same combinations)
+        GRUT_REQUIRE(c.primitive_type <= GRUT_PRIM_DIAMOND, "neural harmonic features: primitive_type %d is not provided (instances and the closed mesh proxies are)", c.primitive_type);
         GRUT_REQUIRE(c.feature_interpolation_support == 0 || c.feature_interpolation_support == 1, "feature_interpolation_support must be 0 (centre) or 1 (tetrahedra)");
         GRUT_REQUIRE(c.feature_activation_type >= 0 && c.feature_activation_type <= 3, "feature_activation_type must be 0..3");
         const int points = c.feature_interpolation_support == 1 ? 4 : 1;
@@ -181,6 +196,7 @@ int grt_trim(GrtHandle* h) {
     GRUT_HIP(hipDeviceSynchronize());
     release_scratch(h);
     h->built = false;
+    h->tree_async = false;
     h->mesh_built = false;
     h->N = 0;
     h->NP = 0;
@@ -197,6 +213,7 @@ int grt_trim(GrtHandle* h) {
 
 void grt_destroy(GrtHandle* h) {
     if (!h) return;
+    if (h->tree_stream) (void)hipStreamSynchronize(h->tree_stream);   // (the refit may still be reading the buffers released below)
     release_scratch(h);
     if (h->log_state_host) (void)hipHostFree(h->log_state_host);
     if (h->l_host) (void)hipHostFree(h->l_host);
@@ -205,6 +222,9 @@ void grt_destroy(GrtHandle* h) {
     if (h->side_fork) (void)hipEventDestroy(h->side_fork);
     if (h->side_join) (void)hipEventDestroy(h->side_join);
     if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->tree_fork) (void)hipEventDestroy(h->tree_fork);
+    if (h->tree_done) (void)hipEventDestroy(h->tree_done);
+    if (h->tree_stream) (void)hipStreamDestroy(h->tree_stream);
     h->fwd_timer.destroy();
     h->bwd_timer.destroy();
     h->build_timer.destroy();
@@ -230,6 +250,7 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     const uint32_t per = h->cfg.primitive_type == GRUT_PRIM_TRIHEXA ? 3u : 1u;
     GRUT_REQUIRE((uint64_t)N * per <= 0x1FFFFFFEu, "grt_build_bvh: %u particles (the hit buffers keep 29 bits of proxy index)", N);
     if (!rebuild && (!h->built || h->N != N)) rebuild = 1;  // "cannot refit GAS with a different number of gaussian" (optixTracer.cpp:629-632)
+    GRUT_CHECK(h->wait_tree(s));   // the previous build's tree stages read what this build is about to overwrite (and its scratch may move)
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.begin(s));
     const uint32_t NP = N * per;
     const size_t n = NP;
@@ -259,20 +280,40 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     // refit-only updates keep the sorted order of the last full build, so the code / id buffers must stay untouched
     grt_launch_morton(s, NP, h->aabb.as<float>(), scene_enc, h->scene.as<float>(), rebuild ? h->codes.as<uint32_t>() : nullptr,
                       rebuild ? h->ids.as<uint32_t>() : nullptr);
+    GRUT_CHECK(h->refit_todo.ensure((n + 1) * 4, 1.25f));
+    // proxies, world boxes and the scene box are final here: everything behind this line links the tree (see GrtHandle::tree_stream)
+    static const bool sync_build = getenv("GRUT_GRT_SYNC_BUILD") != nullptr;
+    hipStream_t ts = s;
+    h->tree_async = false;
+    if (!sync_build) {
+        if (!h->tree_stream) {
+            GRUT_HIP(hipStreamCreateWithFlags(&h->tree_stream, hipStreamNonBlocking));
+            GRUT_HIP(hipEventCreateWithFlags(&h->tree_fork, hipEventDisableTiming));
+            GRUT_HIP(hipEventCreateWithFlags(&h->tree_done, hipEventDisableTiming));
+        }
+        GRUT_HIP(hipEventRecord(h->tree_fork, s));
+        GRUT_HIP(hipStreamWaitEvent(h->tree_stream, h->tree_fork, 0));
+        ts = h->tree_stream;
+    }
     if (rebuild) {
         uint32_t *sc = nullptr, *si = nullptr;
-        GRUT_CHECK(sort_pairs_u32(s, NP, nullptr, 0, 30, h->codes.as<uint32_t>(), h->ids.as<uint32_t>(), h->codes_tmp.as<uint32_t>(),
+        GRUT_CHECK(sort_pairs_u32(ts, NP, nullptr, 0, 30, h->codes.as<uint32_t>(), h->ids.as<uint32_t>(), h->codes_tmp.as<uint32_t>(),
                                   h->ids_tmp.as<uint32_t>(), h->sort_scratch.ptr, h->sort_scratch.bytes, &sc, &si));
         h->sorted_codes = sc;
         h->sorted_ids = si;
-        grt_launch_hierarchy(s, NP, sc, si, h->nodes.as<GrtNode>());
+        grt_launch_hierarchy(ts, NP, sc, si, h->nodes.as<GrtNode>());
     }
     // the refit re-derives every box from the fresh proxies; on rebuild = 0 the sorted order of the last build is reused
-    GRUT_HIP(hipMemsetAsync(h->counters.ptr, 0, n, s));   // per-node "done in pass" bytes
-    GRUT_CHECK(h->refit_todo.ensure((n + 1) * 4, 1.25f));
-    grt_launch_refit(s, NP, h->aabb.as<float>(), h->slack.as<float>(), h->nodes.as<GrtNode>(), h->counters.as<uint8_t>(), h->refit_todo.as<uint32_t>());
+    GRUT_HIP(hipMemsetAsync(h->counters.ptr, 0, n, ts));   // per-node "done in pass" bytes
+    grt_launch_refit(ts, NP, h->aabb.as<float>(), h->slack.as<float>(), h->nodes.as<GrtNode>(), h->counters.as<uint8_t>(), h->refit_todo.as<uint32_t>());
     GRUT_HIP(hipGetLastError());
-    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.end(s));
+    // (the build stage's time runs to the end of the tree, on whichever stream that is: with the tree on its own stream the stage
+    // overlaps the forward's list build and trace, and the stages no longer add up to the step)
+    if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->build_timer.end(ts));
+    if (ts != s) {
+        GRUT_HIP(hipEventRecord(h->tree_done, ts));
+        h->tree_async = true;
+    }
     h->N = N;
     h->NP = NP;
     h->built = true;
@@ -450,6 +491,7 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     GrtLists lists;
     GRUT_CHECK(build_lists(h, s, P, bvh, ray_origin, ray_direction, &lists));
     if (h->log_valid) h->log_lists = lists;   // the backward's exact rounds (flagged rays) scan the same lists
+    if (!lists.ranges) GRUT_CHECK(h->wait_tree(s));   // this frame walks the tree
     grt_launch_trace_fwd(s, P, bvh, particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
                          out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters, log, lists);
     if (P.nht) {
@@ -488,6 +530,9 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
         fprintf(stderr, "[grut] grt fwd list batches fetched (64 entries each) %llu\n", h->work_host[12]);
         fprintf(stderr, "[grut] grt fwd leaf tests: passed %llu, distance out of range %llu, box missed %llu, beyond 3 sigma %llu; wave-level leaf visits %llu, of which ran the box test %llu, the insert chain %llu\n",
                 h->work_host[5], h->work_host[6], h->work_host[7], h->work_host[8], h->work_host[9], h->work_host[10], h->work_host[11]);
+        fprintf(stderr, "[grut] grt fwd phases, summed over the packets' waves (ms): scans %.1f (candidate work loops %.1f with packet lists), hit log %.1f, per-hit evaluation %.1f\n", h->work_host[13] * 1e-5,
+                lists.ranges ? h->work_host[0] * 1e-5 : 0.0, h->work_host[14] * 1e-5, h->work_host[15] * 1e-5);
+        if (lists.ranges) h->work_host[0] = 0;   // (grt_stats reports word 0 as node visits)
     }
     GRUT_HIP(hipGetLastError());
     if (h->cfg.enable_kernel_timings) GRUT_CHECK(h->fwd_timer.end(s));
@@ -554,6 +599,7 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
         fprintf(stderr, "[grut] grt bwd: %zu of %zu rays re-derive their rounds (log chunks %u, overflow %u, lists %s)\n", flagged, nb.size(), st[0], st[1],
                 lists.ranges ? "yes" : "no");
     }
+    if (!lists.ranges) GRUT_CHECK(h->wait_tree(s));   // a backward without the forward's lists walks the tree (before the fork: the side stream inherits the wait)
     hipStream_t rederive = s;
     // whatever happens after the fork, the caller's stream must wait for the side stream again before this call returns (the
     // re-derivation may still be adding to the gradient buffers): the guard joins on every exit path
@@ -654,6 +700,7 @@ int grt_trace_hybrid(GrtHandle* h, void* stream_, const GrtFrame* frame, const f
     GRUT_REQUIRE((mesh->vertex_tangents != nullptr) == (mesh->vertex_has_tangents != nullptr), "grt_trace_hybrid: vertex_tangents and vertex_has_tangents go together");
     GRUT_REQUIRE(mesh->num_materials == 0 || mesh->materials, "grt_trace_hybrid: null material table");
     const GrtTraceParams P = trace_params(h, *frame);
+    GRUT_CHECK(h->wait_tree(s));   // bounced rays walk the tree
     GrtBvh bvh = bvh_view(h);
     // the material table travels with the launch (a default material stands in when the caller has none: faces that need one then
     // shade with the reference's own fallback values, tracer.py:150-170)

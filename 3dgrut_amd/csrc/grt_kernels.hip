@@ -563,9 +563,24 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
         c.ok = c.box && wanted;
         return c;
     }
-    // slab test of the unit box: one reciprocal per axis, IEEE minNum / maxNum
-    const float ix = 1.f / pdx, iy = 1.f / pdy, iz = 1.f / pdz;
-    const float ax0 = (-1.f - pox) * ix, ax1 = (1.f - pox) * ix, ay0 = (-1.f - poy) * iy, ay1 = (1.f - poy) * iy, az0 = (-1.f - poz) * iz, az1 = (1.f - poz) * iz;
+    // slab test of the unit box: the three reciprocals from ONE correctly rounded division - 1 / (pdx pdy pdz) times the product of the other
+    // two components (round 6: 20 instead of 39 instructions; the box test is a fifth of the forward's issue time) - unless that product
+    // leaves [1e-24, 1e24] (a ray within rounding of perpendicular to a proxy axis, a zero component): then one division per axis and the
+    // planes as (plane - po) * reciprocal, as before (an infinite reciprocal must meet a finite factor).
+    // Every intermediate of the short form is a normal number.  IEEE minNum / maxNum.  Same operations, same order in the CPU checker.
+    float ax0, ax1, ay0, ay1, az0, az1;
+    {
+        const float pxy = pdx * pdy, prod = pxy * pdz, aprod = fabsf(prod);
+        if (aprod >= 1e-24f && aprod <= 1e24f) {
+            const float q = 1.f / prod;
+            const float ix = q * (pdy * pdz), iy = q * (pdx * pdz), iz = q * pxy;
+            // the slab planes (-1 - po) i and (1 - po) i as one fused multiply-add each (finite reciprocals here)
+            ax0 = fmaf(-pox, ix, -ix); ax1 = fmaf(-pox, ix, ix); ay0 = fmaf(-poy, iy, -iy); ay1 = fmaf(-poy, iy, iy); az0 = fmaf(-poz, iz, -iz); az1 = fmaf(-poz, iz, iz);
+        } else {
+            const float ix = 1.f / pdx, iy = 1.f / pdy, iz = 1.f / pdz;
+            ax0 = (-1.f - pox) * ix; ax1 = (1.f - pox) * ix; ay0 = (-1.f - poy) * iy; ay1 = (1.f - poy) * iy; az0 = (-1.f - poz) * iz; az1 = (1.f - poz) * iz;
+        }
+    }
     const float tnear = max3f(fminf(ax0, ax1), fminf(ay0, ay1), fminf(az0, az1));
     const float tfar = min3f(fmaxf(ax0, ax1), fmaxf(ay0, ay1), fmaxf(az0, az1));
     if (wanted) c.why = 2;
@@ -713,6 +728,7 @@ struct GhostLog {
 // one optixTrace: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in (t, particle)
 struct TraceCounters {
     uint32_t nodes = 0, leaf_tests = 0, inserts = 0, rounds = 0, processed = 0, rej[4] = {0, 0, 0, 0}, wave_leaves = 0, wave_slab = 0, wave_insert = 0, batch_loads = 0;
+    unsigned long long phase[3] = {0ull, 0ull, 0ull}, test_ticks = 0ull;   // (test_ticks: the part of the scans spent in the candidate tests' work loops)   // instrumented launches: 10 ns ticks a packet's wave spent in the rounds' scans / the hit log / the per-hit evaluation
 };
 
 // one optixTrace for every ray of the wave: the (up to) 16 nearest candidates with t in (tmin, tmax), ascending in
@@ -799,53 +815,71 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
 //     |x.dh| <= sqrt 3 sqrt(|S e|^2 - 1 / |S^-1 e|^2)      (zero for a sphere: its hit distance IS v.dh)
 // Over the cone, v.dh = |v| cos(phi) with phi within theta of the angle between v and the axis; |S e| is kmax-Lipschitz and |S^-1 e|
 // (1/kmin)-Lipschitz in dh.  (S e)_i = kscl_i^2 (W_i . dh), (S^-1 e)_i = W_i . dh.
+// (hardware reciprocal / square root, 1 ulp each: the bounds are conservative by their margins - 1e-5 relative on every norm, 3e-6 L and
+// 6e-6 on the angular part, which cover a dozen such roundings - not by correctly rounded operations; the IEEE sequences were 200
+// instructions per staged entry, 7 % of the forward's issue time)
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ void packet_bounds(const GrtCone& k, f3 v, float L2, const float4& a, const float4& b, float w22, float key, float ub,
                                               float dmin, float dmax, float& lo, float& hi) {
     lo = key; hi = ub;
     if (k.cos_t <= -1.f) return;   // cone of everything
-    const float L = sqrtf(L2);
-    const float k0 = 1.f / (a.x * a.x + a.y * a.y + a.z * a.z), k1 = 1.f / (a.w * a.w + b.x * b.x + b.y * b.y), k2 = 1.f / (b.z * b.z + b.w * b.w + w22 * w22);   // kscl^2
-    const float kmax = sqrtf(fmaxf(k0, fmaxf(k1, k2))), kmin = sqrtf(fminf(k0, fminf(k1, k2)));
+    const float L = fast_sqrt(L2);
+    const float k0 = fast_rcp(a.x * a.x + a.y * a.y + a.z * a.z), k1 = fast_rcp(a.w * a.w + b.x * b.x + b.y * b.y), k2 = fast_rcp(b.z * b.z + b.w * b.w + w22 * w22);   // kscl^2
+    const float kmax = fast_sqrt(fmaxf(k0, fmaxf(k1, k2))), ikmin = __builtin_amdgcn_rsqf(fminf(k0, fminf(k1, k2)));
     const float w0 = a.x * k.ax + a.y * k.ay + a.z * k.az, w1 = a.w * k.ax + b.x * k.ay + b.y * k.az, w2 = b.z * k.ax + b.w * k.ay + w22 * k.az;
     const float s0 = k0 * w0, s1 = k1 * w1, s2 = k2 * w2;
-    const float chord = sqrtf(fmaxf(0.f, 2.f * (1.f - k.cos_t))) * 1.00001f;
-    const float se = (sqrtf(s0 * s0 + s1 * s1 + s2 * s2) + kmax * chord) * 1.00001f;       // >= |S e| over the cone
-    const float sie = (sqrtf(w0 * w0 + w1 * w1 + w2 * w2) + chord / kmin) * 1.00001f;       // >= |S^-1 e| over the cone
-    const float h = 1.7320509f * sqrtf(fmaxf(0.f, se * se - (1.f - 1e-5f) / (sie * sie))) * 1.00002f + 2e-6f * L + 1e-30f;
-    const float ca = L > 0.f ? fminf(1.f, fmaxf(-1.f, (v.x * k.ax + v.y * k.ay + v.z * k.az) / L)) : 1.f;
-    const float sa = sqrtf(fmaxf(0.f, 1.f - ca * ca));
-    const float cmax = (ca >= k.cos_t) ? 1.f : fminf(1.f, ca * k.cos_t + sa * k.sin_t + 4e-6f);     // cos of (alpha - theta), or 1 inside the cone
-    const float cmin = (ca <= -k.cos_t) ? -1.f : fmaxf(-1.f, ca * k.cos_t - sa * k.sin_t - 4e-6f);  // cos of (alpha + theta), or -1 past pi
+    const float chord = fast_sqrt(fmaxf(0.f, 2.f * (1.f - k.cos_t))) * 1.00001f;
+    const float se = (fast_sqrt(s0 * s0 + s1 * s1 + s2 * s2) + kmax * chord) * 1.00001f;       // >= |S e| over the cone
+    const float sie = (fast_sqrt(w0 * w0 + w1 * w1 + w2 * w2) + chord * ikmin) * 1.00001f;      // >= |S^-1 e| over the cone
+    const float h = 1.7320509f * fast_sqrt(fmaxf(0.f, se * se - (1.f - 1e-5f) * fast_rcp(sie * sie))) * 1.00002f + 3e-6f * L + 1e-30f;
+    const float ca = L > 0.f ? fminf(1.f, fmaxf(-1.f, (v.x * k.ax + v.y * k.ay + v.z * k.az) * fast_rcp(L))) : 1.f;
+    const float sa = fast_sqrt(fmaxf(0.f, 1.f - ca * ca));
+    const float cmax = (ca >= k.cos_t) ? 1.f : fminf(1.f, ca * k.cos_t + sa * k.sin_t + 6e-6f);     // cos of (alpha - theta), or 1 inside the cone
+    const float cmin = (ca <= -k.cos_t) ? -1.f : fmaxf(-1.f, ca * k.cos_t - sa * k.sin_t - 6e-6f);  // cos of (alpha + theta), or -1 past pi
     const float tl = L * cmin - h, th = L * cmax + h;   // bounds of t |d|
-    const float l2 = tl > 0.f ? (tl / dmax) * (1.f - 4e-6f) : 0.f;
-    const float h2 = th > 0.f ? (th / dmin) * (1.f + 4e-6f) + 1e-30f : 0.f;
+    const float l2 = tl > 0.f ? (tl * fast_rcp(dmax)) * (1.f - 4e-6f) : 0.f;
+    const float h2 = th > 0.f ? (th * fast_rcp(dmin)) * (1.f + 4e-6f) + 1e-30f : 0.f;
     lo = fmaxf(lo, l2);
     hi = fminf(hi, h2);
 }
 // ---------------------------------------------------------------------------------------------
 // packet lists (GrtLists): one k = 16 trace round as a scan of a window of the packet's candidate list
 // ---------------------------------------------------------------------------------------------
-// max over the wave of non-negative floats (or any mix with at least one non-negative value): the four DPP steps leave each 16-lane
-// row's maximum in all its lanes, the rows meet on the scalar unit (the bit patterns of non-negative floats order like integers)
-__device__ __forceinline__ float wave_max_nonneg(float v) {
-    v = fmaxf(v, dpp_perm<0xB1>(v));    // quad_perm [1,0,3,2]
-    v = fmaxf(v, dpp_perm<0x4E>(v));    // quad_perm [2,3,0,1]
-    v = fmaxf(v, dpp_perm<0x141>(v));   // row_half_mirror
-    v = fmaxf(v, dpp_perm<0x140>(v));   // row_mirror
-    const int a = __builtin_amdgcn_readlane(__float_as_int(v), 0), b = __builtin_amdgcn_readlane(__float_as_int(v), 16);
-    const int c = __builtin_amdgcn_readlane(__float_as_int(v), 32), d = __builtin_amdgcn_readlane(__float_as_int(v), 48);
-    return __int_as_float(max(max(a, b), max(c, d)));
-}
-// min / max over the wave of any floats (DPP within the rows of 16, the four rows meet through scalar registers)
+// min / max over the wave of any floats: the DPP modifier rides on the min / max instruction itself (v_min_f32_dpp: four steps inside the
+// rows of 16, then row_bcast:15 / row_bcast:31 carry the rows' results down to lane 63) - 6 instructions + one v_readlane_b32 where the
+// compiler's form of fminf(v, dpp(v)) is mov_dpp + two canonicalisations + min per step and four readlanes (25 issue slots: a tenth of
+// the forward's VALU time went into the two reductions of every first test).  IEEE mode: a NaN operand loses, like fminf / fmaxf.
+// (the hazard between a VALU write and a DPP read of the same register - two wait states - is covered by the s_nop in front of each step:
+// the compiler does not look into inline asm)
+#define GRT_DPP_STEP(op, ctl) "s_nop 1\n\t" op " %0, %0, %0 " ctl " row_mask:0xf bank_mask:0xf\n\t"
 template <bool MAX>
 __device__ __forceinline__ float wave_extreme(float v) {
-    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
-    v = op(v, dpp_perm<0xB1>(v));
-    v = op(v, dpp_perm<0x4E>(v));
-    v = op(v, dpp_perm<0x141>(v));
-    v = op(v, dpp_perm<0x140>(v));
-    auto rl = [](float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); };
-    return op(op(rl(v, 0), rl(v, 16)), op(rl(v, 32), rl(v, 48)));
+    if (MAX) {
+        asm(GRT_DPP_STEP("v_max_f32_dpp", "quad_perm:[1,0,3,2]") GRT_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1]") GRT_DPP_STEP("v_max_f32_dpp", "row_half_mirror")
+            GRT_DPP_STEP("v_max_f32_dpp", "row_mirror")
+            "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+            : "+v"(v));
+    } else {
+        asm(GRT_DPP_STEP("v_min_f32_dpp", "quad_perm:[1,0,3,2]") GRT_DPP_STEP("v_min_f32_dpp", "quad_perm:[2,3,0,1]") GRT_DPP_STEP("v_min_f32_dpp", "row_half_mirror")
+            GRT_DPP_STEP("v_min_f32_dpp", "row_mirror")
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0"
+            : "+v"(v));
+    }
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_nonneg(float v) { return wave_extreme<true>(v); }
+// the minimum of `lo` and the maximum of `hi` over the wave in one interleaved sequence (each chain's steps sit in the other's wait states)
+#define GRT_DPP_PAIR(ctl) "v_min_f32_dpp %0, %0, %0 " ctl "\n\tv_max_f32_dpp %1, %1, %1 " ctl "\n\ts_nop 0\n\t"
+__device__ __forceinline__ void wave_min_max(float lo, float hi, float& lo_all, float& hi_all) {
+    asm("s_nop 1\n\t" GRT_DPP_PAIR("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") GRT_DPP_PAIR("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+        GRT_DPP_PAIR("row_half_mirror row_mask:0xf bank_mask:0xf") GRT_DPP_PAIR("row_mirror row_mask:0xf bank_mask:0xf")
+        GRT_DPP_PAIR("row_bcast:15 row_mask:0xa bank_mask:0xf") GRT_DPP_PAIR("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        : "+v"(lo), "+v"(hi));
+    lo_all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), 63));
+    hi_all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi), 63));
 }
 struct ListEntry {
     float4 a, b, e;    // proxy record {W rows, W (o - mu)}
@@ -916,6 +950,9 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
 // second pass goes through the deferred entries with whatever bound the first pass left.  Entries refined during a round carry their
 // flag only from the round's end (`pending`, LDS): in the second pass an entry without the flag has been tested by the first.
 constexpr uint32_t kGrtPendingCap = 512;
+#ifndef GRT_LIST_ILP
+#define GRT_LIST_ILP 1   // entries tested per iteration of list_round's work loop (2: two independent candidate chains)
+#endif
 template <bool COUNT, int G, bool GHOST = false, bool REFINE = false>
 __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& cone, float dmin, float dmax, uint32_t le, uint32_t& start, const RayW& r,
                                            float tmin, float tmax, bool active, int lane, float4* __restrict__ s_ent /* [64][3] */, HitBufferT<G>& buf,
@@ -924,7 +961,7 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
     buf.clear();
     if (COUNT && active) tc.rounds++;
     if (!__any(active)) return;
-    const float wmin_tmin = wave_min(active ? tmin : 3.0e38f);
+    const float wmin_tmin = wave_extreme<false>(active ? tmin : 3.0e38f);
     float wmax_bound = wave_max_nonneg(active ? tmax : -1.f);   // no lane holds 16 candidates yet
     const float mark = (REFINE && *span < 1.0e37f) ? wmin_tmin + mark_factor * *span : 3.0e38f;
     uint32_t n_pending = 0u;
@@ -960,6 +997,79 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
                 seen_live = alive != 0ull;
             }
             int tested = 0;
+            const unsigned long long tt0 = (COUNT && live) ? wall_clock64() : 0ull;
+            const bool timed_tests = COUNT && live;
+#if GRT_LIST_ILP == 2
+            // Two live entries per iteration: their candidate tests are independent instruction chains (the second one's early-out uses
+            // the bound BEFORE the first one's insertion - a superset; `reach` re-checks against the buffer as it then stands, so
+            // decisions, buffers and ghosts are those of the one-by-one loop).  A packet's wave is latency-bound when its SIMD is not
+            // full - the last 45 % of the launch's span - and the two chains fill each other's issue gaps.
+            while (live) {
+                const int j0 = __ffsll((long long)live) - 1;
+                live &= live - 1;
+                const bool two = live != 0ull;
+                const int j1 = two ? __ffsll((long long)live) - 1 : j0;
+                live &= live - 1;   // (0 & -1 = 0 when there was no second entry)
+                const uint32_t id0 = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j0), id1 = (uint32_t)__builtin_amdgcn_readlane((int)my_id, j1);
+                if (COUNT && lane == 0) tc.wave_leaves += two ? 2u : 1u;
+                const bool ft0 = REFINE && pass == 0 && ((fresh >> j0) & 1ull) && n_pending < kGrtPendingCap;
+                const bool ft1 = two && REFINE && pass == 0 && ((fresh >> j1) & 1ull) && n_pending + (ft0 ? 1u : 0u) < kGrtPendingCap;
+                float lo0 = 3.0e38f, hi0 = -3.0e38f, lo1 = 3.0e38f, hi1 = -3.0e38f;
+                if (active) {
+                    const float t_lo = GHOST ? ghosts->tie_t : tmin;
+                    const Cand c0 = GHOST ? candidate_abe<true, true>(s_ent[j0 * 3], s_ent[j0 * 3 + 1], s_ent[j0 * 3 + 2], r, t_lo, buf.t[G - 1], id0, buf.id[G - 1], ft0)
+                                          : candidate_abe<true>(s_ent[j0 * 3], s_ent[j0 * 3 + 1], s_ent[j0 * 3 + 2], r, t_lo, buf.t[G - 1], id0, buf.id[G - 1], ft0);
+                    Cand c1 = GHOST ? candidate_abe<true, true>(s_ent[j1 * 3], s_ent[j1 * 3 + 1], s_ent[j1 * 3 + 2], r, t_lo, buf.t[G - 1], id1, buf.id[G - 1], ft1)
+                                    : candidate_abe<true>(s_ent[j1 * 3], s_ent[j1 * 3 + 1], s_ent[j1 * 3 + 2], r, t_lo, buf.t[G - 1], id1, buf.id[G - 1], ft1);
+                    if (!two) { c1.ok = false; c1.box = false; }
+                    auto take = [&](const Cand& cd, uint32_t id, float& tl, float& th) {
+                        if (REFINE && cd.box) { tl = cd.t; th = cd.t; }
+                        const bool reach = cd.ok && (cd.t < tmax) && (cd.tnear <= tmax) && hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
+                        const bool in_range = reach && (cd.t > tmin);
+                        const bool ins = in_range && (cd.tfar >= tmin);
+                        if (GHOST && ((in_range && !ins) || (reach && !in_range && hit_less(ghosts->tie_t, ghosts->tie_id, cd.t, id)))) ghosts->add(cd.tfar, id);
+                        if (COUNT) {
+                            tc.leaf_tests++; tc.rej[cd.ok ? 0 : cd.why]++;
+                            const unsigned long long ms = __ballot(cd.ok || cd.why != 1), mi = __ballot(ins);
+                            if (ms && lane == __ffsll((long long)ms) - 1) tc.wave_slab++;
+                            if (mi && lane == __ffsll((long long)mi) - 1) tc.wave_insert++;
+                        }
+                        if (ins) {
+                            buf.insert(cd.t, id);
+                            if (COUNT) tc.inserts++;
+                        }
+                    };
+                    take(c0, id0, lo0, hi0);
+                    if (two) take(c1, id1, lo1, hi1);
+                }
+                if (ft0 || ft1) {
+                    float l0, h0, l1, h1;
+                    wave_min_max(lo0, hi0, l0, h0);
+                    wave_min_max(lo1, hi1, l1, h1);
+                    if (ft0) {
+                        if (lane == 0) {
+                            __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.bounds + base + (uint32_t)j0),
+                                               (unsigned long long)__float_as_uint(l0) | ((unsigned long long)__float_as_uint(h0) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            pending[n_pending] = base + (uint32_t)j0;
+                        }
+                        ++n_pending;
+                    }
+                    if (ft1) {
+                        if (lane == 0) {
+                            __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.bounds + base + (uint32_t)j1),
+                                               (unsigned long long)__float_as_uint(l1) | ((unsigned long long)__float_as_uint(h1) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            pending[n_pending] = base + (uint32_t)j1;
+                        }
+                        ++n_pending;
+                    }
+                }
+                tested += 2;
+                if ((tested & 7) == 0 && live) {
+                    wmax_bound = wave_max_nonneg(active ? fminf(tmax, buf.t[G - 1]) : -1.f);
+                    live &= __ballot(!(my_lo > wmax_bound));
+                }
+            }
+#else
             while (live) {
                 const int j = __ffsll((long long)live) - 1;
                 live &= live - 1;
@@ -988,7 +1098,8 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
                 }
                 if (first_test) {
                     // (a NaN distance fails every comparison of the candidate test: such a ray never wants the entry; fminf / fmaxf drop it)
-                    const float lo_all = wave_extreme<false>(t_mine_lo), hi_all = wave_extreme<true>(t_mine_hi);
+                    float lo_all, hi_all;
+                    wave_min_max(t_mine_lo, t_mine_hi, lo_all, hi_all);
                     if (lane == 0) {
                         __hip_atomic_store(reinterpret_cast<unsigned long long*>(L.bounds + base + (uint32_t)j),
                                            (unsigned long long)__float_as_uint(lo_all) | ((unsigned long long)__float_as_uint(hi_all) << 32), __ATOMIC_RELAXED,
@@ -1002,6 +1113,8 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
                     live &= __ballot(!(my_lo > wmax_bound));
                 }
             }
+#endif
+            if (timed_tests) tc.test_ticks += wall_clock64() - tt0;
             __syncthreads();
             if (beyond) break;
             wmax_bound = wave_max_nonneg(active ? fminf(tmax, buf.t[G - 1]) : -1.f);
@@ -1199,6 +1312,9 @@ template <int DEG, bool COUNT, bool UNI, bool LOG>
 #ifndef GRT_FWD_WAVES
 #define GRT_FWD_WAVES 4
 #endif
+#ifndef GRT_HIT_PREFETCH
+#define GRT_HIT_PREFETCH 0
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVES, GRT_FWD_WAVES))) void grt_trace_fwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
                                                            const float* __restrict__ sph, const float* __restrict__ ray_o,
                                                            const float* __restrict__ ray_d, float* __restrict__ out_rad,
@@ -1273,6 +1389,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         GhostLog ghosts = {s_hit_id + lane, 0u, tmin_prev2, tLast, last_id};
         if (LOG) { tmin_prev2 = tmin_prev1; tmin_prev1 = tLast + eps; }
         uint32_t g_id[kGrtMaxGhosts];
+        const unsigned long long ph0 = COUNT ? wall_clock64() : 0ull;
         {
             HitBuffer buf;
             if (UNI) list_round<COUNT, kGrtMaxHits, LOG, true>(lists, cone, dmin, dmax, list_end, list_start, r, tLast + eps, tExit + eps, running, lane, s_ent, buf, tc, &ghosts,
@@ -1286,6 +1403,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         }
         if (s_hit_id[lane] == 0xFFFFFFFFu) running = false;
         const bool full = s_hit_id[(kGrtMaxHits - 1) * 64 + lane] != 0xFFFFFFFFu;
+        const unsigned long long ph1 = COUNT ? wall_clock64() : 0ull;
         // LOG: the round's chunk holds the round's candidates AND its ghosts, merged in (t, particle) order — the replay walks a chunk
         // front to back and decides with the backward program's own intervals which entries that program is offered (the candidates
         // behind the ray's termination are among them: whether the backward reaches one is a matter of ITS interval, t < endT)
@@ -1300,13 +1418,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
 #pragma unroll
             for (int g = 0; g < kGrtMaxGhosts; ++g) {
                 const bool have = g_id[g] != 0xFFFFFFFFu;
-                g_t[g] = have ? candidate(bvh.inst + 12 * (size_t)g_id[g], r, 3.0e38f).t : 3.0e38f;   // (the very value the round computed: same arithmetic, same inputs)
+                g_t[g] = 3.0e38f;
+                g_pos[g] = 0u;
+                if (!__any(have)) continue;   // (slot g is empty on every ray of the packet - the usual case for the later slots: no distance to evaluate)
+                if (have) g_t[g] = candidate(bvh.inst + 12 * (size_t)g_id[g], r, 3.0e38f).t;   // (the very value the round computed: same arithmetic, same inputs)
                 // beyond the 16th candidate of a full round: not this round's business (the next round meets it again)
                 if (have && full && !hit_less(g_t[g], g_id[g], t16, id16)) { g_id[g] = 0xFFFFFFFFu; g_t[g] = 3.0e38f; }
                 ng += g_id[g] != 0xFFFFFFFFu ? 1u : 0u;
-                g_pos[g] = 0u;
             }
             const bool any_ghost = __any(ng != 0u);
+            // which ghost slots hold anything on any ray of the packet (wave-uniform): the merge below skips the others - a round's ghosts are
+            // few, the slots fill from 0
+            uint32_t slot_used = 0u;
+#pragma unroll
+            for (int g = 0; g < kGrtMaxGhosts; ++g) slot_used |= __any(g_id[g] != 0xFFFFFFFFu) ? (1u << g) : 0u;
             if (chunk) {
 #pragma unroll 1
                 for (int i = 0; i < kGrtMaxHits; ++i) {
@@ -1316,6 +1441,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                     if (any_ghost) {
 #pragma unroll
                         for (int g = 0; g < kGrtMaxGhosts; ++g) {
+                            if (!((slot_used >> g) & 1u)) continue;
                             const bool ghost_first = g_id[g] != 0xFFFFFFFFu && hit_less(g_t[g], g_id[g], ft, fid);
                             pos += ghost_first ? 1u : 0u;
                             g_pos[g] += (g_id[g] != 0xFFFFFFFFu && !ghost_first && fid != 0xFFFFFFFFu) ? 1u : 0u;
@@ -1326,9 +1452,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                 if (any_ghost) {
 #pragma unroll
                     for (int g = 0; g < kGrtMaxGhosts; ++g) {
+                        if (!((slot_used >> g) & 1u)) continue;
 #pragma unroll
                         for (int h = 0; h < kGrtMaxGhosts; ++h)
-                            if (h != g) g_pos[g] += (g_id[h] != 0xFFFFFFFFu && hit_less(g_t[h], g_id[h], g_t[g], g_id[g])) ? 1u : 0u;
+                            if (h != g && ((slot_used >> h) & 1u)) g_pos[g] += (g_id[h] != 0xFFFFFFFFu && hit_less(g_t[h], g_id[h], g_t[g], g_id[g])) ? 1u : 0u;
                         if (g_id[g] != 0xFFFFFFFFu) chunk[g_pos[g] * 64] = g_id[g] | kGrtGhostBit;
                     }
                 }
@@ -1337,21 +1464,50 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                     if ((uint32_t)g >= ng) chunk[(kGrtMaxHits + g) * 64] = 0xFFFFFFFFu;   // the unused tail of the chunk
             }
         }
+        const unsigned long long ph2 = COUNT ? wall_clock64() : 0ull;
         {
             f3 dir = r.d;   // opaque copy: stops the compiler from hoisting the basis back out of the round loop
             asm volatile("" : "+v"(dir.x), "+v"(dir.y), "+v"(dir.z));
             sh_basis16(P.sph_degree, dir, basis);
         }
         // processHit (gaussianParticles.cuh:337-405) for the round's hits in order, while the ray is above min_transmittance
+#if GRT_HIT_PREFETCH
+        // the next hit's parameter row is requested while this hit is evaluated (a lone wave otherwise waits a memory round trip per hit, and
+        // another one for the SH row of an accepted hit: one word of each of its cache lines is touched ahead)
+        uint32_t id_next = s_hit_id[lane];
+        float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nq = na, ns = na;
+        float touch = 0.f;
+        auto request = [&](uint32_t idn) {
+            if (running && idn != 0xFFFFFFFFu) {
+                const uint32_t pn = particle_of(P, idn);
+                na = density12[3 * (size_t)pn]; nq = density12[3 * (size_t)pn + 1]; ns = density12[3 * (size_t)pn + 2];
+                if (!P.nht && !P.sph_half) { const float* c = sph + (size_t)pn * 3 * P.ncoef; touch = c[0] + c[3 * P.ncoef - 1]; }
+            }
+        };
+        request(id_next);
+#endif
 #pragma unroll 1
         for (int i = 0; i < kGrtMaxHits; ++i) {
+#if GRT_HIT_PREFETCH
+            const uint32_t id = id_next;
+            const float4 ca_ = na, cq_ = nq, cs_ = ns;
+            asm volatile("" :: "v"(touch));
+            if (i + 1 < kGrtMaxHits) { id_next = s_hit_id[(i + 1) * 64 + lane]; request(id_next); }
+#else
             const uint32_t id = s_hit_id[i * 64 + lane];
+#endif
             const float hit_t = s_hit_t[i * 64 + lane];
             const bool process = running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
             if (!__any(process)) break;  // ascending list: nothing further for any lane
             if (process) {
                 const uint32_t pid = particle_of(P, id);
+#if GRT_HIT_PREFETCH
+                Particle p;
+                p.pos = mk3(ca_.x, ca_.y, ca_.z); p.density = ca_.w; p.quat = cq_; p.scl = mk3(cs_.x, cs_.y, cs_.z);
+                p.rotT = quat_wxyz_to_rotT(cq_.x, cq_.y, cq_.z, cq_.w);
+#else
                 const Particle p = load_particle(density12, pid);
+#endif
                 const HitGeom g = hit_geometry<DEG>(P, p, r);
                 if (g.accept) {
                     const float weight = g.galpha * T;
@@ -1386,6 +1542,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
             }
         }
         if (!full) running = false;   // the round held every remaining candidate of this ray
+        if (COUNT) { const unsigned long long ph3 = wall_clock64(); tc.phase[0] += ph1 - ph0; tc.phase[1] += ph2 - ph1; tc.phase[2] += ph3 - ph2; }
     }
     if (!in_image) return;
     store_radiance(P, out_rad, pix, rad);
@@ -1402,7 +1559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
             counters[16 + 3 * (size_t)blockIdx.x + 1] = t_end - t_begin;
             counters[16 + 3 * (size_t)blockIdx.x + 2] = ((unsigned long long)tc.nodes << 32) | tc.wave_leaves;
         }
-        atomicAdd(&counters[0], (unsigned long long)tc.nodes);
+        atomicAdd(&counters[0], UNI ? (lane == 0 ? tc.test_ticks : 0ull) : (unsigned long long)tc.nodes);   // (packet lists visit no node: the word carries the work loops' ticks)
         atomicAdd(&counters[1], (unsigned long long)tc.leaf_tests);
         atomicAdd(&counters[2], (unsigned long long)tc.processed);
         atomicAdd(&counters[3], (unsigned long long)tc.rounds);
@@ -1412,6 +1569,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         atomicAdd(&counters[10], (unsigned long long)tc.wave_slab);
         atomicAdd(&counters[11], (unsigned long long)tc.wave_insert);
         atomicAdd(&counters[12], (unsigned long long)tc.batch_loads);
+        if (lane == 0) for (int k = 0; k < 3; ++k) atomicAdd(&counters[13 + k], tc.phase[k]);
     }
 }
 
@@ -2475,11 +2633,12 @@ __device__ __forceinline__ void trace_segment(const GrtTraceParams& P, const Grt
             const bool process = running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
             if (!__any(process)) break;   // ascending lists: nothing further for any lane
             if (process) {
-                const Particle p = load_particle(density12, id);
+                const uint32_t pid = particle_of(P, id);   // (trihexa: three proxies per particle - the tree and the buffers are keyed by proxy)
+                const Particle p = load_particle(density12, pid);
                 const HitGeom g = hit_geometry<DEG>(P, p, r);
                 if (g.accept) {
                     const float weight = g.galpha * T;
-                    const f3 u = sh_radiance(P, sph, id, basis);
+                    const f3 u = sh_radiance(P, sph, pid, basis);
                     rad = rad + mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f)) * weight;
                     T *= (1.f - g.galpha);
                 }
@@ -2888,6 +3047,11 @@ void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float*
     if (todo && N > 2) hipLaunchKernelGGL(grt_refit_finish_kernel, dim3(1), dim3(1024), 0, s, N, passes, aabb, slack, nodes, done, todo);
 }
 
+// (GRT_ONLY_DEGREE_4: development builds of kernel variants - scripts/build_variant.sh - instantiate the default kernel degree only: a
+// quarter of the file's four minutes of compile time)
+#ifdef GRT_ONLY_DEGREE_4
+#define GRT_DISPATCH_DEGREE(DEG, ...) { constexpr int D_ = 4; __VA_ARGS__; }
+#else
 #define GRT_DISPATCH_DEGREE(DEG, ...)                          \
     switch (DEG) {                                             \
     case 0: { constexpr int D_ = 0; __VA_ARGS__; } break;      \
@@ -2898,6 +3062,7 @@ void grt_launch_refit(hipStream_t s, uint32_t N, const float* aabb, const float*
     case 8: { constexpr int D_ = 8; __VA_ARGS__; } break;      \
     default: { constexpr int D_ = 4; __VA_ARGS__; } break;     \
     }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // packet lists: bounding cones of the ray packets, particle binning (the 3DGUT pipeline over cones instead of screen tiles)
@@ -3024,18 +3189,23 @@ __global__ __launch_bounds__(64) void grt_block_cone_kernel(GrtTraceParams P, co
     }
 }
 // the union of the tangent-plane rectangles over each packet column and each packet row
+// (one wave per column / row, the lanes stride over its packets: a thread per column walked its ~100 rectangles as a chain of dependent
+// loads - 48 us on the forward's critical path for 200 intervals)
 __global__ __launch_bounds__(64) void grt_grid_tables_kernel(GrtTraceParams P, GrtCone* __restrict__ cones) {
-    const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H), i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H), i = blockIdx.x;
+    const int lane = threadIdx.x;
     const GrtGrid G = grt_block_grid(cones, gx * gy, gx);
     if (i >= gx + gy) return;
     float lo = 3.0e38f, hi = -3.0e38f;
     if (i < gx) {
-        for (uint32_t r = 0; r < gy; ++r) { const float4 q = G.rects[r * gx + i]; lo = fminf(lo, q.x); hi = fmaxf(hi, q.y); }
-        G.cols[i] = make_float2(lo, hi);
+        for (uint32_t r = (uint32_t)lane; r < gy; r += 64u) { const float4 q = G.rects[r * gx + i]; lo = fminf(lo, q.x); hi = fmaxf(hi, q.y); }
     } else {
-        const uint32_t r = i - gx;
-        for (uint32_t c = 0; c < gx; ++c) { const float4 q = G.rects[r * gx + c]; lo = fminf(lo, q.z); hi = fmaxf(hi, q.w); }
-        G.rows[r] = make_float2(lo, hi);
+        for (uint32_t c = (uint32_t)lane; c < gx; c += 64u) { const float4 q = G.rects[(i - gx) * gx + c]; lo = fminf(lo, q.z); hi = fmaxf(hi, q.w); }
+    }
+    lo = wave_extreme<false>(lo); hi = wave_extreme<true>(hi);
+    if (lane == 0) {
+        if (i < gx) G.cols[i] = make_float2(lo, hi);
+        else G.rows[i - gx] = make_float2(lo, hi);
     }
 }
 // one wave per super tile (8x8 packets): cone around its packets' cones
@@ -3551,7 +3721,7 @@ void grt_launch_list_cones(hipStream_t s, const GrtTraceParams& P, const float* 
     const bool packable = blocks_x(P.W) <= 4096u && blocks_y(P.H) <= 4096u;   // grid_pack keeps 12 bits per coordinate (frames up to 32768 pixels a side)
     hipLaunchKernelGGL(grt_list_init_kernel, dim3(1), dim3(1), 0, s, uniform_origin, dir_len_enc, G.hdr, (no_grid || P.sphere_lists || !packable) ? 0u : 1u);
     hipLaunchKernelGGL(grt_block_cone_kernel, dim3(grt_num_blocks(P.W, P.H)), dim3(64), 0, s, P, ray_o, ray_d, uniform_origin, block_cones);
-    hipLaunchKernelGGL(grt_grid_tables_kernel, dim3(div_up(blocks_x(P.W) + blocks_y(P.H), 64u)), dim3(64), 0, s, P, block_cones);
+    hipLaunchKernelGGL(grt_grid_tables_kernel, dim3(blocks_x(P.W) + blocks_y(P.H)), dim3(64), 0, s, P, block_cones);
     hipLaunchKernelGGL(grt_super_cone_kernel, dim3(grt_num_super(P.W, P.H)), dim3(64), 0, s, P, block_cones, super_cones, dir_len_enc);
 }
 void grt_launch_list_count(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh, const float* ray_o, const uint32_t* uniform_origin,

@@ -515,12 +515,14 @@ int inclusive_scan_u32(hipStream_t s, uint32_t n, const uint32_t* in, const uint
 
 // one-sweep layout of the scratch: [kMaxPasses][kRadix] digit totals | kMaxPasses tickets (+ padding to 64 words) | [passes][tiles][kRadix] status words
 constexpr size_t kOnesweepHead = (size_t)kMaxPasses * kRadix + 64;
+static bool sort_legacy();
 size_t sort_scratch_bytes(uint32_t n) {
     const uint32_t nb = div_up(n, (uint32_t)(kSortThreads * kSortRoundsSmall));   // (the smaller tile: an upper bound for either layout)
     const size_t hist = (size_t)kRadix * nb * sizeof(uint32_t);
     const size_t legacy = hist + kRadix * sizeof(uint32_t) + 256;  // per-block digit counts + digit totals
     const size_t onesweep = (kOnesweepHead + (size_t)kMaxPasses * nb * kRadix) * sizeof(uint32_t);
-    return legacy > onesweep ? legacy : onesweep;
+    // (the one-sweep layout is ~4x the three-kernel one: only handles that opted into it pay for it)
+    return (sort_legacy() || legacy > onesweep) ? legacy : onesweep;
 }
 
 // Measured (round 5, one box, 1 M Gaussians @ 1080p, profiles/r05_sort_variants.txt): the one-sweep pass of the 11.5 M tile entries takes 92 us -

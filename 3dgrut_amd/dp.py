@@ -118,7 +118,8 @@ class FactoredGradientExchange:
         hook = self.local_gradient_hook
         if hook is None:
             return
-        if getattr(self, "_hook_arity", None) is None:
+        if getattr(self, "_hook_arity_of", None) is not hook:   # (keyed on the hook object: assigning another hook later re-derives it)
+            self._hook_arity_of = hook
             import inspect
             try:
                 params = [p for p in inspect.signature(hook).parameters.values()
@@ -408,7 +409,9 @@ class HalfFactorsExchange(FactoredGradientExchange):
         w_geo = dist.all_reduce(g_density, op=op, group=self.group, async_op=True)
         n = g_radiance.shape[0] - 1
         peak = g_radiance[:n].abs().max().clamp_min(1e-38)
-        expo = torch.floor(torch.log2(peak))                    # largest magnitude in [2^e, 2^(e+1))
+        # largest magnitude in [2^e, 2^(e+1)); the exponent is held above -100 so that the scale 2^(14 - e) stays finite in fp32 - a view that
+        # sees nothing (all-zero factors) or whose factors lie below 2^-100 would otherwise scale by inf and send 0 * inf = NaN to every rank
+        expo = torch.floor(torch.log2(peak)).clamp(min=-100.0)
         scale = torch.exp2(14.0 - expo)                         # -> [2^14, 2^15): inside half's range, no overflow
         halves = (g_radiance[:n] * scale).to(torch.float16)
         head = torch.cat([g_radiance[n], scale.reshape(1)])     # sensor position + the scale, fp32

@@ -165,11 +165,23 @@ static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist, uint32_
         c.ok = (r_fma(cr.z, cr.z, r_fma(cr.y, cr.y, cr.x * cr.x)) * bx[6] < max_sqdist * dd);
         return c;
     }
-    /* slab test of the unit box */
-    const real ix = 1 / pd.x, iy = 1 / pd.y, iz = 1 / pd.z;
-    const real ax0 = (-1 - po.x) * ix, ax1 = (1 - po.x) * ix;
-    const real ay0 = (-1 - po.y) * iy, ay1 = (1 - po.y) * iy;
-    const real az0 = (-1 - po.z) * iz, az1 = (1 - po.z) * iz;
+    /* slab test of the unit box: the reciprocals from one division where the product of the components is a comfortable normal number
+     * (candidate_abe, round 6), one division per axis otherwise */
+    real ax0, ax1, ay0, ay1, az0, az1;
+    {
+        const real pxy = pd.x * pd.y, prod = pxy * pd.z, aprod = r_fabs(prod);
+        if (aprod >= R_(1e-24) && aprod <= R_(1e24)) {
+            const real q = 1 / prod;
+            const real ix = q * (pd.y * pd.z), iy = q * (pd.x * pd.z), iz = q * pxy;
+            ax0 = r_fma(-po.x, ix, -ix); ax1 = r_fma(-po.x, ix, ix); ay0 = r_fma(-po.y, iy, -iy); ay1 = r_fma(-po.y, iy, iy);
+            az0 = r_fma(-po.z, iz, -iz); az1 = r_fma(-po.z, iz, iz);
+        } else {
+            const real ix = 1 / pd.x, iy = 1 / pd.y, iz = 1 / pd.z;
+            ax0 = (-1 - po.x) * ix; ax1 = (1 - po.x) * ix;
+            ay0 = (-1 - po.y) * iy; ay1 = (1 - po.y) * iy;
+            az0 = (-1 - po.z) * iz; az1 = (1 - po.z) * iz;
+        }
+    }
     const real tnear = r_fmax(r_fmax(r_fmin(ax0, ax1), r_fmin(ay0, ay1)), r_fmin(az0, az1));
     const real tfar  = r_fmin(r_fmin(r_fmax(ax0, ax1), r_fmax(ay0, ay1)), r_fmax(az0, az1));
     if (!(tnear <= tfar)) return c;
