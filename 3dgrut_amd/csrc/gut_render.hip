@@ -1258,20 +1258,6 @@ __device__ __forceinline__ void k_process_fwd(const GutParams& P, const float* _
     if (s.T < P.min_transmittance) alive = false;
 }
 
-// the same with the radiance of the hit already in registers (requested when the hit was popped, see GRUT_K_DEFER)
-__device__ __forceinline__ void k_process_fwd_loaded(const GutParams& P, f3 c, float hitT, float alpha, KFwdState& s, bool& alive) {
-    const float w = alpha * s.T;
-    s.D = fmaf(hitT, w, s.D);
-    s.T *= (1.f - alpha);
-    if (w > 0.f) {
-        s.Cr = fmaf(fmaxf(c.x, 0.f), w, s.Cr);
-        s.Cg = fmaf(fmaxf(c.y, 0.f), w, s.Cg);
-        s.Cb = fmaf(fmaxf(c.z, 0.f), w, s.Cb);
-        s.cnt += 1.f;
-    }
-    if (s.T < P.min_transmittance) alive = false;
-}
-
 // gradient of sum_ij (b_i e_j) rotT_ij(q) w.r.t. q = (r,x,y,z)  (matmul_bw_quat, mathUtils.cuh:458-521)
 __device__ __forceinline__ float4 quat_outer_contract(f3 b, f3 e, float4 q) {
     const float r = 2.f * q.x, x = 2.f * q.y, y = 2.f * q.z, z = 2.f * q.w;
@@ -1380,9 +1366,6 @@ __device__ __forceinline__ void k_bwd_flush(bool have, uint32_t idx, const float
 #ifndef GRUT_K_FLUSH_LDS
 #define GRUT_K_FLUSH_LDS 1
 #endif
-#ifndef GRUT_K_DEFER
-#define GRUT_K_DEFER 1   // one pending popped hit per pixel (gut_render_k_body)
-#endif
 #ifndef GRUT_K_FLUSH_MINK
 #define GRUT_K_FLUSH_MINK 8    // smallest K that takes the LDS flush and the three-waves allocation that goes with it (K = 4 runs three waves
                                // on the DPP reduce-scatter already; measured at 1 M / 1080p, step: K = 16 11.89 -> 10.90 ms, K = 8 8.89 -> 8.41 ms)
@@ -1447,24 +1430,6 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
     }
     KBuffer<K> kb;
     kb.clear();
-    // Round 6 (GRUT_K_DEFER): a popped hit is not composited / differentiated on the spot.  Each lane keeps ONE pending hit.
-    // Backward: the per-hit gradient code (~250 instructions behind four dependent gathers) used to run for every list entry on which ANY
-    // pixel of the strip popped - with a third of the lanes, each on its own particle; now it runs when some lane pops a SECOND time, for
-    // every lane that holds a pending hit: the same hits in the same per-pixel order (a pixel's hits are worked off first in, first out;
-    // a pixel that turns out to have terminated drops what it popped since - the reference would not have popped it), 2-3x fewer passes
-    // through that code.  Forward: the radiance row of the popped hit is requested at once and composited at the pixel's next pop, so the
-    // gather's round trip lies under the entries in between.
-    bool pend = false;
-    float pend_t = 0.f, pend_a = 0.f;
-    uint32_t pend_i = 0u;
-    f3 pend_c = mk3(0.f, 0.f, 0.f);   // forward: the pending hit's radiance
-    auto work_off_pending = [&]() {   // backward, wave-uniform call
-        float terms[16];
-        const bool have = pend && k_bwd_terms(P, ray, density12, rgb, pend_t, pend_a, pend_i, bs, alive, terms);
-        if (kLdsFlush) k_bwd_flush_lds(have, pend_i, terms, lane, s_kterms, g_density12, g_rgb);
-        else k_bwd_flush(have, pend_i, terms, lane, g_density12, g_rgb);
-        pend = false;
-    };
     const uint2 range = ranges[tile];
     for (uint32_t b = range.x; b < range.y; b += 64) {
         if (!__any(alive)) break;
@@ -1533,40 +1498,18 @@ __device__ __forceinline__ void gut_render_k_body(const GutParams& P, const uint
                 }
             }
             if (BWD) {
-#if GRUT_K_DEFER
-                if (__any(pop && pend)) work_off_pending();   // some lane's one-deep queue is full: every pending hit of the strip goes
-                if (pop && alive) { pend = true; pend_t = pop_t; pend_a = pop_a; pend_i = pop_i; }   // (a pixel that just terminated drops this pop)
-#else
                 if (__any(pop)) {   // wave-level: gradients of lanes that popped the same particle are summed before the atomics
                     float terms[16];
                     const bool have = pop && k_bwd_terms(P, ray, density12, rgb, pop_t, pop_a, pop_i, bs, alive, terms);
                     if (kLdsFlush) k_bwd_flush_lds(have, pop_i, terms, lane, s_kterms, g_density12, g_rgb);
                     else k_bwd_flush(have, pop_i, terms, lane, g_density12, g_rgb);
                 }
-#endif
             } else if (pop) {
-#if GRUT_K_DEFER
-                if (pend) k_process_fwd_loaded(P, pend_c, pend_t, pend_a, fs, alive);
-                pend = alive;
-                if (alive) {
-                    pend_t = pop_t; pend_a = pop_a;
-                    pend_c = mk3(rgb[3 * (size_t)pop_i], rgb[3 * (size_t)pop_i + 1], rgb[3 * (size_t)pop_i + 2]);
-                }
-#else
                 k_process_fwd(P, rgb, pop_t, pop_a, pop_i, fs, alive);
-#endif
             }
         }
         __syncthreads();
     }
-#if GRUT_K_DEFER
-    if (BWD) {
-        if (__any(pend)) work_off_pending();
-    } else if (pend) {
-        k_process_fwd_loaded(P, pend_c, pend_t, pend_a, fs, alive);
-        pend = false;
-    }
-#endif
     // drain what is left, nearest first (:343-351).  The buffer is ascending with the empty slots (hitT = -1) in front: K steps
     // that each take slot 0 and shift the rest down visit the pending hits in order; one copy of the per-hit code instead of K
     // (the gradient terms alone are ~600 instructions).
