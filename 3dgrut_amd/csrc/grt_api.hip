@@ -354,7 +354,8 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
         // particles in key order, then the offsets of their entries
         GRUT_CHECK(h->l_sort_scratch.ensure(sort_scratch_bytes((uint32_t)(N * 1.25f) + 4096)));
         uint32_t *sorted_key = nullptr, *rank_to_particle = nullptr;
-        GRUT_CHECK(sort_pairs_u32(s, N, nullptr, 0, 32, h->l_key_bits.as<uint32_t>(), h->l_pidx.as<uint32_t>(), h->l_key_tmp.as<uint32_t>(),
+        // (bits 16..31: bin_particle truncates the keys; 0xFFFFFFFF - no packet reached - still sorts last)
+        GRUT_CHECK(sort_pairs_u32(s, N, nullptr, 16, 32, h->l_key_bits.as<uint32_t>(), h->l_pidx.as<uint32_t>(), h->l_key_tmp.as<uint32_t>(),
                                   h->l_pidx_tmp.as<uint32_t>(), h->l_sort_scratch.ptr, h->l_sort_scratch.bytes, &sorted_key, &rank_to_particle, true));
         GRUT_CHECK(inclusive_scan_u32(s, N, h->l_counts.as<uint32_t>(), rank_to_particle, h->l_offsets.as<uint32_t>(), h->l_scan_scratch.ptr,
                                       h->l_scan_scratch.bytes));

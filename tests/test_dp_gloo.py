@@ -88,6 +88,12 @@ def _variant_worker(rank, world, port, out):
     # round 5: view factors as scaled halves; direct pairwise transfers instead of ring collectives
     hf_geo, hf_fac, hf_bytes = dp.HalfFactorsExchange(average=True).exchange(geo.clone(), fac.clone() * 1e-7)   # (gradients of a 2 M-pixel frame: ~1e-7)
     res["hf_geo"], res["hf_fac"], res["hf_bytes"] = hf_geo.numpy(), hf_fac.numpy(), hf_bytes
+    # (round 6, advisor) a view that sees nothing - all-zero factors on rank 1 - must not turn into NaN on every rank (scale 2^(14 - e) overflowed)
+    zf = fac.clone() * 1e-7
+    if rank == 1:
+        zf[:n] = 0
+    z_geo, z_fac, _ = dp.HalfFactorsExchange(average=True).exchange(geo.clone(), zf)
+    res["hfz_fac"], res["hfz_in"] = z_fac.numpy(), zf.numpy().copy()
     al_geo, al_fac, al_bytes = dp.AllLinksExchange(average=True).exchange(geo.clone(), fac.clone())
     res["al_geo"], res["al_fac"], res["al_bytes"] = al_geo.numpy(), al_fac.numpy(), al_bytes
     # fewer particles than ranks x (ranks - 1): the last rank owns the empty range [n, n) (ShardedGradientExchange.shard_rows clamps)
@@ -147,6 +153,11 @@ def test_exchange_variants_world2():
             assert np.abs(r[k]["hf_fac"][v, :n]).max() > 0.5 * np.abs(want).max()
         np.testing.assert_allclose(r[k]["hf_fac"][:, n], facs[:, n] * 1e-7, rtol=1e-6)
         assert r[k]["hf_bytes"] == n * 48 + n * 6 + 16
+        # the all-zero view of rank 1: finite everywhere, its rows exactly zero, rank 0's view as precise as before
+        assert np.isfinite(r[k]["hfz_fac"]).all()
+        assert not r[k]["hfz_fac"][1, :n].any()
+        want0 = r[0]["hfz_in"][:n]
+        assert np.abs(r[k]["hfz_fac"][0, :n] - want0).max() <= 4.9e-4 * np.abs(want0).max()
         # direct transfers: same sums (up to the order of two additions: exact here), same factors
         np.testing.assert_allclose(r[k]["al_geo"], mean_geo, rtol=1e-6, atol=1e-7)
         np.testing.assert_array_equal(r[k]["al_fac"], facs)

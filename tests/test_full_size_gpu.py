@@ -81,7 +81,11 @@ def test_gut_nht_frame_matches_oracle_at_baseline_size():
     # the flat proxies (round 5): plane-crossing candidates, the surfel branches of the per-hit math; tree walk
     ("c3_grt_trisurfel_1m_800", 1_000_000, 800, 800, 0.01, 149, "trisurfel"),
     # three offers per particle (every rhombus a proxy of its own), tree walk
-    ("c3_grt_trihexa_1m_800", 1_000_000, 800, 800, 0.01, 149, "trihexa")])
+    ("c3_grt_trihexa_1m_800", 1_000_000, 800, 800, 0.01, 149, "trihexa"),
+    # round 6: EVERY ray with gradients (stride 1 = HIP backward against the checker's backward of the same frame) for the three proxies that
+    # had a gradient comparison at test size only
+    ("c3_grt_custom_100k_200", 100_000, 200, 200, 0.01, 1, "custom"), ("c3_grt_trisurfel_100k_200", 100_000, 200, 200, 0.01, 1, "trisurfel"),
+    ("c3_grt_trihexa_100k_200", 100_000, 200, 200, 0.01, 1, "trihexa")])
 def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, ray_stride, prim):
     """3DGRT (LBVH + software traversal) against the oracle: the per-ray order of processed particles bit-exact, images within
     1e-4, gradients within 1e-3 relative (full frame at 100 k particles; a 4 k-ray subsample of the 1 M / 800x800 frame)."""
@@ -93,6 +97,22 @@ def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, 
                                primitive_type=prim)
     pu.record_full_parity(name, stats)
     pu.assert_grt_full_parity(stats)
+
+
+@pytest.mark.parametrize("name,prim,half", [("c3_grt_nht_1m_800", "instances", False), ("c3_grt_icosahedron_nht_1m_800", "icosahedron", False),
+                                            ("c3_grt_nht_fp16_1m_800", "instances", True)])
+def test_grt_feature_frames_match_oracle_on_a_ray_sample_at_baseline_size(name, prim, half):
+    """Round 6: the configurations that were benched at 1 M Gaussians / 800x800 but compared at test size only - neural harmonic features
+    on the 3DGRT plugin (instances and the paper's icosahedron proxies) and fp16 feature I/O - against the checker on every 149th ray of the
+    BASELINE config 3 frame (4 296 rays, every particle offered to every one of them; the checker is fed the GPU's proxy records like the SH
+    frames'): hit counts equal except on borderline accept decisions, ray features / opacity within 1e-4 (half output: + half an ulp of the
+    half image) outside them."""
+    stats = pu.grt_feature_parity(1_000_000, 800, 800, 0.01, ray_stride=149, primitive_type=prim, half=half, log=print)
+    pu.record_full_parity(name, stats)
+    assert stats["F_rays_compared"] >= 4000 and stats["F_feature_abs_max"] > 0.3
+    assert stats["F_rays_hit_count_differs"] <= max(8, 5e-3 * stats["F_rays_compared"]), stats
+    assert stats["F_rays_beyond_tolerance_without_a_flip"] == 0, stats
+    assert stats["F_max_err_without_a_flip"] <= 1e-4 + stats["F_half_ulp_allowance"], stats
 
 
 def _trimmed(got, ref, n_drop):

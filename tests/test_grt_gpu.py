@@ -576,6 +576,26 @@ def test_unsupported_primitives_are_refused():
             grt.Tracer({"render": {"primitive_type": prim}})
 
 
+def test_c_abi_refuses_feature_kernels_on_open_proxies():
+    """Round 6 (advisor): the plugin refuses neural harmonic features on custom / trisurfel / trihexa (grt_config_from_conf); the C-ABI must too -
+    its feature kernels index the feature rows by the log's proxy id (3 N of them for trihexa: out of bounds)."""
+    import ctypes as C
+    grt = importlib.import_module("3dgrut_amd.grt_tracer")
+    abi = importlib.import_module("3dgrut_amd._abi")
+    lib = abi.load_library()
+    for prim in ("custom", "trisurfel", "trihexa"):
+        cfg = grt.grt_config_from_conf({"render": {"pipeline_type": "referenceSlang"}, "model": NHT_CONF})
+        cfg.primitive_type = abi.GRT_PRIMITIVES[prim]
+        handle = C.c_void_p()
+        status = lib.grt_create(C.byref(cfg), C.byref(handle))
+        assert status != 0 and not handle.value, (prim, status)
+        assert b"neural harmonic features" in lib.grut_last_error()
+    cfg = grt.grt_config_from_conf({"render": {"pipeline_type": "referenceSlang", "primitive_type": "icosahedron"}, "model": NHT_CONF})
+    handle = C.c_void_p()
+    assert lib.grt_create(C.byref(cfg), C.byref(handle)) == 0
+    lib.grt_destroy(handle)
+
+
 # ---- packet lists (frames with one ray origin) against the tree walk -------------------------------------------------------
 def _hits_with(scene, monkeypatch, no_lists, rays_ori=None, rays_dir=None, **render_kw):
     import torch

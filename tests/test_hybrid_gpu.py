@@ -87,6 +87,28 @@ def test_hybrid_trace_matches_oracle(kind, n, w, h, opts, bounces):
         assert b.max() >= 1 and (b == 0).any()                       # some rays bounce off the mirror, some do not
 
 
+def test_hybrid_trace_with_trihexa_proxies_matches_oracle():
+    """Round 6 (advisor): render.primitive_type trihexa builds the tree over 3 N proxies; the hybrid tracer's segments must shade particle
+    proxy / 3 (trace_segment indexed the parameter rows by the raw proxy: out of bounds beyond N, the wrong particle everywhere else)."""
+    import torch
+    pt = importlib.import_module("3dgrut_amd.playground_tracer")
+    n, w, h = 5000, 72, 48
+    sc = ps.make_playground_scene("classic", width=w, height=h, n=n, seed=5)
+    tr = pt.Tracer({"render": {"primitive_type": "trihexa"}})
+    res, tr = _render(sc, 0, 5, 2, tracer=tr)
+    nat = tr.tracer_wrapper
+    inst = nat.instances(n, "cuda").cpu().numpy()
+    scene_aabb = np.array(list(nat.stats().scene_aabb), np.float32)
+    ora = oracle.grt_hybrid(oracle.default_grt_config(primitive_type=7), sc["density12"], sc["sph"], 3, tr._min_transmittance, np.eye(4, dtype=np.float32),
+                            sc["ray_o"], sc["ray_d"], sc["mesh"], opts=0, max_pbr_bounces=5, materials=sc["materials"], envmap=sc["envmap"],
+                            envmap_offset=sc["envmap_offset"], frame_number=2, inst=inst, scene=scene_aabb, ray_max_t=sc["ray_max_t"])
+    e, el = _errors(res, ora["rgba"][..., :3], ora["rgba"][..., 3], ora["last_ray"][..., :3], ora["last_ray"][..., 3:])
+    flips = (res["mirror_bounces"][..., 0] != ora["bounces"].astype(np.int32)) | (e > 1e-4) | (el > 1e-4)
+    print(f"trihexa hybrid: {int(flips.sum())} of {flips.size} rays differ; median err {np.median(e):.1e}")
+    assert flips.mean() <= 6e-3 and np.isfinite(res["pred_features"]).all(), (int(flips.sum()), float(e.max()))
+    assert res["pred_opacity"].max() > 0.3   # the Gaussians are seen
+
+
 def test_primary_segment_through_packet_lists_equals_the_tree_walk(monkeypatch):
     """The first segment of every path starts at the camera: it scans the frame's packet lists (3DGRT forward) up to the
     surface the ray hits; bounced rays walk the tree.  Same candidates, same order: every output is identical to the all-walk run."""
