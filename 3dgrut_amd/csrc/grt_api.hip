@@ -334,9 +334,9 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
     // first tests refine to exact ones like the instance path's; GRUT_GRT_NO_MESH_LISTS=1 keeps them on the tree walk)
     // (custom primitives: the candidates are the rays of the particle's WORLD box, which the packet binning - bounds of the oriented proxy - does
     // not cover: tree walk)
-    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && h->cfg.primitive_type != GRUT_PRIM_CUSTOM && h->cfg.primitive_type != GRUT_PRIM_TRIHEXA && !(h->cfg.primitive_type == GRUT_PRIM_TRISURFEL && getenv("GRUT_GRT_TRISURFEL_WALK")) &&
+    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && h->cfg.primitive_type != GRUT_PRIM_CUSTOM && !(h->cfg.primitive_type == GRUT_PRIM_TRIHEXA && getenv("GRUT_GRT_TRIHEXA_WALK")) && !(h->cfg.primitive_type == GRUT_PRIM_TRISURFEL && getenv("GRUT_GRT_TRISURFEL_WALK")) &&
         (h->cfg.primitive_type == GRUT_PRIM_INSTANCES || !getenv("GRUT_GRT_NO_MESH_LISTS"))) {
-        const uint32_t N = h->N, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
+        const uint32_t N = h->NP, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
         if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));
         GRUT_CHECK(h->l_flags.ensure(64));
         GRUT_CHECK(h->l_block_cones.ensure(grt_cone_table_bytes(P.W, P.H), 1.25f));   // cones, pyramids, tangent-plane tables

@@ -881,6 +881,16 @@ __device__ __forceinline__ void wave_min_max(float lo, float hi, float& lo_all, 
     lo_all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo), 63));
     hi_all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(hi), 63));
 }
+// half extents of a proxy's vertices along the axes of its frame (the unit cube: 1): the polyhedron's table entry; GRUT_PRIM_TRIHEXA: proxy
+// 3 p + j is the rhombus in plane j - flat along axis j, sqrt 2 along the other two
+__device__ __forceinline__ void proxy_extents(int prim, uint32_t id, float (&ext)[3]) {
+    if (prim == GRUT_PRIM_TRIHEXA) {
+        const uint32_t plane = id % 3u;
+        ext[0] = plane == 0u ? 0.f : 1.4142135381698608f; ext[1] = plane == 1u ? 0.f : 1.4142135381698608f; ext[2] = plane == 2u ? 0.f : 1.4142135381698608f;
+    } else {
+        ext[0] = kGrtPolyhedra[prim].ext[0]; ext[1] = kGrtPolyhedra[prim].ext[1]; ext[2] = kGrtPolyhedra[prim].ext[2];
+    }
+}
 struct ListEntry {
     float4 a, b, e;    // proxy record {W rows, W (o - mu)}
     uint32_t id;       // particle
@@ -912,10 +922,11 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
             } else if (prim != GRUT_PRIM_INSTANCES) {
                 // mesh proxies: until the packet's first test refines it, the entry distance lies within the bounding sphere of the
                 // polyhedron's box around the centre's distance (the key is that sphere's near end over the frame's direction lengths)
-                const GrtPolyhedron& ph = kGrtPolyhedra[prim];
-                const float k0 = ph.ext[0] * ph.ext[0] / (x.a.x * x.a.x + x.a.y * x.a.y + x.a.z * x.a.z),
-                            k1 = ph.ext[1] * ph.ext[1] / (x.a.w * x.a.w + x.b.x * x.b.x + x.b.y * x.b.y),
-                            k2 = ph.ext[2] * ph.ext[2] / (x.b.z * x.b.z + x.b.w * x.b.w + x.e.x * x.e.x);
+                float ext[3];
+                proxy_extents(prim, x.id, ext);
+                const float k0 = ext[0] * ext[0] / (x.a.x * x.a.x + x.a.y * x.a.y + x.a.z * x.a.z),
+                            k1 = ext[1] * ext[1] / (x.a.w * x.a.w + x.b.x * x.b.x + x.b.y * x.b.y),
+                            k2 = ext[2] * ext[2] / (x.b.z * x.b.z + x.b.w * x.b.w + x.e.x * x.e.x);
                 x.lo = vk.w;
                 x.hi = ((sqrtf(dot(v, v)) * (1.f + 2e-6f) + sqrtf(k0 + k1 + k2) * 1.00002f) / dmin) * (1.f + 2e-6f) + 1e-30f;
                 x.fresh = true;
@@ -1315,6 +1326,14 @@ template <int DEG, bool COUNT, bool UNI, bool LOG, bool GEN>
 #ifndef GRT_HIT_PREFETCH
 #define GRT_HIT_PREFETCH 0
 #endif
+// GRT_FWD_PRIO = K > 0: a packet raises its wave's issue priority by one step every K trace rounds (s_setprio 1..3).  A packet's lifetime
+// is its number of wave-level tests (correlation 0.99) and nothing known before the launch predicts it (list length: 0.44), but the
+// lifetimes are heavy-tailed - a packet that has already run many rounds is one of the long ones - and the launch ends with its longest
+// packets (last third of the span at falling occupancy): letting those win the issue arbitration against the three lighter packets of
+// their SIMD while the chip is still full shortens the tail without touching the order of the launch (every reordering lost to locality).
+#ifndef GRT_FWD_PRIO
+#define GRT_FWD_PRIO 0
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVES, GRT_FWD_WAVES))) void grt_trace_fwd_kernel(GrtTraceParams P, GrtBvh bvh, const float4* __restrict__ density12,
                                                            const float* __restrict__ sph, const float* __restrict__ ray_o,
                                                            const float* __restrict__ ray_d, float* __restrict__ out_rad,
@@ -1372,6 +1391,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
     bool ghost_overflow = false;   // LOG: a round of this ray saw more ghosts than a chunk holds
     float tmin_prev1 = -3.0e38f, tmin_prev2 = -3.0e38f;   // LOG: tmin of the previous round and of the one before (GhostLog::min_tfar)
     uint32_t last_id = 0xFFFFFFFFu;                       // LOG: the last processed hit is (tLast, last_id)
+    uint32_t rounds_done = 0u;                            // GRT_FWD_PRIO
 
     // one chunk of the hit log per (wave, trace round)
     auto open_chunk = [&]() -> uint32_t* {
@@ -1427,7 +1447,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
                 g_t[g] = 3.0e38f;
                 g_pos[g] = 0u;
                 if (!__any(have)) continue;   // (slot g is empty on every ray of the packet - the usual case for the later slots: no distance to evaluate)
-                if (have) g_t[g] = candidate(bvh.inst + 12 * (size_t)g_id[g], r, 3.0e38f).t;   // (the very value the round computed: same arithmetic, same inputs)
+                if (have) g_t[g] = candidate(bvh.inst + 12 * (size_t)g_id[g], r, 3.0e38f, 3.0e38f, g_id[g]).t;   // (the proxy index: a trihexa proxy's plane)   // (the very value the round computed: same arithmetic, same inputs)
                 // beyond the 16th candidate of a full round: not this round's business (the next round meets it again)
                 if (have && full && !hit_less(g_t[g], g_id[g], t16, id16)) { g_id[g] = 0xFFFFFFFFu; g_t[g] = 3.0e38f; }
                 ng += g_id[g] != 0xFFFFFFFFu ? 1u : 0u;
@@ -1549,6 +1569,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         }
         if (!full) running = false;   // the round held every remaining candidate of this ray
         if (COUNT) { const unsigned long long ph3 = wall_clock64(); tc.phase[0] += ph1 - ph0; tc.phase[1] += ph2 - ph1; tc.phase[2] += ph3 - ph2; }
+#if GRT_FWD_PRIO > 0
+        ++rounds_done;
+        if (rounds_done == 1u * GRT_FWD_PRIO) __builtin_amdgcn_s_setprio(1);
+        else if (rounds_done == 2u * GRT_FWD_PRIO) __builtin_amdgcn_s_setprio(2);
+        else if (rounds_done == 3u * GRT_FWD_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
     }
     if (!in_image) return;
     store_radiance(P, out_rad, pix, rad);
@@ -3300,7 +3326,7 @@ __device__ __forceinline__ bool packet_hit(const GrtCone& k, const GrtPyramid& p
 // bounds: the hit "distance" t of a candidate is the ray parameter of the point closest to the centre in the proxy's metric; that point
 // lies within sqrt(3) max(kscl) of the centre whenever the ray touches the proxy box (the box holds a point of the ray at metric distance
 // <= sqrt 3 and the closest one is no farther), so |o + t d - mu| <= Rt and (|v| - Rt) / |d| <= t <= (|v| + Rt) / |d|
-__device__ __forceinline__ BinParticle bin_particle(const float4& a, const float4& b, const float4& e, f3 o, float dmin, float dmax, int prim) {
+__device__ __forceinline__ BinParticle bin_particle(const float4& a, const float4& b, const float4& e, f3 o, float dmin, float dmax, int prim, uint32_t id) {
     BinParticle q;
     float k0 = 1.f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), k1 = 1.f / sqrtf(a.w * a.w + b.x * b.x + b.y * b.y),
           k2 = 1.f / sqrtf(b.z * b.z + b.w * b.w + e.x * e.x);   // rows of W = R^T / kscl
@@ -3311,9 +3337,10 @@ __device__ __forceinline__ BinParticle bin_particle(const float4& a, const float
         // triangle-mesh proxies: the box of the polyhedron's vertices (half extents ext_i along the proxy's axes) stands in for the unit
         // cube in every separation test, and the reported distance is the ENTRY into the polyhedron - a point of that box: within its
         // bounding sphere of the centre's distance along any ray
-        const GrtPolyhedron& ph = kGrtPolyhedra[prim];
-        k0 *= ph.ext[0]; k1 *= ph.ext[1]; k2 *= ph.ext[2];
-        q.h0 = q.h0 * ph.ext[0]; q.h1 = q.h1 * ph.ext[1]; q.h2 = q.h2 * ph.ext[2];
+        float ext[3];
+        proxy_extents(prim, id, ext);
+        k0 *= ext[0]; k1 *= ext[1]; k2 *= ext[2];
+        q.h0 = q.h0 * ext[0]; q.h1 = q.h1 * ext[1]; q.h2 = q.h2 * ext[2];
         Rt = sqrtf(k0 * k0 + k1 * k1 + k2 * k2) * 1.00002f;
     }
     q.Rs = sqrtf(k0 * k0 + k1 * k1 + k2 * k2) * 1.00001f;
@@ -3597,7 +3624,7 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
         const float4* rec = reinterpret_cast<const float4*>(bvh.inst) + 3 * (size_t)i;
         a = rec[0]; b = rec[1]; e = rec[2];
     }
-    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim);
+    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim, i);
     const BinOut cache = {nullptr, nullptr, pairs, pair_n};
     const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H);
     const GrtGrid G = grt_block_grid(block_cones, gx * gy, gx);
@@ -3676,7 +3703,7 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
         }
         const bool again = have && np == kGridWaveTested;
         if (__any(again)) {
-            const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim);
+            const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim, p);
             GridParticle g = grid_particle(G, gx, gy, again, q, P.bin_lane_area);
             if (!again) g.kind = 0;
             uint32_t n = 0u;
@@ -3688,7 +3715,7 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
     const bool cached = have && np <= (uint32_t)kBinCachedPairs;
     emit_cached_pairs(P, lane, cached, p, np, off, end, out);
     // (what the cache did not hold: tested again; pads whatever the masks left unwritten, which is not expected)
-    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim);
+    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim, p);
     const bool again = have && !cached;
     if (__any(again)) bin_pairs<true>(P, block_cones, super_cones, lane, again, q, p, off, again ? end : off, out);
     if (cached) {

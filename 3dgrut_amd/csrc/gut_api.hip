@@ -36,7 +36,7 @@ struct GutHandle {
     DeviceBuffer tiles_count, proj_pos, conic_opacity, extent, depth, rgb, depth_key, particle_idx;
     DeviceBuffer depth_key_tmp, particle_idx_tmp, offsets, sort_scratch, scan_scratch, counters;
     DeviceBuffer rec64;   // [N][4] float4: the per-particle 64-byte records of the direct tile lists (GutParams::rec64)
-    DeviceBuffer part_offset, pos_particle, grad_partial, grad_flag, g_rgb, poses_dev;
+    DeviceBuffer part_offset, pos_particle, grad_partial, grad_flag, g_rgb, poses_dev, walk8;
     // per-intersection scratch
     DeviceBuffer tile_keys, tile_vals, tile_keys_tmp, tile_vals_tmp, tile_sort_scratch, ranges;
     DeviceBuffer ck_tc, ck_d, ck_reached, ck_boundary_tile, ck_nht;
@@ -176,6 +176,7 @@ static int ensure_particle_scratch(GutHandle* h, uint32_t N) {
     GRUT_CHECK(h->offsets.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->part_offset.ensure(n * 4, 1.25f));
     GRUT_CHECK(h->rec64.ensure(n * 64, 1.25f));
+    GRUT_CHECK(h->walk8.ensure(n * 8, 1.25f));
     GRUT_CHECK(h->sort_scratch.ensure(sort_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     GRUT_CHECK(h->scan_scratch.ensure(scan_scratch_bytes((uint32_t)(n * 1.25f) + 4096)));
     if (!h->counters.ptr) {   // [1] counts the visible particles of a frame: zero once here, re-armed on the device after every read
@@ -227,6 +228,8 @@ static GutProjected projected_view(GutHandle* h) {
     p.particle_idx = h->particle_idx.as<uint32_t>();
     p.part_offset = h->part_offset.as<uint32_t>();
     p.rec64 = h->rec64.as<float4>();
+    static const bool no_walk_cache = getenv("GRUT_GUT_NO_WALK_CACHE") != nullptr;   // (development switch: the expansion evaluates the tile test again)
+    p.walk8 = (no_walk_cache || h->params.gx >= 4096 || h->params.gy >= 4096) ? nullptr : h->walk8.as<uint2>();
     return p;
 }
 
@@ -267,7 +270,7 @@ int gut_create(const GutConfig* config, GutHandle** handle) {
 static void release_scratch(GutHandle* h) {
     DeviceBuffer* bufs[] = {&h->tiles_count, &h->proj_pos, &h->conic_opacity, &h->extent, &h->depth, &h->rgb, &h->depth_key,
                             &h->particle_idx, &h->depth_key_tmp, &h->particle_idx_tmp, &h->offsets, &h->sort_scratch,
-                            &h->scan_scratch, &h->counters, &h->rec64, &h->part_offset, &h->pos_particle, &h->grad_partial, &h->grad_flag,
+                            &h->scan_scratch, &h->counters, &h->rec64, &h->walk8, &h->part_offset, &h->pos_particle, &h->grad_partial, &h->grad_flag,
                             &h->g_rgb, &h->poses_dev, &h->work_counters, &h->tile_keys, &h->tile_vals, &h->tile_keys_tmp,
                             &h->tile_vals_tmp, &h->tile_sort_scratch, &h->ranges, &h->ck_tc, &h->ck_d, &h->ck_nht, &h->ck_reached,
                             &h->ck_boundary_tile};

@@ -51,6 +51,7 @@ struct GutProjected {
     uint32_t* particle_idx;  // [N] identity, value array of the depth sort
     uint32_t* part_offset;   // [N] start of the particle's tile entries in expansion order (valid where tiles_count > 0)
     float4* rec64;           // [N][4] see GutParams::rec64
+    uint2* walk8;            // [N] {tile box | kind << 30, keep mask} of the counting pass's one-step walks (gut_project_kernel); null = the expansion tests again
 };
 
 // Gradient partials of the compositing sweep.  Tile entries are identified by their position q in EXPANSION order

@@ -449,6 +449,9 @@ __device__ __forceinline__ void write_split_outputs(const GutParams& P, size_t p
 // Rounds are aligned to multiples of 64 in the global sorted list, so every segment boundary (multiple of
 // kGutSegment) is a round start, where the running state is checkpointed for the gradient sweep.
 // ---------------------------------------------------------------------------------------------
+#ifndef GRUT_FWD_PRIO
+#define GRUT_FWD_PRIO 0   // K > 0: s_setprio 1 / 2 / 3 after K / 2 K / 3 K composited rounds of 64 entries (see render_fwd_sweep)
+#endif
 #ifndef GRUT_FWD_HALF_TILE_CULL
 #define GRUT_FWD_HALF_TILE_CULL 1   // staged entries whose sphere misses the wave's ray pyramid are dropped (see WavePyramid)
 #endif
@@ -467,6 +470,7 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
     const unsigned long long t_sweep = COUNT ? wall_clock64() : 0ull;
     unsigned long long t_first = 0ull, t_stage = 0ull;
     uint32_t b = range.x;
+    uint32_t n_prio = 0u;   // GRUT_FWD_PRIO
     RawEntry next = load_entry<false>(b + lane, min(range.y, (b & ~63u) + 64u), lists, density12, rgb);
     constexpr bool CULL = GRUT_FWD_HALF_TILE_CULL != 0;
     WavePyramid pyr;
@@ -591,6 +595,15 @@ __device__ __forceinline__ void render_fwd_sweep(const GutParams& P, const RayPa
         }
         __syncthreads();
         b = bend;
+#if GRUT_FWD_PRIO > 0
+        // a wave that has already composited many rounds is one of the launch's long ones (the lifetimes follow the accepted entries, which
+        // nothing known before the launch predicts): it takes issue priority over the younger waves of its SIMD, so the long waves end
+        // earlier and the launch's ramp-down shortens
+        ++n_prio;
+        if (n_prio == 1u * GRUT_FWD_PRIO) __builtin_amdgcn_s_setprio(1);
+        else if (n_prio == 2u * GRUT_FWD_PRIO) __builtin_amdgcn_s_setprio(2);
+        else if (n_prio == 3u * GRUT_FWD_PRIO) __builtin_amdgcn_s_setprio(3);
+#endif
     }
     st = FwdState{T, D, Cr, Cg, Cb, cnt, 0ull};
     if (COUNT && P.work && lane == 0) {   // per-wave words, summed on the host (atomics on two shared counters would serialise the waves' exits)

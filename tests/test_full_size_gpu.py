@@ -80,7 +80,7 @@ def test_gut_nht_frame_matches_oracle_at_baseline_size():
     ("c3_grt_custom_1m_800", 1_000_000, 800, 800, 0.01, 149, "custom"),
     # the flat proxies (round 5): plane-crossing candidates, the surfel branches of the per-hit math; tree walk
     ("c3_grt_trisurfel_1m_800", 1_000_000, 800, 800, 0.01, 149, "trisurfel"),
-    # three offers per particle (every rhombus a proxy of its own), tree walk
+    # three offers per particle (every rhombus a proxy of its own); packet lists over the 3 N rhombi since round 6
     ("c3_grt_trihexa_1m_800", 1_000_000, 800, 800, 0.01, 149, "trihexa"),
     # round 6: EVERY ray with gradients (stride 1 = HIP backward against the checker's backward of the same frame) for the three proxies that
     # had a gradient comparison at test size only
@@ -92,7 +92,7 @@ def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, 
     # 1 M particles: every 149th ray through all pairs (4296 rays), then every 9th ray (71 k) with the oracle's scan restricted to the
     # packet lists the GPU built - checked to change nothing on the 4296
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
-    has_lists = prim not in ("custom", "trihexa") or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
+    has_lists = prim != "custom" or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
     stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print, wide_stride=9 if ray_stride > 1 and has_lists else 0,
                                primitive_type=prim)
     pu.record_full_parity(name, stats)
