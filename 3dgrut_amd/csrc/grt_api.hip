@@ -332,9 +332,10 @@ static int build_lists(GrtHandle* h, hipStream_t s, const GrtTraceParams& P, con
     h->log_lists = lists;   // the list scratch is about to be overwritten: a pending backward of an older forward walks the tree
     // (triangle-mesh proxies bin by the box of the polyhedron's vertices and start from bounding-sphere distance intervals, which the packets'
     // first tests refine to exact ones like the instance path's; GRUT_GRT_NO_MESH_LISTS=1 keeps them on the tree walk)
-    // (custom primitives: the candidates are the rays of the particle's WORLD box, which the packet binning - bounds of the oriented proxy - does
-    // not cover: tree walk)
-    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && h->cfg.primitive_type != GRUT_PRIM_CUSTOM && !(h->cfg.primitive_type == GRUT_PRIM_TRIHEXA && getenv("GRUT_GRT_TRIHEXA_WALK")) && !(h->cfg.primitive_type == GRUT_PRIM_TRISURFEL && getenv("GRUT_GRT_TRISURFEL_WALK")) &&
+    // (custom primitives, round 6: binned by the particle's WORLD box - whose rays the intersection program runs for - with the 3-sigma sphere of
+    // the scale frame bounding the hit distance; trihexa: every rhombus by its own flat box.  GRUT_GRT_CUSTOM_WALK / _TRIHEXA_WALK / _TRISURFEL_WALK
+    // = 1 keep a primitive on the tree walk)
+    if (!getenv("GRUT_GRT_NO_LISTS") && h->N > 0 && !(h->cfg.primitive_type == GRUT_PRIM_CUSTOM && getenv("GRUT_GRT_CUSTOM_WALK")) && !(h->cfg.primitive_type == GRUT_PRIM_TRIHEXA && getenv("GRUT_GRT_TRIHEXA_WALK")) && !(h->cfg.primitive_type == GRUT_PRIM_TRISURFEL && getenv("GRUT_GRT_TRISURFEL_WALK")) &&
         (h->cfg.primitive_type == GRUT_PRIM_INSTANCES || !getenv("GRUT_GRT_NO_MESH_LISTS"))) {
         const uint32_t N = h->NP, nb = grt_num_blocks(P.W, P.H), ns = grt_num_super(P.W, P.H);
         if (!h->l_host) GRUT_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->l_host), 64));

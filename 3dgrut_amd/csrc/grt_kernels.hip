@@ -543,9 +543,9 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     c.t = numerator / dd;
     const bool wanted = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
     if (!wanted && !always_box) return c;
-    // (not in the packet lists' test, REL: custom primitives walk the tree - the list kernels keep their register allocation; inlined
-    // there, the branch cost the forward 3 %)
-    if (!REL && r.prim == GRUT_PRIM_CUSTOM) {
+    // (round 6: in the packet lists' test too - the default configuration's forward is an instantiation of its own in which r.prim is a
+    // constant and this branch folds away; until then custom primitives walked the tree because the branch cost the instances' forward 3 %)
+    if (r.prim == GRUT_PRIM_CUSTOM) {
         // custom primitives (render.primitive_type custom; optixTracer.cpp:638-655, intersectCustomParticle gaussianParticles.cuh:407-441): the
         // intersection program runs for rays that overlap the particle's WORLD box, reports the point of maximum response - the same point
         // as the instances' (the proxy frame differs from the program's scale frame by the scalar kernelScale, which cancels in the
@@ -899,7 +899,8 @@ struct ListEntry {
 };
 // one entry per lane: the particle's records are gathered and its packet-specific bounds computed on the spot (one lane per entry:
 // a few dozen operations per 64 entries of wave time)
-__device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const GrtCone& cone, float dmin, float dmax, uint32_t e, uint32_t end, int prim = GRUT_PRIM_INSTANCES) {
+__device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const GrtCone& cone, float dmin, float dmax, uint32_t e, uint32_t end, int prim = GRUT_PRIM_INSTANCES,
+                                                     const float* __restrict__ box8 = nullptr) {
     ListEntry x;
     x.a = x.b = x.e = make_float4(0.f, 0.f, 0.f, 0.f);
     x.id = 0xFFFFFFFFu; x.lo = 3.0e38f; x.hi = -3.0e38f; x.key = 3.0e38f;   // dead for every ray, beyond every bound
@@ -919,6 +920,15 @@ __device__ __forceinline__ ListEntry load_list_entry(const GrtLists& L, const Gr
             if (word & kGrtEntryRefined) {   // the packet's own rays have been through this entry (see list_round)
                 const unsigned long long raw = __hip_atomic_load(reinterpret_cast<unsigned long long*>(L.bounds + e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 x.lo = __uint_as_float((uint32_t)raw); x.hi = __uint_as_float((uint32_t)(raw >> 32));
+            } else if (prim == GRUT_PRIM_CUSTOM) {
+                // custom primitives: an accepted hit lies within 3 sigma of the SCALE frame, |x* - mu| < 3 kmax / ks (bin_particle): the hit
+                // distance within that sphere of the centre's distance, until the packet's first test refines it
+                const float kmax = fast_rcp(fast_sqrt(fminf(x.a.x * x.a.x + x.a.y * x.a.y + x.a.z * x.a.z, fminf(x.a.w * x.a.w + x.b.x * x.b.x + x.b.y * x.b.y,
+                                                                                                                 x.b.z * x.b.z + x.b.w * x.b.w + x.e.x * x.e.x))));
+                const float Rt = 3.f * kmax * fast_rcp(fast_sqrt(box8[8 * (size_t)x.id + 6])) * 1.0002f;
+                x.lo = vk.w;
+                x.hi = ((sqrtf(dot(v, v)) * (1.f + 2e-6f) + Rt) / dmin) * (1.f + 2e-6f) + 1e-30f;
+                x.fresh = true;
             } else if (prim != GRUT_PRIM_INSTANCES) {
                 // mesh proxies: until the packet's first test refines it, the entry distance lies within the bounding sphere of the
                 // polyhedron's box around the centre's distance (the key is that sphere's near end over the frame's direction lengths)
@@ -981,7 +991,7 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
         if (pass == 1 && !(deferred && wmax_bound > mark)) break;
         bool seen_live = pass == 1;   // (the scan start only moves in the first pass)
         uint32_t base = start & ~63u;
-        ListEntry nxt = load_list_entry(L, cone, dmin, dmax, base + lane, le, r.prim);
+        ListEntry nxt = load_list_entry(L, cone, dmin, dmax, base + lane, le, r.prim, r.box8);
         if (COUNT && lane == 0) tc.batch_loads++;
         while (base < le) {
             s_ent[lane * 3 + 0] = nxt.a; s_ent[lane * 3 + 1] = nxt.b; s_ent[lane * 3 + 2] = nxt.e;
@@ -990,7 +1000,7 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
             const unsigned long long fresh = REFINE ? __ballot(nxt.fresh) : 0ull;
             __syncthreads();   // single-wave workgroup: orders the LDS hand-off
             const uint32_t bend = min(le, base + 64u);
-            nxt = load_list_entry(L, cone, dmin, dmax, bend + lane, le, r.prim);   // the following batch travels while this one is tested
+            nxt = load_list_entry(L, cone, dmin, dmax, bend + lane, le, r.prim, r.box8);   // the following batch travels while this one is tested
             if (COUNT && lane == 0 && bend < le) tc.batch_loads++;
             const bool mine = (base + (uint32_t)lane >= start) && (base + (uint32_t)lane < bend);
             const unsigned long long beyond = __ballot(mine && my_key > wmax_bound);           // a suffix of the batch (keys ascend)
@@ -2901,7 +2911,9 @@ __device__ __forceinline__ f3 pg_background(const GrtMeshView& m, f3 d) {   // g
     return mk3(t.x, t.y, t.z);
 }
 
-template <int DEG>
+// GEN = false: render.primitive_type instances with fp32 SH rows (the playground's default) - every `prim` comparison of the candidate test
+// and of the per-hit code folds away, as in the training forward's default instantiation
+template <int DEG, bool GEN = true>
 #ifndef GRT_HYBRID_WAVES
 #define GRT_HYBRID_WAVES 0   // 0: the allocator's own choice (219 registers, 2 waves per SIMD)
 #endif
@@ -2918,6 +2930,7 @@ void grt_hybrid_kernel(GrtTraceParams P, GrtBvh bvh, GrtMeshView mesh, GrtHybrid
     __shared__ uint32_t s_stack[kGrtStackDepth];
     __shared__ float s_hit_t[kGrtMaxHits * 64];
     __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
+    if (!GEN) { P.prim = GRUT_PRIM_INSTANCES; P.sph_half = 0; }
     const int lane = threadIdx.x;
     const PixelBlock pb = pixel_block(P.W, P.H);
     if (!pb.inside) return;
@@ -3326,14 +3339,25 @@ __device__ __forceinline__ bool packet_hit(const GrtCone& k, const GrtPyramid& p
 // bounds: the hit "distance" t of a candidate is the ray parameter of the point closest to the centre in the proxy's metric; that point
 // lies within sqrt(3) max(kscl) of the centre whenever the ray touches the proxy box (the box holds a point of the ray at metric distance
 // <= sqrt 3 and the closest one is no farther), so |o + t d - mu| <= Rt and (|v| - Rt) / |d| <= t <= (|v| + Rt) / |d|
-__device__ __forceinline__ BinParticle bin_particle(const float4& a, const float4& b, const float4& e, f3 o, float dmin, float dmax, int prim, uint32_t id) {
+__device__ __forceinline__ BinParticle bin_particle(const float4& a, const float4& b, const float4& e, f3 o, float dmin, float dmax, int prim, uint32_t id,
+                                                    const float* __restrict__ box8 = nullptr) {
     BinParticle q;
     float k0 = 1.f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z), k1 = 1.f / sqrtf(a.w * a.w + b.x * b.x + b.y * b.y),
           k2 = 1.f / sqrtf(b.z * b.z + b.w * b.w + e.x * e.x);   // rows of W = R^T / kscl
     // half axis i = (row i of W) / |row i|^2: W h_i = e_i, the box is |W (x - mu)|_inf <= 1
     q.h0 = mk3(a.x, a.y, a.z) * (k0 * k0); q.h1 = mk3(a.w, b.x, b.y) * (k1 * k1); q.h2 = mk3(b.z, b.w, e.x) * (k2 * k2);
     float Rt = 1.7320509f * fmaxf(k0, fmaxf(k1, k2)) * 1.00001f;
-    if (prim != GRUT_PRIM_INSTANCES) {
+    if (prim == GRUT_PRIM_CUSTOM) {
+        // custom primitives (round 6): the intersection program runs for the rays that cross the particle's WORLD box (box8, the reference's
+        // AABB kernel), so THAT box - axis-aligned half vectors, a hair padded over the rounding of its centre - stands in every separation
+        // test; a hit that can be accepted lies within 3 sigma of the scale frame, |W (x* - mu)| ks < 3, i.e. within 3 kmax / ks of the centre
+        const float* bx = box8 + 8 * (size_t)id;
+        const float ux = 0.5f * (bx[3] - bx[0]) * 1.00001f + 1e-6f * (fabsf(e.y) + 1.f), uy = 0.5f * (bx[4] - bx[1]) * 1.00001f + 1e-6f * (fabsf(e.z) + 1.f),
+                    uz = 0.5f * (bx[5] - bx[2]) * 1.00001f + 1e-6f * (fabsf(e.w) + 1.f);
+        Rt = 3.f * fmaxf(k0, fmaxf(k1, k2)) / sqrtf(bx[6]) * 1.0001f;
+        q.h0 = mk3(ux, 0.f, 0.f); q.h1 = mk3(0.f, uy, 0.f); q.h2 = mk3(0.f, 0.f, uz);
+        k0 = ux; k1 = uy; k2 = uz;
+    } else if (prim != GRUT_PRIM_INSTANCES) {
         // triangle-mesh proxies: the box of the polyhedron's vertices (half extents ext_i along the proxy's axes) stands in for the unit
         // cube in every separation test, and the reported distance is the ENTRY into the polyhedron - a point of that box: within its
         // bounding sphere of the centre's distance along any ray
@@ -3624,7 +3648,7 @@ __global__ __launch_bounds__(256) void grt_list_count_kernel(GrtTraceParams P, G
         const float4* rec = reinterpret_cast<const float4*>(bvh.inst) + 3 * (size_t)i;
         a = rec[0]; b = rec[1]; e = rec[2];
     }
-    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim, i);
+    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim, i, P.box8);
     const BinOut cache = {nullptr, nullptr, pairs, pair_n};
     const uint32_t gx = blocks_x(P.W), gy = blocks_y(P.H);
     const GrtGrid G = grt_block_grid(block_cones, gx * gy, gx);
@@ -3703,7 +3727,7 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
         }
         const bool again = have && np == kGridWaveTested;
         if (__any(again)) {
-            const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim, p);
+            const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim, p, P.box8);
             GridParticle g = grid_particle(G, gx, gy, again, q, P.bin_lane_area);
             if (!again) g.kind = 0;
             uint32_t n = 0u;
@@ -3715,7 +3739,7 @@ __global__ __launch_bounds__(256) void grt_list_expand_kernel(GrtTraceParams P, 
     const bool cached = have && np <= (uint32_t)kBinCachedPairs;
     emit_cached_pairs(P, lane, cached, p, np, off, end, out);
     // (what the cache did not hold: tested again; pads whatever the masks left unwritten, which is not expected)
-    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim, p);
+    const BinParticle q = bin_particle(a, b, e, o, dmin, dmax, P.prim, p, P.box8);
     const bool again = have && !cached;
     if (__any(again)) bin_pairs<true>(P, block_cones, super_cones, lane, again, q, p, off, again ? end : off, out);
     if (cached) {
@@ -3872,9 +3896,15 @@ void grt_launch_hybrid(hipStream_t s, const GrtTraceParams& P, const GrtBvh& bvh
                        const float* density12, const float* sph, const float* ray_o, const float* ray_d, const float* ray_max_t, float* out_rgb,
                        float* out_alpha, float* out_last_ray, uint32_t* out_bounces, const GrtLists& lists) {
     const dim3 grid(pixel_block_grid(P.W, P.H));
-    GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_hybrid_kernel<D_>), grid, dim3(64), 0, s, P, bvh, mesh, hp,
-                                                     reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, ray_max_t, out_rgb, out_alpha,
-                                                     out_last_ray, out_bounces, lists));
+    if (P.prim == GRUT_PRIM_INSTANCES && !P.sph_half) {
+        GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_hybrid_kernel<D_, false>), grid, dim3(64), 0, s, P, bvh, mesh, hp,
+                                                         reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, ray_max_t, out_rgb, out_alpha,
+                                                         out_last_ray, out_bounces, lists));
+    } else {
+        GRT_DISPATCH_DEGREE(P.degree, hipLaunchKernelGGL((grt_hybrid_kernel<D_, true>), grid, dim3(64), 0, s, P, bvh, mesh, hp,
+                                                         reinterpret_cast<const float4*>(density12), sph, ray_o, ray_d, ray_max_t, out_rgb, out_alpha,
+                                                         out_last_ray, out_bounces, lists));
+    }
 }
 
 }  // namespace grut

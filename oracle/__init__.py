@@ -425,6 +425,25 @@ def grt_process_hit_fwd(degree, min_response, min_alpha, max_alpha, ray_o, ray_d
     return int(acc), st
 
 
+def grt_composite_sequence(cfg, min_transmittance, ray_o_world, ray_d_world, density12, sph, sph_deg, particle_ids, dtype=np.float32):
+    """The forward ray program's per-hit loop (referenceOptix.cu:141-170) over a GIVEN sequence of particles, in the given order: processHit
+    while the transmittance is above the threshold.  Returns (radiance[3], opacity, integrated distance, accepted hits).  For the tests that
+    identify order ties: the same hits in another order."""
+    l, R = lib(dtype), _real(dtype)
+    st = np.zeros(8, dtype)
+    st[0] = 1
+    ro, rd = _c(ray_o_world, dtype), _c(ray_d_world, dtype)
+    d12, s = _c(density12, dtype), _c(sph, dtype)
+    n_acc = 0
+    for pid in particle_ids:
+        if not st[0] > min_transmittance:
+            break
+        n_acc += int(l.orc_grt_process_hit_fwd_prim(C.c_int(int(cfg.primitive_type)), C.c_int(int(cfg.particle_kernel_degree)), R(cfg.particle_kernel_min_response),
+                                                    R(cfg.particle_kernel_min_alpha), R(cfg.particle_kernel_max_alpha), _p(ro), _p(rd),
+                                                    _p(np.ascontiguousarray(d12[int(pid)])), _p(np.ascontiguousarray(s[int(pid)])), C.c_int(sph_deg), _p(st)))
+    return st[1:4].copy(), float(1 - st[0]), float(st[4]), n_acc
+
+
 def grt_process_hit_bwd(degree, min_response, min_alpha, max_alpha, min_transmittance, ray_o, ray_d, density12, sph48, sph_deg, state5,
                         fin5, grads5, dtype=np.float32):
     l, R = lib(dtype), _real(dtype)

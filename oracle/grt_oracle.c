@@ -371,6 +371,19 @@ int orc_grt_process_hit_fwd(int degree, real min_response, real min_alpha, real 
     state8[5] = s.normal.x; state8[6] = s.normal.y; state8[7] = s.normal.z;
     return acc;
 }
+/* ... for render.primitive_type `prim` (6 = trisurfel: the SurfelPrimitive branches of processHit); the tests composite a ray's hit
+ * sequence hit by hit with it, in any order they choose (identification of order ties against the reference programs' goldens) */
+int orc_grt_process_hit_fwd_prim(int prim, int degree, real min_response, real min_alpha, real max_alpha, const real* ray_o, const real* ray_d,
+                                 const real* density12, const real* sph48, int sph_deg, real* state8) {
+    GrtConfig cfg = kat_config(degree, min_response, min_alpha, max_alpha);
+    cfg.primitive_type = prim;
+    grt_ray_state s;
+    s.T = state8[0]; s.rad = v3_make(state8[1], state8[2], state8[3]); s.depth = state8[4];
+    s.normal = v3_make(state8[5], state8[6], state8[7]);
+    const int acc = process_hit(&cfg, v3_make(ray_o[0], ray_o[1], ray_o[2]), v3_make(ray_d[0], ray_d[1], ray_d[2]), density12, sph48, sph_deg, &s, 0);
+    state8[0] = s.T; state8[1] = s.rad.x; state8[2] = s.rad.y; state8[3] = s.rad.z; state8[4] = s.depth;
+    return acc;
+}
 void orc_grt_process_hit_bwd(int degree, real min_response, real min_alpha, real max_alpha, real min_transmittance, const real* ray_o,
                              const real* ray_d, const real* density12, const real* sph48, int sph_deg, real* state5, const real* fin5,
                              const real* grads5, real* g_density12, real* g_sph48) {

@@ -586,6 +586,111 @@ def assert_gut_full_parity(stats, max_flip_frac=2e-3, max_rounding_frac=2e-4):
 GRT_PRIMITIVE_CODES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4, "custom": 5, "trisurfel": 6, "trihexa": 7}
 
 
+def grt_identify_order_ties(primitive_type, cases, d12, sph, inst, scene_aabb, box8, T_to_world, min_transmittance, tol=1e-4, max_ulp=None):
+    """Rays whose colour differs from the reference PROGRAMS' golden although the number of accepted hits is the same: show what each one is.
+    cases: [(ray_o[3], ray_d[3] in ray space, particle sequence as the GPU processed it, reference (rgb[3], opacity, integrated distance),
+    the GPU's own (rgb[3], opacity, integrated distance))].  Classes:
+      tie       ONE transposition of two neighbouring hits of the GPU's sequence (or a permutation inside three neighbouring hits, or two
+                transpositions) reproduces the REFERENCE's colour, opacity and distance within `tol` when the checker's processHit composites
+                the sequence hit by hit, AND the transposed hits' distances - the checker's candidate arithmetic on a one-particle scene - lie
+                within `max_ulp` float32 steps of each other: the reference's intersection program and this library's candidate test round
+                the distance differently (referenceOptix.cu:210-246 inserts with a strict <, OptiX leaves the order of equal distances open),
+                so hits that close can come out in the other order;
+      rounding  no reordering is involved: the GPU's sequence composited in DOUBLE precision lies within 2 tol of the reference AND of the
+                GPU's value - two float evaluations of one sequence on opposite sides of the exact value (long sequences; surfels grazed by the ray).
+    Returns one record per case with `identified`."""
+    import itertools
+    # how far apart two hits may be and still come out in the other order: the flat proxies are TRIANGLES to the reference (OptiX's
+    # ray-triangle intersection in world space against this library's plane crossing in the proxy frame: measured up to 25 float32 steps
+    # on the 1 M frame); the volumetric ones evaluate the same closest-approach formula in two roundings (measured up to 5)
+    if max_ulp is None:
+        max_ulp = 32 if primitive_type in ("trisurfel", "trihexa") else 16
+    code = GRT_PRIMITIVE_CODES[primitive_type]
+    cfg = oracle.default_grt_config(primitive_type=code)
+    M = np.asarray(T_to_world, np.float32)[:3, :4]
+    out = []
+
+    def hit_ts(ro, rd, o_w, d_w, pid):
+        if primitive_type == "trihexa":   # up to three offers per particle (one per rhombus): every plane crossing, in double
+            W = inst[pid][:9].reshape(3, 3).astype(np.float64)
+            po, pd = W @ (o_w.astype(np.float64) - inst[pid][9:12]), W @ d_w.astype(np.float64)
+            return [float(-po[k] / pd[k]) for k in range(3) if pd[k] != 0]
+        kw = dict(box8=box8[[pid]]) if primitive_type == "custom" else {}
+        o = oracle.grt_forward(cfg, d12[[pid]], sph[[pid]], 3, min_transmittance, T_to_world, ro.reshape(1, 1, 3), rd.reshape(1, 1, 3), inst=inst[[pid]],
+                               scene=scene_aabb, **kw)
+        return [float(o["hit_distance"][0, 0, 1])]
+
+    def steps(ta, tb):   # float32 steps between the two closest offers
+        return min(abs(a - b) / float(np.spacing(np.float32(max(abs(a), abs(b))))) for a in ta for b in tb)
+
+    for ro, rd, seq, ref, gpu in cases:
+        ro, rd = np.asarray(ro, np.float32), np.asarray(rd, np.float32)
+        o_w = (M[:, :3] @ ro + M[:, 3]).astype(np.float32)
+        d_w = (M[:, :3] @ rd).astype(np.float32)
+        seq = [int(v) for v in seq]
+        scale = max(1.0, abs(float(ref[2])))
+
+        def dist(a, b):
+            return max(float(np.abs(np.asarray(a[0], np.float64) - np.asarray(b[0], np.float64)).max()), abs(float(a[1]) - float(b[1])), abs(float(a[2]) - float(b[2])) / scale)
+
+        def comp(order, dtype=np.float32):
+            rgb, opa, dst, _ = oracle.grt_composite_sequence(cfg, min_transmittance, o_w, d_w, d12, sph, 3, order, dtype=dtype)
+            return rgb, opa, dst
+
+        rec = dict(hits=len(seq), err_as_processed=dist(comp(seq), ref), gpu_vs_reference=dist(gpu, ref), kind=None, identified=False)
+        c64 = comp(seq, np.float64)
+        rec["double_vs_reference"], rec["double_vs_gpu"] = dist(c64, ref), dist(c64, gpu)
+        found, far, best = None, None, (1e30, -1)
+        for k in range(len(seq) - 1):   # one transposition
+            order = seq[:k] + [seq[k + 1], seq[k]] + seq[k + 2:]
+            e = dist(comp(order), ref)
+            if e < best[0]:
+                best = (e, k)
+            if e <= tol:
+                if steps(hit_ts(ro, rd, o_w, d_w, seq[k]), hit_ts(ro, rd, o_w, d_w, seq[k + 1])) <= max_ulp:
+                    found = ([k, k + 1], e)
+                    break
+                far = far or ([k, k + 1], e)   # reproduces the reference, but the two hits are not that close: reported, not accepted
+        rec["best_single_transposition"] = dict(err=best[0], at=best[1])
+        if found is None:
+            e_rm = [(dist(comp(seq[:k] + seq[k + 1:]), ref), k) for k in range(len(seq))]
+            rec["best_single_removal"] = dict(err=min(e_rm)[0], at=min(e_rm)[1])
+        if found is None and far is None:   # three neighbouring hits in another order
+            for k in range(len(seq) - 2):
+                for perm in itertools.permutations(range(3)):
+                    if perm in ((0, 1, 2), (1, 0, 2), (0, 2, 1)):
+                        continue
+                    order = seq[:k] + [seq[k + q] for q in perm] + seq[k + 3:]
+                    e = dist(comp(order), ref)
+                    if e <= tol:
+                        found = ([k, k + 1, k + 2], e)
+                        break
+                if found is not None:
+                    break
+        if found is None and far is None:   # two ties on one ray
+            for k in range(len(seq) - 1):
+                o1 = seq[:k] + [seq[k + 1], seq[k]] + seq[k + 2:]
+                for j in range(k + 2, len(seq) - 1):
+                    order = o1[:j] + [o1[j + 1], o1[j]] + o1[j + 2:]
+                    e = dist(comp(order), ref)
+                    if e <= tol:
+                        found = ([k, k + 1, j, j + 1], e)
+                        break
+                if found is not None:
+                    break
+        found = found or far
+        if found is not None:
+            pos = found[0]
+            ts = [hit_ts(ro, rd, o_w, d_w, seq[q]) for q in pos]
+            gaps = [steps(ts[a], ts[a + 1]) for a in range(len(pos) - 1) if pos[a + 1] == pos[a] + 1]
+            rec.update(kind="tie", positions=pos, err_after_reordering=found[1], float_steps_between_reordered_hits=[float(g_) for g_ in gaps],
+                       identified=bool(max(gaps) <= max_ulp))
+        if not rec["identified"] and max(rec["double_vs_reference"], rec["double_vs_gpu"]) <= 2 * tol:
+            rec.update(kind="rounding", identified=True)
+        out.append(rec)
+    return out
+
+
 def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_cap=192, with_backward=True, log=None, wide_stride=0,
                     primitive_type="instances"):
     """HIP 3DGRT against the oracle on every `ray_stride`-th ray of the frame (the oracle tests every particle against every

@@ -92,7 +92,7 @@ def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, 
     # 1 M particles: every 149th ray through all pairs (4296 rays), then every 9th ray (71 k) with the oracle's scan restricted to the
     # packet lists the GPU built - checked to change nothing on the 4296
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
-    has_lists = prim != "custom" or getattr(grt, "CUSTOM_PRIMITIVES_USE_PACKET_LISTS", False)
+    has_lists = True   # (custom and trihexa since round 6)
     stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print, wide_stride=9 if ray_stride > 1 and has_lists else 0,
                                primitive_type=prim)
     pu.record_full_parity(name, stats)
@@ -200,7 +200,8 @@ def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_siz
     d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=ms)
     K = syn.pinhole_intrinsics(w, h)
     ro, rd = syn.pinhole_rays(w, h, K)
-    batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(0, n_views=8)[None], intrinsics=K), "cuda")
+    inp_T = syn.orbit_pose(0, n_views=8)
+    batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=inp_T[None], intrinsics=K), "cuda")
     tracer = grt.Tracer({"render": {"enable_hitcounts": True, "primitive_type": prim}})
     gs = syn.SimpleGaussians(d12, sph)
     tracer.build_acc(gs, rebuild=True)
@@ -224,7 +225,40 @@ def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_siz
     pu.record_full_parity(f"ref_programs_{prim}_c3_1m_800", dict(rays=int(flips.size), count_flips=int(flips.sum()), order_ties=int(tied.sum()),
                                                                  max_rgb_err_in_ties=float(e_f[tied].max()) if tied.any() else 0.0,
                                                                  max_rgb_err_elsewhere=float(e_f[ok & ~tied].max()), hits_per_ray=float(g["hits_count"].mean())))
-    assert tied.mean() <= 5e-3 and (not tied.any() or (e_f[tied].max() < 5e-2 and e_o[tied].max() < 5e-2))
+    assert tied.mean() <= 5e-3
+    # round 6: every such ray IDENTIFIED as an order tie instead of fenced (it used to pass with up to 5e-2 on 0.5 % of the rays): one
+    # transposition of two neighbouring hits of the GPU's own sequence reproduces the reference's colour, opacity and distance within 1e-4,
+    # and the two hits' distances are within a few float32 steps of each other (pu.grt_identify_order_ties)
+    if tied.any():
+        nat = tracer.tracer_wrapper
+        frame = nat.make_frame(0, 3, tracer._min_transmittance, n, h, w, batch.T_to_world)
+        res = nat.trace(frame, torch.as_tensor(d12, device="cuda").contiguous(), torch.as_tensor(sph, device="cuda").contiguous(),
+                        batch.rays_ori.contiguous(), batch.rays_dir.contiguous(), hit_capacity=256)
+        ids_all, num_all = res[6], res[7].reshape(-1)
+        inst = nat.instances(n, "cuda").cpu().numpy()
+        scene_aabb = np.array(list(nat.stats().scene_aabb), np.float32)
+        box8 = nat.custom_boxes(n, "cuda").cpu().numpy() if prim == "custom" else None
+        cases = []
+        for sy_, sx_ in zip(*np.nonzero(tied)):
+            pix = int(ys[sy_]) * w + int(xs[sx_])
+            k = int(num_all[pix])
+            assert k <= 256
+            cases.append((ro.reshape(-1, 3)[pix], rd.reshape(-1, 3)[pix], ids_all[pix, :k].cpu().numpy().view(np.uint32),
+                          (g["features"][sy_, sx_], g["density"][sy_, sx_, 0], g["hit_distance"][sy_, sx_, 0]),
+                          (pick(out["pred_features"])[sy_, sx_], pick(out["pred_opacity"])[sy_, sx_, 0], pick(out["pred_dist"])[sy_, sx_, 0])))
+        recs = pu.grt_identify_order_ties(prim, cases, d12, sph, inst, scene_aabb, box8, inp_T, tracer._min_transmittance)
+        for r_ in recs:
+            print(f"{prim}: tie ray: {r_}")
+        pu.record_full_parity(f"ref_programs_{prim}_c3_1m_800_ties", dict(
+            rays=len(recs), ties=int(sum(r_["kind"] == "tie" and r_["identified"] for r_ in recs)), rounding=int(sum(r_["kind"] == "rounding" for r_ in recs)),
+            unidentified=int(sum(not r_["identified"] for r_ in recs)),
+            max_float_steps_between_reordered_hits=float(max([max(r_.get("float_steps_between_reordered_hits", [0.0])) for r_ in recs if r_["identified"]] + [0.0])),
+            max_err_after_reordering=float(max([r_.get("err_after_reordering", 0.0) for r_ in recs if r_["identified"]] + [0.0])), records=recs))
+        # what is NOT identified (round 6: one ray of the custom frame, one of the trisurfel frame - no reordering inside three neighbouring hits
+        # and no single removal reproduces the reference; without the reference programs' own hit log in the golden they cannot be told
+        # apart further) stays under the old fence, and there may be at most one such ray per frame
+        bad = [r_ for r_ in recs if not r_["identified"]]
+        assert len(bad) <= 1 and all(r_["gpu_vs_reference"] < 5e-2 for r_ in bad), bad
     ok = ok & ~tied
     # backward: the upstream gradient lives on the sampled rays only
     g_rad, g_dns, g_hit = mg.grt_trace_upstream(sh, sw)
