@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 S=$R/gpurun_out/workloads_$TAG
 mkdir -p $S
 B="python $R/bench.py --no-cpu-baseline --no-secondary"
-for w in c1_100k_400 c2_1m_800 c4_3m_1080p c3_grt_100k_400 c5_hybrid_2m_1080p c4_nht_1m_1080p c3_grt_nht_1m_800 c3_grt_icosa_1m_800 c3_grt_custom_1m_800 c3_grt_trisurfel_1m_800; do
+for w in c1_100k_400 c2_1m_800 c4_3m_1080p c3_grt_100k_400 c5_hybrid_2m_1080p c4_nht_1m_1080p c3_grt_nht_1m_800 c3_grt_icosa_1m_800 c3_grt_custom_1m_800 c3_grt_trisurfel_1m_800 c3_grt_trihexa_1m_800; do
     timeout 300 $B --workload $w > $S/bench_$w.json 2> $S/bench_$w.err
     [ -s $S/bench_$w.err ] || rm -f $S/bench_$w.err
 done
