@@ -443,7 +443,7 @@ __device__ __forceinline__ f3 proxy_origin(const float4& a, const float4& b, con
 // (TIES: candidates AT t_lo are evaluated too — t_lo is then the ray's last hit distance, see GhostLog)
 template <bool REL, bool TIES = false>
 __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi,
-                                              bool always_box = false);
+                                              bool always_box = false, bool may_skip = false);
 template <typename Q, bool REL, bool TIES>
 __device__ __forceinline__ Cand candidate_q(const Q* __restrict__ rec, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi) {
     const float4 a = ld4(rec, 0), b = ld4(rec, 1), e = ld4(rec, 2);
@@ -454,8 +454,10 @@ __device__ __forceinline__ float min3f(float a, float b, float c);
 // always_box (wave-uniform): the box test runs for rays outside the wanted range too and its outcome is reported in `box`; `ok` and
 // everything else are what the plain call returns
 template <bool REL, bool TIES>
+// may_skip (the rounds' scans only - callers that read `t` of a candidate that is not `ok` must leave it off): the mesh proxies' plane loop may
+// end early when no ray of the wave can become a candidate any more (see there)
 __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi,
-                                              bool always_box) {
+                                              bool always_box, bool may_skip) {
 #pragma clang fp contract(off)
     Cand c;
     c.ok = false; c.box = false; c.t = 0.f; c.tnear = 0.f; c.tfar = 0.f; c.why = 1;
@@ -480,16 +482,28 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
             const float dn = fmaf(nz, pdz, fmaf(ny, pdy, nx * pdx));
             const float dt = fmaf(nz, poz, fmaf(ny, poy, nx * pox));
             const float on_a = hh - dt, on_b = hh + dt;
-            const float tf_a = on_a / dn, tf_b = on_b / (-dn);
+            // (round 6) ONE correctly rounded reciprocal per pair instead of two divisions: 1 / (-dn) = -(1 / dn) exactly, so the second plane's
+            // distance is the negated product, bit for bit what the plane-by-plane loop of the CPU checker computes with its own 1 / dn
+            const float inv = 1.f / dn;
+            const float tf_a = on_a * inv, tf_b = -(on_b * inv);
             if (dn < 0.f) { tin = fmaxf(tin, tf_a); tout = fminf(tout, tf_b); }
             else if (dn > 0.f) { tout = fminf(tout, tf_a); tin = fmaxf(tin, tf_b); }
             else if (on_a < 0.f || on_b < 0.f) miss = true;
+            // (round 6) the entry distance only grows and the exit distance only shrinks from plane to plane: a ray that has missed (tin > tout)
+            // or whose entry is already beyond the wanted range (tin > t_hi), or whose exit is already before it (tout < t_lo: the final
+            // tin <= tout < t_lo), cannot become a candidate - when that holds for every ray of the wave the remaining planes are skipped.
+            // Exact: the result of such a ray is `not ok` either way and nothing reads its distance (first tests want the true `box`: then
+            // only the miss counts).
+            if (may_skip && p + 1 < ph.num_pairs && __all(miss || !(tin <= tout) || (!always_box && ((tin > t_hi) || (tout < t_lo))))) {
+                c.t = tin; c.tnear = tin; c.tfar = 3.0e38f;
+                return c;
+            }
         }
         for (int f = 2 * ph.num_pairs; f < ph.num_planes; ++f) {
             const float nx = ph.planes[f][0], ny = ph.planes[f][1], nz = ph.planes[f][2], hh = ph.planes[f][3];
             const float dn = fmaf(nz, pdz, fmaf(ny, pdy, nx * pdx));
             const float on = hh - fmaf(nz, poz, fmaf(ny, poy, nx * pox));
-            const float tf = on / dn;
+            const float tf = on * (1.f / dn);
             if (dn < 0.f) tin = fmaxf(tin, tf);
             else if (dn > 0.f) tout = fminf(tout, tf);
             else if (on < 0.f) miss = true;
@@ -1038,10 +1052,10 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
                 float lo0 = 3.0e38f, hi0 = -3.0e38f, lo1 = 3.0e38f, hi1 = -3.0e38f;
                 if (active) {
                     const float t_lo = GHOST ? ghosts->tie_t : tmin;
-                    const Cand c0 = GHOST ? candidate_abe<true, true>(s_ent[j0 * 3], s_ent[j0 * 3 + 1], s_ent[j0 * 3 + 2], r, t_lo, buf.t[G - 1], id0, buf.id[G - 1], ft0)
-                                          : candidate_abe<true>(s_ent[j0 * 3], s_ent[j0 * 3 + 1], s_ent[j0 * 3 + 2], r, t_lo, buf.t[G - 1], id0, buf.id[G - 1], ft0);
-                    Cand c1 = GHOST ? candidate_abe<true, true>(s_ent[j1 * 3], s_ent[j1 * 3 + 1], s_ent[j1 * 3 + 2], r, t_lo, buf.t[G - 1], id1, buf.id[G - 1], ft1)
-                                    : candidate_abe<true>(s_ent[j1 * 3], s_ent[j1 * 3 + 1], s_ent[j1 * 3 + 2], r, t_lo, buf.t[G - 1], id1, buf.id[G - 1], ft1);
+                    const Cand c0 = GHOST ? candidate_abe<true, true>(s_ent[j0 * 3], s_ent[j0 * 3 + 1], s_ent[j0 * 3 + 2], r, t_lo, buf.t[G - 1], id0, buf.id[G - 1], ft0, true)
+                                          : candidate_abe<true>(s_ent[j0 * 3], s_ent[j0 * 3 + 1], s_ent[j0 * 3 + 2], r, t_lo, buf.t[G - 1], id0, buf.id[G - 1], ft0, true);
+                    Cand c1 = GHOST ? candidate_abe<true, true>(s_ent[j1 * 3], s_ent[j1 * 3 + 1], s_ent[j1 * 3 + 2], r, t_lo, buf.t[G - 1], id1, buf.id[G - 1], ft1, true)
+                                    : candidate_abe<true>(s_ent[j1 * 3], s_ent[j1 * 3 + 1], s_ent[j1 * 3 + 2], r, t_lo, buf.t[G - 1], id1, buf.id[G - 1], ft1, true);
                     if (!two) { c1.ok = false; c1.box = false; }
                     auto take = [&](const Cand& cd, uint32_t id, float& tl, float& th) {
                         if (REFINE && cd.box) { tl = cd.t; th = cd.t; }
@@ -1099,8 +1113,8 @@ __device__ __forceinline__ void list_round(const GrtLists& L, const GrtCone& con
                 float t_mine_lo = 3.0e38f, t_mine_hi = -3.0e38f;
                 const bool first_test = REFINE && pass == 0 && ((fresh >> j) & 1ull) && n_pending < kGrtPendingCap;
                 if (active) {
-                    const Cand cd = GHOST ? candidate_abe<true, true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, ghosts->tie_t, buf.t[G - 1], id, buf.id[G - 1], first_test)
-                                          : candidate_abe<true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, tmin, buf.t[G - 1], id, buf.id[G - 1], first_test);
+                    const Cand cd = GHOST ? candidate_abe<true, true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, ghosts->tie_t, buf.t[G - 1], id, buf.id[G - 1], first_test, true)
+                                          : candidate_abe<true>(s_ent[j * 3], s_ent[j * 3 + 1], s_ent[j * 3 + 2], r, tmin, buf.t[G - 1], id, buf.id[G - 1], first_test, true);
                     if (REFINE && cd.box) { t_mine_lo = cd.t; t_mine_hi = cd.t; }
                     const bool reach = cd.ok && (cd.t < tmax) && (cd.tnear <= tmax) && hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
                     const bool in_range = reach && (cd.t > tmin);

@@ -505,9 +505,12 @@ def main():
     dp = importlib.import_module("3dgrut_amd.dp")
     exch = None
     exchange_kind = "none"
-    # pipelined by default since round 5 (collectives of particle range i under the finalisation kernels of range i + 1; bit-identical to the
-    # one-piece exchange: tests/test_dp_gloo.py, tests/test_dp_gpu.py); GRUT_BENCH_EXCHANGE_CHUNKS=1 restores the one-piece form
-    chunks = int(os.environ.get("GRUT_BENCH_EXCHANGE_CHUNKS", "4"))
+    # ONE-PIECE by default again (round 6): RCCL has never executed this path - no multi-GPU box in six rounds - and the first run should have as
+    # few ways to fail as possible: one all-reduce + one all-gather on the compute stream after the backward.  The pipelined form (collectives
+    # of particle range i under the finalisation kernels of range i + 1, issued from a callback inside autograd's backward; bit-identical over
+    # gloo: tests/test_dp_gloo.py, tests/test_dp_gpu.py) is GRUT_BENCH_EXCHANGE_CHUNKS=4; a hang or a mis-ordering there would not be an exception
+    # the net below could catch
+    chunks = int(os.environ.get("GRUT_BENCH_EXCHANGE_CHUNKS", "1"))
     auto_exchange = False
     if world > 1:
         exchange_kind = os.environ.get("GRUT_BENCH_EXCHANGE", "auto")

@@ -131,7 +131,7 @@ static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist, uint32_
             const real nx = (real)ph->planes[f][0], ny = (real)ph->planes[f][1], nz = (real)ph->planes[f][2], hh = (real)ph->planes[f][3];
             const real dn = r_fma(nz, pd.z, r_fma(ny, pd.y, nx * pd.x));
             const real on = hh - r_fma(nz, po.z, r_fma(ny, po.y, nx * po.x));
-            const real tf = on / dn;
+            const real tf = on * (1 / dn);   /* (round 6: reciprocal + product, as candidate_abe - one division per antipodal pair there) */
             if (dn < 0) tin = r_fmax(tin, tf);
             else if (dn > 0) tout = r_fmin(tout, tf);
             else if (on < 0) miss = 1;
