@@ -453,9 +453,49 @@ __device__ __forceinline__ float max3f(float a, float b, float c);
 __device__ __forceinline__ float min3f(float a, float b, float c);
 // always_box (wave-uniform): the box test runs for rays outside the wanted range too and its outcome is reported in `box`; `ok` and
 // everything else are what the plain call returns
-template <bool REL, bool TIES>
+// Clip a proxy-frame ray against the face planes n . x <= h of polyhedron PRIM, fully unrolled (the coefficients are instruction literals):
+// entering planes (n . d < 0) raise tin, leaving planes lower tout, parallel-and-outside = miss.  Antipodal pairs (n, h) / (-n, h) share their
+// two dot products and ONE correctly rounded reciprocal (1 / (-dn) = -(1 / dn) exactly).  The selects pick exactly what the CPU checker's
+// plane-by-plane branches assign.  Returns true when `may_skip` let it stop early: the distances only tighten from plane to plane, so a
+// ray that has missed (tin > tout), whose entry is beyond the wanted range (tin > t_hi) or whose exit is before it (tout < t_lo) cannot
+// become a candidate - when that holds for every ray of the wave the remaining planes are skipped (first tests, always_box, want the true
+// `box`: then only the miss counts).
+template <int PRIM>
+__device__ __forceinline__ bool clip_polyhedron(float pox, float poy, float poz, float pdx, float pdy, float pdz, float t_lo, float t_hi, bool always_box,
+                                                bool may_skip, float& tin, float& tout, bool& miss) {
+#pragma clang fp contract(off)
+    constexpr int kPairs = kGrtPolyhedraCx[PRIM].num_pairs, kPlanes = kGrtPolyhedraCx[PRIM].num_planes;
+#pragma unroll
+    for (int p = 0; p < kPairs; ++p) {
+        const float nx = kGrtPolyhedraCx[PRIM].planes[2 * p][0], ny = kGrtPolyhedraCx[PRIM].planes[2 * p][1], nz = kGrtPolyhedraCx[PRIM].planes[2 * p][2],
+                    hh = kGrtPolyhedraCx[PRIM].planes[2 * p][3];
+        const float dn = fmaf(nz, pdz, fmaf(ny, pdy, nx * pdx));
+        const float dt = fmaf(nz, poz, fmaf(ny, poy, nx * pox));
+        const float on_a = hh - dt, on_b = hh + dt;
+        const float inv = 1.f / dn;
+        const float tf_a = on_a * inv, tf_b = -(on_b * inv);
+        const bool neg = dn < 0.f, cut = neg || (dn > 0.f);
+        const float t_en = neg ? tf_a : tf_b, t_le = neg ? tf_b : tf_a;
+        tin = cut ? fmaxf(tin, t_en) : tin;
+        tout = cut ? fminf(tout, t_le) : tout;
+        miss = miss || (!cut && (on_a < 0.f || on_b < 0.f));
+        if (may_skip && (p % 3 == 2) && (2 * p + 2 < kPlanes) && __all(miss || !(tin <= tout) || (!always_box && ((tin > t_hi) || (tout < t_lo))))) return true;
+    }
+#pragma unroll
+    for (int f = 2 * kPairs; f < kPlanes; ++f) {
+        const float nx = kGrtPolyhedraCx[PRIM].planes[f][0], ny = kGrtPolyhedraCx[PRIM].planes[f][1], nz = kGrtPolyhedraCx[PRIM].planes[f][2], hh = kGrtPolyhedraCx[PRIM].planes[f][3];
+        const float dn = fmaf(nz, pdz, fmaf(ny, pdy, nx * pdx));
+        const float on = hh - fmaf(nz, poz, fmaf(ny, poy, nx * pox));
+        const float tf = on * (1.f / dn);
+        tin = dn < 0.f ? fmaxf(tin, tf) : tin;
+        tout = dn > 0.f ? fminf(tout, tf) : tout;
+        miss = miss || (!(dn < 0.f) && !(dn > 0.f) && on < 0.f);
+    }
+    return false;
+}
 // may_skip (the rounds' scans only - callers that read `t` of a candidate that is not `ok` must leave it off): the mesh proxies' plane loop may
 // end early when no ray of the wave can become a candidate any more (see there)
+template <bool REL, bool TIES>
 __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, const float4& e, const RayW& r, float t_lo, float t_hi, uint32_t id, uint32_t id_hi,
                                               bool always_box, bool may_skip) {
 #pragma clang fp contract(off)
@@ -471,43 +511,19 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
         // what OptiX reports for the one front-facing triangle of the reference's mesh the ray passes (back faces culled; a ray that starts
         // inside is not offered the particle).  Clip against the face planes n . x <= h: entering planes (n . d < 0) raise the entry
         // distance, leaving planes lower the exit distance; parallel and outside = miss.  Same operations, same order in the CPU checker.
-        const GrtPolyhedron& ph = kGrtPolyhedra[r.prim];
         float tin = -3.0e38f, tout = 3.0e38f;
         bool miss = false;
-        // antipodal pairs (n, h) / (-n, h) - all of the icosahedron's and the octahedron's faces: n . d and n . o of the second plane are the
-        // first's negated, bit for bit (every operand of its fused multiply-adds is negated), so one pair of dot products serves two planes
-        // and the values equal the plane-by-plane loop's (which the CPU checker runs over the same table)
-        for (int p = 0; p < ph.num_pairs; ++p) {
-            const float nx = ph.planes[2 * p][0], ny = ph.planes[2 * p][1], nz = ph.planes[2 * p][2], hh = ph.planes[2 * p][3];
-            const float dn = fmaf(nz, pdz, fmaf(ny, pdy, nx * pdx));
-            const float dt = fmaf(nz, poz, fmaf(ny, poy, nx * pox));
-            const float on_a = hh - dt, on_b = hh + dt;
-            // (round 6) ONE correctly rounded reciprocal per pair instead of two divisions: 1 / (-dn) = -(1 / dn) exactly, so the second plane's
-            // distance is the negated product, bit for bit what the plane-by-plane loop of the CPU checker computes with its own 1 / dn
-            const float inv = 1.f / dn;
-            const float tf_a = on_a * inv, tf_b = -(on_b * inv);
-            if (dn < 0.f) { tin = fmaxf(tin, tf_a); tout = fminf(tout, tf_b); }
-            else if (dn > 0.f) { tout = fminf(tout, tf_a); tin = fmaxf(tin, tf_b); }
-            else if (on_a < 0.f || on_b < 0.f) miss = true;
-            // (round 6) the entry distance only grows and the exit distance only shrinks from plane to plane: a ray that has missed (tin > tout)
-            // or whose entry is already beyond the wanted range (tin > t_hi), or whose exit is already before it (tout < t_lo: the final
-            // tin <= tout < t_lo), cannot become a candidate - when that holds for every ray of the wave the remaining planes are skipped.
-            // Exact: the result of such a ray is `not ok` either way and nothing reads its distance (first tests want the true `box`: then
-            // only the miss counts).
-            if (may_skip && p + 1 < ph.num_pairs && __all(miss || !(tin <= tout) || (!always_box && ((tin > t_hi) || (tout < t_lo))))) {
-                c.t = tin; c.tnear = tin; c.tfar = 3.0e38f;
-                return c;
-            }
+        // (round 6) the plane loop unrolled per primitive over the constexpr copy of the table (clip_polyhedron): the rolled loop that used to
+        // stand here fetched every pair through the scalar cache and waited for it (s_load_dwordx4 + s_waitcnt per pair) and branched on the
+        // sign of n . d - the icosahedra's forward went from 11.9 to 8.0 ms
+        bool skipped = false;
+        switch (r.prim) {
+        case GRUT_PRIM_ICOSAHEDRON: skipped = clip_polyhedron<GRUT_PRIM_ICOSAHEDRON>(pox, poy, poz, pdx, pdy, pdz, t_lo, t_hi, always_box, may_skip, tin, tout, miss); break;
+        case GRUT_PRIM_OCTAHEDRON: skipped = clip_polyhedron<GRUT_PRIM_OCTAHEDRON>(pox, poy, poz, pdx, pdy, pdz, t_lo, t_hi, always_box, may_skip, tin, tout, miss); break;
+        case GRUT_PRIM_TETRAHEDRON: skipped = clip_polyhedron<GRUT_PRIM_TETRAHEDRON>(pox, poy, poz, pdx, pdy, pdz, t_lo, t_hi, always_box, may_skip, tin, tout, miss); break;
+        default: skipped = clip_polyhedron<GRUT_PRIM_DIAMOND>(pox, poy, poz, pdx, pdy, pdz, t_lo, t_hi, always_box, may_skip, tin, tout, miss); break;
         }
-        for (int f = 2 * ph.num_pairs; f < ph.num_planes; ++f) {
-            const float nx = ph.planes[f][0], ny = ph.planes[f][1], nz = ph.planes[f][2], hh = ph.planes[f][3];
-            const float dn = fmaf(nz, pdz, fmaf(ny, pdy, nx * pdx));
-            const float on = hh - fmaf(nz, poz, fmaf(ny, poy, nx * pox));
-            const float tf = on * (1.f / dn);
-            if (dn < 0.f) tin = fmaxf(tin, tf);
-            else if (dn > 0.f) tout = fminf(tout, tf);
-            else if (on < 0.f) miss = true;
-        }
+        if (skipped) { c.t = tin; c.tnear = tin; c.tfar = 3.0e38f; return c; }
         c.t = tin;
         c.box = !miss && (tin <= tout) && (tin > -3.0e38f);
         const bool want = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));

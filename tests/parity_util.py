@@ -686,6 +686,8 @@ def grt_identify_order_ties(primitive_type, cases, d12, sph, inst, scene_aabb, b
             rec.update(kind="tie", positions=pos, err_after_reordering=found[1], float_steps_between_reordered_hits=[float(g_) for g_ in gaps],
                        identified=bool(max(gaps) <= max_ulp))
         if not rec["identified"] and max(rec["double_vs_reference"], rec["double_vs_gpu"]) <= 2 * tol:
+            for key in ("positions", "err_after_reordering", "float_steps_between_reordered_hits"):   # (a far-apart reordering that happened to fit: not the explanation)
+                rec.pop(key, None)
             rec.update(kind="rounding", identified=True)
         out.append(rec)
     return out
