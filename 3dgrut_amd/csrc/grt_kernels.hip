@@ -839,6 +839,67 @@ __device__ __forceinline__ void trace_round(const GrtBvh& bvh, const RayW& r, fl
     }
 }
 
+// One optixTrace per LANE (round 6): every ray walks the tree on its own - its own current node, its own stack (LDS, `depth` words per
+// lane at `lstack[k * 64 + lane]`), the nearer child first - for rays that do NOT share their path: the hybrid tracer's bounced segments
+// (mirror, glass and PBR bounces leave a packet's 64 rays with 64 origins and directions).  The packet walk above visits the UNION of the
+// 64 paths one node after the other (thousands of ~0.66 us steps for a wave with a single live ray as for 64 incoherent ones); here a
+// step serves 64 different nodes at once and a round takes as many steps as its longest single path (a few hundred).  Same candidate test,
+// same per-lane buffers ordered by (distance, particle): the result of a round does not depend on the order in which candidates arrive, so
+// it equals the packet walk's bit for bit.  Pruning: the packet walk's own per-lane conditions, against the lane's current bound.
+// Returns false if some lane's stack overflowed (the caller repeats the round with the packet walk; not observed on the bench scenes).
+template <int G>
+__device__ __forceinline__ bool trace_round_lanes(const GrtBvh& bvh, const RayW& r, float tmin, float tmax, bool active, int lane,
+                                                  uint32_t* __restrict__ lstack, int depth, HitBufferT<G>& buf) {
+    buf.clear();
+    if (!__any(active)) return true;
+    constexpr uint32_t kDone = 0xFFFFFFFEu;
+    uint32_t cur = active ? 0u : kDone;   // root
+    int sp = 0;
+    bool overflow = false;
+    const float4* nodes4 = reinterpret_cast<const float4*>(bvh.nodes);
+    while (__any(cur != kDone)) {
+        if (cur != kDone) {
+            const float4 q0 = nodes4[4 * (size_t)cur], q1 = nodes4[4 * (size_t)cur + 1], q2 = nodes4[4 * (size_t)cur + 2], q3 = nodes4[4 * (size_t)cur + 3];
+            const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+            float tn0, tf0, tn1, tf1;
+            bool ok0, ok1;
+            boxes_hit(q0, q1, q2, r, tn0, tf0, tn1, tf1, ok0, ok1);
+            const float bound = fminf(tmax, buf.t[G - 1]);
+            bool h0 = (c0 != kGrtNoChild) && ok0 && (tf0 >= tmin) && (tn0 <= tmax) && (tn0 - q3.z <= bound);
+            bool h1 = (c1 != kGrtNoChild) && ok1 && (tf1 >= tmin) && (tn1 <= tmax) && (tn1 - q3.w <= bound);
+            const bool l0 = h0 && (c0 & kGrtLeafBit), l1 = h1 && (c1 & kGrtLeafBit);
+            if (l0 || l1) {   // at most one pass per leaf child; the two leaves of a node are tested one after the other (the nearer box first)
+                const bool first1 = l1 && (!l0 || tn1 < tn0);
+#pragma unroll 1
+                for (int k = 0; k < 2; ++k) {
+                    const bool take1 = (k == 0) ? first1 : !first1;
+                    const bool doit = take1 ? l1 : l0;
+                    if (doit) {
+                        const uint32_t id = (take1 ? c1 : c0) & ~kGrtLeafBit;
+                        const Cand cd = candidate(bvh.inst + 12 * (size_t)id, r, tmin, buf.t[G - 1], id, buf.id[G - 1]);
+                        const bool reach = cd.ok && (cd.t < tmax) && (cd.tnear <= tmax) && hit_less(cd.t, id, buf.t[G - 1], buf.id[G - 1]);
+                        if (reach && (cd.t > tmin) && (cd.tfar >= tmin)) buf.insert(cd.t, id);
+                    }
+                }
+                h0 = h0 && !l0; h1 = h1 && !l1;
+            }
+            if (h0 && h1) {   // both inner children: the nearer one now, the other parked
+                const bool near0 = tn0 <= tn1;
+                if (sp < depth) lstack[sp * 64 + lane] = near0 ? c1 : c0; else overflow = true;
+                sp += sp < depth ? 1 : 0;
+                cur = near0 ? c0 : c1;
+            } else if (h0 || h1) {
+                cur = h0 ? c0 : c1;
+            } else if (sp > 0) {
+                cur = lstack[--sp * 64 + lane];
+            } else {
+                cur = kDone;
+            }
+        }
+    }
+    return !__any(overflow);
+}
+
 // Tight bounds of the hit distance of one particle for the rays of ONE packet (cone axis `k`, half angle theta).  With x = o + t d - mu
 // the closest-approach point, y = W x and u = W dh (dh the unit direction): y is perpendicular to u (t minimises |W x|) and |y| <= sqrt 3
 // (the ray touches the proxy box), and t |d| = v.dh + x.dh with x.dh = y.(S e), e = R^T dh, u = S^-1 e, (S e).u = 1, hence
@@ -2670,6 +2731,9 @@ __device__ __forceinline__ MeshHit mesh_closest(const GrtMeshView& m, const RayW
 // REFINE (LISTS only): this call is the LAST scan of the packet's list by a set of rays that contains every ray of any later scan —
 // list_round may then keep exact per-entry intervals (see there).  The hybrid tracer scans the list twice in its first iteration
 // (the diffuse rays, then all rays): only the second scan refines.
+#ifndef GRT_LANE_WALK
+#define GRT_LANE_WALK 1   // 0: bounced segments take the packet walk (round 5)
+#endif
 template <int DEG, bool LISTS = false, bool REFINE = false>
 __device__ __forceinline__ void trace_segment(const GrtTraceParams& P, const GrtBvh& bvh, const float4* __restrict__ density12,
                                               const float* __restrict__ sph, const RayW& r, float tmin, float tmax, bool active, int lane,
@@ -2696,7 +2760,16 @@ __device__ __forceinline__ void trace_segment(const GrtTraceParams& P, const Grt
             if (LISTS) list_round<false, kGrtMaxHits, false, REFINE>(*lists, *cone, dmin, dmax, list_end, list_start, r, tLast + eps, t1 + eps, running, lane,
                                                                      reinterpret_cast<float4*>(s_hit_t), buf, tc, nullptr, s_hit_id + kGrtMaxGhosts * 64, &list_span,
                                                                      P.list_mark);
-            else trace_round<false, kGrtMaxHits>(bvh, r, tLast + eps, t1 + eps, running, lane, s_stack, buf, tc);
+            else {
+                // rays with their own origins (bounced segments): one walk per lane, its stack in the LDS words of the round's hit arrays - which
+                // hold nothing while the round is gathered (32 levels per lane; deeper: the round is repeated by the packet walk)
+                static_assert(sizeof(float) == 4 && kGrtMaxHits * 64 * 2 >= 32 * 64, "the per-lane stacks live in s_hit_t + s_hit_id");
+                bool done = false;
+                if (GRT_LANE_WALK)   // (s_hit_id = s_hit_t + 16 x 64 words: the caller's ONE array, grt_hybrid_kernel)
+                    done = trace_round_lanes<kGrtMaxHits>(bvh, r, tLast + eps, t1 + eps, running, lane, reinterpret_cast<uint32_t*>(s_hit_t), 32, buf);
+                if (!done) trace_round<false, kGrtMaxHits>(bvh, r, tLast + eps, t1 + eps, running, lane, s_stack, buf, tc);
+                __syncthreads();   // single-wave workgroup: the stacks' last reads before the hit arrays are written
+            }
             buf.store(s_hit_t, s_hit_id, lane);
         }
         if (s_hit_id[lane] == 0xFFFFFFFFu) running = false;
@@ -2958,8 +3031,9 @@ void grt_hybrid_kernel(GrtTraceParams P, GrtBvh bvh, GrtMeshView mesh, GrtHybrid
                                                         float* __restrict__ out_alpha, float* __restrict__ out_last_ray,
                                                         uint32_t* __restrict__ out_bounces, GrtLists lists) {
     __shared__ uint32_t s_stack[kGrtStackDepth];
-    __shared__ float s_hit_t[kGrtMaxHits * 64];
-    __shared__ uint32_t s_hit_id[kGrtMaxHits * 64];
+    __shared__ float s_hits[2 * kGrtMaxHits * 64];   // one array: the per-lane walk's stacks span both halves (trace_segment)
+    float* s_hit_t = s_hits;
+    uint32_t* s_hit_id = reinterpret_cast<uint32_t*>(s_hits + kGrtMaxHits * 64);
     if (!GEN) { P.prim = GRUT_PRIM_INSTANCES; P.sph_half = 0; }
     const int lane = threadIdx.x;
     const PixelBlock pb = pixel_block(P.W, P.H);
