@@ -2732,7 +2732,9 @@ __device__ __forceinline__ MeshHit mesh_closest(const GrtMeshView& m, const RayW
 // list_round may then keep exact per-entry intervals (see there).  The hybrid tracer scans the list twice in its first iteration
 // (the diffuse rays, then all rays): only the second scan refines.
 #ifndef GRT_LANE_WALK
-#define GRT_LANE_WALK 1   // 0: bounced segments take the packet walk (round 5)
+#define GRT_LANE_WALK 0   // 1: bounced segments walk the tree per lane (trace_round_lanes).  Built and measured in round 6: bit-identical, SLOWER - config 5
+                          // 98.7 vs 81 ms: the sparse scene's rays never fill their buffers, so a single ray's path through 2 M particles is thousands of
+                          // nodes long, and a per-lane step is four divergent 16-byte gathers at two waves per SIMD instead of one scalar fetch
 #endif
 template <int DEG, bool LISTS = false, bool REFINE = false>
 __device__ __forceinline__ void trace_segment(const GrtTraceParams& P, const GrtBvh& bvh, const float4* __restrict__ density12,
