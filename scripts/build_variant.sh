@@ -4,7 +4,7 @@
 set -e
 cd "$(dirname "$0")/../3dgrut_amd/csrc"
 name=$1; src=$2; shift 2; out=${OUTNAME:-${src%.hip}}
-mkdir -p ../../variants
+mkdir -p ../../variants   # (scratch: variants/ is not tracked and is emptied after every experiment)
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp-contract=fast -fno-slp-vectorize"
 [ "$src" = "grt_kernels.hip" ] && FLAGS="$FLAGS -ffp-contract=on"
 /opt/rocm/bin/hipcc -x hip $FLAGS "$@" -c "$src" -o "../../variants/${name}_${src%.hip}.o"
