@@ -237,6 +237,35 @@ def test_grt_forward_orders_hits_and_matches_brute_force_compositing():
     assert np.all(out["density"] >= 0) and np.all(out["density"] <= 1) and np.all(out["hit_distance"][..., 0] >= 0)
 
 
+@pytest.mark.parametrize("prim", [0, 6])
+def test_grt_sequence_compositor_reproduces_the_forward_and_moves_with_the_order(prim):
+    """oracle.grt_composite_sequence (round 6; the GPU tests use it to identify order ties against the reference programs' goldens): a ray's
+    processed-particle sequence composited hit by hit by the checker's processHit gives the checker's own forward outputs - radiance, opacity,
+    integrated distance, accepted-hit count - for the volumetric particles and for the surfels; and the same hits in another order give another
+    colour (what a tie against the reference does) at the same opacity."""
+    scene, T = _grt_scene(n=600)
+    cfg = oracle.default_grt_config(primitive_type=prim)
+    out = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, T, *scene["rays"], dbg_cap=256)
+    M = np.asarray(T, np.float32)[:3, :4]
+    ro, rd = (a.reshape(-1, 3) for a in scene["rays"])
+    checked = moved = 0
+    for r in np.argsort(-out["hit_num"])[:12]:
+        n = int(out["hit_num"][r])
+        if n < 2:
+            continue
+        seq = out["hit_ids"][r, :n]
+        o_w, d_w = (M[:, :3] @ ro[r] + M[:, 3]).astype(np.float32), (M[:, :3] @ rd[r]).astype(np.float32)
+        rgb, opa, dist, acc = oracle.grt_composite_sequence(cfg, 1e-3, o_w, d_w, scene["density12"], scene["sph"], 3, seq)
+        assert np.abs(rgb - out["features"].reshape(-1, 3)[r]).max() < 2e-6 and abs(opa - out["density"].reshape(-1)[r]) < 2e-6
+        assert abs(dist - out["hit_distance"].reshape(-1, 2)[r, 0]) < 1e-5 and acc == int(out["hit_count"].reshape(-1)[r])
+        checked += 1
+        rgb2, opa2, _, _ = oracle.grt_composite_sequence(cfg, 1e-3, o_w, d_w, scene["density12"], scene["sph"], 3, seq[::-1])
+        moved += int(np.abs(rgb2 - rgb).max() > 1e-5)
+        if opa < 0.99:   # nothing terminates either way: the product of the transmittances does not depend on the order
+            assert abs(opa2 - opa) < 1e-5
+    assert checked >= 6 and moved >= 3
+
+
 def test_grt_backward_is_the_gradient_of_forward_away_from_the_last_hit():
     """Finite differences of the f64 oracle forward reproduce its analytic backward, except for the reference's own quirk
     that the backward replay excludes the hit AT the saved last-hit distance (endT = tLast + 1e-9, strict compare,
