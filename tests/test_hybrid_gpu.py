@@ -171,5 +171,6 @@ def test_config5_size_frame_matches_oracle_on_a_ray_sample():
     b = sub["mirror_bounces"][..., 0]
     flips = (b != ora["bounces"].astype(np.int32)) | (e > 1e-4) | (el > 1e-4)
     print(f"config 5: {int(flips.sum())} of {flips.size} sampled rays differ; median err {np.median(e):.1e}; rays with a mirror bounce {float((b > 0).mean()):.3f}")
-    assert sel.size >= 2000 and flips.mean() <= 1e-2, (int(flips.sum()), float(e.max()))
+    # (round 6: NO ray of the sample may differ - 0 of 2 080 measured; the allowance of 1 % that stood here until round 5 had nothing to allow)
+    assert sel.size >= 2000 and int(flips.sum()) == 0, (int(flips.sum()), float(e.max()))
     assert (b > 0).any() and float(sub["pred_opacity"].mean()) > 0.05
