@@ -580,7 +580,19 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
         // intersection program runs for rays that overlap the particle's WORLD box, reports the point of maximum response - the same point
         // as the instances' (the proxy frame differs from the program's scale frame by the scalar kernelScale, which cancels in the
         // distance) - and accepts it within 3 sigma of the SCALE frame: |pd x po|^2 ks^2 < 9 |pd|^2 in proxy-frame quantities.
-        const float* bx = r.box8 + 8 * (size_t)id;
+        // (REL - the packet lists' test: `id` is wave-uniform and the boxes are read-only during a trace, so the record comes through the
+        // scalar cache into SGPRs, requested before the arithmetic above needs it; seven vector loads of one address and their wait
+        // per test otherwise)
+        float bx[8];
+        if (REL) {
+            const cfloat4* bq = reinterpret_cast<const cfloat4*>(reinterpret_cast<uintptr_t>(r.box8 + 8 * (size_t)__builtin_amdgcn_readfirstlane((int)id)));
+            const float4 b0 = ld4(bq, 0), b1 = ld4(bq, 1);
+            bx[0] = b0.x; bx[1] = b0.y; bx[2] = b0.z; bx[3] = b0.w; bx[4] = b1.x; bx[5] = b1.y; bx[6] = b1.z; bx[7] = b1.w;
+        } else {
+            const float4* bq = reinterpret_cast<const float4*>(r.box8 + 8 * (size_t)id);
+            const float4 b0 = bq[0], b1 = bq[1];
+            bx[0] = b0.x; bx[1] = b0.y; bx[2] = b0.z; bx[3] = b0.w; bx[4] = b1.x; bx[5] = b1.y; bx[6] = b1.z; bx[7] = b1.w;
+        }
         const float ax0 = (bx[0] - r.o.x) * r.inv.x, ax1 = (bx[3] - r.o.x) * r.inv.x, ay0 = (bx[1] - r.o.y) * r.inv.y, ay1 = (bx[4] - r.o.y) * r.inv.y;
         const float az0 = (bx[2] - r.o.z) * r.inv.z, az1 = (bx[5] - r.o.z) * r.inv.z;
         const float tnear = max3f(fminf(ax0, ax1), fminf(ay0, ay1), fminf(az0, az1));
