@@ -111,7 +111,7 @@ class GrutAdamGroup(C.Structure):
 
 VIS_NONE, VIS_BOOL_U8, VIS_INT32, VIS_FLOAT_BITS = range(4)
 # GrtConfig::primitive_type (render.primitive_type, optixTracer.cpp:176-201)
-GRT_PRIMITIVES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4, "custom": 5, "trisurfel": 6, "trihexa": 7}
+GRT_PRIMITIVES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4, "custom": 5, "trisurfel": 6, "trihexa": 7, "sphere": 8}
 
 
 class GrtTexture(C.Structure):

@@ -16,7 +16,7 @@ struct GrtHandle {
     hipStream_t build_stream = nullptr;
     DeviceBuffer refit_todo;   // the nodes the level-synchronous refit launches leave to grt_refit_finish_kernel
     DeviceBuffer box8;   // GRUT_PRIM_CUSTOM: the particles' exact world boxes + kernelScale^2 (grt_proxy_kernel)
-    uint32_t NP = 0;     // proxies of the last build (= N; 3 N for GRUT_PRIM_TRIHEXA)
+    uint32_t NP = 0;     // proxies of the last build (= N; 3 N for GRUT_PRIM_TRIHEXA, 2 N for GRUT_PRIM_SPHERE)
     DeviceBuffer inst, aabb, slack, scene_enc, scene, codes, ids, codes_tmp, ids_tmp, sort_scratch, nodes,
         counters, dbg_ids, dbg_count;
     uint32_t* sorted_ids = nullptr;
@@ -81,8 +81,8 @@ struct GrtHandle {
 
 static int grt_validate(const GrtConfig& c) {
     GRUT_REQUIRE(c.particle_radiance_sph_degree >= 0 && c.particle_radiance_sph_degree <= 3, "sph degree must be in [0,3]");
-    if (c.primitive_type < GRUT_PRIM_INSTANCES || c.primitive_type > GRUT_PRIM_TRIHEXA) {
-        set_last_error("primitive_type %d: instances (0), icosahedron (1), octahedron (2), tetrahedron (3), diamond (4), custom (5), trisurfel (6), trihexa (7) are provided", c.primitive_type);
+    if (c.primitive_type < GRUT_PRIM_INSTANCES || c.primitive_type > GRUT_PRIM_SPHERE) {
+        set_last_error("primitive_type %d: instances (0), icosahedron (1), octahedron (2), tetrahedron (3), diamond (4), custom (5), trisurfel (6), trihexa (7), sphere (8) are provided", c.primitive_type);
         return GRUT_ERR_UNSUPPORTED;
     }
     const int d = c.particle_kernel_degree;
@@ -247,7 +247,8 @@ int grt_build_bvh(GrtHandle* h, void* stream_, uint32_t N, const float* position
     }
     GRUT_REQUIRE(positions && rotations && scales && densities, "grt_build_bvh: null buffer");
     // proxies: one per particle, three (one per rhombus) for GRUT_PRIM_TRIHEXA - the tree, the hit buffers and the log are keyed by PROXY
-    const uint32_t per = h->cfg.primitive_type == GRUT_PRIM_TRIHEXA ? 3u : 1u;
+    // (GRUT_PRIM_SPHERE: two - the ray's entry into the enclosing sphere and its exit, both offered by OptiX's built-in intersector)
+    const uint32_t per = h->cfg.primitive_type == GRUT_PRIM_TRIHEXA ? 3u : (h->cfg.primitive_type == GRUT_PRIM_SPHERE ? 2u : 1u);
     GRUT_REQUIRE((uint64_t)N * per <= 0x1FFFFFFEu, "grt_build_bvh: %u particles (the hit buffers keep 29 bits of proxy index)", N);
     if (!rebuild && (!h->built || h->N != N)) rebuild = 1;  // "cannot refit GAS with a different number of gaussian" (optixTracer.cpp:629-632)
     GRUT_CHECK(h->wait_tree(s));   // the previous build's tree stages read what this build is about to overwrite (and its scratch may move)
@@ -791,7 +792,7 @@ int grt_stats(GrtHandle* h, GrtStats* stats) {
 // copies the proxy instance records (inverse maps {W rows, mu}, [N,12]) of the last build to a caller DEVICE buffer
 int grt_debug_fetch_instances(GrtHandle* h, void* stream_, float* instances) {
     GRUT_REQUIRE(h && h->built && instances, "grt_debug_fetch_instances: no BVH / null buffer");
-    // (GRUT_PRIM_TRIHEXA keeps three identical records per particle, one per rhombus: the caller gets one)
+    // (GRUT_PRIM_TRIHEXA keeps three identical records per particle, one per rhombus, GRUT_PRIM_SPHERE two, one per root: the caller gets one)
     const size_t per = h->N ? h->NP / h->N : 1;
     if (h->N) GRUT_HIP(hipMemcpy2DAsync(instances, 48, h->inst.ptr, 48 * per, 48, h->N, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream_)));
     return GRUT_OK;

@@ -75,30 +75,44 @@ __global__ __launch_bounds__(256) void grt_proxy_kernel(GrtBuildParams P, const 
     if (i < P.N) {
         // GRUT_PRIM_TRIHEXA: proxy 3 p + j is the rhombus of particle p in the proxy frame's plane j (x = 0, y = 0, z = 0); its record is
         // the particle's (the candidate test reads the plane from the proxy index)
-        const bool hexa = P.prim == GRUT_PRIM_TRIHEXA;
-        const size_t pi = hexa ? i / 3u : i;
+        // GRUT_PRIM_SPHERE: proxies 2 p and 2 p + 1 are the entry and the exit root of particle p's enclosing sphere (one record for both)
+        const bool hexa = P.prim == GRUT_PRIM_TRIHEXA, ball = P.prim == GRUT_PRIM_SPHERE;
+        const size_t pi = hexa ? i / 3u : (ball ? i / 2u : i);
         const int plane = hexa ? (int)(i - 3u * (uint32_t)pi) : -1;
         const m3 rt = quat_wxyz_to_rotT(rot[4 * pi], rot[4 * pi + 1], rot[4 * pi + 2], rot[4 * pi + 3]);
         const float ks = kernel_scale(dns[pi], P.min_response, P.clamping, (float)P.degree);
-        const float k0 = ks * scl[3 * pi], k1 = ks * scl[3 * pi + 1], k2 = ks * scl[3 * pi + 2];
+        float k0 = ks * scl[3 * pi], k1 = ks * scl[3 * pi + 1], k2 = ks * scl[3 * pi + 2];
         const float cx = pos[3 * pi], cy = pos[3 * pi + 1], cz = pos[3 * pi + 2];
         float* o = inst + 12 * (size_t)i;
+        if (ball) {
+            // computeGaussianEnclosingSphereKernel (particlePrimitives.cu:386-403): radius = max(scale) * kernelScale; the record is the map
+            // into the frame scaled by it, W = diag(1 / r) (orc_grt_proxies writes the same quotients)
+            const float rad = fmaxf(scl[3 * pi], fmaxf(scl[3 * pi + 1], scl[3 * pi + 2])) * ks;
+            k0 = k1 = k2 = rad;
+            const float ir = 1.f / rad;
+            o[0] = ir; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; o[4] = ir; o[5] = 0.f; o[6] = 0.f; o[7] = 0.f; o[8] = ir;
+            o[9] = cx; o[10] = cy; o[11] = cz;
+        } else {
         o[0] = rt.r0.x / k0; o[1] = rt.r0.y / k0; o[2] = rt.r0.z / k0;
         o[3] = rt.r1.x / k1; o[4] = rt.r1.y / k1; o[5] = rt.r1.z / k1;
         o[6] = rt.r2.x / k2; o[7] = rt.r2.y / k2; o[8] = rt.r2.z / k2;
         o[9] = cx; o[10] = cy; o[11] = cz;
+        }
         // world half extents of the oriented box, padded by a hair so that rounding can never make the ray miss the
         // AABB of a box it touches (culling must stay conservative; candidates are decided in the proxy's own frame)
         // (triangle-mesh proxies: the polyhedron's vertices reach ext_k along axis k of the proxy's frame instead of 1)
         float e0, e1, e2;
         if (hexa) {   // a rhombus (+-sqrt 2 along the two axes of its plane, flat along the third)
             e0 = plane == 0 ? 0.f : 1.4142135381698608f * k0; e1 = plane == 1 ? 0.f : 1.4142135381698608f * k1; e2 = plane == 2 ? 0.f : 1.4142135381698608f * k2;
+        } else if (ball) {
+            e0 = e1 = e2 = k0;
         } else {
             e0 = k0 * kGrtPolyhedra[P.prim].ext[0]; e1 = k1 * kGrtPolyhedra[P.prim].ext[1]; e2 = k2 * kGrtPolyhedra[P.prim].ext[2];
         }
         float hx = fabsf(rt.r0.x) * e0 + fabsf(rt.r1.x) * e1 + fabsf(rt.r2.x) * e2;
         float hy = fabsf(rt.r0.y) * e0 + fabsf(rt.r1.y) * e1 + fabsf(rt.r2.y) * e2;
         float hz = fabsf(rt.r0.z) * e0 + fabsf(rt.r1.z) * e1 + fabsf(rt.r2.z) * e2;
+        if (ball) { hx = k0; hy = k0; hz = k0; }   // (the sphere's own box)
         if (P.prim == GRUT_PRIM_CUSTOM) {
             // computeGaussianEnclosingAABBKernel (particlePrimitives.cu:498-541): min / max over the 8 corners R (c * kscl) + mu, c = +-1 - the
             // extreme corner of an axis has all three products of one sign, so the bound is mu -+ ((|R_c0| k0 + |R_c1| k1) + |R_c2| k2) in the
@@ -553,6 +567,23 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
         c.ok = c.box && want;
         return c;
     }
+    if (r.prim == GRUT_PRIM_SPHERE) {
+        // sphere (optixTracer.cpp:765-781, 823-833): proxy `id` is the entry (even) or the exit (odd) of the ray through the unit sphere of the
+        // frame scaled by the particle's radius - the two offers OptiX's built-in sphere intersector makes to an any-hit program that ignores
+        // them (include/grut_amd.h).  Same operations, same order as the CPU checker's sphere_candidates and the emulated OptiX.
+        const float qa = fmaf(pdz, pdz, fmaf(pdy, pdy, pdx * pdx)), qb = fmaf(poz, pdz, fmaf(poy, pdy, pox * pdx));
+        const float qc = fmaf(poz, poz, fmaf(poy, poy, pox * pox)) - 1.f;
+        const float disc = fmaf(qb, qb, -(qa * qc));
+        if (!(disc >= 0.f) || !(qa > 0.f)) { c.why = 2; return c; }
+        const float sq = sqrtf(disc);
+        const float t = (id & 1u) ? (-qb + sq) / qa : (-qb - sq) / qa;
+        c.t = t; c.tnear = t; c.tfar = 3.0e38f;
+        c.box = true;
+        const bool want = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
+        c.why = 1;
+        c.ok = want;
+        return c;
+    }
     if (r.prim == GRUT_PRIM_TRISURFEL) {
         // trisurfel (particlePrimitives.cu:155-205): two triangles = the rhombus |x| + |y| <= sqrt 2 of the proxy's z = 0 plane, traced WITHOUT
         // face culling (referenceOptix.cu:62: SurfelPrimitive -> OPTIX_RAY_FLAG_NONE): the reported distance is the plane crossing's.  Same
@@ -990,6 +1021,8 @@ __device__ __forceinline__ void proxy_extents(int prim, uint32_t id, float (&ext
     if (prim == GRUT_PRIM_TRIHEXA) {
         const uint32_t plane = id % 3u;
         ext[0] = plane == 0u ? 0.f : 1.4142135381698608f; ext[1] = plane == 1u ? 0.f : 1.4142135381698608f; ext[2] = plane == 2u ? 0.f : 1.4142135381698608f;
+    } else if (prim == GRUT_PRIM_SPHERE) {
+        ext[0] = ext[1] = ext[2] = 1.f;   // (the unit sphere of the frame scaled by the radius)
     } else {
         ext[0] = kGrtPolyhedra[prim].ext[0]; ext[1] = kGrtPolyhedra[prim].ext[1]; ext[2] = kGrtPolyhedra[prim].ext[2];
     }
@@ -1361,7 +1394,9 @@ __device__ __forceinline__ f3 sh_radiance(const GrtTraceParams& P, const float* 
 }
 
 // the particle behind a proxy index (hit buffers, the log and the tree are keyed by proxy; GRUT_PRIM_TRIHEXA has three proxies per particle)
-__device__ __forceinline__ uint32_t particle_of(const GrtTraceParams& P, uint32_t proxy) { return P.prim == GRUT_PRIM_TRIHEXA ? proxy / 3u : proxy; }
+__device__ __forceinline__ uint32_t particle_of(const GrtTraceParams& P, uint32_t proxy) {
+    return P.prim == GRUT_PRIM_TRIHEXA ? proxy / 3u : (P.prim == GRUT_PRIM_SPHERE ? proxy >> 1 : proxy);   // (GRUT_PRIM_SPHERE: the two roots)
+}
 
 struct HitGeom {
     f3 gposc, gposcr, gro, rdr, grdu, grd, gcrod, giscl;

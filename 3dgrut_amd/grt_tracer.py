@@ -47,8 +47,7 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
                                   f"(only {tuple(p + 'Bwd' for p in allowed)})")
     prim = _conf_get(render, "primitive_type", "instances")
     if prim not in _abi.GRT_PRIMITIVES:
-        raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (provided: {tuple(_abi.GRT_PRIMITIVES)}; "
-                                  "the sphere proxies are not)")
+        raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (provided: {tuple(_abi.GRT_PRIMITIVES)})")
     if nht and prim not in ("instances", "icosahedron", "octahedron", "tetrahedron", "diamond"):
         # (the feature path walks the trace kernel's hit log and evaluates the features at each hit's canonical intersection: it does not care
         # which candidate test ordered the log - instances and the closed mesh proxies; the surfel / world-box per-hit variants are not built)

@@ -44,7 +44,8 @@ WORKLOADS = {
     # render.primitive_type = custom (world boxes: tree walk every round) / trisurfel (flat proxies, on the packet lists)
     "c3_grt_custom_1m_800": (1_000_000, 800, 800, 0.01),
     "c3_grt_trisurfel_1m_800": (1_000_000, 800, 800, 0.01),
-    "c3_grt_trihexa_1m_800": (1_000_000, 800, 800, 0.01),    # three rhombi per particle, each a proxy of its own: tree walk
+    "c3_grt_trihexa_1m_800": (1_000_000, 800, 800, 0.01),    # three rhombi per particle, each a proxy of its own
+    "c3_grt_sphere_1m_800": (1_000_000, 800, 800, 0.01),     # OptiX's built-in spheres: entry and exit of every enclosing sphere, each a proxy of its own
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
 
@@ -206,7 +207,7 @@ def bench_grt(args, world, rank, dev, dist, n, W, H, ms, name=None, emit=True):
                              "model": {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1},
                                                                                "interpolation_type": "barycentric"}}})
     else:
-        prim = next((v for k, v in (("icosa", "icosahedron"), ("custom", "custom"), ("trisurfel", "trisurfel"), ("trihexa", "trihexa")) if k in name), "instances")
+        prim = next((v for k, v in (("icosa", "icosahedron"), ("custom", "custom"), ("trisurfel", "trisurfel"), ("trihexa", "trihexa"), ("sphere", "sphere")) if k in name), "instances")
         tracer = grt.Tracer({"render": {"enable_kernel_timings": True, "primitive_type": prim}})
     g = syn.SimpleGaussians(d12, sph, device=dev)
     g_fd_np, _ = syn.upstream_grads(W, H)

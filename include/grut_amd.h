@@ -327,7 +327,7 @@ typedef struct GrtConfig {
      * triangles with back faces culled, referenceOptix.cu:62), rays that start inside are not offered it.  GRUT_PRIM_CUSTOM: custom primitives over
      * the particles' WORLD boxes (computeGaussianEnclosingAABBKernel) with the world-space intersection program intersectCustomParticle
      * (gaussianParticles.cuh:407-441): the instances' hit point, offered to the rays that cross the world box, accepted within 3 sigma.
-     * The open meshes GRUT_PRIM_TRISURFEL / GRUT_PRIM_TRIHEXA: below.  `sphere` (OptiX's built-in sphere intersector) is GRUT_ERR_UNSUPPORTED. */
+     * The open meshes GRUT_PRIM_TRISURFEL / GRUT_PRIM_TRIHEXA and the enclosing spheres GRUT_PRIM_SPHERE: below. */
     int32_t primitive_type;
 } GrtConfig;
 enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON = 2, GRUT_PRIM_TETRAHEDRON = 3, GRUT_PRIM_DIAMOND = 4, GRUT_PRIM_CUSTOM = 5,
@@ -338,8 +338,16 @@ enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON 
        /* trihexa (particlePrimitives.cu:107-153): three rhombi in the proxy's coordinate planes, six triangles, back faces culled - the windings
         * make the x = 0 / y = 0 rhombi face +x / +y and the two halves of the z = 0 rhombus face opposite ways, so a ray is offered the SAME
         * particle up to three times at three distances and the programs process every offer as a hit of the particle.  Here every rhombus is a
-        * proxy of its own (3 N leaves, proxy 3 i + j = plane j of particle i).  Tree walk. */
-       GRUT_PRIM_TRIHEXA = 7 };
+        * proxy of its own (3 N leaves, proxy 3 i + j = plane j of particle i). */
+       GRUT_PRIM_TRIHEXA = 7,
+       /* sphere (optixTracer.cpp:189-190, 765-781, 823-833; computeGaussianEnclosingSphereKernel, particlePrimitives.cu:386-403): one OptiX
+        * built-in sphere per particle, centre mu, radius max(scale) * kernelScale.  The built-in intersector offers the any-hit program the
+        * ray's ENTRY into the sphere and - the program ignores every offer but the one that fills its payload - its EXIT as well: the particle is
+        * a candidate at both roots and is processed twice when both fall into the ray's rounds (the volumetric processHit either time).  Here
+        * every root is a proxy of its own (2 N leaves, proxy 2 i = entry, 2 i + 1 = exit of particle i).  NVIDIA does not publish the
+        * intersector's arithmetic: the roots are those of |po + t pd|^2 = 1 in the frame scaled by the radius, operation by operation as
+        * oracle/grt_oracle.c and the emulated OptiX of oracle/ref/ref_grt_emul.inl evaluate them. */
+       GRUT_PRIM_SPHERE = 8 };
 
 typedef struct GrtFrame {
     uint32_t frame_id;

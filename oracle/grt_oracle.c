@@ -67,6 +67,19 @@ int orc_grt_proxies(const GrtConfig* cfg, uint32_t N, const real* positions, con
             o[3 * r] = rotT.r[r].x / kscl[r]; o[3 * r + 1] = rotT.r[r].y / kscl[r]; o[3 * r + 2] = rotT.r[r].z / kscl[r];
         }
         o[9] = positions[3 * i]; o[10] = positions[3 * i + 1]; o[11] = positions[3 * i + 2];
+        if (cfg->primitive_type == 8) {
+            /* render.primitive_type sphere - computeGaussianEnclosingSphereKernel, particlePrimitives.cu:386-403: centre mu, radius
+             * max(scale) * kernelScale.  The record maps into the frame scaled by the radius, W = diag(1 / r); the world box is the sphere's. */
+            const real rad = r_max(scales[3 * i], r_max(scales[3 * i + 1], scales[3 * i + 2])) * ks;
+            const real ir = 1 / rad;
+            for (int k = 0; k < 9; ++k) o[k] = 0;
+            o[0] = ir; o[4] = ir; o[8] = ir;
+            real* b = aabb6 + 6 * (size_t)i;
+            for (int k = 0; k < 3; ++k) { b[k] = o[9 + k] - rad; b[3 + k] = o[9 + k] + rad; }
+            slack[i] = R_(1.41421356237) * rad;
+            for (int k = 0; k < 3; ++k) { scene6[k] = r_min(scene6[k], b[k]); scene6[3 + k] = r_max(scene6[3 + k], b[3 + k]); }
+            continue;
+        }
         /* world half extent_c = sum_r |R_cr| kscl_r with R_cr = rotT.r[r].c */
         const orc_polyhedron* ph = &orc_polyhedra[cfg->primitive_type];   /* (instances: ext = 1) */
         const real ex[3] = {kscl[0] * (real)ph->ext[0], kscl[1] * (real)ph->ext[1], kscl[2] * (real)ph->ext[2]};
@@ -473,8 +486,44 @@ static uint32_t trihexa_candidates(const real* inst, v3 o, v3 d, uint32_t id, gr
     }
     return n;
 }
+/* sphere (optixTracer.cpp:189-190, 765-781, 823-833; checker for GRUT_PRIM_SPHERE): OptiX's built-in sphere intersector offers the any-hit
+ * program the ray's ENTRY into the particle's enclosing sphere and, that offer being ignored (__anyhit__ah keeps only the one that fills its
+ * payload), its EXIT: two offers per particle, at the two roots of |po + t pd|^2 = 1 in the frame scaled by the radius.  NVIDIA does not
+ * publish the intersector's arithmetic; this sequence - the emulated OptiX's (oracle/ref/ref_grt_emul.inl) and candidate_abe's
+ * (grt_kernels.hip), operation by operation - is the definition here. */
+static uint32_t sphere_candidates(const real* inst, v3 o, v3 d, uint32_t id, grt_hit* out) {
+    const v3 dl = v3_make(o.x - inst[9], o.y - inst[10], o.z - inst[11]);
+    const v3 po = v3_make(inst[0] * dl.x + inst[1] * dl.y + inst[2] * dl.z, inst[3] * dl.x + inst[4] * dl.y + inst[5] * dl.z,
+                          inst[6] * dl.x + inst[7] * dl.y + inst[8] * dl.z);
+    const v3 pd = v3_make(r_fma(inst[2], d.z, r_fma(inst[1], d.y, inst[0] * d.x)), r_fma(inst[5], d.z, r_fma(inst[4], d.y, inst[3] * d.x)),
+                          r_fma(inst[8], d.z, r_fma(inst[7], d.y, inst[6] * d.x)));
+    const real qa = r_fma(pd.z, pd.z, r_fma(pd.y, pd.y, pd.x * pd.x)), qb = r_fma(po.z, pd.z, r_fma(po.y, pd.y, po.x * pd.x));
+    const real qc = r_fma(po.z, po.z, r_fma(po.y, po.y, po.x * po.x)) - 1;
+    const real disc = r_fma(qb, qb, -(qa * qc));
+    if (!(disc >= 0) || !(qa > 0)) return 0;
+    const real sq = r_sqrt(disc);
+    out[0].t = (-qb - sq) / qa; out[0].id = id; out[0].tnear = out[0].t; out[0].tfar = R_(3.0e38);
+    out[1].t = (-qb + sq) / qa; out[1].id = id; out[1].tnear = out[1].t; out[1].tfar = R_(3.0e38);
+    return 2;
+}
 static uint32_t ray_candidates(uint32_t N, const real* inst12, v3 o, v3 d, grt_hit* out, uint32_t ray) {
     uint32_t n = 0;
+    if (g_prim == 8) {   /* (two offers per particle) */
+        if (g_pre_ranges && ray != 0xFFFFFFFFu) {   /* the GPU's lists hold PROXIES 2 i (entry) and 2 i + 1 (exit), binned by one box: the even one names the particle */
+            const uint32_t p = g_pre_ray_packet[ray];
+            for (uint32_t e = g_pre_ranges[2 * p]; e < g_pre_ranges[2 * p + 1]; ++e) {
+                uint32_t i = g_pre_entries[e];
+                if (i == 0xFFFFFFFFu) continue;
+                i &= 0x7FFFFFFFu;
+                if ((i & 1u) || (i >> 1) >= N) continue;
+                n += sphere_candidates(inst12 + 12 * (size_t)(i >> 1), o, d, i >> 1, out + n);
+            }
+        } else {
+            for (uint32_t i = 0; i < N; ++i) n += sphere_candidates(inst12 + 12 * (size_t)i, o, d, i, out + n);
+        }
+        qsort(out, n, sizeof(grt_hit), hit_cmp);
+        return n;
+    }
     if (g_prim == 7) {   /* (up to three offers per particle: the callers' buffers hold 3 N + 3 entries) */
         for (uint32_t i = 0; i < N; ++i) n += trihexa_candidates(inst12 + 12 * (size_t)i, o, d, i, out + n);
         qsort(out, n, sizeof(grt_hit), hit_cmp);

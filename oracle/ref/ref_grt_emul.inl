@@ -29,6 +29,10 @@ struct Scene {
     // custom primitives (render.primitive_type custom: one custom-primitive GAS over the particles' world boxes, optixTracer.cpp:638-655, 810-817)
     uint32_t num_boxes = 0;
     const float* boxes = nullptr;      // [n,6] min xyz, max xyz, as computeGaussianEnclosingAABBKernel wrote them
+    // sphere proxies (render.primitive_type sphere: one built-in sphere GAS over the particles' enclosing spheres, optixTracer.cpp:765-781, 823-833)
+    uint32_t num_spheres = 0;
+    const float* centers = nullptr;    // [n,3] / [n]: as computeGaussianEnclosingSphereKernel wrote them (particlePrimitives.cu:386-403)
+    const float* radii = nullptr;
     // Optional per-ray candidate subsets (ref_grt_set_ray_candidates): ray r is offered only the particles cand[cand_begin[r] .. cand_begin[r+1])
     // (ascending, so the index order of the full loops is kept).  The caller guarantees a CONSERVATIVE superset - every particle whose proxy
     // the ray's line can touch at all (tests/golden/make_fullsize_golden.py: bounding spheres in float64 with a margin) - so the programs
@@ -94,6 +98,36 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
         if (!(t > g_optix.tmin && t < g_optix.tmax)) continue;
         g_optix.primitive = f;
         optixReportIntersection(t, 0);
+    }
+    return;
+#endif
+#ifdef SHIM_OPTIX_SPHERE_PROXIES
+    // Built-in spheres (OPTIX_PRIMITIVE_TYPE_SPHERE, the built-in intersection module of optixTracer.cpp:405-408, 452-454 - no program of the
+    // reference's runs here): the intersector offers the any-hit program the ray's ENTRY into the sphere and, when that offer does not end
+    // the ray (the program ignored it, or it lies outside the ray's interval), its EXIT - the second root.  (Back-face culling is a
+    // triangle flag: it does not apply.)  __anyhit__ah ignores every offer but the one that fills the payload's last slot, so a ray is
+    // offered the SAME particle twice - at both roots - and processes it twice when both fall into its rounds, like the trihexa's repeats.
+    // NVIDIA does not publish the intersector's arithmetic; the emulation fixes it: roots of |po + t pd|^2 = 1 in the frame scaled by the
+    // radius, po = (o - c) / r, pd = d / r, separately rounded fp32 operations, t = (-b -+ sqrt(b^2 - a (|po|^2 - 1))) / a; the interval
+    // is open like the triangles' (a hit AT tmin reported again would never let the round loop advance).
+    for (uint32_t k = 0, nk = cand_count(g_scene.num_spheres); k < nk; ++k) {
+        const uint32_t i = cand_at(k);
+        const float ir = 1.f / g_scene.radii[i];
+        const float* c = g_scene.centers + 3 * (size_t)i;
+        const float pox = (o.x - c[0]) * ir, poy = (o.y - c[1]) * ir, poz = (o.z - c[2]) * ir;
+        const float pdx = d.x * ir, pdy = d.y * ir, pdz = d.z * ir;
+        const float a = fmaf(pdz, pdz, fmaf(pdy, pdy, pdx * pdx)), b = fmaf(poz, pdz, fmaf(poy, pdy, pox * pdx));
+        const float cc = fmaf(poz, poz, fmaf(poy, poy, pox * pox)) - 1.f;
+        const float disc = fmaf(b, b, -(a * cc));
+        if (!(disc >= 0.f) || !(a > 0.f)) continue;
+        const float sq = sqrtf(disc);
+        const float roots[2] = {(-b - sq) / a, (-b + sq) / a};
+        for (int q = 0; q < 2; ++q) {
+            const float t = roots[q];
+            if (!(t > g_optix.tmin && t < g_optix.tmax)) continue;
+            g_optix.primitive = i;
+            if (optixReportIntersection(t, 0)) break;   // accepted: the ray ends at the entry, its exit lies beyond
+        }
     }
     return;
 #endif
@@ -189,6 +223,10 @@ static void set_scene_triangles(uint32_t num_triangles, uint32_t triangles_per_p
 }
 
 static void set_scene_boxes(uint32_t n, const float* boxes) { g_scene.num_boxes = n; g_scene.boxes = boxes; }
+static void set_scene_spheres(uint32_t n, const float* centers, const float* radii) {
+    g_scene.num_spheres = n; g_scene.centers = centers; g_scene.radii = radii;
+    params.gPrimNumTri = 1;   // "number of primitives per gaussian" (optixTracer.cpp:766-767): optixPrimitiveIndex() divides by it
+}
 
 static void launch_raygen(int width, int height) {
     for (int y = 0; y < height; ++y)

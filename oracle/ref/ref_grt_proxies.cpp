@@ -35,6 +35,17 @@ void ref_enclosing_proxies(unsigned n, const float* pos, const float* rot, const
     delete[] inst;
 }
 
+// render.primitive_type sphere: centers [n,3] and radii [n] of the particles' enclosing spheres, written by the reference's own kernel
+// (computeGaussianEnclosingSphereKernel, particlePrimitives.cu:386-403)
+void ref_enclosing_spheres(unsigned n, const float* pos, const float* rot, const float* scl, const float* dns, float min_response, unsigned opts, float degree,
+                           float* centers, float* radii) {
+    blockDim.x = 1; threadIdx.x = 0;
+    for (unsigned i = 0; i < n; ++i) {
+        blockIdx.x = i;
+        computeGaussianEnclosingSphereKernel(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)centers, radii);
+    }
+}
+
 // the triangle-mesh proxies: prim 1 icosahedron, 2 octahedron, 3 tetrahedron, 4 diamond (GRUT_PRIM_*), 6 trisurfel, 7 trihexa (checker only) -> vertices [n * V, 3] in world space,
 // triangles [n * T, 3] (indices into all vertices), written by the reference's own mesh kernel of that type.  Returns T (V through *num_vertices).
 unsigned ref_enclosing_mesh(int prim, unsigned n, const float* pos, const float* rot, const float* scl, const float* dns, float min_response, unsigned opts,

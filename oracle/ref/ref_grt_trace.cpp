@@ -29,6 +29,9 @@
 #elif defined(REF_CUSTOM)   // render.primitive_type custom: world boxes + intersectCustomParticle (optixTracer.cpp:197-198)
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingCustom
 #define SHIM_OPTIX_CUSTOM_PROXIES
+#elif defined(REF_SPHERE)   // render.primitive_type sphere: OptiX's built-in sphere primitive (optixTracer.cpp:189-190, 765-781)
+#define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingSphere
+#define SHIM_OPTIX_SPHERE_PROXIES
 #else
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingInstances
 #endif
@@ -80,6 +83,19 @@ void ref_grt_trace_fwd_custom(uint32_t n, const float* boxes, const float* densi
     set_common_params(width, height, ray_to_world, ray_o, ray_d, density12, sph48, scene_aabb6, min_transmittance, min_response, min_alpha,
                       sph_degree, features, density, hit_distance2, normals, hits_count, visibility);
     set_scene_boxes(n, boxes);
+    launch_raygen(width, height);
+}
+#endif
+
+#ifdef REF_SPHERE
+// the same programs over the particles' enclosing spheres (centers [n,3], radii [n] as the reference's sphere kernel wrote them, ref_grt_proxies.cpp)
+void ref_grt_trace_fwd_sphere(uint32_t n, const float* centers, const float* radii, const float* density12, const float* sph48, int width, int height,
+                              const float* ray_to_world, const float* ray_o, const float* ray_d, const float* scene_aabb6, float min_transmittance, float min_response,
+                              float min_alpha, unsigned sph_degree, float* features, float* density, float* hit_distance2, float* normals, float* hits_count,
+                              int32_t* visibility) {
+    set_common_params(width, height, ray_to_world, ray_o, ray_d, density12, sph48, scene_aabb6, min_transmittance, min_response, min_alpha,
+                      sph_degree, features, density, hit_distance2, normals, hits_count, visibility);
+    set_scene_spheres(n, centers, radii);
     launch_raygen(width, height);
 }
 #endif

@@ -29,6 +29,9 @@
 #elif defined(REF_CUSTOM)   // render.primitive_type custom: world boxes + intersectCustomParticle (optixTracer.cpp:197-198)
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingCustom
 #define SHIM_OPTIX_CUSTOM_PROXIES
+#elif defined(REF_SPHERE)   // render.primitive_type sphere: OptiX's built-in sphere primitive (optixTracer.cpp:189-190, 765-781)
+#define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingSphere
+#define SHIM_OPTIX_SPHERE_PROXIES
 #else
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingInstances
 #endif
@@ -57,6 +60,7 @@ static void bwd_params_and_launch(uint32_t n, const float* density12, const floa
                       sph_degree, const_cast<float*>(features), const_cast<float*>(density), const_cast<float*>(hit_distance2), dummy3.data(),
                       dummy1.data(), vis.data());
     if (vertices) set_scene_triangles(n * triangles_per_particle, triangles_per_particle, vertices, triangles);
+    if (g_scene.num_spheres) params.gPrimNumTri = 1;   // (set_common_params cleared it; see set_scene_spheres)
     const int32_t sz3[4] = {1, height, width, 3}, st3[4] = {height * width * 3, width * 3, 3, 1};
     const int32_t sz1[4] = {1, height, width, 1}, st1[4] = {height * width, width, 1, 1};
     fill_accessor(params.rayFeaturesGrad, const_cast<float*>(g_features), sz3, st3);
@@ -89,6 +93,17 @@ void ref_grt_trace_bwd_mesh(uint32_t n, uint32_t triangles_per_particle, const f
     bwd_params_and_launch(n, density12, sph48, width, height, ray_to_world, ray_o, ray_d, scene_aabb6, min_transmittance, min_response, min_alpha, sph_degree,
                           features, density, hit_distance2, g_features, g_density, g_hit_distance, g_density12, g_sph48, triangles_per_particle, vertices,
                           triangles);
+}
+#endif
+
+#ifdef REF_SPHERE
+void ref_grt_trace_bwd_sphere(uint32_t n, const float* centers, const float* radii, const float* density12, const float* sph48, int width, int height,
+                              const float* ray_to_world, const float* ray_o, const float* ray_d, const float* scene_aabb6, float min_transmittance, float min_response,
+                              float min_alpha, unsigned sph_degree, const float* features, const float* density, const float* hit_distance2, const float* g_features,
+                              const float* g_density, const float* g_hit_distance, float* g_density12, float* g_sph48) {
+    set_scene_spheres(n, centers, radii);
+    bwd_params_and_launch(n, density12, sph48, width, height, ray_to_world, ray_o, ray_d, scene_aabb6, min_transmittance, min_response, min_alpha, sph_degree,
+                          features, density, hit_distance2, g_features, g_density, g_hit_distance, g_density12, g_sph48, 0, nullptr, nullptr);
 }
 #endif
 

@@ -49,7 +49,7 @@ enum { OPTIX_RAY_FLAG_DISABLE_ANYHIT = 1 << 0 };
 // the two-register trace of the mesh pass (trace.cuh:175-195)
 void optixTrace(OptixTraversableHandle handle, float3 origin, float3 direction, float tmin, float tmax, float time, OptixVisibilityMask mask,
                 unsigned flags, unsigned sbtOffset, unsigned sbtStride, unsigned missIndex, uint32_t& p0, uint32_t& p1);
-#elif defined(SHIM_OPTIX_TRIANGLE_PROXIES) || defined(SHIM_OPTIX_CUSTOM_PROXIES)
+#elif defined(SHIM_OPTIX_TRIANGLE_PROXIES) || defined(SHIM_OPTIX_CUSTOM_PROXIES) || defined(SHIM_OPTIX_SPHERE_PROXIES)
 inline unsigned optixGetPrimitiveIndex() { return g_optix.primitive; }   // the hit triangle of the particles' triangle GAS (optixTracer.cpp:836-845) / the particle's custom primitive (:810-817)
 #else
 inline unsigned optixGetPrimitiveIndex() { return 0; }   // the instanced BLAS holds one custom primitive (optixTracer.cpp:551-563)

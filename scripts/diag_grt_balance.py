@@ -52,3 +52,6 @@ for name, order in (("launch order", np.argsort(start)), ("longest first", np.ar
 names = ["wave_node_visits", "lane_tests", "processed_hits", "lane_rounds", "lane_inserts", "lane_passed_all", "lane_rej_t_range", "lane_rej_box", "lane_rej_distance",
          "wave_tests", "wave_tests_with_a_lane_in_t_range", "wave_tests_with_an_insert", "list_batches"]
 print({k: int(v) for k, v in zip(names, raw[:13])})
+ph = raw[13:16].astype(np.float64)
+print("phase ticks (lane 0 of every packet, 100 MHz): trace rounds %.3f, log merge %.3f, hit processing %.3f of their sum; work-loop (candidate tests) ticks / trace-round ticks = %.3f" % (
+    ph[0] / ph.sum(), ph[1] / ph.sum(), ph[2] / ph.sum(), raw[0] / max(ph[0], 1.0)))

@@ -414,6 +414,45 @@ def make_grt_trace_mesh():
     print("wrote grt_trace_mesh.npz")
 
 
+def make_grt_trace_sphere():
+    """tests/golden/grt_trace_sphere.npz: the reference's 3DGRT forward / backward programs compiled with PARTICLE_PRIMITIVE_TYPE = MOGTracingSphere
+    (render.primitive_type sphere, optixTracer.cpp:189-190) over the emulated OptiX's built-in sphere primitive (oracle/ref/ref_grt_emul.inl: both
+    roots of a ray are offered to the any-hit program); centres and radii from the reference's own kernel (computeGaussianEnclosingSphereKernel
+    through oracle/ref/ref_grt_proxies.cpp).  Both scenes of GRT_TRACE_SCENES."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import make_scene
+    px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    fw = C.CDLL(os.path.join(REF, "libref_grt_trace_Sphere_deg4.so"))
+    bw = C.CDLL(os.path.join(REF, "libref_grt_trace_bwd_Sphere_deg4.so"))
+    out = {}
+    for k, kw in enumerate(GRT_TRACE_SCENES):
+        sc = make_scene(**kw)
+        d12, sph = np.ascontiguousarray(sc["density12"]), np.ascontiguousarray(sc["sph"])
+        n, H, W = len(d12), kw["height"], kw["width"]
+        pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
+                              np.ascontiguousarray(d12[:, 3]))
+        ctr, rad = np.zeros((n, 3), F), np.zeros(n, F)
+        px.ref_enclosing_spheres(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(ctr), _p(rad))
+        box = np.concatenate([(ctr - rad[:, None]).min(0), (ctr + rad[:, None]).max(0)]).astype(F)
+        r2w = np.ascontiguousarray(np.asarray(sc["batch"]["T_to_world"][0], F)[:3, :4])
+        ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)) for a in sc["rays"])
+        feat, den, hit, nrm = np.zeros((H, W, 3), F), np.zeros((H, W, 1), F), np.zeros((H, W, 2), F), np.zeros((H, W, 3), F)
+        cnt, vis = np.zeros((H, W, 1), F), np.zeros(n, np.int32)
+        common = (C.c_uint(n), _p(ctr), _p(rad), _p(d12), _p(sph), W, H, _p(r2w), _p(ro), _p(rd), _p(box), C.c_float(MIN_T_GRT), C.c_float(MIN_RESPONSE),
+                  C.c_float(MIN_ALPHA), C.c_uint(3))
+        fw.ref_grt_trace_fwd_sphere(*common, _p(feat), _p(den), _p(hit), _p(nrm), _p(cnt), _p(vis))
+        g_rad, g_dns, g_hit = grt_trace_upstream(H, W)
+        gd, gs = np.zeros((n, 12), F), np.zeros((n, 48), F)
+        bw.ref_grt_trace_bwd_sphere(*common, _p(feat), _p(den), _p(hit), _p(g_rad), _p(g_dns), _p(g_hit), _p(gd), _p(gs))
+        for key, a in dict(features=feat, density=den, hit_distance=hit, hits_count=cnt, visibility=vis, grad_density=gd, grad_sph=gs, scene_box=box, centers=ctr,
+                           radii=rad).items():
+            out[f"sphere_s{k}_{key}"] = a
+        print(f"sphere scene {k}: hits per ray {cnt.mean():.1f} (max {cnt.max():.0f}), opacity {den.mean():.3f}")
+    np.savez_compressed(os.path.join(HERE, "grt_trace_sphere.npz"), **out)
+    print("wrote grt_trace_sphere.npz")
+
+
 def make_grt_trace_nht():
     """tests/golden/grt_trace_nht.npz: the reference's SLANG forward pipeline (referenceSlangOptix.cu: raygen round loop, intersection, any-hit
     k-buffer) in the neural-harmonic-features configuration, on the host over the emulated OptiX (oracle/ref/ref_grt_trace_slang.cpp), on the
@@ -825,7 +864,7 @@ def make_playground():
 if __name__ == "__main__":
     import sys
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
-    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "grt_trace_mesh", "gut_render", "playground", "gut_nht", "grt_trace_nht", "grt_trace_nht_mesh", "grt_trace_slang_sh"]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "grt_trace_mesh", "gut_render", "playground", "gut_nht", "grt_trace_nht", "grt_trace_nht_mesh", "grt_trace_slang_sh", "grt_trace_sphere"]
     if "--adam-only" in sys.argv:
         which = ["adam"]
     if "per_hit" in which:
@@ -855,3 +894,5 @@ if __name__ == "__main__":
         make_grt_trace_nht_mesh()
     if "grt_trace_slang_sh" in which:
         make_grt_trace_slang_sh()
+    if "grt_trace_sphere" in which:
+        make_grt_trace_sphere()

@@ -583,7 +583,7 @@ def assert_gut_full_parity(stats, max_flip_frac=2e-3, max_rounding_frac=2e-4):
 # ---------------------------------------------------------------------------------------------------------------------
 # 3DGRT at BASELINE config 3's sizes
 # ---------------------------------------------------------------------------------------------------------------------
-GRT_PRIMITIVE_CODES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4, "custom": 5, "trisurfel": 6, "trihexa": 7}
+GRT_PRIMITIVE_CODES = {"instances": 0, "icosahedron": 1, "octahedron": 2, "tetrahedron": 3, "diamond": 4, "custom": 5, "trisurfel": 6, "trihexa": 7, "sphere": 8}
 
 
 def grt_identify_order_ties(primitive_type, cases, d12, sph, inst, scene_aabb, box8, T_to_world, min_transmittance, tol=1e-4, max_ulp=None):

@@ -57,7 +57,7 @@ def test_primitive_codes_match_the_header_and_the_checker():
     assert enum == abi.GRT_PRIMITIVES, (enum, abi.GRT_PRIMITIVES)
     assert sorted(enum.values()) == list(range(len(enum)))
     checker = open(os.path.join(ROOT, "oracle", "grt_oracle.c")).read()
-    for name in ("custom", "trisurfel", "trihexa"):        # the codes the checker branches on by number
+    for name in ("custom", "trisurfel", "trihexa", "sphere"):        # the codes the checker branches on by number
         assert re.search(rf"g_prim == {enum[name]}\b", checker), name
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))

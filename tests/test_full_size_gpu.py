@@ -85,7 +85,9 @@ def test_gut_nht_frame_matches_oracle_at_baseline_size():
     # round 6: EVERY ray with gradients (stride 1 = HIP backward against the checker's backward of the same frame) for the three proxies that
     # had a gradient comparison at test size only
     ("c3_grt_custom_100k_200", 100_000, 200, 200, 0.01, 1, "custom"), ("c3_grt_trisurfel_100k_200", 100_000, 200, 200, 0.01, 1, "trisurfel"),
-    ("c3_grt_trihexa_100k_200", 100_000, 200, 200, 0.01, 1, "trihexa")])
+    ("c3_grt_trihexa_100k_200", 100_000, 200, 200, 0.01, 1, "trihexa"),
+    # render.primitive_type sphere (round 6): two offers per particle (entry and exit of the enclosing sphere), each a proxy of its own
+    ("c3_grt_sphere_1m_800", 1_000_000, 800, 800, 0.01, 149, "sphere"), ("c3_grt_sphere_100k_200", 100_000, 200, 200, 0.01, 1, "sphere")])
 def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, ray_stride, prim):
     """3DGRT (LBVH + software traversal) against the oracle: the per-ray order of processed particles bit-exact, images within
     1e-4, gradients within 1e-3 relative (full frame at 100 k particles; a 4 k-ray subsample of the 1 M / 800x800 frame)."""

@@ -334,7 +334,7 @@ def test_mesh_proxies_hit_order_equals_oracle(prim):
     assert rel_err(gd[:, :11], rd[:, :11]) < 1e-3 and rel_err(gs, rs) < 1e-3
 
 
-@pytest.mark.parametrize("prim", ["icosahedron", "octahedron", "tetrahedron", "diamond", "trisurfel", "trihexa", "custom"])
+@pytest.mark.parametrize("prim", ["icosahedron", "octahedron", "tetrahedron", "diamond", "trisurfel", "trihexa", "custom", "sphere"])
 def test_mesh_proxy_packet_lists_equal_the_tree_walk(monkeypatch, prim):
     """The packet lists with the mesh proxies: binning by the box of the polyhedron's vertices, entry-distance intervals from the bounding
     sphere until a packet's first test refines them - every output and every ray's sequence of processed particles must equal the tree
@@ -571,9 +571,81 @@ def test_trihexa_matches_reference_programs_golden_and_the_oracle():
     assert all(max(m[f"grad_replay_{r}"]) < 1e-3 for r in (True, False)), m
 
 
+def test_sphere_matches_reference_programs_golden_and_the_oracle():
+    """render.primitive_type = sphere (round 6; optixTracer.cpp:189-190, 765-781): one OptiX built-in sphere per particle - the any-hit program is
+    offered a ray's entry into the sphere and, ignoring it, its exit: every root is a proxy of its own here (2 N leaves).  (i) DIRECTLY against
+    tests/golden/grt_trace_sphere.npz = the reference's forward / backward programs compiled for MOGTracingSphere over the emulated OptiX's sphere
+    primitive, both scenes, both backward paths; (ii) every ray's SEQUENCE of processed particles - repeats included - against the oracle given
+    the GPU-built proxy records, then images and gradients."""
+    import os
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    g = np.load(os.path.join(here, "golden", "grt_trace_sphere.npz"))
+    for k, kw in enumerate(make_golden.GRT_TRACE_SCENES):
+        scene = make_scene(**kw)
+        H, W = kw["height"], kw["width"]
+        g_rad, g_dns, g_hit = make_golden.grt_trace_upstream(H, W)
+        for replay in (True, False):
+            gpu = _render(scene, g_rad, g_dns, g_hit, primitive_type="sphere", backward_hit_replay=replay)
+            out = gpu["out"]
+            assert int(gpu["tracer"].tracer_wrapper.stats().list_entries) > 0      # packet lists over the 2 N roots
+            cnt = out["hits_count"][0].detach().cpu().numpy()
+            flips = (cnt != g[f"sphere_s{k}_hits_count"])[..., 0]
+            assert flips.mean() <= 0.01 and cnt.max() >= 20, f"scene {k}: {int(flips.sum())} rays with a different number of accepted hits"
+            e = np.abs(out["pred_features"][0].detach().cpu().numpy() - g[f"sphere_s{k}_features"]).max(-1)
+            hd = g[f"sphere_s{k}_hit_distance"]
+            e_d = np.abs(out["pred_dist"][0].detach().cpu().numpy() - hd[..., :1])[..., 0]
+            tied = ~flips & ((e > 1e-4) | (e_d > 1e-4 * max(1.0, np.abs(hd).max())))
+            assert tied.mean() <= 0.01 and (not tied.any() or e[tied].max() < 5e-2), f"scene {k}: {int(tied.sum())} rays differ with the same hit count"
+            ok = ~flips & ~tied
+            assert np.abs(out["pred_opacity"][0].detach().cpu().numpy() - g[f"sphere_s{k}_density"])[ok].max() < 1e-4
+            vis = out["mog_visibility"].view(-1).view(torch.int32).cpu().numpy() != 0
+            ndrop = 3 * int((flips | tied).sum())
+            assert (vis != (g[f"sphere_s{k}_visibility"] != 0)).sum() <= ndrop
+            gd, gs = gpu["grads"]
+            rd, rs = g[f"sphere_s{k}_grad_density"], g[f"sphere_s{k}_grad_sph"]
+            per = np.sort(np.abs(gd[:, :11].astype(np.float64) - rd[:, :11]).max(1))[: max(1, len(gd) - ndrop)]
+            assert per.max() / np.abs(rd[:, :11]).max() < 1e-3, (k, replay, per.max() / np.abs(rd[:, :11]).max())
+            per = np.sort(np.abs(gs.astype(np.float64) - rs).max(1))[: max(1, len(gs) - ndrop)]
+            assert per.max() / np.abs(rs).max() < 1e-3, (k, replay)
+    # (ii) the sequences
+    scene = _scene(4000, 64, 48, 0.06)
+    tr, (feat, dns, hit, nrm, cnt, vis, ids, num), inst, scene_aabb = _gpu_hits(scene, cap=512, primitive_type="sphere")
+    assert inst.shape == (4000, 12)                                  # (one record per particle, not per root)
+    cfg = oracle.default_grt_config(primitive_type=8)
+    ora = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=scene_aabb, dbg_cap=512)
+    num = num.astype(np.int64)
+    assert np.array_equal(num, ora["hit_num"].astype(np.int64)), f"{(num != ora['hit_num']).sum()} rays with a different number of processed hits"
+    kk = np.minimum(num, 512)
+    got, ref = ids.view(np.uint32), ora["hit_ids"]
+    repeats = 0
+    for r in range(scene["H"] * scene["W"]):
+        assert np.array_equal(got[r, :kk[r]], ref[r, :kk[r]]), f"ray {r}: order differs"
+        repeats += int(kk[r] - len(np.unique(got[r, :kk[r]])))
+    assert num.max() > 20 and repeats > 0, "no ray was offered a particle twice"
+    flips = (cnt[0] != ora["hit_count"])[..., 0]
+    m = dict(flips=int(flips.sum()), feat=float(np.abs(feat[0] - ora["features"]).max()), dns=float(np.abs(dns[0] - ora["density"]).max()))
+    rng = np.random.default_rng(4)
+    g_rad = rng.normal(size=(scene["H"], scene["W"], 3)).astype(np.float32)
+    g_dns = rng.normal(size=(scene["H"], scene["W"], 1)).astype(np.float32)
+    for a in (g_rad, g_dns):
+        a[flips] = 0.0
+    rd, rs = oracle.grt_backward(cfg, 3, 1e-3, ora, g_rad, g_dns, np.zeros_like(g_dns))
+    for replay in (True, False):
+        gpu = _render(scene, g_rad, g_dns, None, primitive_type="sphere", backward_hit_replay=replay)
+        gd, gs = gpu["grads"]
+        m[f"grad_replay_{replay}"] = (rel_err(gd[:, :11], rd[:, :11]), rel_err(gs, rs))
+    print("sphere:", m, "repeats", repeats)
+    assert m["flips"] <= max(2, 2e-3 * flips.size) and m["feat"] < 1e-4 and m["dns"] < 1e-4, m
+    assert all(max(m[f"grad_replay_{r}"]) < 1e-3 for r in (True, False)), m
+
+
 def test_unsupported_primitives_are_refused():
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
-    for prim in ("sphere", "dodecahedron"):
+    for prim in ("dodecahedron", "cube"):
         with pytest.raises(NotImplementedError, match="primitive_type"):
             grt.Tracer({"render": {"primitive_type": prim}})
 

@@ -192,8 +192,8 @@ def test_grt_configuration_defaults_and_unsupported_pipelines():
     grt.grt_config_from_conf({"render": {"pipeline_type": "reference", "backward_pipeline_type": "referenceBwd"}})
     # the closed triangle-mesh proxies of particlePrimitives.cu (icosahedron = the paper's configuration), the custom primitives and the flat trisurfel proxies are provided
     assert [grt.grt_config_from_conf({"render": {"primitive_type": p}}).primitive_type
-            for p in ("instances", "icosahedron", "octahedron", "tetrahedron", "diamond", "custom", "trisurfel", "trihexa")] == [0, 1, 2, 3, 4, 5, 6, 7]
-    for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "dodecahedron"}, {"primitive_type": "sphere"}, {"backward_pipeline_type": "referenceB2FSlangBwd"},
+            for p in ("instances", "icosahedron", "octahedron", "tetrahedron", "diamond", "custom", "trisurfel", "trihexa", "sphere")] == [0, 1, 2, 3, 4, 5, 6, 7, 8]
+    for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "dodecahedron"}, {"backward_pipeline_type": "referenceB2FSlangBwd"},
                 {"pipeline_type": "barycentricSurfels"}):
         with pytest.raises(NotImplementedError):
             grt.grt_config_from_conf({"render": bad})

@@ -601,6 +601,40 @@ def test_grt_trihexa_checker_matches_reference_programs_golden():
     assert per.max() / np.abs(rs).max() < 2e-4, "SH gradients"
 
 
+def test_grt_sphere_checker_matches_reference_programs_golden():
+    """render.primitive_type = sphere (round 6): the reference's programs compiled with PARTICLE_PRIMITIVE_TYPE = MOGTracingSphere over the emulated
+    OptiX's built-in sphere primitive (oracle/ref/ref_grt_emul.inl: the any-hit program is offered a ray's entry into a particle's enclosing sphere and,
+    ignoring it, its exit), centres and radii from the reference's own kernel - against the oracle's two offers per particle.  The intersector's
+    arithmetic is the emulation's (NVIDIA publishes none) and the oracle evaluates the same sequence: the frames agree to the last bit."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = np.load(os.path.join(HERE, "golden", "grt_trace_sphere.npz"))
+    cfg = oracle.default_grt_config(primitive_type=8)
+    for k, kw in enumerate(make_golden.GRT_TRACE_SCENES):
+        sc = make_scene(**kw)
+        H, W = kw["height"], kw["width"]
+        o = oracle.grt_forward(cfg, sc["density12"], sc["sph"], 3, 1e-3, sc["batch"]["T_to_world"][0], *sc["rays"], dbg_cap=256)
+        # the spheres are the reference kernel's: scene box = union of centre -+ radius
+        assert np.abs(o["scene"] - g[f"sphere_s{k}_scene_box"]).max() <= 4e-7 * np.abs(g[f"sphere_s{k}_scene_box"]).max()
+        assert np.allclose(1.0 / o["inst"][:, 0], g[f"sphere_s{k}_radii"], rtol=4e-7, atol=0)
+        ref_cnt = g[f"sphere_s{k}_hits_count"]
+        assert np.array_equal(o["hit_count"], ref_cnt) and ref_cnt.max() >= 20
+        assert np.abs(o["features"] - g[f"sphere_s{k}_features"]).max() <= 1e-6
+        assert np.abs(o["density"] - g[f"sphere_s{k}_density"]).max() <= 1e-6
+        assert np.abs(o["hit_distance"] - g[f"sphere_s{k}_hit_distance"]).max() <= 2e-6
+        assert np.array_equal(o["visibility"] != 0, g[f"sphere_s{k}_visibility"] != 0)
+        # the quirk is real: rays process a particle at both roots
+        ids, num = o["hit_ids"], o["hit_num"]
+        assert sum(int(min(int(num[r]), 256) - len(set(ids[r, :min(int(num[r]), 256)].tolist()))) for r in range(H * W)) > 100
+        # ... so the frame is not the instances' frame
+        assert ref_cnt.sum() != np.load(os.path.join(HERE, "golden", "grt_trace.npz"))[f"s{k}_hits_count"].sum()
+        g_rad, g_dns, g_hit = make_golden.grt_trace_upstream(H, W)
+        gd, gs = oracle.grt_backward(cfg, 3, 1e-3, o, g_rad, g_dns, g_hit)
+        rd, rs = g[f"sphere_s{k}_grad_density"], g[f"sphere_s{k}_grad_sph"]
+        assert np.abs(gd[:, :11] - rd[:, :11]).max() / np.abs(rd[:, :11]).max() < 2e-5
+        assert np.abs(gs - rs).max() / np.abs(rs).max() < 2e-5
+
+
 def test_grt_custom_primitives_match_reference_programs_golden():
     """render.primitive_type = custom: the oracle (world boxes of computeGaussianEnclosingAABBKernel + the maximum-response point within
     3 sigma, orc_grt_custom_boxes / candidate) against tests/golden/grt_trace_mesh.npz `custom_*` = the reference's programs compiled with
