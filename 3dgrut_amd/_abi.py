@@ -80,7 +80,7 @@ class GrtConfig(C.Structure):
         ("max_hits_per_trace", C.c_int32), ("particle_feature_half", C.c_int32), ("feature_output_half", C.c_int32),
         ("feature_transform_type", C.c_int32), ("particle_feature_dim", C.c_int32), ("interp_point_feature_dim", C.c_int32),
         ("feature_interpolation_support", C.c_int32), ("feature_activation_type", C.c_int32), ("feature_activation_num_frequencies", C.c_int32),
-        ("primitive_type", C.c_int32),
+        ("primitive_type", C.c_int32), ("pipeline_type", C.c_int32),
     ]
 
 

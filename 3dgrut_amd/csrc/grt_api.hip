@@ -43,7 +43,8 @@ struct GrtHandle {
                log_frame.device_ray_to_world == f.device_ray_to_world &&
                memcmp(log_frame.ray_to_world, f.ray_to_world, sizeof(f.ray_to_world)) == 0;
     }
-    uint32_t* log_state_host = nullptr;  // pinned copy of {chunks used, overflow} of the last logged forward
+    uint32_t* log_state_host = nullptr;  // pinned copy of {chunks used, overflow, .., [7] = a packet ran out of table columns} of the last logged forward
+    uint32_t log_rounds = 48;            // columns of the chunk table (trace rounds a packet may log); doubled on demand
     hipEvent_t log_event = nullptr;
     hipEvent_t list_event = nullptr;     // the entry count of build_lists has reached the host
     bool log_event_pending = false;
@@ -92,7 +93,12 @@ static int grt_validate(const GrtConfig& c) {
         GRUT_REQUIRE(!c.enable_normals, "neural harmonic features: enable_normals must be off");
         // (the feature kernels index the feature rows by the log's proxy id and blend at the volumetric intersection: closed proxies only —
         // the plugin's grt_config_from_conf refuses the same combinations)
-        GRUT_REQUIRE(c.primitive_type <= GRUT_PRIM_DIAMOND, "neural harmonic features: primitive_type %d is not provided (instances and the closed mesh proxies are)", c.primitive_type);
+        // round 6: trihexa and sphere too (proxy -> particle at the per-hit sites).  trisurfel would need the surfel branches of the feature
+        // programs (the blend point on the surfel's plane); the Slang pipeline's custom-primitive test (particleDensityHitCustom,
+        // gaussianParticles.slang:489-523) reports the UNSIGNED distance of the closest approach, not intersectCustomParticle's signed one -
+        // another candidate test than GRUT_PRIM_CUSTOM's: neither is built
+        GRUT_REQUIRE(c.primitive_type != GRUT_PRIM_TRISURFEL && c.primitive_type != GRUT_PRIM_CUSTOM,
+                     "neural harmonic features: primitive_type %d (custom / trisurfel) is not provided (every other proxy is)", c.primitive_type);
         GRUT_REQUIRE(c.feature_interpolation_support == 0 || c.feature_interpolation_support == 1, "feature_interpolation_support must be 0 (centre) or 1 (tetrahedra)");
         GRUT_REQUIRE(c.feature_activation_type >= 0 && c.feature_activation_type <= 3, "feature_activation_type must be 0..3");
         const int points = c.feature_interpolation_support == 1 ? 4 : 1;
@@ -103,7 +109,13 @@ static int grt_validate(const GrtConfig& c) {
         GRUT_REQUIRE(nf >= 1 && nr >= 1 && nr <= 32, "ray feature dim %d: 1..32 supported", nr);
         GRUT_REQUIRE(c.particle_feature_dim + 11 <= 64, "particle_feature_dim %d: at most 53 (one wave carries a hit's gradient words)", c.particle_feature_dim);
     }
-    if (c.max_hits_per_trace != 0 && c.max_hits_per_trace != kGrtMaxHits) {
+    if (c.pipeline_type != GRUT_PIPELINE_REFERENCE) {
+        GRUT_REQUIRE(c.pipeline_type == GRUT_PIPELINE_BARYCENTRIC_SURFELS, "pipeline_type %d: reference (0) or barycentricSurfels (1)", c.pipeline_type);
+        // (barycentricSurfelsOptix.cu reads the hit triangle's barycentrics and the trisurfel kernel's {normal, density} rows, optixTracer.cpp:735-748)
+        GRUT_REQUIRE(c.primitive_type == GRUT_PRIM_TRISURFEL, "pipeline_type barycentricSurfels: primitive_type must be trisurfel");
+        GRUT_REQUIRE(c.feature_transform_type == 0 && !c.particle_feature_half && !c.feature_output_half, "pipeline_type barycentricSurfels: fp32 SH radiance only");
+    }
+    if (c.max_hits_per_trace != 0 && c.max_hits_per_trace != kGrtMaxHits && !(c.pipeline_type == GRUT_PIPELINE_BARYCENTRIC_SURFELS && c.max_hits_per_trace == 10)) {
         set_last_error("max_hits_per_trace=%d: the hit buffer is %d entries (PipelineParameters::MaxNumHitPerTrace)", c.max_hits_per_trace, kGrtMaxHits);
         return GRUT_ERR_UNSUPPORTED;
     }
@@ -115,6 +127,8 @@ static GrtTraceParams trace_params(const GrtHandle* h, const GrtFrame& f) {
     memset(&P, 0, sizeof(P));
     P.degree = h->cfg.particle_kernel_degree;
     P.prim = h->cfg.primitive_type;
+    P.bary = h->cfg.pipeline_type == GRUT_PIPELINE_BARYCENTRIC_SURFELS;
+    P.clamping = h->cfg.particle_kernel_density_clamping;
     P.box8 = h->cfg.primitive_type == GRUT_PRIM_CUSTOM ? h->box8.as<float>() : nullptr;
     P.ncoef = (h->cfg.particle_radiance_sph_degree + 1) * (h->cfg.particle_radiance_sph_degree + 1);
     P.sph_degree = f.sph_degree < h->cfg.particle_radiance_sph_degree ? f.sph_degree : h->cfg.particle_radiance_sph_degree;
@@ -451,15 +465,19 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     h->log_valid = false;
     GRUT_REQUIRE(!(P.nht && dbg_ids), "grt_debug_forward_hits: not provided with neural harmonic features");
     // (neural harmonic features: the ray features are computed FROM the log, so every forward keeps one)
-    if ((frame->keep_hits_for_backward || P.nht) && !dbg_ids) {
+    if ((frame->keep_hits_for_backward || P.nht) && !dbg_ids && !P.bary) {
         const uint32_t blocks = div_up((uint32_t)P.W, 8) * div_up((uint32_t)P.H, 8);
-        constexpr uint32_t kMaxRounds = 48;
+        // columns of the chunk table = trace rounds a packet may log: 48 to start with, doubled when a frame reports a packet that needed more
+        // (state[7]; until then such a frame counts as overflowed and its backward traverses again) - spheres and trihexa offer a particle
+        // several times and make rays of 200 hits and more
         uint32_t want = blocks * 10u;  // first guess; grown from the measured use of earlier frames
         if (h->log_event_pending && hipEventQuery(h->log_event) == hipSuccess) {
             h->log_event_pending = false;
             const uint32_t used = h->log_state_host[0];
             if (used + used / 2 > want) want = used + used / 2;
+            if (h->log_state_host[7] && h->log_rounds < 4096u) h->log_rounds *= 2u;
         }
+        const uint32_t kMaxRounds = h->log_rounds;
         if (h->log.capacity_chunks > want) want = h->log.capacity_chunks;
         if (const char* e = getenv("GRUT_GRT_LOG_CHUNKS")) want = (uint32_t)atoi(e) > 0 ? (uint32_t)atoi(e) : 1u;  // tests: force the overflow fallback
         GRUT_CHECK(h->log_pool.ensure((size_t)want * kGrtLogSlots * 64 * 4));
@@ -502,16 +520,22 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
         // the hit log.  The log must hold the whole frame: if the pool overflowed, grow it and trace again (a host round trip per frame
         // on this path — first version).
         for (int attempt = 0; attempt < 8; ++attempt) {
-            uint32_t st[4] = {0, 0, 0, 0};
-            GRUT_HIP(hipMemcpyAsync(st, log.state, 16, hipMemcpyDeviceToHost, s));
+            uint32_t st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            GRUT_HIP(hipMemcpyAsync(st, log.state, 32, hipMemcpyDeviceToHost, s));
             GRUT_HIP(hipStreamSynchronize(s));
-            if (st[1] == 0u) break;
+            if (st[1] == 0u && st[7] == 0u) break;
             GRUT_REQUIRE(attempt < 7, "grt_forward: the hit log does not fit (neural harmonic features)");
-            const uint32_t want = h->log.capacity_chunks * 2u;
+            const uint32_t blocks = div_up((uint32_t)P.W, 8) * div_up((uint32_t)P.H, 8);
+            if (st[7]) {   // a packet ran out of table columns: widen the table
+                h->log_rounds = h->log_rounds < 4096u ? h->log_rounds * 2u : h->log_rounds;
+                GRUT_CHECK(h->log_table.ensure((size_t)blocks * h->log_rounds * 4, 1.25f));
+                h->log.table = h->log_table.as<uint32_t>();
+                h->log.max_rounds = h->log_rounds;
+            }
+            const uint32_t want = st[7] && st[0] < h->log.capacity_chunks ? h->log.capacity_chunks : h->log.capacity_chunks * 2u;
             GRUT_CHECK(h->log_pool.ensure((size_t)want * kGrtLogSlots * 64 * 4));
             h->log.pool = h->log_pool.as<uint32_t>();
             h->log.capacity_chunks = want;
-            const uint32_t blocks = div_up((uint32_t)P.W, 8) * div_up((uint32_t)P.H, 8);
             GRUT_HIP(hipMemsetAsync(h->log.table, 0xFF, (size_t)blocks * h->log.max_rounds * 4, s));
             GRUT_HIP(hipMemsetAsync(h->log.state, 0, 64, s));
             log = h->log;
@@ -521,7 +545,7 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
         grt_launch_nht_fwd(s, P, particle_density, particle_sph, ray_origin, ray_direction, out_features, log);
     }
     if (log.pool && !h->log_event_pending) {  // how much of the pool the frame used, read lazily by a later forward
-        GRUT_HIP(hipMemcpyAsync(h->log_state_host, log.state, 8, hipMemcpyDeviceToHost, s));
+        GRUT_HIP(hipMemcpyAsync(h->log_state_host, log.state, 32, hipMemcpyDeviceToHost, s));
         GRUT_HIP(hipEventRecord(h->log_event, s));
         h->log_event_pending = true;
     }
@@ -570,6 +594,10 @@ int grt_backward(GrtHandle* h, void* stream_, const GrtFrame* frame, const float
     (void)normals;
     (void)grad_normals;  // the reference's backward does not propagate the normal gradient either (referenceBwdOptix.cu:103-170)
     GRUT_REQUIRE(h && frame, "grt_backward: null handle/frame");
+    if (h->cfg.pipeline_type == GRUT_PIPELINE_BARYCENTRIC_SURFELS) {   // (optixTracer.cpp:311-314 would look for barycentricSurfelsBwdOptix.cu: not in the checkout)
+        set_last_error("grt_backward: pipeline_type barycentricSurfels is forward only (the reference ships no backward program for it)");
+        return GRUT_ERR_UNSUPPORTED;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     ScratchStreamScope scratch_scope(s);
     if (!h->built) {

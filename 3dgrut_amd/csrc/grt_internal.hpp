@@ -43,6 +43,8 @@ struct GrtTraceParams {
     float min_response, min_alpha, max_alpha, min_transmittance;
     int W, H;
     int prim;                 // GrtConfig::primitive_type (GRUT_PRIM_*): which candidate test a (ray, particle) pair takes
+    int bary;                 // GrtConfig::pipeline_type == GRUT_PIPELINE_BARYCENTRIC_SURFELS: ten hits per trace, response from the plane crossing (forward only)
+    int clamping;             // GrtConfig::particle_kernel_density_clamping (the surfel pipeline's scaled response needs it per hit)
     const float* box8;        // GRUT_PRIM_CUSTOM: [N,8] {world box, kernelScale^2, 0} of the proxy kernel (null otherwise)
     float ray_to_world[12];
     const float* ray_to_world_dev;   // optional: the same matrix in device memory (GrtFrame::device_ray_to_world), used instead when set

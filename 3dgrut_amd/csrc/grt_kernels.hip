@@ -1464,6 +1464,37 @@ __device__ __forceinline__ void gray_distance_grads(bool surfel, const HitGeom& 
 // ---------------------------------------------------------------------------------------------
 // forward: __raygen__rg of referenceOptix.cu:103-186
 // ---------------------------------------------------------------------------------------------
+// render.pipeline_type barycentricSurfels (barycentricSurfelsOptix.cu; GrtTraceParams::bary).  A hit of that pipeline is the ray's crossing of
+// the surfel's plane - the trisurfel candidate of candidate_abe - and carries the squared distance of the crossing from the surfel's centre in
+// the proxy frame (computeTrisurfelSquaredDistance, :179-188, from the triangle's barycentrics: both triangles map onto |(x, y)|^2).  The
+// crossing is evaluated again per processed hit, operation by operation as the candidate test (and as the CPU checker's trace_bary_fwd).
+__device__ __forceinline__ float surfel_crossing_sqdist(const float* __restrict__ inst, const RayW& r) {
+#pragma clang fp contract(off)
+    const float4* q = reinterpret_cast<const float4*>(inst);
+    const float4 a = q[0], b = q[1], e = q[2];
+    const f3 po = proxy_origin(a, b, e, r.o);
+    const float pdx = fmaf(a.z, r.d.z, fmaf(a.y, r.d.y, a.x * r.d.x)), pdy = fmaf(b.y, r.d.z, fmaf(b.x, r.d.y, a.w * r.d.x)),
+                pdz = fmaf(e.x, r.d.z, fmaf(b.w, r.d.y, b.z * r.d.x));
+    const float t = -po.z / pdz;
+    const float hx = fmaf(t, pdx, po.x), hy = fmaf(t, pdy, po.y);
+    return fmaf(hy, hy, hx * hx);
+}
+// particleScaledResponse (gaussianParticles.cuh:296-333): the kernel response in the proxy frame, where the unit distance is the particle's
+// extent at the density-modulated minimum response
+__device__ __forceinline__ float scaled_response(int degree, bool clamped, float gray, float modulated_min_response, float modulation) {
+    const float min_response = fminf(modulated_min_response / modulation, 0.97f);
+    const float lm = clamped ? logf(min_response) : modulated_min_response;
+    switch (degree) {
+    case 8: { const float g2 = gray * gray; return expf(lm * g2 * g2); }
+    case 5: return expf(lm * gray * gray * sqrtf(gray));
+    case 4: return expf(lm * gray * gray);
+    case 3: return expf(lm * gray * sqrtf(gray));
+    case 1: return expf(lm * sqrtf(gray));
+    case 0: { const float sl = (1.f - min_response) / 3.f; return fmaxf(1.f + sl * sqrtf(gray), 0.f); }
+    default: return expf(lm * gray);
+    }
+}
+
 template <int DEG, bool COUNT, bool UNI, bool LOG, bool GEN>
 // 4 waves per SIMD (128 VGPRs): the walk is a chain of dependent fetches, a fourth wave hides more of it than the few
 // spilled registers cost (measured: 65.8 -> 60.2 ms at 1M particles, 800x800; 5 waves: 69.9 ms; again on the list path at the end of
@@ -1505,7 +1536,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
     // kernel is a fifth shorter and 5 % faster (forward 6.87 -> 6.51 ms at 1 M / 800x800, A/B on one box).  The launcher picks it for the
     // default configuration only: fp32 SH radiance in and out, no normals - those branches fold away with it (the per-ray hit dump of the
     // order tests stays: they must see THIS kernel).
-    if (!GEN) { P.prim = GRUT_PRIM_INSTANCES; P.nht = 0; P.sph_half = 0; P.out_half = 0; P.normals = 0; }
+    if (!GEN) { P.prim = GRUT_PRIM_INSTANCES; P.nht = 0; P.sph_half = 0; P.out_half = 0; P.normals = 0; P.bary = 0; }
+    // barycentricSurfels: a trace returns the TEN nearest hits (MaxNumHitPerTrace, barycentricSurfelsOptix.cu:26) - the first ten of the
+    // sixteen the round gathers; the next round starts behind the tenth
+    const int k_round = (GEN && P.bary) ? 10 : kGrtMaxHits;
     const PixelBlock pb = pixel_block(P.W, P.H);
     if (!pb.inside) return;
     const unsigned long long t_begin = COUNT ? wall_clock64() : 0ull;
@@ -1546,6 +1580,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         uint32_t c = 0xFFFFFFFFu;
         if (lane == 0) {
             if (round < log.max_rounds) c = atomicAdd(&log.state[0], 1u);
+            else log.state[7] = 1u;   // the packet needs more rounds than the table has columns: the host widens the table for the next frame
             if (c >= log.capacity_chunks) { c = 0xFFFFFFFFu; log.state[1] = 1u; }
             if (round < log.max_rounds) log.table[(size_t)block * log.max_rounds + round] = c;
         }
@@ -1576,7 +1611,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
             buf.store(s_hit_t, s_hit_id, lane);
         }
         if (s_hit_id[lane] == 0xFFFFFFFFu) running = false;
-        const bool full = s_hit_id[(kGrtMaxHits - 1) * 64 + lane] != 0xFFFFFFFFu;
+        const bool full = s_hit_id[(k_round - 1) * 64 + lane] != 0xFFFFFFFFu;
         const unsigned long long ph1 = COUNT ? wall_clock64() : 0ull;
         // LOG: the round's chunk holds the round's candidates AND its ghosts, merged in (t, particle) order — the replay walks a chunk
         // front to back and decides with the backward program's own intervals which entries that program is offered (the candidates
@@ -1661,7 +1696,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
         request(id_next);
 #endif
 #pragma unroll 1
-        for (int i = 0; i < kGrtMaxHits; ++i) {
+        for (int i = 0; i < k_round; ++i) {
 #if GRT_HIT_PREFETCH
             const uint32_t id = id_next;
             const float4 ca_ = na, cq_ = nq, cs_ = ns;
@@ -1673,6 +1708,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GRT_FWD_WAVE
             const float hit_t = s_hit_t[i * 64 + lane];
             const bool process = running && (id != 0xFFFFFFFFu) && (T > P.min_transmittance);
             if (!__any(process)) break;  // ascending list: nothing further for any lane
+            if (GEN && P.bary) {
+                // barycentricSurfelsOptix.cu:113-166: response from the crossing's squared distance, depth from the HIT distance, the surfel's normal
+                if (process) {
+                    const float density = density12[3 * (size_t)id].w;
+                    const float gray = surfel_crossing_sqdist(bvh.inst + 12 * (size_t)id, r);
+                    const bool clamped = P.clamping != 0;
+                    const float scale_min = (clamped || DEG == 0) ? P.min_response : logf(P.min_response);
+                    const float response = scaled_response(DEG, clamped, gray, scale_min, density);
+                    const float alpha = fminf(0.99f, response * density);
+                    if ((response > P.min_response) && (alpha > P.min_alpha)) {
+                        const float weight = alpha * T;
+                        const f3 u = sh_radiance(P, sph, id, basis);
+                        rad = rad + mk3(fmaxf(u.x, 0.f), fmaxf(u.y, 0.f), fmaxf(u.z, 0.f)) * weight;
+                        T *= (1.f - alpha);
+                        depth += hit_t * weight;
+                        if (P.normals) {   // the trisurfel kernel's normal: normalize(cross(v1 - v0, v2 - v0)) = -(the particle's third axis)
+                            const float4 q = density12[3 * (size_t)id + 1];
+                            const m3 rt = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
+                            const f3 n0 = mk3(-rt.r2.x, -rt.r2.y, -rt.r2.z);
+                            nrm = nrm + n0 * ((dot(n0, r.d) < 0.f ? -1.f : 1.f) * weight);
+                        }
+                        visibility[id] = 1;
+                        cnt += 1.f;
+                    }
+                    tLast = fmaxf(tLast, hit_t);
+                    if (COUNT) tc.processed++;
+                    if (dbg_ids && ndbg < P.dbg_cap) dbg_ids[pix * P.dbg_cap + ndbg] = id;
+                    ndbg++;
+                }
+                continue;
+            }
             if (process) {
                 const uint32_t pid = particle_of(P, id);
 #if GRT_HIT_PREFETCH
@@ -1999,10 +2065,11 @@ __global__ __launch_bounds__(64) void grt_nht_fwd_kernel(GrtTraceParams P, const
         const uint32_t* chunk = log.pool + (size_t)c * (kGrtLogSlots * 64) + lane;
 #pragma unroll 1
         for (int i = 0; i < kGrtLogSlots; ++i) {
-            const uint32_t id = in_image ? chunk[i * 64] : 0xFFFFFFFFu;
-            if (!__any(id != 0xFFFFFFFFu)) break;
+            const uint32_t slot = in_image ? chunk[i * 64] : 0xFFFFFFFFu;
+            if (!__any(slot != 0xFFFFFFFFu)) break;
             // the forward processed the round's CANDIDATES (not its ghosts) in this order while the ray was above min_transmittance
-            if (id != 0xFFFFFFFFu && !(id & kGrtGhostBit) && (T > P.min_transmittance)) {
+            if (slot != 0xFFFFFFFFu && !(slot & kGrtGhostBit) && (T > P.min_transmittance)) {
+                const uint32_t id = particle_of(P, slot);   // (the log is keyed by proxy: trihexa / sphere hold several per particle)
                 const Particle p = load_particle(density12, id);
                 const HitGeom g = hit_geometry<DEG>(P, p, r);
                 if (g.accept) {
@@ -2241,6 +2308,7 @@ template <int DEG>
 __device__ __forceinline__ void process_hit_bwd_nht(const GrtTraceParams& P, const RayW& r, uint32_t id, const float4* __restrict__ density12,
                                                     const float* __restrict__ features, const NhtTetra& tet, NhtBwdRay& st,
                                                     float* __restrict__ g_density12, float* __restrict__ g_features) {
+    id = particle_of(P, id);   // (the traversal hands over the proxy)
     const Particle p = load_particle(density12, id);
     const HitGeom g = hit_geometry<DEG>(P, p, r);
     float gd[11], wq[4], gbase[kGrtNhtMaxIpd];
@@ -2618,6 +2686,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     bw_max = fmaxf(bw_max, cd.t);
                     if (++bw_cnt == (uint32_t)kGrtMaxHits) { bw_start = bw_max; bw_cnt = 0u; }
                     dbg_n++; dbg_sig += (unsigned long long)id * 0x9E3779B97F4A7C15ull + 1ull;
+                    id = particle_of(P, id);   // from here on: the particle (its rows are the atomics' targets, lanes merge by particle)
                     const Particle p = load_particle(density12, id);
                     const HitGeom g = hit_geometry<DEG>(P, p, r);
                     float gd[11], wq[4], gbase[kGrtNhtMaxIpd];

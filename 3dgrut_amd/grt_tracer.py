@@ -39,20 +39,32 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
     # integrate the same function as the hand-written ones — same hit test, response, alpha clamps, weights and radiance — in another
     # rounding order; both names are served by the same kernels (the SH path is pinned by the `reference` programs only)
     allowed = _SUPPORTED_PIPELINES
-    if pipeline not in allowed:
-        raise NotImplementedError(f"3dgrut_amd: render.pipeline_type={pipeline!r} is not supported (only {allowed})")
+    # `barycentricSurfels` (barycentricSurfelsOptix.cu, round 6): the surfel forward pipeline - trisurfel proxies, ten hits per trace, the
+    # response from the hit triangle's barycentrics.  FORWARD ONLY: the reference ships no backward program for it (the constructor's default
+    # backward name `barycentricSurfelsBwd` has no file, optixTracer.cpp:311-314); backward() raises here
+    if pipeline == "barycentricSurfels":
+        if _conf_get(render, "primitive_type", "instances") != "trisurfel":
+            raise NotImplementedError("3dgrut_amd: render.pipeline_type='barycentricSurfels' needs render.primitive_type='trisurfel' "
+                                      "(the program reads the trisurfel kernel's per-particle rows, optixTracer.cpp:735-748)")
+        if nht:
+            raise NotImplementedError("3dgrut_amd: render.pipeline_type='barycentricSurfels' integrates SH radiance only")
+        cfg.pipeline_type = 1
+        cfg.max_hits_per_trace = 10
+    elif pipeline not in allowed:
+        raise NotImplementedError(f"3dgrut_amd: render.pipeline_type={pipeline!r} is not supported (only {allowed + ('barycentricSurfels',)})")
     bwd_pipeline = _conf_get(render, "backward_pipeline_type", pipeline + "Bwd")
-    if bwd_pipeline not in tuple(p + "Bwd" for p in allowed):
+    if bwd_pipeline not in tuple(p + "Bwd" for p in allowed) + (("barycentricSurfelsBwd",) if pipeline == "barycentricSurfels" else ()):
         raise NotImplementedError(f"3dgrut_amd: render.backward_pipeline_type={bwd_pipeline!r} is not supported "
                                   f"(only {tuple(p + 'Bwd' for p in allowed)})")
     prim = _conf_get(render, "primitive_type", "instances")
     if prim not in _abi.GRT_PRIMITIVES:
         raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (provided: {tuple(_abi.GRT_PRIMITIVES)})")
-    if nht and prim not in ("instances", "icosahedron", "octahedron", "tetrahedron", "diamond"):
+    if nht and prim in ("trisurfel", "custom"):
         # (the feature path walks the trace kernel's hit log and evaluates the features at each hit's canonical intersection: it does not care
-        # which candidate test ordered the log - instances and the closed mesh proxies; the surfel / world-box per-hit variants are not built)
-        raise NotImplementedError("3dgrut_amd: neural harmonic features are provided with primitive_type instances / icosahedron / octahedron / "
-                                  "tetrahedron / diamond only")
+        # which candidate test ordered the log - instances, the closed mesh proxies, trihexa and sphere (round 6: proxy -> particle at the
+        # per-hit sites).  The surfel variant blends at the ray's crossing of the surfel's plane, and the Slang pipeline's custom-primitive
+        # test reports an unsigned distance (gaussianParticles.slang:489-523) - another candidate test than `custom`'s: neither is built)
+        raise NotImplementedError("3dgrut_amd: neural harmonic features are not provided with primitive_type custom / trisurfel (every other proxy is)")
     cfg.primitive_type = _abi.GRT_PRIMITIVES[prim]
     # fp16 feature I/O (setup_3dgrt.py:41-44): run-time switches here, compile-time macros in the reference
     cfg.particle_feature_half = int(bool(_conf_get(render, "particle_feature_half", False)))

@@ -329,7 +329,15 @@ typedef struct GrtConfig {
      * (gaussianParticles.cuh:407-441): the instances' hit point, offered to the rays that cross the world box, accepted within 3 sigma.
      * The open meshes GRUT_PRIM_TRISURFEL / GRUT_PRIM_TRIHEXA and the enclosing spheres GRUT_PRIM_SPHERE: below. */
     int32_t primitive_type;
+    /* render.pipeline_type (optixTracer.cpp:246-318: the forward program's file).  GRUT_PIPELINE_REFERENCE: referenceOptix.cu (and the Slang
+     * pipelines, served by the same kernels).  GRUT_PIPELINE_BARYCENTRIC_SURFELS: barycentricSurfelsOptix.cu - FORWARD ONLY (the reference ships
+     * no backward program for it): trisurfel proxies (primitive_type must be GRUT_PRIM_TRISURFEL), ten hits per trace, the response evaluated
+     * from the squared distance of the ray's crossing of the surfel's plane in the proxy frame (the hit triangle's barycentrics) with the
+     * kernel-scaled minimum response, depth from the triangle hit distances, normals from the surfel's plane.  grt_backward returns
+     * GRUT_ERR_UNSUPPORTED. */
+    int32_t pipeline_type;
 } GrtConfig;
+enum { GRUT_PIPELINE_REFERENCE = 0, GRUT_PIPELINE_BARYCENTRIC_SURFELS = 1 };
 enum { GRUT_PRIM_INSTANCES = 0, GRUT_PRIM_ICOSAHEDRON = 1, GRUT_PRIM_OCTAHEDRON = 2, GRUT_PRIM_TETRAHEDRON = 3, GRUT_PRIM_DIAMOND = 4, GRUT_PRIM_CUSTOM = 5,
        /* trisurfel (particlePrimitives.cu:155-205): two triangles per particle = the rhombus |x| + |y| <= sqrt 2 of the proxy's z = 0 plane, traced
         * WITHOUT face culling (referenceOptix.cu:62); the hit is the ray's crossing of that plane and the per-hit math takes its

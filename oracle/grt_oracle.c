@@ -559,6 +559,119 @@ static int trace_round(const grt_hit* cands, uint32_t n, real tmin, real tmax, i
     return k;
 }
 
+/* render.pipeline_type barycentricSurfels - __raygen__rg / __anyhit__ah of barycentricSurfelsOptix.cu:84-228 (FORWARD ONLY in the reference).
+ * Trisurfel proxies traced without face culling; a trace returns the TEN nearest triangle hits beyond the last hit distance, each with the
+ * squared distance of the hit point from the surfel's centre in the proxy frame (computeTrisurfelSquaredDistance from the triangle's
+ * barycentrics, :179-188: both triangles of a surfel map onto |(x, y)|^2 of the plane crossing); per hit: the kernel response SCALED to the
+ * proxy frame (particleScaledResponse, gaussianParticles.cuh:296-333, with the density-modulated minimum response), alpha = min(0.99, response
+ * x density), radiance from SH along the ray, depth += HIT distance x weight, normal = the surfel's, flipped along the ray (:160-164).
+ * The plane crossing is evaluated as the trisurfel candidate test does (grt_kernels.hip: surfel_crossing, operation by operation). */
+static real scaled_response(int degree, int clamped, real gray, real modulated_min_response, real modulation) {
+    const real min_response = r_min(modulated_min_response / modulation, R_(0.97));
+    const real lm = clamped ? r_log(min_response) : modulated_min_response;
+    switch (degree) {
+    case 8: { const real g2 = gray * gray; return r_exp(lm * g2 * g2); }
+    case 5: return r_exp(lm * gray * gray * r_sqrt(gray));
+    case 4: return r_exp(lm * gray * gray);
+    case 3: return r_exp(lm * gray * r_sqrt(gray));
+    case 1: return r_exp(lm * r_sqrt(gray));
+    case 0: { const real s = (1 - min_response) / 3; return r_max(1 + s * r_sqrt(gray), 0); }
+    default: return r_exp(lm * gray);
+    }
+}
+typedef struct { real t, sq; uint32_t id; } bary_hit;
+static int bary_cmp(const void* a, const void* b) {
+    const bary_hit* x = (const bary_hit*)a; const bary_hit* y = (const bary_hit*)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
+}
+static int trace_bary_fwd(const GrtConfig* cfg, uint32_t N, const real* density12, const real* sph, int sph_deg, real min_T, const real* inst12,
+                          const real* scene6, const real* ray_to_world12, uint32_t nrays, const real* ray_o, const real* ray_d, real* out_rad,
+                          real* out_dns, real* out_hit2, real* out_nrm, real* out_cnt, int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count,
+                          uint32_t dbg_cap) {
+    const int K = 10;   /* MaxNumHitPerTrace, barycentricSurfelsOptix.cu:26 */
+    const int ncoef = (cfg->particle_radiance_sph_degree + 1) * (cfg->particle_radiance_sph_degree + 1);
+    const real eps = R_(1e-9);
+    const int clamped = cfg->particle_kernel_density_clamping != 0, degree = cfg->particle_kernel_degree;
+    const real hit_min = (real)cfg->particle_kernel_min_response;
+    const real scale_min = (clamped || degree == 0) ? hit_min : r_log(hit_min);   /* particleScaleMinResponse, :108-109 */
+#pragma omp parallel
+    {
+        bary_hit* cands = (bary_hit*)malloc(sizeof(bary_hit) * ((size_t)N + 1));
+#pragma omp for schedule(dynamic, 8)
+        for (uint32_t r = 0; r < nrays; ++r) {
+            const v3 o = xform_point(ray_to_world12, v3_make(ray_o[3 * r], ray_o[3 * r + 1], ray_o[3 * r + 2]));
+            const v3 d = xform_dir(ray_to_world12, v3_make(ray_d[3 * r], ray_d[3 * r + 1], ray_d[3 * r + 2]));
+            uint32_t n = 0;
+            for (uint32_t i = 0; i < N; ++i) {
+                const real* inst = inst12 + 12 * (size_t)i;
+                const v3 dl = v3_make(o.x - inst[9], o.y - inst[10], o.z - inst[11]);
+                const v3 po = v3_make(inst[0] * dl.x + inst[1] * dl.y + inst[2] * dl.z, inst[3] * dl.x + inst[4] * dl.y + inst[5] * dl.z,
+                                      inst[6] * dl.x + inst[7] * dl.y + inst[8] * dl.z);
+                const v3 pd = v3_make(r_fma(inst[2], d.z, r_fma(inst[1], d.y, inst[0] * d.x)), r_fma(inst[5], d.z, r_fma(inst[4], d.y, inst[3] * d.x)),
+                                      r_fma(inst[8], d.z, r_fma(inst[7], d.y, inst[6] * d.x)));
+                if (pd.z == 0) continue;
+                const real t = -po.z / pd.z;
+                const real hx = r_fma(t, pd.x, po.x), hy = r_fma(t, pd.y, po.y);
+                if (!(r_fabs(hx) + r_fabs(hy) <= R_(1.4142135381698608))) continue;
+                cands[n].t = t; cands[n].id = i; cands[n].sq = r_fma(hy, hy, hx * hx); n++;
+            }
+            qsort(cands, n, sizeof(bary_hit), bary_cmp);
+            real T = 1, depth = 0, cnt = 0;
+            v3 rad = v3_make(0, 0, 0), nrm = v3_make(0, 0, 0);
+            real tEnter, tExit;
+            scene_interval(scene6, o, d, &tEnter, &tExit);
+            real tLast = r_max(0, tEnter - eps);      /* intersectAABB, :38-44: {max(0, tnear - eps), tfar + eps} */
+            const real tMax = tExit + eps;
+            uint32_t ndbg = 0, at = 0;
+            while ((tLast <= tMax) && (T > min_T)) {
+                /* the ten nearest hits with t in (tLast + eps, tMax): the list is sorted, `at` only moves forward */
+                while (at < n && !(cands[at].t > tLast + eps)) at++;
+                int k = 0;
+                for (; k < K && at + (uint32_t)k < n && cands[at + k].t < tMax; ++k) {}
+                if (k == 0) break;
+                for (int i = 0; i < k; ++i) {
+                    const bary_hit* h = &cands[at + i];
+                    if (T > min_T) {
+                        const real* pdn = density12 + 12 * (size_t)h->id;
+                        const real density = pdn[3];
+                        const real response = scaled_response(degree, clamped, h->sq, scale_min, density);
+                        const real alpha = r_min(R_(0.99), response * density);
+                        if ((response > hit_min) && (alpha > (real)cfg->particle_kernel_min_alpha)) {
+                            const real weight = alpha * T;
+                            const v3 c = v3_max0(sh_radiance_unclamped(sph_deg, sph + (size_t)h->id * 3 * ncoef, d));
+                            rad = v3_add(rad, v3_scale(c, weight));
+                            T *= (1 - alpha);
+                            depth += h->t * weight;
+#pragma omp atomic write
+                            visibility[h->id] = 1;
+                            if (cfg->enable_normals) {   /* the surfel's normal as the trisurfel kernel leaves it: normalize(cross(v1 - v0, v2 - v0)) = -(third axis) */
+                                const grt_particle p = load_particle(pdn);
+                                const v3 n0 = v3_make(-p.rotT.r[2].x, -p.rotT.r[2].y, -p.rotT.r[2].z);
+                                const real sgn = v3_dot(n0, d) < 0 ? R_(-1.0) : R_(1.0);
+                                nrm = v3_add(nrm, v3_scale(n0, sgn * weight));
+                            }
+                            cnt += 1;
+                        }
+                        tLast = r_max(tLast, h->t);
+                        if (dbg_ids && ndbg < dbg_cap) dbg_ids[(size_t)r * dbg_cap + ndbg] = h->id;
+                        ndbg++;
+                    }
+                }
+                at += (uint32_t)k;
+            }
+            out_rad[3 * r] = rad.x; out_rad[3 * r + 1] = rad.y; out_rad[3 * r + 2] = rad.z;
+            out_dns[r] = 1 - T;
+            out_hit2[2 * r] = depth; out_hit2[2 * r + 1] = tLast;
+            if (cfg->enable_normals) { out_nrm[3 * r] = nrm.x; out_nrm[3 * r + 1] = nrm.y; out_nrm[3 * r + 2] = nrm.z; }
+            if (cfg->enable_hitcounts) out_cnt[r] = cnt;
+            if (dbg_count) dbg_count[r] = ndbg;
+        }
+        free(cands);
+    }
+    return 0;
+}
+
 /* __raygen__rg, referenceOptix.cu:103-186.  rays are [nrays,3] in ray space; outputs per ray.
  * dbg_ids (optional): [nrays, dbg_cap] processed candidates in order; dbg_count [nrays]. */
 int orc_grt_trace_fwd(const GrtConfig* cfg, uint32_t N, const real* density12, const real* sph, int sph_deg, real min_T,
@@ -566,6 +679,9 @@ int orc_grt_trace_fwd(const GrtConfig* cfg, uint32_t N, const real* density12, c
                       const real* ray_d, real* out_rad, real* out_dns, real* out_hit2, real* out_nrm, real* out_cnt,
                       int32_t* visibility, uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap) {
     orc_grt_set_primitive(cfg->primitive_type);
+    if (cfg->pipeline_type == GRUT_PIPELINE_BARYCENTRIC_SURFELS)
+        return cfg->primitive_type == 6 ? trace_bary_fwd(cfg, N, density12, sph, sph_deg, min_T, inst12, scene6, ray_to_world12, nrays, ray_o, ray_d, out_rad, out_dns,
+                                                         out_hit2, out_nrm, out_cnt, visibility, dbg_ids, dbg_count, dbg_cap) : -2;
     const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
     if (K > GRT_MAX_K) return -1;
     const int ncoef = (cfg->particle_radiance_sph_degree + 1) * (cfg->particle_radiance_sph_degree + 1);

@@ -97,6 +97,7 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
         // the last hit distance itself in fp32 - a hit AT tmin reported again would never let the round loop advance
         if (!(t > g_optix.tmin && t < g_optix.tmax)) continue;
         g_optix.primitive = f;
+        g_optix.barycentrics = float2{u, v};   // (read by the surfel pipeline's any-hit program only, barycentricSurfelsOptix.cu:210)
         optixReportIntersection(t, 0);
     }
     return;
@@ -149,6 +150,7 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
     }
     return;
 #endif
+#ifndef SHIM_OPTIX_NO_INTERSECTION_PROGRAM   // (the surfel pipeline has triangles only: no __intersection__is to run)
     for (uint32_t k = 0, nk = cand_count(g_scene.n); k < nk; ++k) {
         const uint32_t i = cand_at(k);
         const float* m = &g_scene.inv[12 * (size_t)i];
@@ -165,6 +167,7 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
         g_optix.instance = i; g_optix.objectOrigin = oo; g_optix.objectDirection = od;
         __intersection__is();
     }
+#endif
 }
 
 // instance matrices (object -> world, row-major 3x4, as the reference's instance kernel writes them) -> inverse maps

@@ -46,6 +46,18 @@ void ref_enclosing_spheres(unsigned n, const float* pos, const float* rot, const
     }
 }
 
+// the trisurfel meshes together with the per-particle {normal, density} rows the surfel pipeline reads (params.particleExtendedData,
+// optixTracer.cpp:735-748, 937): vertices [n * 4, 3], triangles [n * 2, 3], normal_density [n, 4]
+void ref_enclosing_trisurfels(unsigned n, const float* pos, const float* rot, const float* scl, const float* dns, float min_response, unsigned opts, float degree,
+                              float* vertices, int* triangles, float* normal_density) {
+    blockDim.x = 1; threadIdx.x = 0;
+    for (unsigned i = 0; i < n; ++i) {
+        blockIdx.x = i;
+        computeGaussianEnclosingTriSurfelKernel<false>(n, (const float3*)pos, (const float4*)rot, (const float3*)scl, dns, min_response, opts, degree, (float3*)vertices,
+                                                       (int3*)triangles, (float4*)normal_density);
+    }
+}
+
 // the triangle-mesh proxies: prim 1 icosahedron, 2 octahedron, 3 tetrahedron, 4 diamond (GRUT_PRIM_*), 6 trisurfel, 7 trihexa (checker only) -> vertices [n * V, 3] in world space,
 // triangles [n * T, 3] (indices into all vertices), written by the reference's own mesh kernel of that type.  Returns T (V through *num_vertices).
 unsigned ref_enclosing_mesh(int prim, unsigned n, const float* pos, const float* rot, const float* scl, const float* dns, float min_response, unsigned opts,

@@ -50,6 +50,7 @@ enum { OPTIX_RAY_FLAG_DISABLE_ANYHIT = 1 << 0 };
 void optixTrace(OptixTraversableHandle handle, float3 origin, float3 direction, float tmin, float tmax, float time, OptixVisibilityMask mask,
                 unsigned flags, unsigned sbtOffset, unsigned sbtStride, unsigned missIndex, uint32_t& p0, uint32_t& p1);
 #elif defined(SHIM_OPTIX_TRIANGLE_PROXIES) || defined(SHIM_OPTIX_CUSTOM_PROXIES) || defined(SHIM_OPTIX_SPHERE_PROXIES)
+inline float2 optixGetTriangleBarycentrics() { return g_optix.barycentrics; }   // of the reported triangle hit: hit = (1 - u - v) V0 + u V1 + v V2 (barycentricSurfelsOptix.cu:210)
 inline unsigned optixGetPrimitiveIndex() { return g_optix.primitive; }   // the hit triangle of the particles' triangle GAS (optixTracer.cpp:836-845) / the particle's custom primitive (:810-817)
 #else
 inline unsigned optixGetPrimitiveIndex() { return 0; }   // the instanced BLAS holds one custom primitive (optixTracer.cpp:551-563)
@@ -76,4 +77,15 @@ void optixTrace(OptixTraversableHandle handle, float3 origin, float3 direction, 
                 uint32_t& p13, uint32_t& p14, uint32_t& p15, uint32_t& p16, uint32_t& p17, uint32_t& p18, uint32_t& p19, uint32_t& p20,
                 uint32_t& p21, uint32_t& p22, uint32_t& p23, uint32_t& p24, uint32_t& p25, uint32_t& p26, uint32_t& p27, uint32_t& p28,
                 uint32_t& p29, uint32_t& p30, uint32_t& p31);
+// the 30-register trace of barycentricSurfelsOptix.cu:58-68 (ten hits x {particle, distance, squared distance})
+inline void optixTrace(OptixTraversableHandle handle, float3 origin, float3 direction, float tmin, float tmax, float time, OptixVisibilityMask mask,
+                       unsigned flags, unsigned sbtOffset, unsigned sbtStride, unsigned missIndex, uint32_t& p0, uint32_t& p1, uint32_t& p2, uint32_t& p3,
+                       uint32_t& p4, uint32_t& p5, uint32_t& p6, uint32_t& p7, uint32_t& p8, uint32_t& p9, uint32_t& p10, uint32_t& p11, uint32_t& p12,
+                       uint32_t& p13, uint32_t& p14, uint32_t& p15, uint32_t& p16, uint32_t& p17, uint32_t& p18, uint32_t& p19, uint32_t& p20,
+                       uint32_t& p21, uint32_t& p22, uint32_t& p23, uint32_t& p24, uint32_t& p25, uint32_t& p26, uint32_t& p27, uint32_t& p28,
+                       uint32_t& p29) {
+    uint32_t unused30 = 0, unused31 = 0;
+    optixTrace(handle, origin, direction, tmin, tmax, time, mask, flags, sbtOffset, sbtStride, missIndex, p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10, p11, p12,
+               p13, p14, p15, p16, p17, p18, p19, p20, p21, p22, p23, p24, p25, p26, p27, p28, p29, unused30, unused31);
+}
 #endif

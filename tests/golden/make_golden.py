@@ -453,6 +453,39 @@ def make_grt_trace_sphere():
     print("wrote grt_trace_sphere.npz")
 
 
+def make_grt_trace_bary():
+    """tests/golden/grt_trace_bary.npz: the reference's surfel forward pipeline (render.pipeline_type barycentricSurfels:
+    barycentricSurfelsOptix.cu - ten hits per trace, the response from the hit triangle's barycentrics) over the emulated OptiX's triangles
+    (no face culling), trisurfel meshes and {normal, density} rows from the reference's own kernel.  Both scenes of GRT_TRACE_SCENES.  The
+    reference has no backward program for this pipeline."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenes import make_scene
+    px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
+    fw = C.CDLL(os.path.join(REF, "libref_grt_trace_bary_deg4.so"))
+    out = {}
+    for k, kw in enumerate(GRT_TRACE_SCENES):
+        sc = make_scene(**kw)
+        d12, sph = np.ascontiguousarray(sc["density12"]), np.ascontiguousarray(sc["sph"])
+        n, H, W = len(d12), kw["height"], kw["width"]
+        pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
+                              np.ascontiguousarray(d12[:, 3]))
+        verts, tris, nd = np.zeros((n * 4, 3), F), np.zeros((n * 2, 3), np.int32), np.zeros((n, 4), F)
+        px.ref_enclosing_trisurfels(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(verts), _p(tris), _p(nd))
+        box = np.concatenate([verts.min(0), verts.max(0)]).astype(F)
+        r2w = np.ascontiguousarray(np.asarray(sc["batch"]["T_to_world"][0], F)[:3, :4])
+        ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)) for a in sc["rays"])
+        feat, den, hit, nrm = np.zeros((H, W, 3), F), np.zeros((H, W, 1), F), np.zeros((H, W, 2), F), np.zeros((H, W, 3), F)
+        cnt, vis = np.zeros((H, W, 1), F), np.zeros(n, np.int32)
+        fw.ref_grt_trace_bary_fwd(C.c_uint(n), _p(verts), _p(tris), _p(nd), _p(d12), _p(sph), W, H, _p(r2w), _p(ro), _p(rd), _p(box), C.c_float(MIN_T_GRT),
+                                  C.c_float(MIN_RESPONSE), C.c_float(MIN_ALPHA), C.c_uint(3), _p(feat), _p(den), _p(hit), _p(nrm), _p(cnt), _p(vis))
+        for key, a in dict(features=feat, density=den, hit_distance=hit, normals=nrm, hits_count=cnt, visibility=vis, scene_box=box, normal_density=nd).items():
+            out[f"bary_s{k}_{key}"] = a
+        print(f"barycentricSurfels scene {k}: hits per ray {cnt.mean():.1f} (max {cnt.max():.0f}), opacity {den.mean():.3f}")
+    np.savez_compressed(os.path.join(HERE, "grt_trace_bary.npz"), **out)
+    print("wrote grt_trace_bary.npz")
+
+
 def make_grt_trace_nht():
     """tests/golden/grt_trace_nht.npz: the reference's SLANG forward pipeline (referenceSlangOptix.cu: raygen round loop, intersection, any-hit
     k-buffer) in the neural-harmonic-features configuration, on the host over the emulated OptiX (oracle/ref/ref_grt_trace_slang.cpp), on the
@@ -497,31 +530,40 @@ def make_grt_trace_nht_mesh():
     from scenes import make_scene
     px = C.CDLL(os.path.join(REF, "libref_grt_proxies.so"))
     px.ref_enclosing_mesh.restype = C.c_uint
-    fw = C.CDLL(os.path.join(REF, "libref_grt_trace_slang_IcosaHedron_deg4.so"))
-    assert fw.ref_grt_slang_ray_feature_dim() == 24
     out = {}
-    code, _ = MESH_PRIMITIVES["icosahedron"]
-    for k, kw in enumerate(GRT_TRACE_SCENES[:1]):
-        sc = make_scene(**kw)
-        d12 = np.ascontiguousarray(sc["density12"])
-        n, H, W = len(d12), kw["height"], kw["width"]
-        feats = nht_features(n, seed=55 + k)
-        pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
-                              np.ascontiguousarray(d12[:, 3]))
-        verts, tris, nv = np.zeros((n * 12, 3), F), np.zeros((n * 20, 3), np.int32), C.c_uint(0)
-        nt = px.ref_enclosing_mesh(code, C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(verts), _p(tris),
-                                   C.byref(nv))
-        verts, tris = np.ascontiguousarray(verts[:n * nv.value]), np.ascontiguousarray(tris[:n * nt])
-        box = np.concatenate([verts.min(0), verts.max(0)]).astype(F)
-        r2w = np.ascontiguousarray(np.asarray(sc["batch"]["T_to_world"][0], F)[:3, :4])
-        ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)) for a in sc["rays"])
-        feat, den, hit = np.zeros((H, W, 24), F), np.zeros((H, W, 1), F), np.zeros((H, W, 2), F)
-        cnt, vis = np.zeros((H, W, 1), F), np.zeros(n, np.int32)
-        fw.ref_grt_trace_slang_fwd_mesh(C.c_uint(n), C.c_uint(nt), _p(verts), _p(tris), _p(d12), _p(feats), W, H, _p(r2w), _p(ro), _p(rd), _p(box),
-                                        C.c_float(MIN_T_GRT), C.c_float(MIN_RESPONSE), C.c_float(MIN_ALPHA), _p(feat), _p(den), _p(hit), _p(cnt), _p(vis))
-        for name, a in dict(nht_features=feats, features=feat, density=den, hit_distance=hit, hits_count=cnt, visibility=vis, scene_box=box).items():
-            out[f"icosahedron_s{k}_{name}"] = a
-        print(f"grt nht icosahedron scene {k}: hits per ray {cnt.mean():.1f}, |features| mean {np.abs(feat).mean():.3f}")
+    # round 6: the trihexa proxies (three offers per particle) and OptiX's built-in spheres (two offers) through the same Slang programs
+    for prim, tag in (("icosahedron", "IcosaHedron"), ("trihexa", "TriHexa"), ("sphere", "Sphere")):
+        fw = C.CDLL(os.path.join(REF, f"libref_grt_trace_slang_{tag}_deg4.so"))
+        assert fw.ref_grt_slang_ray_feature_dim() == 24
+        for k, kw in enumerate(GRT_TRACE_SCENES[:1]):
+            sc = make_scene(**kw)
+            d12 = np.ascontiguousarray(sc["density12"])
+            n, H, W = len(d12), kw["height"], kw["width"]
+            feats = nht_features(n, seed=55 + k)
+            pos, rot, scl, dns = (np.ascontiguousarray(d12[:, 0:3]), np.ascontiguousarray(d12[:, 4:8]), np.ascontiguousarray(d12[:, 8:11]),
+                                  np.ascontiguousarray(d12[:, 3]))
+            r2w = np.ascontiguousarray(np.asarray(sc["batch"]["T_to_world"][0], F)[:3, :4])
+            ro, rd = (np.ascontiguousarray(a.reshape(H, W, 3)) for a in sc["rays"])
+            feat, den, hit = np.zeros((H, W, 24), F), np.zeros((H, W, 1), F), np.zeros((H, W, 2), F)
+            cnt, vis = np.zeros((H, W, 1), F), np.zeros(n, np.int32)
+            tail = (W, H, _p(r2w), _p(ro), _p(rd))
+            tail2 = (C.c_float(MIN_T_GRT), C.c_float(MIN_RESPONSE), C.c_float(MIN_ALPHA), _p(feat), _p(den), _p(hit), _p(cnt), _p(vis))
+            if prim == "sphere":
+                ctr, rad = np.zeros((n, 3), F), np.zeros(n, F)
+                px.ref_enclosing_spheres(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(ctr), _p(rad))
+                box = np.concatenate([(ctr - rad[:, None]).min(0), (ctr + rad[:, None]).max(0)]).astype(F)
+                fw.ref_grt_trace_slang_fwd_sphere(C.c_uint(n), _p(ctr), _p(rad), _p(d12), _p(feats), *tail, _p(box), *tail2)
+            else:
+                code, _ = MESH_PRIMITIVES[prim]
+                verts, tris, nv = np.zeros((n * 12, 3), F), np.zeros((n * 20, 3), np.int32), C.c_uint(0)
+                nt = px.ref_enclosing_mesh(code, C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(verts), _p(tris),
+                                           C.byref(nv))
+                verts, tris = np.ascontiguousarray(verts[:n * nv.value]), np.ascontiguousarray(tris[:n * nt])
+                box = np.concatenate([verts.min(0), verts.max(0)]).astype(F)
+                fw.ref_grt_trace_slang_fwd_mesh(C.c_uint(n), C.c_uint(nt), _p(verts), _p(tris), _p(d12), _p(feats), *tail, _p(box), *tail2)
+            for name, a in dict(nht_features=feats, features=feat, density=den, hit_distance=hit, hits_count=cnt, visibility=vis, scene_box=box).items():
+                out[f"{prim}_s{k}_{name}"] = a
+            print(f"grt nht {prim} scene {k}: hits per ray {cnt.mean():.1f}, |features| mean {np.abs(feat).mean():.3f}")
     np.savez_compressed(os.path.join(HERE, "grt_trace_nht_mesh.npz"), **out)
     print("wrote grt_trace_nht_mesh.npz")
 
@@ -864,7 +906,7 @@ def make_playground():
 if __name__ == "__main__":
     import sys
     only = [a for a in sys.argv[1:] if a.startswith("--only=")]
-    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "grt_trace_mesh", "gut_render", "playground", "gut_nht", "grt_trace_nht", "grt_trace_nht_mesh", "grt_trace_slang_sh", "grt_trace_sphere"]
+    which = only[0][len("--only="):].split(",") if only else ["per_hit", "adam", "camera", "projector", "grt_proxies", "grt_trace", "grt_trace_mesh", "gut_render", "playground", "gut_nht", "grt_trace_nht", "grt_trace_nht_mesh", "grt_trace_slang_sh", "grt_trace_sphere", "grt_trace_bary"]
     if "--adam-only" in sys.argv:
         which = ["adam"]
     if "per_hit" in which:
@@ -896,3 +938,5 @@ if __name__ == "__main__":
         make_grt_trace_slang_sh()
     if "grt_trace_sphere" in which:
         make_grt_trace_sphere()
+    if "grt_trace_bary" in which:
+        make_grt_trace_bary()

@@ -643,6 +643,79 @@ def test_sphere_matches_reference_programs_golden_and_the_oracle():
     assert all(max(m[f"grad_replay_{r}"]) < 1e-3 for r in (True, False)), m
 
 
+def test_barycentric_surfels_forward_matches_reference_program_golden_and_the_oracle():
+    """render.pipeline_type = barycentricSurfels with render.primitive_type = trisurfel (round 6): the surfel FORWARD pipeline - ten hits per
+    trace, the response from the crossing's squared distance in the proxy frame, depth from the hit distances, the surfel's normals.  (i) DIRECTLY
+    against tests/golden/grt_trace_bary.npz = barycentricSurfelsOptix.cu over the emulated OptiX's triangles, both scenes; (ii) every ray's sequence
+    of processed particles and the images against the oracle given the GPU-built proxy records, packet lists = tree walk; (iii) the backward is
+    refused (the reference ships no backward program for this pipeline)."""
+    import os
+    import sys
+    import torch
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_golden
+    g = np.load(os.path.join(here, "golden", "grt_trace_bary.npz"))
+    kw_r = dict(primitive_type="trisurfel", pipeline_type="barycentricSurfels", enable_normals=True)
+    for k, kw in enumerate(make_golden.GRT_TRACE_SCENES):
+        scene = make_scene(**kw)
+        tr = _tracer(**kw_r)
+        gs = syn.SimpleGaussians(scene["density12"], scene["sph"], requires_grad=False)
+        tr.build_acc(gs, rebuild=True)
+        with torch.no_grad():
+            out = tr.render(gs, torch_batch(scene["batch"], "cuda"))
+        assert int(tr.tracer_wrapper.stats().list_entries) > 0
+        cnt = out["hits_count"][0].cpu().numpy()
+        flips = (cnt != g[f"bary_s{k}_hits_count"])[..., 0]
+        assert flips.mean() <= 0.01 and cnt.max() >= 20, f"scene {k}: {int(flips.sum())} rays with a different number of accepted hits"
+        ok = ~flips
+        assert np.abs(out["pred_features"][0].cpu().numpy() - g[f"bary_s{k}_features"])[ok].max() < 1e-4
+        assert np.abs(out["pred_opacity"][0].cpu().numpy() - g[f"bary_s{k}_density"])[ok].max() < 1e-4
+        hd = g[f"bary_s{k}_hit_distance"]
+        assert np.abs(out["pred_dist"][0].cpu().numpy() - hd[..., :1])[ok].max() <= 1e-4 * max(1.0, np.abs(hd).max())
+        gn = g[f"bary_s{k}_normals"]
+        gl = np.linalg.norm(gn, axis=-1, keepdims=True)     # (the plugin returns the integrated normal NORMALISED, tracer.py:346)
+        sel = ok & (gl[..., 0] > 0.05)
+        assert sel.sum() > 0.5 * ok.sum() and np.abs(out["pred_normals"][0].cpu().numpy() - gn / np.maximum(gl, 1e-12))[sel].max() < 2e-3
+        vis = out["mog_visibility"].view(-1).view(torch.int32).cpu().numpy() != 0
+        assert (vis != (g[f"bary_s{k}_visibility"] != 0)).sum() <= 3 * int(flips.sum())
+    # (ii) sequences against the oracle, lists against the walk
+    scene = _scene(4000, 64, 48, 0.06)
+    tr, (feat, dns, hit, nrm, cnt, vis, ids, num), inst, scene_aabb = _gpu_hits(scene, **kw_r)
+    cfg = oracle.default_grt_config(primitive_type=6, pipeline_type=1, enable_normals=1)
+    ora = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=scene_aabb, dbg_cap=256)
+    num = num.astype(np.int64)
+    assert np.array_equal(num, ora["hit_num"].astype(np.int64)), f"{(num != ora['hit_num']).sum()} rays with a different number of processed hits"
+    kk = np.minimum(num, 256)
+    got, ref = ids.view(np.uint32), ora["hit_ids"]
+    for r in range(scene["H"] * scene["W"]):
+        assert np.array_equal(got[r, :kk[r]], ref[r, :kk[r]]), f"ray {r}: order differs"
+    flips = (cnt[0] != ora["hit_count"])[..., 0]
+    assert flips.sum() <= max(2, 2e-3 * flips.size) and num.max() > 20
+    assert np.abs(feat[0] - ora["features"])[~flips].max() < 1e-4 and np.abs(dns[0] - ora["density"])[~flips].max() < 1e-4
+    assert np.abs(nrm[0] - ora["normals"])[~flips].max() < 1e-4
+    assert (np.abs(hit[0] - ora["hit_distance"]) / np.maximum(1.0, np.abs(ora["hit_distance"])))[~flips].max() < 1e-4
+
+
+def test_barycentric_surfels_lists_equal_the_tree_walk_and_the_backward_is_refused(monkeypatch):
+    import torch
+    kw_r = dict(primitive_type="trisurfel", pipeline_type="barycentricSurfels")
+    scene = _scene(20000, 100, 60, 0.03)
+    (a, n_lists), (b, n_walk) = _hits_with(scene, monkeypatch, False, **kw_r), _hits_with(scene, monkeypatch, True, **kw_r)
+    assert n_lists > 0 and n_walk == 0
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    tr = _tracer(**kw_r)
+    gs = syn.SimpleGaussians(scene["density12"], scene["sph"])
+    tr.build_acc(gs, rebuild=True)
+    out = tr.render(gs, torch_batch(scene["batch"], "cuda"), train=True)
+    with pytest.raises(RuntimeError, match="forward only"):
+        out["pred_features"].sum().backward()
+    grt = importlib.import_module("3dgrut_amd.grt_tracer")
+    with pytest.raises(NotImplementedError, match="trisurfel"):
+        grt.Tracer({"render": {"pipeline_type": "barycentricSurfels"}})
+
+
 def test_unsupported_primitives_are_refused():
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     for prim in ("dodecahedron", "cube"):
@@ -651,13 +724,16 @@ def test_unsupported_primitives_are_refused():
 
 
 def test_c_abi_refuses_feature_kernels_on_open_proxies():
-    """Round 6 (advisor): the plugin refuses neural harmonic features on custom / trisurfel / trihexa (grt_config_from_conf); the C-ABI must too -
-    its feature kernels index the feature rows by the log's proxy id (3 N of them for trihexa: out of bounds)."""
+    """Round 6 (advisor): the plugin refuses neural harmonic features on custom / trisurfel (grt_config_from_conf); the C-ABI must too - trisurfel
+    would blend at the volumetric intersection instead of the surfel's plane crossing, the Slang pipeline's custom-primitive test is another
+    one than GRUT_PRIM_CUSTOM's.  (trihexa and sphere are served since the feature kernels map the log's proxy ids to particles.)"""
     import ctypes as C
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     abi = importlib.import_module("3dgrut_amd._abi")
     lib = abi.load_library()
-    for prim in ("custom", "trisurfel", "trihexa"):
+    for prim in ("custom", "trisurfel"):
+        with pytest.raises(NotImplementedError, match="neural harmonic"):
+            grt.grt_config_from_conf({"render": {"pipeline_type": "referenceSlang", "primitive_type": prim}, "model": NHT_CONF})
         cfg = grt.grt_config_from_conf({"render": {"pipeline_type": "referenceSlang"}, "model": NHT_CONF})
         cfg.primitive_type = abi.GRT_PRIMITIVES[prim]
         handle = C.c_void_p()
@@ -1019,8 +1095,10 @@ def test_nht_backward_matches_oracle(replay, half):
     assert trimmed(gf, rf, 3 * n_flip) < 1e-3 and gf.shape == (n, 48) and np.abs(rf).max() > 0
 
 
-def test_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden_and_the_oracle():
-    """model.feature_type = nht with render.primitive_type = icosahedron (round 5; refused until then): the forward DIRECTLY against
+@pytest.mark.parametrize("prim,code", [("icosahedron", 1), ("trihexa", 7), ("sphere", 8)])
+def test_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden_and_the_oracle(prim, code):
+    """(round 6: also trihexa and sphere - several proxies per particle, the feature kernels map the log's proxy ids to particles.)
+    model.feature_type = nht with render.primitive_type = icosahedron (round 5; refused until then): the forward DIRECTLY against
     tests/golden/grt_trace_nht_mesh.npz = the reference's Slang forward programs compiled for MOGTracingIcosaHedron over the emulated OptiX's
     triangles (tests/test_oracle_cpu.py pins the oracle on the same file), then forward and both backward paths against the oracle given the
     GPU-built proxy records."""
@@ -1033,32 +1111,32 @@ def test_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden_and_
     gold = np.load(os.path.join(here, "golden", "grt_trace_nht_mesh.npz"))
     kw = make_golden.GRT_TRACE_SCENES[0]
     scene = make_scene(**kw)
-    feats = gold["icosahedron_s0_nht_features"]
-    tr = _nht_tracer(primitive_type="icosahedron")
+    feats = gold[f"{prim}_s0_nht_features"]
+    tr = _nht_tracer(primitive_type=prim)
     g = syn.SimpleGaussians(scene["density12"], feats, requires_grad=False)
     tr.build_acc(g, rebuild=True)
     with torch.no_grad():
         out = tr.render(g, torch_batch(scene["batch"], "cuda"))
     cnt = out["hits_count"][0].cpu().numpy()
-    flips = (cnt != gold["icosahedron_s0_hits_count"])[..., 0]
+    flips = (cnt != gold[f"{prim}_s0_hits_count"])[..., 0]
     assert flips.mean() <= 0.01, f"{int(flips.sum())} rays with a different number of accepted hits"
-    e = np.abs(out["pred_features"][0].cpu().numpy() - gold["icosahedron_s0_features"]).max(-1)
+    e = np.abs(out["pred_features"][0].cpu().numpy() - gold[f"{prim}_s0_features"]).max(-1)
     tied = ~flips & (e > 1e-4)
     assert tied.mean() <= 0.02 and (not tied.any() or e[tied].max() < 5e-2), (int(tied.sum()), float(e.max()))
     ok = ~flips & ~tied
-    assert np.abs(out["pred_opacity"][0].cpu().numpy() - gold["icosahedron_s0_density"])[ok].max() < 1e-4
-    assert np.abs(gold["icosahedron_s0_features"]).max() > 0.5 and cnt.max() >= 15
+    assert np.abs(out["pred_opacity"][0].cpu().numpy() - gold[f"{prim}_s0_density"])[ok].max() < 1e-4
+    assert np.abs(gold[f"{prim}_s0_features"]).max() > 0.5 and cnt.max() >= 15
     # against the oracle on a second scene, with gradients through both backward paths
     n, w, h = 2500, 56, 40
     scene = _scene(n, w, h, 0.07)
     feats = np.random.default_rng(21).uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)
-    cfg = oracle.default_grt_config(primitive_type=1)
+    cfg = oracle.default_grt_config(primitive_type=code)
     rng = np.random.default_rng(4)
     g_f = rng.normal(size=(h, w, 24)).astype(np.float32)
     g_d = rng.normal(size=(h, w, 1)).astype(np.float32)
     g_h = (rng.normal(size=(h, w, 1)) * 0.1).astype(np.float32)
     for replay in (True, False):
-        tr = _nht_tracer(primitive_type="icosahedron", backward_hit_replay=replay)
+        tr = _nht_tracer(primitive_type=prim, backward_hit_replay=replay)
         g = syn.SimpleGaussians(scene["density12"], feats)
         tr.build_acc(g, rebuild=True)
         out = tr.render(g, torch_batch(scene["batch"], "cuda"), train=True)

@@ -193,8 +193,11 @@ def test_grt_configuration_defaults_and_unsupported_pipelines():
     # the closed triangle-mesh proxies of particlePrimitives.cu (icosahedron = the paper's configuration), the custom primitives and the flat trisurfel proxies are provided
     assert [grt.grt_config_from_conf({"render": {"primitive_type": p}}).primitive_type
             for p in ("instances", "icosahedron", "octahedron", "tetrahedron", "diamond", "custom", "trisurfel", "trihexa", "sphere")] == [0, 1, 2, 3, 4, 5, 6, 7, 8]
+    # the surfel forward pipeline (round 6): trisurfel proxies only, ten hits per trace
+    bary = grt.grt_config_from_conf({"render": {"pipeline_type": "barycentricSurfels", "primitive_type": "trisurfel"}})
+    assert (bary.pipeline_type, bary.primitive_type, bary.max_hits_per_trace) == (1, 6, 10) and cfg.pipeline_type == 0
     for bad in ({"pipeline_type": "fullStochastic"}, {"primitive_type": "dodecahedron"}, {"backward_pipeline_type": "referenceB2FSlangBwd"},
-                {"pipeline_type": "barycentricSurfels"}):
+                {"pipeline_type": "barycentricSurfels"}, {"pipeline_type": "barycentricSurfels", "primitive_type": "icosahedron"}):
         with pytest.raises(NotImplementedError):
             grt.grt_config_from_conf({"render": bad})
 

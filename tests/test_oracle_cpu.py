@@ -635,6 +635,41 @@ def test_grt_sphere_checker_matches_reference_programs_golden():
         assert np.abs(gs - rs).max() / np.abs(rs).max() < 2e-5
 
 
+def test_grt_barycentric_surfels_checker_matches_reference_program_golden():
+    """render.pipeline_type = barycentricSurfels (round 6): the reference's surfel forward program (barycentricSurfelsOptix.cu: ten hits per trace,
+    the response from the hit triangle's barycentrics, depth from the triangle hit distances, the surfel kernel's normals) over the emulated
+    OptiX's triangles - tests/golden/grt_trace_bary.npz - against the checker's restatement (oracle/grt_oracle.c: trace_bary_fwd), both scenes.
+    The checker evaluates the plane crossing in the proxy frame, the reference Moeller-Trumbore on float32 world vertices: roundings differ."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    g = np.load(os.path.join(HERE, "golden", "grt_trace_bary.npz"))
+    cfg = oracle.default_grt_config(primitive_type=6, pipeline_type=1, enable_normals=1)
+    for k, kw in enumerate(make_golden.GRT_TRACE_SCENES):
+        sc = make_scene(**kw)
+        o = oracle.grt_forward(cfg, sc["density12"], sc["sph"], 3, 1e-3, sc["batch"]["T_to_world"][0], *sc["rays"])
+        ref_cnt = g[f"bary_s{k}_hits_count"]
+        flips = (o["hit_count"] != ref_cnt)[..., 0]
+        assert flips.mean() <= 0.01 and ref_cnt.max() >= 20, f"scene {k}: {int(flips.sum())} rays with another number of accepted hits"
+        ok = ~flips
+        assert np.abs(o["features"] - g[f"bary_s{k}_features"])[ok].max() < 5e-5
+        assert np.abs(o["density"] - g[f"bary_s{k}_density"])[ok].max() < 5e-5
+        hd = g[f"bary_s{k}_hit_distance"]
+        assert np.abs(o["hit_distance"] - hd)[ok].max() <= 5e-5 * max(1.0, np.abs(hd).max())
+        assert np.abs(o["normals"] - g[f"bary_s{k}_normals"])[ok].max() < 5e-5
+        assert ((o["visibility"] != 0) != (g[f"bary_s{k}_visibility"] != 0)).sum() <= 3 * int(flips.sum())
+        # a cross-check program against program: the `reference` pipeline's trisurfel frame integrates the SAME function - the scaled response at
+        # the plane crossing is processHit's surfel response in another frame, the triangle hit distance is the crossing's distance - in rounds of
+        # sixteen instead of ten (the normals differ: this pipeline flips the surfel's normal ALONG the ray, :160-164)
+        tri = np.load(os.path.join(HERE, "golden", "grt_trace_mesh.npz"))
+        if k == 0:
+            assert np.abs(g["bary_s0_features"] - tri["trisurfel_s0_features"]).max() < 1e-4
+            assert np.abs(g["bary_s0_hit_distance"] - tri["trisurfel_s0_hit_distance"]).max() < 1e-4
+    # another primitive with this pipeline: refused by the checker as by the plugin
+    bad = oracle.default_grt_config(primitive_type=0, pipeline_type=1)
+    with pytest.raises(AssertionError):
+        oracle.grt_forward(bad, sc["density12"], sc["sph"], 3, 1e-3, sc["batch"]["T_to_world"][0], *sc["rays"])
+
+
 def test_grt_custom_primitives_match_reference_programs_golden():
     """render.primitive_type = custom: the oracle (world boxes of computeGaussianEnclosingAABBKernel + the maximum-response point within
     3 sigma, orc_grt_custom_boxes / candidate) against tests/golden/grt_trace_mesh.npz `custom_*` = the reference's programs compiled with
@@ -1060,8 +1095,10 @@ def test_grt_nht_forward_matches_reference_slang_programs_golden():
         assert g[f"s{k}_hits_count"].max() >= 20 and np.abs(g[f"s{k}_features"]).max() > 0.5
 
 
-def test_grt_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden():
-    """model.feature_type = nht together with render.primitive_type = icosahedron (round 5): orc_grt_trace_nht_fwd with the polyhedron clip as
+@pytest.mark.parametrize("prim,code", [("icosahedron", 1), ("trihexa", 7), ("sphere", 8)])
+def test_grt_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden(prim, code):
+    """(round 6: also trihexa - three offers per particle - and sphere - two - built the same way: libref_grt_trace_slang_{TriHexa,Sphere}_deg4.so)
+    model.feature_type = nht together with render.primitive_type = icosahedron (round 5): orc_grt_trace_nht_fwd with the polyhedron clip as
     candidate test against tests/golden/grt_trace_nht_mesh.npz = the reference's Slang forward programs compiled for MOGTracingIcosaHedron
     over the emulated OptiX's built-in triangles (meshes from the reference's mesh kernel, back faces culled).  Like the SH meshes
     (test_grt_mesh_proxies_...): two roundings of the same entry distance - ideal polyhedron in the proxy frame vs float32 world
@@ -1069,23 +1106,23 @@ def test_grt_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden(
     sys.path.insert(0, os.path.join(HERE, "golden"))
     import make_golden
     g = np.load(os.path.join(HERE, "golden", "grt_trace_nht_mesh.npz"))
-    cfg = oracle.default_grt_config(primitive_type=1)
+    cfg = oracle.default_grt_config(primitive_type=code)
     kw = make_golden.GRT_TRACE_SCENES[0]
     sc = make_scene(**kw)
-    o = oracle.grt_forward_nht(cfg, sc["density12"], g["icosahedron_s0_nht_features"], 1e-3, sc["batch"]["T_to_world"][0], *sc["rays"])
-    flips = (o["hit_count"] != g["icosahedron_s0_hits_count"])[..., 0]
+    o = oracle.grt_forward_nht(cfg, sc["density12"], g[f"{prim}_s0_nht_features"], 1e-3, sc["batch"]["T_to_world"][0], *sc["rays"])
+    flips = (o["hit_count"] != g[f"{prim}_s0_hits_count"])[..., 0]
     assert flips.mean() <= 0.01, f"{int(flips.sum())} rays with another number of accepted hits"
-    e = np.abs(o["features"] - g["icosahedron_s0_features"]).max(-1)
+    e = np.abs(o["features"] - g[f"{prim}_s0_features"]).max(-1)
     tied = ~flips & (e > 1e-5)
     assert tied.mean() <= 0.02 and (not tied.any() or e[tied].max() < 5e-2), (int(tied.sum()), float(e[tied].max()) if tied.any() else 0.0)
     ok = ~flips & ~tied
-    assert np.abs(o["density"] - g["icosahedron_s0_density"])[ok].max() < 1e-5
-    hd = g["icosahedron_s0_hit_distance"]
+    assert np.abs(o["density"] - g[f"{prim}_s0_density"])[ok].max() < 1e-5
+    hd = g[f"{prim}_s0_hit_distance"]
     assert np.abs(o["hit_distance"] - hd)[ok].max() <= 2e-5 * max(1.0, np.abs(hd).max())
-    assert (o["visibility"] != 0).sum() > 0 and ((o["visibility"] != 0) != (g["icosahedron_s0_visibility"] != 0)).sum() <= 3 * int((flips | tied).sum())
+    assert (o["visibility"] != 0).sum() > 0 and ((o["visibility"] != 0) != (g[f"{prim}_s0_visibility"] != 0)).sum() <= 3 * int((flips | tied).sum())
     # not the instances' frame: the particle is offered at the distance the ray ENTERS its icosahedron
     inst = np.load(os.path.join(HERE, "golden", "grt_trace_nht.npz"))
-    assert np.abs(g["icosahedron_s0_features"] - inst["s0_features"]).max() > 1e-2 and g["icosahedron_s0_hits_count"].max() >= 15
+    assert np.abs(g[f"{prim}_s0_features"] - inst["s0_features"]).max() > (1e-2 if prim == "icosahedron" else 1e-4) and g[f"{prim}_s0_hits_count"].max() >= 15
 
 
 def test_slang_forward_with_sh_radiance_is_the_reference_forward():
