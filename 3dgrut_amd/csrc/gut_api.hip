@@ -98,7 +98,7 @@ static int validate_config(const GutConfig& c) {
     }
     if (c.feature_transform_type != 0) {
         GRUT_REQUIRE(c.feature_transform_type == 1, "feature_transform_type %d: 0 (SH) or 1 (neural harmonic features)", c.feature_transform_type);
-        GRUT_REQUIRE(c.k_buffer_size == 0, "neural harmonic features: k_buffer_size must be 0");
+        // (k_buffer_size > 0 with features: the sorted hit buffer in front of the feature integration, gutKBufferRenderer.cuh:158-225 - round 6)
         GRUT_REQUIRE(c.feature_interpolation_support == 0 || c.feature_interpolation_support == 1, "feature_interpolation_support must be 0 (centre) or 1 (tetrahedra)");
         GRUT_REQUIRE(c.feature_activation_type >= 0 && c.feature_activation_type <= 3, "feature_activation_type must be 0..3");
         const int points = c.feature_interpolation_support == 1 ? 4 : 1;

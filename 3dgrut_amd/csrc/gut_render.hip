@@ -2061,6 +2061,350 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Neural harmonic features behind the SORTED hit buffer (render.splat.k_buffer_size > 0 with model.feature_type = nht; round 6):
+// gutKBufferRenderer.cuh:273-352 (evalKBuffer) with Params::PerRayParticleFeatures - processHitParticle :158-225 integrates, per popped hit,
+// the features interpolated at the hit's canonical intersection.  The tile loop, the hit test, the hit distance in the checker's operation
+// order (it is the buffer's sort key) and the buffer itself are gut_render_k_body's; a popped hit is a (particle, alpha, distance) triple,
+// everything else the feature integration needs - the canonical intersection, the response for the gradient chain - is a function of
+// (ray, particle) and is evaluated again at the pop from the particle's own rows (the reference keeps the intersection in the buffer: the
+// same value).  The gradients leave per lane and hit with atomics, like the reference's (featuresIntegrateBwdToBuffer /
+// densityProcessHitBwdToBuffer); the per-hit arithmetic is the unsorted strip kernels' above, hit by hit.
+// ---------------------------------------------------------------------------------------------
+struct NhtTetra4 { f3 v0, e1, e2, e3, c23, gw0, gw1, gw2, gw3; float inv_det; };
+__device__ __forceinline__ NhtTetra4 nht_tetra4() {
+    NhtTetra4 t;
+    const float edge = 4.898979485566356f, face_h = 4.242640687119285f, face_in = 1.4142135623730951f;
+    const f3 v1 = mk3(-0.5f * edge, -face_in, -1.f), v2 = mk3(0.f, face_h - face_in, -1.f), v3 = mk3(0.f, 0.f, 3.f);
+    t.v0 = mk3(0.5f * edge, -face_in, -1.f);
+    t.e1 = v1 - t.v0; t.e2 = v2 - t.v0; t.e3 = v3 - t.v0;
+    t.c23 = cross(t.e2, t.e3);
+    t.inv_det = 1.f / dot(t.e1, t.c23);
+    t.gw1 = t.c23 * t.inv_det; t.gw2 = cross(t.e3, t.e1) * t.inv_det; t.gw3 = cross(t.e1, t.e2) * t.inv_det;
+    t.gw0 = (t.gw1 + t.gw2 + t.gw3) * -1.f;
+    return t;
+}
+__device__ __forceinline__ float nht_feature_word(const GutParams& P, const float* __restrict__ features, uint32_t idx, int word) {
+    const size_t at = (size_t)idx * P.nht_k + word;
+    return P.sph_half ? __half2float(reinterpret_cast<const __half*>(features)[at]) : features[at];
+}
+// feature i of the activation and its derivative with respect to its base feature kb (the unsorted strip kernels' rules)
+__device__ __forceinline__ void nht_activation_rt(const GutParams& P, const float (&base)[kNhtMaxIpd], int i, float& f, float& df, int& kb) {
+    const int nf = P.nht_nf;
+    if (P.nht_act == 0) { kb = i; f = base[kb < kNhtMaxIpd ? kb : 0]; df = 1.f; }
+    else if (P.nht_act == 3) { kb = i; const float bv = base[kb < kNhtMaxIpd ? kb : 0]; f = fmaxf(0.f, bv); df = bv > 0.f ? 1.f : 0.f; }
+    else if (P.nht_act == 2) {
+        kb = i / (2 * nf);
+        const int rem = i - kb * 2 * nf, fq = rem >> 1;
+        const float fr = (float)(fq + 1), ang = base[kb < kNhtMaxIpd ? kb : 0] * fr;
+        const float sn = nht_sin(ang), cs = nht_cos(ang);
+        f = (rem & 1) ? cs : sn; df = (rem & 1) ? -fr * sn : fr * cs;
+    } else {
+        kb = i / nf;
+        const float fr = ldexpf(1.f, i - kb * nf), ang = base[kb < kNhtMaxIpd ? kb : 0] * fr;
+        f = nht_sin(ang); df = fr * nht_cos(ang);
+    }
+}
+struct NhtKFwdState { float T, D, cnt; float acc[kNhtMaxRay]; };
+__device__ __forceinline__ void nht_k_pop_fwd(const GutParams& P, const Ray& ray, const NhtTetra4& tet, const float4* __restrict__ density12,
+                                              const float* __restrict__ features, float hitT, float alpha, uint32_t idx, NhtKFwdState& s, bool& alive) {
+    const float w = alpha * s.T;
+    s.D = fmaf(hitT, w, s.D);
+    s.T *= (1.f - alpha);
+    if (w > 0.f) {
+        const float4 a = density12[3 * (size_t)idx], q = density12[3 * (size_t)idx + 1], sc = density12[3 * (size_t)idx + 2];
+        const m3 rt = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
+        const f3 giscl = mk3(1.f / sc.x, 1.f / sc.y, 1.f / sc.z);
+        const f3 gro = giscl * mul_rows(rt, ray.o - mk3(a.x, a.y, a.z));
+        const f3 grdu = giscl * mul_rows(rt, ray.d);
+        const float along = -dot(grdu, gro) / dot(grdu, grdu);
+        const f3 Pc = gro + grdu * along;
+        float wq[4] = {1.f, 0.f, 0.f, 0.f};
+        if (P.nht_support == 1) {
+            const f3 d = Pc - tet.v0;
+            wq[1] = dot(d, tet.c23) * tet.inv_det; wq[2] = dot(tet.e1, cross(d, tet.e3)) * tet.inv_det; wq[3] = dot(tet.e1, cross(tet.e2, d)) * tet.inv_det;
+            wq[0] = 1.f - wq[1] - wq[2] - wq[3];
+        }
+        const int points = P.nht_support == 1 ? 4 : 1, ipd = P.nht_ipd, nr = P.nht_ray_dim;
+        float base[kNhtMaxIpd];
+#pragma unroll
+        for (int m = 0; m < kNhtMaxIpd; ++m) {
+            base[m] = 0.f;
+            if (m < ipd)
+                for (int k = 0; k < points; ++k) {
+                    const float fv = nht_feature_word(P, features, idx, k * ipd + m);
+                    base[m] = k == 0 ? fv * wq[0] : fmaf(wq[k], fv, base[m]);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < kNhtMaxRay; ++i) {
+            if (i < nr) {
+                float f, df; int kb;
+                nht_activation_rt(P, base, i, f, df, kb);
+                s.acc[i] = fmaf(f, w, s.acc[i]);
+            }
+        }
+        s.cnt += 1.f;
+    }
+    if (s.T < P.min_transmittance) alive = false;
+}
+struct NhtKBwdState { float Cb[kNhtMaxRay], gC[kNhtMaxRay], Tb, gT, Db, gD, T; };
+__device__ __forceinline__ void nht_k_pop_bwd(const GutParams& P, const Ray& ray, const NhtTetra4& tet, const float4* __restrict__ density12,
+                                              const float* __restrict__ features, float hitT, float alpha, uint32_t idx, NhtKBwdState& s, bool& alive,
+                                              float* __restrict__ g_density12, float* __restrict__ g_features) {
+    const int points = P.nht_support == 1 ? 4 : 1, ipd = P.nht_ipd, nr = P.nht_ray_dim;
+    const float4 a = density12[3 * (size_t)idx], q = density12[3 * (size_t)idx + 1], sc = density12[3 * (size_t)idx + 2];
+    const m3 rotT = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
+    const f3 gscl = mk3(sc.x, sc.y, sc.z), giscl = mk3(1.f / sc.x, 1.f / sc.y, 1.f / sc.z);
+    const f3 gposc = ray.o - mk3(a.x, a.y, a.z);
+    const f3 gposcr = mul_rows(rotT, gposc);
+    const f3 gro = giscl * gposcr;
+    const f3 rdr = mul_rows(rotT, ray.d);
+    const f3 grdu = giscl * rdr;
+    const float l2 = dot(grdu, grdu);
+    const float il = 1.f / sqrtf(l2);
+    const f3 grd = grdu * il;
+    const f3 gcrod = cross(grd, gro);
+    const float gray = dot(gcrod, gcrod);
+    const float gres = response_rt(P.degree, gray);
+    const float pdot = -dot(grd, gro);
+    const f3 grdd = grd * pdot;
+    const f3 Pc = gro + grdd;
+    const f3 grds = gscl * grdd;
+    const float gsq = dot(grds, grds);
+    const bool hit = alpha > 0.f;
+    float wq[4] = {1.f, 0.f, 0.f, 0.f};
+    if (P.nht_support == 1) {
+        const f3 d = Pc - tet.v0;
+        wq[1] = dot(d, tet.c23) * tet.inv_det; wq[2] = dot(tet.e1, cross(d, tet.e3)) * tet.inv_det; wq[3] = dot(tet.e1, cross(tet.e2, d)) * tet.inv_det;
+        wq[0] = 1.f - wq[1] - wq[2] - wq[3];
+    }
+    float base[kNhtMaxIpd], gbase[kNhtMaxIpd];
+#pragma unroll
+    for (int m = 0; m < kNhtMaxIpd; ++m) {
+        base[m] = 0.f; gbase[m] = 0.f;
+        if (m < ipd)
+            for (int k = 0; k < points; ++k) {
+                const float fv = nht_feature_word(P, features, idx, k * ipd + m);
+                base[m] = k == 0 ? fv * wq[0] : fmaf(wq[k], fv, base[m]);
+            }
+    }
+    const float w = 1.f / (1.f - alpha);
+    float dalpha = 0.f;
+    if (hit) {
+#pragma unroll
+        for (int i = 0; i < kNhtMaxRay; ++i) {
+            if (i < nr) {
+                float f, df; int kb;
+                nht_activation_rt(P, base, i, f, df, kb);
+                s.Cb[i] = (s.Cb[i] - f * alpha) * w;
+                dalpha = fmaf(f - s.Cb[i], s.gC[i], dalpha);
+                const float gf = alpha * s.gC[i];
+                s.gC[i] *= (1.f - alpha);
+#pragma unroll
+                for (int m = 0; m < kNhtMaxIpd; ++m)
+                    if (m == kb) gbase[m] = fmaf(df, gf, gbase[m]);
+            }
+        }
+    }
+    // blend backward: the feature rows (per-hit atomics, as the reference) and the canonical position
+    f3 dP = mk3(0.f, 0.f, 0.f);
+    if (hit) {
+        float dw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < kNhtMaxIpd; ++m)
+            if (m < ipd)
+                for (int k = 0; k < points; ++k) {
+                    dw[k] = fmaf(nht_feature_word(P, features, idx, k * ipd + m), gbase[m], dw[k]);
+                    const float g = wq[k] * gbase[m];
+                    if (g != 0.f) atomicAdd(g_features + (size_t)idx * P.nht_k + (size_t)k * ipd + m, g);
+                }
+        if (P.nht_support == 1) dP = tet.gw0 * dw[0] + tet.gw1 * dw[1] + tet.gw2 * dw[2] + tet.gw3 * dw[3];
+    }
+    // density: T_out = T_in (1 - alpha), D_front = lerp(D_behind, depth, alpha)
+    s.Tb *= w;
+    s.Db = (s.Db - hitT * alpha) * w;
+    dalpha += (hitT - s.Db) * s.gD - s.Tb * s.gT;
+    const float ddepth = alpha * s.gD;
+    s.gD *= (1.f - alpha);
+    s.gT *= (1.f - alpha);
+    if (hit) {
+        float dres = 0.f, ddens = 0.f;
+        if (gres * a.w < P.max_alpha) { dres = a.w * dalpha; ddens = gres * dalpha; }
+        const float grayGrd = response_grd_rt(P.degree, gray, gres, dres);
+        const f3 grdsGrd = gsq > 0.f ? grds * (ddepth / hitT) : mk3(0.f, 0.f, 0.f);
+        const f3 gsclHit = grdd * grdsGrd;
+        const float sdot = dot(grdsGrd * gscl, grd);
+        const float gdP = dot(grd, dP);
+        const f3 grdHit = gscl * grdsGrd * pdot - gro * sdot + dP * pdot - gro * gdP;
+        const f3 groHit = grd * (-sdot) + dP - grd * gdP;
+        const f3 gcrodGrd = gcrod * (2.f * grayGrd);
+        const f3 grdGrd = mk3(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
+        const f3 groGrd = mk3(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+        const f3 groTot = groGrd + groHit;
+        const f3 is2 = giscl * giscl;
+        const f3 gsclGro = mk3(-gposcr.x * is2.x, -gposcr.y * is2.y, -gposcr.z * is2.z) * groTot;
+        const f3 gposcrGrd = giscl * groTot;
+        const f3 gposcGrd = mul_cols(rotT, gposcrGrd);
+        const f3 dn = grdGrd + grdHit;
+        const f3 grduGrd = dn * il - grdu * (il * il * il * dot(dn, grdu));   // normalize backward
+        const f3 sclGrd = gsclHit + gsclGro + mk3(-rdr.x * is2.x, -rdr.y * is2.y, -rdr.z * is2.z) * grduGrd;
+        const float4 gq1 = quat_outer_contract(gposcrGrd, gposc, q), gq2 = quat_outer_contract(giscl * grduGrd, ray.d, q);
+        float* gd = g_density12 + 12 * (size_t)idx;
+        atomicAdd(gd + 0, -gposcGrd.x); atomicAdd(gd + 1, -gposcGrd.y); atomicAdd(gd + 2, -gposcGrd.z); atomicAdd(gd + 3, ddens);
+        atomicAdd(gd + 4, gq1.x + gq2.x); atomicAdd(gd + 5, gq1.y + gq2.y); atomicAdd(gd + 6, gq1.z + gq2.z); atomicAdd(gd + 7, gq1.w + gq2.w);
+        atomicAdd(gd + 8, sclGrd.x); atomicAdd(gd + 9, sclGrd.y); atomicAdd(gd + 10, sclGrd.z);
+    }
+    s.T *= (1.f - alpha);
+    if (s.T < P.min_transmittance) alive = false;
+}
+template <int K, bool BWD>
+__global__ __launch_bounds__(64) void gut_render_nht_k_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+                                                              const float4* __restrict__ density12, const float* __restrict__ features,
+                                                              const float* __restrict__ ray_o, const float* __restrict__ ray_d,
+                                                              float* __restrict__ fd /* BWD: the forward's image (read) */, float* __restrict__ dist,
+                                                              float* __restrict__ out_cnt, const float* __restrict__ g_fd, const float* __restrict__ g_dist,
+                                                              float* __restrict__ g_density12, float* __restrict__ g_features) {
+    constexpr int kQ = 8;   // as gut_render_k_body: 0-2 M rows | pos, 3 scale | density, 4 particle | accept limit, 5-7 rows of R^T | 1 / scale
+    __shared__ float4 s_rec[64 * kQ];
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+    const uint32_t tile = ((slot >> 2) << 3) + xcd, strip = slot & 3u;
+    if (tile >= (uint32_t)(P.gx * P.gy)) return;
+    const int lane = threadIdx.x;
+    const int px = (int)(tile % P.gx) * 16 + (lane & 15);
+    const int py = (int)(tile / P.gx) * 16 + (int)strip * 4 + (lane >> 4);
+    const Ray ray = init_ray(P, ray_o, ray_d, px, py);
+    bool alive = ray.valid;
+    const size_t pix = ray.valid ? (size_t)py * P.W + px : 0;
+    const int nr = P.nht_ray_dim;
+    const NhtTetra4 tet = nht_tetra4();
+    NhtKFwdState fs;
+    NhtKBwdState bs;
+    if (!BWD) {
+        fs.T = 1.f; fs.D = 0.f; fs.cnt = 0.f;
+#pragma unroll
+        for (int i = 0; i < kNhtMaxRay; ++i) fs.acc[i] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < kNhtMaxRay; ++i) {
+            const bool use = alive && i < nr;
+            bs.Cb[i] = use ? (P.out_half ? __half2float(reinterpret_cast<const __half*>(fd)[pix * (nr + 1) + i]) : fd[pix * (nr + 1) + i]) : 0.f;
+            bs.gC[i] = use ? g_fd[pix * (nr + 1) + i] : 0.f;
+        }
+        bs.Tb = 1.f; bs.gT = 0.f; bs.Db = 0.f; bs.gD = 0.f; bs.T = 1.f;
+        if (alive) {
+            const float op = P.out_half ? __half2float(reinterpret_cast<const __half*>(fd)[pix * (nr + 1) + nr]) : fd[pix * (nr + 1) + nr];
+            bs.Tb = 1.f - op; bs.gT = -g_fd[pix * (nr + 1) + nr];
+            bs.Db = dist[pix]; bs.gD = g_dist ? g_dist[pix] : 0.f;
+        }
+    }
+    KBuffer<K> kb;
+    kb.clear();
+    const uint2 range = ranges[tile];
+    for (uint32_t b = range.x; b < range.y; b += 64) {
+        if (!__any(alive)) break;
+        {   // stage up to 64 entries (gut_render_k_body)
+            const RawEntry e = load_entry<false>(b + lane, range.y, lists, density12, nullptr);
+            float4 r0 = make_float4(1.f, 0.f, 0.f, 0.f), r1 = make_float4(0.f, 1.f, 0.f, 0.f), r2 = make_float4(0.f, 0.f, 1.f, 0.f);
+            float4 r3 = make_float4(1.f, 1.f, 1.f, 0.f), r4 = make_float4(__uint_as_float(0xFFFFFFFFu), 0.f, 0.f, 0.f);
+            float4 r5 = r0, r6 = r1, r7 = r2;
+            if (e.idx != 0xFFFFFFFFu) {
+                {
+                    f3 t0, t1, t2;
+                    rn_rotT(e.q.x, e.q.y, e.q.z, e.q.w, t0, t1, t2);
+                    r5 = make_float4(t0.x, t0.y, t0.z, 1.f / e.s.x);
+                    r6 = make_float4(t1.x, t1.y, t1.z, 1.f / e.s.y);
+                    r7 = make_float4(t2.x, t2.y, t2.z, 1.f / e.s.z);
+                }
+                const m3 rt = quat_wxyz_to_rotT(e.q.x, e.q.y, e.q.z, e.q.w);
+                const float ix = __builtin_amdgcn_rcpf(e.s.x), iy = __builtin_amdgcn_rcpf(e.s.y), iz = __builtin_amdgcn_rcpf(e.s.z);
+                r0 = make_float4(rt.r0.x * ix, rt.r0.y * ix, rt.r0.z * ix, e.a.x);
+                r1 = make_float4(rt.r1.x * iy, rt.r1.y * iy, rt.r1.z * iy, e.a.y);
+                r2 = make_float4(rt.r2.x * iz, rt.r2.y * iz, rt.r2.z * iz, e.a.z);
+                r3 = make_float4(e.s.x, e.s.y, e.s.z, e.a.w);
+                r4.x = __uint_as_float(e.idx);
+                const float need = fmaxf(P.min_response, P.min_alpha / e.a.w);
+                r4.y = (P.max_alpha > P.min_alpha && e.a.w > 0.f) ? gray_limit_rt(P.degree, need) : 0.f;
+            }
+            float4* rec = &s_rec[lane * kQ];
+            rec[0] = r0; rec[1] = r1; rec[2] = r2; rec[3] = r3; rec[4] = r4; rec[5] = r5; rec[6] = r6; rec[7] = r7;
+        }
+        __syncthreads();
+        const int n = (int)min(64u, range.y - b);
+        for (int j = 0; j < n; ++j) {
+            if (!__any(alive)) break;
+            const float4* rec = &s_rec[j * kQ];
+            const uint32_t idx = __float_as_uint(rec[4].x);
+            if (idx == 0xFFFFFFFFu) break;
+            bool pop = false;
+            float pop_t = 0.f, pop_a = 0.f;
+            uint32_t pop_i = 0u;
+            if (alive) {
+                const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+                const f3 dl = ray.o - mk3(q0.w, q1.w, q2.w);
+                const f3 gro = mk3(dot(mk3(q0.x, q0.y, q0.z), dl), dot(mk3(q1.x, q1.y, q1.z), dl), dot(mk3(q2.x, q2.y, q2.z), dl));
+                const f3 grdu = mk3(dot(mk3(q0.x, q0.y, q0.z), ray.d), dot(mk3(q1.x, q1.y, q1.z), ray.d), dot(mk3(q2.x, q2.y, q2.z), ray.d));
+                const float l2 = dot(grdu, grdu);
+                const f3 gc = cross(grdu, gro);
+                const float cc = dot(gc, gc);
+                if (cc < rec[4].y * l2) {
+                    const float il2 = __builtin_amdgcn_rcpf(l2);
+                    const float resp = response_rt(P.degree, cc * il2);
+                    const float alpha = fminf(P.max_alpha, resp * q3.w);
+                    const float4 q5 = rec[5], q6 = rec[6], q7 = rec[7];
+                    const float hitT = oracle_order_hit_t(ray, mk3(q0.w, q1.w, q2.w), mk3(q3.x, q3.y, q3.z), mk3(q5.x, q5.y, q5.z), mk3(q6.x, q6.y, q6.z),
+                                                          mk3(q7.x, q7.y, q7.z), mk3(q5.w, q6.w, q7.w));
+                    if ((hitT > ray.tmin) && (hitT < ray.tmax)) {
+                        if (kb.num == K) {
+                            pop = true; pop_t = kb.hitT[0]; pop_a = kb.alpha[0]; pop_i = kb.idx[0];
+                            kb.hitT[0] = -1.f;
+                        } else {
+                            kb.num++;
+                        }
+                        kb.insert(hitT, alpha, idx);
+                    }
+                }
+            }
+            if (pop) {
+                if (BWD) nht_k_pop_bwd(P, ray, tet, density12, features, pop_t, pop_a, pop_i, bs, alive, g_density12, g_features);
+                else nht_k_pop_fwd(P, ray, tet, density12, features, pop_t, pop_a, pop_i, fs, alive);
+            }
+        }
+        __syncthreads();
+    }
+    // drain what is left, nearest first (:343-351), as gut_render_k_body
+#pragma unroll 1
+    for (int step = 0; step < K; ++step) {
+        const float t0 = kb.hitT[0], a0 = kb.alpha[0];
+        const uint32_t i0 = kb.idx[0];
+#pragma unroll
+        for (int i = 0; i + 1 < K; ++i) { kb.hitT[i] = kb.hitT[i + 1]; kb.alpha[i] = kb.alpha[i + 1]; kb.idx[i] = kb.idx[i + 1]; }
+        kb.hitT[K - 1] = -1.f;
+        const bool act = alive && (t0 >= 0.f);
+        if (act) {
+            if (BWD) nht_k_pop_bwd(P, ray, tet, density12, features, t0, a0, i0, bs, alive, g_density12, g_features);
+            else nht_k_pop_fwd(P, ray, tet, density12, features, t0, a0, i0, fs, alive);
+        }
+    }
+    if (!BWD && ray.inside) {
+        const size_t opix = (size_t)py * P.W + px;
+        const size_t stride = (size_t)nr + 1;
+#pragma unroll
+        for (int i = 0; i < kNhtMaxRay; ++i) {
+            if (i < nr) {
+                const float v = ray.valid ? fs.acc[i] : 0.f;
+                if (P.out_half) reinterpret_cast<__half*>(fd)[opix * stride + i] = __float2half(v);
+                else fd[opix * stride + i] = v;
+            }
+        }
+        const float op = ray.valid ? 1.f - fs.T : 0.f;
+        if (P.out_half) reinterpret_cast<__half*>(fd)[opix * stride + nr] = __float2half(op);
+        else fd[opix * stride + nr] = op;
+        dist[opix] = ray.valid ? fs.D : 1e6f;
+        if (P.hitcounts) out_cnt[opix] = ray.valid ? fs.cnt : 0.f;
+    }
+}
+
 #include "gut_render_nht.inl"
 
 static uint32_t strip_grid(const GutParams& P) {
@@ -2117,6 +2461,12 @@ void launch_render_nht_fwd(hipStream_t s, const GutParams& P, const uint32_t* ra
                            const float* density12, const float* features, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                            float* out_cnt) {
     const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
+    if (P.k_buffer > 0) {   // the sorted hit buffer in front of the feature integration (round 6)
+        GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_nht_k_kernel<K_, false>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                       reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), features,
+                                                       ray_o, ray_d, out_fd, out_dist, out_cnt, nullptr, nullptr, nullptr, nullptr));
+        return;
+    }
     hipLaunchKernelGGL(gut_render_nht_fwd_kernel, dim3(strip_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
                        reinterpret_cast<const float4*>(density12), features, ray_o, ray_d, out_fd, out_dist, out_cnt);
 }
@@ -2124,6 +2474,13 @@ void launch_render_nht_bwd(hipStream_t s, const GutParams& P, const uint32_t* ra
                            const float* density12, const float* features, const float* ray_o, const float* ray_d, const float* fd, const float* g_fd,
                            const float* dist, const float* g_dist, float* g_density12, float* g_features) {
     const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
+    if (P.k_buffer > 0) {
+        GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_nht_k_kernel<K_, true>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                       reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), features,
+                                                       ray_o, ray_d, const_cast<float*>(fd), const_cast<float*>(dist), nullptr, g_fd, g_dist, g_density12,
+                                                       g_features));
+        return;
+    }
     hipLaunchKernelGGL(gut_render_nht_bwd_kernel, dim3(strip_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
                        reinterpret_cast<const float4*>(density12), features, ray_o, ray_d, fd, g_fd, dist, g_dist, g_density12, g_features);
 }

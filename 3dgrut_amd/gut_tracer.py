@@ -327,7 +327,8 @@ class _NhtAutograd(torch.autograd.Function):
         H, W, nr = fd.shape[0], fd.shape[1], fd.shape[2] - 1
         c = ctx.native.cfg
         if (ctx.exchange is None and c.particle_feature_dim == 48 and c.interp_point_feature_dim == 12 and c.feature_interpolation_support == 1
-                and c.feature_activation_type == 2 and c.feature_activation_num_frequencies == 1 and not os.environ.get("GRUT_NHT_GENERIC")):
+                and c.feature_activation_type == 2 and c.feature_activation_num_frequencies == 1 and int(c.k_buffer_size) == 0
+                and not os.environ.get("GRUT_NHT_GENERIC")):
             # the default feature model runs on the pixel-pair sweeps, which take the upstream gradients as autograd delivers them and write
             # the model's four gradient tensors directly: no concatenation before, no unpack pass after
             g_pos, g_dns, g_rot, g_scl, g_features = ctx.native.trace_bwd_unpacked(

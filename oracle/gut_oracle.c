@@ -814,13 +814,38 @@ static void nht_features_at(const int* nht, const real* row, v3 P, real* out) {
             for (int f = 0; f < nf; ++f) out[k * nf + f] = r_sin(base[k] * (real)ldexp(1.0, f));
     }
 }
+/* one hit of the feature forward (processHitParticle fwd with PerRayParticleFeatures, gutKBufferRenderer.cuh:199-225): the hit's weight, depth and
+ * transmittance from (alpha, hitT) as tested - K > 0: as they sat in the hit buffer -, its features interpolated at the canonical
+ * intersection, which is a function of (ray, particle) and is evaluated here with the operations of the test (density_hit_ex) */
+static void nht_fwd_hit(const GutConfig* cfg, const int* nht, const orc_ray* ray, const real* density12, const real* features, const orc_hit* h,
+                        int nr, real* T, real* D, real* acc, uint32_t* cnt, int* alive) {
+    const real w = h->alpha * (*T);
+    *D += h->hitT * w;
+    *T *= (1 - h->alpha);
+    if (w > 0) {
+        const orc_particle p = load_particle(density12 + 12 * (size_t)h->idx);
+        const v3 giscl = v3_make(1 / p.scl.x, 1 / p.scl.y, 1 / p.scl.z);
+        const v3 gro = v3_mul(giscl, v3_mul_rows(v3_sub(ray->o, p.pos), &p.rotT));
+        const v3 grdu = v3_mul(giscl, v3_mul_rows(ray->d, &p.rotT));
+        const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
+        const v3 cg = v3_scale(grd, v3_dot(grd, v3_scale(gro, -1)));
+        const v3 P = v3_add(gro, cg);
+        real f[ORC_NHT_MAX_RAY_DIM];
+        nht_features_at(nht, features + (size_t)nht[0] * h->idx, P, f);
+        for (int i = 0; i < nr; ++i) acc[i] += f[i] * w;
+        (*cnt)++;
+    }
+    if (*T < (real)cfg->min_transmittance) *alive = 0;
+}
+/* k_buffer_size > 0 (round 6): the sorted hit buffer of orc_gut_render_fwd (HitParticleKBufferT, :62-122, 331-351) in front of nht_fwd_hit */
 int orc_gut_render_nht_fwd(const GutConfig* cfg, const int* nht, int width, int height, const real* pose_start7, const real* pose_end7,
                            const real* density12, const real* features, const uint32_t* sorted_idx, const uint32_t* tile_ranges,
                            const real* ray_o, const real* ray_d, real* out_fd, real* out_dist, real* out_cnt) {
     const orc_frame_poses fp = frame_poses(pose_start7, pose_end7);
     const int gx = tile_grid_dim(width);
     const int nr = nht_ray_dim(nht);
-    if (cfg->k_buffer_size != 0 || nr > ORC_NHT_MAX_RAY_DIM || nht[1] > ORC_NHT_MAX_RAY_DIM) return -1;
+    const int K = cfg->k_buffer_size;
+    if (K > ORC_MAX_K || nr > ORC_NHT_MAX_RAY_DIM || nht[1] > ORC_NHT_MAX_RAY_DIM) return -1;
 #pragma omp parallel for schedule(dynamic, 16)
     for (int pix = 0; pix < width * height; ++pix) {
         const int x = pix % width, y = pix / width;
@@ -830,35 +855,27 @@ int orc_gut_render_nht_fwd(const GutConfig* cfg, const int* nht, int width, int 
         const uint32_t beg = tile_ranges[2 * tile], end = tile_ranges[2 * tile + 1];
         real T = 1, D = 0, acc[ORC_NHT_MAX_RAY_DIM]; uint32_t cnt = 0; int alive = 1;
         for (int i = 0; i < nr; ++i) acc[i] = 0;
+        orc_hit kbuf[ORC_MAX_K]; int nhits = 0;
+        for (int k = 0; k < K; ++k) { kbuf[k].idx = ORC_INVALID_IDX; kbuf[k].hitT = -1; kbuf[k].alpha = 0; }
         for (uint32_t e = beg; e < end && alive; ++e) {
             const uint32_t idx = sorted_idx[e];
             if (idx == ORC_INVALID_IDX) break;
             const orc_particle p = load_particle(density12 + 12 * (size_t)idx);
-            /* density_hit_ex with the canonical intersection kept (gaussianParticles.slang:181-190) */
-            const v3 giscl = v3_make(1 / p.scl.x, 1 / p.scl.y, 1 / p.scl.z);
-            const v3 gro = v3_mul(giscl, v3_mul_rows(v3_sub(ray.o, p.pos), &p.rotT));
-            const v3 grdu = v3_mul(giscl, v3_mul_rows(ray.d, &p.rotT));
-            const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
-            const v3 gcrod = v3_cross(grd, gro);
-            const real resp = particle_response(cfg->particle_kernel_degree, v3_dot(gcrod, gcrod));
-            const real alpha = r_min((real)cfg->particle_kernel_max_alpha, resp * p.density);
-            if (!((resp > (real)cfg->particle_kernel_min_response) && (alpha > (real)cfg->particle_kernel_min_alpha))) continue;
-            const v3 cg = v3_scale(grd, v3_dot(grd, v3_scale(gro, -1)));
-            const v3 P = v3_add(gro, cg);
-            const v3 grds = v3_mul(p.scl, cg);
-            const real hitT = r_sqrt(v3_dot(grds, grds));
-            if (!(hitT > ray.tmin && hitT < ray.tmax)) continue;
-            const real w = alpha * T;
-            D += hitT * w;
-            T *= (1 - alpha);
-            if (w > 0) {
-                real f[ORC_NHT_MAX_RAY_DIM];
-                nht_features_at(nht, features + (size_t)nht[0] * idx, P, f);
-                for (int i = 0; i < nr; ++i) acc[i] += f[i] * w;
-                cnt++;
+            orc_hit h; h.idx = idx; h.hitT = -1; h.alpha = 0;
+            if (!(density_hit(cfg, ray.o, ray.d, &p, &h.alpha, &h.hitT) && h.hitT > ray.tmin && h.hitT < ray.tmax)) continue;
+            if (K == 0) {
+                nht_fwd_hit(cfg, nht, &ray, density12, features, &h, nr, &T, &D, acc, &cnt, &alive);
+            } else {
+                if (nhits == K) {
+                    nht_fwd_hit(cfg, nht, &ray, density12, features, &kbuf[0], nr, &T, &D, acc, &cnt, &alive);
+                    kbuf[0].hitT = -1;
+                } else nhits++;
+                for (int i = K - 1; i >= 0; --i)
+                    if (h.hitT > kbuf[i].hitT) { const orc_hit t = kbuf[i]; kbuf[i] = h; h = t; }
             }
-            if (T < (real)cfg->min_transmittance) alive = 0;
         }
+        if (K > 0)
+            for (int i = 0; alive && i < nhits; ++i) nht_fwd_hit(cfg, nht, &ray, density12, features, &kbuf[K - nhits + i], nr, &T, &D, acc, &cnt, &alive);
         real* o = out_fd + (size_t)(nr + 1) * pix;
         for (int i = 0; i < nr; ++i) o[i] = acc[i];
         o[nr] = 1 - T;
@@ -911,6 +928,144 @@ int orc_gut_pixel_trace_nht(const GutConfig* cfg, const int* nht, int width, int
 }
 
 static size_t list_particle_bound(int width, int height, const uint32_t* sorted_idx, const uint32_t* tile_ranges);
+typedef struct {
+    const GutConfig* cfg; const int* nht; const real* density12; const real* features; double* acc_d; double* acc_f;
+    v3 v0, e1, e2, e3, c23, gw[4]; real inv_det; int nr, K, ipd, act, nf, points;
+} nht_bwd_ctx;
+typedef struct { real Cb[ORC_NHT_MAX_RAY_DIM], gC[ORC_NHT_MAX_RAY_DIM], Tb, gT, Db, gD, T; int alive; } nht_bwd_ray;
+/* one hit of the feature backward (processHitParticle<Backward> with PerRayParticleFeatures, gutKBufferRenderer.cuh:158-198): the reverse of
+ * nht_fwd_hit for the hit (particle, alpha, hitT) - K > 0: as it sat in the hit buffer; everything else is a function of (ray, particle) */
+static void nht_bwd_hit(const nht_bwd_ctx* c, const orc_ray* rayp, nht_bwd_ray* st, const orc_hit* h) {
+    const GutConfig* cfg = c->cfg; const int* nht = c->nht;
+    const int nr = c->nr, K = c->K, ipd = c->ipd, act = c->act, nf = c->nf, points = c->points;
+    const v3 v0 = c->v0, e1 = c->e1, e2 = c->e2, e3 = c->e3, c23 = c->c23; const v3* gw = c->gw; const real inv_det = c->inv_det;
+    double* acc_d = c->acc_d; double* acc_f = c->acc_f;
+    const orc_ray ray = *rayp;
+    real* Cb = st->Cb; real* gC = st->gC;
+    real Tb = st->Tb, gT = st->gT, Db = st->Db, gD = st->gD;
+    const uint32_t idx = h->idx;
+    const real alpha = h->alpha, hitT = h->hitT;
+    const orc_particle p = load_particle(c->density12 + 12 * (size_t)idx);
+    const real* features = c->features;
+    const v3 gscl = p.scl;
+    const v3 giscl = v3_make(1 / gscl.x, 1 / gscl.y, 1 / gscl.z);
+    const v3 gposc = v3_sub(ray.o, p.pos);
+    const v3 gposcr = v3_mul_rows(gposc, &p.rotT);
+    const v3 gro = v3_mul(giscl, gposcr);
+    const v3 rdr = v3_mul_rows(ray.d, &p.rotT);
+    const v3 grdu = v3_mul(giscl, rdr);
+    const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
+    const v3 gcrod = v3_cross(grd, gro);
+    const real gray = v3_dot(gcrod, gcrod);
+    const real gres = particle_response(cfg->particle_kernel_degree, gray);
+    const real pdot = v3_dot(grd, v3_scale(gro, -1));
+    const v3 grdd = v3_scale(grd, pdot);
+    const v3 P = v3_add(gro, grdd);
+    const v3 grds = v3_mul(gscl, grdd);
+    const real gsq = v3_dot(grds, grds);
+    /* ---- the hit's features and the reverse of their integration (lerp form, un-blending front to back) ---- */
+    const real* row = features + (size_t)K * idx;
+    real wq[4] = {1, 0, 0, 0};
+    if (points == 4) {
+        const v3 d = v3_sub(P, v0);
+        wq[1] = v3_dot(d, c23) * inv_det; wq[2] = v3_dot(e1, v3_cross(d, e3)) * inv_det; wq[3] = v3_dot(e1, v3_cross(e2, d)) * inv_det;
+        wq[0] = 1 - wq[1] - wq[2] - wq[3];
+    }
+    real base[ORC_NHT_MAX_RAY_DIM], f[ORC_NHT_MAX_RAY_DIM], gf[ORC_NHT_MAX_RAY_DIM], gbase[ORC_NHT_MAX_RAY_DIM];
+    for (int n = 0; n < ipd; ++n) {
+        base[n] = row[n] * wq[0];
+        for (int k = 1; k < points; ++k) base[n] += wq[k] * row[k * ipd + n];
+    }
+    nht_features_at(nht, row, P, f);
+    const real w = 1 / (1 - alpha);
+    real dalpha = 0;
+    if (alpha > 0) {   /* (particleFeaturesIntegrateBwdToBuffer: if (alpha > 0)) */
+        for (int i = 0; i < nr; ++i) {
+            Cb[i] = (Cb[i] - f[i] * alpha) * w;
+            dalpha += (f[i] - Cb[i]) * gC[i];
+            gf[i] = alpha * gC[i];
+            gC[i] *= (1 - alpha);
+        }
+    } else {
+        for (int i = 0; i < nr; ++i) gf[i] = 0;
+    }
+    /* activation backward */
+    for (int n = 0; n < ipd; ++n) gbase[n] = 0;
+    if (act == 0) { for (int i = 0; i < ipd; ++i) gbase[i] = gf[i]; }
+    else if (act == 3) { for (int i = 0; i < ipd; ++i) gbase[i] = base[i] > 0 ? gf[i] : 0; }
+    else if (act == 2) {
+        for (int k = 0; k < ipd; ++k)
+            for (int q = 0; q < nf; ++q) {
+                const real fr = (real)(q + 1), ang = base[k] * fr;
+                gbase[k] += fr * (r_cos(ang) * gf[k * nf * 2 + q * 2] - r_sin(ang) * gf[k * nf * 2 + q * 2 + 1]);
+            }
+    } else {
+        for (int k = 0; k < ipd; ++k)
+            for (int q = 0; q < nf; ++q) {
+                const real fr = (real)ldexp(1.0, q);
+                gbase[k] += fr * r_cos(base[k] * fr) * gf[k * nf + q];
+            }
+    }
+    /* blend backward: feature rows and the canonical position */
+    v3 dP = v3_make(0, 0, 0);
+    for (int k = 0; k < points; ++k) {
+        real dwk = 0;
+        for (int n = 0; n < ipd; ++n) {
+            const real g = wq[k] * gbase[n];
+            if (g != 0) {
+#pragma omp atomic
+                acc_f[(size_t)K * idx + k * ipd + n] += (double)g;
+            }
+            dwk += row[k * ipd + n] * gbase[n];
+        }
+        if (points == 4) dP = v3_add(dP, v3_scale(gw[k], dwk));
+    }
+    /* ---- density: T_out = T_in (1 - alpha), D_front = lerp(D_behind, depth, alpha) (as process_hit_bwd_k) ---- */
+    Tb *= w;
+    Db = (Db - hitT * alpha) * w;
+    dalpha += (hitT - Db) * gD - Tb * gT;
+    const real ddepth = alpha * gD;
+    gD *= (1 - alpha);
+    gT *= (1 - alpha);
+    real gd[12];
+    for (int k = 0; k < 12; ++k) gd[k] = 0;
+    real dres = 0, ddens = 0;
+    if (gres * p.density < (real)cfg->particle_kernel_max_alpha) { dres = p.density * dalpha; ddens = gres * dalpha; }
+    gd[3] = ddens;
+    const real grayGrd = particle_response_grd(cfg->particle_kernel_degree, gray, gres, dres);
+    const v3 grdsGrd = gsq > 0 ? v3_scale(grds, ddepth / hitT) : v3_make(0, 0, 0);
+    const v3 gsclHit = v3_mul(grdd, grdsGrd);
+    const real sdot = v3_dot(v3_mul(grdsGrd, gscl), grd);
+    v3 grdHit = v3_sub(v3_scale(v3_mul(gscl, grdsGrd), pdot), v3_scale(gro, sdot));
+    v3 groHit = v3_scale(grd, -sdot);
+    /* canonical intersection P = gro + grd (grd . -gro) */
+    const real gdP = v3_dot(grd, dP);
+    groHit = v3_add(groHit, v3_sub(dP, v3_scale(grd, gdP)));
+    grdHit = v3_add(grdHit, v3_sub(v3_scale(dP, pdot), v3_scale(gro, gdP)));
+    const v3 gcrodGrd = v3_scale(gcrod, 2 * grayGrd);
+    const v3 grdGrd = v3_make(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
+    const v3 groGrd = v3_make(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
+    const v3 groTot = v3_add(groGrd, groHit);
+    const v3 gsclGro = v3_mul(v3_make(-gposcr.x / (gscl.x * gscl.x), -gposcr.y / (gscl.y * gscl.y), -gposcr.z / (gscl.z * gscl.z)), groTot);
+    const v3 gposcrGrd = v3_mul(giscl, groTot);
+    const v3 gposcGrd = matmul_bw_vec(&p.rotT, gposcrGrd);
+    const v4 gq1 = matmul_bw_quat(gposc, gposcrGrd, p.quat);
+    gd[0] = -gposcGrd.x; gd[1] = -gposcGrd.y; gd[2] = -gposcGrd.z;
+    const v3 grduGrd = v3_safe_normalize_bw(grdu, v3_add(grdGrd, grdHit));
+    const v3 sclGrd = v3_add(v3_add(gsclHit, gsclGro),
+                             v3_mul(v3_make(-rdr.x / (gscl.x * gscl.x), -rdr.y / (gscl.y * gscl.y), -rdr.z / (gscl.z * gscl.z)), grduGrd));
+    gd[8] = sclGrd.x; gd[9] = sclGrd.y; gd[10] = sclGrd.z;
+    const v4 gq2 = matmul_bw_quat(ray.d, v3_mul(giscl, grduGrd), p.quat);
+    gd[4] = gq1.x + gq2.x; gd[5] = gq1.y + gq2.y; gd[6] = gq1.z + gq2.z; gd[7] = gq1.w + gq2.w;
+    for (int k = 0; k < 11; ++k)
+        if (gd[k] != 0) {
+#pragma omp atomic
+            acc_d[12 * (size_t)idx + k] += (double)gd[k];
+        }
+    st->Tb = Tb; st->gT = gT; st->Db = Db; st->gD = gD;
+    st->T *= (1 - alpha);
+    if (st->T < (real)cfg->min_transmittance) st->alive = 0;
+}
 /* --------------------------------------------------------------------------------------
  * render backward with neural harmonic features (K = 0): evalBackwardNoKBuffer's PerRayParticleFeatures branch
  * (gutKBufferRenderer.cuh:546-641): per hit featuresIntegrateBwdToLocalGrad (Slang reverse mode of integrateFeaturesFromBuffer<true>,
@@ -927,7 +1082,8 @@ int orc_gut_render_nht_bwd(const GutConfig* cfg, const int* nht, int width, int 
     const int gx = tile_grid_dim(width);
     const int nr = nht_ray_dim(nht), K = nht[0], ipd = nht[1], act = nht[3], nf = nht[4];
     const int points = nht[2] == 1 ? 4 : 1;
-    if (cfg->k_buffer_size != 0 || nr > ORC_NHT_MAX_RAY_DIM || ipd > ORC_NHT_MAX_RAY_DIM) return -1;
+    const int Kb = cfg->k_buffer_size;   /* (K is the feature row length here) */
+    if (Kb > ORC_MAX_K || nr > ORC_NHT_MAX_RAY_DIM || ipd > ORC_NHT_MAX_RAY_DIM) return -1;
     const size_t n_acc = list_particle_bound(width, height, sorted_idx, tile_ranges);
     double* acc_d = (double*)calloc(n_acc * 12 + 1, sizeof(double));
     double* acc_f = (double*)calloc(n_acc * (size_t)K + 1, sizeof(double));
@@ -942,6 +1098,10 @@ int orc_gut_render_nht_bwd(const GutConfig* cfg, const int* nht, int width, int 
     v3 gw[4];
     gw[1] = v3_scale(c23, inv_det); gw[2] = v3_scale(v3_cross(e3, e1), inv_det); gw[3] = v3_scale(v3_cross(e1, e2), inv_det);
     gw[0] = v3_scale(v3_add(v3_add(gw[1], gw[2]), gw[3]), -1);
+    nht_bwd_ctx ctx;
+    ctx.cfg = cfg; ctx.nht = nht; ctx.density12 = density12; ctx.features = features; ctx.acc_d = acc_d; ctx.acc_f = acc_f;
+    ctx.v0 = v0; ctx.e1 = e1; ctx.e2 = e2; ctx.e3 = e3; ctx.c23 = c23; for (int k = 0; k < 4; ++k) ctx.gw[k] = gw[k];
+    ctx.inv_det = inv_det; ctx.nr = nr; ctx.K = K; ctx.ipd = ipd; ctx.act = act; ctx.nf = nf; ctx.points = points;
 #pragma omp parallel for schedule(dynamic, 16)
     for (int pix = 0; pix < width * height; ++pix) {
         const int x = pix % width, y = pix / width;
@@ -949,138 +1109,33 @@ int orc_gut_render_nht_bwd(const GutConfig* cfg, const int* nht, int width, int 
         if (!ray.valid) continue;
         const uint32_t tile = (uint32_t)((y / ORC_TILE) * gx + (x / ORC_TILE));
         const uint32_t beg = tile_ranges[2 * tile], end = tile_ranges[2 * tile + 1];
-        real Cb[ORC_NHT_MAX_RAY_DIM], gC[ORC_NHT_MAX_RAY_DIM];
+        nht_bwd_ray st;
         const real* f_in = fd + (size_t)(nr + 1) * pix;
         const real* g_in = g_fd + (size_t)(nr + 1) * pix;
-        for (int i = 0; i < nr; ++i) { Cb[i] = f_in[i]; gC[i] = g_in[i]; }
-        real Tb = 1 - f_in[nr], gT = -g_in[nr], Db = dist[pix], gD = g_dist ? g_dist[pix] : 0;
-        real T = 1; int alive = 1;
-        for (uint32_t e = beg; e < end && alive; ++e) {
+        for (int i = 0; i < nr; ++i) { st.Cb[i] = f_in[i]; st.gC[i] = g_in[i]; }
+        st.Tb = 1 - f_in[nr]; st.gT = -g_in[nr]; st.Db = dist[pix]; st.gD = g_dist ? g_dist[pix] : 0;
+        st.T = 1; st.alive = 1;
+        orc_hit kbuf[ORC_MAX_K]; int nhits = 0;
+        for (int k = 0; k < Kb; ++k) { kbuf[k].idx = ORC_INVALID_IDX; kbuf[k].hitT = -1; kbuf[k].alpha = 0; }
+        for (uint32_t e = beg; e < end && st.alive; ++e) {
             const uint32_t idx = sorted_idx[e];
             if (idx == ORC_INVALID_IDX) break;
             const orc_particle p = load_particle(density12 + 12 * (size_t)idx);
-            const v3 gscl = p.scl;
-            const v3 giscl = v3_make(1 / gscl.x, 1 / gscl.y, 1 / gscl.z);
-            const v3 gposc = v3_sub(ray.o, p.pos);
-            const v3 gposcr = v3_mul_rows(gposc, &p.rotT);
-            const v3 gro = v3_mul(giscl, gposcr);
-            const v3 rdr = v3_mul_rows(ray.d, &p.rotT);
-            const v3 grdu = v3_mul(giscl, rdr);
-            const v3 grd = v3_scale(grdu, 1 / r_sqrt(v3_dot(grdu, grdu)));
-            const v3 gcrod = v3_cross(grd, gro);
-            const real gray = v3_dot(gcrod, gcrod);
-            const real gres = particle_response(cfg->particle_kernel_degree, gray);
-            const real alpha = r_min((real)cfg->particle_kernel_max_alpha, gres * p.density);
-            if (!((gres > (real)cfg->particle_kernel_min_response) && (alpha > (real)cfg->particle_kernel_min_alpha))) continue;
-            const real pdot = v3_dot(grd, v3_scale(gro, -1));
-            const v3 grdd = v3_scale(grd, pdot);
-            const v3 P = v3_add(gro, grdd);
-            const v3 grds = v3_mul(gscl, grdd);
-            const real gsq = v3_dot(grds, grds);
-            const real hitT = r_sqrt(gsq);
-            if (!(hitT > ray.tmin && hitT < ray.tmax)) continue;
-            /* ---- the hit's features and the reverse of their integration (lerp form, un-blending front to back) ---- */
-            const real* row = features + (size_t)K * idx;
-            real wq[4] = {1, 0, 0, 0};
-            if (points == 4) {
-                const v3 d = v3_sub(P, v0);
-                wq[1] = v3_dot(d, c23) * inv_det; wq[2] = v3_dot(e1, v3_cross(d, e3)) * inv_det; wq[3] = v3_dot(e1, v3_cross(e2, d)) * inv_det;
-                wq[0] = 1 - wq[1] - wq[2] - wq[3];
+            orc_hit h; h.idx = idx; h.hitT = -1; h.alpha = 0;
+            if (!(density_hit(cfg, ray.o, ray.d, &p, &h.alpha, &h.hitT) && h.hitT > ray.tmin && h.hitT < ray.tmax)) continue;
+            if (Kb == 0) {
+                nht_bwd_hit(&ctx, &ray, &st, &h);
+            } else {   /* the sorted hit buffer of render_bwd_kbuffer */
+                if (nhits == Kb) {
+                    nht_bwd_hit(&ctx, &ray, &st, &kbuf[0]);
+                    kbuf[0].hitT = -1;
+                } else nhits++;
+                for (int i = Kb - 1; i >= 0; --i)
+                    if (h.hitT > kbuf[i].hitT) { const orc_hit t = kbuf[i]; kbuf[i] = h; h = t; }
             }
-            real base[ORC_NHT_MAX_RAY_DIM], f[ORC_NHT_MAX_RAY_DIM], gf[ORC_NHT_MAX_RAY_DIM], gbase[ORC_NHT_MAX_RAY_DIM];
-            for (int n = 0; n < ipd; ++n) {
-                base[n] = row[n] * wq[0];
-                for (int k = 1; k < points; ++k) base[n] += wq[k] * row[k * ipd + n];
-            }
-            nht_features_at(nht, row, P, f);
-            const real w = 1 / (1 - alpha);
-            real dalpha = 0;
-            if (alpha > 0) {   /* (particleFeaturesIntegrateBwdToBuffer: if (alpha > 0)) */
-                for (int i = 0; i < nr; ++i) {
-                    Cb[i] = (Cb[i] - f[i] * alpha) * w;
-                    dalpha += (f[i] - Cb[i]) * gC[i];
-                    gf[i] = alpha * gC[i];
-                    gC[i] *= (1 - alpha);
-                }
-            } else {
-                for (int i = 0; i < nr; ++i) gf[i] = 0;
-            }
-            /* activation backward */
-            for (int n = 0; n < ipd; ++n) gbase[n] = 0;
-            if (act == 0) { for (int i = 0; i < ipd; ++i) gbase[i] = gf[i]; }
-            else if (act == 3) { for (int i = 0; i < ipd; ++i) gbase[i] = base[i] > 0 ? gf[i] : 0; }
-            else if (act == 2) {
-                for (int k = 0; k < ipd; ++k)
-                    for (int q = 0; q < nf; ++q) {
-                        const real fr = (real)(q + 1), ang = base[k] * fr;
-                        gbase[k] += fr * (r_cos(ang) * gf[k * nf * 2 + q * 2] - r_sin(ang) * gf[k * nf * 2 + q * 2 + 1]);
-                    }
-            } else {
-                for (int k = 0; k < ipd; ++k)
-                    for (int q = 0; q < nf; ++q) {
-                        const real fr = (real)ldexp(1.0, q);
-                        gbase[k] += fr * r_cos(base[k] * fr) * gf[k * nf + q];
-                    }
-            }
-            /* blend backward: feature rows and the canonical position */
-            v3 dP = v3_make(0, 0, 0);
-            for (int k = 0; k < points; ++k) {
-                real dwk = 0;
-                for (int n = 0; n < ipd; ++n) {
-                    const real g = wq[k] * gbase[n];
-                    if (g != 0) {
-#pragma omp atomic
-                        acc_f[(size_t)K * idx + k * ipd + n] += (double)g;
-                    }
-                    dwk += row[k * ipd + n] * gbase[n];
-                }
-                if (points == 4) dP = v3_add(dP, v3_scale(gw[k], dwk));
-            }
-            /* ---- density: T_out = T_in (1 - alpha), D_front = lerp(D_behind, depth, alpha) (as process_hit_bwd_k) ---- */
-            Tb *= w;
-            Db = (Db - hitT * alpha) * w;
-            dalpha += (hitT - Db) * gD - Tb * gT;
-            const real ddepth = alpha * gD;
-            gD *= (1 - alpha);
-            gT *= (1 - alpha);
-            real gd[12];
-            for (int k = 0; k < 12; ++k) gd[k] = 0;
-            real dres = 0, ddens = 0;
-            if (gres * p.density < (real)cfg->particle_kernel_max_alpha) { dres = p.density * dalpha; ddens = gres * dalpha; }
-            gd[3] = ddens;
-            const real grayGrd = particle_response_grd(cfg->particle_kernel_degree, gray, gres, dres);
-            const v3 grdsGrd = gsq > 0 ? v3_scale(grds, ddepth / hitT) : v3_make(0, 0, 0);
-            const v3 gsclHit = v3_mul(grdd, grdsGrd);
-            const real sdot = v3_dot(v3_mul(grdsGrd, gscl), grd);
-            v3 grdHit = v3_sub(v3_scale(v3_mul(gscl, grdsGrd), pdot), v3_scale(gro, sdot));
-            v3 groHit = v3_scale(grd, -sdot);
-            /* canonical intersection P = gro + grd (grd . -gro) */
-            const real gdP = v3_dot(grd, dP);
-            groHit = v3_add(groHit, v3_sub(dP, v3_scale(grd, gdP)));
-            grdHit = v3_add(grdHit, v3_sub(v3_scale(dP, pdot), v3_scale(gro, gdP)));
-            const v3 gcrodGrd = v3_scale(gcrod, 2 * grayGrd);
-            const v3 grdGrd = v3_make(gcrodGrd.z * gro.y - gcrodGrd.y * gro.z, gcrodGrd.x * gro.z - gcrodGrd.z * gro.x, gcrodGrd.y * gro.x - gcrodGrd.x * gro.y);
-            const v3 groGrd = v3_make(gcrodGrd.y * grd.z - gcrodGrd.z * grd.y, gcrodGrd.z * grd.x - gcrodGrd.x * grd.z, gcrodGrd.x * grd.y - gcrodGrd.y * grd.x);
-            const v3 groTot = v3_add(groGrd, groHit);
-            const v3 gsclGro = v3_mul(v3_make(-gposcr.x / (gscl.x * gscl.x), -gposcr.y / (gscl.y * gscl.y), -gposcr.z / (gscl.z * gscl.z)), groTot);
-            const v3 gposcrGrd = v3_mul(giscl, groTot);
-            const v3 gposcGrd = matmul_bw_vec(&p.rotT, gposcrGrd);
-            const v4 gq1 = matmul_bw_quat(gposc, gposcrGrd, p.quat);
-            gd[0] = -gposcGrd.x; gd[1] = -gposcGrd.y; gd[2] = -gposcGrd.z;
-            const v3 grduGrd = v3_safe_normalize_bw(grdu, v3_add(grdGrd, grdHit));
-            const v3 sclGrd = v3_add(v3_add(gsclHit, gsclGro),
-                                     v3_mul(v3_make(-rdr.x / (gscl.x * gscl.x), -rdr.y / (gscl.y * gscl.y), -rdr.z / (gscl.z * gscl.z)), grduGrd));
-            gd[8] = sclGrd.x; gd[9] = sclGrd.y; gd[10] = sclGrd.z;
-            const v4 gq2 = matmul_bw_quat(ray.d, v3_mul(giscl, grduGrd), p.quat);
-            gd[4] = gq1.x + gq2.x; gd[5] = gq1.y + gq2.y; gd[6] = gq1.z + gq2.z; gd[7] = gq1.w + gq2.w;
-            for (int k = 0; k < 11; ++k)
-                if (gd[k] != 0) {
-#pragma omp atomic
-                    acc_d[12 * (size_t)idx + k] += (double)gd[k];
-                }
-            T *= (1 - alpha);
-            if (T < (real)cfg->min_transmittance) alive = 0;
         }
+        if (Kb > 0)
+            for (int i = 0; st.alive && i < nhits; ++i) nht_bwd_hit(&ctx, &ray, &st, &kbuf[Kb - nhits + i]);
     }
     for (size_t k = 0; k < n_acc * 12; ++k) g_density12[k] += (real)acc_d[k];
     for (size_t k = 0; k < n_acc * (size_t)K; ++k) g_features[k] += (real)acc_f[k];

@@ -173,7 +173,7 @@ def nht_features(feat_rows, P, ipd=12, nf=1):
     return torch.stack(out, 1).reshape(-1)                                       # index k*nf*2 + f*2 + {0,1}
 
 
-def render_nht(d12, feats, lists, ranges, rays_o, rays_d, W, H, nr=24):
+def render_nht(d12, feats, lists, ranges, rays_o, rays_d, W, H, nr=24, K=0):
     pos, density, quat, scale = d12[:, 0:3], d12[:, 3], d12[:, 4:8], d12[:, 8:11]
     gx = (W + 15) // 16
     fd_rows, dist_rows = [], []
@@ -197,7 +197,21 @@ def render_nht(d12, feats, lists, ranges, rays_o, rays_d, W, H, nr=24):
                 Pc = gro + cg
                 grds = scale[idx] * cg
                 hit_t = (grds * grds).sum(1).clamp_min(1e-300).sqrt()
-                for e in [int(e) for e in torch.nonzero(accept & (hit_t > 0)).flatten()]:
+                order = [int(e) for e in torch.nonzero(accept & (hit_t > 0)).flatten()]
+                if K > 0:   # the sorted hit buffer (evalKBuffer, as in render above): the order in which the hits are composited
+                    hv = hit_t.detach().numpy()
+                    buf, seq = [], []
+                    for e in order:
+                        if len(buf) == K:
+                            seq.append(buf.pop(0))
+                        pos_in = 0
+                        while pos_in < len(buf) and hv[buf[pos_in]] < hv[e]:
+                            pos_in += 1
+                        buf.insert(pos_in, e)
+                    # (a ray that dies on a popped hit stops examining entries: the hits behind it are never reached - the break below covers
+                    # both the pops and the final drain, because composited hits only ever come off the front of `seq + buf`)
+                    order = seq + buf
+                for e in order:
                     w = alpha[e] * T
                     D = D + hit_t[e] * w
                     T = T * (1 - alpha[e])
@@ -212,9 +226,9 @@ def render_nht(d12, feats, lists, ranges, rays_o, rays_d, W, H, nr=24):
     return torch.stack(fd_rows), torch.stack(dist_rows)
 
 
-def case_nht(with_depth_grad, n=260, w=32, h=24, seed=5):
+def case_nht(with_depth_grad, n=260, w=32, h=24, seed=5, K=0):
     scene = make_scene(n=n, width=w, height=h, median_scale=0.16, seed=seed)
-    cfg = oracle.default_gut_config()
+    cfg = oracle.default_gut_config(k_buffer_size=K)
     feats_np = np.random.default_rng(91).uniform(-np.pi / 2, np.pi / 2, size=(n, 48))
     fwd = oracle.gut_forward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats_np, *scene["rays"], dtype=np.float64)
     T = scene["batch"]["T_to_world"][0].astype(np.float64)
@@ -223,7 +237,7 @@ def case_nht(with_depth_grad, n=260, w=32, h=24, seed=5):
     rays_d = torch.as_tensor(rd[0].astype(np.float64) @ T[:3, :3].T)
     d12 = torch.as_tensor(scene["density12"].astype(np.float64)).requires_grad_(True)
     feats = torch.as_tensor(feats_np).requires_grad_(True)
-    fd, dist = render_nht(d12, feats, fwd["sorted_idx"], fwd["tile_ranges"].astype(np.int64), rays_o, rays_d, w, h)
+    fd, dist = render_nht(d12, feats, fwd["sorted_idx"], fwd["tile_ranges"].astype(np.int64), rays_o, rays_d, w, h, K=K)
     e_img = np.abs(fd.detach().numpy() - fwd["feat_density"]).max()
     e_dist = np.abs(dist.detach().numpy() - fwd["hit_distance"][..., 0]).max()
     assert e_img < 1e-6 and e_dist < 1e-6, (e_img, e_dist)
@@ -231,9 +245,9 @@ def case_nht(with_depth_grad, n=260, w=32, h=24, seed=5):
     g_fd = rng.normal(size=(h, w, 25))
     g_dist = rng.normal(size=(h, w)) * (0.1 if with_depth_grad else 0.0)
     ((fd * torch.as_tensor(g_fd)).sum() + (dist * torch.as_tensor(g_dist)).sum()).backward()
-    print(f"nht depth_grad={with_depth_grad}: forward agrees to {e_img:.1e} / {e_dist:.1e}; hits per pixel mean {fwd['hit_count'].mean():.1f}")
+    print(f"nht K={K} depth_grad={with_depth_grad}: forward agrees to {e_img:.1e} / {e_dist:.1e}; hits per pixel mean {fwd['hit_count'].mean():.1f}")
     return dict(density12=scene["density12"], features=feats_np.astype(np.float32), g_fd=g_fd.astype(np.float32), g_dist=g_dist.astype(np.float32)[..., None],
-                grad_density12=d12.grad.numpy().copy(), grad_features=feats.grad.numpy().copy(), n=n, w=w, h=h, seed=seed)
+                grad_density12=d12.grad.numpy().copy(), grad_features=feats.grad.numpy().copy(), n=n, w=w, h=h, seed=seed, K=K)
 
 
 def case(K, with_depth_grad, n=260, w=32, h=24, seed=5):
@@ -269,8 +283,9 @@ def case(K, with_depth_grad, n=260, w=32, h=24, seed=5):
 if __name__ == "__main__":
     if "--nht" in sys.argv:
         out = {}
-        for name, dg in (("nht", False), ("nht_depth", True)):
-            for k, v in case_nht(dg).items():
+        # (round 6: the sorted hit buffer in front of the feature integration - K = 4 and K = 16 with a hit-distance gradient)
+        for name, dg, K in (("nht", False, 0), ("nht_depth", True, 0), ("nht_k4", False, 4), ("nht_k16_depth", True, 16)):
+            for k, v in case_nht(dg, K=K).items():
                 out[f"{name}_{k}"] = v
         np.savez_compressed(os.path.join(HERE, "autograd_gut_nht.npz"), **out)
         print("wrote tests/golden/autograd_gut_nht.npz")

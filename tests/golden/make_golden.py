@@ -762,14 +762,14 @@ def nht_features(n, seed=77, dim=48):
     return np.random.default_rng(seed).uniform(-np.pi / 2, np.pi / 2, size=(n, dim)).astype(F)
 
 
-def gut_reference_frame_nht(sc, feats):
+def gut_reference_frame_nht(sc, feats, k_buffer=0):
     """The reference's 3DGUT kernels built for model.feature_type = nht (oracle/_ref/libref_gut_render_nht_deg2_k0.so: FEATURE_TRANSFORM_TYPE 1,
     48 floats per particle = 4 tetrahedron vertices x 12, sincos x 1 frequency -> 24 ray features): projectOnTiles (no per-particle
     radiance), expansion, sort, ranges, render -> [H,W,25] features + opacity, hit distance, hit count."""
-    lib = C.CDLL(os.path.join(REF, "libref_gut_render_nht_deg2_k0.so"))
+    lib = C.CDLL(os.path.join(REF, f"libref_gut_render_nht_deg2_k{k_buffer}.so"))
     plib = C.CDLL(os.path.join(REF, "libref_projector.so"))
     nf = lib.ref_gut_ray_feature_dim()
-    assert nf == 24 and lib.ref_gut_particle_feature_dim() == feats.shape[1] == 48 and lib.ref_gut_k_buffer_size() == 0
+    assert nf == 24 and lib.ref_gut_particle_feature_dim() == feats.shape[1] == 48 and lib.ref_gut_k_buffer_size() == k_buffer
     W, H = sc["W"], sc["H"]
     d12, feats = np.ascontiguousarray(sc["density12"], F), np.ascontiguousarray(feats, F)
     n = len(d12)
@@ -819,6 +819,13 @@ def make_gut_nht():
             out[f"s{k}_{name}"] = o[name]
         print(f"nht scene {k}: opacity {o['feat_density'][..., -1].mean():.3f}, |features| mean {np.abs(o['feat_density'][..., :-1]).mean():.3f}, "
               f"hits/ray {o['hit_count'].mean():.1f}")
+        # round 6: the same frames through the sorted hit buffer (GAUSSIAN_K_BUFFER_SIZE 4 / 16 with the feature macros)
+        for K in (4, 16):
+            ok = gut_reference_frame_nht(sc, feats, k_buffer=K)
+            assert np.array_equal(ok["sorted_idx"], o["sorted_idx"])
+            for name in ("feat_density", "hit_distance", "hit_count"):
+                out[f"s{k}_k{K}_{name}"] = ok[name]
+            print(f"nht scene {k} K={K}: max |features - unsorted| {np.abs(ok['feat_density'] - o['feat_density']).max():.3f}")
     np.savez_compressed(os.path.join(HERE, "gut_nht.npz"), **out)
     print("wrote gut_nht.npz")
 

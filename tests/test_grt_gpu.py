@@ -183,7 +183,7 @@ def test_refit_update_matches_full_rebuild():
 def test_errors_are_loud():
     gt = importlib.import_module("3dgrut_amd.grt_tracer")
     with pytest.raises(NotImplementedError):
-        gt.Tracer({"render": {"primitive_type": "sphere"}})
+        gt.Tracer({"render": {"primitive_type": "dodecahedron"}})
     tr = _tracer()
     scene = _scene(10, 8, 8, 0.2)
     g = syn.SimpleGaussians(scene["density12"], scene["sph"])

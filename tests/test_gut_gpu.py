@@ -974,7 +974,85 @@ def test_quarter_tile_forward_equals_the_half_tile_forward(depth_grad, rolling, 
     assert float(np.abs(a[4]).max()) > 0
 
 
-def test_nht_refuses_what_it_does_not_provide():
+@pytest.mark.parametrize("k,K", [(0, 4), (0, 16), (1, 4), (1, 16)])
+def test_nht_with_the_sorted_hit_buffer_matches_reference_kernels_golden(k, K):
+    """Round 6 (refused until then): model.feature_type = nht together with render.splat.k_buffer_size > 0 - the sorted hit buffer in front of
+    the feature integration (gutKBufferRenderer.cuh:158-225, 273-352 with PerRayParticleFeatures) - against tests/golden/gut_nht.npz s*_k{4,16}_* =
+    the reference's own kernels built with GAUSSIAN_K_BUFFER_SIZE 4 / 16 AND the feature macros."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden as mg
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gut_nht.npz"))
+    scene = make_scene(**mg.GUT_RENDER_SCENES[k])
+    import torch
     gt = importlib.import_module("3dgrut_amd.gut_tracer")
-    with pytest.raises(RuntimeError, match="k_buffer_size must be 0"):
-        gt.Tracer({"render": {"splat": {"k_buffer_size": 16}}, "model": NHT_MODEL})
+    tr = gt.Tracer({"render": {"splat": {"k_buffer_size": K}}, "model": NHT_MODEL})
+    gs = syn.SimpleGaussians(scene["density12"], g[f"s{k}_features"], requires_grad=False)
+    with torch.no_grad():
+        out = tr.render(gs, torch_batch(scene["batch"], "cuda"))
+    ref = g[f"s{k}_k{K}_feat_density"]
+    f = out["pred_features"][0].cpu().numpy()
+    o = out["pred_opacity"][0].cpu().numpy()
+    cnt = out["hits_count"][0].cpu().numpy()
+    flips = (cnt != g[f"s{k}_k{K}_hit_count"])[..., 0]
+    bad = (np.abs(f - ref[..., :24]).max(-1) > 1e-4) | (np.abs(o - ref[..., 24:])[..., 0] > 1e-4) | \
+          (np.abs(out["pred_dist"][0].cpu().numpy() - g[f"s{k}_k{K}_hit_distance"])[..., 0] > 1e-4)
+    # (hits whose distances tie to rounding may come out of the buffer in the other order: bounded, like the SH sorted mode's golden test)
+    assert flips.mean() <= 5e-3 and (bad & ~flips).mean() <= 5e-3, f"{int(bad.sum())} pixels beyond 1e-4, {int(flips.sum())} flips"
+    assert np.abs(ref - g[f"s{k}_feat_density"]).max() > 0.1    # (not the unsorted frame)
+
+
+@pytest.mark.parametrize("name", ["nht_k4", "nht_k16_depth"])
+def test_nht_with_the_sorted_hit_buffer_gradients_match_autograd_golden(name):
+    """... and its backward against float64 torch.autograd of the restated forward with the hit buffer's order (tests/golden/autograd_gut_nht.npz:
+    nht_k4, nht_k16_depth) - particle rows and the feature buffer, with a hit-distance gradient for K = 16."""
+    import torch
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "autograd_gut_nht.npz"))
+    n, w, h, seed, K = (int(g[f"{name}_{k}"]) for k in ("n", "w", "h", "seed", "K"))
+    scene = make_scene(n=n, width=w, height=h, median_scale=0.16, seed=seed)
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    tr = gt.Tracer({"render": {"splat": {"k_buffer_size": K}}, "model": NHT_MODEL})
+    gs = syn.SimpleGaussians(scene["density12"], g[f"{name}_features"])
+    out = tr.render(gs, torch_batch(scene["batch"], "cuda"), train=True)
+    g_fd, g_dist = torch.as_tensor(g[f"{name}_g_fd"], device="cuda"), torch.as_tensor(g[f"{name}_g_dist"], device="cuda")
+    loss = (out["pred_features"][0] * g_fd[..., :24]).sum() + (out["pred_opacity"][0] * g_fd[..., 24:]).sum()
+    if name.endswith("depth"):
+        loss = loss + (out["pred_dist"][0] * g_dist).sum()
+    loss.backward()
+    gd, gf = gs.grads_packed()
+    ref_d, ref_f = g[f"{name}_grad_density12"], g[f"{name}_grad_features"]
+    for key, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
+        assert rel_err(gd[:, sl], ref_d[:, sl]) < 1e-3, (key, rel_err(gd[:, sl], ref_d[:, sl]))
+    assert rel_err(gf, ref_f) < 1e-3 and gf.shape == (n, 48)
+
+
+@pytest.mark.parametrize("K,model_kw", [(8, {}), (16, {"nht_features": {"dim": 16, "activation": {"type": "siren", "num_frequencies": 3}, "interpolation_type": "barycentric"}})])
+def test_nht_with_the_sorted_hit_buffer_matches_oracle_on_a_larger_frame(K, model_kw):
+    import torch
+    model = dict(NHT_MODEL, **model_kw)
+    nf = model["nht_features"]
+    scene = make_scene(n=5000, width=112, height=64, median_scale=0.05)
+    feats = np.random.default_rng(5).uniform(-np.pi / 2, np.pi / 2, size=(5000, nf["dim"])).astype(np.float32)
+    nht = dict(particle_feature_dim=nf["dim"], interp_point_dim=nf["dim"] // 4, support=1,
+               activation={"none": 0, "siren": 1, "sincos": 2, "relu": 3}[nf["activation"]["type"]], num_frequencies=nf["activation"]["num_frequencies"])
+    nr = oracle.nht_ray_feature_dim(nht)
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    tr = gt.Tracer({"render": {"splat": {"k_buffer_size": K}}, "model": model})
+    gs = syn.SimpleGaussians(scene["density12"], feats)
+    out = tr.render(gs, torch_batch(scene["batch"], "cuda"), train=True)
+    rng = np.random.default_rng(8)
+    g_fd = rng.normal(size=(64, 112, nr + 1)).astype(np.float32)
+    t = torch.as_tensor(g_fd, device="cuda")
+    ((out["pred_features"][0] * t[..., :nr]).sum() + (out["pred_opacity"][0] * t[..., nr:]).sum()).backward()
+    gd, gf = gs.grads_packed()
+    cfg = oracle.default_gut_config(k_buffer_size=K)
+    fwd = oracle.gut_forward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats, *scene["rays"], nht=nht)
+    got = np.concatenate([out["pred_features"][0].detach().cpu().numpy(), out["pred_opacity"][0].detach().cpu().numpy()], -1)
+    flips = (out["hits_count"][0].detach().cpu().numpy() != fwd["hit_count"])[..., 0]
+    bad = (np.abs(got - fwd["feat_density"]) > 1e-4).any(-1)
+    assert flips.mean() <= 2e-3 and (bad & ~flips).mean() <= 2e-3, f"{int(bad.sum())} pixels beyond tolerance, {int(flips.sum())} flips"
+    rd, rf = oracle.gut_backward_nht(cfg, scene["cam"], scene["pose_start"], scene["pose_end"], scene["density12"], feats, *scene["rays"], fwd, g_fd, nht=nht)
+    nflip = int((flips | bad).sum())
+    for key, sl in {"position": slice(0, 3), "density": slice(3, 4), "rotation": slice(4, 8), "scale": slice(8, 11)}.items():
+        assert _trimmed_rel_err(gd[:, sl], rd[:, sl], 3 * nflip) < 1e-3, key
+    assert _trimmed_rel_err(gf, rf, 3 * nflip) < 1e-3

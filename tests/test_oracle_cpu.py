@@ -932,6 +932,19 @@ def test_nht_forward_matches_reference_kernels_golden(k):
     full = oracle.gut_forward_nht(cfg, sc["cam"], sc["pose_start"], sc["pose_end"], sc["density12"], feats, *sc["rays"])
     assert np.array_equal(full["sorted_idx"], g[f"s{k}_sorted_idx"])
     assert np.abs(full["feat_density"] - ref).max() < 2e-5
+    # round 6: the sorted hit buffer in front of the feature integration - the reference's kernels built with GAUSSIAN_K_BUFFER_SIZE 4 / 16 AND
+    # the feature macros (libref_gut_render_nht_deg2_k{4,16}.so), same tile lists.  Hits whose distances tie to rounding may swap: bounded.
+    for K in (4, 16):
+        cfg_k = oracle.default_gut_config(k_buffer_size=K)
+        ok = oracle.gut_forward_nht(cfg_k, sc["cam"], sc["pose_start"], sc["pose_end"], sc["density12"], feats, *sc["rays"],
+                                    lists=(g[f"s{k}_sorted_idx"], g[f"s{k}_tile_ranges"]))
+        ref_k = g[f"s{k}_k{K}_feat_density"]
+        assert np.abs(ref_k - ref).max() > 0.1      # (not the unsorted frame)
+        flips = (ok["hit_count"] != g[f"s{k}_k{K}_hit_count"])[..., 0]
+        e = np.abs(ok["feat_density"] - ref_k).max(-1)
+        bad = ~flips & (e > 2e-5)
+        assert flips.mean() <= 5e-3 and bad.mean() <= 5e-3, (K, int(flips.sum()), int(bad.sum()), float(e.max()))
+        assert np.abs(ok["hit_distance"] - g[f"s{k}_k{K}_hit_distance"])[~flips & ~bad].max() < 2e-5
 
 
 def test_nht_pixel_trace_recomposites_the_frame_and_identifies_a_toggled_decision():
@@ -981,7 +994,7 @@ def test_nht_pixel_trace_recomposites_the_frame_and_identifies_a_toggled_decisio
     assert (narrow == -1).all(), narrow
 
 
-@pytest.mark.parametrize("name", ["nht", "nht_depth"])
+@pytest.mark.parametrize("name", ["nht", "nht_depth", "nht_k4", "nht_k16_depth"])
 def test_nht_backward_matches_autograd_of_the_restated_reference_forward(name):
     """The nht backward is Slang autodiff output in the reference (not in the checkout): the oracle's reverse mode against float64
     torch.autograd of the restated forward (tests/golden/make_autograd_golden.py --nht), gradients w.r.t. the particle rows and the
@@ -989,7 +1002,8 @@ def test_nht_backward_matches_autograd_of_the_restated_reference_forward(name):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "autograd_gut_nht.npz"))
     n, w, h, seed = (int(g[f"{name}_{k}"]) for k in ("n", "w", "h", "seed"))
     scene = make_scene(n=n, width=w, height=h, median_scale=0.16, seed=seed)
-    cfg = oracle.default_gut_config()
+    # (round 6: nht_k4 / nht_k16_depth = the sorted hit buffer in front of the feature integration, gutKBufferRenderer.cuh:158-225, 273-352)
+    cfg = oracle.default_gut_config(k_buffer_size=int(g[f"{name}_K"]))
     feats = g[f"{name}_features"]
     # float64 build: 5e-6, not 1e-9 - the two sides share float32 INPUTS but the golden carries the ray through the frame's float32
     # pose block while the double build re-derives that block in double (their forwards agree to 8e-7, printed by the generator)
