@@ -10,7 +10,7 @@
 
 #include "../../include/grut_amd.h"
 
-#define GRUT_ABI_VERSION 4
+#define GRUT_ABI_VERSION 5
 #define GRUT_WAVE 64
 
 namespace grut {

@@ -93,12 +93,10 @@ static int grt_validate(const GrtConfig& c) {
         GRUT_REQUIRE(!c.enable_normals, "neural harmonic features: enable_normals must be off");
         // (the feature kernels index the feature rows by the log's proxy id and blend at the volumetric intersection: closed proxies only —
         // the plugin's grt_config_from_conf refuses the same combinations)
-        // round 6: trihexa and sphere too (proxy -> particle at the per-hit sites).  trisurfel would need the surfel branches of the feature
-        // programs (the blend point on the surfel's plane); the Slang pipeline's custom-primitive test (particleDensityHitCustom,
-        // gaussianParticles.slang:489-523) reports the UNSIGNED distance of the closest approach, not intersectCustomParticle's signed one -
-        // another candidate test than GRUT_PRIM_CUSTOM's: neither is built
-        GRUT_REQUIRE(c.primitive_type != GRUT_PRIM_TRISURFEL && c.primitive_type != GRUT_PRIM_CUSTOM,
-                     "neural harmonic features: primitive_type %d (custom / trisurfel) is not provided (every other proxy is)", c.primitive_type);
+        // round 6: trihexa and sphere too (proxy -> particle at the per-hit sites), and custom with the Slang pipeline's own candidate test
+        // (particleDensityHitCustom reports the UNSIGNED distance of the maximum: RayW::absdist).  trisurfel would need the surfel branches of
+        // the feature programs (the blend point on the surfel's plane): not built
+        GRUT_REQUIRE(c.primitive_type != GRUT_PRIM_TRISURFEL, "neural harmonic features: primitive_type trisurfel is not provided (every other proxy is)");
         GRUT_REQUIRE(c.feature_interpolation_support == 0 || c.feature_interpolation_support == 1, "feature_interpolation_support must be 0 (centre) or 1 (tetrahedra)");
         GRUT_REQUIRE(c.feature_activation_type >= 0 && c.feature_activation_type <= 3, "feature_activation_type must be 0..3");
         const int points = c.feature_interpolation_support == 1 ? 4 : 1;

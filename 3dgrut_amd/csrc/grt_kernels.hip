@@ -382,6 +382,7 @@ __global__ __launch_bounds__(1024) void grt_refit_finish_kernel(uint32_t N, uint
 struct RayW {
     f3 o, d, inv;
     int prim;   // GrtTraceParams::prim rides with the ray: the candidate test is the one place that depends on it
+    int absdist;   // custom primitives under the Slang pipelines (neural harmonic features): the UNSIGNED hit distance of particleDensityHitCustom
     const float* box8;   // GRUT_PRIM_CUSTOM: per particle {world box min, max (as the reference's AABB kernel computes it), kernelScale^2, 0}
 };
 __device__ __forceinline__ float safe_rcp(float v) {
@@ -406,6 +407,7 @@ __device__ __forceinline__ RayW make_ray(const GrtTraceParams& P, const float* _
     }
     r.inv = mk3(safe_rcp(r.d.x), safe_rcp(r.d.y), safe_rcp(r.d.z));
     r.prim = P.prim;
+    r.absdist = (P.prim == GRUT_PRIM_CUSTOM && P.nht) ? 1 : 0;
     r.box8 = P.box8;
     return r;
 }
@@ -602,6 +604,10 @@ __device__ __forceinline__ Cand candidate_abe(const float4& a, const float4& b, 
     const float numerator = -fmaf(poz, pdz, fmaf(poy, pdy, pox * pdx));
     const float dd = fmaf(pdz, pdz, fmaf(pdy, pdy, pdx * pdx));
     c.t = numerator / dd;
+    // (custom primitives with neural harmonic features: the Slang pipeline's intersection test, particleDensityHitCustom,
+    // gaussianParticles.slang:489-523, reports canonicalRayDistance - a length - where intersectCustomParticle reports it with the ray
+    // parameter's sign: a particle whose maximum lies behind the ray origin is a candidate there.  Folds away for every other primitive.)
+    if (r.prim == GRUT_PRIM_CUSTOM && r.absdist) c.t = fabsf(c.t);
     const bool wanted = (TIES ? (c.t >= t_lo) : (c.t > t_lo)) && ((c.t < t_hi) || (c.t == t_hi && id < id_hi));
     if (!wanted && !always_box) return c;
     // (round 6: in the packet lists' test too - the default configuration's forward is an instantiation of its own in which r.prim is a

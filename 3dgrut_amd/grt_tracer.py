@@ -59,12 +59,12 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
     prim = _conf_get(render, "primitive_type", "instances")
     if prim not in _abi.GRT_PRIMITIVES:
         raise NotImplementedError(f"3dgrut_amd: render.primitive_type={prim!r} is not supported (provided: {tuple(_abi.GRT_PRIMITIVES)})")
-    if nht and prim in ("trisurfel", "custom"):
+    if nht and prim == "trisurfel":
         # (the feature path walks the trace kernel's hit log and evaluates the features at each hit's canonical intersection: it does not care
         # which candidate test ordered the log - instances, the closed mesh proxies, trihexa and sphere (round 6: proxy -> particle at the
-        # per-hit sites).  The surfel variant blends at the ray's crossing of the surfel's plane, and the Slang pipeline's custom-primitive
-        # test reports an unsigned distance (gaussianParticles.slang:489-523) - another candidate test than `custom`'s: neither is built)
-        raise NotImplementedError("3dgrut_amd: neural harmonic features are not provided with primitive_type custom / trisurfel (every other proxy is)")
+        # per-hit sites), custom (round 6: with the Slang pipeline's own test, which reports an unsigned distance, gaussianParticles.slang:489-523).
+        # The surfel variant blends at the ray's crossing of the surfel's plane: not built)
+        raise NotImplementedError("3dgrut_amd: neural harmonic features are not provided with primitive_type trisurfel (every other proxy is)")
     cfg.primitive_type = _abi.GRT_PRIMITIVES[prim]
     # fp16 feature I/O (setup_3dgrt.py:41-44): run-time switches here, compile-time macros in the reference
     cfg.particle_feature_half = int(bool(_conf_get(render, "particle_feature_half", False)))

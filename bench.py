@@ -362,7 +362,7 @@ def bench_nht(args, dev, n, W, H, ms, emit=True):
     K = syn.pinhole_intrinsics(W, H)
     ro, rd = syn.pinhole_rays(W, H, K)
     batch = torch_batch(dict(rays_ori=ro, rays_dir=rd, T_to_world=syn.orbit_pose(0, n_views=8)[None], intrinsics=K), dev)
-    tracer = gt.Tracer({"render": {"enable_kernel_timings": True, "splat": {}},
+    tracer = gt.Tracer({"render": {"enable_kernel_timings": True, "splat": {"k_buffer_size": int(getattr(args, "k_buffer", 0))}},   # (--k-buffer K: the sorted hit buffer in front)
                         "model": {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1},
                                                                           "interpolation_type": "barycentric"}}})
     g = syn.SimpleGaussians(d12, feats, device=dev)
@@ -387,7 +387,7 @@ def bench_nht(args, dev, n, W, H, ms, emit=True):
     result = {"metric": "train rays/sec (3DGUT, neural harmonic features, forward+backward)", "value": W * H * args.steps / dt, "unit": "rays/s",
               "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup, "n_gpus": 1, "higher_is_better": True, "dtype": "f32",
               "data": "synthetic", "stages_ms": tracer.timings,
-              "config": {"workload": f"3DGUT fwd+bwd with neural harmonic features, {n} Gaussians, {W}x{H}, 48 feature floats per particle -> 24 ray features",
+              "config": {"workload": f"3DGUT fwd+bwd with neural harmonic features, {n} Gaussians, {W}x{H}, 48 feature floats per particle -> 24 ray features, k_buffer {int(args.k_buffer)}",
                          "name": args.workload},
               "work": {"N": int(st.num_particles), "Nv": int(st.num_visible), "I": int(st.num_intersections)}}
     if emit:

@@ -347,7 +347,8 @@ def _nht_prm(nht):
     return nht, np.array([nht["particle_feature_dim"], nht["interp_point_dim"], nht["support"], nht["activation"], nht["num_frequencies"]], np.int32)
 
 
-def grt_forward_nht(cfg, density12, features, min_transmittance, ray_to_world, ray_o, ray_d, nht=None, inst=None, scene=None, dbg_cap=0, dtype=np.float32):
+def grt_forward_nht(cfg, density12, features, min_transmittance, ray_to_world, ray_o, ray_d, nht=None, inst=None, scene=None, dbg_cap=0, dtype=np.float32,
+                    box8=None):
     """The Slang pipeline with neural harmonic features (referenceSlangOptix.cu): like grt_forward, `features` [N, K] -> out features [H, W, ray_dim]."""
     l, R = lib(dtype), _real(dtype)
     nht, prm = _nht_prm(nht)
@@ -357,6 +358,8 @@ def grt_forward_nht(cfg, density12, features, min_transmittance, ray_to_world, r
         pr = grt_proxies(cfg, d12[:, 0:3], d12[:, 4:8], d12[:, 8:11], d12[:, 3], dtype)
         inst, scene = pr["inst"], pr["scene"]
     inst, scene = _c(inst, dtype), _c(scene, dtype)
+    if cfg.primitive_type == 5:   # custom primitives: the world boxes (the GPU's, when given - like `inst`)
+        box8 = grt_custom_boxes(cfg, d12, dtype) if box8 is None else grt_set_custom_boxes(box8, dtype)
     ro, rd = _c(ray_o, dtype), _c(ray_d, dtype)
     H, W = ro.shape[-3], ro.shape[-2]
     n = H * W
@@ -370,7 +373,7 @@ def grt_forward_nht(cfg, density12, features, min_transmittance, ray_to_world, r
                                 _p(ro), _p(rd), _p(out["features"]), _p(out["density"]), _p(out["hit_distance"]), _p(out["hit_count"]),
                                 _p(out["visibility"]), _p(dbg_ids) if dbg_cap else None, _p(dbg_cnt), C.c_uint32(dbg_cap))
     assert r == 0
-    out.update(hit_ids=dbg_ids, hit_num=dbg_cnt, inst=inst, scene=scene, density12=d12, nht_features=f, rays=(ro, rd), ray_to_world=m, nht=nht)
+    out.update(hit_ids=dbg_ids, hit_num=dbg_cnt, inst=inst, scene=scene, density12=d12, nht_features=f, rays=(ro, rd), ray_to_world=m, nht=nht, box8=box8)
     return out
 
 
@@ -384,6 +387,8 @@ def grt_backward_nht(cfg, min_transmittance, fwd, g_features, g_density, g_hit_d
     n = ro.shape[-3] * ro.shape[-2]
     gd, gf = np.zeros((N, 12), dtype), np.zeros_like(f)
     gh = np.zeros((n,), dtype) if g_hit_distance is None else _c(g_hit_distance, dtype)
+    if cfg.primitive_type == 5:
+        grt_set_custom_boxes(fwd["box8"], dtype)
     r = l.orc_grt_trace_nht_bwd(C.byref(cfg), _p(prm), C.c_uint32(N), _p(d12), _p(f), R(min_transmittance), _p(fwd["inst"]), _p(fwd["scene"]),
                                 _p(fwd["ray_to_world"]), C.c_uint32(n), _p(ro), _p(rd), _p(_c(fwd["features"], dtype)), _p(_c(fwd["density"], dtype)),
                                 _p(_c(fwd["hit_distance"], dtype)), _p(_c(g_features, dtype)), _p(_c(g_density, dtype)), _p(gh), _p(gd), _p(gf))

@@ -43,7 +43,12 @@ real orc_grt_kernel_scale(real density, real min_response, int clamping, real de
  * A process-wide setting of this test library (the entry points that take a GrtConfig set it from cfg->primitive_type). */
 #include "orc_polyhedra.h"
 static int g_prim = 0;
-void orc_grt_set_primitive(int prim) { g_prim = prim; }
+/* custom primitives under the SLANG pipelines (neural harmonic features): particleDensityHitCustom (gaussianParticles.slang:489-523) reports
+ * canonicalRayDistance - the UNSIGNED distance of the maximum-response point - where intersectCustomParticle (gaussianParticles.cuh:407-441)
+ * reports it with the sign of the ray parameter: a particle whose maximum lies BEHIND the ray origin is a candidate of the Slang pipeline.
+ * Set by the feature entry points, cleared by every other one. */
+static int g_custom_abs = 0;
+void orc_grt_set_primitive(int prim) { g_prim = prim; g_custom_abs = 0; }
 /* GRUT_PRIM_CUSTOM (render.primitive_type custom): per particle {world box min, max, kernelScale^2, 0} - orc_grt_custom_boxes fills it, the
  * caller keeps it alive and registers it here before tracing (process-wide, like the primitive type). */
 static const real* g_box8 = NULL;
@@ -174,6 +179,7 @@ static grt_cand candidate(const real* inst, v3 o, v3 d, real max_sqdist, uint32_
         const real numerator = -r_fma(po.z, pd.z, r_fma(po.y, pd.y, po.x * pd.x));
         const real dd = r_fma(pd.z, pd.z, r_fma(pd.y, pd.y, pd.x * pd.x));
         c.t = numerator / dd;
+        if (g_custom_abs) c.t = r_fabs(c.t);
         const v3 cr = v3_make(r_fma(pd.y, po.z, -(pd.z * po.y)), r_fma(pd.z, po.x, -(pd.x * po.z)), r_fma(pd.x, po.y, -(pd.y * po.x)));
         c.ok = (r_fma(cr.z, cr.z, r_fma(cr.y, cr.y, cr.x * cr.x)) * bx[6] < max_sqdist * dd);
         return c;
@@ -845,6 +851,7 @@ int orc_grt_trace_nht_fwd(const GrtConfig* cfg, const int* nht, uint32_t N, cons
                           const real* ray_d, real* out_feat, real* out_dns, real* out_hit2, real* out_cnt, int32_t* visibility,
                           uint32_t* dbg_ids, uint32_t* dbg_count, uint32_t dbg_cap) {
     orc_grt_set_primitive(cfg->primitive_type);
+    g_custom_abs = cfg->primitive_type == 5;
     const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
     const int nr = orc_nht_ray_dim(nht), KF = nht[0];
     if (K > GRT_MAX_K || nr > ORC_NHT_MAX_DIM || nht[1] > ORC_NHT_MAX_DIM) return -1;
@@ -919,6 +926,7 @@ int orc_grt_trace_nht_bwd(const GrtConfig* cfg, const int* nht, uint32_t N, cons
                           const real* ray_d, const real* feat, const real* dns, const real* hit2, const real* g_feat, const real* g_dns,
                           const real* g_hit, real* g_density12, real* g_features) {
     orc_grt_set_primitive(cfg->primitive_type);
+    g_custom_abs = cfg->primitive_type == 5;
     (void)min_T;
     const int K = cfg->max_hits_per_trace > 0 ? cfg->max_hits_per_trace : 16;
     const int nr = orc_nht_ray_dim(nht), KF = nht[0];

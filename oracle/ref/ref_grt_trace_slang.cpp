@@ -37,6 +37,9 @@
 #ifdef REF_PRIMITIVE   // a triangle-mesh proxy: -DREF_PRIMITIVE=MOGTracingIcosaHedron (as ref_grt_trace.cpp; tests/golden/grt_trace_nht_mesh.npz)
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::REF_PRIMITIVE
 #define SHIM_OPTIX_TRIANGLE_PROXIES
+#elif defined(REF_CUSTOM)   // custom primitives: world boxes + the Slang pipeline's own intersection test particleDensityHitCustom (referenceSlangOptix.cu:204-220)
+#define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingCustom
+#define SHIM_OPTIX_CUSTOM_PROXIES
 #elif defined(REF_SPHERE)   // OptiX's built-in sphere primitive (as ref_grt_trace.cpp)
 #define PARTICLE_PRIMITIVE_TYPE MOGPrimitiveTypes::MOGTracingSphere
 #define SHIM_OPTIX_SPHERE_PROXIES
@@ -80,6 +83,20 @@ void ref_grt_trace_slang_fwd_mesh(uint32_t n, uint32_t triangles_per_particle, c
     set_common_params(width, height, ray_to_world, ray_o, ray_d, density12, features48, scene_aabb6, min_transmittance, min_response, min_alpha, 3,
                       features, density, hit_distance2, unused_normals.data(), hits_count, visibility);
     set_scene_triangles(n * triangles_per_particle, triangles_per_particle, vertices, triangles);
+    launch_raygen(width, height);
+}
+#endif
+
+#ifdef REF_CUSTOM
+// the same programs over the particles' world boxes (boxes [n,6] as the reference's AABB kernel wrote them, ref_grt_proxies.cpp)
+void ref_grt_trace_slang_fwd_custom(uint32_t n, const float* boxes, const float* density12, const float* features48, int width, int height, const float* ray_to_world,
+                                    const float* ray_o, const float* ray_d, const float* scene_aabb6, float min_transmittance, float min_response, float min_alpha,
+                                    float* features, float* density, float* hit_distance2, float* hits_count, int32_t* visibility) {
+    static thread_local std::vector<float> unused_normals;
+    unused_normals.assign((size_t)width * height * 3, 0.f);
+    set_common_params(width, height, ray_to_world, ray_o, ray_d, density12, features48, scene_aabb6, min_transmittance, min_response, min_alpha, 3,
+                      features, density, hit_distance2, unused_normals.data(), hits_count, visibility);
+    set_scene_boxes(n, boxes);
     launch_raygen(width, height);
 }
 #endif

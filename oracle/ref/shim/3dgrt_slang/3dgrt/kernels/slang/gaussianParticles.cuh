@@ -249,7 +249,25 @@ inline bool particleDensityHitInstance(float3 o, float3 dUn, float minHitDistanc
     const float3 gcrod = {d.y * o.z - d.z * o.y, d.z * o.x - d.x * o.z, d.x * o.y - d.y * o.x};
     return (*hitDistance > minHitDistance) && (*hitDistance < maxHitDistance) && (dot3(gcrod, gcrod) < maxParticleSquaredDistance);
 }
-// particleDensityHitCustom (:489-523) is the custom-primitive pipeline's test; the playground's default build traces instances
-inline bool particleDensityHitCustom(float3, float3, int32_t, gaussianParticle_CommonParameters_0, float, float, float, float*) {
-    std::abort();
+// particleDensityHitCustom (gaussianParticles.slang:489-523), the custom-primitive pipeline's test in world space: cannonicalRay (:103-117), the
+// hit distance canonicalRayDistance (:180-186) = |scale * d (d . -o)| - UNSIGNED, unlike intersectCustomParticle's of the CUDA pipeline -,
+// accepted within maxParticleSquaredDistance of the centre in the scale frame (canonicalRayMinSquaredDistance :118-132, volumetric)
+inline bool particleDensityHitCustom(float3 rayOrigin, float3 rayDirection, int32_t particleIdx, gaussianParticle_CommonParameters_0 common, float minHitDistance,
+                                     float maxHitDistance, float maxParticleSquaredDistance, float* hitDistance) {
+    using namespace grt_slang_standin;
+    const gaussianParticle_RawParameters_0 raw = common.parametersBuffer_0._dataPtr_0[particleIdx];
+    const Rot rotT = rotation_transpose(raw.quaternion_0);
+    const float3 giscl = {1.0f / raw.scale_0.x, 1.0f / raw.scale_0.y, 1.0f / raw.scale_0.z};
+    const float3 gposc = {rayOrigin.x - raw.position_0.x, rayOrigin.y - raw.position_0.y, rayOrigin.z - raw.position_0.z};
+    const float3 gposcr = mul33(rotT, gposc);
+    const float3 o = {giscl.x * gposcr.x, giscl.y * gposcr.y, giscl.z * gposcr.z};
+    const float3 rayDirR = mul33(rotT, rayDirection);
+    const float3 grdu = {giscl.x * rayDirR.x, giscl.y * rayDirR.y, giscl.z * rayDirR.z};
+    const float inv_len = 1.0f / std::sqrt(dot3(grdu, grdu));
+    const float3 d = {grdu.x * inv_len, grdu.y * inv_len, grdu.z * inv_len};
+    const float along = dot3(d, {-1.f * o.x, -1.f * o.y, -1.f * o.z});
+    const float3 grds = {raw.scale_0.x * (d.x * along), raw.scale_0.y * (d.y * along), raw.scale_0.z * (d.z * along)};
+    *hitDistance = std::sqrt(dot3(grds, grds));
+    const float3 gcrod = {d.y * o.z - d.z * o.y, d.z * o.x - d.x * o.z, d.x * o.y - d.y * o.x};
+    return (*hitDistance > minHitDistance) && (*hitDistance < maxHitDistance) && (dot3(gcrod, gcrod) < maxParticleSquaredDistance);
 }

@@ -532,7 +532,7 @@ def make_grt_trace_nht_mesh():
     px.ref_enclosing_mesh.restype = C.c_uint
     out = {}
     # round 6: the trihexa proxies (three offers per particle) and OptiX's built-in spheres (two offers) through the same Slang programs
-    for prim, tag in (("icosahedron", "IcosaHedron"), ("trihexa", "TriHexa"), ("sphere", "Sphere")):
+    for prim, tag in (("icosahedron", "IcosaHedron"), ("trihexa", "TriHexa"), ("sphere", "Sphere"), ("custom", "Custom")):
         fw = C.CDLL(os.path.join(REF, f"libref_grt_trace_slang_{tag}_deg4.so"))
         assert fw.ref_grt_slang_ray_feature_dim() == 24
         for k, kw in enumerate(GRT_TRACE_SCENES[:1]):
@@ -553,6 +553,11 @@ def make_grt_trace_nht_mesh():
                 px.ref_enclosing_spheres(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(ctr), _p(rad))
                 box = np.concatenate([(ctr - rad[:, None]).min(0), (ctr + rad[:, None]).max(0)]).astype(F)
                 fw.ref_grt_trace_slang_fwd_sphere(C.c_uint(n), _p(ctr), _p(rad), _p(d12), _p(feats), *tail, _p(box), *tail2)
+            elif prim == "custom":   # world boxes + the Slang pipeline's own intersection test (particleDensityHitCustom: restated in the shim)
+                aabb, tf = np.zeros((n, 6), F), np.zeros((n, 12), F)
+                px.ref_enclosing_proxies(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(aabb), _p(tf))
+                box = np.concatenate([aabb[:, :3].min(0), aabb[:, 3:].max(0)]).astype(F)
+                fw.ref_grt_trace_slang_fwd_custom(C.c_uint(n), _p(aabb), _p(d12), _p(feats), *tail, _p(box), *tail2)
             else:
                 code, _ = MESH_PRIMITIVES[prim]
                 verts, tris, nv = np.zeros((n * 12, 3), F), np.zeros((n * 20, 3), np.int32), C.c_uint(0)

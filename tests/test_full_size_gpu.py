@@ -71,6 +71,35 @@ def test_gut_nht_frame_matches_oracle_at_baseline_size():
     pu.assert_gut_full_parity_nht(stats)
 
 
+def test_gut_nht_behind_the_sorted_hit_buffer_matches_oracle_at_baseline_size():
+    """Round 6: model.feature_type = nht with render.splat.k_buffer_size = 16 (refused until then) at the bench size: the checker composites the
+    GPU's own tile lists through the sorted hit buffer (orc_gut_render_nht_fwd with k_buffer_size 16).  Pixels whose hit count differs are
+    decision flips; among the others a pixel beyond 1e-4 is an order tie of two hits in the buffer or the rounding class - bounded in number
+    here (the K = 0 feature frame and the SH sorted frame identify theirs pixel by pixel; this first version of the combination bounds them)."""
+    import importlib
+    import torch
+    n, w, h = N, W, H
+    inp = pu.make_frame_inputs(n, w, h, 0.01)
+    feats = np.random.default_rng(43).uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)
+    gt = importlib.import_module("3dgrut_amd.gut_tracer")
+    model = {"feature_type": "nht", "nht_features": {"dim": 48, "activation": {"type": "sincos", "num_frequencies": 1}, "interpolation_type": "barycentric"}}
+    tracer = gt.Tracer({"render": {"enable_hitcounts": True, "splat": {"k_buffer_size": 16}}, "model": model})
+    hip = pu.hip_forward(dict(inp, sph=feats), tracer=tracer, device_pose=True)
+    cfg = pu.oracle.default_gut_config(k_buffer_size=16)
+    ora = pu.oracle.gut_forward_nht(cfg, inp["cam"], inp["ps"], inp["pe"], inp["d12"], feats, *inp["rays"], lists=(hip["sorted_idx"], hip["tile_ranges"]))
+    d_img = np.abs(hip["fd"] - ora["feat_density"]).max(-1)
+    d_dist = np.abs(hip["dist"] - ora["hit_distance"])[..., 0]
+    X = hip["cnt"] != ora["hit_count"][..., 0]
+    bad = ((d_img > 1e-4) | (d_dist > 1e-4)) & ~X
+    stats = dict(N=n, W=w, H=h, P=w * h, variant="nht_k16", B_flip_pixels=int(X.sum()), B_flip_frac=float(X.mean()), B_beyond_1e4_outside_flips=int(bad.sum()),
+                 B_beyond_1e4_frac=float(bad.mean()), B_max_err_outside_flips=float(d_img[~X].max()), B_median_err=float(np.median(d_img)),
+                 B_feature_abs_max=float(np.abs(ora["feat_density"][..., :24]).max()), hits_per_pixel=float(ora["hit_count"].mean()))
+    print(stats)
+    pu.record_full_parity("c4_1m_1080p_nht_k16", stats)
+    assert stats["B_flip_frac"] <= 2e-3 and stats["B_beyond_1e4_frac"] <= 2e-3 and stats["B_feature_abs_max"] > 0.3, stats
+    assert stats["B_max_err_outside_flips"] < 5e-2 and stats["B_median_err"] < 1e-5, stats
+
+
 @pytest.mark.parametrize("name,n,w,h,median_scale,ray_stride,prim", [
     ("c3_grt_100k_400", 100_000, 400, 400, 0.01, 1, "instances"), ("c3_grt_1m_800", 1_000_000, 800, 800, 0.01, 149, "instances"),
     # the reference paper's own 3DGRT configuration (configs/paper/3dgrt/base_ours_reference.yaml:16) and the custom-primitive proxies at

@@ -731,7 +731,7 @@ def test_c_abi_refuses_feature_kernels_on_open_proxies():
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     abi = importlib.import_module("3dgrut_amd._abi")
     lib = abi.load_library()
-    for prim in ("custom", "trisurfel"):
+    for prim in ("trisurfel",):
         with pytest.raises(NotImplementedError, match="neural harmonic"):
             grt.grt_config_from_conf({"render": {"pipeline_type": "referenceSlang", "primitive_type": prim}, "model": NHT_CONF})
         cfg = grt.grt_config_from_conf({"render": {"pipeline_type": "referenceSlang"}, "model": NHT_CONF})
@@ -1095,7 +1095,7 @@ def test_nht_backward_matches_oracle(replay, half):
     assert trimmed(gf, rf, 3 * n_flip) < 1e-3 and gf.shape == (n, 48) and np.abs(rf).max() > 0
 
 
-@pytest.mark.parametrize("prim,code", [("icosahedron", 1), ("trihexa", 7), ("sphere", 8)])
+@pytest.mark.parametrize("prim,code", [("icosahedron", 1), ("trihexa", 7), ("sphere", 8), ("custom", 5)])
 def test_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden_and_the_oracle(prim, code):
     """(round 6: also trihexa and sphere - several proxies per particle, the feature kernels map the log's proxy ids to particles.)
     model.feature_type = nht with render.primitive_type = icosahedron (round 5; refused until then): the forward DIRECTLY against
@@ -1147,7 +1147,8 @@ def test_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden_and_
         nat = tr.tracer_wrapper
         inst = nat.instances(n, "cuda").cpu().numpy()
         aabb = np.array(list(nat.stats().scene_aabb), np.float32)
-        ora = oracle.grt_forward_nht(cfg, scene["density12"], feats, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=aabb)
+        box_kw = dict(box8=nat.custom_boxes(n, "cuda").cpu().numpy()) if prim == "custom" else {}   # (the checker gets the GPU's world boxes like its records)
+        ora = oracle.grt_forward_nht(cfg, scene["density12"], feats, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=aabb, **box_kw)
         f = out["pred_features"][0].detach().cpu().numpy()
         flips = (out["hits_count"][0].detach().cpu().numpy() != ora["hit_count"])[..., 0]
         bad = (np.abs(f - ora["features"]) > 1e-4).any(-1) | (np.abs(out["pred_opacity"][0].detach().cpu().numpy() - ora["density"])[..., 0] > 1e-4)
@@ -1160,6 +1161,36 @@ def test_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden_and_
             err = np.sort(err)[: max(1, len(err) - drop)]
             return float(err.max() / (np.abs(b).max() + 1e-12))
         assert trimmed(gd[:, :11], rd[:, :11], 3 * n_flip) < 1e-3 and trimmed(gf, rf, 3 * n_flip) < 1e-3, (replay, trimmed(gd[:, :11], rd[:, :11], 3 * n_flip), trimmed(gf, rf, 3 * n_flip))
+
+
+def test_custom_primitives_with_features_use_the_slang_pipelines_unsigned_hit_distance():
+    """Round 6: render.primitive_type custom under the Slang pipelines.  particleDensityHitCustom (gaussianParticles.slang:489-523) reports
+    canonicalRayDistance - a LENGTH - where the CUDA pipeline's intersectCustomParticle reports the distance with the ray parameter's sign: a
+    particle whose point of maximum response lies BEHIND the ray origin (the origin inside its world box) is a candidate of the Slang pipeline
+    and not of the CUDA one.  A camera in the middle of a few large particles: the feature frame (HIP and checker agree) counts hits the SH
+    frame of the same proxies does not."""
+    import torch
+    n, w, h = 400, 32, 24
+    scene = _scene(n, w, h, 0.9, max_density=0.5)
+    feats = np.random.default_rng(2).uniform(-np.pi / 2, np.pi / 2, size=(n, 48)).astype(np.float32)
+    tr = _nht_tracer(primitive_type="custom")
+    g = syn.SimpleGaussians(scene["density12"], feats, requires_grad=False)
+    tr.build_acc(g, rebuild=True)
+    with torch.no_grad():
+        out = tr.render(g, torch_batch(scene["batch"], "cuda"))
+    nat = tr.tracer_wrapper
+    inst = nat.instances(n, "cuda").cpu().numpy()
+    aabb = np.array(list(nat.stats().scene_aabb), np.float32)
+    box8 = nat.custom_boxes(n, "cuda").cpu().numpy()
+    cfg = oracle.default_grt_config(primitive_type=5)
+    ora = oracle.grt_forward_nht(cfg, scene["density12"], feats, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=aabb, box8=box8)
+    cnt = out["hits_count"][0].cpu().numpy()
+    flips = (cnt != ora["hit_count"])[..., 0]
+    bad = (np.abs(out["pred_features"][0].cpu().numpy() - ora["features"]) > 1e-4).any(-1)
+    assert flips.mean() <= 5e-3 and (bad & ~flips).mean() <= 5e-3, (int(flips.sum()), int(bad.sum()))
+    # the SH frame over the same proxies (signed distances): fewer processed hits
+    sh = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, scene["T"], *scene["rays"], inst=inst, scene=aabb, box8=box8)
+    assert ora["hit_count"].sum() > sh["hit_count"].sum(), (float(ora["hit_count"].sum()), float(sh["hit_count"].sum()))
 
 
 def test_nht_forward_matches_reference_slang_programs_golden():

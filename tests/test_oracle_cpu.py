@@ -1109,7 +1109,7 @@ def test_grt_nht_forward_matches_reference_slang_programs_golden():
         assert g[f"s{k}_hits_count"].max() >= 20 and np.abs(g[f"s{k}_features"]).max() > 0.5
 
 
-@pytest.mark.parametrize("prim,code", [("icosahedron", 1), ("trihexa", 7), ("sphere", 8)])
+@pytest.mark.parametrize("prim,code", [("icosahedron", 1), ("trihexa", 7), ("sphere", 8), ("custom", 5)])
 def test_grt_nht_on_icosahedron_proxies_matches_reference_slang_programs_golden(prim, code):
     """(round 6: also trihexa - three offers per particle - and sphere - two - built the same way: libref_grt_trace_slang_{TriHexa,Sphere}_deg4.so)
     model.feature_type = nht together with render.primitive_type = icosahedron (round 5): orc_grt_trace_nht_fwd with the polyhedron clip as
