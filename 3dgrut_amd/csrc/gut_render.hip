@@ -2149,9 +2149,10 @@ __device__ __forceinline__ void nht_k_pop_fwd(const GutParams& P, const Ray& ray
     if (s.T < P.min_transmittance) alive = false;
 }
 struct NhtKBwdState { float Cb[kNhtMaxRay], gC[kNhtMaxRay], Tb, gT, Db, gD, T; };
-__device__ __forceinline__ void nht_k_pop_bwd(const GutParams& P, const Ray& ray, const NhtTetra4& tet, const float4* __restrict__ density12,
+// returns whether the hit carries gradients; gd = its 11 geometric words, wq / gbase = the factors of its feature-row words (wq[k] * gbase[m])
+__device__ __forceinline__ bool nht_k_pop_bwd(const GutParams& P, const Ray& ray, const NhtTetra4& tet, const float4* __restrict__ density12,
                                               const float* __restrict__ features, float hitT, float alpha, uint32_t idx, NhtKBwdState& s, bool& alive,
-                                              float* __restrict__ g_density12, float* __restrict__ g_features) {
+                                              float (&gd)[11], float (&wq)[4], float (&gbase)[kNhtMaxIpd]) {
     const int points = P.nht_support == 1 ? 4 : 1, ipd = P.nht_ipd, nr = P.nht_ray_dim;
     const float4 a = density12[3 * (size_t)idx], q = density12[3 * (size_t)idx + 1], sc = density12[3 * (size_t)idx + 2];
     const m3 rotT = quat_wxyz_to_rotT(q.x, q.y, q.z, q.w);
@@ -2173,13 +2174,15 @@ __device__ __forceinline__ void nht_k_pop_bwd(const GutParams& P, const Ray& ray
     const f3 grds = gscl * grdd;
     const float gsq = dot(grds, grds);
     const bool hit = alpha > 0.f;
-    float wq[4] = {1.f, 0.f, 0.f, 0.f};
+    wq[0] = 1.f; wq[1] = 0.f; wq[2] = 0.f; wq[3] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) gd[k] = 0.f;
     if (P.nht_support == 1) {
         const f3 d = Pc - tet.v0;
         wq[1] = dot(d, tet.c23) * tet.inv_det; wq[2] = dot(tet.e1, cross(d, tet.e3)) * tet.inv_det; wq[3] = dot(tet.e1, cross(tet.e2, d)) * tet.inv_det;
         wq[0] = 1.f - wq[1] - wq[2] - wq[3];
     }
-    float base[kNhtMaxIpd], gbase[kNhtMaxIpd];
+    float base[kNhtMaxIpd];
 #pragma unroll
     for (int m = 0; m < kNhtMaxIpd; ++m) {
         base[m] = 0.f; gbase[m] = 0.f;
@@ -2207,18 +2210,14 @@ __device__ __forceinline__ void nht_k_pop_bwd(const GutParams& P, const Ray& ray
             }
         }
     }
-    // blend backward: the feature rows (per-hit atomics, as the reference) and the canonical position
+    // blend backward: the canonical position (the feature rows' words wq[k] * gbase[m] leave through nht_k_bwd_flush)
     f3 dP = mk3(0.f, 0.f, 0.f);
     if (hit) {
         float dw[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < kNhtMaxIpd; ++m)
             if (m < ipd)
-                for (int k = 0; k < points; ++k) {
-                    dw[k] = fmaf(nht_feature_word(P, features, idx, k * ipd + m), gbase[m], dw[k]);
-                    const float g = wq[k] * gbase[m];
-                    if (g != 0.f) atomicAdd(g_features + (size_t)idx * P.nht_k + (size_t)k * ipd + m, g);
-                }
+                for (int k = 0; k < points; ++k) dw[k] = fmaf(nht_feature_word(P, features, idx, k * ipd + m), gbase[m], dw[k]);
         if (P.nht_support == 1) dP = tet.gw0 * dw[0] + tet.gw1 * dw[1] + tet.gw2 * dw[2] + tet.gw3 * dw[3];
     }
     // density: T_out = T_in (1 - alpha), D_front = lerp(D_behind, depth, alpha)
@@ -2250,13 +2249,55 @@ __device__ __forceinline__ void nht_k_pop_bwd(const GutParams& P, const Ray& ray
         const f3 grduGrd = dn * il - grdu * (il * il * il * dot(dn, grdu));   // normalize backward
         const f3 sclGrd = gsclHit + gsclGro + mk3(-rdr.x * is2.x, -rdr.y * is2.y, -rdr.z * is2.z) * grduGrd;
         const float4 gq1 = quat_outer_contract(gposcrGrd, gposc, q), gq2 = quat_outer_contract(giscl * grduGrd, ray.d, q);
-        float* gd = g_density12 + 12 * (size_t)idx;
-        atomicAdd(gd + 0, -gposcGrd.x); atomicAdd(gd + 1, -gposcGrd.y); atomicAdd(gd + 2, -gposcGrd.z); atomicAdd(gd + 3, ddens);
-        atomicAdd(gd + 4, gq1.x + gq2.x); atomicAdd(gd + 5, gq1.y + gq2.y); atomicAdd(gd + 6, gq1.z + gq2.z); atomicAdd(gd + 7, gq1.w + gq2.w);
-        atomicAdd(gd + 8, sclGrd.x); atomicAdd(gd + 9, sclGrd.y); atomicAdd(gd + 10, sclGrd.z);
+        gd[0] = -gposcGrd.x; gd[1] = -gposcGrd.y; gd[2] = -gposcGrd.z; gd[3] = ddens;
+        gd[4] = gq1.x + gq2.x; gd[5] = gq1.y + gq2.y; gd[6] = gq1.z + gq2.z; gd[7] = gq1.w + gq2.w;
+        gd[8] = sclGrd.x; gd[9] = sclGrd.y; gd[10] = sclGrd.z;
     }
     s.T *= (1.f - alpha);
     if (s.T < P.min_transmittance) alive = false;
+    return hit;
+}
+// The gradients of a step's popped hits, hit-major through LDS (k_bwd_flush_lds / the 3DGRT feature replay): every popping lane parks its 11
+// geometric words, 4 barycentric weights and <= 16 base-feature gradients; per DISTINCT particle of the step the lanes ARE the words of its
+// rows - feature word (k, m) = sum over the member lanes of wq[k] * gbase[m], then the 11 geometric words - and leave as one atomic
+// instruction per 64 consecutive words.  (Per-lane atomics of all 59 words, the reference's own scheme and this kernel's first version: 644 ms
+// for the 1 M / 1080p backward.)
+constexpr int kNhtKTermStride = 33;
+__device__ __forceinline__ void nht_k_bwd_flush(const GutParams& P, bool have, uint32_t idx, const float (&gd)[11], const float (&wq)[4],
+                                                const float (&gbase)[kNhtMaxIpd], int lane, float* __restrict__ s_terms, float* __restrict__ g_density12,
+                                                float* __restrict__ g_features) {
+    if (have) {
+        float* tw = s_terms + lane * kNhtKTermStride;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) tw[k] = gd[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tw[11 + k] = wq[k];
+#pragma unroll
+        for (int m = 0; m < kNhtMaxIpd; ++m) tw[15 + m] = gbase[m];
+    }
+    __syncthreads();   // single-wave workgroup: orders the LDS hand-off
+    const int points = P.nht_support == 1 ? 4 : 1, ipd = P.nht_ipd, words = points * ipd;
+    unsigned long long m = __ballot(have);
+    while (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t pid = (uint32_t)__builtin_amdgcn_readlane((int)idx, leader);
+        const unsigned long long same = __ballot(have && idx == pid);
+        m &= ~same;
+        for (int chunk = 0; chunk < words; chunk += 64) {
+            const int word = chunk + lane;
+            const int kq = word < words ? word / ipd : 0, nq = word < words ? word - kq * ipd : 0;
+            float v = 0.f;
+            for (unsigned long long r = same; r; r &= r - 1) {
+                const float* tw = s_terms + (__ffsll((long long)r) - 1) * kNhtKTermStride;
+                v = fmaf(tw[11 + kq], tw[15 + nq], v);
+            }
+            if (word < words && v != 0.f) atomicAdd(g_features + (size_t)pid * P.nht_k + word, v);
+        }
+        float v = 0.f;
+        for (unsigned long long r = same; r; r &= r - 1) v += s_terms[(__ffsll((long long)r) - 1) * kNhtKTermStride + (lane < 11 ? lane : 0)];
+        if (lane < 11 && v != 0.f) atomicAdd(g_density12 + 12 * (size_t)pid + lane, v);
+    }
+    __syncthreads();   // the next step overwrites s_terms
 }
 template <int K, bool BWD>
 __global__ __launch_bounds__(64) void gut_render_nht_k_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
@@ -2267,6 +2308,7 @@ __global__ __launch_bounds__(64) void gut_render_nht_k_kernel(GutParams P, const
                                                               float* __restrict__ g_density12, float* __restrict__ g_features) {
     constexpr int kQ = 8;   // as gut_render_k_body: 0-2 M rows | pos, 3 scale | density, 4 particle | accept limit, 5-7 rows of R^T | 1 / scale
     __shared__ float4 s_rec[64 * kQ];
+    __shared__ float s_kterms[BWD ? 64 * kNhtKTermStride : 1];
     const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
     const uint32_t tile = ((slot >> 2) << 3) + xcd, strip = slot & 3u;
     if (tile >= (uint32_t)(P.gx * P.gy)) return;
@@ -2365,9 +2407,14 @@ __global__ __launch_bounds__(64) void gut_render_nht_k_kernel(GutParams P, const
                     }
                 }
             }
-            if (pop) {
-                if (BWD) nht_k_pop_bwd(P, ray, tet, density12, features, pop_t, pop_a, pop_i, bs, alive, g_density12, g_features);
-                else nht_k_pop_fwd(P, ray, tet, density12, features, pop_t, pop_a, pop_i, fs, alive);
+            if (BWD) {
+                if (__any(pop)) {   // wave-level: the popped hits' gradients leave hit-major, lanes that popped the same particle together
+                    float gd[11], wq[4], gbase[kNhtMaxIpd];
+                    const bool have = pop && nht_k_pop_bwd(P, ray, tet, density12, features, pop_t, pop_a, pop_i, bs, alive, gd, wq, gbase);
+                    nht_k_bwd_flush(P, have, pop_i, gd, wq, gbase, lane, s_kterms, g_density12, g_features);
+                }
+            } else if (pop) {
+                nht_k_pop_fwd(P, ray, tet, density12, features, pop_t, pop_a, pop_i, fs, alive);
             }
         }
         __syncthreads();
@@ -2381,9 +2428,14 @@ __global__ __launch_bounds__(64) void gut_render_nht_k_kernel(GutParams P, const
         for (int i = 0; i + 1 < K; ++i) { kb.hitT[i] = kb.hitT[i + 1]; kb.alpha[i] = kb.alpha[i + 1]; kb.idx[i] = kb.idx[i + 1]; }
         kb.hitT[K - 1] = -1.f;
         const bool act = alive && (t0 >= 0.f);
-        if (act) {
-            if (BWD) nht_k_pop_bwd(P, ray, tet, density12, features, t0, a0, i0, bs, alive, g_density12, g_features);
-            else nht_k_pop_fwd(P, ray, tet, density12, features, t0, a0, i0, fs, alive);
+        if (BWD) {
+            if (__any(act)) {
+                float gd[11], wq[4], gbase[kNhtMaxIpd];
+                const bool have = act && nht_k_pop_bwd(P, ray, tet, density12, features, t0, a0, i0, bs, alive, gd, wq, gbase);
+                nht_k_bwd_flush(P, have, i0, gd, wq, gbase, lane, s_kterms, g_density12, g_features);
+            }
+        } else if (act) {
+            nht_k_pop_fwd(P, ray, tet, density12, features, t0, a0, i0, fs, alive);
         }
     }
     if (!BWD && ray.inside) {

@@ -221,6 +221,13 @@ def make_grt_prim(prim):
         centres = 0.5 * (aabb[:, :3].astype(np.float64) + aabb[:, 3:])
         radii = 0.5 * np.linalg.norm(aabb[:, 3:].astype(np.float64) - aabb[:, :3], axis=1)
         scene_args = (C.c_uint(n), _p(aabb))
+    elif prim == "sphere":   # (round 6) OptiX's built-in spheres: centres / radii from the reference's own kernel; the proxy IS its bounding sphere
+        tag, fn = "Sphere", "sphere"
+        ctr, rad = np.zeros((n, 3), F), np.zeros(n, F)
+        px.ref_enclosing_spheres(C.c_uint(n), _p(pos), _p(rot), _p(scl), _p(dns), C.c_float(mg.MIN_RESPONSE), C.c_uint(1), C.c_float(4), _p(ctr), _p(rad))
+        box = np.concatenate([(ctr - rad[:, None]).min(0), (ctr + rad[:, None]).max(0)]).astype(F)
+        centres, radii = ctr.astype(np.float64), rad.astype(np.float64)
+        scene_args = (C.c_uint(n), _p(ctr), _p(rad))
     else:
         (code, tag), fn = mg.MESH_PRIMITIVES[prim], "mesh"
         verts, tris, nv = np.zeros((n * 12, 3), F), np.zeros((n * 20, 3), np.int32), C.c_uint(0)
@@ -278,7 +285,7 @@ def make_grt_prim(prim):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gut_c4", "gut_c2", "grt_c3", "grt_icosahedron", "grt_custom", "grt_trisurfel", "grt_trihexa"]
+    which = sys.argv[1:] or ["gut_c4", "gut_c2", "grt_c3", "grt_icosahedron", "grt_custom", "grt_trisurfel", "grt_trihexa", "grt_sphere"]
     for w_ in which:
         if w_.startswith("grt_") and w_ != "grt_c3":
             make_grt_prim(w_[4:])

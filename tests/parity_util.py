@@ -604,7 +604,7 @@ def grt_identify_order_ties(primitive_type, cases, d12, sph, inst, scene_aabb, b
     # ray-triangle intersection in world space against this library's plane crossing in the proxy frame: measured up to 25 float32 steps
     # on the 1 M frame); the volumetric ones evaluate the same closest-approach formula in two roundings (measured up to 5)
     if max_ulp is None:
-        max_ulp = 32 if primitive_type in ("trisurfel", "trihexa") else 16
+        max_ulp = 32 if primitive_type in ("trisurfel", "trihexa", "sphere") else 16
     code = GRT_PRIMITIVE_CODES[primitive_type]
     cfg = oracle.default_grt_config(primitive_type=code)
     M = np.asarray(T_to_world, np.float32)[:3, :4]
@@ -615,6 +615,12 @@ def grt_identify_order_ties(primitive_type, cases, d12, sph, inst, scene_aabb, b
             W = inst[pid][:9].reshape(3, 3).astype(np.float64)
             po, pd = W @ (o_w.astype(np.float64) - inst[pid][9:12]), W @ d_w.astype(np.float64)
             return [float(-po[k] / pd[k]) for k in range(3) if pd[k] != 0]
+        if primitive_type == "sphere":    # two offers per particle: both roots of the ray through the enclosing sphere, in double
+            r_ = 1.0 / float(inst[pid][0])
+            po, pd = (o_w.astype(np.float64) - inst[pid][9:12]) / r_, d_w.astype(np.float64) / r_
+            a_, b_, c_ = float(pd @ pd), float(po @ pd), float(po @ po) - 1.0
+            disc = b_ * b_ - a_ * c_
+            return [(-b_ - disc ** 0.5) / a_, (-b_ + disc ** 0.5) / a_] if disc >= 0 else [float("nan")]
         kw = dict(box8=box8[[pid]]) if primitive_type == "custom" else {}
         o = oracle.grt_forward(cfg, d12[[pid]], sph[[pid]], 3, min_transmittance, T_to_world, ro.reshape(1, 1, 3), rd.reshape(1, 1, 3), inst=inst[[pid]],
                                scene=scene_aabb, **kw)
