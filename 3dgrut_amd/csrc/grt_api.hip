@@ -509,7 +509,9 @@ static int grt_forward_impl(GrtHandle* h, hipStream_t s, const GrtFrame* frame, 
     GrtBvh bvh = bvh_view(h);
     GrtLists lists;
     GRUT_CHECK(build_lists(h, s, P, bvh, ray_origin, ray_direction, &lists));
-    if (h->log_valid) h->log_lists = lists;   // the backward's exact rounds (flagged rays) scan the same lists
+    // the backward's exact rounds (flagged rays) scan the same lists.  (barycentricSurfels keeps no log - it has no backward - but a train-mode
+    // forward keeps its lists like every other, for grt_debug_fetch_lists)
+    if (h->log_valid || (P.bary && frame->keep_hits_for_backward)) h->log_lists = lists;
     if (!lists.ranges) GRUT_CHECK(h->wait_tree(s));   // this frame walks the tree
     grt_launch_trace_fwd(s, P, bvh, particle_density, particle_sph, ray_origin, ray_direction, out_features, out_density,
                          out_hit_distance, out_normals, out_hits_count, out_visibility, dbg_ids, dbg_count, counters, log, lists);

@@ -700,7 +700,7 @@ def grt_identify_order_ties(primitive_type, cases, d12, sph, inst, scene_aabb, b
 
 
 def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_cap=192, with_backward=True, log=None, wide_stride=0,
-                    primitive_type="instances"):
+                    primitive_type="instances", pipeline_type=None):
     """HIP 3DGRT against the oracle on every `ray_stride`-th ray of the frame (the oracle tests every particle against every
     ray: stride 1 at 100 k particles / 400x400, a >= 4 k-ray subsample at 1 M particles / 800x800).
 
@@ -717,6 +717,9 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
     inp = make_frame_inputs(n, w, h, median_scale, seed=seed, view=view)
     d12, sph = inp["d12"], inp["sph"]
     render_conf = {"enable_hitcounts": True, "primitive_type": primitive_type}
+    if pipeline_type:   # render.pipeline_type barycentricSurfels (forward only: stages P, T, W)
+        render_conf["pipeline_type"] = pipeline_type
+        with_backward = False
     tr = grt.Tracer({"render": dict(render_conf)})
     g = syn.SimpleGaussians(d12, sph)
     tr.build_acc(g, rebuild=True)
@@ -734,7 +737,7 @@ def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_ca
     vis = vis.view(torch.int32).reshape(-1).cpu().numpy() != 0
     ids, num = ids.cpu().numpy().view(np.uint32), num.cpu().numpy().astype(np.int64)
     stats = dict(N=n, W=w, H=h, P=w * h, primitive_type=primitive_type)
-    cfg = oracle.default_grt_config(primitive_type=GRT_PRIMITIVE_CODES[primitive_type])
+    cfg = oracle.default_grt_config(primitive_type=GRT_PRIMITIVE_CODES[primitive_type], pipeline_type=1 if pipeline_type == "barycentricSurfels" else 0)
     box_kw = dict(box8=nat.custom_boxes(n, "cuda").cpu().numpy()) if primitive_type == "custom" else {}
     # ---- stage P: proxies ----------------------------------------------------------------------------------------------
     pr = oracle.grt_proxies(cfg, d12[:, 0:3], d12[:, 4:8], d12[:, 8:11], d12[:, 3])

@@ -116,7 +116,9 @@ def test_gut_nht_behind_the_sorted_hit_buffer_matches_oracle_at_baseline_size():
     ("c3_grt_custom_100k_200", 100_000, 200, 200, 0.01, 1, "custom"), ("c3_grt_trisurfel_100k_200", 100_000, 200, 200, 0.01, 1, "trisurfel"),
     ("c3_grt_trihexa_100k_200", 100_000, 200, 200, 0.01, 1, "trihexa"),
     # render.primitive_type sphere (round 6): two offers per particle (entry and exit of the enclosing sphere), each a proxy of its own
-    ("c3_grt_sphere_1m_800", 1_000_000, 800, 800, 0.01, 149, "sphere"), ("c3_grt_sphere_100k_200", 100_000, 200, 200, 0.01, 1, "sphere")])
+    ("c3_grt_sphere_1m_800", 1_000_000, 800, 800, 0.01, 149, "sphere"), ("c3_grt_sphere_100k_200", 100_000, 200, 200, 0.01, 1, "sphere"),
+    # render.pipeline_type barycentricSurfels over the trisurfel proxies (round 6; forward only: proxies, order and images)
+    ("c3_grt_bary_1m_800", 1_000_000, 800, 800, 0.01, 149, "trisurfel+barycentricSurfels")])
 def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, ray_stride, prim):
     """3DGRT (LBVH + software traversal) against the oracle: the per-ray order of processed particles bit-exact, images within
     1e-4, gradients within 1e-3 relative (full frame at 100 k particles; a 4 k-ray subsample of the 1 M / 800x800 frame)."""
@@ -124,8 +126,9 @@ def test_grt_frame_matches_oracle_at_baseline_size(name, n, w, h, median_scale, 
     # packet lists the GPU built - checked to change nothing on the 4296
     grt = importlib.import_module("3dgrut_amd.grt_tracer")
     has_lists = True   # (custom and trihexa since round 6)
+    prim, _, pipeline = prim.partition("+")
     stats = pu.grt_full_parity(n, w, h, median_scale, ray_stride=ray_stride, log=print, wide_stride=9 if ray_stride > 1 and has_lists else 0,
-                               primitive_type=prim)
+                               primitive_type=prim, pipeline_type=pipeline or None)
     pu.record_full_parity(name, stats)
     pu.assert_grt_full_parity(stats)
 
