@@ -2088,6 +2088,60 @@ __device__ __forceinline__ float nht_feature_word(const GutParams& P, const floa
     const size_t at = (size_t)idx * P.nht_k + word;
     return P.sph_half ? __half2float(reinterpret_cast<const __half*>(features)[at]) : features[at];
 }
+// a popped hit's particle is the lane's own: its feature row is gathered per lane.  The default model's row (48 floats = 4 vertices x 12,
+// fp32) comes as twelve 16-byte loads instead of 48 single words (the first version's forward spent most of its time issuing them)
+__host__ __device__ __forceinline__ bool nht_row48(const GutParams& P) { return P.nht_k == 48 && P.nht_ipd == 12 && P.nht_support == 1 && !P.sph_half; }
+__device__ __forceinline__ void nht_row_blend(const GutParams& P, const float* __restrict__ features, uint32_t idx, const float (&wq)[4], float (&base)[kNhtMaxIpd]) {
+    const int points = P.nht_support == 1 ? 4 : 1, ipd = P.nht_ipd;
+#pragma unroll
+    for (int m = 0; m < kNhtMaxIpd; ++m) base[m] = 0.f;
+    if (nht_row48(P)) {
+        const float4* src = reinterpret_cast<const float4*>(features + (size_t)idx * 48);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const float4 v = src[q];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                constexpr int kIpd = 12;
+                const int w = 4 * q + c, k = w / kIpd, m = w - k * kIpd;
+                base[m] = k == 0 ? e[c] * wq[0] : fmaf(wq[k], e[c], base[m]);   // (base = f0 w0, then += wk fk: the strip kernels' order)
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < kNhtMaxIpd; ++m)
+        if (m < ipd)
+            for (int k = 0; k < points; ++k) {
+                const float fv = nht_feature_word(P, features, idx, k * ipd + m);
+                base[m] = k == 0 ? fv * wq[0] : fmaf(wq[k], fv, base[m]);
+            }
+}
+// dw[k] = sum_m F[k][m] gbase[m]: the barycentric weights' gradients
+__device__ __forceinline__ void nht_row_dots(const GutParams& P, const float* __restrict__ features, uint32_t idx, const float (&gbase)[kNhtMaxIpd], float (&dw)[4]) {
+    const int points = P.nht_support == 1 ? 4 : 1, ipd = P.nht_ipd;
+    dw[0] = dw[1] = dw[2] = dw[3] = 0.f;
+    if (nht_row48(P)) {
+        const float4* src = reinterpret_cast<const float4*>(features + (size_t)idx * 48);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            const float4 v = src[q];
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                constexpr int kIpd = 12;
+                const int w = 4 * q + c, k = w / kIpd, m = w - k * kIpd;
+                dw[k] = fmaf(e[c], gbase[m], dw[k]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int m = 0; m < kNhtMaxIpd; ++m)
+        if (m < ipd)
+            for (int k = 0; k < points; ++k) dw[k] = fmaf(nht_feature_word(P, features, idx, k * ipd + m), gbase[m], dw[k]);
+}
 // feature i of the activation and its derivative with respect to its base feature kb (the unsorted strip kernels' rules)
 __device__ __forceinline__ void nht_activation_rt(const GutParams& P, const float (&base)[kNhtMaxIpd], int i, float& f, float& df, int& kb) {
     const int nf = P.nht_nf;
@@ -2106,6 +2160,9 @@ __device__ __forceinline__ void nht_activation_rt(const GutParams& P, const floa
     }
 }
 struct NhtKFwdState { float T, D, cnt; float acc[kNhtMaxRay]; };
+// FAST: the default feature model (48 = 4 x 12 fp32 floats, sincos with one frequency -> 24 ray features) as compile-time constants - the
+// arrays shrink to what it uses and a base feature's sine and cosine are evaluated once for its two ray features (446 VGPRs -> see obj_resources)
+template <bool FAST>
 __device__ __forceinline__ void nht_k_pop_fwd(const GutParams& P, const Ray& ray, const NhtTetra4& tet, const float4* __restrict__ density12,
                                               const float* __restrict__ features, float hitT, float alpha, uint32_t idx, NhtKFwdState& s, bool& alive) {
     const float w = alpha * s.T;
@@ -2125,23 +2182,23 @@ __device__ __forceinline__ void nht_k_pop_fwd(const GutParams& P, const Ray& ray
             wq[1] = dot(d, tet.c23) * tet.inv_det; wq[2] = dot(tet.e1, cross(d, tet.e3)) * tet.inv_det; wq[3] = dot(tet.e1, cross(tet.e2, d)) * tet.inv_det;
             wq[0] = 1.f - wq[1] - wq[2] - wq[3];
         }
-        const int points = P.nht_support == 1 ? 4 : 1, ipd = P.nht_ipd, nr = P.nht_ray_dim;
+        const int nr = P.nht_ray_dim;
         float base[kNhtMaxIpd];
+        nht_row_blend(P, features, idx, wq, base);
+        if (FAST) {
 #pragma unroll
-        for (int m = 0; m < kNhtMaxIpd; ++m) {
-            base[m] = 0.f;
-            if (m < ipd)
-                for (int k = 0; k < points; ++k) {
-                    const float fv = nht_feature_word(P, features, idx, k * ipd + m);
-                    base[m] = k == 0 ? fv * wq[0] : fmaf(wq[k], fv, base[m]);
+            for (int m = 0; m < 12; ++m) {
+                s.acc[2 * m] = fmaf(nht_sin(base[m]), w, s.acc[2 * m]);
+                s.acc[2 * m + 1] = fmaf(nht_cos(base[m]), w, s.acc[2 * m + 1]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kNhtMaxRay; ++i) {
+                if (i < nr) {
+                    float f, df; int kb;
+                    nht_activation_rt(P, base, i, f, df, kb);
+                    s.acc[i] = fmaf(f, w, s.acc[i]);
                 }
-        }
-#pragma unroll
-        for (int i = 0; i < kNhtMaxRay; ++i) {
-            if (i < nr) {
-                float f, df; int kb;
-                nht_activation_rt(P, base, i, f, df, kb);
-                s.acc[i] = fmaf(f, w, s.acc[i]);
             }
         }
         s.cnt += 1.f;
@@ -2150,6 +2207,7 @@ __device__ __forceinline__ void nht_k_pop_fwd(const GutParams& P, const Ray& ray
 }
 struct NhtKBwdState { float Cb[kNhtMaxRay], gC[kNhtMaxRay], Tb, gT, Db, gD, T; };
 // returns whether the hit carries gradients; gd = its 11 geometric words, wq / gbase = the factors of its feature-row words (wq[k] * gbase[m])
+template <bool FAST>
 __device__ __forceinline__ bool nht_k_pop_bwd(const GutParams& P, const Ray& ray, const NhtTetra4& tet, const float4* __restrict__ density12,
                                               const float* __restrict__ features, float hitT, float alpha, uint32_t idx, NhtKBwdState& s, bool& alive,
                                               float (&gd)[11], float (&wq)[4], float (&gbase)[kNhtMaxIpd]) {
@@ -2183,18 +2241,27 @@ __device__ __forceinline__ bool nht_k_pop_bwd(const GutParams& P, const Ray& ray
         wq[0] = 1.f - wq[1] - wq[2] - wq[3];
     }
     float base[kNhtMaxIpd];
+    nht_row_blend(P, features, idx, wq, base);
 #pragma unroll
-    for (int m = 0; m < kNhtMaxIpd; ++m) {
-        base[m] = 0.f; gbase[m] = 0.f;
-        if (m < ipd)
-            for (int k = 0; k < points; ++k) {
-                const float fv = nht_feature_word(P, features, idx, k * ipd + m);
-                base[m] = k == 0 ? fv * wq[0] : fmaf(wq[k], fv, base[m]);
-            }
-    }
+    for (int m = 0; m < kNhtMaxIpd; ++m) gbase[m] = 0.f;
     const float w = 1.f / (1.f - alpha);
     float dalpha = 0.f;
-    if (hit) {
+    if (hit && FAST) {
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+            const float sn = nht_sin(base[m]), cs = nht_cos(base[m]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {   // ray features 2 m (sine) and 2 m + 1 (cosine), in this order like the generic loop
+                const int i = 2 * m + h;
+                const float f = h ? cs : sn, df = h ? -sn : cs;
+                s.Cb[i] = (s.Cb[i] - f * alpha) * w;
+                dalpha = fmaf(f - s.Cb[i], s.gC[i], dalpha);
+                const float gf = alpha * s.gC[i];
+                s.gC[i] *= (1.f - alpha);
+                gbase[m] = fmaf(df, gf, gbase[m]);
+            }
+        }
+    } else if (hit) {
 #pragma unroll
         for (int i = 0; i < kNhtMaxRay; ++i) {
             if (i < nr) {
@@ -2212,13 +2279,10 @@ __device__ __forceinline__ bool nht_k_pop_bwd(const GutParams& P, const Ray& ray
     }
     // blend backward: the canonical position (the feature rows' words wq[k] * gbase[m] leave through nht_k_bwd_flush)
     f3 dP = mk3(0.f, 0.f, 0.f);
-    if (hit) {
-        float dw[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < kNhtMaxIpd; ++m)
-            if (m < ipd)
-                for (int k = 0; k < points; ++k) dw[k] = fmaf(nht_feature_word(P, features, idx, k * ipd + m), gbase[m], dw[k]);
-        if (P.nht_support == 1) dP = tet.gw0 * dw[0] + tet.gw1 * dw[1] + tet.gw2 * dw[2] + tet.gw3 * dw[3];
+    if (hit && P.nht_support == 1) {
+        float dw[4];
+        nht_row_dots(P, features, idx, gbase, dw);
+        dP = tet.gw0 * dw[0] + tet.gw1 * dw[1] + tet.gw2 * dw[2] + tet.gw3 * dw[3];
     }
     // density: T_out = T_in (1 - alpha), D_front = lerp(D_behind, depth, alpha)
     s.Tb *= w;
@@ -2263,6 +2327,7 @@ __device__ __forceinline__ bool nht_k_pop_bwd(const GutParams& P, const Ray& ray
 // instruction per 64 consecutive words.  (Per-lane atomics of all 59 words, the reference's own scheme and this kernel's first version: 644 ms
 // for the 1 M / 1080p backward.)
 constexpr int kNhtKTermStride = 33;
+template <bool FAST>
 __device__ __forceinline__ void nht_k_bwd_flush(const GutParams& P, bool have, uint32_t idx, const float (&gd)[11], const float (&wq)[4],
                                                 const float (&gbase)[kNhtMaxIpd], int lane, float* __restrict__ s_terms, float* __restrict__ g_density12,
                                                 float* __restrict__ g_features) {
@@ -2273,10 +2338,10 @@ __device__ __forceinline__ void nht_k_bwd_flush(const GutParams& P, bool have, u
 #pragma unroll
         for (int k = 0; k < 4; ++k) tw[11 + k] = wq[k];
 #pragma unroll
-        for (int m = 0; m < kNhtMaxIpd; ++m) tw[15 + m] = gbase[m];
+        for (int m = 0; m < (FAST ? 12 : kNhtMaxIpd); ++m) tw[15 + m] = gbase[m];
     }
     __syncthreads();   // single-wave workgroup: orders the LDS hand-off
-    const int points = P.nht_support == 1 ? 4 : 1, ipd = P.nht_ipd, words = points * ipd;
+    const int points = FAST ? 4 : (P.nht_support == 1 ? 4 : 1), ipd = FAST ? 12 : P.nht_ipd, words = points * ipd;
     unsigned long long m = __ballot(have);
     while (m) {
         const int leader = __ffsll((long long)m) - 1;
@@ -2299,8 +2364,11 @@ __device__ __forceinline__ void nht_k_bwd_flush(const GutParams& P, bool have, u
     }
     __syncthreads();   // the next step overwrites s_terms
 }
-template <int K, bool BWD>
-__global__ __launch_bounds__(64) void gut_render_nht_k_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
+#ifndef GRUT_NHT_K_WAVES
+#define GRUT_NHT_K_WAVES 2   // the default model's instantiations are held to two waves per SIMD (256 VGPRs): forward K = 16 259 -> 256
+#endif
+template <int K, bool BWD, bool FAST>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FAST ? GRUT_NHT_K_WAVES : 1, 8))) void gut_render_nht_k_kernel(GutParams P, const uint2* __restrict__ ranges, EntryLists lists,
                                                               const float4* __restrict__ density12, const float* __restrict__ features,
                                                               const float* __restrict__ ray_o, const float* __restrict__ ray_d,
                                                               float* __restrict__ fd /* BWD: the forward's image (read) */, float* __restrict__ dist,
@@ -2318,17 +2386,17 @@ __global__ __launch_bounds__(64) void gut_render_nht_k_kernel(GutParams P, const
     const Ray ray = init_ray(P, ray_o, ray_d, px, py);
     bool alive = ray.valid;
     const size_t pix = ray.valid ? (size_t)py * P.W + px : 0;
-    const int nr = P.nht_ray_dim;
+    const int nr = FAST ? 24 : P.nht_ray_dim;
     const NhtTetra4 tet = nht_tetra4();
     NhtKFwdState fs;
     NhtKBwdState bs;
     if (!BWD) {
         fs.T = 1.f; fs.D = 0.f; fs.cnt = 0.f;
 #pragma unroll
-        for (int i = 0; i < kNhtMaxRay; ++i) fs.acc[i] = 0.f;
+        for (int i = 0; i < (FAST ? 24 : kNhtMaxRay); ++i) fs.acc[i] = 0.f;
     } else {
 #pragma unroll
-        for (int i = 0; i < kNhtMaxRay; ++i) {
+        for (int i = 0; i < (FAST ? 24 : kNhtMaxRay); ++i) {
             const bool use = alive && i < nr;
             bs.Cb[i] = use ? (P.out_half ? __half2float(reinterpret_cast<const __half*>(fd)[pix * (nr + 1) + i]) : fd[pix * (nr + 1) + i]) : 0.f;
             bs.gC[i] = use ? g_fd[pix * (nr + 1) + i] : 0.f;
@@ -2410,11 +2478,11 @@ __global__ __launch_bounds__(64) void gut_render_nht_k_kernel(GutParams P, const
             if (BWD) {
                 if (__any(pop)) {   // wave-level: the popped hits' gradients leave hit-major, lanes that popped the same particle together
                     float gd[11], wq[4], gbase[kNhtMaxIpd];
-                    const bool have = pop && nht_k_pop_bwd(P, ray, tet, density12, features, pop_t, pop_a, pop_i, bs, alive, gd, wq, gbase);
-                    nht_k_bwd_flush(P, have, pop_i, gd, wq, gbase, lane, s_kterms, g_density12, g_features);
+                    const bool have = pop && nht_k_pop_bwd<FAST>(P, ray, tet, density12, features, pop_t, pop_a, pop_i, bs, alive, gd, wq, gbase);
+                    nht_k_bwd_flush<FAST>(P, have, pop_i, gd, wq, gbase, lane, s_kterms, g_density12, g_features);
                 }
             } else if (pop) {
-                nht_k_pop_fwd(P, ray, tet, density12, features, pop_t, pop_a, pop_i, fs, alive);
+                nht_k_pop_fwd<FAST>(P, ray, tet, density12, features, pop_t, pop_a, pop_i, fs, alive);
             }
         }
         __syncthreads();
@@ -2431,18 +2499,18 @@ __global__ __launch_bounds__(64) void gut_render_nht_k_kernel(GutParams P, const
         if (BWD) {
             if (__any(act)) {
                 float gd[11], wq[4], gbase[kNhtMaxIpd];
-                const bool have = act && nht_k_pop_bwd(P, ray, tet, density12, features, t0, a0, i0, bs, alive, gd, wq, gbase);
-                nht_k_bwd_flush(P, have, i0, gd, wq, gbase, lane, s_kterms, g_density12, g_features);
+                const bool have = act && nht_k_pop_bwd<FAST>(P, ray, tet, density12, features, t0, a0, i0, bs, alive, gd, wq, gbase);
+                nht_k_bwd_flush<FAST>(P, have, i0, gd, wq, gbase, lane, s_kterms, g_density12, g_features);
             }
         } else if (act) {
-            nht_k_pop_fwd(P, ray, tet, density12, features, t0, a0, i0, fs, alive);
+            nht_k_pop_fwd<FAST>(P, ray, tet, density12, features, t0, a0, i0, fs, alive);
         }
     }
     if (!BWD && ray.inside) {
         const size_t opix = (size_t)py * P.W + px;
         const size_t stride = (size_t)nr + 1;
 #pragma unroll
-        for (int i = 0; i < kNhtMaxRay; ++i) {
+        for (int i = 0; i < (FAST ? 24 : kNhtMaxRay); ++i) {
             if (i < nr) {
                 const float v = ray.valid ? fs.acc[i] : 0.f;
                 if (P.out_half) reinterpret_cast<__half*>(fd)[opix * stride + i] = __float2half(v);
@@ -2514,9 +2582,16 @@ void launch_render_nht_fwd(hipStream_t s, const GutParams& P, const uint32_t* ra
                            float* out_cnt) {
     const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
     if (P.k_buffer > 0) {   // the sorted hit buffer in front of the feature integration (round 6)
-        GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_nht_k_kernel<K_, false>), dim3(strip_grid(P)), dim3(64), 0, s, P,
-                                                       reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), features,
-                                                       ray_o, ray_d, out_fd, out_dist, out_cnt, nullptr, nullptr, nullptr, nullptr));
+        const bool fast = nht_row48(P) && P.nht_act == 2 && P.nht_nf == 1;   // the default feature model
+        if (fast) {
+            GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_nht_k_kernel<K_, false, true>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                           reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), features,
+                                                           ray_o, ray_d, out_fd, out_dist, out_cnt, nullptr, nullptr, nullptr, nullptr));
+        } else {
+            GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_nht_k_kernel<K_, false, false>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                           reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), features,
+                                                           ray_o, ray_d, out_fd, out_dist, out_cnt, nullptr, nullptr, nullptr, nullptr));
+        }
         return;
     }
     hipLaunchKernelGGL(gut_render_nht_fwd_kernel, dim3(strip_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
@@ -2527,10 +2602,18 @@ void launch_render_nht_bwd(hipStream_t s, const GutParams& P, const uint32_t* ra
                            const float* dist, const float* g_dist, float* g_density12, float* g_features) {
     const EntryLists lists = entry_lists(P, sorted_pos, pos_particle);
     if (P.k_buffer > 0) {
-        GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_nht_k_kernel<K_, true>), dim3(strip_grid(P)), dim3(64), 0, s, P,
-                                                       reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), features,
-                                                       ray_o, ray_d, const_cast<float*>(fd), const_cast<float*>(dist), nullptr, g_fd, g_dist, g_density12,
-                                                       g_features));
+        const bool fast = nht_row48(P) && P.nht_act == 2 && P.nht_nf == 1;
+        if (fast) {
+            GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_nht_k_kernel<K_, true, true>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                           reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), features,
+                                                           ray_o, ray_d, const_cast<float*>(fd), const_cast<float*>(dist), nullptr, g_fd, g_dist, g_density12,
+                                                           g_features));
+        } else {
+            GRUT_DISPATCH_K(P.k_buffer, hipLaunchKernelGGL((gut_render_nht_k_kernel<K_, true, false>), dim3(strip_grid(P)), dim3(64), 0, s, P,
+                                                           reinterpret_cast<const uint2*>(ranges), lists, reinterpret_cast<const float4*>(density12), features,
+                                                           ray_o, ray_d, const_cast<float*>(fd), const_cast<float*>(dist), nullptr, g_fd, g_dist, g_density12,
+                                                           g_features));
+        }
         return;
     }
     hipLaunchKernelGGL(gut_render_nht_bwd_kernel, dim3(strip_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
