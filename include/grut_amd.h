@@ -100,7 +100,7 @@ typedef struct GutConfig {
      *   rayPayloadBackward.cuh:50-58); GutFrame::out_features / out_opacity must then be NULL.  Hit distance / count stay fp32. */
     int32_t particle_feature_half;
     int32_t feature_output_half;
-    /* Neural harmonic features (model.feature_type = nht; setup_3dgut.py:47-57, threedgrut/model/features.py:133-175; round 3: k_buffer_size 0 only).  feature_transform_type 1: `particle_sph` is the per-particle feature buffer [N, particle_feature_dim] (fp32 or
+    /* Neural harmonic features (model.feature_type = nht; setup_3dgut.py:47-57, threedgrut/model/features.py:133-175; any k_buffer_size since round 6: with k_buffer_size > 0 the sorted hit buffer sits in front of the feature integration, gutKBufferRenderer.cuh:158-225).  feature_transform_type 1: `particle_sph` is the per-particle feature buffer [N, particle_feature_dim] (fp32 or
      * half), features are interpolated per hit at the canonical intersection (gutKBufferRenderer.cuh:199-225,
      * neuralHarmonicFeaturesParticle.slang:146-196) and out_feat_density is [H, W, ray_feature_dim + 1] with
      * ray_feature_dim = interp_point_feature_dim x (2 x num_frequencies for sincos | num_frequencies for siren | 1), at most 32;
