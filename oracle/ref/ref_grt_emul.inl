@@ -40,6 +40,8 @@ struct Scene {
     const uint32_t* cand_begin = nullptr;
     const uint32_t* cand = nullptr;
     uint32_t cur_ray = 0;
+    // optional per-ray log of what the traces returned (see optixTrace): ids / distances [rays, log_cap], counts [rays]
+    uint32_t* log_ids = nullptr; float* log_ts = nullptr; uint32_t* log_num = nullptr; uint32_t log_cap = 0;
 } g_scene;
 // first / one-past-last position of the current ray's primitives in its candidate list, or the whole range [0, n)
 static inline uint32_t cand_count(uint32_t n) { return g_scene.cand_begin ? g_scene.cand_begin[g_scene.cur_ray + 1] - g_scene.cand_begin[g_scene.cur_ray] : n; }
@@ -56,6 +58,7 @@ bool optixReportIntersection(float t, unsigned) {
     return true;               // accepted: the ray now ends at t
 }
 
+static void optix_traverse(float3 o, float3 d, unsigned ray_flags);
 void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tmax, float, OptixVisibilityMask, unsigned ray_flags, unsigned, unsigned,
                 unsigned, uint32_t& p0, uint32_t& p1, uint32_t& p2, uint32_t& p3, uint32_t& p4, uint32_t& p5, uint32_t& p6, uint32_t& p7,
                 uint32_t& p8, uint32_t& p9, uint32_t& p10, uint32_t& p11, uint32_t& p12, uint32_t& p13, uint32_t& p14, uint32_t& p15,
@@ -67,6 +70,23 @@ void optixTrace(OptixTraversableHandle, float3 o, float3 d, float tmin, float tm
     g_optix.worldOrigin = o; g_optix.worldDirection = d;
     g_optix.tmin = tmin; g_optix.tmax = tmax;
     g_scene.trace_tmax = tmax;
+    optix_traverse(o, d, ray_flags);
+    // optional hit log (ref_grt_set_hit_log): what this trace returned to the raygen program - the (particle, distance) pairs of the payload,
+    // nearest first - appended to the current ray's row.  The raygen program processes them in this order while the ray is above
+    // min_transmittance; tests/golden/make_fullsize_golden.py stores the rows of the rays that differ from the checker, so that the GPU test can
+    // say WHICH hits the reference's programs took in another order (or which particle they took instead)
+    if (g_scene.log_ids) {
+        const uint32_t r = g_scene.cur_ray;
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t id = *g_optix.payload[2 * k];
+            if (id == 0xFFFFFFFFu) break;
+            uint32_t& n = g_scene.log_num[r];
+            if (n < g_scene.log_cap) { g_scene.log_ids[(size_t)r * g_scene.log_cap + n] = id; std::memcpy(&g_scene.log_ts[(size_t)r * g_scene.log_cap + n], g_optix.payload[2 * k + 1], 4); }
+            n++;
+        }
+    }
+}
+static void optix_traverse(float3 o, float3 d, unsigned ray_flags) {
 #ifdef SHIM_OPTIX_TRIANGLE_PROXIES
     // Built-in triangles with OPTIX_RAY_FLAG_CULL_BACK_FACING_TRIANGLES (referenceOptix.cu:62): every FRONT-facing triangle (counter-clockwise
     // seen from the ray origin, OptiX's default) the ray crosses within its CURRENT interval is reported to the any-hit program, in
@@ -241,4 +261,6 @@ static void launch_raygen(int width, int height) {
 }
 
 // per-ray candidate subsets for the NEXT launches of this library: offsets [rays + 1], particles [offsets[rays]] ascending per ray; nulls clear
+// per-ray hit log of the NEXT launches (rows zeroed by the caller); nulls switch it off
+extern "C" void ref_grt_set_hit_log(uint32_t* ids, float* ts, uint32_t* num, uint32_t cap) { g_scene.log_ids = ids; g_scene.log_ts = ts; g_scene.log_num = num; g_scene.log_cap = cap; }
 extern "C" void ref_grt_set_ray_candidates(const uint32_t* offsets, const uint32_t* particles) { g_scene.cand_begin = offsets; g_scene.cand = particles; }

@@ -192,7 +192,7 @@ def ray_candidates(centres, radii, origin, dirs, chunk=4000):
     return offsets, parts
 
 
-def make_grt_prim(prim):
+def make_grt_prim(prim, hitlog_only=False):
     """fullsize_grt_<prim>_c3_1m_800.npz: the reference's forward / backward programs built for `prim` (icosahedron: the paper's own 3DGRT
     configuration, configs/paper/3dgrt/base_ours_reference.yaml:16; custom: world boxes + intersectCustomParticle) on GRT_PRIM_RAYS rays of
     BASELINE config 3's frame, proxies by the reference's own mesh / AABB kernels over all 1 M particles.  Each ray is offered the particles
@@ -251,8 +251,37 @@ def make_grt_prim(prim):
     fw.ref_grt_set_ray_candidates(_p(offsets), _p(cand))
     bw.ref_grt_set_ray_candidates(_p(offsets), _p(cand))
     t0 = time.time()
+    LOG_CAP = 640
+    if hitlog_only:   # what every trace returned to the raygen program, per ray (ref_grt_emul.inl: ref_grt_set_hit_log)
+        log_ids, log_ts, log_num = np.full((sh * sw, LOG_CAP), 0xFFFFFFFF, np.uint32), np.zeros((sh * sw, LOG_CAP), F), np.zeros(sh * sw, np.uint32)
+        fw.ref_grt_set_hit_log(_p(log_ids), _p(log_ts), _p(log_num), C.c_uint(LOG_CAP))
     getattr(fw, f"ref_grt_trace_fwd_{fn}")(*common, _p(feat), _p(den), _p(hit), _p(nrm), _p(cnt), _p(vis))
     print(f"grt {prim}: forward programs on {sh * sw} rays in {time.time() - t0:.1f} s; hits per ray {cnt.mean():.1f}", flush=True)
+    if hitlog_only:
+        fw.ref_grt_set_hit_log(None, None, None, C.c_uint(0))
+        main = np.load(os.path.join(HERE, f"fullsize_grt_{prim}_c3_1m_800.npz"))
+        assert np.array_equal(main["features"], feat) and np.array_equal(main["hits_count"], cnt), "the logged run is not the stored golden's run"
+        # the rays whose value differs from the CHECKER's (oracle/grt_oracle.c on its own proxies, every particle offered) although the number of
+        # accepted hits agrees - the rays the GPU test calls "order ties" - and a margin of rays close to that: their rows are stored
+        import oracle
+        from parity_util import GRT_PRIMITIVE_CODES
+        cfg = oracle.default_grt_config(primitive_type=GRT_PRIMITIVE_CODES[prim])
+        t0 = time.time()
+        ora = oracle.grt_forward(cfg, d12, sph, 3, mg.MIN_T_GRT, inp["batch"]["T_to_world"][0], ro.reshape(1, -1, 3), rd.reshape(1, -1, 3))
+        print(f"grt {prim}: checker on the same rays in {time.time() - t0:.1f} s", flush=True)
+        e = np.maximum(np.abs(ora["features"].reshape(-1, 3) - feat.reshape(-1, 3)).max(-1), np.abs(ora["density"].reshape(-1) - den.reshape(-1)))
+        e = np.maximum(e, np.abs(ora["hit_distance"].reshape(-1, 2)[:, 0] - hit.reshape(-1, 2)[:, 0]) / max(1.0, float(np.abs(hit).max())))
+        sel_rays = np.flatnonzero(e > 3e-5)
+        if len(sel_rays) == 0:   # (sphere: the checker evaluates the emulated intersector's own arithmetic - no ray differs; nothing to store)
+            print(f"grt {prim}: the checker reproduces the programs on every sampled ray: no hit-log file", flush=True)
+            return
+        assert log_num[sel_rays].max() <= LOG_CAP
+        width = int(log_num[sel_rays].max()) if len(sel_rays) else 1
+        np.savez_compressed(os.path.join(HERE, f"fullsize_grt_{prim}_c3_1m_800_hitlog.npz"), rays=sel_rays.astype(np.uint32), num=log_num[sel_rays],
+                            ids=log_ids[sel_rays][:, :width], ts=log_ts[sel_rays][:, :width])
+        print(f"wrote fullsize_grt_{prim}_c3_1m_800_hitlog.npz: {len(sel_rays)} rays (checker vs programs beyond 3e-5; same count beyond 1e-4: "
+              f"{int(((e > 1e-4) & (ora['hit_count'].reshape(-1) == cnt.reshape(-1))).sum())}), longest row {width}", flush=True)
+        return
     g_rad, g_dns, g_hit = mg.grt_trace_upstream(sh, sw)
     gd, gs = np.zeros((n, 12), F), np.zeros((n, 48), F)
     t0 = time.time()
@@ -287,7 +316,9 @@ def make_grt_prim(prim):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gut_c4", "gut_c2", "grt_c3", "grt_icosahedron", "grt_custom", "grt_trisurfel", "grt_trihexa", "grt_sphere"]
     for w_ in which:
-        if w_.startswith("grt_") and w_ != "grt_c3":
+        if w_.startswith("hitlog_"):     # e.g. hitlog_custom: the side file with the reference programs' per-ray hit rows (round 6)
+            make_grt_prim(w_[7:], hitlog_only=True)
+        elif w_.startswith("grt_") and w_ != "grt_c3":
             make_grt_prim(w_[4:])
     if "gut_c4" in which:
         make_gut("c4_1m_1080p")

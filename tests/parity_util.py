@@ -699,6 +699,95 @@ def grt_identify_order_ties(primitive_type, cases, d12, sph, inst, scene_aabb, b
     return out
 
 
+def grt_identify_with_reference_log(primitive_type, case, ref_ids, ref_ts, d12, sph, inst, scene_aabb, box8, T_to_world, min_transmittance, tol=1e-4, max_ulp=None):
+    """A ray whose value differs from the reference PROGRAMS' golden, explained with the programs' own hit log (round 6;
+    tests/golden/fullsize_grt_<prim>_c3_1m_800_hitlog.npz: what every trace returned to the raygen program, in order):
+      (1) the CHECKER's processHit composited over the REFERENCE's logged order reproduces the reference's colour, opacity and distance within
+          `tol` - the per-hit arithmetic agrees, the difference IS the order;
+      (2) every place where the GPU's processed sequence departs from the logged order is one of
+            tie        a block of 2-4 neighbouring hits in another order whose distances (the checker's candidate arithmetic) lie within
+                       `max_ulp` float32 steps of each other - the two libraries round the same distance differently;
+            boundary   a hit the GPU processed that the reference's programs never returned, within `max_ulp` steps of the LAST hit of one of
+                       the reference's rounds (log position 16 k - 1): the programs' k-buffer inserts with a strict < and the next trace starts
+                       at (last distance + 1e-9) = the last distance itself in fp32, so a candidate that TIES with a round's last hit in the
+                       reference's rounding is never returned (referenceOptix.cu:128-130, 210-246) - in this library's rounding it is not a
+                       tie and the hit is processed (or the same with the roles exchanged).
+    Returns a record with `identified`."""
+    if max_ulp is None:
+        max_ulp = 32 if primitive_type in ("trisurfel", "trihexa", "sphere") else 16
+    ro, rd, seq, ref, gpu = case
+    cfg = oracle.default_grt_config(primitive_type=GRT_PRIMITIVE_CODES[primitive_type])
+    M = np.asarray(T_to_world, np.float32)[:3, :4]
+    ro, rd = np.asarray(ro, np.float32), np.asarray(rd, np.float32)
+    o_w = (M[:, :3] @ ro + M[:, 3]).astype(np.float32)
+    d_w = (M[:, :3] @ rd).astype(np.float32)
+    seq, ref_ids = [int(v) for v in seq], [int(v) for v in ref_ids]
+    scale = max(1.0, abs(float(ref[2])))
+
+    def dist(a, b):
+        return max(float(np.abs(np.asarray(a[0], np.float64) - np.asarray(b[0], np.float64)).max()), abs(float(a[1]) - float(b[1])), abs(float(a[2]) - float(b[2])) / scale)
+
+    def hit_ts(pid):
+        if primitive_type == "trihexa":
+            W = inst[pid][:9].reshape(3, 3).astype(np.float64)
+            po, pd = W @ (o_w.astype(np.float64) - inst[pid][9:12]), W @ d_w.astype(np.float64)
+            return [float(-po[k] / pd[k]) for k in range(3) if pd[k] != 0]
+        if primitive_type == "sphere":
+            r_ = 1.0 / float(inst[pid][0])
+            po, pd = (o_w.astype(np.float64) - inst[pid][9:12]) / r_, d_w.astype(np.float64) / r_
+            a_, b_, c_ = float(pd @ pd), float(po @ pd), float(po @ po) - 1.0
+            disc = b_ * b_ - a_ * c_
+            return [(-b_ - disc ** 0.5) / a_, (-b_ + disc ** 0.5) / a_] if disc >= 0 else [float("nan")]
+        kw = dict(box8=box8[[pid]]) if primitive_type == "custom" else {}
+        o = oracle.grt_forward(cfg, d12[[pid]], sph[[pid]], 3, min_transmittance, T_to_world, ro.reshape(1, 1, 3), rd.reshape(1, 1, 3), inst=inst[[pid]],
+                               scene=scene_aabb, **kw)
+        return [float(o["hit_distance"][0, 0, 1])]
+
+    def steps(ta, tb):
+        return min(abs(a - b) / float(np.spacing(np.float32(max(abs(a), abs(b))))) for a in ta for b in tb)
+
+    rgb, opa, dst, _ = oracle.grt_composite_sequence(cfg, min_transmittance, o_w, d_w, d12, sph, 3, ref_ids)
+    rec = dict(hits=len(seq), logged=len(ref_ids), gpu_vs_reference=dist(gpu, ref), reference_order_composited_vs_reference=dist((rgb, opa, dst), ref), events=[])
+    i = j = 0
+    ok = rec["reference_order_composited_vs_reference"] <= tol
+    while i < len(seq) and j < len(ref_ids):
+        if seq[i] == ref_ids[j]:
+            i += 1; j += 1
+            continue
+        done = False
+        for m in (2, 3, 4):   # a block of neighbours in another order
+            if i + m <= len(seq) and j + m <= len(ref_ids) and sorted(seq[i:i + m]) == sorted(ref_ids[j:j + m]):
+                ts = [hit_ts(p_) for p_ in seq[i:i + m]]
+                gap = max(steps(ts[a], ts[a + 1]) for a in range(m - 1))
+                rec["events"].append(dict(kind="tie", at=i, hits=m, float_steps=float(gap), identified=bool(gap <= max_ulp)))
+                i += m; j += m; done = True
+                break
+        if done:
+            continue
+        if seq[i] not in ref_ids:       # processed here, never returned to the reference's raygen program
+            # (the reference's hit at log position j took the LAST slot of a round, j = 16 k - 1, at a distance that ties with this one's)
+            # (... or the round ended just before, at j - 1 = 16 k - 1, and this hit ties with THAT one in the reference's rounding: it lies at or
+            # before the next trace's start there, behind it here)
+            end = j if j % 16 == 15 else (j - 1 if j % 16 == 0 and j > 0 else -1)
+            gap = steps(hit_ts(seq[i]), [float(ref_ts[end])]) if end >= 0 else 1e30
+            rec["events"].append(dict(kind="boundary", at=i, particle=seq[i], reference_round_ends_at=end, float_steps=float(gap),
+                                      identified=bool(end >= 0 and gap <= max_ulp)))
+            i += 1
+            continue
+        if ref_ids[j] not in seq:       # returned to the reference's program, not a candidate here: the same tie with the roles exchanged
+            end = i if i % 16 == 15 else (i - 1 if i % 16 == 0 and i > 0 else -1)
+            gap = steps(hit_ts(ref_ids[j]), hit_ts(seq[end])) if end >= 0 else 1e30
+            rec["events"].append(dict(kind="boundary", at=i, particle=ref_ids[j], missing_here=True, round_ends_at=end, float_steps=float(gap),
+                                      identified=bool(end >= 0 and gap <= max_ulp)))
+            j += 1
+            continue
+        rec["events"].append(dict(kind="unknown", at=i, identified=False))
+        break
+    rec["identified"] = bool(ok and rec["events"] and all(e_["identified"] for e_ in rec["events"]))
+    rec["kind"] = "+".join(sorted({e_["kind"] for e_ in rec["events"]})) if rec["events"] else None
+    return rec
+
+
 def grt_full_parity(n, w, h, median_scale, seed=42, view=0, ray_stride=1, hit_cap=192, with_backward=True, log=None, wide_stride=0,
                     primitive_type="instances", pipeline_type=None):
     """HIP 3DGRT against the oracle on every `ray_stride`-th ray of the frame (the oracle tests every particle against every

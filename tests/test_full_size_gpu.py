@@ -282,10 +282,27 @@ def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_siz
                           (g["features"][sy_, sx_], g["density"][sy_, sx_, 0], g["hit_distance"][sy_, sx_, 0]),
                           (pick(out["pred_features"])[sy_, sx_], pick(out["pred_opacity"])[sy_, sx_, 0], pick(out["pred_dist"])[sy_, sx_, 0])))
         recs = pu.grt_identify_order_ties(prim, cases, d12, sph, inst, scene_aabb, box8, inp_T, tracer._min_transmittance)
+        # round 6, last session: what that search leaves open is explained with the reference programs' OWN hit log where the golden carries one
+        # (tests/golden/fullsize_grt_<prim>_c3_1m_800_hitlog.npz, make_fullsize_golden.py hitlog_<prim>): ties at a round's last slot, which no
+        # reordering of the GPU's sequence reproduces because the reference then never sees one of the two hits
+        log_path = os.path.join(here, "golden", f"fullsize_grt_{prim}_c3_1m_800_hitlog.npz")
+        if os.path.exists(log_path):
+            hl = np.load(log_path)
+            row_of = {int(r_): q for q, r_ in enumerate(hl["rays"])}
+            for q, ((sy_, sx_), r_) in enumerate(zip(zip(*np.nonzero(tied)), recs)):
+                key = int(sy_) * sw + int(sx_)
+                if not r_["identified"] and key in row_of:
+                    row = row_of[key]
+                    r2 = pu.grt_identify_with_reference_log(prim, cases[q], hl["ids"][row, :int(hl["num"][row])], hl["ts"][row, :int(hl["num"][row])], d12, sph, inst,
+                                                            scene_aabb, box8, inp_T, tracer._min_transmittance)
+                    print(f"{prim}: with the reference programs' hit log: {r2}")
+                    if r2["identified"]:
+                        recs[q] = dict(r_, identified=True, kind="log:" + r2["kind"], with_reference_log=r2)
         for r_ in recs:
             print(f"{prim}: tie ray: {r_}")
         pu.record_full_parity(f"ref_programs_{prim}_c3_1m_800_ties", dict(
             rays=len(recs), ties=int(sum(r_["kind"] == "tie" and r_["identified"] for r_ in recs)), rounding=int(sum(r_["kind"] == "rounding" for r_ in recs)),
+            with_reference_log=int(sum(str(r_["kind"]).startswith("log:") for r_ in recs)),
             unidentified=int(sum(not r_["identified"] for r_ in recs)),
             max_float_steps_between_reordered_hits=float(max([max(r_.get("float_steps_between_reordered_hits", [0.0])) for r_ in recs if r_["identified"]] + [0.0])),
             max_err_after_reordering=float(max([r_.get("err_after_reordering", 0.0) for r_ in recs if r_["identified"]] + [0.0])), records=recs))
