@@ -309,8 +309,10 @@ def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_siz
         # what is NOT identified (round 6: one ray of the custom frame, one of the trisurfel frame - no reordering inside three neighbouring hits
         # and no single removal reproduces the reference; without the reference programs' own hit log in the golden they cannot be told
         # apart further) stays under the old fence, and there may be at most one such ray per frame
+        # (last session of round 6: with the programs' hit log the custom and the trisurfel ray are identified - ties at a round's last slot -;
+        # sphere, whose intersector the checker restates operation by operation, has no log file: at most one ray there stays under the fence)
         bad = [r_ for r_ in recs if not r_["identified"]]
-        assert len(bad) <= 1 and all(r_["gpu_vs_reference"] < 5e-2 for r_ in bad), bad
+        assert len(bad) <= (1 if prim == "sphere" else 0) and all(r_["gpu_vs_reference"] < 5e-2 for r_ in bad), bad
     ok = ok & ~tied
     # backward: the upstream gradient lives on the sampled rays only
     g_rad, g_dns, g_hit = mg.grt_trace_upstream(sh, sw)
