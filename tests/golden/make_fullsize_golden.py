@@ -251,7 +251,7 @@ def make_grt_prim(prim, hitlog_only=False):
     fw.ref_grt_set_ray_candidates(_p(offsets), _p(cand))
     bw.ref_grt_set_ray_candidates(_p(offsets), _p(cand))
     t0 = time.time()
-    LOG_CAP = 640
+    LOG_CAP = 1536 if prim == "sphere" else 640
     if hitlog_only:   # what every trace returned to the raygen program, per ray (ref_grt_emul.inl: ref_grt_set_hit_log)
         log_ids, log_ts, log_num = np.full((sh * sw, LOG_CAP), 0xFFFFFFFF, np.uint32), np.zeros((sh * sw, LOG_CAP), F), np.zeros(sh * sw, np.uint32)
         fw.ref_grt_set_hit_log(_p(log_ids), _p(log_ts), _p(log_num), C.c_uint(LOG_CAP))
@@ -272,7 +272,13 @@ def make_grt_prim(prim, hitlog_only=False):
         e = np.maximum(np.abs(ora["features"].reshape(-1, 3) - feat.reshape(-1, 3)).max(-1), np.abs(ora["density"].reshape(-1) - den.reshape(-1)))
         e = np.maximum(e, np.abs(ora["hit_distance"].reshape(-1, 2)[:, 0] - hit.reshape(-1, 2)[:, 0]) / max(1.0, float(np.abs(hit).max())))
         sel_rays = np.flatnonzero(e > 3e-5)
-        if len(sel_rays) == 0:   # (sphere: the checker evaluates the emulated intersector's own arithmetic - no ray differs; nothing to store)
+        if prim == "sphere":
+            # the checker evaluates the emulated intersector's own arithmetic on the same radii: no ray differs from the programs.  The GPU builds
+            # its own proxy records (another rounding of 1 / radius), so ITS ties cannot be found on the host: the log is kept for the rows of
+            # the sample on which the HIP frame differed from this golden on an MI355X (the test prints them as `ray_key`; committed list)
+            import json
+            sel_rays = np.union1d(sel_rays, np.array(json.load(open(os.path.join(HERE, "fullsize_grt_sphere_c3_1m_800_hitlog_rays.json")))["rays"], np.int64))
+        if len(sel_rays) == 0:
             print(f"grt {prim}: the checker reproduces the programs on every sampled ray: no hit-log file", flush=True)
             return
         assert log_num[sel_rays].max() <= LOG_CAP

@@ -774,6 +774,14 @@ def grt_identify_with_reference_log(primitive_type, case, ref_ids, ref_ts, d12, 
                                       identified=bool(end >= 0 and gap <= max_ulp)))
             i += 1
             continue
+        if i == len(seq) - 1 and j + 1 < len(ref_ids) and ref_ids[j + 1] == seq[i] and ref_ids[j] not in seq:
+            # a tie at the ray's END: the reference processed Y and stopped on the transmittance threshold with X returned but unprocessed
+            # (the log holds what the traces RETURN); here X came first and Y stayed unprocessed behind it - the same two neighbours in the
+            # other order, only that the second of them lies behind the end of both processed sequences
+            gap = steps(hit_ts(seq[i]), hit_ts(ref_ids[j]))
+            rec["events"].append(dict(kind="tie_at_end", at=i, particle=ref_ids[j], float_steps=float(gap), identified=bool(gap <= max_ulp)))
+            i += 1; j += 2
+            continue
         if ref_ids[j] not in seq:       # returned to the reference's program, not a candidate here: the same tie with the roles exchanged
             end = i if i % 16 == 15 else (i - 1 if i % 16 == 0 and i > 0 else -1)
             gap = steps(hit_ts(ref_ids[j]), hit_ts(seq[end])) if end >= 0 else 1e30

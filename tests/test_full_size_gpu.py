@@ -298,7 +298,8 @@ def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_siz
                     print(f"{prim}: with the reference programs' hit log: {r2}")
                     if r2["identified"]:
                         recs[q] = dict(r_, identified=True, kind="log:" + r2["kind"], with_reference_log=r2)
-        for r_ in recs:
+        for (sy_, sx_), r_ in zip(zip(*np.nonzero(tied)), recs):
+            r_["ray_key"] = int(sy_) * sw + int(sx_)   # (row of the golden's ray sample: what make_fullsize_golden.py's hit log is keyed by)
             print(f"{prim}: tie ray: {r_}")
         pu.record_full_parity(f"ref_programs_{prim}_c3_1m_800_ties", dict(
             rays=len(recs), ties=int(sum(r_["kind"] == "tie" and r_["identified"] for r_ in recs)), rounding=int(sum(r_["kind"] == "rounding" for r_ in recs)),
@@ -310,9 +311,11 @@ def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_siz
         # and no single removal reproduces the reference; without the reference programs' own hit log in the golden they cannot be told
         # apart further) stays under the old fence, and there may be at most one such ray per frame
         # (last session of round 6: with the programs' hit log the custom and the trisurfel ray are identified - ties at a round's last slot -;
-        # sphere, whose intersector the checker restates operation by operation, has no log file: at most one ray there stays under the fence)
+        # sphere: the ninth ray is a tie of the two LAST neighbours - the reference processes Y and stops on the transmittance threshold with X
+        # returned but unprocessed, here X comes first (9.5 float steps apart): `tie_at_end` in pu.grt_identify_with_reference_log, seen in the
+        # programs' log of that ray, tests/golden/fullsize_grt_sphere_c3_1m_800_hitlog.npz)
         bad = [r_ for r_ in recs if not r_["identified"]]
-        assert len(bad) <= (1 if prim == "sphere" else 0) and all(r_["gpu_vs_reference"] < 5e-2 for r_ in bad), bad
+        assert len(bad) == 0, bad
     ok = ok & ~tied
     # backward: the upstream gradient lives on the sampled rays only
     g_rad, g_dns, g_hit = mg.grt_trace_upstream(sh, sw)
