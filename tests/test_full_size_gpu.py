@@ -307,10 +307,9 @@ def test_grt_frame_equals_the_reference_programs_on_a_ray_sample_at_baseline_siz
             unidentified=int(sum(not r_["identified"] for r_ in recs)),
             max_float_steps_between_reordered_hits=float(max([max(r_.get("float_steps_between_reordered_hits", [0.0])) for r_ in recs if r_["identified"]] + [0.0])),
             max_err_after_reordering=float(max([r_.get("err_after_reordering", 0.0) for r_ in recs if r_["identified"]] + [0.0])), records=recs))
-        # what is NOT identified (round 6: one ray of the custom frame, one of the trisurfel frame - no reordering inside three neighbouring hits
-        # and no single removal reproduces the reference; without the reference programs' own hit log in the golden they cannot be told
-        # apart further) stays under the old fence, and there may be at most one such ray per frame
-        # (last session of round 6: with the programs' hit log the custom and the trisurfel ray are identified - ties at a round's last slot -;
+        # nothing may stay unidentified (the 5e-2 fence of round 5 is gone).  The rays the reordering search leaves open - one of the custom frame,
+        # one of the trisurfel frame, one of the sphere frame - are explained with the reference programs' own hit log: custom / trisurfel are
+        # ties at a round's last slot (the reference never returns one of the two hits);
         # sphere: the ninth ray is a tie of the two LAST neighbours - the reference processes Y and stops on the transmittance threshold with X
         # returned but unprocessed, here X comes first (9.5 float steps apart): `tie_at_end` in pu.grt_identify_with_reference_log, seen in the
         # programs' log of that ray, tests/golden/fullsize_grt_sphere_c3_1m_800_hitlog.npz)
