@@ -64,7 +64,8 @@ def grt_config_from_conf(conf) -> _abi.GrtConfig:
         # which candidate test ordered the log - instances, the closed mesh proxies, trihexa and sphere (round 6: proxy -> particle at the
         # per-hit sites), custom (round 6: with the Slang pipeline's own test, which reports an unsigned distance, gaussianParticles.slang:489-523).
         # The surfel variant blends at the ray's crossing of the surfel's plane: not built)
-        raise NotImplementedError("3dgrut_amd: neural harmonic features are not provided with primitive_type trisurfel (every other proxy is)")
+        raise NotImplementedError("3dgrut_amd: neural harmonic features are not provided with primitive_type trisurfel (every other proxy is): the Slang "
+                                  "surfel mode (scale.z = 1e-6) leaves the feature lookup point's z to the generated code's rounding order - DESIGN.md 7c")
     cfg.primitive_type = _abi.GRT_PRIMITIVES[prim]
     # fp16 feature I/O (setup_3dgrt.py:41-44): run-time switches here, compile-time macros in the reference
     cfg.particle_feature_half = int(bool(_conf_get(render, "particle_feature_half", False)))
