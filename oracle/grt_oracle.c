@@ -468,7 +468,7 @@ void orc_grt_set_candidate_prefilter(const uint32_t* ranges, const uint32_t* ent
  * back faces culled.  The windings make the x = 0 rhombus face +x, the y = 0 rhombus +y, and the two triangles of the z = 0 rhombus face opposite
  * ways (the x >= 0 half +z, the x <= 0 half -z): a ray is offered the particle once per front-facing piece it crosses - up to three times, at
  * three distances - and the any-hit / processHit programs treat every offer as a hit of the particle. */
-static uint32_t trihexa_candidates(const real* inst, v3 o, v3 d, uint32_t id, grt_hit* out) {
+static uint32_t trihexa_candidates_of(const real* inst, v3 o, v3 d, uint32_t id, unsigned planes /* bit k: the rhombus of plane k is offered */, grt_hit* out) {
     const v3 dl = v3_make(o.x - inst[9], o.y - inst[10], o.z - inst[11]);
     const v3 po = v3_make(inst[0] * dl.x + inst[1] * dl.y + inst[2] * dl.z, inst[3] * dl.x + inst[4] * dl.y + inst[5] * dl.z,
                           inst[6] * dl.x + inst[7] * dl.y + inst[8] * dl.z);
@@ -476,15 +476,15 @@ static uint32_t trihexa_candidates(const real* inst, v3 o, v3 d, uint32_t id, gr
                           r_fma(inst[8], d.z, r_fma(inst[7], d.y, inst[6] * d.x)));
     const real D = R_(1.4142135381698608);
     uint32_t n = 0;
-    if (pd.x < 0) {   /* the x = 0 rhombus, seen from +x */
+    if ((planes & 1u) && pd.x < 0) {   /* the x = 0 rhombus, seen from +x */
         const real t = -po.x / pd.x, hy = r_fma(t, pd.y, po.y), hz = r_fma(t, pd.z, po.z);
         if (r_fabs(hy) + r_fabs(hz) <= D) { out[n].t = t; out[n].id = id; out[n].tnear = t; out[n].tfar = R_(3.0e38); n++; }
     }
-    if (pd.y < 0) {   /* the y = 0 rhombus, seen from +y */
+    if ((planes & 2u) && pd.y < 0) {   /* the y = 0 rhombus, seen from +y */
         const real t = -po.y / pd.y, hx = r_fma(t, pd.x, po.x), hz = r_fma(t, pd.z, po.z);
         if (r_fabs(hx) + r_fabs(hz) <= D) { out[n].t = t; out[n].id = id; out[n].tnear = t; out[n].tfar = R_(3.0e38); n++; }
     }
-    if (pd.z != 0) {  /* the z = 0 rhombus: its x >= 0 half seen from +z, its x <= 0 half from -z */
+    if ((planes & 4u) && pd.z != 0) {  /* the z = 0 rhombus: its x >= 0 half seen from +z, its x <= 0 half from -z */
         const real t = -po.z / pd.z, hx = r_fma(t, pd.x, po.x), hy = r_fma(t, pd.y, po.y);
         if (r_fabs(hx) + r_fabs(hy) <= D && ((hx > 0 && pd.z < 0) || (hx < 0 && pd.z > 0))) {
             out[n].t = t; out[n].id = id; out[n].tnear = t; out[n].tfar = R_(3.0e38); n++;
@@ -492,6 +492,7 @@ static uint32_t trihexa_candidates(const real* inst, v3 o, v3 d, uint32_t id, gr
     }
     return n;
 }
+static uint32_t trihexa_candidates(const real* inst, v3 o, v3 d, uint32_t id, grt_hit* out) { return trihexa_candidates_of(inst, o, d, id, 7u, out); }
 /* sphere (optixTracer.cpp:189-190, 765-781, 823-833; checker for GRUT_PRIM_SPHERE): OptiX's built-in sphere intersector offers the any-hit
  * program the ray's ENTRY into the particle's enclosing sphere and, that offer being ignored (__anyhit__ah keeps only the one that fills its
  * payload), its EXIT: two offers per particle, at the two roots of |po + t pd|^2 = 1 in the frame scaled by the radius.  NVIDIA does not
@@ -531,6 +532,18 @@ static uint32_t ray_candidates(uint32_t N, const real* inst12, v3 o, v3 d, grt_h
         return n;
     }
     if (g_prim == 7) {   /* (up to three offers per particle: the callers' buffers hold 3 N + 3 entries) */
+        if (g_pre_ranges && ray != 0xFFFFFFFFu) {   /* the GPU's lists hold PROXIES 3 i + plane, every rhombus binned by its own box: one offer each */
+            const uint32_t p = g_pre_ray_packet[ray];
+            for (uint32_t e = g_pre_ranges[2 * p]; e < g_pre_ranges[2 * p + 1]; ++e) {
+                uint32_t q = g_pre_entries[e];
+                if (q == 0xFFFFFFFFu) continue;
+                q &= 0x7FFFFFFFu;
+                if (q / 3u >= N) continue;
+                n += trihexa_candidates_of(inst12 + 12 * (size_t)(q / 3u), o, d, q / 3u, 1u << (q % 3u), out + n);
+            }
+            qsort(out, n, sizeof(grt_hit), hit_cmp);
+            return n;
+        }
         for (uint32_t i = 0; i < N; ++i) n += trihexa_candidates(inst12 + 12 * (size_t)i, o, d, i, out + n);
         qsort(out, n, sizeof(grt_hit), hit_cmp);
         return n;

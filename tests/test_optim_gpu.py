@@ -163,11 +163,11 @@ train_surrogate = importlib.import_module("workloads.surrogate").train_surrogate
 @pytest.mark.parametrize("method", ["3dgut", "3dgrt"])
 def test_training_at_config1_scale_recovers_the_teacher(method):
     """BASELINE config 1's scale — 100 k Gaussians, 8 views at 400x400, 500 SelectiveAdam steps — against ORACLE-rendered teacher
-    images, certified by the oracle again at the end (3DGUT: every pixel of every view; 3DGRT: every 8th ray of every view, the oracle
+    images, certified by the oracle again at the end (3DGUT: every pixel of every view; 3DGRT: every 16th ray of every view, the oracle
     tests every particle against every ray)."""
     from camera_util import oracle_views
     n, w, h, views = 100_000, 400, 400, 8
-    stride = 1 if method == "3dgut" else 8
+    stride = 1 if method == "3dgut" else 16   # (every 16th ray: 10 k rays per view against all 100 k particles, three times over)
     d12, sph = syn.cloud_trained_like(n, seed=42, median_scale=0.01)
     teacher_sub = oracle_views(method, d12, sph, w, h, views, stride)
     teacher_full = oracle_views(method, d12, sph, w, h, views, 1) if (method == "3dgut") else None

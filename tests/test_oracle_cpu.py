@@ -1156,3 +1156,31 @@ def test_slang_forward_with_sh_radiance_is_the_reference_forward():
         assert np.abs(a[f"s{k}_hit_distance"] - b[f"s{k}_hit_distance"]).max() <= 1e-6
         k += 1
     assert k == 2
+
+
+def test_grt_backward_is_linear_in_the_upstream_gradient_and_separable_by_ray():
+    """What tests/parity_util.py: grt_full_parity (stage G) relies on to price the checker's gradient of a frame with some rays' upstream gradient
+    zeroed: it is the whole frame's gradient minus a backward over THOSE rays alone (their own rows of the forward's outputs)."""
+    scene, T = _grt_scene(n=150, w=12, h=8)
+    cfg = oracle.default_grt_config()
+    H, W = 8, 12
+    rng = np.random.default_rng(5)
+    g_rad, g_dns = rng.normal(size=(H, W, 3)).astype(np.float32), rng.normal(size=(H, W, 1)).astype(np.float32)
+    zero = np.zeros((H, W, 1), np.float32)
+    fwd = oracle.grt_forward(cfg, scene["density12"], scene["sph"], 3, 1e-3, T, *scene["rays"])
+    gd, gs = oracle.grt_backward(cfg, 3, 1e-3, fwd, g_rad, g_dns, zero)
+    idx = np.array([3, 17, 40, 41, 77])
+    mask = np.zeros(H * W, bool)
+    mask[idx] = True
+    g_rad2, g_dns2 = g_rad.copy().reshape(-1, 3), g_dns.copy().reshape(-1, 1)
+    g_rad2[mask] = 0
+    g_dns2[mask] = 0
+    gd2, gs2 = oracle.grt_backward(cfg, 3, 1e-3, fwd, g_rad2.reshape(H, W, 3), g_dns2.reshape(H, W, 1), zero)
+    sub = dict(fwd)
+    sub["rays"] = tuple(np.ascontiguousarray(np.asarray(r_, np.float32).reshape(-1, 3)[idx]).reshape(1, -1, 3) for r_ in fwd["rays"])
+    for key, width in (("features", 3), ("density", 1), ("hit_distance", 2)):
+        sub[key] = np.ascontiguousarray(fwd[key].reshape(-1, width)[idx]).reshape(1, -1, width)
+    gd_s, gs_s = oracle.grt_backward(cfg, 3, 1e-3, sub, g_rad.reshape(-1, 3)[idx].reshape(1, -1, 3), g_dns.reshape(-1, 1)[idx].reshape(1, -1, 1),
+                                     np.zeros((1, idx.size, 1), np.float32))
+    assert np.abs(gd_s).max() > 0
+    assert np.abs((gd - gd_s) - gd2).max() <= 1e-5 * np.abs(gd).max() and np.abs((gs - gs_s) - gs2).max() <= 1e-5 * np.abs(gs).max()
