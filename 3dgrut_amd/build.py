@@ -25,7 +25,13 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-at
 # hit ORDER is reproducible bit for bit by the CPU checker; the pragma is only honoured when the command-line mode is
 # `on` (with `fast` the backend fuses regardless), so that file is built with -ffp-contract=on.
 # gut_poses.hip derives the frame's poses the way the reference's HOST code does (numpy / torch / host C++: nothing contracts there).
-FILE_FLAGS = {"grt_kernels.hip": ["-ffp-contract=on"], "gut_poses.hip": ["-ffp-contract=off"]}
+# gut_render.hip (the compositing sweeps: fp32 VALU issue while their waves run, latency in the launch's ramp-down): the backend's max-ILP
+# scheduling strategy instead of the default occupancy-first one - the kernels' occupancy is pinned by amdgpu_waves_per_eu anyway.  Same
+# instructions in another order: gradient sweep 0.807 -> 0.792 ms, forward 0.449 -> 0.443 ms, step -1.1 % (A/B on one box, interleaved:
+# scripts/ab_sched_variants.sh, profiles/r06_sched_strategy_ab.txt).  Measured and NOT applied: gut_kernels.hip (the gradient gather loses
+# 12 us), grt_kernels.hip (trace forward -0.1 ms, replay backward +0.03: one file), max-memory-clause (slower everywhere).
+FILE_FLAGS = {"grt_kernels.hip": ["-ffp-contract=on"], "gut_poses.hip": ["-ffp-contract=off"],
+              "gut_render.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 
 
 def _hipcc() -> str:
