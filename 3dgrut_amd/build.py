@@ -30,8 +30,13 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-at
 # instructions in another order: gradient sweep 0.807 -> 0.792 ms, forward 0.449 -> 0.443 ms, step -1.1 % (A/B on one box, interleaved:
 # scripts/ab_sched_variants.sh, profiles/r06_sched_strategy_ab.txt).  Measured and NOT applied: gut_kernels.hip (the gradient gather loses
 # 12 us), grt_kernels.hip (trace forward -0.1 ms, replay backward +0.03: one file), max-memory-clause (slower everywhere).
-FILE_FLAGS = {"grt_kernels.hip": ["-ffp-contract=on"], "gut_poses.hip": ["-ffp-contract=off"],
-              "gut_render.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# The sorted hit buffer's kernels (SH radiance) LOSE with it (K = 16 frame 10.87 -> 11.32 ms), so gut_render.hip is compiled twice: part 0
+# (everything else, max-ILP) and part 1 (launch_render_k_fwd / _bwd and the kernels they instantiate, default strategy) - see the file's head.
+FILE_FLAGS = {"grt_kernels.hip": ["-ffp-contract=on"], "gut_poses.hip": ["-ffp-contract=off"]}
+# translation units: (source, object, flags of this unit)
+UNITS = [(s_, s_.replace(".hip", ".o"), []) for s_ in SOURCES if s_ != "gut_render.hip"] + [
+    ("gut_render.hip", "gut_render.o", ["-DGRUT_RENDER_PART=0", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+    ("gut_render.hip", "gut_render_k.o", ["-DGRUT_RENDER_PART=1"])]
 
 
 def _hipcc() -> str:
@@ -57,14 +62,14 @@ def build(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     hipcc = _hipcc()
     deps = _deps()
     objs, jobs = [], []
-    for src in SOURCES:
+    for src, obj, unit_flags in UNITS:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
             continue
-        op = os.path.join(CSRC, src.replace(".hip", ".o"))
+        op = os.path.join(CSRC, obj)
         objs.append(op)
         if force or _stale(op, [sp] + deps):
-            jobs.append([hipcc, "-x", "hip", *FLAGS, *FILE_FLAGS.get(src, []), *extra_flags, "-c", sp, "-o", op])
+            jobs.append([hipcc, "-x", "hip", *FLAGS, *FILE_FLAGS.get(src, []), *unit_flags, *extra_flags, "-c", sp, "-o", op])
 
     def run(cmd):
         if verbose:

@@ -24,6 +24,13 @@
 #include <hip/hip_fp16.h>
 
 #include "gut_internal.hpp"
+// This file is compiled TWICE (3dgrut_amd/build.py): GRUT_RENDER_PART=0 -> gut_render.o, everything except the launchers of the sorted hit
+// buffer with SH radiance, built with the backend's max-ILP scheduling strategy (the unsorted sweeps gain 1-2 %, the feature sweeps 2.5 %);
+// GRUT_RENDER_PART=1 -> gut_render_k.o, launch_render_k_fwd / launch_render_k_bwd and the kernels they instantiate, with the default strategy
+// (max-ILP costs the K = 16 frame 4 %: 10.87 -> 11.32 ms).  Undefined (a plain compile of the file): both parts, as before.
+#ifndef GRUT_RENDER_PART
+#define GRUT_RENDER_PART 2
+#endif
 
 // tuning switches of the gradient sweep (scripts/build_variant.sh -D...)
 #ifndef GRUT_BWD_FULL_REDUCE
@@ -1612,6 +1619,7 @@ static uint32_t segment_grid(const GutParams& P, uint32_t num_boundaries) {
     default: { constexpr int D_ = 2; __VA_ARGS__; } break;     \
     }
 
+#if GRUT_RENDER_PART != 1   // everything but the sorted hit buffer with SH radiance
 void launch_render_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                        const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                        float* out_cnt, const GutCheckpoints& ck, bool write_checkpoints) {
@@ -2527,6 +2535,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FAST ? GRUT_
 
 #include "gut_render_nht.inl"
 
+#endif   // GRUT_RENDER_PART != 1
 static uint32_t strip_grid(const GutParams& P) {
     const uint32_t tiles = (uint32_t)(P.gx * P.gy);
     return ((tiles + 7u) & ~7u) * 4u;
@@ -2537,6 +2546,7 @@ static uint32_t strip_grid(const GutParams& P) {
     case 8: { constexpr int K_ = 8; __VA_ARGS__; } break;      \
     default: { constexpr int K_ = 16; __VA_ARGS__; } break;    \
     }
+#if GRUT_RENDER_PART != 1
 bool nht_fast_path(const GutParams& P) {
     const bool generic = getenv("GRUT_NHT_GENERIC") != nullptr;   // (development / test switch, read per call: the strip kernels for every shape)
     return P.nht && !generic && P.nht_k == kNhtK && P.nht_ipd == kNhtIpd && P.nht_support == 1 && P.nht_act == 2 && P.nht_nf == 1 && P.k_buffer == 0;
@@ -2619,6 +2629,8 @@ void launch_render_nht_bwd(hipStream_t s, const GutParams& P, const uint32_t* ra
     hipLaunchKernelGGL(gut_render_nht_bwd_kernel, dim3(strip_grid(P)), dim3(64), 0, s, P, reinterpret_cast<const uint2*>(ranges), lists,
                        reinterpret_cast<const float4*>(density12), features, ray_o, ray_d, fd, g_fd, dist, g_dist, g_density12, g_features);
 }
+#endif   // GRUT_RENDER_PART != 1
+#if GRUT_RENDER_PART != 0   // the sorted hit buffer's launchers (and, through them, its kernels' instantiations): see the note at the top
 void launch_render_k_fwd(hipStream_t s, const GutParams& P, const uint32_t* ranges, const uint32_t* sorted_pos, const uint32_t* pos_particle,
                          const float* density12, const float* rgb, const float* ray_o, const float* ray_d, float* out_fd, float* out_dist,
                          float* out_cnt) {
@@ -2637,4 +2649,5 @@ void launch_render_k_bwd(hipStream_t s, const GutParams& P, const uint32_t* rang
                                                    reinterpret_cast<const float4*>(g_fd), g_dist, g_density12, g_rgb));
 }
 
+#endif   // GRUT_RENDER_PART != 0
 }  // namespace grut
