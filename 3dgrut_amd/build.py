@@ -39,6 +39,11 @@ UNITS = [(s_, s_.replace(".hip", ".o"), []) for s_ in SOURCES if s_ != "gut_rend
     ("gut_render.hip", "gut_render_k.o", ["-DGRUT_RENDER_PART=1"])]
 
 
+def unit_flags(src: str):
+    """Per-file + per-unit flags of `src`'s FIRST translation unit (what scripts/kernel_resources.py and valu_model.py compile with)."""
+    return [*FILE_FLAGS.get(src, []), *next((f for s_, _, f in UNITS if s_ == src), [])]
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.sep not in c or os.path.exists(c)):

@@ -22,7 +22,7 @@ def main():
     src = sys.argv[1]
     flt = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("-") else ""
     extra = [a for a in sys.argv[2:] if a.startswith("-")]
-    cmd = [b._hipcc(), "-x", "hip", *b.FLAGS, *b.FILE_FLAGS.get(src, []), *extra, "-Rpass-analysis=kernel-resource-usage", "-c",
+    cmd = [b._hipcc(), "-x", "hip", *b.FLAGS, *b.unit_flags(src), *extra, "-Rpass-analysis=kernel-resource-usage", "-c",
            os.path.join(b.CSRC, src), "-o", "/dev/null"]
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None

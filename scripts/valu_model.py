@@ -61,7 +61,7 @@ def main():
     asm = {}
     for stage, (src, pat) in KERNELS.items():
         if src not in asm:
-            cmd = [b._hipcc(), "-x", "hip", *b.FLAGS, *b.FILE_FLAGS.get(src, []), "--cuda-device-only", "-S", os.path.join(b.CSRC, src), "-o", "-"]
+            cmd = [b._hipcc(), "-x", "hip", *b.FLAGS, *b.unit_flags(src), "--cuda-device-only", "-S", os.path.join(b.CSRC, src), "-o", "-"]
             asm[src] = subprocess.run(cmd, capture_output=True, text=True).stdout
         s = asm[src]
         names = [n for n in re.findall(r"^(_Z\w+):", s, re.M) if re.search(pat, n)]
